@@ -1,0 +1,89 @@
+"""Container-only harness: import the read-only reference at /root/reference as a parity oracle.
+
+TEST INFRASTRUCTURE -- never imported by the product package (dahitra_amd/).  It is used only by
+oracle/make_golden.py (to generate tests/golden/*.npz) and by the `-m "not gpu"` tests that pin
+oracle/cdnet_ref.py against the reference itself.  /root/reference does not exist on the GPU box;
+everything here is skipped there.
+
+Stubs: torchvision / timm / segmentation_models_pytorch are imported by
+the reference (models/networks.py:6-7,17; models/losses.py:3) but are not needed by the hot path.
+The ImageNet download in models/resnet.py:228-234 is replaced by a no-op (init_weights overwrites
+every conv/linear weight anyway, models/networks.py:88-105).
+"""
+import os
+import sys
+import types
+import contextlib
+import io
+
+REF_ROOT = os.environ.get("DAHITRA_REFERENCE", "/root/reference")
+
+
+def available():
+    return os.path.isdir(os.path.join(REF_ROOT, "models"))
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+_loaded = {}
+
+
+def load():
+    """Returns (networks_module, losses_module) of the reference."""
+    if _loaded:
+        return _loaded["networks"], _loaded["losses"]
+    if not available():
+        raise RuntimeError("reference not present at %s" % REF_ROOT)
+    import torch
+
+    def _na(*a, **k):
+        raise RuntimeError("stubbed third-party symbol called on the hot path")
+
+    tv = _stub("torchvision")
+    tvm = _stub("torchvision.models", resnet34=_na)
+    tv.models = tvm
+    _stub("timm")
+    _stub("timm.models")
+    _stub("timm.models.layers", DropPath=torch.nn.Identity, to_2tuple=lambda x: (x, x),
+          trunc_normal_=lambda t, std=0.02: t)
+    smp = _stub("segmentation_models_pytorch")
+    smp.losses = _stub("segmentation_models_pytorch.losses", DiceLoss=_na)
+    # the reference package is called `models`; make sure ours never shadows it
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[k]
+    sys.path.insert(0, REF_ROOT)
+    try:
+        import models.resnet as ref_resnet
+        ref_resnet.load_state_dict_from_url = lambda *a, **k: None
+        _orig = ref_resnet.ResNet.load_state_dict
+        ref_resnet.ResNet.load_state_dict = (
+            lambda self, sd, *a, **k: None if sd is None else _orig(self, sd, *a, **k))
+        import models.networks as ref_networks
+        import models.losses as ref_losses
+    finally:
+        sys.path.remove(REF_ROOT)
+    _loaded["networks"] = ref_networks
+    _loaded["losses"] = ref_losses
+    return ref_networks, ref_losses
+
+
+def define_G(net_G):
+    """Reference define_G (models/networks.py:130-168) on CPU; chatter silenced."""
+    nets, _ = load()
+    args = types.SimpleNamespace(net_G=net_G)
+    with contextlib.redirect_stdout(io.StringIO()):
+        return nets.define_G(args=args, gpu_ids=[])
+
+
+def build_resnet50_variant(output_nc=2):
+    """C5 model: BASE_Transformer(backbone='resnet50') (models/networks.py:186-197)."""
+    nets, _ = load()
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = nets.BASE_Transformer(input_nc=3, output_nc=output_nc, token_len=4,
+                                    resnet_stages_num=4, with_pos='learned', backbone='resnet50')
+        return nets.init_net(net, 'normal', 0.02, [])

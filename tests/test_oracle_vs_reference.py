@@ -1,0 +1,52 @@
+"""Oracle pinned against the imported reference (build container only; skipped elsewhere)."""
+import pytest
+import torch
+
+import cdnet_ref as O
+import ref_import
+
+pytestmark = pytest.mark.skipif(not ref_import.available(), reason="/root/reference not present")
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_t8_e2d4"])
+def test_train_step_equals_reference(name):
+    """logits, focal loss, every gradient and two AdamW updates vs models/networks.py +
+    models/losses.py + torch.optim.AdamW (models/trainer.py:39-40,302-308)."""
+    _, ref_losses = ref_import.load()
+    cfg = O.get_config(name)
+    net = ref_import.define_G(name)
+    net.load_state_dict(O.deterministic_state(name))
+    net.train()
+    opt = torch.optim.AdamW(net.parameters(), lr=0.01, betas=(0.9, 0.999), weight_decay=0.01)
+    st = O.TrainState(name, O.deterministic_state(name), lr=0.01)
+    a, b, lab = O.synthetic_batch(3, 64, seed=7, n_class=cfg["n_class"])
+    for it in range(2):
+        y = net(a, b)
+        opt.zero_grad()
+        loss = ref_losses.focal_loss(y, lab)
+        loss.backward()
+        opt.step()
+        yo, lo = st.step(a, b, lab)
+        assert float((y.detach() - yo).abs().max()) <= 1e-5 * float(y.abs().max())
+        assert abs(float(loss.detach()) - lo) < 1e-6
+        for k, p in net.named_parameters():
+            q = st.sd[k]
+            assert (p.grad is None) == (q.grad is None), k
+            if p.grad is not None:
+                assert float((p.grad - q.grad).abs().max()) <= 1e-5 * float(p.grad.abs().max()) + 1e-9, k
+            assert float((p.detach() - q.detach()).abs().max()) <= 1e-5, k
+
+
+def test_reference_anchor_from_survey():
+    """SURVEY.md section 8c anchor: define_G under torch.manual_seed(0), s4 eval."""
+    torch.manual_seed(0)
+    net = ref_import.define_G("base_transformer_pos_s4").eval()
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(2, 3, 256, 256, generator=g)
+    b = torch.randn(2, 3, 256, 256, generator=g)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        y = net(a, b)
+        yo = O.forward(sd, "base_transformer_pos_s4", a, b, training=False)
+    assert abs(float(y.sum()) - (-415.798811)) < 1e-2
+    assert float((y - yo).abs().max()) <= 1e-6
