@@ -1,0 +1,24 @@
+# Builds the gfx950 kernel library (product) and nothing else.  hipcc cross-compiles without a GPU.
+HIPCC ?= hipcc
+ARCH  ?= gfx950
+CSRC  := dahitra_amd/csrc
+OBJ   := build/obj
+LIB   := dahitra_amd/lib/libdahitra_hip.so
+SRCS  := $(wildcard $(CSRC)/*.hip)
+OBJS  := $(patsubst $(CSRC)/%.hip,$(OBJ)/%.o,$(SRCS))
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result
+
+all: $(LIB)
+
+$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/common.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(FLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p $(dir $(LIB))
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -rf build $(LIB)
+
+.PHONY: all clean

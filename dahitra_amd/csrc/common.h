@@ -1,0 +1,95 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of dahitra_amd.
+// Activations are NHWC ("pixels x channels", channels contiguous) in T = float (parity mode)
+// or bf16 (throughput mode); accumulation, statistics, master weights and weight gradients
+// are always fp32.  Wavefront = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct bf16 { unsigned short x; };
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define DH_DTYPE_F32 0
+#define DH_DTYPE_BF16 1
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                    // RNE
+    return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16* p) { return bf2f(p->x); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16* p, float v) { p->x = f2bf(v); }
+
+// 4 consecutive elements (16 B fp32 / 8 B bf16); address must be aligned to that size.
+__device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void ld4(const bf16* p, float (&o)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void st4(bf16* p, const float (&o)[4]) {
+    uint2 v;
+    v.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+    v.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+}
+// 8 consecutive elements for bf16 (16 B), 4 for fp32 (16 B): the 16-byte vector unit "V16".
+template <typename T> struct V16 { static constexpr int N = 16 / sizeof(T); };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+#define DH_ACT_NONE 0
+#define DH_ACT_RELU 1
+#define DH_ACT_GELU 2
+
+// ---- host side -------------------------------------------------------------------------------
+#include <stdio.h>
+#include <string.h>
+extern "C" void dh_set_error(const char* msg);
+#define DH_FAIL(...)                                                     \
+    do {                                                                 \
+        char _b[512];                                                    \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                           \
+        dh_set_error(_b);                                                \
+        return 1;                                                        \
+    } while (0)
+#define DH_REQUIRE(cond, ...)           \
+    do {                                \
+        if (!(cond)) DH_FAIL(__VA_ARGS__); \
+    } while (0)
+#define DH_CHECK_LAUNCH(name)                                                      \
+    do {                                                                           \
+        hipError_t _e = hipGetLastError();                                         \
+        if (_e != hipSuccess) DH_FAIL("%s launch: %s", name, hipGetErrorString(_e)); \
+    } while (0)
+static inline int dh_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

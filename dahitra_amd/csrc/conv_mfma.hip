@@ -1,0 +1,284 @@
+// NHWC direct convolution on the CDNA4 matrix cores (gfx950), im2col-free.
+//
+// One 256-thread workgroup (4 wavefronts of 64) produces an 8x16-pixel output tile of one image
+// for NT output channels.  Per 64-byte input-channel chunk (32 bf16 / 16 fp32 channels) the
+// haloed input tile and the weights of all KSxKS taps are staged once in LDS; every tap is then a
+// shifted 1x1 product D[cout][pixel] += W[cout][k] * X[pixel][k] issued as MFMA
+//   bf16: v_mfma_f32_16x16x32_bf16   (one per 32 channels)
+//   fp32: v_mfma_f32_16x16x4_f32 x4  (exact fp32, parity mode)
+// with fp32 accumulation.  Weights are the A operand so that a lane ends up with 4 consecutive
+// output channels of one pixel (8/16-byte stores).  Epilogue: +bias, +residual, ReLU/GELU, and
+// optional per-workgroup partial sums (sum, sum of squares) per channel for train-mode BatchNorm.
+//
+// The same kernel serves: every 3x3 / 1x1 convolution of the trunk and head (reference
+// models/resnet.py:24-32, models/help_funcs.py:7-15, models/networks.py:215), their data
+// gradients (transposed, flipped weights), every nn.Linear of the token / pixel transformers
+// (models/help_funcs.py:52-63,86-88,111), and the per-image attention products QK^T / PV in their
+// re-associated 32x32 form (per-image weights via w_nstride).
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;          // output tile (pixels)
+constexpr int PITCH = 80;               // LDS bytes per row: 64 B of channels + 16 B pad
+
+struct ConvArgs {
+    const void* x;
+    const void* w;
+    void* y;
+    const float* bias;
+    const void* res;
+    float* stats;      // [gridDim.x][2][CoutPad] partial (sum, sumsq) or null
+    void* y2;          // optional: value before the activation (needed by the GELU derivative)
+    int N, H, W, Cin, OH, OW, Cout, CoutPad, pad, act;
+    int npix;          // valid output pixels per image in linear order (OH*OW unless a row view)
+    int in_npix;       // valid input pixels per image in linear order (H*W unless a row view)
+    long w_nstride;    // elements between per-image weight sets (0: shared)
+    int tilesX, tilesY;
+};
+
+union V16u {
+    uint4 u;
+    float f[4];
+    s16x8 h;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(const V16u& a, const V16u& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[0], b.f[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[1], b.f[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[2], b.f[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[3], b.f[3], c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ void run(const V16u& a, const V16u& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+    }
+};
+
+template <typename T, int KS, int STRIDE, int NT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
+    constexpr int HH = (TH - 1) * STRIDE + KS;
+    constexpr int HWD = (TW - 1) * STRIDE + KS;
+    constexpr int TAPS = KS * KS;
+    constexpr int CK = 64 / (int)sizeof(T);     // channels per 64-byte chunk
+    constexpr int NS = NT / 16;                 // 16-channel output sub-tiles
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* halo = smem;                                  // [HH*HWD][PITCH]
+    unsigned char* wts = smem + HH * HWD * PITCH;                // [TAPS*NT][PITCH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    int bt = blockIdx.x;
+    const int tx = bt % p.tilesX; bt /= p.tilesX;
+    const int ty = bt % p.tilesY;
+    const int n = bt / p.tilesY;
+    const int co0 = blockIdx.y * NT;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
+
+    const unsigned char* xin = reinterpret_cast<const unsigned char*>(p.x) +
+                               (size_t)n * p.H * p.W * p.Cin * sizeof(T);
+    const unsigned char* wgt = reinterpret_cast<const unsigned char*>(p.w) +
+                               (size_t)n * p.w_nstride * sizeof(T);
+
+    f32x4 acc[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        acc[s][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[s][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int c0 = 0; c0 < p.Cin; c0 += CK) {
+        // ---- stage the haloed input tile: HH*HWD pixels x 64 B ----
+        for (int idx = tid; idx < HH * HWD * 4; idx += 256) {
+            const int px = idx >> 2, q = idx & 3;
+            const int hy = px / HWD, hx = px - hy * HWD;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && iy * p.W + ix < p.in_npix)
+                v = *reinterpret_cast<const uint4*>(
+                    xin + ((size_t)(iy * p.W + ix) * p.Cin + c0) * sizeof(T) + q * 16);
+            *reinterpret_cast<uint4*>(halo + px * PITCH + q * 16) = v;
+        }
+        // ---- stage the weights of every tap for this chunk: TAPS*NT rows x 64 B ----
+        for (int idx = tid; idx < TAPS * NT * 4; idx += 256) {
+            const int row = idx >> 2, q = idx & 3;
+            const int tap = row / NT, co = row - tap * NT;
+            const uint4 v = *reinterpret_cast<const uint4*>(
+                wgt + ((size_t)(tap * p.CoutPad + co0 + co) * p.Cin + c0) * sizeof(T) + q * 16);
+            *reinterpret_cast<uint4*>(wts + row * PITCH + q * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const int tap = kh * KS + kw;
+                V16u b0, b1;
+                b0.u = *reinterpret_cast<const uint4*>(
+                    halo + (((2 * wv) * STRIDE + kh) * HWD + pl * STRIDE + kw) * PITCH + g * 16);
+                b1.u = *reinterpret_cast<const uint4*>(
+                    halo + (((2 * wv + 1) * STRIDE + kh) * HWD + pl * STRIDE + kw) * PITCH + g * 16);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    V16u a;
+                    a.u = *reinterpret_cast<const uint4*>(wts + (tap * NT + s * 16 + pl) * PITCH + g * 16);
+                    Mma<T>::run(a, b0, acc[s][0]);
+                    Mma<T>::run(a, b1, acc[s][1]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    T* yout = reinterpret_cast<T*>(p.y) + (size_t)n * p.OH * p.OW * p.Cout;
+    const T* rin = p.res ? reinterpret_cast<const T*>(p.res) + (size_t)n * p.OH * p.OW * p.Cout : nullptr;
+    const bool vec_ok = (p.Cout & 3) == 0;
+    float ssum[NS][4], ssq[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ssum[s][j] = 0.f; ssq[s][j] = 0.f; }
+
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + 2 * wv + r, ox = ox0 + pl;
+        const bool pvalid = (oy < p.OH) && (ox < p.OW) && (oy * p.OW + ox < p.npix);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = co0 + s * 16 + g * 4;
+            if (!pvalid || c >= p.Cout) continue;
+            float v[4] = {acc[s][r][0], acc[s][r][1], acc[s][r][2], acc[s][r][3]};
+            const size_t off = (size_t)(oy * p.OW + ox) * p.Cout + c;
+            if (vec_ok) {
+                if (p.bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += p.bias[c + j];
+                }
+                if (rin) {
+                    float rr[4];
+                    ld4(rin + off, rr);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += rr[j];
+                }
+                if (p.y2) st4(reinterpret_cast<T*>(p.y2) + (size_t)n * p.OH * p.OW * p.Cout + off, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (p.act == DH_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+                    else if (p.act == DH_ACT_GELU) v[j] = gelu_erf(v[j]);
+                    ssum[s][j] += v[j];
+                    ssq[s][j] += v[j] * v[j];
+                }
+                st4(yout + off, v);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (c + j >= p.Cout) continue;
+                    float t = v[j];
+                    if (p.bias) t += p.bias[c + j];
+                    if (rin) t += ldf(rin + off + j);
+                    if (p.y2) stf(reinterpret_cast<T*>(p.y2) + (size_t)n * p.OH * p.OW * p.Cout + off + j, t);
+                    if (p.act == DH_ACT_RELU) t = fmaxf(t, 0.f);
+                    else if (p.act == DH_ACT_GELU) t = gelu_erf(t);
+                    ssum[s][j] += t;
+                    ssq[s][j] += t * t;
+                    stf(yout + off + j, t);
+                }
+            }
+        }
+    }
+
+    if (p.stats) {
+        // reduce over the 16 pixel lanes of each lane group, then over the 4 waves through LDS
+        float* red = reinterpret_cast<float*>(smem);   // [4 waves][2][NT]; staging LDS is free now
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = ssum[s][j], b = ssq[s][j];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    b += __shfl_xor(b, o, 64);
+                }
+                if (pl == 0) {
+                    red[(wv * 2 + 0) * NT + s * 16 + g * 4 + j] = a;
+                    red[(wv * 2 + 1) * NT + s * 16 + g * 4 + j] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < 2 * NT) {
+            const int which = tid / NT, c = tid - which * NT;
+            const float t = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] +
+                            red[(2 * 2 + which) * NT + c] + red[(3 * 2 + which) * NT + c];
+            if (co0 + c < p.CoutPad)
+                p.stats[((size_t)blockIdx.x * 2 + which) * p.CoutPad + co0 + c] = t;
+        }
+    }
+}
+
+template <typename T, int KS, int STRIDE, int NT>
+int launch(const ConvArgs& a, hipStream_t st) {
+    constexpr int HH = (TH - 1) * STRIDE + KS, HWD = (TW - 1) * STRIDE + KS;
+    const size_t lds = (size_t)(HH * HWD + KS * KS * NT) * PITCH;
+    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) DH_FAIL("conv_mfma: cannot raise dynamic LDS to %zu", lds);
+    }
+    dim3 grid(a.N * a.tilesX * a.tilesY, a.CoutPad / NT);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    DH_CHECK_LAUNCH("conv_mfma");
+    return 0;
+}
+
+template <typename T, int KS, int STRIDE>
+int launch_nt(const ConvArgs& a, hipStream_t st) {
+    if (a.CoutPad % 64 == 0) return launch<T, KS, STRIDE, 64>(a, st);
+    if (a.CoutPad % 32 == 0) return launch<T, KS, STRIDE, 32>(a, st);
+    return launch<T, KS, STRIDE, 16>(a, st);
+}
+
+template <typename T>
+int launch_ks(const ConvArgs& a, int ks, int stride, hipStream_t st) {
+    if (ks == 3 && stride == 1) return launch_nt<T, 3, 1>(a, st);
+    if (ks == 3 && stride == 2) return launch_nt<T, 3, 2>(a, st);
+    if (ks == 1 && stride == 1) return launch_nt<T, 1, 1>(a, st);
+    if (ks == 1 && stride == 2) return launch_nt<T, 1, 2>(a, st);
+    if (ks == 4 && stride == 1) return launch_nt<T, 4, 1>(a, st);     // space-to-depth stem
+    DH_FAIL("conv_mfma: unsupported kernel %dx%d stride %d", ks, ks, stride);
+}
+
+}  // namespace
+
+// C ABI: see include/dahitra_hip.h
+extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const float* bias,
+                             const void* residual, float* stats_partial, int N, int H, int W, int Cin,
+                             int OH, int OW, int Cout, int CoutPad, int ks, int stride, int pad, int act,
+                             int npix_valid, long w_image_stride, void* y_preact, void* stream) {
+    const int esz = dtype == DH_DTYPE_BF16 ? 2 : 4;
+    DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "conv2d_fwd: bad dtype %d", dtype);
+    DH_REQUIRE((Cin * esz) % 64 == 0, "conv2d_fwd: Cin=%d must be a multiple of %d", Cin, 64 / esz);
+    DH_REQUIRE(CoutPad % 16 == 0 && CoutPad >= Cout, "conv2d_fwd: CoutPad=%d invalid for Cout=%d", CoutPad, Cout);
+    DH_REQUIRE(N > 0 && OH > 0 && OW > 0, "conv2d_fwd: empty output");
+    ConvArgs a;
+    a.x = x; a.w = w_packed; a.y = y; a.bias = bias; a.res = residual; a.stats = stats_partial; a.y2 = y_preact;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.CoutPad = CoutPad;
+    a.pad = pad; a.act = act; a.npix = npix_valid > 0 ? npix_valid : OH * OW;
+    a.in_npix = npix_valid > 0 ? npix_valid : H * W; a.w_nstride = w_image_stride;
+    a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, TH);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == DH_DTYPE_BF16) return launch_ks<bf16>(a, ks, stride, st);
+    return launch_ks<float>(a, ks, stride, st);
+}
+
+// number of workgroup tiles along the pixel dimension (= rows of the stats_partial buffer)
+extern "C" int dh_conv2d_fwd_num_tiles(int N, int OH, int OW) {
+    return N * dh_cdiv(OW, TW) * dh_cdiv(OH, TH);
+}

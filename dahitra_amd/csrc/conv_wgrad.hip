@@ -1,0 +1,278 @@
+// Weight gradient of an NHWC convolution / linear layer on the CDNA4 matrix cores.
+//
+//   dW[tap][co][ci] = sum over (n, oy, ox) of dY[n,oy,ox,co] * X[n, oy*s - pad + kh, ox*s - pad + kw, ci]
+//
+// is a GEMM whose reduction dimension is the PIXEL index, so both MFMA operands need k (= pixel)
+// contiguous per lane while memory is channel-contiguous.  The 8x16-pixel dY tile and the haloed
+// X tile are staged in LDS as [pixel][channel]; fragments are then gathered
+//   fp32: one ds_read_b32 per operand and v_mfma_f32_16x16x4_f32 (4 pixels per MFMA);
+//   bf16: two ds_read_b64_tr_b16 (the gfx950 LDS transpose read) per operand, or 8 ds_read_u16
+//         when TR = false, feeding v_mfma_f32_16x16x32_bf16 (32 pixels per MFMA).
+// A workgroup owns a 64(co) x IT(ci) x all-taps slab of dW (wave w = co sub-tile w), walks a
+// strided subset of the pixel tiles (split-K) and writes an fp32 partial slab; dh_wgrad_reduce
+// sums the partials deterministically straight into the OIHW master-gradient layout.
+// groups == N gives one dW per image (per-image attention products, see tokens.hip).
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;
+constexpr int CT = 64;
+
+struct WgArgs {
+    const void* x;
+    const void* dy;
+    float* part;       // [groups][splitk][taps][Cout][Cin]
+    int N, H, W, Cin, OH, OW, Cout, pad;
+    int tilesX, tilesY, splitk, groups, npix, in_npix;
+    int ci_tiles;
+};
+
+template <typename T>
+__device__ __forceinline__ void stage_rows(unsigned char* lds, int pitch, int row, int cbytes_tile,
+                                           const T* src_row /*null => zeros*/, int c0, int Ctot, int q) {
+    // copies the 16-byte piece q of channels [c0, c0 + cbytes_tile/sizeof(T)) of one pixel row
+    constexpr int EPV = 16 / (int)sizeof(T);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    const int c = c0 + q * EPV;
+    if (src_row) {
+        if (((Ctot * (int)sizeof(T)) & 15) == 0 && c + EPV <= Ctot) {
+            v = *reinterpret_cast<const uint4*>(src_row + c);
+        } else {
+            __attribute__((aligned(16))) T tmp[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                if (c + e < Ctot) tmp[e] = src_row[c + e];
+                else stf(&tmp[e], 0.f);
+            }
+            v = *reinterpret_cast<uint4*>(tmp);
+        }
+    }
+    *reinterpret_cast<uint4*>(lds + row * pitch + q * 16) = v;
+}
+
+union F8 {
+    s16x8 v;
+    s16x4 h[2];
+    unsigned short s[8];
+};
+
+template <typename T, int KS, int STRIDE, int IT, bool TR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
+    constexpr int HH = (TH - 1) * STRIDE + KS;
+    constexpr int HWD = (TW - 1) * STRIDE + KS;
+    constexpr int TAPS = KS * KS;
+    constexpr int NI = IT / 16;
+    constexpr int XP = IT * (int)sizeof(T) + 16;     // halo pitch (bytes)
+    constexpr int DP = CT * (int)sizeof(T) + 16;     // dY tile pitch (bytes)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* halo = smem;                      // [HH*HWD][XP]
+    unsigned char* dyt = smem + HH * HWD * XP;       // [128][DP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    const int cot = blockIdx.x / p.ci_tiles, cit = blockIdx.x % p.ci_tiles;
+    const int co0 = cot * CT, ci0 = cit * IT;
+    const int kz = blockIdx.y, grp = blockIdx.z;
+    const int imgs_per_group = p.N / p.groups;
+    const int tiles_per_img = p.tilesX * p.tilesY;
+    const int ntiles = imgs_per_group * tiles_per_img;
+
+    f32x4 acc[TAPS][NI];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = kz; tile < ntiles; tile += p.splitk) {
+        const int n = grp * imgs_per_group + tile / tiles_per_img;
+        const int tt = tile % tiles_per_img;
+        const int ty = tt / p.tilesX, tx = tt % p.tilesX;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
+        const T* xin = reinterpret_cast<const T*>(p.x) + (size_t)n * p.H * p.W * p.Cin;
+        const T* dyin = reinterpret_cast<const T*>(p.dy) + (size_t)n * p.OH * p.OW * p.Cout;
+        constexpr int XQ = IT * (int)sizeof(T) / 16, DQ = CT * (int)sizeof(T) / 16;
+        for (int idx = tid; idx < HH * HWD * XQ; idx += 256) {
+            const int px = idx / XQ, q = idx % XQ;
+            const int hy = px / HWD, hx = px % HWD;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && iy * p.W + ix < p.in_npix;
+            stage_rows<T>(halo, XP, px, IT * (int)sizeof(T), ok ? xin + (size_t)(iy * p.W + ix) * p.Cin : nullptr,
+                          ci0, p.Cin, q);
+        }
+        for (int idx = tid; idx < TH * TW * DQ; idx += 256) {
+            const int px = idx / DQ, q = idx % DQ;
+            const int oy = oy0 + px / TW, ox = ox0 + px % TW;
+            const bool ok = oy < p.OH && ox < p.OW && oy * p.OW + ox < p.npix;
+            stage_rows<T>(dyt, DP, px, CT * (int)sizeof(T), ok ? dyin + (size_t)(oy * p.OW + ox) * p.Cout : nullptr,
+                          co0, p.Cout, q);
+        }
+        __syncthreads();
+
+        if constexpr (sizeof(T) == 4) {
+            // 4 pixels per MFMA: lane (pl, g) supplies pixel k0+g, channel pl
+            for (int k0 = 0; k0 < TH * TW; k0 += 4) {
+                const int k = k0 + g, row = k / TW, col = k % TW;
+                const float a = *reinterpret_cast<const float*>(dyt + k * DP + (wv * 16 + pl) * 4);
+#pragma unroll
+                for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < KS; ++kw) {
+                        const int hp = (row * STRIDE + kh) * HWD + col * STRIDE + kw;
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            const float b = *reinterpret_cast<const float*>(halo + hp * XP + (i * 16 + pl) * 4);
+                            acc[kh * KS + kw][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[kh * KS + kw][i], 0, 0, 0);
+                        }
+                    }
+            }
+        } else {
+            // 32 pixels per MFMA: lane group g supplies pixels k0 + g*8 .. +7 of one tile row
+            for (int k0 = 0; k0 < TH * TW; k0 += 32) {
+                const int kb = k0 + g * 8, row = kb / TW, col = kb % TW;
+                F8 a;
+                if constexpr (TR) {
+                    // lane p of each 16-lane group points at the 8-byte piece (pixel p/4, channels 4*(p%4)..+3)
+                    const unsigned char* base = dyt + (kb + (pl >> 2)) * DP + (wv * 16 + (pl & 3) * 4) * 2;
+                    a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(base));
+                    a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(base + 4 * DP));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        a.s[j] = *reinterpret_cast<const unsigned short*>(dyt + (kb + j) * DP + (wv * 16 + pl) * 2);
+                }
+#pragma unroll
+                for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < KS; ++kw) {
+                        const int hp = (row * STRIDE + kh) * HWD + col * STRIDE + kw;
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            F8 b;
+                            if constexpr (TR && STRIDE == 1) {
+                                const unsigned char* base = halo + (hp + (pl >> 2)) * XP + (i * 16 + (pl & 3) * 4) * 2;
+                                b.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                    (__attribute__((address_space(3))) s16x4*)(base));
+                                b.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                    (__attribute__((address_space(3))) s16x4*)(base + 4 * XP));
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j)
+                                    b.s[j] = *reinterpret_cast<const unsigned short*>(
+                                        halo + (hp + j * STRIDE) * XP + (i * 16 + pl) * 2);
+                            }
+                            acc[kh * KS + kw][i] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc[kh * KS + kw][i], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // partial slab: [grp][kz][tap][Cout][Cin]
+    float* out = p.part + ((size_t)grp * p.splitk + kz) * TAPS * p.Cout * p.Cin;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + wv * 16 + g * 4 + j, ci = ci0 + i * 16 + pl;
+                if (co < p.Cout && ci < p.Cin) out[((size_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][j];
+            }
+}
+
+// dw_oihw[g][o][i][tap] (+)= sum_kz part[g][kz][tap][o][i]      (blockIdx.y = group)
+__global__ void wgrad_reduce_oihw_kernel(const float* __restrict__ part, int splitk, int taps, int Oslab, int O, int I,
+                                         float* __restrict__ dw, int accumulate) {
+    const long n = (long)O * I * taps;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    part += (size_t)blockIdx.y * splitk * taps * Oslab * I;
+    dw += (size_t)blockIdx.y * n;
+    const int tap = (int)(i % taps);
+    const int ci = (int)((i / taps) % I);
+    const int o = (int)(i / ((long)taps * I));
+    float s = 0.f;
+    for (int k = 0; k < splitk; ++k) s += part[(((size_t)k * taps + tap) * Oslab + o) * I + ci];
+    if (accumulate) dw[i] += s; else dw[i] = s;
+}
+
+template <typename T, int KS, int STRIDE, int IT>
+int launch(const WgArgs& a, bool tr, hipStream_t st) {
+    constexpr int HH = (TH - 1) * STRIDE + KS, HWD = (TW - 1) * STRIDE + KS;
+    const size_t lds = (size_t)HH * HWD * (IT * sizeof(T) + 16) + (size_t)TH * TW * (CT * sizeof(T) + 16);
+    dim3 grid(dh_cdiv(a.Cout, CT) * a.ci_tiles, a.splitk, a.groups);
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) DH_FAIL("conv_wgrad: cannot raise dynamic LDS to %zu", lds);
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+        DH_CHECK_LAUNCH("conv_wgrad");
+        return 0;
+    };
+    if (tr) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true>);
+    return go(conv_wgrad_kernel<T, KS, STRIDE, IT, false>);
+}
+
+template <typename T>
+int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
+    const bool wide = a.Cin > 32 && ks == 1;     // 64-wide ci tiles only where the accumulators fit
+    const int it = wide ? 64 : 32;
+    a.ci_tiles = dh_cdiv(a.Cin, it);
+    if (ks == 3 && stride == 1) return launch<T, 3, 1, 32>(a, tr, st);
+    if (ks == 3 && stride == 2) return launch<T, 3, 2, 32>(a, tr, st);
+    if (ks == 1 && stride == 1) return wide ? launch<T, 1, 1, 64>(a, tr, st) : launch<T, 1, 1, 32>(a, tr, st);
+    if (ks == 1 && stride == 2) return wide ? launch<T, 1, 2, 64>(a, tr, st) : launch<T, 1, 2, 32>(a, tr, st);
+    if (ks == 4 && stride == 1) return launch<T, 4, 1, 32>(a, tr, st);     // space-to-depth stem
+    DH_FAIL("conv_wgrad: unsupported kernel %d stride %d", ks, stride);
+}
+
+}  // namespace
+
+// split-K factor: aim at ~1024 workgroups, never more slabs than pixel tiles
+extern "C" int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, int ks, int groups) {
+    const long tiles = (long)(N / (groups > 0 ? groups : 1)) * dh_cdiv(OW, TW) * dh_cdiv(OH, TH);
+    const int it = (Cin > 32 && ks == 1) ? 64 : 32;
+    const long slabs = (long)dh_cdiv(Cout, CT) * dh_cdiv(Cin, it) * (groups > 0 ? groups : 1);
+    long sk = (1024 + slabs - 1) / slabs;
+    if (sk > 64) sk = 64;
+    if (sk > tiles) sk = tiles;
+    return (int)(sk < 1 ? 1 : sk);
+}
+
+extern "C" long dh_conv2d_wgrad_workspace_size(int N, int OH, int OW, int Cin, int Cout, int ks, int groups) {
+    return (long)groups * dh_conv2d_wgrad_splitk(N, OH, OW, Cin, Cout, ks, groups) * ks * ks * Cout * Cin * 4;
+}
+
+// x: [N,H,W,Cin], dy: [N,OH,OW,Cout]; groups == 1: dw_oihw (+)= gradient in torch OIHW layout;
+// groups == N : dw_oihw is [N][Cout][Cin] (ks must be 1) -- one gradient per image.
+extern "C" int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N,
+                               int H, int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad,
+                               int groups, int npix_valid, int use_tr, int Cout_real, void* workspace, void* stream) {
+    DH_REQUIRE(groups == 1 || (groups == N && ks == 1), "conv2d_wgrad: groups must be 1 or N (with ks=1)");
+    WgArgs a;
+    a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.pad = pad;
+    a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, TH);
+    a.groups = groups; a.splitk = dh_conv2d_wgrad_splitk(N, OH, OW, Cin, Cout, ks, groups);
+    a.npix = npix_valid > 0 ? npix_valid : OH * OW;
+    a.in_npix = npix_valid > 0 ? npix_valid : H * W;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = dtype == DH_DTYPE_BF16 ? launch_all<bf16>(a, ks, stride, use_tr != 0, st)
+                                    : launch_all<float>(a, ks, stride, false, st);
+    if (rc) return rc;
+    const int taps = ks * ks;
+    const int oreal = Cout_real > 0 ? Cout_real : Cout;     // dy may carry zero-padded channels
+    const long n = (long)oreal * Cin * taps;
+    hipLaunchKernelGGL(wgrad_reduce_oihw_kernel, dim3(dh_cdiv(n, 256), groups), dim3(256), 0, st, a.part, a.splitk,
+                       taps, Cout, oreal, Cin, dw_oihw, accumulate);
+    DH_CHECK_LAUNCH("wgrad_reduce");
+    return 0;
+}

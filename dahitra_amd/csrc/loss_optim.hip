@@ -1,0 +1,208 @@
+// Focal loss (forward + gradient in one pass), arg-max mask, fused multi-tensor AdamW, and the
+// space-to-depth helpers that turn the 7x7/stride-2 stem into a 4x4/stride-1 MFMA convolution.
+//
+// Reference semantics restated:
+//   focal_loss ..... models/losses.py:106-196 (alpha 0.5, gamma 2, one_hot + 1e-6, mean over B*H*W)
+//   mask ........... torch.argmax(dim=1), first maximum wins (models/trainer.py:170, evaluator.py:101)
+//   AdamW .......... torch.optim.AdamW(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+//                    (models/trainer.py:39-40), decoupled decay, bias-corrected, no amsgrad
+//   stem ........... nn.Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (models/resnet.py:150)
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 8;
+
+// logits NCHW fp32 [B][C][HW]; target int64 [B][HW]; dlogits NCHW fp32 (already scaled by gscale/(B*HW))
+__global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                    int B, int C, long HW, float alpha, float gscale,
+                                                    float* __restrict__ dlogits, float* __restrict__ partial) {
+    __shared__ float red[256];
+    const long total = (long)B * HW;
+    float lsum = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / HW, p = i % HW;
+        float z[MAXC], pr[MAXC], lp[MAXC];
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) { z[c] = logits[(b * C + c) * HW + p]; m = fmaxf(m, z[c]); }
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) { pr[c] = expf(z[c] - m); s += pr[c]; }
+        const float ls = logf(s), inv = 1.f / s;
+        const int t = (int)target[i];
+        float loss = 0.f, gsum = 0.f, gp[MAXC];
+        for (int c = 0; c < C; ++c) {
+            pr[c] *= inv;
+            lp[c] = z[c] - m - ls;
+            const float oh = (c == t ? 1.f : 0.f) + 1e-6f;
+            const float om = 1.f - pr[c];
+            loss += oh * (-alpha * om * om * lp[c]);
+            // d f_c / d p_c * p_c, f_c = -alpha (1-p)^2 log p
+            gp[c] = oh * (-alpha) * (-2.f * om * pr[c] * lp[c] + om * om);
+            gsum += gp[c];
+        }
+        lsum += loss;
+        if (dlogits)
+            for (int c = 0; c < C; ++c) dlogits[(b * C + c) * HW + p] = gscale * (gp[c] - pr[c] * gsum);
+    }
+    red[threadIdx.x] = lsum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void argmax_nchw_kernel(const float* __restrict__ logits, long long* __restrict__ mask, int B, int C, long HW) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const long b = i / HW, p = i % HW;
+    float best = logits[(b * C) * HW + p];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+        const float v = logits[(b * C + c) * HW + p];
+        if (v > best) { best = v; arg = c; }
+    }
+    mask[i] = arg;
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
+                             float wd, float bc1, float bc2_sqrt, float grad_scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * grad_scale;
+        float w = p[i];
+        w *= 1.f - lr * wd;
+        const float mm = m[i] + (1.f - beta1) * (gr - m[i]);
+        const float vv = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        m[i] = mm;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        w -= (lr / bc1) * (mm / denom);
+        p[i] = w;
+    }
+}
+
+// x NCHW fp32 [N][3][H][W] -> space-to-depth NHWC T [N][H/2][W/2][CP], channel (ry*2+rx)*3 + c
+template <typename T>
+__global__ void stem_s2d_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int H, int W, int CP) {
+    const int H2 = H / 2, W2 = W / 2;
+    const long total = (long)N * H2 * W2 * CP;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % CP);
+        long t = i / CP;
+        const int x2 = (int)(t % W2); t /= W2;
+        const int y2 = (int)(t % H2);
+        const long n = t / H2;
+        float v = 0.f;
+        if (ch < 12) {
+            const int c = ch % 3, r = ch / 3, ry = r >> 1, rx = r & 1;
+            v = x[((n * 3 + c) * H + 2 * y2 + ry) * W + 2 * x2 + rx];
+        }
+        stf(y + i, v);
+    }
+}
+// w OIHW fp32 [O][3][7][7] -> packed [16 taps (dy,dx)][O][CP] T, kh = 2*dy + ry - 1, kw = 2*dx + rx - 1
+template <typename T>
+__global__ void stem_pack_kernel(const float* __restrict__ w, T* __restrict__ out, int O, int CP) {
+    const long total = 16L * O * CP;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % CP);
+        const int o = (int)((i / CP) % O);
+        const int tap = (int)(i / ((long)CP * O));
+        float v = 0.f;
+        if (ch < 12) {
+            const int c = ch % 3, r = ch / 3, ry = r >> 1, rx = r & 1;
+            const int kh = 2 * (tap / 4) + ry - 1, kw = 2 * (tap % 4) + rx - 1;
+            if (kh >= 0 && kh < 7 && kw >= 0 && kw < 7) v = w[((o * 3 + c) * 7 + kh) * 7 + kw];
+        }
+        stf(out + i, v);
+    }
+}
+// dw2 OIHW-of-the-4x4 form [O][CP][4][4] fp32 -> dw [O][3][7][7] (+)=
+__global__ void stem_unpack_grad_kernel(const float* __restrict__ dw2, float* __restrict__ dw, int O, int CP,
+                                        int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= O * 147) return;
+    const int kw = i % 7, kh = (i / 7) % 7, c = (i / 49) % 3, o = i / 147;
+    const int dy = (kh + 1) / 2, ry = (kh + 1) % 2, dx = (kw + 1) / 2, rx = (kw + 1) % 2;
+    const int ch = (ry * 2 + rx) * 3 + c;
+    const float v = dw2[((long)(o * CP + ch) * 4 + dy) * 4 + dx];
+    if (accumulate) dw[i] += v; else dw[i] = v;
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+extern "C" int dh_reduce_partials(const float* partial, long nt, long n, float scale, float* out, int accumulate,
+                                  void* stream);
+
+// workspace: 1024 floats.  loss_out: device scalar.  dlogits may be null (evaluation).
+extern "C" int dh_focal_loss(const float* logits_nchw, const long long* target, int B, int C, long HW, float alpha,
+                             float grad_scale, float* loss_out, float* dlogits_nchw, void* workspace, void* stream) {
+    DH_REQUIRE(C >= 1 && C <= MAXC, "focal_loss: n_class=%d unsupported (max %d)", C, MAXC);
+    const long total = (long)B * HW;
+    long g = (total + 255) / 256;
+    if (g > 1024) g = 1024;
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(focal_kernel, dim3((int)g), dim3(256), 0, ST(stream), logits_nchw, target, B, C, HW, alpha,
+                       grad_scale / (float)total, dlogits_nchw, partial);
+    DH_CHECK_LAUNCH("focal_loss");
+    return dh_reduce_partials(partial, g, 1, 1.0f / (float)total, loss_out, 0, stream);
+}
+
+extern "C" int dh_argmax_nchw(const float* logits_nchw, long long* mask, int B, int C, long HW, void* stream) {
+    hipLaunchKernelGGL(argmax_nchw_kernel, dim3(dh_cdiv((long)B * HW, 256)), dim3(256), 0, ST(stream), logits_nchw,
+                       mask, B, C, HW);
+    DH_CHECK_LAUNCH("argmax");
+    return 0;
+}
+
+// one launch over the flat fp32 arenas (param / grad / exp_avg / exp_avg_sq); step >= 1
+extern "C" int dh_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                             void* stream) {
+    DH_REQUIRE(step >= 1, "adamw: step must be >= 1");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adamw_kernel, dim3((int)g), dim3(256), 0, ST(stream), param, grad, exp_avg, exp_avg_sq, n, lr,
+                       beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    DH_CHECK_LAUNCH("adamw");
+    return 0;
+}
+
+extern "C" int dh_stem_space_to_depth(int dtype, const float* x_nchw, void* y, int N, int H, int W, int CP,
+                                      void* stream) {
+    DH_REQUIRE(H % 2 == 0 && W % 2 == 0 && CP >= 12, "stem_s2d: H, W must be even and CP >= 12");
+    const long n = (long)N * (H / 2) * (W / 2) * CP;
+    long g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(stem_s2d_kernel<bf16>, dim3((int)g), dim3(256), 0, ST(stream), x_nchw, (bf16*)y, N, H, W, CP);
+    else hipLaunchKernelGGL(stem_s2d_kernel<float>, dim3((int)g), dim3(256), 0, ST(stream), x_nchw, (float*)y, N, H, W, CP);
+    DH_CHECK_LAUNCH("stem_s2d");
+    return 0;
+}
+extern "C" int dh_stem_pack_weight(int dtype, const float* w_oihw, void* packed, int O, int CP, void* stream) {
+    const long n = 16L * O * CP;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(stem_pack_kernel<bf16>, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), w_oihw, (bf16*)packed, O, CP);
+    else hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), w_oihw, (float*)packed, O, CP);
+    DH_CHECK_LAUNCH("stem_pack");
+    return 0;
+}
+extern "C" int dh_stem_unpack_grad(const float* dw2, float* dw_oihw, int O, int CP, int accumulate, void* stream) {
+    hipLaunchKernelGGL(stem_unpack_grad_kernel, dim3(dh_cdiv(O * 147, 256)), dim3(256), 0, ST(stream), dw2, dw_oihw, O,
+                       CP, accumulate);
+    DH_CHECK_LAUNCH("stem_unpack_grad");
+    return 0;
+}
+
+// ---- error channel ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+extern "C" void dh_set_error(const char* msg) {
+    strncpy(g_err, msg, sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
+extern "C" const char* dh_last_error(void) { return g_err; }
+extern "C" int dh_abi_version(void) { return 1; }

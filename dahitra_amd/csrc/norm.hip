@@ -1,0 +1,421 @@
+// BatchNorm2d (train / eval, forward / backward) and LayerNorm(32) kernels, NHWC.
+//
+// BatchNorm follows torch.nn.BatchNorm2d as used by the reference (models/resnet.py:152,
+// models/help_funcs.py:11): eps 1e-5, momentum 0.1, biased variance for normalisation, unbiased
+// for running_var.  The Siamese trunk is run once on the concatenated [A;B] batch; "groups"
+// reproduces the reference's two separate forward_single calls (models/networks.py:360-361):
+// statistics are per stream and the running buffers are updated stream A first, then B.
+// All kernels are HBM-bound element-wise / reduction passes with 16-byte (fp32 x4 / bf16 x4)
+// accesses; statistics are accumulated in fp32 per workgroup and combined in fp64.
+#include "common.h"
+
+namespace {
+
+// ---- finalize train-mode statistics --------------------------------------------------------
+// partial: [ntiles][2][CP] from the conv epilogue (tile order = image order).
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, int CP, int C, int G,
+                                   double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;      // 64 threads
+    const int tpg = ntiles / G;
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+    for (int g = 0; g < G; ++g) {
+        double s = 0.0, q = 0.0;
+        for (int t = g * tpg + lane; t < (g + 1) * tpg; t += 64) {
+            s += (double)partial[((size_t)t * 2 + 0) * CP + c];
+            q += (double)partial[((size_t)t * 2 + 1) * CP + c];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        if (lane == 0) {
+            const double mean = s / count;
+            double var = q / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = gamma[c] * invstd;
+            mean_out[g * C + c] = (float)mean;
+            invstd_out[g * C + c] = invstd;
+            scale_out[g * C + c] = sc;
+            shift_out[g * C + c] = beta[c] - (float)mean * sc;
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            rm = (1.f - momentum) * rm + momentum * (float)mean;
+            rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+        }
+    }
+    if (lane == 0 && running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+}
+
+__global__ void bn_eval_params_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---- y = act(x*scale[g][c] + shift[g][c] (+ res)) -------------------------------------------
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                const float* __restrict__ scale, const float* __restrict__ shift, long nvec,
+                                int C, long group_vec, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const int g = (int)(i / group_vec);
+        float v[4];
+        ld4(x + i * 4, v);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + g * C + c);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + g * C + c);
+        v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
+        v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+        if (res) {
+            float r[4];
+            ld4(res + i * 4, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += r[j];
+        }
+        if (act == DH_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        st4(y + i * 4, v);
+    }
+}
+
+// ---- backward, pass 1: per-workgroup partial sums of dy and dy*xhat -------------------------
+// dy = dout * (out > 0) when `out` (the post-ReLU activation) is given.
+// partial: [G*bpg][2][C]; a workgroup never straddles two groups.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                            const T* __restrict__ x,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int C,
+                                                            long pix_per_group, int bpg,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[2 * 256 * 4];
+    const int g = blockIdx.x / bpg, b = blockIdx.x % bpg;
+    const int cvn = C / 4;                     // vector columns
+    const int cv = threadIdx.x % cvn, r0 = threadIdx.x / cvn, rstep = 256 / cvn;
+    const long chunk = (pix_per_group + bpg - 1) / bpg;
+    const long p0 = b * chunk, p1 = (p0 + chunk < pix_per_group) ? p0 + chunk : pix_per_group;
+    float mu[4], is[4], s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = mean[g * C + cv * 4 + j]; is[j] = invstd[g * C + cv * 4 + j]; }
+    for (long p = p0 + r0; p < p1; p += rstep) {
+        const size_t off = ((size_t)g * pix_per_group + p) * C + cv * 4;
+        float d[4], xv[4];
+        ld4(dout + off, d);
+        ld4(x + off, xv);
+        if (out) {
+            float o[4];
+            ld4(out + off, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s1[j] += d[j];
+            s2[j] += d[j] * (xv[j] - mu[j]) * is[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[(0 * 256 + threadIdx.x) * 4 + j] = s1[j];
+        red[(1 * 256 + threadIdx.x) * 4 + j] = s2[j];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 2 * C; o += 256) {
+        const int which = o / C, c = o % C;
+        float t = 0.f;
+        for (int r = 0; r < rstep; ++r) t += red[(which * 256 + r * cvn + c / 4) * 4 + (c & 3)];
+        partial[((size_t)blockIdx.x * 2 + which) * C + c] = t;
+    }
+}
+
+// combine partials: per-group sums (for dx) and total dgamma / dbeta (accumulated or assigned)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int bpg, int G, int C,
+                                       float* __restrict__ sums /*[G][2][C]*/, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double tg = 0.0, tb = 0.0;
+    for (int g = 0; g < G; ++g) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int t = lane; t < bpg; t += 64) {
+            s1 += (double)partial[((size_t)(g * bpg + t) * 2 + 0) * C + c];
+            s2 += (double)partial[((size_t)(g * bpg + t) * 2 + 1) * C + c];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (lane == 0) { sums[(g * 2 + 0) * C + c] = (float)s1; sums[(g * 2 + 1) * C + c] = (float)s2; }
+        tb += s1; tg += s2;
+    }
+    if (lane == 0) {
+        if (accumulate) { dgamma[c] += (float)tg; dbeta[c] += (float)tb; }
+        else { dgamma[c] = (float)tg; dbeta[c] = (float)tb; }
+    }
+}
+
+// ---- backward, pass 2: dx = gamma*invstd*(dy - (s1 + xhat*s2)/M); optional dres = dy --------
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ sums, float inv_m,
+                                    long nvec, int C, long group_vec, T* __restrict__ dx, T* __restrict__ dres) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const int g = (int)(i / group_vec);
+        float d[4], xv[4], r[4];
+        ld4(dout + i * 4, d);
+        ld4(x + i * 4, xv);
+        if (out) {
+            float o[4];
+            ld4(out + i * 4, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float is = invstd[g * C + c + j];
+            const float xh = (xv[j] - mean[g * C + c + j]) * is;
+            r[j] = gamma[c + j] * is * (d[j] - (sums[(g * 2 + 0) * C + c + j] + xh * sums[(g * 2 + 1) * C + c + j]) * inv_m);
+        }
+        st4(dx + i * 4, r);
+        if (dres) st4(dres + i * 4, d);
+    }
+}
+
+// eval-mode / frozen-statistics backward is not needed: the reference only trains in train mode.
+
+// ---- LayerNorm over 32 channels: 8 lanes per row, 4 channels per lane -----------------------
+template <typename T>
+__global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ stats,
+                              long rows, float eps) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long row = gid >> 3;
+    const int q = (int)(gid & 7);
+    const bool ok = row < rows;
+    float v[4] = {0, 0, 0, 0};
+    if (ok) ld4(x + row * 32 + q * 4, v);
+    float s = v[0] + v[1] + v[2] + v[3];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    const float mean = s * (1.f / 32.f);
+    float d[4], qq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { d[j] = v[j] - mean; qq += d[j] * d[j]; }
+    qq += __shfl_xor(qq, 1, 64); qq += __shfl_xor(qq, 2, 64); qq += __shfl_xor(qq, 4, 64);
+    const float rstd = rsqrtf(qq * (1.f / 32.f) + eps);
+    if (!ok) return;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = d[j] * rstd * gamma[q * 4 + j] + beta[q * 4 + j];
+    st4(y + row * 32 + q * 4, o);
+    if (stats && q == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+}
+
+// dx (optionally accumulated into dx_acc) and per-workgroup partial dgamma/dbeta [nblk][2][32]
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ stats,
+                                                     const float* __restrict__ gamma, T* __restrict__ dx,
+                                                     const T* __restrict__ dx_add, float* __restrict__ partial,
+                                                     long rows) {
+    __shared__ float red[2][32][33];
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long row = gid >> 3;
+    const int q = (int)(gid & 7);
+    const bool ok = row < rows;
+    float g[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0};
+    float mean = 0.f, rstd = 0.f;
+    if (ok) {
+        ld4(dy + row * 32 + q * 4, g);
+        ld4(x + row * 32 + q * 4, xv);
+        mean = stats[row * 2];
+        rstd = stats[row * 2 + 1];
+    }
+    float xh[4], gh[4], a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        xh[j] = (xv[j] - mean) * rstd;
+        gh[j] = g[j] * gamma[q * 4 + j];
+        a += gh[j];
+        b += gh[j] * xh[j];
+    }
+    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+    b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64); b += __shfl_xor(b, 4, 64);
+    if (ok) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (gh[j] - (a + xh[j] * b) * (1.f / 32.f));
+        if (dx_add) {
+            float e[4];
+            ld4(dx_add + row * 32 + q * 4, e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += e[j];
+        }
+        st4(dx + row * 32 + q * 4, o);
+    }
+    // partial dgamma / dbeta over the 32 rows of this workgroup
+    const int lr = threadIdx.x >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][lr][q * 4 + j] = ok ? g[j] * xh[j] : 0.f;
+        red[1][lr][q * 4 + j] = ok ? g[j] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+        float t = 0.f;
+        for (int r = 0; r < 32; ++r) t += red[which][r][c];
+        partial[((size_t)blockIdx.x * 2 + which) * 32 + c] = t;
+    }
+}
+
+// out[i] (+)= scale * sum_t partial[t][i], t < nt  (deterministic second reduction stage)
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, long nt, long n, float scale,
+                                       float* __restrict__ out, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (long t = 0; t < nt; ++t) s += (double)partial[t * n + i];
+    const float v = (float)(s * scale);
+    if (accumulate) out[i] += v; else out[i] = v;
+}
+
+inline int ew_grid(long n, int block) {
+    long g = (n + block - 1) / block;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int dh_bn_finalize(const float* partial, int ntiles, int CP, int C, int groups, double count,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                              void* stream) {
+    DH_REQUIRE(groups > 0 && ntiles % groups == 0, "bn_finalize: ntiles=%d not divisible by groups=%d", ntiles, groups);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, ntiles, CP, C, groups, count,
+                       gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    DH_CHECK_LAUNCH("bn_finalize");
+    return 0;
+}
+
+extern "C" int dh_bn_eval_params(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, int C, float* scale, float* shift,
+                                 void* stream) {
+    hipLaunchKernelGGL(bn_eval_params_kernel, dim3(dh_cdiv(C, 64)), dim3(64), 0, ST(stream), gamma, beta,
+                       running_mean, running_var, eps, C, scale, shift);
+    DH_CHECK_LAUNCH("bn_eval_params");
+    return 0;
+}
+
+extern "C" int dh_bn_apply(int dtype, const void* x, const void* residual, void* y, const float* scale,
+                           const float* shift, long npix, int C, int groups, int act, void* stream) {
+    DH_REQUIRE(C % 4 == 0 && npix % groups == 0, "bn_apply: C=%d npix=%ld groups=%d", C, npix, groups);
+    const long nvec = npix * C / 4, gvec = nvec / groups;
+    if (dtype == DH_DTYPE_BF16)
+        hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const bf16*)x,
+                           (const bf16*)residual, (bf16*)y, scale, shift, nvec, C, gvec, act);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const float*)x,
+                           (const float*)residual, (float*)y, scale, shift, nvec, C, gvec, act);
+    DH_CHECK_LAUNCH("bn_apply");
+    return 0;
+}
+
+// workspace: partial [groups*bpg][2][C] floats + sums [groups][2][C] floats
+extern "C" long dh_bn_bwd_workspace_size(long npix, int C, int groups) {
+    const int bpg = 128;
+    return ((long)groups * bpg * 2 * C + (long)groups * 2 * C) * 4;
+}
+
+extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, const void* x, const float* mean,
+                         const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
+                         void* dres, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                         void* stream) {
+    DH_REQUIRE(C % 4 == 0 && 1024 % C == 0, "bn_bwd: unsupported C=%d", C);
+    DH_REQUIRE(npix % groups == 0, "bn_bwd: npix %% groups");
+    const int bpg = 128;
+    const long ppg = npix / groups;
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* sums = partial + (long)groups * bpg * 2 * C;
+    const long nvec = npix * C / 4;
+    if (dtype == DH_DTYPE_BF16) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(groups * bpg), dim3(256), 0, ST(stream), (const bf16*)dout,
+                           (const bf16*)out_relu, (const bf16*)x, mean, invstd, C, ppg, bpg, partial);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, bpg, groups, C, sums,
+                           dgamma, dbeta, accumulate);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream),
+                           (const bf16*)dout, (const bf16*)out_relu, (const bf16*)x, mean, invstd, gamma, sums,
+                           1.0f / (float)ppg, nvec, C, nvec / groups, (bf16*)dx, (bf16*)dres);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(groups * bpg), dim3(256), 0, ST(stream), (const float*)dout,
+                           (const float*)out_relu, (const float*)x, mean, invstd, C, ppg, bpg, partial);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, bpg, groups, C, sums,
+                           dgamma, dbeta, accumulate);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream),
+                           (const float*)dout, (const float*)out_relu, (const float*)x, mean, invstd, gamma, sums,
+                           1.0f / (float)ppg, nvec, C, nvec / groups, (float*)dx, (float*)dres);
+    }
+    DH_CHECK_LAUNCH("bn_bwd");
+    return 0;
+}
+
+extern "C" int dh_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
+                                float* stats, long rows, int C, float eps, void* stream) {
+    DH_REQUIRE(C == 32, "layernorm: only dim 32 (the reference's transformer width), got %d", C);
+    if (rows == 0) return 0;
+    const int grid = dh_cdiv(rows * 8, 256);
+    if (dtype == DH_DTYPE_BF16)
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)x, gamma, beta,
+                           (bf16*)y, stats, rows, eps);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)x, gamma, beta,
+                           (float*)y, stats, rows, eps);
+    DH_CHECK_LAUNCH("layernorm_fwd");
+    return 0;
+}
+
+extern "C" long dh_layernorm_bwd_workspace_size(long rows) { return ((long)dh_cdiv(rows * 8, 256) * 64 + 64) * 4; }
+
+extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
+                                void* dx, const void* dx_add, float* dgamma, float* dbeta, int accumulate,
+                                long rows, int C, void* workspace, void* stream) {
+    DH_REQUIRE(C == 32, "layernorm_bwd: only dim 32, got %d", C);
+    if (rows == 0) return 0;
+    const int grid = dh_cdiv(rows * 8, 256);
+    float* partial = reinterpret_cast<float*>(workspace);
+    if (dtype == DH_DTYPE_BF16)
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dy, (const bf16*)x,
+                           stats, gamma, (bf16*)dx, (const bf16*)dx_add, partial, rows);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)dy,
+                           (const float*)x, stats, gamma, (float*)dx, (const float*)dx_add, partial, rows);
+    // per-block partial rows are [dgamma(32) | dbeta(32)]: reduce into a 64-float temp, then split
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, ST(stream), partial, (long)grid, 64L, 1.0f,
+                       partial + (long)grid * 64, 0);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(32), 0, ST(stream), partial + (long)grid * 64, 1L, 32L,
+                       1.0f, dgamma, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(32), 0, ST(stream), partial + (long)grid * 64 + 32, 1L,
+                       32L, 1.0f, dbeta, accumulate);
+    DH_CHECK_LAUNCH("layernorm_bwd");
+    return 0;
+}
+
+extern "C" int dh_reduce_partials(const float* partial, long nt, long n, float scale, float* out, int accumulate,
+                                  void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), partial, nt, n,
+                       scale, out, accumulate);
+    DH_CHECK_LAUNCH("reduce_partials");
+    return 0;
+}

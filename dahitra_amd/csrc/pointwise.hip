@@ -1,0 +1,539 @@
+// HBM-bound NHWC pointwise / resampling / layout kernels (gfx950).
+// Reference ops restated: MaxPool2d(3,2,1) models/resnet.py:154; nn.Upsample(x2 nearest) and
+// nn.Upsample(x4 bilinear, align_corners=False) models/networks.py:199-200; torch.abs(x1-x2)
+// models/networks.py:384; GELU / ReLU derivatives; channel concat (torch.cat) models/networks.py:1312,1348.
+// Every kernel is a grid-stride loop over 4-channel vectors (16 B fp32 / 8 B bf16 per lane).
+#include "common.h"
+
+namespace {
+
+inline int ew_grid(long n, int block) {
+    long g = (n + block - 1) / block;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+#define GSL(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// ---- NCHW fp32 <-> NHWC T -------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, long HW, int CP) {
+    const long total = (long)N * HW * CP;      // destination channels zero-padded to CP >= C
+    GSL(i, total) {
+        const int c = (int)(i % CP);
+        const long p = (i / CP) % HW;
+        const long n = i / (CP * HW);
+        stf(dst + i, c < C ? src[(n * C + c) * HW + p] : 0.f);
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int N, int C, long HW) {
+    const long total = (long)N * HW * C;
+    GSL(i, total) {   // i indexes the NCHW destination (coalesced stores)
+        const long p = i % HW;
+        const int c = (int)((i / HW) % C);
+        const long n = i / (HW * C);
+        dst[i] = ldf(src + (n * HW + p) * C + c);
+    }
+}
+
+// ---- channel-slice copy: dst[p, dc0 + c] = src[p, sc0 + c], c < Cn -------------------------
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ src, int Cs, int sc0, T* __restrict__ dst, int Cd,
+                                     int dc0, int Cn, long P) {
+    const int vn = Cn / 4;
+    GSL(i, P * vn) {
+        const long p = i / vn;
+        const int c = (int)(i % vn) * 4;
+        float v[4];
+        ld4(src + p * Cs + sc0 + c, v);
+        st4(dst + p * Cd + dc0 + c, v);
+    }
+}
+
+// ---- y = a + b ------------------------------------------------------------------------------
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long nvec) {
+    GSL(i, nvec) {
+        float u[4], v[4];
+        ld4(a + i * 4, u);
+        ld4(b + i * 4, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] += v[j];
+        st4(y + i * 4, u);
+    }
+}
+
+// y[n,p,c] = x[n,p,c] + pos[c,p]  (pos is an NCHW fp32 parameter [1,C,h,w]; networks.py:1291)
+template <typename T>
+__global__ void add_pos_kernel(const T* __restrict__ x, const float* __restrict__ pos, T* __restrict__ y, int N,
+                               long HW, int C) {
+    GSL(i, (long)N * HW * C) {
+        const int c = (int)(i % C);
+        const long p = (i / C) % HW;
+        stf(y + i, ldf(x + i) + pos[c * HW + p]);
+    }
+}
+// dpos[c,p] (+)= sum_n dy[n,p,c]
+template <typename T>
+__global__ void add_pos_bwd_kernel(const T* __restrict__ dy, float* __restrict__ dpos, int N, long HW, int C,
+                                   int accumulate) {
+    GSL(i, HW * C) {   // i indexes dpos (c-major)
+        const long p = i % HW;
+        const int c = (int)(i / HW);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += ldf(dy + ((long)n * HW + p) * C + c);
+        if (accumulate) dpos[i] += s; else dpos[i] = s;
+    }
+}
+
+// ---- activation derivative: dx = dy * f'(.) ---------------------------------------------------
+// mode RELU: ref = post-activation output (mask ref > 0); mode GELU: ref = pre-activation.
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ ref, T* __restrict__ dx, long nvec,
+                               int act) {
+    GSL(i, nvec) {
+        float g[4], r[4];
+        ld4(dy + i * 4, g);
+        ld4(ref + i * 4, r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = act == DH_ACT_RELU ? (r[j] > 0.f ? g[j] : 0.f) : g[j] * gelu_erf_grad(r[j]);
+        st4(dx + i * 4, g);
+    }
+}
+
+// ---- MaxPool 3x3 stride 2 pad 1 -------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int OH,
+                                   int OW) {
+    const int vn = C / 4;
+    GSL(i, (long)N * OH * OW * vn) {
+        const int c = (int)(i % vn) * 4;
+        long t = i / vn;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const long n = t / OH;
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                float v[4];
+                ld4(x + ((n * H + iy) * W + ix) * C + c, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+            }
+        }
+        st4(y + i * 4, m);
+    }
+}
+// gather form: an input pixel receives dy of every window whose first maximum (row-major scan,
+// strict >, as ATen's CPU kernel) it is.  Deterministic, no atomics.
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int N,
+                                   int H, int W, int C, int OH, int OW) {
+    const int vn = C / 4;
+    GSL(i, (long)N * H * W * vn) {
+        const int c = (int)(i % vn) * 4;
+        long t = i / vn;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const long n = t / H;
+        float g[4] = {0, 0, 0, 0};
+        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {   // windows with 2*oy-1 <= iy <= 2*oy+1
+            if (oy < 0 || oy >= OH) continue;
+            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox < 0 || ox >= OW) continue;
+                // scan the window of (oy, ox)
+                float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int arg[4] = {-1, -1, -1, -1};
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = oy * 2 - 1 + ky;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = ox * 2 - 1 + kx;
+                        if (xx < 0 || xx >= W) continue;
+                        float v[4];
+                        ld4(x + ((n * H + yy) * W + xx) * C + c, v);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (v[j] > m[j] || arg[j] < 0) { m[j] = v[j]; arg[j] = yy * W + xx; }
+                    }
+                }
+                float d[4];
+                ld4(dy + ((n * OH + oy) * OW + ox) * C + c, d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (arg[j] == iy * W + ix) g[j] += d[j];
+            }
+        }
+        st4(dx + i * 4, g);
+    }
+}
+
+// ---- nearest x2 -----------------------------------------------------------------------------
+template <typename T>
+__global__ void up2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
+    const int vn = C / 4;
+    GSL(i, (long)N * 4 * H * W * vn) {
+        const int c = (int)(i % vn) * 4;
+        long t = i / vn;
+        const int ox = (int)(t % (2 * W)); t /= 2 * W;
+        const int oy = (int)(t % (2 * H));
+        const long n = t / (2 * H);
+        float v[4];
+        ld4(x + ((n * H + oy / 2) * W + ox / 2) * C + c, v);
+        st4(y + i * 4, v);
+    }
+}
+template <typename T>
+__global__ void up2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C) {
+    const int vn = C / 4;
+    GSL(i, (long)N * H * W * vn) {
+        const int c = (int)(i % vn) * 4;
+        long t = i / vn;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const long n = t / H;
+        float s[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+            for (int dxx = 0; dxx < 2; ++dxx) {
+                float v[4];
+                ld4(dy + ((n * 2 * H + 2 * iy + dyy) * 2 * W + 2 * ix + dxx) * C + c, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += v[j];
+            }
+        st4(dx + i * 4, s);
+    }
+}
+
+// ---- |a - b| then bilinear x4 (align_corners=False) ------------------------------------------
+__device__ __forceinline__ void bil_src(int d, int in, int& i0, int& i1, float& l) {
+    float s = ((float)d + 0.5f) * 0.25f - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l = s - (float)i0;
+}
+template <typename T>
+__global__ void absdiff_up4_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int N,
+                                       int H, int W, int C) {
+    const int vn = C / 4, OH = 4 * H, OW = 4 * W;
+    GSL(i, (long)N * OH * OW * vn) {
+        const int c = (int)(i % vn) * 4;
+        long t = i / vn;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const long n = t / OH;
+        int y0, y1, x0, x1; float ly, lx;
+        bil_src(oy, H, y0, y1, ly);
+        bil_src(ox, W, x0, x1, lx);
+        float acc[4] = {0, 0, 0, 0};
+        const int ys[2] = {y0, y1}, xs[2] = {x0, x1};
+        const float wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float u[4], v[4];
+                const long off = ((n * H + ys[p]) * W + xs[q]) * C + c;
+                ld4(a + off, u);
+                ld4(b + off, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += wy[p] * wx[q] * fabsf(u[j] - v[j]);
+            }
+        st4(y + i * 4, acc);
+    }
+}
+// gather backward: source pixel (iy, ix) collects from destination rows 4*iy-2 .. 4*iy+5
+template <typename T>
+__global__ void absdiff_up4_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ dy,
+                                       T* __restrict__ da, T* __restrict__ db, int N, int H, int W, int C) {
+    const int vn = C / 4, OH = 4 * H, OW = 4 * W;
+    GSL(i, (long)N * H * W * vn) {
+        const int c = (int)(i % vn) * 4;
+        long t = i / vn;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const long n = t / H;
+        float g[4] = {0, 0, 0, 0};
+        for (int oy = 4 * iy - 2; oy <= 4 * iy + 5; ++oy) {
+            if (oy < 0 || oy >= OH) continue;
+            int y0, y1; float ly;
+            bil_src(oy, H, y0, y1, ly);
+            const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = 4 * ix - 2; ox <= 4 * ix + 5; ++ox) {
+                if (ox < 0 || ox >= OW) continue;
+                int x0, x1; float lx;
+                bil_src(ox, W, x0, x1, lx);
+                const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                if (wx == 0.f) continue;
+                float d[4];
+                ld4(dy + ((n * OH + oy) * OW + ox) * C + c, d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] += wy * wx * d[j];
+            }
+        }
+        float u[4], v[4], ga[4], gb[4];
+        ld4(a + i * 4, u);
+        ld4(b + i * 4, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float df = u[j] - v[j];
+            const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            ga[j] = sg * g[j];
+            gb[j] = -ga[j];
+        }
+        st4(da + i * 4, ga);
+        st4(db + i * 4, gb);
+    }
+}
+
+// |a-b| on small fp32/T row tensors (token differences, networks.py:1311) and its derivative
+template <typename T>
+__global__ void absdiff_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n) {
+    GSL(i, n) stf(y + i, fabsf(ldf(a + i) - ldf(b + i)));
+}
+template <typename T>
+__global__ void absdiff_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ dy,
+                                   T* __restrict__ da, T* __restrict__ db, long n, int accumulate) {
+    GSL(i, n) {
+        const float df = ldf(a + i) - ldf(b + i);
+        const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+        const float g = sg * ldf(dy + i);
+        if (accumulate) { stf(da + i, ldf(da + i) + g); stf(db + i, ldf(db + i) - g); }
+        else { stf(da + i, g); stf(db + i, -g); }
+    }
+}
+
+// ---- zero insertion for stride-2 data gradients: z[n, 2y, 2x, c] = dy[n, y, x, c] ------------
+template <typename T>
+__global__ void zero_insert2_kernel(const T* __restrict__ dy, T* __restrict__ z, int N, int OH, int OW, int H, int W,
+                                    int C) {
+    const int vn = C / 4;
+    GSL(i, (long)N * H * W * vn) {
+        const int c = (int)(i % vn) * 4;
+        long t = i / vn;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const long n = t / H;
+        float v[4] = {0, 0, 0, 0};
+        if (!(x & 1) && !(y & 1) && y / 2 < OH && x / 2 < OW) ld4(dy + ((n * OH + y / 2) * OW + x / 2) * C + c, v);
+        st4(z + i * 4, v);
+    }
+}
+
+// ---- weight packing: OIHW fp32 -> [tap][OPad][I] T  and  [tap'][IPad][O] T (flipped) ---------
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, int O, int I, int KS, int OPad, T* __restrict__ fwd,
+                                   int IPad, int OK, T* __restrict__ dgrad) {
+    const int taps = KS * KS;
+    if (fwd) {
+        GSL(i, (long)taps * OPad * I) {
+            const int ci = (int)(i % I);
+            const int o = (int)((i / I) % OPad);
+            const int tap = (int)(i / ((long)I * OPad));
+            stf(fwd + i, o < O ? w[((long)o * I + ci) * taps + tap] : 0.f);
+        }
+    }
+    if (dgrad) {
+        GSL(i, (long)taps * IPad * OK) {     // reduction dim (output channels) zero-padded to OK
+            const int o = (int)(i % OK);
+            const int ci = (int)((i / OK) % IPad);
+            const int tap = (int)(i / ((long)OK * IPad));
+            stf(dgrad + i, (ci < I && o < O) ? w[((long)o * I + ci) * taps + (taps - 1 - tap)] : 0.f);
+        }
+    }
+}
+
+// ---- column sums: out[c] (+)= sum_p x[p, c]  (bias gradients) --------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long P, int C,
+                                                             float* __restrict__ partial) {
+    // block b sums rows b, b+grid, ...; thread t covers channel t % C, row phase t / C
+    __shared__ float red[256];
+    const int c = threadIdx.x % C, ph = threadIdx.x / C, nph = 256 / C;
+    float s = 0.f;
+    if (ph < nph)
+        for (long p = (long)blockIdx.x * nph + ph; p < P; p += (long)gridDim.x * nph) s += ldf(x + p * C + c);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float t = 0.f;
+        for (int r = 0; r < nph; ++r) t += red[r * C + threadIdx.x];
+        partial[(long)blockIdx.x * C + threadIdx.x] = t;
+    }
+}
+
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+    GSL(i, n) stf(dst + i, src[i]);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, long n, int accumulate) {
+    GSL(i, n) { if (accumulate) dst[i] += ldf(src + i); else dst[i] = ldf(src + i); }
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+extern "C" int dh_reduce_partials(const float* partial, long nt, long n, float scale, float* out, int accumulate,
+                                  void* stream);
+
+extern "C" int dh_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, long HW, int CP, void* stream) {
+    if (CP < C) CP = C;
+    const long n = (long)N * CP * HW;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), src, (bf16*)dst, N, C, HW, CP);
+    else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), src, (float*)dst, N, C, HW, CP);
+    DH_CHECK_LAUNCH("nchw_to_nhwc");
+    return 0;
+}
+extern "C" int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream) {
+    const long n = (long)N * C * HW;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)src, dst, N, C, HW);
+    else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)src, dst, N, C, HW);
+    DH_CHECK_LAUNCH("nhwc_to_nchw");
+    return 0;
+}
+extern "C" int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, void* dst, int Cd, int dc0, int Cn,
+                                long P, void* stream) {
+    DH_REQUIRE(Cn % 4 == 0 && sc0 % 4 == 0 && dc0 % 4 == 0 && Cs % 4 == 0 && Cd % 4 == 0, "copy_channels: channel counts must be multiples of 4");
+    const long n = P * (Cn / 4);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(copy_channels_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)src, Cs, sc0, (bf16*)dst, Cd, dc0, Cn, P);
+    else hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)src, Cs, sc0, (float*)dst, Cd, dc0, Cn, P);
+    DH_CHECK_LAUNCH("copy_channels");
+    return 0;
+}
+extern "C" int dh_add(int dtype, const void* a, const void* b, void* y, long n, void* stream) {
+    DH_REQUIRE(n % 4 == 0, "add: n must be a multiple of 4");
+    const long nv = n / 4;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(add_kernel<bf16>, dim3(ew_grid(nv, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (bf16*)y, nv);
+    else hipLaunchKernelGGL(add_kernel<float>, dim3(ew_grid(nv, 256)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (float*)y, nv);
+    DH_CHECK_LAUNCH("add");
+    return 0;
+}
+extern "C" int dh_add_pos(int dtype, const void* x, const float* pos, void* y, int N, long HW, int C, void* stream) {
+    const long n = (long)N * HW * C;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(add_pos_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, pos, (bf16*)y, N, HW, C);
+    else hipLaunchKernelGGL(add_pos_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, pos, (float*)y, N, HW, C);
+    DH_CHECK_LAUNCH("add_pos");
+    return 0;
+}
+extern "C" int dh_add_pos_bwd(int dtype, const void* dy, float* dpos, int N, long HW, int C, int accumulate, void* stream) {
+    const long n = HW * C;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(add_pos_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)dy, dpos, N, HW, C, accumulate);
+    else hipLaunchKernelGGL(add_pos_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)dy, dpos, N, HW, C, accumulate);
+    DH_CHECK_LAUNCH("add_pos_bwd");
+    return 0;
+}
+extern "C" int dh_act_bwd(int dtype, const void* dy, const void* ref, void* dx, long n, int act, void* stream) {
+    DH_REQUIRE(n % 4 == 0 && (act == DH_ACT_RELU || act == DH_ACT_GELU), "act_bwd: bad arguments");
+    const long nv = n / 4;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(ew_grid(nv, 256)), dim3(256), 0, ST(stream), (const bf16*)dy, (const bf16*)ref, (bf16*)dx, nv, act);
+    else hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(ew_grid(nv, 256)), dim3(256), 0, ST(stream), (const float*)dy, (const float*)ref, (float*)dx, nv, act);
+    DH_CHECK_LAUNCH("act_bwd");
+    return 0;
+}
+extern "C" int dh_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+    DH_REQUIRE(C % 4 == 0, "maxpool: C %% 4");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long n = (long)N * OH * OW * (C / 4);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, N, H, W, C, OH, OW);
+    else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, N, H, W, C, OH, OW);
+    DH_CHECK_LAUNCH("maxpool_fwd");
+    return 0;
+}
+extern "C" int dh_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
+    DH_REQUIRE(C % 4 == 0, "maxpool: C %% 4");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long n = (long)N * H * W * (C / 4);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (const bf16*)dy, (bf16*)dx, N, H, W, C, OH, OW);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (const float*)dy, (float*)dx, N, H, W, C, OH, OW);
+    DH_CHECK_LAUNCH("maxpool_bwd");
+    return 0;
+}
+extern "C" int dh_upsample2_nearest_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+    DH_REQUIRE(C % 4 == 0, "upsample2: C %% 4");
+    const long n = (long)N * 4 * H * W * (C / 4);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(up2_fwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, N, H, W, C);
+    else hipLaunchKernelGGL(up2_fwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, N, H, W, C);
+    DH_CHECK_LAUNCH("up2_fwd");
+    return 0;
+}
+extern "C" int dh_upsample2_nearest_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
+    DH_REQUIRE(C % 4 == 0, "upsample2: C %% 4");
+    const long n = (long)N * H * W * (C / 4);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(up2_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)dy, (bf16*)dx, N, H, W, C);
+    else hipLaunchKernelGGL(up2_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)dy, (float*)dx, N, H, W, C);
+    DH_CHECK_LAUNCH("up2_bwd");
+    return 0;
+}
+extern "C" int dh_absdiff_upsample4_fwd(int dtype, const void* a, const void* b, void* y, int N, int H, int W, int C, void* stream) {
+    DH_REQUIRE(C % 4 == 0, "absdiff_upsample4: C %% 4");
+    const long n = (long)N * 16 * H * W * (C / 4);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(absdiff_up4_fwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (bf16*)y, N, H, W, C);
+    else hipLaunchKernelGGL(absdiff_up4_fwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (float*)y, N, H, W, C);
+    DH_CHECK_LAUNCH("absdiff_up4_fwd");
+    return 0;
+}
+extern "C" int dh_absdiff_upsample4_bwd(int dtype, const void* a, const void* b, const void* dy, void* da, void* db, int N, int H, int W, int C, void* stream) {
+    DH_REQUIRE(C % 4 == 0, "absdiff_upsample4: C %% 4");
+    const long n = (long)N * H * W * (C / 4);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(absdiff_up4_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (const bf16*)dy, (bf16*)da, (bf16*)db, N, H, W, C);
+    else hipLaunchKernelGGL(absdiff_up4_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (const float*)dy, (float*)da, (float*)db, N, H, W, C);
+    DH_CHECK_LAUNCH("absdiff_up4_bwd");
+    return 0;
+}
+extern "C" int dh_absdiff(int dtype, const void* a, const void* b, void* y, long n, void* stream) {
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(absdiff_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (bf16*)y, n);
+    else hipLaunchKernelGGL(absdiff_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (float*)y, n);
+    DH_CHECK_LAUNCH("absdiff");
+    return 0;
+}
+extern "C" int dh_absdiff_bwd(int dtype, const void* a, const void* b, const void* dy, void* da, void* db, long n, int accumulate, void* stream) {
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(absdiff_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (const bf16*)dy, (bf16*)da, (bf16*)db, n, accumulate);
+    else hipLaunchKernelGGL(absdiff_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (const float*)dy, (float*)da, (float*)db, n, accumulate);
+    DH_CHECK_LAUNCH("absdiff_bwd");
+    return 0;
+}
+extern "C" int dh_zero_insert2(int dtype, const void* dy, void* z, int N, int OH, int OW, int H, int W, int C, void* stream) {
+    DH_REQUIRE(C % 4 == 0, "zero_insert2: C %% 4");
+    const long n = (long)N * H * W * (C / 4);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(zero_insert2_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)dy, (bf16*)z, N, OH, OW, H, W, C);
+    else hipLaunchKernelGGL(zero_insert2_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)dy, (float*)z, N, OH, OW, H, W, C);
+    DH_CHECK_LAUNCH("zero_insert2");
+    return 0;
+}
+extern "C" int dh_pack_weight(int dtype, const float* w_oihw, int O, int I, int ks, int OPad, void* fwd, int IPad, int dgrad_inner, void* dgrad, void* stream) {
+    const int OK = dgrad_inner > O ? dgrad_inner : O;
+    const long n = (long)ks * ks * (OPad > IPad ? OPad : IPad) * (OK > I ? OK : I);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), w_oihw, O, I, ks, OPad, (bf16*)fwd, IPad, OK, (bf16*)dgrad);
+    else hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), w_oihw, O, I, ks, OPad, (float*)fwd, IPad, OK, (float*)dgrad);
+    DH_CHECK_LAUNCH("pack_weight");
+    return 0;
+}
+// workspace: 256 * C floats
+extern "C" int dh_colsum(int dtype, const void* x, long P, int C, float* out, int accumulate, void* workspace, void* stream) {
+    DH_REQUIRE(C >= 1 && C <= 256, "colsum: C=%d out of range", C);
+    const int grid = 256;
+    float* partial = reinterpret_cast<float*>(workspace);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)x, P, C, partial);
+    else hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)x, P, C, partial);
+    DH_CHECK_LAUNCH("colsum");
+    return dh_reduce_partials(partial, grid, C, 1.0f, out, accumulate, stream);
+}
+extern "C" int dh_cast_from_f32(int dtype, const float* src, void* dst, long n, void* stream) {
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(cast_from_f32_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), src, (bf16*)dst, n);
+    else hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), src, (float*)dst, n);
+    DH_CHECK_LAUNCH("cast_from_f32");
+    return 0;
+}
+extern "C" int dh_cast_to_f32(int dtype, const void* src, float* dst, long n, int accumulate, void* stream) {
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(cast_to_f32_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)src, dst, n, accumulate);
+    else hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)src, dst, n, accumulate);
+    DH_CHECK_LAUNCH("cast_to_f32");
+    return 0;
+}

@@ -1,0 +1,636 @@
+// Token-side kernels of the bitemporal transformer (gfx950).  All of this is a few hundred KFLOP
+// per image: latency-, not roofline-bound.  Internal math is fp32; tensors crossing to the pixel
+// side are in the activation type T.
+//
+//  * semantic tokenizer  (reference models/networks.py:312-319): 1x1 conv 32->L, softmax over the
+//    HW pixels, attention-weighted pooling -> L tokens of width 32 per image; + learned pos
+//    (networks.py:332-334) fused into the store of the concatenated [A;B] token set.
+//  * cross-attention operand preparation (models/help_funcs.py:66-114).  For a pixel row x and the
+//    L tokens m of its image, with k_l = Wk LN(m_l), v_l = Wv LN(m_l):
+//        dots[h,l] = scale * <Wq_h LN(x), k_{l,h}>  = LN(x) . Kq[h,l,:],  Kq[h,l,:] = scale * Wq_h^T k_{l,h}
+//        out       = Wo concat_h(sum_l a[h,l] v_{l,h}) = sum_{h,l} a[h,l] Vo[h,l,:], Vo[h,l,:] = Wo_h v_{l,h}
+//    i.e. two dense (H*L)x32 products per pixel instead of materialising the 4096x512 q / out
+//    tensors (fp re-association of the same sums; ~17x fewer FLOPs).  Kq / Vo are produced here
+//    per image, the pixel-side products run on the MFMA conv kernel with per-image weights.
+//  * grouped softmax over the L keys of each head (help_funcs.py:103), forward and backward.
+//  * token self-attention core of the encoder (models/networks.py:457-488) for <= 16 tokens.
+#include "common.h"
+
+namespace {
+
+constexpr int D = 32;   // transformer width
+
+// ------------------------------------------------------------------------------------------
+// tokenizer
+// ------------------------------------------------------------------------------------------
+template <typename T, int L>
+__global__ void tok_logits_kernel(const T* __restrict__ x, const float* __restrict__ wa, float* __restrict__ logits,
+                                  long P) {
+    __shared__ float w[L * D];
+    for (int i = threadIdx.x; i < L * D; i += blockDim.x) w[i] = wa[i];
+    __syncthreads();
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float acc[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) acc[l] = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        float v[4];
+        ld4(x + p * D + c, v);
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[l] += v[j] * w[l * D + c + j];
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) logits[p * L + l] = acc[l];
+}
+
+// one workgroup per image: softmax statistics over HW, then pooled tokens.
+// tok_cat: [B][2L][32] T (stream = s / B selects the half), pooled: [S][L][32] fp32 (saved).
+template <typename T, int L>
+__global__ __launch_bounds__(256) void tok_pool_kernel(const T* __restrict__ x, const float* __restrict__ logits,
+                                                       const float* __restrict__ pos /*[2L][32] or null*/, int HW,
+                                                       int B, float* __restrict__ stats /*[S][L][2]*/,
+                                                       float* __restrict__ pooled, T* __restrict__ tok_cat) {
+    __shared__ float red[256];
+    __shared__ float smax[L], sinv[L];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const float* lg = logits + (size_t)s * HW * L;
+    // max and sum-exp per token: threads are split into L interleaved sets
+    const int l_of = tid % L, sub = tid / L, nsub = 256 / L;
+    float m = -INFINITY;
+    for (int n = sub; n < HW; n += nsub) m = fmaxf(m, lg[(size_t)n * L + l_of]);
+    red[tid] = m;
+    __syncthreads();
+    if (tid < L) {
+        float t = -INFINITY;
+        for (int r = 0; r < nsub; ++r) t = fmaxf(t, red[r * L + tid]);
+        smax[tid] = t;
+    }
+    __syncthreads();
+    float e = 0.f;
+    for (int n = sub; n < HW; n += nsub) e += __expf(lg[(size_t)n * L + l_of] - smax[l_of]);
+    red[tid] = e;
+    __syncthreads();
+    if (tid < L) {
+        float t = 0.f;
+        for (int r = 0; r < nsub; ++r) t += red[r * L + tid];
+        sinv[tid] = 1.f / t;
+        stats[((size_t)s * L + tid) * 2 + 0] = smax[tid];
+        stats[((size_t)s * L + tid) * 2 + 1] = 1.f / t;
+    }
+    __syncthreads();
+    // pooled[l][c] = sum_n p[n][l] x[n][c]; thread (l, c) for L*32 <= 256
+    if (tid < L * D) {
+        const int l = tid / D, c = tid % D;
+        const T* xs = x + (size_t)s * HW * D;
+        float acc = 0.f;
+        const float mx = smax[l], iv = sinv[l];
+        for (int n = 0; n < HW; ++n) acc += __expf(lg[(size_t)n * L + l] - mx) * ldf(xs + (size_t)n * D + c);
+        acc *= iv;
+        pooled[((size_t)s * L + l) * D + c] = acc;
+        const int b = s % B, stream = s / B;
+        const int j = stream * L + l;
+        stf(tok_cat + ((size_t)b * 2 * L + j) * D + c, acc + (pos ? pos[j * D + c] : 0.f));
+    }
+}
+
+// per pixel: dlogit and the tokenizer's contribution to dx (accumulated into dx in place)
+template <typename T, int L>
+__global__ void tok_bwd_kernel(const T* __restrict__ x, const float* __restrict__ logits,
+                               const float* __restrict__ stats, const float* __restrict__ pooled,
+                               const T* __restrict__ dtok_cat, const float* __restrict__ wa, int HW, int B,
+                               T* __restrict__ dx, float* __restrict__ dlogits) {
+    __shared__ float sdt[L * D], sw[L * D], sdot[L], smx[L], siv[L];
+    const int s = blockIdx.y;
+    const int b = s % B, stream = s / B;
+    for (int i = threadIdx.x; i < L * D; i += blockDim.x) {
+        sdt[i] = ldf(dtok_cat + ((size_t)b * 2 * L + stream * L) * D + i);
+        sw[i] = wa[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < L) {
+        float t = 0.f;
+        for (int c = 0; c < D; ++c) t += sdt[threadIdx.x * D + c] * pooled[((size_t)s * L + threadIdx.x) * D + c];
+        sdot[threadIdx.x] = t;
+        smx[threadIdx.x] = stats[((size_t)s * L + threadIdx.x) * 2];
+        siv[threadIdx.x] = stats[((size_t)s * L + threadIdx.x) * 2 + 1];
+    }
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= HW) return;
+    const size_t row = (size_t)s * HW + n;
+    float xv[D];
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        float v[4];
+        ld4(x + row * D + c, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[c + j] = v[j];
+    }
+    float pr[L], dl[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        pr[l] = __expf(logits[row * L + l] - smx[l]) * siv[l];
+        float dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) dp += sdt[l * D + c] * xv[c];
+        dl[l] = pr[l] * (dp - sdot[l]);
+        dlogits[row * L + l] = dl[l];
+    }
+#pragma unroll
+    for (int c = 0; c < D; c += 4) {
+        float g[4];
+        ld4(dx + row * D + c, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int l = 0; l < L; ++l) t += pr[l] * sdt[l * D + c + j] + dl[l] * sw[l * D + c + j];
+            g[j] += t;
+        }
+        st4(dx + row * D + c, g);
+    }
+}
+
+// partial dWa[l][c] over a chunk of pixel rows: thread (l, c)
+template <typename T, int L>
+__global__ void tok_dwa_kernel(const T* __restrict__ x, const float* __restrict__ dlogits, long P, long chunk,
+                               float* __restrict__ partial) {
+    const int tid = threadIdx.x;
+    if (tid >= L * D) return;
+    const int l = tid / D, c = tid % D;
+    const long p0 = (long)blockIdx.x * chunk, p1 = (p0 + chunk < P) ? p0 + chunk : P;
+    float acc = 0.f;
+    for (long p = p0; p < p1; ++p) acc += dlogits[p * L + l] * ldf(x + p * D + c);
+    partial[(size_t)blockIdx.x * L * D + tid] = acc;
+}
+
+// dpos[j][c] (+)= sum_b dtok_cat[b][j][c]
+template <typename T>
+__global__ void tok_dpos_kernel(const T* __restrict__ dtok_cat, int B, int n, float* __restrict__ dpos, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += ldf(dtok_cat + (size_t)b * n + i);
+    if (accumulate) dpos[i] += s; else dpos[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// cross-attention operand preparation (per image)
+// ------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const void* tok;        // token rows, T
+    long tok_bstride, tok_sstride;   // elements between batch items / streams
+    int B, S, L, heads, dh, HLP;
+    float scale, eps;
+    const float *ln_g, *ln_b, *wq, *wk, *wv, *wo;
+    float *mn, *mstats, *k, *v;      // saved fp32: [S][L][32], [S][L][2], [S][L][inner] x2
+    void *kq, *kqT, *vo, *voT;       // packed T: [S][HLP][32], [S][32][HLP], [S][HLP][32], [S][32][HLP]
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void xattn_prep_kernel(PrepArgs a) {
+    extern __shared__ float sm[];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int L = a.L, inner = a.heads * a.dh, HL = a.heads * L;
+    float* smn = sm;                    // [L][32]
+    float* sk = smn + L * D;            // [L][inner]
+    float* sv = sk + L * inner;         // [L][inner]
+    const T* m = reinterpret_cast<const T*>(a.tok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
+    // LayerNorm of the L token rows (shared LN of PreNorm2, help_funcs.py:48-49)
+    if (tid < L) {
+        float mu = 0.f;
+        for (int c = 0; c < D; ++c) mu += ldf(m + tid * D + c);
+        mu *= 1.f / D;
+        float q = 0.f;
+        for (int c = 0; c < D; ++c) { const float d = ldf(m + tid * D + c) - mu; q += d * d; }
+        const float rstd = rsqrtf(q * (1.f / D) + a.eps);
+        a.mstats[((size_t)s * L + tid) * 2] = mu;
+        a.mstats[((size_t)s * L + tid) * 2 + 1] = rstd;
+        for (int c = 0; c < D; ++c) {
+            const float v = (ldf(m + tid * D + c) - mu) * rstd * a.ln_g[c] + a.ln_b[c];
+            smn[tid * D + c] = v;
+            a.mn[((size_t)s * L + tid) * D + c] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < L * inner; i += 256) {
+        const int l = i / inner, hd = i % inner;
+        float kk = 0.f, vv = 0.f;
+        for (int c = 0; c < D; ++c) {
+            const float x = smn[l * D + c];
+            kk += a.wk[hd * D + c] * x;
+            vv += a.wv[hd * D + c] * x;
+        }
+        sk[i] = kk; sv[i] = vv;
+        a.k[(size_t)s * L * inner + i] = kk;
+        a.v[(size_t)s * L * inner + i] = vv;
+    }
+    __syncthreads();
+    T* kq = reinterpret_cast<T*>(a.kq) + (size_t)s * a.HLP * D;
+    T* kqT = reinterpret_cast<T*>(a.kqT) + (size_t)s * a.HLP * D;
+    T* vo = reinterpret_cast<T*>(a.vo) + (size_t)s * a.HLP * D;
+    T* voT = reinterpret_cast<T*>(a.voT) + (size_t)s * a.HLP * D;
+    for (int i = tid; i < a.HLP * D; i += 256) {
+        const int hl = i / D, c = i % D;
+        float q = 0.f, o = 0.f;
+        if (hl < HL) {
+            const int h = hl / L, l = hl % L;
+            for (int d = 0; d < a.dh; ++d) {
+                const int hd = h * a.dh + d;
+                q += a.wq[hd * D + c] * sk[l * inner + hd];
+                o += a.wo[c * inner + hd] * sv[l * inner + hd];
+            }
+            q *= a.scale;
+        }
+        stf(kq + hl * D + c, q);
+        stf(kqT + c * a.HLP + hl, q);
+        stf(vo + hl * D + c, o);
+        stf(voT + c * a.HLP + hl, o);
+    }
+}
+
+struct PrepBwdArgs {
+    long tok_bstride, tok_sstride;
+    int B, S, L, heads, dh, HLP;
+    float scale;
+    const void* tok;                 // T, forward token rows (for the LN backward)
+    void* dtok;                      // T, accumulated in place (same addressing as tok)
+    const float *ln_g, *wq, *wk, *wv, *wo;
+    const float *mn, *mstats;
+    const float *dkq, *dvoT;         // [S][HLP][32], [S][32][HLP] fp32 (per-image weight gradients)
+    float *dk, *dv;                  // out [S][L][inner]
+    float* ln_partial;               // out [S][2][32]  (dgamma, dbeta) contributions
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
+    extern __shared__ float sm[];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int L = a.L, inner = a.heads * a.dh;
+    float* sdk = sm;                 // [L][inner]
+    float* sdv = sdk + L * inner;    // [L][inner]
+    float* sdmn = sdv + L * inner;   // [L][32]
+    const float* dkq = a.dkq + (size_t)s * a.HLP * D;
+    const float* dvoT = a.dvoT + (size_t)s * a.HLP * D;
+    for (int i = tid; i < L * inner; i += 256) {
+        const int l = i / inner, hd = i % inner, h = hd / a.dh, hl = h * L + l;
+        float gk = 0.f, gv = 0.f;
+        for (int c = 0; c < D; ++c) {
+            gk += dkq[hl * D + c] * a.wq[hd * D + c];
+            gv += dvoT[c * a.HLP + hl] * a.wo[c * inner + hd];
+        }
+        gk *= a.scale;
+        sdk[i] = gk; sdv[i] = gv;
+        a.dk[(size_t)s * L * inner + i] = gk;
+        a.dv[(size_t)s * L * inner + i] = gv;
+    }
+    __syncthreads();
+    for (int i = tid; i < L * D; i += 256) {
+        const int l = i / D, c = i % D;
+        float g = 0.f;
+        for (int hd = 0; hd < inner; ++hd) g += sdk[l * inner + hd] * a.wk[hd * D + c] + sdv[l * inner + hd] * a.wv[hd * D + c];
+        sdmn[i] = g;
+    }
+    __syncthreads();
+    // LayerNorm backward on the L rows; accumulate into dtok; per-image dgamma/dbeta
+    const T* m = reinterpret_cast<const T*>(a.tok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
+    T* dm = reinterpret_cast<T*>(a.dtok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
+    if (tid < L) {
+        const float mu = a.mstats[((size_t)s * L + tid) * 2], rstd = a.mstats[((size_t)s * L + tid) * 2 + 1];
+        float sa = 0.f, sb = 0.f;
+        for (int c = 0; c < D; ++c) {
+            const float xh = (ldf(m + tid * D + c) - mu) * rstd, gh = sdmn[tid * D + c] * a.ln_g[c];
+            sa += gh; sb += gh * xh;
+        }
+        for (int c = 0; c < D; ++c) {
+            const float xh = (ldf(m + tid * D + c) - mu) * rstd, gh = sdmn[tid * D + c] * a.ln_g[c];
+            const float g = rstd * (gh - (sa + xh * sb) * (1.f / D));
+            stf(dm + tid * D + c, ldf(dm + tid * D + c) + g);
+        }
+    }
+    if (tid >= 64 && tid < 64 + 2 * D) {
+        const int which = (tid - 64) / D, c = (tid - 64) % D;
+        float t = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const float mu = a.mstats[((size_t)s * L + l) * 2], rstd = a.mstats[((size_t)s * L + l) * 2 + 1];
+            const float xh = (ldf(m + l * D + c) - mu) * rstd;
+            t += which == 0 ? sdmn[l * D + c] * xh : sdmn[l * D + c];
+        }
+        a.ln_partial[((size_t)s * 2 + which) * D + c] = t;
+    }
+}
+
+// weight gradients of to_q / to_k / to_v / to_out: one thread per element, loop over images
+struct PrepWgArgs {
+    int S, L, heads, dh, HLP;
+    float scale;
+    const float *mn, *k, *v, *dk, *dv, *dkq, *dvoT;
+    float *dwq, *dwk, *dwv, *dwo;
+    int accumulate;
+};
+__global__ void xattn_prep_wgrad_kernel(PrepWgArgs a) {
+    const int inner = a.heads * a.dh, L = a.L;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= inner * D) return;
+    const int which = blockIdx.y;
+    float acc = 0.f;
+    if (which < 3) {
+        const int hd = i / D, c = i % D, h = hd / a.dh;
+        for (int s = 0; s < a.S; ++s)
+            for (int l = 0; l < L; ++l) {
+                const size_t r = ((size_t)s * L + l);
+                if (which == 0) acc += a.dkq[((size_t)s * a.HLP + h * L + l) * D + c] * a.k[r * inner + hd];
+                else if (which == 1) acc += a.dk[r * inner + hd] * a.mn[r * D + c];
+                else acc += a.dv[r * inner + hd] * a.mn[r * D + c];
+            }
+        if (which == 0) acc *= a.scale;
+        float* out = which == 0 ? a.dwq : (which == 1 ? a.dwk : a.dwv);
+        if (a.accumulate) out[i] += acc; else out[i] = acc;
+    } else {
+        const int c = i / inner, hd = i % inner, h = hd / a.dh;     // to_out weight is [32][inner]
+        for (int s = 0; s < a.S; ++s)
+            for (int l = 0; l < L; ++l)
+                acc += a.dvoT[((size_t)s * D + c) * a.HLP + h * L + l] * a.v[((size_t)s * L + l) * inner + hd];
+        if (a.accumulate) a.dwo[i] += acc; else a.dwo[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// grouped softmax over the L keys of each head: x, y [rows][HLP]; columns >= heads*L are zero
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void softmax_groups_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int heads, int L,
+                                          int HLP) {
+    const int gpr = HLP / L;     // groups per row incl. padding groups
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * gpr) return;
+    const long r = i / gpr;
+    const int h = (int)(i % gpr);
+    const T* xp = x + r * HLP + h * L;
+    T* yp = y + r * HLP + h * L;
+    if (h >= heads) { for (int l = 0; l < L; ++l) stf(yp + l, 0.f); return; }
+    float v[16], m = -INFINITY, s = 0.f;
+    for (int l = 0; l < L; ++l) { v[l] = ldf(xp + l); m = fmaxf(m, v[l]); }
+    for (int l = 0; l < L; ++l) { v[l] = __expf(v[l] - m); s += v[l]; }
+    const float inv = 1.f / s;
+    for (int l = 0; l < L; ++l) stf(yp + l, v[l] * inv);
+}
+template <typename T>
+__global__ void softmax_groups_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx,
+                                          long rows, int heads, int L, int HLP) {
+    const int gpr = HLP / L;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * gpr) return;
+    const long r = i / gpr;
+    const int h = (int)(i % gpr);
+    const size_t o = r * HLP + h * L;
+    if (h >= heads) { for (int l = 0; l < L; ++l) stf(dx + o + l, 0.f); return; }
+    float p[16], g[16], dot = 0.f;
+    for (int l = 0; l < L; ++l) { p[l] = ldf(y + o + l); g[l] = ldf(dy + o + l); dot += p[l] * g[l]; }
+    for (int l = 0; l < L; ++l) stf(dx + o + l, p[l] * (g[l] - dot));
+}
+
+// ------------------------------------------------------------------------------------------
+// token self-attention core (encoder): qkv [B*n][3*inner] -> o [B*n][inner], n <= 16 tokens
+// one 64-thread workgroup per (batch item, head)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void self_attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
+                                                           float* __restrict__ attn /*[B][heads][n][n]*/, int n,
+                                                           int heads, int dh, float scale) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x, inner = heads * dh;
+    float* q = sm;
+    float* k = q + n * dh;
+    float* v = k + n * dh;
+    float* a = v + n * dh;     // [n][n]
+    for (int i = tid; i < n * dh; i += 64) {
+        const int t = i / dh, d = i % dh;
+        const T* row = qkv + ((size_t)b * n + t) * 3 * inner + h * dh + d;
+        q[i] = ldf(row); k[i] = ldf(row + inner); v[i] = ldf(row + 2 * inner);
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 64) {
+        const int i = e / n, j = e % n;
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s += q[i * dh + d] * k[j * dh + d];
+        a[e] = s * scale;
+    }
+    __syncthreads();
+    if (tid < n) {
+        float m = -INFINITY, s = 0.f;
+        for (int j = 0; j < n; ++j) m = fmaxf(m, a[tid * n + j]);
+        for (int j = 0; j < n; ++j) { const float e = __expf(a[tid * n + j] - m); a[tid * n + j] = e; s += e; }
+        const float inv = 1.f / s;
+        for (int j = 0; j < n; ++j) {
+            a[tid * n + j] *= inv;
+            attn[(((size_t)b * heads + h) * n + tid) * n + j] = a[tid * n + j];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n * dh; i += 64) {
+        const int t = i / dh, d = i % dh;
+        float s = 0.f;
+        for (int j = 0; j < n; ++j) s += a[t * n + j] * v[j * dh + d];
+        stf(o + ((size_t)b * n + t) * inner + h * dh + d, s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void self_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ attn,
+                                                           const T* __restrict__ dout, T* __restrict__ dqkv, int n,
+                                                           int heads, int dh, float scale) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x, inner = heads * dh;
+    float* q = sm;
+    float* k = q + n * dh;
+    float* v = k + n * dh;
+    float* go = v + n * dh;
+    float* a = go + n * dh;    // [n][n]
+    float* ds = a + n * n;     // [n][n]
+    for (int i = tid; i < n * dh; i += 64) {
+        const int t = i / dh, d = i % dh;
+        const T* row = qkv + ((size_t)b * n + t) * 3 * inner + h * dh + d;
+        q[i] = ldf(row); k[i] = ldf(row + inner); v[i] = ldf(row + 2 * inner);
+        go[i] = ldf(dout + ((size_t)b * n + t) * inner + h * dh + d);
+    }
+    for (int e = tid; e < n * n; e += 64) a[e] = attn[((size_t)b * heads + h) * n * n + e];
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 64) {
+        const int i = e / n, j = e % n;
+        float s = 0.f;
+        for (int d = 0; d < dh; ++d) s += go[i * dh + d] * v[j * dh + d];
+        ds[e] = s;      // dA
+    }
+    __syncthreads();
+    if (tid < n) {
+        float dot = 0.f;
+        for (int j = 0; j < n; ++j) dot += a[tid * n + j] * ds[tid * n + j];
+        for (int j = 0; j < n; ++j) ds[tid * n + j] = a[tid * n + j] * (ds[tid * n + j] - dot) * scale;
+    }
+    __syncthreads();
+    for (int i = tid; i < n * dh; i += 64) {
+        const int t = i / dh, d = i % dh;
+        float gq = 0.f, gk = 0.f, gv = 0.f;
+        for (int j = 0; j < n; ++j) {
+            gq += ds[t * n + j] * k[j * dh + d];
+            gk += ds[j * n + t] * q[j * dh + d];
+            gv += a[j * n + t] * go[j * dh + d];
+        }
+        T* row = dqkv + ((size_t)b * n + t) * 3 * inner + h * dh + d;
+        stf(row, gq); stf(row + inner, gk); stf(row + 2 * inner, gv);
+    }
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+extern "C" int dh_reduce_partials(const float* partial, long nt, long n, float scale, float* out, int accumulate,
+                                  void* stream);
+
+// workspace-free; logits [S*HW][L] fp32, stats [S][L][2], pooled [S][L][32] are saved for backward
+extern "C" int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const float* pos, int S, int B, int HW,
+                                int L, float* logits, float* stats, float* pooled, void* tok_cat, void* stream) {
+    DH_REQUIRE(L == 4 || L == 8, "tokenizer: token_len must be 4 or 8, got %d", L);
+    DH_REQUIRE(S % B == 0 && S / B <= 2, "tokenizer: S=%d must be B or 2B (B=%d)", S, B);
+    const long P = (long)S * HW;
+#define TOKF(TT, LL)                                                                                              \
+    do {                                                                                                          \
+        hipLaunchKernelGGL((tok_logits_kernel<TT, LL>), dim3(dh_cdiv(P, 256)), dim3(256), 0, ST(stream),          \
+                           (const TT*)x, wa, logits, P);                                                          \
+        hipLaunchKernelGGL((tok_pool_kernel<TT, LL>), dim3(S), dim3(256), 0, ST(stream), (const TT*)x, logits, pos, \
+                           HW, B, stats, pooled, (TT*)tok_cat);                                                   \
+    } while (0)
+    if (dtype == DH_DTYPE_BF16) { if (L == 4) TOKF(bf16, 4); else TOKF(bf16, 8); }
+    else { if (L == 4) TOKF(float, 4); else TOKF(float, 8); }
+#undef TOKF
+    DH_CHECK_LAUNCH("tokenizer_fwd");
+    return 0;
+}
+
+// workspace: dlogits [S*HW][L] floats + partial [nblk][L*32] floats, nblk = ceil(S*HW / 2048)
+extern "C" long dh_tokenizer_bwd_workspace_size(int S, int HW, int L) {
+    const long P = (long)S * HW;
+    return (P * L + (long)dh_cdiv(P, 2048) * L * 32) * 4;
+}
+extern "C" int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S, int B, int HW, int L,
+                                const float* logits, const float* stats, const float* pooled, const void* dtok_cat,
+                                void* dx_accum, float* dwa, float* dpos, int accumulate, void* workspace,
+                                void* stream) {
+    DH_REQUIRE(L == 4 || L == 8, "tokenizer_bwd: token_len must be 4 or 8, got %d", L);
+    const long P = (long)S * HW;
+    float* dlogits = reinterpret_cast<float*>(workspace);
+    float* partial = dlogits + P * L;
+    const int nblk = dh_cdiv(P, 2048);
+#define TOKB(TT, LL)                                                                                              \
+    do {                                                                                                          \
+        hipLaunchKernelGGL((tok_bwd_kernel<TT, LL>), dim3(dh_cdiv(HW, 128), S), dim3(128), 0, ST(stream),         \
+                           (const TT*)x, logits, stats, pooled, (const TT*)dtok_cat, wa, HW, B, (TT*)dx_accum,    \
+                           dlogits);                                                                              \
+        hipLaunchKernelGGL((tok_dwa_kernel<TT, LL>), dim3(nblk), dim3(256), 0, ST(stream), (const TT*)x, dlogits, \
+                           P, 2048L, partial);                                                                    \
+        if (dpos)                                                                                                 \
+            hipLaunchKernelGGL(tok_dpos_kernel<TT>, dim3(dh_cdiv(2 * LL * 32, 64)), dim3(64), 0, ST(stream),      \
+                               (const TT*)dtok_cat, B, 2 * LL * 32, dpos, accumulate);                            \
+    } while (0)
+    if (dtype == DH_DTYPE_BF16) { if (L == 4) TOKB(bf16, 4); else TOKB(bf16, 8); }
+    else { if (L == 4) TOKB(float, 4); else TOKB(float, 8); }
+#undef TOKB
+    DH_CHECK_LAUNCH("tokenizer_bwd");
+    return dh_reduce_partials(partial, nblk, (long)L * 32, 1.0f, dwa, accumulate, stream);
+}
+
+extern "C" int dh_xattn_prep_fwd(int dtype, const void* tok, long tok_bstride, long tok_sstride, int B, int S, int L,
+                                 int heads, int dim_head, int HLP, float scale, float eps, const float* ln_g,
+                                 const float* ln_b, const float* wq, const float* wk, const float* wv,
+                                 const float* wo, float* mn, float* mstats, float* k, float* v, void* kq, void* kqT,
+                                 void* vo, void* voT, void* stream) {
+    DH_REQUIRE(heads * L <= HLP && HLP % L == 0, "xattn_prep: heads*L=%d exceeds HLP=%d", heads * L, HLP);
+    PrepArgs a;
+    a.tok = tok; a.tok_bstride = tok_bstride; a.tok_sstride = tok_sstride; a.B = B; a.S = S; a.L = L;
+    a.heads = heads; a.dh = dim_head; a.HLP = HLP; a.scale = scale; a.eps = eps; a.ln_g = ln_g; a.ln_b = ln_b;
+    a.wq = wq; a.wk = wk; a.wv = wv; a.wo = wo; a.mn = mn; a.mstats = mstats; a.k = k; a.v = v;
+    a.kq = kq; a.kqT = kqT; a.vo = vo; a.voT = voT;
+    const size_t lds = (size_t)(L * 32 + 2 * L * heads * dim_head) * 4;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_kernel<bf16>, dim3(S), dim3(256), lds, ST(stream), a);
+    else hipLaunchKernelGGL(xattn_prep_kernel<float>, dim3(S), dim3(256), lds, ST(stream), a);
+    DH_CHECK_LAUNCH("xattn_prep_fwd");
+    return 0;
+}
+
+// workspace: ln_partial [S][2][32] floats
+extern "C" int dh_xattn_prep_bwd(int dtype, const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride,
+                                 int B, int S, int L, int heads, int dim_head, int HLP, float scale,
+                                 const float* ln_g, const float* wq, const float* wk, const float* wv,
+                                 const float* wo, const float* mn, const float* mstats, const float* k,
+                                 const float* v, const float* dkq, const float* dvoT, float* dk, float* dv,
+                                 float* dln_g, float* dln_b, float* dwq, float* dwk, float* dwv, float* dwo,
+                                 int accumulate, void* workspace, void* stream) {
+    PrepBwdArgs a;
+    a.tok_bstride = tok_bstride; a.tok_sstride = tok_sstride; a.B = B; a.S = S; a.L = L; a.heads = heads;
+    a.dh = dim_head; a.HLP = HLP; a.scale = scale; a.tok = tok; a.dtok = dtok_accum; a.ln_g = ln_g; a.wq = wq;
+    a.wk = wk; a.wv = wv; a.wo = wo; a.mn = mn; a.mstats = mstats; a.dkq = dkq; a.dvoT = dvoT; a.dk = dk; a.dv = dv;
+    a.ln_partial = reinterpret_cast<float*>(workspace);
+    const int inner = heads * dim_head;
+    const size_t lds = (size_t)(2 * L * inner + L * 32) * 4;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_bwd_kernel<bf16>, dim3(S), dim3(256), lds, ST(stream), a);
+    else hipLaunchKernelGGL(xattn_prep_bwd_kernel<float>, dim3(S), dim3(256), lds, ST(stream), a);
+    PrepWgArgs w;
+    w.S = S; w.L = L; w.heads = heads; w.dh = dim_head; w.HLP = HLP; w.scale = scale; w.mn = mn; w.k = k; w.v = v;
+    w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;
+    w.accumulate = accumulate;
+    hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(dh_cdiv(inner * 32, 256), 4), dim3(256), 0, ST(stream), w);
+    DH_CHECK_LAUNCH("xattn_prep_bwd");
+    // ln_partial rows are [dgamma(32) | dbeta(32)] per image: always accumulated (the pixel-side
+    // LayerNorm backward of the same shared LN has already written its part)
+    float* part = reinterpret_cast<float*>(workspace);
+    float* tmp = part + (size_t)S * 64;
+    int rc = dh_reduce_partials(part, S, 64, 1.0f, tmp, 0, stream);
+    if (rc) return rc;
+    rc = dh_reduce_partials(tmp, 1, 32, 1.0f, dln_g, 1, stream);
+    if (rc) return rc;
+    return dh_reduce_partials(tmp + 32, 1, 32, 1.0f, dln_b, 1, stream);
+}
+extern "C" long dh_xattn_prep_bwd_workspace_size(int S) { return ((long)S * 64 + 64) * 4; }
+
+extern "C" int dh_softmax_groups_fwd(int dtype, const void* x, void* y, long rows, int heads, int L, int HLP,
+                                     void* stream) {
+    DH_REQUIRE(L <= 16 && HLP % L == 0, "softmax_groups: L=%d HLP=%d", L, HLP);
+    const long n = rows * (HLP / L);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(softmax_groups_fwd_kernel<bf16>, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, rows, heads, L, HLP);
+    else hipLaunchKernelGGL(softmax_groups_fwd_kernel<float>, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, rows, heads, L, HLP);
+    DH_CHECK_LAUNCH("softmax_groups_fwd");
+    return 0;
+}
+extern "C" int dh_softmax_groups_bwd(int dtype, const void* y, const void* dy, void* dx, long rows, int heads, int L,
+                                     int HLP, void* stream) {
+    DH_REQUIRE(L <= 16 && HLP % L == 0, "softmax_groups: L=%d HLP=%d", L, HLP);
+    const long n = rows * (HLP / L);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(softmax_groups_bwd_kernel<bf16>, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), (const bf16*)y, (const bf16*)dy, (bf16*)dx, rows, heads, L, HLP);
+    else hipLaunchKernelGGL(softmax_groups_bwd_kernel<float>, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), (const float*)y, (const float*)dy, (float*)dx, rows, heads, L, HLP);
+    DH_CHECK_LAUNCH("softmax_groups_bwd");
+    return 0;
+}
+
+extern "C" int dh_self_attn_fwd(int dtype, const void* qkv, void* o, float* attn, int B, int n, int heads,
+                                int dim_head, float scale, void* stream) {
+    DH_REQUIRE(n <= 16, "self_attn: at most 16 tokens, got %d", n);
+    const size_t lds = (size_t)(3 * n * dim_head + n * n) * 4;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(self_attn_fwd_kernel<bf16>, dim3(B * heads), dim3(64), lds, ST(stream), (const bf16*)qkv, (bf16*)o, attn, n, heads, dim_head, scale);
+    else hipLaunchKernelGGL(self_attn_fwd_kernel<float>, dim3(B * heads), dim3(64), lds, ST(stream), (const float*)qkv, (float*)o, attn, n, heads, dim_head, scale);
+    DH_CHECK_LAUNCH("self_attn_fwd");
+    return 0;
+}
+extern "C" int dh_self_attn_bwd(int dtype, const void* qkv, const float* attn, const void* dout, void* dqkv, int B,
+                                int n, int heads, int dim_head, float scale, void* stream) {
+    DH_REQUIRE(n <= 16, "self_attn: at most 16 tokens, got %d", n);
+    const size_t lds = (size_t)(4 * n * dim_head + 2 * n * n) * 4;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(self_attn_bwd_kernel<bf16>, dim3(B * heads), dim3(64), lds, ST(stream), (const bf16*)qkv, attn, (const bf16*)dout, (bf16*)dqkv, n, heads, dim_head, scale);
+    else hipLaunchKernelGGL(self_attn_bwd_kernel<float>, dim3(B * heads), dim3(64), lds, ST(stream), (const float*)qkv, attn, (const float*)dout, (float*)dqkv, n, heads, dim_head, scale);
+    DH_CHECK_LAUNCH("self_attn_bwd");
+    return 0;
+}

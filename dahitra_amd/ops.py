@@ -1,0 +1,485 @@
+"""Thin torch-tensor wrappers over the C ABI (include/dahitra_hip.h).
+
+torch is used for device memory and the current HIP stream only; every arithmetic result below is
+produced by a kernel of libdahitra_hip.so.  All activations are NHWC tensors of dtype float32
+(parity mode) or bfloat16 (throughput mode)."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+_vp = ctypes.c_void_p
+_ci = ctypes.c_int
+_cl = ctypes.c_long
+_cf = ctypes.c_float
+_cd = ctypes.c_double
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError("dahitra_amd: unsupported activation dtype %s" % t.dtype)
+
+
+def chunk_channels(dtype):
+    """channels per 64-byte MFMA K-chunk: the granularity of Cin for dh_conv2d_fwd"""
+    return 32 if dtype == torch.bfloat16 else 16
+
+
+def P(t):
+    if t is None:
+        return _vp(0)
+    assert t.is_cuda and t.is_contiguous(), "dahitra_amd ops need contiguous device tensors"
+    return _vp(t.data_ptr())
+
+
+def S():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+_ws = {}
+
+
+def workspace(nbytes, device):
+    key = str(device)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def _call(name, *args):
+    L = _lib.lib()
+    _lib.check(getattr(L, name)(*args), name)
+
+
+def cdiv(a, b):
+    return (a + b - 1) // b
+
+
+def pad16(c):
+    return cdiv(c, 16) * 16
+
+
+# ---- weights -------------------------------------------------------------------------------------
+def pack_weight(w, dtype, want_dgrad=True, dgrad_inner=0):
+    """w: OIHW (or [O, I]) fp32 master.  Returns (fwd [taps, OPad, I], dgrad [taps, IPad, OK] | None)."""
+    if w.dim() == 2:
+        O, I = w.shape
+        ks = 1
+    else:
+        O, I, ks, _ = w.shape
+    OPad, IPad = pad16(O), pad16(I)
+    OK = max(O, dgrad_inner)
+    fwd = torch.empty(ks * ks, OPad, I, dtype=dtype, device=w.device)
+    dg = torch.empty(ks * ks, IPad, OK, dtype=dtype, device=w.device) if want_dgrad else None
+    _call("dh_pack_weight", _ci(_DT[dtype]), P(w), _ci(O), _ci(I), _ci(ks), _ci(OPad), P(fwd), _ci(IPad), _ci(OK),
+          P(dg), S())
+    return fwd, dg
+
+
+# ---- convolution / linear ------------------------------------------------------------------------
+def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT_NONE, want_stats=False,
+           want_preact=False, npix_valid=0, w_image_stride=0, out_hw=None):
+    N, H, W, Cin = x.shape
+    if out_hw is None:
+        OH = (H + 2 * pad - ks) // stride + 1
+        OW = (W + 2 * pad - ks) // stride + 1
+    else:
+        OH, OW = out_hw
+    cpad = wp.shape[-2]
+    y = torch.empty(N, OH, OW, cout, dtype=x.dtype, device=x.device)
+    pre = torch.empty_like(y) if want_preact else None
+    stats = None
+    if want_stats:
+        nt = _lib.lib().dh_conv2d_fwd_num_tiles(N, OH, OW)
+        stats = torch.empty(nt, 2, cpad, dtype=torch.float32, device=x.device)
+    _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
+          _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
+          _cl(w_image_stride), P(pre), S())
+    out = [y]
+    if want_stats:
+        out.append(stats)
+    if want_preact:
+        out.append(pre)
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def rows_view(x2d):
+    """[rows, C] -> the [1, ceil(rows/16), 16, C] image view used for linear layers (no copy when
+    rows % 16 == 0; otherwise the tail rows are masked through npix_valid)."""
+    rows, C = x2d.shape
+    return rows, cdiv(rows, 16), C
+
+
+def linear(x2d, wp, cout, bias=None, residual=None, act=ACT_NONE, want_preact=False, images=1, w_image_stride=0):
+    """x2d [rows, Cin] (rows = images * rows_per_image).  Returns [rows, cout]."""
+    rows, Cin = x2d.shape
+    rpi = rows // images
+    Hh = cdiv(rpi, 16)
+    cpad = wp.shape[-2]
+    y = torch.empty(rows, cout, dtype=x2d.dtype, device=x2d.device)
+    pre = torch.empty_like(y) if want_preact else None
+    _call("dh_conv2d_fwd", _ci(dt(x2d)), P(x2d), P(wp), P(y), P(bias), P(residual), _vp(0), _ci(images), _ci(Hh),
+          _ci(16), _ci(Cin), _ci(Hh), _ci(16), _ci(cout), _ci(cpad), _ci(1), _ci(1), _ci(0), _ci(act), _ci(rpi),
+          _cl(w_image_stride), P(pre), S())
+    # note: with rows_per_image % 16 != 0 the image stride used by the kernel (Hh*16 rows) would differ
+    # from rpi; callers guarantee rpi % 16 == 0 whenever images > 1.
+    assert images == 1 or rpi % 16 == 0
+    return (y, pre) if want_preact else y
+
+
+def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=True, cout_real=0):
+    """dw (OIHW fp32, or [N, Cout, Cin] when groups == N) (+)= weight gradient."""
+    N, H, W, Cin = x.shape
+    _, OH, OW, Cout = dy.shape
+    L = _lib.lib()
+    nbytes = L.dh_conv2d_wgrad_workspace_size(N, OH, OW, Cin, Cout, ks, groups)
+    ws = workspace(nbytes, x.device)
+    _call("dh_conv2d_wgrad", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W), _ci(Cin),
+          _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(groups), _ci(0), _ci(int(use_tr)),
+          _ci(cout_real), P(ws), S())
+
+
+def linear_wgrad(x2d, dy2d, dw, accumulate=False, images=1, per_image=False, use_tr=True):
+    rows, Cin = x2d.shape
+    Cout = dy2d.shape[1]
+    rpi = rows // images
+    Hh = cdiv(rpi, 16)
+    groups = images if per_image else 1
+    L = _lib.lib()
+    nbytes = L.dh_conv2d_wgrad_workspace_size(images, Hh, 16, Cin, Cout, 1, groups)
+    ws = workspace(nbytes, x2d.device)
+    assert images == 1 or rpi % 16 == 0
+    _call("dh_conv2d_wgrad", _ci(dt(x2d)), P(x2d), P(dy2d), P(dw), _ci(int(accumulate)), _ci(images), _ci(Hh), _ci(16),
+          _ci(Cin), _ci(Hh), _ci(16), _ci(Cout), _ci(1), _ci(1), _ci(0), _ci(groups), _ci(rpi), _ci(int(use_tr)),
+          _ci(0), P(ws), S())
+
+
+def zero_insert2(dy, H, W):
+    N, OH, OW, C = dy.shape
+    z = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)
+    _call("dh_zero_insert2", _ci(dt(dy)), P(dy), P(z), _ci(N), _ci(OH), _ci(OW), _ci(H), _ci(W), _ci(C), S())
+    return z
+
+
+# ---- stem ----------------------------------------------------------------------------------------
+def stem_space_to_depth(x_nchw, dtype):
+    N, C, H, W = x_nchw.shape
+    assert C == 3
+    cp = chunk_channels(dtype)
+    y = torch.empty(N, H // 2, W // 2, cp, dtype=dtype, device=x_nchw.device)
+    _call("dh_stem_space_to_depth", _ci(_DT[dtype]), P(x_nchw), P(y), _ci(N), _ci(H), _ci(W), _ci(cp), S())
+    return y
+
+
+def stem_pack_weight(w, dtype):
+    O = w.shape[0]
+    cp = chunk_channels(dtype)
+    out = torch.empty(16, O, cp, dtype=dtype, device=w.device)
+    _call("dh_stem_pack_weight", _ci(_DT[dtype]), P(w), P(out), _ci(O), _ci(cp), S())
+    return out
+
+
+def stem_wgrad(x_s2d, dy, dw, accumulate=False, use_tr=True):
+    N, H2, W2, cp = x_s2d.shape
+    O = dy.shape[-1]
+    dw2 = torch.empty(O, cp, 4, 4, dtype=torch.float32, device=dy.device)
+    conv2d_wgrad(x_s2d, dy, dw2, ks=4, stride=1, pad=2, use_tr=use_tr)
+    _call("dh_stem_unpack_grad", P(dw2), P(dw), _ci(O), _ci(cp), _ci(int(accumulate)), S())
+
+
+# ---- normalisation -------------------------------------------------------------------------------
+def bn_finalize(stats, C, groups, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+    nt, _, cp = stats.shape
+    dev = stats.device
+    mean = torch.empty(groups, C, dtype=torch.float32, device=dev)
+    invstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    _call("dh_bn_finalize", P(stats), _ci(nt), _ci(cp), _ci(C), _ci(groups), _cd(float(count)), P(gamma), P(beta),
+          P(running_mean), P(running_var), _cf(momentum), _cf(eps), P(mean), P(invstd), P(scale), P(shift), S())
+    return mean, invstd, scale, shift
+
+
+def bn_eval_params(gamma, beta, rm, rv, eps=1e-5):
+    C = gamma.numel()
+    scale = torch.empty(1, C, dtype=torch.float32, device=gamma.device)
+    shift = torch.empty_like(scale)
+    _call("dh_bn_eval_params", P(gamma), P(beta), P(rm), P(rv), _cf(eps), _ci(C), P(scale), P(shift), S())
+    return scale, shift
+
+
+def bn_apply(x, scale, shift, groups=1, act=ACT_NONE, residual=None):
+    C = x.shape[-1]
+    npix = x.numel() // C
+    y = torch.empty_like(x)
+    _call("dh_bn_apply", _ci(dt(x)), P(x), P(residual), P(y), P(scale), P(shift), _cl(npix), _ci(C), _ci(groups),
+          _ci(act), S())
+    return y
+
+
+def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accumulate=False, want_dres=False):
+    C = x.shape[-1]
+    npix = x.numel() // C
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    L = _lib.lib()
+    ws = workspace(L.dh_bn_bwd_workspace_size(_cl(npix), C, groups), x.device)
+    _call("dh_bn_bwd", _ci(dt(x)), P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
+          _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(ws), S())
+    return (dx, dres) if want_dres else dx
+
+
+def layernorm(x2d, gamma, beta, eps=1e-5, want_stats=True):
+    rows, C = x2d.shape
+    y = torch.empty_like(x2d)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x2d.device) if want_stats else None
+    _call("dh_layernorm_fwd", _ci(dt(x2d)), P(x2d), P(gamma), P(beta), P(y), P(stats), _cl(rows), _ci(C), _cf(eps), S())
+    return (y, stats) if want_stats else y
+
+
+def layernorm_bwd(dy, x2d, stats, gamma, dgamma, dbeta, dx_add=None, accumulate=False):
+    rows, C = x2d.shape
+    dx = torch.empty_like(x2d)
+    L = _lib.lib()
+    ws = workspace(L.dh_layernorm_bwd_workspace_size(_cl(rows)), x2d.device)
+    _call("dh_layernorm_bwd", _ci(dt(x2d)), P(dy), P(x2d), P(stats), P(gamma), P(dx), P(dx_add), P(dgamma), P(dbeta),
+          _ci(int(accumulate)), _cl(rows), _ci(C), P(ws), S())
+    return dx
+
+
+# ---- pointwise -----------------------------------------------------------------------------------
+def nchw_to_nhwc(x, dtype, cpad=0):
+    N, C, H, W = x.shape
+    cp = max(C, cpad)
+    y = torch.empty(N, H, W, cp, dtype=dtype, device=x.device)
+    _call("dh_nchw_to_nhwc", _ci(_DT[dtype]), P(x), P(y), _ci(N), _ci(C), _cl(H * W), _ci(cp), S())
+    return y
+
+
+def nhwc_to_nchw(x):
+    N, H, W, C = x.shape
+    y = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
+    _call("dh_nhwc_to_nchw", _ci(dt(x)), P(x), P(y), _ci(N), _ci(C), _cl(H * W), S())
+    return y
+
+
+def copy_channels(src, sc0, dst, dc0, cn):
+    Cs, Cd = src.shape[-1], dst.shape[-1]
+    Pn = src.numel() // Cs
+    _call("dh_copy_channels", _ci(dt(src)), P(src), _ci(Cs), _ci(sc0), P(dst), _ci(Cd), _ci(dc0), _ci(cn), _cl(Pn), S())
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    _call("dh_add", _ci(dt(a)), P(a), P(b), P(y), _cl(a.numel()), S())
+    return y
+
+
+def add_pos(x, pos):
+    N, H, W, C = x.shape
+    y = torch.empty_like(x)
+    _call("dh_add_pos", _ci(dt(x)), P(x), P(pos), P(y), _ci(N), _cl(H * W), _ci(C), S())
+    return y
+
+
+def add_pos_bwd(dy, dpos, accumulate=False):
+    N, H, W, C = dy.shape
+    _call("dh_add_pos_bwd", _ci(dt(dy)), P(dy), P(dpos), _ci(N), _cl(H * W), _ci(C), _ci(int(accumulate)), S())
+
+
+def act_bwd(dy, ref, act):
+    dx = torch.empty_like(dy)
+    _call("dh_act_bwd", _ci(dt(dy)), P(dy), P(ref), P(dx), _cl(dy.numel()), _ci(act), S())
+    return dx
+
+
+def maxpool(x):
+    N, H, W, C = x.shape
+    y = torch.empty(N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C, dtype=x.dtype, device=x.device)
+    _call("dh_maxpool3x3s2_fwd", _ci(dt(x)), P(x), P(y), _ci(N), _ci(H), _ci(W), _ci(C), S())
+    return y
+
+
+def maxpool_bwd(x, dy):
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _call("dh_maxpool3x3s2_bwd", _ci(dt(x)), P(x), P(dy), P(dx), _ci(N), _ci(H), _ci(W), _ci(C), S())
+    return dx
+
+
+def upsample2(x):
+    N, H, W, C = x.shape
+    y = torch.empty(N, 2 * H, 2 * W, C, dtype=x.dtype, device=x.device)
+    _call("dh_upsample2_nearest_fwd", _ci(dt(x)), P(x), P(y), _ci(N), _ci(H), _ci(W), _ci(C), S())
+    return y
+
+
+def upsample2_bwd(dy):
+    N, H2, W2, C = dy.shape
+    dx = torch.empty(N, H2 // 2, W2 // 2, C, dtype=dy.dtype, device=dy.device)
+    _call("dh_upsample2_nearest_bwd", _ci(dt(dy)), P(dy), P(dx), _ci(N), _ci(H2 // 2), _ci(W2 // 2), _ci(C), S())
+    return dx
+
+
+def absdiff_upsample4(a, b):
+    N, H, W, C = a.shape
+    y = torch.empty(N, 4 * H, 4 * W, C, dtype=a.dtype, device=a.device)
+    _call("dh_absdiff_upsample4_fwd", _ci(dt(a)), P(a), P(b), P(y), _ci(N), _ci(H), _ci(W), _ci(C), S())
+    return y
+
+
+def absdiff_upsample4_bwd(a, b, dy):
+    N, H, W, C = a.shape
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    _call("dh_absdiff_upsample4_bwd", _ci(dt(a)), P(a), P(b), P(dy), P(da), P(db), _ci(N), _ci(H), _ci(W), _ci(C), S())
+    return da, db
+
+
+def absdiff(a, b):
+    y = torch.empty_like(a)
+    _call("dh_absdiff", _ci(dt(a)), P(a), P(b), P(y), _cl(a.numel()), S())
+    return y
+
+
+def absdiff_bwd(a, b, dy, da, db, accumulate=True):
+    _call("dh_absdiff_bwd", _ci(dt(a)), P(a), P(b), P(dy), P(da), P(db), _cl(a.numel()), _ci(int(accumulate)), S())
+
+
+def colsum(x2d, out, accumulate=False):
+    C = x2d.shape[-1]
+    Pn = x2d.numel() // C
+    ws = workspace(256 * C * 4 + 1024, x2d.device)
+    _call("dh_colsum", _ci(dt(x2d)), P(x2d), _cl(Pn), _ci(C), P(out), _ci(int(accumulate)), P(ws), S())
+
+
+def cast_from_f32(src, dtype):
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _call("dh_cast_from_f32", _ci(_DT[dtype]), P(src), P(dst), _cl(src.numel()), S())
+    return dst
+
+
+def cast_to_f32(src, dst=None, accumulate=False):
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    _call("dh_cast_to_f32", _ci(dt(src)), P(src), P(dst), _cl(src.numel()), _ci(int(accumulate)), S())
+    return dst
+
+
+# ---- token side ----------------------------------------------------------------------------------
+def tokenizer_fwd(x, wa, pos, B, L):
+    """x [S, H, W, 32]; returns (tok_cat [B, 2L, 32] T written for the S/B streams present, saved)"""
+    Sn, H, W, C = x.shape
+    HW = H * W
+    dev = x.device
+    logits = torch.empty(Sn * HW, L, dtype=torch.float32, device=dev)
+    stats = torch.empty(Sn, L, 2, dtype=torch.float32, device=dev)
+    pooled = torch.empty(Sn, L, 32, dtype=torch.float32, device=dev)
+    tok = torch.empty(B, 2 * L, 32, dtype=x.dtype, device=dev)
+    _call("dh_tokenizer_fwd", _ci(dt(x)), P(x), P(wa), P(pos), _ci(Sn), _ci(B), _ci(HW), _ci(L), P(logits), P(stats),
+          P(pooled), P(tok), S())
+    return tok, (logits, stats, pooled)
+
+
+def tokenizer_bwd(x, wa, saved, dtok_cat, dx_accum, dwa, dpos, B, L, accumulate=False):
+    Sn, H, W, C = x.shape
+    HW = H * W
+    logits, stats, pooled = saved
+    Lb = _lib.lib()
+    ws = workspace(Lb.dh_tokenizer_bwd_workspace_size(Sn, HW, L), x.device)
+    _call("dh_tokenizer_bwd", _ci(dt(x)), P(x), P(wa), _ci(Sn), _ci(B), _ci(HW), _ci(L), P(logits), P(stats), P(pooled),
+          P(dtok_cat), P(dx_accum), P(dwa), P(dpos), _ci(int(accumulate)), P(ws), S())
+
+
+class XattnPrep:
+    """Per-image operands of the re-associated cross attention (see csrc/tokens.hip)."""
+
+    def __init__(self, tok, bstride, sstride, B, Sn, L, heads, dim_head, ln_g, ln_b, wq, wk, wv, wo, dtype,
+                 scale=32 ** -0.5, eps=1e-5):
+        dev = tok.device
+        inner = heads * dim_head
+        self.HLP = cdiv(heads * L, 32) * 32
+        self.args = (bstride, sstride, B, Sn, L, heads, dim_head)
+        self.scale = scale
+        self.mn = torch.empty(Sn, L, 32, dtype=torch.float32, device=dev)
+        self.mstats = torch.empty(Sn, L, 2, dtype=torch.float32, device=dev)
+        self.k = torch.empty(Sn, L, inner, dtype=torch.float32, device=dev)
+        self.v = torch.empty_like(self.k)
+        self.kq = torch.empty(Sn, self.HLP, 32, dtype=dtype, device=dev)
+        self.kqT = torch.empty(Sn, 32, self.HLP, dtype=dtype, device=dev)
+        self.vo = torch.empty(Sn, self.HLP, 32, dtype=dtype, device=dev)
+        self.voT = torch.empty(Sn, 32, self.HLP, dtype=dtype, device=dev)
+        _call("dh_xattn_prep_fwd", _ci(_DT[dtype]), P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(L),
+              _ci(heads), _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), P(ln_g), P(ln_b), P(wq), P(wk), P(wv),
+              P(wo), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq), P(self.kqT), P(self.vo),
+              P(self.voT), S())
+
+
+def xattn_prep_bwd(prep, tok, dtok_accum, ln_g, wq, wk, wv, wo, dkq, dvoT, dln_g, dln_b, dwq, dwk, dwv, dwo,
+                   accumulate, dtype):
+    bstride, sstride, B, Sn, L, heads, dim_head = prep.args
+    dk = torch.empty_like(prep.k)
+    dv = torch.empty_like(prep.v)
+    Lb = _lib.lib()
+    ws = workspace(Lb.dh_xattn_prep_bwd_workspace_size(Sn), tok.device)
+    _call("dh_xattn_prep_bwd", _ci(_DT[dtype]), P(tok), P(dtok_accum), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn),
+          _ci(L), _ci(heads), _ci(dim_head), _ci(prep.HLP), _cf(prep.scale), P(ln_g), P(wq), P(wk), P(wv), P(wo),
+          P(prep.mn), P(prep.mstats), P(prep.k), P(prep.v), P(dkq), P(dvoT), P(dk), P(dv), P(dln_g), P(dln_b), P(dwq),
+          P(dwk), P(dwv), P(dwo), _ci(int(accumulate)), P(ws), S())
+
+
+def softmax_groups(x2d, heads, L):
+    rows, HLP = x2d.shape
+    y = torch.empty_like(x2d)
+    _call("dh_softmax_groups_fwd", _ci(dt(x2d)), P(x2d), P(y), _cl(rows), _ci(heads), _ci(L), _ci(HLP), S())
+    return y
+
+
+def softmax_groups_bwd(y, dy, heads, L):
+    rows, HLP = y.shape
+    dx = torch.empty_like(y)
+    _call("dh_softmax_groups_bwd", _ci(dt(y)), P(y), P(dy), P(dx), _cl(rows), _ci(heads), _ci(L), _ci(HLP), S())
+    return dx
+
+
+def self_attn(qkv, B, n, heads, dim_head, scale=32 ** -0.5):
+    inner = heads * dim_head
+    o = torch.empty(B * n, inner, dtype=qkv.dtype, device=qkv.device)
+    attn = torch.empty(B, heads, n, n, dtype=torch.float32, device=qkv.device)
+    _call("dh_self_attn_fwd", _ci(dt(qkv)), P(qkv), P(o), P(attn), _ci(B), _ci(n), _ci(heads), _ci(dim_head),
+          _cf(scale), S())
+    return o, attn
+
+
+def self_attn_bwd(qkv, attn, dout, B, n, heads, dim_head, scale=32 ** -0.5):
+    dqkv = torch.empty_like(qkv)
+    _call("dh_self_attn_bwd", _ci(dt(qkv)), P(qkv), P(attn), P(dout), P(dqkv), _ci(B), _ci(n), _ci(heads),
+          _ci(dim_head), _cf(scale), S())
+    return dqkv
+
+
+# ---- loss / mask / optimizer ---------------------------------------------------------------------
+def focal_loss(logits_nchw, target, want_grad=True, grad_scale=1.0, alpha=0.5):
+    B, C, H, W = logits_nchw.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits_nchw.device)
+    dl = torch.empty_like(logits_nchw) if want_grad else None
+    ws = workspace(4096, logits_nchw.device)
+    _call("dh_focal_loss", P(logits_nchw), P(target), _ci(B), _ci(C), _cl(H * W), _cf(alpha), _cf(grad_scale), P(loss),
+          P(dl), P(ws), S())
+    return loss, dl
+
+
+def argmax_nchw(logits_nchw):
+    B, C, H, W = logits_nchw.shape
+    mask = torch.empty(B, H, W, dtype=torch.int64, device=logits_nchw.device)
+    _call("dh_argmax_nchw", P(logits_nchw), P(mask), _ci(B), _ci(C), _cl(H * W), S())
+    return mask
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _call("dh_adamw_step", P(param), P(grad), P(exp_avg), P(exp_avg_sq), _cl(param.numel()), _cf(lr), _cf(beta1),
+          _cf(beta2), _cf(eps), _cf(weight_decay), _ci(step), _cf(grad_scale), S())

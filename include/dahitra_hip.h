@@ -1,0 +1,148 @@
+/* dahitra_hip.h -- C ABI of libdahitra_hip.so, the MI355X (gfx950) kernel library behind
+ * dahitra_amd's drop-in replacement of the DAHiTra change-detection hot path.
+ *
+ * The reference (nka77/DAHiTra) owns no native code: its hot path issues stock torch operators.
+ * Each entry point below therefore cites the reference call site(s) whose torch operator it
+ * replaces (paths relative to the reference root).  A maintainer binds these with ctypes exactly as
+ * dahitra_amd/_lib.py does.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; dh_last_error() gives the message
+ *   - all pointers are DEVICE pointers (hipMalloc / torch CUDA tensors) unless stated otherwise;
+ *     buffers are caller-allocated, no ownership is transferred, nothing is allocated inside
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); calls are async
+ *   - `dtype`: DH_F32 (parity mode, exact-fp32 MFMA) or DH_BF16 (throughput mode, bf16 MFMA with
+ *     fp32 accumulation) selects the ACTIVATION type "T"; parameters, statistics, optimizer state
+ *     and weight gradients are always fp32
+ *   - activations are NHWC: [N][H][W][C], C contiguous; "rows x C" tensors are the same thing
+ *   - `*_workspace_size` twins return the bytes of scratch the call needs (contents undefined)
+ */
+#ifndef DAHITRA_HIP_H
+#define DAHITRA_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DH_F32 0
+#define DH_BF16 1
+#define DH_ACT_NONE 0
+#define DH_ACT_RELU 1
+#define DH_ACT_GELU 2
+
+int dh_abi_version(void);
+const char* dh_last_error(void);
+void dh_set_error(const char* msg);
+
+/* ---- convolution / linear on the matrix cores ------------------------------------------------
+ * replaces F.conv2d / nn.Linear at: models/resnet.py:24-32,150 (trunk), models/networks.py:215
+ * (conv_pred), models/help_funcs.py:7-15 (TwoLayerConv2d), :52-63 (FeedForward), :86-88,111
+ * (to_q/k/v/out), models/networks.py:1178-1185,1196-1199,1235-1243 (squeeze / decode / top-down
+ * convs); with transposed+flipped weights it is also their input gradient (autograd
+ * convolution_backward), and with w_image_stride != 0 the per-image attention products
+ * (help_funcs.py:92,109) in re-associated form.
+ * y[n,oy,ox,co] = act( sum_{kh,kw,ci} x[n, oy*stride-pad+kh, ox*stride-pad+kw, ci] * w[kh*ks+kw][co][ci]
+ *                      + bias[co] + residual[n,oy,ox,co] )
+ * w_packed: [ks*ks][CoutPad][Cin] T (dh_pack_weight).  Cin*sizeof(T) must be a multiple of 64.
+ * y_preact (optional): receives the value before `act`.  stats_partial (optional):
+ * [dh_conv2d_fwd_num_tiles][2][CoutPad] fp32 per-tile (sum, sum of squares) of y for BatchNorm.
+ * npix_valid > 0: treat each image as a row list with that many valid rows (H*W >= npix_valid). */
+int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const float* bias,
+                  const void* residual, float* stats_partial, int N, int H, int W, int Cin, int OH, int OW,
+                  int Cout, int CoutPad, int ks, int stride, int pad, int act, int npix_valid,
+                  long w_image_stride, void* y_preact, void* stream);
+int dh_conv2d_fwd_num_tiles(int N, int OH, int OW);
+
+/* weight gradient (autograd convolution_backward / mm for nn.Linear): groups == 1 writes the
+ * torch OIHW layout [Cout_real][Cin][ks][ks]; groups == N (ks == 1) one [Cout][Cin] per image. */
+int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N, int H,
+                    int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad, int groups,
+                    int npix_valid, int use_tr, int Cout_real, void* workspace, void* stream);
+long dh_conv2d_wgrad_workspace_size(int N, int OH, int OW, int Cin, int Cout, int ks, int groups);
+int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, int ks, int groups);
+
+/* OIHW fp32 master weight -> kernel layouts: fwd [ks*ks][OPad][I] T and (optional) the data-gradient
+ * form [ks*ks flipped][IPad][max(O, dgrad_inner)] T. */
+int dh_pack_weight(int dtype, const float* w_oihw, int O, int I, int ks, int OPad, void* fwd, int IPad,
+                   int dgrad_inner, void* dgrad, void* stream);
+/* z[n,2y,2x,c] = dy[n,y,x,c] (zero elsewhere): stride-2 data gradients as stride-1 convolutions */
+int dh_zero_insert2(int dtype, const void* dy, void* z, int N, int OH, int OW, int H, int W, int C, void* stream);
+
+/* stem nn.Conv2d(3,64,7,2,3) (models/resnet.py:150) as a 4x4/stride-1 conv on a space-to-depth image */
+int dh_stem_space_to_depth(int dtype, const float* x_nchw, void* y, int N, int H, int W, int CP, void* stream);
+int dh_stem_pack_weight(int dtype, const float* w_oihw, void* packed, int O, int CP, void* stream);
+int dh_stem_unpack_grad(const float* dw2, float* dw_oihw, int O, int CP, int accumulate, void* stream);
+
+/* ---- BatchNorm2d (models/resnet.py:152,40-44; help_funcs.py:11) and LayerNorm(32) (help_funcs.py:34-49) */
+int dh_bn_finalize(const float* partial, int ntiles, int CP, int C, int groups, double count, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+int dh_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, int C, float* scale, float* shift, void* stream);
+int dh_bn_apply(int dtype, const void* x, const void* residual, void* y, const float* scale, const float* shift,
+                long npix, int C, int groups, int act, void* stream);
+int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, const void* x, const float* mean,
+              const float* invstd, const float* gamma, long npix, int C, int groups, void* dx, void* dres,
+              float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream);
+long dh_bn_bwd_workspace_size(long npix, int C, int groups);
+int dh_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                     long rows, int C, float eps, void* stream);
+int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx,
+                     const void* dx_add, float* dgamma, float* dbeta, int accumulate, long rows, int C,
+                     void* workspace, void* stream);
+long dh_layernorm_bwd_workspace_size(long rows);
+int dh_reduce_partials(const float* partial, long nt, long n, float scale, float* out, int accumulate, void* stream);
+
+/* ---- pointwise / resampling / layout (models/resnet.py:154; networks.py:199-200,384,1312,1348) ---- */
+int dh_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, long HW, int CP, void* stream);
+int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream);
+int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, void* dst, int Cd, int dc0, int Cn, long P, void* stream);
+int dh_add(int dtype, const void* a, const void* b, void* y, long n, void* stream);
+int dh_add_pos(int dtype, const void* x, const float* pos, void* y, int N, long HW, int C, void* stream);
+int dh_add_pos_bwd(int dtype, const void* dy, float* dpos, int N, long HW, int C, int accumulate, void* stream);
+int dh_act_bwd(int dtype, const void* dy, const void* ref, void* dx, long n, int act, void* stream);
+int dh_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
+int dh_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+int dh_upsample2_nearest_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
+int dh_upsample2_nearest_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+int dh_absdiff_upsample4_fwd(int dtype, const void* a, const void* b, void* y, int N, int H, int W, int C, void* stream);
+int dh_absdiff_upsample4_bwd(int dtype, const void* a, const void* b, const void* dy, void* da, void* db, int N, int H, int W, int C, void* stream);
+int dh_absdiff(int dtype, const void* a, const void* b, void* y, long n, void* stream);
+int dh_absdiff_bwd(int dtype, const void* a, const void* b, const void* dy, void* da, void* db, long n, int accumulate, void* stream);
+int dh_colsum(int dtype, const void* x, long P, int C, float* out, int accumulate, void* workspace, void* stream);
+int dh_cast_from_f32(int dtype, const float* src, void* dst, long n, void* stream);
+int dh_cast_to_f32(int dtype, const void* src, float* dst, long n, int accumulate, void* stream);
+
+/* ---- token side (models/networks.py:312-336,457-488; help_funcs.py:66-114) -------------------- */
+int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const float* pos, int S, int B, int HW, int L,
+                     float* logits, float* stats, float* pooled, void* tok_cat, void* stream);
+int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S, int B, int HW, int L, const float* logits,
+                     const float* stats, const float* pooled, const void* dtok_cat, void* dx_accum, float* dwa,
+                     float* dpos, int accumulate, void* workspace, void* stream);
+long dh_tokenizer_bwd_workspace_size(int S, int HW, int L);
+int dh_xattn_prep_fwd(int dtype, const void* tok, long tok_bstride, long tok_sstride, int B, int S, int L, int heads,
+                      int dim_head, int HLP, float scale, float eps, const float* ln_g, const float* ln_b,
+                      const float* wq, const float* wk, const float* wv, const float* wo, float* mn, float* mstats,
+                      float* k, float* v, void* kq, void* kqT, void* vo, void* voT, void* stream);
+int dh_xattn_prep_bwd(int dtype, const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride, int B, int S,
+                      int L, int heads, int dim_head, int HLP, float scale, const float* ln_g, const float* wq,
+                      const float* wk, const float* wv, const float* wo, const float* mn, const float* mstats,
+                      const float* k, const float* v, const float* dkq, const float* dvoT, float* dk, float* dv,
+                      float* dln_g, float* dln_b, float* dwq, float* dwk, float* dwv, float* dwo, int accumulate,
+                      void* workspace, void* stream);
+long dh_xattn_prep_bwd_workspace_size(int S);
+int dh_softmax_groups_fwd(int dtype, const void* x, void* y, long rows, int heads, int L, int HLP, void* stream);
+int dh_softmax_groups_bwd(int dtype, const void* y, const void* dy, void* dx, long rows, int heads, int L, int HLP, void* stream);
+int dh_self_attn_fwd(int dtype, const void* qkv, void* o, float* attn, int B, int n, int heads, int dim_head, float scale, void* stream);
+int dh_self_attn_bwd(int dtype, const void* qkv, const float* attn, const void* dout, void* dqkv, int B, int n, int heads, int dim_head, float scale, void* stream);
+
+/* ---- loss, mask, optimizer (models/losses.py:106-196; trainer.py:39-40,170) ------------------- */
+int dh_focal_loss(const float* logits_nchw, const long long* target, int B, int C, long HW, float alpha,
+                  float grad_scale, float* loss_out, float* dlogits_nchw, void* workspace, void* stream);
+int dh_argmax_nchw(const float* logits_nchw, long long* mask, int B, int C, long HW, void* stream);
+int dh_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
