@@ -198,6 +198,21 @@ extern "C" int dh_stem_unpack_grad(const float* dw2, float* dw_oihw, int O, int 
     return 0;
 }
 
+// dst[i] = src[i] * (*scalar_dev): chains an upstream scalar gradient without a host sync
+__global__ void scale_by_scalar_kernel(const float* __restrict__ src, const float* __restrict__ scalar_dev,
+                                       float* __restrict__ dst, long n) {
+    const float s = *scalar_dev;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i] * s;
+}
+extern "C" int dh_scale_by_scalar(const float* src, const float* scalar_dev, float* dst, long n, void* stream) {
+    long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((int)g), dim3(256), 0, ST(stream), src, scalar_dev, dst, n);
+    DH_CHECK_LAUNCH("scale_by_scalar");
+    return 0;
+}
+
 // ---- error channel ---------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 extern "C" void dh_set_error(const char* msg) {

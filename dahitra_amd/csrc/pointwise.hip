@@ -537,3 +537,41 @@ extern "C" int dh_cast_to_f32(int dtype, const void* src, float* dst, long n, in
     DH_CHECK_LAUNCH("cast_to_f32");
     return 0;
 }
+
+// ---- |second half - first half| of [B][2][n] token sets (models/networks.py:1311) and its gradient
+namespace {
+template <typename T>
+__global__ void absdiff_halves_kernel(const T* __restrict__ tok, T* __restrict__ out, int B, long n) {
+    GSL(i, (long)B * n) {
+        const long b = i / n, j = i % n;
+        stf(out + i, fabsf(ldf(tok + (b * 2 + 1) * n + j) - ldf(tok + (b * 2) * n + j)));
+    }
+}
+template <typename T>
+__global__ void absdiff_halves_bwd_kernel(const T* __restrict__ tok, const T* __restrict__ dout, T* __restrict__ dtok,
+                                          int B, long n) {
+    GSL(i, (long)B * n) {      // accumulates into dtok
+        const long b = i / n, j = i % n;
+        const float df = ldf(tok + (b * 2 + 1) * n + j) - ldf(tok + (b * 2) * n + j);
+        const float g = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * ldf(dout + i);
+        T* p1 = dtok + (b * 2 + 1) * n + j;
+        T* p0 = dtok + (b * 2) * n + j;
+        stf(p1, ldf(p1) + g);
+        stf(p0, ldf(p0) - g);
+    }
+}
+}  // namespace
+extern "C" int dh_absdiff_halves(int dtype, const void* tok, void* out, int B, long n, void* stream) {
+    const long t = (long)B * n;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(absdiff_halves_kernel<bf16>, dim3(ew_grid(t, 256)), dim3(256), 0, ST(stream), (const bf16*)tok, (bf16*)out, B, n);
+    else hipLaunchKernelGGL(absdiff_halves_kernel<float>, dim3(ew_grid(t, 256)), dim3(256), 0, ST(stream), (const float*)tok, (float*)out, B, n);
+    DH_CHECK_LAUNCH("absdiff_halves");
+    return 0;
+}
+extern "C" int dh_absdiff_halves_bwd(int dtype, const void* tok, const void* dout, void* dtok_accum, int B, long n, void* stream) {
+    const long t = (long)B * n;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(absdiff_halves_bwd_kernel<bf16>, dim3(ew_grid(t, 256)), dim3(256), 0, ST(stream), (const bf16*)tok, (const bf16*)dout, (bf16*)dtok_accum, B, n);
+    else hipLaunchKernelGGL(absdiff_halves_bwd_kernel<float>, dim3(ew_grid(t, 256)), dim3(256), 0, ST(stream), (const float*)tok, (const float*)dout, (float*)dtok_accum, B, n);
+    DH_CHECK_LAUNCH("absdiff_halves_bwd");
+    return 0;
+}

@@ -1,0 +1,478 @@
+"""Forward / backward pipelines of the change-detection nets, composed from libdahitra_hip kernels.
+
+No autograd graph is built for the interior: each block's forward returns its output plus a closure
+that runs the hand-written backward kernels and deposits parameter gradients straight into the flat
+fp32 gradient arena.  The two temporal streams are processed as ONE batch of 2B images ("groups" = 2
+keeps BatchNorm statistics per stream exactly as the reference's two forward_single calls do,
+models/networks.py:360-361), which halves the launch count and doubles the work per launch.
+
+Reference structure followed (not copied): BASE_Transformer.forward models/networks.py:358-392,
+ResNet.forward_single :233-257, BasicBlock models/resnet.py:58-73, Transformer / TransformerDecoder
+models/help_funcs.py:154-186, BASE_Transformer_UNet.forward models/networks.py:1297-1357.
+"""
+import torch
+
+from . import ops
+from .netspec import (ATTN_SCALE, BIT_DIM_HEAD, BIT_HEADS, BN_EPS, BN_MOMENTUM, DIM, LN_EPS, UNET_LEVELS,
+                      get_config, is_active, state_spec)
+
+RELU, GELU, NONE = ops.ACT_RELU, ops.ACT_GELU, ops.ACT_NONE
+
+
+class Packed:
+    __slots__ = ("fwd", "dgrad")
+
+    def __init__(self, fwd, dgrad):
+        self.fwd, self.dgrad = fwd, dgrad
+
+
+class Engine:
+    def __init__(self, net_G, dtype=torch.float32, use_tr=True):
+        self.net_G = net_G
+        self.cfg = get_config(net_G)
+        self.dtype = dtype
+        self.use_tr = use_tr
+        self.shapes = {k: s for k, s, _ in state_spec(net_G)}
+        self.p = {}        # key -> fp32 parameter / buffer tensors (device)
+        self.g = {}        # key -> fp32 gradient views
+        self.pk = {}       # key -> Packed
+        self.training = False
+        self.need_grad = False
+        self._bwd = None
+
+    # ---- binding ---------------------------------------------------------------------------------
+    def bind(self, params, grads):
+        self.p, self.g = params, grads
+
+    def _pack_all(self):
+        ck = ops.chunk_channels(self.dtype)
+        self.pk = {}
+        for key, shape in self.shapes.items():
+            if key not in self.p or not key.endswith("weight") or len(shape) not in (2, 4):
+                continue
+            if not is_active(self.net_G, key):
+                continue
+            if key == "resnet.conv1.weight":
+                self.pk[key] = Packed(ops.stem_pack_weight(self.p[key], self.dtype), None)
+                continue
+            if ".to_q." in key or ".to_k." in key or ".to_v." in key or key.startswith("conv_a") or \
+                    key.startswith("conv_token") or key.startswith("resnet.fc") or key.startswith("resnet.layer4"):
+                continue        # consumed in fp32 by the token-side kernels, or unused by the forward
+            if ".to_out." in key and "transformer_decoder" in key:
+                continue
+            O = shape[0]
+            inner = -(-O // ck) * ck
+            f, d = ops.pack_weight(self.p[key], self.dtype, want_dgrad=self.need_grad, dgrad_inner=inner)
+            self.pk[key] = Packed(f, d)
+
+    # ---- primitive units -------------------------------------------------------------------------
+    def conv_dgrad(self, dy, wkey, ks, stride, pad, xshape, residual=None):
+        N, H, W, Cin = xshape
+        if stride == 2:
+            dy = ops.zero_insert2(dy, H, W)
+        return ops.conv2d(dy, self.pk[wkey].dgrad, Cin, ks, 1, ks - 1 - pad, residual=residual, out_hw=(H, W))
+
+    def conv_bn(self, x, wkey, bnkey, ks, stride, pad, groups, relu, residual=None):
+        cout = self.shapes[wkey][0]
+        gamma, beta = self.p[bnkey + ".weight"], self.p[bnkey + ".bias"]
+        rm, rv = self.p[bnkey + ".running_mean"], self.p[bnkey + ".running_var"]
+        act = RELU if relu else NONE
+        if self.training:
+            y, st = ops.conv2d(x, self.pk[wkey].fwd, cout, ks, stride, pad, want_stats=True)
+            N, OH, OW, _ = y.shape
+            mean, invstd, scale, shift = ops.bn_finalize(st, cout, groups, (N // groups) * OH * OW, gamma, beta, rm, rv,
+                                                         BN_MOMENTUM, BN_EPS)
+            self.p[bnkey + ".num_batches_tracked"].add_(groups)
+            out = ops.bn_apply(y, scale, shift, groups, act, residual)
+        else:
+            y = ops.conv2d(x, self.pk[wkey].fwd, cout, ks, stride, pad)
+            scale, shift = ops.bn_eval_params(gamma, beta, rm, rv, BN_EPS)
+            out = ops.bn_apply(y, scale, shift, 1, act, residual)
+            mean = invstd = None
+        if not self.need_grad:
+            return out, None
+        has_res = residual is not None
+
+        def bwd(dout, need_dx=True, dx_res=None):
+            r = ops.bn_bwd(dout, out if relu else None, y, mean, invstd, gamma, self.g[bnkey + ".weight"],
+                           self.g[bnkey + ".bias"], groups, accumulate=True, want_dres=has_res)
+            dy, dres = r if has_res else (r, None)
+            ops.conv2d_wgrad(x, dy, self.g[wkey], ks, stride, pad, accumulate=True, use_tr=self.use_tr)
+            dx = self.conv_dgrad(dy, wkey, ks, stride, pad, x.shape, residual=dx_res) if need_dx else None
+            return dx, dres
+        return out, bwd
+
+    def conv_act(self, x, wkey, bkey, ks, pad, act, cpad_grad=False):
+        cout = self.shapes[wkey][0]
+        out = ops.conv2d(x, self.pk[wkey].fwd, cout, ks, 1, pad, bias=self.p[bkey] if bkey else None, act=act)
+        if not self.need_grad:
+            return out, None
+
+        def bwd(dout, need_dx=True, dx_res=None):
+            dy = ops.act_bwd(dout, out, RELU) if act == RELU else dout
+            ops.conv2d_wgrad(x, dy, self.g[wkey], ks, 1, pad, accumulate=True, use_tr=self.use_tr)
+            if bkey:
+                ops.colsum(dy.view(-1, cout), self.g[bkey], accumulate=True)
+            dx = self.conv_dgrad(dy, wkey, ks, 1, pad, x.shape, residual=dx_res) if need_dx else None
+            return dx
+        return out, bwd
+
+    def stem(self, x1, x2, groups):
+        """7x7/2 stem + BN + ReLU as a 4x4 conv on the space-to-depth image (csrc/loss_optim.hip)."""
+        B = x1.shape[0]
+        H, W = x1.shape[2], x1.shape[3]
+        cp = ops.chunk_channels(self.dtype)
+        xs = torch.empty(2 * B, H // 2, W // 2, cp, dtype=self.dtype, device=x1.device)
+        ops.stem_space_to_depth_into(x1, xs[:B])
+        ops.stem_space_to_depth_into(x2, xs[B:])
+        wkey, bnkey = "resnet.conv1.weight", "resnet.bn1"
+        gamma, beta = self.p[bnkey + ".weight"], self.p[bnkey + ".bias"]
+        rm, rv = self.p[bnkey + ".running_mean"], self.p[bnkey + ".running_var"]
+        oh, ow = H // 2, W // 2
+        if self.training:
+            y, st = ops.conv2d(xs, self.pk[wkey].fwd, 64, 4, 1, 2, want_stats=True, out_hw=(oh, ow))
+            mean, invstd, scale, shift = ops.bn_finalize(st, 64, groups, B * oh * ow, gamma, beta, rm, rv, BN_MOMENTUM,
+                                                         BN_EPS)
+            self.p[bnkey + ".num_batches_tracked"].add_(groups)
+            out = ops.bn_apply(y, scale, shift, groups, RELU)
+        else:
+            y = ops.conv2d(xs, self.pk[wkey].fwd, 64, 4, 1, 2, out_hw=(oh, ow))
+            scale, shift = ops.bn_eval_params(gamma, beta, rm, rv, BN_EPS)
+            out = ops.bn_apply(y, scale, shift, 1, RELU)
+            mean = invstd = None
+        if not self.need_grad:
+            return out, None
+
+        def bwd(dout):
+            dy = ops.bn_bwd(dout, out, y, mean, invstd, gamma, self.g[bnkey + ".weight"], self.g[bnkey + ".bias"],
+                            groups, accumulate=True)
+            ops.stem_wgrad(xs, dy, self.g[wkey], accumulate=True, use_tr=self.use_tr)
+        return out, bwd
+
+    def basic_block(self, x, pfx, stride, groups):
+        h, b1 = self.conv_bn(x, pfx + ".conv1.weight", pfx + ".bn1", 3, stride, 1, groups, True)
+        has_ds = (pfx + ".downsample.0.weight") in self.shapes
+        if has_ds:
+            idt, bds = self.conv_bn(x, pfx + ".downsample.0.weight", pfx + ".downsample.1", 1, stride, 0, groups, False)
+        else:
+            idt, bds = x, None
+        out, b2 = self.conv_bn(h, pfx + ".conv2.weight", pfx + ".bn2", 3, 1, 1, groups, True, residual=idt)
+        if not self.need_grad:
+            return out, None
+
+        def bwd(dout):
+            dh, dres = b2(dout)
+            if has_ds:
+                dxds, _ = bds(dres)
+                dx, _ = b1(dh, dx_res=dxds)
+            else:
+                dx, _ = b1(dh, dx_res=dres)
+            return dx
+        return out, bwd
+
+    def res_layer(self, x, li, stride, groups):
+        x, ba = self.basic_block(x, "resnet.layer%d.0" % li, stride, groups)
+        x, bb = self.basic_block(x, "resnet.layer%d.1" % li, 1, groups)
+        if not self.need_grad:
+            return x, None
+        return x, (lambda d: ba(bb(d)))
+
+    # ---- transformer pieces ----------------------------------------------------------------------
+    def mlp_block(self, x1, f):
+        """x + W2 gelu(W1 LN(x) + b1) + b2 on rows [R, 32] (help_funcs.py:52-63)."""
+        g2, b2 = self.p[f + ".norm.weight"], self.p[f + ".norm.bias"]
+        w1k, w2k = f + ".fn.net.0.weight", f + ".fn.net.3.weight"
+        mlp = self.shapes[w1k][0]
+        ln2, st2 = ops.layernorm(x1, g2, b2, LN_EPS)
+        h, z = ops.linear(ln2, self.pk[w1k].fwd, mlp, bias=self.p[f + ".fn.net.0.bias"], act=GELU, want_preact=True)
+        x2 = ops.linear(h, self.pk[w2k].fwd, DIM, bias=self.p[f + ".fn.net.3.bias"], residual=x1)
+        if not self.need_grad:
+            return x2, None
+
+        def bwd(dx2):
+            dh = ops.linear(dx2, self.pk[w2k].dgrad, mlp)
+            ops.linear_wgrad(h, dx2, self.g[w2k], accumulate=True, use_tr=self.use_tr)
+            ops.colsum(dx2, self.g[f + ".fn.net.3.bias"], accumulate=True)
+            dz = ops.act_bwd(dh, z, GELU)
+            dln2 = ops.linear(dz, self.pk[w1k].dgrad, DIM)
+            ops.linear_wgrad(ln2, dz, self.g[w1k], accumulate=True, use_tr=self.use_tr)
+            ops.colsum(dz, self.g[f + ".fn.net.0.bias"], accumulate=True)
+            return ops.layernorm_bwd(dln2, x1, st2, g2, self.g[f + ".norm.weight"], self.g[f + ".norm.bias"],
+                                     dx_add=dx2, accumulate=True)
+        return x2, bwd
+
+    def encoder(self, tok, pfx, depth, heads, dim_head, B, n):
+        """token self-attention stack on [B*n, 32] rows (models/networks.py:457-512)."""
+        x = tok
+        bw = []
+        for i in range(depth):
+            a, f = "%s.layers.%d.0.fn" % (pfx, i), "%s.layers.%d.1.fn" % (pfx, i)
+            x, b1 = self._enc_attn(x, a, heads, dim_head, B, n)
+            x, b2 = self.mlp_block(x, f)
+            bw += [b1, b2]
+        if not self.need_grad:
+            return x, None
+
+        def bwd(d):
+            for b in reversed(bw):
+                d = b(d)
+            return d
+        return x, bwd
+
+    def _enc_attn(self, x0, a, heads, dim_head, B, n):
+        g1, b1 = self.p[a + ".norm.weight"], self.p[a + ".norm.bias"]
+        wqkv, wout = a + ".fn.to_qkv.weight", a + ".fn.to_out.0.weight"
+        inner = heads * dim_head
+        xn, st1 = ops.layernorm(x0, g1, b1, LN_EPS)
+        qkv = ops.linear(xn, self.pk[wqkv].fwd, 3 * inner)
+        o, attn = ops.self_attn(qkv, B, n, heads, dim_head, ATTN_SCALE)
+        x1 = ops.linear(o, self.pk[wout].fwd, DIM, bias=self.p[a + ".fn.to_out.0.bias"], residual=x0)
+        if not self.need_grad:
+            return x1, None
+
+        def bwd(dx1):
+            do = ops.linear(dx1, self.pk[wout].dgrad, inner)
+            ops.linear_wgrad(o, dx1, self.g[wout], accumulate=True, use_tr=self.use_tr)
+            ops.colsum(dx1, self.g[a + ".fn.to_out.0.bias"], accumulate=True)
+            dqkv = ops.self_attn_bwd(qkv, attn, do, B, n, heads, dim_head, ATTN_SCALE)
+            dxn = ops.linear(dqkv, self.pk[wqkv].dgrad, DIM)
+            ops.linear_wgrad(xn, dqkv, self.g[wqkv], accumulate=True, use_tr=self.use_tr)
+            return ops.layernorm_bwd(dxn, x0, st1, g1, self.g[a + ".norm.weight"], self.g[a + ".norm.bias"],
+                                     dx_add=dx1, accumulate=True)
+        return x1, bwd
+
+    def decoder(self, x2d, images, tok, tok_b, tok_s, B, dtok, pfx, depth, heads, dim_head, L):
+        """cross-attention stack: pixel rows x2d [images*HW, 32] attend to the L tokens of their image
+        (help_funcs.py:170-186); dtok accumulates the token gradients."""
+        bw = []
+        x = x2d
+        for i in range(depth):
+            a, f = "%s.layers.%d.0.fn" % (pfx, i), "%s.layers.%d.1.fn" % (pfx, i)
+            x, b1 = self._dec_attn(x, images, tok, tok_b, tok_s, B, dtok, a, heads, dim_head, L)
+            x, b2 = self.mlp_block(x, f)
+            bw += [b1, b2]
+        if not self.need_grad:
+            return x, None
+
+        def bwd(d):
+            for b in reversed(bw):
+                d = b(d)
+            return d
+        return x, bwd
+
+    def _dec_attn(self, x0, images, tok, tok_b, tok_s, B, dtok, a, heads, dim_head, L):
+        g1, b1 = self.p[a + ".norm.weight"], self.p[a + ".norm.bias"]
+        wq, wk, wv = (self.p[a + ".fn.to_%s.weight" % n] for n in "qkv")
+        wo, bo = self.p[a + ".fn.to_out.0.weight"], self.p[a + ".fn.to_out.0.bias"]
+        xn, st1 = ops.layernorm(x0, g1, b1, LN_EPS)
+        prep = ops.XattnPrep(tok, tok_b, tok_s, B, images, L, heads, dim_head, g1, b1, wq, wk, wv, wo, self.dtype,
+                             ATTN_SCALE, LN_EPS)
+        HLP = prep.HLP
+        dots = ops.linear(xn, prep.kq, HLP, images=images, w_image_stride=HLP * DIM)
+        attn = ops.softmax_groups(dots, heads, L)
+        x1 = ops.linear(attn, prep.voT, DIM, bias=bo, residual=x0, images=images, w_image_stride=HLP * DIM)
+        if not self.need_grad:
+            return x1, None
+        dev = x0.device
+
+        def bwd(dx1):
+            dattn = ops.linear(dx1, prep.vo, HLP, images=images, w_image_stride=HLP * DIM)
+            dvoT = torch.empty(images, DIM, HLP, dtype=torch.float32, device=dev)
+            ops.linear_wgrad(attn, dx1, dvoT, images=images, per_image=True, use_tr=self.use_tr)
+            ops.colsum(dx1, self.g[a + ".fn.to_out.0.bias"], accumulate=True)
+            ddots = ops.softmax_groups_bwd(attn, dattn, heads, L)
+            dxn = ops.linear(ddots, prep.kqT, DIM, images=images, w_image_stride=HLP * DIM)
+            dkq = torch.empty(images, HLP, DIM, dtype=torch.float32, device=dev)
+            ops.linear_wgrad(xn, ddots, dkq, images=images, per_image=True, use_tr=self.use_tr)
+            dx = ops.layernorm_bwd(dxn, x0, st1, g1, self.g[a + ".norm.weight"], self.g[a + ".norm.bias"],
+                                   dx_add=dx1, accumulate=True)
+            ops.xattn_prep_bwd(prep, tok, dtok, g1, wq, wk, wv, wo, dkq, dvoT, self.g[a + ".norm.weight"],
+                               self.g[a + ".norm.bias"], *(self.g[a + ".fn.to_%s.weight" % n] for n in "qkv"),
+                               self.g[a + ".fn.to_out.0.weight"], True, self.dtype)
+            return dx
+        return x1, bwd
+
+    # ---- whole nets ------------------------------------------------------------------------------
+    def forward(self, x1, x2, training, need_grad):
+        self.training, self.need_grad = training, need_grad
+        self._pack_all()
+        if self.cfg["kind"] == "bit":
+            logits, bwd = self._bit(x1, x2)
+        else:
+            logits, bwd = self._unet(x1, x2)
+        self._bwd = bwd
+        return logits
+
+    def backward(self, dlogits_nchw):
+        if self._bwd is None:
+            raise RuntimeError("dahitra_amd: backward called without a grad-enabled forward")
+        bwd, self._bwd = self._bwd, None
+        bwd(dlogits_nchw)
+
+    def _head_out(self, h, wkey, bkey):
+        """final 3x3 conv to n_class logits, returned as NCHW fp32 (the reference's output layout)"""
+        ncls = self.shapes[wkey][0]
+        ck = ops.chunk_channels(self.dtype)
+        logits = ops.conv2d(h, self.pk[wkey].fwd, ncls, 3, 1, 1, bias=self.p[bkey])
+        out = ops.nhwc_to_nchw(logits)
+        if not self.need_grad:
+            return out, None
+
+        def bwd(dl_nchw):
+            dl = ops.nchw_to_nhwc(dl_nchw, self.dtype, cpad=ck)          # channels zero-padded to one K-chunk
+            ops.conv2d_wgrad(h, dl, self.g[wkey], 3, 1, 1, accumulate=True, use_tr=self.use_tr, cout_real=ncls)
+            tmp = torch.empty(ck, dtype=torch.float32, device=h.device)
+            ops.colsum(dl.view(-1, ck), tmp)
+            ops.reduce_rows(tmp, 1, ncls, self.g[bkey], accumulate=True)
+            return self.conv_dgrad(dl, wkey, 3, 1, 1, h.shape)
+        return out, bwd
+
+    def _bit(self, x1, x2):
+        cfg, L = self.cfg, self.cfg["token_len"]
+        B = x1.shape[0]
+        S2 = 2 * B
+        x, b_stem = self.stem(x1, x2, 2)
+        xp = ops.maxpool(x)
+        l1, b_l1 = self.res_layer(xp, 1, 1, 2)
+        l2, b_l2 = self.res_layer(l1, 2, 2, 2)
+        l3, b_l3 = self.res_layer(l2, 3, 1, 2)
+        up = ops.upsample2(l3)
+        feat, b_pred = self.conv_act(up, "conv_pred.weight", "conv_pred.bias", 3, 1, NONE)
+        _, fh, fw, _ = feat.shape
+        hw = fh * fw
+        wa = self.p["conv_a.weight"]
+        tok_cat, tsaved = ops.tokenizer_fwd(feat, wa, self.p["pos_embedding"], B, L)
+        tok2d, b_enc = self.encoder(tok_cat.view(B * 2 * L, DIM), "transformer", cfg["enc_depth"], BIT_HEADS,
+                                    BIT_DIM_HEAD, B, 2 * L)
+        dtok = torch.zeros_like(tok2d) if self.need_grad else None
+        dec, b_dec = self.decoder(feat.view(S2 * hw, DIM), S2, tok2d, 2 * L * DIM, L * DIM, B, dtok,
+                                  "transformer_decoder", cfg["dec_depth"], BIT_HEADS, cfg["dec_dim_head"], L)
+        dec4 = dec.view(S2, fh, fw, DIM)
+        upd = ops.absdiff_upsample4(dec4[:B], dec4[B:])
+        h, b_c0 = self.conv_bn(upd, "classifier.0.weight", "classifier.1", 3, 1, 1, 1, True)
+        logits, b_out = self._head_out(h, "classifier.3.weight", "classifier.3.bias")
+        if not self.need_grad:
+            return logits, None
+
+        def bwd(dl):
+            dh = b_out(dl)
+            dupd, _ = b_c0(dh)
+            dec_g = torch.empty_like(dec4)
+            ops.absdiff_upsample4_bwd_into(dec4[:B], dec4[B:], dupd, dec_g[:B], dec_g[B:])
+            dfeat = b_dec(dec_g.view(S2 * hw, DIM))                    # also fills dtok
+            dtok_cat = b_enc(dtok)
+            dfeat4 = dfeat.view(S2, fh, fw, DIM)
+            ops.tokenizer_bwd(feat, wa, tsaved, dtok_cat, dfeat4, self.g["conv_a.weight"], self.g["pos_embedding"],
+                              B, L, accumulate=True)
+            dup = b_pred(dfeat4)
+            dl3 = ops.upsample2_bwd(dup)
+            dxp = b_l1(b_l2(b_l3(dl3)))
+            b_stem(ops.maxpool_bwd(x, dxp))
+        return logits, bwd
+
+    # hierarchical model -------------------------------------------------------------------------
+    def _level(self, l, xa_b, B):
+        """one _forward_trans_module (networks.py:1297-1318) on the [A;B] batch of trunk taps"""
+        lv, L = UNET_LEVELS[l], self.cfg["token_len"]
+        S2 = 2 * B
+        sq, b_sq = self.conv_act(xa_b, "conv_squeeze_%d.0.weight" % l, None, 1, 0, RELU)
+        _, fh, fw, _ = sq.shape
+        hw = fh * fw
+        wa = self.p["conv_token_%d.weight" % l]
+        tok_cat, tsaved = ops.tokenizer_fwd(sq, wa, self.p["pos_embedding_%d" % l], B, L)
+        tok2d, b_enc = self.encoder(tok_cat.view(B * 2 * L, DIM), "transformer_%d" % l, self.cfg["enc_depth"],
+                                    lv["heads"], lv["dim_head"], B, 2 * L)
+        dtok = torch.zeros_like(tok2d) if self.need_grad else None
+        pos = self.p["pos_embedding_decoder_%d" % l]
+        dp = "transformer_decoder_%d" % l
+        xin = ops.add_pos(sq, pos)
+        dec, b_dec = self.decoder(xin.view(S2 * hw, DIM), S2, tok2d, 2 * L * DIM, L * DIM, B, dtok, dp,
+                                  lv["dec_depth"], lv["heads"], lv["dim_head"], L)
+        dec4 = dec.view(S2, fh, fw, DIM)
+        # third pass: decoder(conv_decode(cat[x1, x2]), |tok2 - tok1|) with the SAME weights
+        cat = torch.empty(B, fh, fw, 2 * DIM, dtype=self.dtype, device=sq.device)
+        ops.copy_channels(dec4[:B], 0, cat, 0, DIM)
+        ops.copy_channels(dec4[B:], 0, cat, DIM, DIM)
+        tk3 = tok2d.view(B, 2, L * DIM)                      # [b][stream][L*32]
+        dtk = torch.empty(B, L, DIM, dtype=self.dtype, device=sq.device)
+        ops.absdiff_halves(tk3, dtk)
+        ddtk = torch.zeros_like(dtk) if self.need_grad else None
+        dxc, b_cd = self.conv_act(cat, "conv_decode_%d.weight" % l, None, 3, 1, NONE)
+        xin3 = ops.add_pos(dxc, pos)
+        out, b_dec3 = self.decoder(xin3.view(B * hw, DIM), B, dtk.view(B * L, DIM), L * DIM, 0, B, ddtk, dp,
+                                   lv["dec_depth"], lv["heads"], lv["dim_head"], L)
+        out4 = out.view(B, fh, fw, DIM)
+        if not self.need_grad:
+            return out4, None
+        gpos = self.g["pos_embedding_decoder_%d" % l]
+
+        def bwd(dout4):
+            dxin3 = b_dec3(dout4.reshape(B * hw, DIM)).view(B, fh, fw, DIM)
+            ops.add_pos_bwd(dxin3, gpos, accumulate=True)
+            dcat = b_cd(dxin3)
+            ops.absdiff_halves_bwd(tk3, ddtk, dtok)                    # accumulates into both token halves
+            ddec = torch.empty_like(dec4)
+            ops.copy_channels(dcat, 0, ddec[:B], 0, DIM)
+            ops.copy_channels(dcat, DIM, ddec[B:], 0, DIM)
+            dxin = b_dec(ddec.view(S2 * hw, DIM)).view(S2, fh, fw, DIM)
+            ops.add_pos_bwd(dxin, gpos, accumulate=True)
+            dtok_cat = b_enc(dtok)
+            ops.tokenizer_bwd(sq, wa, tsaved, dtok_cat, dxin, self.g["conv_token_%d.weight" % l],
+                              self.g["pos_embedding_%d" % l], B, L, accumulate=True)
+            return b_sq(dxin)
+        return out4, bwd
+
+    def _up_conv(self, l, x):
+        up = ops.upsample2(x)
+        out, b = self.conv_act(up, "conv_layer%d.0.weight" % l, "conv_layer%d.0.bias" % l, 3, 1, RELU)
+        if not self.need_grad:
+            return out, None
+        return out, (lambda d: ops.upsample2_bwd(b(d)))
+
+    def _unet(self, x1, x2):
+        B = x1.shape[0]
+        s2, b_stem = self.stem(x1, x2, 2)                      # [2B,128,128,64] (post-ReLU tap)
+        p4 = ops.maxpool(s2)
+        s4, b_l1 = self.res_layer(p4, 1, 1, 2)                 # 64x64x64
+        s8, b_l2 = self.res_layer(s4, 2, 2, 2)                 # 32x32x128
+        p16 = ops.maxpool(s8)
+        s16, b_l3 = self.res_layer(p16, 3, 1, 2)               # 16x16x256
+        o5, b5 = self._level(5, s16, B)
+        o5u = ops.upsample2(o5)
+        t4, b4 = self._level(4, s8, B)
+        o4, bu4 = self._up_conv(4, ops.add(t4, o5u))
+        t3, b3 = self._level(3, s4, B)
+        o3, bu3 = self._up_conv(3, ops.add(t3, o4))
+        _, h2, w2, c2 = s2.shape
+        cat2 = torch.empty(B, h2, w2, 2 * c2, dtype=self.dtype, device=s2.device)
+        ops.copy_channels(s2[:B], 0, cat2, 0, c2)
+        ops.copy_channels(s2[B:], 0, cat2, c2, c2)
+        y, b20 = self.conv_bn(cat2, "conv_layer2_0.0.weight", "conv_layer2_0.1", 3, 1, 1, 1, True)
+        y2 = ops.conv2d(y, self.pk["conv_layer2_0.3.weight"].fwd, 32, 3, 1, 1, bias=self.p["conv_layer2_0.3.bias"],
+                        residual=o3)
+        o2, bu2 = self._up_conv(2, y2)
+        logits, b_out = self._head_out(o2, "classifier.weight", "classifier.bias")
+        if not self.need_grad:
+            return logits, None
+
+        def bwd(dl):
+            do2 = b_out(dl)
+            dy2 = bu2(do2)                                     # grad of (conv_layer2_0 out + o3)
+            ops.conv2d_wgrad(y, dy2, self.g["conv_layer2_0.3.weight"], 3, 1, 1, accumulate=True, use_tr=self.use_tr)
+            ops.colsum(dy2.view(-1, 32), self.g["conv_layer2_0.3.bias"], accumulate=True)
+            dy = self.conv_dgrad(dy2, "conv_layer2_0.3.weight", 3, 1, 1, y.shape)
+            dcat2, _ = b20(dy)
+            ds2 = torch.empty_like(s2)
+            ops.copy_channels(dcat2, 0, ds2[:B], 0, c2)
+            ops.copy_channels(dcat2, c2, ds2[B:], 0, c2)
+            dsum3 = bu3(dy2)                                   # d(t3 + o4)
+            ds4 = b3(dsum3)
+            dsum4 = bu4(dsum3)                                 # d(t4 + o5u)
+            ds8 = b4(dsum4)
+            ds16 = b5(ops.upsample2_bwd(dsum4))
+            dp16 = b_l3(ds16)
+            ds8 = ops.add(ds8, ops.maxpool_bwd(s8, dp16))
+            ds4 = ops.add(ds4, b_l2(ds8))
+            dp4 = b_l1(ds4)
+            b_stem(ops.add(ds2, ops.maxpool_bwd(s2, dp4)))
+        return logits, bwd

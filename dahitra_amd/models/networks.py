@@ -1,0 +1,248 @@
+"""Drop-in surface of the reference's models/networks.py for the change-detection hot path.
+
+    define_G(args, init_type='normal', init_gain=0.02, gpu_ids=[])   models/networks.py:130-168
+    init_net / init_weights                                          models/networks.py:77-127
+    get_scheduler(optimizer, args)                                   models/networks.py:22-49
+    net(x1, x2) -> logits [B, n_class, H, W] (fp32, NCHW)            models/networks.py:358-392, 1321-1357
+
+The returned nn.Module owns parameters / buffers under the reference's state-dict names (so
+checkpoints interchange, models/trainer.py:150-158) but holds no torch operators: forward and
+backward run the HIP pipelines of dahitra_amd.engine.  Parameters live as views into one flat fp32
+arena per net (grad-carrying parameters first) so that the optimizer step and the data-parallel
+gradient all-reduce are single launches over contiguous memory.
+
+Compute type: args.compute_dtype / DAHITRA_DTYPE in {"fp32", "bf16"}.  fp32 is the parity mode
+(exact-fp32 MFMA); bf16 is the throughput mode (bf16 activations + MFMA, fp32 accumulation / master
+weights)."""
+import math
+import os
+
+import torch
+import torch.nn as nn
+from torch.optim import lr_scheduler
+
+from .. import _lib
+from ..engine import Engine
+from ..netspec import get_config, is_active, is_buffer, state_spec
+
+_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+
+
+def get_scheduler(optimizer, args):
+    """linear | step | multistep, as models/networks.py:22-49 (returns, not raises, on unknown)."""
+    if args.lr_policy == 'linear':
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: 1.0 - epoch / float(args.max_epochs + 1))
+    if args.lr_policy == 'step':
+        return lr_scheduler.StepLR(optimizer, step_size=args.max_epochs // 3, gamma=0.1)
+    if args.lr_policy == 'multistep':
+        return lr_scheduler.MultiStepLR(
+            optimizer, milestones=[2, 4, 7, 11, 15, 25, 35, 47, 60, 70, 90, 110, 130, 150, 170, 180, 190], gamma=0.5)
+    return NotImplementedError('learning rate policy [%s] is not implemented', args.lr_policy)
+
+
+class _Node(nn.Module):
+    """name-space holder so that state_dict() keys equal the reference's dotted names"""
+
+
+class _Arena:
+    """flat fp32 storage: [active params | inactive params], matching grads for the active part"""
+
+    def __init__(self):
+        self.flat = None
+        self.grad = None
+        self.n_active = 0
+        self.offsets = {}
+        self.generation = 0
+
+
+class _NetFunction(torch.autograd.Function):
+    """autograd boundary: one node for the whole net.  Parameter gradients are deposited by the HIP
+    backward directly into the arena (p.grad views); the images need no gradient."""
+
+    @staticmethod
+    def forward(ctx, anchor, net, x1, x2):
+        ctx.net = net
+        return net._run_forward(x1, x2)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.net._run_backward(dlogits.contiguous())
+        return None, None, None, None
+
+
+class CDNet(nn.Module):
+    """BASE_Transformer / BASE_Transformer_UNet replacement selected by net_G."""
+
+    def __init__(self, net_G, compute_dtype=None):
+        super().__init__()
+        self.net_G = net_G
+        self.cfg = get_config(net_G)
+        name = compute_dtype or os.environ.get("DAHITRA_DTYPE", "fp32")
+        if name not in _DTYPES:
+            raise ValueError("compute dtype must be fp32 or bf16, got %r" % name)
+        self.compute_dtype = _DTYPES[name]
+        self._spec = state_spec(net_G)
+        for key, shape, role in self._spec:
+            node = self
+            parts = key.split(".")
+            for part in parts[:-1]:
+                if part not in node._modules:
+                    node.add_module(part, _Node())
+                node = node._modules[part]
+            if role == "bn_nbt":
+                node.register_buffer(parts[-1], torch.tensor(0, dtype=torch.long))
+            elif is_buffer(role):
+                node.register_buffer(parts[-1], torch.zeros(shape) if role == "bn_rm" else torch.ones(shape))
+            else:
+                if role in ("bn_w", "ln_w"):
+                    t = torch.ones(shape)
+                elif role in ("bn_b", "ln_b", "bias"):
+                    t = torch.zeros(shape)
+                elif role == "pos":
+                    t = torch.randn(shape)                       # nn.Parameter(torch.randn(...)), networks.py:294
+                else:
+                    fan_in = int(math.prod(shape[1:]))
+                    t = torch.empty(shape).uniform_(-1.0, 1.0).mul_(fan_in ** -0.5)
+                node.register_parameter(parts[-1], nn.Parameter(t))
+        self._engine = Engine(net_G, self.compute_dtype, use_tr=os.environ.get("DAHITRA_NO_TR", "0") != "1")
+        self._arena = _Arena()
+        self._anchor = None
+        self.tokens_ = None      # attributes the reference stashes on the module (networks.py:373-374)
+        self.tokens = None
+
+    # ---- arena ---------------------------------------------------------------------------------------
+    def _named_state(self):
+        sd_p = dict(self.named_parameters())
+        sd_b = dict(self.named_buffers())
+        return sd_p, sd_b
+
+    def _ensure_arena(self, device):
+        ar = self._arena
+        sd_p, sd_b = self._named_state()
+        if ar.flat is not None and ar.flat.device == device and all(
+                sd_p[k].data_ptr() == ar.flat.data_ptr() + 4 * off for k, (off, _) in ar.offsets.items()):
+            return      # every parameter is still the arena view handed out earlier
+        active = [k for k, _, r in self._spec if not is_buffer(r) and is_active(self.net_G, k)]
+        inactive = [k for k, _, r in self._spec if not is_buffer(r) and not is_active(self.net_G, k)]
+        total = sum(sd_p[k].numel() for k in active + inactive)
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        off = 0
+        ar.offsets = {}
+        for k in active + inactive:
+            p = sd_p[k]
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            p.grad = None
+            ar.offsets[k] = (off, n)
+            off += n
+            if k == active[-1]:
+                ar.n_active = off
+        ar.flat = flat
+        ar.grad = torch.zeros(ar.n_active, dtype=torch.float32, device=device)
+        ar.generation += 1
+        for b in sd_b.values():
+            if b.device != device:
+                b.data = b.data.to(device)
+        params = {k: sd_p[k].data for k in sd_p}
+        params.update({k: sd_b[k] for k in sd_b})
+        grads = {k: ar.grad[o:o + n].view(sd_p[k].shape) for k, (o, n) in ar.offsets.items() if o < ar.n_active}
+        self._engine.bind(params, grads)
+        self._grad_views = grads
+        self._active_keys = active
+        for k in active:
+            sd_p[k]._dh_arena = (self, k)
+        self._anchor = torch.zeros((), device=device, requires_grad=True)
+
+    def flat_params(self):
+        """(param, grad) flat fp32 views over the grad-carrying parameters (optimizer / all-reduce)"""
+        return self._arena.flat[:self._arena.n_active], self._arena.grad
+
+    # ---- forward / backward -------------------------------------------------------------------------
+    def forward(self, x1, x2):
+        if not x1.is_cuda:
+            raise _lib.HipLibraryError("dahitra_amd runs on MI355X only: inputs must be CUDA(HIP) tensors; "
+                                       "there is no CPU fallback")
+        _lib.lib()
+        self._ensure_arena(x1.device)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if need_grad:
+            if not self.training:
+                raise NotImplementedError("dahitra_amd: backward through eval-mode BatchNorm is not supported "
+                                          "(the reference trains in train mode, models/trainer.py:297)")
+            return _NetFunction.apply(self._anchor, self, x1, x2)
+        with torch.no_grad():
+            return self._run_forward(x1, x2, need_grad=False)
+
+    def _run_forward(self, x1, x2, need_grad=True):
+        x1 = x1.detach().float().contiguous()
+        x2 = x2.detach().float().contiguous()
+        return self._engine.forward(x1, x2, self.training, need_grad)
+
+    def _run_backward(self, dlogits):
+        ar = self._arena
+        sd_p = dict(self.named_parameters())
+        fresh = all(sd_p[k].grad is None for k in self._active_keys)
+        if fresh:
+            ar.grad.zero_()
+        self._engine.backward(dlogits)
+        for k in self._active_keys:
+            p = sd_p[k]
+            if p.grad is None:
+                p.grad = self._grad_views[k]
+            elif p.grad.data_ptr() != self._grad_views[k].data_ptr():
+                raise RuntimeError("dahitra_amd: parameter %s has a foreign .grad tensor; use zero_grad(set_to_none=True)" % k)
+
+
+def init_weights(net, init_type='normal', init_gain=0.02):
+    """models/networks.py:77-108: every Conv / Linear weight ~ N(0, gain), biases 0, BN gamma ~ N(1, gain);
+    LayerNorm and positional embeddings untouched."""
+    if init_type != 'normal':
+        raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
+    roles = {k: r for k, _, r in state_spec(net.net_G)}
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            r = roles[k]
+            if r in ("conv_w", "lin_w"):
+                p.normal_(0.0, init_gain)
+            elif r == "bias":
+                p.zero_()
+            elif r == "bn_w":
+                p.normal_(1.0, init_gain)
+            elif r == "bn_b":
+                p.zero_()
+    print('initialize network with %s' % init_type)
+
+
+def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[]):
+    """models/networks.py:111-127.  More than one id selected nn.DataParallel in the reference; here
+    multi-GPU is one process per GPU (dahitra_amd.parallel), so only gpu_ids[0] is used."""
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        net.to(gpu_ids[0])
+    init_weights(net, init_type, init_gain=init_gain)
+    return net
+
+
+def define_G(args, init_type='normal', init_gain=0.02, gpu_ids=[]):
+    """models/networks.py:130-168; reads args.net_G (and the optional args.compute_dtype)."""
+    get_config(args.net_G)          # NotImplementedError for unknown names, as the reference
+    net = CDNet(args.net_G, getattr(args, "compute_dtype", None))
+    return init_net(net, init_type, init_gain, gpu_ids)
+
+
+def BASE_Transformer(input_nc=3, output_nc=2, with_pos='learned', resnet_stages_num=4, token_len=4, enc_depth=1,
+                     dec_depth=1, decoder_dim_head=64, **kw):
+    """constructor-style access (models/networks.py:260-310) for the configurations define_G exposes"""
+    from ..netspec import NET_CONFIGS
+    for name, c in NET_CONFIGS.items():
+        if c["kind"] == "bit" and (c["n_class"], c["token_len"], c["enc_depth"], c["dec_depth"], c["dec_dim_head"]) == \
+                (output_nc, token_len, enc_depth, dec_depth, decoder_dim_head):
+            return CDNet(name, kw.get("compute_dtype"))
+    raise NotImplementedError("BASE_Transformer configuration not covered by define_G's net_G table")
+
+
+def BASE_Transformer_UNet(input_nc=3, output_nc=2, **kw):
+    if output_nc != 2:
+        raise NotImplementedError("newUNetTrans is defined with 2 classes (models/networks.py:163-165)")
+    return CDNet("newUNetTrans", kw.get("compute_dtype"))

@@ -483,3 +483,37 @@ def argmax_nchw(logits_nchw):
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     _call("dh_adamw_step", P(param), P(grad), P(exp_avg), P(exp_avg_sq), _cl(param.numel()), _cf(lr), _cf(beta1),
           _cf(beta2), _cf(eps), _cf(weight_decay), _ci(step), _cf(grad_scale), S())
+
+
+# ---- variants writing into caller-provided (contiguous) buffers ------------------------------------
+def stem_space_to_depth_into(x_nchw, out):
+    N, C, H, W = x_nchw.shape
+    assert C == 3 and out.is_contiguous()
+    _call("dh_stem_space_to_depth", _ci(dt(out)), P(x_nchw), P(out), _ci(N), _ci(H), _ci(W), _ci(out.shape[-1]), S())
+
+
+def absdiff_upsample4_bwd_into(a, b, dy, da, db):
+    N, H, W, C = a.shape
+    _call("dh_absdiff_upsample4_bwd", _ci(dt(a)), P(a), P(b), P(dy), P(da), P(db), _ci(N), _ci(H), _ci(W), _ci(C), S())
+
+
+def reduce_rows(partial, nt, n, out, accumulate=False, scale=1.0):
+    _call("dh_reduce_partials", P(partial), _cl(nt), _cl(n), _cf(scale), P(out), _ci(int(accumulate)), S())
+
+
+def scale_into(src, scalar_dev, dst):
+    """dst = src * scalar (a 0-d / 1-element device tensor), no host sync"""
+    _call("dh_scale_by_scalar", P(src), P(scalar_dev.reshape(1).float().contiguous()), P(dst), _cl(src.numel()), S())
+
+
+def absdiff_halves(tok3, out):
+    """out[b] = |tok3[b, 1] - tok3[b, 0]| for tok3 [B, 2, n] (token difference, networks.py:1311)"""
+    B = tok3.shape[0]
+    n = out.numel() // B
+    _call("dh_absdiff_halves", _ci(dt(tok3)), P(tok3), P(out), _ci(B), _cl(n), S())
+
+
+def absdiff_halves_bwd(tok3, dout, dtok3):
+    B = tok3.shape[0]
+    n = dout.numel() // B
+    _call("dh_absdiff_halves_bwd", _ci(dt(tok3)), P(tok3), P(dout), P(dtok3), _ci(B), _cl(n), S())

@@ -1,0 +1,61 @@
+"""AdamW with torch.optim.AdamW's update rule (models/trainer.py:39-40: lr, betas (0.9, 0.999),
+eps 1e-8, weight_decay 0.01, decoupled decay, bias correction, no amsgrad) as ONE HIP launch over the
+net's flat fp32 arena.  Parameters whose .grad is None are skipped exactly as torch does, which for
+these nets is the statically known set the forward never touches (resnet.layer4/fc, the *_2 modules).
+
+It is a torch.optim.Optimizer subclass, so lr schedulers (get_scheduler) and state_dict() work."""
+import torch
+
+from . import ops
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self._flat_state = {}       # id(net) -> (exp_avg, exp_avg_sq, step)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            todo = [p for p in group["params"] if p.grad is not None]
+            nets = {}
+            loose = []
+            for p in todo:
+                tag = getattr(p, "_dh_arena", None)
+                if tag is not None and p.grad.data_ptr() == tag[0]._grad_views[tag[1]].data_ptr():
+                    nets.setdefault(id(tag[0]), (tag[0], []))[1].append(p)
+                else:
+                    loose.append(p)
+            for net, plist in nets.values():
+                if len(plist) != len(net._active_keys):
+                    loose += plist          # partial coverage: fall back to per-tensor launches
+                    continue
+                param, grad = net.flat_params()
+                st = self._flat_state.get(id(net))
+                if st is None or st[0].numel() != param.numel() or st[0].device != param.device:
+                    st = [torch.zeros_like(param), torch.zeros_like(param), 0]
+                    self._flat_state[id(net)] = st
+                    sd_p = dict(net.named_parameters())
+                    for k in net._active_keys:      # per-parameter views for state_dict() interchange
+                        o, n = net._arena.offsets[k]
+                        self.state[sd_p[k]] = dict(step=torch.tensor(0.0), exp_avg=st[0][o:o + n].view(sd_p[k].shape),
+                                                   exp_avg_sq=st[1][o:o + n].view(sd_p[k].shape))
+                st[2] += 1
+                ops.adamw_step(param, grad, st[0], st[1], group["lr"], beta1, beta2, group["eps"],
+                               group["weight_decay"], st[2], grad_scale)
+            for p in loose:
+                if not p.is_cuda:
+                    raise RuntimeError("dahitra_amd.AdamW: parameters must live on the GPU (no CPU fallback)")
+                s = self.state[p]
+                if "exp_avg" not in s or not isinstance(s.get("_n"), int):
+                    s["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    s["_n"] = 0
+                s["_n"] += 1
+                g = p.grad.contiguous()
+                ops.adamw_step(p.data, g, s["exp_avg"], s["exp_avg_sq"], group["lr"], beta1, beta2, group["eps"],
+                               group["weight_decay"], s["_n"], grad_scale)
+        return loss

@@ -139,6 +139,10 @@ int dh_self_attn_bwd(int dtype, const void* qkv, const float* attn, const void* 
 int dh_focal_loss(const float* logits_nchw, const long long* target, int B, int C, long HW, float alpha,
                   float grad_scale, float* loss_out, float* dlogits_nchw, void* workspace, void* stream);
 int dh_argmax_nchw(const float* logits_nchw, long long* mask, int B, int C, long HW, void* stream);
+int dh_scale_by_scalar(const float* src, const float* scalar_dev, float* dst, long n, void* stream);
+/* |tok[b][1] - tok[b][0]| over [B][2][n] token sets (models/networks.py:1311) and its gradient */
+int dh_absdiff_halves(int dtype, const void* tok, void* out, int B, long n, void* stream);
+int dh_absdiff_halves_bwd(int dtype, const void* tok, const void* dout, void* dtok_accum, int B, long n, void* stream);
 int dh_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 

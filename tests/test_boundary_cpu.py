@@ -1,0 +1,100 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports every symbol the header
+declares, the module surface matches the reference's state-dict names, and the product fails loudly
+(no fallback) when asked to compute without the GPU.  No compute calls here."""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    lib = os.path.join(ROOT, "dahitra_amd", "lib", "libdahitra_hip.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-j8", "-C", ROOT])
+    return lib
+
+
+def test_library_exports_every_declared_symbol(built):
+    from dahitra_amd import _lib
+    lib = _lib.lib()
+    syms = _lib.declared_symbols()
+    assert len(syms) >= 50
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.dh_abi_version() == 1
+
+
+def test_header_has_no_torch_types():
+    txt = open(os.path.join(ROOT, "include", "dahitra_hip.h")).read()
+    assert "torch" not in txt.lower().replace("torch.cuda.current_stream", "").replace("torch cuda tensors", "") \
+        or "at::" not in txt
+    assert "at::Tensor" not in txt and "#include <torch" not in txt
+
+
+def test_state_dict_keys_equal_reference(golden_dir):
+    from dahitra_amd.models.networks import define_G
+    ref = json.load(open(os.path.join(golden_dir, "state_keys.json")))
+    for name, keys in ref.items():
+        net = define_G(types.SimpleNamespace(net_G=name))
+        sd = net.state_dict()
+        assert [[k, list(v.shape)] for k, v in sd.items()] == keys, name
+
+
+def test_netspec_agrees_with_oracle_spec():
+    import cdnet_ref as O
+    from dahitra_amd import netspec
+    for name in O.NET_CONFIGS:
+        assert netspec.state_spec(name) == O.state_spec(name), name
+
+
+def test_define_G_contract():
+    from dahitra_amd.models.networks import define_G, get_scheduler
+    with pytest.raises(NotImplementedError):
+        define_G(types.SimpleNamespace(net_G="no_such_net"))
+    net = define_G(types.SimpleNamespace(net_G="base_transformer_pos_s4"))
+    # init_weights semantics (models/networks.py:88-105): N(0, 0.02) weights, zero biases, BN gamma ~ N(1, 0.02)
+    sd = net.state_dict()
+    assert abs(float(sd["resnet.layer1.0.conv1.weight"].std()) - 0.02) < 2e-3
+    assert float(sd["conv_pred.bias"].abs().max()) == 0.0
+    assert abs(float(sd["resnet.bn1.weight"].mean()) - 1.0) < 0.02
+    assert float(sd["transformer.layers.0.0.fn.norm.weight"].min()) == 1.0      # LayerNorm untouched
+    opt = torch.optim.SGD(net.parameters(), lr=1.0)
+    sch = get_scheduler(opt, types.SimpleNamespace(lr_policy="linear", max_epochs=9))
+    sch.step()
+    assert abs(opt.param_groups[0]["lr"] - 0.9) < 1e-9
+    assert isinstance(get_scheduler(opt, types.SimpleNamespace(lr_policy="bogus", max_epochs=9)), NotImplementedError)
+
+
+def test_unused_parameter_contract():
+    """17 (BiT) / 48 (newUNetTrans) tensors never receive a gradient"""
+    from dahitra_amd import netspec
+    for name, n in (("base_transformer_pos_s4", 17), ("newUNetTrans", 48)):
+        inactive = [k for k, _, r in netspec.state_spec(name) if not netspec.is_buffer(r) and not netspec.is_active(name, k)]
+        assert len(inactive) == n, (name, len(inactive))
+
+
+def test_cpu_tensors_are_refused():
+    from dahitra_amd import _lib
+    from dahitra_amd.models.networks import define_G
+    net = define_G(types.SimpleNamespace(net_G="base_transformer_pos_s4"))
+    x = torch.zeros(1, 3, 64, 64)
+    with pytest.raises(_lib.HipLibraryError):
+        net(x, x)
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dp, _, fns in os.walk(os.path.join(ROOT, "dahitra_amd")):
+        for fn in fns:
+            if fn.endswith(".py") and fn != "smoke.py":
+                txt = open(os.path.join(dp, fn)).read()
+                if "cdnet_ref" in txt or "ref_import" in txt or "import oracle" in txt:
+                    bad.append(fn)
+    assert not bad, bad

@@ -186,8 +186,9 @@ def test_batchnorm_train_two_streams_and_backward(ops, dtype):
     rcat = dev(nhwc(torch.cat(res)), dtype)
     y = ops.bn_apply(xconv, scale, shift, groups=2, act=ops.ACT_RELU, residual=rcat)
     close(nchw(y), torch.cat(outs).detach(), dtype, "bn fwd")
-    close(rmd, rm, torch.float32, "running_mean", factor=5)
-    close(rvd, rv, torch.float32, "running_var", factor=5)
+    # (in bf16 mode the device input is the bf16 rounding of xs, so the statistics move by ~2^-9)
+    close(rmd, rm, dtype, "running_mean", factor=5 if dtype == torch.float32 else 0.5)
+    close(rvd, rv, dtype, "running_var", factor=5 if dtype == torch.float32 else 0.5)
     dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     dx, dres = ops.bn_bwd(dev(nhwc(torch.cat(dout)), dtype), y, xconv, mean, invstd, g, dg, db, groups=2,
                           want_dres=True)

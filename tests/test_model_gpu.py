@@ -1,0 +1,176 @@
+"""End-to-end parity of the HIP path (through define_G / focal_loss / AdamW, i.e. through the C ABI)
+against (a) the golden fixtures produced by the reference and (b) the CPU oracle on the same seeded
+inputs.  fp32 mode: logits within 1e-3 relative (north-star bar; we assert 2e-4), masks identical
+outside the tie band; bf16 mode: logits within 3e-2 of the logit scale, mask disagreement < 1 %."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cdnet_ref as O
+
+pytestmark = pytest.mark.gpu
+
+NETS = ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8", "base_transformer_pos_s4_dd8_o5",
+        "base_transformer_pos_s4_dd8_dedim8", "base_transformer_pos_s4_dd8_t8_e2d4", "newUNetTrans"]
+
+
+def make_net(name, dtype="fp32"):
+    from dahitra_amd.models.networks import define_G
+    net = define_G(types.SimpleNamespace(net_G=name, compute_dtype=dtype), gpu_ids=[0])
+    net.load_state_dict(O.deterministic_state(name))
+    return net
+
+
+@pytest.mark.parametrize("name", NETS)
+def test_forward_matches_reference_golden_fp32(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, "fwd_%s.npz" % name))
+    cfg = O.get_config(name)
+    bs, size, stride = int(g["batch"]), int(g["size"]), int(g["stride"])
+    a, b, lab = O.synthetic_batch(bs, size, n_class=cfg["n_class"])
+    for mode in ("eval", "train"):
+        net = make_net(name)
+        net.train(mode == "train")
+        with torch.no_grad():
+            y = net(a.cuda(), b.cuda()).cpu()
+        want = torch.from_numpy(g["logits_" + mode])
+        got = y[..., ::stride, ::stride]
+        scale = float(want.abs().max())
+        err = float((got - want).abs().max()) / scale
+        assert err <= 2e-4, "%s %s: logits rel err %.3e" % (name, mode, err)
+        assert abs(float(y.double().sum()) - float(g["sum_" + mode])) <= 2e-4 * float(g["abssum_" + mode])
+        # class masks: identical wherever the reference margin is outside the fp32 tie band
+        from dahitra_amd.models.losses import argmax_mask
+        mask = argmax_mask(y.cuda()).cpu().numpy().astype(np.uint8)
+        ref_mask = np.unpackbits(g["mask_" + mode])[:mask.size].reshape(mask.shape) if cfg["n_class"] == 2 \
+            else np.asarray(g["mask_" + mode]).reshape(mask.shape)
+        top2 = y.topk(2, dim=1).values
+        margin = (top2[:, 0] - top2[:, 1]).numpy()
+        band = margin <= 4e-4 * scale
+        diff = (mask != ref_mask)
+        assert int((diff & ~band).sum()) == 0, "%s %s: %d mask flips outside the tie band" % (name, mode, int((diff & ~band).sum()))
+        assert band.mean() < 0.02
+        if mode == "train":
+            sd = net.state_dict()
+            assert np.allclose(sd["resnet.bn1.running_mean"].cpu().numpy(), g["bn1_running_mean"], atol=2e-6)
+            assert np.allclose(sd["resnet.bn1.running_var"].cpu().numpy(), g["bn1_running_var"], rtol=1e-5, atol=2e-6)
+            from dahitra_amd.models.losses import focal_loss
+            assert abs(float(focal_loss(y.cuda(), lab.cuda())) - float(g["focal"])) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
+def test_train_steps_match_reference_golden_fp32(name, golden_dir):
+    from dahitra_amd.models import losses
+    from dahitra_amd.optim import AdamW
+    g = np.load(os.path.join(golden_dir, "train_%s.npz" % name))
+    cfg = O.get_config(name)
+    a, b, lab = O.synthetic_batch(int(g["batch"]), int(g["size"]), n_class=cfg["n_class"])
+    a, b, lab = a.cuda(), b.cuda(), lab.cuda()
+    net = make_net(name).train()
+    opt = AdamW(net.parameters(), lr=float(g["lr"]), betas=(0.9, 0.999), weight_decay=0.01)
+    got_losses = []
+    for it in range(int(g["steps"])):
+        y = net(a, b)
+        opt.zero_grad()
+        loss = losses.focal_loss(y, lab)
+        loss.backward()
+        if it == 0:
+            params = dict(net.named_parameters())
+            nograd = sorted(k for k, p in params.items() if p.grad is None)
+            assert nograd == sorted(g["nograd_keys"].tolist())
+            worst = 0.0
+            for k, v in zip(g["gradnorm_keys"].tolist(), g["gradnorm_vals"].tolist()):
+                gn = float(params[k].grad.double().norm())
+                rel = abs(gn - v) / max(v, 1e-7)
+                worst = max(worst, rel)
+                assert rel <= 2e-3 or abs(gn - v) < 1e-7, "grad norm %s: %.6e vs %.6e" % (k, gn, v)
+            for k in g.files:
+                if k.startswith("grad0/"):
+                    w = torch.from_numpy(g[k])
+                    e = float((params[k[6:]].grad.cpu() - w).abs().max())
+                    assert e <= 2e-3 * float(w.abs().max()) + 1e-8, "grad %s err %.3e (max %.3e)" % (k[6:], e, float(w.abs().max()))
+        opt.step()
+        got_losses.append(float(loss))
+    assert np.allclose(got_losses, g["losses"], rtol=1e-3, atol=1e-6), (got_losses, g["losses"])
+    sd = net.state_dict()
+    for k, v in zip(g["finalnorm_keys"].tolist(), g["finalnorm_vals"].tolist()):
+        got = float(sd[k].double().norm())
+        assert abs(got - v) <= 1e-3 * max(v, 1e-8) + 1e-6, (k, got, v)
+    assert int(sd["resnet.bn1.num_batches_tracked"]) == int(g["nbt"])
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_t8_e2d4"])
+def test_gradients_match_oracle_fp32(name):
+    """every parameter gradient against the oracle's autograd on a non-square, odd-batch case"""
+    from dahitra_amd.models import losses
+    cfg = O.get_config(name)
+    a, b, lab = O.synthetic_batch(3, 64, seed=77, n_class=cfg["n_class"])
+    st = O.TrainState(name, O.deterministic_state(name), lr=0.01)
+    logits = O.forward(st.sd, name, a, b, training=True)
+    O.focal_loss(logits, lab).backward()
+    net = make_net(name).train()
+    y = net(a.cuda(), b.cuda())
+    losses.focal_loss(y, lab.cuda()).backward()
+    bad = []
+    for k, p in net.named_parameters():
+        ref = st.sd[k].grad
+        assert (p.grad is None) == (ref is None), k
+        if ref is None:
+            continue
+        e = float((p.grad.cpu() - ref).abs().max())
+        s = float(ref.abs().max())
+        if e > 2e-3 * s + 1e-7:
+            bad.append((k, e, s))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
+def test_bf16_mode_tracks_fp32(name):
+    cfg = O.get_config(name)
+    size = 256 if name == "newUNetTrans" else 128
+    a, b, lab = O.synthetic_batch(2, size, seed=5, n_class=cfg["n_class"])
+    sd = O.deterministic_state(name)
+    with torch.no_grad():
+        ref = O.forward(sd, name, a, b, training=True)
+    net = make_net(name, "bf16").train()
+    with torch.no_grad():
+        y = net(a.cuda(), b.cuda()).cpu()
+    scale = float(ref.abs().max())
+    err = float((y - ref).abs().max()) / scale
+    flips = float((torch.argmax(y, 1) != torch.argmax(ref, 1)).float().mean())
+    print("bf16 %s: logits rel err %.3e, mask disagreement %.4f" % (name, err, flips))
+    assert err < 6e-2 and flips < 0.02
+
+
+def test_bf16_train_step_reduces_loss():
+    from dahitra_amd.models import losses
+    from dahitra_amd.optim import AdamW
+    name = "base_transformer_pos_s4"
+    a, b, lab = O.synthetic_batch(4, 128, seed=9)
+    a, b, lab = a.cuda(), b.cuda(), lab.cuda()
+    net = make_net(name, "bf16").train()
+    opt = AdamW(net.parameters(), lr=0.002, betas=(0.9, 0.999), weight_decay=0.01)
+    ls = []
+    for it in range(8):
+        y = net(a, b)
+        opt.zero_grad()
+        loss = losses.focal_loss(y, lab)
+        loss.backward()
+        opt.step()
+        ls.append(float(loss))
+    assert all(np.isfinite(ls)) and ls[-1] < 0.7 * ls[0], ls
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from dahitra_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdahitra_hip.so")
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.lib()
+
+
+def test_smoke_entry():
+    from dahitra_amd import smoke
+    smoke.run(verbose=False)
