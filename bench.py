@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 256x256 image-pairs/s of one full change-detection TRAIN step
+(forward + focal loss + backward + gradient all-reduce + AdamW) of base_transformer_pos_s4 in bf16,
+32 pairs per GPU (BASELINE.json configs[1]; configs[2] = the same at N = 8), inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the dominant kernel class (3x3 MFMA direct conv, all its launches of a step): algorithmic
+                  FLOPs / HIP-event time, against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md)
+  cpu_baseline -- the CPU oracle (a port of the reference's step, oracle/cdnet_ref.py) timed on this host
+                  on a bounded sample (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NET = "base_transformer_pos_s4"
+SIZE = 256
+PER_GPU_BATCH = 32
+GFLOP_PER_PAIR = 50.20          # BASELINE.md section 2 (fwd+bwd, algorithmic, FlopCounterMode on the reference)
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def synthetic(batch, size, seed, device):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(batch, 3, size, size, generator=g).clamp_(-1, 1)
+    b = torch.randn(batch, 3, size, size, generator=g).clamp_(-1, 1)
+    lab = (torch.rand(batch, 1, size, size, generator=g) > 0.95).to(torch.int64)
+    return a.to(device), b.to(device), lab.to(device)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """the oracle's train step (port of models/trainer.py:302-308) on the host cores"""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cdnet_ref as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    bs = 4
+    a, b, lab = O.synthetic_batch(bs, SIZE, seed=1234)
+    st = O.TrainState(NET, O.deterministic_state(NET), lr=0.01)
+    st.step(a, b, lab)                      # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 12):
+        st.step(a, b, lab)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(bs * n / dt, 3), "unit": "image-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d train steps of batch %d, %s fp32 256x256 (oracle/cdnet_ref.py, torch CPU)" % (n, bs, NET)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--net", default=NET)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="pairs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true", help="report eval-mode forward pairs/s instead")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from dahitra_amd import ops, parallel
+    from dahitra_amd.models import losses
+    from dahitra_amd.models.networks import define_G
+    from dahitra_amd.optim import AdamW
+
+    rank, local, world = parallel.init_from_env("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    net = define_G(types.SimpleNamespace(net_G=args.net, compute_dtype=args.dtype), gpu_ids=[local])
+    net.train(not args.fwd_only)
+    opt = AdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    a, b, lab = synthetic(args.batch, SIZE, 1234 + rank, dev)
+    net._ensure_arena(dev)
+    parallel.broadcast_params_(net)
+
+    def step():
+        if args.fwd_only:
+            with torch.no_grad():
+                return net(a, b)
+        logits = net(a, b)
+        opt.zero_grad()
+        loss = losses.focal_loss(logits, lab)
+        loss.backward()
+        scale = parallel.allreduce_net_grads_(net)
+        opt.step(grad_scale=scale)
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final = float(out) if not args.fwd_only else 0.0
+
+    # ---- roofline of the dominant kernel class: HIP events around every MFMA-conv launch (2 extra steps) ----
+    roof = None
+    if rank == 0:
+        ops.PROFILE = {}
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for key, recs in prof.items():
+            ms = sum(e[0].elapsed_time(e[1]) for e, _, _ in recs)
+            agg[key] = (ms, sum(f for _, f, _ in recs), len(recs))
+        if agg:
+            key = max(agg, key=lambda k: agg[k][0])
+            ms, fl, n = agg[key]
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": key, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n // 2,
+                    "avg_launch_us": round(ms * 1e3 / n, 2),
+                    "all_mfma_conv_ms_per_step": round(sum(v[0] for v in agg.values()) / 2, 3)}
+
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        res = {
+            "metric": "image-pairs/s (256x256) %s, 1/2/4/8 MI355X + CPU ref" % ("eval forward" if args.fwd_only else "train step"),
+            "value": round(pairs / dt, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "LEVIR-CD 256x256 synthetic pairs, %s, %s, batch %d per GPU (global %d), "
+                                   "fwd+focal+bwd+allreduce+AdamW" % (args.net, args.dtype, args.batch, args.batch * world),
+                       "net_G": args.net, "global_batch": args.batch * world, "img_size": SIZE,
+                       "parallelism": "dp%d" % world, "final_loss": round(final, 6),
+                       "step_tflops": round(pairs / dt * GFLOP_PER_PAIR / 1e3, 2) if args.net == NET and not args.fwd_only else None},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,9 +68,11 @@ class Engine:
     # ---- primitive units -------------------------------------------------------------------------
     def conv_dgrad(self, dy, wkey, ks, stride, pad, xshape, residual=None):
         N, H, W, Cin = xshape
+        flops = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * self.shapes[wkey][0] * Cin * ks * ks   # algorithmic
         if stride == 2:
             dy = ops.zero_insert2(dy, H, W)
-        return ops.conv2d(dy, self.pk[wkey].dgrad, Cin, ks, 1, ks - 1 - pad, residual=residual, out_hw=(H, W))
+        return ops.conv2d(dy, self.pk[wkey].dgrad, Cin, ks, 1, ks - 1 - pad, residual=residual, out_hw=(H, W),
+                          alg_flops=flops)
 
     def conv_bn(self, x, wkey, bnkey, ks, stride, pad, groups, relu, residual=None):
         cout = self.shapes[wkey][0]

@@ -84,8 +84,11 @@ def pack_weight(w, dtype, want_dgrad=True, dgrad_inner=0):
 
 
 # ---- convolution / linear ------------------------------------------------------------------------
+PROFILE = None       # set to {} by bench.py to collect (events, algorithmic flops, bytes) per conv launch
+
+
 def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT_NONE, want_stats=False,
-           want_preact=False, npix_valid=0, w_image_stride=0, out_hw=None):
+           want_preact=False, npix_valid=0, w_image_stride=0, out_hw=None, alg_flops=0):
     N, H, W, Cin = x.shape
     if out_hw is None:
         OH = (H + 2 * pad - ks) // stride + 1
@@ -99,9 +102,20 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     if want_stats:
         nt = _lib.lib().dh_conv2d_fwd_num_tiles(N, OH, OW)
         stats = torch.empty(nt, 2, cpad, dtype=torch.float32, device=x.device)
+    ev = None
+    if PROFILE is not None:      # bench.py: HIP events on the launch stream around this kernel class
+        nt = 64 if cpad % 64 == 0 else (32 if cpad % 32 == 0 else 16)
+        key = "conv_mfma<%s,ks%d,s%d,nt%d>" % ("bf16" if x.dtype == torch.bfloat16 else "f32", ks, stride, nt)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        flops = alg_flops if alg_flops else 2.0 * N * OH * OW * cout * Cin * ks * ks
+        bytes_ = (x.numel() + y.numel() + wp.numel()) * x.element_size()
+        PROFILE.setdefault(key, []).append((ev, flops, bytes_))
+        ev[0].record()
     _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
           _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
           _cl(w_image_stride), P(pre), S())
+    if ev is not None:
+        ev[1].record()
     out = [y]
     if want_stats:
         out.append(stats)

@@ -1,0 +1,59 @@
+"""Data parallelism for the change-detection train step: one process per GPU, image pairs sharded by
+rank, BatchNorm statistics per replica (what the reference's nn.DataParallel does,
+models/networks.py:121-125), and ONE all-reduce per step over the net's flat fp32 gradient arena
+(only grad-carrying parameters: 12.0 MB for base_transformer_pos_s4, 16.8 MB for newUNetTrans).
+
+backend "nccl" is RCCL on ROCm; on an 8xMI355X node the ring runs over xGMI.  The 1/world factor of
+the mean is folded into the AdamW kernel's grad_scale, so the reduced buffer is consumed as is."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_batch(global_batch, rank, world):
+    """contiguous, equal shards (equal sizes make mean-of-shard-means == global mean of the focal loss)"""
+    if global_batch % world:
+        raise ValueError("global batch %d is not divisible by world size %d" % (global_batch, world))
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_sum_(flat, group=None):
+    """in-place SUM all-reduce of a flat gradient buffer; returns the factor (1/world) that turns it
+    into the mean (pass it to AdamW.step(grad_scale=...))."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 1.0
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / dist.get_world_size(group)
+
+
+def allreduce_net_grads_(net, group=None):
+    """all-reduce the whole gradient arena of a dahitra_amd CDNet in one collective"""
+    _, grad = net.flat_params()
+    return allreduce_sum_(grad, group)
+
+
+def broadcast_params_(net, src=0, group=None):
+    """replicas start from rank `src`'s parameters and BN buffers"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    flat = net._arena.flat
+    dist.broadcast(flat, src=src, group=group)
+    for b in net.buffers():
+        dist.broadcast(b, src=src, group=group)

@@ -21,6 +21,9 @@ def run(net_G="base_transformer_pos_s4", batch=2, size=64, verbose=True):
     opt = AdamW(net.parameters(), lr=0.01, betas=(0.9, 0.999), weight_decay=0.01)
     st = O.TrainState(net_G, sd, lr=0.01)
     for it in range(2):
+        # teacher forcing: every step starts from the oracle's current weights / BN buffers, because an
+        # Adam trajectory amplifies fp32-noise-level gradient differences (first update = lr*sign(g))
+        net.load_state_dict({k: v.detach() for k, v in st.sd.items()})
         logits = net(a.cuda(), b.cuda())
         opt.zero_grad()
         loss = losses.focal_loss(logits, lab.cuda())

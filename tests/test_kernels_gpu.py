@@ -162,7 +162,7 @@ def test_linear_rows_gelu_and_per_image_weights(ops, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_batchnorm_train_two_streams_and_backward(ops, dtype):
     B, C, H, W = 3, 64, 24, 24
-    xs = [rnd((B, C, H, W), dtype, 20 + i, 1.5) + 0.3 for i in range(2)]
+    xs = [(rnd((B, C, H, W), torch.float32, 20 + i, 1.5) + 0.3).to(dtype).float() for i in range(2)]
     res = [rnd((B, C, H, W), dtype, 30 + i) for i in range(2)]
     gamma = (1 + 0.1 * rnd((C,), torch.float32, 22)).requires_grad_(True)
     beta = (0.1 * rnd((C,), torch.float32, 23)).requires_grad_(True)
