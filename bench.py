@@ -45,7 +45,7 @@ def cpu_baseline(seconds_budget=25.0):
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cdnet_ref as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)     # more threads than this only oversubscribe these small convs
     torch.set_num_threads(cores)
     bs = 4
     a, b, lab = O.synthetic_batch(bs, SIZE, seed=1234)
@@ -122,7 +122,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    final = float(out) if not args.fwd_only else 0.0
+    final = float(out.detach()) if not args.fwd_only else 0.0
 
     # ---- roofline of the dominant kernel class: HIP events around every MFMA-conv launch (2 extra steps) ----
     roof = None

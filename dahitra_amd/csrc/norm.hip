@@ -228,46 +228,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const T* __restrict__ dx_add, float* __restrict__ partial,
                                                      long rows) {
     __shared__ float red[2][32][33];
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long row = gid >> 3;
-    const int q = (int)(gid & 7);
-    const bool ok = row < rows;
-    float g[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0};
-    float mean = 0.f, rstd = 0.f;
-    if (ok) {
-        ld4(dy + row * 32 + q * 4, g);
-        ld4(x + row * 32 + q * 4, xv);
-        mean = stats[row * 2];
-        rstd = stats[row * 2 + 1];
-    }
-    float xh[4], gh[4], a = 0.f, b = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        xh[j] = (xv[j] - mean) * rstd;
-        gh[j] = g[j] * gamma[q * 4 + j];
-        a += gh[j];
-        b += gh[j] * xh[j];
-    }
-    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
-    b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64); b += __shfl_xor(b, 4, 64);
-    if (ok) {
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = rstd * (gh[j] - (a + xh[j] * b) * (1.f / 32.f));
-        if (dx_add) {
-            float e[4];
-            ld4(dx_add + row * 32 + q * 4, e);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += e[j];
+    const int q = threadIdx.x & 7, lr = threadIdx.x >> 3;
+    float pg[4] = {0, 0, 0, 0}, pb[4] = {0, 0, 0, 0};
+    // grid-stride over groups of 32 rows: the number of partial rows stays <= gridDim.x
+    for (long base = (long)blockIdx.x * 32; base < rows; base += (long)gridDim.x * 32) {
+        const long row = base + lr;
+        const bool ok = row < rows;
+        float g[4] = {0, 0, 0, 0}, xv[4] = {0, 0, 0, 0};
+        float mean = 0.f, rstd = 0.f;
+        if (ok) {
+            ld4(dy + row * 32 + q * 4, g);
+            ld4(x + row * 32 + q * 4, xv);
+            mean = stats[row * 2];
+            rstd = stats[row * 2 + 1];
         }
-        st4(dx + row * 32 + q * 4, o);
+        float xh[4], gh[4], a = 0.f, b = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xh[j] = (xv[j] - mean) * rstd;
+            gh[j] = g[j] * gamma[q * 4 + j];
+            a += gh[j];
+            b += gh[j] * xh[j];
+        }
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+        b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64); b += __shfl_xor(b, 4, 64);
+        if (ok) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rstd * (gh[j] - (a + xh[j] * b) * (1.f / 32.f));
+            if (dx_add) {
+                float e[4];
+                ld4(dx_add + row * 32 + q * 4, e);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += e[j];
+            }
+            st4(dx + row * 32 + q * 4, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pg[j] += g[j] * xh[j]; pb[j] += g[j]; }
+        }
     }
-    // partial dgamma / dbeta over the 32 rows of this workgroup
-    const int lr = threadIdx.x >> 3;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        red[0][lr][q * 4 + j] = ok ? g[j] * xh[j] : 0.f;
-        red[1][lr][q * 4 + j] = ok ? g[j] : 0.f;
+        red[0][lr][q * 4 + j] = pg[j];
+        red[1][lr][q * 4 + j] = pb[j];
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -279,14 +282,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 }
 
 // out[i] (+)= scale * sum_t partial[t][i], t < nt  (deterministic second reduction stage)
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, long nt, long n, float scale,
-                                       float* __restrict__ out, int accumulate) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// 256 threads = 8 row phases x 32 consecutive outputs (coalesced rows), fp64 accumulation.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, long nt, long n,
+                                                              float scale, float* __restrict__ out, int accumulate) {
+    __shared__ double red[8][32];
+    const int lane = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + lane;
     double s = 0.0;
-    for (long t = 0; t < nt; ++t) s += (double)partial[t * n + i];
-    const float v = (float)(s * scale);
-    if (accumulate) out[i] += v; else out[i] = v;
+    if (i < n)
+        for (long t = ph; t < nt; t += 8) s += (double)partial[t * n + i];
+    red[ph][lane] = s;
+    __syncthreads();
+    if (ph == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][lane];
+        const float v = (float)(t * scale);
+        if (accumulate) out[i] += v; else out[i] = v;
+    }
+}
+inline void launch_reduce(const float* partial, long nt, long n, float scale, float* out, int accumulate,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, partial, nt, n,
+                       scale, out, accumulate);
 }
 
 inline int ew_grid(long n, int block) {
@@ -385,14 +403,15 @@ extern "C" int dh_layernorm_fwd(int dtype, const void* x, const float* gamma, co
     return 0;
 }
 
-extern "C" long dh_layernorm_bwd_workspace_size(long rows) { return ((long)dh_cdiv(rows * 8, 256) * 64 + 64) * 4; }
+static inline int ln_bwd_grid(long rows) { long g = dh_cdiv(rows * 8, 256); return (int)(g > 512 ? 512 : g); }
+extern "C" long dh_layernorm_bwd_workspace_size(long rows) { return ((long)ln_bwd_grid(rows) * 64 + 64) * 4; }
 
 extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
                                 void* dx, const void* dx_add, float* dgamma, float* dbeta, int accumulate,
                                 long rows, int C, void* workspace, void* stream) {
     DH_REQUIRE(C == 32, "layernorm_bwd: only dim 32, got %d", C);
     if (rows == 0) return 0;
-    const int grid = dh_cdiv(rows * 8, 256);
+    const int grid = ln_bwd_grid(rows);
     float* partial = reinterpret_cast<float*>(workspace);
     if (dtype == DH_DTYPE_BF16)
         hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dy, (const bf16*)x,
@@ -401,12 +420,9 @@ extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const 
         hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)dy,
                            (const float*)x, stats, gamma, (float*)dx, (const float*)dx_add, partial, rows);
     // per-block partial rows are [dgamma(32) | dbeta(32)]: reduce into a 64-float temp, then split
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, ST(stream), partial, (long)grid, 64L, 1.0f,
-                       partial + (long)grid * 64, 0);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(32), 0, ST(stream), partial + (long)grid * 64, 1L, 32L,
-                       1.0f, dgamma, accumulate);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(32), 0, ST(stream), partial + (long)grid * 64 + 32, 1L,
-                       32L, 1.0f, dbeta, accumulate);
+    launch_reduce(partial, (long)grid, 64L, 1.0f, partial + (long)grid * 64, 0, ST(stream));
+    launch_reduce(partial + (long)grid * 64, 1L, 32L, 1.0f, dgamma, accumulate, ST(stream));
+    launch_reduce(partial + (long)grid * 64 + 32, 1L, 32L, 1.0f, dbeta, accumulate, ST(stream));
     DH_CHECK_LAUNCH("layernorm_bwd");
     return 0;
 }
@@ -414,8 +430,7 @@ extern "C" int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const 
 extern "C" int dh_reduce_partials(const float* partial, long nt, long n, float scale, float* out, int accumulate,
                                   void* stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), partial, nt, n,
-                       scale, out, accumulate);
+    launch_reduce(partial, nt, n, scale, out, accumulate, ST(stream));
     DH_CHECK_LAUNCH("reduce_partials");
     return 0;
 }

@@ -1,0 +1,69 @@
+"""The N > 1 path on CPU: two gloo ranks shard the image pairs, all-reduce ONE flat gradient buffer and
+end with identical parameters equal to the mean-of-shards update (SURVEY.md section 8e parity protocol:
+the reduced gradient equals the mean of the per-shard oracle gradients; BatchNorm stays per replica)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAME = "base_transformer_pos_s4"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import cdnet_ref as O
+    from dahitra_amd import parallel
+    r, _, w = parallel.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    a, b, lab = O.synthetic_batch(4, 64, seed=3)
+    lo, hi = parallel.shard_batch(4, rank, world)
+    st = O.TrainState(NAME, O.deterministic_state(NAME), lr=0.01)
+    logits = O.forward(st.sd, NAME, a[lo:hi], b[lo:hi], training=True)
+    O.focal_loss(logits, lab[lo:hi]).backward()
+    keys = [k for k in O.trainable_keys(NAME) if st.sd[k].grad is not None]
+    flat = torch.cat([st.sd[k].grad.reshape(-1) for k in keys])          # the flat gradient arena
+    local = flat.clone()
+    scale = parallel.allreduce_sum_(flat)
+    assert abs(scale - 1.0 / world) < 1e-12
+    torch.save({"local": local, "reduced": flat * scale, "n": flat.numel()}, os.path.join(out, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_is_mean_of_shards(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "r0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "r1.pt"))
+    assert r0["n"] == r1["n"] == 3006562            # grad-carrying parameters of s4
+    assert torch.equal(r0["reduced"], r1["reduced"])
+    want = 0.5 * (r0["local"] + r1["local"])
+    assert float((r0["reduced"] - want).abs().max()) <= 1e-7 * float(want.abs().max()) + 1e-12
+    assert float((r0["local"] - r1["local"]).abs().max()) > 0        # shards really differ
+
+
+def test_shard_batch_and_single_process_noops():
+    sys.path.insert(0, ROOT)
+    from dahitra_amd import parallel
+    assert [parallel.shard_batch(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
+    with pytest.raises(ValueError):
+        parallel.shard_batch(10, 0, 4)
+    t = torch.ones(5)
+    assert parallel.allreduce_sum_(t) == 1.0 and torch.equal(t, torch.ones(5))
