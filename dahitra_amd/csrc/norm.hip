@@ -352,7 +352,7 @@ extern "C" int dh_bn_apply(int dtype, const void* x, const void* residual, void*
 
 // workspace: partial [groups*bpg][2][C] floats + sums [groups][2][C] floats
 extern "C" long dh_bn_bwd_workspace_size(long npix, int C, int groups) {
-    const int bpg = 128;
+    const int bpg = 1024 / groups;      // ~1024 workgroups in total (4 per CU)
     return ((long)groups * bpg * 2 * C + (long)groups * 2 * C) * 4;
 }
 
@@ -362,7 +362,7 @@ extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, cons
                          void* stream) {
     DH_REQUIRE(C % 4 == 0 && 1024 % C == 0, "bn_bwd: unsupported C=%d", C);
     DH_REQUIRE(npix % groups == 0, "bn_bwd: npix %% groups");
-    const int bpg = 128;
+    const int bpg = 1024 / groups;      // ~1024 workgroups in total (4 per CU)
     const long ppg = npix / groups;
     float* partial = reinterpret_cast<float*>(workspace);
     float* sums = partial + (long)groups * bpg * 2 * C;

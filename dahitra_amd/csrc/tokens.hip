@@ -47,54 +47,61 @@ __global__ void tok_logits_kernel(const T* __restrict__ x, const float* __restri
     for (int l = 0; l < L; ++l) logits[p * L + l] = acc[l];
 }
 
-// one workgroup per image: softmax statistics over HW, then pooled tokens.
-// tok_cat: [B][2L][32] T (stream = s / B selects the half), pooled: [S][L][32] fp32 (saved).
-template <typename T, int L>
-__global__ __launch_bounds__(256) void tok_pool_kernel(const T* __restrict__ x, const float* __restrict__ logits,
-                                                       const float* __restrict__ pos /*[2L][32] or null*/, int HW,
-                                                       int B, float* __restrict__ stats /*[S][L][2]*/,
-                                                       float* __restrict__ pooled, T* __restrict__ tok_cat) {
-    __shared__ float red[256];
-    __shared__ float smax[L], sinv[L];
-    const int s = blockIdx.x, tid = threadIdx.x;
-    const float* lg = logits + (size_t)s * HW * L;
-    // max and sum-exp per token: threads are split into L interleaved sets
-    const int l_of = tid % L, sub = tid / L, nsub = 256 / L;
+// softmax statistics over the HW pixels of one (image, token): one 256-thread workgroup each
+template <int L>
+__global__ __launch_bounds__(256) void tok_stats_kernel(const float* __restrict__ logits, int HW,
+                                                        float* __restrict__ stats /*[S][L][2]*/) {
+    __shared__ float red[4];
+    const int s = blockIdx.x / L, l = blockIdx.x % L, tid = threadIdx.x;
+    const float* lg = logits + (size_t)s * HW * L + l;
     float m = -INFINITY;
-    for (int n = sub; n < HW; n += nsub) m = fmaxf(m, lg[(size_t)n * L + l_of]);
-    red[tid] = m;
+    for (int n = tid; n < HW; n += 256) m = fmaxf(m, lg[(size_t)n * L]);
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-    if (tid < L) {
-        float t = -INFINITY;
-        for (int r = 0; r < nsub; ++r) t = fmaxf(t, red[r * L + tid]);
-        smax[tid] = t;
-    }
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float e = 0.f;
-    for (int n = sub; n < HW; n += nsub) e += __expf(lg[(size_t)n * L + l_of] - smax[l_of]);
-    red[tid] = e;
+    for (int n = tid; n < HW; n += 256) e += __expf(lg[(size_t)n * L] - m);
+    e = wave_sum(e);
+    if ((tid & 63) == 0) red[tid >> 6] = e;
     __syncthreads();
-    if (tid < L) {
-        float t = 0.f;
-        for (int r = 0; r < nsub; ++r) t += red[r * L + tid];
-        sinv[tid] = 1.f / t;
-        stats[((size_t)s * L + tid) * 2 + 0] = smax[tid];
-        stats[((size_t)s * L + tid) * 2 + 1] = 1.f / t;
+    if (tid == 0) {
+        stats[(size_t)blockIdx.x * 2 + 0] = m;
+        stats[(size_t)blockIdx.x * 2 + 1] = 1.f / (red[0] + red[1] + red[2] + red[3]);
     }
-    __syncthreads();
-    // pooled[l][c] = sum_n p[n][l] x[n][c]; thread (l, c) for L*32 <= 256
-    if (tid < L * D) {
-        const int l = tid / D, c = tid % D;
-        const T* xs = x + (size_t)s * HW * D;
-        float acc = 0.f;
-        const float mx = smax[l], iv = sinv[l];
-        for (int n = 0; n < HW; ++n) acc += __expf(lg[(size_t)n * L + l] - mx) * ldf(xs + (size_t)n * D + c);
-        acc *= iv;
-        pooled[((size_t)s * L + l) * D + c] = acc;
-        const int b = s % B, stream = s / B;
-        const int j = stream * L + l;
-        stf(tok_cat + ((size_t)b * 2 * L + j) * D + c, acc + (pos ? pos[j * D + c] : 0.f));
-    }
+}
+
+// partial pooled sums over one chunk of pixels: thread (l, c); grid (chunks, S)
+template <typename T, int L>
+__global__ void tok_pool_partial_kernel(const T* __restrict__ x, const float* __restrict__ logits,
+                                        const float* __restrict__ stats, int HW, int chunk,
+                                        float* __restrict__ partial /*[S][chunks][L*32]*/) {
+    const int s = blockIdx.y, tid = threadIdx.x;
+    const int l = tid / D, c = tid % D;
+    const float* lg = logits + (size_t)s * HW * L;
+    const T* xs = x + (size_t)s * HW * D;
+    const float mx = stats[((size_t)s * L + l) * 2];
+    const int n0 = blockIdx.x * chunk, n1 = min(n0 + chunk, HW);
+    float acc = 0.f;
+    for (int n = n0; n < n1; ++n) acc += __expf(lg[(size_t)n * L + l] - mx) * ldf(xs + (size_t)n * D + c);
+    partial[((size_t)s * gridDim.x + blockIdx.x) * (L * D) + tid] = acc;
+}
+
+// combine chunks, normalise, add the learned positional embedding and place into [B][2L][32]
+template <typename T, int L>
+__global__ void tok_finish_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
+                                  const float* __restrict__ pos /*[2L][32] or null*/, int chunks, int B,
+                                  float* __restrict__ pooled, T* __restrict__ tok_cat) {
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int l = tid / D, c = tid % D;
+    float acc = 0.f;
+    for (int k = 0; k < chunks; ++k) acc += partial[((size_t)s * chunks + k) * (L * D) + tid];
+    acc *= stats[((size_t)s * L + l) * 2 + 1];
+    pooled[((size_t)s * L + l) * D + c] = acc;
+    const int b = s % B, stream = s / B;
+    const int j = stream * L + l;
+    stf(tok_cat + ((size_t)b * 2 * L + j) * D + c, acc + (pos ? pos[j * D + c] : 0.f));
 }
 
 // per pixel: dlogit and the tokenizer's contribution to dx (accumulated into dx in place)
@@ -492,18 +499,26 @@ __global__ __launch_bounds__(64) void self_attn_bwd_kernel(const T* __restrict__
 extern "C" int dh_reduce_partials(const float* partial, long nt, long n, float scale, float* out, int accumulate,
                                   void* stream);
 
-// workspace-free; logits [S*HW][L] fp32, stats [S][L][2], pooled [S][L][32] are saved for backward
+// logits [S*HW][L] fp32, stats [S][L][2], pooled [S][L][32] are saved for backward
+static inline int tok_chunks(int HW) { int c = HW / 256; return c < 1 ? 1 : (c > 64 ? 64 : c); }
+extern "C" long dh_tokenizer_fwd_workspace_size(int S, int HW, int L) { return (long)S * tok_chunks(HW) * L * 32 * 4; }
 extern "C" int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const float* pos, int S, int B, int HW,
-                                int L, float* logits, float* stats, float* pooled, void* tok_cat, void* stream) {
+                                int L, float* logits, float* stats, float* pooled, void* tok_cat, void* workspace,
+                                void* stream) {
     DH_REQUIRE(L == 4 || L == 8, "tokenizer: token_len must be 4 or 8, got %d", L);
     DH_REQUIRE(S % B == 0 && S / B <= 2, "tokenizer: S=%d must be B or 2B (B=%d)", S, B);
     const long P = (long)S * HW;
+    const int nch = tok_chunks(HW), chunk = dh_cdiv(HW, nch);
+    float* part = reinterpret_cast<float*>(workspace);
 #define TOKF(TT, LL)                                                                                              \
     do {                                                                                                          \
         hipLaunchKernelGGL((tok_logits_kernel<TT, LL>), dim3(dh_cdiv(P, 256)), dim3(256), 0, ST(stream),          \
                            (const TT*)x, wa, logits, P);                                                          \
-        hipLaunchKernelGGL((tok_pool_kernel<TT, LL>), dim3(S), dim3(256), 0, ST(stream), (const TT*)x, logits, pos, \
-                           HW, B, stats, pooled, (TT*)tok_cat);                                                   \
+        hipLaunchKernelGGL((tok_stats_kernel<LL>), dim3(S * LL), dim3(256), 0, ST(stream), logits, HW, stats);     \
+        hipLaunchKernelGGL((tok_pool_partial_kernel<TT, LL>), dim3(nch, S), dim3(LL * 32), 0, ST(stream),         \
+                           (const TT*)x, logits, stats, HW, chunk, part);                                         \
+        hipLaunchKernelGGL((tok_finish_kernel<TT, LL>), dim3(S), dim3(LL * 32), 0, ST(stream), part, stats, pos,  \
+                           nch, B, pooled, (TT*)tok_cat);                                                         \
     } while (0)
     if (dtype == DH_DTYPE_BF16) { if (L == 4) TOKF(bf16, 4); else TOKF(bf16, 8); }
     else { if (L == 4) TOKF(float, 4); else TOKF(float, 8); }
@@ -512,10 +527,10 @@ extern "C" int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const
     return 0;
 }
 
-// workspace: dlogits [S*HW][L] floats + partial [nblk][L*32] floats, nblk = ceil(S*HW / 2048)
+// workspace: dlogits [S*HW][L] floats + partial [nblk][L*32] floats, nblk = ceil(S*HW / 256)
 extern "C" long dh_tokenizer_bwd_workspace_size(int S, int HW, int L) {
     const long P = (long)S * HW;
-    return (P * L + (long)dh_cdiv(P, 2048) * L * 32) * 4;
+    return (P * L + (long)dh_cdiv(P, 256) * L * 32) * 4;
 }
 extern "C" int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S, int B, int HW, int L,
                                 const float* logits, const float* stats, const float* pooled, const void* dtok_cat,
@@ -525,14 +540,14 @@ extern "C" int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S
     const long P = (long)S * HW;
     float* dlogits = reinterpret_cast<float*>(workspace);
     float* partial = dlogits + P * L;
-    const int nblk = dh_cdiv(P, 2048);
+    const int nblk = dh_cdiv(P, 256);
 #define TOKB(TT, LL)                                                                                              \
     do {                                                                                                          \
         hipLaunchKernelGGL((tok_bwd_kernel<TT, LL>), dim3(dh_cdiv(HW, 128), S), dim3(128), 0, ST(stream),         \
                            (const TT*)x, logits, stats, pooled, (const TT*)dtok_cat, wa, HW, B, (TT*)dx_accum,    \
                            dlogits);                                                                              \
         hipLaunchKernelGGL((tok_dwa_kernel<TT, LL>), dim3(nblk), dim3(256), 0, ST(stream), (const TT*)x, dlogits, \
-                           P, 2048L, partial);                                                                    \
+                           P, 256L, partial);                                                                    \
         if (dpos)                                                                                                 \
             hipLaunchKernelGGL(tok_dpos_kernel<TT>, dim3(dh_cdiv(2 * LL * 32, 64)), dim3(64), 0, ST(stream),      \
                                (const TT*)dtok_cat, B, 2 * LL * 32, dpos, accumulate);                            \

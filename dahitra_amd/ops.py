@@ -148,16 +148,18 @@ def linear(x2d, wp, cout, bias=None, residual=None, act=ACT_NONE, want_preact=Fa
     return (y, pre) if want_preact else y
 
 
-def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=True, cout_real=0):
-    """dw (OIHW fp32, or [N, Cout, Cin] when groups == N) (+)= weight gradient."""
-    N, H, W, Cin = x.shape
+def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=True, cout_real=0, cin=0):
+    """dw (OIHW fp32, or [N, Cout, Cin] when groups == N) (+)= weight gradient.
+    cin > 0: use only the first `cin` channels of x (x keeps its own channel pitch)."""
+    N, H, W, pitch = x.shape
+    Cin = cin if cin else pitch
     _, OH, OW, Cout = dy.shape
     L = _lib.lib()
     nbytes = L.dh_conv2d_wgrad_workspace_size(N, OH, OW, Cin, Cout, ks, groups)
     ws = workspace(nbytes, x.device)
     _call("dh_conv2d_wgrad", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W), _ci(Cin),
           _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(groups), _ci(0), _ci(int(use_tr)),
-          _ci(cout_real), P(ws), S())
+          _ci(cout_real), _ci(pitch), P(ws), S())
 
 
 def linear_wgrad(x2d, dy2d, dw, accumulate=False, images=1, per_image=False, use_tr=True):
@@ -172,7 +174,7 @@ def linear_wgrad(x2d, dy2d, dw, accumulate=False, images=1, per_image=False, use
     assert images == 1 or rpi % 16 == 0
     _call("dh_conv2d_wgrad", _ci(dt(x2d)), P(x2d), P(dy2d), P(dw), _ci(int(accumulate)), _ci(images), _ci(Hh), _ci(16),
           _ci(Cin), _ci(Hh), _ci(16), _ci(Cout), _ci(1), _ci(1), _ci(0), _ci(groups), _ci(rpi), _ci(int(use_tr)),
-          _ci(0), P(ws), S())
+          _ci(0), _ci(0), P(ws), S())
 
 
 def zero_insert2(dy, H, W):
@@ -203,9 +205,9 @@ def stem_pack_weight(w, dtype):
 def stem_wgrad(x_s2d, dy, dw, accumulate=False, use_tr=True):
     N, H2, W2, cp = x_s2d.shape
     O = dy.shape[-1]
-    dw2 = torch.empty(O, cp, 4, 4, dtype=torch.float32, device=dy.device)
-    conv2d_wgrad(x_s2d, dy, dw2, ks=4, stride=1, pad=2, use_tr=use_tr)
-    _call("dh_stem_unpack_grad", P(dw2), P(dw), _ci(O), _ci(cp), _ci(int(accumulate)), S())
+    dw2 = torch.empty(O, 16, 4, 4, dtype=torch.float32, device=dy.device)     # 12 real + 4 zero channels
+    conv2d_wgrad(x_s2d, dy, dw2, ks=4, stride=1, pad=2, use_tr=use_tr, cin=16)
+    _call("dh_stem_unpack_grad", P(dw2), P(dw), _ci(O), _ci(16), _ci(int(accumulate)), S())
 
 
 # ---- normalisation -------------------------------------------------------------------------------
@@ -394,8 +396,9 @@ def tokenizer_fwd(x, wa, pos, B, L):
     stats = torch.empty(Sn, L, 2, dtype=torch.float32, device=dev)
     pooled = torch.empty(Sn, L, 32, dtype=torch.float32, device=dev)
     tok = torch.empty(B, 2 * L, 32, dtype=x.dtype, device=dev)
+    ws = workspace(_lib.lib().dh_tokenizer_fwd_workspace_size(Sn, HW, L), dev)
     _call("dh_tokenizer_fwd", _ci(dt(x)), P(x), P(wa), P(pos), _ci(Sn), _ci(B), _ci(HW), _ci(L), P(logits), P(stats),
-          P(pooled), P(tok), S())
+          P(pooled), P(tok), P(ws), S())
     return tok, (logits, stats, pooled)
 
 

