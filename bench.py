@@ -86,7 +86,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    net = define_G(types.SimpleNamespace(net_G=args.net, compute_dtype=args.dtype), gpu_ids=[local])
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):       # define_G prints like the reference; stdout = one JSON line
+        net = define_G(types.SimpleNamespace(net_G=args.net, compute_dtype=args.dtype), gpu_ids=[local])
     net.train(not args.fwd_only)
     opt = AdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
     a, b, lab = synthetic(args.batch, SIZE, 1234 + rank, dev)

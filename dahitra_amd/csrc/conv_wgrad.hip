@@ -233,11 +233,15 @@ __global__ void wgrad_reduce_oihw_kernel(const float* __restrict__ part, int spl
     part += (size_t)blockIdx.y * splitk * taps * Oslab * I;
     dw += (size_t)blockIdx.y * n;
     float acc = 0.f;
+    // lanes walk the SLAB order (tap, o, ci) so the splitk reads are coalesced; the single OIHW write scatters
+    int tap = 0, ci = 0, o = 0;
     if (i < n) {
-        const int tap = (int)(i % taps);
-        const int ci = (int)((i / taps) % I);
-        const int o = (int)(i / ((long)taps * I));
-        for (int k = ph; k < splitk; k += 8) acc += part[(((size_t)k * taps + tap) * Oslab + o) * I + ci];
+        ci = (int)(i % I);
+        o = (int)((i / I) % O);
+        tap = (int)(i / ((long)I * O));
+        const size_t slab = (size_t)taps * Oslab * I;
+        const float* src = part + ((size_t)tap * Oslab + o) * I + ci;
+        for (int k = ph; k < splitk; k += 8) acc += src[(size_t)k * slab];
     }
     red[ph][lane] = acc;
     __syncthreads();
@@ -245,7 +249,8 @@ __global__ void wgrad_reduce_oihw_kernel(const float* __restrict__ part, int spl
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) s += red[r][lane];
-        if (accumulate) dw[i] += s; else dw[i] = s;
+        const size_t d = ((size_t)o * I + ci) * taps + tap;
+        if (accumulate) dw[d] += s; else dw[d] = s;
     }
 }
 

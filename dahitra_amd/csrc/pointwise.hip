@@ -102,8 +102,8 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ r
 
 // ---- MaxPool 3x3 stride 2 pad 1 -------------------------------------------------------------
 template <typename T>
-__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int OH,
-                                   int OW) {
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ arg, int N,
+                                   int H, int W, int C, int OH, int OW) {
     const int vn = C / 4;
     GSL(i, (long)N * OH * OW * vn) {
         const int c = (int)(i % vn) * 4;
@@ -112,6 +112,7 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, i
         const int oy = (int)(t % OH);
         const long n = t / OH;
         float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int k[4] = {-1, -1, -1, -1};
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * 2 - 1 + ky;
             if (iy < 0 || iy >= H) continue;
@@ -121,17 +122,19 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, i
                 float v[4];
                 ld4(x + ((n * H + iy) * W + ix) * C + c, v);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                for (int j = 0; j < 4; ++j)
+                    if (v[j] > m[j] || k[j] < 0) { m[j] = v[j]; k[j] = ky * 3 + kx; }     // first maximum wins
             }
         }
         st4(y + i * 4, m);
+        if (arg) *reinterpret_cast<uchar4*>(arg + i * 4) = make_uchar4(k[0], k[1], k[2], k[3]);
     }
 }
-// gather form: an input pixel receives dy of every window whose first maximum (row-major scan,
-// strict >, as ATen's CPU kernel) it is.  Deterministic, no atomics.
+// gather form with the saved window arg-max (row-major scan, strict >, as ATen's CPU kernel): an input pixel
+// receives dy of each of the <= 4 windows covering it whose arg-max it is.  Deterministic, no atomics.
 template <typename T>
-__global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int N,
-                                   int H, int W, int C, int OH, int OW) {
+__global__ void maxpool_bwd_kernel(const unsigned char* __restrict__ arg, const T* __restrict__ dy, T* __restrict__ dx,
+                                   int N, int H, int W, int C, int OH, int OW) {
     const int vn = C / 4;
     GSL(i, (long)N * H * W * vn) {
         const int c = (int)(i % vn) * 4;
@@ -141,30 +144,18 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict_
         const long n = t / H;
         float g[4] = {0, 0, 0, 0};
         for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {   // windows with 2*oy-1 <= iy <= 2*oy+1
-            if (oy < 0 || oy >= OH) continue;
+            if (oy >= OH) continue;
             for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
-                if (ox < 0 || ox >= OW) continue;
-                // scan the window of (oy, ox)
-                float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                int arg[4] = {-1, -1, -1, -1};
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int yy = oy * 2 - 1 + ky;
-                    if (yy < 0 || yy >= H) continue;
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int xx = ox * 2 - 1 + kx;
-                        if (xx < 0 || xx >= W) continue;
-                        float v[4];
-                        ld4(x + ((n * H + yy) * W + xx) * C + c, v);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (v[j] > m[j] || arg[j] < 0) { m[j] = v[j]; arg[j] = yy * W + xx; }
-                    }
-                }
+                if (ox >= OW) continue;
+                const int kk = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
+                const long o = ((n * OH + oy) * OW + ox) * C + c;
+                const uchar4 a = *reinterpret_cast<const uchar4*>(arg + o);
                 float d[4];
-                ld4(dy + ((n * OH + oy) * OW + ox) * C + c, d);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (arg[j] == iy * W + ix) g[j] += d[j];
+                ld4(dy + o, d);
+                if (a.x == kk) g[0] += d[0];
+                if (a.y == kk) g[1] += d[1];
+                if (a.z == kk) g[2] += d[2];
+                if (a.w == kk) g[3] += d[3];
             }
         }
         st4(dx + i * 4, g);
@@ -354,7 +345,28 @@ template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long P, int C,
                                                              float* __restrict__ partial) {
     // block b sums rows b, b+grid, ...; thread t covers channel t % C, row phase t / C
-    __shared__ float red[256];
+    __shared__ float red[256 * 4];
+    if ((C & 3) == 0 && C <= 1024) {
+        // 4 channels per lane (8/16-byte loads), 256/(C/4) row phases per workgroup
+        const int cvn = C / 4, cv = threadIdx.x % cvn, ph = threadIdx.x / cvn, nph = 256 / cvn;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ph < nph)
+            for (long p = (long)blockIdx.x * nph + ph; p < P; p += (long)gridDim.x * nph) {
+                float v[4];
+                ld4(x + p * C + cv * 4, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += v[j];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[threadIdx.x * 4 + j] = ph < nph ? s[j] : 0.f;
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float t = 0.f;
+            for (int r = 0; r < nph; ++r) t += red[(r * cvn + c / 4) * 4 + (c & 3)];
+            partial[(long)blockIdx.x * C + c] = t;
+        }
+        return;
+    }
     const int c = threadIdx.x % C, ph = threadIdx.x / C, nph = 256 / C;
     float s = 0.f;
     if (ph < nph)
@@ -437,21 +449,21 @@ extern "C" int dh_act_bwd(int dtype, const void* dy, const void* ref, void* dx, 
     DH_CHECK_LAUNCH("act_bwd");
     return 0;
 }
-extern "C" int dh_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+extern "C" int dh_maxpool3x3s2_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int N, int H, int W, int C, void* stream) {
     DH_REQUIRE(C % 4 == 0, "maxpool: C %% 4");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const long n = (long)N * OH * OW * (C / 4);
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, N, H, W, C, OH, OW);
-    else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, N, H, W, C, OH, OW);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, argmax, N, H, W, C, OH, OW);
+    else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, argmax, N, H, W, C, OH, OW);
     DH_CHECK_LAUNCH("maxpool_fwd");
     return 0;
 }
-extern "C" int dh_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
+extern "C" int dh_maxpool3x3s2_bwd(int dtype, const unsigned char* argmax, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
     DH_REQUIRE(C % 4 == 0, "maxpool: C %% 4");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const long n = (long)N * H * W * (C / 4);
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (const bf16*)dy, (bf16*)dx, N, H, W, C, OH, OW);
-    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (const float*)dy, (float*)dx, N, H, W, C, OH, OW);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), argmax, (const bf16*)dy, (bf16*)dx, N, H, W, C, OH, OW);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), argmax, (const float*)dy, (float*)dx, N, H, W, C, OH, OW);
     DH_CHECK_LAUNCH("maxpool_bwd");
     return 0;
 }

@@ -334,7 +334,7 @@ class Engine:
         B = x1.shape[0]
         S2 = 2 * B
         x, b_stem = self.stem(x1, x2, 2)
-        xp = ops.maxpool(x)
+        xp, xarg = ops.maxpool(x, want_arg=True)
         l1, b_l1 = self.res_layer(xp, 1, 1, 2)
         l2, b_l2 = self.res_layer(l1, 2, 2, 2)
         l3, b_l3 = self.res_layer(l2, 3, 1, 2)
@@ -369,7 +369,7 @@ class Engine:
             dup = b_pred(dfeat4)
             dl3 = ops.upsample2_bwd(dup)
             dxp = b_l1(b_l2(b_l3(dl3)))
-            b_stem(ops.maxpool_bwd(x, dxp))
+            b_stem(ops.maxpool_bwd(xarg, dxp, x.shape))
         return logits, bwd
 
     # hierarchical model -------------------------------------------------------------------------
@@ -434,10 +434,10 @@ class Engine:
     def _unet(self, x1, x2):
         B = x1.shape[0]
         s2, b_stem = self.stem(x1, x2, 2)                      # [2B,128,128,64] (post-ReLU tap)
-        p4 = ops.maxpool(s2)
+        p4, arg4 = ops.maxpool(s2, want_arg=True)
         s4, b_l1 = self.res_layer(p4, 1, 1, 2)                 # 64x64x64
         s8, b_l2 = self.res_layer(s4, 2, 2, 2)                 # 32x32x128
-        p16 = ops.maxpool(s8)
+        p16, arg16 = ops.maxpool(s8, want_arg=True)
         s16, b_l3 = self.res_layer(p16, 3, 1, 2)               # 16x16x256
         o5, b5 = self._level(5, s16, B)
         o5u = ops.upsample2(o5)
@@ -473,8 +473,8 @@ class Engine:
             ds8 = b4(dsum4)
             ds16 = b5(ops.upsample2_bwd(dsum4))
             dp16 = b_l3(ds16)
-            ds8 = ops.add(ds8, ops.maxpool_bwd(s8, dp16))
+            ds8 = ops.add(ds8, ops.maxpool_bwd(arg16, dp16, s8.shape))
             ds4 = ops.add(ds4, b_l2(ds8))
             dp4 = b_l1(ds4)
-            b_stem(ops.add(ds2, ops.maxpool_bwd(s2, dp4)))
+            b_stem(ops.add(ds2, ops.maxpool_bwd(arg4, dp4, s2.shape)))
         return logits, bwd

@@ -314,17 +314,18 @@ def act_bwd(dy, ref, act):
     return dx
 
 
-def maxpool(x):
+def maxpool(x, want_arg=False):
     N, H, W, C = x.shape
     y = torch.empty(N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C, dtype=x.dtype, device=x.device)
-    _call("dh_maxpool3x3s2_fwd", _ci(dt(x)), P(x), P(y), _ci(N), _ci(H), _ci(W), _ci(C), S())
-    return y
+    arg = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if want_arg else None
+    _call("dh_maxpool3x3s2_fwd", _ci(dt(x)), P(x), P(y), P(arg), _ci(N), _ci(H), _ci(W), _ci(C), S())
+    return (y, arg) if want_arg else y
 
 
-def maxpool_bwd(x, dy):
-    N, H, W, C = x.shape
-    dx = torch.empty_like(x)
-    _call("dh_maxpool3x3s2_bwd", _ci(dt(x)), P(x), P(dy), P(dx), _ci(N), _ci(H), _ci(W), _ci(C), S())
+def maxpool_bwd(arg, dy, in_shape):
+    N, H, W, C = in_shape
+    dx = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)
+    _call("dh_maxpool3x3s2_bwd", _ci(dt(dy)), P(arg), P(dy), P(dx), _ci(N), _ci(H), _ci(W), _ci(C), S())
     return dx
 
 

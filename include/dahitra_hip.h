@@ -100,8 +100,9 @@ int dh_add(int dtype, const void* a, const void* b, void* y, long n, void* strea
 int dh_add_pos(int dtype, const void* x, const float* pos, void* y, int N, long HW, int C, void* stream);
 int dh_add_pos_bwd(int dtype, const void* dy, float* dpos, int N, long HW, int C, int accumulate, void* stream);
 int dh_act_bwd(int dtype, const void* dy, const void* ref, void* dx, long n, int act, void* stream);
-int dh_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
-int dh_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+/* argmax (optional, [N][OH][OW][C] bytes): window position 0..8 of the first maximum, consumed by the backward */
+int dh_maxpool3x3s2_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int N, int H, int W, int C, void* stream);
+int dh_maxpool3x3s2_bwd(int dtype, const unsigned char* argmax, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
 int dh_upsample2_nearest_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
 int dh_upsample2_nearest_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
 int dh_absdiff_upsample4_fwd(int dtype, const void* a, const void* b, void* y, int N, int H, int W, int C, void* stream);

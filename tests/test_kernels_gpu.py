@@ -227,8 +227,9 @@ def test_pool_and_resample(ops, dtype):
     dy = rnd(tuple(y.shape), dtype, 61)
     y.backward(dy)
     xd = dev(nhwc(x.detach()), dtype)
-    close(nchw(ops.maxpool(xd)), y.detach(), dtype, "maxpool")
-    close(nchw(ops.maxpool_bwd(xd, dev(nhwc(dy), dtype))), x.grad, dtype, "maxpool bwd", factor=2)
+    yd, arg = ops.maxpool(xd, want_arg=True)
+    close(nchw(yd), y.detach(), dtype, "maxpool")
+    close(nchw(ops.maxpool_bwd(arg, dev(nhwc(dy), dtype), xd.shape)), x.grad, dtype, "maxpool bwd", factor=2)
     x2 = rnd((N, C, 10, 12), dtype, 62).requires_grad_(True)
     u = F.interpolate(x2, scale_factor=2, mode="nearest")
     du = rnd(tuple(u.shape), dtype, 63)
