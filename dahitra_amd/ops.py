@@ -100,7 +100,7 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     pre = torch.empty_like(y) if want_preact else None
     stats = None
     if want_stats:
-        nt = _lib.lib().dh_conv2d_fwd_num_tiles(N, OH, OW)
+        nt = _lib.lib().dh_conv2d_fwd_num_tiles(N, OH, OW, Cin, ks, stride)
         stats = torch.empty(nt, 2, cpad, dtype=torch.float32, device=x.device)
     ev = None
     if PROFILE is not None:      # bench.py: HIP events on the launch stream around this kernel class

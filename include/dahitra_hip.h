@@ -44,13 +44,13 @@ void dh_set_error(const char* msg);
  *                      + bias[co] + residual[n,oy,ox,co] )
  * w_packed: [ks*ks][CoutPad][Cin] T (dh_pack_weight).  Cin*sizeof(T) must be a multiple of 64.
  * y_preact (optional): receives the value before `act`.  stats_partial (optional):
- * [dh_conv2d_fwd_num_tiles][2][CoutPad] fp32 per-tile (sum, sum of squares) of y for BatchNorm.
+ * [dh_conv2d_fwd_num_tiles(N,OH,OW,Cin,ks,stride)][2][CoutPad] fp32 per-tile (sum, sum of squares) of y for BatchNorm.
  * npix_valid > 0: treat each image as a row list with that many valid rows (H*W >= npix_valid). */
 int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const float* bias,
                   const void* residual, float* stats_partial, int N, int H, int W, int Cin, int OH, int OW,
                   int Cout, int CoutPad, int ks, int stride, int pad, int act, int npix_valid,
                   long w_image_stride, void* y_preact, void* stream);
-int dh_conv2d_fwd_num_tiles(int N, int OH, int OW);
+int dh_conv2d_fwd_num_tiles(int N, int OH, int OW, int Cin, int ks, int stride);
 
 /* weight gradient (autograd convolution_backward / mm for nn.Linear): groups == 1 writes the
  * torch OIHW layout [Cout_real][Cin][ks][ks]; groups == N (ks == 1) one [Cout][Cin] per image. */
