@@ -277,7 +277,9 @@ int launch_rw(const ConvArgs& a, hipStream_t st) {
     constexpr int HH = (TH - 1) * STRIDE + KS, HWD = (TW - 1) * STRIDE + KS;
     const size_t lds = (size_t)HH * HWD * HaloLayout<STRIDE>::PITCH + (size_t)KS * KS * NT * WPITCH;
     auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW>;
-    if (lds > 64 * 1024) {
+    static bool attr_done = false;      // once per instantiation (and never inside a graph capture)
+    if (lds > 64 * 1024 && !attr_done) {
+        attr_done = true;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {

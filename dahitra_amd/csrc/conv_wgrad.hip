@@ -260,7 +260,9 @@ int launch(const WgArgs& a, bool tr, hipStream_t st) {
     const size_t lds = (size_t)HH * HWD * lds_pitch(IT * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T));
     dim3 grid(dh_cdiv(a.Cout, CT) * a.ci_tiles, a.splitk, a.groups);
     auto go = [&](auto kern) -> int {
-        if (lds > 64 * 1024) {
+        static bool attr_done = false;      // once per instantiation (and never inside a graph capture)
+        if (lds > 64 * 1024 && !attr_done) {
+            attr_done = true;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) {

@@ -198,6 +198,42 @@ extern "C" int dh_stem_unpack_grad(const float* dw2, float* dw_oihw, int O, int 
     return 0;
 }
 
+// ---- graph-capturable AdamW: hyper-parameters and the step counter live in device memory -------------
+// hyper: [lr, beta1, beta2, eps, weight_decay, grad_scale, bc1 (out), bc2_sqrt (out)]
+__global__ void adamw_tick_kernel(float* hyper, int* step) {
+    const int s = *step + 1;
+    *step = s;
+    hyper[6] = (float)(1.0 - pow((double)hyper[1], (double)s));
+    hyper[7] = (float)sqrt(1.0 - pow((double)hyper[2], (double)s));
+}
+__global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, long n, const float* __restrict__ hyper) {
+    const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4], gs = hyper[5];
+    const float bc1 = hyper[6], bc2_sqrt = hyper[7];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * gs;
+        float w = p[i];
+        w *= 1.f - lr * wd;
+        const float mm = m[i] + (1.f - beta1) * (gr - m[i]);
+        const float vv = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        m[i] = mm;
+        v[i] = vv;
+        w -= (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        p[i] = w;
+    }
+}
+extern "C" int dh_adamw_step_graph(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                                   float* hyper_dev, int* step_dev, void* stream) {
+    if (n == 0) return 0;
+    long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, ST(stream), hyper_dev, step_dev);
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3((int)g), dim3(256), 0, ST(stream), param, grad, exp_avg, exp_avg_sq, n,
+                       hyper_dev);
+    DH_CHECK_LAUNCH("adamw_graph");
+    return 0;
+}
+
 // dst[i] = src[i] * (*scalar_dev): chains an upstream scalar gradient without a host sync
 __global__ void scale_by_scalar_kernel(const float* __restrict__ src, const float* __restrict__ scalar_dev,
                                        float* __restrict__ dst, long n) {

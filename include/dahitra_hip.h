@@ -141,6 +141,10 @@ int dh_self_attn_bwd(int dtype, const void* qkv, const float* attn, const void* 
 int dh_focal_loss(const float* logits_nchw, const long long* target, int B, int C, long HW, float alpha,
                   float grad_scale, float* loss_out, float* dlogits_nchw, void* workspace, void* stream);
 int dh_argmax_nchw(const float* logits_nchw, long long* mask, int B, int C, long HW, void* stream);
+/* HIP-graph-capturable form: hyper_dev = [lr, beta1, beta2, eps, weight_decay, grad_scale, bc1, bc2_sqrt] and the
+ * step counter live on the device; every call (or graph replay) advances the counter and the bias correction */
+int dh_adamw_step_graph(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                        float* hyper_dev, int* step_dev, void* stream);
 int dh_scale_by_scalar(const float* src, const float* scalar_dev, float* dst, long n, void* stream);
 /* |tok[b][1] - tok[b][0]| over [B][2][n] token sets (models/networks.py:1311) and its gradient */
 int dh_absdiff_halves(int dtype, const void* tok, void* out, int B, long n, void* stream);

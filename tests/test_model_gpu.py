@@ -174,6 +174,41 @@ def test_bf16_train_step_reduces_loss():
     assert all(np.isfinite(ls)) and ls[-1] < 0.7 * ls[0], ls
 
 
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
+def test_hip_graph_step_equals_eager_step(name):
+    """GraphedTrainStep (one hipGraphLaunch per step) must reproduce the eager step: same kernels, same
+    order, same losses; parameters to 1e-6."""
+    from dahitra_amd.graph import GraphedTrainStep
+    from dahitra_amd.models import losses
+    from dahitra_amd.optim import AdamW
+    size = 256 if name == "newUNetTrans" else 64
+    a, b, lab = (t.cuda() for t in O.synthetic_batch(2, size, seed=11))
+    res = {}
+    for mode in ("eager", "graph"):
+        net = make_net(name, "bf16").train()
+        opt = AdamW(net.parameters(), lr=0.002, capturable=(mode == "graph"))
+        ls = []
+        if mode == "graph":
+            step = GraphedTrainStep(net, opt, a, b, lab)
+            for _ in range(3):
+                ls.append(float(step(a, b, lab)))
+        else:
+            for _ in range(3):
+                y = net(a, b)
+                opt.zero_grad()
+                loss = losses.focal_loss(y, lab)
+                loss.backward()
+                opt.step()
+                ls.append(float(loss))
+        res[mode] = (ls, net._arena.flat.clone(), net.state_dict()["resnet.bn1.running_var"].clone(),
+                     int(net.state_dict()["resnet.bn1.num_batches_tracked"]))
+    assert res["eager"][0] == res["graph"][0], (res["eager"][0], res["graph"][0])
+    # (the device-side bias correction works from float-rounded betas: agreement to 1e-6, not bitwise)
+    assert float((res["eager"][1] - res["graph"][1]).abs().max()) <= 1e-6 * float(res["eager"][1].abs().max())
+    assert torch.allclose(res["eager"][2], res["graph"][2], rtol=1e-5)
+    assert res["eager"][3] == res["graph"][3] == 6
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from dahitra_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
