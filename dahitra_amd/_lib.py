@@ -25,7 +25,7 @@ def declared_symbols():
 
 
 _LONG_RET = {"dh_conv2d_wgrad_workspace_size", "dh_bn_bwd_workspace_size", "dh_layernorm_bwd_workspace_size",
-             "dh_tokenizer_bwd_workspace_size", "dh_tokenizer_fwd_workspace_size", "dh_xattn_prep_bwd_workspace_size"}
+             "dh_tokenizer_bwd_workspace_size", "dh_decoder_layer_bwd_workspace_size", "dh_tokenizer_fwd_workspace_size", "dh_xattn_prep_bwd_workspace_size"}
 
 
 def lib():

@@ -1,0 +1,637 @@
+// Fused cross-attention decoder layer (bf16, token_len 4, heads*4 <= 32) for gfx950:
+//
+//   x1 = x + Wo . softmax_l( scale * <Wq LN(x), k_l> ) v_l + bo        (help_funcs.py:66-114, Residual2 / PreNorm2)
+//   y  = x1 + W2 gelu(W1 LN(x1) + b1) + b2                             (help_funcs.py:52-63, Residual / PreNorm)
+//
+// in ONE kernel per direction instead of 7 (forward) / ~25 (backward) launches.  The attention uses the
+// per-image re-associated operands Kq = scale*Wq^T k, Vo = Wo v of tokens.hip, so every product is a
+// 32-wide MFMA (v_mfma_f32_16x16x32_bf16, fp32 accumulate):
+//   dots[hl] = Kq . LN(x)      softmax over the 4 keys of a head = the 4 accumulator registers of a lane
+//   o[c]     = VoT . attn      z[m] = W1 . LN(x1)      out[c] = W2 . gelu(z)
+// Register layout ("D layout"): lane (pl = lane&15, g = lane>>4) of a 16-pixel sub-tile owns pixel pl and
+// channels s*16 + g*4 + j (s = 16-channel half, j = 0..3) -- exactly what an MFMA leaves in its accumulator
+// when the weights are the A operand.  The same registers, packed to bf16, ARE the next MFMA's B operand if
+// the weight rows are read with the matching k-permutation kappa(g, e) = e < 4 ? g*4+e : 16+g*4+(e-4), so
+// activations never round-trip through LDS; LayerNorm reduces over the 4 lane groups with two shuffles.
+//
+// The backward kernel recomputes the forward from x (nothing but x is saved), chains the data gradients the
+// same way, and forms the pixel-reduction gradients (dW1, dW2, per-image dKq, dVoT) with K = 32 pixels per
+// MFMA through wave-private LDS tiles read back with ds_read_b64_tr_b16; biases / LayerNorm gradients are
+// lane-local sums.  Per-workgroup partials are combined deterministically by dec_bwd_finalize_kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int D = 32;
+constexpr int WP = 40;           // LDS pitch (elements) of 32-wide weight rows: 80 B, conflict-free 8-byte reads
+
+struct DecArgs {
+    const bf16* x;
+    bf16* y;                     // fwd: output; bwd: dx
+    const bf16* dy;              // bwd: gradient of the layer output
+    const bf16 *kq, *voT, *vo, *kqT;          // per image [S][32][32] bf16 (vo, kqT: backward only)
+    const bf16 *w1, *w2, *w1T, *w2T;          // [MLP][32], [32][MLP], [32][MLP], [MLP][32]
+    const float *g1, *be1, *bo, *g2, *be2, *fb1, *fb2;
+    float* partial;              // bwd: [nblk][PSZ]
+    int rows_per_image, rows_per_block;
+    long rows;
+    float eps;
+};
+
+union U8 {
+    uint4 u;
+    uint2 h[2];
+    s16x8 v;
+};
+
+__device__ __forceinline__ s16x8 pack8(const float (&a)[4], const float (&b)[4]) {
+    U8 r;
+    r.u.x = (unsigned)f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16);
+    r.u.y = (unsigned)f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16);
+    r.u.z = (unsigned)f2bf(b[0]) | ((unsigned)f2bf(b[1]) << 16);
+    r.u.w = (unsigned)f2bf(b[2]) | ((unsigned)f2bf(b[3]) << 16);
+    return r.v;
+}
+// A fragment of weight row `row`, logical k = koff + kappa(g, e): two 8-byte LDS reads
+__device__ __forceinline__ s16x8 lds_a(const unsigned short* base, int pitch, int row, int koff, int g) {
+    U8 r;
+    r.h[0] = *reinterpret_cast<const uint2*>(base + row * pitch + koff + g * 4);
+    r.h[1] = *reinterpret_cast<const uint2*>(base + row * pitch + koff + 16 + g * 4);
+    return r.v;
+}
+__device__ __forceinline__ f32x4 mma(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float group4_sum(float v) {      // over the 4 lane groups holding one pixel's channels
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+// cooperative copy of a [rows][cols] bf16 matrix (global, dense) into LDS with pitch
+__device__ __forceinline__ void stage(unsigned short* dst, int pitch, const bf16* src, int rows, int cols, int tid) {
+    const int vec = cols / 4;
+    for (int i = tid; i < rows * vec; i += 256) {
+        const int r = i / vec, c = (i % vec) * 4;
+        *reinterpret_cast<uint2*>(dst + r * pitch + c) = *reinterpret_cast<const uint2*>(src + (size_t)r * cols + c);
+    }
+}
+
+struct LNres {
+    float mean, rstd;
+};
+// LayerNorm of one pixel held as v[2][4] across 4 lane groups; returns xhat in place of v and the affine in o
+__device__ __forceinline__ LNres layer_norm(const float (&v)[2][4], const float* gam, const float* bet, int g,
+                                            float eps, float (&xh)[2][4], float (&o)[2][4]) {
+    float s = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += v[h][j];
+    const float mean = group4_sum(s) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[h][j] - mean; q += d * d; }
+    const float rstd = rsqrtf(group4_sum(q) * (1.f / D) + eps);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = h * 16 + g * 4 + j;
+            xh[h][j] = (v[h][j] - mean) * rstd;
+            o[h][j] = xh[h][j] * gam[c] + bet[c];
+        }
+    return LNres{mean, rstd};
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward: 256 threads, 128 pixel rows per workgroup (one 16-pixel sub-tile pair per wavefront)
+// ------------------------------------------------------------------------------------------------------
+template <int MLP>
+__global__ __launch_bounds__(256) void dec_fwd_kernel(DecArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned short sKq[32 * WP], sVoT[32 * WP], sW1[MLP * WP],
+        sW2[32 * (MLP + 8)];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
+    const long row0 = (long)blockIdx.x * 128;
+    const int img = (int)(row0 / p.rows_per_image);
+    stage(sKq, WP, p.kq + (size_t)img * 32 * D, 32, D, tid);
+    stage(sVoT, WP, p.voT + (size_t)img * D * 32, D, 32, tid);
+    stage(sW1, WP, p.w1, MLP, D, tid);
+    stage(sW2, MLP + 8, p.w2, D, MLP, tid);
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const long row = row0 + wv * 32 + ps * 16 + pl;
+        if (row >= p.rows) continue;               // (never splits a wave's MFMA: rows % 16 == 0 is required)
+        const bf16* xr = p.x + row * D;
+        float x[2][4], xh[2][4], xn[2][4];
+        ld4(xr + g * 4, x[0]);
+        ld4(xr + 16 + g * 4, x[1]);
+        layer_norm(x, p.g1, p.be1, g, p.eps, xh, xn);
+        // dots -> softmax over the 4 keys of each head (lane-local)
+        const s16x8 bxn = pack8(xn[0], xn[1]);
+        float at[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 d = mma(lds_a(sKq, WP, s * 16 + pl, 0, g), bxn, f32x4{0.f, 0.f, 0.f, 0.f});
+            const float m = fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]));
+            float e[4], sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { e[j] = __expf(d[j] - m); sum += e[j]; }
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) at[s][j] = e[j] * inv;
+        }
+        const s16x8 bat = pack8(at[0], at[1]);
+        float x1[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 o = mma(lds_a(sVoT, WP, s * 16 + pl, 0, g), bat, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x1[s][j] = o[j] + p.bo[s * 16 + g * 4 + j] + x[s][j];
+        }
+        float xh2[2][4], l2[2][4];
+        layer_norm(x1, p.g2, p.be2, g, p.eps, xh2, l2);
+        const s16x8 bl2 = pack8(l2[0], l2[1]);
+        float hh[MLP / 16][4];
+#pragma unroll
+        for (int s = 0; s < MLP / 16; ++s) {
+            f32x4 z = mma(lds_a(sW1, WP, s * 16 + pl, 0, g), bl2, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hh[s][j] = gelu_erf(z[j] + p.fb1[s * 16 + g * 4 + j]);
+        }
+        f32x4 out[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int q = 0; q < MLP / 32; ++q) {
+            const s16x8 bh = pack8(hh[2 * q], hh[2 * q + 1]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) out[s] = mma(lds_a(sW2, MLP + 8, s * 16 + pl, 32 * q, g), bh, out[s]);
+        }
+        bf16* yr = p.y + row * D;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = out[s][j] + p.fb2[s * 16 + g * 4 + j] + x1[s][j];
+            st4(yr + s * 16 + g * 4, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------------
+// partial layout per workgroup (floats)
+template <int MLP> struct PL {
+    static constexpr int W1 = 0, W2 = MLP * D, B1 = 2 * MLP * D, B2 = B1 + MLP, BO = B2 + D, G1 = BO + D, BE1 = G1 + D,
+                         G2 = BE1 + D, BE2 = G2 + D, KQ = BE2 + D, VOT = KQ + 32 * D, SIZE = VOT + D * 32;
+};
+constexpr int lds_pitch(int row_bytes) { return ((row_bytes / 32) & 1) ? row_bytes : row_bytes + 32; }
+
+// transpose read: channel-sub `cs` of a wave-private [32 px][ch] bf16 tile -> fragment with k = pixels
+__device__ __forceinline__ s16x8 tile_frag(const unsigned char* tile, int pitch, int cs, int pl, int g) {
+    const unsigned char* base = tile + (g * 4 + (pl >> 2)) * pitch + (cs * 16 + (pl & 3) * 4) * 2;
+    U8 r;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 16 * pitch));
+    r.v = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r.v;
+}
+// write a packed (kappa-ordered) 32-channel operand of pixel `pp` into a tile at channel offset c0
+__device__ __forceinline__ void tile_put(unsigned char* tile, int pitch, int pp, int c0, int g, s16x8 v) {
+    U8 r;
+    r.v = v;
+    *reinterpret_cast<uint2*>(tile + pp * pitch + (c0 + g * 4) * 2) = r.h[0];
+    *reinterpret_cast<uint2*>(tile + pp * pitch + (c0 + 16 + g * 4) * 2) = r.h[1];
+}
+
+template <int MLP>
+__global__ __launch_bounds__(256) void dec_bwd_kernel(DecArgs p) {
+    constexpr int NM = MLP / 16, NQ = MLP / 32;
+    constexpr int TP32 = lds_pitch(64), TPM = lds_pitch(MLP * 2);       // tile pitches (bytes)
+    constexpr int TILE = 32 * (TPM > TP32 ? TPM : TP32);                // bytes per wave-private tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* sKq = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* sVoT = sKq + 32 * WP;
+    unsigned short* sVo = sVoT + 32 * WP;
+    unsigned short* sKqT = sVo + 32 * WP;
+    unsigned short* sW1 = sKqT + 32 * WP;                   // [MLP][32]
+    unsigned short* sW2T = sW1 + MLP * WP;                  // [MLP][32]
+    unsigned short* sW2 = sW2T + MLP * WP;                  // [32][MLP]
+    unsigned short* sW1T = sW2 + 32 * (MLP + 8);            // [32][MLP]
+    unsigned char* tiles = reinterpret_cast<unsigned char*>(sW1T + 32 * (MLP + 8));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
+    unsigned char* tA = tiles + (wv * 2 + 0) * TILE;
+    unsigned char* tB = tiles + (wv * 2 + 1) * TILE;
+    const long row0 = (long)blockIdx.x * p.rows_per_block;
+    const int img = (int)(row0 / p.rows_per_image);
+    stage(sKq, WP, p.kq + (size_t)img * 32 * D, 32, D, tid);
+    stage(sVoT, WP, p.voT + (size_t)img * D * 32, D, 32, tid);
+    stage(sVo, WP, p.vo + (size_t)img * 32 * D, 32, D, tid);
+    stage(sKqT, WP, p.kqT + (size_t)img * D * 32, D, 32, tid);
+    stage(sW1, WP, p.w1, MLP, D, tid);
+    stage(sW2T, WP, p.w2T, MLP, D, tid);
+    stage(sW2, MLP + 8, p.w2, D, MLP, tid);
+    stage(sW1T, MLP + 8, p.w1T, D, MLP, tid);
+    __syncthreads();
+
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 aW1[NM][2], aW2[2][NM], aKq[2][2], aVoT[2][2];
+#pragma unroll
+    for (int a = 0; a < NM; ++a) { aW1[a][0] = aW1[a][1] = zero4; aW2[0][a] = aW2[1][a] = zero4; }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { aKq[a][0] = aKq[a][1] = zero4; aVoT[a][0] = aVoT[a][1] = zero4; }
+    float sb1[NM][4], sb2[2][4], sbo[2][4], sg1[2][4], sbe1[2][4], sg2[2][4], sbe2[2][4];
+#pragma unroll
+    for (int a = 0; a < NM; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sb1[a][j] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sb2[a][j] = sbo[a][j] = sg1[a][j] = sbe1[a][j] = sg2[a][j] = sbe2[a][j] = 0.f; }
+
+    for (int it = 0; it < p.rows_per_block / 128; ++it) {
+        // packed operands of the two 16-pixel sub-tiles kept for the pixel-reduction products
+        s16x8 kdy[2], kl2[2], kdd[2], kxn[2], kdx1[2], kat[2], kh[2][NQ], kdz[2][NQ];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const long row = row0 + it * 128 + wv * 32 + ps * 16 + pl;
+            const bf16* xr = p.x + row * D;
+            float x[2][4], xh1[2][4], xn[2][4];
+            ld4(xr + g * 4, x[0]);
+            ld4(xr + 16 + g * 4, x[1]);
+            const LNres n1 = layer_norm(x, p.g1, p.be1, g, p.eps, xh1, xn);
+            kxn[ps] = pack8(xn[0], xn[1]);
+            float at[2][4];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f32x4 d = mma(lds_a(sKq, WP, s * 16 + pl, 0, g), kxn[ps], zero4);
+                const float m = fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]));
+                float e[4], sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { e[j] = __expf(d[j] - m); sum += e[j]; }
+                const float inv = 1.f / sum;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) at[s][j] = e[j] * inv;
+            }
+            kat[ps] = pack8(at[0], at[1]);
+            float x1[2][4];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f32x4 o = mma(lds_a(sVoT, WP, s * 16 + pl, 0, g), kat[ps], zero4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x1[s][j] = o[j] + p.bo[s * 16 + g * 4 + j] + x[s][j];
+            }
+            float xh2[2][4], l2[2][4];
+            const LNres n2 = layer_norm(x1, p.g2, p.be2, g, p.eps, xh2, l2);
+            kl2[ps] = pack8(l2[0], l2[1]);
+            float z[NM][4], hh[NM][4];
+#pragma unroll
+            for (int s = 0; s < NM; ++s) {
+                f32x4 zz = mma(lds_a(sW1, WP, s * 16 + pl, 0, g), kl2[ps], zero4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { z[s][j] = zz[j] + p.fb1[s * 16 + g * 4 + j]; hh[s][j] = gelu_erf(z[s][j]); }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) kh[ps][q] = pack8(hh[2 * q], hh[2 * q + 1]);
+            // ---- backward chain ----
+            const bf16* gr = p.dy + row * D;
+            float dy[2][4];
+            ld4(gr + g * 4, dy[0]);
+            ld4(gr + 16 + g * 4, dy[1]);
+            kdy[ps] = pack8(dy[0], dy[1]);
+            float dz[NM][4];
+#pragma unroll
+            for (int s = 0; s < NM; ++s) {
+                f32x4 dh = mma(lds_a(sW2T, WP, s * 16 + pl, 0, g), kdy[ps], zero4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dz[s][j] = dh[j] * gelu_erf_grad(z[s][j]); sb1[s][j] += dz[s][j]; }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) kdz[ps][q] = pack8(dz[2 * q], dz[2 * q + 1]);
+            f32x4 dl2[2] = {zero4, zero4};
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) dl2[s] = mma(lds_a(sW1T, MLP + 8, s * 16 + pl, 32 * q, g), kdz[ps][q], dl2[s]);
+            // LayerNorm-2 backward (+ residual)
+            float gh[2][4], sa = 0.f, sbb = 0.f, dx1[2][4];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = s * 16 + g * 4 + j;
+                    sg2[s][j] += dl2[s][j] * xh2[s][j];
+                    sbe2[s][j] += dl2[s][j];
+                    sb2[s][j] += dy[s][j];
+                    gh[s][j] = dl2[s][j] * p.g2[c];
+                    sa += gh[s][j];
+                    sbb += gh[s][j] * xh2[s][j];
+                }
+            sa = group4_sum(sa);
+            sbb = group4_sum(sbb);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dx1[s][j] = n2.rstd * (gh[s][j] - (sa + xh2[s][j] * sbb) * (1.f / D)) + dy[s][j];
+                    sbo[s][j] += dx1[s][j];
+                }
+            kdx1[ps] = pack8(dx1[0], dx1[1]);
+            // attention backward
+            float dd[2][4];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f32x4 da = mma(lds_a(sVo, WP, s * 16 + pl, 0, g), kdx1[ps], zero4);
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dot += at[s][j] * da[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dd[s][j] = at[s][j] * (da[j] - dot);
+            }
+            kdd[ps] = pack8(dd[0], dd[1]);
+            float dxn[2][4];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f32x4 t = mma(lds_a(sKqT, WP, s * 16 + pl, 0, g), kdd[ps], zero4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dxn[s][j] = t[j];
+            }
+            sa = 0.f; sbb = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = s * 16 + g * 4 + j;
+                    sg1[s][j] += dxn[s][j] * xh1[s][j];
+                    sbe1[s][j] += dxn[s][j];
+                    gh[s][j] = dxn[s][j] * p.g1[c];
+                    sa += gh[s][j];
+                    sbb += gh[s][j] * xh1[s][j];
+                }
+            sa = group4_sum(sa);
+            sbb = group4_sum(sbb);
+            bf16* dxr = p.y + row * D;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = n1.rstd * (gh[s][j] - (sa + xh1[s][j] * sbb) * (1.f / D)) + dx1[s][j];
+                st4(dxr + s * 16 + g * 4, r);
+            }
+        }
+        // ---- pixel-reduction products over this wave's 32 pixels (K = 32), through wave-private LDS tiles ----
+        // dW2[c][m] += dy^T h
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            tile_put(tA, TP32, ps * 16 + pl, 0, g, kdy[ps]);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) tile_put(tB, TPM, ps * 16 + pl, 32 * q, g, kh[ps][q]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sc = 0; sc < 2; ++sc) {
+            const s16x8 fa = tile_frag(tA, TP32, sc, pl, g);
+#pragma unroll
+            for (int sm = 0; sm < NM; ++sm) aW2[sc][sm] = mma(fa, tile_frag(tB, TPM, sm, pl, g), aW2[sc][sm]);
+        }
+        __syncthreads();
+        // dW1[m][c] += dz^T l2
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) tile_put(tA, TPM, ps * 16 + pl, 32 * q, g, kdz[ps][q]);
+            tile_put(tB, TP32, ps * 16 + pl, 0, g, kl2[ps]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sm = 0; sm < NM; ++sm) {
+            const s16x8 fa = tile_frag(tA, TPM, sm, pl, g);
+#pragma unroll
+            for (int sc = 0; sc < 2; ++sc) aW1[sm][sc] = mma(fa, tile_frag(tB, TP32, sc, pl, g), aW1[sm][sc]);
+        }
+        __syncthreads();
+        // dKq[hl][c] += dd^T xn
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            tile_put(tA, TP32, ps * 16 + pl, 0, g, kdd[ps]);
+            tile_put(tB, TP32, ps * 16 + pl, 0, g, kxn[ps]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sr = 0; sr < 2; ++sr) {
+            const s16x8 fa = tile_frag(tA, TP32, sr, pl, g);
+#pragma unroll
+            for (int sc = 0; sc < 2; ++sc) aKq[sr][sc] = mma(fa, tile_frag(tB, TP32, sc, pl, g), aKq[sr][sc]);
+        }
+        __syncthreads();
+        // dVoT[c][hl] += dx1^T attn
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            tile_put(tA, TP32, ps * 16 + pl, 0, g, kdx1[ps]);
+            tile_put(tB, TP32, ps * 16 + pl, 0, g, kat[ps]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sr = 0; sr < 2; ++sr) {
+            const s16x8 fa = tile_frag(tA, TP32, sr, pl, g);
+#pragma unroll
+            for (int sc = 0; sc < 2; ++sc) aVoT[sr][sc] = mma(fa, tile_frag(tB, TP32, sc, pl, g), aVoT[sr][sc]);
+        }
+        __syncthreads();
+    }
+
+    // ---- combine the 4 wavefronts deterministically in LDS, then write this workgroup's partial ----
+    float* red = reinterpret_cast<float*>(tiles);            // PL::SIZE floats (fits: checked on the host)
+    using P = PL<MLP>;
+    auto put = [&](int idx, float v, bool first) { if (first) red[idx] = v; else red[idx] += v; };
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+            const bool first = w == 0;
+#pragma unroll
+            for (int sm = 0; sm < NM; ++sm)
+#pragma unroll
+                for (int sc = 0; sc < 2; ++sc)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        put(P::W1 + (sm * 16 + g * 4 + j) * D + sc * 16 + pl, aW1[sm][sc][j], first);
+                        put(P::W2 + (sc * 16 + g * 4 + j) * MLP + sm * 16 + pl, aW2[sc][sm][j], first);
+                    }
+#pragma unroll
+            for (int sr = 0; sr < 2; ++sr)
+#pragma unroll
+                for (int sc = 0; sc < 2; ++sc)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        put(P::KQ + (sr * 16 + g * 4 + j) * D + sc * 16 + pl, aKq[sr][sc][j], first);
+                        put(P::VOT + (sr * 16 + g * 4 + j) * 32 + sc * 16 + pl, aVoT[sr][sc][j], first);
+                    }
+            // lane-local column sums: reduce over the 16 pixel lanes first
+#pragma unroll
+            for (int s = 0; s < NM; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = sb1[s][j];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    if (pl == 0) put(P::B1 + s * 16 + g * 4 + j, v, first);
+                }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[6] = {sb2[s][j], sbo[s][j], sg1[s][j], sbe1[s][j], sg2[s][j], sbe2[s][j]};
+                    const int off[6] = {P::B2, P::BO, P::G1, P::BE1, P::G2, P::BE2};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        float t = v[k];
+#pragma unroll
+                        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                        if (pl == 0) put(off[k] + s * 16 + g * 4 + j, t, first);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    float* out = p.partial + (size_t)blockIdx.x * P::SIZE;
+    for (int i = tid; i < P::SIZE; i += 256) out[i] = red[i];
+}
+
+// sums the workgroup partials: shared parameters over all workgroups (accumulated into the gradient arena),
+// per-image dKq / dVoT over the workgroups of that image (assigned)
+template <int MLP>
+__global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int bpi,
+                                                               float* dw1, float* dw2, float* db1, float* db2,
+                                                               float* dbo, float* dg1, float* dbe1, float* dg2,
+                                                               float* dbe2, float* dkq, float* dvoT) {
+    using P = PL<MLP>;
+    __shared__ double red[8][32];
+    const int lane = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + lane;                 // element of the shared-parameter part
+    if (blockIdx.y == 0) {
+        double s = 0.0;
+        if (i < P::KQ)
+            for (int b = ph; b < nblk; b += 8) s += (double)partial[(size_t)b * P::SIZE + i];
+        red[ph][lane] = s;
+        __syncthreads();
+        if (ph == 0 && i < P::KQ) {
+            double t = 0.0;
+            for (int r = 0; r < 8; ++r) t += red[r][lane];
+            float* dst;
+            int o;
+            if (i < P::W2) { dst = dw1; o = i - P::W1; }
+            else if (i < P::B1) { dst = dw2; o = i - P::W2; }
+            else if (i < P::B2) { dst = db1; o = i - P::B1; }
+            else if (i < P::BO) { dst = db2; o = i - P::B2; }
+            else if (i < P::G1) { dst = dbo; o = i - P::BO; }
+            else if (i < P::BE1) { dst = dg1; o = i - P::G1; }
+            else if (i < P::G2) { dst = dbe1; o = i - P::BE1; }
+            else if (i < P::BE2) { dst = dg2; o = i - P::G2; }
+            else { dst = dbe2; o = i - P::BE2; }
+            dst[o] += (float)t;
+        }
+    } else {
+        const int img = blockIdx.y - 1;
+        const int e = blockIdx.x * 256 + threadIdx.x;     // element of [dKq | dVoT] (2048)
+        if (e < 2048) {
+            float s = 0.f;
+            for (int b = 0; b < bpi; ++b) s += partial[(size_t)(img * bpi + b) * P::SIZE + P::KQ + e];
+            if (e < 1024) dkq[(size_t)img * 1024 + e] = s;
+            else dvoT[(size_t)img * 1024 + e - 1024] = s;
+        }
+    }
+}
+
+template <int MLP> size_t bwd_lds_bytes() {
+    const size_t w = (size_t)(4 * 32 * WP + 2 * MLP * WP + 2 * 32 * (MLP + 8)) * 2;
+    const size_t tile = 32 * (size_t)(lds_pitch(MLP * 2) > lds_pitch(64) ? lds_pitch(MLP * 2) : lds_pitch(64));
+    size_t t = 8 * tile;
+    if (t < (size_t)PL<MLP>::SIZE * 4) t = (size_t)PL<MLP>::SIZE * 4;
+    return w + t;
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+static int check_common(long rows, int rows_per_image, int mlp) {
+    DH_REQUIRE(mlp == 32 || mlp == 64, "decoder_fused: mlp_dim must be 32 or 64, got %d", mlp);
+    DH_REQUIRE(rows_per_image % 128 == 0 && rows % rows_per_image == 0, "decoder_fused: rows per image (%d) must be a multiple of 128", rows_per_image);
+    return 0;
+}
+
+// x, y: [rows][32] bf16; kq, voT: [images][32][32] bf16 (dh_xattn_prep_fwd); w1: [mlp][32], w2: [32][mlp] bf16
+extern "C" int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, const void* voT, const float* ln1_g,
+                                    const float* ln1_b, const float* bo, const float* ln2_g, const float* ln2_b,
+                                    const void* w1, const float* b1, const void* w2, const float* b2, long rows,
+                                    int rows_per_image, int mlp, float eps, void* stream) {
+    if (check_common(rows, rows_per_image, mlp)) return 1;
+    DecArgs a = {};
+    a.x = (const bf16*)x; a.y = (bf16*)y; a.kq = (const bf16*)kq; a.voT = (const bf16*)voT;
+    a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2;
+    a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
+    a.rows_per_image = rows_per_image; a.rows = rows; a.eps = eps;
+    const int grid = (int)(rows / 128);
+    if (mlp == 64) hipLaunchKernelGGL(dec_fwd_kernel<64>, dim3(grid), dim3(256), 0, ST(stream), a);
+    else hipLaunchKernelGGL(dec_fwd_kernel<32>, dim3(grid), dim3(256), 0, ST(stream), a);
+    DH_CHECK_LAUNCH("decoder_layer_fwd");
+    return 0;
+}
+
+static inline int dec_rows_per_block(int rows_per_image) { return rows_per_image >= 512 ? 512 : (rows_per_image >= 256 ? 256 : 128); }
+
+extern "C" long dh_decoder_layer_bwd_workspace_size(long rows, int rows_per_image, int mlp) {
+    const long nblk = rows / dec_rows_per_block(rows_per_image);
+    return nblk * (mlp == 64 ? PL<64>::SIZE : PL<32>::SIZE) * 4;
+}
+
+// dx: [rows][32] bf16.  Shared-parameter gradients are ACCUMULATED into dw1 [mlp][32], dw2 [32][mlp], db1, db2,
+// dbo, dln1_g/b, dln2_g/b (fp32); per-image dkq [images][32][32], dvoT [images][32][32] are assigned.
+extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, const void* kq, const void* voT,
+                                    const void* vo, const void* kqT, const float* ln1_g, const float* ln1_b,
+                                    const float* bo, const float* ln2_g, const float* ln2_b, const void* w1,
+                                    const void* w1T, const float* b1, const void* w2, const void* w2T, const float* b2,
+                                    float* dw1, float* dw2, float* db1, float* db2, float* dbo, float* dln1_g,
+                                    float* dln1_b, float* dln2_g, float* dln2_b, float* dkq, float* dvoT, long rows,
+                                    int rows_per_image, int mlp, float eps, void* workspace, void* stream) {
+    if (check_common(rows, rows_per_image, mlp)) return 1;
+    DecArgs a = {};
+    a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.y = (bf16*)dx;
+    a.kq = (const bf16*)kq; a.voT = (const bf16*)voT; a.vo = (const bf16*)vo; a.kqT = (const bf16*)kqT;
+    a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2; a.w1T = (const bf16*)w1T; a.w2T = (const bf16*)w2T;
+    a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
+    a.partial = reinterpret_cast<float*>(workspace);
+    a.rows_per_image = rows_per_image; a.rows_per_block = dec_rows_per_block(rows_per_image); a.rows = rows; a.eps = eps;
+    const int nblk = (int)(rows / a.rows_per_block), bpi = rows_per_image / a.rows_per_block;
+    const int images = (int)(rows / rows_per_image);
+    static bool attr64 = false, attr32 = false;
+    if (mlp == 64) {
+        const size_t lds = bwd_lds_bytes<64>();
+        if (!attr64) {
+            attr64 = true;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                DH_FAIL("decoder_layer_bwd: cannot raise dynamic LDS to %zu", lds);
+            }
+        }
+        hipLaunchKernelGGL(dec_bwd_kernel<64>, dim3(nblk), dim3(256), lds, ST(stream), a);
+        hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(dh_cdiv(PL<64>::KQ, 32), 1 + images), dim3(256), 0, ST(stream),
+                           a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT);
+    } else {
+        const size_t lds = bwd_lds_bytes<32>();
+        if (!attr32) {
+            attr32 = true;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                DH_FAIL("decoder_layer_bwd: cannot raise dynamic LDS to %zu", lds);
+            }
+        }
+        hipLaunchKernelGGL(dec_bwd_kernel<32>, dim3(nblk), dim3(256), lds, ST(stream), a);
+        hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(dh_cdiv(PL<32>::KQ, 32), 1 + images), dim3(256), 0, ST(stream),
+                           a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT);
+    }
+    DH_CHECK_LAUNCH("decoder_layer_bwd");
+    return 0;
+}

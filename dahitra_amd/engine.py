@@ -10,6 +10,8 @@ Reference structure followed (not copied): BASE_Transformer.forward models/netwo
 ResNet.forward_single :233-257, BasicBlock models/resnet.py:58-73, Transformer / TransformerDecoder
 models/help_funcs.py:154-186, BASE_Transformer_UNet.forward models/networks.py:1297-1357.
 """
+import os
+
 import torch
 
 from . import ops
@@ -32,6 +34,7 @@ class Engine:
         self.cfg = get_config(net_G)
         self.dtype = dtype
         self.use_tr = use_tr
+        self.fused_decoder = os.environ.get("DAHITRA_NO_FUSED_DECODER", "0") != "1"
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -248,8 +251,15 @@ class Engine:
         (help_funcs.py:170-186); dtok accumulates the token gradients."""
         bw = []
         x = x2d
+        rpi = x2d.shape[0] // images
         for i in range(depth):
             a, f = "%s.layers.%d.0.fn" % (pfx, i), "%s.layers.%d.1.fn" % (pfx, i)
+            mlp = self.shapes[f + ".fn.net.0.weight"][0]
+            if self.fused_decoder and self.dtype == torch.bfloat16 and L == 4 and heads * L <= 32 and rpi % 128 == 0 \
+                    and mlp in (32, 64):
+                x, b1 = self._dec_layer_fused(x, images, rpi, tok, tok_b, tok_s, B, dtok, a, f, heads, dim_head, L, mlp)
+                bw.append(b1)
+                continue
             x, b1 = self._dec_attn(x, images, tok, tok_b, tok_s, B, dtok, a, heads, dim_head, L)
             x, b2 = self.mlp_block(x, f)
             bw += [b1, b2]
@@ -261,6 +271,34 @@ class Engine:
                 d = b(d)
             return d
         return x, bwd
+
+    def _dec_layer_fused(self, x0, images, rpi, tok, tok_b, tok_s, B, dtok, a, f, heads, dim_head, L, mlp):
+        """one decoder layer = one HIP kernel per direction (csrc/decoder_fused.hip) + the per-image operand prep"""
+        g1, b1 = self.p[a + ".norm.weight"], self.p[a + ".norm.bias"]
+        wq, wk, wv = (self.p[a + ".fn.to_%s.weight" % n] for n in "qkv")
+        wo, bo = self.p[a + ".fn.to_out.0.weight"], self.p[a + ".fn.to_out.0.bias"]
+        g2, b2 = self.p[f + ".norm.weight"], self.p[f + ".norm.bias"]
+        w1k, w2k = f + ".fn.net.0.weight", f + ".fn.net.3.weight"
+        fb1, fb2 = self.p[f + ".fn.net.0.bias"], self.p[f + ".fn.net.3.bias"]
+        prep = ops.XattnPrep(tok, tok_b, tok_s, B, images, L, heads, dim_head, g1, b1, wq, wk, wv, wo, self.dtype,
+                             ATTN_SCALE, LN_EPS)
+        y = ops.decoder_layer_fwd(x0, prep, rpi, g1, b1, bo, g2, b2, self.pk[w1k].fwd, fb1, self.pk[w2k].fwd, fb2, mlp,
+                                  LN_EPS)
+        if not self.need_grad:
+            return y, None
+
+        def bwd(dy):
+            grads = (self.g[w1k], self.g[w2k], self.g[f + ".fn.net.0.bias"], self.g[f + ".fn.net.3.bias"],
+                     self.g[a + ".fn.to_out.0.bias"], self.g[a + ".norm.weight"], self.g[a + ".norm.bias"],
+                     self.g[f + ".norm.weight"], self.g[f + ".norm.bias"])
+            dx, dkq, dvoT = ops.decoder_layer_bwd(x0, dy, prep, rpi, g1, b1, bo, g2, b2, self.pk[w1k].fwd,
+                                                  self.pk[w1k].dgrad, fb1, self.pk[w2k].fwd, self.pk[w2k].dgrad, fb2,
+                                                  grads, mlp, LN_EPS)
+            ops.xattn_prep_bwd(prep, tok, dtok, g1, wq, wk, wv, wo, dkq, dvoT, self.g[a + ".norm.weight"],
+                               self.g[a + ".norm.bias"], *(self.g[a + ".fn.to_%s.weight" % n] for n in "qkv"),
+                               self.g[a + ".fn.to_out.0.weight"], True, self.dtype)
+            return dx
+        return y, bwd
 
     def _dec_attn(self, x0, images, tok, tok_b, tok_s, B, dtok, a, heads, dim_head, L):
         g1, b1 = self.p[a + ".norm.weight"], self.p[a + ".norm.bias"]

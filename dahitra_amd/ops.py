@@ -450,6 +450,30 @@ def xattn_prep_bwd(prep, tok, dtok_accum, ln_g, wq, wk, wv, wo, dkq, dvoT, dln_g
           P(dwk), P(dwv), P(dwo), _ci(int(accumulate)), P(ws), S())
 
 
+def decoder_layer_fwd(x2d, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b, w1, b1, w2, b2, mlp, eps=1e-5):
+    """fused cross-attention + MLP decoder layer (csrc/decoder_fused.hip); x2d [rows, 32] bf16"""
+    y = torch.empty_like(x2d)
+    _call("dh_decoder_layer_fwd", P(x2d), P(y), P(prep.kq), P(prep.voT), P(ln1_g), P(ln1_b), P(bo), P(ln2_g), P(ln2_b),
+          P(w1), P(b1), P(w2), P(b2), _cl(x2d.shape[0]), _ci(rows_per_image), _ci(mlp), _cf(eps), S())
+    return y
+
+
+def decoder_layer_bwd(x2d, dy, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b, w1, w1T, b1, w2, w2T, b2, grads, mlp,
+                      eps=1e-5):
+    """returns (dx, dkq [S,32,32] fp32, dvoT [S,32,32] fp32); grads = (dw1, dw2, db1, db2, dbo, dg1, dbe1, dg2, dbe2)
+    are accumulated in place"""
+    rows = x2d.shape[0]
+    images = rows // rows_per_image
+    dx = torch.empty_like(x2d)
+    dkq = torch.empty(images, 32, 32, dtype=torch.float32, device=x2d.device)
+    dvoT = torch.empty(images, 32, 32, dtype=torch.float32, device=x2d.device)
+    ws = workspace(_lib.lib().dh_decoder_layer_bwd_workspace_size(_cl(rows), rows_per_image, mlp), x2d.device)
+    _call("dh_decoder_layer_bwd", P(x2d), P(dy), P(dx), P(prep.kq), P(prep.voT), P(prep.vo), P(prep.kqT), P(ln1_g),
+          P(ln1_b), P(bo), P(ln2_g), P(ln2_b), P(w1), P(w1T), P(b1), P(w2), P(w2T), P(b2), *(P(t) for t in grads),
+          P(dkq), P(dvoT), _cl(rows), _ci(rows_per_image), _ci(mlp), _cf(eps), P(ws), S())
+    return dx, dkq, dvoT
+
+
 def softmax_groups(x2d, heads, L):
     rows, HLP = x2d.shape
     y = torch.empty_like(x2d)

@@ -137,6 +137,21 @@ int dh_softmax_groups_bwd(int dtype, const void* y, const void* dy, void* dx, lo
 int dh_self_attn_fwd(int dtype, const void* qkv, void* o, float* attn, int B, int n, int heads, int dim_head, float scale, void* stream);
 int dh_self_attn_bwd(int dtype, const void* qkv, const float* attn, const void* dout, void* dqkv, int B, int n, int heads, int dim_head, float scale, void* stream);
 
+/* Fused cross-attention decoder layer (help_funcs.py:170-186: Residual2(PreNorm2(Cross_Attention)) + Residual(PreNorm(
+ * FeedForward))) in one kernel per direction; bf16, token_len 4, heads*4 <= 32, rows per image % 128 == 0.
+ * kq / voT / vo / kqT are the per-image operands of dh_xattn_prep_fwd; w1 [mlp][32], w2 [32][mlp] (+ transposes). */
+int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, const void* voT, const float* ln1_g,
+                         const float* ln1_b, const float* bo, const float* ln2_g, const float* ln2_b, const void* w1,
+                         const float* b1, const void* w2, const float* b2, long rows, int rows_per_image, int mlp,
+                         float eps, void* stream);
+int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, const void* kq, const void* voT, const void* vo,
+                         const void* kqT, const float* ln1_g, const float* ln1_b, const float* bo, const float* ln2_g,
+                         const float* ln2_b, const void* w1, const void* w1T, const float* b1, const void* w2,
+                         const void* w2T, const float* b2, float* dw1, float* dw2, float* db1, float* db2, float* dbo,
+                         float* dln1_g, float* dln1_b, float* dln2_g, float* dln2_b, float* dkq, float* dvoT, long rows,
+                         int rows_per_image, int mlp, float eps, void* workspace, void* stream);
+long dh_decoder_layer_bwd_workspace_size(long rows, int rows_per_image, int mlp);
+
 /* ---- loss, mask, optimizer (models/losses.py:106-196; trainer.py:39-40,170) ------------------- */
 int dh_focal_loss(const float* logits_nchw, const long long* target, int B, int C, long HW, float alpha,
                   float grad_scale, float* loss_out, float* dlogits_nchw, void* workspace, void* stream);
