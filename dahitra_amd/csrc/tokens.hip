@@ -188,12 +188,15 @@ __global__ void tok_dpos_kernel(const T* __restrict__ dtok_cat, int B, int n, fl
 // ------------------------------------------------------------------------------------------
 // cross-attention operand preparation (per image)
 // ------------------------------------------------------------------------------------------
+// Weight access is coalesced everywhere: thread index runs along the contiguous dimension of whichever form
+// (fp32 master [out][in], or the packed transpose in T produced by dh_pack_weight) makes that possible.
 struct PrepArgs {
     const void* tok;        // token rows, T
     long tok_bstride, tok_sstride;   // elements between batch items / streams
     int B, S, L, heads, dh, HLP;
     float scale, eps;
-    const float *ln_g, *ln_b, *wq, *wk, *wv, *wo;
+    const float *ln_g, *ln_b, *wq;   // wq fp32 [inner][32]
+    const void *wkT, *wvT, *woT;     // T: [32][inner], [32][inner], [inner][32]
     float *mn, *mstats, *k, *v;      // saved fp32: [S][L][32], [S][L][2], [S][L][inner] x2
     void *kq, *kqT, *vo, *voT;       // packed T: [S][HLP][32], [S][32][HLP], [S][HLP][32], [S][32][HLP]
 };
@@ -207,40 +210,52 @@ __global__ __launch_bounds__(256) void xattn_prep_kernel(PrepArgs a) {
     float* sk = smn + L * D;            // [L][inner]
     float* sv = sk + L * inner;         // [L][inner]
     const T* m = reinterpret_cast<const T*>(a.tok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
-    // LayerNorm of the L token rows (shared LN of PreNorm2, help_funcs.py:48-49)
-    if (tid < L) {
-        float mu = 0.f;
-        for (int c = 0; c < D; ++c) mu += ldf(m + tid * D + c);
-        mu *= 1.f / D;
-        float q = 0.f;
-        for (int c = 0; c < D; ++c) { const float d = ldf(m + tid * D + c) - mu; q += d * d; }
-        const float rstd = rsqrtf(q * (1.f / D) + a.eps);
-        a.mstats[((size_t)s * L + tid) * 2] = mu;
-        a.mstats[((size_t)s * L + tid) * 2 + 1] = rstd;
-        for (int c = 0; c < D; ++c) {
-            const float v = (ldf(m + tid * D + c) - mu) * rstd * a.ln_g[c] + a.ln_b[c];
-            smn[tid * D + c] = v;
-            a.mn[((size_t)s * L + tid) * D + c] = v;
+    // LayerNorm of the L token rows (shared LN of PreNorm2, help_funcs.py:48-49): 32 lanes per row
+    {
+        const int l = tid >> 5, c = tid & 31;
+        if (l < L) {
+            const float x = ldf(m + l * D + c);
+            float t = x;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            const float mu = t * (1.f / D);
+            float q = (x - mu) * (x - mu);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            const float rstd = rsqrtf(q * (1.f / D) + a.eps);
+            const float v = (x - mu) * rstd * a.ln_g[c] + a.ln_b[c];
+            smn[l * D + c] = v;
+            a.mn[((size_t)s * L + l) * D + c] = v;
+            if (c == 0) { a.mstats[((size_t)s * L + l) * 2] = mu; a.mstats[((size_t)s * L + l) * 2 + 1] = rstd; }
         }
     }
     __syncthreads();
-    for (int i = tid; i < L * inner; i += 256) {
-        const int l = i / inner, hd = i % inner;
-        float kk = 0.f, vv = 0.f;
+    const T* wkT = reinterpret_cast<const T*>(a.wkT);
+    const T* wvT = reinterpret_cast<const T*>(a.wvT);
+    for (int hd = tid; hd < inner; hd += 256) {
+        float kk[8], vv[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) { kk[l] = 0.f; vv[l] = 0.f; }
         for (int c = 0; c < D; ++c) {
-            const float x = smn[l * D + c];
-            kk += a.wk[hd * D + c] * x;
-            vv += a.wv[hd * D + c] * x;
+            const float wk = ldf(wkT + (size_t)c * inner + hd), wv = ldf(wvT + (size_t)c * inner + hd);
+#pragma unroll
+            for (int l = 0; l < 8; ++l)
+                if (l < L) { kk[l] += wk * smn[l * D + c]; vv[l] += wv * smn[l * D + c]; }
         }
-        sk[i] = kk; sv[i] = vv;
-        a.k[(size_t)s * L * inner + i] = kk;
-        a.v[(size_t)s * L * inner + i] = vv;
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+            if (l < L) {
+                sk[l * inner + hd] = kk[l]; sv[l * inner + hd] = vv[l];
+                a.k[((size_t)s * L + l) * inner + hd] = kk[l];
+                a.v[((size_t)s * L + l) * inner + hd] = vv[l];
+            }
     }
     __syncthreads();
     T* kq = reinterpret_cast<T*>(a.kq) + (size_t)s * a.HLP * D;
     T* kqT = reinterpret_cast<T*>(a.kqT) + (size_t)s * a.HLP * D;
     T* vo = reinterpret_cast<T*>(a.vo) + (size_t)s * a.HLP * D;
     T* voT = reinterpret_cast<T*>(a.voT) + (size_t)s * a.HLP * D;
+    const T* woT = reinterpret_cast<const T*>(a.woT);
     for (int i = tid; i < a.HLP * D; i += 256) {
         const int hl = i / D, c = i % D;
         float q = 0.f, o = 0.f;
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(256) void xattn_prep_kernel(PrepArgs a) {
             for (int d = 0; d < a.dh; ++d) {
                 const int hd = h * a.dh + d;
                 q += a.wq[hd * D + c] * sk[l * inner + hd];
-                o += a.wo[c * inner + hd] * sv[l * inner + hd];
+                o += ldf(woT + (size_t)hd * D + c) * sv[l * inner + hd];
             }
             q *= a.scale;
         }
@@ -266,7 +281,8 @@ struct PrepBwdArgs {
     float scale;
     const void* tok;                 // T, forward token rows (for the LN backward)
     void* dtok;                      // T, accumulated in place (same addressing as tok)
-    const float *ln_g, *wq, *wk, *wv, *wo;
+    const float *ln_g, *wk, *wv, *wo;   // fp32 masters: wk, wv [inner][32]; wo [32][inner]
+    const void* wqT;                 // T [32][inner]
     const float *mn, *mstats;
     const float *dkq, *dvoT;         // [S][HLP][32], [S][32][HLP] fp32 (per-image weight gradients)
     float *dk, *dv;                  // out [S][L][inner]
@@ -281,88 +297,131 @@ __global__ __launch_bounds__(256) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
     float* sdk = sm;                 // [L][inner]
     float* sdv = sdk + L * inner;    // [L][inner]
     float* sdmn = sdv + L * inner;   // [L][32]
-    const float* dkq = a.dkq + (size_t)s * a.HLP * D;
-    const float* dvoT = a.dvoT + (size_t)s * a.HLP * D;
-    for (int i = tid; i < L * inner; i += 256) {
-        const int l = i / inner, hd = i % inner, h = hd / a.dh, hl = h * L + l;
-        float gk = 0.f, gv = 0.f;
+    float* sgk = sdmn + L * D;       // [HLP][32]   staged dKq
+    float* sgv = sgk + a.HLP * D;    // [32][HLP]   staged dVoT
+    float* sred = sgv + a.HLP * D;   // [8][L][32]
+    for (int i = tid; i < a.HLP * D; i += 256) {
+        sgk[i] = a.dkq[(size_t)s * a.HLP * D + i];
+        sgv[i] = a.dvoT[(size_t)s * a.HLP * D + i];
+    }
+    __syncthreads();
+    const T* wqT = reinterpret_cast<const T*>(a.wqT);
+    for (int hd = tid; hd < inner; hd += 256) {
+        const int h = hd / a.dh;
+        float gk[8], gv[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) { gk[l] = 0.f; gv[l] = 0.f; }
         for (int c = 0; c < D; ++c) {
-            gk += dkq[hl * D + c] * a.wq[hd * D + c];
-            gv += dvoT[c * a.HLP + hl] * a.wo[c * inner + hd];
+            const float wq = ldf(wqT + (size_t)c * inner + hd), wo = a.wo[(size_t)c * inner + hd];
+#pragma unroll
+            for (int l = 0; l < 8; ++l)
+                if (l < L) { gk[l] += sgk[(h * L + l) * D + c] * wq; gv[l] += sgv[c * a.HLP + h * L + l] * wo; }
         }
-        gk *= a.scale;
-        sdk[i] = gk; sdv[i] = gv;
-        a.dk[(size_t)s * L * inner + i] = gk;
-        a.dv[(size_t)s * L * inner + i] = gv;
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+            if (l < L) {
+                const float t = gk[l] * a.scale;
+                sdk[l * inner + hd] = t; sdv[l * inner + hd] = gv[l];
+                a.dk[((size_t)s * L + l) * inner + hd] = t;
+                a.dv[((size_t)s * L + l) * inner + hd] = gv[l];
+            }
+    }
+    __syncthreads();
+    // dmn[l][c] = sum_hd dk[l][hd] wk[hd][c] + dv[l][hd] wv[hd][c]: 8 hd-chunks x 32 channels, then LDS reduce
+    {
+        const int c = tid & 31, ch = tid >> 5, per = (inner + 7) / 8;
+        float acc[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[l] = 0.f;
+        for (int hd = ch * per; hd < (ch + 1) * per && hd < inner; ++hd) {
+            const float wk = a.wk[(size_t)hd * D + c], wv = a.wv[(size_t)hd * D + c];
+#pragma unroll
+            for (int l = 0; l < 8; ++l)
+                if (l < L) acc[l] += sdk[l * inner + hd] * wk + sdv[l * inner + hd] * wv;
+        }
+#pragma unroll
+        for (int l = 0; l < 8; ++l)
+            if (l < L) sred[(ch * L + l) * D + c] = acc[l];
     }
     __syncthreads();
     for (int i = tid; i < L * D; i += 256) {
-        const int l = i / D, c = i % D;
-        float g = 0.f;
-        for (int hd = 0; hd < inner; ++hd) g += sdk[l * inner + hd] * a.wk[hd * D + c] + sdv[l * inner + hd] * a.wv[hd * D + c];
-        sdmn[i] = g;
+        float t = 0.f;
+        for (int ch = 0; ch < 8; ++ch) t += sred[ch * L * D + i];
+        sdmn[i] = t;
     }
     __syncthreads();
-    // LayerNorm backward on the L rows; accumulate into dtok; per-image dgamma/dbeta
+    // LayerNorm backward on the L rows (32 lanes per row); accumulate into dtok; per-image dgamma/dbeta
     const T* m = reinterpret_cast<const T*>(a.tok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
     T* dm = reinterpret_cast<T*>(a.dtok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
-    if (tid < L) {
-        const float mu = a.mstats[((size_t)s * L + tid) * 2], rstd = a.mstats[((size_t)s * L + tid) * 2 + 1];
-        float sa = 0.f, sb = 0.f;
-        for (int c = 0; c < D; ++c) {
-            const float xh = (ldf(m + tid * D + c) - mu) * rstd, gh = sdmn[tid * D + c] * a.ln_g[c];
-            sa += gh; sb += gh * xh;
-        }
-        for (int c = 0; c < D; ++c) {
-            const float xh = (ldf(m + tid * D + c) - mu) * rstd, gh = sdmn[tid * D + c] * a.ln_g[c];
-            const float g = rstd * (gh - (sa + xh * sb) * (1.f / D));
-            stf(dm + tid * D + c, ldf(dm + tid * D + c) + g);
-        }
-    }
-    if (tid >= 64 && tid < 64 + 2 * D) {
-        const int which = (tid - 64) / D, c = (tid - 64) % D;
-        float t = 0.f;
-        for (int l = 0; l < L; ++l) {
+    {
+        const int l = tid >> 5, c = tid & 31;
+        float pg = 0.f, pb = 0.f;
+        if (l < L) {
             const float mu = a.mstats[((size_t)s * L + l) * 2], rstd = a.mstats[((size_t)s * L + l) * 2 + 1];
-            const float xh = (ldf(m + l * D + c) - mu) * rstd;
-            t += which == 0 ? sdmn[l * D + c] * xh : sdmn[l * D + c];
+            const float xh = (ldf(m + l * D + c) - mu) * rstd, g = sdmn[l * D + c], gh = g * a.ln_g[c];
+            float sa = gh, sb = gh * xh;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+            stf(dm + l * D + c, ldf(dm + l * D + c) + rstd * (gh - (sa + xh * sb) * (1.f / D)));
+            pg = g * xh; pb = g;
         }
+        // sum the L rows' contributions per channel through LDS (rows live in different half-waves)
+        sred[(0 * 8 + l) * D + c] = pg;
+        sred[(1 * 8 + l) * D + c] = pb;
+    }
+    __syncthreads();
+    if (tid < 2 * D) {
+        const int which = tid / D, c = tid % D;
+        float t = 0.f;
+        for (int l = 0; l < L; ++l) t += sred[(which * 8 + l) * D + c];
         a.ln_partial[((size_t)s * 2 + which) * D + c] = t;
     }
 }
 
-// weight gradients of to_q / to_k / to_v / to_out: one thread per element, loop over images
+// weight gradients of to_q / to_k / to_v / to_out: one workgroup per (matrix, hd); 8 image phases x 32 channels,
+// LDS reduce.  blockIdx.y == 4: the shared LayerNorm's dgamma / dbeta from the per-image partials.
 struct PrepWgArgs {
     int S, L, heads, dh, HLP;
     float scale;
-    const float *mn, *k, *v, *dk, *dv, *dkq, *dvoT;
-    float *dwq, *dwk, *dwv, *dwo;
+    const float *mn, *k, *v, *dk, *dv, *dkq, *dvoT, *ln_partial;
+    float *dwq, *dwk, *dwv, *dwo, *dln_g, *dln_b;
     int accumulate;
 };
-__global__ void xattn_prep_wgrad_kernel(PrepWgArgs a) {
+__global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
+    __shared__ float red[8][33];
     const int inner = a.heads * a.dh, L = a.L;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= inner * D) return;
-    const int which = blockIdx.y;
+    const int c = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    const int which = blockIdx.y, hd = blockIdx.x;
     float acc = 0.f;
-    if (which < 3) {
-        const int hd = i / D, c = i % D, h = hd / a.dh;
-        for (int s = 0; s < a.S; ++s)
+    if (which == 4) {
+        if (hd >= 2) return;                                   // hd = 0: dgamma, 1: dbeta
+        for (int s = ph; s < a.S; s += 8) acc += a.ln_partial[((size_t)s * 2 + hd) * D + c];
+    } else {
+        const int h = hd / a.dh;
+        for (int s = ph; s < a.S; s += 8)
             for (int l = 0; l < L; ++l) {
-                const size_t r = ((size_t)s * L + l);
+                const size_t r = (size_t)s * L + l;
                 if (which == 0) acc += a.dkq[((size_t)s * a.HLP + h * L + l) * D + c] * a.k[r * inner + hd];
                 else if (which == 1) acc += a.dk[r * inner + hd] * a.mn[r * D + c];
-                else acc += a.dv[r * inner + hd] * a.mn[r * D + c];
+                else if (which == 2) acc += a.dv[r * inner + hd] * a.mn[r * D + c];
+                else acc += a.dvoT[((size_t)s * D + c) * a.HLP + h * L + l] * a.v[r * inner + hd];
             }
-        if (which == 0) acc *= a.scale;
-        float* out = which == 0 ? a.dwq : (which == 1 ? a.dwk : a.dwv);
-        if (a.accumulate) out[i] += acc; else out[i] = acc;
-    } else {
-        const int c = i / inner, hd = i % inner, h = hd / a.dh;     // to_out weight is [32][inner]
-        for (int s = 0; s < a.S; ++s)
-            for (int l = 0; l < L; ++l)
-                acc += a.dvoT[((size_t)s * D + c) * a.HLP + h * L + l] * a.v[((size_t)s * L + l) * inner + hd];
-        if (a.accumulate) a.dwo[i] += acc; else a.dwo[i] = acc;
+    }
+    red[ph][c] = acc;
+    __syncthreads();
+    if (ph == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][c];
+        if (which == 4) {
+            float* out = hd == 0 ? a.dln_g : a.dln_b;
+            out[c] += t;                                       // the pixel-side LN backward wrote its part already
+            return;
+        }
+        if (which == 0) t *= a.scale;
+        float* out = which == 0 ? a.dwq : (which == 1 ? a.dwk : (which == 2 ? a.dwv : a.dwo));
+        const size_t o = which == 3 ? (size_t)c * inner + hd : (size_t)hd * D + c;     // to_out weight is [32][inner]
+        if (a.accumulate) out[o] += t; else out[o] = t;
     }
 }
 
@@ -561,14 +620,14 @@ extern "C" int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S
 
 extern "C" int dh_xattn_prep_fwd(int dtype, const void* tok, long tok_bstride, long tok_sstride, int B, int S, int L,
                                  int heads, int dim_head, int HLP, float scale, float eps, const float* ln_g,
-                                 const float* ln_b, const float* wq, const float* wk, const float* wv,
-                                 const float* wo, float* mn, float* mstats, float* k, float* v, void* kq, void* kqT,
+                                 const float* ln_b, const float* wq, const void* wkT, const void* wvT,
+                                 const void* woT, float* mn, float* mstats, float* k, float* v, void* kq, void* kqT,
                                  void* vo, void* voT, void* stream) {
-    DH_REQUIRE(heads * L <= HLP && HLP % L == 0, "xattn_prep: heads*L=%d exceeds HLP=%d", heads * L, HLP);
+    DH_REQUIRE(heads * L <= HLP && HLP % L == 0 && L <= 8, "xattn_prep: heads*L=%d exceeds HLP=%d (or L > 8)", heads * L, HLP);
     PrepArgs a;
     a.tok = tok; a.tok_bstride = tok_bstride; a.tok_sstride = tok_sstride; a.B = B; a.S = S; a.L = L;
     a.heads = heads; a.dh = dim_head; a.HLP = HLP; a.scale = scale; a.eps = eps; a.ln_g = ln_g; a.ln_b = ln_b;
-    a.wq = wq; a.wk = wk; a.wv = wv; a.wo = wo; a.mn = mn; a.mstats = mstats; a.k = k; a.v = v;
+    a.wq = wq; a.wkT = wkT; a.wvT = wvT; a.woT = woT; a.mn = mn; a.mstats = mstats; a.k = k; a.v = v;
     a.kq = kq; a.kqT = kqT; a.vo = vo; a.voT = voT;
     const size_t lds = (size_t)(L * 32 + 2 * L * heads * dim_head) * 4;
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_kernel<bf16>, dim3(S), dim3(256), lds, ST(stream), a);
@@ -580,35 +639,29 @@ extern "C" int dh_xattn_prep_fwd(int dtype, const void* tok, long tok_bstride, l
 // workspace: ln_partial [S][2][32] floats
 extern "C" int dh_xattn_prep_bwd(int dtype, const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride,
                                  int B, int S, int L, int heads, int dim_head, int HLP, float scale,
-                                 const float* ln_g, const float* wq, const float* wk, const float* wv,
+                                 const float* ln_g, const void* wqT, const float* wk, const float* wv,
                                  const float* wo, const float* mn, const float* mstats, const float* k,
                                  const float* v, const float* dkq, const float* dvoT, float* dk, float* dv,
                                  float* dln_g, float* dln_b, float* dwq, float* dwk, float* dwv, float* dwo,
                                  int accumulate, void* workspace, void* stream) {
+    DH_REQUIRE(L <= 8, "xattn_prep_bwd: L=%d > 8", L);
     PrepBwdArgs a;
     a.tok_bstride = tok_bstride; a.tok_sstride = tok_sstride; a.B = B; a.S = S; a.L = L; a.heads = heads;
-    a.dh = dim_head; a.HLP = HLP; a.scale = scale; a.tok = tok; a.dtok = dtok_accum; a.ln_g = ln_g; a.wq = wq;
+    a.dh = dim_head; a.HLP = HLP; a.scale = scale; a.tok = tok; a.dtok = dtok_accum; a.ln_g = ln_g; a.wqT = wqT;
     a.wk = wk; a.wv = wv; a.wo = wo; a.mn = mn; a.mstats = mstats; a.dkq = dkq; a.dvoT = dvoT; a.dk = dk; a.dv = dv;
     a.ln_partial = reinterpret_cast<float*>(workspace);
     const int inner = heads * dim_head;
-    const size_t lds = (size_t)(2 * L * inner + L * 32) * 4;
+    const size_t lds = (size_t)(2 * L * inner + L * 32 + 2 * HLP * 32 + 16 * 32 + 8 * L * 32) * 4;
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_bwd_kernel<bf16>, dim3(S), dim3(256), lds, ST(stream), a);
     else hipLaunchKernelGGL(xattn_prep_bwd_kernel<float>, dim3(S), dim3(256), lds, ST(stream), a);
     PrepWgArgs w;
     w.S = S; w.L = L; w.heads = heads; w.dh = dim_head; w.HLP = HLP; w.scale = scale; w.mn = mn; w.k = k; w.v = v;
     w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;
+    w.ln_partial = a.ln_partial; w.dln_g = dln_g; w.dln_b = dln_b;
     w.accumulate = accumulate;
-    hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(dh_cdiv(inner * 32, 256), 4), dim3(256), 0, ST(stream), w);
+    hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(inner, 5), dim3(256), 0, ST(stream), w);
     DH_CHECK_LAUNCH("xattn_prep_bwd");
-    // ln_partial rows are [dgamma(32) | dbeta(32)] per image: always accumulated (the pixel-side
-    // LayerNorm backward of the same shared LN has already written its part)
-    float* part = reinterpret_cast<float*>(workspace);
-    float* tmp = part + (size_t)S * 64;
-    int rc = dh_reduce_partials(part, S, 64, 1.0f, tmp, 0, stream);
-    if (rc) return rc;
-    rc = dh_reduce_partials(tmp, 1, 32, 1.0f, dln_g, 1, stream);
-    if (rc) return rc;
-    return dh_reduce_partials(tmp + 32, 1, 32, 1.0f, dln_b, 1, stream);
+    return 0;
 }
 extern "C" long dh_xattn_prep_bwd_workspace_size(int S) { return ((long)S * 64 + 64) * 4; }
 

@@ -58,10 +58,13 @@ class Engine:
             if key == "resnet.conv1.weight":
                 self.pk[key] = Packed(ops.stem_pack_weight(self.p[key], self.dtype), None)
                 continue
-            if ".to_q." in key or ".to_k." in key or ".to_v." in key or key.startswith("conv_a") or \
-                    key.startswith("conv_token") or key.startswith("resnet.fc") or key.startswith("resnet.layer4"):
-                continue        # consumed in fp32 by the token-side kernels, or unused by the forward
-            if ".to_out." in key and "transformer_decoder" in key:
+            if key.startswith("conv_a") or key.startswith("conv_token") or key.startswith("resnet.fc") or \
+                    key.startswith("resnet.layer4"):
+                continue        # consumed in fp32 by the tokenizer kernels, or unused by the forward
+            if ".to_q." in key or ".to_k." in key or ".to_v." in key or \
+                    (".to_out." in key and "transformer_decoder" in key):
+                # cross-attention weights: the token-side prep reads their transposes (coalesced)
+                self.pk[key] = Packed(None, ops.pack_weight(self.p[key], self.dtype, want_dgrad=True)[1])
                 continue
             O = shape[0]
             inner = -(-O // ck) * ck
@@ -280,7 +283,9 @@ class Engine:
         g2, b2 = self.p[f + ".norm.weight"], self.p[f + ".norm.bias"]
         w1k, w2k = f + ".fn.net.0.weight", f + ".fn.net.3.weight"
         fb1, fb2 = self.p[f + ".fn.net.0.bias"], self.p[f + ".fn.net.3.bias"]
-        prep = ops.XattnPrep(tok, tok_b, tok_s, B, images, L, heads, dim_head, g1, b1, wq, wk, wv, wo, self.dtype,
+        wqT, wkT, wvT = (self.pk[a + ".fn.to_%s.weight" % n].dgrad for n in "qkv")
+        woT = self.pk[a + ".fn.to_out.0.weight"].dgrad
+        prep = ops.XattnPrep(tok, tok_b, tok_s, B, images, L, heads, dim_head, g1, b1, wq, wkT, wvT, woT, self.dtype,
                              ATTN_SCALE, LN_EPS)
         y = ops.decoder_layer_fwd(x0, prep, rpi, g1, b1, bo, g2, b2, self.pk[w1k].fwd, fb1, self.pk[w2k].fwd, fb2, mlp,
                                   LN_EPS)
@@ -294,7 +299,7 @@ class Engine:
             dx, dkq, dvoT = ops.decoder_layer_bwd(x0, dy, prep, rpi, g1, b1, bo, g2, b2, self.pk[w1k].fwd,
                                                   self.pk[w1k].dgrad, fb1, self.pk[w2k].fwd, self.pk[w2k].dgrad, fb2,
                                                   grads, mlp, LN_EPS)
-            ops.xattn_prep_bwd(prep, tok, dtok, g1, wq, wk, wv, wo, dkq, dvoT, self.g[a + ".norm.weight"],
+            ops.xattn_prep_bwd(prep, tok, dtok, g1, wqT, wk, wv, wo, dkq, dvoT, self.g[a + ".norm.weight"],
                                self.g[a + ".norm.bias"], *(self.g[a + ".fn.to_%s.weight" % n] for n in "qkv"),
                                self.g[a + ".fn.to_out.0.weight"], True, self.dtype)
             return dx
@@ -305,7 +310,9 @@ class Engine:
         wq, wk, wv = (self.p[a + ".fn.to_%s.weight" % n] for n in "qkv")
         wo, bo = self.p[a + ".fn.to_out.0.weight"], self.p[a + ".fn.to_out.0.bias"]
         xn, st1 = ops.layernorm(x0, g1, b1, LN_EPS)
-        prep = ops.XattnPrep(tok, tok_b, tok_s, B, images, L, heads, dim_head, g1, b1, wq, wk, wv, wo, self.dtype,
+        wqT, wkT, wvT = (self.pk[a + ".fn.to_%s.weight" % n].dgrad for n in "qkv")
+        woT = self.pk[a + ".fn.to_out.0.weight"].dgrad
+        prep = ops.XattnPrep(tok, tok_b, tok_s, B, images, L, heads, dim_head, g1, b1, wq, wkT, wvT, woT, self.dtype,
                              ATTN_SCALE, LN_EPS)
         HLP = prep.HLP
         dots = ops.linear(xn, prep.kq, HLP, images=images, w_image_stride=HLP * DIM)
@@ -326,7 +333,7 @@ class Engine:
             ops.linear_wgrad(xn, ddots, dkq, images=images, per_image=True, use_tr=self.use_tr)
             dx = ops.layernorm_bwd(dxn, x0, st1, g1, self.g[a + ".norm.weight"], self.g[a + ".norm.bias"],
                                    dx_add=dx1, accumulate=True)
-            ops.xattn_prep_bwd(prep, tok, dtok, g1, wq, wk, wv, wo, dkq, dvoT, self.g[a + ".norm.weight"],
+            ops.xattn_prep_bwd(prep, tok, dtok, g1, wqT, wk, wv, wo, dkq, dvoT, self.g[a + ".norm.weight"],
                                self.g[a + ".norm.bias"], *(self.g[a + ".fn.to_%s.weight" % n] for n in "qkv"),
                                self.g[a + ".fn.to_out.0.weight"], True, self.dtype)
             return dx

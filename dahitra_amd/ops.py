@@ -416,7 +416,7 @@ def tokenizer_bwd(x, wa, saved, dtok_cat, dx_accum, dwa, dpos, B, L, accumulate=
 class XattnPrep:
     """Per-image operands of the re-associated cross attention (see csrc/tokens.hip)."""
 
-    def __init__(self, tok, bstride, sstride, B, Sn, L, heads, dim_head, ln_g, ln_b, wq, wk, wv, wo, dtype,
+    def __init__(self, tok, bstride, sstride, B, Sn, L, heads, dim_head, ln_g, ln_b, wq, wkT, wvT, woT, dtype,
                  scale=32 ** -0.5, eps=1e-5):
         dev = tok.device
         inner = heads * dim_head
@@ -432,12 +432,12 @@ class XattnPrep:
         self.vo = torch.empty(Sn, self.HLP, 32, dtype=dtype, device=dev)
         self.voT = torch.empty(Sn, 32, self.HLP, dtype=dtype, device=dev)
         _call("dh_xattn_prep_fwd", _ci(_DT[dtype]), P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(L),
-              _ci(heads), _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), P(ln_g), P(ln_b), P(wq), P(wk), P(wv),
-              P(wo), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq), P(self.kqT), P(self.vo),
+              _ci(heads), _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), P(ln_g), P(ln_b), P(wq), P(wkT), P(wvT),
+              P(woT), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq), P(self.kqT), P(self.vo),
               P(self.voT), S())
 
 
-def xattn_prep_bwd(prep, tok, dtok_accum, ln_g, wq, wk, wv, wo, dkq, dvoT, dln_g, dln_b, dwq, dwk, dwv, dwo,
+def xattn_prep_bwd(prep, tok, dtok_accum, ln_g, wqT, wk, wv, wo, dkq, dvoT, dln_g, dln_b, dwq, dwk, dwv, dwo,
                    accumulate, dtype):
     bstride, sstride, B, Sn, L, heads, dim_head = prep.args
     dk = torch.empty_like(prep.k)
@@ -445,7 +445,7 @@ def xattn_prep_bwd(prep, tok, dtok_accum, ln_g, wq, wk, wv, wo, dkq, dvoT, dln_g
     Lb = _lib.lib()
     ws = workspace(Lb.dh_xattn_prep_bwd_workspace_size(Sn), tok.device)
     _call("dh_xattn_prep_bwd", _ci(_DT[dtype]), P(tok), P(dtok_accum), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn),
-          _ci(L), _ci(heads), _ci(dim_head), _ci(prep.HLP), _cf(prep.scale), P(ln_g), P(wq), P(wk), P(wv), P(wo),
+          _ci(L), _ci(heads), _ci(dim_head), _ci(prep.HLP), _cf(prep.scale), P(ln_g), P(wqT), P(wk), P(wv), P(wo),
           P(prep.mn), P(prep.mstats), P(prep.k), P(prep.v), P(dkq), P(dvoT), P(dk), P(dv), P(dln_g), P(dln_b), P(dwq),
           P(dwk), P(dwv), P(dwo), _ci(int(accumulate)), P(ws), S())
 

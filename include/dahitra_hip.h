@@ -113,7 +113,9 @@ int dh_colsum(int dtype, const void* x, long P, int C, float* out, int accumulat
 int dh_cast_from_f32(int dtype, const float* src, void* dst, long n, void* stream);
 int dh_cast_to_f32(int dtype, const void* src, float* dst, long n, int accumulate, void* stream);
 
-/* ---- token side (models/networks.py:312-336,457-488; help_funcs.py:66-114) -------------------- */
+/* ---- token side (models/networks.py:312-336,457-488; help_funcs.py:66-114) --------------------
+ * xattn_prep: wq / wk / wv / wo are the fp32 masters ([inner][32] resp. [32][inner]); wkT, wvT, wqT ([32][inner])
+ * and woT ([inner][32]) are their transposes in T as produced by dh_pack_weight's data-gradient form. */
 int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const float* pos, int S, int B, int HW, int L,
                      float* logits, float* stats, float* pooled, void* tok_cat, void* workspace, void* stream);
 long dh_tokenizer_fwd_workspace_size(int S, int HW, int L);
@@ -123,10 +125,10 @@ int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S, int B, in
 long dh_tokenizer_bwd_workspace_size(int S, int HW, int L);
 int dh_xattn_prep_fwd(int dtype, const void* tok, long tok_bstride, long tok_sstride, int B, int S, int L, int heads,
                       int dim_head, int HLP, float scale, float eps, const float* ln_g, const float* ln_b,
-                      const float* wq, const float* wk, const float* wv, const float* wo, float* mn, float* mstats,
+                      const float* wq, const void* wkT, const void* wvT, const void* woT, float* mn, float* mstats,
                       float* k, float* v, void* kq, void* kqT, void* vo, void* voT, void* stream);
 int dh_xattn_prep_bwd(int dtype, const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride, int B, int S,
-                      int L, int heads, int dim_head, int HLP, float scale, const float* ln_g, const float* wq,
+                      int L, int heads, int dim_head, int HLP, float scale, const float* ln_g, const void* wqT,
                       const float* wk, const float* wv, const float* wo, const float* mn, const float* mstats,
                       const float* k, const float* v, const float* dkq, const float* dvoT, float* dk, float* dv,
                       float* dln_g, float* dln_b, float* dwq, float* dwk, float* dwv, float* dwo, int accumulate,
