@@ -202,9 +202,9 @@ struct PrepArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void xattn_prep_kernel(PrepArgs a) {
+__global__ __launch_bounds__(1024) void xattn_prep_kernel(PrepArgs a) {
     extern __shared__ float sm[];
-    const int s = blockIdx.x, tid = threadIdx.x;
+    const int s = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int L = a.L, inner = a.heads * a.dh, HL = a.heads * L;
     float* smn = sm;                    // [L][32]
     float* sk = smn + L * D;            // [L][inner]
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void xattn_prep_kernel(PrepArgs a) {
     __syncthreads();
     const T* wkT = reinterpret_cast<const T*>(a.wkT);
     const T* wvT = reinterpret_cast<const T*>(a.wvT);
-    for (int hd = tid; hd < inner; hd += 256) {
+    for (int hd = tid; hd < inner; hd += NT) {
         float kk[8], vv[8];
 #pragma unroll
         for (int l = 0; l < 8; ++l) { kk[l] = 0.f; vv[l] = 0.f; }
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void xattn_prep_kernel(PrepArgs a) {
     T* vo = reinterpret_cast<T*>(a.vo) + (size_t)s * a.HLP * D;
     T* voT = reinterpret_cast<T*>(a.voT) + (size_t)s * a.HLP * D;
     const T* woT = reinterpret_cast<const T*>(a.woT);
-    for (int i = tid; i < a.HLP * D; i += 256) {
+    for (int i = tid; i < a.HLP * D; i += NT) {
         const int hl = i / D, c = i % D;
         float q = 0.f, o = 0.f;
         if (hl < HL) {
@@ -290,9 +290,9 @@ struct PrepBwdArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
+__global__ __launch_bounds__(1024) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
     extern __shared__ float sm[];
-    const int s = blockIdx.x, tid = threadIdx.x;
+    const int s = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int L = a.L, inner = a.heads * a.dh;
     float* sdk = sm;                 // [L][inner]
     float* sdv = sdk + L * inner;    // [L][inner]
@@ -300,13 +300,13 @@ __global__ __launch_bounds__(256) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
     float* sgk = sdmn + L * D;       // [HLP][32]   staged dKq
     float* sgv = sgk + a.HLP * D;    // [32][HLP]   staged dVoT
     float* sred = sgv + a.HLP * D;   // [8][L][32]
-    for (int i = tid; i < a.HLP * D; i += 256) {
+    for (int i = tid; i < a.HLP * D; i += NT) {
         sgk[i] = a.dkq[(size_t)s * a.HLP * D + i];
         sgv[i] = a.dvoT[(size_t)s * a.HLP * D + i];
     }
     __syncthreads();
     const T* wqT = reinterpret_cast<const T*>(a.wqT);
-    for (int hd = tid; hd < inner; hd += 256) {
+    for (int hd = tid; hd < inner; hd += NT) {
         const int h = hd / a.dh;
         float gk[8], gv[8];
 #pragma unroll
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
     __syncthreads();
     // dmn[l][c] = sum_hd dk[l][hd] wk[hd][c] + dv[l][hd] wv[hd][c]: 8 hd-chunks x 32 channels, then LDS reduce
     {
-        const int c = tid & 31, ch = tid >> 5, per = (inner + 7) / 8;
+        const int c = tid & 31, ch = tid >> 5, nch = NT >> 5, per = (inner + nch - 1) / nch;
         float acc[8];
 #pragma unroll
         for (int l = 0; l < 8; ++l) acc[l] = 0.f;
@@ -344,9 +344,9 @@ __global__ __launch_bounds__(256) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
             if (l < L) sred[(ch * L + l) * D + c] = acc[l];
     }
     __syncthreads();
-    for (int i = tid; i < L * D; i += 256) {
+    for (int i = tid; i < L * D; i += NT) {
         float t = 0.f;
-        for (int ch = 0; ch < 8; ++ch) t += sred[ch * L * D + i];
+        for (int ch = 0; ch < (NT >> 5); ++ch) t += sred[ch * L * D + i];
         sdmn[i] = t;
     }
     __syncthreads();
@@ -366,8 +366,10 @@ __global__ __launch_bounds__(256) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
             pg = g * xh; pb = g;
         }
         // sum the L rows' contributions per channel through LDS (rows live in different half-waves)
-        sred[(0 * 8 + l) * D + c] = pg;
-        sred[(1 * 8 + l) * D + c] = pb;
+        if (l < 8) {
+            sred[(0 * 8 + l) * D + c] = pg;
+            sred[(1 * 8 + l) * D + c] = pb;
+        }
     }
     __syncthreads();
     if (tid < 2 * D) {
@@ -630,8 +632,8 @@ extern "C" int dh_xattn_prep_fwd(int dtype, const void* tok, long tok_bstride, l
     a.wq = wq; a.wkT = wkT; a.wvT = wvT; a.woT = woT; a.mn = mn; a.mstats = mstats; a.k = k; a.v = v;
     a.kq = kq; a.kqT = kqT; a.vo = vo; a.voT = voT;
     const size_t lds = (size_t)(L * 32 + 2 * L * heads * dim_head) * 4;
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_kernel<bf16>, dim3(S), dim3(256), lds, ST(stream), a);
-    else hipLaunchKernelGGL(xattn_prep_kernel<float>, dim3(S), dim3(256), lds, ST(stream), a);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_kernel<bf16>, dim3(S), dim3(1024), lds, ST(stream), a);
+    else hipLaunchKernelGGL(xattn_prep_kernel<float>, dim3(S), dim3(1024), lds, ST(stream), a);
     DH_CHECK_LAUNCH("xattn_prep_fwd");
     return 0;
 }
@@ -651,9 +653,9 @@ extern "C" int dh_xattn_prep_bwd(int dtype, const void* tok, void* dtok_accum, l
     a.wk = wk; a.wv = wv; a.wo = wo; a.mn = mn; a.mstats = mstats; a.dkq = dkq; a.dvoT = dvoT; a.dk = dk; a.dv = dv;
     a.ln_partial = reinterpret_cast<float*>(workspace);
     const int inner = heads * dim_head;
-    const size_t lds = (size_t)(2 * L * inner + L * 32 + 2 * HLP * 32 + 16 * 32 + 8 * L * 32) * 4;
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_bwd_kernel<bf16>, dim3(S), dim3(256), lds, ST(stream), a);
-    else hipLaunchKernelGGL(xattn_prep_bwd_kernel<float>, dim3(S), dim3(256), lds, ST(stream), a);
+    const size_t lds = (size_t)(2 * L * inner + L * 32 + 2 * HLP * 32 + 16 * 32 + 32 * L * 32) * 4;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_bwd_kernel<bf16>, dim3(S), dim3(1024), lds, ST(stream), a);
+    else hipLaunchKernelGGL(xattn_prep_bwd_kernel<float>, dim3(S), dim3(1024), lds, ST(stream), a);
     PrepWgArgs w;
     w.S = S; w.L = L; w.heads = heads; w.dh = dim_head; w.HLP = HLP; w.scale = scale; w.mn = mn; w.k = k; w.v = v;
     w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;
