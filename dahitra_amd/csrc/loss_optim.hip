@@ -104,7 +104,8 @@ __global__ void stem_s2d_kernel(const float* __restrict__ x, T* __restrict__ y, 
 }
 // w OIHW fp32 [O][3][7][7] -> packed [16 taps (dy,dx)][O][CP] T, kh = 2*dy + ry - 1, kw = 2*dx + rx - 1
 template <typename T>
-__global__ void stem_pack_kernel(const float* __restrict__ w, T* __restrict__ out, int O, int CP) {
+__global__ void stem_pack_kernel(const float* __restrict__ w, const float* __restrict__ oscale, T* __restrict__ out, int O,
+                                 int CP) {
     const long total = 16L * O * CP;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int ch = (int)(i % CP);
@@ -114,7 +115,7 @@ __global__ void stem_pack_kernel(const float* __restrict__ w, T* __restrict__ ou
         if (ch < 12) {
             const int c = ch % 3, r = ch / 3, ry = r >> 1, rx = r & 1;
             const int kh = 2 * (tap / 4) + ry - 1, kw = 2 * (tap % 4) + rx - 1;
-            if (kh >= 0 && kh < 7 && kw >= 0 && kw < 7) v = w[((o * 3 + c) * 7 + kh) * 7 + kw];
+            if (kh >= 0 && kh < 7 && kw >= 0 && kw < 7) v = w[((o * 3 + c) * 7 + kh) * 7 + kw] * (oscale ? oscale[o] : 1.f);
         }
         stf(out + i, v);
     }
@@ -184,10 +185,10 @@ extern "C" int dh_stem_space_to_depth(int dtype, const float* x_nchw, void* y, i
     DH_CHECK_LAUNCH("stem_s2d");
     return 0;
 }
-extern "C" int dh_stem_pack_weight(int dtype, const float* w_oihw, void* packed, int O, int CP, void* stream) {
+extern "C" int dh_stem_pack_weight(int dtype, const float* w_oihw, const float* out_scale, void* packed, int O, int CP, void* stream) {
     const long n = 16L * O * CP;
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(stem_pack_kernel<bf16>, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), w_oihw, (bf16*)packed, O, CP);
-    else hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), w_oihw, (float*)packed, O, CP);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(stem_pack_kernel<bf16>, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), w_oihw, out_scale, (bf16*)packed, O, CP);
+    else hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(dh_cdiv(n, 256)), dim3(256), 0, ST(stream), w_oihw, out_scale, (float*)packed, O, CP);
     DH_CHECK_LAUNCH("stem_pack");
     return 0;
 }
@@ -231,6 +232,42 @@ extern "C" int dh_adamw_step_graph(float* param, const float* grad, float* exp_a
     hipLaunchKernelGGL(adamw_dev_kernel, dim3((int)g), dim3(256), 0, ST(stream), param, grad, exp_avg, exp_avg_sq, n,
                        hyper_dev);
     DH_CHECK_LAUNCH("adamw_graph");
+    return 0;
+}
+
+// ---- arg-max mask + confusion matrix in one pass (models/trainer.py:163-173, misc/metric_tool.py:141-158) ---------
+// counts[gt * C + pred] += 1 over all pixels (int64, atomics on integers: order-independent, exact); mask optional
+__global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                        int B, int C, long HW, long long* __restrict__ mask,
+                                                        unsigned long long* __restrict__ counts) {
+    __shared__ unsigned int hist[MAXC * MAXC];
+    for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0;
+    __syncthreads();
+    const long total = (long)B * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / HW, p = i % HW;
+        float best = logits[(b * C) * HW + p];
+        int arg = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = logits[(b * C + c) * HW + p];
+            if (v > best) { best = v; arg = c; }
+        }
+        if (mask) mask[i] = arg;
+        const int t = (int)target[i];
+        if (t >= 0 && t < C) atomicAdd(&hist[t * C + arg], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += 256)
+        if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+extern "C" int dh_confusion_matrix(const float* logits_nchw, const long long* target, int B, int C, long HW,
+                                   long long* mask, long long* counts, void* stream) {
+    DH_REQUIRE(C >= 1 && C <= MAXC, "confusion_matrix: n_class=%d unsupported (max %d)", C, MAXC);
+    long g = ((long)B * HW + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(confusion_kernel, dim3((int)g), dim3(256), 0, ST(stream), logits_nchw, target, B, C, HW, mask,
+                       reinterpret_cast<unsigned long long*>(counts));
+    DH_CHECK_LAUNCH("confusion_matrix");
     return 0;
 }
 

@@ -319,15 +319,15 @@ __global__ void zero_insert2_kernel(const T* __restrict__ dy, T* __restrict__ z,
 
 // ---- weight packing: OIHW fp32 -> [tap][OPad][I] T  and  [tap'][IPad][O] T (flipped) ---------
 template <typename T>
-__global__ void pack_weight_kernel(const float* __restrict__ w, int O, int I, int KS, int OPad, T* __restrict__ fwd,
-                                   int IPad, int OK, T* __restrict__ dgrad) {
+__global__ void pack_weight_kernel(const float* __restrict__ w, const float* __restrict__ oscale, int O, int I, int KS,
+                                   int OPad, T* __restrict__ fwd, int IPad, int OK, T* __restrict__ dgrad) {
     const int taps = KS * KS;
     if (fwd) {
         GSL(i, (long)taps * OPad * I) {
             const int ci = (int)(i % I);
             const int o = (int)((i / I) % OPad);
             const int tap = (int)(i / ((long)I * OPad));
-            stf(fwd + i, o < O ? w[((long)o * I + ci) * taps + tap] : 0.f);
+            stf(fwd + i, o < O ? w[((long)o * I + ci) * taps + tap] * (oscale ? oscale[o] : 1.f) : 0.f);
         }
     }
     if (dgrad) {
@@ -519,11 +519,11 @@ extern "C" int dh_zero_insert2(int dtype, const void* dy, void* z, int N, int OH
     DH_CHECK_LAUNCH("zero_insert2");
     return 0;
 }
-extern "C" int dh_pack_weight(int dtype, const float* w_oihw, int O, int I, int ks, int OPad, void* fwd, int IPad, int dgrad_inner, void* dgrad, void* stream) {
+extern "C" int dh_pack_weight(int dtype, const float* w_oihw, const float* out_scale, int O, int I, int ks, int OPad, void* fwd, int IPad, int dgrad_inner, void* dgrad, void* stream) {
     const int OK = dgrad_inner > O ? dgrad_inner : O;
     const long n = (long)ks * ks * (OPad > IPad ? OPad : IPad) * (OK > I ? OK : I);
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), w_oihw, O, I, ks, OPad, (bf16*)fwd, IPad, OK, (bf16*)dgrad);
-    else hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), w_oihw, O, I, ks, OPad, (float*)fwd, IPad, OK, (float*)dgrad);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), w_oihw, out_scale, O, I, ks, OPad, (bf16*)fwd, IPad, OK, (bf16*)dgrad);
+    else hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), w_oihw, out_scale, O, I, ks, OPad, (float*)fwd, IPad, OK, (float*)dgrad);
     DH_CHECK_LAUNCH("pack_weight");
     return 0;
 }

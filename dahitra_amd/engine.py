@@ -93,10 +93,11 @@ class Engine:
             self.p[bnkey + ".num_batches_tracked"].add_(groups)
             out = ops.bn_apply(y, scale, shift, groups, act, residual)
         else:
-            y = ops.conv2d(x, self.pk[wkey].fwd, cout, ks, stride, pad)
+            # eval: BatchNorm folds into the convolution -- scale into the packed weights, shift as the bias
             scale, shift = ops.bn_eval_params(gamma, beta, rm, rv, BN_EPS)
-            out = ops.bn_apply(y, scale, shift, 1, act, residual)
-            mean = invstd = None
+            wp = ops.pack_weight(self.p[wkey], self.dtype, want_dgrad=False, out_scale=scale)[0]
+            out = ops.conv2d(x, wp, cout, ks, stride, pad, bias=shift, residual=residual, act=act)
+            y = mean = invstd = None
         if not self.need_grad:
             return out, None
         has_res = residual is not None
@@ -144,10 +145,10 @@ class Engine:
             self.p[bnkey + ".num_batches_tracked"].add_(groups)
             out = ops.bn_apply(y, scale, shift, groups, RELU)
         else:
-            y = ops.conv2d(xs, self.pk[wkey].fwd, 64, 4, 1, 2, out_hw=(oh, ow))
             scale, shift = ops.bn_eval_params(gamma, beta, rm, rv, BN_EPS)
-            out = ops.bn_apply(y, scale, shift, 1, RELU)
-            mean = invstd = None
+            wp = ops.stem_pack_weight(self.p[wkey], self.dtype, out_scale=scale)
+            out = ops.conv2d(xs, wp, 64, 4, 1, 2, bias=shift, act=RELU, out_hw=(oh, ow))
+            y = mean = invstd = None
         if not self.need_grad:
             return out, None
 

@@ -12,6 +12,7 @@ import os
 
 import torch
 
+from .. import ops
 from ..optim import AdamW
 from . import losses
 from .networks import define_G, get_scheduler
@@ -40,7 +41,7 @@ class CDTrainer:
         self.best_val_acc = 0.0
         self.best_epoch_id = 0
         self.epoch_id = 0
-        self.confusion = torch.zeros(self.n_class, self.n_class, dtype=torch.float64, device=self.device)
+        self.confusion = torch.zeros(self.n_class, self.n_class, dtype=torch.int64, device=self.device)
 
     # ---- the hot step --------------------------------------------------------------------------------
     def _forward_pass(self, batch):
@@ -68,15 +69,13 @@ class CDTrainer:
         return self.G_loss
 
     def _update_metric(self):
-        pred = losses.argmax_mask(self.G_pred)
-        gt = self.batch['L'].to(self.device).long().reshape(pred.shape)
-        idx = (gt * self.n_class + pred).reshape(-1)
-        self.confusion += torch.bincount(idx, minlength=self.n_class ** 2).reshape(self.n_class, self.n_class)
+        gt = self.batch['L'].to(self.device).long().contiguous()
+        ops.confusion_matrix(self.G_pred.detach().float().contiguous(), gt, self.confusion)   # arg-max + counts, one kernel
 
     def scores(self):
         """acc / mIoU / mF1 from the confusion matrix (misc/metric_tool.py:96-138)"""
-        cm = self.confusion.cpu().numpy()
         import numpy as np
+        cm = self.confusion.cpu().numpy().astype(np.float64)
         tp = np.diag(cm)
         sum_r, sum_c = cm.sum(1), cm.sum(0)
         eps = np.finfo(np.float32).eps

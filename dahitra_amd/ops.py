@@ -67,8 +67,9 @@ def pad16(c):
 
 
 # ---- weights -------------------------------------------------------------------------------------
-def pack_weight(w, dtype, want_dgrad=True, dgrad_inner=0):
-    """w: OIHW (or [O, I]) fp32 master.  Returns (fwd [taps, OPad, I], dgrad [taps, IPad, OK] | None)."""
+def pack_weight(w, dtype, want_dgrad=True, dgrad_inner=0, out_scale=None):
+    """w: OIHW (or [O, I]) fp32 master.  Returns (fwd [taps, OPad, I], dgrad [taps, IPad, OK] | None).
+    out_scale [O]: per-output-channel factor folded into the forward form (eval-mode BatchNorm)."""
     if w.dim() == 2:
         O, I = w.shape
         ks = 1
@@ -78,7 +79,7 @@ def pack_weight(w, dtype, want_dgrad=True, dgrad_inner=0):
     OK = max(O, dgrad_inner)
     fwd = torch.empty(ks * ks, OPad, I, dtype=dtype, device=w.device)
     dg = torch.empty(ks * ks, IPad, OK, dtype=dtype, device=w.device) if want_dgrad else None
-    _call("dh_pack_weight", _ci(_DT[dtype]), P(w), _ci(O), _ci(I), _ci(ks), _ci(OPad), P(fwd), _ci(IPad), _ci(OK),
+    _call("dh_pack_weight", _ci(_DT[dtype]), P(w), P(out_scale), _ci(O), _ci(I), _ci(ks), _ci(OPad), P(fwd), _ci(IPad), _ci(OK),
           P(dg), S())
     return fwd, dg
 
@@ -194,11 +195,11 @@ def stem_space_to_depth(x_nchw, dtype):
     return y
 
 
-def stem_pack_weight(w, dtype):
+def stem_pack_weight(w, dtype, out_scale=None):
     O = w.shape[0]
     cp = chunk_channels(dtype)
     out = torch.empty(16, O, cp, dtype=dtype, device=w.device)
-    _call("dh_stem_pack_weight", _ci(_DT[dtype]), P(w), P(out), _ci(O), _ci(cp), S())
+    _call("dh_stem_pack_weight", _ci(_DT[dtype]), P(w), P(out_scale), P(out), _ci(O), _ci(cp), S())
     return out
 
 
@@ -513,6 +514,14 @@ def focal_loss(logits_nchw, target, want_grad=True, grad_scale=1.0, alpha=0.5):
     _call("dh_focal_loss", P(logits_nchw), P(target), _ci(B), _ci(C), _cl(H * W), _cf(alpha), _cf(grad_scale), P(loss),
           P(dl), P(ws), S())
     return loss, dl
+
+
+def confusion_matrix(logits_nchw, target, counts, want_mask=False):
+    """counts [C, C] int64 (device) += confusion of argmax(logits) against target; optionally returns the mask"""
+    B, C, H, W = logits_nchw.shape
+    mask = torch.empty(B, H, W, dtype=torch.int64, device=logits_nchw.device) if want_mask else None
+    _call("dh_confusion_matrix", P(logits_nchw), P(target), _ci(B), _ci(C), _cl(H * W), P(mask), P(counts), S())
+    return mask
 
 
 def argmax_nchw(logits_nchw):

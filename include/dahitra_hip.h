@@ -61,15 +61,16 @@ long dh_conv2d_wgrad_workspace_size(int N, int OH, int OW, int Cin, int Cout, in
 int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, int ks, int groups);
 
 /* OIHW fp32 master weight -> kernel layouts: fwd [ks*ks][OPad][I] T and (optional) the data-gradient
- * form [ks*ks flipped][IPad][max(O, dgrad_inner)] T. */
-int dh_pack_weight(int dtype, const float* w_oihw, int O, int I, int ks, int OPad, void* fwd, int IPad,
+ * form [ks*ks flipped][IPad][max(O, dgrad_inner)] T.  out_scale (optional, [O]) multiplies the forward form per
+ * output channel: eval-mode BatchNorm folded into the convolution (its shift then goes in as `bias`). */
+int dh_pack_weight(int dtype, const float* w_oihw, const float* out_scale, int O, int I, int ks, int OPad, void* fwd, int IPad,
                    int dgrad_inner, void* dgrad, void* stream);
 /* z[n,2y,2x,c] = dy[n,y,x,c] (zero elsewhere): stride-2 data gradients as stride-1 convolutions */
 int dh_zero_insert2(int dtype, const void* dy, void* z, int N, int OH, int OW, int H, int W, int C, void* stream);
 
 /* stem nn.Conv2d(3,64,7,2,3) (models/resnet.py:150) as a 4x4/stride-1 conv on a space-to-depth image */
 int dh_stem_space_to_depth(int dtype, const float* x_nchw, void* y, int N, int H, int W, int CP, void* stream);
-int dh_stem_pack_weight(int dtype, const float* w_oihw, void* packed, int O, int CP, void* stream);
+int dh_stem_pack_weight(int dtype, const float* w_oihw, const float* out_scale, void* packed, int O, int CP, void* stream);
 int dh_stem_unpack_grad(const float* dw2, float* dw_oihw, int O, int CP, int accumulate, void* stream);
 
 /* ---- BatchNorm2d (models/resnet.py:152,40-44; help_funcs.py:11) and LayerNorm(32) (help_funcs.py:34-49) */
@@ -162,6 +163,9 @@ int dh_argmax_nchw(const float* logits_nchw, long long* mask, int B, int C, long
  * step counter live on the device; every call (or graph replay) advances the counter and the bias correction */
 int dh_adamw_step_graph(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                         float* hyper_dev, int* step_dev, void* stream);
+/* arg-max over classes (first maximum wins) + confusion counts[gt*C+pred] (int64, accumulated); mask optional */
+int dh_confusion_matrix(const float* logits_nchw, const long long* target, int B, int C, long HW, long long* mask,
+                        long long* counts, void* stream);
 int dh_scale_by_scalar(const float* src, const float* scalar_dev, float* dst, long n, void* stream);
 /* |tok[b][1] - tok[b][0]| over [B][2][n] token sets (models/networks.py:1311) and its gradient */
 int dh_absdiff_halves(int dtype, const void* tok, void* out, int B, long n, void* stream);

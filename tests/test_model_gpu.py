@@ -267,6 +267,38 @@ def test_eager_step_is_deterministic():
     assert torch.equal(flats[0], flats[1])
 
 
+def test_evaluator_confusion_matrix_and_checkpoint_interchange(tmp_path):
+    """eval path (section 8f-1/2): a checkpoint written in the reference's format (trainer.py:150-158, with a
+    DataParallel 'module.' prefix) loads; the on-device confusion matrix equals numpy's on the oracle's masks."""
+    from dahitra_amd.models.evaluator import CDEvaluator, cm2score
+    name = "base_transformer_pos_s4"
+    sd = O.deterministic_state(name)
+    torch.save({"epoch_id": 3, "best_val_acc": 0.5, "best_epoch_id": 2,
+                "model_G_state_dict": {"module." + k: v for k, v in sd.items()}}, tmp_path / "best_ckpt.pt")
+    batches = []
+    for seed in (1, 2):
+        a, b, lab = O.synthetic_batch(2, 64, seed=seed)
+        batches.append({"A": a, "B": b, "L": lab})
+    args = types.SimpleNamespace(net_G=name, compute_dtype="fp32", gpu_ids=[0], n_class=2, checkpoint_dir=str(tmp_path))
+    ev = CDEvaluator(args, batches)
+    with pytest.raises(FileNotFoundError):
+        ev.eval_models("missing.pt")
+    scores = ev.eval_models("best_ckpt.pt")
+    cm = np.zeros((2, 2))
+    sd2 = O.deterministic_state(name)
+    for bt in batches:
+        with torch.no_grad():
+            y = O.forward(sd2, name, bt["A"], bt["B"], training=False)
+        pred = torch.argmax(y, 1).numpy().ravel()
+        gt = bt["L"].numpy().ravel()
+        cm += np.bincount(2 * gt + pred, minlength=4).reshape(2, 2)
+    got = ev.confusion.cpu().numpy()
+    assert got.sum() == cm.sum()
+    assert np.abs(got - cm).sum() <= 4            # at most a couple of tie-band pixels may differ
+    ref = cm2score(cm)
+    assert abs(scores["acc"] - ref["acc"]) < 1e-3 and abs(scores["mf1"] - ref["mf1"]) < 2e-3
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from dahitra_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
