@@ -151,8 +151,15 @@ def main():
             ms, fl, n = agg[key]
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = fl / (ms * 1e-3) / 1e12
+            traffic = None        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
+            tpath = os.path.join(ROOT, "profiles", "r01c_pmc_traffic_conv3x3.json")
+            if args.dtype == "bf16" and args.net == NET and os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                ln = sum(v["launches"] for v in tj.values())
+                traffic = round(sum(v["launches"] * (v["fetch_MB_per_launch_corrected_x2"] + v["write_MB_per_launch"])
+                                    for v in tj.values()) / ln * 1e6)
             roof = {"bound": "mfma", "kernel": key, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": n // 2,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "launches_per_step": n // 2,
                     "avg_launch_us": round(ms * 1e3 / n, 2),
                     "all_mfma_conv_ms_per_step": round(sum(v[0] for v in agg.values()) / 2, 3)}
 
