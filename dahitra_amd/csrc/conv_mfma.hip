@@ -48,6 +48,7 @@ struct ConvArgs {
     long w_nstride;    // elements between per-image weight sets (0: shared)
     int tilesX, tilesY;
     int rw;            // rows per wavefront (tile height = 4*rw)
+    int dil;           // dilation (1, or 2 for the ResNet-50 layer3 3x3 convolutions)
 };
 
 union V16u {
@@ -71,11 +72,11 @@ template <> struct Mma<bf16> {
     }
 };
 
-template <typename T, int KS, int STRIDE, int NT, int RW>
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     constexpr int TH = 4 * RW;
-    constexpr int HH = (TH - 1) * STRIDE + KS;
-    constexpr int HWD = (TW - 1) * STRIDE + KS;
+    constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
+    constexpr int HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     constexpr int TAPS = KS * KS;
     constexpr int CK = 64 / (int)sizeof(T);     // channels per 64-byte chunk
     constexpr int NS = NT / 16;                 // 16-channel output sub-tiles
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
                 for (int r = 0; r < RW; ++r)
                     b[r].u = *reinterpret_cast<const uint4*>(
-                        halo + HL::off(((RW * wv + r) * STRIDE + kh) * HWD + pl * STRIDE + kw, g));
+                        halo + HL::off(((RW * wv + r) * STRIDE + kh * DIL) * HWD + pl * STRIDE + kw * DIL, g));
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     V16u a;
@@ -271,12 +272,12 @@ static inline int pick_rw(int N, int OH, int OW, int Cin, int ks, int stride) {
     return 2;
 }
 
-template <typename T, int KS, int STRIDE, int NT, int RW>
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL>
 int launch_rw(const ConvArgs& a, hipStream_t st) {
     constexpr int TH = 4 * RW;
-    constexpr int HH = (TH - 1) * STRIDE + KS, HWD = (TW - 1) * STRIDE + KS;
+    constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     const size_t lds = (size_t)HH * HWD * HaloLayout<STRIDE>::PITCH + (size_t)KS * KS * NT * WPITCH;
-    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW>;
+    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW, DIL>;
     static bool attr_done = false;      // once per instantiation (and never inside a graph capture)
     if (lds > 64 * 1024 && !attr_done) {
         attr_done = true;
@@ -296,9 +297,10 @@ int launch_rw(const ConvArgs& a, hipStream_t st) {
 template <typename T, int KS, int STRIDE, int NT>
 int launch(const ConvArgs& a, hipStream_t st) {
     if constexpr (KS == 3 && STRIDE == 1) {
-        if (a.rw == 4) return launch_rw<T, KS, STRIDE, NT, 4>(a, st);
+        if (a.dil == 2) return a.rw == 4 ? launch_rw<T, KS, STRIDE, NT, 4, 2>(a, st) : launch_rw<T, KS, STRIDE, NT, 2, 2>(a, st);
+        if (a.rw == 4) return launch_rw<T, KS, STRIDE, NT, 4, 1>(a, st);
     }
-    return launch_rw<T, KS, STRIDE, NT, 2>(a, st);
+    return launch_rw<T, KS, STRIDE, NT, 2, 1>(a, st);
 }
 
 template <typename T, int KS, int STRIDE>
@@ -324,7 +326,7 @@ int launch_ks(const ConvArgs& a, int ks, int stride, hipStream_t st) {
 extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const float* bias,
                              const void* residual, float* stats_partial, int N, int H, int W, int Cin,
                              int OH, int OW, int Cout, int CoutPad, int ks, int stride, int pad, int act,
-                             int npix_valid, long w_image_stride, void* y_preact, void* stream) {
+                             int npix_valid, long w_image_stride, void* y_preact, int dilation, void* stream) {
     const int esz = dtype == DH_DTYPE_BF16 ? 2 : 4;
     DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "conv2d_fwd: bad dtype %d", dtype);
     DH_REQUIRE((Cin * esz) % 64 == 0, "conv2d_fwd: Cin=%d must be a multiple of %d", Cin, 64 / esz);
@@ -335,6 +337,8 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.CoutPad = CoutPad;
     a.pad = pad; a.act = act; a.npix = npix_valid > 0 ? npix_valid : OH * OW;
     a.in_npix = npix_valid > 0 ? npix_valid : H * W; a.w_nstride = w_image_stride;
+    DH_REQUIRE(dilation == 1 || (dilation == 2 && ks == 3 && stride == 1), "conv2d_fwd: dilation %d unsupported here", dilation);
+    a.dil = dilation;
     a.rw = pick_rw(N, OH, OW, Cin, ks, stride);
     a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, 4 * a.rw);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

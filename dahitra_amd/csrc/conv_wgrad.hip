@@ -27,6 +27,7 @@ struct WgArgs {
     int tilesX, tilesY, splitk, groups, npix, in_npix;
     int ci_tiles;
     int CinPitch;      // elements between consecutive pixels of x (>= Cin; the stem reads a padded image)
+    int dil;
 };
 
 // the 16-byte piece q of channels [c0, ...) of one pixel row (zeros past Ctot / for a null row)
@@ -59,10 +60,10 @@ union F8 {
     unsigned short s[8];
 };
 
-template <typename T, int KS, int STRIDE, int IT, bool TR>
+template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
-    constexpr int HH = (TH - 1) * STRIDE + KS;
-    constexpr int HWD = (TW - 1) * STRIDE + KS;
+    constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
+    constexpr int HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     constexpr int TAPS = KS * KS;
     constexpr int NI = IT / 16;
     // LDS pitches are ODD multiples of 32 B: a half-wave of ds_read_b64_tr_b16 then touches 8 consecutive
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
                 for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < KS; ++kw) {
-                        const int hp = (row * STRIDE + kh) * HWD + col * STRIDE + kw;
+                        const int hp = (row * STRIDE + kh * DIL) * HWD + col * STRIDE + kw * DIL;
 #pragma unroll
                         for (int i = 0; i < NI; ++i) {
                             const float b = *reinterpret_cast<const float*>(halo + hp * XP + (i * 16 + pl) * 4);
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
                 for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < KS; ++kw) {
-                        const int hp = (r0 * STRIDE + kh) * HWD + c0 * STRIDE + kw;
+                        const int hp = (r0 * STRIDE + kh * DIL) * HWD + c0 * STRIDE + kw * DIL;
 #pragma unroll
                         for (int i = 0; i < NI; ++i) {
                             F8 b;
@@ -254,9 +255,9 @@ __global__ void wgrad_reduce_oihw_kernel(const float* __restrict__ part, int spl
     }
 }
 
-template <typename T, int KS, int STRIDE, int IT>
+template <typename T, int KS, int STRIDE, int IT, int DIL = 1>
 int launch(const WgArgs& a, bool tr, hipStream_t st) {
-    constexpr int HH = (TH - 1) * STRIDE + KS, HWD = (TW - 1) * STRIDE + KS;
+    constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     const size_t lds = (size_t)HH * HWD * lds_pitch(IT * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T));
     dim3 grid(dh_cdiv(a.Cout, CT) * a.ci_tiles, a.splitk, a.groups);
     auto go = [&](auto kern) -> int {
@@ -274,8 +275,8 @@ int launch(const WgArgs& a, bool tr, hipStream_t st) {
         DH_CHECK_LAUNCH("conv_wgrad");
         return 0;
     };
-    if (tr) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true>);
-    return go(conv_wgrad_kernel<T, KS, STRIDE, IT, false>);
+    if (tr) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true, DIL>);
+    return go(conv_wgrad_kernel<T, KS, STRIDE, IT, false, DIL>);
 }
 
 template <typename T>
@@ -283,6 +284,7 @@ int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
     const bool wide = a.Cin > 32 && ks == 1 && stride == 1;   // 64-wide ci tiles only where accumulators / LDS fit
     const int it = ks == 4 ? 16 : (wide ? 64 : 32);
     a.ci_tiles = dh_cdiv(a.Cin, it);
+    if (ks == 3 && stride == 1 && a.dil == 2) return launch<T, 3, 1, 32, 2>(a, tr, st);
     if (ks == 3 && stride == 1) return launch<T, 3, 1, 32>(a, tr, st);
     if (ks == 3 && stride == 2) return launch<T, 3, 2, 32>(a, tr, st);
     if (ks == 1 && stride == 1) return wide ? launch<T, 1, 1, 64>(a, tr, st) : launch<T, 1, 1, 32>(a, tr, st);
@@ -314,11 +316,13 @@ extern "C" long dh_conv2d_wgrad_workspace_size(int N, int OH, int OW, int Cin, i
 // groups == N : dw_oihw is [N][Cout][Cin] (ks must be 1) -- one gradient per image.
 extern "C" int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N,
                                int H, int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad,
-                               int groups, int npix_valid, int use_tr, int Cout_real, int cin_pitch, void* workspace,
-                               void* stream) {
+                               int groups, int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation,
+                               void* workspace, void* stream) {
     DH_REQUIRE(groups == 1 || (groups == N && ks == 1), "conv2d_wgrad: groups must be 1 or N (with ks=1)");
     WgArgs a;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
+    DH_REQUIRE(dilation == 1 || (dilation == 2 && ks == 3 && stride == 1), "conv2d_wgrad: dilation %d unsupported here", dilation);
+    a.dil = dilation;
     a.CinPitch = cin_pitch > 0 ? cin_pitch : Cin;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.pad = pad;
     a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, TH);

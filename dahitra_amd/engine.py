@@ -72,21 +72,21 @@ class Engine:
             self.pk[key] = Packed(f, d)
 
     # ---- primitive units -------------------------------------------------------------------------
-    def conv_dgrad(self, dy, wkey, ks, stride, pad, xshape, residual=None):
+    def conv_dgrad(self, dy, wkey, ks, stride, pad, xshape, residual=None, dilation=1):
         N, H, W, Cin = xshape
         flops = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * self.shapes[wkey][0] * Cin * ks * ks   # algorithmic
         if stride == 2:
             dy = ops.zero_insert2(dy, H, W)
-        return ops.conv2d(dy, self.pk[wkey].dgrad, Cin, ks, 1, ks - 1 - pad, residual=residual, out_hw=(H, W),
-                          alg_flops=flops)
+        return ops.conv2d(dy, self.pk[wkey].dgrad, Cin, ks, 1, dilation * (ks - 1) - pad, residual=residual,
+                          out_hw=(H, W), alg_flops=flops, dilation=dilation)
 
-    def conv_bn(self, x, wkey, bnkey, ks, stride, pad, groups, relu, residual=None):
+    def conv_bn(self, x, wkey, bnkey, ks, stride, pad, groups, relu, residual=None, dilation=1):
         cout = self.shapes[wkey][0]
         gamma, beta = self.p[bnkey + ".weight"], self.p[bnkey + ".bias"]
         rm, rv = self.p[bnkey + ".running_mean"], self.p[bnkey + ".running_var"]
         act = RELU if relu else NONE
         if self.training:
-            y, st = ops.conv2d(x, self.pk[wkey].fwd, cout, ks, stride, pad, want_stats=True)
+            y, st = ops.conv2d(x, self.pk[wkey].fwd, cout, ks, stride, pad, want_stats=True, dilation=dilation)
             N, OH, OW, _ = y.shape
             mean, invstd, scale, shift = ops.bn_finalize(st, cout, groups, (N // groups) * OH * OW, gamma, beta, rm, rv,
                                                          BN_MOMENTUM, BN_EPS)
@@ -96,7 +96,7 @@ class Engine:
             # eval: BatchNorm folds into the convolution -- scale into the packed weights, shift as the bias
             scale, shift = ops.bn_eval_params(gamma, beta, rm, rv, BN_EPS)
             wp = ops.pack_weight(self.p[wkey], self.dtype, want_dgrad=False, out_scale=scale)[0]
-            out = ops.conv2d(x, wp, cout, ks, stride, pad, bias=shift, residual=residual, act=act)
+            out = ops.conv2d(x, wp, cout, ks, stride, pad, bias=shift, residual=residual, act=act, dilation=dilation)
             y = mean = invstd = None
         if not self.need_grad:
             return out, None
@@ -106,8 +106,10 @@ class Engine:
             r = ops.bn_bwd(dout, out if relu else None, y, mean, invstd, gamma, self.g[bnkey + ".weight"],
                            self.g[bnkey + ".bias"], groups, accumulate=True, want_dres=has_res)
             dy, dres = r if has_res else (r, None)
-            ops.conv2d_wgrad(x, dy, self.g[wkey], ks, stride, pad, accumulate=True, use_tr=self.use_tr)
-            dx = self.conv_dgrad(dy, wkey, ks, stride, pad, x.shape, residual=dx_res) if need_dx else None
+            ops.conv2d_wgrad(x, dy, self.g[wkey], ks, stride, pad, accumulate=True, use_tr=self.use_tr,
+                             dilation=dilation)
+            dx = self.conv_dgrad(dy, wkey, ks, stride, pad, x.shape, residual=dx_res, dilation=dilation) \
+                if need_dx else None
             return dx, dres
         return out, bwd
 
@@ -178,6 +180,49 @@ class Engine:
                 dx, _ = b1(dh, dx_res=dres)
             return dx
         return out, bwd
+
+    def bottleneck(self, x, pfx, stride, dilation, groups):
+        """Bottleneck (models/resnet.py:76-122): 1x1 -> 3x3 (stride / dilation, pad = dilation) -> 1x1 (+identity)."""
+        h1, b1 = self.conv_bn(x, pfx + ".conv1.weight", pfx + ".bn1", 1, 1, 0, groups, True)
+        h2, b2 = self.conv_bn(h1, pfx + ".conv2.weight", pfx + ".bn2", 3, stride, dilation, groups, True,
+                              dilation=dilation)
+        has_ds = (pfx + ".downsample.0.weight") in self.shapes
+        if has_ds:
+            idt, bds = self.conv_bn(x, pfx + ".downsample.0.weight", pfx + ".downsample.1", 1, stride, 0, groups, False)
+        else:
+            idt, bds = x, None
+        out, b3 = self.conv_bn(h2, pfx + ".conv3.weight", pfx + ".bn3", 1, 1, 0, groups, True, residual=idt)
+        if not self.need_grad:
+            return out, None
+
+        def bwd(dout):
+            dh2, dres = b3(dout)
+            dh1, _ = b2(dh2)
+            if has_ds:
+                dxds, _ = bds(dres)
+                dx, _ = b1(dh1, dx_res=dxds)
+            else:
+                dx, _ = b1(dh1, dx_res=dres)
+            return dx
+        return out, bwd
+
+    def res50_layer(self, x, li, stride, first_dilation, dilation, groups):
+        """_make_layer (resnet.py:178-199): block 0 keeps the previous dilation, the others use the new one."""
+        from .netspec import RESNET50_BLOCKS
+        bwds = []
+        x, b = self.bottleneck(x, "resnet.layer%d.0" % li, stride, first_dilation, groups)
+        bwds.append(b)
+        for i in range(1, RESNET50_BLOCKS[li - 1]):
+            x, b = self.bottleneck(x, "resnet.layer%d.%d" % (li, i), 1, dilation, groups)
+            bwds.append(b)
+        if not self.need_grad:
+            return x, None
+
+        def bwd(d):
+            for b in reversed(bwds):
+                d = b(d)
+            return d
+        return x, bwd
 
     def res_layer(self, x, li, stride, groups):
         x, ba = self.basic_block(x, "resnet.layer%d.0" % li, stride, groups)
@@ -381,9 +426,14 @@ class Engine:
         S2 = 2 * B
         x, b_stem = self.stem(x1, x2, 2)
         xp, xarg = ops.maxpool(x, want_arg=True)
-        l1, b_l1 = self.res_layer(xp, 1, 1, 2)
-        l2, b_l2 = self.res_layer(l1, 2, 2, 2)
-        l3, b_l3 = self.res_layer(l2, 3, 1, 2)
+        if cfg.get("backbone") == "resnet50":
+            l1, b_l1 = self.res50_layer(xp, 1, 1, 1, 1, 2)
+            l2, b_l2 = self.res50_layer(l1, 2, 2, 1, 1, 2)
+            l3, b_l3 = self.res50_layer(l2, 3, 1, 1, 2, 2)       # stride replaced by dilation 2 (honoured)
+        else:
+            l1, b_l1 = self.res_layer(xp, 1, 1, 2)
+            l2, b_l2 = self.res_layer(l1, 2, 2, 2)
+            l3, b_l3 = self.res_layer(l2, 3, 1, 2)
         up = ops.upsample2(l3)
         feat, b_pred = self.conv_act(up, "conv_pred.weight", "conv_pred.bias", 3, 1, NONE)
         _, fh, fw, _ = feat.shape

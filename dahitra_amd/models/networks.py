@@ -226,17 +226,24 @@ def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[]):
 
 def define_G(args, init_type='normal', init_gain=0.02, gpu_ids=[]):
     """models/networks.py:130-168; reads args.net_G (and the optional args.compute_dtype)."""
-    get_config(args.net_G)          # NotImplementedError for unknown names, as the reference
+    if get_config(args.net_G).get("ctor_only"):   # NotImplementedError for unknown names, as the reference
+        raise NotImplementedError("Generator model name [%s] is not recognized" % args.net_G)
     net = CDNet(args.net_G, getattr(args, "compute_dtype", None))
     return init_net(net, init_type, init_gain, gpu_ids)
 
 
 def BASE_Transformer(input_nc=3, output_nc=2, with_pos='learned', resnet_stages_num=4, token_len=4, enc_depth=1,
-                     dec_depth=1, decoder_dim_head=64, **kw):
-    """constructor-style access (models/networks.py:260-310) for the configurations define_G exposes"""
+                     dec_depth=1, decoder_dim_head=64, backbone='resnet18', **kw):
+    """constructor-style access (models/networks.py:260-310) for the configurations define_G exposes, plus the
+    ResNet-50 trunk (backbone='resnet50', networks.py:192-195) that only a constructor call reaches"""
     from ..netspec import NET_CONFIGS
+    if backbone not in ("resnet18", "resnet50") or input_nc != 3 or with_pos != 'learned' or resnet_stages_num != 4:
+        raise NotImplementedError("BASE_Transformer(backbone=%r, input_nc=%r, with_pos=%r, resnet_stages_num=%r) is "
+                                  "outside the supported configurations" % (backbone, input_nc, with_pos,
+                                                                           resnet_stages_num))
     for name, c in NET_CONFIGS.items():
-        if c["kind"] == "bit" and (c["n_class"], c["token_len"], c["enc_depth"], c["dec_depth"], c["dec_dim_head"]) == \
+        if c["kind"] == "bit" and c.get("backbone", "resnet18") == backbone and \
+                (c["n_class"], c["token_len"], c["enc_depth"], c["dec_depth"], c["dec_dim_head"]) == \
                 (output_nc, token_len, enc_depth, dec_depth, decoder_dim_head):
             return CDNet(name, kw.get("compute_dtype"))
     raise NotImplementedError("BASE_Transformer configuration not covered by define_G's net_G table")

@@ -21,7 +21,12 @@ NET_CONFIGS = {
     "base_transformer_pos_s4_dd8_t8_e2d4": dict(kind="bit", n_class=2, token_len=8, enc_depth=2, dec_depth=4,
                                                 dec_dim_head=8),
     "newUNetTrans": dict(kind="unet", n_class=2, token_len=4, enc_depth=1),
+    # ResNet-50 trunk: NOT a define_G name in the reference -- only reachable through the constructor
+    # BASE_Transformer(..., backbone='resnet50') (networks.py:192-195); define_G below refuses it too.
+    "base_transformer_pos_s4_resnet50": dict(kind="bit", n_class=2, token_len=4, enc_depth=1, dec_depth=1,
+                                             dec_dim_head=64, backbone="resnet50", ctor_only=True),
 }
+RESNET50_BLOCKS = (3, 4, 6, 3)
 BIT_HEADS, BIT_DIM_HEAD = 8, 64
 # hierarchical model, level suffix -> trunk channels / heads / decoder depth / dim_head / map size
 UNET_LEVELS = {
@@ -57,6 +62,23 @@ def _resnet18(p="resnet"):
     return s + [(p + ".fc.weight", (1000, 512), "lin_w"), (p + ".fc.bias", (1000,), "bias")]
 
 
+def _resnet50(p="resnet"):
+    """Bottleneck trunk (models/resnet.py:76-122, 261-270): expansion 4, a 1x1 downsample in every first block."""
+    s = [(p + ".conv1.weight", (64, 3, 7, 7), "conv_w")] + _bn(p + ".bn1", 64)
+    cin = 64
+    for li, planes, blocks in zip((1, 2, 3, 4), (64, 128, 256, 512), RESNET50_BLOCKS):
+        for b in range(blocks):
+            q = "%s.layer%d.%d" % (p, li, b)
+            s += [(q + ".conv1.weight", (planes, cin, 1, 1), "conv_w")] + _bn(q + ".bn1", planes)
+            s += [(q + ".conv2.weight", (planes, planes, 3, 3), "conv_w")] + _bn(q + ".bn2", planes)
+            s += [(q + ".conv3.weight", (4 * planes, planes, 1, 1), "conv_w")] + _bn(q + ".bn3", 4 * planes)
+            if b == 0:
+                s += [(q + ".downsample.0.weight", (4 * planes, cin, 1, 1), "conv_w")] + \
+                     _bn(q + ".downsample.1", 4 * planes)
+            cin = 4 * planes
+    return s + [(p + ".fc.weight", (1000, 2048), "lin_w"), (p + ".fc.bias", (1000,), "bias")]
+
+
 def _xformer(p, depth, heads, dim_head, mlp, cross):
     inner = heads * dim_head
     s = []
@@ -79,10 +101,11 @@ def state_spec(net_G):
     cfg = get_config(net_G)
     L = cfg["token_len"]
     if cfg["kind"] == "bit":
-        s = [("pos_embedding", (1, 2 * L, DIM), "pos")] + _resnet18()
+        r50 = cfg.get("backbone") == "resnet50"
+        s = [("pos_embedding", (1, 2 * L, DIM), "pos")] + (_resnet50() if r50 else _resnet18())
         s += [("classifier.0.weight", (32, 32, 3, 3), "conv_w")] + _bn("classifier.1", 32)
         s += [("classifier.3.weight", (cfg["n_class"], 32, 3, 3), "conv_w"), ("classifier.3.bias", (cfg["n_class"],), "bias"),
-              ("conv_pred.weight", (32, 256, 3, 3), "conv_w"), ("conv_pred.bias", (32,), "bias"),
+              ("conv_pred.weight", (32, 1024 if r50 else 256, 3, 3), "conv_w"), ("conv_pred.bias", (32,), "bias"),
               ("conv_a.weight", (L, 32, 1, 1), "conv_w")]
         s += _xformer("transformer", cfg["enc_depth"], BIT_HEADS, BIT_DIM_HEAD, 2 * DIM, False)
         s += _xformer("transformer_decoder", cfg["dec_depth"], BIT_HEADS, cfg["dec_dim_head"], 2 * DIM, True)

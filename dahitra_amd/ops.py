@@ -89,11 +89,11 @@ PROFILE = None       # set to {} by bench.py to collect (events, algorithmic flo
 
 
 def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT_NONE, want_stats=False,
-           want_preact=False, npix_valid=0, w_image_stride=0, out_hw=None, alg_flops=0):
+           want_preact=False, npix_valid=0, w_image_stride=0, out_hw=None, alg_flops=0, dilation=1):
     N, H, W, Cin = x.shape
     if out_hw is None:
-        OH = (H + 2 * pad - ks) // stride + 1
-        OW = (W + 2 * pad - ks) // stride + 1
+        OH = (H + 2 * pad - dilation * (ks - 1) - 1) // stride + 1
+        OW = (W + 2 * pad - dilation * (ks - 1) - 1) // stride + 1
     else:
         OH, OW = out_hw
     cpad = wp.shape[-2]
@@ -114,7 +114,7 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
         ev[0].record()
     _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
           _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
-          _cl(w_image_stride), P(pre), S())
+          _cl(w_image_stride), P(pre), _ci(dilation), S())
     if ev is not None:
         ev[1].record()
     out = [y]
@@ -142,14 +142,14 @@ def linear(x2d, wp, cout, bias=None, residual=None, act=ACT_NONE, want_preact=Fa
     pre = torch.empty_like(y) if want_preact else None
     _call("dh_conv2d_fwd", _ci(dt(x2d)), P(x2d), P(wp), P(y), P(bias), P(residual), _vp(0), _ci(images), _ci(Hh),
           _ci(16), _ci(Cin), _ci(Hh), _ci(16), _ci(cout), _ci(cpad), _ci(1), _ci(1), _ci(0), _ci(act), _ci(rpi),
-          _cl(w_image_stride), P(pre), S())
+          _cl(w_image_stride), P(pre), _ci(1), S())
     # note: with rows_per_image % 16 != 0 the image stride used by the kernel (Hh*16 rows) would differ
     # from rpi; callers guarantee rpi % 16 == 0 whenever images > 1.
     assert images == 1 or rpi % 16 == 0
     return (y, pre) if want_preact else y
 
 
-def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=True, cout_real=0, cin=0):
+def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=True, cout_real=0, cin=0, dilation=1):
     """dw (OIHW fp32, or [N, Cout, Cin] when groups == N) (+)= weight gradient.
     cin > 0: use only the first `cin` channels of x (x keeps its own channel pitch)."""
     N, H, W, pitch = x.shape
@@ -160,7 +160,7 @@ def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=
     ws = workspace(nbytes, x.device)
     _call("dh_conv2d_wgrad", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W), _ci(Cin),
           _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(groups), _ci(0), _ci(int(use_tr)),
-          _ci(cout_real), _ci(pitch), P(ws), S())
+          _ci(cout_real), _ci(pitch), _ci(dilation), P(ws), S())
 
 
 def linear_wgrad(x2d, dy2d, dw, accumulate=False, images=1, per_image=False, use_tr=True):
@@ -175,7 +175,7 @@ def linear_wgrad(x2d, dy2d, dw, accumulate=False, images=1, per_image=False, use
     assert images == 1 or rpi % 16 == 0
     _call("dh_conv2d_wgrad", _ci(dt(x2d)), P(x2d), P(dy2d), P(dw), _ci(int(accumulate)), _ci(images), _ci(Hh), _ci(16),
           _ci(Cin), _ci(Hh), _ci(16), _ci(Cout), _ci(1), _ci(1), _ci(0), _ci(groups), _ci(rpi), _ci(int(use_tr)),
-          _ci(0), _ci(0), P(ws), S())
+          _ci(0), _ci(0), _ci(1), P(ws), S())
 
 
 def zero_insert2(dy, H, W):

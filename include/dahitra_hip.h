@@ -49,14 +49,14 @@ void dh_set_error(const char* msg);
 int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const float* bias,
                   const void* residual, float* stats_partial, int N, int H, int W, int Cin, int OH, int OW,
                   int Cout, int CoutPad, int ks, int stride, int pad, int act, int npix_valid,
-                  long w_image_stride, void* y_preact, void* stream);
+                  long w_image_stride, void* y_preact, int dilation, void* stream);
 int dh_conv2d_fwd_num_tiles(int N, int OH, int OW, int Cin, int ks, int stride);
 
 /* weight gradient (autograd convolution_backward / mm for nn.Linear): groups == 1 writes the
  * torch OIHW layout [Cout_real][Cin][ks][ks]; groups == N (ks == 1) one [Cout][Cin] per image. */
 int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N, int H,
                     int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad, int groups,
-                    int npix_valid, int use_tr, int Cout_real, int cin_pitch, void* workspace, void* stream);
+                    int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation, void* workspace, void* stream);
 long dh_conv2d_wgrad_workspace_size(int N, int OH, int OW, int Cin, int Cout, int ks, int groups);
 int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, int ks, int groups);
 

@@ -42,6 +42,11 @@ NET_CONFIGS = {
     "base_transformer_pos_s4_dd8_t8_e2d4": dict(kind="bit", n_class=2, token_len=8, enc_depth=2,
                                                 dec_depth=4, dec_dim_head=8),
     "newUNetTrans": dict(kind="unet", n_class=2, token_len=4, enc_depth=1),
+    # NOT a define_G name: the reference reaches this model only through the constructor call
+    # BASE_Transformer(..., backbone='resnet50') (networks.py:192-195).  It is
+    # keyed here so that the same spec/forward/train helpers serve it.
+    "base_transformer_pos_s4_resnet50": dict(kind="bit", n_class=2, token_len=4, enc_depth=1, dec_depth=1,
+                                             dec_dim_head=64, backbone="resnet50"),
 }
 DIM = 32           # transformer width everywhere (networks.py:289, 1178)
 ENC_HEADS = 8      # BiT encoder/decoder heads (networks.py:305-310)
@@ -92,6 +97,31 @@ def _resnet18_spec(pfx="resnet"):
     return s
 
 
+RESNET50_BLOCKS = (3, 4, 6, 3)
+
+
+def _resnet50_spec(pfx="resnet"):
+    """Bottleneck trunk (models/resnet.py:76-122, 261-270): width = planes, expansion 4; every layer's
+    first block carries a 1x1 downsample (resnet.py:186-190)."""
+    s = [(pfx + ".conv1.weight", (64, 3, 7, 7), "conv_w")] + _bn_spec(pfx + ".bn1", 64)
+    cin = 64
+    for li, planes, blocks in zip((1, 2, 3, 4), (64, 128, 256, 512), RESNET50_BLOCKS):
+        for b in range(blocks):
+            p = "%s.layer%d.%d" % (pfx, li, b)
+            s.append((p + ".conv1.weight", (planes, cin, 1, 1), "conv_w"))
+            s += _bn_spec(p + ".bn1", planes)
+            s.append((p + ".conv2.weight", (planes, planes, 3, 3), "conv_w"))
+            s += _bn_spec(p + ".bn2", planes)
+            s.append((p + ".conv3.weight", (4 * planes, planes, 1, 1), "conv_w"))
+            s += _bn_spec(p + ".bn3", 4 * planes)
+            if b == 0:
+                s.append((p + ".downsample.0.weight", (4 * planes, cin, 1, 1), "conv_w"))
+                s += _bn_spec(p + ".downsample.1", 4 * planes)
+            cin = 4 * planes
+    s += [(pfx + ".fc.weight", (1000, 2048), "lin_w"), (pfx + ".fc.bias", (1000,), "bias")]
+    return s
+
+
 def _encoder_spec(pfx, depth, heads, dim_head, mlp_dim):
     inner = heads * dim_head
     s = []
@@ -136,11 +166,12 @@ def state_spec(net_G):
     L = cfg["token_len"]
     if cfg["kind"] == "bit":
         s = [("pos_embedding", (1, 2 * L, DIM), "pos")]
-        s += _resnet18_spec()
+        r50 = cfg.get("backbone") == "resnet50"
+        s += _resnet50_spec() if r50 else _resnet18_spec()
         s += [("classifier.0.weight", (32, 32, 3, 3), "conv_w")] + _bn_spec("classifier.1", 32)
         s += [("classifier.3.weight", (cfg["n_class"], 32, 3, 3), "conv_w"),
               ("classifier.3.bias", (cfg["n_class"],), "bias"),
-              ("conv_pred.weight", (32, 256, 3, 3), "conv_w"), ("conv_pred.bias", (32,), "bias"),
+              ("conv_pred.weight", (32, 1024 if r50 else 256, 3, 3), "conv_w"), ("conv_pred.bias", (32,), "bias"),
               ("conv_a.weight", (L, 32, 1, 1), "conv_w")]
         s += _encoder_spec("transformer", cfg["enc_depth"], ENC_HEADS, ENC_DIM_HEAD, 2 * DIM)
         s += _decoder_spec("transformer_decoder", cfg["dec_depth"], ENC_HEADS,
@@ -273,6 +304,28 @@ def _basic_block(sd, pfx, x, stride, training):
     return F.relu(y + x)
 
 
+def _bottleneck(sd, pfx, x, stride, dilation, training):
+    """models/resnet.py:102-122: 1x1 -> 3x3 (stride and dilation live here, padding = dilation) -> 1x1."""
+    y = F.conv2d(x, sd[pfx + ".conv1.weight"])
+    y = F.relu(_bn(sd, pfx + ".bn1", y, training))
+    y = F.conv2d(y, sd[pfx + ".conv2.weight"], None, stride, dilation, dilation)
+    y = F.relu(_bn(sd, pfx + ".bn2", y, training))
+    y = F.conv2d(y, sd[pfx + ".conv3.weight"])
+    y = _bn(sd, pfx + ".bn3", y, training)
+    if (pfx + ".downsample.0.weight") in sd:
+        x = F.conv2d(x, sd[pfx + ".downsample.0.weight"], None, stride, 0)
+        x = _bn(sd, pfx + ".downsample.1", x, training)
+    return F.relu(y + x)
+
+
+def _res50_layer(sd, li, x, stride, first_dilation, dilation, training):
+    """_make_layer (resnet.py:178-199): block 0 uses the PREVIOUS dilation, the rest the new one."""
+    x = _bottleneck(sd, "resnet.layer%d.0" % li, x, stride, first_dilation, training)
+    for b in range(1, RESNET50_BLOCKS[li - 1]):
+        x = _bottleneck(sd, "resnet.layer%d.%d" % (li, b), x, 1, dilation, training)
+    return x
+
+
 def _res_layer(sd, li, x, stride, training):
     x = _basic_block(sd, "resnet.layer%d.0" % li, x, stride, training)
     return _basic_block(sd, "resnet.layer%d.1" % li, x, 1, training)
@@ -362,9 +415,14 @@ def _bit_forward(sd, cfg, x1, x2, training, taps):
     def trunk(x):
         x = _stem(sd, x, training)
         x = F.max_pool2d(x, 3, 2, 1)
-        x = _res_layer(sd, 1, x, 1, training)
-        x = _res_layer(sd, 2, x, 2, training)
-        x = _res_layer(sd, 3, x, 1, training)          # stride replaced by (ignored) dilation
+        if cfg.get("backbone") == "resnet50":
+            x = _res50_layer(sd, 1, x, 1, 1, 1, training)
+            x = _res50_layer(sd, 2, x, 2, 1, 1, training)
+            x = _res50_layer(sd, 3, x, 1, 1, 2, training)  # stride -> dilation 2, honoured by Bottleneck
+        else:
+            x = _res_layer(sd, 1, x, 1, training)
+            x = _res_layer(sd, 2, x, 2, training)
+            x = _res_layer(sd, 3, x, 1, training)          # stride replaced by (ignored) dilation
         x = F.interpolate(x, scale_factor=2, mode="nearest")
         return F.conv2d(x, sd["conv_pred.weight"], sd["conv_pred.bias"], 1, 1)
 

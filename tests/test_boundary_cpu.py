@@ -39,10 +39,16 @@ def test_header_has_no_torch_types():
 
 
 def test_state_dict_keys_equal_reference(golden_dir):
-    from dahitra_amd.models.networks import define_G
+    from dahitra_amd.models.networks import BASE_Transformer, define_G
     ref = json.load(open(os.path.join(golden_dir, "state_keys.json")))
     for name, keys in ref.items():
-        net = define_G(types.SimpleNamespace(net_G=name))
+        if name.endswith("_resnet50"):          # only a constructor call reaches it (networks.py:192-195)
+            with pytest.raises(NotImplementedError):
+                define_G(types.SimpleNamespace(net_G=name))
+            net = BASE_Transformer(input_nc=3, output_nc=2, token_len=4, resnet_stages_num=4, with_pos='learned',
+                                   backbone='resnet50')
+        else:
+            net = define_G(types.SimpleNamespace(net_G=name))
         sd = net.state_dict()
         assert [[k, list(v.shape)] for k, v in sd.items()] == keys, name
 
@@ -75,7 +81,7 @@ def test_define_G_contract():
 def test_unused_parameter_contract():
     """17 (BiT) / 48 (newUNetTrans) tensors never receive a gradient"""
     from dahitra_amd import netspec
-    for name, n in (("base_transformer_pos_s4", 17), ("newUNetTrans", 48)):
+    for name, n in (("base_transformer_pos_s4", 17), ("newUNetTrans", 48), ("base_transformer_pos_s4_resnet50", 32)):
         inactive = [k for k, _, r in netspec.state_spec(name) if not netspec.is_buffer(r) and not netspec.is_active(name, k)]
         assert len(inactive) == n, (name, len(inactive))
 

@@ -54,19 +54,23 @@ def ops():
     dict(ks=3, stride=1, pad=1, cin=32, cout=2, h=20, w=20),
     dict(ks=3, stride=1, pad=1, cin=32, cout=5, h=16, w=16),
     dict(ks=3, stride=1, pad=1, cin=256, cout=256, h=16, w=16),
+    dict(ks=3, stride=1, pad=2, dil=2, cin=64, cout=64, h=20, w=24),      # ResNet-50 layer3 (resnet.py:31-33)
+    dict(ks=3, stride=1, pad=2, dil=2, cin=256, cout=256, h=16, w=32),    # 16-row tile variant
+    dict(ks=1, stride=1, pad=0, cin=1024, cout=256, h=8, w=8),
 ])
 def test_conv2d_fwd(ops, dtype, cfg):
     N = 3
     x = rnd((N, cfg["cin"], cfg["h"], cfg["w"]), dtype, 1)
     w = rnd((cfg["cout"], cfg["cin"], cfg["ks"], cfg["ks"]), dtype, 2, scale=(cfg["cin"] * cfg["ks"] ** 2) ** -0.5)
     b = rnd((cfg["cout"],), torch.float32, 3, 0.1)
-    want_pre = F.conv2d(x, w, b, cfg["stride"], cfg["pad"])
+    dil = cfg.get("dil", 1)
+    want_pre = F.conv2d(x, w, b, cfg["stride"], cfg["pad"], dil)
     r = rnd(tuple(want_pre.shape), dtype, 4)
     want = F.relu(want_pre + r)
     wp, _ = ops.pack_weight(w.cuda(), dtype, want_dgrad=False)
     y, stats, pre = ops.conv2d(dev(nhwc(x), dtype), wp, cfg["cout"], cfg["ks"], cfg["stride"], cfg["pad"],
                                bias=b.cuda(), residual=dev(nhwc(r), dtype), act=ops.ACT_RELU, want_stats=True,
-                               want_preact=True)
+                               want_preact=True, dilation=dil)
     close(nchw(y), want, dtype, "conv2d out")
     close(nchw(pre), want_pre + r, dtype, "conv2d preact")
     tot = stats.sum(0).cpu()           # [2][CoutPad]
@@ -81,13 +85,16 @@ def test_conv2d_fwd(ops, dtype, cfg):
     dict(ks=1, stride=2, pad=0, cin=64, cout=128, h=32, w=32),
     dict(ks=1, stride=1, pad=0, cin=256, cout=32, h=16, w=16),
     dict(ks=3, stride=1, pad=1, cin=32, cout=2, h=16, w=16),
+    dict(ks=3, stride=1, pad=2, dil=2, cin=64, cout=64, h=20, w=24),
+    dict(ks=3, stride=1, pad=2, dil=2, cin=128, cout=128, h=8, w=8),      # dilation reaches past a whole 8x8 map edge
 ])
 def test_conv2d_dgrad_and_wgrad(ops, dtype, cfg):
     N = 2
     x = rnd((N, cfg["cin"], cfg["h"], cfg["w"]), dtype, 5).requires_grad_(True)
     w = rnd((cfg["cout"], cfg["cin"], cfg["ks"], cfg["ks"]), dtype, 6, scale=(cfg["cin"] * cfg["ks"] ** 2) ** -0.5)
     w.requires_grad_(True)
-    y = F.conv2d(x, w, None, cfg["stride"], cfg["pad"])
+    dil = cfg.get("dil", 1)
+    y = F.conv2d(x, w, None, cfg["stride"], cfg["pad"], dil)
     dy = rnd(tuple(y.shape), dtype, 7)
     y.backward(dy)
     ck = ops.chunk_channels(dtype)
@@ -98,12 +105,13 @@ def test_conv2d_dgrad_and_wgrad(ops, dtype, cfg):
     dyd = dev(dyp, dtype)
     if cfg["stride"] == 2:
         dyd = ops.zero_insert2(dyd, cfg["h"], cfg["w"])
-    dx = ops.conv2d(dyd, wd, cfg["cin"], cfg["ks"], 1, cfg["ks"] - 1 - cfg["pad"], out_hw=(cfg["h"], cfg["w"]))
+    dx = ops.conv2d(dyd, wd, cfg["cin"], cfg["ks"], 1, dil * (cfg["ks"] - 1) - cfg["pad"], out_hw=(cfg["h"], cfg["w"]),
+                    dilation=dil)
     close(nchw(dx), x.grad, dtype, "dgrad", factor=2.0)
     for tr in ([True, False] if dtype == torch.bfloat16 else [False]):
         dw = torch.full(tuple(w.shape), 0.5, device="cuda")
         ops.conv2d_wgrad(dev(nhwc(x.detach()), dtype), dev(nhwc(dy), dtype), dw, cfg["ks"], cfg["stride"], cfg["pad"],
-                         accumulate=True, use_tr=tr)
+                         accumulate=True, use_tr=tr, dilation=dil)
         close(dw - 0.5, w.grad, dtype, "wgrad tr=%s" % tr, factor=4.0)
 
 

@@ -6,27 +6,37 @@ outside the tie band; bf16 mode: worst logit within 0.15 of the logit scale, mas
 Gradient tolerances are calibrated to the measured fp32 noise floor of THIS computation: the oracle run
 in fp64 vs fp32 on the same inputs differs by 4e-3 (median over parameters) and up to 6e-2 (layer3
 convs) of max|grad|, because ReLU / max-pool / |a-b| make the gradient discontinuous in the
-activations.  GRAD_TOL below is that floor; forward quantities keep the tight bounds."""
+activations.  GRAD_TOL below is that floor; forward quantities keep the tight bounds.  The 50-layer
+ResNet-50 variant has a higher floor (same measurement: median 1e-2, worst 0.13 in layer3.5.conv3 /
+conv2); two fp32 implementations each carry that deviation, so their worst-tensor distance is bounded
+by twice it (GRAD_TOL_R50), while the median over tensors and the per-tensor cosine stay tight."""
 import os
 import types
 
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import cdnet_ref as O
 
 pytestmark = pytest.mark.gpu
 GRAD_TOL = 6e-2        # of max|grad| per tensor (see module docstring)
+GRAD_TOL_R50 = 0.26
 NORM_TOL = 3e-2
 
+R50 = "base_transformer_pos_s4_resnet50"      # ctor-only model (networks.py:192-195): ResNet-50 trunk, dilation 2
 NETS = ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8", "base_transformer_pos_s4_dd8_o5",
-        "base_transformer_pos_s4_dd8_dedim8", "base_transformer_pos_s4_dd8_t8_e2d4", "newUNetTrans"]
+        "base_transformer_pos_s4_dd8_dedim8", "base_transformer_pos_s4_dd8_t8_e2d4", "newUNetTrans", R50]
 
 
 def make_net(name, dtype="fp32"):
-    from dahitra_amd.models.networks import define_G
-    net = define_G(types.SimpleNamespace(net_G=name, compute_dtype=dtype), gpu_ids=[0])
+    from dahitra_amd.models.networks import BASE_Transformer, define_G, init_net
+    if name == R50:
+        net = init_net(BASE_Transformer(input_nc=3, output_nc=2, token_len=4, resnet_stages_num=4, with_pos='learned',
+                                        backbone='resnet50', compute_dtype=dtype), gpu_ids=[0])
+    else:
+        net = define_G(types.SimpleNamespace(net_G=name, compute_dtype=dtype), gpu_ids=[0])
     net.load_state_dict(O.deterministic_state(name))
     return net
 
@@ -67,7 +77,7 @@ def test_forward_matches_reference_golden_fp32(name, golden_dir):
             assert abs(float(focal_loss(y.cuda(), lab.cuda())) - float(g["focal"])) < 2e-5
 
 
-@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans", R50])
 def test_train_steps_match_reference_golden_fp32(name, golden_dir):
     from dahitra_amd.models import losses
     from dahitra_amd.optim import AdamW
@@ -97,7 +107,8 @@ def test_train_steps_match_reference_golden_fp32(name, golden_dir):
                 if k.startswith("grad0/"):
                     w = torch.from_numpy(g[k])
                     e = float((params[k[6:]].grad.cpu() - w).abs().max())
-                    assert e <= GRAD_TOL * float(w.abs().max()) + 1e-8, "grad %s err %.3e (max %.3e)" % (k[6:], e, float(w.abs().max()))
+                    tol = GRAD_TOL_R50 if name == R50 else GRAD_TOL
+                    assert e <= tol * float(w.abs().max()) + 1e-8, "grad %s err %.3e (max %.3e)" % (k[6:], e, float(w.abs().max()))
         opt.step()
         got_losses.append(float(loss))
     # step 0 is a pure function of the fixture's weights: tight.  Later steps follow an Adam trajectory,
@@ -112,7 +123,7 @@ def test_train_steps_match_reference_golden_fp32(name, golden_dir):
     assert int(sd["resnet.bn1.num_batches_tracked"]) == int(g["nbt"])
 
 
-@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_t8_e2d4"])
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_t8_e2d4", R50])
 def test_gradients_match_oracle_fp32(name):
     """every parameter gradient against the oracle's autograd on a non-square, odd-batch case"""
     from dahitra_amd.models import losses
@@ -124,7 +135,7 @@ def test_gradients_match_oracle_fp32(name):
     net = make_net(name).train()
     y = net(a.cuda(), b.cuda())
     losses.focal_loss(y, lab.cuda()).backward()
-    bad = []
+    bad, rels, coss = [], [], []
     for k, p in net.named_parameters():
         ref = st.sd[k].grad
         assert (p.grad is None) == (ref is None), k
@@ -132,9 +143,14 @@ def test_gradients_match_oracle_fp32(name):
             continue
         e = float((p.grad.cpu() - ref).abs().max())
         s = float(ref.abs().max())
-        if e > GRAD_TOL * s + 1e-7:
+        rels.append(e / max(s, 1e-30))
+        if ref.numel() >= 64:
+            coss.append(float(F.cosine_similarity(p.grad.cpu().double().flatten(), ref.double().flatten(), dim=0)))
+        if e > (GRAD_TOL_R50 if name == R50 else GRAD_TOL) * s + 1e-7:
             bad.append((k, e, s))
     assert not bad, bad[:10]
+    assert float(np.median(rels)) <= 2e-2, float(np.median(rels))
+    assert min(coss) >= 0.995, min(coss)
 
 
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
@@ -153,6 +169,38 @@ def test_bf16_mode_tracks_fp32(name):
     flips = float((torch.argmax(y, 1) != torch.argmax(ref, 1)).float().mean())
     print("bf16 %s: logits rel err %.3e, mask disagreement %.4f" % (name, err, flips))
     assert err < 0.15 and flips < 0.03
+
+
+def test_bf16_mode_resnet50_within_the_nets_own_sensitivity():
+    """The 50-layer trunk with RANDOM weights and batch-statistics BN is chaotic: rounding only the weights and
+    images to bf16 inside the fp32 pipeline already moves the logits by ~0.3 (relative L2; tools/r50_bf16_diag.py).
+    So the bf16 pipeline is held to (a) the usual bound in eval mode, where running statistics tame the net, and
+    (b) a small multiple of that measured sensitivity in train mode."""
+    a, b, lab = O.synthetic_batch(2, 128, seed=5)
+    sd = O.deterministic_state(R50)
+    sd_r = {k: (v.bfloat16().float() if v.dtype.is_floating_point and v.dim() > 1 else v) for k, v in sd.items()}
+
+    def run(dtype, state, x1, x2, train):
+        net = make_net(R50, dtype)
+        net.load_state_dict(state)
+        net.train(train)
+        with torch.no_grad():
+            return net(x1.cuda(), x2.cuda()).float().cpu()
+
+    l2 = lambda u, v: float((u - v).norm() / v.norm())
+    with torch.no_grad():
+        ref_eval = O.forward({k: v.clone() for k, v in sd.items()}, R50, a, b, training=False)
+    y_eval = run("bf16", sd, a, b, False)
+    flips = float((y_eval.argmax(1) != ref_eval.argmax(1)).float().mean())
+    err = float((y_eval - ref_eval).abs().max() / ref_eval.abs().max())
+    print("bf16 resnet50 eval: rel err %.3e flips %.4f" % (err, flips))
+    assert err < 0.15 and flips < 0.03
+    ref = run("fp32", sd, a, b, True)
+    sens = l2(run("fp32", sd_r, a.bfloat16().float(), b.bfloat16().float(), True), ref)
+    got = l2(run("bf16", sd, a, b, True), ref)
+    print("bf16 resnet50 train: l2 %.3f, sensitivity to bf16-rounded weights %.3f" % (got, sens))
+    assert sens > 0.05            # the premise: this configuration amplifies bf16-sized perturbations
+    assert got <= 3.0 * sens
 
 
 def test_bf16_train_step_reduces_loss():

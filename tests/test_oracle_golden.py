@@ -10,7 +10,8 @@ import torch
 import cdnet_ref as O
 
 FWD = ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8", "base_transformer_pos_s4_dd8_o5",
-       "base_transformer_pos_s4_dd8_dedim8", "base_transformer_pos_s4_dd8_t8_e2d4", "newUNetTrans"]
+       "base_transformer_pos_s4_dd8_dedim8", "base_transformer_pos_s4_dd8_t8_e2d4", "newUNetTrans",
+       "base_transformer_pos_s4_resnet50"]
 
 
 def test_state_keys_match_reference(golden_dir):
@@ -23,7 +24,8 @@ def test_state_keys_match_reference(golden_dir):
 def test_param_counts():
     # SURVEY.md section 8 a1 (probed from the reference)
     want = {"base_transformer_pos_s4": 11913290, "base_transformer_pos_s4_dd8": 12402506,
-            "base_transformer_pos_s4_dd8_dedim8": 11943754, "newUNetTrans": 13381226}
+            "base_transformer_pos_s4_dd8_dedim8": 11943754, "newUNetTrans": 13381226,
+            "base_transformer_pos_s4_resnet50": 26001994}
     for name, n in want.items():
         got = sum(int(np.prod(s)) if len(s) else 1 for k, s, r in O.state_spec(name)
                   if not O.is_buffer(r))
@@ -68,7 +70,7 @@ def test_forward_matches_golden(name, golden_dir):
             assert abs(float(O.focal_loss(y, lab)) - float(g["focal"])) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans", "base_transformer_pos_s4_resnet50"])
 def test_train_steps_match_golden(name, golden_dir):
     torch.set_num_threads(8)
     g = np.load(os.path.join(golden_dir, "train_%s.npz" % name))

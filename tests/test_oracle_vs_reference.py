@@ -8,13 +8,14 @@ import ref_import
 pytestmark = pytest.mark.skipif(not ref_import.available(), reason="/root/reference not present")
 
 
-@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_t8_e2d4"])
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_t8_e2d4",
+                                  "base_transformer_pos_s4_resnet50"])
 def test_train_step_equals_reference(name):
     """logits, focal loss, every gradient and two AdamW updates vs models/networks.py +
     models/losses.py + torch.optim.AdamW (models/trainer.py:39-40,302-308)."""
     _, ref_losses = ref_import.load()
     cfg = O.get_config(name)
-    net = ref_import.define_G(name)
+    net = ref_import.build_resnet50_variant() if cfg.get("backbone") == "resnet50" else ref_import.define_G(name)
     net.load_state_dict(O.deterministic_state(name))
     net.train()
     opt = torch.optim.AdamW(net.parameters(), lr=0.01, betas=(0.9, 0.999), weight_decay=0.01)
