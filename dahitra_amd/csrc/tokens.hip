@@ -1,6 +1,8 @@
 // Token-side kernels of the bitemporal transformer (gfx950).  All of this is a few hundred KFLOP
 // per image: latency-, not roofline-bound.  Internal math is fp32; tensors crossing to the pixel
-// side are in the activation type T.
+// side are in the activation type T.  The TOKENS themselves (a few KB) are always fp32, whatever T is:
+// the hierarchical nets decode against |token2 - token1| (networks.py:1311), and two bf16-rounded tokens
+// that are close cancel catastrophically (measured: 0.4 % token error -> 40 % decoder-output error).
 //
 //  * semantic tokenizer  (reference models/networks.py:312-319): 1x1 conv 32->L, softmax over the
 //    HW pixels, attention-weighted pooling -> L tokens of width 32 per image; + learned pos
@@ -92,7 +94,7 @@ __global__ void tok_pool_partial_kernel(const T* __restrict__ x, const float* __
 template <typename T, int L>
 __global__ void tok_finish_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
                                   const float* __restrict__ pos /*[2L][32] or null*/, int chunks, int B,
-                                  float* __restrict__ pooled, T* __restrict__ tok_cat) {
+                                  float* __restrict__ pooled, float* __restrict__ tok_cat) {
     const int s = blockIdx.x, tid = threadIdx.x;
     const int l = tid / D, c = tid % D;
     float acc = 0.f;
@@ -101,20 +103,20 @@ __global__ void tok_finish_kernel(const float* __restrict__ partial, const float
     pooled[((size_t)s * L + l) * D + c] = acc;
     const int b = s % B, stream = s / B;
     const int j = stream * L + l;
-    stf(tok_cat + ((size_t)b * 2 * L + j) * D + c, acc + (pos ? pos[j * D + c] : 0.f));
+    tok_cat[((size_t)b * 2 * L + j) * D + c] = acc + (pos ? pos[j * D + c] : 0.f);   // tokens stay fp32 (see header)
 }
 
 // per pixel: dlogit and the tokenizer's contribution to dx (accumulated into dx in place)
 template <typename T, int L>
 __global__ void tok_bwd_kernel(const T* __restrict__ x, const float* __restrict__ logits,
                                const float* __restrict__ stats, const float* __restrict__ pooled,
-                               const T* __restrict__ dtok_cat, const float* __restrict__ wa, int HW, int B,
+                               const float* __restrict__ dtok_cat, const float* __restrict__ wa, int HW, int B,
                                T* __restrict__ dx, float* __restrict__ dlogits) {
     __shared__ float sdt[L * D], sw[L * D], sdot[L], smx[L], siv[L];
     const int s = blockIdx.y;
     const int b = s % B, stream = s / B;
     for (int i = threadIdx.x; i < L * D; i += blockDim.x) {
-        sdt[i] = ldf(dtok_cat + ((size_t)b * 2 * L + stream * L) * D + i);
+        sdt[i] = dtok_cat[((size_t)b * 2 * L + stream * L) * D + i];
         sw[i] = wa[i];
     }
     __syncthreads();
@@ -176,12 +178,11 @@ __global__ void tok_dwa_kernel(const T* __restrict__ x, const float* __restrict_
 }
 
 // dpos[j][c] (+)= sum_b dtok_cat[b][j][c]
-template <typename T>
-__global__ void tok_dpos_kernel(const T* __restrict__ dtok_cat, int B, int n, float* __restrict__ dpos, int accumulate) {
+__global__ void tok_dpos_kernel(const float* __restrict__ dtok_cat, int B, int n, float* __restrict__ dpos, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += ldf(dtok_cat + (size_t)b * n + i);
+    for (int b = 0; b < B; ++b) s += dtok_cat[(size_t)b * n + i];
     if (accumulate) dpos[i] += s; else dpos[i] = s;
 }
 
@@ -191,7 +192,7 @@ __global__ void tok_dpos_kernel(const T* __restrict__ dtok_cat, int B, int n, fl
 // Weight access is coalesced everywhere: thread index runs along the contiguous dimension of whichever form
 // (fp32 master [out][in], or the packed transpose in T produced by dh_pack_weight) makes that possible.
 struct PrepArgs {
-    const void* tok;        // token rows, T
+    const void* tok;        // token rows, fp32
     long tok_bstride, tok_sstride;   // elements between batch items / streams
     int B, S, L, heads, dh, HLP;
     float scale, eps;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(1024) void xattn_prep_kernel(PrepArgs a) {
     float* smn = sm;                    // [L][32]
     float* sk = smn + L * D;            // [L][inner]
     float* sv = sk + L * inner;         // [L][inner]
-    const T* m = reinterpret_cast<const T*>(a.tok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
+    const float* m = reinterpret_cast<const float*>(a.tok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
     // LayerNorm of the L token rows (shared LN of PreNorm2, help_funcs.py:48-49): 32 lanes per row
     {
         const int l = tid >> 5, c = tid & 31;
@@ -279,8 +280,8 @@ struct PrepBwdArgs {
     long tok_bstride, tok_sstride;
     int B, S, L, heads, dh, HLP;
     float scale;
-    const void* tok;                 // T, forward token rows (for the LN backward)
-    void* dtok;                      // T, accumulated in place (same addressing as tok)
+    const void* tok;                 // fp32, forward token rows (for the LN backward)
+    void* dtok;                      // fp32, accumulated in place (same addressing as tok)
     const float *ln_g, *wk, *wv, *wo;   // fp32 masters: wk, wv [inner][32]; wo [32][inner]
     const void* wqT;                 // T [32][inner]
     const float *mn, *mstats;
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(1024) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
     }
     __syncthreads();
     // LayerNorm backward on the L rows (32 lanes per row); accumulate into dtok; per-image dgamma/dbeta
-    const T* m = reinterpret_cast<const T*>(a.tok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
-    T* dm = reinterpret_cast<T*>(a.dtok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
+    const float* m = reinterpret_cast<const float*>(a.tok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
+    float* dm = reinterpret_cast<float*>(a.dtok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride;
     {
         const int l = tid >> 5, c = tid & 31;
         float pg = 0.f, pb = 0.f;
@@ -564,7 +565,7 @@ extern "C" int dh_reduce_partials(const float* partial, long nt, long n, float s
 static inline int tok_chunks(int HW) { int c = HW / 256; return c < 1 ? 1 : (c > 64 ? 64 : c); }
 extern "C" long dh_tokenizer_fwd_workspace_size(int S, int HW, int L) { return (long)S * tok_chunks(HW) * L * 32 * 4; }
 extern "C" int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const float* pos, int S, int B, int HW,
-                                int L, float* logits, float* stats, float* pooled, void* tok_cat, void* workspace,
+                                int L, float* logits, float* stats, float* pooled, float* tok_cat, void* workspace,
                                 void* stream) {
     DH_REQUIRE(L == 4 || L == 8, "tokenizer: token_len must be 4 or 8, got %d", L);
     DH_REQUIRE(S % B == 0 && S / B <= 2, "tokenizer: S=%d must be B or 2B (B=%d)", S, B);
@@ -579,7 +580,7 @@ extern "C" int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const
         hipLaunchKernelGGL((tok_pool_partial_kernel<TT, LL>), dim3(nch, S), dim3(LL * 32), 0, ST(stream),         \
                            (const TT*)x, logits, stats, HW, chunk, part);                                         \
         hipLaunchKernelGGL((tok_finish_kernel<TT, LL>), dim3(S), dim3(LL * 32), 0, ST(stream), part, stats, pos,  \
-                           nch, B, pooled, (TT*)tok_cat);                                                         \
+                           nch, B, pooled, tok_cat);                                                         \
     } while (0)
     if (dtype == DH_DTYPE_BF16) { if (L == 4) TOKF(bf16, 4); else TOKF(bf16, 8); }
     else { if (L == 4) TOKF(float, 4); else TOKF(float, 8); }
@@ -594,7 +595,7 @@ extern "C" long dh_tokenizer_bwd_workspace_size(int S, int HW, int L) {
     return (P * L + (long)dh_cdiv(P, 256) * L * 32) * 4;
 }
 extern "C" int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S, int B, int HW, int L,
-                                const float* logits, const float* stats, const float* pooled, const void* dtok_cat,
+                                const float* logits, const float* stats, const float* pooled, const float* dtok_cat,
                                 void* dx_accum, float* dwa, float* dpos, int accumulate, void* workspace,
                                 void* stream) {
     DH_REQUIRE(L == 4 || L == 8, "tokenizer_bwd: token_len must be 4 or 8, got %d", L);
@@ -605,13 +606,13 @@ extern "C" int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S
 #define TOKB(TT, LL)                                                                                              \
     do {                                                                                                          \
         hipLaunchKernelGGL((tok_bwd_kernel<TT, LL>), dim3(dh_cdiv(HW, 128), S), dim3(128), 0, ST(stream),         \
-                           (const TT*)x, logits, stats, pooled, (const TT*)dtok_cat, wa, HW, B, (TT*)dx_accum,    \
+                           (const TT*)x, logits, stats, pooled, dtok_cat, wa, HW, B, (TT*)dx_accum,              \
                            dlogits);                                                                              \
         hipLaunchKernelGGL((tok_dwa_kernel<TT, LL>), dim3(nblk), dim3(256), 0, ST(stream), (const TT*)x, dlogits, \
                            P, 256L, partial);                                                                    \
         if (dpos)                                                                                                 \
-            hipLaunchKernelGGL(tok_dpos_kernel<TT>, dim3(dh_cdiv(2 * LL * 32, 64)), dim3(64), 0, ST(stream),      \
-                               (const TT*)dtok_cat, B, 2 * LL * 32, dpos, accumulate);                            \
+            hipLaunchKernelGGL(tok_dpos_kernel, dim3(dh_cdiv(2 * LL * 32, 64)), dim3(64), 0, ST(stream),          \
+                               dtok_cat, B, 2 * LL * 32, dpos, accumulate);                                       \
     } while (0)
     if (dtype == DH_DTYPE_BF16) { if (L == 4) TOKB(bf16, 4); else TOKB(bf16, 8); }
     else { if (L == 4) TOKB(float, 4); else TOKB(float, 8); }

@@ -67,6 +67,14 @@ class Engine:
                 self.pk[key] = Packed(None, ops.pack_weight(self.p[key], self.dtype, want_dgrad=True)[1])
                 continue
             O = shape[0]
+            if key.startswith("transformer") and not key.startswith("transformer_decoder"):
+                # the token encoder (<= 16 rows per image) runs in fp32 in every mode: its output feeds
+                # |token2 - token1|, which bf16 rounding would wipe out (csrc/tokens.hip header)
+                ck32 = ops.chunk_channels(torch.float32)
+                f, d = ops.pack_weight(self.p[key], torch.float32, want_dgrad=self.need_grad,
+                                       dgrad_inner=-(-O // ck32) * ck32)
+                self.pk[key] = Packed(f, d)
+                continue
             inner = -(-O // ck) * ck
             f, d = ops.pack_weight(self.p[key], self.dtype, want_dgrad=self.need_grad, dgrad_inner=inner)
             self.pk[key] = Packed(f, d)
@@ -392,7 +400,7 @@ class Engine:
         if self.cfg["kind"] == "bit":
             logits, bwd = self._bit(x1, x2)
         else:
-            logits, bwd = self._unet(x1, x2)
+            logits, bwd = self._unet(x1, x2)        # "unet" and "xbd" share the trunk / up path; levels differ
         self._bwd = bwd
         return logits
 
@@ -492,7 +500,7 @@ class Engine:
         ops.copy_channels(dec4[:B], 0, cat, 0, DIM)
         ops.copy_channels(dec4[B:], 0, cat, DIM, DIM)
         tk3 = tok2d.view(B, 2, L * DIM)                      # [b][stream][L*32]
-        dtk = torch.empty(B, L, DIM, dtype=self.dtype, device=sq.device)
+        dtk = torch.empty(B, L, DIM, dtype=torch.float32, device=sq.device)
         ops.absdiff_halves(tk3, dtk)
         ddtk = torch.zeros_like(dtk) if self.need_grad else None
         dxc, b_cd = self.conv_act(cat, "conv_decode_%d.weight" % l, None, 3, 1, NONE)
@@ -520,6 +528,53 @@ class Engine:
             return b_sq(dxin)
         return out4, bwd
 
+    def _xbd_level(self, l, xa_b, B):
+        """_forward_trans_module of the xBD copy (xBD_code/zoo/model_transformer_encoding.py:385-406): squeeze, tokens,
+        encoder, then ONE decoder pass on conv_decode(cat[x1, x2]) against |token2 - token1|.  Positional terms exist
+        only in the level-5 call, which receives the *_3 embeddings (layer index 3, lines 358-383)."""
+        lv, L = UNET_LEVELS[l], self.cfg["token_len"]
+        sq, b_sq = self.conv_act(xa_b, "conv_squeeze_%d.0.weight" % l, None, 1, 0, RELU)
+        _, fh, fw, _ = sq.shape
+        hw = fh * fw
+        wa = self.p["conv_token_%d.weight" % l]
+        with_pos = l == 5
+        pos_tok = self.p["pos_embedding_3"] if with_pos else torch.zeros(1, 2 * L, DIM, device=sq.device)
+        tok_cat, tsaved = ops.tokenizer_fwd(sq, wa, pos_tok, B, L)
+        tok2d, b_enc = self.encoder(tok_cat.view(B * 2 * L, DIM), "transformer_%d" % l, self.cfg["enc_depth"],
+                                    lv["heads"], lv["dim_head"], B, 2 * L)
+        tk3 = tok2d.view(B, 2, L * DIM)
+        dtk = torch.empty(B, L, DIM, dtype=torch.float32, device=sq.device)
+        ops.absdiff_halves(tk3, dtk)
+        ddtk = torch.zeros_like(dtk) if self.need_grad else None
+        cat = torch.empty(B, fh, fw, 2 * DIM, dtype=self.dtype, device=sq.device)
+        ops.copy_channels(sq[:B], 0, cat, 0, DIM)
+        ops.copy_channels(sq[B:], 0, cat, DIM, DIM)
+        dxc, b_cd = self.conv_act(cat, "conv_decode_%d.weight" % l, None, 3, 1, NONE)
+        pos = self.p["pos_embedding_decoder_3"] if (with_pos and self.cfg["decoder_pos"]) else None
+        xin = ops.add_pos(dxc, pos) if pos is not None else dxc
+        out, b_dec = self.decoder(xin.view(B * hw, DIM), B, dtk.view(B * L, DIM), L * DIM, 0, B, ddtk,
+                                  "transformer_decoder_%d" % l, lv["dec_depth"], lv["heads"], lv["dim_head"], L)
+        out4 = out.view(B, fh, fw, DIM)
+        if not self.need_grad:
+            return out4, None
+
+        def bwd(dout4):
+            dxin = b_dec(dout4.reshape(B * hw, DIM)).view(B, fh, fw, DIM)
+            if pos is not None:
+                ops.add_pos_bwd(dxin, self.g["pos_embedding_decoder_3"], accumulate=True)
+            dcat = b_cd(dxin)
+            dtok = torch.zeros_like(tok2d)
+            ops.absdiff_halves_bwd(tk3, ddtk, dtok)
+            dtok_cat = b_enc(dtok)
+            dsq = torch.empty_like(sq)
+            ops.copy_channels(dcat, 0, dsq[:B], 0, DIM)
+            ops.copy_channels(dcat, DIM, dsq[B:], 0, DIM)
+            gpos = self.g["pos_embedding_3"] if with_pos else torch.zeros(1, 2 * L, DIM, device=sq.device)
+            ops.tokenizer_bwd(sq, wa, tsaved, dtok_cat, dsq, self.g["conv_token_%d.weight" % l], gpos, B, L,
+                              accumulate=True)
+            return b_sq(dsq)
+        return out4, bwd
+
     def _up_conv(self, l, x):
         up = ops.upsample2(x)
         out, b = self.conv_act(up, "conv_layer%d.0.weight" % l, "conv_layer%d.0.bias" % l, 3, 1, RELU)
@@ -535,11 +590,12 @@ class Engine:
         s8, b_l2 = self.res_layer(s4, 2, 2, 2)                 # 32x32x128
         p16, arg16 = ops.maxpool(s8, want_arg=True)
         s16, b_l3 = self.res_layer(p16, 3, 1, 2)               # 16x16x256
-        o5, b5 = self._level(5, s16, B)
+        level = self._xbd_level if self.cfg["kind"] == "xbd" else self._level
+        o5, b5 = level(5, s16, B)
         o5u = ops.upsample2(o5)
-        t4, b4 = self._level(4, s8, B)
+        t4, b4 = level(4, s8, B)
         o4, bu4 = self._up_conv(4, ops.add(t4, o5u))
-        t3, b3 = self._level(3, s4, B)
+        t3, b3 = level(3, s4, B)
         o3, bu3 = self._up_conv(3, ops.add(t3, o4))
         _, h2, w2, c2 = s2.shape
         cat2 = torch.empty(B, h2, w2, 2 * c2, dtype=self.dtype, device=s2.device)

@@ -23,7 +23,7 @@ from torch.optim import lr_scheduler
 
 from .. import _lib
 from ..engine import Engine
-from ..netspec import get_config, is_active, is_buffer, state_spec
+from ..netspec import get_config, is_active, is_alias, is_buffer, state_spec
 
 _DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
 
@@ -89,7 +89,11 @@ class CDNet(nn.Module):
                 if part not in node._modules:
                     node.add_module(part, _Node())
                 node = node._modules[part]
-            if role == "bn_nbt":
+            if is_alias(role):
+                # the reference registers the same sub-module twice (nn.ModuleList holders of the xBD model):
+                # one Parameter object under two names -- state_dict() lists both, parameters() once
+                node.register_parameter(parts[-1], self.get_parameter(role[6:]))
+            elif role == "bn_nbt":
                 node.register_buffer(parts[-1], torch.tensor(0, dtype=torch.long))
             elif is_buffer(role):
                 node.register_buffer(parts[-1], torch.zeros(shape) if role == "bn_rm" else torch.ones(shape))
@@ -122,8 +126,9 @@ class CDNet(nn.Module):
         if ar.flat is not None and ar.flat.device == device and all(
                 sd_p[k].data_ptr() == ar.flat.data_ptr() + 4 * off for k, (off, _) in ar.offsets.items()):
             return      # every parameter is still the arena view handed out earlier
-        active = [k for k, _, r in self._spec if not is_buffer(r) and is_active(self.net_G, k)]
-        inactive = [k for k, _, r in self._spec if not is_buffer(r) and not is_active(self.net_G, k)]
+        own = [k for k, _, r in self._spec if not is_buffer(r) and not is_alias(r)]
+        active = [k for k in own if is_active(self.net_G, k)]
+        inactive = [k for k in own if not is_active(self.net_G, k)]
         total = sum(sd_p[k].numel() for k in active + inactive)
         flat = torch.empty(total, dtype=torch.float32, device=device)
         off = 0
@@ -159,7 +164,18 @@ class CDNet(nn.Module):
         return self._arena.flat[:self._arena.n_active], self._arena.grad
 
     # ---- forward / backward -------------------------------------------------------------------------
-    def forward(self, x1, x2):
+    def forward(self, x1, x2=None):
+        if self.cfg["kind"] == "xbd":
+            # ONE 6-channel tensor, split in the forward (xBD_code/zoo/model_transformer_encoding.py:409-412)
+            if x2 is not None or x1.dim() != 4 or x1.shape[1] != 6:
+                raise ValueError("the xBD model takes one [B, 6, H, W] tensor (pre | post image)")
+            if self.cfg["decoder_pos"] and tuple(x1.shape[2:]) != (1024, 1024):
+                raise RuntimeError("pos_embedding_decoder_3 [1,32,64,64] is added to the 1/16-scale map "
+                                   "(model_transformer_encoding.py:372-383): input must be 1024x1024, got %dx%d"
+                                   % tuple(x1.shape[2:]))
+            x1, x2 = x1[:, :3], x1[:, 3:]
+        elif x2 is None:
+            raise TypeError("forward() missing the second image")
         if not x1.is_cuda:
             raise _lib.HipLibraryError("dahitra_amd runs on MI355X only: inputs must be CUDA(HIP) tensors; "
                                        "there is no CPU fallback")

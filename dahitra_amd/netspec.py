@@ -25,6 +25,14 @@ NET_CONFIGS = {
     # BASE_Transformer(..., backbone='resnet50') (networks.py:192-195); define_G below refuses it too.
     "base_transformer_pos_s4_resnet50": dict(kind="bit", n_class=2, token_len=4, enc_depth=1, dec_depth=1,
                                              dec_dim_head=64, backbone="resnet50", ctor_only=True),
+    # xBD copy of the hierarchical model (xBD_code/zoo/model_transformer_encoding.py:242-449, built at
+    # xBD_code/train.py:44-45).  One 6-channel input, 5 output channels, difference-only decoder pass, ModuleList
+    # alias keys, `layer == 5/4/3` positional quirk.  The first is train.py's model (1024x1024 input only), the
+    # second the same constructor with with_decoder_pos=None (any multiple of 64).  Constructor access only:
+    # dahitra_amd.models.xbd.BASE_Transformer_UNet.
+    "xbd_unet_transformer": dict(kind="xbd", n_class=5, token_len=4, enc_depth=1, decoder_pos=True, ctor_only=True),
+    "xbd_unet_transformer_nodecpos": dict(kind="xbd", n_class=5, token_len=4, enc_depth=1, decoder_pos=False,
+                                          ctor_only=True),
 }
 RESNET50_BLOCKS = (3, 4, 6, 3)
 BIT_HEADS, BIT_DIM_HEAD = 8, 64
@@ -110,6 +118,8 @@ def state_spec(net_G):
         s += _xformer("transformer", cfg["enc_depth"], BIT_HEADS, BIT_DIM_HEAD, 2 * DIM, False)
         s += _xformer("transformer_decoder", cfg["dec_depth"], BIT_HEADS, cfg["dec_dim_head"], 2 * DIM, True)
         return s
+    if cfg["kind"] == "xbd":
+        return _xbd(cfg)
     s = [("pos_embedding_%d" % l, (1, 2 * L, DIM), "pos") for l in (5, 4, 3, 2)]
     s += [("pos_embedding_decoder_%d" % l, (1, DIM, UNET_LEVELS[l]["size"], UNET_LEVELS[l]["size"]), "pos")
           for l in (5, 4, 3, 2)]
@@ -129,6 +139,58 @@ def state_spec(net_G):
     return s + [("classifier.weight", (cfg["n_class"], 32, 3, 3), "conv_w"), ("classifier.bias", (cfg["n_class"],), "bias")]
 
 
+def _xbd(cfg):
+    """State dict of the xBD model.  Its nn.ModuleList holders (model_transformer_encoding.py:285-334) list the
+    per-level modules in the order 2,3,4,5, so every such tensor appears twice: under its own name and as
+    `<holder>.<index>...`; the second occurrence has role "alias:<own name>" and shares storage."""
+    L = cfg["token_len"]
+    order, held = (5, 4, 3, 2), (2, 3, 4, 5)
+    s = [("pos_embedding_%d" % l, (1, 2 * L, DIM), "pos") for l in (5, 4, 3)]
+    if cfg["decoder_pos"]:
+        s += [("pos_embedding_decoder_%d" % l, (1, DIM, UNET_LEVELS[l]["size"], UNET_LEVELS[l]["size"]), "pos")
+              for l in (5, 4, 3)]
+    s += _resnet18() + [("conv_pred.weight", (32, 384, 3, 3), "conv_w"), ("conv_pred.bias", (32,), "bias")]
+
+    def aliases(holder, own_prefix, entries_of):
+        out = []
+        for i, l in enumerate(held):
+            pre = own_prefix % l
+            out += [(holder + ".%d" % i + k[len(pre):], shp, "alias:" + k) for k, shp, _ in entries_of(l)]
+        return out
+
+    for own, holder, entries_of in (
+            ("conv_squeeze_%d", "conv_squeeze_layers",
+             lambda l: [("conv_squeeze_%d.0.weight" % l, (DIM, UNET_LEVELS[l]["cin"], 1, 1), "conv_w")]),
+            ("conv_token_%d", "conv_tokens_layers", lambda l: [("conv_token_%d.weight" % l, (L, DIM, 1, 1), "conv_w")]),
+            ("conv_decode_%d", "conv_decode_layers",
+             lambda l: [("conv_decode_%d.weight" % l, (DIM, 2 * DIM, 3, 3), "conv_w")])):
+        for l in order:
+            s += entries_of(l)
+        s += aliases(holder, own, entries_of)
+
+    def enc(l):
+        lv = UNET_LEVELS[l]
+        return _xformer("transformer_%d" % l, cfg["enc_depth"], lv["heads"], lv["dim_head"], DIM, False)
+
+    def dec(l):
+        lv = UNET_LEVELS[l]
+        return _xformer("transformer_decoder_%d" % l, lv["dec_depth"], lv["heads"], lv["dim_head"], DIM, True)
+
+    for l in order:
+        s += enc(l) + dec(l)
+    s += aliases("transformer_layers", "transformer_%d", enc)
+    s += aliases("transformer_decoder_layers", "transformer_decoder_%d", dec)
+    s += [("conv_layer2_0.0.weight", (128, 128, 3, 3), "conv_w")] + _bn("conv_layer2_0.1", 128)
+    s += [("conv_layer2_0.3.weight", (32, 128, 3, 3), "conv_w"), ("conv_layer2_0.3.bias", (32,), "bias")]
+    for l in (2, 3, 4):
+        s += [("conv_layer%d.0.weight" % l, (32, 32, 3, 3), "conv_w"), ("conv_layer%d.0.bias" % l, (32,), "bias")]
+    return s + [("classifier.weight", (cfg["n_class"], 32, 3, 3), "conv_w"), ("classifier.bias", (cfg["n_class"],), "bias")]
+
+
+def is_alias(role):
+    return role.startswith("alias:")
+
+
 def is_buffer(role):
     return role in ("bn_rm", "bn_rv", "bn_nbt")
 
@@ -141,6 +203,11 @@ def unused_prefixes(net_G):
     if cfg["kind"] == "unet":
         pre += ["conv_pred.", "conv_squeeze_2.", "conv_token_2.", "conv_decode_2.", "pos_embedding_2",
                 "pos_embedding_decoder_2", "transformer_2.", "transformer_decoder_2."]
+    if cfg["kind"] == "xbd":
+        # only the level-5 call adds positional embeddings, and it picks the *_3 ones (layer index 3)
+        pre += ["conv_pred.", "conv_squeeze_2.", "conv_token_2.", "conv_decode_2.", "transformer_2.",
+                "transformer_decoder_2.", "pos_embedding_5", "pos_embedding_4", "pos_embedding_decoder_5",
+                "pos_embedding_decoder_4"]
     return pre
 
 

@@ -390,14 +390,15 @@ def cast_to_f32(src, dst=None, accumulate=False):
 
 # ---- token side ----------------------------------------------------------------------------------
 def tokenizer_fwd(x, wa, pos, B, L):
-    """x [S, H, W, 32]; returns (tok_cat [B, 2L, 32] T written for the S/B streams present, saved)"""
+    """x [S, H, W, 32]; returns (tok_cat [B, 2L, 32] fp32 written for the S/B streams present, saved).  Tokens are
+    fp32 in every compute mode (csrc/tokens.hip header)."""
     Sn, H, W, C = x.shape
     HW = H * W
     dev = x.device
     logits = torch.empty(Sn * HW, L, dtype=torch.float32, device=dev)
     stats = torch.empty(Sn, L, 2, dtype=torch.float32, device=dev)
     pooled = torch.empty(Sn, L, 32, dtype=torch.float32, device=dev)
-    tok = torch.empty(B, 2 * L, 32, dtype=x.dtype, device=dev)
+    tok = torch.empty(B, 2 * L, 32, dtype=torch.float32, device=dev)
     ws = workspace(_lib.lib().dh_tokenizer_fwd_workspace_size(Sn, HW, L), dev)
     _call("dh_tokenizer_fwd", _ci(dt(x)), P(x), P(wa), P(pos), _ci(Sn), _ci(B), _ci(HW), _ci(L), P(logits), P(stats),
           P(pooled), P(tok), P(ws), S())
@@ -410,6 +411,7 @@ def tokenizer_bwd(x, wa, saved, dtok_cat, dx_accum, dwa, dpos, B, L, accumulate=
     logits, stats, pooled = saved
     Lb = _lib.lib()
     ws = workspace(Lb.dh_tokenizer_bwd_workspace_size(Sn, HW, L), x.device)
+    assert dtok_cat.dtype == torch.float32
     _call("dh_tokenizer_bwd", _ci(dt(x)), P(x), P(wa), _ci(Sn), _ci(B), _ci(HW), _ci(L), P(logits), P(stats), P(pooled),
           P(dtok_cat), P(dx_accum), P(dwa), P(dpos), _ci(int(accumulate)), P(ws), S())
 
@@ -420,6 +422,7 @@ class XattnPrep:
     def __init__(self, tok, bstride, sstride, B, Sn, L, heads, dim_head, ln_g, ln_b, wq, wkT, wvT, woT, dtype,
                  scale=32 ** -0.5, eps=1e-5):
         dev = tok.device
+        assert tok.dtype == torch.float32, "tokens are fp32 in every compute mode"
         inner = heads * dim_head
         self.HLP = cdiv(heads * L, 32) * 32
         self.args = (bstride, sstride, B, Sn, L, heads, dim_head)
@@ -534,6 +537,39 @@ def argmax_nchw(logits_nchw):
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     _call("dh_adamw_step", P(param), P(grad), P(exp_avg), P(exp_avg_sq), _cl(param.numel()), _cf(lr), _cf(beta1),
           _cf(beta2), _cf(eps), _cf(weight_decay), _ci(step), _cf(grad_scale), S())
+
+
+# ---- xBD train step (csrc/xbd_step.hip) ---------------------------------------------------------------
+def combo_loss_fwd(logits, masks, weights_dev, dice_weight=1.0, focal_weight=8.0):
+    """per-channel ComboLoss{dice, focal} (xBD_code/losses.py:95-126).  Returns (loss [], channel_loss [C], sums [C,4])"""
+    B, C, H, W = logits.shape
+    dev = logits.device
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    ch = torch.empty(C, dtype=torch.float32, device=dev)
+    sums = torch.empty(C, 4, dtype=torch.float32, device=dev)
+    ws = workspace(_lib.lib().dh_combo_loss_workspace_size(C), dev)
+    _call("dh_combo_loss_fwd", P(logits), P(masks), _ci(B), _ci(C), _cl(H * W), P(weights_dev), _cf(dice_weight),
+          _cf(focal_weight), P(sums), P(ch), P(loss), P(ws), S())
+    return loss, ch, sums
+
+
+def combo_loss_bwd(logits, masks, sums, weights_dev, upstream, dice_weight=1.0, focal_weight=8.0):
+    B, C, H, W = logits.shape
+    dl = torch.empty_like(logits)
+    _call("dh_combo_loss_bwd", P(logits), P(masks), P(sums), P(weights_dev), P(upstream), _cf(dice_weight),
+          _cf(focal_weight), _ci(B), _ci(C), _cl(H * W), P(dl), S())
+    return dl
+
+
+def grad_norm_clip_coef(grad_flat, max_norm, out):
+    """out [2] fp32 (device): total L2 norm of the flat gradient arena, clip_grad_norm_ coefficient"""
+    ws = workspace(_lib.lib().dh_grad_norm_workspace_size(), grad_flat.device)
+    _call("dh_grad_norm_clip_coef", P(grad_flat), _cl(grad_flat.numel()), _cf(max_norm), P(out), P(ws), S())
+
+
+def adamw_xbd_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale_dev=None):
+    _call("dh_adamw_xbd_step", P(param), P(grad), P(exp_avg), P(exp_avg_sq), _cl(param.numel()), _cf(lr), _cf(beta1),
+          _cf(beta2), _cf(eps), _cf(weight_decay), _ci(step), P(grad_scale_dev), S())
 
 
 # ---- variants writing into caller-provided (contiguous) buffers ------------------------------------

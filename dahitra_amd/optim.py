@@ -14,6 +14,8 @@ from . import _lib, ops
 
 
 class AdamW(torch.optim.Optimizer):
+    _rule = "torch"      # "xbd": the hand-rolled rule of xBD_code/adamw.py (subclass in models/xbd.py)
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
@@ -83,8 +85,7 @@ class AdamW(torch.optim.Optimizer):
                               ctypes.c_long(param.numel()), ops.P(st[3]), ops.P(st[2]), ops.S())
                 else:
                     st[2] += 1
-                    ops.adamw_step(param, grad, st[0], st[1], group["lr"], beta1, beta2, group["eps"],
-                                   group["weight_decay"], st[2], grad_scale)
+                    self._launch(param, grad, st[0], st[1], group, st[2], grad_scale)
             for p in loose:
                 if not p.is_cuda:
                     raise _lib.HipLibraryError("dahitra_amd.AdamW: parameters must live on the GPU (no CPU fallback)")
@@ -94,6 +95,15 @@ class AdamW(torch.optim.Optimizer):
                     s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     s["_n"] = 0
                 s["_n"] += 1
-                ops.adamw_step(p.data, p.grad.contiguous(), s["exp_avg"], s["exp_avg_sq"], group["lr"], beta1, beta2,
-                               group["eps"], group["weight_decay"], s["_n"], grad_scale)
+                self._launch(p.data, p.grad.contiguous(), s["exp_avg"], s["exp_avg_sq"], group, s["_n"], grad_scale)
         return loss
+
+    def _launch(self, param, grad, m, v, group, step, grad_scale):
+        beta1, beta2 = group["betas"]
+        if self._rule == "xbd":
+            if grad_scale != 1.0:
+                raise ValueError("the xBD AdamW takes no host-side grad_scale (clip with clip_grad_norm_)")
+            ops.adamw_xbd_step(param, grad, m, v, group["lr"], beta1, beta2, group["eps"], group["weight_decay"], step)
+        else:
+            ops.adamw_step(param, grad, m, v, group["lr"], beta1, beta2, group["eps"], group["weight_decay"], step,
+                           grad_scale)

@@ -118,10 +118,10 @@ int dh_cast_to_f32(int dtype, const void* src, float* dst, long n, int accumulat
  * xattn_prep: wq / wk / wv / wo are the fp32 masters ([inner][32] resp. [32][inner]); wkT, wvT, wqT ([32][inner])
  * and woT ([inner][32]) are their transposes in T as produced by dh_pack_weight's data-gradient form. */
 int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const float* pos, int S, int B, int HW, int L,
-                     float* logits, float* stats, float* pooled, void* tok_cat, void* workspace, void* stream);
+                     float* logits, float* stats, float* pooled, float* tok_cat, void* workspace, void* stream);
 long dh_tokenizer_fwd_workspace_size(int S, int HW, int L);
 int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S, int B, int HW, int L, const float* logits,
-                     const float* stats, const float* pooled, const void* dtok_cat, void* dx_accum, float* dwa,
+                     const float* stats, const float* pooled, const float* dtok_cat, void* dx_accum, float* dwa,
                      float* dpos, int accumulate, void* workspace, void* stream);
 long dh_tokenizer_bwd_workspace_size(int S, int HW, int L);
 int dh_xattn_prep_fwd(int dtype, const void* tok, long tok_bstride, long tok_sstride, int B, int S, int L, int heads,
@@ -172,6 +172,27 @@ int dh_absdiff_halves(int dtype, const void* tok, void* out, int B, long n, void
 int dh_absdiff_halves_bwd(int dtype, const void* tok, const void* dout, void* dtok_accum, int B, long n, void* stream);
 int dh_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+
+/* ---- xBD train step (csrc/xbd_step.hip) -------------------------------------------
+ * ComboLoss{dice, focal} per output channel on sigmoid(logits) (xBD_code/losses.py:24-34, 95-126, 273-288) with the
+ * per-channel weights of xBD_code/train.py:348-353.  logits / masks are [B][C][HW] fp32.  fwd writes the channel
+ * totals sums_out [C][4] = {sum s*t, sum s, sum t, sum focal} (needed by bwd), channel_loss_out [C] and loss_out [1]. */
+long dh_combo_loss_workspace_size(int C);
+int dh_combo_loss_fwd(const float* logits, const float* masks, int B, int C, long HW, const float* weights_dev,
+                      float dice_weight, float focal_weight, float* sums_out, float* channel_loss_out, float* loss_out,
+                      void* workspace, void* stream);
+int dh_combo_loss_bwd(const float* logits, const float* masks, const float* sums, const float* weights_dev,
+                      const float* upstream_dev, float dice_weight, float focal_weight, int B, int C, long HW,
+                      float* dlogits, void* stream);
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) over the flat gradient arena (xBD_code/train.py:373):
+ * out_dev[0] = total L2 norm, out_dev[1] = min(1, max_norm / (norm + 1e-6)); the optimizer reads out_dev + 1 */
+long dh_grad_norm_workspace_size(void);
+int dh_grad_norm_clip_coef(const float* grad, long n, float max_norm, float* out_dev, void* workspace, void* stream);
+/* xBD_code/adamw.py:37-86: like dh_adamw_step but denom = sqrt(v) + eps (eps before the bias correction) and the
+ * gradient scale is read from device memory (NULL = 1) */
+int dh_adamw_xbd_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int step, const float* grad_scale_dev, void* stream);
 
 #ifdef __cplusplus
 }

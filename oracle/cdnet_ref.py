@@ -47,6 +47,13 @@ NET_CONFIGS = {
     # keyed here so that the same spec/forward/train helpers serve it.
     "base_transformer_pos_s4_resnet50": dict(kind="bit", n_class=2, token_len=4, enc_depth=1, dec_depth=1,
                                              dec_dim_head=64, backbone="resnet50"),
+    # xBD copy of the hierarchical model (xBD_code/zoo/model_transformer_encoding.py:242-449, built at
+    # xBD_code/train.py:44-45): ONE 6-channel input, 5 output channels, diff-only decoder pass, ModuleList
+    # aliases in the state dict, and the `layer == 5/4/3` positional-embedding quirk.
+    # "xbd_unet_transformer" is train.py's model (with_decoder_pos='learned' => 1024x1024 input only);
+    # "_nodecpos" is the same constructor with with_decoder_pos=None, which runs at any multiple of 64.
+    "xbd_unet_transformer": dict(kind="xbd", n_class=5, token_len=4, enc_depth=1, decoder_pos=True),
+    "xbd_unet_transformer_nodecpos": dict(kind="xbd", n_class=5, token_len=4, enc_depth=1, decoder_pos=False),
 }
 DIM = 32           # transformer width everywhere (networks.py:289, 1178)
 ENC_HEADS = 8      # BiT encoder/decoder heads (networks.py:305-310)
@@ -177,6 +184,8 @@ def state_spec(net_G):
         s += _decoder_spec("transformer_decoder", cfg["dec_depth"], ENC_HEADS,
                            cfg["dec_dim_head"], 2 * DIM)
         return s
+    if cfg["kind"] == "xbd":
+        return _xbd_spec(cfg)
     # hierarchical model (networks.py:1146-1249)
     s = [("pos_embedding_%d" % l, (1, 2 * L, DIM), "pos") for l in (5, 4, 3, 2)]
     s += [("pos_embedding_decoder_5", (1, DIM, 16, 16), "pos"),
@@ -204,6 +213,59 @@ def state_spec(net_G):
     s += [("classifier.weight", (cfg["n_class"], 32, 3, 3), "conv_w"),
           ("classifier.bias", (cfg["n_class"],), "bias")]
     return s
+
+
+def _xbd_spec(cfg):
+    """xBD_code/zoo/model_transformer_encoding.py:255-340.  The nn.ModuleList holders (285-334) register every
+    level's modules a second time, so state_dict() carries alias keys; role "alias:<primary key>"."""
+    L = cfg["token_len"]
+    s = [("pos_embedding_%d" % l, (1, 2 * L, DIM), "pos") for l in (5, 4, 3)]
+    if cfg["decoder_pos"]:
+        s += [("pos_embedding_decoder_%d" % l, (1, DIM, UNET_LEVELS[l]["size"], UNET_LEVELS[l]["size"]), "pos")
+              for l in (5, 4, 3)]
+    s += _resnet18_spec()
+    s += [("conv_pred.weight", (32, 384, 3, 3), "conv_w"), ("conv_pred.bias", (32,), "bias")]
+
+    def with_aliases(groups, holder):
+        """groups: {level: [(key, shape, role)]} registered 5,4,3,2; the holder lists them 2,3,4,5"""
+        out = []
+        for l in (5, 4, 3, 2):
+            out += groups[l][1]
+        for i, l in enumerate((2, 3, 4, 5)):
+            pfx, items = groups[l]
+            out += [("%s.%d%s" % (holder, i, k[len(pfx):]), shp, "alias:" + k) for k, shp, _ in items]
+        return out
+
+    s += with_aliases({l: ("conv_squeeze_%d" % l, [("conv_squeeze_%d.0.weight" % l, (DIM, UNET_LEVELS[l]["cin"], 1, 1),
+                                                     "conv_w")]) for l in (5, 4, 3, 2)}, "conv_squeeze_layers")
+    s += with_aliases({l: ("conv_token_%d" % l, [("conv_token_%d.weight" % l, (L, DIM, 1, 1), "conv_w")])
+                       for l in (5, 4, 3, 2)}, "conv_tokens_layers")
+    s += with_aliases({l: ("conv_decode_%d" % l, [("conv_decode_%d.weight" % l, (DIM, 2 * DIM, 3, 3), "conv_w")])
+                       for l in (5, 4, 3, 2)}, "conv_decode_layers")
+    enc, dec = {}, {}
+    for l in (5, 4, 3, 2):
+        lv = UNET_LEVELS[l]
+        enc[l] = ("transformer_%d" % l, _encoder_spec("transformer_%d" % l, cfg["enc_depth"], lv["heads"],
+                                                       lv["dim_head"], DIM))
+        dec[l] = ("transformer_decoder_%d" % l, _decoder_spec("transformer_decoder_%d" % l, lv["dec_depth"],
+                                                               lv["heads"], lv["dim_head"], DIM))
+        s += enc[l][1] + dec[l][1]
+    for holder, groups in (("transformer_layers", enc), ("transformer_decoder_layers", dec)):
+        for i, l in enumerate((2, 3, 4, 5)):
+            pfx, items = groups[l]
+            s += [("%s.%d%s" % (holder, i, k[len(pfx):]), shp, "alias:" + k) for k, shp, _ in items]
+    s += [("conv_layer2_0.0.weight", (128, 128, 3, 3), "conv_w")] + _bn_spec("conv_layer2_0.1", 128)
+    s += [("conv_layer2_0.3.weight", (32, 128, 3, 3), "conv_w"), ("conv_layer2_0.3.bias", (32,), "bias")]
+    for l in (2, 3, 4):
+        s += [("conv_layer%d.0.weight" % l, (32, 32, 3, 3), "conv_w"),
+              ("conv_layer%d.0.bias" % l, (32,), "bias")]
+    s += [("classifier.weight", (cfg["n_class"], 32, 3, 3), "conv_w"),
+          ("classifier.bias", (cfg["n_class"],), "bias")]
+    return s
+
+
+def is_alias(role):
+    return role.startswith("alias:")
 
 
 def is_buffer(role):
@@ -242,6 +304,9 @@ def deterministic_state(net_G, salt=0, gain=1.0):
     import numpy as np
     sd = OrderedDict()
     for key, shape, role in state_spec(net_G):
+        if is_alias(role):
+            sd[key] = sd[role[6:]]          # the same tensor object, as in the reference's state_dict()
+            continue
         n = int(np.prod(shape)) if len(shape) else 1
         u = _hash_uniform(_crc32(key) + 7919 * salt, n)
         if role in ("conv_w", "lin_w"):
@@ -490,11 +555,65 @@ def _unet_forward(sd, cfg, x1, x2, training, taps):
     return logits
 
 
-def forward(sd, net_G, x1, x2, training=False, taps=None):
-    """logits [B, n_class, H, W]; BN buffers in `sd` are updated in place when training."""
+def _xbd_forward(sd, cfg, x1, x2, training, taps):
+    """xBD_code/zoo/model_transformer_encoding.py:356-449.  Differences from _unet_forward: only the
+    difference pass of the decoder runs (385-406), it reads conv_decode(cat[squeezed x1, squeezed x2]) and
+    |token2 - token1|; positional embeddings are picked by `if layer == 5/4/3` while the callers pass the
+    ModuleList index 3/2/1 (416-432), so ONLY the level-5 call (layer=3) adds pos_embedding_3 to its tokens
+    and pos_embedding_decoder_3 [1,32,64,64] to its 1/16-scale map -- which therefore must be 64x64."""
+    def trunk(x):
+        s2 = _stem(sd, x, training)
+        s4 = _res_layer(sd, 1, F.max_pool2d(s2, 3, 2, 1), 1, training)
+        s8 = _res_layer(sd, 2, s4, 2, training)
+        s16 = _res_layer(sd, 3, F.max_pool2d(s8, 3, 2, 1), 1, training)
+        return s2, s4, s8, s16
+
+    def level(l, xa, xb):
+        lv = UNET_LEVELS[l]
+        wsq = sd["conv_squeeze_%d.0.weight" % l]
+        xa = F.relu(F.conv2d(xa, wsq))
+        xb = F.relu(F.conv2d(xb, wsq))
+        ta = _tokenizer(xa, sd["conv_token_%d.weight" % l])
+        tb = _tokenizer(xb, sd["conv_token_%d.weight" % l])
+        tok = torch.cat([ta, tb], dim=1)
+        if l == 5:                                    # layer index 3 == the `if layer == 3` branch
+            tok = tok + sd["pos_embedding_3"]
+        tok = _encoder(sd, "transformer_%d" % l, tok, cfg["enc_depth"], lv["heads"])
+        ma, mb = tok.chunk(2, dim=1)
+        dtok = torch.abs(mb - ma)
+        dx = F.conv2d(torch.cat([xa, xb], dim=1), sd["conv_decode_%d.weight" % l], None, 1, 1)
+        pos = sd["pos_embedding_decoder_3"] if (l == 5 and cfg["decoder_pos"]) else None
+        return _decode_map(sd, "transformer_decoder_%d" % l, dx, dtok, lv["dec_depth"], lv["heads"], pos)
+
+    def up_conv(l, x):
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        return F.relu(F.conv2d(x, sd["conv_layer%d.0.weight" % l], sd["conv_layer%d.0.bias" % l], 1, 1))
+
+    a2, a4, a8, a16 = trunk(x1)
+    b2, b4, b8, b16 = trunk(x2)
+    o5 = F.interpolate(level(5, a16, b16), scale_factor=2, mode="nearest")
+    o4 = up_conv(4, level(4, a8, b8) + o5)
+    o3 = up_conv(3, level(3, a4, b4) + o4)
+    y = F.conv2d(torch.cat([a2, b2], dim=1), sd["conv_layer2_0.0.weight"], None, 1, 1)
+    y = F.relu(_bn(sd, "conv_layer2_0.1", y, training))
+    y = F.conv2d(y, sd["conv_layer2_0.3.weight"], sd["conv_layer2_0.3.bias"], 1, 1)
+    o2 = up_conv(2, y + o3)
+    logits = F.conv2d(o2, sd["classifier.weight"], sd["classifier.bias"], 1, 1)
+    if taps is not None:
+        taps.update(out5=o5, out4=o4, out3=o3, out2=o2)
+    return logits
+
+
+def forward(sd, net_G, x1, x2=None, training=False, taps=None):
+    """logits [B, n_class, H, W]; BN buffers in `sd` are updated in place when training.  The xBD model
+    takes ONE 6-channel tensor (model_transformer_encoding.py:409-412): pass it as x1 with x2=None."""
     cfg = get_config(net_G)
     if cfg["kind"] == "bit":
         return _bit_forward(sd, cfg, x1, x2, training, taps)
+    if cfg["kind"] == "xbd":
+        if x2 is None:
+            x1, x2 = x1[:, :3], x1[:, 3:]
+        return _xbd_forward(sd, cfg, x1, x2, training, taps)
     return _unet_forward(sd, cfg, x1, x2, training, taps)
 
 
@@ -533,7 +652,90 @@ def argmax_mask(logits):
 
 
 def trainable_keys(net_G):
-    return [k for k, _, role in state_spec(net_G) if not is_buffer(role)]
+    return [k for k, _, role in state_spec(net_G) if not is_buffer(role) and not is_alias(role)]
+
+
+# ---- xBD train step (xBD_code/train.py:310-374) ---------------------------------------------------
+XBD_CHANNEL_WEIGHTS = (0.05, 0.2, 0.8, 0.7, 0.4)        # train.py:353
+XBD_EPS = 1e-6                                           # xBD_code/losses.py:12
+
+
+def xbd_masks(label, n_class=5):
+    """float masks [B,5,H,W] like TrainData's `msk` (train.py:150-166): channel 0 = any building,
+    channels 1..4 = damage level; built from an integer map with values 0..4."""
+    m = [(label > 0)] + [(label == c) for c in range(1, n_class)]
+    return torch.stack([t.reshape(label.shape[0], *label.shape[-2:]) for t in m], dim=1).to(torch.float32)
+
+
+def combo_loss_channel(logit, target):
+    """ComboLoss({'dice': 1, 'focal': 8}) on one channel (xBD_code/losses.py:95-126): both terms read the
+    sigmoid; dice over the whole batch (per_image=False, losses.py:24-34), FocalLoss2d gamma 2 with both
+    operands clamped to [1e-6, 1-1e-6] (losses.py:273-288)."""
+    s = torch.sigmoid(logit)
+    t = target.float()
+    so, to = s.reshape(1, -1), t.reshape(1, -1)
+    inter = (so * to).sum(1)
+    union = so.sum(1) + to.sum(1) + XBD_EPS
+    dice = (1 - (2 * inter + XBD_EPS) / union).mean()
+    o = s.reshape(-1).clamp(XBD_EPS, 1.0 - XBD_EPS)
+    tt = t.reshape(-1).clamp(XBD_EPS, 1.0 - XBD_EPS)
+    pt = (1 - tt) * (1 - o) + tt * o
+    focal = (-(1.0 - pt) ** 2 * torch.log(pt)).mean()
+    return 1 * dice + 8 * focal
+
+
+def xbd_loss(logits, masks):
+    """train.py:348-353"""
+    return sum(w * combo_loss_channel(logits[:, c], masks[:, c]) for c, w in enumerate(XBD_CHANNEL_WEIGHTS))
+
+
+class XbdTrainState:
+    """train.py:331-374 + the hand-rolled AdamW of xBD_code/adamw.py:37-86 (eps is added to sqrt(v) BEFORE the
+    bias correction, unlike torch.optim.AdamW) + clip_grad_norm_(0.999) BEFORE the step (train.py:373)."""
+
+    def __init__(self, net_G, sd, lr=1e-4, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, max_norm=0.999):
+        self.net_G = net_G
+        self.sd = OrderedDict()
+        for k, _, role in state_spec(net_G):
+            if is_alias(role):
+                self.sd[k] = self.sd[role[6:]]
+                continue
+            t = sd[k].detach().clone()
+            if not is_buffer(role):
+                t.requires_grad_(True)
+            self.sd[k] = t
+        self.params = [self.sd[k] for k in trainable_keys(net_G)]
+        self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.state = {}
+        self.last_total_norm = None
+
+    def step(self, x6, masks):
+        for p in self.params:
+            p.grad = None
+        logits = forward(self.sd, self.net_G, x6, None, training=True)
+        loss = xbd_loss(logits, masks)
+        loss.backward()
+        grads = [p.grad for p in self.params if p.grad is not None]
+        total = torch.norm(torch.stack([torch.norm(g.detach(), 2.0) for g in grads]), 2.0)
+        self.last_total_norm = float(total)
+        coef = torch.clamp(self.max_norm / (total + 1e-6), max=1.0)
+        b1, b2 = self.betas
+        with torch.no_grad():
+            for i, p in enumerate(self.params):
+                if p.grad is None:
+                    continue
+                g = p.grad * coef
+                st = self.state.setdefault(i, dict(step=0, m=torch.zeros_like(p), v=torch.zeros_like(p)))
+                st["step"] += 1
+                st["m"].mul_(b1).add_(g, alpha=1 - b1)
+                st["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = st["v"].sqrt().add_(self.eps)
+                bc1, bc2 = 1 - b1 ** st["step"], 1 - b2 ** st["step"]
+                step_size = self.lr * math.sqrt(bc2) / bc1
+                if self.wd != 0:
+                    p.add_(p, alpha=-self.wd * self.lr)
+                p.addcdiv_(st["m"], denom, value=-step_size)
+        return logits.detach(), float(loss.detach())
 
 
 class TrainState:
@@ -543,6 +745,9 @@ class TrainState:
         self.net_G = net_G
         self.sd = OrderedDict()
         for k, _, role in state_spec(net_G):
+            if is_alias(role):
+                self.sd[k] = self.sd[role[6:]]
+                continue
             t = sd[k].detach().clone()
             if not is_buffer(role):
                 t.requires_grad_(True)

@@ -87,3 +87,56 @@ def build_resnet50_variant(output_nc=2):
         net = nets.BASE_Transformer(input_nc=3, output_nc=output_nc, token_len=4,
                                     resnet_stages_num=4, with_pos='learned', backbone='resnet50')
         return nets.init_net(net, 'normal', 0.02, [])
+
+
+# ---------------------------------------------------------------------------------------------------
+# xBD copy of the hierarchical model
+# ---------------------------------------------------------------------------------------------------
+_xbd = {}
+
+
+def load_xbd():
+    """Returns (model_module, losses_module, adamw_module) of xBD_code/.  The model file loads its trunk
+    with SourceFileLoader('zoo/bit_resnet.py') relative to the working directory
+    (zoo/model_transformer_encoding.py:10-11), hence the temporary chdir."""
+    if _xbd:
+        return _xbd["model"], _xbd["losses"], _xbd["adamw"]
+    load()          # installs the torchvision stubs
+    import importlib.util
+    import torch
+    tvm = sys.modules["torchvision.models"]
+    for n in ("resnet34", "resnet18", "efficientnet_b0"):
+        setattr(tvm, n, getattr(tvm, n, None) or (lambda *a, **k: (_ for _ in ()).throw(RuntimeError("stub"))))
+    import torch.hub
+    xroot = os.path.join(REF_ROOT, "xBD_code")
+    cwd = os.getcwd()
+    hub_orig = torch.hub.load_state_dict_from_url
+    os.chdir(xroot)
+    try:
+        def imp(name, rel):
+            spec = importlib.util.spec_from_file_location(name, os.path.join(xroot, rel))
+            m = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(m)
+            return m
+        torch.hub.load_state_dict_from_url = lambda *a, **k: None
+        model = imp("_xbd_model_transformer_encoding", "zoo/model_transformer_encoding.py")
+        bm = model.bitmodule
+        bm.load_state_dict_from_url = lambda *a, **k: None
+        _o = bm.ResNet.load_state_dict
+        bm.ResNet.load_state_dict = lambda self, sd, *a, **k: None if sd is None else _o(self, sd, *a, **k)
+        _xbd["model"] = model
+        _xbd["losses"] = imp("_xbd_losses", "losses.py")
+        _xbd["adamw"] = imp("_xbd_adamw", "adamw.py")
+    finally:
+        os.chdir(cwd)
+        torch.hub.load_state_dict_from_url = hub_orig
+    return _xbd["model"], _xbd["losses"], _xbd["adamw"]
+
+
+def build_xbd_model(with_decoder_pos='learned'):
+    """the model xBD_code/train.py:44-45 builds (default torch init; no init_weights in that script)"""
+    model, _, _ = load_xbd()
+    with contextlib.redirect_stdout(io.StringIO()):
+        return model.BASE_Transformer_UNet(input_nc=3, output_nc=5, token_len=4, resnet_stages_num=4,
+                                           with_pos='learned', with_decoder_pos=with_decoder_pos,
+                                           enc_depth=1, dec_depth=8)

@@ -47,6 +47,15 @@ def test_state_dict_keys_equal_reference(golden_dir):
                 define_G(types.SimpleNamespace(net_G=name))
             net = BASE_Transformer(input_nc=3, output_nc=2, token_len=4, resnet_stages_num=4, with_pos='learned',
                                    backbone='resnet50')
+        elif name.startswith("xbd_"):           # xBD_code/train.py:44-45 builds it by constructor
+            from dahitra_amd.models.xbd import BASE_Transformer_UNet
+            with pytest.raises(NotImplementedError):
+                define_G(types.SimpleNamespace(net_G=name))
+            net = BASE_Transformer_UNet(input_nc=3, output_nc=5, token_len=4, resnet_stages_num=4, with_pos='learned',
+                                        with_decoder_pos=None if name.endswith("nodecpos") else 'learned',
+                                        enc_depth=1, dec_depth=8)
+            assert sum(p.numel() for p in net.parameters()) == 13250765 - (0 if not name.endswith("nodecpos") else
+                                                                           32 * (16 * 16 + 32 * 32 + 64 * 64))
         else:
             net = define_G(types.SimpleNamespace(net_G=name))
         sd = net.state_dict()
@@ -81,8 +90,10 @@ def test_define_G_contract():
 def test_unused_parameter_contract():
     """17 (BiT) / 48 (newUNetTrans) tensors never receive a gradient"""
     from dahitra_amd import netspec
-    for name, n in (("base_transformer_pos_s4", 17), ("newUNetTrans", 48), ("base_transformer_pos_s4_resnet50", 32)):
-        inactive = [k for k, _, r in netspec.state_spec(name) if not netspec.is_buffer(r) and not netspec.is_active(name, k)]
+    for name, n in (("base_transformer_pos_s4", 17), ("newUNetTrans", 48), ("base_transformer_pos_s4_resnet50", 32), ("xbd_unet_transformer", 50),
+                    ("xbd_unet_transformer_nodecpos", 48)):
+        inactive = [k for k, _, r in netspec.state_spec(name)
+                    if not netspec.is_buffer(r) and not netspec.is_alias(r) and not netspec.is_active(name, k)]
         assert len(inactive) == n, (name, len(inactive))
 
 

@@ -275,7 +275,7 @@ def test_tokenizer(ops, dtype, L):
     dx = torch.zeros_like(xd)
     dwa = torch.zeros(L, 32, device="cuda")
     dpos = torch.zeros(2 * L, 32, device="cuda")
-    ops.tokenizer_bwd(xd, wa.detach().reshape(L, 32).cuda(), saved, dev(dt, dtype), dx, dwa, dpos, B, L)
+    ops.tokenizer_bwd(xd, wa.detach().reshape(L, 32).cuda(), saved, dt.float().cuda(), dx, dwa, dpos, B, L)   # tokens: fp32
     close(nchw(dx), x.grad, dtype, "tokenizer dx", factor=4)
     close(dwa, wa.grad.reshape(L, 32), dtype, "tokenizer dwa", factor=8)
     close(dpos, pos.grad.reshape(2 * L, 32), dtype, "dpos", factor=4)

@@ -116,3 +116,43 @@ def test_focal_loss_small_known_answer():
     lab = torch.ones(1, 1, 1, 1, dtype=torch.int64)
     want = (1 + 2e-6) * 0.125 * np.log(2.0)
     assert abs(float(O.focal_loss(logits, lab)) - want) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["xbd_unet_transformer_nodecpos"])
+def test_xbd_train_steps_match_golden(name, golden_dir):
+    """xBD 5-class step: forward, ComboLoss, clip, hand-rolled AdamW against the fixture the
+    reference produced (oracle/make_golden.py XBD_CASES).  The 1024x1024 fixture is checked on the GPU side
+    (tests/test_xbd_gpu.py) and, in the build container, in tests/test_oracle_vs_reference.py."""
+    g = np.load(os.path.join(golden_dir, "xbd_%s.npz" % name))
+    bs, size, stride = int(g["batch"]), int(g["size"]), int(g["stride"])
+    a, b, lab = O.synthetic_batch(bs, size, seed=11, n_class=5)
+    x6, msk = torch.cat([a, b], 1), O.xbd_masks(lab)
+    with torch.no_grad():
+        y = O.forward(O.deterministic_state(name), name, x6, None, training=False)
+    assert float((y[..., ::stride, ::stride] - torch.from_numpy(g["logits_eval"])).abs().max()) <= 1e-5
+    st = O.XbdTrainState(name, O.deterministic_state(name), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    losses, norms = [], []
+    for it in range(int(g["steps"])):
+        yo, lo = st.step(x6, msk)
+        if it == 0:
+            assert float((yo[..., ::stride, ::stride] - torch.from_numpy(g["logits_train"])).abs().max()) <= 1e-5
+            assert sorted(k for k in O.trainable_keys(name) if st.sd[k].grad is None) == sorted(g["nograd_keys"].tolist())
+        losses.append(lo)
+        norms.append(st.last_total_norm)
+    assert np.allclose(losses, g["losses"], rtol=1e-5), (losses, g["losses"])
+    assert np.allclose(norms, g["total_norms"], rtol=1e-4), (norms, g["total_norms"])
+    for k, v in zip(g["finalnorm_keys"].tolist(), g["finalnorm_vals"].tolist()):
+        assert abs(float(st.sd[k].double().norm()) - v) <= 1e-6 * max(v, 1e-8) + 1e-9, k
+
+
+def test_xbd_state_has_the_modulelist_aliases(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "state_keys.json")))
+    for name in ("xbd_unet_transformer", "xbd_unet_transformer_nodecpos"):
+        spec = O.state_spec(name)
+        assert [[k, list(s)] for k, s, _ in spec] == ref[name], name
+        sd = O.deterministic_state(name)
+        assert sd["conv_squeeze_layers.3.0.weight"] is sd["conv_squeeze_5.0.weight"]
+        assert sd["transformer_decoder_layers.1.layers.7.1.fn.fn.net.3.bias"] is \
+            sd["transformer_decoder_3.layers.7.1.fn.fn.net.3.bias"]
+    n = sum(int(np.prod(s)) for k, s, r in O.state_spec("xbd_unet_transformer") if not O.is_buffer(r) and not O.is_alias(r))
+    assert n == 13250765          # SURVEY.md row a12

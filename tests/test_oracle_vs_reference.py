@@ -51,3 +51,36 @@ def test_reference_anchor_from_survey():
         yo = O.forward(sd, "base_transformer_pos_s4", a, b, training=False)
     assert abs(float(y.sum()) - (-415.798811)) < 1e-2
     assert float((y - yo).abs().max()) <= 1e-6
+
+
+def test_xbd_train_step_equals_reference():
+    """xBD copy (xBD_code/zoo/model_transformer_encoding.py), ComboLoss (xBD_code/losses.py), clip_grad_norm_ and the
+    hand-rolled AdamW (xBD_code/adamw.py) exactly as xBD_code/train.py:331-374 chains them; with_decoder_pos=None so that
+    a 256x256 input runs (the 'learned' variant is pinned at 1024x1024 through the golden fixture)."""
+    import warnings
+    name = "xbd_unet_transformer_nodecpos"
+    _, xlosses, xadamw = ref_import.load_xbd()
+    net = ref_import.build_xbd_model(None)
+    sd = O.deterministic_state(name)
+    net.load_state_dict(sd)
+    net.train()
+    a, b, lab = O.synthetic_batch(2, 256, seed=21, n_class=5)
+    x6, msk = torch.cat([a, b], 1), O.xbd_masks(lab)
+    opt = xadamw.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-6)
+    seg = xlosses.ComboLoss({'dice': 1, 'focal': 8}, per_image=False)
+    st = O.XbdTrainState(name, sd)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in range(2):
+            net.zero_grad()
+            out = net(x6)
+            loss = sum(w * seg(out[:, c], msk[:, c]) for c, w in enumerate(O.XBD_CHANNEL_WEIGHTS))
+            loss.backward()
+            tn = torch.nn.utils.clip_grad_norm_(net.parameters(), 0.999)
+            opt.step()
+            yo, lo = st.step(x6, msk)
+            assert float((out.detach() - yo).abs().max()) <= 1e-5 * float(out.abs().max())
+            assert abs(float(loss.detach()) - lo) <= 1e-6 * lo
+            assert abs(float(tn) - st.last_total_norm) <= 1e-5 * float(tn)
+            for k, p in net.named_parameters():
+                assert float((p.detach() - st.sd[k].detach()).abs().max()) <= 1e-6, k
