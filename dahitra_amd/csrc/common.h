@@ -93,3 +93,16 @@ extern "C" void dh_set_error(const char* msg);
         if (_e != hipSuccess) DH_FAIL("%s launch: %s", name, hipGetErrorString(_e)); \
     } while (0)
 static inline int dh_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// fp64 sum over a workgroup of whole wavefronts (<= 1024 threads); every thread must call it; the result is valid
+// in thread 0.  `sh` is a __shared__ double[16].
+__device__ __forceinline__ double dh_block_sum_f64(double v, double* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;
+}

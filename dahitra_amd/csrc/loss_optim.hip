@@ -53,6 +53,96 @@ __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ lo
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// ---- cross entropy of the batch-size-1 branch (models/losses.py:9-26, trainer.py:260-261): class weights [1, 1],
+// ignore_index, mean over the non-ignored pixels.  partial[blk] = {sum of -log p_t, count}
+__global__ __launch_bounds__(256) void ce_partial_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                         int B, int C, long HW, int ignore, double* __restrict__ partial) {
+    __shared__ double sh[16];
+    double ls = 0.0, cnt = 0.0;
+    const long total = (long)B * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)target[i];
+        if (t == ignore) continue;
+        const long b = i / HW, p = i % HW;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, logits[(b * C + c) * HW + p]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(logits[(b * C + c) * HW + p] - m);
+        ls += (double)(m + logf(s) - logits[(b * C + t) * HW + p]);
+        cnt += 1.0;
+    }
+    double r = dh_block_sum_f64(ls, sh);
+    if (threadIdx.x == 0) partial[2 * blockIdx.x] = r;
+    r = dh_block_sum_f64(cnt, sh);
+    if (threadIdx.x == 0) partial[2 * blockIdx.x + 1] = r;
+}
+// out[0] = mean loss, out[1] = number of contributing pixels
+__global__ void ce_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out) {
+    __shared__ double sh[16];
+    double ls = 0.0, cnt = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) { ls += partial[2 * i]; cnt += partial[2 * i + 1]; }
+    const double a = dh_block_sum_f64(ls, sh);
+    const double n = dh_block_sum_f64(cnt, sh);
+    if (threadIdx.x == 0) { out[0] = (float)(a / n); out[1] = (float)n; }      // 0/0 = nan, as torch
+}
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, const long long* __restrict__ target, int B, int C, long HW,
+                              int ignore, const float* __restrict__ fwd_out, const float* __restrict__ upstream,
+                              float* __restrict__ dlogits) {
+    const long total = (long)B * HW;
+    const float gs = (upstream ? *upstream : 1.f) / fwd_out[1];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / HW, p = i % HW;
+        const int t = (int)target[i];
+        if (t == ignore) {
+            for (int c = 0; c < C; ++c) dlogits[(b * C + c) * HW + p] = 0.f;
+            continue;
+        }
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, logits[(b * C + c) * HW + p]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(logits[(b * C + c) * HW + p] - m);
+        const float inv = 1.f / s;
+        for (int c = 0; c < C; ++c)
+            dlogits[(b * C + c) * HW + p] = gs * (expf(logits[(b * C + c) * HW + p] - m) * inv - (c == t ? 1.f : 0.f));
+    }
+}
+
+// ---- the gradient-free dice term of trainer.py:256-259: smp DiceLoss(mode='binary') on the ARG-MAX mask
+// (from_logits => sigmoid of the mask value, dims (0, 2), smooth 0, eps 1e-7, zeroed when the target is empty).
+// partial[blk] = {sum p*t, sum (p + t), sum t}
+__global__ __launch_bounds__(256) void dice_argmax_partial_kernel(const float* __restrict__ logits,
+                                                                  const long long* __restrict__ target, int B, int C, long HW,
+                                                                  double* __restrict__ partial) {
+    __shared__ double sh[16];
+    double aI = 0.0, aC = 0.0, aT = 0.0;
+    const long total = (long)B * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / HW, p = i % HW;
+        float best = logits[(b * C) * HW + p];
+        int arg = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = logits[(b * C + c) * HW + p];
+            if (v > best) { best = v; arg = c; }
+        }
+        const float pr = 1.f / (1.f + expf(-(float)arg));        // logsigmoid(mask).exp()
+        const float t = (float)target[i];
+        aI += (double)pr * t; aC += (double)pr + t; aT += t;
+    }
+    double r = dh_block_sum_f64(aI, sh); if (threadIdx.x == 0) partial[3 * blockIdx.x] = r;
+    r = dh_block_sum_f64(aC, sh); if (threadIdx.x == 0) partial[3 * blockIdx.x + 1] = r;
+    r = dh_block_sum_f64(aT, sh); if (threadIdx.x == 0) partial[3 * blockIdx.x + 2] = r;
+}
+__global__ void dice_argmax_finalize_kernel(const double* __restrict__ partial, int nblk, float eps, float* __restrict__ out) {
+    __shared__ double sh[16];
+    double aI = 0.0, aC = 0.0, aT = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) { aI += partial[3 * i]; aC += partial[3 * i + 1]; aT += partial[3 * i + 2]; }
+    const double I = dh_block_sum_f64(aI, sh), Cd = dh_block_sum_f64(aC, sh), T = dh_block_sum_f64(aT, sh);
+    if (threadIdx.x == 0) {
+        const float card = fmaxf((float)Cd, eps);
+        *out = T > 0.0 ? 1.f - 2.f * (float)I / card : 0.f;
+    }
+}
+
 __global__ void argmax_nchw_kernel(const float* __restrict__ logits, long long* __restrict__ mask, int B, int C, long HW) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * HW) return;
@@ -150,6 +240,45 @@ extern "C" int dh_focal_loss(const float* logits_nchw, const long long* target, 
                        grad_scale / (float)total, dlogits_nchw, partial);
     DH_CHECK_LAUNCH("focal_loss");
     return dh_reduce_partials(partial, g, 1, 1.0f / (float)total, loss_out, 0, stream);
+}
+
+// workspace: 2048 doubles.  out_dev[0] = loss, out_dev[1] = contributing pixel count (needed by the backward)
+extern "C" int dh_cross_entropy_fwd(const float* logits_nchw, const long long* target, int B, int C, long HW,
+                                    int ignore_index, float* out_dev, void* workspace, void* stream) {
+    DH_REQUIRE(C >= 1 && B > 0 && HW > 0, "cross_entropy: empty input");
+    const long total = (long)B * HW;
+    long g = (total + 255) / 256;
+    if (g > 1024) g = 1024;
+    double* partial = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(ce_partial_kernel, dim3((int)g), dim3(256), 0, ST(stream), logits_nchw, target, B, C, HW,
+                       ignore_index, partial);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), partial, (int)g, out_dev);
+    DH_CHECK_LAUNCH("cross_entropy_fwd");
+    return 0;
+}
+extern "C" int dh_cross_entropy_bwd(const float* logits_nchw, const long long* target, int B, int C, long HW,
+                                    int ignore_index, const float* fwd_out_dev, const float* upstream_dev,
+                                    float* dlogits_nchw, void* stream) {
+    const long total = (long)B * HW;
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((int)g), dim3(256), 0, ST(stream), logits_nchw, target, B, C, HW, ignore_index,
+                       fwd_out_dev, upstream_dev, dlogits_nchw);
+    DH_CHECK_LAUNCH("cross_entropy_bwd");
+    return 0;
+}
+// workspace: 3072 doubles
+extern "C" int dh_dice_argmax_constant(const float* logits_nchw, const long long* target, int B, int C, long HW, float eps,
+                                       float* loss_out, void* workspace, void* stream) {
+    const long total = (long)B * HW;
+    long g = (total + 255) / 256;
+    if (g > 1024) g = 1024;
+    double* partial = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(dice_argmax_partial_kernel, dim3((int)g), dim3(256), 0, ST(stream), logits_nchw, target, B, C, HW,
+                       partial);
+    hipLaunchKernelGGL(dice_argmax_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), partial, (int)g, eps, loss_out);
+    DH_CHECK_LAUNCH("dice_argmax_constant");
+    return 0;
 }
 
 extern "C" int dh_argmax_nchw(const float* logits_nchw, long long* mask, int B, int C, long HW, void* stream) {

@@ -14,21 +14,10 @@ constexpr float XEPS = 1e-6f;        // xBD_code/losses.py:12
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-__device__ __forceinline__ double block_sum(double v, double* sh) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    __syncthreads();
-    if (l == 0) sh[w] = v;
-    __syncthreads();
-    double t = 0.0;
-    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
-    return t;                         // valid in thread 0
-}
-
 // partial[c][blk][4] = { sum s*t, sum s, sum t, sum focal } over the pixels this workgroup visits
 __global__ __launch_bounds__(256) void combo_partial_kernel(const float* __restrict__ logits, const float* __restrict__ masks,
                                                             int B, int C, long HW, double* __restrict__ partial) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     const int c = blockIdx.y;
     double aI = 0, aS = 0, aT = 0, aF = 0;
     const long n = (long)B * HW;
@@ -44,10 +33,10 @@ __global__ __launch_bounds__(256) void combo_partial_kernel(const float* __restr
     }
     double* dst = partial + ((long)c * gridDim.x + blockIdx.x) * 4;
     double r;
-    r = block_sum(aI, sh); if (threadIdx.x == 0) dst[0] = r;
-    r = block_sum(aS, sh); if (threadIdx.x == 0) dst[1] = r;
-    r = block_sum(aT, sh); if (threadIdx.x == 0) dst[2] = r;
-    r = block_sum(aF, sh); if (threadIdx.x == 0) dst[3] = r;
+    r = dh_block_sum_f64(aI, sh); if (threadIdx.x == 0) dst[0] = r;
+    r = dh_block_sum_f64(aS, sh); if (threadIdx.x == 0) dst[1] = r;
+    r = dh_block_sum_f64(aT, sh); if (threadIdx.x == 0) dst[2] = r;
+    r = dh_block_sum_f64(aF, sh); if (threadIdx.x == 0) dst[3] = r;
 }
 
 // sums[c][4] totals, channel_loss[c] = dice + 8 focal, *loss = sum_c w_c channel_loss[c]
@@ -105,7 +94,7 @@ __global__ __launch_bounds__(256) void combo_bwd_kernel(const float* __restrict_
 
 // ---- gradient norm + clip coefficient -----------------------------------------------------------
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ partial) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     double a = 0.0;
     const long n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -114,15 +103,15 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
         a += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; a += (double)v * v; }
-    const double r = block_sum(a, sh);
+    const double r = dh_block_sum_f64(a, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 // out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))  (torch clip_grad_norm_)
 __global__ void clip_coef_kernel(const double* __restrict__ partial, int nblk, float max_norm, float* __restrict__ out) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     double a = 0.0;
     for (int i = threadIdx.x; i < nblk; i += blockDim.x) a += partial[i];
-    const double r = block_sum(a, sh);
+    const double r = dh_block_sum_f64(a, sh);
     if (threadIdx.x == 0) {
         const float norm = (float)sqrt(r);
         out[0] = norm;

@@ -3,7 +3,7 @@
 Mirrored (same names, argument meaning, order of operations):
     __init__(args, dataloaders)      trainer.py:21-103  net_G = define_G(args, gpu_ids), AdamW, scheduler
     _forward_pass(batch)             trainer.py:247-252 batch {'A','B','L'} -> self.G_pred
-    _backward_G()                    trainer.py:254-262 B != 1: diceloss(argmax) + focal_loss
+    _backward_G()                    trainer.py:254-262 B != 1: diceloss(argmax) + focal_loss; B == 1: cross_entropy
     train_models()                   trainer.py:288-334 forward, zero_grad, backward, step (then the no-op clip)
 Out of scope here (host plumbing): Logger/Timer files, visualisation jpgs,
 numpy accuracy curves.  The running confusion matrix is kept on the device instead of the per-step
@@ -53,11 +53,13 @@ class CDTrainer:
 
     def _backward_G(self):
         gt = self.batch['L'].to(self.device).long()
-        if gt.shape[0] == 1:
-            raise NotImplementedError("batch size 1 takes the reference's cross_entropy branch "
-                                      "(trainer.py:260-261), which is outside the measured path")
-        # the dice term of trainer.py:259 is a gradient-free constant (argmax); focal carries the step
-        self.G_loss = losses.focal_loss(self.G_pred, gt)
+        self._pxl_loss1 = losses.diceloss
+        self._pxl_loss2 = losses.focal_loss
+        if gt.shape[0] != 1:
+            # the dice term (trainer.py:259) is a gradient-free constant (argmax): it shifts the logged value only
+            self.G_loss = self._pxl_loss1(self.G_pred, gt) + self._pxl_loss2(self.G_pred, gt)
+        else:
+            self.G_loss = losses.cross_entropy(self.G_pred, gt)
         self.G_loss.backward()
 
     def train_step(self, batch):

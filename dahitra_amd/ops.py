@@ -519,6 +519,31 @@ def focal_loss(logits_nchw, target, want_grad=True, grad_scale=1.0, alpha=0.5):
     return loss, dl
 
 
+def cross_entropy_fwd(logits_nchw, target, ignore_index=255):
+    """returns out [2] (device): mean CE over the non-ignored pixels, their count"""
+    B, C, H, W = logits_nchw.shape
+    out = torch.empty(2, dtype=torch.float32, device=logits_nchw.device)
+    ws = workspace(16384, logits_nchw.device)
+    _call("dh_cross_entropy_fwd", P(logits_nchw), P(target), _ci(B), _ci(C), _cl(H * W), _ci(ignore_index), P(out), P(ws), S())
+    return out
+
+
+def cross_entropy_bwd(logits_nchw, target, fwd_out, upstream, ignore_index=255):
+    B, C, H, W = logits_nchw.shape
+    dl = torch.empty_like(logits_nchw)
+    _call("dh_cross_entropy_bwd", P(logits_nchw), P(target), _ci(B), _ci(C), _cl(H * W), _ci(ignore_index), P(fwd_out),
+          P(upstream), P(dl), S())
+    return dl
+
+
+def dice_argmax_constant(logits_nchw, target, eps=1e-7):
+    B, C, H, W = logits_nchw.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits_nchw.device)
+    ws = workspace(24576, logits_nchw.device)
+    _call("dh_dice_argmax_constant", P(logits_nchw), P(target), _ci(B), _ci(C), _cl(H * W), _cf(eps), P(loss), P(ws), S())
+    return loss
+
+
 def confusion_matrix(logits_nchw, target, counts, want_mask=False):
     """counts [C, C] int64 (device) += confusion of argmax(logits) against target; optionally returns the mask"""
     B, C, H, W = logits_nchw.shape

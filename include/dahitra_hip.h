@@ -159,6 +159,18 @@ long dh_decoder_layer_bwd_workspace_size(long rows, int rows_per_image, int mlp)
 int dh_focal_loss(const float* logits_nchw, const long long* target, int B, int C, long HW, float alpha,
                   float grad_scale, float* loss_out, float* dlogits_nchw, void* workspace, void* stream);
 int dh_argmax_nchw(const float* logits_nchw, long long* mask, int B, int C, long HW, void* stream);
+/* batch-size-1 branch of the trainer (models/trainer.py:260-261 -> losses.py:9-26): F.cross_entropy with class
+ * weights [1, 1], ignore_index, mean over the contributing pixels.  out_dev[0] = loss, out_dev[1] = pixel count.
+ * workspace: 16 KiB. */
+int dh_cross_entropy_fwd(const float* logits_nchw, const long long* target, int B, int C, long HW, int ignore_index,
+                         float* out_dev, void* workspace, void* stream);
+int dh_cross_entropy_bwd(const float* logits_nchw, const long long* target, int B, int C, long HW, int ignore_index,
+                         const float* fwd_out_dev, const float* upstream_dev, float* dlogits_nchw, void* stream);
+/* the gradient-free dice term of models/trainer.py:256-259 (losses.py:333-339): binary DiceLoss of
+ * segmentation_models_pytorch applied to the arg-max mask (third party, not vendored: see oracle dice_constant).
+ * workspace: 24 KiB. */
+int dh_dice_argmax_constant(const float* logits_nchw, const long long* target, int B, int C, long HW, float eps,
+                            float* loss_out, void* workspace, void* stream);
 /* HIP-graph-capturable form: hyper_dev = [lr, beta1, beta2, eps, weight_decay, grad_scale, bc1, bc2_sqrt] and the
  * step counter live on the device; every call (or graph replay) advances the counter and the bias correction */
 int dh_adamw_step_graph(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,

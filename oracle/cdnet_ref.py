@@ -631,6 +631,16 @@ def focal_loss(logits, target, alpha=0.5, gamma=2.0):
     return (oh * focal).sum(dim=1).mean()
 
 
+def cross_entropy(logits, target, ignore_index=255):
+    """models/losses.py:9-26, the batch-size-1 branch of trainer.py:260-261: F.cross_entropy with the hard-coded
+    class weights [1, 1] (created with .cuda() in the reference, so that function itself cannot run on a CPU:
+    restated here), ignore_index 255, mean reduction."""
+    if target.dim() == logits.dim():
+        target = target[:, 0]
+    w = torch.ones(logits.shape[1], dtype=logits.dtype)
+    return F.cross_entropy(logits, target.long(), weight=w, ignore_index=ignore_index, reduction="mean")
+
+
 def dice_constant(logits, target, eps=1e-7):
     """The gradient-free dice term of trainer.py:256-259 (smp DiceLoss(mode='binary') applied to
     the argmax mask: from_logits => logsigmoid().exp(), dims (0,2), smooth 0).  PARITY UNPINNED:

@@ -330,3 +330,31 @@ def test_focal_argmax_adamw(ops):
         opt.step()
         ops.adamw_step(pd, g.cuda(), m, v, 0.01, 0.9, 0.999, 1e-8, 0.01, step)
         close(pd, ref.detach(), torch.float32, "adamw step %d" % step, factor=1)
+
+
+def test_cross_entropy_branch_and_dice_constant(ops):
+    """batch-size-1 branch (models/losses.py:9-26) and the gradient-free dice term (losses.py:333-339)"""
+    import cdnet_ref as O
+    from dahitra_amd.models import losses
+    g = torch.Generator().manual_seed(17)
+    for C in (2, 5):
+        logits = (torch.randn(1, C, 40, 56, generator=g) * 2).requires_grad_(True)
+        tgt = torch.randint(0, C, (1, 1, 40, 56), generator=g)
+        tgt[0, 0, :3] = 255                                  # ignore_index rows
+        want = O.cross_entropy(logits, tgt)
+        (want * 0.7).backward()
+        lg = logits.detach().cuda().requires_grad_(True)
+        got = losses.cross_entropy(lg, tgt.cuda())
+        (got * 0.7).backward()
+        assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
+        assert float((lg.grad.cpu() - logits.grad).abs().max()) <= 1e-6 * float(logits.grad.abs().max()) + 1e-12
+        assert float(lg.grad[0, :, :3].abs().max()) == 0.0
+    for C, bs in ((2, 3), (5, 2)):
+        logits = torch.randn(bs, C, 32, 32, generator=g)
+        tgt = (torch.rand(bs, 1, 32, 32, generator=g) > 0.7).long()
+        want = O.dice_constant(logits, tgt)
+        got = losses.diceloss(logits.cuda(), tgt.cuda())
+        assert abs(float(got) - float(want)) <= 1e-6, (float(got), float(want))
+        assert not got.requires_grad
+    empty = torch.zeros(2, 1, 32, 32, dtype=torch.long)
+    assert float(losses.diceloss(torch.randn(2, 2, 32, 32, generator=g).cuda(), empty.cuda())) == 0.0   # empty-target mask
