@@ -27,6 +27,9 @@ NET = "base_transformer_pos_s4"
 SIZE = 256
 PER_GPU_BATCH = 32
 GFLOP_PER_PAIR = 50.20          # BASELINE.md section 2 (fwd+bwd, algorithmic, FlopCounterMode on the reference)
+# other configurations (same counter), GFLOP per pair at 256x256; conv FLOPs scale with the area
+GFLOP_256 = {"base_transformer_pos_s4": 50.20, "newUNetTrans": 70.13, "base_transformer_pos_s4_dd8_o5": 258.5 / 4,
+             "base_transformer_pos_s4_resnet50": 135.2}
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
@@ -69,6 +72,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--net", default=NET)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="pairs per GPU")
+    ap.add_argument("--img", type=int, default=SIZE, help="image side (the headline metric is quoted at 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="report eval-mode forward pairs/s instead")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of one HIP graph")
@@ -88,12 +92,32 @@ def main():
     dev = torch.device("cuda", local)
 
     import contextlib
+    from dahitra_amd.netspec import get_config
+    cfg = get_config(args.net)
+    xbd_mode = cfg["kind"] == "xbd"
     with contextlib.redirect_stdout(sys.stderr):       # define_G prints like the reference; stdout = one JSON line
-        net = define_G(types.SimpleNamespace(net_G=args.net, compute_dtype=args.dtype), gpu_ids=[local])
+        if xbd_mode:                                   # xBD_code/train.py:44-45 (constructor call, default init)
+            from dahitra_amd.models import xbd
+            net = xbd.BASE_Transformer_UNet(with_decoder_pos='learned' if cfg["decoder_pos"] else None,
+                                            compute_dtype=args.dtype).to(dev)
+        elif cfg.get("backbone") == "resnet50":        # models/networks.py:192-195 (constructor call only)
+            from dahitra_amd.models.networks import BASE_Transformer, init_net
+            net = init_net(BASE_Transformer(backbone='resnet50', compute_dtype=args.dtype), gpu_ids=[local])
+        else:
+            net = define_G(types.SimpleNamespace(net_G=args.net, compute_dtype=args.dtype), gpu_ids=[local])
     net.train(not args.fwd_only)
-    use_graph = not args.no_graph and not args.fwd_only
-    opt = AdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, capturable=use_graph)
-    a, b, lab = synthetic(args.batch, SIZE, 1234 + rank, dev)
+    use_graph = not args.no_graph and not args.fwd_only and not xbd_mode
+    if xbd_mode:
+        opt = xbd.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-6)          # xBD_code/train.py:439
+    else:
+        opt = AdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, capturable=use_graph)
+    a, b, lab = synthetic(args.batch, args.img, 1234 + rank, dev)
+    if xbd_mode:
+        g5 = torch.Generator().manual_seed(99 + rank)
+        r = torch.rand(args.batch, args.img, args.img, generator=g5)
+        lab5 = torch.where(r < 0.85, torch.zeros_like(r), 1 + torch.floor((r - 0.85) / 0.15 * 4).clamp_(max=3)).long()
+        msk = torch.stack([(lab5 > 0)] + [(lab5 == c) for c in range(1, 5)], 1).float().to(dev)
+        x6 = torch.cat([a, b], 1).contiguous()
     net._ensure_arena(dev)
     parallel.broadcast_params_(net)
     graphed = None
@@ -104,7 +128,17 @@ def main():
     def step():
         if args.fwd_only:
             with torch.no_grad():
-                return net(a, b)
+                return net(x6) if xbd_mode else net(a, b)
+        if xbd_mode:                                         # xBD_code/train.py:331-374
+            net.zero_grad()
+            loss = xbd.xbd_loss(net(x6), msk)
+            loss.backward()
+            scale = parallel.allreduce_net_grads_(net)
+            if scale != 1.0:
+                ops.scale_into(net.flat_params()[1], torch.tensor([scale], device=dev), net.flat_params()[1])
+            xbd.clip_grad_norm_(net.parameters(), 0.999)
+            opt.step()
+            return loss
         if graphed is not None and ops.PROFILE is None:
             return graphed(a, b, lab)                        # inputs already resident; copied into the static buffers
         logits = net(a, b)
@@ -153,7 +187,7 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             traffic = None        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
             tpath = os.path.join(ROOT, "profiles", "r01c_pmc_traffic_conv3x3.json")
-            if args.dtype == "bf16" and args.net == NET and os.path.exists(tpath):
+            if args.dtype == "bf16" and args.net == NET and args.img == SIZE and os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 ln = sum(v["launches"] for v in tj.values())
                 traffic = round(sum(v["launches"] * (v["fetch_MB_per_launch_corrected_x2"] + v["write_MB_per_launch"])
@@ -166,18 +200,21 @@ def main():
     if rank == 0:
         pairs = args.batch * world * args.steps
         res = {
-            "metric": "image-pairs/s (256x256) %s, 1/2/4/8 MI355X + CPU ref" % ("eval forward" if args.fwd_only else "train step"),
+            "metric": "image-pairs/s (%dx%d) %s, 1/2/4/8 MI355X + CPU ref" % (args.img, args.img, "eval forward" if args.fwd_only else "train step"),
             "value": round(pairs / dt, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "LEVIR-CD 256x256 synthetic pairs, %s, %s, batch %d per GPU (global %d), "
-                                   "fwd+focal+bwd+allreduce+AdamW" % (args.net, args.dtype, args.batch, args.batch * world),
-                       "net_G": args.net, "global_batch": args.batch * world, "img_size": SIZE,
+            "config": {"workload": "%s %dx%d synthetic pairs, %s, %s, batch %d per GPU (global %d), %s"
+                                   % ("xBD" if xbd_mode else "LEVIR-CD", args.img, args.img, args.net, args.dtype, args.batch,
+                                      args.batch * world, "fwd+ComboLoss+bwd+allreduce+clip+AdamW" if xbd_mode
+                                      else "fwd+focal+bwd+allreduce+AdamW"),
+                       "net_G": args.net, "global_batch": args.batch * world, "img_size": args.img,
                        "parallelism": "dp%d" % world, "final_loss": round(final, 6), "hip_graph": bool(use_graph),
-                       "step_tflops": round(pairs / dt * GFLOP_PER_PAIR / 1e3, 2) if args.net == NET and not args.fwd_only else None},
+                       "step_tflops": round(pairs / dt * GFLOP_256[args.net] * (args.img / 256.0) ** 2 / 1e3, 2)
+                       if args.net in GFLOP_256 and not args.fwd_only else None},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.net == NET and args.img == SIZE:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
     if world > 1:
