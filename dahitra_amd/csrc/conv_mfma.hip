@@ -9,6 +9,10 @@
 // with fp32 accumulation.  Weights are the A operand so that a lane ends up with 4 consecutive
 // output channels of one pixel (8/16-byte stores).  Epilogue: +bias, +residual, ReLU/GELU, and
 // optional per-workgroup partial sums (sum, sum of squares) per channel for train-mode BatchNorm.
+// A data-gradient launch can instead be "gated" for the BatchNorm layer it back-propagates into: the epilogue
+// applies that layer's ReLU mask, stores g = dout*mask and emits the per-tile partials (sum g, sum g*xhat) of the
+// BN backward -- the separate reduction pass over (dout, out, y) disappears and the apply pass reads 2 tensors
+// instead of 3.
 //
 // The same kernel serves: every 3x3 / 1x1 convolution of the trunk and head (reference
 // models/resnet.py:24-32, models/help_funcs.py:7-15, models/networks.py:215), their data
@@ -49,6 +53,13 @@ struct ConvArgs {
     int tilesX, tilesY;
     int rw;            // rows per wavefront (tile height = 4*rw)
     int dil;           // dilation (1, or 2 for the ResNet-50 layer3 3x3 convolutions)
+    // BatchNorm-backward gating of a data-gradient launch (see the epilogue): tensors of the BN layer whose output
+    // this launch differentiates -- same [N][OH][OW][Cout] shape as y
+    const void* gate_out;       // that layer's post-ReLU output (null: no ReLU)
+    const void* gate_y;         // its pre-normalisation input (null: gating off)
+    const float* gate_mean;     // [groups][Cout]
+    const float* gate_invstd;   // [groups][Cout]
+    int gate_groups;
 };
 
 union V16u {
@@ -209,6 +220,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                     for (int j = 0; j < 4; ++j) v[j] += rr[j];
                 }
                 if (p.y2) st4(reinterpret_cast<T*>(p.y2) + (size_t)n * p.OH * p.OW * p.Cout + off, v);
+                if (p.gate_y) {
+                    const size_t goff = (size_t)n * p.OH * p.OW * p.Cout + off;
+                    const int gi = (n / (p.N / p.gate_groups)) * p.Cout + c;
+                    float xv[4];
+                    ld4(reinterpret_cast<const T*>(p.gate_y) + goff, xv);
+                    if (p.gate_out) {
+                        float ov[4];
+                        ld4(reinterpret_cast<const T*>(p.gate_out) + goff, ov);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = ov[j] > 0.f ? v[j] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xh = (xv[j] - p.gate_mean[gi + j]) * p.gate_invstd[gi + j];
+                        ssum[s][j] += v[j];
+                        ssq[s][j] += v[j] * xh;
+                    }
+                    st4(yout + off, v);
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (p.act == DH_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
@@ -326,7 +357,9 @@ int launch_ks(const ConvArgs& a, int ks, int stride, hipStream_t st) {
 extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const float* bias,
                              const void* residual, float* stats_partial, int N, int H, int W, int Cin,
                              int OH, int OW, int Cout, int CoutPad, int ks, int stride, int pad, int act,
-                             int npix_valid, long w_image_stride, void* y_preact, int dilation, void* stream) {
+                             int npix_valid, long w_image_stride, void* y_preact, int dilation, const void* gate_out,
+                             const void* gate_y, const float* gate_mean, const float* gate_invstd, int gate_groups,
+                             void* stream) {
     const int esz = dtype == DH_DTYPE_BF16 ? 2 : 4;
     DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "conv2d_fwd: bad dtype %d", dtype);
     DH_REQUIRE((Cin * esz) % 64 == 0, "conv2d_fwd: Cin=%d must be a multiple of %d", Cin, 64 / esz);
@@ -339,6 +372,12 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     a.in_npix = npix_valid > 0 ? npix_valid : H * W; a.w_nstride = w_image_stride;
     DH_REQUIRE(dilation == 1 || (dilation == 2 && ks == 3 && stride == 1), "conv2d_fwd: dilation %d unsupported here", dilation);
     a.dil = dilation;
+    a.gate_out = gate_out; a.gate_y = gate_y; a.gate_mean = gate_mean; a.gate_invstd = gate_invstd;
+    a.gate_groups = gate_groups > 0 ? gate_groups : 1;
+    if (gate_y) {
+        DH_REQUIRE(stats_partial && gate_mean && gate_invstd && Cout % 4 == 0 && act == DH_ACT_NONE && N % a.gate_groups == 0,
+                   "conv2d_fwd: BN-backward gating needs stats_partial, mean/invstd, Cout %% 4 == 0, no activation");
+    }
     a.rw = pick_rw(N, OH, OW, Cin, ks, stride);
     a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, 4 * a.rw);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

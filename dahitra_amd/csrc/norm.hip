@@ -388,6 +388,31 @@ extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, cons
     return 0;
 }
 
+// BN backward when the producer of dout (a gated data-gradient launch of conv_mfma) already applied the ReLU mask and
+// left per-tile partials [ntiles][2][C] = (sum g, sum g*xhat): combine them, then dx = gamma*invstd*(g - (s1 + xhat*s2)/M).
+// workspace: sums [groups][2][C] floats
+extern "C" int dh_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* partial, int ntiles,
+                                       const float* mean, const float* invstd, const float* gamma, long npix, int C,
+                                       int groups, void* dx, float* dgamma, float* dbeta, int accumulate,
+                                       void* workspace, void* stream) {
+    DH_REQUIRE(C % 4 == 0 && groups > 0 && ntiles % groups == 0 && npix % groups == 0,
+               "bn_bwd_from_partials: C=%d ntiles=%d npix=%ld groups=%d", C, ntiles, npix, groups);
+    float* sums = reinterpret_cast<float*>(workspace);
+    const long ppg = npix / groups, nvec = npix * C / 4;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, ntiles / groups, groups, C, sums,
+                       dgamma, dbeta, accumulate);
+    if (dtype == DH_DTYPE_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const bf16*)g,
+                           (const bf16*)nullptr, (const bf16*)x, mean, invstd, gamma, sums, 1.0f / (float)ppg, nvec, C,
+                           nvec / groups, (bf16*)dx, (bf16*)nullptr);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const float*)g,
+                           (const float*)nullptr, (const float*)x, mean, invstd, gamma, sums, 1.0f / (float)ppg, nvec, C,
+                           nvec / groups, (float*)dx, (float*)nullptr);
+    DH_CHECK_LAUNCH("bn_bwd_from_partials");
+    return 0;
+}
+
 extern "C" int dh_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
                                 float* stats, long rows, int C, float eps, void* stream) {
     DH_REQUIRE(C == 32, "layernorm: only dim 32 (the reference's transformer width), got %d", C);

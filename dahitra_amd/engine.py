@@ -28,6 +28,15 @@ class Packed:
         self.fwd, self.dgrad = fwd, dgrad
 
 
+class Gated:
+    """Output of a data-gradient launch that was gated for the BatchNorm layer it feeds (ops.conv2d(..., gate=...)):
+    g = dout * ReLU-mask and the per-tile partial sums (sum g, sum g * xhat) of that layer's backward."""
+    __slots__ = ("g", "partial")
+
+    def __init__(self, g, partial):
+        self.g, self.partial = g, partial
+
+
 class Engine:
     def __init__(self, net_G, dtype=torch.float32, use_tr=True):
         self.net_G = net_G
@@ -35,6 +44,8 @@ class Engine:
         self.dtype = dtype
         self.use_tr = use_tr
         self.fused_decoder = os.environ.get("DAHITRA_NO_FUSED_DECODER", "0") != "1"
+        # BatchNorm backward: reduction pass folded into the epilogue of the data-gradient conv that produces dout
+        self.fused_bn_bwd = os.environ.get("DAHITRA_NO_BN_FUSION", "0") != "1"
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -80,13 +91,16 @@ class Engine:
             self.pk[key] = Packed(f, d)
 
     # ---- primitive units -------------------------------------------------------------------------
-    def conv_dgrad(self, dy, wkey, ks, stride, pad, xshape, residual=None, dilation=1):
+    def conv_dgrad(self, dy, wkey, ks, stride, pad, xshape, residual=None, dilation=1, gate=None):
+        """data gradient of a convolution; with `gate` (the .gate of the BN layer that produced this conv's input) the
+        result is a Gated pair instead of the plain gradient"""
         N, H, W, Cin = xshape
         flops = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * self.shapes[wkey][0] * Cin * ks * ks   # algorithmic
         if stride == 2:
             dy = ops.zero_insert2(dy, H, W)
-        return ops.conv2d(dy, self.pk[wkey].dgrad, Cin, ks, 1, dilation * (ks - 1) - pad, residual=residual,
-                          out_hw=(H, W), alg_flops=flops, dilation=dilation)
+        r = ops.conv2d(dy, self.pk[wkey].dgrad, Cin, ks, 1, dilation * (ks - 1) - pad, residual=residual,
+                       out_hw=(H, W), alg_flops=flops, dilation=dilation, gate=gate)
+        return Gated(*r) if gate is not None else r
 
     def conv_bn(self, x, wkey, bnkey, ks, stride, pad, groups, relu, residual=None, dilation=1):
         cout = self.shapes[wkey][0]
@@ -110,15 +124,22 @@ class Engine:
             return out, None
         has_res = residual is not None
 
-        def bwd(dout, need_dx=True, dx_res=None):
-            r = ops.bn_bwd(dout, out if relu else None, y, mean, invstd, gamma, self.g[bnkey + ".weight"],
-                           self.g[bnkey + ".bias"], groups, accumulate=True, want_dres=has_res)
-            dy, dres = r if has_res else (r, None)
+        def bwd(dout, need_dx=True, dx_res=None, next_gate=None):
+            if isinstance(dout, Gated):       # ReLU mask and the reduction pass were done by the producer of dout
+                dy = ops.bn_bwd_from_partials(dout.g, y, dout.partial, mean, invstd, gamma, self.g[bnkey + ".weight"],
+                                              self.g[bnkey + ".bias"], groups, accumulate=True)
+                dres = dout.g if has_res else None
+            else:
+                r = ops.bn_bwd(dout, out if relu else None, y, mean, invstd, gamma, self.g[bnkey + ".weight"],
+                               self.g[bnkey + ".bias"], groups, accumulate=True, want_dres=has_res)
+                dy, dres = r if has_res else (r, None)
             ops.conv2d_wgrad(x, dy, self.g[wkey], ks, stride, pad, accumulate=True, use_tr=self.use_tr,
                              dilation=dilation)
-            dx = self.conv_dgrad(dy, wkey, ks, stride, pad, x.shape, residual=dx_res, dilation=dilation) \
-                if need_dx else None
+            dx = self.conv_dgrad(dy, wkey, ks, stride, pad, x.shape, residual=dx_res, dilation=dilation,
+                                 gate=next_gate) if need_dx else None
             return dx, dres
+        # what an upstream data-gradient launch needs to gate for this layer (None: keep the two-pass backward)
+        bwd.gate = (out if relu else None, y, mean, invstd, groups) if (self.fused_bn_bwd and cout % 16 == 0) else None
         return out, bwd
 
     def conv_act(self, x, wkey, bkey, ks, pad, act, cpad_grad=False):
@@ -179,14 +200,15 @@ class Engine:
         if not self.need_grad:
             return out, None
 
-        def bwd(dout):
-            dh, dres = b2(dout)
+        def bwd(dout, next_gate=None):
+            dh, dres = b2(dout, next_gate=b1.gate)
             if has_ds:
                 dxds, _ = bds(dres)
-                dx, _ = b1(dh, dx_res=dxds)
+                dx, _ = b1(dh, dx_res=dxds, next_gate=next_gate)
             else:
-                dx, _ = b1(dh, dx_res=dres)
+                dx, _ = b1(dh, dx_res=dres, next_gate=next_gate)
             return dx
+        bwd.gate = b2.gate
         return out, bwd
 
     def bottleneck(self, x, pfx, stride, dilation, groups):
@@ -203,15 +225,16 @@ class Engine:
         if not self.need_grad:
             return out, None
 
-        def bwd(dout):
-            dh2, dres = b3(dout)
-            dh1, _ = b2(dh2)
+        def bwd(dout, next_gate=None):
+            dh2, dres = b3(dout, next_gate=b2.gate)
+            dh1, _ = b2(dh2, next_gate=b1.gate)
             if has_ds:
                 dxds, _ = bds(dres)
-                dx, _ = b1(dh1, dx_res=dxds)
+                dx, _ = b1(dh1, dx_res=dxds, next_gate=next_gate)
             else:
-                dx, _ = b1(dh1, dx_res=dres)
+                dx, _ = b1(dh1, dx_res=dres, next_gate=next_gate)
             return dx
+        bwd.gate = b3.gate
         return out, bwd
 
     def res50_layer(self, x, li, stride, first_dilation, dilation, groups):
@@ -226,10 +249,11 @@ class Engine:
         if not self.need_grad:
             return x, None
 
-        def bwd(d):
-            for b in reversed(bwds):
-                d = b(d)
+        def bwd(d, next_gate=None):
+            for i in range(len(bwds) - 1, -1, -1):
+                d = bwds[i](d, next_gate=bwds[i - 1].gate if i > 0 else next_gate)
             return d
+        bwd.gate = bwds[-1].gate
         return x, bwd
 
     def res_layer(self, x, li, stride, groups):
@@ -237,7 +261,11 @@ class Engine:
         x, bb = self.basic_block(x, "resnet.layer%d.1" % li, 1, groups)
         if not self.need_grad:
             return x, None
-        return x, (lambda d: ba(bb(d)))
+
+        def bwd(d, next_gate=None):
+            return ba(bb(d, next_gate=ba.gate), next_gate=next_gate)
+        bwd.gate = bb.gate
+        return x, bwd
 
     # ---- transformer pieces ----------------------------------------------------------------------
     def mlp_block(self, x1, f):
@@ -419,13 +447,13 @@ class Engine:
         if not self.need_grad:
             return out, None
 
-        def bwd(dl_nchw):
+        def bwd(dl_nchw, next_gate=None):
             dl = ops.nchw_to_nhwc(dl_nchw, self.dtype, cpad=ck)          # channels zero-padded to one K-chunk
             ops.conv2d_wgrad(h, dl, self.g[wkey], 3, 1, 1, accumulate=True, use_tr=self.use_tr, cout_real=ncls)
             tmp = torch.empty(ck, dtype=torch.float32, device=h.device)
             ops.colsum(dl.view(-1, ck), tmp)
             ops.reduce_rows(tmp, 1, ncls, self.g[bkey], accumulate=True)
-            return self.conv_dgrad(dl, wkey, 3, 1, 1, h.shape)
+            return self.conv_dgrad(dl, wkey, 3, 1, 1, h.shape, gate=next_gate)
         return out, bwd
 
     def _bit(self, x1, x2):
@@ -461,7 +489,7 @@ class Engine:
             return logits, None
 
         def bwd(dl):
-            dh = b_out(dl)
+            dh = b_out(dl, next_gate=b_c0.gate)
             dupd, _ = b_c0(dh)
             dec_g = torch.empty_like(dec4)
             ops.absdiff_upsample4_bwd_into(dec4[:B], dec4[B:], dupd, dec_g[:B], dec_g[B:])
@@ -472,7 +500,7 @@ class Engine:
                               B, L, accumulate=True)
             dup = b_pred(dfeat4)
             dl3 = ops.upsample2_bwd(dup)
-            dxp = b_l1(b_l2(b_l3(dl3)))
+            dxp = b_l1(b_l2(b_l3(dl3, next_gate=b_l2.gate), next_gate=b_l1.gate))
             b_stem(ops.maxpool_bwd(xarg, dxp, x.shape))
         return logits, bwd
 
@@ -614,7 +642,7 @@ class Engine:
             dy2 = bu2(do2)                                     # grad of (conv_layer2_0 out + o3)
             ops.conv2d_wgrad(y, dy2, self.g["conv_layer2_0.3.weight"], 3, 1, 1, accumulate=True, use_tr=self.use_tr)
             ops.colsum(dy2.view(-1, 32), self.g["conv_layer2_0.3.bias"], accumulate=True)
-            dy = self.conv_dgrad(dy2, "conv_layer2_0.3.weight", 3, 1, 1, y.shape)
+            dy = self.conv_dgrad(dy2, "conv_layer2_0.3.weight", 3, 1, 1, y.shape, gate=b20.gate)
             dcat2, _ = b20(dy)
             ds2 = torch.empty_like(s2)
             ops.copy_channels(dcat2, 0, ds2[:B], 0, c2)

@@ -88,9 +88,20 @@ def pack_weight(w, dtype, want_dgrad=True, dgrad_inner=0, out_scale=None):
 PROFILE = None       # set to {} by bench.py to collect (events, algorithmic flops, bytes) per conv launch
 
 
+def _gate_args(gate):
+    if gate is None:
+        return _vp(0), _vp(0), _vp(0), _vp(0), _ci(0)
+    out_relu, y, mean, invstd, groups = gate
+    return P(out_relu), P(y), P(mean), P(invstd), _ci(groups)
+
+
 def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT_NONE, want_stats=False,
-           want_preact=False, npix_valid=0, w_image_stride=0, out_hw=None, alg_flops=0, dilation=1):
+           want_preact=False, npix_valid=0, w_image_stride=0, out_hw=None, alg_flops=0, dilation=1, gate=None):
+    """gate = (out_relu | None, y_pre_bn, mean, invstd, groups): BN-backward gating of a data-gradient launch; the
+    call then returns (g, partials) for bn_bwd_from_partials (see include/dahitra_hip.h)."""
     N, H, W, Cin = x.shape
+    if gate is not None:
+        want_stats = True
     if out_hw is None:
         OH = (H + 2 * pad - dilation * (ks - 1) - 1) // stride + 1
         OW = (W + 2 * pad - dilation * (ks - 1) - 1) // stride + 1
@@ -114,7 +125,7 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
         ev[0].record()
     _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
           _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
-          _cl(w_image_stride), P(pre), _ci(dilation), S())
+          _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), S())
     if ev is not None:
         ev[1].record()
     out = [y]
@@ -142,7 +153,7 @@ def linear(x2d, wp, cout, bias=None, residual=None, act=ACT_NONE, want_preact=Fa
     pre = torch.empty_like(y) if want_preact else None
     _call("dh_conv2d_fwd", _ci(dt(x2d)), P(x2d), P(wp), P(y), P(bias), P(residual), _vp(0), _ci(images), _ci(Hh),
           _ci(16), _ci(Cin), _ci(Hh), _ci(16), _ci(cout), _ci(cpad), _ci(1), _ci(1), _ci(0), _ci(act), _ci(rpi),
-          _cl(w_image_stride), P(pre), _ci(1), S())
+          _cl(w_image_stride), P(pre), _ci(1), *_gate_args(None), S())
     # note: with rows_per_image % 16 != 0 the image stride used by the kernel (Hh*16 rows) would differ
     # from rpi; callers guarantee rpi % 16 == 0 whenever images > 1.
     assert images == 1 or rpi % 16 == 0
@@ -249,6 +260,19 @@ def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accu
     _call("dh_bn_bwd", _ci(dt(x)), P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
           _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(ws), S())
     return (dx, dres) if want_dres else dx
+
+
+def bn_bwd_from_partials(g, x, partial, mean, invstd, gamma, dgamma, dbeta, groups=1, accumulate=False):
+    """BN backward fed by a gated data-gradient launch (conv2d(..., gate=...)): g already carries the ReLU mask"""
+    C = x.shape[-1]
+    npix = x.numel() // C
+    nt, _, cp = partial.shape
+    assert cp == C and g.shape == x.shape
+    dx = torch.empty_like(x)
+    ws = workspace(groups * 2 * C * 4, x.device)
+    _call("dh_bn_bwd_from_partials", _ci(dt(x)), P(g), P(x), P(partial), _ci(nt), P(mean), P(invstd), P(gamma), _cl(npix),
+          _ci(C), _ci(groups), P(dx), P(dgamma), P(dbeta), _ci(int(accumulate)), P(ws), S())
+    return dx
 
 
 def layernorm(x2d, gamma, beta, eps=1e-5, want_stats=True):

@@ -49,7 +49,14 @@ void dh_set_error(const char* msg);
 int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const float* bias,
                   const void* residual, float* stats_partial, int N, int H, int W, int Cin, int OH, int OW,
                   int Cout, int CoutPad, int ks, int stride, int pad, int act, int npix_valid,
-                  long w_image_stride, void* y_preact, int dilation, void* stream);
+                  long w_image_stride, void* y_preact, int dilation, const void* gate_out, const void* gate_y,
+                  const float* gate_mean, const float* gate_invstd, int gate_groups, void* stream);
+/* gate_* (all NULL / 0 = off): BatchNorm-backward gating of a data-gradient launch.  gate_y / gate_out are the
+ * pre-normalisation input and the post-ReLU output (NULL: no ReLU) of the BN layer whose output gradient this launch
+ * produces ([N][OH][OW][Cout] like y), gate_mean / gate_invstd its batch statistics [gate_groups][Cout].  The
+ * epilogue then stores g = dout * (gate_out > 0) and writes stats_partial[tile] = (sum g, sum g * xhat), which
+ * dh_bn_bwd_from_partials consumes (replaces the reduction pass of dh_bn_bwd; torch autograd's native_batch_norm
+ * backward + threshold_backward, called from models/resnet.py:58-73 via loss.backward()). */
 int dh_conv2d_fwd_num_tiles(int N, int OH, int OW, int Cin, int ks, int stride);
 
 /* weight gradient (autograd convolution_backward / mm for nn.Linear): groups == 1 writes the
@@ -85,6 +92,9 @@ int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, const void* x, 
               const float* invstd, const float* gamma, long npix, int C, int groups, void* dx, void* dres,
               float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream);
 long dh_bn_bwd_workspace_size(long npix, int C, int groups);
+int dh_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* partial, int ntiles, const float* mean,
+                            const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
+                            float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream);
 int dh_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                      long rows, int C, float eps, void* stream);
 int dh_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx,

@@ -358,3 +358,32 @@ def test_cross_entropy_branch_and_dice_constant(ops):
         assert not got.requires_grad
     empty = torch.zeros(2, 1, 32, 32, dtype=torch.long)
     assert float(losses.diceloss(torch.randn(2, 2, 32, 32, generator=g).cuda(), empty.cuda())) == 0.0   # empty-target mask
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_backward_gated_in_the_dgrad_epilogue_equals_two_pass(ops, dtype, relu):
+    """conv2d(..., gate=...) + bn_bwd_from_partials against the separate (conv2d -> bn_bwd) passes, two BN groups"""
+    N, H, W, Cin, Cout = 4, 24, 40, 64, 64           # the data-gradient conv maps Cout -> Cin; BN layer has Cin channels
+    dy = dev(rnd((N, H, W, Cout), dtype, 201), dtype)
+    w = rnd((Cin, Cout, 3, 3), dtype, 202, (Cout * 9) ** -0.5)
+    wp, _ = ops.pack_weight(w.cuda(), dtype, want_dgrad=False)
+    res = dev(rnd((N, H, W, Cin), dtype, 203), dtype)
+    y_pre = dev(rnd((N, H, W, Cin), dtype, 204, 1.5), dtype)
+    groups = 2
+    mean = rnd((groups, Cin), torch.float32, 205, 0.2).cuda()
+    invstd = (rnd((groups, Cin), torch.float32, 206, 0.1) + 0.8).cuda()
+    gamma = (rnd((Cin,), torch.float32, 207, 0.1) + 1.0).cuda()
+    out = torch.relu(dev(rnd((N, H, W, Cin), dtype, 208), dtype)) if relu else None
+    # two-pass reference path
+    dout = ops.conv2d(dy, wp, Cin, 3, 1, 1, residual=res)
+    dg0, db0 = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+    dx0, dres0 = ops.bn_bwd(dout, out, y_pre, mean, invstd, gamma, dg0, db0, groups, accumulate=False, want_dres=True)
+    # gated path
+    g, part = ops.conv2d(dy, wp, Cin, 3, 1, 1, residual=res, gate=(out, y_pre, mean, invstd, groups))
+    dg1, db1 = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+    dx1 = ops.bn_bwd_from_partials(g, y_pre, part, mean, invstd, gamma, dg1, db1, groups, accumulate=False)
+    close(g, dres0.float().cpu(), dtype, "gated g vs dres")
+    close(dg1, dg0.cpu(), dtype, "dgamma", factor=4.0)
+    close(db1, db0.cpu(), dtype, "dbeta", factor=4.0)
+    close(dx1, dx0.float().cpu(), dtype, "dx", factor=4.0)

@@ -380,3 +380,25 @@ def test_trainer_step_branches_match_oracle():
         k = "classifier.3.bias"
         got = dict(tr.net_G.named_parameters())[k].grad.cpu()
         assert float((got - st.sd[k].grad).abs().max()) <= GRAD_TOL * float(st.sd[k].grad.abs().max())
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans", R50])
+def test_bn_backward_fused_into_dgrad_equals_two_pass(name, monkeypatch):
+    """the gated data-gradient epilogue + bn_bwd_from_partials against the separate reduce / apply passes (fp32 mode)"""
+    from dahitra_amd.models import losses
+    size = 256 if name == "newUNetTrans" else 64
+    a, b, lab = O.synthetic_batch(2, size, seed=41)
+    grads = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("DAHITRA_NO_BN_FUSION", off)
+        net = make_net(name).train()
+        assert net._engine.fused_bn_bwd == (off == "0")
+        losses.focal_loss(net(a.cuda(), b.cuda()), lab.cuda()).backward()
+        grads[off] = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    assert grads["0"].keys() == grads["1"].keys()
+    worst = 0.0
+    for k, g0 in grads["1"].items():
+        s = float(g0.abs().max())
+        worst = max(worst, float((grads["0"][k] - g0).abs().max()) / max(s, 1e-20))
+    # same arithmetic, different summation order of the per-channel reductions
+    assert worst <= 2e-3, worst
