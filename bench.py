@@ -106,9 +106,9 @@ def main():
         else:
             net = define_G(types.SimpleNamespace(net_G=args.net, compute_dtype=args.dtype), gpu_ids=[local])
     net.train(not args.fwd_only)
-    use_graph = not args.no_graph and not args.fwd_only and not xbd_mode
+    use_graph = not args.no_graph and not args.fwd_only
     if xbd_mode:
-        opt = xbd.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-6)          # xBD_code/train.py:439
+        opt = xbd.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-6, capturable=use_graph)     # xBD_code/train.py:439
     else:
         opt = AdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, capturable=use_graph)
     a, b, lab = synthetic(args.batch, args.img, 1234 + rank, dev)
@@ -122,13 +122,16 @@ def main():
     parallel.broadcast_params_(net)
     graphed = None
     if use_graph:
-        from dahitra_amd.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(net, opt, a, b, lab)     # fwd + loss + bwd (+ AdamW when single process)
+        from dahitra_amd.graph import GraphedTrainStep, GraphedXbdStep
+        # fwd + loss + bwd (+ clip / AdamW when single process) recorded once, replayed per step
+        graphed = GraphedXbdStep(net, opt, x6, msk) if xbd_mode else GraphedTrainStep(net, opt, a, b, lab)
 
     def step():
         if args.fwd_only:
             with torch.no_grad():
                 return net(x6) if xbd_mode else net(a, b)
+        if graphed is not None and ops.PROFILE is None:
+            return graphed(x6, msk) if xbd_mode else graphed(a, b, lab)      # inputs already resident
         if xbd_mode:                                         # xBD_code/train.py:331-374
             net.zero_grad()
             loss = xbd.xbd_loss(net(x6), msk)
@@ -139,8 +142,6 @@ def main():
             xbd.clip_grad_norm_(net.parameters(), 0.999)
             opt.step()
             return loss
-        if graphed is not None and ops.PROFILE is None:
-            return graphed(a, b, lab)                        # inputs already resident; copied into the static buffers
         logits = net(a, b)
         opt.zero_grad()
         loss = losses.focal_loss(logits, lab)

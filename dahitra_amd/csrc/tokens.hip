@@ -200,6 +200,10 @@ struct PrepArgs {
     const void *wkT, *wvT, *woT;     // T: [32][inner], [32][inner], [inner][32]
     float *mn, *mstats, *k, *v;      // saved fp32: [S][L][32], [S][L][2], [S][L][inner] x2
     void *kq, *kqT, *vo, *voT;       // packed T: [S][HLP][32], [S][32][HLP], [S][HLP][32], [S][32][HLP]
+    // All layers of one decoder stack read the SAME tokens, so they are prepared by one launch (blockIdx.y = layer).
+    // ls_param: floats between the fp32 parameters of consecutive layers (they sit in the net's flat arena at a
+    // constant layer pitch); ls_pack: elements between the packed transposes; outputs are stacked [layer][...].
+    long ls_param, ls_pack;
 };
 
 template <typename T>
@@ -207,6 +211,17 @@ __global__ __launch_bounds__(1024) void xattn_prep_kernel(PrepArgs a) {
     extern __shared__ float sm[];
     const int s = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int L = a.L, inner = a.heads * a.dh, HL = a.heads * L;
+    {
+        const size_t ly = blockIdx.y;
+        a.ln_g += ly * a.ls_param; a.ln_b += ly * a.ls_param; a.wq += ly * a.ls_param;
+        a.wkT = reinterpret_cast<const T*>(a.wkT) + ly * a.ls_pack;
+        a.wvT = reinterpret_cast<const T*>(a.wvT) + ly * a.ls_pack;
+        a.woT = reinterpret_cast<const T*>(a.woT) + ly * a.ls_pack;
+        a.mn += ly * a.S * L * D; a.mstats += ly * a.S * L * 2;
+        a.k += ly * a.S * L * inner; a.v += ly * a.S * L * inner;
+        a.kq = reinterpret_cast<T*>(a.kq) + ly * a.S * a.HLP * D; a.kqT = reinterpret_cast<T*>(a.kqT) + ly * a.S * a.HLP * D;
+        a.vo = reinterpret_cast<T*>(a.vo) + ly * a.S * a.HLP * D; a.voT = reinterpret_cast<T*>(a.voT) + ly * a.S * a.HLP * D;
+    }
     float* smn = sm;                    // [L][32]
     float* sk = smn + L * D;            // [L][inner]
     float* sv = sk + L * inner;         // [L][inner]
@@ -288,6 +303,10 @@ struct PrepBwdArgs {
     const float *dkq, *dvoT;         // [S][HLP][32], [S][32][HLP] fp32 (per-image weight gradients)
     float *dk, *dv;                  // out [S][L][inner]
     float* ln_partial;               // out [S][2][32]  (dgamma, dbeta) contributions
+    // stacked form (blockIdx.y = layer, see PrepArgs): the layers' token gradients cannot be accumulated in place
+    // by concurrent workgroups, so each layer writes dtok_part[layer][S][L][32] and dtok_reduce_kernel adds them up
+    float* dtok_part;                // null: accumulate into dtok directly (single layer)
+    long ls_param, ls_pack;
 };
 
 template <typename T>
@@ -295,6 +314,16 @@ __global__ __launch_bounds__(1024) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
     extern __shared__ float sm[];
     const int s = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int L = a.L, inner = a.heads * a.dh;
+    {
+        const size_t ly = blockIdx.y;
+        a.ln_g += ly * a.ls_param; a.wk += ly * a.ls_param; a.wv += ly * a.ls_param; a.wo += ly * a.ls_param;
+        a.wqT = reinterpret_cast<const T*>(a.wqT) + ly * a.ls_pack;
+        a.mn += ly * a.S * L * D; a.mstats += ly * a.S * L * 2;
+        a.dkq += ly * a.S * a.HLP * D; a.dvoT += ly * a.S * a.HLP * D;
+        a.dk += ly * a.S * L * inner; a.dv += ly * a.S * L * inner;
+        a.ln_partial += ly * a.S * 2 * D;
+        if (a.dtok_part) a.dtok_part += ly * a.S * L * D;
+    }
     float* sdk = sm;                 // [L][inner]
     float* sdv = sdk + L * inner;    // [L][inner]
     float* sdmn = sdv + L * inner;   // [L][32]
@@ -363,7 +392,9 @@ __global__ __launch_bounds__(1024) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
             float sa = gh, sb = gh * xh;
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
-            stf(dm + l * D + c, ldf(dm + l * D + c) + rstd * (gh - (sa + xh * sb) * (1.f / D)));
+            const float dt = rstd * (gh - (sa + xh * sb) * (1.f / D));
+            if (a.dtok_part) a.dtok_part[((size_t)s * L + l) * D + c] = dt;
+            else stf(dm + l * D + c, ldf(dm + l * D + c) + dt);
             pg = g * xh; pb = g;
         }
         // sum the L rows' contributions per channel through LDS (rows live in different half-waves)
@@ -389,10 +420,19 @@ struct PrepWgArgs {
     const float *mn, *k, *v, *dk, *dv, *dkq, *dvoT, *ln_partial;
     float *dwq, *dwk, *dwv, *dwo, *dln_g, *dln_b;
     int accumulate;
+    long ls_param;                   // stacked form: blockIdx.z = layer (inputs stacked, gradients at the arena's layer pitch)
 };
 __global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
     __shared__ float red[8][33];
     const int inner = a.heads * a.dh, L = a.L;
+    {
+        const size_t ly = blockIdx.z;
+        a.mn += ly * a.S * L * D; a.k += ly * a.S * L * inner; a.v += ly * a.S * L * inner;
+        a.dk += ly * a.S * L * inner; a.dv += ly * a.S * L * inner;
+        a.dkq += ly * a.S * a.HLP * D; a.dvoT += ly * a.S * a.HLP * D; a.ln_partial += ly * a.S * 2 * D;
+        a.dwq += ly * a.ls_param; a.dwk += ly * a.ls_param; a.dwv += ly * a.ls_param; a.dwo += ly * a.ls_param;
+        a.dln_g += ly * a.ls_param; a.dln_b += ly * a.ls_param;
+    }
     const int c = threadIdx.x & 31, ph = threadIdx.x >> 5;
     const int which = blockIdx.y, hd = blockIdx.x;
     float acc = 0.f;
@@ -426,6 +466,16 @@ __global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
         const size_t o = which == 3 ? (size_t)c * inner + hd : (size_t)hd * D + c;     // to_out weight is [32][inner]
         if (a.accumulate) out[o] += t; else out[o] = t;
     }
+}
+
+// dtok[token rows of image s] += sum over the layers of dtok_part[layer][s]   (fixed order: deterministic)
+__global__ void dtok_reduce_kernel(const float* __restrict__ part, int layers, int S, int L, int B, long bstride,
+                                   long sstride, float* __restrict__ dtok) {
+    const int s = blockIdx.x, i = threadIdx.x;           // blockDim = L*32
+    float t = 0.f;
+    for (int ly = 0; ly < layers; ++ly) t += part[((size_t)ly * S + s) * L * D + i];
+    float* dm = dtok + (size_t)(s % B) * bstride + (size_t)(s / B) * sstride;
+    dm[i] += t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -621,25 +671,73 @@ extern "C" int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S
     return dh_reduce_partials(partial, nblk, (long)L * 32, 1.0f, dwa, accumulate, stream);
 }
 
-extern "C" int dh_xattn_prep_fwd(int dtype, const void* tok, long tok_bstride, long tok_sstride, int B, int S, int L,
-                                 int heads, int dim_head, int HLP, float scale, float eps, const float* ln_g,
-                                 const float* ln_b, const float* wq, const void* wkT, const void* wvT,
-                                 const void* woT, float* mn, float* mstats, float* k, float* v, void* kq, void* kqT,
-                                 void* vo, void* voT, void* stream) {
+// layers > 1: one launch prepares every layer of a decoder stack (same tokens): parameters ln_g / ln_b / wq (forward),
+// ln_g / wk / wv / wo and all gradient outputs (backward) are the FIRST layer's pointers, consecutive layers lie
+// param_stride floats apart (the net's flat arena); wkT / wvT / woT / wqT are stacked [layers][32*inner]; every saved /
+// output tensor is stacked [layers][...] with the single-layer shape.
+extern "C" int dh_xattn_prep_fwd_stack(int dtype, const void* tok, long tok_bstride, long tok_sstride, int B, int S, int L,
+                                       int heads, int dim_head, int HLP, float scale, float eps, int layers,
+                                       long param_stride, const float* ln_g, const float* ln_b, const float* wq,
+                                       const void* wkT, const void* wvT, const void* woT, float* mn, float* mstats,
+                                       float* k, float* v, void* kq, void* kqT, void* vo, void* voT, void* stream) {
     DH_REQUIRE(heads * L <= HLP && HLP % L == 0 && L <= 8, "xattn_prep: heads*L=%d exceeds HLP=%d (or L > 8)", heads * L, HLP);
+    DH_REQUIRE(layers >= 1, "xattn_prep: layers=%d", layers);
     PrepArgs a;
     a.tok = tok; a.tok_bstride = tok_bstride; a.tok_sstride = tok_sstride; a.B = B; a.S = S; a.L = L;
     a.heads = heads; a.dh = dim_head; a.HLP = HLP; a.scale = scale; a.eps = eps; a.ln_g = ln_g; a.ln_b = ln_b;
     a.wq = wq; a.wkT = wkT; a.wvT = wvT; a.woT = woT; a.mn = mn; a.mstats = mstats; a.k = k; a.v = v;
     a.kq = kq; a.kqT = kqT; a.vo = vo; a.voT = voT;
+    a.ls_param = param_stride; a.ls_pack = 32L * heads * dim_head;
     const size_t lds = (size_t)(L * 32 + 2 * L * heads * dim_head) * 4;
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_kernel<bf16>, dim3(S), dim3(1024), lds, ST(stream), a);
-    else hipLaunchKernelGGL(xattn_prep_kernel<float>, dim3(S), dim3(1024), lds, ST(stream), a);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_kernel<bf16>, dim3(S, layers), dim3(1024), lds, ST(stream), a);
+    else hipLaunchKernelGGL(xattn_prep_kernel<float>, dim3(S, layers), dim3(1024), lds, ST(stream), a);
     DH_CHECK_LAUNCH("xattn_prep_fwd");
     return 0;
 }
+extern "C" int dh_xattn_prep_fwd(int dtype, const void* tok, long tok_bstride, long tok_sstride, int B, int S, int L,
+                                 int heads, int dim_head, int HLP, float scale, float eps, const float* ln_g,
+                                 const float* ln_b, const float* wq, const void* wkT, const void* wvT,
+                                 const void* woT, float* mn, float* mstats, float* k, float* v, void* kq, void* kqT,
+                                 void* vo, void* voT, void* stream) {
+    return dh_xattn_prep_fwd_stack(dtype, tok, tok_bstride, tok_sstride, B, S, L, heads, dim_head, HLP, scale, eps, 1, 0,
+                                   ln_g, ln_b, wq, wkT, wvT, woT, mn, mstats, k, v, kq, kqT, vo, voT, stream);
+}
 
-// workspace: ln_partial [S][2][32] floats
+// workspace: ln_partial [layers][S][2][32] floats (+ dtok_part [layers][S][L][32] floats when layers > 1)
+extern "C" long dh_xattn_prep_bwd_stack_workspace_size(int S, int L, int layers) {
+    return ((long)layers * S * 64 + 64 + (layers > 1 ? (long)layers * S * L * 32 : 0)) * 4;
+}
+extern "C" int dh_xattn_prep_bwd_stack(int dtype, const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride,
+                                       int B, int S, int L, int heads, int dim_head, int HLP, float scale, int layers,
+                                       long param_stride, const float* ln_g, const void* wqT, const float* wk,
+                                       const float* wv, const float* wo, const float* mn, const float* mstats,
+                                       const float* k, const float* v, const float* dkq, const float* dvoT, float* dk,
+                                       float* dv, float* dln_g, float* dln_b, float* dwq, float* dwk, float* dwv,
+                                       float* dwo, int accumulate, void* workspace, void* stream) {
+    DH_REQUIRE(L <= 8 && layers >= 1, "xattn_prep_bwd: L=%d layers=%d", L, layers);
+    PrepBwdArgs a;
+    a.tok_bstride = tok_bstride; a.tok_sstride = tok_sstride; a.B = B; a.S = S; a.L = L; a.heads = heads;
+    a.dh = dim_head; a.HLP = HLP; a.scale = scale; a.tok = tok; a.dtok = dtok_accum; a.ln_g = ln_g; a.wqT = wqT;
+    a.wk = wk; a.wv = wv; a.wo = wo; a.mn = mn; a.mstats = mstats; a.dkq = dkq; a.dvoT = dvoT; a.dk = dk; a.dv = dv;
+    a.ln_partial = reinterpret_cast<float*>(workspace);
+    a.dtok_part = layers > 1 ? a.ln_partial + (long)layers * S * 64 + 64 : nullptr;
+    a.ls_param = param_stride; a.ls_pack = 32L * heads * dim_head;
+    const int inner = heads * dim_head;
+    const size_t lds = (size_t)(2 * L * inner + L * 32 + 2 * HLP * 32 + 16 * 32 + 32 * L * 32) * 4;
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_bwd_kernel<bf16>, dim3(S, layers), dim3(1024), lds, ST(stream), a);
+    else hipLaunchKernelGGL(xattn_prep_bwd_kernel<float>, dim3(S, layers), dim3(1024), lds, ST(stream), a);
+    if (layers > 1)
+        hipLaunchKernelGGL(dtok_reduce_kernel, dim3(S), dim3(L * 32), 0, ST(stream), a.dtok_part, layers, S, L, B,
+                           tok_bstride, tok_sstride, reinterpret_cast<float*>(dtok_accum));
+    PrepWgArgs w;
+    w.S = S; w.L = L; w.heads = heads; w.dh = dim_head; w.HLP = HLP; w.scale = scale; w.mn = mn; w.k = k; w.v = v;
+    w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;
+    w.ln_partial = a.ln_partial; w.dln_g = dln_g; w.dln_b = dln_b;
+    w.accumulate = accumulate; w.ls_param = param_stride;
+    hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(inner, 5, layers), dim3(256), 0, ST(stream), w);
+    DH_CHECK_LAUNCH("xattn_prep_bwd");
+    return 0;
+}
 extern "C" int dh_xattn_prep_bwd(int dtype, const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride,
                                  int B, int S, int L, int heads, int dim_head, int HLP, float scale,
                                  const float* ln_g, const void* wqT, const float* wk, const float* wv,
@@ -647,24 +745,9 @@ extern "C" int dh_xattn_prep_bwd(int dtype, const void* tok, void* dtok_accum, l
                                  const float* v, const float* dkq, const float* dvoT, float* dk, float* dv,
                                  float* dln_g, float* dln_b, float* dwq, float* dwk, float* dwv, float* dwo,
                                  int accumulate, void* workspace, void* stream) {
-    DH_REQUIRE(L <= 8, "xattn_prep_bwd: L=%d > 8", L);
-    PrepBwdArgs a;
-    a.tok_bstride = tok_bstride; a.tok_sstride = tok_sstride; a.B = B; a.S = S; a.L = L; a.heads = heads;
-    a.dh = dim_head; a.HLP = HLP; a.scale = scale; a.tok = tok; a.dtok = dtok_accum; a.ln_g = ln_g; a.wqT = wqT;
-    a.wk = wk; a.wv = wv; a.wo = wo; a.mn = mn; a.mstats = mstats; a.dkq = dkq; a.dvoT = dvoT; a.dk = dk; a.dv = dv;
-    a.ln_partial = reinterpret_cast<float*>(workspace);
-    const int inner = heads * dim_head;
-    const size_t lds = (size_t)(2 * L * inner + L * 32 + 2 * HLP * 32 + 16 * 32 + 32 * L * 32) * 4;
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_bwd_kernel<bf16>, dim3(S), dim3(1024), lds, ST(stream), a);
-    else hipLaunchKernelGGL(xattn_prep_bwd_kernel<float>, dim3(S), dim3(1024), lds, ST(stream), a);
-    PrepWgArgs w;
-    w.S = S; w.L = L; w.heads = heads; w.dh = dim_head; w.HLP = HLP; w.scale = scale; w.mn = mn; w.k = k; w.v = v;
-    w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;
-    w.ln_partial = a.ln_partial; w.dln_g = dln_g; w.dln_b = dln_b;
-    w.accumulate = accumulate;
-    hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(inner, 5), dim3(256), 0, ST(stream), w);
-    DH_CHECK_LAUNCH("xattn_prep_bwd");
-    return 0;
+    return dh_xattn_prep_bwd_stack(dtype, tok, dtok_accum, tok_bstride, tok_sstride, B, S, L, heads, dim_head, HLP, scale, 1,
+                                   0, ln_g, wqT, wk, wv, wo, mn, mstats, k, v, dkq, dvoT, dk, dv, dln_g, dln_b, dwq, dwk,
+                                   dwv, dwo, accumulate, workspace, stream);
 }
 extern "C" long dh_xattn_prep_bwd_workspace_size(int S) { return ((long)S * 64 + 64) * 4; }
 

@@ -137,6 +137,31 @@ __global__ void adamw_xbd_kernel(float* __restrict__ p, const float* __restrict_
     }
 }
 
+// HIP-graph form: hyper = [lr, beta1, beta2, eps, weight_decay, -, step_size (out)], step counter on the device
+__global__ void adamw_xbd_tick_kernel(float* hyper, int* step) {
+    const int s = *step + 1;
+    *step = s;
+    const double bc1 = 1.0 - pow((double)hyper[1], (double)s), bc2 = 1.0 - pow((double)hyper[2], (double)s);
+    hyper[6] = (float)((double)hyper[0] * sqrt(bc2) / bc1);
+}
+__global__ void adamw_xbd_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                     float* __restrict__ v, long n, const float* __restrict__ hyper,
+                                     const float* __restrict__ grad_scale_dev) {
+    const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4], step_size = hyper[6];
+    const float gs = grad_scale_dev ? *grad_scale_dev : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * gs;
+        const float mm = m[i] * beta1 + (1.f - beta1) * gr;
+        const float vv = v[i] * beta2 + (1.f - beta2) * gr * gr;
+        m[i] = mm;
+        v[i] = vv;
+        float w = p[i];
+        if (wd != 0.f) w += (-wd * lr) * w;
+        w += -step_size * (mm / (sqrtf(vv) + eps));
+        p[i] = w;
+    }
+}
+
 inline hipStream_t ST(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
@@ -198,5 +223,17 @@ extern "C" int dh_adamw_xbd_step(float* param, const float* grad, float* exp_avg
     hipLaunchKernelGGL(adamw_xbd_kernel, dim3((int)g), dim3(256), 0, ST(stream), param, grad, exp_avg, exp_avg_sq, n, lr,
                        beta1, beta2, eps, weight_decay, step_size, grad_scale_dev);
     DH_CHECK_LAUNCH("adamw_xbd");
+    return 0;
+}
+
+extern "C" int dh_adamw_xbd_step_graph(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                                       float* hyper_dev, int* step_dev, const float* grad_scale_dev, void* stream) {
+    if (n == 0) return 0;
+    long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(adamw_xbd_tick_kernel, dim3(1), dim3(1), 0, ST(stream), hyper_dev, step_dev);
+    hipLaunchKernelGGL(adamw_xbd_dev_kernel, dim3((int)g), dim3(256), 0, ST(stream), param, grad, exp_avg, exp_avg_sq, n,
+                       hyper_dev, grad_scale_dev);
+    DH_CHECK_LAUNCH("adamw_xbd_graph");
     return 0;
 }

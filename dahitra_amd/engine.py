@@ -61,6 +61,7 @@ class Engine:
     def _pack_all(self):
         ck = ops.chunk_channels(self.dtype)
         self.pk = {}
+        self.xstack = {}       # (decoder prefix, matrix) -> stacked transposes [depth, 32*inner]
         for key, shape in self.shapes.items():
             if key not in self.p or not key.endswith("weight") or len(shape) not in (2, 4):
                 continue
@@ -74,8 +75,19 @@ class Engine:
                 continue        # consumed in fp32 by the tokenizer kernels, or unused by the forward
             if ".to_q." in key or ".to_k." in key or ".to_v." in key or \
                     (".to_out." in key and "transformer_decoder" in key):
-                # cross-attention weights: the token-side prep reads their transposes (coalesced)
-                self.pk[key] = Packed(None, ops.pack_weight(self.p[key], self.dtype, want_dgrad=True)[1])
+                # cross-attention weights: the token-side prep reads their transposes (coalesced).  The transposes of
+                # one decoder stack live in ONE [depth, 32*inner] buffer per matrix, so that a single launch can
+                # prepare every layer (ops.XattnPrepStack); the per-layer views serve the layer-at-a-time path.
+                pfx, rest = key.split(".layers.")
+                li, which = int(rest.split(".")[0]), rest.split(".fn.fn.")[1]
+                skey = (pfx, which)
+                if skey not in self.xstack:
+                    depth = 1 + max(int(k.split(".layers.")[1].split(".")[0]) for k in self.shapes
+                                    if k.startswith(pfx + ".layers.") and k.endswith(which))
+                    self.xstack[skey] = torch.empty(depth, shape[0] * shape[1], dtype=self.dtype, device=self.p[key].device)
+                view = self.xstack[skey][li]
+                ops.pack_weight(self.p[key], self.dtype, want_dgrad=True, want_fwd=False, out_dgrad=view)
+                self.pk[key] = Packed(None, view)
                 continue
             O = shape[0]
             if key.startswith("transformer") and not key.startswith("transformer_decoder"):
@@ -337,12 +349,17 @@ class Engine:
         bw = []
         x = x2d
         rpi = x2d.shape[0] // images
+        mlp0 = self.shapes["%s.layers.0.1.fn.fn.net.0.weight" % pfx][0]
+        fused = self.fused_decoder and self.dtype == torch.bfloat16 and L == 4 and heads * L <= 32 and rpi % 128 == 0 \
+            and mlp0 in (32, 64)
+        stack = self._prep_stack(tok, tok_b, tok_s, B, images, L, heads, dim_head, pfx, depth) if fused and depth > 1 \
+            else None
         for i in range(depth):
             a, f = "%s.layers.%d.0.fn" % (pfx, i), "%s.layers.%d.1.fn" % (pfx, i)
             mlp = self.shapes[f + ".fn.net.0.weight"][0]
-            if self.fused_decoder and self.dtype == torch.bfloat16 and L == 4 and heads * L <= 32 and rpi % 128 == 0 \
-                    and mlp in (32, 64):
-                x, b1 = self._dec_layer_fused(x, images, rpi, tok, tok_b, tok_s, B, dtok, a, f, heads, dim_head, L, mlp)
+            if fused:
+                x, b1 = self._dec_layer_fused(x, images, rpi, tok, tok_b, tok_s, B, dtok, a, f, heads, dim_head, L, mlp,
+                                              stack=stack, li=i)
                 bw.append(b1)
                 continue
             x, b1 = self._dec_attn(x, images, tok, tok_b, tok_s, B, dtok, a, heads, dim_head, L)
@@ -354,11 +371,42 @@ class Engine:
         def bwd(d):
             for b in reversed(bw):
                 d = b(d)
+            if stack is not None:            # token-side backward of ALL layers in one pass (they stored dkq / dvoT)
+                a0 = "%s.layers.0.0.fn" % pfx
+                stack.backward(tok, dtok, self.p[a0 + ".norm.weight"], self.xstack[(pfx, "to_q.weight")],
+                               *(self.p[a0 + ".fn.to_%s.weight" % n] for n in ("k", "v", "out.0")),
+                               self.g[a0 + ".norm.weight"], self.g[a0 + ".norm.bias"],
+                               *(self.g[a0 + ".fn.to_%s.weight" % n] for n in ("q", "k", "v", "out.0")))
             return d
         return x, bwd
 
-    def _dec_layer_fused(self, x0, images, rpi, tok, tok_b, tok_s, B, dtok, a, f, heads, dim_head, L, mlp):
-        """one decoder layer = one HIP kernel per direction (csrc/decoder_fused.hip) + the per-image operand prep"""
+    def _prep_stack(self, tok, tok_b, tok_s, B, images, L, heads, dim_head, pfx, depth):
+        """ops.XattnPrepStack for the `depth` layers of decoder `pfx`, or None when the layers' parameters do not sit
+        at one constant pitch in the flat arenas (then every layer is prepared on its own)"""
+        names = ("norm.weight", "norm.bias", "fn.to_q.weight", "fn.to_k.weight", "fn.to_v.weight", "fn.to_out.0.weight")
+        key = lambda i, n: "%s.layers.%d.0.fn.%s" % (pfx, i, n)
+        stride = None
+        for table in (self.p, self.g):
+            for n in names:
+                if any(key(i, n) not in table for i in range(depth)):
+                    if table is self.g and not self.need_grad:
+                        continue
+                    return None
+                for i in range(1, depth):
+                    d = table[key(i, n)].data_ptr() - table[key(i - 1, n)].data_ptr()
+                    if d % 4 or (stride is not None and d // 4 != stride):
+                        return None
+                    stride = d // 4
+        a0 = "%s.layers.0.0.fn" % pfx
+        return ops.XattnPrepStack(tok, tok_b, tok_s, B, images, L, heads, dim_head, depth, stride,
+                                  self.p[a0 + ".norm.weight"], self.p[a0 + ".norm.bias"], self.p[a0 + ".fn.to_q.weight"],
+                                  self.xstack[(pfx, "to_k.weight")], self.xstack[(pfx, "to_v.weight")],
+                                  self.xstack[(pfx, "to_out.0.weight")], self.dtype, ATTN_SCALE, LN_EPS)
+
+    def _dec_layer_fused(self, x0, images, rpi, tok, tok_b, tok_s, B, dtok, a, f, heads, dim_head, L, mlp, stack=None,
+                         li=0):
+        """one decoder layer = one HIP kernel per direction (csrc/decoder_fused.hip) + the per-image operand prep
+        (`stack`: prepared for all layers at once by ops.XattnPrepStack; its backward runs once after the last layer)"""
         g1, b1 = self.p[a + ".norm.weight"], self.p[a + ".norm.bias"]
         wq, wk, wv = (self.p[a + ".fn.to_%s.weight" % n] for n in "qkv")
         wo, bo = self.p[a + ".fn.to_out.0.weight"], self.p[a + ".fn.to_out.0.bias"]
@@ -367,8 +415,9 @@ class Engine:
         fb1, fb2 = self.p[f + ".fn.net.0.bias"], self.p[f + ".fn.net.3.bias"]
         wqT, wkT, wvT = (self.pk[a + ".fn.to_%s.weight" % n].dgrad for n in "qkv")
         woT = self.pk[a + ".fn.to_out.0.weight"].dgrad
-        prep = ops.XattnPrep(tok, tok_b, tok_s, B, images, L, heads, dim_head, g1, b1, wq, wkT, wvT, woT, self.dtype,
-                             ATTN_SCALE, LN_EPS)
+        prep = stack.layer(li) if stack is not None else \
+            ops.XattnPrep(tok, tok_b, tok_s, B, images, L, heads, dim_head, g1, b1, wq, wkT, wvT, woT, self.dtype,
+                          ATTN_SCALE, LN_EPS)
         y = ops.decoder_layer_fwd(x0, prep, rpi, g1, b1, bo, g2, b2, self.pk[w1k].fwd, fb1, self.pk[w2k].fwd, fb2, mlp,
                                   LN_EPS)
         if not self.need_grad:
@@ -378,6 +427,11 @@ class Engine:
             grads = (self.g[w1k], self.g[w2k], self.g[f + ".fn.net.0.bias"], self.g[f + ".fn.net.3.bias"],
                      self.g[a + ".fn.to_out.0.bias"], self.g[a + ".norm.weight"], self.g[a + ".norm.bias"],
                      self.g[f + ".norm.weight"], self.g[f + ".norm.bias"])
+            if stack is not None:
+                dx, _, _ = ops.decoder_layer_bwd(x0, dy, prep, rpi, g1, b1, bo, g2, b2, self.pk[w1k].fwd,
+                                                 self.pk[w1k].dgrad, fb1, self.pk[w2k].fwd, self.pk[w2k].dgrad, fb2,
+                                                 grads, mlp, LN_EPS, dkq=stack.dkq[li], dvoT=stack.dvoT[li])
+                return dx
             dx, dkq, dvoT = ops.decoder_layer_bwd(x0, dy, prep, rpi, g1, b1, bo, g2, b2, self.pk[w1k].fwd,
                                                   self.pk[w1k].dgrad, fb1, self.pk[w2k].fwd, self.pk[w2k].dgrad, fb2,
                                                   grads, mlp, LN_EPS)

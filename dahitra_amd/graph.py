@@ -22,7 +22,7 @@ class GraphedTrainStep:
             raise ValueError("GraphedTrainStep needs dahitra_amd.optim.AdamW(..., capturable=True)")
         self.net, self.opt = net, opt
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.a, self.b, self.lab = a.clone(), b.clone(), lab.clone()
+        self._set_inputs(a, b, lab)
         net._ensure_arena(a.device)
         # ---- snapshot the training state, warm up eagerly on a side stream, restore -------------------
         flat0 = net._arena.flat.clone()
@@ -47,6 +47,14 @@ class GraphedTrainStep:
             self.loss = self._eager_body(include_opt=self.world == 1)
         torch.cuda.synchronize()
 
+    def _set_inputs(self, a, b, lab):
+        self.a, self.b, self.lab = a.clone(), b.clone(), lab.clone()
+
+    def _copy_inputs(self, a, b, lab):
+        self.a.copy_(a, non_blocking=True)
+        self.b.copy_(b, non_blocking=True)
+        self.lab.copy_(lab, non_blocking=True)
+
     def _eager_body(self, include_opt):
         logits = self.net(self.a, self.b)
         self.opt.zero_grad()
@@ -56,14 +64,54 @@ class GraphedTrainStep:
             self.opt.step()
         return loss.detach()
 
-    def __call__(self, a=None, b=None, lab=None):
-        if a is not None:
-            self.a.copy_(a, non_blocking=True)
-            self.b.copy_(b, non_blocking=True)
-            self.lab.copy_(lab, non_blocking=True)
+    def _after_replay(self):
+        """world > 1: the exchange step and the update run eagerly after the replayed forward/backward"""
+        parallel.allreduce_net_grads_(self.net)
+        self.opt.step()
+
+    def __call__(self, *inputs):
+        if inputs and inputs[0] is not None:
+            self._copy_inputs(*inputs)
         self.opt.sync_hyper(1.0 / self.world)
         self.graph.replay()
         if self.world > 1:
-            parallel.allreduce_net_grads_(self.net)
-            self.opt.step()
+            self._after_replay()
         return self.loss
+
+
+class GraphedXbdStep(GraphedTrainStep):
+    """The xBD step (xBD_code/train.py:331-374) as one HIP graph: forward of the 6-channel model, the five weighted
+    ComboLoss terms, backward, clip_grad_norm_(0.999) and the hand-rolled AdamW.
+
+        step = GraphedXbdStep(net, xbd.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-6, capturable=True), imgs, msks)
+        loss = step(imgs, msks)"""
+
+    def __init__(self, net, opt, imgs, msks, max_norm=0.999, warmup=3):
+        self.max_norm = max_norm
+        super().__init__(net, opt, imgs, None, msks, warmup=warmup)
+
+    def _set_inputs(self, imgs, _unused, msks):
+        self.a, self.lab = imgs.clone(), msks.clone()
+
+    def _copy_inputs(self, imgs, msks):
+        self.a.copy_(imgs, non_blocking=True)
+        self.lab.copy_(msks, non_blocking=True)
+
+    def _eager_body(self, include_opt):
+        from .models import xbd
+        self.net.zero_grad()
+        loss = xbd.xbd_loss(self.net(self.a), self.lab)
+        loss.backward()
+        if include_opt:
+            xbd.clip_grad_norm_(self.net.parameters(), self.max_norm)
+            self.opt.step()
+        return loss.detach()
+
+    def _after_replay(self):
+        from . import ops
+        from .models import xbd
+        scale = parallel.allreduce_net_grads_(self.net)
+        _, grad = self.net.flat_params()
+        ops.scale_into(grad, torch.tensor([scale], device=grad.device), grad)     # mean over ranks before the clip
+        xbd.clip_grad_norm_(self.net.parameters(), self.max_norm)
+        self.opt.step()

@@ -16,6 +16,7 @@ from ..optim import AdamW as _ArenaAdamW
 from .networks import CDNet
 
 CHANNEL_WEIGHTS = (0.05, 0.2, 0.8, 0.7, 0.4)          # xBD_code/train.py:353
+_weights = {}
 
 
 def BASE_Transformer_UNet(input_nc=3, output_nc=5, with_pos='learned', resnet_stages_num=4, token_len=4, token_trans=True,
@@ -80,7 +81,10 @@ class ComboLoss(nn.Module):
         lo = outputs.float().contiguous()
         lo = lo.unsqueeze(1) if lo.dim() == 3 else lo
         ta = targets.float().contiguous().view(lo.shape)
-        ones = torch.ones(lo.shape[1], dtype=torch.float32, device=lo.device)
+        key = (str(lo.device), (1.0,) * lo.shape[1])
+        ones = _weights.get(key)
+        if ones is None:
+            ones = _weights[key] = torch.ones(lo.shape[1], dtype=torch.float32, device=lo.device)
         loss, _ = _Combo.apply(lo, ta, ones, float(self.weights.get("dice", 0)), float(self.weights.get("focal", 0)))
         return loss
 
@@ -88,7 +92,10 @@ class ComboLoss(nn.Module):
 def xbd_loss(out, msks, channel_weights=CHANNEL_WEIGHTS, dice=1.0, focal=8.0, want_channels=False):
     """train.py:348-353 in one pass: sum_c w_c * ComboLoss{dice:1, focal:8}(out[:, c], msks[:, c])"""
     _check(out, msks)
-    w = torch.tensor(channel_weights, dtype=torch.float32, device=out.device)
+    key = (str(out.device), tuple(float(v) for v in channel_weights))
+    w = _weights.get(key)
+    if w is None:                    # cached: no host-to-device copy inside a HIP-graph capture
+        w = _weights[key] = torch.tensor(key[1], dtype=torch.float32, device=out.device)
     loss, channel = _Combo.apply(out.float().contiguous(), msks.float().contiguous(), w, float(dice), float(focal))
     return (loss, channel) if want_channels else loss
 
@@ -117,5 +124,5 @@ class AdamW(_ArenaAdamW):
     w -= weight_decay * lr * w before the Adam term.  One launch over the net's flat arena."""
     _rule = "xbd"
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
-        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=False)
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, capturable=False):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable)

@@ -67,9 +67,10 @@ def pad16(c):
 
 
 # ---- weights -------------------------------------------------------------------------------------
-def pack_weight(w, dtype, want_dgrad=True, dgrad_inner=0, out_scale=None):
+def pack_weight(w, dtype, want_dgrad=True, dgrad_inner=0, out_scale=None, want_fwd=True, out_dgrad=None):
     """w: OIHW (or [O, I]) fp32 master.  Returns (fwd [taps, OPad, I], dgrad [taps, IPad, OK] | None).
-    out_scale [O]: per-output-channel factor folded into the forward form (eval-mode BatchNorm)."""
+    out_scale [O]: per-output-channel factor folded into the forward form (eval-mode BatchNorm).
+    out_dgrad: write the data-gradient form into this (contiguous) buffer instead of a fresh one."""
     if w.dim() == 2:
         O, I = w.shape
         ks = 1
@@ -77,8 +78,12 @@ def pack_weight(w, dtype, want_dgrad=True, dgrad_inner=0, out_scale=None):
         O, I, ks, _ = w.shape
     OPad, IPad = pad16(O), pad16(I)
     OK = max(O, dgrad_inner)
-    fwd = torch.empty(ks * ks, OPad, I, dtype=dtype, device=w.device)
-    dg = torch.empty(ks * ks, IPad, OK, dtype=dtype, device=w.device) if want_dgrad else None
+    fwd = torch.empty(ks * ks, OPad, I, dtype=dtype, device=w.device) if want_fwd else None
+    if out_dgrad is not None:
+        assert out_dgrad.numel() == ks * ks * IPad * OK and out_dgrad.dtype == dtype
+        dg = out_dgrad
+    else:
+        dg = torch.empty(ks * ks, IPad, OK, dtype=dtype, device=w.device) if want_dgrad else None
     _call("dh_pack_weight", _ci(_DT[dtype]), P(w), P(out_scale), _ci(O), _ci(I), _ci(ks), _ci(OPad), P(fwd), _ci(IPad), _ci(OK),
           P(dg), S())
     return fwd, dg
@@ -465,6 +470,63 @@ class XattnPrep:
               P(self.voT), S())
 
 
+class _PrepView:
+    """one layer of an XattnPrepStack, with the attributes of XattnPrep"""
+    __slots__ = ("mn", "mstats", "k", "v", "kq", "kqT", "vo", "voT", "HLP", "args", "scale")
+
+
+class XattnPrepStack:
+    """XattnPrep for ALL layers of a decoder stack in one launch (they read the same tokens).  ln_g0 / ln_b0 / wq0 are
+    the first layer's fp32 parameters, consecutive layers lie `param_stride` floats apart (the net's flat arena);
+    wkT / wvT / woT are stacked [layers, 32 * inner] transposes in `dtype`."""
+
+    def __init__(self, tok, bstride, sstride, B, Sn, L, heads, dim_head, layers, param_stride, ln_g0, ln_b0, wq0, wkT, wvT,
+                 woT, dtype, scale=32 ** -0.5, eps=1e-5):
+        dev = tok.device
+        assert tok.dtype == torch.float32, "tokens are fp32 in every compute mode"
+        inner = heads * dim_head
+        self.layers, self.param_stride, self.dtype = layers, param_stride, dtype
+        self.HLP = cdiv(heads * L, 32) * 32
+        self.args = (bstride, sstride, B, Sn, L, heads, dim_head)
+        self.scale = scale
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.mn = torch.empty(layers, Sn, L, 32, **f32)
+        self.mstats = torch.empty(layers, Sn, L, 2, **f32)
+        self.k = torch.empty(layers, Sn, L, inner, **f32)
+        self.v = torch.empty_like(self.k)
+        self.kq = torch.empty(layers, Sn, self.HLP, 32, dtype=dtype, device=dev)
+        self.kqT = torch.empty(layers, Sn, 32, self.HLP, dtype=dtype, device=dev)
+        self.vo = torch.empty_like(self.kq)
+        self.voT = torch.empty_like(self.kqT)
+        # per-image weight gradients of every layer, filled by the layers' backward kernels
+        self.dkq = torch.empty(layers, Sn, self.HLP, 32, **f32)
+        self.dvoT = torch.empty(layers, Sn, 32, self.HLP, **f32)
+        _call("dh_xattn_prep_fwd_stack", _ci(_DT[dtype]), P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(L),
+              _ci(heads), _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), _ci(layers), _cl(param_stride), P(ln_g0),
+              P(ln_b0), P(wq0), P(wkT), P(wvT), P(woT), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq),
+              P(self.kqT), P(self.vo), P(self.voT), S())
+
+    def layer(self, i):
+        v = _PrepView()
+        for n in ("mn", "mstats", "k", "v", "kq", "kqT", "vo", "voT"):
+            setattr(v, n, getattr(self, n)[i])
+        v.HLP, v.args, v.scale = self.HLP, self.args, self.scale
+        return v
+
+    def backward(self, tok, dtok_accum, ln_g0, wqT, wk0, wv0, wo0, dln_g0, dln_b0, dwq0, dwk0, dwv0, dwo0):
+        """after every layer's backward stored its dkq / dvoT: token gradient (accumulated into dtok_accum), the
+        to_q / to_k / to_v / to_out weight gradients and the shared LayerNorm's, for all layers, in one pass"""
+        bstride, sstride, B, Sn, L, heads, dim_head = self.args
+        dk = torch.empty_like(self.k)
+        dv = torch.empty_like(self.v)
+        ws = workspace(_lib.lib().dh_xattn_prep_bwd_stack_workspace_size(Sn, L, self.layers), tok.device)
+        _call("dh_xattn_prep_bwd_stack", _ci(_DT[self.dtype]), P(tok), P(dtok_accum), _cl(bstride), _cl(sstride), _ci(B),
+              _ci(Sn), _ci(L), _ci(heads), _ci(dim_head), _ci(self.HLP), _cf(self.scale), _ci(self.layers),
+              _cl(self.param_stride), P(ln_g0), P(wqT), P(wk0), P(wv0), P(wo0), P(self.mn), P(self.mstats), P(self.k),
+              P(self.v), P(self.dkq), P(self.dvoT), P(dk), P(dv), P(dln_g0), P(dln_b0), P(dwq0), P(dwk0), P(dwv0),
+              P(dwo0), _ci(1), P(ws), S())
+
+
 def xattn_prep_bwd(prep, tok, dtok_accum, ln_g, wqT, wk, wv, wo, dkq, dvoT, dln_g, dln_b, dwq, dwk, dwv, dwo,
                    accumulate, dtype):
     bstride, sstride, B, Sn, L, heads, dim_head = prep.args
@@ -487,14 +549,15 @@ def decoder_layer_fwd(x2d, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b,
 
 
 def decoder_layer_bwd(x2d, dy, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b, w1, w1T, b1, w2, w2T, b2, grads, mlp,
-                      eps=1e-5):
+                      eps=1e-5, dkq=None, dvoT=None):
     """returns (dx, dkq [S,32,32] fp32, dvoT [S,32,32] fp32); grads = (dw1, dw2, db1, db2, dbo, dg1, dbe1, dg2, dbe2)
     are accumulated in place"""
     rows = x2d.shape[0]
     images = rows // rows_per_image
     dx = torch.empty_like(x2d)
-    dkq = torch.empty(images, 32, 32, dtype=torch.float32, device=x2d.device)
-    dvoT = torch.empty(images, 32, 32, dtype=torch.float32, device=x2d.device)
+    if dkq is None:
+        dkq = torch.empty(images, 32, 32, dtype=torch.float32, device=x2d.device)
+        dvoT = torch.empty(images, 32, 32, dtype=torch.float32, device=x2d.device)
     ws = workspace(_lib.lib().dh_decoder_layer_bwd_workspace_size(_cl(rows), rows_per_image, mlp), x2d.device)
     _call("dh_decoder_layer_bwd", P(x2d), P(dy), P(dx), P(prep.kq), P(prep.voT), P(prep.vo), P(prep.kqT), P(ln1_g),
           P(ln1_b), P(bo), P(ln2_g), P(ln2_b), P(w1), P(w1T), P(b1), P(w2), P(w2T), P(b2), *(P(t) for t in grads),

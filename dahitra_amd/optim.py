@@ -81,8 +81,12 @@ class AdamW(torch.optim.Optimizer):
                 if self.capturable:
                     if st[4] is None:
                         self.sync_hyper(grad_scale)
-                    ops._call("dh_adamw_step_graph", ops.P(param), ops.P(grad), ops.P(st[0]), ops.P(st[1]),
-                              ctypes.c_long(param.numel()), ops.P(st[3]), ops.P(st[2]), ops.S())
+                    if self._rule == "xbd":
+                        ops._call("dh_adamw_xbd_step_graph", ops.P(param), ops.P(grad), ops.P(st[0]), ops.P(st[1]),
+                                  ctypes.c_long(param.numel()), ops.P(st[3]), ops.P(st[2]), ops.P(None), ops.S())
+                    else:
+                        ops._call("dh_adamw_step_graph", ops.P(param), ops.P(grad), ops.P(st[0]), ops.P(st[1]),
+                                  ctypes.c_long(param.numel()), ops.P(st[3]), ops.P(st[2]), ops.S())
                 else:
                     st[2] += 1
                     self._launch(param, grad, st[0], st[1], group, st[2], grad_scale)

@@ -138,6 +138,21 @@ int dh_xattn_prep_fwd(int dtype, const void* tok, long tok_bstride, long tok_sst
                       int dim_head, int HLP, float scale, float eps, const float* ln_g, const float* ln_b,
                       const float* wq, const void* wkT, const void* wvT, const void* woT, float* mn, float* mstats,
                       float* k, float* v, void* kq, void* kqT, void* vo, void* voT, void* stream);
+/* stacked forms: ONE launch prepares all `layers` of a decoder stack (they read the same tokens).  Parameter /
+ * gradient pointers are the first layer's, consecutive layers lie param_stride floats apart (the net's flat arena);
+ * wkT / wvT / woT / wqT and every saved / output tensor are stacked [layers][single-layer shape]. */
+int dh_xattn_prep_fwd_stack(int dtype, const void* tok, long tok_bstride, long tok_sstride, int B, int S, int L, int heads,
+                            int dim_head, int HLP, float scale, float eps, int layers, long param_stride,
+                            const float* ln_g, const float* ln_b, const float* wq, const void* wkT, const void* wvT,
+                            const void* woT, float* mn, float* mstats, float* k, float* v, void* kq, void* kqT, void* vo,
+                            void* voT, void* stream);
+int dh_xattn_prep_bwd_stack(int dtype, const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride, int B, int S,
+                            int L, int heads, int dim_head, int HLP, float scale, int layers, long param_stride,
+                            const float* ln_g, const void* wqT, const float* wk, const float* wv, const float* wo,
+                            const float* mn, const float* mstats, const float* k, const float* v, const float* dkq,
+                            const float* dvoT, float* dk, float* dv, float* dln_g, float* dln_b, float* dwq, float* dwk,
+                            float* dwv, float* dwo, int accumulate, void* workspace, void* stream);
+long dh_xattn_prep_bwd_stack_workspace_size(int S, int L, int layers);
 int dh_xattn_prep_bwd(int dtype, const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride, int B, int S,
                       int L, int heads, int dim_head, int HLP, float scale, const float* ln_g, const void* wqT,
                       const float* wk, const float* wv, const float* wo, const float* mn, const float* mstats,
@@ -215,6 +230,10 @@ int dh_grad_norm_clip_coef(const float* grad, long n, float max_norm, float* out
  * gradient scale is read from device memory (NULL = 1) */
 int dh_adamw_xbd_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int step, const float* grad_scale_dev, void* stream);
+/* HIP-graph form: hyper_dev = [lr, beta1, beta2, eps, weight_decay, (unused), step_size (out)]; every call / replay
+ * advances the device step counter */
+int dh_adamw_xbd_step_graph(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float* hyper_dev,
+                            int* step_dev, const float* grad_scale_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -196,3 +196,29 @@ def test_bf16_mode_tracks_fp32_and_trains():
         opt.step()
         hist.append(float(loss))
     assert hist[-1] < hist[0], hist
+
+
+def test_hip_graph_xbd_step_equals_eager_step():
+    from dahitra_amd.graph import GraphedXbdStep
+    from dahitra_amd.models import xbd
+    name = "xbd_unet_transformer_nodecpos"
+    a, b, lab = O.synthetic_batch(2, 256, seed=11, n_class=5)
+    x6, msk = torch.cat([a, b], 1).cuda(), O.xbd_masks(lab).cuda()
+    eager = make(name).train()
+    opt_e = xbd.AdamW(eager.parameters(), lr=1e-4, weight_decay=1e-6)
+    graphed = make(name).train()
+    opt_g = xbd.AdamW(graphed.parameters(), lr=1e-4, weight_decay=1e-6, capturable=True)
+    step = GraphedXbdStep(graphed, opt_g, x6, msk)
+    for it in range(3):
+        eager.zero_grad()
+        le = xbd.xbd_loss(eager(x6), msk)
+        le.backward()
+        xbd.clip_grad_norm_(eager.parameters(), 0.999)
+        opt_e.step()
+        lg = step(x6, msk)
+        assert abs(float(le) - float(lg)) <= 1e-5 * abs(float(le)), (it, float(le), float(lg))
+    se, sg = eager.state_dict(), graphed.state_dict()
+    for k in se:
+        if se[k].dtype.is_floating_point:
+            assert float((se[k] - sg[k]).abs().max()) <= 1e-6 + 1e-5 * float(se[k].abs().max()), k
+    assert opt_g.step_count(graphed) == 3
