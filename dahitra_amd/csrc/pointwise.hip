@@ -340,6 +340,49 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, const float* __r
     }
 }
 
+// All weights of a net in ONE launch: the per-step re-pack was ~120 four-microsecond launches for newUNetTrans.
+// jobs[] (device memory, built once by the host: sources live in the flat arena, destinations are persistent)
+// are sorted by first_block; a workgroup finds its job by bisection.
+struct PackJob {
+    const float* w;
+    void* fwd;          // [taps][OPad][I] or null
+    void* dgrad;        // [taps][IPad][OK] (flipped taps) or null
+    int O, I, KS, OPad, IPad, OK;
+    int dtype;          // DH_DTYPE_*
+    int first_block, nblocks;
+};
+template <typename T>
+__device__ __forceinline__ void pack_job(const PackJob& j, int lb) {
+    const int taps = j.KS * j.KS;
+    const long step = (long)j.nblocks * blockDim.x;
+    T* fwd = reinterpret_cast<T*>(j.fwd);
+    T* dgrad = reinterpret_cast<T*>(j.dgrad);
+    if (fwd)
+        for (long i = (long)lb * blockDim.x + threadIdx.x; i < (long)taps * j.OPad * j.I; i += step) {
+            const int ci = (int)(i % j.I);
+            const int o = (int)((i / j.I) % j.OPad);
+            const int tap = (int)(i / ((long)j.I * j.OPad));
+            stf(fwd + i, o < j.O ? j.w[((long)o * j.I + ci) * taps + tap] : 0.f);
+        }
+    if (dgrad)
+        for (long i = (long)lb * blockDim.x + threadIdx.x; i < (long)taps * j.IPad * j.OK; i += step) {
+            const int o = (int)(i % j.OK);
+            const int ci = (int)((i / j.OK) % j.IPad);
+            const int tap = (int)(i / ((long)j.OK * j.IPad));
+            stf(dgrad + i, (ci < j.I && o < j.O) ? j.w[((long)o * j.I + ci) * taps + (taps - 1 - tap)] : 0.f);
+        }
+}
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                               // last job whose first_block <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const int lb = blockIdx.x - j.first_block;
+    if (j.dtype == DH_DTYPE_BF16) pack_job<bf16>(j, lb); else pack_job<float>(j, lb);
+}
+
 // ---- column sums: out[c] (+)= sum_p x[p, c]  (bias gradients) --------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long P, int C,
@@ -525,6 +568,16 @@ extern "C" int dh_pack_weight(int dtype, const float* w_oihw, const float* out_s
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), w_oihw, out_scale, O, I, ks, OPad, (bf16*)fwd, IPad, OK, (bf16*)dgrad);
     else hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), w_oihw, out_scale, O, I, ks, OPad, (float*)fwd, IPad, OK, (float*)dgrad);
     DH_CHECK_LAUNCH("pack_weight");
+    return 0;
+}
+extern "C" int dh_pack_job_size(void) { return (int)sizeof(PackJob); }
+// jobs_dev: njobs PackJob records in device memory {w, fwd, dgrad: 3 pointers; O, I, KS, OPad, IPad, OK, dtype,
+// first_block, nblocks: 9 ints; padded to dh_pack_job_size() bytes}, sorted by first_block; total_blocks = sum nblocks
+extern "C" int dh_pack_weights_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream) {
+    if (njobs <= 0) return 0;
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(total_blocks), dim3(256), 0, ST(stream),
+                       reinterpret_cast<const PackJob*>(jobs_dev), njobs);
+    DH_CHECK_LAUNCH("pack_weights_multi");
     return 0;
 }
 // workspace: 256 * C floats

@@ -53,22 +53,33 @@ class Engine:
         self.training = False
         self.need_grad = False
         self._bwd = None
+        self._plans = {}
 
     # ---- binding ---------------------------------------------------------------------------------
     def bind(self, params, grads):
         self.p, self.g = params, grads
+        self._plans = {}       # the packed buffers point into the old arena
 
     def _pack_all(self):
+        """kernel-layout copies of every weight the forward (and, with need_grad, the data gradients) will read.
+        The destinations and the job table are built once per (arena, need_grad) and then refreshed by ONE launch
+        per step (ops.PackPlan); the 7x7 stem has its own space-to-depth pack."""
+        plan = self._plans.get(self.need_grad)
+        if plan is None:
+            plan = self._plans[self.need_grad] = self._build_plan()
+        pack, self.pk, self.xstack = plan
+        pack.run()
+        key = "resnet.conv1.weight"
+        self.pk[key] = Packed(ops.stem_pack_weight(self.p[key], self.dtype), None)
+
+    def _build_plan(self):
         ck = ops.chunk_channels(self.dtype)
-        self.pk = {}
-        self.xstack = {}       # (decoder prefix, matrix) -> stacked transposes [depth, 32*inner]
+        pack = ops.PackPlan(self.p["resnet.conv1.weight"].device)
+        pk, xstack = {}, {}    # xstack: (decoder prefix, matrix) -> stacked transposes [depth, 32*inner]
         for key, shape in self.shapes.items():
             if key not in self.p or not key.endswith("weight") or len(shape) not in (2, 4):
                 continue
-            if not is_active(self.net_G, key):
-                continue
-            if key == "resnet.conv1.weight":
-                self.pk[key] = Packed(ops.stem_pack_weight(self.p[key], self.dtype), None)
+            if not is_active(self.net_G, key) or key == "resnet.conv1.weight":
                 continue
             if key.startswith("conv_a") or key.startswith("conv_token") or key.startswith("resnet.fc") or \
                     key.startswith("resnet.layer4"):
@@ -81,26 +92,24 @@ class Engine:
                 pfx, rest = key.split(".layers.")
                 li, which = int(rest.split(".")[0]), rest.split(".fn.fn.")[1]
                 skey = (pfx, which)
-                if skey not in self.xstack:
+                if skey not in xstack:
                     depth = 1 + max(int(k.split(".layers.")[1].split(".")[0]) for k in self.shapes
                                     if k.startswith(pfx + ".layers.") and k.endswith(which))
-                    self.xstack[skey] = torch.empty(depth, shape[0] * shape[1], dtype=self.dtype, device=self.p[key].device)
-                view = self.xstack[skey][li]
-                ops.pack_weight(self.p[key], self.dtype, want_dgrad=True, want_fwd=False, out_dgrad=view)
-                self.pk[key] = Packed(None, view)
+                    xstack[skey] = torch.empty(depth, shape[0] * shape[1], dtype=self.dtype, device=self.p[key].device)
+                view = xstack[skey][li]
+                pack.add(self.p[key], self.dtype, want_fwd=False, out_dgrad=view)
+                pk[key] = Packed(None, view)
                 continue
             O = shape[0]
+            dt = self.dtype
             if key.startswith("transformer") and not key.startswith("transformer_decoder"):
                 # the token encoder (<= 16 rows per image) runs in fp32 in every mode: its output feeds
                 # |token2 - token1|, which bf16 rounding would wipe out (csrc/tokens.hip header)
-                ck32 = ops.chunk_channels(torch.float32)
-                f, d = ops.pack_weight(self.p[key], torch.float32, want_dgrad=self.need_grad,
-                                       dgrad_inner=-(-O // ck32) * ck32)
-                self.pk[key] = Packed(f, d)
-                continue
-            inner = -(-O // ck) * ck
-            f, d = ops.pack_weight(self.p[key], self.dtype, want_dgrad=self.need_grad, dgrad_inner=inner)
-            self.pk[key] = Packed(f, d)
+                dt = torch.float32
+            c = ops.chunk_channels(dt)
+            f, d = pack.add(self.p[key], dt, want_dgrad=self.need_grad, dgrad_inner=-(-O // c) * c)
+            pk[key] = Packed(f, d)
+        return pack, pk, xstack
 
     # ---- primitive units -------------------------------------------------------------------------
     def conv_dgrad(self, dy, wkey, ks, stride, pad, xshape, residual=None, dilation=1, gate=None):

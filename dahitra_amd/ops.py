@@ -89,6 +89,46 @@ def pack_weight(w, dtype, want_dgrad=True, dgrad_inner=0, out_scale=None, want_f
     return fwd, dg
 
 
+class PackPlan:
+    """persistent packed-weight buffers + the device job table of dh_pack_weights_multi (one launch per step)"""
+
+    class _Job(ctypes.Structure):
+        _fields_ = [("w", ctypes.c_void_p), ("fwd", ctypes.c_void_p), ("dgrad", ctypes.c_void_p), ("O", ctypes.c_int),
+                    ("I", ctypes.c_int), ("KS", ctypes.c_int), ("OPad", ctypes.c_int), ("IPad", ctypes.c_int),
+                    ("OK", ctypes.c_int), ("dtype", ctypes.c_int), ("first_block", ctypes.c_int), ("nblocks", ctypes.c_int)]
+
+    def __init__(self, device):
+        self.device, self.jobs, self.blocks, self.table, self.keep = device, [], 0, None, []
+
+    def add(self, w, dtype, want_fwd=True, want_dgrad=True, dgrad_inner=0, out_dgrad=None):
+        """same contract as pack_weight; returns the (persistent) fwd / dgrad buffers"""
+        if w.dim() == 2:
+            (O, I), ks = w.shape, 1
+        else:
+            O, I, ks, _ = w.shape
+        OPad, IPad, OK = pad16(O), pad16(I), max(O, dgrad_inner)
+        fwd = torch.empty(ks * ks, OPad, I, dtype=dtype, device=w.device) if want_fwd else None
+        dg = out_dgrad if out_dgrad is not None else \
+            (torch.empty(ks * ks, IPad, OK, dtype=dtype, device=w.device) if want_dgrad else None)
+        n = max(fwd.numel() if fwd is not None else 0, dg.numel() if dg is not None else 0)
+        nb = max(1, min(64, cdiv(n, 1024)))
+        self.jobs.append(self._Job(w.data_ptr(), fwd.data_ptr() if fwd is not None else None,
+                                   dg.data_ptr() if dg is not None else None, O, I, ks, OPad, IPad, OK, _DT[dtype],
+                                   self.blocks, nb))
+        self.blocks += nb
+        self.keep += [w, fwd, dg]
+        return fwd, dg
+
+    def run(self):
+        if not self.jobs:
+            return
+        if self.table is None:
+            assert ctypes.sizeof(self._Job) == _lib.lib().dh_pack_job_size()
+            raw = b"".join(bytes(j) for j in self.jobs)
+            self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        _call("dh_pack_weights_multi", P(self.table), _ci(len(self.jobs)), _ci(self.blocks), S())
+
+
 # ---- convolution / linear ------------------------------------------------------------------------
 PROFILE = None       # set to {} by bench.py to collect (events, algorithmic flops, bytes) per conv launch
 

@@ -72,6 +72,11 @@ int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, int ks, int
  * output channel: eval-mode BatchNorm folded into the convolution (its shift then goes in as `bias`). */
 int dh_pack_weight(int dtype, const float* w_oihw, const float* out_scale, int O, int I, int ks, int OPad, void* fwd, int IPad,
                    int dgrad_inner, void* dgrad, void* stream);
+/* every weight of a net in one launch.  jobs_dev: njobs records {const float* w; void* fwd; void* dgrad; int O, I, KS,
+ * OPad, IPad, OK, dtype, first_block, nblocks;} (dh_pack_job_size() bytes each) in device memory, sorted by
+ * first_block; record k is served by workgroups [first_block, first_block + nblocks). */
+int dh_pack_weights_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream);
+int dh_pack_job_size(void);
 /* z[n,2y,2x,c] = dy[n,y,x,c] (zero elsewhere): stride-2 data gradients as stride-1 convolutions */
 int dh_zero_insert2(int dtype, const void* dy, void* z, int N, int OH, int OW, int H, int W, int C, void* stream);
 
