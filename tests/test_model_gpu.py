@@ -390,7 +390,7 @@ def test_bn_backward_fused_into_dgrad_equals_two_pass(name, monkeypatch):
     a, b, lab = O.synthetic_batch(2, size, seed=41)
     grads = {}
     for off in ("1", "0"):
-        monkeypatch.setenv("DAHITRA_NO_BN_FUSION", off)
+        monkeypatch.setenv("DAHITRA_BN_FUSION", "0" if off == "1" else "1")
         net = make_net(name).train()
         assert net._engine.fused_bn_bwd == (off == "0")
         losses.focal_loss(net(a.cuda(), b.cuda()), lab.cuda()).backward()
