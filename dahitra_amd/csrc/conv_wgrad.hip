@@ -8,16 +8,19 @@
 //   fp32: one ds_read_b32 per operand and v_mfma_f32_16x16x4_f32 (4 pixels per MFMA);
 //   bf16: two ds_read_b64_tr_b16 (the gfx950 LDS transpose read) per operand, or 8 ds_read_u16
 //         when TR = false, feeding v_mfma_f32_16x16x32_bf16 (32 pixels per MFMA).
-// A workgroup owns a 64(co) x IT(ci) x all-taps slab of dW (wave w = co sub-tile w), walks a
-// strided subset of the pixel tiles (split-K) and writes an fp32 partial slab; dh_wgrad_reduce
-// sums the partials deterministically straight into the OIHW master-gradient layout.
+// A workgroup owns a CTT(co) x IT(ci) x all-taps slab of dW, walks a strided subset of the pixel tiles
+// (split-K) and writes an fp32 partial slab; dh_wgrad_reduce sums the partials deterministically straight
+// into the OIHW master-gradient layout.  CTT = 64: wave w = co sub-tile w.  CTT = 32 (layers with <= 32
+// output channels -- the 32-wide transformer side, the heads: half of a 64-wide tile would be zero padding):
+// waves (0,1) and (2,3) take the two co sub-tiles for the first / second half of every tile's pixels and
+// are added through LDS at the end.
 // groups == N gives one dW per image (per-image attention products, see tokens.hip).
 #include "common.h"
 
 namespace {
 
 constexpr int TH = 8, TW = 16;
-constexpr int CT = 64;
+static inline int co_tile(int Cout) { return Cout <= 32 ? 32 : 64; }
 
 struct WgArgs {
     const void* x;
@@ -60,8 +63,12 @@ union F8 {
     unsigned short s[8];
 };
 
-template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL>
+template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
+    constexpr int CT = CTT;
+    constexpr int CW = CTT / 16;                   // co sub-tiles (waves along co)
+    constexpr int KSPLIT = 4 / CW;                 // wave groups along the pixel (K) dimension of a tile
+    constexpr int KPW = TH * TW / KSPLIT;          // pixels of a tile per wave group
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
     constexpr int HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     constexpr int TAPS = KS * KS;
@@ -76,6 +83,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
+    const int cw = wv % CW, kq = wv / CW;
     const int cot = blockIdx.x / p.ci_tiles, cit = blockIdx.x % p.ci_tiles;
     const int co0 = cot * CT, ci0 = cit * IT;
     const int kz = blockIdx.y, grp = blockIdx.z;
@@ -147,9 +155,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
 
         if constexpr (sizeof(T) == 4) {
             // 4 pixels per MFMA: lane (pl, g) supplies pixel k0+g, channel pl
-            for (int k0 = 0; k0 < TH * TW; k0 += 4) {
+            for (int k0 = kq * KPW; k0 < (kq + 1) * KPW; k0 += 4) {
                 const int k = k0 + g, row = k / TW, col = k % TW;
-                const float a = *reinterpret_cast<const float*>(dyt + k * DP + (wv * 16 + pl) * 4);
+                const float a = *reinterpret_cast<const float*>(dyt + k * DP + (cw * 16 + pl) * 4);
 #pragma unroll
                 for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
@@ -165,12 +173,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
         } else {
             // 32 pixels (two tile rows) per MFMA: lane group g supplies columns 4g..4g+3 of rows r0 and r0+1,
             // so the 32 lanes of a half-wave read 8 consecutive pixels per transpose-read (see pitch note)
-            for (int k0 = 0; k0 < TH * TW; k0 += 32) {
+            for (int k0 = kq * KPW; k0 < (kq + 1) * KPW; k0 += 32) {
                 const int r0 = k0 / TW, c0 = g * 4;
                 F8 a;
                 if constexpr (TR) {
                     // lane p of each 16-lane group points at the 8-byte piece (pixel p/4, channels 4*(p%4)..+3)
-                    const unsigned char* base = dyt + (k0 + c0 + (pl >> 2)) * DP + (wv * 16 + (pl & 3) * 4) * 2;
+                    const unsigned char* base = dyt + (k0 + c0 + (pl >> 2)) * DP + (cw * 16 + (pl & 3) * 4) * 2;
                     a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(base));
                     a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
                         a.s[j] = *reinterpret_cast<const unsigned short*>(
-                            dyt + (k0 + (j >> 2) * TW + c0 + (j & 3)) * DP + (wv * 16 + pl) * 2);
+                            dyt + (k0 + (j >> 2) * TW + c0 + (j & 3)) * DP + (cw * 16 + pl) * 2);
                 }
 #pragma unroll
                 for (int kh = 0; kh < KS; ++kh)
@@ -210,6 +218,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
         __syncthreads();
     }
 
+    if constexpr (KSPLIT > 1) {
+        // add the wave groups that split the pixels (fixed order): group q > 0 parks its accumulators in LDS
+        float* red = reinterpret_cast<float*>(smem);            // [CW][TAPS*NI][64 lanes][4]   (host sized the LDS)
+        for (int q = 1; q < KSPLIT; ++q) {
+            if (kq == q) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        *reinterpret_cast<f32x4*>(red + (((size_t)cw * TAPS * NI + t * NI + i) * 64 + lane) * 4) = acc[t][i];
+            }
+            __syncthreads();
+            if (kq == 0) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(red + (((size_t)cw * TAPS * NI + t * NI + i) * 64 + lane) * 4);
+                        acc[t][i][0] += o[0]; acc[t][i][1] += o[1]; acc[t][i][2] += o[2]; acc[t][i][3] += o[3];
+                    }
+            }
+            __syncthreads();
+        }
+        if (kq != 0) return;
+    }
     // partial slab: [grp][kz][tap][Cout][Cin]
     float* out = p.part + ((size_t)grp * p.splitk + kz) * TAPS * p.Cout * p.Cin;
 #pragma unroll
@@ -218,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int co = co0 + wv * 16 + g * 4 + j, ci = ci0 + i * 16 + pl;
+                const int co = co0 + cw * 16 + g * 4 + j, ci = ci0 + i * 16 + pl;
                 if (co < p.Cout && ci < p.Cin) out[((size_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][j];
             }
 }
@@ -255,10 +288,14 @@ __global__ void wgrad_reduce_oihw_kernel(const float* __restrict__ part, int spl
     }
 }
 
-template <typename T, int KS, int STRIDE, int IT, int DIL = 1>
-int launch(const WgArgs& a, bool tr, hipStream_t st) {
+template <typename T, int KS, int STRIDE, int IT, int DIL, int CT>
+int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
-    const size_t lds = (size_t)HH * HWD * lds_pitch(IT * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T));
+    size_t lds = (size_t)HH * HWD * lds_pitch(IT * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T));
+    if (CT == 32) {                                    // the end-of-kernel wave-group combine parks accumulators here
+        const size_t red = (size_t)2 * KS * KS * (IT / 16) * 64 * 16;
+        if (lds < red) lds = red;
+    }
     dim3 grid(dh_cdiv(a.Cout, CT) * a.ci_tiles, a.splitk, a.groups);
     auto go = [&](auto kern) -> int {
         static bool attr_done = false;      // once per instantiation (and never inside a graph capture)
@@ -275,8 +312,13 @@ int launch(const WgArgs& a, bool tr, hipStream_t st) {
         DH_CHECK_LAUNCH("conv_wgrad");
         return 0;
     };
-    if (tr) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true, DIL>);
-    return go(conv_wgrad_kernel<T, KS, STRIDE, IT, false, DIL>);
+    if (tr) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true, DIL, CT>);
+    return go(conv_wgrad_kernel<T, KS, STRIDE, IT, false, DIL, CT>);
+}
+template <typename T, int KS, int STRIDE, int IT, int DIL = 1>
+int launch(const WgArgs& a, bool tr, hipStream_t st) {
+    if (co_tile(a.Cout) == 32) return launch_ct<T, KS, STRIDE, IT, DIL, 32>(a, tr, st);
+    return launch_ct<T, KS, STRIDE, IT, DIL, 64>(a, tr, st);
 }
 
 template <typename T>
@@ -301,7 +343,7 @@ extern "C" int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, 
     // NOTE: stride is not known here; the 64-wide ci tile is only used at stride 1, where this
     // estimate is exact; at stride 2 it under-estimates the slab count (harmless: more workgroups)
     const int it = ks == 4 ? 16 : ((Cin > 32 && ks == 1) ? 64 : 32);
-    const long slabs = (long)dh_cdiv(Cout, CT) * dh_cdiv(Cin, it) * (groups > 0 ? groups : 1);
+    const long slabs = (long)dh_cdiv(Cout, co_tile(Cout)) * dh_cdiv(Cin, it) * (groups > 0 ? groups : 1);
     long sk = (1024 + slabs - 1) / slabs;      // ~4 workgroups per CU however small Cout x Cin is ...
     if (sk > tiles / 8) sk = tiles / 8;        // ... but at least 8 pixel tiles per workgroup (slab write amortised)
     if (sk > 1024) sk = 1024;
