@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int TH = 8, TW = 16;
-static inline int co_tile(int Cout) { return Cout <= 32 ? 32 : 64; }
+static inline int co_tile(int Cout) { return Cout <= 16 ? 16 : (Cout <= 32 ? 32 : 64); }
 
 struct WgArgs {
     const void* x;
@@ -31,6 +31,7 @@ struct WgArgs {
     int ci_tiles;
     int CinPitch;      // elements between consecutive pixels of x (>= Cin; the stem reads a padded image)
     int dil;
+    int CoutUse;       // output channels that carry a gradient (<= Cout: dy may be zero-padded to a K-chunk)
 };
 
 // the 16-byte piece q of channels [c0, ...) of one pixel row (zeros past Ctot / for a null row)
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int co = co0 + cw * 16 + g * 4 + j, ci = ci0 + i * 16 + pl;
-                if (co < p.Cout && ci < p.Cin) out[((size_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][j];
+                if (co < p.CoutUse && ci < p.Cin) out[((size_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][j];
             }
 }
 
@@ -292,11 +293,11 @@ template <typename T, int KS, int STRIDE, int IT, int DIL, int CT>
 int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     size_t lds = (size_t)HH * HWD * lds_pitch(IT * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T));
-    if (CT == 32) {                                    // the end-of-kernel wave-group combine parks accumulators here
-        const size_t red = (size_t)2 * KS * KS * (IT / 16) * 64 * 16;
+    if (CT < 64) {                                     // the end-of-kernel wave-group combine parks accumulators here
+        const size_t red = (size_t)(CT / 16) * KS * KS * (IT / 16) * 64 * 16;
         if (lds < red) lds = red;
     }
-    dim3 grid(dh_cdiv(a.Cout, CT) * a.ci_tiles, a.splitk, a.groups);
+    dim3 grid(dh_cdiv(a.CoutUse, CT) * a.ci_tiles, a.splitk, a.groups);
     auto go = [&](auto kern) -> int {
         static bool attr_done = false;      // once per instantiation (and never inside a graph capture)
         if (lds > 64 * 1024 && !attr_done) {
@@ -317,7 +318,8 @@ int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
 }
 template <typename T, int KS, int STRIDE, int IT, int DIL = 1>
 int launch(const WgArgs& a, bool tr, hipStream_t st) {
-    if (co_tile(a.Cout) == 32) return launch_ct<T, KS, STRIDE, IT, DIL, 32>(a, tr, st);
+    if (co_tile(a.CoutUse) == 16) return launch_ct<T, KS, STRIDE, IT, DIL, 16>(a, tr, st);
+    if (co_tile(a.CoutUse) == 32) return launch_ct<T, KS, STRIDE, IT, DIL, 32>(a, tr, st);
     return launch_ct<T, KS, STRIDE, IT, DIL, 64>(a, tr, st);
 }
 
@@ -368,6 +370,7 @@ extern "C" int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* 
     a.CinPitch = cin_pitch > 0 ? cin_pitch : Cin;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.pad = pad;
     a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, TH);
+    a.CoutUse = Cout_real > 0 ? Cout_real : Cout;
     a.groups = groups; a.splitk = dh_conv2d_wgrad_splitk(N, OH, OW, Cin, Cout, ks, groups);
     a.npix = npix_valid > 0 ? npix_valid : OH * OW;
     a.in_npix = npix_valid > 0 ? npix_valid : H * W;
