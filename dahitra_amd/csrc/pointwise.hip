@@ -35,6 +35,61 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
     }
 }
 
+// ---- data gradient of the class head: 3x3 / stride 1 / pad 1 convolution 32 -> NC channels (NC = n_class <= 8) ----
+//   dX[n][y][x][ci] = sum_{kh,kw} sum_{co<NC} dY[n][y+1-kh][x+1-kw][co] * W[co][ci][kh][kw]
+// (models/help_funcs.py:13-14 / networks.py:1247 backward).  With 2..5 real output channels the reduction is 18..45
+// long: as an MFMA convolution it would run on a dY zero-padded to a 32-channel K-chunk (16x the bytes and the
+// FLOPs); here dY stays [pixel][CP] with CP = one 16-byte piece, one lane owns a pixel and all 32 input channels,
+// the weights are LDS broadcasts.  HBM-bound: 16 B read (x9 from L1/L2) + 64/128 B written per pixel.
+template <typename T, int CP>
+__global__ __launch_bounds__(256) void head_dgrad3x3_kernel(const T* __restrict__ dy, const float* __restrict__ w_oihw,
+                                                            T* __restrict__ dx, int N, int H, int W, int NC) {
+    __shared__ __attribute__((aligned(16))) float sw[9 * 8 * 32];          // [tap][co][ci]
+    for (int i = threadIdx.x; i < 9 * NC * 32; i += blockDim.x) {
+        const int ci = i & 31, co = (i >> 5) % NC, tap = i / (32 * NC);
+        sw[i] = w_oihw[((size_t)co * 32 + ci) * 9 + tap];
+    }
+    __syncthreads();
+    const long total = (long)N * H * W;
+    for (long px = (long)blockIdx.x * blockDim.x + threadIdx.x; px < total; px += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(px % W), y = (int)((px / W) % H);
+        const long n = px / ((long)W * H);
+        float acc[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int yy = y + 1 - kh, xx = x + 1 - kw;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                float v[CP];
+                const T* src = dy + ((n * H + yy) * W + xx) * CP;
+#pragma unroll
+                for (int q = 0; q < CP; q += 4) {
+                    float t4[4];
+                    ld4(src + q, t4);
+                    v[q] = t4[0]; v[q + 1] = t4[1]; v[q + 2] = t4[2]; v[q + 3] = t4[3];
+                }
+                for (int co = 0; co < NC; ++co) {
+                    const float* wr = sw + ((kh * 3 + kw) * NC + co) * 32;
+                    const float d = v[co];
+#pragma unroll
+                    for (int c = 0; c < 32; c += 4) {
+                        const float4 ww = *reinterpret_cast<const float4*>(wr + c);
+                        acc[c] += d * ww.x; acc[c + 1] += d * ww.y; acc[c + 2] += d * ww.z; acc[c + 3] += d * ww.w;
+                    }
+                }
+            }
+        T* dst = dx + px * 32;
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+            float r4[4] = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+            st4(dst + c, r4);
+        }
+    }
+}
+
 // ---- channel-slice copy: dst[p, dc0 + c] = src[p, sc0 + c], c < Cn -------------------------
 template <typename T>
 __global__ void copy_channels_kernel(const T* __restrict__ src, int Cs, int sc0, T* __restrict__ dst, int Cd,
@@ -444,6 +499,25 @@ extern "C" int dh_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, in
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), src, (bf16*)dst, N, C, HW, CP);
     else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), src, (float*)dst, N, C, HW, CP);
     DH_CHECK_LAUNCH("nchw_to_nhwc");
+    return 0;
+}
+// dy: [N][H][W][CP] T with CP = 8 (bf16) or 4 / 8 (fp32) channels per pixel, the first NC real; w_oihw: [NC][32][3][3]
+// fp32 master; dx: [N][H][W][32] T
+extern "C" int dh_head_dgrad3x3(int dtype, const void* dy, int CP, const float* w_oihw, int NC, void* dx, int N, int H,
+                                int W, void* stream) {
+    DH_REQUIRE(NC >= 1 && NC <= 8 && NC <= CP, "head_dgrad3x3: n_class=%d with CP=%d", NC, CP);
+    const long n = (long)N * H * W;
+    const int grid = ew_grid(n, 256);
+    if (dtype == DH_DTYPE_BF16) {
+        DH_REQUIRE(CP == 8, "head_dgrad3x3: bf16 needs 8 channels per pixel (one 16-byte piece), got %d", CP);
+        hipLaunchKernelGGL((head_dgrad3x3_kernel<bf16, 8>), dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dy, w_oihw, (bf16*)dx, N, H, W, NC);
+    } else if (CP == 4) {
+        hipLaunchKernelGGL((head_dgrad3x3_kernel<float, 4>), dim3(grid), dim3(256), 0, ST(stream), (const float*)dy, w_oihw, (float*)dx, N, H, W, NC);
+    } else {
+        DH_REQUIRE(CP == 8, "head_dgrad3x3: fp32 needs 4 or 8 channels per pixel, got %d", CP);
+        hipLaunchKernelGGL((head_dgrad3x3_kernel<float, 8>), dim3(grid), dim3(256), 0, ST(stream), (const float*)dy, w_oihw, (float*)dx, N, H, W, NC);
+    }
+    DH_CHECK_LAUNCH("head_dgrad3x3");
     return 0;
 }
 extern "C" int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream) {

@@ -513,7 +513,20 @@ class Engine:
         if not self.need_grad:
             return out, None
 
+        small = 8 if (self.dtype == torch.bfloat16 or ncls > 4) else 4          # channels of one 16-byte piece
+        direct = h.shape[-1] == 32 and ncls <= small
+
         def bwd(dl_nchw, next_gate=None):
+            if direct and next_gate is None:
+                # n_class (2..5) real channels: keep dlogits at ONE 16-byte piece per pixel instead of padding them to
+                # a 32-channel K-chunk (4x the bytes, written and read twice), and take the data gradient with the
+                # dedicated head kernel instead of an MFMA convolution over 94 % zeros
+                dl = ops.nchw_to_nhwc(dl_nchw, self.dtype, cpad=small)
+                ops.conv2d_wgrad(h, dl, self.g[wkey], 3, 1, 1, accumulate=True, use_tr=self.use_tr, cout_real=ncls)
+                tmp = torch.empty(small, dtype=torch.float32, device=h.device)
+                ops.colsum(dl.view(-1, small), tmp)
+                ops.reduce_rows(tmp, 1, ncls, self.g[bkey], accumulate=True)
+                return ops.head_dgrad3x3(dl, self.p[wkey], ncls)
             dl = ops.nchw_to_nhwc(dl_nchw, self.dtype, cpad=ck)          # channels zero-padded to one K-chunk
             ops.conv2d_wgrad(h, dl, self.g[wkey], 3, 1, 1, accumulate=True, use_tr=self.use_tr, cout_real=ncls)
             tmp = torch.empty(ck, dtype=torch.float32, device=h.device)

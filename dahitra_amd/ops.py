@@ -347,6 +347,15 @@ def nchw_to_nhwc(x, dtype, cpad=0):
     return y
 
 
+def head_dgrad3x3(dy, w_oihw, ncls):
+    """data gradient of the 3x3 class head (32 -> ncls): dy [N,H,W,CP] with one 16-byte piece per pixel -> [N,H,W,32]"""
+    N, H, W, CP = dy.shape
+    assert w_oihw.shape == (ncls, 32, 3, 3) and w_oihw.dtype == torch.float32
+    dx = torch.empty(N, H, W, 32, dtype=dy.dtype, device=dy.device)
+    _call("dh_head_dgrad3x3", _ci(dt(dy)), P(dy), _ci(CP), P(w_oihw), _ci(ncls), P(dx), _ci(N), _ci(H), _ci(W), S())
+    return dx
+
+
 def nhwc_to_nchw(x):
     N, H, W, C = x.shape
     y = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)

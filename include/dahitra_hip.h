@@ -110,6 +110,11 @@ int dh_reduce_partials(const float* partial, long nt, long n, float scale, float
 
 /* ---- pointwise / resampling / layout (models/resnet.py:154; networks.py:199-200,384,1312,1348) ---- */
 int dh_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, long HW, int CP, void* stream);
+/* data gradient of the class head (3x3 / s1 / p1, 32 -> n_class <= 8 channels; help_funcs.py:13-14, networks.py:1247):
+ * dy [N][H][W][CP] (CP = 8 bf16 / 4 or 8 fp32 channels per pixel, the first NC real), w_oihw [NC][32][3][3] fp32,
+ * dx [N][H][W][32] */
+int dh_head_dgrad3x3(int dtype, const void* dy, int CP, const float* w_oihw, int NC, void* dx, int N, int H, int W,
+                     void* stream);
 int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream);
 int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, void* dst, int Cd, int dc0, int Cn, long P, void* stream);
 int dh_add(int dtype, const void* a, const void* b, void* y, long n, void* stream);

@@ -387,3 +387,19 @@ def test_bn_backward_gated_in_the_dgrad_epilogue_equals_two_pass(ops, dtype, rel
     close(dg1, dg0.cpu(), dtype, "dgamma", factor=4.0)
     close(db1, db0.cpu(), dtype, "dbeta", factor=4.0)
     close(dx1, dx0.float().cpu(), dtype, "dx", factor=4.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ncls", [2, 5])
+def test_head_data_gradient_kernel(ops, dtype, ncls):
+    """dh_head_dgrad3x3 (compact dlogits, one 16-byte piece per pixel) against autograd of F.conv2d(32 -> n_class)"""
+    N, H, W = 2, 20, 36
+    x = rnd((N, 32, H, W), dtype, 301).requires_grad_(True)
+    w = rnd((ncls, 32, 3, 3), torch.float32, 302, 0.1)
+    dy = rnd((N, ncls, H, W), dtype, 303)
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    cp = 8 if (dtype == torch.bfloat16 or ncls > 4) else 4
+    dl = ops.nchw_to_nhwc(dy.float().cuda().contiguous(), dtype, cpad=cp)
+    assert dl.shape[-1] == cp
+    dx = ops.head_dgrad3x3(dl, w.cuda(), ncls)
+    close(nchw(dx), x.grad, dtype, "head dgrad", factor=2.0)
