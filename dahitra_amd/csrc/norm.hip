@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, int C,
                                                             long pix_per_group, int bpg,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial,
+                                                            const float* __restrict__ mscale,
+                                                            const float* __restrict__ mshift) {
     __shared__ float red[2 * 256 * 4];
     const int g = blockIdx.x / bpg, b = blockIdx.x % bpg;
     const int cvn = C / 4;                     // vector columns
@@ -118,6 +120,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             ld4(out + off, o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+        } else if (mscale) {
+            // ReLU mask recomputed from the pre-normalisation input (layers without a residual): the same
+            // x * scale + shift the forward evaluated, so one tensor read less in each backward pass
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[j] = (xv[j] * mscale[g * C + cv * 4 + j] + mshift[g * C + cv * 4 + j]) > 0.f ? d[j] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -167,7 +175,8 @@ template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ sums, float inv_m,
-                                    long nvec, int C, long group_vec, T* __restrict__ dx, T* __restrict__ dres) {
+                                    long nvec, int C, long group_vec, T* __restrict__ dx, T* __restrict__ dres,
+                                    const float* __restrict__ mscale, const float* __restrict__ mshift) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         const int g = (int)(i / group_vec);
@@ -179,6 +188,9 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
             ld4(out + i * 4, o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+        } else if (mscale) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = (xv[j] * mscale[g * C + c + j] + mshift[g * C + c + j]) > 0.f ? d[j] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -358,8 +370,9 @@ extern "C" long dh_bn_bwd_workspace_size(long npix, int C, int groups) {
 
 extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, const void* x, const float* mean,
                          const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
-                         void* dres, float* dgamma, float* dbeta, int accumulate, void* workspace,
-                         void* stream) {
+                         void* dres, float* dgamma, float* dbeta, int accumulate, const float* mask_scale,
+                         const float* mask_shift, void* workspace, void* stream) {
+    DH_REQUIRE(!(out_relu && mask_scale), "bn_bwd: give the ReLU mask either as out_relu or as mask_scale/shift");
     DH_REQUIRE(C % 4 == 0 && 1024 % C == 0, "bn_bwd: unsupported C=%d", C);
     DH_REQUIRE(npix % groups == 0, "bn_bwd: npix %% groups");
     const int bpg = 1024 / groups;      // ~1024 workgroups in total (4 per CU)
@@ -369,20 +382,20 @@ extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, cons
     const long nvec = npix * C / 4;
     if (dtype == DH_DTYPE_BF16) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(groups * bpg), dim3(256), 0, ST(stream), (const bf16*)dout,
-                           (const bf16*)out_relu, (const bf16*)x, mean, invstd, C, ppg, bpg, partial);
+                           (const bf16*)out_relu, (const bf16*)x, mean, invstd, C, ppg, bpg, partial, mask_scale, mask_shift);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, bpg, groups, C, sums,
                            dgamma, dbeta, accumulate);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream),
                            (const bf16*)dout, (const bf16*)out_relu, (const bf16*)x, mean, invstd, gamma, sums,
-                           1.0f / (float)ppg, nvec, C, nvec / groups, (bf16*)dx, (bf16*)dres);
+                           1.0f / (float)ppg, nvec, C, nvec / groups, (bf16*)dx, (bf16*)dres, mask_scale, mask_shift);
     } else {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(groups * bpg), dim3(256), 0, ST(stream), (const float*)dout,
-                           (const float*)out_relu, (const float*)x, mean, invstd, C, ppg, bpg, partial);
+                           (const float*)out_relu, (const float*)x, mean, invstd, C, ppg, bpg, partial, mask_scale, mask_shift);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, bpg, groups, C, sums,
                            dgamma, dbeta, accumulate);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream),
                            (const float*)dout, (const float*)out_relu, (const float*)x, mean, invstd, gamma, sums,
-                           1.0f / (float)ppg, nvec, C, nvec / groups, (float*)dx, (float*)dres);
+                           1.0f / (float)ppg, nvec, C, nvec / groups, (float*)dx, (float*)dres, mask_scale, mask_shift);
     }
     DH_CHECK_LAUNCH("bn_bwd");
     return 0;
@@ -404,11 +417,11 @@ extern "C" int dh_bn_bwd_from_partials(int dtype, const void* g, const void* x, 
     if (dtype == DH_DTYPE_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const bf16*)g,
                            (const bf16*)nullptr, (const bf16*)x, mean, invstd, gamma, sums, 1.0f / (float)ppg, nvec, C,
-                           nvec / groups, (bf16*)dx, (bf16*)nullptr);
+                           nvec / groups, (bf16*)dx, (bf16*)nullptr, (const float*)nullptr, (const float*)nullptr);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const float*)g,
                            (const float*)nullptr, (const float*)x, mean, invstd, gamma, sums, 1.0f / (float)ppg, nvec, C,
-                           nvec / groups, (float*)dx, (float*)nullptr);
+                           nvec / groups, (float*)dx, (float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     DH_CHECK_LAUNCH("bn_bwd_from_partials");
     return 0;
 }

@@ -153,6 +153,11 @@ class Engine:
                 dy = ops.bn_bwd_from_partials(dout.g, y, dout.partial, mean, invstd, gamma, self.g[bnkey + ".weight"],
                                               self.g[bnkey + ".bias"], groups, accumulate=True)
                 dres = dout.g if has_res else None
+            elif relu and not has_res:
+                # no residual: the ReLU mask is recomputed from y (x * scale + shift > 0) -- `out` is not read
+                dy, dres = ops.bn_bwd(dout, None, y, mean, invstd, gamma, self.g[bnkey + ".weight"],
+                                      self.g[bnkey + ".bias"], groups, accumulate=True, mask_scale=scale,
+                                      mask_shift=shift), None
             else:
                 r = ops.bn_bwd(dout, out if relu else None, y, mean, invstd, gamma, self.g[bnkey + ".weight"],
                                self.g[bnkey + ".bias"], groups, accumulate=True, want_dres=has_res)
@@ -208,8 +213,8 @@ class Engine:
             return out, None
 
         def bwd(dout):
-            dy = ops.bn_bwd(dout, out, y, mean, invstd, gamma, self.g[bnkey + ".weight"], self.g[bnkey + ".bias"],
-                            groups, accumulate=True)
+            dy = ops.bn_bwd(dout, None, y, mean, invstd, gamma, self.g[bnkey + ".weight"], self.g[bnkey + ".bias"],
+                            groups, accumulate=True, mask_scale=scale, mask_shift=shift)
             ops.stem_wgrad(xs, dy, self.g[wkey], accumulate=True, use_tr=self.use_tr)
         return out, bwd
 

@@ -295,7 +295,8 @@ def bn_apply(x, scale, shift, groups=1, act=ACT_NONE, residual=None):
     return y
 
 
-def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accumulate=False, want_dres=False):
+def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accumulate=False, want_dres=False,
+           mask_scale=None, mask_shift=None):
     C = x.shape[-1]
     npix = x.numel() // C
     dx = torch.empty_like(x)
@@ -303,7 +304,7 @@ def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accu
     L = _lib.lib()
     ws = workspace(L.dh_bn_bwd_workspace_size(_cl(npix), C, groups), x.device)
     _call("dh_bn_bwd", _ci(dt(x)), P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
-          _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(ws), S())
+          _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(mask_scale), P(mask_shift), P(ws), S())
     return (dx, dres) if want_dres else dx
 
 

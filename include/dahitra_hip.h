@@ -95,7 +95,10 @@ int dh_bn_apply(int dtype, const void* x, const void* residual, void* y, const f
                 long npix, int C, int groups, int act, void* stream);
 int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, const void* x, const float* mean,
               const float* invstd, const float* gamma, long npix, int C, int groups, void* dx, void* dres,
-              float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream);
+              float* dgamma, float* dbeta, int accumulate, const float* mask_scale, const float* mask_shift,
+              void* workspace, void* stream);
+/* ReLU mask of the layer: out_relu (its post-activation output) OR mask_scale / mask_shift [groups][C] (the forward's
+ * scale / shift: mask = x * scale + shift > 0, for layers without a residual input) OR neither (no ReLU) */
 long dh_bn_bwd_workspace_size(long npix, int C, int groups);
 int dh_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* partial, int ntiles, const float* mean,
                             const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,

@@ -403,3 +403,25 @@ def test_head_data_gradient_kernel(ops, dtype, ncls):
     assert dl.shape[-1] == cp
     dx = ops.head_dgrad3x3(dl, w.cuda(), ncls)
     close(nchw(dx), x.grad, dtype, "head dgrad", factor=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_backward_mask_recomputed_from_input(ops, dtype):
+    """ReLU mask as x * scale + shift > 0 (layers without a residual) == mask from the stored post-ReLU output"""
+    N, H, W, C, groups = 4, 12, 20, 64, 2
+    x = dev(rnd((N, H, W, C), dtype, 401, 1.5), dtype)
+    scale = (rnd((groups, C), torch.float32, 402, 0.2) + 1.0).cuda()
+    shift = rnd((groups, C), torch.float32, 403, 0.5).cuda()
+    out = ops.bn_apply(x, scale, shift, groups, ops.ACT_RELU)
+    dout = dev(rnd((N, H, W, C), dtype, 404), dtype)
+    mean = rnd((groups, C), torch.float32, 405, 0.2).cuda()
+    invstd = (rnd((groups, C), torch.float32, 406, 0.1) + 0.9).cuda()
+    gamma = (rnd((C,), torch.float32, 407, 0.1) + 1.0).cuda()
+    r = []
+    for kw in (dict(out=out), dict(out=None, mask_scale=scale, mask_shift=shift)):
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        o = kw.pop("out")
+        dx = ops.bn_bwd(dout, o, x, mean, invstd, gamma, dg, db, groups, accumulate=False, **kw)
+        r.append((dx.float(), dg, db))
+    assert float((out > 0).float().mean()) > 0.2 and float((out == 0).float().mean()) > 0.2
+    assert torch.equal(r[0][0], r[1][0]) and torch.equal(r[0][1], r[1][1]) and torch.equal(r[0][2], r[1][2])
