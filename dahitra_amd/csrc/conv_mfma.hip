@@ -44,7 +44,8 @@ struct ConvArgs {
     void* y;
     const float* bias;
     const void* res;
-    float* stats;      // [gridDim.x][2][CoutPad] partial (sum, sumsq) or null
+    float* stats;      // [2][CoutPad][gridDim.x] partial (sum, sumsq) per pixel tile, or null: channel-major, so that
+                       // the per-channel combine (bn_finalize) reads contiguous runs
     void* y2;          // optional: value before the activation (needed by the GELU derivative)
     int N, H, W, Cin, OH, OW, Cout, CoutPad, pad, act;
     int npix;          // valid output pixels per image in linear order (OH*OW unless a row view)
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
             const float t = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] +
                             red[(2 * 2 + which) * NT + c] + red[(3 * 2 + which) * NT + c];
             if (co0 + c < p.CoutPad)
-                p.stats[((size_t)blockIdx.x * 2 + which) * p.CoutPad + co0 + c] = t;
+                p.stats[((size_t)which * p.CoutPad + co0 + c) * gridDim.x + blockIdx.x] = t;   // [2][CoutPad][tiles]
         }
     }
 }

@@ -12,22 +12,24 @@
 namespace {
 
 // ---- finalize train-mode statistics --------------------------------------------------------
-// partial: [ntiles][2][CP] from the conv epilogue (tile order = image order).
+// partial: [2][CP][ntiles] from the conv epilogue (tile order = image order): one channel's tiles are contiguous.
 __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, int CP, int C, int G,
                                    double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float momentum, float eps,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                   long long* __restrict__ nbt) {
     const int c = blockIdx.x;
+    if (nbt && c == 0 && threadIdx.x == 0) *nbt += G;      // one forward_single per stream (models/networks.py:359-360)
     const int lane = threadIdx.x;      // 64 threads
     const int tpg = ntiles / G;
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
     for (int g = 0; g < G; ++g) {
         double s = 0.0, q = 0.0;
         for (int t = g * tpg + lane; t < (g + 1) * tpg; t += 64) {
-            s += (double)partial[((size_t)t * 2 + 0) * CP + c];
-            q += (double)partial[((size_t)t * 2 + 1) * CP + c];
+            s += (double)partial[((size_t)0 * CP + c) * ntiles + t];
+            q += (double)partial[((size_t)1 * CP + c) * ntiles + t];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -91,7 +93,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ r
 
 // ---- backward, pass 1: per-workgroup partial sums of dy and dy*xhat -------------------------
 // dy = dout * (out > 0) when `out` (the post-ReLU activation) is given.
-// partial: [G*bpg][2][C]; a workgroup never straddles two groups.
+// partial: [2][C][G*bpg]; a workgroup never straddles two groups.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                             const T* __restrict__ x,
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         const int which = o / C, c = o % C;
         float t = 0.f;
         for (int r = 0; r < rstep; ++r) t += red[(which * 256 + r * cvn + c / 4) * 4 + (c & 3)];
-        partial[((size_t)blockIdx.x * 2 + which) * C + c] = t;
+        partial[((size_t)which * C + c) * gridDim.x + blockIdx.x] = t;      // [2][C][G*bpg]
     }
 }
 
@@ -156,8 +158,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int bp
     for (int g = 0; g < G; ++g) {
         double s1 = 0.0, s2 = 0.0;
         for (int t = lane; t < bpg; t += 64) {
-            s1 += (double)partial[((size_t)(g * bpg + t) * 2 + 0) * C + c];
-            s2 += (double)partial[((size_t)(g * bpg + t) * 2 + 1) * C + c];
+            s1 += (double)partial[((size_t)0 * C + c) * G * bpg + g * bpg + t];
+            s2 += (double)partial[((size_t)1 * C + c) * G * bpg + g * bpg + t];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
@@ -331,10 +333,11 @@ inline int ew_grid(long n, int block) {
 extern "C" int dh_bn_finalize(const float* partial, int ntiles, int CP, int C, int groups, double count,
                               const float* gamma, const float* beta, float* running_mean, float* running_var,
                               float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                              void* stream) {
+                              long long* num_batches_tracked, void* stream) {
     DH_REQUIRE(groups > 0 && ntiles % groups == 0, "bn_finalize: ntiles=%d not divisible by groups=%d", ntiles, groups);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, ntiles, CP, C, groups, count,
-                       gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                       gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                       num_batches_tracked);
     DH_CHECK_LAUNCH("bn_finalize");
     return 0;
 }

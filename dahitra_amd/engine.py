@@ -135,8 +135,7 @@ class Engine:
             y, st = ops.conv2d(x, self.pk[wkey].fwd, cout, ks, stride, pad, want_stats=True, dilation=dilation)
             N, OH, OW, _ = y.shape
             mean, invstd, scale, shift = ops.bn_finalize(st, cout, groups, (N // groups) * OH * OW, gamma, beta, rm, rv,
-                                                         BN_MOMENTUM, BN_EPS)
-            self.p[bnkey + ".num_batches_tracked"].add_(groups)
+                                                         BN_MOMENTUM, BN_EPS, nbt=self.p[bnkey + ".num_batches_tracked"])
             out = ops.bn_apply(y, scale, shift, groups, act, residual)
         else:
             # eval: BatchNorm folds into the convolution -- scale into the packed weights, shift as the bias
@@ -201,8 +200,7 @@ class Engine:
         if self.training:
             y, st = ops.conv2d(xs, self.pk[wkey].fwd, 64, 4, 1, 2, want_stats=True, out_hw=(oh, ow))
             mean, invstd, scale, shift = ops.bn_finalize(st, 64, groups, B * oh * ow, gamma, beta, rm, rv, BN_MOMENTUM,
-                                                         BN_EPS)
-            self.p[bnkey + ".num_batches_tracked"].add_(groups)
+                                                         BN_EPS, nbt=self.p[bnkey + ".num_batches_tracked"])
             out = ops.bn_apply(y, scale, shift, groups, RELU)
         else:
             scale, shift = ops.bn_eval_params(gamma, beta, rm, rv, BN_EPS)

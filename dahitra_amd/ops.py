@@ -158,7 +158,7 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     stats = None
     if want_stats:
         nt = _lib.lib().dh_conv2d_fwd_num_tiles(N, OH, OW, Cin, ks, stride)
-        stats = torch.empty(nt, 2, cpad, dtype=torch.float32, device=x.device)
+        stats = torch.empty(2, cpad, nt, dtype=torch.float32, device=x.device)      # [sum | sumsq][channel][tile]
     ev = None
     if PROFILE is not None:      # bench.py: HIP events on the launch stream around this kernel class
         nt = 64 if cpad % 64 == 0 else (32 if cpad % 32 == 0 else 16)
@@ -268,13 +268,14 @@ def stem_wgrad(x_s2d, dy, dw, accumulate=False, use_tr=True):
 
 
 # ---- normalisation -------------------------------------------------------------------------------
-def bn_finalize(stats, C, groups, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
-    nt, _, cp = stats.shape
+def bn_finalize(stats, C, groups, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, nbt=None):
+    """nbt: the layer's int64 num_batches_tracked buffer (device), incremented by `groups` in the same launch"""
+    _, cp, nt = stats.shape
     dev = stats.device
     mean = torch.empty(groups, C, dtype=torch.float32, device=dev)
     invstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
     _call("dh_bn_finalize", P(stats), _ci(nt), _ci(cp), _ci(C), _ci(groups), _cd(float(count)), P(gamma), P(beta),
-          P(running_mean), P(running_var), _cf(momentum), _cf(eps), P(mean), P(invstd), P(scale), P(shift), S())
+          P(running_mean), P(running_var), _cf(momentum), _cf(eps), P(mean), P(invstd), P(scale), P(shift), P(nbt), S())
     return mean, invstd, scale, shift
 
 
@@ -312,7 +313,7 @@ def bn_bwd_from_partials(g, x, partial, mean, invstd, gamma, dgamma, dbeta, grou
     """BN backward fed by a gated data-gradient launch (conv2d(..., gate=...)): g already carries the ReLU mask"""
     C = x.shape[-1]
     npix = x.numel() // C
-    nt, _, cp = partial.shape
+    _, cp, nt = partial.shape
     assert cp == C and g.shape == x.shape
     dx = torch.empty_like(x)
     ws = workspace(groups * 2 * C * 4, x.device)

@@ -44,7 +44,8 @@ void dh_set_error(const char* msg);
  *                      + bias[co] + residual[n,oy,ox,co] )
  * w_packed: [ks*ks][CoutPad][Cin] T (dh_pack_weight).  Cin*sizeof(T) must be a multiple of 64.
  * y_preact (optional): receives the value before `act`.  stats_partial (optional):
- * [dh_conv2d_fwd_num_tiles(N,OH,OW,Cin,ks,stride)][2][CoutPad] fp32 per-tile (sum, sum of squares) of y for BatchNorm.
+ * [2][CoutPad][dh_conv2d_fwd_num_tiles(N,OH,OW,Cin,ks,stride)] fp32 per-tile (sum, sum of squares) of y for BatchNorm
+ * (channel-major: the per-channel combine reads contiguous runs).
  * npix_valid > 0: treat each image as a row list with that many valid rows (H*W >= npix_valid). */
 int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const float* bias,
                   const void* residual, float* stats_partial, int N, int H, int W, int Cin, int OH, int OW,
@@ -88,7 +89,8 @@ int dh_stem_unpack_grad(const float* dw2, float* dw_oihw, int O, int CP, int acc
 /* ---- BatchNorm2d (models/resnet.py:152,40-44; help_funcs.py:11) and LayerNorm(32) (help_funcs.py:34-49) */
 int dh_bn_finalize(const float* partial, int ntiles, int CP, int C, int groups, double count, const float* gamma,
                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+                   float* mean, float* invstd, float* scale, float* shift, long long* num_batches_tracked,
+                   void* stream);   /* partial: [2][CP][ntiles]; num_batches_tracked (optional) += groups */
 int dh_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float eps, int C, float* scale, float* shift, void* stream);
 int dh_bn_apply(int dtype, const void* x, const void* residual, void* y, const float* scale, const float* shift,

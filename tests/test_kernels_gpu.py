@@ -73,7 +73,7 @@ def test_conv2d_fwd(ops, dtype, cfg):
                                want_preact=True, dilation=dil)
     close(nchw(y), want, dtype, "conv2d out")
     close(nchw(pre), want_pre + r, dtype, "conv2d preact")
-    tot = stats.sum(0).cpu()           # [2][CoutPad]
+    tot = stats.sum(2).cpu()           # [2][CoutPad]
     close(tot[0, :cfg["cout"]], want.sum((0, 2, 3)), dtype, "stats sum", scale=float(want.abs().sum((0, 2, 3)).max()))
     close(tot[1, :cfg["cout"]], (want * want).sum((0, 2, 3)), dtype, "stats sumsq")
 
