@@ -68,26 +68,25 @@ template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                 const float* __restrict__ scale, const float* __restrict__ shift, long nvec,
                                 int C, long group_vec, int act) {
+    constexpr int V = V16<T>::N;        // one 16-byte piece per lane
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
+        const int c = (int)((i * V) % C);
         const int g = (int)(i / group_vec);
-        float v[4];
-        ld4(x + i * 4, v);
-        const float4 sc = *reinterpret_cast<const float4*>(scale + g * C + c);
-        const float4 sh = *reinterpret_cast<const float4*>(shift + g * C + c);
-        v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
-        v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
-        if (res) {
-            float r[4];
-            ld4(res + i * 4, r);
+        float v[V];
+        ldv(x + i * V, v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += r[j];
+        for (int j = 0; j < V; ++j) v[j] = v[j] * scale[g * C + c + j] + shift[g * C + c + j];
+        if (res) {
+            float r[V];
+            ldv(res + i * V, r);
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] += r[j];
         }
         if (act == DH_ACT_RELU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            for (int j = 0; j < V; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        st4(y + i * 4, v);
+        stv(y + i * V, v);
     }
 }
 
@@ -103,48 +102,49 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             float* __restrict__ partial,
                                                             const float* __restrict__ mscale,
                                                             const float* __restrict__ mshift) {
-    __shared__ float red[2 * 256 * 4];
+    constexpr int V = V16<T>::N;               // channels per lane: one 16-byte piece
+    __shared__ float red[2 * 256 * V];
     const int g = blockIdx.x / bpg, b = blockIdx.x % bpg;
-    const int cvn = C / 4;                     // vector columns
+    const int cvn = C / V;                     // vector columns
     const int cv = threadIdx.x % cvn, r0 = threadIdx.x / cvn, rstep = 256 / cvn;
     const long chunk = (pix_per_group + bpg - 1) / bpg;
     const long p0 = b * chunk, p1 = (p0 + chunk < pix_per_group) ? p0 + chunk : pix_per_group;
-    float mu[4], is[4], s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float mu[V], is[V], s1[V], s2[V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { mu[j] = mean[g * C + cv * 4 + j]; is[j] = invstd[g * C + cv * 4 + j]; }
+    for (int j = 0; j < V; ++j) { mu[j] = mean[g * C + cv * V + j]; is[j] = invstd[g * C + cv * V + j]; s1[j] = 0.f; s2[j] = 0.f; }
     for (long p = p0 + r0; p < p1; p += rstep) {
-        const size_t off = ((size_t)g * pix_per_group + p) * C + cv * 4;
-        float d[4], xv[4];
-        ld4(dout + off, d);
-        ld4(x + off, xv);
+        const size_t off = ((size_t)g * pix_per_group + p) * C + cv * V;
+        float d[V], xv[V];
+        ldv(dout + off, d);
+        ldv(x + off, xv);
         if (out) {
-            float o[4];
-            ld4(out + off, o);
+            float o[V];
+            ldv(out + off, o);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+            for (int j = 0; j < V; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
         } else if (mscale) {
             // ReLU mask recomputed from the pre-normalisation input (layers without a residual): the same
             // x * scale + shift the forward evaluated, so one tensor read less in each backward pass
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                d[j] = (xv[j] * mscale[g * C + cv * 4 + j] + mshift[g * C + cv * 4 + j]) > 0.f ? d[j] : 0.f;
+            for (int j = 0; j < V; ++j)
+                d[j] = (xv[j] * mscale[g * C + cv * V + j] + mshift[g * C + cv * V + j]) > 0.f ? d[j] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < V; ++j) {
             s1[j] += d[j];
             s2[j] += d[j] * (xv[j] - mu[j]) * is[j];
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        red[(0 * 256 + threadIdx.x) * 4 + j] = s1[j];
-        red[(1 * 256 + threadIdx.x) * 4 + j] = s2[j];
+    for (int j = 0; j < V; ++j) {
+        red[(0 * 256 + threadIdx.x) * V + j] = s1[j];
+        red[(1 * 256 + threadIdx.x) * V + j] = s2[j];
     }
     __syncthreads();
     for (int o = threadIdx.x; o < 2 * C; o += 256) {
         const int which = o / C, c = o % C;
         float t = 0.f;
-        for (int r = 0; r < rstep; ++r) t += red[(which * 256 + r * cvn + c / 4) * 4 + (c & 3)];
+        for (int r = 0; r < rstep; ++r) t += red[(which * 256 + r * cvn + c / V) * V + (c % V)];
         partial[((size_t)which * C + c) * gridDim.x + blockIdx.x] = t;      // [2][C][G*bpg]
     }
 }
@@ -179,29 +179,30 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
                                     const float* __restrict__ gamma, const float* __restrict__ sums, float inv_m,
                                     long nvec, int C, long group_vec, T* __restrict__ dx, T* __restrict__ dres,
                                     const float* __restrict__ mscale, const float* __restrict__ mshift) {
+    constexpr int V = V16<T>::N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
+        const int c = (int)((i * V) % C);
         const int g = (int)(i / group_vec);
-        float d[4], xv[4], r[4];
-        ld4(dout + i * 4, d);
-        ld4(x + i * 4, xv);
+        float d[V], xv[V], r[V];
+        ldv(dout + i * V, d);
+        ldv(x + i * V, xv);
         if (out) {
-            float o[4];
-            ld4(out + i * 4, o);
+            float o[V];
+            ldv(out + i * V, o);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+            for (int j = 0; j < V; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
         } else if (mscale) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[j] = (xv[j] * mscale[g * C + c + j] + mshift[g * C + c + j]) > 0.f ? d[j] : 0.f;
+            for (int j = 0; j < V; ++j) d[j] = (xv[j] * mscale[g * C + c + j] + mshift[g * C + c + j]) > 0.f ? d[j] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < V; ++j) {
             const float is = invstd[g * C + c + j];
             const float xh = (xv[j] - mean[g * C + c + j]) * is;
             r[j] = gamma[c + j] * is * (d[j] - (sums[(g * 2 + 0) * C + c + j] + xh * sums[(g * 2 + 1) * C + c + j]) * inv_m);
         }
-        st4(dx + i * 4, r);
-        if (dres) st4(dres + i * 4, d);
+        stv(dx + i * V, r);
+        if (dres) stv(dres + i * V, d);
     }
 }
 
@@ -353,8 +354,9 @@ extern "C" int dh_bn_eval_params(const float* gamma, const float* beta, const fl
 
 extern "C" int dh_bn_apply(int dtype, const void* x, const void* residual, void* y, const float* scale,
                            const float* shift, long npix, int C, int groups, int act, void* stream) {
-    DH_REQUIRE(C % 4 == 0 && npix % groups == 0, "bn_apply: C=%d npix=%ld groups=%d", C, npix, groups);
-    const long nvec = npix * C / 4, gvec = nvec / groups;
+    const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;       // elements of one 16-byte piece
+    DH_REQUIRE(C % V == 0 && npix % groups == 0, "bn_apply: C=%d npix=%ld groups=%d", C, npix, groups);
+    const long nvec = npix * C / V, gvec = nvec / groups;
     if (dtype == DH_DTYPE_BF16)
         hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const bf16*)x,
                            (const bf16*)residual, (bf16*)y, scale, shift, nvec, C, gvec, act);
@@ -376,13 +378,14 @@ extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, cons
                          void* dres, float* dgamma, float* dbeta, int accumulate, const float* mask_scale,
                          const float* mask_shift, void* workspace, void* stream) {
     DH_REQUIRE(!(out_relu && mask_scale), "bn_bwd: give the ReLU mask either as out_relu or as mask_scale/shift");
-    DH_REQUIRE(C % 4 == 0 && 1024 % C == 0, "bn_bwd: unsupported C=%d", C);
+    const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;       // elements of one 16-byte piece
+    DH_REQUIRE(C % V == 0 && (256 * V) % C == 0, "bn_bwd: unsupported C=%d", C);
     DH_REQUIRE(npix % groups == 0, "bn_bwd: npix %% groups");
     const int bpg = 1024 / groups;      // ~1024 workgroups in total (4 per CU)
     const long ppg = npix / groups;
     float* partial = reinterpret_cast<float*>(workspace);
     float* sums = partial + (long)groups * bpg * 2 * C;
-    const long nvec = npix * C / 4;
+    const long nvec = npix * C / V;
     if (dtype == DH_DTYPE_BF16) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(groups * bpg), dim3(256), 0, ST(stream), (const bf16*)dout,
                            (const bf16*)out_relu, (const bf16*)x, mean, invstd, C, ppg, bpg, partial, mask_scale, mask_shift);
@@ -411,10 +414,11 @@ extern "C" int dh_bn_bwd_from_partials(int dtype, const void* g, const void* x, 
                                        const float* mean, const float* invstd, const float* gamma, long npix, int C,
                                        int groups, void* dx, float* dgamma, float* dbeta, int accumulate,
                                        void* workspace, void* stream) {
-    DH_REQUIRE(C % 4 == 0 && groups > 0 && ntiles % groups == 0 && npix % groups == 0,
+    const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;
+    DH_REQUIRE(C % V == 0 && groups > 0 && ntiles % groups == 0 && npix % groups == 0,
                "bn_bwd_from_partials: C=%d ntiles=%d npix=%ld groups=%d", C, ntiles, npix, groups);
     float* sums = reinterpret_cast<float*>(workspace);
-    const long ppg = npix / groups, nvec = npix * C / 4;
+    const long ppg = npix / groups, nvec = npix * C / V;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, ntiles / groups, groups, C, sums,
                        dgamma, dbeta, accumulate);
     if (dtype == DH_DTYPE_BF16)
