@@ -84,7 +84,7 @@ template <> struct Mma<bf16> {
     }
 };
 
-template <typename T, int KS, int STRIDE, int NT, int RW, int DIL>
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     constexpr int TH = 4 * RW;
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
@@ -162,11 +162,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         }
     };
 
-    fetch(0);
+    // PF = false (layers with at most two channel chunks): nothing to pipeline inside a workgroup, so the staging
+    // registers are not kept alive across the MFMAs -- fewer VGPRs, one more resident workgroup per CU does the overlap
+    if (PF) fetch(0);
     for (int c0 = 0; c0 < p.Cin; c0 += CK) {
+        if (!PF) fetch(c0);
         commit();
         __syncthreads();
-        if (c0 + CK < p.Cin) fetch(c0 + CK);
+        if (PF && c0 + CK < p.Cin) fetch(c0 + CK);
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh) {
 #pragma unroll
@@ -274,12 +277,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float a = ssum[s][j], b = ssq[s][j];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    a += __shfl_xor(a, o, 64);
-                    b += __shfl_xor(b, o, 64);
-                }
+                const float a = row16_sum(ssum[s][j]), b = row16_sum(ssq[s][j]);
                 if (pl == 0) {
                     red[(wv * 2 + 0) * NT + s * 16 + g * 4 + j] = a;
                     red[(wv * 2 + 1) * NT + s * 16 + g * 4 + j] = b;
@@ -304,12 +302,12 @@ static inline int pick_rw(int N, int OH, int OW, int Cin, int ks, int stride) {
     return 2;
 }
 
-template <typename T, int KS, int STRIDE, int NT, int RW, int DIL>
-int launch_rw(const ConvArgs& a, hipStream_t st) {
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>
+int launch_pf(const ConvArgs& a, hipStream_t st) {
     constexpr int TH = 4 * RW;
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     const size_t lds = (size_t)HH * HWD * HaloLayout<STRIDE>::PITCH + (size_t)KS * KS * NT * WPITCH;
-    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW, DIL>;
+    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW, DIL, PF>;
     static bool attr_done = false;      // once per instantiation (and never inside a graph capture)
     if (lds > 64 * 1024 && !attr_done) {
         attr_done = true;
@@ -324,6 +322,15 @@ int launch_rw(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
     DH_CHECK_LAUNCH("conv_mfma");
     return 0;
+}
+
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL>
+int launch_rw(const ConvArgs& a, hipStream_t st) {
+    constexpr int CK = 64 / (int)sizeof(T);
+    if constexpr (RW == 2 && KS == 3 && DIL == 1) {
+        if (a.Cin <= 2 * CK) return launch_pf<T, KS, STRIDE, NT, RW, DIL, false>(a, st);
+    }
+    return launch_pf<T, KS, STRIDE, NT, RW, DIL, true>(a, st);
 }
 
 template <typename T, int KS, int STRIDE, int NT>
