@@ -220,38 +220,42 @@ __global__ void maxpool_bwd_kernel(const unsigned char* __restrict__ arg, const 
 // ---- nearest x2 -----------------------------------------------------------------------------
 template <typename T>
 __global__ void up2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C) {
-    const int vn = C / 4;
+    constexpr int V = V16<T>::N;      // one 16-byte piece per lane
+    const int vn = C / V;
     GSL(i, (long)N * 4 * H * W * vn) {
-        const int c = (int)(i % vn) * 4;
+        const int c = (int)(i % vn) * V;
         long t = i / vn;
         const int ox = (int)(t % (2 * W)); t /= 2 * W;
         const int oy = (int)(t % (2 * H));
         const long n = t / (2 * H);
-        float v[4];
-        ld4(x + ((n * H + oy / 2) * W + ox / 2) * C + c, v);
-        st4(y + i * 4, v);
+        float v[V];
+        ldv(x + ((n * H + oy / 2) * W + ox / 2) * C + c, v);
+        stv(y + i * V, v);
     }
 }
 template <typename T>
 __global__ void up2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C) {
-    const int vn = C / 4;
+    constexpr int V = V16<T>::N;      // one 16-byte piece per lane
+    const int vn = C / V;
     GSL(i, (long)N * H * W * vn) {
-        const int c = (int)(i % vn) * 4;
+        const int c = (int)(i % vn) * V;
         long t = i / vn;
         const int ix = (int)(t % W); t /= W;
         const int iy = (int)(t % H);
         const long n = t / H;
-        float s[4] = {0, 0, 0, 0};
+        float s[V];
+#pragma unroll
+        for (int j_ = 0; j_ < V; ++j_) s[j_] = 0.f;
 #pragma unroll
         for (int dyy = 0; dyy < 2; ++dyy)
 #pragma unroll
             for (int dxx = 0; dxx < 2; ++dxx) {
-                float v[4];
-                ld4(dy + ((n * 2 * H + 2 * iy + dyy) * 2 * W + 2 * ix + dxx) * C + c, v);
+                float v[V];
+                ldv(dy + ((n * 2 * H + 2 * iy + dyy) * 2 * W + 2 * ix + dxx) * C + c, v);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s[j] += v[j];
+                for (int j = 0; j < V; ++j) s[j] += v[j];
             }
-        st4(dx + i * 4, s);
+        stv(dx + i * V, s);
     }
 }
 
@@ -266,9 +270,10 @@ __device__ __forceinline__ void bil_src(int d, int in, int& i0, int& i1, float& 
 template <typename T>
 __global__ void absdiff_up4_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int N,
                                        int H, int W, int C) {
-    const int vn = C / 4, OH = 4 * H, OW = 4 * W;
+    constexpr int V = V16<T>::N;      // one 16-byte piece per lane
+    const int vn = C / V, OH = 4 * H, OW = 4 * W;
     GSL(i, (long)N * OH * OW * vn) {
-        const int c = (int)(i % vn) * 4;
+        const int c = (int)(i % vn) * V;
         long t = i / vn;
         const int ox = (int)(t % OW); t /= OW;
         const int oy = (int)(t % OH);
@@ -276,35 +281,40 @@ __global__ void absdiff_up4_fwd_kernel(const T* __restrict__ a, const T* __restr
         int y0, y1, x0, x1; float ly, lx;
         bil_src(oy, H, y0, y1, ly);
         bil_src(ox, W, x0, x1, lx);
-        float acc[4] = {0, 0, 0, 0};
+        float acc[V];
+#pragma unroll
+        for (int j_ = 0; j_ < V; ++j_) acc[j_] = 0.f;
         const int ys[2] = {y0, y1}, xs[2] = {x0, x1};
         const float wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                float u[4], v[4];
+                float u[V], v[V];
                 const long off = ((n * H + ys[p]) * W + xs[q]) * C + c;
-                ld4(a + off, u);
-                ld4(b + off, v);
+                ldv(a + off, u);
+                ldv(b + off, v);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] += wy[p] * wx[q] * fabsf(u[j] - v[j]);
+                for (int j = 0; j < V; ++j) acc[j] += wy[p] * wx[q] * fabsf(u[j] - v[j]);
             }
-        st4(y + i * 4, acc);
+        stv(y + i * V, acc);
     }
 }
 // gather backward: source pixel (iy, ix) collects from destination rows 4*iy-2 .. 4*iy+5
 template <typename T>
 __global__ void absdiff_up4_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ dy,
                                        T* __restrict__ da, T* __restrict__ db, int N, int H, int W, int C) {
-    const int vn = C / 4, OH = 4 * H, OW = 4 * W;
+    constexpr int V = V16<T>::N;      // one 16-byte piece per lane
+    const int vn = C / V, OH = 4 * H, OW = 4 * W;
     GSL(i, (long)N * H * W * vn) {
-        const int c = (int)(i % vn) * 4;
+        const int c = (int)(i % vn) * V;
         long t = i / vn;
         const int ix = (int)(t % W); t /= W;
         const int iy = (int)(t % H);
         const long n = t / H;
-        float g[4] = {0, 0, 0, 0};
+        float g[V];
+#pragma unroll
+        for (int j_ = 0; j_ < V; ++j_) g[j_] = 0.f;
         for (int oy = 4 * iy - 2; oy <= 4 * iy + 5; ++oy) {
             if (oy < 0 || oy >= OH) continue;
             int y0, y1; float ly;
@@ -317,24 +327,24 @@ __global__ void absdiff_up4_bwd_kernel(const T* __restrict__ a, const T* __restr
                 bil_src(ox, W, x0, x1, lx);
                 const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
                 if (wx == 0.f) continue;
-                float d[4];
-                ld4(dy + ((n * OH + oy) * OW + ox) * C + c, d);
+                float d[V];
+                ldv(dy + ((n * OH + oy) * OW + ox) * C + c, d);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] += wy * wx * d[j];
+                for (int j = 0; j < V; ++j) g[j] += wy * wx * d[j];
             }
         }
-        float u[4], v[4], ga[4], gb[4];
-        ld4(a + i * 4, u);
-        ld4(b + i * 4, v);
+        float u[V], v[V], ga[V], gb[V];
+        ldv(a + i * V, u);
+        ldv(b + i * V, v);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < V; ++j) {
             const float df = u[j] - v[j];
             const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
             ga[j] = sg * g[j];
             gb[j] = -ga[j];
         }
-        st4(da + i * 4, ga);
-        st4(db + i * 4, gb);
+        stv(da + i * V, ga);
+        stv(db + i * V, gb);
     }
 }
 
@@ -585,32 +595,36 @@ extern "C" int dh_maxpool3x3s2_bwd(int dtype, const unsigned char* argmax, const
     return 0;
 }
 extern "C" int dh_upsample2_nearest_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
-    DH_REQUIRE(C % 4 == 0, "upsample2: C %% 4");
-    const long n = (long)N * 4 * H * W * (C / 4);
+    const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;
+    DH_REQUIRE(C % V == 0, "upsample2: C=%d must be a multiple of %d", C, V);
+    const long n = (long)N * 4 * H * W * (C / V);
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(up2_fwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, N, H, W, C);
     else hipLaunchKernelGGL(up2_fwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, N, H, W, C);
     DH_CHECK_LAUNCH("up2_fwd");
     return 0;
 }
 extern "C" int dh_upsample2_nearest_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
-    DH_REQUIRE(C % 4 == 0, "upsample2: C %% 4");
-    const long n = (long)N * H * W * (C / 4);
+    const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;
+    DH_REQUIRE(C % V == 0, "upsample2: C=%d must be a multiple of %d", C, V);
+    const long n = (long)N * H * W * (C / V);
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(up2_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)dy, (bf16*)dx, N, H, W, C);
     else hipLaunchKernelGGL(up2_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)dy, (float*)dx, N, H, W, C);
     DH_CHECK_LAUNCH("up2_bwd");
     return 0;
 }
 extern "C" int dh_absdiff_upsample4_fwd(int dtype, const void* a, const void* b, void* y, int N, int H, int W, int C, void* stream) {
-    DH_REQUIRE(C % 4 == 0, "absdiff_upsample4: C %% 4");
-    const long n = (long)N * 16 * H * W * (C / 4);
+    const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;
+    DH_REQUIRE(C % V == 0, "absdiff_upsample4: C=%d must be a multiple of %d", C, V);
+    const long n = (long)N * 16 * H * W * (C / V);
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(absdiff_up4_fwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (bf16*)y, N, H, W, C);
     else hipLaunchKernelGGL(absdiff_up4_fwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (float*)y, N, H, W, C);
     DH_CHECK_LAUNCH("absdiff_up4_fwd");
     return 0;
 }
 extern "C" int dh_absdiff_upsample4_bwd(int dtype, const void* a, const void* b, const void* dy, void* da, void* db, int N, int H, int W, int C, void* stream) {
-    DH_REQUIRE(C % 4 == 0, "absdiff_upsample4: C %% 4");
-    const long n = (long)N * H * W * (C / 4);
+    const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;
+    DH_REQUIRE(C % V == 0, "absdiff_upsample4: C=%d must be a multiple of %d", C, V);
+    const long n = (long)N * H * W * (C / V);
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(absdiff_up4_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (const bf16*)dy, (bf16*)da, (bf16*)db, N, H, W, C);
     else hipLaunchKernelGGL(absdiff_up4_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (const float*)dy, (float*)da, (float*)db, N, H, W, C);
     DH_CHECK_LAUNCH("absdiff_up4_bwd");
