@@ -156,33 +156,51 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ r
 }
 
 // ---- MaxPool 3x3 stride 2 pad 1 -------------------------------------------------------------
+// V packed arg-max codes (one byte per channel) as one 4- or 8-byte access
+template <int V> __device__ __forceinline__ unsigned long long ld_bytes(const unsigned char* p) {
+    if constexpr (V == 8) return *reinterpret_cast<const unsigned long long*>(p);
+    else return *reinterpret_cast<const unsigned*>(p);
+}
+template <int V> __device__ __forceinline__ void st_bytes(unsigned char* p, unsigned long long v) {
+    if constexpr (V == 8) *reinterpret_cast<unsigned long long*>(p) = v;
+    else *reinterpret_cast<unsigned*>(p) = (unsigned)v;
+}
+
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ arg, int N,
                                    int H, int W, int C, int OH, int OW) {
-    const int vn = C / 4;
+    constexpr int V = V16<T>::N;      // one 16-byte piece per lane
+    const int vn = C / V;
     GSL(i, (long)N * OH * OW * vn) {
-        const int c = (int)(i % vn) * 4;
+        const int c = (int)(i % vn) * V;
         long t = i / vn;
         const int ox = (int)(t % OW); t /= OW;
         const int oy = (int)(t % OH);
         const long n = t / OH;
-        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int k[4] = {-1, -1, -1, -1};
+        float m[V];
+        int k[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { m[j] = -INFINITY; k[j] = -1; }
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * 2 - 1 + ky;
             if (iy < 0 || iy >= H) continue;
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * 2 - 1 + kx;
                 if (ix < 0 || ix >= W) continue;
-                float v[4];
-                ld4(x + ((n * H + iy) * W + ix) * C + c, v);
+                float v[V];
+                ldv(x + ((n * H + iy) * W + ix) * C + c, v);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < V; ++j)
                     if (v[j] > m[j] || k[j] < 0) { m[j] = v[j]; k[j] = ky * 3 + kx; }     // first maximum wins
             }
         }
-        st4(y + i * 4, m);
-        if (arg) *reinterpret_cast<uchar4*>(arg + i * 4) = make_uchar4(k[0], k[1], k[2], k[3]);
+        stv(y + i * V, m);
+        if (arg) {
+            unsigned long long bits = 0;
+#pragma unroll
+            for (int j = 0; j < V; ++j) bits |= (unsigned long long)(k[j] & 0xff) << (8 * j);
+            st_bytes<V>(arg + i * V, bits);
+        }
     }
 }
 // gather form with the saved window arg-max (row-major scan, strict >, as ATen's CPU kernel): an input pixel
@@ -190,30 +208,32 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
 template <typename T>
 __global__ void maxpool_bwd_kernel(const unsigned char* __restrict__ arg, const T* __restrict__ dy, T* __restrict__ dx,
                                    int N, int H, int W, int C, int OH, int OW) {
-    const int vn = C / 4;
+    constexpr int V = V16<T>::N;
+    const int vn = C / V;
     GSL(i, (long)N * H * W * vn) {
-        const int c = (int)(i % vn) * 4;
+        const int c = (int)(i % vn) * V;
         long t = i / vn;
         const int ix = (int)(t % W); t /= W;
         const int iy = (int)(t % H);
         const long n = t / H;
-        float g[4] = {0, 0, 0, 0};
+        float g[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) g[j] = 0.f;
         for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {   // windows with 2*oy-1 <= iy <= 2*oy+1
             if (oy >= OH) continue;
             for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
                 if (ox >= OW) continue;
-                const int kk = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
+                const unsigned kk = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
                 const long o = ((n * OH + oy) * OW + ox) * C + c;
-                const uchar4 a = *reinterpret_cast<const uchar4*>(arg + o);
-                float d[4];
-                ld4(dy + o, d);
-                if (a.x == kk) g[0] += d[0];
-                if (a.y == kk) g[1] += d[1];
-                if (a.z == kk) g[2] += d[2];
-                if (a.w == kk) g[3] += d[3];
+                const unsigned long long bits = ld_bytes<V>(arg + o);
+                float d[V];
+                ldv(dy + o, d);
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                    if (((bits >> (8 * j)) & 0xff) == kk) g[j] += d[j];
             }
         }
-        st4(dx + i * 4, g);
+        stv(dx + i * V, g);
     }
 }
 
@@ -577,18 +597,20 @@ extern "C" int dh_act_bwd(int dtype, const void* dy, const void* ref, void* dx, 
     return 0;
 }
 extern "C" int dh_maxpool3x3s2_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int N, int H, int W, int C, void* stream) {
-    DH_REQUIRE(C % 4 == 0, "maxpool: C %% 4");
+    const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;
+    DH_REQUIRE(C % V == 0, "maxpool: C=%d must be a multiple of %d", C, V);
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    const long n = (long)N * OH * OW * (C / 4);
+    const long n = (long)N * OH * OW * (C / V);
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, argmax, N, H, W, C, OH, OW);
     else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, argmax, N, H, W, C, OH, OW);
     DH_CHECK_LAUNCH("maxpool_fwd");
     return 0;
 }
 extern "C" int dh_maxpool3x3s2_bwd(int dtype, const unsigned char* argmax, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
-    DH_REQUIRE(C % 4 == 0, "maxpool: C %% 4");
+    const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;
+    DH_REQUIRE(C % V == 0, "maxpool: C=%d must be a multiple of %d", C, V);
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    const long n = (long)N * H * W * (C / 4);
+    const long n = (long)N * H * W * (C / V);
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), argmax, (const bf16*)dy, (bf16*)dx, N, H, W, C, OH, OW);
     else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), argmax, (const float*)dy, (float*)dx, N, H, W, C, OH, OW);
     DH_CHECK_LAUNCH("maxpool_bwd");
