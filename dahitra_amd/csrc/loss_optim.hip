@@ -173,23 +173,31 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
-// x NCHW fp32 [N][3][H][W] -> space-to-depth NHWC T [N][H/2][W/2][CP], channel (ry*2+rx)*3 + c
+// x NCHW fp32 [N][3][H][W] -> space-to-depth NHWC T [N][H/2][W/2][CP], channel (ry*2+rx)*3 + c.
+// One lane writes one 16-byte piece (8 bf16 / 4 fp32 channels); the 12 real channels are gathered from the three
+// colour planes, the padding channels are zeros.
 template <typename T>
 __global__ void stem_s2d_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int H, int W, int CP) {
-    const int H2 = H / 2, W2 = W / 2;
-    const long total = (long)N * H2 * W2 * CP;
+    constexpr int V = V16<T>::N;
+    const int H2 = H / 2, W2 = W / 2, vn = CP / V;
+    const long total = (long)N * H2 * W2 * vn;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % CP);
-        long t = i / CP;
+        const int ch0 = (int)(i % vn) * V;
+        long t = i / vn;
         const int x2 = (int)(t % W2); t /= W2;
         const int y2 = (int)(t % H2);
         const long n = t / H2;
-        float v = 0.f;
-        if (ch < 12) {
-            const int c = ch % 3, r = ch / 3, ry = r >> 1, rx = r & 1;
-            v = x[((n * 3 + c) * H + 2 * y2 + ry) * W + 2 * x2 + rx];
+        float v[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int ch = ch0 + j;
+            v[j] = 0.f;
+            if (ch < 12) {
+                const int c = ch % 3, r = ch / 3, ry = r >> 1, rx = r & 1;
+                v[j] = x[((n * 3 + c) * H + 2 * y2 + ry) * W + 2 * x2 + rx];
+            }
         }
-        stf(y + i, v);
+        stv(y + i * V, v);
     }
 }
 // w OIHW fp32 [O][3][7][7] -> packed [16 taps (dy,dx)][O][CP] T, kh = 2*dy + ry - 1, kw = 2*dx + rx - 1
@@ -305,8 +313,9 @@ extern "C" int dh_adamw_step(float* param, const float* grad, float* exp_avg, fl
 
 extern "C" int dh_stem_space_to_depth(int dtype, const float* x_nchw, void* y, int N, int H, int W, int CP,
                                       void* stream) {
-    DH_REQUIRE(H % 2 == 0 && W % 2 == 0 && CP >= 12, "stem_s2d: H, W must be even and CP >= 12");
-    const long n = (long)N * (H / 2) * (W / 2) * CP;
+    const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;
+    DH_REQUIRE(H % 2 == 0 && W % 2 == 0 && CP >= 12 && CP % V == 0, "stem_s2d: H, W must be even and CP >= 12 (multiple of %d)", V);
+    const long n = (long)N * (H / 2) * (W / 2) * (CP / V);
     long g = (n + 255) / 256;
     if (g > 8192) g = 8192;
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(stem_s2d_kernel<bf16>, dim3((int)g), dim3(256), 0, ST(stream), x_nchw, (bf16*)y, N, H, W, CP);
