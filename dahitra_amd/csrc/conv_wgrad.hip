@@ -32,6 +32,8 @@ struct WgArgs {
     int CinPitch;      // elements between consecutive pixels of x (>= Cin; the stem reads a padded image)
     int dil;
     int CoutUse;       // output channels that carry a gradient (<= Cout: dy may be zero-padded to a K-chunk)
+    int direct;        // 0: write the partial slab; 1 / 2: split-K is 1 and the slab layout IS the destination layout
+                       // (1x1, one group), so assign (1) or accumulate (2) straight into dW and skip the reduce launch
 };
 
 // the 16-byte piece q of channels [c0, ...) of one pixel row (zeros past Ctot / for a null row)
@@ -253,7 +255,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int co = co0 + cw * 16 + g * 4 + j, ci = ci0 + i * 16 + pl;
-                if (co < p.CoutUse && ci < p.Cin) out[((size_t)t * p.Cout + co) * p.Cin + ci] = acc[t][i][j];
+                if (co < p.CoutUse && ci < p.Cin) {
+                    float* dst = out + ((size_t)t * p.Cout + co) * p.Cin + ci;
+                    if (p.direct == 2) *dst += acc[t][i][j]; else *dst = acc[t][i][j];
+                }
             }
 }
 
@@ -372,12 +377,16 @@ extern "C" int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* 
     a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, TH);
     a.CoutUse = Cout_real > 0 ? Cout_real : Cout;
     a.groups = groups; a.splitk = dh_conv2d_wgrad_splitk(N, OH, OW, Cin, Cout, ks, groups);
+    // 1x1 with a single K slab: [tap = 1][Cout][Cin] is exactly dW's [Cout][Cin] (also per image: [N][Cout][Cin])
+    a.direct = (ks == 1 && a.splitk == 1 && a.CoutUse == Cout) ? (accumulate ? 2 : 1) : 0;
+    if (a.direct) a.part = dw_oihw;
     a.npix = npix_valid > 0 ? npix_valid : OH * OW;
     a.in_npix = npix_valid > 0 ? npix_valid : H * W;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc = dtype == DH_DTYPE_BF16 ? launch_all<bf16>(a, ks, stride, use_tr != 0, st)
                                     : launch_all<float>(a, ks, stride, false, st);
     if (rc) return rc;
+    if (a.direct) return 0;
     const int taps = ks * ks;
     const int oreal = Cout_real > 0 ? Cout_real : Cout;     // dy may carry zero-padded channels
     const long n = (long)oreal * Cin * taps;
