@@ -44,6 +44,7 @@ class Engine:
         self.dtype = dtype
         self.use_tr = use_tr
         self.fused_decoder = os.environ.get("DAHITRA_NO_FUSED_DECODER", "0") != "1"
+        self.fused_encoder = os.environ.get("DAHITRA_NO_FUSED_ENCODER", "0") != "1"
         # BatchNorm backward with the reduction pass folded into the epilogue of the data-gradient conv that produces
         # dout (DAHITRA_BN_FUSION=1).  Measured time-neutral on MI355X: it removes one of the three tensor reads of
         # the reduction, but the gated MFMA launches slow down by as much (4054.6 vs 4054.1 pairs/s) -- so the
@@ -320,6 +321,9 @@ class Engine:
 
     def encoder(self, tok, pfx, depth, heads, dim_head, B, n):
         """token self-attention stack on [B*n, 32] rows (models/networks.py:457-512)."""
+        fused = self._encoder_fused(tok, pfx, depth, heads, dim_head, B, n) if self.fused_encoder else None
+        if fused is not None:
+            return fused
         x = tok
         bw = []
         for i in range(depth):
@@ -335,6 +339,39 @@ class Engine:
                 d = b(d)
             return d
         return x, bwd
+
+    _ENC_NAMES = ("0.fn.norm.weight", "0.fn.norm.bias", "0.fn.fn.to_qkv.weight", "0.fn.fn.to_out.0.weight",
+                  "0.fn.fn.to_out.0.bias", "1.fn.norm.weight", "1.fn.norm.bias", "1.fn.fn.net.0.weight",
+                  "1.fn.fn.net.0.bias", "1.fn.fn.net.3.weight", "1.fn.fn.net.3.bias")
+
+    def _encoder_fused(self, tok, pfx, depth, heads, dim_head, B, n):
+        """the whole encoder stack as csrc/encoder_fused.hip (3 launches instead of ~22 per layer); None when the
+        shape is outside that kernel or the layers' parameters are not at one constant pitch in the arenas"""
+        mlp = self.shapes["%s.layers.0.1.fn.fn.net.0.weight" % pfx][0]
+        if tok.dtype != torch.float32 or not ops.encoder_supported(n, heads, dim_head, mlp):
+            return None
+        key = lambda i, nm: "%s.layers.%d.%s" % (pfx, i, nm)
+        stride = 0
+        tables = (self.p, self.g) if self.need_grad else (self.p,)
+        for table in tables:
+            for nm in self._ENC_NAMES:
+                if any(key(i, nm) not in table for i in range(depth)):
+                    return None
+                for i in range(1, depth):
+                    d = table[key(i, nm)].data_ptr() - table[key(i - 1, nm)].data_ptr()
+                    if d % 4 or (stride and d // 4 != stride):
+                        return None
+                    stride = d // 4
+        params = [self.p[key(0, nm)] for nm in self._ENC_NAMES]
+        y, xs = ops.encoder_fwd(tok, B, n, depth, heads, dim_head, mlp, stride, params, self.need_grad, ATTN_SCALE, LN_EPS)
+        if not self.need_grad:
+            return y, None
+        grads = [self.g[key(0, nm)] for nm in self._ENC_NAMES]
+
+        def bwd(d):
+            return ops.encoder_bwd(d.contiguous(), xs, B, n, depth, heads, dim_head, mlp, stride, params, grads,
+                                   ATTN_SCALE, LN_EPS)
+        return y, bwd
 
     def _enc_attn(self, x0, a, heads, dim_head, B, n):
         g1, b1 = self.p[a + ".norm.weight"], self.p[a + ".norm.bias"]

@@ -616,6 +616,30 @@ def decoder_layer_bwd(x2d, dy, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln
     return dx, dkq, dvoT
 
 
+def encoder_supported(n, heads, dim_head, mlp):
+    return bool(_lib.lib().dh_encoder_supported(n, heads, dim_head, mlp))
+
+
+def encoder_fwd(tok2d, B, n, depth, heads, dim_head, mlp, pstride, params, save, scale=32 ** -0.5, eps=1e-5):
+    """fused token encoder stack (csrc/encoder_fused.hip).  tok2d [B*n, 32] fp32; params: the 11 first-layer tensors
+    (ln1_g, ln1_b, wqkv, wo, bo, ln2_g, ln2_b, w1, b1, w2, b2).  Returns (y, saved layer inputs | None)."""
+    assert tok2d.dtype == torch.float32 and tok2d.shape == (B * n, 32)
+    y = torch.empty_like(tok2d)
+    xs = torch.empty(depth, B * n, 32, dtype=torch.float32, device=tok2d.device) if save else None
+    _call("dh_encoder_fwd", P(tok2d), P(y), P(xs), _ci(B), _ci(n), _ci(depth), _ci(heads), _ci(dim_head), _ci(mlp),
+          _cf(scale), _cf(eps), _cl(pstride), *(P(t) for t in params), S())
+    return y, xs
+
+
+def encoder_bwd(dy, xs, B, n, depth, heads, dim_head, mlp, pstride, params, grads, scale=32 ** -0.5, eps=1e-5):
+    """dx of the fused encoder; `grads` (same order as params, first layer, in the gradient arena) are accumulated"""
+    dx = torch.empty_like(dy)
+    ws = workspace(_lib.lib().dh_encoder_bwd_workspace_size(B, n, depth, heads, dim_head, mlp), dy.device)
+    _call("dh_encoder_bwd", P(dy), P(dx), P(xs), _ci(B), _ci(n), _ci(depth), _ci(heads), _ci(dim_head), _ci(mlp),
+          _cf(scale), _cf(eps), _cl(pstride), *(P(t) for t in params), *(P(t) for t in grads), P(ws), S())
+    return dx
+
+
 def softmax_groups(x2d, heads, L):
     rows, HLP = x2d.shape
     y = torch.empty_like(x2d)

@@ -180,6 +180,24 @@ int dh_softmax_groups_bwd(int dtype, const void* y, const void* dy, void* dx, lo
 int dh_self_attn_fwd(int dtype, const void* qkv, void* o, float* attn, int B, int n, int heads, int dim_head, float scale, void* stream);
 int dh_self_attn_bwd(int dtype, const void* qkv, const float* attn, const void* dout, void* dqkv, int B, int n, int heads, int dim_head, float scale, void* stream);
 
+/* Fused token encoder stack (models/networks.py:457-512, help_funcs.py:117-167) on the 2*token_len <= 8 tokens of an
+ * image pair, fp32: one workgroup per image and direction + one launch for all parameter gradients.  x, y, dy, dx:
+ * [B][n][32]; parameters are the first layer's pointers in torch layouts (to_qkv [3*inner][32], to_out [32][inner],
+ * net.0 [mlp][32], net.3 [32][mlp]), consecutive layers param_stride floats apart; gradients are accumulated.
+ * dh_encoder_supported: 1 when the shape fits the kernels (n <= 8, mlp <= 64, working set within the 160 KB LDS). */
+int dh_encoder_supported(int n, int heads, int dim_head, int mlp);
+int dh_encoder_fwd(const float* x, float* y, float* saved_inputs, int B, int n, int depth, int heads, int dim_head,
+                   int mlp, float scale, float eps, long param_stride, const float* ln1_g, const float* ln1_b,
+                   const float* wqkv, const float* wo, const float* bo, const float* ln2_g, const float* ln2_b,
+                   const float* w1, const float* b1, const float* w2, const float* b2, void* stream);
+int dh_encoder_bwd(const float* dy, float* dx, const float* saved_inputs, int B, int n, int depth, int heads,
+                   int dim_head, int mlp, float scale, float eps, long param_stride, const float* ln1_g,
+                   const float* ln1_b, const float* wqkv, const float* wo, const float* bo, const float* ln2_g,
+                   const float* ln2_b, const float* w1, const float* b1, const float* w2, const float* b2,
+                   float* dln1_g, float* dln1_b, float* dwqkv, float* dwo, float* dbo, float* dln2_g, float* dln2_b,
+                   float* dw1, float* db1, float* dw2, float* db2, void* workspace, void* stream);
+long dh_encoder_bwd_workspace_size(int B, int n, int depth, int heads, int dim_head, int mlp);
+
 /* Fused cross-attention decoder layer (help_funcs.py:170-186: Residual2(PreNorm2(Cross_Attention)) + Residual(PreNorm(
  * FeedForward))) in one kernel per direction; bf16, token_len 4, heads*4 <= 32, rows per image % 128 == 0.
  * kq / voT / vo / kqT are the per-image operands of dh_xattn_prep_fwd; w1 [mlp][32], w2 [32][mlp] (+ transposes). */

@@ -402,3 +402,28 @@ def test_bn_backward_fused_into_dgrad_equals_two_pass(name, monkeypatch):
         worst = max(worst, float((grads["0"][k] - g0).abs().max()) / max(s, 1e-20))
     # same arithmetic, different summation order of the per-channel reductions
     assert worst <= 2e-3, worst
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fused_token_encoder_equals_layerwise_kernels(name, dtype, monkeypatch):
+    """csrc/encoder_fused.hip (3 launches) against the LayerNorm / linear / attention kernel sequence"""
+    from dahitra_amd.models import losses
+    size = 256 if name == "newUNetTrans" else 64
+    a, b, lab = O.synthetic_batch(2, size, seed=43)
+    res = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("DAHITRA_NO_FUSED_ENCODER", off)
+        net = make_net(name, dtype).train()
+        assert net._engine.fused_encoder == (off == "0")
+        y = net(a.cuda(), b.cuda())
+        losses.focal_loss(y, lab.cuda()).backward()
+        res[off] = (y.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    y1, g1 = res["1"]
+    y0, g0 = res["0"]
+    tol = 1e-4 if dtype == "fp32" else 2e-2          # bf16: the pixel side amplifies last-bit token differences
+    assert float((y0 - y1).abs().max()) <= tol * float(y1.abs().max())
+    for k in g1:
+        if k.startswith("transformer") and not k.startswith("transformer_decoder"):
+            s = float(g1[k].abs().max())
+            assert float((g0[k] - g1[k]).abs().max()) <= (1e-3 if dtype == "fp32" else 5e-2) * s + 1e-9, k
