@@ -427,3 +427,55 @@ def test_fused_token_encoder_equals_layerwise_kernels(name, dtype, monkeypatch):
         if k.startswith("transformer") and not k.startswith("transformer_decoder"):
             s = float(g1[k].abs().max())
             assert float((g0[k] - g1[k]).abs().max()) <= (1e-3 if dtype == "fp32" else 5e-2) * s + 1e-9, k
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_o5"])
+def test_ragged_shapes_match_oracle_fp32(name):
+    """non-square input whose feature maps are not multiples of the kernel tiles (96x160: 24x40 / 12x20 maps, the
+    fused decoder's 128-row blocks do not divide 960 rows -> layer-at-a-time path), odd batch"""
+    from dahitra_amd.models import losses
+    cfg = O.get_config(name)
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(3, 3, 96, 160, generator=g).clamp_(-1, 1)
+    b = torch.randn(3, 3, 96, 160, generator=g).clamp_(-1, 1)
+    lab = torch.randint(0, cfg["n_class"], (3, 1, 96, 160), generator=g)
+    st = O.TrainState(name, O.deterministic_state(name), lr=0.01)
+    ref = O.forward(st.sd, name, a, b, training=True)
+    O.focal_loss(ref, lab).backward()
+    net = make_net(name).train()
+    y = net(a.cuda(), b.cuda())
+    losses.focal_loss(y, lab.cuda()).backward()
+    err = float((y.detach().cpu() - ref.detach()).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-4, err
+    # Max-norm distances of single tensors are dominated by individual tie flips of ReLU / |d1 - d2| (here: one decoder
+    # element with |d1 - d2| = 7e-6 whose gradient is 6 % of the maximum flips sign, tools/ragged_diag.py; away from
+    # the ties the decoder-output gradient agrees to 6e-3), so the bound per tensor is loose and the distribution tight.
+    rels, coss = [], []
+    for k, p in net.named_parameters():
+        r = st.sd[k].grad
+        assert (p.grad is None) == (r is None), k
+        if r is not None:
+            e, s = float((p.grad.cpu() - r).abs().max()), float(r.abs().max())
+            assert e <= 0.2 * s + 1e-7, (k, e, s)
+            rels.append(e / max(s, 1e-30))
+            if r.numel() >= 64:
+                coss.append(float(F.cosine_similarity(p.grad.cpu().double().flatten(), r.double().flatten(), dim=0)))
+    assert float(np.median(rels)) <= 1e-2, float(np.median(rels))
+    assert float(np.quantile(rels, 0.9)) <= 6e-2, float(np.quantile(rels, 0.9))
+    assert min(coss) >= 0.995, min(coss)
+
+
+def test_ragged_shapes_bf16_runs_and_tracks():
+    name = "base_transformer_pos_s4"
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(3, 3, 96, 160, generator=g).clamp_(-1, 1)
+    b = torch.randn(3, 3, 96, 160, generator=g).clamp_(-1, 1)
+    with torch.no_grad():
+        ref = O.forward(O.deterministic_state(name), name, a, b, training=True)
+    net = make_net(name, "bf16").train()
+    from dahitra_amd.models import losses
+    y = net(a.cuda(), b.cuda())
+    losses.focal_loss(y, torch.zeros(3, 1, 96, 160, dtype=torch.long, device="cuda")).backward()
+    err = float((y.detach().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 0.15, err
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
