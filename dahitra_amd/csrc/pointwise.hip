@@ -166,9 +166,13 @@ template <int V> __device__ __forceinline__ void st_bytes(unsigned char* p, unsi
     else *reinterpret_cast<unsigned*>(p) = (unsigned)v;
 }
 
+// bn_scale / bn_shift ([groups][C], optional): the input is a pre-normalisation BatchNorm tensor and
+// relu(x * scale + shift) is applied on load -- the stem's BN+ReLU output is then never written (its only consumer
+// is this pool; rounded to T exactly as the separate bn_apply pass would have stored it)
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ arg, int N,
-                                   int H, int W, int C, int OH, int OW) {
+                                   int H, int W, int C, int OH, int OW, const float* __restrict__ bn_scale,
+                                   const float* __restrict__ bn_shift, int groups) {
     constexpr int V = V16<T>::N;      // one 16-byte piece per lane
     const int vn = C / V;
     GSL(i, (long)N * OH * OW * vn) {
@@ -177,6 +181,12 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
         const int ox = (int)(t % OW); t /= OW;
         const int oy = (int)(t % OH);
         const long n = t / OH;
+        float sc[V], sh[V];
+        if (bn_scale) {
+            const int g = (int)(n / (N / groups));
+#pragma unroll
+            for (int j = 0; j < V; ++j) { sc[j] = bn_scale[g * C + c + j]; sh[j] = bn_shift[g * C + c + j]; }
+        }
         float m[V];
         int k[V];
 #pragma unroll
@@ -189,6 +199,11 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
                 if (ix < 0 || ix >= W) continue;
                 float v[V];
                 ldv(x + ((n * H + iy) * W + ix) * C + c, v);
+                if (bn_scale) {
+                    T r[V];
+#pragma unroll
+                    for (int j = 0; j < V; ++j) { stf(&r[j], fmaxf(v[j] * sc[j] + sh[j], 0.f)); v[j] = ldf(&r[j]); }   // T rounding
+                }
 #pragma unroll
                 for (int j = 0; j < V; ++j)
                     if (v[j] > m[j] || k[j] < 0) { m[j] = v[j]; k[j] = ky * 3 + kx; }     // first maximum wins
@@ -596,13 +611,15 @@ extern "C" int dh_act_bwd(int dtype, const void* dy, const void* ref, void* dx, 
     DH_CHECK_LAUNCH("act_bwd");
     return 0;
 }
-extern "C" int dh_maxpool3x3s2_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int N, int H, int W, int C, void* stream) {
+extern "C" int dh_maxpool3x3s2_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int N, int H, int W, int C,
+                                   const float* bn_scale, const float* bn_shift, int groups, void* stream) {
+    DH_REQUIRE(!bn_scale || (bn_shift && groups > 0 && N % groups == 0), "maxpool: bn_scale needs bn_shift and groups | N");
     const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;
     DH_REQUIRE(C % V == 0, "maxpool: C=%d must be a multiple of %d", C, V);
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const long n = (long)N * OH * OW * (C / V);
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, argmax, N, H, W, C, OH, OW);
-    else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, argmax, N, H, W, C, OH, OW);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, argmax, N, H, W, C, OH, OW, bn_scale, bn_shift, groups);
+    else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, (float*)y, argmax, N, H, W, C, OH, OW, bn_scale, bn_shift, groups);
     DH_CHECK_LAUNCH("maxpool_fwd");
     return 0;
 }

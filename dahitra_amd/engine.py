@@ -186,8 +186,11 @@ class Engine:
             return dx
         return out, bwd
 
-    def stem(self, x1, x2, groups):
-        """7x7/2 stem + BN + ReLU as a 4x4 conv on the space-to-depth image (csrc/loss_optim.hip)."""
+    def stem(self, x1, x2, groups, pool=False):
+        """7x7/2 stem + BN + ReLU as a 4x4 conv on the space-to-depth image (csrc/loss_optim.hip).
+        pool=True (the BiT nets, where the 3x3/2 max-pool is the stem's only consumer): returns
+        (pooled, argmax, stem output shape, bwd); in train mode BN + ReLU are applied while the pool loads, so the
+        stem's activation is never written."""
         B = x1.shape[0]
         H, W = x1.shape[2], x1.shape[3]
         cp = ops.chunk_channels(self.dtype)
@@ -202,19 +205,28 @@ class Engine:
             y, st = ops.conv2d(xs, self.pk[wkey].fwd, 64, 4, 1, 2, want_stats=True, out_hw=(oh, ow))
             mean, invstd, scale, shift = ops.bn_finalize(st, 64, groups, B * oh * ow, gamma, beta, rm, rv, BN_MOMENTUM,
                                                          BN_EPS, nbt=self.p[bnkey + ".num_batches_tracked"])
-            out = ops.bn_apply(y, scale, shift, groups, RELU)
+            if pool:
+                out = None
+                pooled, parg = ops.maxpool(y, want_arg=True, bn=(scale, shift, groups))
+            else:
+                out = ops.bn_apply(y, scale, shift, groups, RELU)
         else:
             scale, shift = ops.bn_eval_params(gamma, beta, rm, rv, BN_EPS)
             wp = ops.stem_pack_weight(self.p[wkey], self.dtype, out_scale=scale)
             out = ops.conv2d(xs, wp, 64, 4, 1, 2, bias=shift, act=RELU, out_hw=(oh, ow))
             y = mean = invstd = None
-        if not self.need_grad:
-            return out, None
+            if pool:
+                pooled, parg = ops.maxpool(out), None
+        oshape = (2 * B, oh, ow, 64)
 
         def bwd(dout):
             dy = ops.bn_bwd(dout, None, y, mean, invstd, gamma, self.g[bnkey + ".weight"], self.g[bnkey + ".bias"],
                             groups, accumulate=True, mask_scale=scale, mask_shift=shift)
             ops.stem_wgrad(xs, dy, self.g[wkey], accumulate=True, use_tr=self.use_tr)
+        if pool:
+            return pooled, parg, oshape, (bwd if self.need_grad else None)
+        if not self.need_grad:
+            return out, None
         return out, bwd
 
     def basic_block(self, x, pfx, stride, groups):
@@ -579,8 +591,7 @@ class Engine:
         cfg, L = self.cfg, self.cfg["token_len"]
         B = x1.shape[0]
         S2 = 2 * B
-        x, b_stem = self.stem(x1, x2, 2)
-        xp, xarg = ops.maxpool(x, want_arg=True)
+        xp, xarg, xshape, b_stem = self.stem(x1, x2, 2, pool=True)
         if cfg.get("backbone") == "resnet50":
             l1, b_l1 = self.res50_layer(xp, 1, 1, 1, 1, 2)
             l2, b_l2 = self.res50_layer(l1, 2, 2, 1, 1, 2)
@@ -620,7 +631,7 @@ class Engine:
             dup = b_pred(dfeat4)
             dl3 = ops.upsample2_bwd(dup)
             dxp = b_l1(b_l2(b_l3(dl3, next_gate=b_l2.gate), next_gate=b_l1.gate))
-            b_stem(ops.maxpool_bwd(xarg, dxp, x.shape))
+            b_stem(ops.maxpool_bwd(xarg, dxp, xshape))
         return logits, bwd
 
     # hierarchical model -------------------------------------------------------------------------

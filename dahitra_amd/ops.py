@@ -395,11 +395,14 @@ def act_bwd(dy, ref, act):
     return dx
 
 
-def maxpool(x, want_arg=False):
+def maxpool(x, want_arg=False, bn=None):
+    """bn = (scale, shift, groups): x is a pre-BatchNorm tensor, relu(x * scale + shift) is applied on load"""
     N, H, W, C = x.shape
     y = torch.empty(N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C, dtype=x.dtype, device=x.device)
     arg = torch.empty(y.shape, dtype=torch.uint8, device=x.device) if want_arg else None
-    _call("dh_maxpool3x3s2_fwd", _ci(dt(x)), P(x), P(y), P(arg), _ci(N), _ci(H), _ci(W), _ci(C), S())
+    sc, sh, groups = bn if bn is not None else (None, None, 0)
+    _call("dh_maxpool3x3s2_fwd", _ci(dt(x)), P(x), P(y), P(arg), _ci(N), _ci(H), _ci(W), _ci(C), P(sc), P(sh), _ci(groups),
+          S())
     return (y, arg) if want_arg else y
 
 

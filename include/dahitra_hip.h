@@ -127,7 +127,10 @@ int dh_add_pos(int dtype, const void* x, const float* pos, void* y, int N, long 
 int dh_add_pos_bwd(int dtype, const void* dy, float* dpos, int N, long HW, int C, int accumulate, void* stream);
 int dh_act_bwd(int dtype, const void* dy, const void* ref, void* dx, long n, int act, void* stream);
 /* argmax (optional, [N][OH][OW][C] bytes): window position 0..8 of the first maximum, consumed by the backward */
-int dh_maxpool3x3s2_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int N, int H, int W, int C, void* stream);
+int dh_maxpool3x3s2_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int N, int H, int W, int C,
+                        const float* bn_scale, const float* bn_shift, int groups, void* stream);
+/* bn_scale / bn_shift [groups][C] (optional): x is the PRE-normalisation input of a train-mode BatchNorm + ReLU whose
+ * only consumer is this pool (the ResNet stem, models/resnet.py:207-210): relu(x * scale + shift) is applied on load */
 int dh_maxpool3x3s2_bwd(int dtype, const unsigned char* argmax, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
 int dh_upsample2_nearest_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
 int dh_upsample2_nearest_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, void* stream);

@@ -425,3 +425,16 @@ def test_bn_backward_mask_recomputed_from_input(ops, dtype):
         r.append((dx.float(), dg, db))
     assert float((out > 0).float().mean()) > 0.2 and float((out == 0).float().mean()) > 0.2
     assert torch.equal(r[0][0], r[1][0]) and torch.equal(r[0][1], r[1][1]) and torch.equal(r[0][2], r[1][2])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_maxpool_with_batchnorm_relu_on_load(ops, dtype):
+    """maxpool(relu(x * scale + shift)) fused == bn_apply followed by maxpool (values and arg-max, two BN groups)"""
+    N, H, W, C, groups = 4, 18, 22, 64, 2
+    x = dev(rnd((N, H, W, C), dtype, 501, 1.5), dtype)
+    scale = (rnd((groups, C), torch.float32, 502, 0.5) + 0.6).cuda()      # some negative scales too
+    shift = rnd((groups, C), torch.float32, 503, 0.5).cuda()
+    h = ops.bn_apply(x, scale, shift, groups, ops.ACT_RELU)
+    y0, a0 = ops.maxpool(h, want_arg=True)
+    y1, a1 = ops.maxpool(x, want_arg=True, bn=(scale, shift, groups))
+    assert torch.equal(y0, y1) and torch.equal(a0, a1)
