@@ -74,20 +74,36 @@ __global__ __launch_bounds__(256) void tok_stats_kernel(const float* __restrict_
     }
 }
 
-// partial pooled sums over one chunk of pixels: thread (l, c); grid (chunks, S)
+// partial pooled sums over one chunk of pixels: thread (phase, l, c), blockDim = PH * L * 32 with PH pixel phases
+// (4 independent accumulators each: the loop is a chain of dependent loads otherwise); grid (chunks, S)
 template <typename T, int L>
 __global__ void tok_pool_partial_kernel(const T* __restrict__ x, const float* __restrict__ logits,
                                         const float* __restrict__ stats, int HW, int chunk,
                                         float* __restrict__ partial /*[S][chunks][L*32]*/) {
+    __shared__ float red[1024];
     const int s = blockIdx.y, tid = threadIdx.x;
-    const int l = tid / D, c = tid % D;
+    const int LD = L * D, PH = blockDim.x / LD, ph = tid / LD, r = tid % LD;
+    const int l = r / D, c = r % D;
     const float* lg = logits + (size_t)s * HW * L;
     const T* xs = x + (size_t)s * HW * D;
     const float mx = stats[((size_t)s * L + l) * 2];
     const int n0 = blockIdx.x * chunk, n1 = min(n0 + chunk, HW);
-    float acc = 0.f;
-    for (int n = n0; n < n1; ++n) acc += __expf(lg[(size_t)n * L + l] - mx) * ldf(xs + (size_t)n * D + c);
-    partial[((size_t)s * gridDim.x + blockIdx.x) * (L * D) + tid] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int n = n0 + ph;
+    for (; n + 3 * PH < n1; n += 4 * PH) {
+        a0 += __expf(lg[(size_t)n * L + l] - mx) * ldf(xs + (size_t)n * D + c);
+        a1 += __expf(lg[(size_t)(n + PH) * L + l] - mx) * ldf(xs + (size_t)(n + PH) * D + c);
+        a2 += __expf(lg[(size_t)(n + 2 * PH) * L + l] - mx) * ldf(xs + (size_t)(n + 2 * PH) * D + c);
+        a3 += __expf(lg[(size_t)(n + 3 * PH) * L + l] - mx) * ldf(xs + (size_t)(n + 3 * PH) * D + c);
+    }
+    for (; n < n1; n += PH) a0 += __expf(lg[(size_t)n * L + l] - mx) * ldf(xs + (size_t)n * D + c);
+    red[tid] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ph == 0) {
+        float t = red[r];
+        for (int q = 1; q < PH; ++q) t += red[q * LD + r];
+        partial[((size_t)s * gridDim.x + blockIdx.x) * LD + r] = t;
+    }
 }
 
 // combine chunks, normalise, add the learned positional embedding and place into [B][2L][32]
@@ -164,17 +180,32 @@ __global__ void tok_bwd_kernel(const T* __restrict__ x, const float* __restrict_
     }
 }
 
-// partial dWa[l][c] over a chunk of pixel rows: thread (l, c)
+// partial dWa[l][c] over a chunk of pixel rows: thread (phase, l, c), 256 / (L*32) pixel phases, 4 accumulators each
 template <typename T, int L>
-__global__ void tok_dwa_kernel(const T* __restrict__ x, const float* __restrict__ dlogits, long P, long chunk,
-                               float* __restrict__ partial) {
-    const int tid = threadIdx.x;
-    if (tid >= L * D) return;
-    const int l = tid / D, c = tid % D;
+__global__ __launch_bounds__(256) void tok_dwa_kernel(const T* __restrict__ x, const float* __restrict__ dlogits, long P,
+                                                      long chunk, float* __restrict__ partial) {
+    __shared__ float red[256];
+    constexpr int LD = L * D, PH = 256 / LD;
+    const int tid = threadIdx.x, ph = tid / LD, r = tid % LD;
+    const int l = r / D, c = r % D;
     const long p0 = (long)blockIdx.x * chunk, p1 = (p0 + chunk < P) ? p0 + chunk : P;
-    float acc = 0.f;
-    for (long p = p0; p < p1; ++p) acc += dlogits[p * L + l] * ldf(x + p * D + c);
-    partial[(size_t)blockIdx.x * L * D + tid] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long p = p0 + ph;
+    for (; p + 3 * PH < p1; p += 4 * PH) {
+        a0 += dlogits[p * L + l] * ldf(x + p * D + c);
+        a1 += dlogits[(p + PH) * L + l] * ldf(x + (p + PH) * D + c);
+        a2 += dlogits[(p + 2 * PH) * L + l] * ldf(x + (p + 2 * PH) * D + c);
+        a3 += dlogits[(p + 3 * PH) * L + l] * ldf(x + (p + 3 * PH) * D + c);
+    }
+    for (; p < p1; p += PH) a0 += dlogits[p * L + l] * ldf(x + p * D + c);
+    red[tid] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ph == 0) {
+        float t = red[r];
+#pragma unroll
+        for (int q = 1; q < PH; ++q) t += red[q * LD + r];
+        partial[(size_t)blockIdx.x * LD + r] = t;
+    }
 }
 
 // dpos[j][c] (+)= sum_b dtok_cat[b][j][c]
@@ -627,7 +658,7 @@ extern "C" int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const
         hipLaunchKernelGGL((tok_logits_kernel<TT, LL>), dim3(dh_cdiv(P, 256)), dim3(256), 0, ST(stream),          \
                            (const TT*)x, wa, logits, P);                                                          \
         hipLaunchKernelGGL((tok_stats_kernel<LL>), dim3(S * LL), dim3(256), 0, ST(stream), logits, HW, stats);     \
-        hipLaunchKernelGGL((tok_pool_partial_kernel<TT, LL>), dim3(nch, S), dim3(LL * 32), 0, ST(stream),         \
+        hipLaunchKernelGGL((tok_pool_partial_kernel<TT, LL>), dim3(nch, S), dim3(256), 0, ST(stream),             \
                            (const TT*)x, logits, stats, HW, chunk, part);                                         \
         hipLaunchKernelGGL((tok_finish_kernel<TT, LL>), dim3(S), dim3(LL * 32), 0, ST(stream), part, stats, pos,  \
                            nch, B, pooled, tok_cat);                                                         \
