@@ -493,13 +493,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
         // 4 channels per lane (8/16-byte loads), 256/(C/4) row phases per workgroup
         const int cvn = C / 4, cv = threadIdx.x % cvn, ph = threadIdx.x / cvn, nph = 256 / cvn;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ph < nph)
-            for (long p = (long)blockIdx.x * nph + ph; p < P; p += (long)gridDim.x * nph) {
+        if (ph < nph) {
+            // two independent row streams per lane: the loop is otherwise one chain of dependent-latency loads
+            const long step = (long)gridDim.x * nph;
+            float s2[4] = {0.f, 0.f, 0.f, 0.f};
+            long p = (long)blockIdx.x * nph + ph;
+            for (; p + step < P; p += 2 * step) {
+                float v[4], w[4];
+                ld4(x + p * C + cv * 4, v);
+                ld4(x + (p + step) * C + cv * 4, w);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[j] += v[j]; s2[j] += w[j]; }
+            }
+            if (p < P) {
                 float v[4];
                 ld4(x + p * C + cv * 4, v);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s[j] += v[j];
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += s2[j];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) red[threadIdx.x * 4 + j] = ph < nph ? s[j] : 0.f;
         __syncthreads();
@@ -707,10 +721,12 @@ extern "C" int dh_pack_weights_multi(const void* jobs_dev, int njobs, int total_
     DH_CHECK_LAUNCH("pack_weights_multi");
     return 0;
 }
-// workspace: 256 * C floats
+// workspace: 1024 * C floats
 extern "C" int dh_colsum(int dtype, const void* x, long P, int C, float* out, int accumulate, void* workspace, void* stream) {
     DH_REQUIRE(C >= 1 && C <= 256, "colsum: C=%d out of range", C);
-    const int grid = 256;
+    const long rows_per_pass = 256 / (C >= 4 && (C & 3) == 0 ? C / 4 : C);       // rows one workgroup covers per step
+    long want = (P + rows_per_pass * 8 - 1) / (rows_per_pass * 8);               // >= 8 steps per workgroup
+    const int grid = (int)(want < 64 ? 64 : (want > 1024 ? 1024 : want));
     float* partial = reinterpret_cast<float*>(workspace);
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)x, P, C, partial);
     else hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)x, P, C, partial);

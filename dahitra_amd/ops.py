@@ -454,7 +454,7 @@ def absdiff_bwd(a, b, dy, da, db, accumulate=True):
 def colsum(x2d, out, accumulate=False):
     C = x2d.shape[-1]
     Pn = x2d.numel() // C
-    ws = workspace(256 * C * 4 + 1024, x2d.device)
+    ws = workspace(1024 * C * 4 + 1024, x2d.device)          # up to 1024 partial rows
     _call("dh_colsum", _ci(dt(x2d)), P(x2d), _cl(Pn), _ci(C), P(out), _ci(int(accumulate)), P(ws), S())
 
 

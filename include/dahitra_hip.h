@@ -138,7 +138,7 @@ int dh_absdiff_upsample4_fwd(int dtype, const void* a, const void* b, void* y, i
 int dh_absdiff_upsample4_bwd(int dtype, const void* a, const void* b, const void* dy, void* da, void* db, int N, int H, int W, int C, void* stream);
 int dh_absdiff(int dtype, const void* a, const void* b, void* y, long n, void* stream);
 int dh_absdiff_bwd(int dtype, const void* a, const void* b, const void* dy, void* da, void* db, long n, int accumulate, void* stream);
-int dh_colsum(int dtype, const void* x, long P, int C, float* out, int accumulate, void* workspace, void* stream);
+int dh_colsum(int dtype, const void* x, long P, int C, float* out, int accumulate, void* workspace, void* stream);  /* workspace: 1024 * C floats */
 int dh_cast_from_f32(int dtype, const float* src, void* dst, long n, void* stream);
 int dh_cast_to_f32(int dtype, const void* src, float* dst, long n, int accumulate, void* stream);
 
