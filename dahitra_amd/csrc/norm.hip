@@ -13,6 +13,9 @@ namespace {
 
 // ---- finalize train-mode statistics --------------------------------------------------------
 // partial: [2][CP][ntiles] from the conv epilogue (tile order = image order): one channel's tiles are contiguous.
+// One workgroup per channel, one WAVEFRONT per statistics group (the two temporal streams are reduced concurrently,
+// not one after the other); thread 0 then applies the running-statistics updates in group order.
+constexpr int BN_MAXG = 4;
 __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, int CP, int C, int G,
                                    double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ running_mean,
@@ -20,23 +23,35 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out,
                                    long long* __restrict__ nbt) {
+    __shared__ double sm[BN_MAXG], sv[BN_MAXG], ps[4], pq[4];
     const int c = blockIdx.x;
     if (nbt && c == 0 && threadIdx.x == 0) *nbt += G;      // one forward_single per stream (models/networks.py:359-360)
-    const int lane = threadIdx.x;      // 64 threads
+    // 4 wavefronts: 4 / G of them share a group's tiles (G in {1, 2, 4}), two accumulator pairs per lane
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wpg = 4 / G;
+    const int g = w / wpg, slice = w % wpg;
     const int tpg = ntiles / G;
-    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
-    for (int g = 0; g < G; ++g) {
-        double s = 0.0, q = 0.0;
-        for (int t = g * tpg + lane; t < (g + 1) * tpg; t += 64) {
-            s += (double)partial[((size_t)0 * CP + c) * ntiles + t];
-            q += (double)partial[((size_t)1 * CP + c) * ntiles + t];
+    {
+        double s = 0.0, q = 0.0, s2 = 0.0, q2 = 0.0;
+        const float* p0 = partial + ((size_t)0 * CP + c) * ntiles + (size_t)g * tpg;
+        const float* p1 = partial + ((size_t)1 * CP + c) * ntiles + (size_t)g * tpg;
+        const int step = 64 * wpg;
+        int t = slice * 64 + lane;
+        for (; t + step < tpg; t += 2 * step) {
+            s += (double)p0[t]; q += (double)p1[t];
+            s2 += (double)p0[t + step]; q2 += (double)p1[t + step];
         }
+        if (t < tpg) { s += (double)p0[t]; q += (double)p1[t]; }
+        s += s2; q += q2;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             s += __shfl_xor(s, o, 64);
             q += __shfl_xor(q, o, 64);
         }
-        if (lane == 0) {
+        if (lane == 0) { ps[w] = s; pq[w] = q; }
+        __syncthreads();
+        if (lane == 0 && slice == 0) {
+            s = 0.0; q = 0.0;
+            for (int k = 0; k < wpg; ++k) { s += ps[g * wpg + k]; q += pq[g * wpg + k]; }
             const double mean = s / count;
             double var = q / count - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -46,12 +61,20 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
             invstd_out[g * C + c] = invstd;
             scale_out[g * C + c] = sc;
             shift_out[g * C + c] = beta[c] - (float)mean * sc;
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            rm = (1.f - momentum) * rm + momentum * (float)mean;
-            rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+            sm[g] = mean;
+            sv[g] = count > 1.0 ? var * count / (count - 1.0) : var;
         }
     }
-    if (lane == 0 && running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+    __syncthreads();
+    if (threadIdx.x == 0 && running_mean) {
+        float rm = running_mean[c], rv = running_var[c];
+        for (int k = 0; k < G; ++k) {
+            rm = (1.f - momentum) * rm + momentum * (float)sm[k];
+            rv = (1.f - momentum) * rv + momentum * (float)sv[k];
+        }
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
 }
 
 __global__ void bn_eval_params_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -153,20 +176,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int bpg, int G, int C,
                                        float* __restrict__ sums /*[G][2][C]*/, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    double tg = 0.0, tb = 0.0;
-    for (int g = 0; g < G; ++g) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int t = lane; t < bpg; t += 64) {
-            s1 += (double)partial[((size_t)0 * C + c) * G * bpg + g * bpg + t];
-            s2 += (double)partial[((size_t)1 * C + c) * G * bpg + g * bpg + t];
-        }
+    __shared__ double t1[BN_MAXG], t2[BN_MAXG];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, g = threadIdx.x >> 6;      // blockDim = 64 * G
+    double s1 = 0.0, s2 = 0.0;
+    const float* p0 = partial + ((size_t)0 * C + c) * G * bpg + (size_t)g * bpg;
+    const float* p1 = partial + ((size_t)1 * C + c) * G * bpg + (size_t)g * bpg;
+    for (int t = lane; t < bpg; t += 64) { s1 += (double)p0[t]; s2 += (double)p1[t]; }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        if (lane == 0) { sums[(g * 2 + 0) * C + c] = (float)s1; sums[(g * 2 + 1) * C + c] = (float)s2; }
-        tb += s1; tg += s2;
-    }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
     if (lane == 0) {
+        sums[(g * 2 + 0) * C + c] = (float)s1;
+        sums[(g * 2 + 1) * C + c] = (float)s2;
+        t1[g] = s1; t2[g] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tb = 0.0, tg = 0.0;
+        for (int k = 0; k < G; ++k) { tb += t1[k]; tg += t2[k]; }
         if (accumulate) { dgamma[c] += (float)tg; dbeta[c] += (float)tb; }
         else { dgamma[c] = (float)tg; dbeta[c] = (float)tb; }
     }
@@ -336,7 +362,8 @@ extern "C" int dh_bn_finalize(const float* partial, int ntiles, int CP, int C, i
                               float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                               long long* num_batches_tracked, void* stream) {
     DH_REQUIRE(groups > 0 && ntiles % groups == 0, "bn_finalize: ntiles=%d not divisible by groups=%d", ntiles, groups);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, ntiles, CP, C, groups, count,
+    DH_REQUIRE(groups == 1 || groups == 2 || groups == 4, "bn_finalize: 1, 2 or 4 statistics groups, got %d", groups);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, ST(stream), partial, ntiles, CP, C, groups, count,
                        gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
                        num_batches_tracked);
     DH_CHECK_LAUNCH("bn_finalize");
@@ -380,7 +407,7 @@ extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, cons
     DH_REQUIRE(!(out_relu && mask_scale), "bn_bwd: give the ReLU mask either as out_relu or as mask_scale/shift");
     const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;       // elements of one 16-byte piece
     DH_REQUIRE(C % V == 0 && (256 * V) % C == 0, "bn_bwd: unsupported C=%d", C);
-    DH_REQUIRE(npix % groups == 0, "bn_bwd: npix %% groups");
+    DH_REQUIRE(npix % groups == 0 && groups <= BN_MAXG, "bn_bwd: npix %% groups, at most %d groups", BN_MAXG);
     const int bpg = 1024 / groups;      // ~1024 workgroups in total (4 per CU)
     const long ppg = npix / groups;
     float* partial = reinterpret_cast<float*>(workspace);
@@ -389,7 +416,7 @@ extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, cons
     if (dtype == DH_DTYPE_BF16) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(groups * bpg), dim3(256), 0, ST(stream), (const bf16*)dout,
                            (const bf16*)out_relu, (const bf16*)x, mean, invstd, C, ppg, bpg, partial, mask_scale, mask_shift);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, bpg, groups, C, sums,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * groups), 0, ST(stream), partial, bpg, groups, C, sums,
                            dgamma, dbeta, accumulate);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream),
                            (const bf16*)dout, (const bf16*)out_relu, (const bf16*)x, mean, invstd, gamma, sums,
@@ -397,7 +424,7 @@ extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, cons
     } else {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(groups * bpg), dim3(256), 0, ST(stream), (const float*)dout,
                            (const float*)out_relu, (const float*)x, mean, invstd, C, ppg, bpg, partial, mask_scale, mask_shift);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, bpg, groups, C, sums,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * groups), 0, ST(stream), partial, bpg, groups, C, sums,
                            dgamma, dbeta, accumulate);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream),
                            (const float*)dout, (const float*)out_relu, (const float*)x, mean, invstd, gamma, sums,
@@ -419,7 +446,7 @@ extern "C" int dh_bn_bwd_from_partials(int dtype, const void* g, const void* x, 
                "bn_bwd_from_partials: C=%d ntiles=%d npix=%ld groups=%d", C, ntiles, npix, groups);
     float* sums = reinterpret_cast<float*>(workspace);
     const long ppg = npix / groups, nvec = npix * C / V;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, ST(stream), partial, ntiles / groups, groups, C, sums,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * groups), 0, ST(stream), partial, ntiles / groups, groups, C, sums,
                        dgamma, dbeta, accumulate);
     if (dtype == DH_DTYPE_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const bf16*)g,
