@@ -330,8 +330,19 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     const int lane = threadIdx.x & 31, ph = threadIdx.x >> 5;
     const long i = (long)blockIdx.x * 32 + lane;
     double s = 0.0;
-    if (i < n)
-        for (long t = ph; t < nt; t += 8) s += (double)partial[t * n + i];
+    if (i < n) {
+        // four independent partial sums: the row loop is otherwise one chain of dependent-latency loads
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        long t = ph;
+        for (; t + 24 < nt; t += 32) {
+            s += (double)partial[t * n + i];
+            s1 += (double)partial[(t + 8) * n + i];
+            s2 += (double)partial[(t + 16) * n + i];
+            s3 += (double)partial[(t + 24) * n + i];
+        }
+        for (; t < nt; t += 8) s += (double)partial[t * n + i];
+        s = (s + s1) + (s2 + s3);
+    }
     red[ph][lane] = s;
     __syncthreads();
     if (ph == 0 && i < n) {
