@@ -281,7 +281,17 @@ __global__ void wgrad_reduce_oihw_kernel(const float* __restrict__ part, int spl
         tap = (int)(i / ((long)I * O));
         const size_t slab = (size_t)taps * Oslab * I;
         const float* src = part + ((size_t)tap * Oslab + o) * I + ci;
-        for (int k = ph; k < splitk; k += 8) acc += src[(size_t)k * slab];
+        // independent partial sums (the slab loop is otherwise a chain of dependent-latency loads)
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = ph;
+        for (; k + 24 < splitk; k += 32) {
+            acc += src[(size_t)k * slab];
+            a1 += src[(size_t)(k + 8) * slab];
+            a2 += src[(size_t)(k + 16) * slab];
+            a3 += src[(size_t)(k + 24) * slab];
+        }
+        for (; k < splitk; k += 8) acc += src[(size_t)k * slab];
+        acc = (acc + a1) + (a2 + a3);
     }
     red[ph][lane] = acc;
     __syncthreads();
