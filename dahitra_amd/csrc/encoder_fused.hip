@@ -92,7 +92,18 @@ __device__ __forceinline__ void ksplit_rows(const float* in, int in_pitch, const
     float acc[MAXN];
 #pragma unroll
     for (int t = 0; t < MAXN; ++t) acc[t] = 0.f;
-    for (int j = j0; j < j1; ++j) {
+    int j = j0;
+    for (; j + 3 < j1; j += 4) {              // four weight loads in flight per step
+        const float w0 = W[(long)j * sj + (long)c * sc], w1 = W[(long)(j + 1) * sj + (long)c * sc];
+        const float w2 = W[(long)(j + 2) * sj + (long)c * sc], w3 = W[(long)(j + 3) * sj + (long)c * sc];
+#pragma unroll
+        for (int t = 0; t < MAXN; ++t)
+            if (t < n) {
+                const float* r = in + t * in_pitch + j;
+                acc[t] += r[0] * w0 + r[1] * w1 + r[2] * w2 + r[3] * w3;
+            }
+    }
+    for (; j < j1; ++j) {
         const float w = W[(long)j * sj + (long)c * sc];
 #pragma unroll
         for (int t = 0; t < MAXN; ++t)
