@@ -113,10 +113,59 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ r
     }
 }
 
+// Same map when 256*V is a multiple of C (every power-of-two width up to 2048): a thread's channel piece is the same in
+// every iteration, so its scale / shift are loaded ONCE (the generic kernel spends 2-7 coefficient loads per data
+// load in the vector cache).  grid = (workgroups per group, groups); two independent pieces in flight per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_hoist_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                             T* __restrict__ y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int C, long group_vec,
+                                                             int act) {
+    constexpr int V = V16<T>::N;
+    const int g = blockIdx.y;
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)((i * V) % C);
+    float sc[V], sh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sc[j] = scale[g * C + c + j]; sh[j] = shift[g * C + c + j]; }
+    const size_t base = (size_t)g * group_vec * V;
+    x += base; y += base;
+    if (res) res += base;
+    const bool relu = act == DH_ACT_RELU;
+    for (; i + stride < group_vec; i += 2 * stride) {
+        float a[V], b[V], ra[V], rb[V];
+        ldv(x + i * V, a);
+        ldv(x + (i + stride) * V, b);
+        if (res) { ldv(res + i * V, ra); ldv(res + (i + stride) * V, rb); }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            a[j] = a[j] * sc[j] + sh[j];
+            b[j] = b[j] * sc[j] + sh[j];
+            if (res) { a[j] += ra[j]; b[j] += rb[j]; }
+            if (relu) { a[j] = fmaxf(a[j], 0.f); b[j] = fmaxf(b[j], 0.f); }
+        }
+        stv(y + i * V, a);
+        stv(y + (i + stride) * V, b);
+    }
+    if (i < group_vec) {
+        float a[V], ra[V];
+        ldv(x + i * V, a);
+        if (res) ldv(res + i * V, ra);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            a[j] = a[j] * sc[j] + sh[j];
+            if (res) a[j] += ra[j];
+            if (relu) a[j] = fmaxf(a[j], 0.f);
+        }
+        stv(y + i * V, a);
+    }
+}
+
 // ---- backward, pass 1: per-workgroup partial sums of dy and dy*xhat -------------------------
 // dy = dout * (out > 0) when `out` (the post-ReLU activation) is given.
 // partial: [2][C][G*bpg]; a workgroup never straddles two groups.
-template <typename T>
+template <typename T, int MASK>      // MASK: 0 none, 1 from `out`, 2 recomputed from x
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                             const T* __restrict__ x,
                                                             const float* __restrict__ mean,
@@ -132,31 +181,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     const int cv = threadIdx.x % cvn, r0 = threadIdx.x / cvn, rstep = 256 / cvn;
     const long chunk = (pix_per_group + bpg - 1) / bpg;
     const long p0 = b * chunk, p1 = (p0 + chunk < pix_per_group) ? p0 + chunk : pix_per_group;
-    float mu[V], is[V], s1[V], s2[V];
+    float mu[V], is[V], s1[V], s2[V], ms[V], mh[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) { mu[j] = mean[g * C + cv * V + j]; is[j] = invstd[g * C + cv * V + j]; s1[j] = 0.f; s2[j] = 0.f; }
-    for (long p = p0 + r0; p < p1; p += rstep) {
+    for (int j = 0; j < V; ++j) {
+        mu[j] = mean[g * C + cv * V + j]; is[j] = invstd[g * C + cv * V + j]; s1[j] = 0.f; s2[j] = 0.f;
+        if (MASK == 2) { ms[j] = mscale[g * C + cv * V + j]; mh[j] = mshift[g * C + cv * V + j]; }
+    }
+    // two pixels' loads in flight per thread; the accumulation order (p ascending) is unchanged
+    auto fetch = [&](long p, float (&d)[V], float (&xv)[V], float (&o)[V]) {
         const size_t off = ((size_t)g * pix_per_group + p) * C + cv * V;
-        float d[V], xv[V];
         ldv(dout + off, d);
         ldv(x + off, xv);
-        if (out) {
-            float o[V];
-            ldv(out + off, o);
-#pragma unroll
-            for (int j = 0; j < V; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
-        } else if (mscale) {
-            // ReLU mask recomputed from the pre-normalisation input (layers without a residual): the same
-            // x * scale + shift the forward evaluated, so one tensor read less in each backward pass
-#pragma unroll
-            for (int j = 0; j < V; ++j)
-                d[j] = (xv[j] * mscale[g * C + cv * V + j] + mshift[g * C + cv * V + j]) > 0.f ? d[j] : 0.f;
-        }
+        if (MASK == 1) ldv(out + off, o);
+    };
+    auto accum = [&](float (&d)[V], float (&xv)[V], float (&o)[V]) {
 #pragma unroll
         for (int j = 0; j < V; ++j) {
+            if (MASK == 1) d[j] = o[j] > 0.f ? d[j] : 0.f;
+            // MASK 2: ReLU mask recomputed from the pre-normalisation input (layers without a residual): the same
+            // x * scale + shift the forward evaluated, so one tensor read less in each backward pass
+            if (MASK == 2) d[j] = (xv[j] * ms[j] + mh[j]) > 0.f ? d[j] : 0.f;
             s1[j] += d[j];
             s2[j] += d[j] * (xv[j] - mu[j]) * is[j];
         }
+    };
+    long p = p0 + r0;
+    for (; p + rstep < p1; p += 2 * rstep) {
+        float d0[V], x0[V], o0[V], d1[V], x1[V], o1[V];
+        fetch(p, d0, x0, o0);
+        fetch(p + rstep, d1, x1, o1);
+        accum(d0, x0, o0);
+        accum(d1, x1, o1);
+    }
+    if (p < p1) {
+        float d0[V], x0[V], o0[V];
+        fetch(p, d0, x0, o0);
+        accum(d0, x0, o0);
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -229,6 +289,63 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
         }
         stv(dx + i * V, r);
         if (dres) stv(dres + i * V, d);
+    }
+}
+
+// The same expression with the per-channel operands hoisted (see bn_apply_hoist_kernel); grid = (workgroups per group, groups)
+template <typename T, int MASK>     // MASK: 0 none, 1 from `out` (post-ReLU activation), 2 recomputed from x
+__global__ __launch_bounds__(256) void bn_bwd_apply_hoist_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                                 const T* __restrict__ x, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ sums, float inv_m, int C,
+                                                                 long group_vec, T* __restrict__ dx, T* __restrict__ dres,
+                                                                 const float* __restrict__ mscale,
+                                                                 const float* __restrict__ mshift) {
+    constexpr int V = V16<T>::N;
+    const int g = blockIdx.y;
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)((i * V) % C);
+    float is[V], mu[V], ga[V], s1[V], s2[V], ms[V], mh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        is[j] = invstd[g * C + c + j]; mu[j] = mean[g * C + c + j]; ga[j] = gamma[c + j];
+        s1[j] = sums[(g * 2 + 0) * C + c + j]; s2[j] = sums[(g * 2 + 1) * C + c + j];
+        if (MASK == 2) { ms[j] = mscale[g * C + c + j]; mh[j] = mshift[g * C + c + j]; }
+    }
+    const size_t base = (size_t)g * group_vec * V;
+    dout += base; x += base; dx += base;
+    if (MASK == 1) out += base;
+    if (dres) dres += base;
+    auto piece = [&](long k, float (&d)[V], float (&xv)[V], float (&o)[V]) {
+        ldv(dout + k * V, d);
+        ldv(x + k * V, xv);
+        if (MASK == 1) ldv(out + k * V, o);
+    };
+    auto finish = [&](long k, float (&d)[V], float (&xv)[V], float (&o)[V]) {
+        float r[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            if (MASK == 1) d[j] = o[j] > 0.f ? d[j] : 0.f;
+            if (MASK == 2) d[j] = (xv[j] * ms[j] + mh[j]) > 0.f ? d[j] : 0.f;
+            const float xh = (xv[j] - mu[j]) * is[j];
+            r[j] = ga[j] * is[j] * (d[j] - (s1[j] + xh * s2[j]) * inv_m);
+        }
+        stv(dx + k * V, r);
+        if (dres) stv(dres + k * V, d);
+    };
+    for (; i + stride < group_vec; i += 2 * stride) {
+        float d0[V], x0[V], o0[V], d1[V], x1[V], o1[V];
+        piece(i, d0, x0, o0);
+        piece(i + stride, d1, x1, o1);
+        finish(i, d0, x0, o0);
+        finish(i + stride, d1, x1, o1);
+    }
+    if (i < group_vec) {
+        float d0[V], x0[V], o0[V];
+        piece(i, d0, x0, o0);
+        finish(i, d0, x0, o0);
     }
 }
 
@@ -363,6 +480,60 @@ inline int ew_grid(long n, int block) {
     long g = (n + block - 1) / block;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
+// workgroups per group of the hoisted element-wise BN kernels: ~2048 in total (8 per CU), >= 2 pieces per thread
+inline int hoist_grid(long gvec, int groups) {
+    long g = (gvec + 511) / 512, cap = 2048 / groups;
+    return (int)(g > cap ? cap : (g < 1 ? 1 : g));
+}
+
+template <typename T>
+void launch_bn_bwd_apply(const void* dout, const void* out_relu, const void* x, const float* mean, const float* invstd,
+                         const float* gamma, const float* sums, long ppg, long nvec, int C, int groups, void* dx, void* dres,
+                         const float* mask_scale, const float* mask_shift, hipStream_t st) {
+    constexpr int V = V16<T>::N;
+    const long gvec = nvec / groups;
+    const float inv_m = 1.0f / (float)ppg;
+    if ((256 * V) % C == 0) {
+        const dim3 grid(hoist_grid(gvec, groups), groups);
+#define DH_BWD_APPLY(M)                                                                                              \
+        hipLaunchKernelGGL((bn_bwd_apply_hoist_kernel<T, M>), grid, dim3(256), 0, st, (const T*)dout, (const T*)out_relu, \
+                           (const T*)x, mean, invstd, gamma, sums, inv_m, C, gvec, (T*)dx, (T*)dres, mask_scale, mask_shift)
+        if (out_relu) DH_BWD_APPLY(1);
+        else if (mask_scale) DH_BWD_APPLY(2);
+        else DH_BWD_APPLY(0);
+#undef DH_BWD_APPLY
+    } else {
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(nvec, 256)), dim3(256), 0, st, (const T*)dout,
+                           (const T*)out_relu, (const T*)x, mean, invstd, gamma, sums, inv_m, nvec, C, gvec, (T*)dx, (T*)dres,
+                           mask_scale, mask_shift);
+    }
+}
+
+template <typename T>
+void launch_bn_bwd_reduce(const void* dout, const void* out_relu, const void* x, const float* mean, const float* invstd, int C,
+                          long ppg, int bpg, int groups, float* partial, const float* mask_scale, const float* mask_shift,
+                          hipStream_t st) {
+#define DH_BWD_REDUCE(M)                                                                                                  \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), dim3(groups * bpg), dim3(256), 0, st, (const T*)dout, (const T*)out_relu, \
+                       (const T*)x, mean, invstd, C, ppg, bpg, partial, mask_scale, mask_shift)
+    if (out_relu) DH_BWD_REDUCE(1);
+    else if (mask_scale) DH_BWD_REDUCE(2);
+    else DH_BWD_REDUCE(0);
+#undef DH_BWD_REDUCE
+}
+
+template <typename T>
+void launch_bn_apply(const void* x, const void* residual, void* y, const float* scale, const float* shift, long nvec, int C,
+                     int groups, int act, hipStream_t st) {
+    constexpr int V = V16<T>::N;
+    const long gvec = nvec / groups;
+    if ((256 * V) % C == 0)
+        hipLaunchKernelGGL(bn_apply_hoist_kernel<T>, dim3(hoist_grid(gvec, groups), groups), dim3(256), 0, st, (const T*)x,
+                           (const T*)residual, (T*)y, scale, shift, C, gvec, act);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_grid(nvec, 256)), dim3(256), 0, st, (const T*)x, (const T*)residual,
+                           (T*)y, scale, shift, nvec, C, gvec, act);
+}
 
 }  // namespace
 
@@ -395,12 +566,9 @@ extern "C" int dh_bn_apply(int dtype, const void* x, const void* residual, void*
     const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;       // elements of one 16-byte piece
     DH_REQUIRE(C % V == 0 && npix % groups == 0, "bn_apply: C=%d npix=%ld groups=%d", C, npix, groups);
     const long nvec = npix * C / V, gvec = nvec / groups;
-    if (dtype == DH_DTYPE_BF16)
-        hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const bf16*)x,
-                           (const bf16*)residual, (bf16*)y, scale, shift, nvec, C, gvec, act);
-    else
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const float*)x,
-                           (const float*)residual, (float*)y, scale, shift, nvec, C, gvec, act);
+    (void)gvec;
+    if (dtype == DH_DTYPE_BF16) launch_bn_apply<bf16>(x, residual, y, scale, shift, nvec, C, groups, act, ST(stream));
+    else launch_bn_apply<float>(x, residual, y, scale, shift, nvec, C, groups, act, ST(stream));
     DH_CHECK_LAUNCH("bn_apply");
     return 0;
 }
@@ -425,21 +593,17 @@ extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, cons
     float* sums = partial + (long)groups * bpg * 2 * C;
     const long nvec = npix * C / V;
     if (dtype == DH_DTYPE_BF16) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(groups * bpg), dim3(256), 0, ST(stream), (const bf16*)dout,
-                           (const bf16*)out_relu, (const bf16*)x, mean, invstd, C, ppg, bpg, partial, mask_scale, mask_shift);
+        launch_bn_bwd_reduce<bf16>(dout, out_relu, x, mean, invstd, C, ppg, bpg, groups, partial, mask_scale, mask_shift, ST(stream));
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * groups), 0, ST(stream), partial, bpg, groups, C, sums,
                            dgamma, dbeta, accumulate);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream),
-                           (const bf16*)dout, (const bf16*)out_relu, (const bf16*)x, mean, invstd, gamma, sums,
-                           1.0f / (float)ppg, nvec, C, nvec / groups, (bf16*)dx, (bf16*)dres, mask_scale, mask_shift);
+        launch_bn_bwd_apply<bf16>(dout, out_relu, x, mean, invstd, gamma, sums, ppg, nvec, C, groups, dx, dres, mask_scale,
+                                  mask_shift, ST(stream));
     } else {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(groups * bpg), dim3(256), 0, ST(stream), (const float*)dout,
-                           (const float*)out_relu, (const float*)x, mean, invstd, C, ppg, bpg, partial, mask_scale, mask_shift);
+        launch_bn_bwd_reduce<float>(dout, out_relu, x, mean, invstd, C, ppg, bpg, groups, partial, mask_scale, mask_shift, ST(stream));
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * groups), 0, ST(stream), partial, bpg, groups, C, sums,
                            dgamma, dbeta, accumulate);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream),
-                           (const float*)dout, (const float*)out_relu, (const float*)x, mean, invstd, gamma, sums,
-                           1.0f / (float)ppg, nvec, C, nvec / groups, (float*)dx, (float*)dres, mask_scale, mask_shift);
+        launch_bn_bwd_apply<float>(dout, out_relu, x, mean, invstd, gamma, sums, ppg, nvec, C, groups, dx, dres, mask_scale,
+                                   mask_shift, ST(stream));
     }
     DH_CHECK_LAUNCH("bn_bwd");
     return 0;
@@ -460,13 +624,11 @@ extern "C" int dh_bn_bwd_from_partials(int dtype, const void* g, const void* x, 
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * groups), 0, ST(stream), partial, ntiles / groups, groups, C, sums,
                        dgamma, dbeta, accumulate);
     if (dtype == DH_DTYPE_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const bf16*)g,
-                           (const bf16*)nullptr, (const bf16*)x, mean, invstd, gamma, sums, 1.0f / (float)ppg, nvec, C,
-                           nvec / groups, (bf16*)dx, (bf16*)nullptr, (const float*)nullptr, (const float*)nullptr);
+        launch_bn_bwd_apply<bf16>(g, nullptr, x, mean, invstd, gamma, sums, ppg, nvec, C, groups, dx, nullptr, nullptr, nullptr,
+                                  ST(stream));
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec, 256)), dim3(256), 0, ST(stream), (const float*)g,
-                           (const float*)nullptr, (const float*)x, mean, invstd, gamma, sums, 1.0f / (float)ppg, nvec, C,
-                           nvec / groups, (float*)dx, (float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+        launch_bn_bwd_apply<float>(g, nullptr, x, mean, invstd, gamma, sums, ppg, nvec, C, groups, dx, nullptr, nullptr, nullptr,
+                                   ST(stream));
     DH_CHECK_LAUNCH("bn_bwd_from_partials");
     return 0;
 }
