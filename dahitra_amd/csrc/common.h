@@ -16,12 +16,15 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define DH_DTYPE_BF16 1
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                                    // RNE
-    return (unsigned short)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950 converts two values per instruction (v_cvt_pk_bf16_f32).  The former
+// software rounding cost ~7 VALU + an exec-mask branch (NaN case) per value in every bf16 store of every kernel.
+typedef __attribute__((ext_vector_type(2))) __bf16 dh_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float dh_f32x2;
+__device__ __forceinline__ unsigned f2bf2(float lo, float hi) {
+    const dh_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dh_bf16x2));
 }
+__device__ __forceinline__ unsigned short f2bf(float f) { return (unsigned short)(f2bf2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16* p) { return bf2f(p->x); }
@@ -43,8 +46,8 @@ __device__ __forceinline__ void st4(float* p, const float (&o)[4]) {
 }
 __device__ __forceinline__ void st4(bf16* p, const float (&o)[4]) {
     uint2 v;
-    v.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-    v.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+    v.x = f2bf2(o[0], o[1]);
+    v.y = f2bf2(o[2], o[3]);
     *reinterpret_cast<uint2*>(p) = v;
 }
 // 8 consecutive elements for bf16 (16 B), 4 for fp32 (16 B): the 16-byte vector unit "V16" -- one dwordx4 per lane
@@ -61,10 +64,10 @@ __device__ __forceinline__ void ldv(const bf16* p, float (&o)[8]) {
 }
 __device__ __forceinline__ void stv(bf16* p, const float (&o)[8]) {
     uint4 v;
-    v.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-    v.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
-    v.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
-    v.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
+    v.x = f2bf2(o[0], o[1]);
+    v.y = f2bf2(o[2], o[3]);
+    v.z = f2bf2(o[4], o[5]);
+    v.w = f2bf2(o[6], o[7]);
     *reinterpret_cast<uint4*>(p) = v;
 }
 

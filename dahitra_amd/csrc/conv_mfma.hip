@@ -84,8 +84,8 @@ template <> struct Mma<bf16> {
     }
 };
 
-template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     constexpr int TH = 4 * RW;
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
     constexpr int HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
@@ -170,23 +170,44 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         commit();
         __syncthreads();
         if (PF && c0 + CK < p.Cin) fetch(c0 + CK);
+        // The taps run column-major (kw outer) so that a pixel fragment -- halo row h = r*STRIDE + kh*DIL of column kw -- is
+        // read from LDS once and reused by every (r, kh) that lands on it; the fragments of step i+1 (4 weight sub-tiles
+        // + the new pixel rows) are issued BEFORE the MFMAs of step i, a whole tap (4*RW MFMAs) ahead of their use.
+        // (Left to the scheduler the reads sat 4 MFMAs ahead of their consumers and every group stalled on LDS latency.)
+        {
+            constexpr int HR = (RW - 1) * STRIDE + (KS - 1) * DIL + 1;
+            V16u B[KS][HR], A[2][NS];
+            bool have[KS][HR];
 #pragma unroll
-        for (int kh = 0; kh < KS; ++kh) {
+            for (int i = 0; i < KS; ++i)
 #pragma unroll
-            for (int kw = 0; kw < KS; ++kw) {
-                const int tap = kh * KS + kw;
-                V16u b[RW];
+                for (int h = 0; h < HR; ++h) have[i][h] = false;
+            auto issue = [&](int step) {
+                const int kw = step / KS, kh = step - kw * KS, tap = kh * KS + kw;
 #pragma unroll
-                for (int r = 0; r < RW; ++r)
-                    b[r].u = *reinterpret_cast<const uint4*>(
-                        halo + HL::off(((RW * wv + r) * STRIDE + kh * DIL) * HWD + pl * STRIDE + kw * DIL, g));
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    V16u a;
-                    a.u = *reinterpret_cast<const uint4*>(wts + wt_off(tap * NT + s * 16 + pl, g));
-#pragma unroll
-                    for (int r = 0; r < RW; ++r) Mma<T>::run(a, b[r], acc[s][r]);
+                for (int r = 0; r < RW; ++r) {
+                    const int h = r * STRIDE + kh * DIL;
+                    if (!have[kw][h]) {
+                        have[kw][h] = true;
+                        B[kw][h].u = *reinterpret_cast<const uint4*>(
+                            halo + HL::off((RW * wv * STRIDE + h) * HWD + pl * STRIDE + kw * DIL, g));
+                    }
                 }
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    A[step & 1][s].u = *reinterpret_cast<const uint4*>(wts + wt_off(tap * NT + s * 16 + pl, g));
+            };
+            issue(0);
+#pragma unroll
+            for (int step = 0; step < TAPS; ++step) {
+                const int kw = step / KS, kh = step - kw * KS;
+                if (step + 1 < TAPS) issue(step + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) Mma<T>::run(A[step & 1][s], B[kw][r * STRIDE + kh * DIL], acc[s][r]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
@@ -196,12 +217,64 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     T* yout = reinterpret_cast<T*>(p.y) + (size_t)n * p.OH * p.OW * p.Cout;
     const T* rin = p.res ? reinterpret_cast<const T*>(p.res) + (size_t)n * p.OH * p.OW * p.Cout : nullptr;
     const bool vec_ok = (p.Cout & 3) == 0;
+    // Output path: a lane holds 4 channels of one pixel (8 / 16 bytes), i.e. a direct store writes 32-byte runs at a
+    // Cout-sized stride -- measured 14-27 us per launch on the trunk layers.  The tile is instead transposed through
+    // the (now free) staging LDS and written as 16-byte pieces, NT*sizeof(T) contiguous bytes per pixel.
+    constexpr int PIECE = 16 / (int)sizeof(T);               // channels per 16-byte piece
+    constexpr int TPITCH = NT * (int)sizeof(T) + 16;         // LDS bytes per pixel row of the transposed tile
+    constexpr int RED_BYTES = 4 * 2 * NT * 4;                // the statistics scratch sits below the tile
+    const bool wide = FAST || (vec_ok && (p.Cout % PIECE) == 0);
+    unsigned char* otile = smem + RED_BYTES;
     float ssum[NS][4], ssq[NS][4];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { ssum[s][j] = 0.f; ssq[s][j] = 0.f; }
 
+    // The trunk's layers (no gating, no pre-activation copy, no GELU) take a COMPACT epilogue, as a separate
+    // instantiation (FAST; chosen by the host).  The fully general one below is ~20 000 instructions once unrolled over
+    // the 4*RW accumulator tiles, i.e. ~160 KB of straight-line code that every workgroup had to stream through the
+    // instruction cache once: measured 5.6 (RW = 2) to 18 us (RW = 4) per workgroup, more than the matrix work of the
+    // 64- and 128-channel layers.  (As a run-time branch in one kernel the compiler interleaved the two paths again.)
+    if constexpr (FAST) {
+        const bool relu = p.act == DH_ACT_RELU;
+        float bs[NS][4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = co0 + s * 16 + g * 4 + j;
+                bs[s][j] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+            }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int oy = oy0 + RW * wv + r, ox = ox0 + pl;
+            const bool pvalid = (oy < p.OH) && (ox < p.OW) && (oy * p.OW + ox < p.npix);
+            T* trow = reinterpret_cast<T*>(otile + ((RW * wv + r) * TW + pl) * TPITCH) + g * 4;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int c = co0 + s * 16 + g * 4;
+                const bool ok = pvalid && c < p.Cout;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[s][r][j] + bs[s][j];
+                if (rin && ok) {
+                    float rr[4];
+                    ld4(rin + (size_t)(oy * p.OW + ox) * p.Cout + c, rr);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += rr[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (relu) v[j] = fmaxf(v[j], 0.f);
+                    const float m = ok ? v[j] : 0.f;
+                    ssum[s][j] += m;
+                    ssq[s][j] += m * m;
+                }
+                st4(trow + s * 16, v);
+            }
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         const int oy = oy0 + RW * wv + r, ox = ox0 + pl;
@@ -241,7 +314,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                         ssum[s][j] += v[j];
                         ssq[s][j] += v[j] * xh;
                     }
-                    st4(yout + off, v);
+                    if (wide) st4(reinterpret_cast<T*>(otile + ((RW * wv + r) * TW + pl) * TPITCH) + s * 16 + g * 4, v);
+                    else st4(yout + off, v);
                     continue;
                 }
 #pragma unroll
@@ -251,7 +325,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                     ssum[s][j] += v[j];
                     ssq[s][j] += v[j] * v[j];
                 }
-                st4(yout + off, v);
+                if (wide) st4(reinterpret_cast<T*>(otile + ((RW * wv + r) * TW + pl) * TPITCH) + s * 16 + g * 4, v);
+                else st4(yout + off, v);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -270,6 +345,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         }
     }
 
+    }   // generic epilogue
     if (p.stats) {
         // reduce over the 16 pixel lanes of each lane group, then over the 4 waves through LDS
         float* red = reinterpret_cast<float*>(smem);   // [4 waves][2][NT]; staging LDS is free now
@@ -283,7 +359,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                     red[(wv * 2 + 1) * NT + s * 16 + g * 4 + j] = b;
                 }
             }
-        __syncthreads();
+    }
+    if (p.stats || wide) __syncthreads();
+    if (wide) {
+        constexpr int PPR = NT * (int)sizeof(T) / 16;         // 16-byte pieces per pixel
+        for (int i = tid; i < TH * TW * PPR; i += 256) {
+            const int px = i / PPR, q = i - px * PPR;
+            const int oy = oy0 + px / TW, ox = ox0 + px % TW, c = co0 + q * PIECE;
+            if (oy < p.OH && ox < p.OW && oy * p.OW + ox < p.npix && c < p.Cout)
+                *reinterpret_cast<uint4*>(yout + (size_t)(oy * p.OW + ox) * p.Cout + c) =
+                    *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
+        }
+    }
+    if (p.stats) {
+        const float* red = reinterpret_cast<const float*>(smem);
         if (tid < 2 * NT) {
             const int which = tid / NT, c = tid - which * NT;
             const float t = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] +
@@ -302,12 +391,14 @@ static inline int pick_rw(int N, int OH, int OW, int Cin, int ks, int stride) {
     return 2;
 }
 
-template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>
-int launch_pf(const ConvArgs& a, hipStream_t st) {
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>
+int launch_fast(const ConvArgs& a, hipStream_t st) {
     constexpr int TH = 4 * RW;
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
-    const size_t lds = (size_t)HH * HWD * HaloLayout<STRIDE>::PITCH + (size_t)KS * KS * NT * WPITCH;
-    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW, DIL, PF>;
+    const size_t staging = (size_t)HH * HWD * HaloLayout<STRIDE>::PITCH + (size_t)KS * KS * NT * WPITCH;
+    const size_t otile = (size_t)4 * 2 * NT * 4 + (size_t)TH * TW * (NT * sizeof(T) + 16);     // epilogue: stats scratch + transposed tile
+    const size_t lds = staging > otile ? staging : otile;
+    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW, DIL, PF, FAST>;
     static bool attr_done = false;      // once per instantiation (and never inside a graph capture)
     if (lds > 64 * 1024 && !attr_done) {
         attr_done = true;
@@ -322,6 +413,14 @@ int launch_pf(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
     DH_CHECK_LAUNCH("conv_mfma");
     return 0;
+}
+
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>
+int launch_pf(const ConvArgs& a, hipStream_t st) {
+    // compact-epilogue instantiation: 16-byte output pieces, no gating / pre-activation copy / GELU
+    const bool fast = (a.Cout % (16 / (int)sizeof(T))) == 0 && !a.gate_y && !a.y2 && a.act != DH_ACT_GELU;
+    if (fast) return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, true>(a, st);
+    return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, false>(a, st);
 }
 
 template <typename T, int KS, int STRIDE, int NT, int RW, int DIL>
@@ -344,7 +443,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
 
 template <typename T, int KS, int STRIDE>
 int launch_nt(const ConvArgs& a, hipStream_t st) {
-    if (a.CoutPad % 64 == 0) return launch<T, KS, STRIDE, 64>(a, st);
+    if (a.CoutPad % 64 == 0 && !(getenv("DH_NT32") && a.Cin <= 64 && KS == 3)) return launch<T, KS, STRIDE, 64>(a, st);
     if (a.CoutPad % 32 == 0) return launch<T, KS, STRIDE, 32>(a, st);
     return launch<T, KS, STRIDE, 16>(a, st);
 }

@@ -46,10 +46,10 @@ union U8 {
 
 __device__ __forceinline__ s16x8 pack8(const float (&a)[4], const float (&b)[4]) {
     U8 r;
-    r.u.x = (unsigned)f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16);
-    r.u.y = (unsigned)f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16);
-    r.u.z = (unsigned)f2bf(b[0]) | ((unsigned)f2bf(b[1]) << 16);
-    r.u.w = (unsigned)f2bf(b[2]) | ((unsigned)f2bf(b[3]) << 16);
+    r.u.x = f2bf2(a[0], a[1]);
+    r.u.y = f2bf2(a[2], a[3]);
+    r.u.z = f2bf2(b[0], b[1]);
+    r.u.w = f2bf2(b[2], b[3]);
     return r.v;
 }
 // A fragment of weight row `row`, logical k = koff + kappa(g, e): two 8-byte LDS reads

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Builds build/exp/lib_TIMING.so: the kernel library with wall-clock phase stamps in conv_mfma_kernel
+(experiment only; tools/conv_timeline.py reads them).  The product library is untouched."""
+import os, subprocess, glob
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+s = open(os.path.join(R, "dahitra_amd/csrc/conv_mfma.hip")).read()
+def rep(old, new):
+    global s
+    assert s.count(old) == 1, old
+    s = s.replace(old, new, 1)
+rep("template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>\n__global__",
+    '''__device__ long long g_ts[8192 * 16];
+#define TS(k) do { if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) g_ts[blockIdx.x * 16 + (k)] = (long long)wall_clock64(); } while (0)
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>
+__global__''')
+rep("    if (PF) fetch(0);\n    for (int c0 = 0; c0 < p.Cin; c0 += CK) {\n        if (!PF) fetch(c0);\n        commit();\n        __syncthreads();\n",
+    '''    TS(0);
+    if (PF) fetch(0);
+    for (int c0 = 0; c0 < p.Cin; c0 += CK) {
+        if (!PF) fetch(c0);
+        if (c0 == 0) TS(1);
+        commit();
+        if (c0 == 0) TS(2);
+        __syncthreads();
+        if (c0 == 0) TS(3);
+        if (c0 == CK) TS(5);
+''')
+rep("        __syncthreads();\n    }\n\n    // ---- epilogue ----", "        if (c0 == 0) TS(4);\n        __syncthreads();\n    }\n    TS(6);\n\n    // ---- epilogue ----")
+rep("    if (p.stats) {\n        // reduce over the 16 pixel lanes", "    TS(7);\n    if (p.stats) {\n        // reduce over the 16 pixel lanes")
+rep("    if (p.stats || wide) __syncthreads();\n    if (wide) {", "    TS(8);\n    if (p.stats || wide) __syncthreads();\n    TS(9);\n    if (wide) {")
+rep("    if (p.stats) {\n        const float* red = reinterpret_cast<const float*>(smem);", "    TS(10);\n    if (p.stats) {\n        const float* red = reinterpret_cast<const float*>(smem);")
+rep('''                p.stats[((size_t)which * p.CoutPad + co0 + c) * gridDim.x + blockIdx.x] = t;   // [2][CoutPad][tiles]
+        }
+    }
+}
+''', '''                p.stats[((size_t)which * p.CoutPad + co0 + c) * gridDim.x + blockIdx.x] = t;   // [2][CoutPad][tiles]
+        }
+    }
+    TS(11);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TS(12);
+}
+extern "C" int dh_debug_ts(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ts), (size_t)n * 8); }
+extern "C" int dh_debug_clear() { static long long z[8192 * 16]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ts), z, sizeof(z)); }
+''')
+os.makedirs(os.path.join(R, "build/exp"), exist_ok=True)
+src = os.path.join(R, "build/exp/conv_timing.hip")
+open(src, "w").write(s)
+flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(R, "include"), "-I" + os.path.join(R, "dahitra_amd/csrc"), "-Wno-unused-result"]
+subprocess.check_call(["hipcc"] + flags + ["-c", src, "-o", os.path.join(R, "build/exp/conv_TIMING.o")])
+objs = [o for o in glob.glob(os.path.join(R, "build/obj/*.o")) if not o.endswith("conv_mfma.o")]
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(R, "build/exp/lib_TIMING.so"), os.path.join(R, "build/exp/conv_TIMING.o")] + objs)
+print("built build/exp/lib_TIMING.so")
