@@ -20,6 +20,7 @@
 // (models/help_funcs.py:52-63,86-88,111), and the per-image attention products QK^T / PV in their
 // re-associated 32x32 form (per-image weights via w_nstride).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     // instruction cache once: measured 5.6 (RW = 2) to 18 us (RW = 4) per workgroup, more than the matrix work of the
     // 64- and 128-channel layers.  (As a run-time branch in one kernel the compiler interleaved the two paths again.)
     if constexpr (FAST) {
-        const bool relu = p.act == DH_ACT_RELU;
+        // straight-line variants, ONE executed: without statistics (data-gradient launches), with statistics on a
+        // tile that lies fully inside the image (no masking), the masked general case; each with / without ReLU
         float bs[NS][4];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -246,34 +248,48 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
                 const int c = co0 + s * 16 + g * 4 + j;
                 bs[s][j] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
             }
+        auto body = [&](auto with_stats, auto masked, auto relu) {
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const int oy = oy0 + RW * wv + r, ox = ox0 + pl;
-            const bool pvalid = (oy < p.OH) && (ox < p.OW) && (oy * p.OW + ox < p.npix);
-            T* trow = reinterpret_cast<T*>(otile + ((RW * wv + r) * TW + pl) * TPITCH) + g * 4;
+            for (int r = 0; r < RW; ++r) {
+                const int oy = oy0 + RW * wv + r, ox = ox0 + pl;
+                const bool pvalid = (oy < p.OH) && (ox < p.OW) && (oy * p.OW + ox < p.npix);
+                T* trow = reinterpret_cast<T*>(otile + ((RW * wv + r) * TW + pl) * TPITCH) + g * 4;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int c = co0 + s * 16 + g * 4;
-                const bool ok = pvalid && c < p.Cout;
-                float v[4];
+                for (int s = 0; s < NS; ++s) {
+                    float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[s][r][j] + bs[s][j];
-                if (rin && ok) {
-                    float rr[4];
-                    ld4(rin + (size_t)(oy * p.OW + ox) * p.Cout + c, rr);
+                    for (int j = 0; j < 4; ++j) v[j] = acc[s][r][j] + bs[s][j];
+                    if (rin) {
+                        const int c = co0 + s * 16 + g * 4;
+                        if (pvalid && c < p.Cout) {
+                            float rr[4];
+                            ld4(rin + (size_t)(oy * p.OW + ox) * p.Cout + c, rr);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += rr[j];
+                            for (int j = 0; j < 4; ++j) v[j] += rr[j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (decltype(relu)::value) v[j] = fmaxf(v[j], 0.f);
+                        if constexpr (decltype(with_stats)::value) {
+                            // channels beyond Cout carry zero weights and zero bias: they add 0 without a mask
+                            const float m = (decltype(masked)::value && !pvalid) ? 0.f : v[j];
+                            ssum[s][j] += m;
+                            ssq[s][j] += m * m;
+                        }
+                    }
+                    st4(trow + s * 16, v);
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (relu) v[j] = fmaxf(v[j], 0.f);
-                    const float m = ok ? v[j] : 0.f;
-                    ssum[s][j] += m;
-                    ssq[s][j] += m * m;
-                }
-                st4(trow + s * 16, v);
             }
-        }
+        };
+        const bool inside = oy0 + TH <= p.OH && ox0 + TW <= p.OW && (oy0 + TH - 1) * p.OW + ox0 + TW - 1 < p.npix;
+        auto pick = [&](auto relu) {
+            if (!p.stats) body(std::false_type{}, std::false_type{}, relu);
+            else if (inside) body(std::true_type{}, std::false_type{}, relu);
+            else body(std::true_type{}, std::true_type{}, relu);
+        };
+        if (p.act == DH_ACT_RELU) pick(std::true_type{});
+        else pick(std::false_type{});
     } else {
 #pragma unroll
     for (int r = 0; r < RW; ++r) {

@@ -8,10 +8,10 @@ def rep(old, new):
     global s
     assert s.count(old) == 1, old
     s = s.replace(old, new, 1)
-rep("template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>\n__global__",
+rep("template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>\n__global__",
     '''__device__ long long g_ts[8192 * 16];
 #define TS(k) do { if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) g_ts[blockIdx.x * 16 + (k)] = (long long)wall_clock64(); } while (0)
-template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>
 __global__''')
 rep("    if (PF) fetch(0);\n    for (int c0 = 0; c0 < p.Cin; c0 += CK) {\n        if (!PF) fetch(c0);\n        commit();\n        __syncthreads();\n",
     '''    TS(0);
@@ -26,6 +26,7 @@ rep("    if (PF) fetch(0);\n    for (int c0 = 0; c0 < p.Cin; c0 += CK) {\n      
         if (c0 == CK) TS(5);
 ''')
 rep("        __syncthreads();\n    }\n\n    // ---- epilogue ----", "        if (c0 == 0) TS(4);\n        __syncthreads();\n    }\n    TS(6);\n\n    // ---- epilogue ----")
+rep("                    st4(trow + s * 16, v);\n                }\n", "                    st4(trow + s * 16, v);\n                }\n                if (r < 3) TS(13 + r);\n")
 rep("    if (p.stats) {\n        // reduce over the 16 pixel lanes", "    TS(7);\n    if (p.stats) {\n        // reduce over the 16 pixel lanes")
 rep("    if (p.stats || wide) __syncthreads();\n    if (wide) {", "    TS(8);\n    if (p.stats || wide) __syncthreads();\n    TS(9);\n    if (wide) {")
 rep("    if (p.stats) {\n        const float* red = reinterpret_cast<const float*>(smem);", "    TS(10);\n    if (p.stats) {\n        const float* red = reinterpret_cast<const float*>(smem);")

@@ -23,7 +23,7 @@ for name, (N, H, W, Cin, Cout) in SHAPES.items():
     rc = lib.dh_debug_ts(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
     ts = buf.reshape(8192, 16)
     used = ts[:, 0] > 0
-    ts = ts[used][:, :13]
+    ts = ts[used][:, :16]
     t0 = ts[:, 0].min()
     rel = (ts[:, :13] - t0) / 100.0          # wall_clock64: 100 MHz -> us
     print(name, "workgroups (y=0):", len(ts), "span %.1f us" % rel[:, 12].max())
@@ -31,6 +31,9 @@ for name, (N, H, W, Cin, Cout) in SHAPES.items():
     lab = ["fetch0 issue", "commit0 (vm wait)", "barrier", "mfma chunk0", "->chunk1 mfma start", "chunk1..end loop", "epi: registers+LDS tile", "epi: stats dpp+red", "epi: barrier", "epi: wide stores issue", "epi: stats store", "store drain"]
     for i, l in enumerate(lab):
         print("   %-24s mean %6.2f  p50 %6.2f  p90 %6.2f us" % (l, d[:, i].mean(), np.median(d[:, i]), np.quantile(d[:, i], 0.9)))
+    sub = (ts[:, 13:16] - t0) / 100.0
+    print("   epilogue rows: TS6->row0 %.2f  row0->row1 %.2f  row1->row2 %.2f  row2->TS7 %.2f us" % (
+        (sub[:, 0] - rel[:, 6]).mean(), (sub[:, 1] - sub[:, 0]).mean(), (sub[:, 2] - sub[:, 1]).mean(), (rel[:, 7] - sub[:, 2]).mean()))
     life = rel[:, 12] - rel[:, 0]
     print("   lifetime mean %.2f us; start times: p50 %.1f p90 %.1f max %.1f" % (life.mean(), np.median(rel[:, 0]), np.quantile(rel[:, 0], 0.9), rel[:, 0].max()))
     # concurrent workgroups: sample at the median time
