@@ -36,28 +36,6 @@ struct WgArgs {
                        // (1x1, one group), so assign (1) or accumulate (2) straight into dW and skip the reduce launch
 };
 
-// the 16-byte piece q of channels [c0, ...) of one pixel row (zeros past Ctot / for a null row)
-template <typename T>
-__device__ __forceinline__ uint4 load_piece(const T* src_row, int c0, int Ctot, int q) {
-    constexpr int EPV = 16 / (int)sizeof(T);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    const int c = c0 + q * EPV;
-    if (src_row) {
-        if (((Ctot * (int)sizeof(T)) & 15) == 0 && c + EPV <= Ctot) {
-            v = *reinterpret_cast<const uint4*>(src_row + c);
-        } else {
-            __attribute__((aligned(16))) T tmp[EPV];
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                if (c + e < Ctot) tmp[e] = src_row[c + e];
-                else stf(&tmp[e], 0.f);
-            }
-            v = *reinterpret_cast<uint4*>(tmp);
-        }
-    }
-    return v;
-}
-
 constexpr int lds_pitch(int row_bytes) { return ((row_bytes / 32) & 1) ? row_bytes : row_bytes + 32; }
 
 union F8 {
@@ -105,37 +83,81 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
     constexpr int XQ = IT * (int)sizeof(T) / 16, DQ = CT * (int)sizeof(T) / 16;
     constexpr int NXV = (HH * HWD * XQ + 255) / 256, NDV = (TH * TW * DQ + 255) / 256;
     uint4 rx[NXV], rd[NDV];
-    auto fetch = [&](int tile) {
-        const int n = grp * imgs_per_group + tile / tiles_per_img;
-        const int tt = tile % tiles_per_img;
-        const int ty = tt / p.tilesX, tx = tt % p.tilesX;
-        const int oy0 = ty * TH, ox0 = tx * TW;
-        const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
-        const T* xin = reinterpret_cast<const T*>(p.x) + (size_t)n * p.H * p.W * p.CinPitch;
-        const T* dyin = reinterpret_cast<const T*>(p.dy) + (size_t)n * p.OH * p.OW * p.Cout;
+    // Everything about a 16-byte piece that does not depend on the tile is computed ONCE: its halo / tile position,
+    // its element offset from the tile origin and how it is loaded (0: zeros, 1: one 16-byte load, 2: ragged channel
+    // tail).  Per tile only the scalar tile origin and the border tests remain (no divisions by runtime tile counts,
+    // no 64-bit products per piece).
+    int x_hy[NXV], x_hx[NXV], x_rel[NXV], x_mode[NXV];
+    int d_py[NDV], d_px[NDV], d_rel[NDV], d_mode[NDV];
+    constexpr int EPV = 16 / (int)sizeof(T);
+    {
+        const bool xal = ((p.Cin * (int)sizeof(T)) & 15) == 0, dal = ((p.Cout * (int)sizeof(T)) & 15) == 0;
 #pragma unroll
         for (int i = 0; i < NXV; ++i) {
             const int idx = tid + i * 256;
-            rx[i] = make_uint4(0, 0, 0, 0);
-            if (idx < HH * HWD * XQ) {
-                const int px = idx / XQ, q = idx % XQ;
-                const int hy = px / HWD, hx = px % HWD;
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && iy * p.W + ix < p.in_npix;
-                rx[i] = load_piece<T>(ok ? xin + (size_t)(iy * p.W + ix) * p.CinPitch : nullptr, ci0, p.Cin, q);
-            }
+            const int px = idx / XQ, q = idx % XQ;
+            x_hy[i] = px / HWD; x_hx[i] = px % HWD;
+            const int c = ci0 + q * EPV;
+            x_rel[i] = (x_hy[i] * p.W + x_hx[i]) * p.CinPitch + c;
+            x_mode[i] = (idx >= HH * HWD * XQ || c >= p.Cin) ? 0 : ((xal && c + EPV <= p.Cin) ? 1 : 2);
         }
 #pragma unroll
         for (int i = 0; i < NDV; ++i) {
             const int idx = tid + i * 256;
-            rd[i] = make_uint4(0, 0, 0, 0);
-            if (idx < TH * TW * DQ) {
-                const int px = idx / DQ, q = idx % DQ;
-                const int oy = oy0 + px / TW, ox = ox0 + px % TW;
-                const bool ok = oy < p.OH && ox < p.OW && oy * p.OW + ox < p.npix;
-                rd[i] = load_piece<T>(ok ? dyin + (size_t)(oy * p.OW + ox) * p.Cout : nullptr, co0, p.Cout, q);
+            const int px = idx / DQ, q = idx % DQ;
+            d_py[i] = px / TW; d_px[i] = px % TW;
+            const int c = co0 + q * EPV;
+            d_rel[i] = (d_py[i] * p.OW + d_px[i]) * p.Cout + c;
+            d_mode[i] = (idx >= TH * TW * DQ || c >= p.Cout) ? 0 : ((dal && c + EPV <= p.Cout) ? 1 : 2);
+        }
+    }
+    // ragged channel tail of one piece: element loads, zeros past `nvalid` elements
+    auto load_tail = [&](const T* src, int nvalid) {
+        __attribute__((aligned(16))) T tmp[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            if (e < nvalid) tmp[e] = src[e];
+            else stf(&tmp[e], 0.f);
+        }
+        return *reinterpret_cast<uint4*>(tmp);
+    };
+    // tile = (image, ty, tx) advances by splitk tiles per step: a three-digit counter instead of divisions
+    const int dn = p.splitk / tiles_per_img, drem = p.splitk % tiles_per_img;
+    const int dty = drem / p.tilesX, dtx = drem % p.tilesX;
+    int f_n = kz / tiles_per_img, f_ty = (kz % tiles_per_img) / p.tilesX, f_tx = (kz % tiles_per_img) % p.tilesX;
+    auto fetch = [&]() {      // loads the tile the counter points at, then advances the counter
+        const int n = grp * imgs_per_group + f_n;
+        const int oy0 = f_ty * TH, ox0 = f_tx * TW;
+        const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
+        const T* xin = reinterpret_cast<const T*>(p.x) + (size_t)n * p.H * p.W * p.CinPitch +
+                       ((long)iy0 * p.W + ix0) * p.CinPitch;
+        const T* dyin = reinterpret_cast<const T*>(p.dy) + (size_t)n * p.OH * p.OW * p.Cout +
+                        ((long)oy0 * p.OW + ox0) * p.Cout;
+#pragma unroll
+        for (int i = 0; i < NXV; ++i) {
+            rx[i] = make_uint4(0, 0, 0, 0);
+            const int iy = iy0 + x_hy[i], ix = ix0 + x_hx[i];
+            const bool ok = x_mode[i] != 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && iy * p.W + ix < p.in_npix;
+            if (ok) {
+                if (x_mode[i] == 1) rx[i] = *reinterpret_cast<const uint4*>(xin + x_rel[i]);
+                else rx[i] = load_tail(xin + x_rel[i], p.Cin - (ci0 + ((tid + i * 256) % XQ) * EPV));
             }
         }
+#pragma unroll
+        for (int i = 0; i < NDV; ++i) {
+            rd[i] = make_uint4(0, 0, 0, 0);
+            const int oy = oy0 + d_py[i], ox = ox0 + d_px[i];
+            const bool ok = d_mode[i] != 0 && oy < p.OH && ox < p.OW && oy * p.OW + ox < p.npix;
+            if (ok) {
+                if (d_mode[i] == 1) rd[i] = *reinterpret_cast<const uint4*>(dyin + d_rel[i]);
+                else rd[i] = load_tail(dyin + d_rel[i], p.Cout - (co0 + ((tid + i * 256) % DQ) * EPV));
+            }
+        }
+        f_tx += dtx;
+        if (f_tx >= p.tilesX) { f_tx -= p.tilesX; ++f_ty; }
+        f_ty += dty;
+        if (f_ty >= p.tilesY) { f_ty -= p.tilesY; ++f_n; }
+        f_n += dn;
     };
     auto commit = [&]() {
 #pragma unroll
@@ -150,11 +172,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
         }
     };
 
-    if (kz < ntiles) fetch(kz);
+    if (kz < ntiles) fetch();
     for (int tile = kz; tile < ntiles; tile += p.splitk) {
         commit();
         __syncthreads();
-        if (tile + p.splitk < ntiles) fetch(tile + p.splitk);
+        if (tile + p.splitk < ntiles) fetch();
 
         if constexpr (sizeof(T) == 4) {
             // 4 pixels per MFMA: lane (pl, g) supplies pixel k0+g, channel pl
@@ -175,42 +197,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
             }
         } else {
             // 32 pixels (two tile rows) per MFMA: lane group g supplies columns 4g..4g+3 of rows r0 and r0+1,
-            // so the 32 lanes of a half-wave read 8 consecutive pixels per transpose-read (see pitch note)
-            for (int k0 = kq * KPW; k0 < (kq + 1) * KPW; k0 += 32) {
-                const int r0 = k0 / TW, c0 = g * 4;
+            // so the 32 lanes of a half-wave read 8 consecutive pixels per transpose-read (see pitch note).
+            // The k-steps are fully unrolled from per-lane base addresses: every LDS read is base + immediate.
+            const int c0 = g * 4;
+            const unsigned char* a_base = TR ? dyt + (kq * KPW + c0 + (pl >> 2)) * DP + (cw * 16 + (pl & 3) * 4) * 2
+                                             : dyt + (kq * KPW + c0) * DP + (cw * 16 + pl) * 2;
+            const unsigned char* b_base = (TR && STRIDE == 1)
+                ? halo + (kq * (KPW / TW) * STRIDE * HWD + c0 * STRIDE + (pl >> 2)) * XP + ((pl & 3) * 4) * 2
+                : halo + (kq * (KPW / TW) * STRIDE * HWD + c0 * STRIDE) * XP + pl * 2;
+#pragma unroll
+            for (int kk = 0; kk < KPW; kk += 32) {
                 F8 a;
                 if constexpr (TR) {
                     // lane p of each 16-lane group points at the 8-byte piece (pixel p/4, channels 4*(p%4)..+3)
-                    const unsigned char* base = dyt + (k0 + c0 + (pl >> 2)) * DP + (cw * 16 + (pl & 3) * 4) * 2;
                     a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(base));
+                        (__attribute__((address_space(3))) s16x4*)(a_base + kk * DP));
                     a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(base + TW * DP));
+                        (__attribute__((address_space(3))) s16x4*)(a_base + (kk + TW) * DP));
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        a.s[j] = *reinterpret_cast<const unsigned short*>(
-                            dyt + (k0 + (j >> 2) * TW + c0 + (j & 3)) * DP + (cw * 16 + pl) * 2);
+                        a.s[j] = *reinterpret_cast<const unsigned short*>(a_base + (kk + (j >> 2) * TW + (j & 3)) * DP);
                 }
 #pragma unroll
                 for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < KS; ++kw) {
-                        const int hp = (r0 * STRIDE + kh * DIL) * HWD + c0 * STRIDE + kw * DIL;
+                        const int hp = ((kk / TW) * STRIDE + kh * DIL) * HWD + kw * DIL;      // compile-time
 #pragma unroll
                         for (int i = 0; i < NI; ++i) {
                             F8 b;
                             if constexpr (TR && STRIDE == 1) {
-                                const unsigned char* base = halo + (hp + (pl >> 2)) * XP + (i * 16 + (pl & 3) * 4) * 2;
                                 b.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                    (__attribute__((address_space(3))) s16x4*)(base));
+                                    (__attribute__((address_space(3))) s16x4*)(b_base + hp * XP + i * 32));
                                 b.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                    (__attribute__((address_space(3))) s16x4*)(base + HWD * XP));
+                                    (__attribute__((address_space(3))) s16x4*)(b_base + (hp + HWD) * XP + i * 32));
                             } else {
 #pragma unroll
                                 for (int j = 0; j < 8; ++j)
                                     b.s[j] = *reinterpret_cast<const unsigned short*>(
-                                        halo + (hp + (j >> 2) * STRIDE * HWD + (j & 3) * STRIDE) * XP + (i * 16 + pl) * 2);
+                                        b_base + (hp + (j >> 2) * STRIDE * HWD + (j & 3) * STRIDE) * XP + i * 32);
                             }
                             acc[kh * KS + kw][i] =
                                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc[kh * KS + kw][i], 0, 0, 0);
@@ -247,19 +273,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
         if (kq != 0) return;
     }
     // partial slab: [grp][kz][tap][Cout][Cin]
-    float* out = p.part + ((size_t)grp * p.splitk + kz) * TAPS * p.Cout * p.Cin;
+    // (one 64-bit base + 32-bit offsets, bounds hoisted: the slab of one workgroup is far below 2^31 elements)
+    const int cob = co0 + cw * 16 + g * 4, cib = ci0 + pl;
+    float* out = p.part + ((size_t)grp * p.splitk + kz) * TAPS * p.Cout * p.Cin + (size_t)cob * p.Cin + cib;
+    const int tstride = p.Cout * p.Cin;
+    bool okj[4], oki[NI];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int j = 0; j < 4; ++j) okj[j] = cob + j < p.CoutUse;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i) oki[i] = cib + i * 16 < p.Cin;
+    if (p.direct == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = co0 + cw * 16 + g * 4 + j, ci = ci0 + i * 16 + pl;
-                if (co < p.CoutUse && ci < p.Cin) {
-                    float* dst = out + ((size_t)t * p.Cout + co) * p.Cin + ci;
-                    if (p.direct == 2) *dst += acc[t][i][j]; else *dst = acc[t][i][j];
-                }
-            }
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (okj[j] && oki[i]) out[t * tstride + j * p.Cin + i * 16] += acc[t][i][j];
+    } else {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (okj[j] && oki[i]) out[t * tstride + j * p.Cin + i * 16] = acc[t][i][j];
+    }
 }
 
 // dw_oihw[g][o][i][tap] (+)= sum_kz part[g][kz][tap][o][i]      (blockIdx.y = group)

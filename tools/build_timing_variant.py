@@ -10,7 +10,7 @@ def rep(old, new):
     s = s.replace(old, new, 1)
 rep("template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>\n__global__",
     '''__device__ long long g_ts[8192 * 16];
-#define TS(k) do { if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 8192) g_ts[blockIdx.x * 16 + (k)] = (long long)wall_clock64(); } while (0)
+#define TS(k) do { if (tid == 0 && blockIdx.x + blockIdx.y * gridDim.x < 8192) g_ts[(blockIdx.x + blockIdx.y * gridDim.x) * 16 + (k)] = (long long)wall_clock64(); } while (0)
 template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>
 __global__''')
 rep("    if (PF) fetch(0);\n    for (int c0 = 0; c0 < p.Cin; c0 += CK) {\n        if (!PF) fetch(c0);\n        commit();\n        __syncthreads();\n",

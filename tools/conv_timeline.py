@@ -34,6 +34,13 @@ for name, (N, H, W, Cin, Cout) in SHAPES.items():
     sub = (ts[:, 13:16] - t0) / 100.0
     print("   epilogue rows: TS6->row0 %.2f  row0->row1 %.2f  row1->row2 %.2f  row2->TS7 %.2f us" % (
         (sub[:, 0] - rel[:, 6]).mean(), (sub[:, 1] - sub[:, 0]).mean(), (sub[:, 2] - sub[:, 1]).mean(), (rel[:, 7] - sub[:, 2]).mean()))
+    early = rel[:, 0] < 4.0
+    late = rel[:, 0] > 8.0
+    for nm, sel in (("first-round", early), ("later", late)):
+        if sel.sum():
+            print("   %-12s (%4d wgs): fetch0 %.2f  commit-wait %.2f  mfma0 %.2f  epi-regs %.2f  epi-total %.2f  lifetime %.2f us" % (
+                nm, sel.sum(), d[sel, 0].mean(), d[sel, 1].mean(), d[sel, 3].mean(), d[sel, 6].mean(),
+                (rel[sel, 12] - rel[sel, 6]).mean(), (rel[sel, 12] - rel[sel, 0]).mean()))
     life = rel[:, 12] - rel[:, 0]
     print("   lifetime mean %.2f us; start times: p50 %.1f p90 %.1f max %.1f" % (life.mean(), np.median(rel[:, 0]), np.quantile(rel[:, 0], 0.9), rel[:, 0].max()))
     # concurrent workgroups: sample at the median time
