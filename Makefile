@@ -10,7 +10,7 @@ FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-resul
 
 all: $(LIB)
 
-$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/common.h
+$(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/conv_mfma_impl.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

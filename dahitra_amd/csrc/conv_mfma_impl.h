@@ -1,0 +1,483 @@
+// NHWC direct convolution on the CDNA4 matrix cores (gfx950), im2col-free.
+//
+// One 256-thread workgroup (4 wavefronts of 64) produces an 8x16-pixel output tile of one image
+// for NT output channels.  Per 64-byte input-channel chunk (32 bf16 / 16 fp32 channels) the
+// haloed input tile and the weights of all KSxKS taps are staged once in LDS; every tap is then a
+// shifted 1x1 product D[cout][pixel] += W[cout][k] * X[pixel][k] issued as MFMA
+//   bf16: v_mfma_f32_16x16x32_bf16   (one per 32 channels)
+//   fp32: v_mfma_f32_16x16x4_f32 x4  (exact fp32, parity mode)
+// with fp32 accumulation.  Weights are the A operand so that a lane ends up with 4 consecutive
+// output channels of one pixel (8/16-byte stores).  Epilogue: +bias, +residual, ReLU/GELU, and
+// optional per-workgroup partial sums (sum, sum of squares) per channel for train-mode BatchNorm.
+// A data-gradient launch can instead be "gated" for the BatchNorm layer it back-propagates into: the epilogue
+// applies that layer's ReLU mask, stores g = dout*mask and emits the per-tile partials (sum g, sum g*xhat) of the
+// BN backward -- the separate reduction pass over (dout, out, y) disappears and the apply pass reads 2 tensors
+// instead of 3.
+//
+// The same kernel serves: every 3x3 / 1x1 convolution of the trunk and head (reference
+// models/resnet.py:24-32, models/help_funcs.py:7-15, models/networks.py:215), their data
+// gradients (transposed, flipped weights), every nn.Linear of the token / pixel transformers
+// (models/help_funcs.py:52-63,86-88,111), and the per-image attention products QK^T / PV in their
+// re-associated 32x32 form (per-image weights via w_nstride).
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int TW = 16;                  // output tile: 16 pixels wide, 4*RW rows (RW rows per wavefront)
+// LDS rows hold one 64-byte channel chunk.  ds_read_b128 is served in 16-lane groups
+// {0-3,12-15,20-27},{4-11,16-19,28-31},... (MI355X_MICROARCH.md), each needing 16 distinct 16-byte slots
+// mod 256 B.  Brute force over layouts: for consecutive rows (stride-1 pixels, weight rows) pitch 64 with
+// slot ^= ((row>>2)&1)<<1 is conflict-free at every base offset; for every-other-row reads (stride 2) pitch
+// 80 without swizzle is.  (The former 80-byte pitch cost 2x on stride 1: SQ_LDS_BANK_CONFLICT = 45 %.)
+constexpr int WPITCH = 64;
+template <int STRIDE> struct HaloLayout {
+    static constexpr int PITCH = STRIDE == 1 ? 64 : 80;
+    static __device__ __forceinline__ int off(int row, int q) {
+        return row * PITCH + ((STRIDE == 1 ? (q ^ (((row >> 2) & 1) << 1)) : q) << 4);
+    }
+};
+__device__ __forceinline__ int wt_off(int row, int q) { return row * WPITCH + ((q ^ (((row >> 2) & 1) << 1)) << 4); }
+
+}  // namespace
+
+// (external linkage: the per-dtype launchers of the other translation units take it by reference)
+struct ConvArgs {
+    const void* x;
+    const void* w;
+    void* y;
+    const float* bias;
+    const void* res;
+    float* stats;      // [2][CoutPad][gridDim.x] partial (sum, sumsq) per pixel tile, or null: channel-major, so that
+                       // the per-channel combine (bn_finalize) reads contiguous runs
+    void* y2;          // optional: value before the activation (needed by the GELU derivative)
+    int N, H, W, Cin, OH, OW, Cout, CoutPad, pad, act;
+    int npix;          // valid output pixels per image in linear order (OH*OW unless a row view)
+    int in_npix;       // valid input pixels per image in linear order (H*W unless a row view)
+    long w_nstride;    // elements between per-image weight sets (0: shared)
+    int tilesX, tilesY;
+    int rw;            // rows per wavefront (tile height = 4*rw)
+    int dil;           // dilation (1, or 2 for the ResNet-50 layer3 3x3 convolutions)
+    // BatchNorm-backward gating of a data-gradient launch (see the epilogue): tensors of the BN layer whose output
+    // this launch differentiates -- same [N][OH][OW][Cout] shape as y
+    const void* gate_out;       // that layer's post-ReLU output (null: no ReLU)
+    const void* gate_y;         // its pre-normalisation input (null: gating off)
+    const float* gate_mean;     // [groups][Cout]
+    const float* gate_invstd;   // [groups][Cout]
+    int gate_groups;
+};
+
+namespace {
+
+union V16u {
+    uint4 u;
+    float f[4];
+    s16x8 h;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(const V16u& a, const V16u& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[0], b.f[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[1], b.f[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[2], b.f[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[3], b.f[3], c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ void run(const V16u& a, const V16u& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+    }
+};
+
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
+    constexpr int TH = 4 * RW;
+    constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
+    constexpr int HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
+    constexpr int TAPS = KS * KS;
+    constexpr int CK = 64 / (int)sizeof(T);     // channels per 64-byte chunk
+    constexpr int NS = NT / 16;                 // 16-channel output sub-tiles
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using HL = HaloLayout<STRIDE>;
+    unsigned char* halo = smem;                                  // [HH*HWD] rows, HL layout
+    unsigned char* wts = smem + HH * HWD * HL::PITCH;            // [TAPS*NT] rows, swizzled pitch 64
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    int bt = blockIdx.x;
+    const int tx = bt % p.tilesX; bt /= p.tilesX;
+    const int ty = bt % p.tilesY;
+    const int n = bt / p.tilesY;
+    const int co0 = blockIdx.y * NT;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
+
+    const unsigned char* xin = reinterpret_cast<const unsigned char*>(p.x) +
+                               (size_t)n * p.H * p.W * p.Cin * sizeof(T);
+    const unsigned char* wgt = reinterpret_cast<const unsigned char*>(p.w) +
+                               (size_t)n * p.w_nstride * sizeof(T);
+
+    f32x4 acc[NS][RW];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[s][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Software pipeline over the 64-byte channel chunks: the global loads of chunk c+1 are issued into
+    // registers before the MFMAs of chunk c and committed to LDS after them (latency hides under matrix work).
+    constexpr int NHV = (HH * HWD * 4 + 255) / 256, NWV = (TAPS * NT * 4 + 255) / 256;
+    uint4 rh[NHV], rw[NWV];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NHV; ++i) {
+            const int idx = tid + i * 256;
+            rh[i] = make_uint4(0, 0, 0, 0);
+            if (idx < HH * HWD * 4) {
+                const int px = idx >> 2, q = idx & 3;
+                const int hy = px / HWD, hx = px - hy * HWD;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && iy * p.W + ix < p.in_npix)
+                    rh[i] = *reinterpret_cast<const uint4*>(
+                        xin + ((size_t)(iy * p.W + ix) * p.Cin + c0) * sizeof(T) + q * 16);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256;
+            rw[i] = make_uint4(0, 0, 0, 0);
+            if (idx < TAPS * NT * 4) {
+                const int row = idx >> 2, q = idx & 3;
+                const int tap = row / NT, co = row - tap * NT;
+                rw[i] = *reinterpret_cast<const uint4*>(
+                    wgt + ((size_t)(tap * p.CoutPad + co0 + co) * p.Cin + c0) * sizeof(T) + q * 16);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NHV; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < HH * HWD * 4) *reinterpret_cast<uint4*>(halo + HL::off(idx >> 2, idx & 3)) = rh[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < TAPS * NT * 4) *reinterpret_cast<uint4*>(wts + wt_off(idx >> 2, idx & 3)) = rw[i];
+        }
+    };
+
+    // PF = false (layers with at most two channel chunks): nothing to pipeline inside a workgroup, so the staging
+    // registers are not kept alive across the MFMAs -- fewer VGPRs, one more resident workgroup per CU does the overlap
+    if (PF) fetch(0);
+    for (int c0 = 0; c0 < p.Cin; c0 += CK) {
+        if (!PF) fetch(c0);
+        commit();
+        __syncthreads();
+        if (PF && c0 + CK < p.Cin) fetch(c0 + CK);
+        // The taps run column-major (kw outer) so that a pixel fragment -- halo row h = r*STRIDE + kh*DIL of column kw -- is
+        // read from LDS once and reused by every (r, kh) that lands on it; the fragments of step i+1 (4 weight sub-tiles
+        // + the new pixel rows) are issued BEFORE the MFMAs of step i, a whole tap (4*RW MFMAs) ahead of their use.
+        // (Left to the scheduler the reads sat 4 MFMAs ahead of their consumers and every group stalled on LDS latency.)
+        {
+            constexpr int HR = (RW - 1) * STRIDE + (KS - 1) * DIL + 1;
+            V16u B[KS][HR], A[2][NS];
+            bool have[KS][HR];
+#pragma unroll
+            for (int i = 0; i < KS; ++i)
+#pragma unroll
+                for (int h = 0; h < HR; ++h) have[i][h] = false;
+            auto issue = [&](int step) {
+                const int kw = step / KS, kh = step - kw * KS, tap = kh * KS + kw;
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const int h = r * STRIDE + kh * DIL;
+                    if (!have[kw][h]) {
+                        have[kw][h] = true;
+                        B[kw][h].u = *reinterpret_cast<const uint4*>(
+                            halo + HL::off((RW * wv * STRIDE + h) * HWD + pl * STRIDE + kw * DIL, g));
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    A[step & 1][s].u = *reinterpret_cast<const uint4*>(wts + wt_off(tap * NT + s * 16 + pl, g));
+            };
+            issue(0);
+#pragma unroll
+            for (int step = 0; step < TAPS; ++step) {
+                const int kw = step / KS, kh = step - kw * KS;
+                if (step + 1 < TAPS) issue(step + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) Mma<T>::run(A[step & 1][s], B[kw][r * STRIDE + kh * DIL], acc[s][r]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    T* yout = reinterpret_cast<T*>(p.y) + (size_t)n * p.OH * p.OW * p.Cout;
+    const T* rin = p.res ? reinterpret_cast<const T*>(p.res) + (size_t)n * p.OH * p.OW * p.Cout : nullptr;
+    const bool vec_ok = (p.Cout & 3) == 0;
+    // Output path: a lane holds 4 channels of one pixel (8 / 16 bytes), i.e. a direct store writes 32-byte runs at a
+    // Cout-sized stride -- measured 14-27 us per launch on the trunk layers.  The tile is instead transposed through
+    // the (now free) staging LDS and written as 16-byte pieces, NT*sizeof(T) contiguous bytes per pixel.
+    constexpr int PIECE = 16 / (int)sizeof(T);               // channels per 16-byte piece
+    constexpr int TPITCH = NT * (int)sizeof(T) + 16;         // LDS bytes per pixel row of the transposed tile
+    constexpr int RED_BYTES = 4 * 2 * NT * 4;                // the statistics scratch sits below the tile
+    const bool wide = FAST || (vec_ok && (p.Cout % PIECE) == 0);
+    unsigned char* otile = smem + RED_BYTES;
+    float ssum[NS][4], ssq[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ssum[s][j] = 0.f; ssq[s][j] = 0.f; }
+
+    // The trunk's layers (no gating, no pre-activation copy, no GELU) take a COMPACT epilogue, as a separate
+    // instantiation (FAST; chosen by the host).  The fully general one below is ~20 000 instructions once unrolled over
+    // the 4*RW accumulator tiles, i.e. ~160 KB of straight-line code that every workgroup had to stream through the
+    // instruction cache once: measured 5.6 (RW = 2) to 18 us (RW = 4) per workgroup, more than the matrix work of the
+    // 64- and 128-channel layers.  (As a run-time branch in one kernel the compiler interleaved the two paths again.)
+    if constexpr (FAST) {
+        // straight-line variants, ONE executed: without statistics (data-gradient launches), with statistics on a
+        // tile that lies fully inside the image (no masking), the masked general case; each with / without ReLU
+        float bs[NS][4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = co0 + s * 16 + g * 4 + j;
+                bs[s][j] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+            }
+        auto body = [&](auto with_stats, auto masked, auto relu) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int oy = oy0 + RW * wv + r, ox = ox0 + pl;
+                const bool pvalid = (oy < p.OH) && (ox < p.OW) && (oy * p.OW + ox < p.npix);
+                T* trow = reinterpret_cast<T*>(otile + ((RW * wv + r) * TW + pl) * TPITCH) + g * 4;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[s][r][j] + bs[s][j];
+                    if (rin) {
+                        const int c = co0 + s * 16 + g * 4;
+                        if (pvalid && c < p.Cout) {
+                            float rr[4];
+                            ld4(rin + (size_t)(oy * p.OW + ox) * p.Cout + c, rr);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += rr[j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (decltype(relu)::value) v[j] = fmaxf(v[j], 0.f);
+                        if constexpr (decltype(with_stats)::value) {
+                            // channels beyond Cout carry zero weights and zero bias: they add 0 without a mask
+                            const float m = (decltype(masked)::value && !pvalid) ? 0.f : v[j];
+                            ssum[s][j] += m;
+                            ssq[s][j] += m * m;
+                        }
+                    }
+                    st4(trow + s * 16, v);
+                }
+            }
+        };
+        const bool inside = oy0 + TH <= p.OH && ox0 + TW <= p.OW && (oy0 + TH - 1) * p.OW + ox0 + TW - 1 < p.npix;
+        auto pick = [&](auto relu) {
+            if (!p.stats) body(std::false_type{}, std::false_type{}, relu);
+            else if (inside) body(std::true_type{}, std::false_type{}, relu);
+            else body(std::true_type{}, std::true_type{}, relu);
+        };
+        if (p.act == DH_ACT_RELU) pick(std::true_type{});
+        else pick(std::false_type{});
+    } else {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int oy = oy0 + RW * wv + r, ox = ox0 + pl;
+        const bool pvalid = (oy < p.OH) && (ox < p.OW) && (oy * p.OW + ox < p.npix);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = co0 + s * 16 + g * 4;
+            if (!pvalid || c >= p.Cout) continue;
+            float v[4] = {acc[s][r][0], acc[s][r][1], acc[s][r][2], acc[s][r][3]};
+            const size_t off = (size_t)(oy * p.OW + ox) * p.Cout + c;
+            if (vec_ok) {
+                if (p.bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += p.bias[c + j];
+                }
+                if (rin) {
+                    float rr[4];
+                    ld4(rin + off, rr);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += rr[j];
+                }
+                if (p.y2) st4(reinterpret_cast<T*>(p.y2) + (size_t)n * p.OH * p.OW * p.Cout + off, v);
+                if (p.gate_y) {
+                    const size_t goff = (size_t)n * p.OH * p.OW * p.Cout + off;
+                    const int gi = (n / (p.N / p.gate_groups)) * p.Cout + c;
+                    float xv[4];
+                    ld4(reinterpret_cast<const T*>(p.gate_y) + goff, xv);
+                    if (p.gate_out) {
+                        float ov[4];
+                        ld4(reinterpret_cast<const T*>(p.gate_out) + goff, ov);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = ov[j] > 0.f ? v[j] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xh = (xv[j] - p.gate_mean[gi + j]) * p.gate_invstd[gi + j];
+                        ssum[s][j] += v[j];
+                        ssq[s][j] += v[j] * xh;
+                    }
+                    if (wide) st4(reinterpret_cast<T*>(otile + ((RW * wv + r) * TW + pl) * TPITCH) + s * 16 + g * 4, v);
+                    else st4(yout + off, v);
+                    continue;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (p.act == DH_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+                    else if (p.act == DH_ACT_GELU) v[j] = gelu_erf(v[j]);
+                    ssum[s][j] += v[j];
+                    ssq[s][j] += v[j] * v[j];
+                }
+                if (wide) st4(reinterpret_cast<T*>(otile + ((RW * wv + r) * TW + pl) * TPITCH) + s * 16 + g * 4, v);
+                else st4(yout + off, v);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (c + j >= p.Cout) continue;
+                    float t = v[j];
+                    if (p.bias) t += p.bias[c + j];
+                    if (rin) t += ldf(rin + off + j);
+                    if (p.y2) stf(reinterpret_cast<T*>(p.y2) + (size_t)n * p.OH * p.OW * p.Cout + off + j, t);
+                    if (p.act == DH_ACT_RELU) t = fmaxf(t, 0.f);
+                    else if (p.act == DH_ACT_GELU) t = gelu_erf(t);
+                    ssum[s][j] += t;
+                    ssq[s][j] += t * t;
+                    stf(yout + off + j, t);
+                }
+            }
+        }
+    }
+
+    }   // generic epilogue
+    if (p.stats) {
+        // reduce over the 16 pixel lanes of each lane group, then over the 4 waves through LDS
+        float* red = reinterpret_cast<float*>(smem);   // [4 waves][2][NT]; staging LDS is free now
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = row16_sum(ssum[s][j]), b = row16_sum(ssq[s][j]);
+                if (pl == 0) {
+                    red[(wv * 2 + 0) * NT + s * 16 + g * 4 + j] = a;
+                    red[(wv * 2 + 1) * NT + s * 16 + g * 4 + j] = b;
+                }
+            }
+    }
+    if (p.stats || wide) __syncthreads();
+    if (wide) {
+        constexpr int PPR = NT * (int)sizeof(T) / 16;         // 16-byte pieces per pixel
+        for (int i = tid; i < TH * TW * PPR; i += 256) {
+            const int px = i / PPR, q = i - px * PPR;
+            const int oy = oy0 + px / TW, ox = ox0 + px % TW, c = co0 + q * PIECE;
+            if (oy < p.OH && ox < p.OW && oy * p.OW + ox < p.npix && c < p.Cout)
+                *reinterpret_cast<uint4*>(yout + (size_t)(oy * p.OW + ox) * p.Cout + c) =
+                    *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
+        }
+    }
+    if (p.stats) {
+        const float* red = reinterpret_cast<const float*>(smem);
+        if (tid < 2 * NT) {
+            const int which = tid / NT, c = tid - which * NT;
+            const float t = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c] +
+                            red[(2 * 2 + which) * NT + c] + red[(3 * 2 + which) * NT + c];
+            if (co0 + c < p.CoutPad)
+                p.stats[((size_t)which * p.CoutPad + co0 + c) * gridDim.x + blockIdx.x] = t;   // [2][CoutPad][tiles]
+        }
+    }
+}
+
+// rows per wavefront: 16x16-pixel tiles (RW = 4) for 3x3 stride-1 layers with enough tiles to fill the
+// chip -- half the weight staging per FLOP and 8 instead of 6 LDS fragment reads per 16 MFMAs
+static inline int pick_rw(int N, int OH, int OW, int Cin, int ks, int stride) {
+    // (layers with 1-2 channel chunks have nothing to pipeline and prefer more, smaller workgroups)
+    if (ks == 3 && stride == 1 && Cin >= 128 && OH >= 16 && (long)N * dh_cdiv(OH, 16) * dh_cdiv(OW, TW) >= 256) return 4;
+    return 2;
+}
+
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>
+int launch_fast(const ConvArgs& a, hipStream_t st) {
+    constexpr int TH = 4 * RW;
+    constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
+    const size_t staging = (size_t)HH * HWD * HaloLayout<STRIDE>::PITCH + (size_t)KS * KS * NT * WPITCH;
+    const size_t otile = (size_t)4 * 2 * NT * 4 + (size_t)TH * TW * (NT * sizeof(T) + 16);     // epilogue: stats scratch + transposed tile
+    const size_t lds = staging > otile ? staging : otile;
+    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW, DIL, PF, FAST>;
+    static bool attr_done = false;      // once per instantiation (and never inside a graph capture)
+    if (lds > 64 * 1024 && !attr_done) {
+        attr_done = true;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            DH_FAIL("conv_mfma: cannot raise dynamic LDS to %zu", lds);
+        }
+    }
+    dim3 grid(a.N * a.tilesX * a.tilesY, a.CoutPad / NT);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    DH_CHECK_LAUNCH("conv_mfma");
+    return 0;
+}
+
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>
+int launch_pf(const ConvArgs& a, hipStream_t st) {
+    // compact-epilogue instantiation: 16-byte output pieces, no gating / pre-activation copy / GELU
+    const bool fast = (a.Cout % (16 / (int)sizeof(T))) == 0 && !a.gate_y && !a.y2 && a.act != DH_ACT_GELU;
+    if (fast) return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, true>(a, st);
+    return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, false>(a, st);
+}
+
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL>
+int launch_rw(const ConvArgs& a, hipStream_t st) {
+    constexpr int CK = 64 / (int)sizeof(T);
+    if constexpr (RW == 2 && KS == 3 && DIL == 1) {
+        if (a.Cin <= 2 * CK) return launch_pf<T, KS, STRIDE, NT, RW, DIL, false>(a, st);
+    }
+    return launch_pf<T, KS, STRIDE, NT, RW, DIL, true>(a, st);
+}
+
+template <typename T, int KS, int STRIDE, int NT>
+int launch(const ConvArgs& a, hipStream_t st) {
+    if constexpr (KS == 3 && STRIDE == 1) {
+        if (a.dil == 2) return a.rw == 4 ? launch_rw<T, KS, STRIDE, NT, 4, 2>(a, st) : launch_rw<T, KS, STRIDE, NT, 2, 2>(a, st);
+        if (a.rw == 4) return launch_rw<T, KS, STRIDE, NT, 4, 1>(a, st);
+    }
+    return launch_rw<T, KS, STRIDE, NT, 2, 1>(a, st);
+}
+
+template <typename T, int KS, int STRIDE>
+int launch_nt(const ConvArgs& a, hipStream_t st) {
+    if (a.CoutPad % 64 == 0 && !(getenv("DH_NT32") && a.Cin <= 64 && KS == 3)) return launch<T, KS, STRIDE, 64>(a, st);
+    if (a.CoutPad % 32 == 0) return launch<T, KS, STRIDE, 32>(a, st);
+    return launch<T, KS, STRIDE, 16>(a, st);
+}
+
+template <typename T>
+int launch_ks(const ConvArgs& a, int ks, int stride, hipStream_t st) {
+    if (ks == 3 && stride == 1) return launch_nt<T, 3, 1>(a, st);
+    if (ks == 3 && stride == 2) return launch_nt<T, 3, 2>(a, st);
+    if (ks == 1 && stride == 1) return launch_nt<T, 1, 1>(a, st);
+    if (ks == 1 && stride == 2) return launch_nt<T, 1, 2>(a, st);
+    if (ks == 4 && stride == 1) return launch_nt<T, 4, 1>(a, st);     // space-to-depth stem
+    DH_FAIL("conv_mfma: unsupported kernel %dx%d stride %d", ks, ks, stride);
+}
+
+}  // namespace

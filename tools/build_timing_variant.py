@@ -3,7 +3,7 @@
 (experiment only; tools/conv_timeline.py reads them).  The product library is untouched."""
 import os, subprocess, glob
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-s = open(os.path.join(R, "dahitra_amd/csrc/conv_mfma.hip")).read()
+s = open(os.path.join(R, "dahitra_amd/csrc/conv_mfma_impl.h")).read()
 def rep(old, new):
     global s
     assert s.count(old) == 1, old
@@ -44,11 +44,18 @@ rep('''                p.stats[((size_t)which * p.CoutPad + co0 + c) * gridDim.x
 extern "C" int dh_debug_ts(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ts), (size_t)n * 8); }
 extern "C" int dh_debug_clear() { static long long z[8192 * 16]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ts), z, sizeof(z)); }
 ''')
-os.makedirs(os.path.join(R, "build/exp"), exist_ok=True)
-src = os.path.join(R, "build/exp/conv_timing.hip")
-open(src, "w").write(s)
+# the stamped kernel is the header; the read-back entry points go into the bf16 translation unit (its copy of g_ts)
+dbg = "\n".join(l for l in s.split("\n") if l.startswith('extern "C" int dh_debug_'))
+s = "\n".join(l for l in s.split("\n") if not l.startswith('extern "C" int dh_debug_'))
+E = os.path.join(R, "build/exp")
+os.makedirs(E, exist_ok=True)
+open(os.path.join(E, "conv_mfma_impl.h"), "w").write(s)
+import shutil
+shutil.copy(os.path.join(R, "dahitra_amd/csrc/conv_mfma_bf16.hip"), os.path.join(E, "conv_mfma_bf16.hip"))
+open(os.path.join(E, "conv_mfma_bf16.hip"), "a").write("\n" + dbg)
 flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(R, "include"), "-I" + os.path.join(R, "dahitra_amd/csrc"), "-Wno-unused-result"]
-subprocess.check_call(["hipcc"] + flags + ["-c", src, "-o", os.path.join(R, "build/exp/conv_TIMING.o")])
-objs = [o for o in glob.glob(os.path.join(R, "build/obj/*.o")) if not o.endswith("conv_mfma.o")]
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(R, "build/exp/lib_TIMING.so"), os.path.join(R, "build/exp/conv_TIMING.o")] + objs)
+o = os.path.join(E, "conv_mfma_bf16_T.o")
+subprocess.check_call(["hipcc"] + flags + ["-c", os.path.join(E, "conv_mfma_bf16.hip"), "-o", o])
+others = [x for x in glob.glob(os.path.join(R, "build/obj/*.o")) if os.path.basename(x) != "conv_mfma_bf16.o"]
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(R, "build/exp/lib_TIMING.so"), o] + others)
 print("built build/exp/lib_TIMING.so")
