@@ -131,7 +131,9 @@ def main():
             with torch.no_grad():
                 return net(x6) if xbd_mode else net(a, b)
         if graphed is not None and ops.PROFILE is None:
-            return graphed(x6, msk) if xbd_mode else graphed(a, b, lab)      # inputs already resident
+            # the synthetic batch already sits in the graph's static input buffers (where a loader's host-to-device
+            # copy would land it): replay without the device-to-device staging copy
+            return graphed()
         if xbd_mode:                                         # xBD_code/train.py:331-374
             net.zero_grad()
             loss = xbd.xbd_loss(net(x6), msk)
