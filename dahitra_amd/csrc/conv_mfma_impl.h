@@ -130,30 +130,38 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     // registers before the MFMAs of chunk c and committed to LDS after them (latency hides under matrix work).
     constexpr int NHV = (HH * HWD * 4 + 255) / 256, NWV = (TAPS * NT * 4 + 255) / 256;
     uint4 rh[NHV], rw[NWV];
+    // Address generation is branch-free with 32-bit offsets from the (uniform) image / weight base: at two waves per
+    // SIMD the prologue runs as one dependent instruction chain (~10 cycles per instruction), so its length is time.
+    // An out-of-image halo piece loads offset 0 (always mapped) and is zeroed by a select.
+    unsigned hoff[NHV];      // ~0u: piece outside the image (or past the tile)
+#pragma unroll
+    for (int i = 0; i < NHV; ++i) {
+        const int idx = tid + i * 256, px = idx >> 2, q = idx & 3;
+        const int hy = px / HWD, hx = px - hy * HWD;
+        const int iy = iy0 + hy, ix = ix0 + hx, lin = iy * p.W + ix;
+        const bool ok = idx < HH * HWD * 4 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && lin < p.in_npix;
+        hoff[i] = ok ? (unsigned)(lin * p.Cin) * (unsigned)sizeof(T) + q * 16 : ~0u;
+    }
+    // weight piece i of a thread is row tid/4 + 64*i of the [TAPS*NT] staged rows: tap advances by 64/NT per piece,
+    // the output channel stays -- one per-lane offset plus a uniform step
+    static_assert(64 % NT == 0, "weight staging assumes NT divides 64");
+    const int wrow = tid >> 2;
+    const unsigned woff0 = (unsigned)(((wrow / NT) * p.CoutPad + co0 + (wrow % NT)) * p.Cin) * (unsigned)sizeof(T) + (tid & 3) * 16;
+    const unsigned wstep = (unsigned)((64 / NT) * p.CoutPad * p.Cin) * (unsigned)sizeof(T);
     auto fetch = [&](int c0) {
+        const unsigned char* xb = xin + (size_t)c0 * sizeof(T);
+        const unsigned char* wb = wgt + (size_t)c0 * sizeof(T);
 #pragma unroll
         for (int i = 0; i < NHV; ++i) {
-            const int idx = tid + i * 256;
-            rh[i] = make_uint4(0, 0, 0, 0);
-            if (idx < HH * HWD * 4) {
-                const int px = idx >> 2, q = idx & 3;
-                const int hy = px / HWD, hx = px - hy * HWD;
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && iy * p.W + ix < p.in_npix)
-                    rh[i] = *reinterpret_cast<const uint4*>(
-                        xin + ((size_t)(iy * p.W + ix) * p.Cin + c0) * sizeof(T) + q * 16);
-            }
+            const bool ok = hoff[i] != ~0u;
+            const uint4 v = *reinterpret_cast<const uint4*>(xb + (ok ? hoff[i] : 0u));
+            rh[i] = ok ? v : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
-            const int idx = tid + i * 256;
-            rw[i] = make_uint4(0, 0, 0, 0);
-            if (idx < TAPS * NT * 4) {
-                const int row = idx >> 2, q = idx & 3;
-                const int tap = row / NT, co = row - tap * NT;
-                rw[i] = *reinterpret_cast<const uint4*>(
-                    wgt + ((size_t)(tap * p.CoutPad + co0 + co) * p.Cin + c0) * sizeof(T) + q * 16);
-            }
+            const bool ok = tid + i * 256 < TAPS * NT * 4;          // only the last piece can be partial
+            const uint4 v = *reinterpret_cast<const uint4*>(wb + (size_t)i * wstep + (ok ? woff0 : 0u));
+            rw[i] = ok ? v : make_uint4(0, 0, 0, 0);
         }
     };
     auto commit = [&]() {

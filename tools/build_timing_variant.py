@@ -10,9 +10,24 @@ def rep(old, new):
     s = s.replace(old, new, 1)
 rep("template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>\n__global__",
     '''__device__ long long g_ts[8192 * 16];
+__device__ long long g_ld[8192 * 16];
 #define TS(k) do { if (tid == 0 && blockIdx.x + blockIdx.y * gridDim.x < 8192) g_ts[(blockIdx.x + blockIdx.y * gridDim.x) * 16 + (k)] = (long long)wall_clock64(); } while (0)
 template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>
 __global__''')
+rep("""                    rh[i] = *reinterpret_cast<const uint4*>(
+                        xin + ((size_t)(iy * p.W + ix) * p.Cin + c0) * sizeof(T) + q * 16);
+            }
+        }""", """                    rh[i] = *reinterpret_cast<const uint4*>(
+                        xin + ((size_t)(iy * p.W + ix) * p.Cin + c0) * sizeof(T) + q * 16);
+            }
+            if (c0 == 0 && tid == 0 && blockIdx.x + blockIdx.y * gridDim.x < 8192) g_ld[(blockIdx.x + blockIdx.y * gridDim.x) * 16 + i] = (long long)wall_clock64();
+        }""")
+rep("""                rw[i] = *reinterpret_cast<const uint4*>(
+                    wgt + ((size_t)(tap * p.CoutPad + co0 + co) * p.Cin + c0) * sizeof(T) + q * 16);
+            }""", """                rw[i] = *reinterpret_cast<const uint4*>(
+                    wgt + ((size_t)(tap * p.CoutPad + co0 + co) * p.Cin + c0) * sizeof(T) + q * 16);
+            }
+            if (c0 == 0 && tid == 0 && blockIdx.x + blockIdx.y * gridDim.x < 8192) g_ld[(blockIdx.x + blockIdx.y * gridDim.x) * 16 + NHV + i] = (long long)wall_clock64();""")
 rep("    if (PF) fetch(0);\n    for (int c0 = 0; c0 < p.Cin; c0 += CK) {\n        if (!PF) fetch(c0);\n        commit();\n        __syncthreads();\n",
     '''    TS(0);
     if (PF) fetch(0);
@@ -42,6 +57,7 @@ rep('''                p.stats[((size_t)which * p.CoutPad + co0 + c) * gridDim.x
     TS(12);
 }
 extern "C" int dh_debug_ts(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ts), (size_t)n * 8); }
+extern "C" int dh_debug_ld(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ld), (size_t)n * 8); }
 extern "C" int dh_debug_clear() { static long long z[8192 * 16]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ts), z, sizeof(z)); }
 ''')
 # the stamped kernel is the header; the read-back entry points go into the bf16 translation unit (its copy of g_ts)

@@ -41,6 +41,12 @@ for name, (N, H, W, Cin, Cout) in SHAPES.items():
             print("   %-12s (%4d wgs): fetch0 %.2f  commit-wait %.2f  mfma0 %.2f  epi-regs %.2f  epi-total %.2f  lifetime %.2f us" % (
                 nm, sel.sum(), d[sel, 0].mean(), d[sel, 1].mean(), d[sel, 3].mean(), d[sel, 6].mean(),
                 (rel[sel, 12] - rel[sel, 6]).mean(), (rel[sel, 12] - rel[sel, 0]).mean()))
+    lb = np.zeros(8192 * 16, dtype=np.int64)
+    lib.dh_debug_ld(lb.ctypes.data_as(ctypes.c_void_p), lb.size)
+    ld = lb.reshape(8192, 16)[used]
+    nl = int((ld[0] > 0).sum())
+    stamps = np.concatenate([ts[:, 0:1], ld[:, :nl]], axis=1)
+    print("   first fetch, us between consecutive load issues:", " ".join("%.2f" % v for v in (np.diff(stamps, axis=1) / 100.0).mean(axis=0)))
     life = rel[:, 12] - rel[:, 0]
     print("   lifetime mean %.2f us; start times: p50 %.1f p90 %.1f max %.1f" % (life.mean(), np.median(rel[:, 0]), np.quantile(rel[:, 0], 0.9), rel[:, 0].max()))
     # concurrent workgroups: sample at the median time
