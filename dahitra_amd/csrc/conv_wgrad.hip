@@ -87,19 +87,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
     // its element offset from the tile origin and how it is loaded (0: zeros, 1: one 16-byte load, 2: ragged channel
     // tail).  Per tile only the scalar tile origin and the border tests remain (no divisions by runtime tile counts,
     // no 64-bit products per piece).
-    int x_hy[NXV], x_hx[NXV], x_rel[NXV], x_mode[NXV];
-    int d_py[NDV], d_px[NDV], d_rel[NDV], d_mode[NDV];
+    int x_hy[NXV], x_hx[NXV], x_mode[NXV];
+    int d_py[NDV], d_px[NDV], d_mode[NDV];
     constexpr int EPV = 16 / (int)sizeof(T);
+    const bool xal_ = ((p.Cin * (int)sizeof(T)) & 15) == 0 && ((p.CinPitch * (int)sizeof(T)) & 15) == 0;
+    const bool dal_ = ((p.Cout * (int)sizeof(T)) & 15) == 0;
     {
-        const bool xal = ((p.Cin * (int)sizeof(T)) & 15) == 0, dal = ((p.Cout * (int)sizeof(T)) & 15) == 0;
 #pragma unroll
         for (int i = 0; i < NXV; ++i) {
             const int idx = tid + i * 256;
             const int px = idx / XQ, q = idx % XQ;
             x_hy[i] = px / HWD; x_hx[i] = px % HWD;
             const int c = ci0 + q * EPV;
-            x_rel[i] = (x_hy[i] * p.W + x_hx[i]) * p.CinPitch + c;
-            x_mode[i] = (idx >= HH * HWD * XQ || c >= p.Cin) ? 0 : ((xal && c + EPV <= p.Cin) ? 1 : 2);
+            x_mode[i] = (idx >= HH * HWD * XQ || c >= p.Cin) ? 0 : ((xal_ && c + EPV <= p.Cin) ? 1 : 2);
         }
 #pragma unroll
         for (int i = 0; i < NDV; ++i) {
@@ -107,8 +107,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
             const int px = idx / DQ, q = idx % DQ;
             d_py[i] = px / TW; d_px[i] = px % TW;
             const int c = co0 + q * EPV;
-            d_rel[i] = (d_py[i] * p.OW + d_px[i]) * p.Cout + c;
-            d_mode[i] = (idx >= TH * TW * DQ || c >= p.Cout) ? 0 : ((dal && c + EPV <= p.Cout) ? 1 : 2);
+            d_mode[i] = (idx >= TH * TW * DQ || c >= p.Cout) ? 0 : ((dal_ && c + EPV <= p.Cout) ? 1 : 2);
         }
     }
     // ragged channel tail of one piece: element loads, zeros past `nvalid` elements
@@ -125,32 +124,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
     const int dn = p.splitk / tiles_per_img, drem = p.splitk % tiles_per_img;
     const int dty = drem / p.tilesX, dtx = drem % p.tilesX;
     int f_n = kz / tiles_per_img, f_ty = (kz % tiles_per_img) / p.tilesX, f_tx = (kz % tiles_per_img) % p.tilesX;
+    // Common case (16-byte aligned channel counts, no ragged channel tail in this workgroup's slab): branch-free loads
+    // at 32-bit byte offsets from the image base -- an out-of-range piece reads offset 0 and is zeroed by a select.
+    // At two to three waves per SIMD this per-tile code is one dependent chain, so its length is time.
+    const int xcb = (ci0 + (tid % XQ) * EPV), dcb = (co0 + (tid % DQ) * EPV);            // channel of this thread's pieces
+    const bool fast = xal_ && dal_ && (ci0 + IT <= p.Cin || (p.Cin - ci0) % EPV == 0) &&
+                      (co0 + CT <= p.Cout || (p.Cout - co0) % EPV == 0);
     auto fetch = [&]() {      // loads the tile the counter points at, then advances the counter
         const int n = grp * imgs_per_group + f_n;
         const int oy0 = f_ty * TH, ox0 = f_tx * TW;
         const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
-        const T* xin = reinterpret_cast<const T*>(p.x) + (size_t)n * p.H * p.W * p.CinPitch +
-                       ((long)iy0 * p.W + ix0) * p.CinPitch;
-        const T* dyin = reinterpret_cast<const T*>(p.dy) + (size_t)n * p.OH * p.OW * p.Cout +
-                        ((long)oy0 * p.OW + ox0) * p.Cout;
+        if (fast) {
+            const unsigned char* xb = reinterpret_cast<const unsigned char*>(
+                reinterpret_cast<const T*>(p.x) + (size_t)n * p.H * p.W * p.CinPitch);
+            const unsigned char* db = reinterpret_cast<const unsigned char*>(
+                reinterpret_cast<const T*>(p.dy) + (size_t)n * p.OH * p.OW * p.Cout);
+            const unsigned xps = (unsigned)p.CinPitch * (unsigned)sizeof(T), dps = (unsigned)p.Cout * (unsigned)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < NXV; ++i) {
-            rx[i] = make_uint4(0, 0, 0, 0);
-            const int iy = iy0 + x_hy[i], ix = ix0 + x_hx[i];
-            const bool ok = x_mode[i] != 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && iy * p.W + ix < p.in_npix;
-            if (ok) {
-                if (x_mode[i] == 1) rx[i] = *reinterpret_cast<const uint4*>(xin + x_rel[i]);
-                else rx[i] = load_tail(xin + x_rel[i], p.Cin - (ci0 + ((tid + i * 256) % XQ) * EPV));
+            for (int i = 0; i < NXV; ++i) {
+                const int iy = iy0 + x_hy[i], ix = ix0 + x_hx[i], lin = iy * p.W + ix;
+                const bool ok = x_mode[i] != 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && lin < p.in_npix;
+                const uint4 v = *reinterpret_cast<const uint4*>(xb + (ok ? (unsigned)lin * xps + (unsigned)xcb * (unsigned)sizeof(T) : 0u));
+                rx[i] = ok ? v : make_uint4(0, 0, 0, 0);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < NDV; ++i) {
-            rd[i] = make_uint4(0, 0, 0, 0);
-            const int oy = oy0 + d_py[i], ox = ox0 + d_px[i];
-            const bool ok = d_mode[i] != 0 && oy < p.OH && ox < p.OW && oy * p.OW + ox < p.npix;
-            if (ok) {
-                if (d_mode[i] == 1) rd[i] = *reinterpret_cast<const uint4*>(dyin + d_rel[i]);
-                else rd[i] = load_tail(dyin + d_rel[i], p.Cout - (co0 + ((tid + i * 256) % DQ) * EPV));
+            for (int i = 0; i < NDV; ++i) {
+                const int oy = oy0 + d_py[i], ox = ox0 + d_px[i], lin = oy * p.OW + ox;
+                const bool ok = d_mode[i] != 0 && oy < p.OH && ox < p.OW && lin < p.npix;
+                const uint4 v = *reinterpret_cast<const uint4*>(db + (ok ? (unsigned)lin * dps + (unsigned)dcb * (unsigned)sizeof(T) : 0u));
+                rd[i] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            const T* xin = reinterpret_cast<const T*>(p.x) + (size_t)n * p.H * p.W * p.CinPitch +
+                           ((long)iy0 * p.W + ix0) * p.CinPitch;
+            const T* dyin = reinterpret_cast<const T*>(p.dy) + (size_t)n * p.OH * p.OW * p.Cout +
+                            ((long)oy0 * p.OW + ox0) * p.Cout;
+#pragma unroll
+            for (int i = 0; i < NXV; ++i) {
+                rx[i] = make_uint4(0, 0, 0, 0);
+                const int iy = iy0 + x_hy[i], ix = ix0 + x_hx[i];
+                const bool ok = x_mode[i] != 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && iy * p.W + ix < p.in_npix;
+                if (ok) {
+                    const T* src = xin + (x_hy[i] * p.W + x_hx[i]) * p.CinPitch + xcb;
+                    if (x_mode[i] == 1) rx[i] = *reinterpret_cast<const uint4*>(src);
+                    else rx[i] = load_tail(src, p.Cin - xcb);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NDV; ++i) {
+                rd[i] = make_uint4(0, 0, 0, 0);
+                const int oy = oy0 + d_py[i], ox = ox0 + d_px[i];
+                const bool ok = d_mode[i] != 0 && oy < p.OH && ox < p.OW && oy * p.OW + ox < p.npix;
+                if (ok) {
+                    const T* src = dyin + (d_py[i] * p.OW + d_px[i]) * p.Cout + dcb;
+                    if (d_mode[i] == 1) rd[i] = *reinterpret_cast<const uint4*>(src);
+                    else rd[i] = load_tail(src, p.Cout - dcb);
+                }
             }
         }
         f_tx += dtx;
