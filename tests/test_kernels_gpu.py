@@ -79,6 +79,45 @@ def test_conv2d_fwd(ops, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("want_stats", [False, True])
+@pytest.mark.parametrize("cfg", [
+    dict(ks=3, stride=1, pad=1, cin=64, cout=64, h=32, w=32),       # tiles fully inside the image (unmasked statistics)
+    dict(ks=3, stride=1, pad=1, cin=64, cout=64, h=24, w=40),       # ragged: masked statistics, partial stores
+    dict(ks=3, stride=1, pad=1, cin=256, cout=256, h=32, w=32),     # 16-row tiles
+    dict(ks=3, stride=1, pad=1, cin=128, cout=128, h=20, w=24),     # 16-row tiles, ragged
+    dict(ks=3, stride=2, pad=1, cin=64, cout=128, h=32, w=32),
+    dict(ks=1, stride=1, pad=0, cin=128, cout=32, h=16, w=16),      # 32-channel tile
+    dict(ks=3, stride=1, pad=1, cin=32, cout=16, h=16, w=20),       # 16-channel tile
+])
+def test_conv2d_fwd_compact_epilogue(ops, dtype, cfg, want_stats, relu):
+    """the host-selected compact-epilogue instantiation of conv_mfma_kernel (no pre-activation copy, no gating, no
+    GELU, Cout a multiple of the 16-byte piece): bias, residual, optional ReLU, optional statistics, LDS-transposed
+    16-byte stores -- every straight-line variant of it"""
+    N = 2
+    x = rnd((N, cfg["cin"], cfg["h"], cfg["w"]), dtype, 11)
+    w = rnd((cfg["cout"], cfg["cin"], cfg["ks"], cfg["ks"]), dtype, 12, scale=(cfg["cin"] * cfg["ks"] ** 2) ** -0.5)
+    b = rnd((cfg["cout"],), torch.float32, 13, 0.1)
+    pre = F.conv2d(x, w, b, cfg["stride"], cfg["pad"])
+    r = rnd(tuple(pre.shape), dtype, 14)
+    want = pre + r
+    if relu:
+        want = F.relu(want)
+    wp, _ = ops.pack_weight(w.cuda(), dtype, want_dgrad=False)
+    out = ops.conv2d(dev(nhwc(x), dtype), wp, cfg["cout"], cfg["ks"], cfg["stride"], cfg["pad"], bias=b.cuda(),
+                     residual=dev(nhwc(r), dtype), act=ops.ACT_RELU if relu else ops.ACT_NONE, want_stats=want_stats)
+    y = out[0] if want_stats else out
+    close(nchw(y), want, dtype, "conv2d out (compact epilogue)")
+    if want_stats:
+        tot = out[1].sum(2).cpu()
+        close(tot[0, :cfg["cout"]], want.sum((0, 2, 3)), dtype, "stats sum", scale=float(want.abs().sum((0, 2, 3)).max()))
+        close(tot[1, :cfg["cout"]], (want * want).sum((0, 2, 3)), dtype, "stats sumsq")
+    # and without bias / residual
+    y2 = ops.conv2d(dev(nhwc(x), dtype), wp, cfg["cout"], cfg["ks"], cfg["stride"], cfg["pad"])
+    close(nchw(y2), F.conv2d(x, w, None, cfg["stride"], cfg["pad"]), dtype, "conv2d out (plain)")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [
     dict(ks=3, stride=1, pad=1, cin=64, cout=64, h=24, w=24),
     dict(ks=3, stride=2, pad=1, cin=64, cout=128, h=32, w=32),
