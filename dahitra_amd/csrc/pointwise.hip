@@ -220,35 +220,57 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
 }
 // gather form with the saved window arg-max (row-major scan, strict >, as ATen's CPU kernel): an input pixel
 // receives dy of each of the <= 4 windows covering it whose arg-max it is.  Deterministic, no atomics.
+// One thread owns the 2x2 input pixels (2*oy + a, 2*ox + b) of a 16-byte channel piece: the four windows
+// (oy..oy+1, ox..ox+1) cover them all, so every window's (arg, dy) piece is loaded once per 4 outputs instead of
+// once per output; contributions are added in the same order as the per-pixel gather (window row, then column).
 template <typename T>
 __global__ void maxpool_bwd_kernel(const unsigned char* __restrict__ arg, const T* __restrict__ dy, T* __restrict__ dx,
                                    int N, int H, int W, int C, int OH, int OW) {
     constexpr int V = V16<T>::N;
-    const int vn = C / V;
-    GSL(i, (long)N * H * W * vn) {
+    const int vn = C / V, BH = (H + 1) / 2, BW = (W + 1) / 2;      // 2x2 input blocks
+    GSL(i, (long)N * BH * BW * vn) {
         const int c = (int)(i % vn) * V;
         long t = i / vn;
-        const int ix = (int)(t % W); t /= W;
-        const int iy = (int)(t % H);
-        const long n = t / H;
-        float g[V];
+        const int bx = (int)(t % BW); t /= BW;
+        const int by = (int)(t % BH);
+        const long n = t / BH;
+        unsigned long long bits[2][2];
+        float d[2][2][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) g[j] = 0.f;
-        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {   // windows with 2*oy-1 <= iy <= 2*oy+1
-            if (oy >= OH) continue;
-            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
-                if (ox >= OW) continue;
-                const unsigned kk = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
-                const long o = ((n * OH + oy) * OW + ox) * C + c;
-                const unsigned long long bits = ld_bytes<V>(arg + o);
-                float d[V];
-                ldv(dy + o, d);
+        for (int wy = 0; wy < 2; ++wy)
 #pragma unroll
-                for (int j = 0; j < V; ++j)
-                    if (((bits >> (8 * j)) & 0xff) == kk) g[j] += d[j];
+            for (int wx = 0; wx < 2; ++wx) {
+                const int oy = by + wy, ox = bx + wx;
+                bits[wy][wx] = ~0ull;                        // no window: matches no tap index
+#pragma unroll
+                for (int j = 0; j < V; ++j) d[wy][wx][j] = 0.f;
+                if (oy < OH && ox < OW) {
+                    const long o = ((n * OH + oy) * OW + ox) * C + c;
+                    bits[wy][wx] = ld_bytes<V>(arg + o);
+                    ldv(dy + o, d[wy][wx]);
+                }
             }
-        }
-        stv(dx + i * V, g);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int iy = 2 * by + a, ix = 2 * bx + b;
+                if (iy >= H || ix >= W) continue;
+                float g[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) g[j] = 0.f;
+                // windows oy in {iy/2, (iy+1)/2} = {by, by + a}, ox likewise: tap index of this pixel inside each
+#pragma unroll
+                for (int wy = 0; wy <= a; ++wy)
+#pragma unroll
+                    for (int wx = 0; wx <= b; ++wx) {
+                        const unsigned kk = (a + 1 - 2 * wy) * 3 + (b + 1 - 2 * wx);
+#pragma unroll
+                        for (int j = 0; j < V; ++j)
+                            if (((bits[wy][wx] >> (8 * j)) & 0xff) == kk) g[j] += d[wy][wx][j];
+                    }
+                stv(dx + (((n * H + iy) * W + ix) * C + c), g);
+            }
     }
 }
 
@@ -668,7 +690,7 @@ extern "C" int dh_maxpool3x3s2_bwd(int dtype, const unsigned char* argmax, const
     const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;
     DH_REQUIRE(C % V == 0, "maxpool: C=%d must be a multiple of %d", C, V);
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    const long n = (long)N * H * W * (C / V);
+    const long n = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / V);      // one thread per 2x2 input block piece
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), argmax, (const bf16*)dy, (bf16*)dx, N, H, W, C, OH, OW);
     else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), argmax, (const float*)dy, (float*)dx, N, H, W, C, OH, OW);
     DH_CHECK_LAUNCH("maxpool_bwd");
