@@ -330,16 +330,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
     }
 }
 
-// dw_oihw[g][o][i][tap] (+)= sum_kz part[g][kz][tap][o][i]      (blockIdx.y = group)
-__global__ void wgrad_reduce_oihw_kernel(const float* __restrict__ part, int splitk, int taps, int Oslab, int O, int I,
-                                         float* __restrict__ dw, int accumulate) {
+// dw_oihw[g][o][i][tap] (+)= sum_kz part[g][kz][tap][o][i]: 32 consecutive outputs of one group per workgroup
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ part, int splitk, int taps, int Oslab, int O,
+                                                   int I, float* __restrict__ dw, int accumulate, long block, float (*red)[33]) {
     // 256 threads = 8 split-K phases x 32 consecutive outputs
-    __shared__ float red[8][33];
     const long n = (long)O * I * taps;
     const int lane = threadIdx.x & 31, ph = threadIdx.x >> 5;
-    const long i = (long)blockIdx.x * 32 + lane;
-    part += (size_t)blockIdx.y * splitk * taps * Oslab * I;
-    dw += (size_t)blockIdx.y * n;
+    const long i = block * 32 + lane;
     float acc = 0.f;
     // lanes walk the SLAB order (tap, o, ci) so the splitk reads are coalesced; the single OIHW write scatters
     int tap = 0, ci = 0, o = 0;
@@ -370,6 +367,28 @@ __global__ void wgrad_reduce_oihw_kernel(const float* __restrict__ part, int spl
         const size_t d = ((size_t)o * I + ci) * taps + tap;
         if (accumulate) dw[d] += s; else dw[d] = s;
     }
+}
+__global__ void wgrad_reduce_oihw_kernel(const float* __restrict__ part, int splitk, int taps, int Oslab, int O, int I,
+                                         float* __restrict__ dw, int accumulate) {      // blockIdx.y = group
+    __shared__ float red[8][33];
+    const long n = (long)O * I * taps;
+    wgrad_reduce_block(part + (size_t)blockIdx.y * splitk * taps * Oslab * I, splitk, taps, Oslab, O, I,
+                       dw + (size_t)blockIdx.y * n, accumulate, blockIdx.x, red);
+}
+// every deferred split-K reduce of a backward pass in ONE launch (dh_wgrad_reduce_multi): record k is served by
+// workgroups [first_block, first_block + nblocks)
+struct WgReduceJob {
+    const float* part;
+    float* dw;
+    int splitk, taps, Oslab, O, I, accumulate, first_block, nblocks;
+};
+__global__ void wgrad_reduce_multi_kernel(const WgReduceJob* __restrict__ jobs, int njobs) {
+    __shared__ float red[8][33];
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
+    const WgReduceJob job = jobs[j];
+    wgrad_reduce_block(job.part, job.splitk, job.taps, job.Oslab, job.O, job.I, job.dw, job.accumulate,
+                       (long)blockIdx.x - job.first_block, red);
 }
 
 template <typename T, int KS, int STRIDE, int IT, int DIL, int CT>
@@ -445,10 +464,11 @@ extern "C" long dh_conv2d_wgrad_workspace_size(int N, int OH, int OW, int Cin, i
 
 // x: [N,H,W,Cin], dy: [N,OH,OW,Cout]; groups == 1: dw_oihw (+)= gradient in torch OIHW layout;
 // groups == N : dw_oihw is [N][Cout][Cin] (ks must be 1) -- one gradient per image.
-extern "C" int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N,
-                               int H, int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad,
-                               int groups, int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation,
-                               void* workspace, void* stream) {
+// defer != 0: only the partial slabs are written; returns the split-K factor (0: the result went straight into dW)
+static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N,
+                             int H, int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad,
+                             int groups, int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation,
+                             void* workspace, void* stream, int defer, int* splitk_out) {
     DH_REQUIRE(groups == 1 || (groups == N && ks == 1), "conv2d_wgrad: groups must be 1 or N (with ks=1)");
     WgArgs a;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
@@ -468,12 +488,40 @@ extern "C" int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* 
     int rc = dtype == DH_DTYPE_BF16 ? launch_all<bf16>(a, ks, stride, use_tr != 0, st)
                                     : launch_all<float>(a, ks, stride, false, st);
     if (rc) return rc;
-    if (a.direct) return 0;
+    if (splitk_out) *splitk_out = a.direct ? 0 : a.splitk;
+    if (a.direct || defer) return 0;
     const int taps = ks * ks;
     const int oreal = Cout_real > 0 ? Cout_real : Cout;     // dy may carry zero-padded channels
     const long n = (long)oreal * Cin * taps;
     hipLaunchKernelGGL(wgrad_reduce_oihw_kernel, dim3(dh_cdiv(n, 32), groups), dim3(256), 0, st, a.part, a.splitk,
                        taps, Cout, oreal, Cin, dw_oihw, accumulate);
     DH_CHECK_LAUNCH("wgrad_reduce");
+    return 0;
+}
+
+extern "C" int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N,
+                               int H, int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad,
+                               int groups, int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation,
+                               void* workspace, void* stream) {
+    return conv2d_wgrad_impl(dtype, x, dy, dw_oihw, accumulate, N, H, W, Cin, OH, OW, Cout, ks, stride, pad, groups,
+                             npix_valid, use_tr, Cout_real, cin_pitch, dilation, workspace, stream, 0, nullptr);
+}
+
+// The same launch without its reduce: the partial slabs stay in `workspace` (which must then outlive the batched
+// reduce) and *splitk_out receives the number of slabs; 0 means the single-slab 1x1 case already wrote dW.
+extern "C" int dh_conv2d_wgrad_partial(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N,
+                                       int H, int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad,
+                                       int groups, int npix_valid, int use_tr, int Cout_real, int cin_pitch,
+                                       int dilation, void* workspace, int* splitk_out, void* stream) {
+    DH_REQUIRE(groups == 1 && splitk_out, "conv2d_wgrad_partial: one group only");
+    return conv2d_wgrad_impl(dtype, x, dy, dw_oihw, accumulate, N, H, W, Cin, OH, OW, Cout, ks, stride, pad, groups,
+                             npix_valid, use_tr, Cout_real, cin_pitch, dilation, workspace, stream, 1, splitk_out);
+}
+extern "C" int dh_wgrad_reduce_job_size(void) { return (int)sizeof(WgReduceJob); }
+extern "C" int dh_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream) {
+    if (njobs <= 0) return 0;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const WgReduceJob*>(jobs_dev), njobs);
+    DH_CHECK_LAUNCH("wgrad_reduce_multi");
     return 0;
 }

@@ -58,6 +58,7 @@ class Engine:
         self.need_grad = False
         self._bwd = None
         self._plans = {}
+        self._wgrad_plan = None
 
     # ---- binding ---------------------------------------------------------------------------------
     def bind(self, params, grads):
@@ -554,7 +555,11 @@ class Engine:
         if self._bwd is None:
             raise RuntimeError("dahitra_amd: backward called without a grad-enabled forward")
         bwd, self._bwd = self._bwd, None
-        bwd(dlogits_nchw)
+        if self._wgrad_plan is None:
+            self._wgrad_plan = ops.WgradPlan(dlogits_nchw.device)
+        with self._wgrad_plan as plan:      # the conv layers' split-K reduces: one launch at the end of the pass
+            bwd(dlogits_nchw)
+            plan.run()
 
     def _head_out(self, h, wkey, bkey):
         """final 3x3 conv to n_class logits, returned as NCHW fp32 (the reference's output layout)"""

@@ -129,6 +129,69 @@ class PackPlan:
         _call("dh_pack_weights_multi", P(self.table), _ci(len(self.jobs)), _ci(self.blocks), S())
 
 
+class WgradPlan:
+    """The split-K reduces of one backward pass as ONE launch (dh_wgrad_reduce_multi): while a plan is active
+    (`with plan:`), conv2d_wgrad writes its partial slabs into a per-layer persistent workspace and records a job;
+    `run()` sums them all into the gradient arena.  The job table is built on the first pass and reused while the
+    sequence of layers (gradient pointers, shapes, split factors) repeats -- which it does for a fixed network and
+    batch shape, and what makes the table capturable in a HIP graph."""
+
+    class _Job(ctypes.Structure):
+        _fields_ = [("part", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("splitk", ctypes.c_int), ("taps", ctypes.c_int),
+                    ("Oslab", ctypes.c_int), ("O", ctypes.c_int), ("I", ctypes.c_int), ("accumulate", ctypes.c_int),
+                    ("first_block", ctypes.c_int), ("nblocks", ctypes.c_int)]
+
+    def __init__(self, device):
+        self.device, self.slots, self.table, self.sig, self.cur, self.blocks = device, [], None, None, 0, 0
+        self._prev = None
+
+    def __enter__(self):
+        global _WGRAD_PLAN
+        self._prev, _WGRAD_PLAN = _WGRAD_PLAN, self
+        self.cur = 0
+        self.jobs = []
+        self.blocks = 0
+        return self
+
+    def __exit__(self, *exc):
+        global _WGRAD_PLAN
+        _WGRAD_PLAN = self._prev
+        return False
+
+    def slab(self, nbytes):
+        """persistent workspace of the cur-th deferred layer of the pass"""
+        if self.cur == len(self.slots):
+            self.slots.append(torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device))
+        elif self.slots[self.cur].numel() < nbytes:
+            self.slots[self.cur] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self.table = None
+        buf = self.slots[self.cur]
+        self.cur += 1
+        return buf
+
+    def add(self, part, dw, splitk, taps, oslab, o, i, accumulate):
+        nb = cdiv(o * i * taps, 32)
+        self.jobs.append(self._Job(part.data_ptr(), dw.data_ptr(), splitk, taps, oslab, o, i, int(accumulate),
+                                   self.blocks, nb))
+        self.blocks += nb
+
+    def run(self):
+        if not self.jobs:
+            return
+        sig = b"".join(bytes(j) for j in self.jobs)
+        if self.table is None or sig != self.sig:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("dahitra_amd: the weight-gradient plan changed during graph capture; run one eager "
+                                   "step of the same shapes first")
+            assert ctypes.sizeof(self._Job) == _lib.lib().dh_wgrad_reduce_job_size()
+            self.table = torch.frombuffer(bytearray(sig), dtype=torch.uint8).to(self.device)
+            self.sig = sig
+        _call("dh_wgrad_reduce_multi", P(self.table), _ci(len(self.jobs)), _ci(self.blocks), S())
+
+
+_WGRAD_PLAN = None
+
+
 # ---- convolution / linear ------------------------------------------------------------------------
 PROFILE = None       # set to {} by bench.py to collect (events, algorithmic flops, bytes) per conv launch
 
@@ -205,7 +268,8 @@ def linear(x2d, wp, cout, bias=None, residual=None, act=ACT_NONE, want_preact=Fa
     return (y, pre) if want_preact else y
 
 
-def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=True, cout_real=0, cin=0, dilation=1):
+def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=True, cout_real=0, cin=0, dilation=1,
+                 defer=True):
     """dw (OIHW fp32, or [N, Cout, Cin] when groups == N) (+)= weight gradient.
     cin > 0: use only the first `cin` channels of x (x keeps its own channel pitch)."""
     N, H, W, pitch = x.shape
@@ -213,6 +277,17 @@ def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=
     _, OH, OW, Cout = dy.shape
     L = _lib.lib()
     nbytes = L.dh_conv2d_wgrad_workspace_size(N, OH, OW, Cin, Cout, ks, groups)
+    plan = _WGRAD_PLAN
+    if plan is not None and groups == 1 and defer:      # defer=False: the caller reads dw right after this call
+        # deferred: partial slabs into this layer's persistent workspace, summed later by plan.run()
+        ws = plan.slab(nbytes)
+        sk = ctypes.c_int(0)
+        _call("dh_conv2d_wgrad_partial", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W),
+              _ci(Cin), _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(1), _ci(0), _ci(int(use_tr)),
+              _ci(cout_real), _ci(pitch), _ci(dilation), P(ws), ctypes.byref(sk), S())
+        if sk.value > 0:
+            plan.add(ws, dw, sk.value, ks * ks, Cout, cout_real if cout_real else Cout, Cin, accumulate)
+        return
     ws = workspace(nbytes, x.device)
     _call("dh_conv2d_wgrad", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W), _ci(Cin),
           _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(groups), _ci(0), _ci(int(use_tr)),
@@ -263,7 +338,7 @@ def stem_wgrad(x_s2d, dy, dw, accumulate=False, use_tr=True):
     N, H2, W2, cp = x_s2d.shape
     O = dy.shape[-1]
     dw2 = torch.empty(O, 16, 4, 4, dtype=torch.float32, device=dy.device)     # 12 real + 4 zero channels
-    conv2d_wgrad(x_s2d, dy, dw2, ks=4, stride=1, pad=2, use_tr=use_tr, cin=16)
+    conv2d_wgrad(x_s2d, dy, dw2, ks=4, stride=1, pad=2, use_tr=use_tr, cin=16, defer=False)     # dw2 is unpacked next
     _call("dh_stem_unpack_grad", P(dw2), P(dw), _ci(O), _ci(16), _ci(int(accumulate)), S())
 
 
