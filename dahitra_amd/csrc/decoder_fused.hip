@@ -528,8 +528,20 @@ __global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(const float* __re
     const int i = blockIdx.x * 32 + lane;                 // element of the shared-parameter part
     if (blockIdx.y == 0) {
         double s = 0.0;
-        if (i < P::KQ)
-            for (int b = ph; b < nblk; b += 8) s += (double)partial[(size_t)b * P::SIZE + i];
+        if (i < P::KQ) {
+            // four independent partial sums: the loop is otherwise one chain of dependent-latency loads
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            const float* src = partial + i;
+            int b = ph;
+            for (; b + 24 < nblk; b += 32) {
+                s += (double)src[(size_t)b * P::SIZE];
+                s1 += (double)src[(size_t)(b + 8) * P::SIZE];
+                s2 += (double)src[(size_t)(b + 16) * P::SIZE];
+                s3 += (double)src[(size_t)(b + 24) * P::SIZE];
+            }
+            for (; b < nblk; b += 8) s += (double)src[(size_t)b * P::SIZE];
+            s = (s + s1) + (s2 + s3);
+        }
         red[ph][lane] = s;
         __syncthreads();
         if (ph == 0 && i < P::KQ) {
@@ -553,7 +565,9 @@ __global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(const float* __re
         const int e = blockIdx.x * 256 + threadIdx.x;     // element of [dKq | dVoT] (2048)
         if (e < 2048) {
             float s = 0.f;
-            for (int b = 0; b < bpi; ++b) s += partial[(size_t)(img * bpi + b) * P::SIZE + P::KQ + e];
+            const float* src = partial + (size_t)img * bpi * P::SIZE + P::KQ + e;
+#pragma unroll 4
+            for (int b = 0; b < bpi; ++b) s += src[(size_t)b * P::SIZE];       // (order kept: loads issue ahead, adds in order)
             if (e < 1024) dkq[(size_t)img * 1024 + e] = s;
             else dvoT[(size_t)img * 1024 + e - 1024] = s;
         }
