@@ -459,60 +459,55 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecArgs p) {
         __syncthreads();
     }
 
-    // ---- combine the 4 wavefronts deterministically in LDS, then write this workgroup's partial ----
-    float* red = reinterpret_cast<float*>(tiles);            // PL::SIZE floats (fits: checked on the host)
+    // ---- combine the 4 wavefronts deterministically, then write this workgroup's partial ----
+    // Every wave parks its sums in its OWN slot (all four at once; the pixel-lane reductions are DPP row sums) and the
+    // slots are added in wave order.  The former turn-taking read-modify-write of one slot, with 56 ds_bpermute
+    // butterfly chains inside each wave's turn, took 40 of the workgroup's 70 us (tools/dec_timeline.py).
     using P = PL<MLP>;
-    auto put = [&](int idx, float v, bool first) { if (first) red[idx] = v; else red[idx] += v; };
-    for (int w = 0; w < 4; ++w) {
-        if (wv == w) {
-            const bool first = w == 0;
+    float* red = reinterpret_cast<float*>(tiles);            // [4][P::SIZE] floats (host sized the LDS)
+    float* mine = red + (size_t)wv * P::SIZE;
 #pragma unroll
-            for (int sm = 0; sm < NM; ++sm)
+    for (int sm = 0; sm < NM; ++sm)
 #pragma unroll
-                for (int sc = 0; sc < 2; ++sc)
+        for (int sc = 0; sc < 2; ++sc)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        put(P::W1 + (sm * 16 + g * 4 + j) * D + sc * 16 + pl, aW1[sm][sc][j], first);
-                        put(P::W2 + (sc * 16 + g * 4 + j) * MLP + sm * 16 + pl, aW2[sc][sm][j], first);
-                    }
+            for (int j = 0; j < 4; ++j) {
+                mine[P::W1 + (sm * 16 + g * 4 + j) * D + sc * 16 + pl] = aW1[sm][sc][j];
+                mine[P::W2 + (sc * 16 + g * 4 + j) * MLP + sm * 16 + pl] = aW2[sc][sm][j];
+            }
 #pragma unroll
-            for (int sr = 0; sr < 2; ++sr)
+    for (int sr = 0; sr < 2; ++sr)
 #pragma unroll
-                for (int sc = 0; sc < 2; ++sc)
+        for (int sc = 0; sc < 2; ++sc)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        put(P::KQ + (sr * 16 + g * 4 + j) * D + sc * 16 + pl, aKq[sr][sc][j], first);
-                        put(P::VOT + (sr * 16 + g * 4 + j) * 32 + sc * 16 + pl, aVoT[sr][sc][j], first);
-                    }
-            // lane-local column sums: reduce over the 16 pixel lanes first
+            for (int j = 0; j < 4; ++j) {
+                mine[P::KQ + (sr * 16 + g * 4 + j) * D + sc * 16 + pl] = aKq[sr][sc][j];
+                mine[P::VOT + (sr * 16 + g * 4 + j) * 32 + sc * 16 + pl] = aVoT[sr][sc][j];
+            }
+    // lane-local column sums: over the 16 pixel lanes of the row (the same butterfly sums as four xor-shuffles)
 #pragma unroll
-            for (int s = 0; s < NM; ++s)
+    for (int s = 0; s < NM; ++s)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = sb1[s][j];
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                    if (pl == 0) put(P::B1 + s * 16 + g * 4 + j, v, first);
-                }
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v[6] = {sb2[s][j], sbo[s][j], sg1[s][j], sbe1[s][j], sg2[s][j], sbe2[s][j]};
-                    const int off[6] = {P::B2, P::BO, P::G1, P::BE1, P::G2, P::BE2};
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        float t = v[k];
-#pragma unroll
-                        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-                        if (pl == 0) put(off[k] + s * 16 + g * 4 + j, t, first);
-                    }
-                }
+        for (int j = 0; j < 4; ++j) {
+            const float v = row16_sum(sb1[s][j]);
+            if (pl == 0) mine[P::B1 + s * 16 + g * 4 + j] = v;
         }
-        __syncthreads();
-    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v[6] = {sb2[s][j], sbo[s][j], sg1[s][j], sbe1[s][j], sg2[s][j], sbe2[s][j]};
+            const int off[6] = {P::B2, P::BO, P::G1, P::BE1, P::G2, P::BE2};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const float t = row16_sum(v[k]);
+                if (pl == 0) mine[off[k] + s * 16 + g * 4 + j] = t;
+            }
+        }
+    __syncthreads();
     float* out = p.partial + (size_t)blockIdx.x * P::SIZE;
-    for (int i = tid; i < P::SIZE; i += 256) out[i] = red[i];
+    for (int i = tid; i < P::SIZE; i += 256)
+        out[i] = ((red[i] + red[P::SIZE + i]) + red[2 * P::SIZE + i]) + red[3 * P::SIZE + i];
 }
 
 // sums the workgroup partials: shared parameters over all workgroups (accumulated into the gradient arena),
@@ -578,7 +573,7 @@ template <int MLP> size_t bwd_lds_bytes() {
     const size_t w = (size_t)(4 * 32 * WP + 2 * MLP * WP + 2 * 32 * (MLP + 8)) * 2;
     const size_t tile = 32 * (size_t)(lds_pitch(MLP * 2) > lds_pitch(64) ? lds_pitch(MLP * 2) : lds_pitch(64));
     size_t t = 8 * tile;
-    if (t < (size_t)PL<MLP>::SIZE * 4) t = (size_t)PL<MLP>::SIZE * 4;
+    if (t < (size_t)PL<MLP>::SIZE * 4 * 4) t = (size_t)PL<MLP>::SIZE * 4 * 4;      // four wave slots of the final combine
     return w + t;
 }
 
