@@ -454,7 +454,11 @@ struct PrepWgArgs {
     long ls_param;                   // stacked form: blockIdx.z = layer (inputs stacked, gradients at the arena's layer pitch)
 };
 __global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
-    __shared__ float red[8][33];
+    // one workgroup per (matrix, block of HB = 8 consecutive inner columns hd): 8 image phases x 32 channels, every
+    // thread carries the 8 columns (their k / v / dk / dv values are two 16-byte broadcast loads).  One workgroup per
+    // single column was 2560 - 10240 tiny workgroups per launch: dispatch-bound (72 us for 17 MFLOP).
+    constexpr int HB = 8;
+    __shared__ float red[8][HB][33];
     const int inner = a.heads * a.dh, L = a.L;
     {
         const size_t ly = blockIdx.z;
@@ -465,34 +469,50 @@ __global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
         a.dln_g += ly * a.ls_param; a.dln_b += ly * a.ls_param;
     }
     const int c = threadIdx.x & 31, ph = threadIdx.x >> 5;
-    const int which = blockIdx.y, hd = blockIdx.x;
-    float acc = 0.f;
+    const int which = blockIdx.y, hd0 = blockIdx.x * HB;
+    float acc[HB];
+#pragma unroll
+    for (int j = 0; j < HB; ++j) acc[j] = 0.f;
     if (which == 4) {
-        if (hd >= 2) return;                                   // hd = 0: dgamma, 1: dbeta
-        for (int s = ph; s < a.S; s += 8) acc += a.ln_partial[((size_t)s * 2 + hd) * D + c];
+        if (blockIdx.x >= 2) return;                           // blockIdx.x = 0: dgamma, 1: dbeta
+        for (int s = ph; s < a.S; s += 8) acc[0] += a.ln_partial[((size_t)s * 2 + blockIdx.x) * D + c];
     } else {
-        const int h = hd / a.dh;
+        const int h = hd0 / a.dh;                              // HB divides dh: the block lies inside one head
+        const float* colsrc = which == 0 ? a.k : (which == 1 ? a.dk : (which == 2 ? a.dv : a.v));
         for (int s = ph; s < a.S; s += 8)
             for (int l = 0; l < L; ++l) {
                 const size_t r = (size_t)s * L + l;
-                if (which == 0) acc += a.dkq[((size_t)s * a.HLP + h * L + l) * D + c] * a.k[r * inner + hd];
-                else if (which == 1) acc += a.dk[r * inner + hd] * a.mn[r * D + c];
-                else if (which == 2) acc += a.dv[r * inner + hd] * a.mn[r * D + c];
-                else acc += a.dvoT[((size_t)s * D + c) * a.HLP + h * L + l] * a.v[r * inner + hd];
+                float rowv;                                    // the per-channel factor of this (image, token)
+                if (which == 0) rowv = a.dkq[((size_t)s * a.HLP + h * L + l) * D + c];
+                else if (which == 3) rowv = a.dvoT[((size_t)s * D + c) * a.HLP + h * L + l];
+                else rowv = a.mn[r * D + c];
+                const float4 c0 = *reinterpret_cast<const float4*>(colsrc + r * inner + hd0);
+                const float4 c1 = *reinterpret_cast<const float4*>(colsrc + r * inner + hd0 + 4);
+                // (operand order of the former one-column form: which 0 / 3: row * col, which 1 / 2: col * row)
+                acc[0] += rowv * c0.x; acc[1] += rowv * c0.y; acc[2] += rowv * c0.z; acc[3] += rowv * c0.w;
+                acc[4] += rowv * c1.x; acc[5] += rowv * c1.y; acc[6] += rowv * c1.z; acc[7] += rowv * c1.w;
             }
     }
-    red[ph][c] = acc;
+#pragma unroll
+    for (int j = 0; j < HB; ++j) red[ph][j][c] = acc[j];
     __syncthreads();
-    if (ph == 0) {
+    if (which == 4) {
+        if (ph == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += red[r][0][c];
+            float* out = blockIdx.x == 0 ? a.dln_g : a.dln_b;
+            out[c] += t;                                       // the pixel-side LN backward wrote its part already
+        }
+        return;
+    }
+    {
+        const int j = ph;                                      // phase group j finishes column hd0 + j
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) t += red[r][c];
-        if (which == 4) {
-            float* out = hd == 0 ? a.dln_g : a.dln_b;
-            out[c] += t;                                       // the pixel-side LN backward wrote its part already
-            return;
-        }
+        for (int r = 0; r < 8; ++r) t += red[r][j][c];
         if (which == 0) t *= a.scale;
+        const int hd = hd0 + j;
         float* out = which == 0 ? a.dwq : (which == 1 ? a.dwk : (which == 2 ? a.dwv : a.dwo));
         const size_t o = which == 3 ? (size_t)c * inner + hd : (size_t)hd * D + c;     // to_out weight is [32][inner]
         if (a.accumulate) out[o] += t; else out[o] = t;
@@ -765,7 +785,8 @@ extern "C" int dh_xattn_prep_bwd_stack(int dtype, const void* tok, void* dtok_ac
     w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;
     w.ln_partial = a.ln_partial; w.dln_g = dln_g; w.dln_b = dln_b;
     w.accumulate = accumulate; w.ls_param = param_stride;
-    hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(inner, 5, layers), dim3(256), 0, ST(stream), w);
+    DH_REQUIRE(dim_head % 8 == 0, "xattn_prep_bwd: dim_head=%d must be a multiple of 8", dim_head);
+    hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(inner / 8, 5, layers), dim3(256), 0, ST(stream), w);
     DH_CHECK_LAUNCH("xattn_prep_bwd");
     return 0;
 }
