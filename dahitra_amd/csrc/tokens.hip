@@ -283,6 +283,7 @@ __global__ __launch_bounds__(1024) void xattn_prep_kernel(PrepArgs a) {
         float kk[8], vv[8];
 #pragma unroll
         for (int l = 0; l < 8; ++l) { kk[l] = 0.f; vv[l] = 0.f; }
+#pragma unroll 8                         // eight iterations' weight loads in flight (the adds stay in order)
         for (int c = 0; c < D; ++c) {
             const float wk = ldf(wkT + (size_t)c * inner + hd), wv = ldf(wvT + (size_t)c * inner + hd);
 #pragma unroll
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(1024) void xattn_prep_kernel(PrepArgs a) {
         float q = 0.f, o = 0.f;
         if (hl < HL) {
             const int h = hl / L, l = hl % L;
+#pragma unroll 8
             for (int d = 0; d < a.dh; ++d) {
                 const int hd = h * a.dh + d;
                 q += a.wq[hd * D + c] * sk[l * inner + hd];
@@ -372,6 +374,7 @@ __global__ __launch_bounds__(1024) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
         float gk[8], gv[8];
 #pragma unroll
         for (int l = 0; l < 8; ++l) { gk[l] = 0.f; gv[l] = 0.f; }
+#pragma unroll 8
         for (int c = 0; c < D; ++c) {
             const float wq = ldf(wqT + (size_t)c * inner + hd), wo = a.wo[(size_t)c * inner + hd];
 #pragma unroll
@@ -394,6 +397,7 @@ __global__ __launch_bounds__(1024) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
         float acc[8];
 #pragma unroll
         for (int l = 0; l < 8; ++l) acc[l] = 0.f;
+#pragma unroll 8
         for (int hd = ch * per; hd < (ch + 1) * per && hd < inner; ++hd) {
             const float wk = a.wk[(size_t)hd * D + c], wv = a.wv[(size_t)hd * D + c];
 #pragma unroll
