@@ -208,6 +208,7 @@ __device__ __forceinline__ void layer_forward(const EncArgs& a, const Lds& l, in
     if (tid < n * D) {
         const int t = tid / D, c = tid % D;
         r = a.b2[ps + c] + l.x1[tid];
+#pragma unroll 8
         for (int m = 0; m < mlp; ++m) r += l.h[t * mlp + m] * w2[(size_t)c * mlp + m];
     }
     __syncthreads();
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(256) void encoder_bwd_kernel(EncArgs a) {
         if (tid < n * D) {
             const int t = tid / D, c = tid % D;
             float s = 0.f;
+#pragma unroll 8
             for (int m = 0; m < mlp; ++m) s += dz[t * mlp + m] * w1[(size_t)m * D + c];
             dx1n[tid] = s;
         }
