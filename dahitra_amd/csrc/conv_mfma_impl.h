@@ -473,7 +473,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
 
 template <typename T, int KS, int STRIDE>
 int launch_nt(const ConvArgs& a, hipStream_t st) {
-    if (a.CoutPad % 64 == 0 && !(getenv("DH_NT32") && a.Cin <= 64 && KS == 3)) return launch<T, KS, STRIDE, 64>(a, st);
+    if (a.CoutPad % 64 == 0) return launch<T, KS, STRIDE, 64>(a, st);
     if (a.CoutPad % 32 == 0) return launch<T, KS, STRIDE, 32>(a, st);
     return launch<T, KS, STRIDE, 16>(a, st);
 }
