@@ -10,9 +10,14 @@ FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-resul
 
 all: $(LIB)
 
+# the token-side kernels are long dependent chains at one or two waves per SIMD: schedule them for ILP, not occupancy
+# (fused decoder backward 39.9 -> 34.9 us, fused encoder forward 66.9 -> 50.7 us)
+ILP_SRCS := decoder_fused encoder_fused tokens
+$(foreach f,$(ILP_SRCS),$(eval $(OBJ)/$(f).o: EXTRA := -mllvm -amdgpu-sched-strategy=max-ilp))
+
 $(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/conv_mfma_impl.h
 	@mkdir -p $(OBJ)
-	$(HIPCC) $(FLAGS) -c $< -o $@
+	$(HIPCC) $(FLAGS) $(EXTRA) -c $< -o $@
 
 $(LIB): $(OBJS)
 	@mkdir -p $(dir $(LIB))
