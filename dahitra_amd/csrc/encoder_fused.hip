@@ -93,7 +93,19 @@ __device__ __forceinline__ void ksplit_rows(const float* in, int in_pitch, const
 #pragma unroll
     for (int t = 0; t < MAXN; ++t) acc[t] = 0.f;
     int j = j0;
-    for (; j + 3 < j1; j += 4) {              // four weight loads in flight per step
+    for (; j + 7 < j1; j += 8) {              // eight weight loads in flight per step (the loop is load-latency-bound)
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = W[(long)(j + u) * sj + (long)c * sc];
+#pragma unroll
+        for (int t = 0; t < MAXN; ++t)
+            if (t < n) {
+                const float* r = in + t * in_pitch + j;
+                acc[t] += r[0] * w[0] + r[1] * w[1] + r[2] * w[2] + r[3] * w[3];
+                acc[t] += r[4] * w[4] + r[5] * w[5] + r[6] * w[6] + r[7] * w[7];
+            }
+    }
+    for (; j + 3 < j1; j += 4) {
         const float w0 = W[(long)j * sj + (long)c * sc], w1 = W[(long)(j + 1) * sj + (long)c * sc];
         const float w2 = W[(long)(j + 2) * sj + (long)c * sc], w3 = W[(long)(j + 3) * sj + (long)c * sc];
 #pragma unroll
