@@ -56,6 +56,12 @@ __device__ __forceinline__ Lds carve(float* sm, int n, int inner, int heads, int
     l.red = sm;                   // [8][n][32]
     return l;
 }
+// floats of one saved (layer, image) record: the forward's LDS image up to (not including) the reduction scratch --
+// layer input, both LayerNorm outputs / normalised values / statistics, qkv, probabilities, attention output,
+// MLP pre-activations and activations
+__host__ __device__ static inline size_t saved_img_floats(int n, int inner, int heads, int mlp) {
+    return (size_t)n * D * 6 + (size_t)n * 3 * inner + (size_t)heads * n * n + (size_t)n * inner + 2 * (size_t)n * mlp + 4 * n;
+}
 static inline size_t fwd_lds_floats(int n, int inner, int heads, int mlp) {
     return (size_t)n * D * 6 + (size_t)n * 3 * inner + (size_t)heads * n * n + (size_t)n * inner + 2 * (size_t)n * mlp + 4 * n +
            (size_t)8 * n * D;
@@ -234,14 +240,24 @@ __global__ __launch_bounds__(256) void encoder_fwd_kernel(EncArgs a) {
     const Lds l = carve(sm, n, a.heads * a.dh, a.heads, a.mlp);
     if (tid < n * D) l.x[tid] = a.x[(size_t)b * n * D + tid];
     __syncthreads();
+    const int img = (int)saved_img_floats(n, a.heads * a.dh, a.heads, a.mlp);       // a multiple of 4
     for (int ly = 0; ly < a.depth; ++ly) {
-        if (a.xs && tid < n * D) a.xs[((size_t)ly * a.B + b) * n * D + tid] = l.x[tid];
-        layer_forward(a, l, ly, l.x);
+        // the layer output goes to the (then idle) reduction scratch, so that the image with the layer INPUT in it
+        // can be saved for the backward pass, which then has nothing to recompute (that recompute was 45 of its 96 us)
+        layer_forward(a, l, ly, l.red);
+        if (a.xs) {
+            float4* dst = reinterpret_cast<float4*>(a.xs + ((size_t)ly * a.B + b) * img);
+            const float4* src = reinterpret_cast<const float4*>(sm);
+            for (int i = tid; i < img / 4; i += blockDim.x) dst[i] = src[i];
+        }
+        __syncthreads();
+        if (tid < n * D) l.x[tid] = l.red[tid];
+        __syncthreads();
     }
     if (tid < n * D) a.y[(size_t)b * n * D + tid] = l.x[tid];
 }
 
-// data gradient: per image, layers in reverse; recomputes each layer's forward from its saved input
+// data gradient: per image, layers in reverse, from each layer's saved forward image
 __global__ __launch_bounds__(256) void encoder_bwd_kernel(EncArgs a) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, n = a.n, inner = a.heads * a.dh, mlp = a.mlp;
@@ -260,9 +276,14 @@ __global__ __launch_bounds__(256) void encoder_bwd_kernel(EncArgs a) {
         const long ps = (long)ly * a.pstride;
         const size_t row0 = ((size_t)ly * a.B + b) * n;
         __syncthreads();
-        if (tid < n * D) l.x[tid] = a.xs[row0 * D + tid];
+        {
+            const int img = (int)saved_img_floats(n, inner, a.heads, mlp);
+            const float4* src = reinterpret_cast<const float4*>(a.xs + ((size_t)ly * a.B + b) * img);
+            float4* dst = reinterpret_cast<float4*>(sm);
+#pragma unroll 8
+            for (int i = tid; i < img / 4; i += blockDim.x) dst[i] = src[i];      // the forward's LDS image of this layer
+        }
         __syncthreads();
-        layer_forward(a, l, ly, dxn);        // the layer output itself is not needed: parked in dxn, overwritten below
         // ---- feed-forward backward ----
         const float* w2 = a.w2 + ps;
         for (int i = tid; i < n * mlp; i += blockDim.x) {
@@ -489,6 +510,11 @@ extern "C" int dh_encoder_fwd(const float* x, float* y, float* saved_inputs, int
     hipLaunchKernelGGL(encoder_fwd_kernel, dim3(B), dim3(256), lds, ST(stream), a);
     DH_CHECK_LAUNCH("encoder_fwd");
     return 0;
+}
+
+// floats of the saved_inputs buffer dh_encoder_fwd fills for dh_encoder_bwd: [depth][B][one forward image]
+extern "C" long dh_encoder_saved_floats(int B, int n, int depth, int heads, int dim_head, int mlp) {
+    return (long)depth * B * (long)saved_img_floats(n, heads * dim_head, heads, mlp);
 }
 
 // workspace floats: depth * B*n * (4*32 + 3*inner + inner + 2*mlp) + depth * B * 128

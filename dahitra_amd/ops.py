@@ -700,10 +700,11 @@ def encoder_supported(n, heads, dim_head, mlp):
 
 def encoder_fwd(tok2d, B, n, depth, heads, dim_head, mlp, pstride, params, save, scale=32 ** -0.5, eps=1e-5):
     """fused token encoder stack (csrc/encoder_fused.hip).  tok2d [B*n, 32] fp32; params: the 11 first-layer tensors
-    (ln1_g, ln1_b, wqkv, wo, bo, ln2_g, ln2_b, w1, b1, w2, b2).  Returns (y, saved layer inputs | None)."""
+    (ln1_g, ln1_b, wqkv, wo, bo, ln2_g, ln2_b, w1, b1, w2, b2).  Returns (y, saved per-layer forward images | None)."""
     assert tok2d.dtype == torch.float32 and tok2d.shape == (B * n, 32)
     y = torch.empty_like(tok2d)
-    xs = torch.empty(depth, B * n, 32, dtype=torch.float32, device=tok2d.device) if save else None
+    xs = torch.empty(_lib.lib().dh_encoder_saved_floats(B, n, depth, heads, dim_head, mlp), dtype=torch.float32,
+                     device=tok2d.device) if save else None          # [depth][B][forward image]
     _call("dh_encoder_fwd", P(tok2d), P(y), P(xs), _ci(B), _ci(n), _ci(depth), _ci(heads), _ci(dim_head), _ci(mlp),
           _cf(scale), _cf(eps), _cl(pstride), *(P(t) for t in params), S())
     return y, xs

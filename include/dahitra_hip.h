@@ -212,6 +212,10 @@ int dh_encoder_bwd(const float* dy, float* dx, const float* saved_inputs, int B,
                    float* dln1_g, float* dln1_b, float* dwqkv, float* dwo, float* dbo, float* dln2_g, float* dln2_b,
                    float* dw1, float* db1, float* dw2, float* db2, void* workspace, void* stream);
 long dh_encoder_bwd_workspace_size(int B, int n, int depth, int heads, int dim_head, int mlp);
+/* floats of `saved_inputs` (non-null in training): per (layer, image) the forward's intermediates -- layer input, LayerNorm
+ * outputs and statistics, qkv, attention probabilities and output, MLP activations -- which dh_encoder_bwd reads back
+ * instead of recomputing the layer */
+long dh_encoder_saved_floats(int B, int n, int depth, int heads, int dim_head, int mlp);
 
 /* Fused cross-attention decoder layer (help_funcs.py:170-186: Residual2(PreNorm2(Cross_Attention)) + Residual(PreNorm(
  * FeedForward))) in one kernel per direction; bf16, token_len 4, heads*4 <= 32, rows per image % 128 == 0.
