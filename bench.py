@@ -197,7 +197,7 @@ def main():
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = fl / (ms * 1e-3) / 1e12
             traffic = None        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
-            tpath = os.path.join(ROOT, "profiles", "r01n_pmc_traffic_conv3x3.json")
+            tpath = os.path.join(ROOT, "profiles", "r01o_pmc_traffic_conv3x3.json")
             if args.dtype == "bf16" and args.net == NET and args.img == SIZE and os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 ln = sum(v["launches"] for v in tj.values())
