@@ -19,6 +19,10 @@
 namespace {
 
 constexpr int D = 32;
+// threads per (one-image) workgroup of the forward / data-gradient kernels: only B workgroups exist, so the strided phases
+// (projections, attention products, copies) run on two waves per SIMD; the fixed 8 x 32 / 4-lanes-per-(head, query) phases
+// use the first 256 threads
+constexpr int ENC_THREADS = 512;
 constexpr int MAXN = 8;          // tokens per image (2 * token_len)
 
 struct EncArgs {
@@ -93,8 +97,8 @@ __device__ __forceinline__ void layer_norm_rows(const float* src, const float* g
 // The caller reads the result from red[0 .. n*32) after the trailing barrier.
 __device__ __forceinline__ void ksplit_rows(const float* in, int in_pitch, const float* __restrict__ W, long sj, long sc, int K,
                                             int n, float* red) {
-    const int kg = threadIdx.x >> 5, c = threadIdx.x & 31;
-    const int per = (K + 7) >> 3, j0 = kg * per, j1 = min(K, j0 + per);
+    const int kg = threadIdx.x >> 5, c = threadIdx.x & 31;       // (threads beyond the 8 x 32 mapping only pass the barriers)
+    const int per = (K + 7) >> 3, j0 = kg < 8 ? kg * per : K, j1 = min(K, j0 + per);
     float acc[MAXN];
 #pragma unroll
     for (int t = 0; t < MAXN; ++t) acc[t] = 0.f;
@@ -129,7 +133,7 @@ __device__ __forceinline__ void ksplit_rows(const float* in, int in_pitch, const
     }
 #pragma unroll
     for (int t = 0; t < MAXN; ++t)
-        if (t < n) red[(kg * n + t) * D + c] = acc[t];
+        if (t < n && kg < 8) red[(kg * n + t) * D + c] = acc[t];
     __syncthreads();
     if (threadIdx.x < n * D) {
         float s = 0.f;
@@ -234,7 +238,7 @@ __device__ __forceinline__ void layer_forward(const EncArgs& a, const Lds& l, in
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void encoder_fwd_kernel(EncArgs a) {
+__global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(EncArgs a) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, n = a.n;
     const Lds l = carve(sm, n, a.heads * a.dh, a.heads, a.mlp);
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void encoder_fwd_kernel(EncArgs a) {
 }
 
 // data gradient: per image, layers in reverse, from each layer's saved forward image
-__global__ __launch_bounds__(256) void encoder_bwd_kernel(EncArgs a) {
+__global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(EncArgs a) {
     extern __shared__ float sm[];
     const int b = blockIdx.x, tid = threadIdx.x, n = a.n, inner = a.heads * a.dh, mlp = a.mlp;
     const Lds l = carve(sm, n, inner, a.heads, mlp);
@@ -507,7 +511,7 @@ extern "C" int dh_encoder_fwd(const float* x, float* y, float* saved_inputs, int
     const size_t lds = fwd_lds_floats(n, heads * dim_head, heads, mlp) * 4;
     static bool done = false;
     if (set_lds(reinterpret_cast<const void*>(encoder_fwd_kernel), lds, done)) return 1;
-    hipLaunchKernelGGL(encoder_fwd_kernel, dim3(B), dim3(256), lds, ST(stream), a);
+    hipLaunchKernelGGL(encoder_fwd_kernel, dim3(B), dim3(ENC_THREADS), lds, ST(stream), a);
     DH_CHECK_LAUNCH("encoder_fwd");
     return 0;
 }
@@ -556,7 +560,7 @@ extern "C" int dh_encoder_bwd(const float* dy, float* dx, const float* saved_inp
                         (size_t)n * 3 * inner + (size_t)heads * n * n) * 4;
     static bool done = false;
     if (set_lds(reinterpret_cast<const void*>(encoder_bwd_kernel), lds, done)) return 1;
-    hipLaunchKernelGGL(encoder_bwd_kernel, dim3(B), dim3(256), lds, ST(stream), a);
+    hipLaunchKernelGGL(encoder_bwd_kernel, dim3(B), dim3(ENC_THREADS), lds, ST(stream), a);
     EncWgArgs g = {};
     g.r_xn = a.r_xn; g.r_dqkv = a.r_dqkv; g.r_o = a.r_o; g.r_dx1 = a.r_dx1; g.r_x1n = a.r_x1n; g.r_dz = a.r_dz;
     g.r_h = a.r_h; g.r_dx2 = a.r_dx2; g.r_ln = a.r_ln;
