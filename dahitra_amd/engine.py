@@ -548,13 +548,24 @@ class Engine:
             logits, bwd = self._bit(x1, x2)
         else:
             logits, bwd = self._unet(x1, x2)        # "unet" and "xbd" share the trunk / up path; levels differ
-        self._bwd = bwd
+        if need_grad:
+            self._bwd = bwd        # a no-grad forward (validation, metrics) leaves a pending backward alone
         return logits
 
-    def backward(self, dlogits_nchw):
-        if self._bwd is None:
-            raise RuntimeError("dahitra_amd: backward called without a grad-enabled forward")
+    def take_backward(self):
+        """the backward closure of the forward that just ran (the autograd node of THAT forward keeps it, so several
+        grad-enabled forwards may be outstanding, as with the reference's autograd graph)"""
         bwd, self._bwd = self._bwd, None
+        return bwd
+
+    def backward(self, dlogits_nchw, bwd=None):
+        if bwd is None:
+            bwd, self._bwd = self._bwd, None
+        if bwd is None:
+            raise RuntimeError("dahitra_amd: backward called without a grad-enabled forward")
+        plan = self._plans.get(True)
+        if plan is not None:       # a no-grad forward in between switched self.pk to the forward-only packed weights
+            self.pk, self.xstack = plan[1], plan[2]
         if self._wgrad_plan is None:
             self._wgrad_plan = ops.WgradPlan(dlogits_nchw.device)
         with self._wgrad_plan as plan:      # the conv layers' split-K reduces: one launch at the end of the pass

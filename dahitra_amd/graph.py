@@ -12,7 +12,7 @@ undone (parameters, BN buffers and optimizer state are restored), so the first g
 import torch
 import torch.distributed as dist
 
-from . import parallel
+from . import ops, parallel
 from .models import losses
 
 
@@ -22,11 +22,13 @@ class GraphedTrainStep:
             raise ValueError("GraphedTrainStep needs dahitra_amd.optim.AdamW(..., capturable=True)")
         self.net, self.opt = net, opt
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.exchange = parallel.exchange_enabled()      # gradient all-reduce + AdamW after the replay
         self._set_inputs(a, b, lab)
         net._ensure_arena(a.device)
         # ---- snapshot the training state, warm up eagerly on a side stream, restore -------------------
         flat0 = net._arena.flat.clone()
         bufs0 = [t.clone() for t in net.buffers()]
+        opt0 = opt.snapshot_flat_state(net)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -37,14 +39,17 @@ class GraphedTrainStep:
         net._arena.flat.copy_(flat0)
         for t, t0 in zip(net.buffers(), bufs0):
             t.copy_(t0)
-        st = opt._flat_state[id(net)]
-        st[0].zero_()
-        st[1].zero_()
-        st[2].zero_()
+        opt.restore_flat_state(net, opt0)     # the optimizer keeps what it carried (e.g. a resumed checkpoint)
         # ---- capture ---------------------------------------------------------------------------------
+        # A captured graph holds RAW pointers: the shared scratch workspace, the weight-gradient plan's slabs and
+        # job table, the packed-weight buffers.  ops.pin_captured_buffers() makes every buffer the capture touched
+        # immutable for the life of the process (a later, larger eager call allocates a NEW buffer instead of
+        # freeing the one the graph still reads and writes).
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = self._eager_body(include_opt=self.world == 1)
+            self.loss = self._eager_body(include_opt=not self.exchange)
+        self._pinned = ops.pin_captured_buffers(net)
+        self._generation = net._arena.generation
         torch.cuda.synchronize()
 
     def _set_inputs(self, a, b, lab):
@@ -57,6 +62,7 @@ class GraphedTrainStep:
 
     def _eager_body(self, include_opt):
         logits = self.net(self.a, self.b)
+        self.logits = logits.detach()          # static output buffer of the graph: valid after every replay
         self.opt.zero_grad()
         loss = losses.focal_loss(logits, self.lab)
         loss.backward()
@@ -70,11 +76,14 @@ class GraphedTrainStep:
         self.opt.step()
 
     def __call__(self, *inputs):
+        if self.net._arena.generation != self._generation:
+            raise RuntimeError("dahitra_amd: the net's parameter arena was rebuilt (moved to another device / "
+                               "parameters replaced) after this step was captured; build a new GraphedTrainStep")
         if inputs and inputs[0] is not None:
             self._copy_inputs(*inputs)
         self.opt.sync_hyper(1.0 / self.world)
         self.graph.replay()
-        if self.world > 1:
+        if self.exchange:
             self._after_replay()
         return self.loss
 
@@ -100,7 +109,9 @@ class GraphedXbdStep(GraphedTrainStep):
     def _eager_body(self, include_opt):
         from .models import xbd
         self.net.zero_grad()
-        loss = xbd.xbd_loss(self.net(self.a), self.lab)
+        logits = self.net(self.a)
+        self.logits = logits.detach()
+        loss = xbd.xbd_loss(logits, self.lab)
         loss.backward()
         if include_opt:
             xbd.clip_grad_norm_(self.net.parameters(), self.max_norm)
@@ -108,7 +119,6 @@ class GraphedXbdStep(GraphedTrainStep):
         return loss.detach()
 
     def _after_replay(self):
-        from . import ops
         from .models import xbd
         scale = parallel.allreduce_net_grads_(self.net)
         _, grad = self.net.flat_params()

@@ -62,11 +62,17 @@ class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, net, x1, x2):
         ctx.net = net
-        return net._run_forward(x1, x2)
+        out = net._run_forward(x1, x2)
+        ctx.bwd = net._engine.take_backward()      # this forward's saved activations + backward kernels
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
-        ctx.net._run_backward(dlogits.contiguous())
+        bwd, ctx.bwd = ctx.bwd, None
+        if bwd is None:
+            raise RuntimeError("dahitra_amd: this forward's backward already ran (no retain_graph: the saved "
+                               "activations are released after one pass)")
+        ctx.net._run_backward(dlogits.contiguous(), bwd)
         return None, None, None, None
 
 
@@ -195,13 +201,13 @@ class CDNet(nn.Module):
         x2 = x2.detach().float().contiguous()
         return self._engine.forward(x1, x2, self.training, need_grad)
 
-    def _run_backward(self, dlogits):
+    def _run_backward(self, dlogits, bwd=None):
         ar = self._arena
         sd_p = dict(self.named_parameters())
         fresh = all(sd_p[k].grad is None for k in self._active_keys)
         if fresh:
             ar.grad.zero_()
-        self._engine.backward(dlogits)
+        self._engine.backward(dlogits, bwd)
         for k in self._active_keys:
             p = sd_p[k]
             if p.grad is None:

@@ -87,7 +87,38 @@ class CDTrainer:
         iou = tp / (sum_r + sum_c - tp + eps)
         return dict(acc=float(acc), miou=float(np.nanmean(iou)), mf1=float(np.nanmean(f1)))
 
+    # ---- checkpoints (trainer.py:106-134, 150-158) ---------------------------------------------------
+    def _load_checkpoint(self, ckpt_name='best_ckpt.pt'):
+        """resume: net, optimizer (flat Adam moments + step count) and scheduler states, epoch counters"""
+        path = os.path.join(self.checkpoint_dir, ckpt_name) if self.checkpoint_dir else None
+        if not path or not os.path.exists(path):
+            print('training from scratch...')
+            return False
+        checkpoint = torch.load(path, map_location=self.device)
+        sd = checkpoint['model_G_state_dict']
+        if all(k.startswith('module.') for k in sd):           # written under nn.DataParallel
+            sd = {k[len('module.'):]: v for k, v in sd.items()}
+        self.net_G.load_state_dict(sd)
+        self.net_G.to(self.device)
+        self.optimizer_G.load_state_dict(checkpoint['optimizer_G_state_dict'])
+        self.exp_lr_scheduler_G.load_state_dict(checkpoint['exp_lr_scheduler_G_state_dict'])
+        self.epoch_to_start = checkpoint['epoch_id'] + 1
+        self.best_val_acc = checkpoint['best_val_acc']
+        self.best_epoch_id = checkpoint['best_epoch_id']
+        print('Epoch_to_start = %d, Historical_best_acc = %.4f (at epoch %d)' %
+              (self.epoch_to_start, self.best_val_acc, self.best_epoch_id))
+        return True
+
+    def _save_checkpoint(self, ckpt_name):
+        os.makedirs(self.checkpoint_dir, exist_ok=True)
+        torch.save({'epoch_id': self.epoch_id, 'best_val_acc': self.best_val_acc,
+                    'best_epoch_id': self.best_epoch_id, 'model_G_state_dict': self.net_G.state_dict(),
+                    'optimizer_G_state_dict': self.optimizer_G.state_dict(),
+                    'exp_lr_scheduler_G_state_dict': self.exp_lr_scheduler_G.state_dict()},
+                   os.path.join(self.checkpoint_dir, ckpt_name))
+
     def train_models(self):
+        self._load_checkpoint()
         for self.epoch_id in range(self.epoch_to_start, self.max_num_epochs):
             self.confusion.zero_()
             self.is_training = True
@@ -107,11 +138,6 @@ class CDTrainer:
             val = self.scores()
             print("epoch %d train mF1 %.5f val mF1 %.5f loss %.6f" % (self.epoch_id, train_scores["mf1"], val["mf1"],
                                                                     float(self.G_loss)))
-            if val["mf1"] > self.best_val_acc and self.checkpoint_dir:
-                self.best_val_acc, self.best_epoch_id = val["mf1"], self.epoch_id
-                os.makedirs(self.checkpoint_dir, exist_ok=True)
-                torch.save({'epoch_id': self.epoch_id, 'best_val_acc': self.best_val_acc,
-                            'best_epoch_id': self.best_epoch_id, 'model_G_state_dict': self.net_G.state_dict(),
-                            'optimizer_G_state_dict': self.optimizer_G.state_dict(),
-                            'exp_lr_scheduler_G_state_dict': self.exp_lr_scheduler_G.state_dict()},
-                           os.path.join(self.checkpoint_dir, 'best_ckpt.pt'))
+            if val["mf1"] > self.best_val_acc and self.checkpoint_dir:      # trainer.py:216-232 (last_ckpt is commented
+                self.best_val_acc, self.best_epoch_id = val["mf1"], self.epoch_id     # out in the reference)
+                self._save_checkpoint('best_ckpt.pt')

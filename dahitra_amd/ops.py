@@ -53,6 +53,28 @@ def workspace(nbytes, device):
     return buf
 
 
+_PINNED = []        # buffers a captured HIP graph points into: kept alive for the life of the process
+
+
+def pin_captured_buffers(net):
+    """Called right after a HIP-graph capture of `net`'s step.  The graph's kernel nodes hold RAW pointers into
+    buffers that live outside the graph's private pool: the shared scratch workspace, the weight-gradient plan's slabs
+    and device job table, the packed-weight plans, the parameter / gradient arenas.  Each of them is normally replaced
+    (and the old tensor returned to the allocator) when a later eager call needs more room or another shape -- the
+    last partial batch of an epoch, an eval forward at a larger size, another net in the process.  Holding a reference
+    here means a replacement allocates a NEW buffer while the one the graph reads and writes stays valid."""
+    keep = list(_ws.values())
+    eng = net._engine
+    if eng._wgrad_plan is not None:
+        keep += list(eng._wgrad_plan.slots) + [eng._wgrad_plan.table]
+    for pack, _, xstack in eng._plans.values():
+        keep += [pack.table] + list(pack.keep) + list(xstack.values())
+    keep += [net._arena.flat, net._arena.grad]
+    keep = [t for t in keep if t is not None]
+    _PINNED.extend(keep)
+    return keep
+
+
 def _call(name, *args):
     L = _lib.lib()
     _lib.check(getattr(L, name)(*args), name)
@@ -193,7 +215,32 @@ _WGRAD_PLAN = None
 
 
 # ---- convolution / linear ------------------------------------------------------------------------
-PROFILE = None       # set to {} by bench.py to collect (events, algorithmic flops, bytes) per conv launch
+PROFILE = None       # set to {} by bench.py to collect (events, algorithmic flops, algorithmic bytes) per launch
+
+
+class _Prof:
+    """bench.py's per-launch timer: HIP events recorded on the launch stream around ONE kernel launch of class `key`,
+    with that launch's algorithmic FLOPs and bytes (what the launch must read + write, each tensor once)"""
+    __slots__ = ("ev",)
+
+    def __init__(self, key, flops, nbytes):
+        self.ev = None
+        if PROFILE is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            PROFILE.setdefault(key, []).append((self.ev, float(flops), float(nbytes)))
+
+    def __enter__(self):
+        if self.ev is not None:
+            self.ev[0].record()
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            self.ev[1].record()
+        return False
+
+
+def _nb(*tensors):
+    return sum(t.numel() * t.element_size() for t in tensors if t is not None)
 
 
 def _gate_args(gate):
@@ -222,20 +269,13 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     if want_stats:
         nt = _lib.lib().dh_conv2d_fwd_num_tiles(N, OH, OW, Cin, ks, stride)
         stats = torch.empty(2, cpad, nt, dtype=torch.float32, device=x.device)      # [sum | sumsq][channel][tile]
-    ev = None
-    if PROFILE is not None:      # bench.py: HIP events on the launch stream around this kernel class
-        nt = 64 if cpad % 64 == 0 else (32 if cpad % 32 == 0 else 16)
-        key = "conv_mfma<%s,ks%d,s%d,nt%d>" % ("bf16" if x.dtype == torch.bfloat16 else "f32", ks, stride, nt)
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        flops = alg_flops if alg_flops else 2.0 * N * OH * OW * cout * Cin * ks * ks
-        bytes_ = (x.numel() + y.numel() + wp.numel()) * x.element_size()
-        PROFILE.setdefault(key, []).append((ev, flops, bytes_))
-        ev[0].record()
-    _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
-          _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
-          _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), S())
-    if ev is not None:
-        ev[1].record()
+    nt_ = 64 if cpad % 64 == 0 else (32 if cpad % 32 == 0 else 16)
+    key = "conv_mfma<%s,ks%d,s%d,nt%d>" % ("bf16" if x.dtype == torch.bfloat16 else "f32", ks, stride, nt_)
+    flops = alg_flops if alg_flops else 2.0 * N * OH * OW * cout * Cin * ks * ks
+    with _Prof(key, flops, _nb(x, y, wp, residual, pre)):
+        _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
+              _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
+              _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), S())
     out = [y]
     if want_stats:
         out.append(stats)
@@ -282,9 +322,11 @@ def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=
         # deferred: partial slabs into this layer's persistent workspace, summed later by plan.run()
         ws = plan.slab(nbytes)
         sk = ctypes.c_int(0)
-        _call("dh_conv2d_wgrad_partial", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W),
-              _ci(Cin), _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(1), _ci(0), _ci(int(use_tr)),
-              _ci(cout_real), _ci(pitch), _ci(dilation), P(ws), ctypes.byref(sk), S())
+        with _Prof("conv_wgrad<%s,ks%d,s%d>" % ("bf16" if x.dtype == torch.bfloat16 else "f32", ks, stride),
+                   2.0 * N * OH * OW * Cout * Cin * ks * ks, _nb(x, dy)):
+            _call("dh_conv2d_wgrad_partial", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W),
+                  _ci(Cin), _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(1), _ci(0), _ci(int(use_tr)),
+                  _ci(cout_real), _ci(pitch), _ci(dilation), P(ws), ctypes.byref(sk), S())
         if sk.value > 0:
             plan.add(ws, dw, sk.value, ks * ks, Cout, cout_real if cout_real else Cout, Cin, accumulate)
         return
@@ -366,8 +408,9 @@ def bn_apply(x, scale, shift, groups=1, act=ACT_NONE, residual=None):
     C = x.shape[-1]
     npix = x.numel() // C
     y = torch.empty_like(x)
-    _call("dh_bn_apply", _ci(dt(x)), P(x), P(residual), P(y), P(scale), P(shift), _cl(npix), _ci(C), _ci(groups),
-          _ci(act), S())
+    with _Prof("bn_apply", 0, _nb(x, residual, y)):
+        _call("dh_bn_apply", _ci(dt(x)), P(x), P(residual), P(y), P(scale), P(shift), _cl(npix), _ci(C), _ci(groups),
+              _ci(act), S())
     return y
 
 
@@ -379,8 +422,10 @@ def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accu
     dres = torch.empty_like(x) if want_dres else None
     L = _lib.lib()
     ws = workspace(L.dh_bn_bwd_workspace_size(_cl(npix), C, groups), x.device)
-    _call("dh_bn_bwd", _ci(dt(x)), P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
-          _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(mask_scale), P(mask_shift), P(ws), S())
+    # two passes (reduce, apply): dout / x (/ out) are read twice, dx (/ dres) written once
+    with _Prof("bn_bwd", 0, 2 * _nb(dout, out_relu, x) + _nb(dx, dres)):
+        _call("dh_bn_bwd", _ci(dt(x)), P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
+              _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(mask_scale), P(mask_shift), P(ws), S())
     return (dx, dres) if want_dres else dx
 
 
@@ -672,8 +717,9 @@ def xattn_prep_bwd(prep, tok, dtok_accum, ln_g, wqT, wk, wv, wo, dkq, dvoT, dln_
 def decoder_layer_fwd(x2d, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b, w1, b1, w2, b2, mlp, eps=1e-5):
     """fused cross-attention + MLP decoder layer (csrc/decoder_fused.hip); x2d [rows, 32] bf16"""
     y = torch.empty_like(x2d)
-    _call("dh_decoder_layer_fwd", P(x2d), P(y), P(prep.kq), P(prep.voT), P(ln1_g), P(ln1_b), P(bo), P(ln2_g), P(ln2_b),
-          P(w1), P(b1), P(w2), P(b2), _cl(x2d.shape[0]), _ci(rows_per_image), _ci(mlp), _cf(eps), S())
+    with _Prof("decoder_layer_fwd", 0, _nb(x2d, y)):
+        _call("dh_decoder_layer_fwd", P(x2d), P(y), P(prep.kq), P(prep.voT), P(ln1_g), P(ln1_b), P(bo), P(ln2_g), P(ln2_b),
+              P(w1), P(b1), P(w2), P(b2), _cl(x2d.shape[0]), _ci(rows_per_image), _ci(mlp), _cf(eps), S())
     return y
 
 
@@ -688,9 +734,10 @@ def decoder_layer_bwd(x2d, dy, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln
         dkq = torch.empty(images, 32, 32, dtype=torch.float32, device=x2d.device)
         dvoT = torch.empty(images, 32, 32, dtype=torch.float32, device=x2d.device)
     ws = workspace(_lib.lib().dh_decoder_layer_bwd_workspace_size(_cl(rows), rows_per_image, mlp), x2d.device)
-    _call("dh_decoder_layer_bwd", P(x2d), P(dy), P(dx), P(prep.kq), P(prep.voT), P(prep.vo), P(prep.kqT), P(ln1_g),
-          P(ln1_b), P(bo), P(ln2_g), P(ln2_b), P(w1), P(w1T), P(b1), P(w2), P(w2T), P(b2), *(P(t) for t in grads),
-          P(dkq), P(dvoT), _cl(rows), _ci(rows_per_image), _ci(mlp), _cf(eps), P(ws), S())
+    with _Prof("decoder_layer_bwd", 0, _nb(x2d, dy, dx)):
+        _call("dh_decoder_layer_bwd", P(x2d), P(dy), P(dx), P(prep.kq), P(prep.voT), P(prep.vo), P(prep.kqT), P(ln1_g),
+              P(ln1_b), P(bo), P(ln2_g), P(ln2_b), P(w1), P(w1T), P(b1), P(w2), P(w2T), P(b2), *(P(t) for t in grads),
+              P(dkq), P(dvoT), _cl(rows), _ci(rows_per_image), _ci(mlp), _cf(eps), P(ws), S())
     return dx, dkq, dvoT
 
 

@@ -16,7 +16,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # DAHITRA_FORCE_DIST=1: build the process group even for one rank, so that the multi-GPU code path (RCCL init,
+    # barrier, gradient all-reduce, AdamW with the 1/world factor after the graph replay) can be exercised on one GPU
+    force = os.environ.get("DAHITRA_FORCE_DIST", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -34,10 +37,18 @@ def shard_batch(global_batch, rank, world):
     return rank * per, (rank + 1) * per
 
 
+def exchange_enabled(group=None):
+    """True when a step must run the gradient exchange: more than one rank, or DAHITRA_FORCE_DIST=1 (one-rank process
+    group: the collective is the identity but the same calls are made)"""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("DAHITRA_FORCE_DIST", "0") == "1"
+
+
 def allreduce_sum_(flat, group=None):
     """in-place SUM all-reduce of a flat gradient buffer; returns the factor (1/world) that turns it
     into the mean (pass it to AdamW.step(grad_scale=...))."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not exchange_enabled(group):
         return 1.0
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / dist.get_world_size(group)
@@ -51,7 +62,7 @@ def allreduce_net_grads_(net, group=None):
 
 def broadcast_params_(net, src=0, group=None):
     """replicas start from rank `src`'s parameters and BN buffers"""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not exchange_enabled(group):
         return
     flat = net._arena.flat
     dist.broadcast(flat, src=src, group=group)

@@ -331,6 +331,19 @@ def deterministic_state(net_G, salt=0, gain=1.0):
     return sd
 
 
+def large_margin_state(net_G, salt=0):
+    """deterministic_state with an ANTISYMMETRIC 2-class head (class-1 filter = -class-0 filter), so that the two logits
+    are l and -l and the arg-max margin is 2|l|: the fraction of pixels inside a 4e-4 * max|logit| tie band drops from
+    ~1 % to < 0.1 %, which makes "masks identical outside the band" a statement about (almost) every pixel."""
+    sd = deterministic_state(net_G, salt)
+    head = "classifier.3" if get_config(net_G)["kind"] == "bit" else "classifier"
+    w, b = sd[head + ".weight"], sd[head + ".bias"]
+    assert w.shape[0] == 2, "large_margin_state is defined for the 2-class heads"
+    w[1] = -w[0]
+    b[1] = -b[0]
+    return sd
+
+
 def synthetic_batch(batch, size, seed=1234, n_class=2, positive_frac=0.05):
     """A, B in [-1,1] and a sparse label map (SURVEY.md section 8d 'Synthetic inputs')."""
     g = torch.Generator().manual_seed(seed)

@@ -1,0 +1,116 @@
+"""BASELINE.json configs[1] at ITS OWN size: base_transformer_pos_s4, batch 32, 256x256, one GraphedTrainStep (the
+exact object bench.py times) -- logits, loss, every parameter gradient and the first AdamW update against the CPU
+oracle on the same seeded batch; fp32 (parity mode) and bf16 (the dtype of the headline number).
+
+The oracle's fwd + bwd at this size is ~1.6 TFLOP of CPU work (seconds on the GPU box's host cores) and is computed
+once per module."""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cdnet_ref as O
+
+pytestmark = pytest.mark.gpu
+NAME, BATCH, SIZE, LR = "base_transformer_pos_s4", 32, 256, 1e-3
+
+
+@pytest.fixture(scope="module")
+def oracle_step():
+    torch.set_num_threads(min(torch.get_num_threads(), 64))
+    a, b, lab = O.synthetic_batch(BATCH, SIZE, seed=1234)
+    st = O.TrainState(NAME, O.deterministic_state(NAME), lr=LR)
+    logits = O.forward(st.sd, NAME, a, b, training=True)
+    loss = O.focal_loss(logits, lab)
+    loss.backward()
+    grads = {k: (None if st.sd[k].grad is None else st.sd[k].grad.clone()) for k in st.sd if st.sd[k].requires_grad}
+    st.opt.step()
+    after = {k: st.sd[k].detach().clone() for k in grads}
+    return dict(a=a, b=b, lab=lab, logits=logits.detach(), loss=float(loss), grads=grads, after=after)
+
+
+def graphed(dtype, a, b, lab, state=None):
+    from dahitra_amd.graph import GraphedTrainStep
+    from dahitra_amd.models.networks import define_G
+    from dahitra_amd.optim import AdamW
+    net = define_G(types.SimpleNamespace(net_G=NAME, compute_dtype=dtype), gpu_ids=[0])
+    net.load_state_dict(state if state is not None else O.deterministic_state(NAME))
+    net.train()
+    opt = AdamW(net.parameters(), lr=LR, betas=(0.9, 0.999), weight_decay=0.01, capturable=True)
+    step = GraphedTrainStep(net, opt, a.cuda(), b.cuda(), lab.cuda())
+    loss = float(step())                     # ONE replay: forward, focal, backward, AdamW -- what bench.py times
+    return net, step, loss
+
+
+def test_config1_full_size_fp32_graphed_step_matches_oracle(oracle_step):
+    r = oracle_step
+    net, step, loss = graphed("fp32", r["a"], r["b"], r["lab"])
+    y = step.logits.float().cpu()
+    scale = float(r["logits"].abs().max())
+    err = float((y - r["logits"]).abs().max()) / scale
+    print("configs[1] fp32: logits rel err %.3e, loss %.7f (oracle %.7f)" % (err, loss, r["loss"]))
+    assert err <= 2e-4
+    assert abs(loss - r["loss"]) <= 2e-5 * max(1.0, abs(r["loss"]))
+    # gradients (the arena still holds them after the replay): every tensor by cosine, the set by median distance
+    rels, coss = [], []
+    params = dict(net.named_parameters())
+    for k, ref in r["grads"].items():
+        p = params[k]
+        assert (p.grad is None) == (ref is None), k
+        if ref is None:
+            continue
+        g = p.grad.cpu()
+        e, s = float((g - ref).abs().max()), float(ref.abs().max())
+        rels.append(e / max(s, 1e-30))
+        if ref.numel() >= 64 and float(ref.norm()) > 0:
+            coss.append((float(F.cosine_similarity(g.double().flatten(), ref.double().flatten(), dim=0)), k))
+    print("configs[1] fp32: grad rel err median %.2e, p90 %.2e, max %.2e; min cosine %.5f (%s)"
+          % (float(np.median(rels)), float(np.quantile(rels, 0.9)), max(rels), min(coss)[0], min(coss)[1]))
+    assert float(np.median(rels)) <= 2e-2
+    assert min(coss)[0] >= 0.995, min(coss)
+    # the AdamW update the graph applied: first step = -lr * (sign(g) + wd * w); only elements whose gradient is far
+    # from zero have a well-defined sign
+    bad = tot = 0
+    for k, ref in r["grads"].items():
+        if ref is None:
+            continue
+        sel = ref.abs() > 1e-2 * ref.abs().max()
+        got = params[k].detach().cpu()[sel]
+        want = r["after"][k][sel]
+        bad += int(((got - want).abs() > 0.2 * LR).sum())
+        tot += int(sel.sum())
+    print("configs[1] fp32: first AdamW update differs on %d of %d well-conditioned elements" % (bad, tot))
+    assert bad <= 1e-3 * tot
+
+
+def test_config1_full_size_bf16_graphed_step_within_twice_input_rounding_error(oracle_step):
+    """the dtype of the headline number, at the headline shape, through the graph bench.py replays"""
+    r = oracle_step
+    rounded = {k: (v.bfloat16().float() if v.dtype.is_floating_point and v.dim() > 1 else v)
+               for k, v in O.deterministic_state(NAME).items()}
+    _, s_round, _ = graphed("fp32", r["a"].bfloat16().float(), r["b"].bfloat16().float(), r["lab"], rounded)
+    y_round = s_round.logits.float().cpu()
+    del s_round
+    net, step, loss = graphed("bf16", r["a"], r["b"], r["lab"])
+    y = step.logits.float().cpu()
+    l2 = lambda u, v: float((u - v).norm() / v.norm())
+    sens, got = l2(y_round, r["logits"]), l2(y, r["logits"])
+    scale = float(r["logits"].abs().max())
+    err = float((y - r["logits"]).abs().max()) / scale
+    flips = float((torch.argmax(y, 1) != torch.argmax(r["logits"], 1)).float().mean())
+    print("configs[1] bf16: logits l2 %.3e (fp32 pipeline, bf16-rounded weights+images: %.3e), max err %.3e, loss %.6f "
+          "(oracle %.6f), mask disagreement %.4f" % (got, sens, err, loss, r["loss"], flips))
+    assert got <= 2.0 * sens, (got, sens)
+    assert abs(loss - r["loss"]) <= 2e-2 * abs(r["loss"])
+    coss = []
+    params = dict(net.named_parameters())
+    for k, ref in r["grads"].items():
+        if ref is None or ref.numel() < 64 or float(ref.norm()) == 0:
+            continue
+        coss.append((float(F.cosine_similarity(params[k].grad.cpu().double().flatten(), ref.double().flatten(), dim=0)), k))
+    coss.sort()
+    print("configs[1] bf16: gradient cosine vs oracle: min %.4f (%s), median %.4f" % (coss[0][0], coss[0][1], coss[len(coss) // 2][0]))
+    assert coss[len(coss) // 2][0] >= 0.99
+    assert coss[0][0] >= 0.9

@@ -55,7 +55,7 @@ def ops():
     dict(ks=3, stride=1, pad=1, cin=32, cout=5, h=16, w=16),
     dict(ks=3, stride=1, pad=1, cin=256, cout=256, h=16, w=16),
     dict(ks=3, stride=1, pad=2, dil=2, cin=64, cout=64, h=20, w=24),      # ResNet-50 layer3 (resnet.py:31-33)
-    dict(ks=3, stride=1, pad=2, dil=2, cin=256, cout=256, h=16, w=32),    # 16-row tile variant
+    dict(ks=3, stride=1, pad=2, dil=2, cin=256, cout=256, h=16, w=32),    # 8-row tile at this N (16-row: bench-scale test below)
     dict(ks=1, stride=1, pad=0, cin=1024, cout=256, h=8, w=8),
 ])
 def test_conv2d_fwd(ops, dtype, cfg):
@@ -84,8 +84,8 @@ def test_conv2d_fwd(ops, dtype, cfg):
 @pytest.mark.parametrize("cfg", [
     dict(ks=3, stride=1, pad=1, cin=64, cout=64, h=32, w=32),       # tiles fully inside the image (unmasked statistics)
     dict(ks=3, stride=1, pad=1, cin=64, cout=64, h=24, w=40),       # ragged: masked statistics, partial stores
-    dict(ks=3, stride=1, pad=1, cin=256, cout=256, h=32, w=32),     # 16-row tiles
-    dict(ks=3, stride=1, pad=1, cin=128, cout=128, h=20, w=24),     # 16-row tiles, ragged
+    dict(ks=3, stride=1, pad=1, cin=256, cout=256, h=32, w=32),     # Cin >= 128 (8-row tile at N = 2; 16-row: bench-scale test)
+    dict(ks=3, stride=1, pad=1, cin=128, cout=128, h=20, w=24),     # Cin >= 128, ragged (8-row tile at N = 2)
     dict(ks=3, stride=2, pad=1, cin=64, cout=128, h=32, w=32),
     dict(ks=1, stride=1, pad=0, cin=128, cout=32, h=16, w=16),      # 32-channel tile
     dict(ks=3, stride=1, pad=1, cin=32, cout=16, h=16, w=20),       # 16-channel tile
@@ -477,3 +477,99 @@ def test_maxpool_with_batchnorm_relu_on_load(ops, dtype):
     y0, a0 = ops.maxpool(h, want_arg=True)
     y1, a1 = ops.maxpool(x, want_arg=True, bn=(scale, shift, groups))
     assert torch.equal(y0, y1) and torch.equal(a0, a1)
+
+
+# ---- the instantiations bench.py's configs[1] step actually launches (2B = 64 images per launch) -----------------
+# pick_rw (csrc/conv_mfma_impl.h) selects the 16x16-pixel tile (RW = 4) only when N * ceil(OH/16) * ceil(OW/16) >= 256
+# and Cin >= 128: the small-N cases above never reach it.  These cases do, and assert that they do.
+BENCH_N = 64
+
+
+def _is_rw4(ops, N, OH, OW, cin, ks=3, stride=1):
+    from dahitra_amd import _lib
+    nt = _lib.lib().dh_conv2d_fwd_num_tiles(N, OH, OW, cin, ks, stride)
+    return nt == N * ops.cdiv(OH, 16) * ops.cdiv(OW, 16) and nt != N * ops.cdiv(OH, 8) * ops.cdiv(OW, 16)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    dict(cin=128, cout=128, h=32, w=32, stats=True, relu=False, res=False),     # layer2 conv (+BN statistics)
+    dict(cin=128, cout=256, h=32, w=32, stats=True, relu=False, res=False),     # layer3.0.conv1
+    dict(cin=256, cout=256, h=32, w=32, stats=True, relu=False, res=False),     # layer3 convs: <T,3,1,64,4,1,true,true>
+    dict(cin=256, cout=256, h=32, w=32, stats=False, relu=True, res=True),      # eval-mode form: bias + residual + ReLU
+    dict(cin=256, cout=128, h=32, w=32, stats=False, relu=False, res=True),     # layer3.0.conv1 data gradient (+ residual)
+    dict(cin=256, cout=32, h=64, w=64, stats=False, relu=False, res=False),     # conv_pred: <T,3,1,32,4,1,true,true>
+    dict(cin=256, cout=256, h=32, w=32, dil=2, stats=True, relu=False, res=False),   # ResNet-50 layer3 3x3, 16-row tile
+    dict(cin=128, cout=128, h=24, w=40, n=96, stats=True, relu=True, res=True),      # 16-row tiles, ragged map
+])
+def test_conv2d_fwd_bench_scale_16row_tiles(ops, dtype, cfg):
+    N = cfg.get("n", BENCH_N)
+    dil = cfg.get("dil", 1)
+    assert _is_rw4(ops, N, cfg["h"], cfg["w"], cfg["cin"]), "case does not select the 16-row tile"
+    x = rnd((N, cfg["cin"], cfg["h"], cfg["w"]), dtype, 601)
+    w = rnd((cfg["cout"], cfg["cin"], 3, 3), dtype, 602, scale=(cfg["cin"] * 9) ** -0.5)
+    b = rnd((cfg["cout"],), torch.float32, 603, 0.1)
+    want = F.conv2d(x, w, b, 1, dil, dil)
+    r = rnd(tuple(want.shape), dtype, 604) if cfg["res"] else None
+    if r is not None:
+        want = want + r
+    if cfg["relu"]:
+        want = F.relu(want)
+    wp, _ = ops.pack_weight(w.cuda(), dtype, want_dgrad=False)
+    out = ops.conv2d(dev(nhwc(x), dtype), wp, cfg["cout"], 3, 1, dil, bias=b.cuda(),
+                     residual=dev(nhwc(r), dtype) if r is not None else None,
+                     act=ops.ACT_RELU if cfg["relu"] else ops.ACT_NONE, want_stats=cfg["stats"], dilation=dil)
+    y = out[0] if cfg["stats"] else out
+    close(nchw(y), want, dtype, "conv2d out (16-row tile)")
+    if cfg["stats"]:
+        tot = out[1].double().sum(2).float().cpu()
+        close(tot[0, :cfg["cout"]], want.sum((0, 2, 3)), dtype, "stats sum", scale=float(want.abs().sum((0, 2, 3)).max()))
+        close(tot[1, :cfg["cout"]], (want * want).sum((0, 2, 3)), dtype, "stats sumsq")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    dict(cin=256, cout=256, h=32, w=32),       # layer3: dgrad on the 16-row tile, wgrad at the one-resident-round split
+    dict(cin=128, cout=256, h=32, w=32),
+    dict(cin=128, cout=128, h=32, w=32),
+    dict(cin=64, cout=64, h=64, w=64, n=32),   # layer1 shape (8-row tile; the wgrad split of the 64-channel layers)
+    dict(cin=256, cout=32, h=64, w=64, n=32),  # conv_pred: 32-wide output-channel tile of the weight gradient
+])
+def test_conv2d_dgrad_wgrad_bench_scale(ops, dtype, cfg):
+    """data gradient through the same RW = 4 instantiation, weight gradient at the 512-workgroup split, both the direct
+    (dh_conv2d_wgrad) and the deferred (dh_conv2d_wgrad_partial + dh_wgrad_reduce_multi) reductions"""
+    N = cfg.get("n", BENCH_N)
+    x = rnd((N, cfg["cin"], cfg["h"], cfg["w"]), dtype, 611).requires_grad_(True)
+    w = rnd((cfg["cout"], cfg["cin"], 3, 3), dtype, 612, scale=(cfg["cin"] * 9) ** -0.5).requires_grad_(True)
+    y = F.conv2d(x, w, None, 1, 1)
+    dy = rnd(tuple(y.shape), dtype, 613)
+    y.backward(dy)
+    ck = ops.chunk_channels(dtype)
+    cout_k = -(-cfg["cout"] // ck) * ck
+    _, wd = ops.pack_weight(w.detach().cuda(), dtype, want_dgrad=True, dgrad_inner=cout_k)
+    dyp = torch.zeros(N, cfg["h"], cfg["w"], cout_k)
+    dyp[..., :cfg["cout"]] = nhwc(dy)
+    if cout_k >= 128:
+        assert _is_rw4(ops, N, cfg["h"], cfg["w"], cout_k)
+    dx = ops.conv2d(dev(dyp, dtype), wd, cfg["cin"], 3, 1, 1)
+    close(nchw(dx), x.grad, dtype, "dgrad (bench scale)", factor=2.0)
+    xd, dyd = dev(nhwc(x.detach()), dtype), dev(nhwc(dy), dtype)
+    gscale = float(w.grad.abs().max())
+    # K = N*H*W pixels (65 536 .. 131 072): bf16 products, fp32 accumulation in split-K slabs
+    fac = 4.0 if dtype == torch.float32 else 1.0
+    dw = torch.full(tuple(w.shape), 0.5, device="cuda")
+    ops.conv2d_wgrad(xd, dyd, dw, 3, 1, 1, accumulate=True)
+    close(dw - 0.5, w.grad, dtype, "wgrad direct", scale=gscale, factor=fac)
+    plan = ops.WgradPlan(xd.device)
+    dw2 = torch.full(tuple(w.shape), 0.25, device="cuda")
+    dw3 = torch.zeros(tuple(w.shape), device="cuda")
+    for _ in range(2):                  # second pass reuses the persistent slabs and the device job table
+        dw2.fill_(0.25)
+        dw3.zero_()
+        with plan:
+            ops.conv2d_wgrad(xd, dyd, dw2, 3, 1, 1, accumulate=True)
+            ops.conv2d_wgrad(xd, dyd, dw3, 3, 1, 1, accumulate=False)
+            plan.run()
+        close(dw2 - 0.25, w.grad, dtype, "wgrad deferred (+=)", scale=gscale, factor=fac)
+        close(dw3, w.grad, dtype, "wgrad deferred (=)", scale=gscale, factor=fac)
+    assert torch.equal(dw3, dw - 0.5) or float((dw3 - (dw - 0.5)).abs().max()) <= 1e-6 * gscale

@@ -63,10 +63,17 @@ def test_forward_matches_reference_golden_fp32(name, golden_dir):
         mask = argmax_mask(y.cuda()).cpu().numpy().astype(np.uint8)
         ref_mask = np.unpackbits(g["mask_" + mode])[:mask.size].reshape(mask.shape) if cfg["n_class"] == 2 \
             else np.asarray(g["mask_" + mode]).reshape(mask.shape)
-        top2 = y.topk(2, dim=1).values
-        margin = (top2[:, 0] - top2[:, 1]).numpy()
+        # tie band from the REFERENCE's stored margins (fixtures at stride 1 hold one per pixel); the strided 256x256
+        # fixture falls back to the margins of the HIP logits (the large-margin test below covers that net per pixel)
+        if stride == 1:
+            margin = np.asarray(g["margin_" + mode]).astype(np.float32).reshape(mask.shape)
+        else:
+            top2 = y.topk(2, dim=1).values
+            margin = (top2[:, 0] - top2[:, 1]).numpy()
         band = margin <= 4e-4 * scale
         diff = (mask != ref_mask)
+        print("%s %s: mask flips total %d, outside the tie band %d, band fraction %.5f (reference margins: %s)"
+              % (name, mode, int(diff.sum()), int((diff & ~band).sum()), float(band.mean()), stride == 1))
         assert int((diff & ~band).sum()) == 0, "%s %s: %d mask flips outside the tie band" % (name, mode, int((diff & ~band).sum()))
         assert band.mean() < 0.02
         if mode == "train":
@@ -154,21 +161,77 @@ def test_gradients_match_oracle_fp32(name):
 
 
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
-def test_bf16_mode_tracks_fp32(name):
+def test_masks_bit_exact_on_large_margin_fixture_fp32(name, golden_dir):
+    """north star: "class masks bit-exact".  Fixture written by the reference with an antisymmetric head
+    (oracle/cdnet_ref.large_margin_state): the reference's own per-pixel margins put < 0.1 % of the pixels inside the
+    4e-4 * max|logit| band that a 2e-4 logit bound cannot decide; every other pixel must carry the reference's class."""
+    g = np.load(os.path.join(golden_dir, "margin_%s.npz" % name))
+    bs, size = int(g["batch"]), int(g["size"])
+    a, b, _ = O.synthetic_batch(bs, size, seed=int(g["seed"]))
+    from dahitra_amd.models.losses import argmax_mask
+    for mode in ("eval", "train"):
+        net = make_net(name)
+        net.load_state_dict(O.large_margin_state(name))
+        net.train(mode == "train")
+        with torch.no_grad():
+            y = net(a.cuda(), b.cuda())
+        scale = float(g["scale_" + mode])
+        st = 4 if size > 64 else 1
+        err = float((y.cpu()[..., ::st, ::st] - torch.from_numpy(g["logits_" + mode])).abs().max()) / scale
+        assert err <= 2e-4, (name, mode, err)
+        mask = argmax_mask(y).cpu().numpy().astype(np.uint8)
+        ref_mask = np.unpackbits(g["mask_" + mode])[:mask.size].reshape(mask.shape)
+        margin = np.asarray(g["margin_" + mode]).astype(np.float32)
+        band = margin <= 4e-4 * scale
+        diff = mask != ref_mask
+        print("%s %s (large margins): flips total %d, outside band %d, band fraction %.5f, logits rel err %.2e"
+              % (name, mode, int(diff.sum()), int((diff & ~band).sum()), float(band.mean()), err))
+        assert float(band.mean()) < 0.002
+        assert int((diff & ~band).sum()) == 0
+
+
+def _bf16_rounded(sd):
+    return {k: (v.bfloat16().float() if v.dtype.is_floating_point and v.dim() > 1 else v) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
+def test_bf16_mode_within_twice_the_bf16_input_rounding_error(name):
+    """bf16 throughput mode against the fp32 oracle, bounded by the error the fp32 HIP pipeline itself shows when only
+    its weights and images are rounded to bf16 (the unavoidable part of computing in bf16): relative L2 distance of
+    the logits <= 2x that, mask flips outside a band of 2x the measured bf16 logit error = 0 on the large-margin state."""
     cfg = O.get_config(name)
     size = 256 if name == "newUNetTrans" else 128
     a, b, lab = O.synthetic_batch(2, size, seed=5, n_class=cfg["n_class"])
-    sd = O.deterministic_state(name)
+    sd = O.large_margin_state(name)
     with torch.no_grad():
-        ref = O.forward(sd, name, a, b, training=True)
-    net = make_net(name, "bf16").train()
-    with torch.no_grad():
-        y = net(a.cuda(), b.cuda()).cpu()
+        ref = O.forward({k: v.clone() for k, v in sd.items()}, name, a, b, training=True)
+
+    def run(dtype, state, x1, x2):
+        net = make_net(name, dtype)
+        net.load_state_dict(state)
+        net.train()
+        with torch.no_grad():
+            return net(x1.cuda(), x2.cuda()).float().cpu()
+
+    l2 = lambda u, v: float((u - v).norm() / v.norm())
+    y32 = run("fp32", sd, a, b)
+    y_round = run("fp32", _bf16_rounded(sd), a.bfloat16().float(), b.bfloat16().float())
+    y = run("bf16", sd, a, b)
+    sens, got = l2(y_round, ref), l2(y, ref)
     scale = float(ref.abs().max())
     err = float((y - ref).abs().max()) / scale
-    flips = float((torch.argmax(y, 1) != torch.argmax(ref, 1)).float().mean())
-    print("bf16 %s: logits rel err %.3e, mask disagreement %.4f" % (name, err, flips))
-    assert err < 0.15 and flips < 0.03
+    err_round = float((y_round - ref).abs().max()) / scale
+    margin = (ref[:, 0] - ref[:, 1]).abs()
+    diff = torch.argmax(y, 1) != torch.argmax(ref, 1)
+    band = margin <= 2.0 * err * scale
+    print("bf16 %s: logits l2 %.3e (fp32 pipeline on bf16-rounded inputs: %.3e, fp32 pipeline: %.1e); max err %.3e "
+          "(rounded inputs %.3e); mask flips %d of %d, outside the 2*err band %d, band fraction %.4f"
+          % (name, got, sens, l2(y32, ref), err, err_round, int(diff.sum()), diff.numel(), int((diff & ~band).sum()),
+             float(band.float().mean())))
+    assert l2(y32, ref) <= 2e-4
+    assert got <= 2.0 * sens, (got, sens)
+    assert int((diff & ~band).sum()) == 0
+    assert float(diff.float().mean()) < 0.03
 
 
 def test_bf16_mode_resnet50_within_the_nets_own_sensitivity():

@@ -156,3 +156,20 @@ def test_xbd_state_has_the_modulelist_aliases(golden_dir):
             sd["transformer_decoder_3.layers.7.1.fn.fn.net.3.bias"]
     n = sum(int(np.prod(s)) for k, s, r in O.state_spec("xbd_unet_transformer") if not O.is_buffer(r) and not O.is_alias(r))
     assert n == 13250765
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
+def test_large_margin_fixture_matches_oracle(name, golden_dir):
+    """the antisymmetric-head fixture (written by the reference, oracle/make_golden.py MARGIN_CASES): the oracle gives
+    the same masks at EVERY pixel and the stored per-pixel margins put < 0.2 % of them in the 4e-4 tie band"""
+    g = np.load(os.path.join(golden_dir, "margin_%s.npz" % name))
+    a, b, _ = O.synthetic_batch(int(g["batch"]), int(g["size"]), seed=int(g["seed"]))
+    for mode in ("eval", "train"):
+        with torch.no_grad():
+            y = O.forward(O.large_margin_state(name), name, a, b, training=(mode == "train"))
+        mask = torch.argmax(y, 1).numpy().astype(np.uint8)
+        assert np.array_equal(np.packbits(mask), g["mask_" + mode])
+        margin = (y[:, 0] - y[:, 1]).abs().numpy()
+        assert np.allclose(margin, g["margin_" + mode].astype(np.float32), rtol=2e-3, atol=1e-6)
+        assert float((g["margin_" + mode].astype(np.float32) <= 4e-4 * float(g["scale_" + mode])).mean()) < 0.002
+        assert abs(float(y.double().sum()) - float(g["sum_" + mode])) <= 1e-6 * float(g["abssum_" + mode])

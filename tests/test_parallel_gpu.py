@@ -100,3 +100,35 @@ def test_two_ranks_match_the_single_process_emulation(tmp_path, use_graph):
         if v.dtype.is_floating_point and "running_" not in k:
             worst = max(worst, float((v - ref[k].cpu()).abs().max()))
     assert worst <= 1e-6, worst
+
+
+def _run_bench(extra_env, launcher):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.update(extra_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable] + launcher + ["bench.py", "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "4",
+                                           "--no-cpu-baseline", "--no-parity-mode"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # exactly ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_multi_gpu_code_path_runs_over_rccl_with_one_rank():
+    """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run ... bench.py), with ONE
+    rank on the one GPU of this box and DAHITRA_FORCE_DIST=1: init_process_group("nccl") = RCCL, parameter broadcast,
+    barrier, graph replay, all-reduce of the flat gradient arena, AdamW with 1/world after the replay, MAX-reduce
+    of the time, destroy_process_group.  Same final loss as the plain single-process run (the collective over one rank is
+    the identity; the kernels and their order are the same)."""
+    port = _free_port()
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    dist_line = _run_bench({"DAHITRA_FORCE_DIST": "1"}, launcher)
+    plain = _run_bench({}, [])
+    assert dist_line["n_gpus"] == 1 and dist_line["value"] > 0
+    assert dist_line["config"]["hip_graph"] is True
+    a, b = dist_line["config"]["final_loss"], plain["config"]["final_loss"]
+    assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (a, b)
