@@ -73,33 +73,36 @@ def _cpu_info():
     return model, (len(phys) or None), os.cpu_count()
 
 
-def cpu_baseline(seconds_budget=24.0):
-    """the oracle's train step (port of models/trainer.py:302-308) on the host cores: median step time at N = all
-    physical cores (capped at 64: these batch-4 convolutions stop scaling well before that) and at N = 8"""
+def cpu_baseline(seconds_budget=28.0):
+    """the oracle's train step (port of models/trainer.py:302-308) on the host cores.  These batch-4 convolutions do
+    not scale with the thread count (measured on the 128-core host: 64 threads are SLOWER than 8), so the step is
+    timed at 8 / 16 / 32 / 64 threads and `value` is the best of them, with its thread count in `cores`."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cdnet_ref as O
     model, phys, logical = _cpu_info()
     bs = 4
     a, b, lab = O.synthetic_batch(bs, SIZE, seed=1234)
+    cap = phys or logical or 1
+    counts = [t for t in (8, 16, 32, 64) if t <= cap] or [cap]
     runs = {}
-    n_all = min(phys or logical or 1, 64)
-    for threads in dict.fromkeys((n_all, min(8, n_all))):
+    for threads in counts:
         torch.set_num_threads(threads)
         st = O.TrainState(NET, O.deterministic_state(NET), lr=0.01)
         st.step(a, b, lab)                      # warm-up
         times, t_start = [], time.time()
-        while len(times) < 3 or (time.time() - t_start < seconds_budget / 2 and len(times) < 12):
+        while len(times) < 3 or (time.time() - t_start < seconds_budget / len(counts) and len(times) < 9):
             t0 = time.time()
             st.step(a, b, lab)
             times.append(time.time() - t0)
         times.sort()
         runs[threads] = (bs / times[len(times) // 2], len(times))
-    return {"value": round(runs[n_all][0], 3), "unit": "image-pairs/s", "cores": n_all, "kind": "port",
-            "sample": "median of %d train steps of batch %d, %s fp32 256x256 (oracle/cdnet_ref.py, torch CPU)"
-                      % (runs[n_all][1], bs, NET),
+    best = max(runs, key=lambda t: runs[t][0])
+    return {"value": round(runs[best][0], 3), "unit": "image-pairs/s", "cores": best, "kind": "port",
+            "sample": "median of %d train steps of batch %d, %s fp32 256x256 (oracle/cdnet_ref.py, torch CPU), best of "
+                      "the thread counts in by_threads" % (runs[best][1], bs, NET),
             "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
-            "value_8_threads": round(runs[min(8, n_all)][0], 3)}
+            "by_threads": {str(t): round(v[0], 3) for t, v in runs.items()}}
 
 
 def build(args, dtype, dev, local, rank, use_graph):
@@ -187,11 +190,18 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of one HIP graph")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: libraries that print banners on fd 1 (RCCL prints its version block at
+    # init) are diverted to stderr for the whole run; the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from dahitra_amd import ops, parallel
 
     rank, local, world = parallel.init_from_env("nccl")        # sets the device BEFORE any other GPU call
+    torch.manual_seed(1234)      # init_weights draws from the device generator, whose default seed differs per process
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
@@ -331,7 +341,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.net == NET and args.img == SIZE:
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res))
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist.is_initialized():
         dist.barrier(device_ids=[local])
         dist.destroy_process_group()
