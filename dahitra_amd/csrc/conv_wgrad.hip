@@ -44,11 +44,18 @@ union F8 {
     unsigned short s[8];
 };
 
-template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
+// CIG = 2 (3x3 layers with >= 64 input channels and a 64-wide co tile): a 512-thread workgroup whose second group of four
+// waves takes the NEXT 32 input channels of the same pixels -- a 64co x 64ci slab per workgroup.  The dY tile is staged
+// once for both halves, and a layer writes (and dh_wgrad_reduce reads) half as many partial slabs at the same number of
+// resident waves: the split-K slab traffic of the bench step was ~500 MB written + ~500 MB read per step.
+template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT, int CIG>
+__global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     constexpr int CT = CTT;
+    constexpr int NTHR = 256 * CIG;
+    constexpr int ITT = IT * CIG;                  // input channels per workgroup
     constexpr int CW = CTT / 16;                   // co sub-tiles (waves along co)
     constexpr int KSPLIT = 4 / CW;                 // wave groups along the pixel (K) dimension of a tile
+    static_assert(CIG == 1 || KSPLIT == 1, "the ci wave groups exist for the 64-wide co tile only");
     constexpr int KPW = TH * TW / KSPLIT;          // pixels of a tile per wave group
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
     constexpr int HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
@@ -56,17 +63,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
     constexpr int NI = IT / 16;
     // LDS pitches are ODD multiples of 32 B: a half-wave of ds_read_b64_tr_b16 then touches 8 consecutive
     // pixel rows x 32 B = 8 distinct bank windows of the 256-byte bank row (conflict-free)
-    constexpr int XP = lds_pitch(IT * (int)sizeof(T));     // halo pitch (bytes)
+    constexpr int XP = lds_pitch(ITT * (int)sizeof(T));    // halo pitch (bytes)
     constexpr int DP = lds_pitch(CT * (int)sizeof(T));     // dY tile pitch (bytes)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;                      // [HH*HWD][XP]
     unsigned char* dyt = smem + HH * HWD * XP;       // [128][DP]
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, cig = tid >> 8;
     const int pl = lane & 15, g = lane >> 4;
     const int cw = wv % CW, kq = wv / CW;
     const int cot = blockIdx.x / p.ci_tiles, cit = blockIdx.x % p.ci_tiles;
-    const int co0 = cot * CT, ci0 = cit * IT;
+    const int co0 = cot * CT, ci0 = cit * ITT;
     const int kz = blockIdx.y, grp = blockIdx.z;
     const int imgs_per_group = p.N / p.groups;
     const int tiles_per_img = p.tilesX * p.tilesY;
@@ -80,8 +87,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
 
     // Software pipeline: the global loads of tile t+1 are issued into registers before the MFMAs of tile t
     // and committed to LDS after them, so HBM/L2 latency hides under the matrix work (T14-style split stage).
-    constexpr int XQ = IT * (int)sizeof(T) / 16, DQ = CT * (int)sizeof(T) / 16;
-    constexpr int NXV = (HH * HWD * XQ + 255) / 256, NDV = (TH * TW * DQ + 255) / 256;
+    constexpr int XQ = ITT * (int)sizeof(T) / 16, DQ = CT * (int)sizeof(T) / 16;
+    constexpr int NXV = (HH * HWD * XQ + NTHR - 1) / NTHR, NDV = (TH * TW * DQ + NTHR - 1) / NTHR;
     uint4 rx[NXV], rd[NDV];
     // Everything about a 16-byte piece that does not depend on the tile is computed ONCE: its halo / tile position,
     // its element offset from the tile origin and how it is loaded (0: zeros, 1: one 16-byte load, 2: ragged channel
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
     {
 #pragma unroll
         for (int i = 0; i < NXV; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTHR;
             const int px = idx / XQ, q = idx % XQ;
             x_hy[i] = px / HWD; x_hx[i] = px % HWD;
             const int c = ci0 + q * EPV;
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < NDV; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTHR;
             const int px = idx / DQ, q = idx % DQ;
             d_py[i] = px / TW; d_px[i] = px % TW;
             const int c = co0 + q * EPV;
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
     // at 32-bit byte offsets from the image base -- an out-of-range piece reads offset 0 and is zeroed by a select.
     // At two to three waves per SIMD this per-tile code is one dependent chain, so its length is time.
     const int xcb = (ci0 + (tid % XQ) * EPV), dcb = (co0 + (tid % DQ) * EPV);            // channel of this thread's pieces
-    const bool fast = xal_ && dal_ && (ci0 + IT <= p.Cin || (p.Cin - ci0) % EPV == 0) &&
+    const bool fast = xal_ && dal_ && (ci0 + ITT <= p.Cin || (p.Cin - ci0) % EPV == 0) &&
                       (co0 + CT <= p.Cout || (p.Cout - co0) % EPV == 0);
     auto fetch = [&]() {      // loads the tile the counter points at, then advances the counter
         const int n = grp * imgs_per_group + f_n;
@@ -191,12 +198,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
     auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < NXV; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTHR;
             if (idx < HH * HWD * XQ) *reinterpret_cast<uint4*>(halo + (idx / XQ) * XP + (idx % XQ) * 16) = rx[i];
         }
 #pragma unroll
         for (int i = 0; i < NDV; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTHR;
             if (idx < TH * TW * DQ) *reinterpret_cast<uint4*>(dyt + (idx / DQ) * DP + (idx % DQ) * 16) = rd[i];
         }
     };
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
                         const int hp = (row * STRIDE + kh * DIL) * HWD + col * STRIDE + kw * DIL;
 #pragma unroll
                         for (int i = 0; i < NI; ++i) {
-                            const float b = *reinterpret_cast<const float*>(halo + hp * XP + (i * 16 + pl) * 4);
+                            const float b = *reinterpret_cast<const float*>(halo + hp * XP + (cig * IT + i * 16 + pl) * 4);
                             acc[kh * KS + kw][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[kh * KS + kw][i], 0, 0, 0);
                         }
                     }
@@ -231,9 +238,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
             const int c0 = g * 4;
             const unsigned char* a_base = TR ? dyt + (kq * KPW + c0 + (pl >> 2)) * DP + (cw * 16 + (pl & 3) * 4) * 2
                                              : dyt + (kq * KPW + c0) * DP + (cw * 16 + pl) * 2;
-            const unsigned char* b_base = (TR && STRIDE == 1)
+            const unsigned char* b_base = ((TR && STRIDE == 1)
                 ? halo + (kq * (KPW / TW) * STRIDE * HWD + c0 * STRIDE + (pl >> 2)) * XP + ((pl & 3) * 4) * 2
-                : halo + (kq * (KPW / TW) * STRIDE * HWD + c0 * STRIDE) * XP + pl * 2;
+                : halo + (kq * (KPW / TW) * STRIDE * HWD + c0 * STRIDE) * XP + pl * 2) + cig * IT * 2;
 #pragma unroll
             for (int kk = 0; kk < KPW; kk += 32) {
                 F8 a;
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
     }
     // partial slab: [grp][kz][tap][Cout][Cin]
     // (one 64-bit base + 32-bit offsets, bounds hoisted: the slab of one workgroup is far below 2^31 elements)
-    const int cob = co0 + cw * 16 + g * 4, cib = ci0 + pl;
+    const int cob = co0 + cw * 16 + g * 4, cib = ci0 + cig * IT + pl;
     float* out = p.part + ((size_t)grp * p.splitk + kz) * TAPS * p.Cout * p.Cin + (size_t)cob * p.Cin + cib;
     const int tstride = p.Cout * p.Cin;
     bool okj[4], oki[NI];
@@ -330,14 +337,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs p) {
     }
 }
 
-// dw_oihw[g][o][i][tap] (+)= sum_kz part[g][kz][tap][o][i]: 32 consecutive outputs of one group per workgroup
+// dw_oihw[g][o][i][tap] (+)= sum_kz part[g][kz][tap][o][i].  A workgroup = 8 split-K phases x 32 lanes; a lane owns FOUR
+// consecutive slab elements (one 16-byte load per slab; Cin % 4 == 0) or one (ragged Cin), i.e. 128 / 32 outputs per
+// workgroup -- wgrad_reduce_epb() is the host's side of that contract.  The slab reads of a step are ~250-500 MB: the
+// former 4-byte-per-lane form ran at ~3.3 TB/s.
+static inline int wgrad_reduce_epb(int I) { return (I & 3) == 0 ? 128 : 32; }
 __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ part, int splitk, int taps, int Oslab, int O,
-                                                   int I, float* __restrict__ dw, int accumulate, long block, float (*red)[33]) {
-    // 256 threads = 8 split-K phases x 32 consecutive outputs
+                                                   int I, float* __restrict__ dw, int accumulate, long block, float (*red)[132]) {
     const long n = (long)O * I * taps;
     const int lane = threadIdx.x & 31, ph = threadIdx.x >> 5;
-    const long i = block * 32 + lane;
-    float acc = 0.f;
+    const bool vec = (I & 3) == 0;
+    const long i = vec ? (block * 32 + lane) * 4 : block * 32 + lane;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     // lanes walk the SLAB order (tap, o, ci) so the splitk reads are coalesced; the single OIHW write scatters
     int tap = 0, ci = 0, o = 0;
     if (i < n) {
@@ -346,31 +357,54 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ par
         tap = (int)(i / ((long)I * O));
         const size_t slab = (size_t)taps * Oslab * I;
         const float* src = part + ((size_t)tap * Oslab + o) * I + ci;
-        // independent partial sums (the slab loop is otherwise a chain of dependent-latency loads)
-        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int k = ph;
-        for (; k + 24 < splitk; k += 32) {
-            acc += src[(size_t)k * slab];
-            a1 += src[(size_t)(k + 8) * slab];
-            a2 += src[(size_t)(k + 16) * slab];
-            a3 += src[(size_t)(k + 24) * slab];
+        if (vec) {
+            // four independent partial sums (otherwise the slab loop is a chain of dependent-latency loads)
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            auto add = [](float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+            int k = ph;
+            for (; k + 24 < splitk; k += 32) {
+                add(a0, *reinterpret_cast<const float4*>(src + (size_t)k * slab));
+                add(a1, *reinterpret_cast<const float4*>(src + (size_t)(k + 8) * slab));
+                add(a2, *reinterpret_cast<const float4*>(src + (size_t)(k + 16) * slab));
+                add(a3, *reinterpret_cast<const float4*>(src + (size_t)(k + 24) * slab));
+            }
+            for (; k < splitk; k += 8) add(a0, *reinterpret_cast<const float4*>(src + (size_t)k * slab));
+            acc[0] = (a0.x + a1.x) + (a2.x + a3.x); acc[1] = (a0.y + a1.y) + (a2.y + a3.y);
+            acc[2] = (a0.z + a1.z) + (a2.z + a3.z); acc[3] = (a0.w + a1.w) + (a2.w + a3.w);
+        } else {
+            float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int k = ph;
+            for (; k + 24 < splitk; k += 32) {
+                acc[0] += src[(size_t)k * slab];
+                a1 += src[(size_t)(k + 8) * slab];
+                a2 += src[(size_t)(k + 16) * slab];
+                a3 += src[(size_t)(k + 24) * slab];
+            }
+            for (; k < splitk; k += 8) acc[0] += src[(size_t)k * slab];
+            acc[0] = (acc[0] + a1) + (a2 + a3);
         }
-        for (; k < splitk; k += 8) acc += src[(size_t)k * slab];
-        acc = (acc + a1) + (a2 + a3);
     }
-    red[ph][lane] = acc;
-    __syncthreads();
-    if (ph == 0 && i < n) {
-        float s = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) s += red[r][lane];
-        const size_t d = ((size_t)o * I + ci) * taps + tap;
-        if (accumulate) dw[d] += s; else dw[d] = s;
+    for (int e = 0; e < 4; ++e) red[ph][lane * 4 + e] = acc[e];
+    __syncthreads();
+    // 128 (vec) / 32 outputs: thread t < 128 finishes element t = lane' * 4 + e
+    const int t = threadIdx.x;
+    if (t < (vec ? 128 : 32)) {
+        const int l2 = vec ? t >> 2 : t, e = vec ? t & 3 : 0;
+        const long i2 = vec ? (block * 32 + l2) * 4 + e : block * 32 + l2;
+        if (i2 < n) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += red[r][l2 * 4 + e];
+            const int ci2 = (int)(i2 % I), o2 = (int)((i2 / I) % O), tap2 = (int)(i2 / ((long)I * O));
+            const size_t d = ((size_t)o2 * I + ci2) * taps + tap2;
+            if (accumulate) dw[d] += s; else dw[d] = s;
+        }
     }
 }
 __global__ void wgrad_reduce_oihw_kernel(const float* __restrict__ part, int splitk, int taps, int Oslab, int O, int I,
                                          float* __restrict__ dw, int accumulate) {      // blockIdx.y = group
-    __shared__ float red[8][33];
+    __shared__ float red[8][132];
     const long n = (long)O * I * taps;
     wgrad_reduce_block(part + (size_t)blockIdx.y * splitk * taps * Oslab * I, splitk, taps, Oslab, O, I,
                        dw + (size_t)blockIdx.y * n, accumulate, blockIdx.x, red);
@@ -383,7 +417,7 @@ struct WgReduceJob {
     int splitk, taps, Oslab, O, I, accumulate, first_block, nblocks;
 };
 __global__ void wgrad_reduce_multi_kernel(const WgReduceJob* __restrict__ jobs, int njobs) {
-    __shared__ float red[8][33];
+    __shared__ float red[8][132];
     int j = 0;
     while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
     const WgReduceJob job = jobs[j];
@@ -391,10 +425,10 @@ __global__ void wgrad_reduce_multi_kernel(const WgReduceJob* __restrict__ jobs, 
                        (long)blockIdx.x - job.first_block, red);
 }
 
-template <typename T, int KS, int STRIDE, int IT, int DIL, int CT>
+template <typename T, int KS, int STRIDE, int IT, int DIL, int CT, int CIG = 1>
 int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
-    size_t lds = (size_t)HH * HWD * lds_pitch(IT * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T));
+    size_t lds = (size_t)HH * HWD * lds_pitch(IT * CIG * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T));
     if (CT < 64) {                                     // the end-of-kernel wave-group combine parks accumulators here
         const size_t red = (size_t)(CT / 16) * KS * KS * (IT / 16) * 64 * 16;
         if (lds < red) lds = red;
@@ -411,24 +445,32 @@ int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
                 DH_FAIL("conv_wgrad: cannot raise dynamic LDS to %zu", lds);
             }
         }
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL(kern, grid, dim3(256 * CIG), lds, st, a);
         DH_CHECK_LAUNCH("conv_wgrad");
         return 0;
     };
-    if (tr) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true, DIL, CT>);
-    return go(conv_wgrad_kernel<T, KS, STRIDE, IT, false, DIL, CT>);
+    if (tr) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true, DIL, CT, CIG>);
+    return go(conv_wgrad_kernel<T, KS, STRIDE, IT, false, DIL, CT, CIG>);
+}
+// 3x3 layers with >= 64 input channels and a 64-wide co tile run the 512-thread, 64co x 64ci variant (CIG = 2)
+static inline bool wide_ci3x3(int Cin, int CoutUse, int ks) {
+    static const bool off = getenv("DAHITRA_WGRAD_CIG1") != nullptr;       // A/B switch for tools/kbench.py
+    return !off && ks == 3 && Cin >= 64 && co_tile(CoutUse) == 64;
 }
 template <typename T, int KS, int STRIDE, int IT, int DIL = 1>
 int launch(const WgArgs& a, bool tr, hipStream_t st) {
     if (co_tile(a.CoutUse) == 16) return launch_ct<T, KS, STRIDE, IT, DIL, 16>(a, tr, st);
     if (co_tile(a.CoutUse) == 32) return launch_ct<T, KS, STRIDE, IT, DIL, 32>(a, tr, st);
+    if constexpr (KS == 3 && IT == 32 && STRIDE == 1) {      // (stride 2: the 64-channel halo does not fit / is slower)
+        if (wide_ci3x3(a.Cin, a.CoutUse, KS)) return launch_ct<T, KS, STRIDE, IT, DIL, 64, 2>(a, tr, st);
+    }
     return launch_ct<T, KS, STRIDE, IT, DIL, 64>(a, tr, st);
 }
 
 template <typename T>
 int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
     const bool wide = a.Cin > 32 && ks == 1 && stride == 1;   // 64-wide ci tiles only where accumulators / LDS fit
-    const int it = ks == 4 ? 16 : (wide ? 64 : 32);
+    const int it = ks == 4 ? 16 : ((wide || (stride == 1 && wide_ci3x3(a.Cin, a.CoutUse, ks))) ? 64 : 32);
     a.ci_tiles = dh_cdiv(a.Cin, it);
     if (ks == 3 && stride == 1 && a.dil == 2) return launch<T, 3, 1, 32, 2>(a, tr, st);
     if (ks == 3 && stride == 1) return launch<T, 3, 1, 32>(a, tr, st);
@@ -446,12 +488,13 @@ extern "C" int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, 
     const long tiles = (long)(N / (groups > 0 ? groups : 1)) * dh_cdiv(OW, TW) * dh_cdiv(OH, TH);
     // NOTE: stride is not known here; the 64-wide ci tile is only used at stride 1, where this
     // estimate is exact; at stride 2 it under-estimates the slab count (harmless: more workgroups)
-    const int it = ks == 4 ? 16 : ((Cin > 32 && ks == 1) ? 64 : 32);
+    const bool big = wide_ci3x3(Cin, Cout, ks);       // 512-thread workgroups, one per CU
+    const int it = ks == 4 ? 16 : (((Cin > 32 && ks == 1) || big) ? 64 : 32);
     const long slabs = (long)dh_cdiv(Cout, co_tile(Cout)) * dh_cdiv(Cin, it) * (groups > 0 ? groups : 1);
     // workgroups in flight: the 3x3 / 4x4 kernels hold two workgroups per CU (168+ registers per lane), so 512 fill the
     // chip in ONE round -- a second round only doubles the partial-slab traffic and the per-workgroup prologue / slab
     // write (measured: layer3 115.6 -> 107.6 us, classifier 75.7 -> 65.1 us); the light 1x1 kernels fit four per CU
-    const long target = ks == 1 ? 1024 : 512;
+    const long target = ks == 1 ? 1024 : (big ? 256 : 512);
     long sk = (target + slabs - 1) / slabs;      // ... however small Cout x Cin is ...
     if (sk > tiles / 8) sk = tiles / 8;        // ... but at least 8 pixel tiles per workgroup (slab write amortised)
     if (sk > 1024) sk = 1024;
@@ -493,7 +536,7 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
     const int taps = ks * ks;
     const int oreal = Cout_real > 0 ? Cout_real : Cout;     // dy may carry zero-padded channels
     const long n = (long)oreal * Cin * taps;
-    hipLaunchKernelGGL(wgrad_reduce_oihw_kernel, dim3(dh_cdiv(n, 32), groups), dim3(256), 0, st, a.part, a.splitk,
+    hipLaunchKernelGGL(wgrad_reduce_oihw_kernel, dim3(dh_cdiv(n, wgrad_reduce_epb(Cin)), groups), dim3(256), 0, st, a.part, a.splitk,
                        taps, Cout, oreal, Cin, dw_oihw, accumulate);
     DH_CHECK_LAUNCH("wgrad_reduce");
     return 0;
@@ -518,6 +561,9 @@ extern "C" int dh_conv2d_wgrad_partial(int dtype, const void* x, const void* dy,
                              npix_valid, use_tr, Cout_real, cin_pitch, dilation, workspace, stream, 1, splitk_out);
 }
 extern "C" int dh_wgrad_reduce_job_size(void) { return (int)sizeof(WgReduceJob); }
+// outputs served by one workgroup of dh_wgrad_reduce_multi for a layer with `Cin` input channels (job.nblocks =
+// ceil(O * I * taps / this))
+extern "C" int dh_wgrad_reduce_outputs_per_block(int Cin) { return wgrad_reduce_epb(Cin); }
 extern "C" int dh_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream) {
     if (njobs <= 0) return 0;
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),

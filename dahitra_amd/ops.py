@@ -192,7 +192,7 @@ class WgradPlan:
         return buf
 
     def add(self, part, dw, splitk, taps, oslab, o, i, accumulate):
-        nb = cdiv(o * i * taps, 32)
+        nb = cdiv(o * i * taps, _lib.lib().dh_wgrad_reduce_outputs_per_block(i))
         self.jobs.append(self._Job(part.data_ptr(), dw.data_ptr(), splitk, taps, oslab, o, i, int(accumulate),
                                    self.blocks, nb))
         self.blocks += nb

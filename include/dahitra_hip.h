@@ -70,7 +70,7 @@ long dh_conv2d_wgrad_workspace_size(int N, int OH, int OW, int Cin, int Cout, in
  * must stay alive until the batched reduce) and *splitk_out receives their count (0: the single-slab 1x1 case wrote
  * dW directly).  dh_wgrad_reduce_multi then sums every deferred layer of a backward pass in one launch.  jobs_dev:
  * njobs records {const float* part; float* dw; int splitk, taps, Oslab, O, I, accumulate, first_block, nblocks;}
- * (dh_wgrad_reduce_job_size() bytes each) sorted by first_block, nblocks = ceil(O*I*taps / 32), Oslab = the Cout the
+ * (dh_wgrad_reduce_job_size() bytes each) sorted by first_block, nblocks = ceil(O*I*taps / dh_wgrad_reduce_outputs_per_block(I)), Oslab = the Cout the
  * kernel was launched with, O = Cout_real.  (autograd convolution_backward's weight term, as dh_conv2d_wgrad.) */
 int dh_conv2d_wgrad_partial(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N, int H,
                             int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad, int groups,
@@ -78,6 +78,7 @@ int dh_conv2d_wgrad_partial(int dtype, const void* x, const void* dy, float* dw_
                             int* splitk_out, void* stream);
 int dh_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 int dh_wgrad_reduce_job_size(void);
+int dh_wgrad_reduce_outputs_per_block(int Cin);
 int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, int ks, int groups);
 
 /* OIHW fp32 master weight -> kernel layouts: fwd [ks*ks][OPad][I] T and (optional) the data-gradient
