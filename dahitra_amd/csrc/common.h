@@ -71,6 +71,24 @@ __device__ __forceinline__ void stv(bf16* p, const float (&o)[8]) {
     *reinterpret_cast<uint4*>(p) = v;
 }
 
+// one 16-byte piece <-> fp32 values (8 bf16 / 4 fp32)
+__device__ __forceinline__ void unpack16(const uint4& u, float (&o)[8]) {
+    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+    o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
+    o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack16(const uint4& u, float (&o)[4]) {
+    o[0] = __uint_as_float(u.x); o[1] = __uint_as_float(u.y); o[2] = __uint_as_float(u.z); o[3] = __uint_as_float(u.w);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float (&o)[16 / sizeof(T)]);
+template <> __device__ __forceinline__ uint4 pack16<bf16>(const float (&o)[8]) {
+    return make_uint4(f2bf2(o[0], o[1]), f2bf2(o[2], o[3]), f2bf2(o[4], o[5]), f2bf2(o[6], o[7]));
+}
+template <> __device__ __forceinline__ uint4 pack16<float>(const float (&o)[4]) {
+    return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
+}
+
 // sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane of the row: four row-rotate adds on
 // the vector ALU instead of four ds_bpermute round trips through the LDS crossbar
 __device__ __forceinline__ float row16_sum(float v) {

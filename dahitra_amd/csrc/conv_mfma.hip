@@ -11,7 +11,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
                              int OH, int OW, int Cout, int CoutPad, int ks, int stride, int pad, int act,
                              int npix_valid, long w_image_stride, void* y_preact, int dilation, const void* gate_out,
                              const void* gate_y, const float* gate_mean, const float* gate_invstd, int gate_groups,
-                             void* stream) {
+                             const float* in_scale, const float* in_shift, int in_groups, void* stream) {
     const int esz = dtype == DH_DTYPE_BF16 ? 2 : 4;
     DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "conv2d_fwd: bad dtype %d", dtype);
     DH_REQUIRE((Cin * esz) % 64 == 0, "conv2d_fwd: Cin=%d must be a multiple of %d", Cin, 64 / esz);
@@ -30,6 +30,9 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
         DH_REQUIRE(stats_partial && gate_mean && gate_invstd && Cout % 4 == 0 && act == DH_ACT_NONE && N % a.gate_groups == 0,
                    "conv2d_fwd: BN-backward gating needs stats_partial, mean/invstd, Cout %% 4 == 0, no activation");
     }
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_groups = in_groups > 0 ? in_groups : 1;
+    if (in_scale) DH_REQUIRE(in_shift && N % a.in_groups == 0 && w_image_stride == 0,
+                             "conv2d_fwd: BatchNorm-on-load needs in_shift and N %% in_groups == 0");
     a.rw = pick_rw(N, OH, OW, Cin, ks, stride);
     a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, 4 * a.rw);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

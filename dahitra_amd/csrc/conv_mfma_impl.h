@@ -66,6 +66,13 @@ struct ConvArgs {
     const float* gate_mean;     // [groups][Cout]
     const float* gate_invstd;   // [groups][Cout]
     int gate_groups;
+    // BatchNorm-apply + ReLU on LOAD (train mode): x is the PRE-normalisation output of the previous conv and the kernel
+    // consumes relu(x * in_scale[g][c] + in_shift[g][c]) -- the separate bn_apply pass over that tensor (one read + one
+    // write of the whole activation) disappears.  Zero padding applies to the post-activation tensor: out-of-image halo
+    // pieces stay zero.
+    const float* in_scale;      // [in_groups][Cin], or null: off
+    const float* in_shift;
+    int in_groups;
 };
 
 namespace {
@@ -91,7 +98,7 @@ template <> struct Mma<bf16> {
     }
 };
 
-template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST, bool INBN = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     constexpr int TH = 4 * RW;
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
@@ -103,6 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     using HL = HaloLayout<STRIDE>;
     unsigned char* halo = smem;                                  // [HH*HWD] rows, HL layout
     unsigned char* wts = smem + HH * HWD * HL::PITCH;            // [TAPS*NT] rows, swizzled pitch 64
+    float* bnp = reinterpret_cast<float*>(wts + TAPS * NT * WPITCH);   // INBN: [2][Cin] scale | shift of this image's group
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -164,7 +172,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
             rw[i] = ok ? v : make_uint4(0, 0, 0, 0);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int c0) {
+        if constexpr (INBN) {
+            // this thread's pieces all hold the same channels (piece index = tid & 3): c0 + (tid & 3) * PIECE ..
+            constexpr int PC = 16 / (int)sizeof(T);
+            float sc[PC], sh[PC];
+            const float* sp = bnp + c0 + (tid & 3) * PC;
+#pragma unroll
+            for (int j = 0; j < PC; j += 4) {
+                *reinterpret_cast<float4*>(sc + j) = *reinterpret_cast<const float4*>(sp + j);
+                *reinterpret_cast<float4*>(sh + j) = *reinterpret_cast<const float4*>(sp + p.Cin + j);
+            }
+#pragma unroll
+            for (int i = 0; i < NHV; ++i) {
+                if (hoff[i] == ~0u) continue;            // padding of the post-activation tensor: stays zero
+                float v[PC];
+                unpack16(rh[i], v);
+#pragma unroll
+                for (int j = 0; j < PC; ++j) v[j] = fmaxf(v[j] * sc[j] + sh[j], 0.f);
+                rh[i] = pack16<T>(v);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NHV; ++i) {
             const int idx = tid + i * 256;
@@ -179,10 +207,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
 
     // PF = false (layers with at most two channel chunks): nothing to pipeline inside a workgroup, so the staging
     // registers are not kept alive across the MFMAs -- fewer VGPRs, one more resident workgroup per CU does the overlap
+    if constexpr (INBN) {
+        const int grp = n / (p.N / p.in_groups);
+        for (int c = tid; c < p.Cin; c += 256) {
+            bnp[c] = p.in_scale[grp * p.Cin + c];
+            bnp[p.Cin + c] = p.in_shift[grp * p.Cin + c];
+        }
+        __syncthreads();
+    }
     if (PF) fetch(0);
     for (int c0 = 0; c0 < p.Cin; c0 += CK) {
         if (!PF) fetch(c0);
-        commit();
+        commit(c0);
         __syncthreads();
         if (PF && c0 + CK < p.Cin) fetch(c0 + CK);
         // The taps run column-major (kw outer) so that a pixel fragment -- halo row h = r*STRIDE + kh*DIL of column kw -- is
@@ -421,14 +457,15 @@ static inline int pick_rw(int N, int OH, int OW, int Cin, int ks, int stride) {
     return 2;
 }
 
-template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST>
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST, bool INBN = false>
 int launch_fast(const ConvArgs& a, hipStream_t st) {
     constexpr int TH = 4 * RW;
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
-    const size_t staging = (size_t)HH * HWD * HaloLayout<STRIDE>::PITCH + (size_t)KS * KS * NT * WPITCH;
+    const size_t staging = (size_t)HH * HWD * HaloLayout<STRIDE>::PITCH + (size_t)KS * KS * NT * WPITCH +
+                           (INBN ? (size_t)2 * a.Cin * sizeof(float) : 0);
     const size_t otile = (size_t)4 * 2 * NT * 4 + (size_t)TH * TW * (NT * sizeof(T) + 16);     // epilogue: stats scratch + transposed tile
     const size_t lds = staging > otile ? staging : otile;
-    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW, DIL, PF, FAST>;
+    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW, DIL, PF, FAST, INBN>;
     static bool attr_done = false;      // once per instantiation (and never inside a graph capture)
     if (lds > 64 * 1024 && !attr_done) {
         attr_done = true;
@@ -449,6 +486,14 @@ template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>
 int launch_pf(const ConvArgs& a, hipStream_t st) {
     // compact-epilogue instantiation: 16-byte output pieces, no gating / pre-activation copy / GELU
     const bool fast = (a.Cout % (16 / (int)sizeof(T))) == 0 && !a.gate_y && !a.y2 && a.act != DH_ACT_GELU;
+    if constexpr (KS == 3 && STRIDE == 1 && DIL == 1) {        // BN-apply + ReLU on load: the 3x3 consumers of a BN layer
+        if (a.in_scale) {
+            if (fast) return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, true, true>(a, st);
+            return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, false, true>(a, st);
+        }
+    } else if (a.in_scale) {
+        DH_FAIL("conv_mfma: BatchNorm-on-load is built for 3x3 stride-1 dilation-1 convolutions (got %dx%d s%d d%d)", KS, KS, STRIDE, DIL);
+    }
     if (fast) return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, true>(a, st);
     return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, false>(a, st);
 }

@@ -34,6 +34,10 @@ struct WgArgs {
     int CoutUse;       // output channels that carry a gradient (<= Cout: dy may be zero-padded to a K-chunk)
     int direct;        // 0: write the partial slab; 1 / 2: split-K is 1 and the slab layout IS the destination layout
                        // (1x1, one group), so assign (1) or accumulate (2) straight into dW and skip the reduce launch
+    // BatchNorm-apply + ReLU on load (see ConvArgs::in_scale): x is the pre-normalisation tensor of the previous layer
+    const float* in_scale;      // [in_groups][Cin] or null
+    const float* in_shift;
+    int in_groups;
 };
 
 constexpr int lds_pitch(int row_bytes) { return ((row_bytes / 32) & 1) ? row_bytes : row_bytes + 32; }
@@ -68,6 +72,7 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;                      // [HH*HWD][XP]
     unsigned char* dyt = smem + HH * HWD * XP;       // [128][DP]
+    float* bnp = reinterpret_cast<float*>(dyt + TH * TW * DP);      // in_scale: [in_groups][2][ITT] scale | shift
 
     const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, cig = tid >> 8;
     const int pl = lane & 15, g = lane >> 4;
@@ -137,8 +142,12 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     const int xcb = (ci0 + (tid % XQ) * EPV), dcb = (co0 + (tid % DQ) * EPV);            // channel of this thread's pieces
     const bool fast = xal_ && dal_ && (ci0 + ITT <= p.Cin || (p.Cin - ci0) % EPV == 0) &&
                       (co0 + CT <= p.Cout || (p.Cout - co0) % EPV == 0);
+    unsigned x_okmask = 0;    // pieces of the fetched halo that lie inside the image (BatchNorm-on-load leaves padding zero)
+    int c_bng = 0;            // BatchNorm group of the fetched tile's image
     auto fetch = [&]() {      // loads the tile the counter points at, then advances the counter
         const int n = grp * imgs_per_group + f_n;
+        x_okmask = 0;
+        c_bng = p.in_scale ? n / (p.N / p.in_groups) : 0;
         const int oy0 = f_ty * TH, ox0 = f_tx * TW;
         const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
         if (fast) {
@@ -153,6 +162,7 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
                 const bool ok = x_mode[i] != 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && lin < p.in_npix;
                 const uint4 v = *reinterpret_cast<const uint4*>(xb + (ok ? (unsigned)lin * xps + (unsigned)xcb * (unsigned)sizeof(T) : 0u));
                 rx[i] = ok ? v : make_uint4(0, 0, 0, 0);
+                x_okmask |= ok ? (1u << i) : 0u;
             }
 #pragma unroll
             for (int i = 0; i < NDV; ++i) {
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
                 const int iy = iy0 + x_hy[i], ix = ix0 + x_hx[i];
                 const bool ok = x_mode[i] != 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && iy * p.W + ix < p.in_npix;
                 if (ok) {
+                    x_okmask |= 1u << i;
                     const T* src = xin + (x_hy[i] * p.W + x_hx[i]) * p.CinPitch + xcb;
                     if (x_mode[i] == 1) rx[i] = *reinterpret_cast<const uint4*>(src);
                     else rx[i] = load_tail(src, p.Cin - xcb);
@@ -196,6 +207,24 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
         f_n += dn;
     };
     auto commit = [&]() {
+        if (p.in_scale) {          // x = relu(x * scale + shift) on its way into LDS; this thread's pieces share their channels
+            float sc[EPV], sh[EPV];
+            const float* sp = bnp + c_bng * 2 * ITT + (tid % XQ) * EPV;
+#pragma unroll
+            for (int j = 0; j < EPV; j += 4) {
+                *reinterpret_cast<float4*>(sc + j) = *reinterpret_cast<const float4*>(sp + j);
+                *reinterpret_cast<float4*>(sh + j) = *reinterpret_cast<const float4*>(sp + ITT + j);
+            }
+#pragma unroll
+            for (int i = 0; i < NXV; ++i) {
+                if (!((x_okmask >> i) & 1u)) continue;
+                float v[EPV];
+                unpack16(rx[i], v);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) v[j] = fmaxf(v[j] * sc[j] + sh[j], 0.f);
+                rx[i] = pack16<T>(v);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NXV; ++i) {
             const int idx = tid + i * NTHR;
@@ -208,6 +237,15 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
         }
     };
 
+    if (p.in_scale) {
+        for (int i = tid; i < p.in_groups * ITT; i += NTHR) {
+            const int gi = i / ITT, c = i % ITT;
+            const bool ok = ci0 + c < p.Cin;
+            bnp[(gi * 2 + 0) * ITT + c] = ok ? p.in_scale[gi * p.Cin + ci0 + c] : 0.f;
+            bnp[(gi * 2 + 1) * ITT + c] = ok ? p.in_shift[gi * p.Cin + ci0 + c] : 0.f;
+        }
+        __syncthreads();
+    }
     if (kz < ntiles) fetch();
     for (int tile = kz; tile < ntiles; tile += p.splitk) {
         commit();
@@ -428,7 +466,8 @@ __global__ void wgrad_reduce_multi_kernel(const WgReduceJob* __restrict__ jobs, 
 template <typename T, int KS, int STRIDE, int IT, int DIL, int CT, int CIG = 1>
 int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
-    size_t lds = (size_t)HH * HWD * lds_pitch(IT * CIG * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T));
+    size_t lds = (size_t)HH * HWD * lds_pitch(IT * CIG * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T)) +
+                 (a.in_scale ? (size_t)a.in_groups * 2 * IT * CIG * sizeof(float) : 0);
     if (CT < 64) {                                     // the end-of-kernel wave-group combine parks accumulators here
         const size_t red = (size_t)(CT / 16) * KS * KS * (IT / 16) * 64 * 16;
         if (lds < red) lds = red;
@@ -511,12 +550,16 @@ extern "C" long dh_conv2d_wgrad_workspace_size(int N, int OH, int OW, int Cin, i
 static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N,
                              int H, int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad,
                              int groups, int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation,
-                             void* workspace, void* stream, int defer, int* splitk_out) {
+                             void* workspace, void* stream, int defer, int* splitk_out, const float* in_scale = nullptr,
+                             const float* in_shift = nullptr, int in_groups = 1) {
     DH_REQUIRE(groups == 1 || (groups == N && ks == 1), "conv2d_wgrad: groups must be 1 or N (with ks=1)");
     WgArgs a;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
     DH_REQUIRE(dilation == 1 || (dilation == 2 && ks == 3 && stride == 1), "conv2d_wgrad: dilation %d unsupported here", dilation);
     a.dil = dilation;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_groups = in_groups > 0 ? in_groups : 1;
+    if (in_scale) DH_REQUIRE(in_shift && groups == 1 && N % a.in_groups == 0 && (Cin * (dtype == DH_DTYPE_BF16 ? 2 : 4)) % 16 == 0,
+                             "conv2d_wgrad: BatchNorm-on-load needs in_shift, one weight group, N %% in_groups == 0, 16-byte channel pieces");
     a.CinPitch = cin_pitch > 0 ? cin_pitch : Cin;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = OH; a.OW = OW; a.Cout = Cout; a.pad = pad;
     a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, TH);
@@ -559,6 +602,18 @@ extern "C" int dh_conv2d_wgrad_partial(int dtype, const void* x, const void* dy,
     DH_REQUIRE(groups == 1 && splitk_out, "conv2d_wgrad_partial: one group only");
     return conv2d_wgrad_impl(dtype, x, dy, dw_oihw, accumulate, N, H, W, Cin, OH, OW, Cout, ks, stride, pad, groups,
                              npix_valid, use_tr, Cout_real, cin_pitch, dilation, workspace, stream, 1, splitk_out);
+}
+// dh_conv2d_wgrad / dh_conv2d_wgrad_partial (splitk_out != NULL: deferred) with BatchNorm-apply + ReLU on the load of x:
+// x is the PRE-normalisation output of the previous convolution, the gradient is taken against
+// relu(x * in_scale[g][ci] + in_shift[g][ci]) (g = image / (N / in_groups)); padding stays zero.
+extern "C" int dh_conv2d_wgrad_bn_in(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N,
+                                     int H, int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad,
+                                     int use_tr, int Cout_real, int dilation, const float* in_scale, const float* in_shift,
+                                     int in_groups, void* workspace, int* splitk_out, void* stream) {
+    DH_REQUIRE(in_scale && in_shift, "conv2d_wgrad_bn_in: scale / shift missing");
+    return conv2d_wgrad_impl(dtype, x, dy, dw_oihw, accumulate, N, H, W, Cin, OH, OW, Cout, ks, stride, pad, 1, 0, use_tr,
+                             Cout_real, 0, dilation, workspace, stream, splitk_out ? 1 : 0, splitk_out, in_scale, in_shift,
+                             in_groups);
 }
 extern "C" int dh_wgrad_reduce_job_size(void) { return (int)sizeof(WgReduceJob); }
 // outputs served by one workgroup of dh_wgrad_reduce_multi for a layer with `Cin` input channels (job.nblocks =

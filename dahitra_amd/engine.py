@@ -50,6 +50,9 @@ class Engine:
         # the reduction, but the gated MFMA launches slow down by as much (4054.6 vs 4054.1 pairs/s) -- so the
         # two-pass backward stays the default and the fused path is kept, tested, as an option.
         self.fused_bn_bwd = os.environ.get("DAHITRA_BN_FUSION", "0") == "1"
+        # BatchNorm-apply + ReLU fused into the load of the consumer convolution (forward and weight gradient): the
+        # normalised activation of conv1 of every BasicBlock / of the head's first conv is never materialised
+        self.lazy_bn = os.environ.get("DAHITRA_NO_LAZY_BN", "0") != "1"
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -128,8 +131,14 @@ class Engine:
                        out_hw=(H, W), alg_flops=flops, dilation=dilation, gate=gate)
         return Gated(*r) if gate is not None else r
 
-    def conv_bn(self, x, wkey, bnkey, ks, stride, pad, groups, relu, residual=None, dilation=1):
+    def conv_bn(self, x, wkey, bnkey, ks, stride, pad, groups, relu, residual=None, dilation=1, lazy=False):
+        """conv + BatchNorm (+ residual) (+ ReLU).  x may be an ops.BnInput (the previous layer's lazy output).
+        lazy=True (train mode, ReLU, no residual; the ONLY consumer must be a 3x3 stride-1 convolution and its weight
+        gradient): the normalised activation is never written -- the call returns an ops.BnInput (pre-BN conv output +
+        scale / shift) and the consumer applies relu(y * scale + shift) while it loads (the bn_apply pass, one read
+        and one write of the activation, disappears)."""
         cout = self.shapes[wkey][0]
+        lazy = lazy and self.training and self.lazy_bn and relu and residual is None and not self.fused_bn_bwd
         gamma, beta = self.p[bnkey + ".weight"], self.p[bnkey + ".bias"]
         rm, rv = self.p[bnkey + ".running_mean"], self.p[bnkey + ".running_var"]
         act = RELU if relu else NONE
@@ -138,7 +147,7 @@ class Engine:
             N, OH, OW, _ = y.shape
             mean, invstd, scale, shift = ops.bn_finalize(st, cout, groups, (N // groups) * OH * OW, gamma, beta, rm, rv,
                                                          BN_MOMENTUM, BN_EPS, nbt=self.p[bnkey + ".num_batches_tracked"])
-            out = ops.bn_apply(y, scale, shift, groups, act, residual)
+            out = ops.BnInput(y, scale, shift, groups) if lazy else ops.bn_apply(y, scale, shift, groups, act, residual)
         else:
             # eval: BatchNorm folds into the convolution -- scale into the packed weights, shift as the bias
             scale, shift = ops.bn_eval_params(gamma, beta, rm, rv, BN_EPS)
@@ -231,7 +240,7 @@ class Engine:
         return out, bwd
 
     def basic_block(self, x, pfx, stride, groups):
-        h, b1 = self.conv_bn(x, pfx + ".conv1.weight", pfx + ".bn1", 3, stride, 1, groups, True)
+        h, b1 = self.conv_bn(x, pfx + ".conv1.weight", pfx + ".bn1", 3, stride, 1, groups, True, lazy=True)
         has_ds = (pfx + ".downsample.0.weight") in self.shapes
         if has_ds:
             idt, bds = self.conv_bn(x, pfx + ".downsample.0.weight", pfx + ".downsample.1", 1, stride, 0, groups, False)
@@ -254,7 +263,8 @@ class Engine:
 
     def bottleneck(self, x, pfx, stride, dilation, groups):
         """Bottleneck (models/resnet.py:76-122): 1x1 -> 3x3 (stride / dilation, pad = dilation) -> 1x1 (+identity)."""
-        h1, b1 = self.conv_bn(x, pfx + ".conv1.weight", pfx + ".bn1", 1, 1, 0, groups, True)
+        h1, b1 = self.conv_bn(x, pfx + ".conv1.weight", pfx + ".bn1", 1, 1, 0, groups, True,
+                              lazy=(stride == 1 and dilation == 1))           # consumed by the 3x3 conv2 only
         h2, b2 = self.conv_bn(h1, pfx + ".conv2.weight", pfx + ".bn2", 3, stride, dilation, groups, True,
                               dilation=dilation)
         has_ds = (pfx + ".downsample.0.weight") in self.shapes
@@ -629,7 +639,7 @@ class Engine:
                                   "transformer_decoder", cfg["dec_depth"], BIT_HEADS, cfg["dec_dim_head"], L)
         dec4 = dec.view(S2, fh, fw, DIM)
         upd = ops.absdiff_upsample4(dec4[:B], dec4[B:])
-        h, b_c0 = self.conv_bn(upd, "classifier.0.weight", "classifier.1", 3, 1, 1, 1, True)
+        h, b_c0 = self.conv_bn(upd, "classifier.0.weight", "classifier.1", 3, 1, 1, 1, True, lazy=True)
         logits, b_out = self._head_out(h, "classifier.3.weight", "classifier.3.bias")
         if not self.need_grad:
             return logits, None
@@ -775,7 +785,7 @@ class Engine:
         cat2 = torch.empty(B, h2, w2, 2 * c2, dtype=self.dtype, device=s2.device)
         ops.copy_channels(s2[:B], 0, cat2, 0, c2)
         ops.copy_channels(s2[B:], 0, cat2, c2, c2)
-        y, b20 = self.conv_bn(cat2, "conv_layer2_0.0.weight", "conv_layer2_0.1", 3, 1, 1, 1, True)
+        y, b20 = self.conv_bn(cat2, "conv_layer2_0.0.weight", "conv_layer2_0.1", 3, 1, 1, 1, True, lazy=True)
         y2 = ops.conv2d(y, self.pk["conv_layer2_0.3.weight"].fwd, 32, 3, 1, 1, bias=self.p["conv_layer2_0.3.bias"],
                         residual=o3)
         o2, bu2 = self._up_conv(2, y2)

@@ -243,6 +243,12 @@ def _nb(*tensors):
     return sum(t.numel() * t.element_size() for t in tensors if t is not None)
 
 
+def _bn_in_args(b):
+    if b is None:
+        return _vp(0), _vp(0), _ci(0)
+    return P(b.scale), P(b.shift), _ci(b.groups)
+
+
 def _gate_args(gate):
     if gate is None:
         return _vp(0), _vp(0), _vp(0), _vp(0), _ci(0)
@@ -250,10 +256,35 @@ def _gate_args(gate):
     return P(out_relu), P(y), P(mean), P(invstd), _ci(groups)
 
 
+class BnInput:
+    """An activation that exists only as (pre-normalisation conv output y, per-group scale / shift): the consumer
+    kernels apply relu(y * scale + shift) while they load it (dh_conv2d_fwd's in_scale, dh_conv2d_wgrad_bn_in)."""
+    __slots__ = ("y", "scale", "shift", "groups")
+
+    def __init__(self, y, scale, shift, groups):
+        self.y, self.scale, self.shift, self.groups = y, scale, shift, groups
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+    @property
+    def device(self):
+        return self.y.device
+
+    @property
+    def dtype(self):
+        return self.y.dtype
+
+
 def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT_NONE, want_stats=False,
            want_preact=False, npix_valid=0, w_image_stride=0, out_hw=None, alg_flops=0, dilation=1, gate=None):
     """gate = (out_relu | None, y_pre_bn, mean, invstd, groups): BN-backward gating of a data-gradient launch; the
-    call then returns (g, partials) for bn_bwd_from_partials (see include/dahitra_hip.h)."""
+    call then returns (g, partials) for bn_bwd_from_partials (see include/dahitra_hip.h).
+    x may be a BnInput: BatchNorm-apply + ReLU happen on load."""
+    bn_in = x if isinstance(x, BnInput) else None
+    if bn_in is not None:
+        x = bn_in.y
     N, H, W, Cin = x.shape
     if gate is not None:
         want_stats = True
@@ -275,7 +306,7 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     with _Prof(key, flops, _nb(x, y, wp, residual, pre)):
         _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
               _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
-              _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), S())
+              _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), *_bn_in_args(bn_in), S())
     out = [y]
     if want_stats:
         out.append(stats)
@@ -301,7 +332,7 @@ def linear(x2d, wp, cout, bias=None, residual=None, act=ACT_NONE, want_preact=Fa
     pre = torch.empty_like(y) if want_preact else None
     _call("dh_conv2d_fwd", _ci(dt(x2d)), P(x2d), P(wp), P(y), P(bias), P(residual), _vp(0), _ci(images), _ci(Hh),
           _ci(16), _ci(Cin), _ci(Hh), _ci(16), _ci(cout), _ci(cpad), _ci(1), _ci(1), _ci(0), _ci(act), _ci(rpi),
-          _cl(w_image_stride), P(pre), _ci(1), *_gate_args(None), S())
+          _cl(w_image_stride), P(pre), _ci(1), *_gate_args(None), *_bn_in_args(None), S())
     # note: with rows_per_image % 16 != 0 the image stride used by the kernel (Hh*16 rows) would differ
     # from rpi; callers guarantee rpi % 16 == 0 whenever images > 1.
     assert images == 1 or rpi % 16 == 0
@@ -311,7 +342,10 @@ def linear(x2d, wp, cout, bias=None, residual=None, act=ACT_NONE, want_preact=Fa
 def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=True, cout_real=0, cin=0, dilation=1,
                  defer=True):
     """dw (OIHW fp32, or [N, Cout, Cin] when groups == N) (+)= weight gradient.
-    cin > 0: use only the first `cin` channels of x (x keeps its own channel pitch)."""
+    cin > 0: use only the first `cin` channels of x (x keeps its own channel pitch).
+    x may be a BnInput (gradient against relu(y * scale + shift), computed on load)."""
+    if isinstance(x, BnInput):
+        return _conv2d_wgrad_bn_in(x, dy, dw, ks, stride, pad, accumulate, use_tr, cout_real, dilation, defer)
     N, H, W, pitch = x.shape
     Cin = cin if cin else pitch
     _, OH, OW, Cout = dy.shape
@@ -334,6 +368,23 @@ def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=
     _call("dh_conv2d_wgrad", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W), _ci(Cin),
           _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(groups), _ci(0), _ci(int(use_tr)),
           _ci(cout_real), _ci(pitch), _ci(dilation), P(ws), S())
+
+
+def _conv2d_wgrad_bn_in(b, dy, dw, ks, stride, pad, accumulate, use_tr, cout_real, dilation, defer):
+    x = b.y
+    N, H, W, Cin = x.shape
+    _, OH, OW, Cout = dy.shape
+    nbytes = _lib.lib().dh_conv2d_wgrad_workspace_size(N, OH, OW, Cin, Cout, ks, 1)
+    plan = _WGRAD_PLAN if defer else None
+    ws = plan.slab(nbytes) if plan is not None else workspace(nbytes, x.device)
+    sk = ctypes.c_int(0)
+    with _Prof("conv_wgrad<%s,ks%d,s%d>" % ("bf16" if x.dtype == torch.bfloat16 else "f32", ks, stride),
+               2.0 * N * OH * OW * Cout * Cin * ks * ks, _nb(x, dy)):
+        _call("dh_conv2d_wgrad_bn_in", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W), _ci(Cin),
+              _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(int(use_tr)), _ci(cout_real), _ci(dilation),
+              P(b.scale), P(b.shift), _ci(b.groups), P(ws), ctypes.byref(sk) if plan is not None else None, S())
+    if plan is not None and sk.value > 0:
+        plan.add(ws, dw, sk.value, ks * ks, Cout, cout_real if cout_real else Cout, Cin, accumulate)
 
 
 def linear_wgrad(x2d, dy2d, dw, accumulate=False, images=1, per_image=False, use_tr=True):

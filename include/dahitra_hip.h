@@ -51,7 +51,12 @@ int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const
                   const void* residual, float* stats_partial, int N, int H, int W, int Cin, int OH, int OW,
                   int Cout, int CoutPad, int ks, int stride, int pad, int act, int npix_valid,
                   long w_image_stride, void* y_preact, int dilation, const void* gate_out, const void* gate_y,
-                  const float* gate_mean, const float* gate_invstd, int gate_groups, void* stream);
+                  const float* gate_mean, const float* gate_invstd, int gate_groups, const float* in_scale,
+                  const float* in_shift, int in_groups, void* stream);
+/* in_scale / in_shift ([in_groups][Cin] fp32, NULL = off; 3x3 stride-1 convolutions): BatchNorm-apply + ReLU on LOAD.  x is
+ * then the PRE-normalisation output of the previous convolution and the kernel consumes relu(x * in_scale[g][ci] +
+ * in_shift[g][ci]), g = n / (N / in_groups); zero padding applies to that post-activation tensor.  Replaces the separate
+ * F.batch_norm + ReLU pass between two convolutions (models/resnet.py:60-65, models/help_funcs.py:11-13). */
 /* gate_* (all NULL / 0 = off): BatchNorm-backward gating of a data-gradient launch.  gate_y / gate_out are the
  * pre-normalisation input and the post-ReLU output (NULL: no ReLU) of the BN layer whose output gradient this launch
  * produces ([N][OH][OW][Cout] like y), gate_mean / gate_invstd its batch statistics [gate_groups][Cout].  The
@@ -76,6 +81,12 @@ int dh_conv2d_wgrad_partial(int dtype, const void* x, const void* dy, float* dw_
                             int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad, int groups,
                             int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation, void* workspace,
                             int* splitk_out, void* stream);
+/* dh_conv2d_wgrad (splitk_out == NULL) / dh_conv2d_wgrad_partial (splitk_out != NULL) against
+ * relu(x * in_scale[g][ci] + in_shift[g][ci]) computed on load (see dh_conv2d_fwd's in_scale) */
+int dh_conv2d_wgrad_bn_in(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N, int H, int W,
+                          int Cin, int OH, int OW, int Cout, int ks, int stride, int pad, int use_tr, int Cout_real,
+                          int dilation, const float* in_scale, const float* in_shift, int in_groups, void* workspace,
+                          int* splitk_out, void* stream);
 int dh_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 int dh_wgrad_reduce_job_size(void);
 int dh_wgrad_reduce_outputs_per_block(int Cin);

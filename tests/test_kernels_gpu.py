@@ -573,3 +573,52 @@ def test_conv2d_dgrad_wgrad_bench_scale(ops, dtype, cfg):
         close(dw2 - 0.25, w.grad, dtype, "wgrad deferred (+=)", scale=gscale, factor=fac)
         close(dw3, w.grad, dtype, "wgrad deferred (=)", scale=gscale, factor=fac)
     assert torch.equal(dw3, dw - 0.5) or float((dw3 - (dw - 0.5)).abs().max()) <= 1e-6 * gscale
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    dict(n=4, cin=64, cout=64, h=24, w=40, groups=2),          # layer1 conv2 shape class (8-row tile, no prefetch), ragged
+    dict(n=64, cin=128, cout=128, h=32, w=32, groups=2),       # 16-row tile
+    dict(n=64, cin=256, cout=256, h=32, w=32, groups=2),       # 16-row tile, 8 chunks (prefetch pipeline)
+    dict(n=2, cin=32, cout=2, h=40, w=56, groups=1),           # class head: one chunk, generic epilogue
+    dict(n=3, cin=32, cout=32, h=20, w=20, groups=1),
+])
+def test_batchnorm_relu_on_load_equals_materialised_activation(ops, dtype, cfg):
+    """dh_conv2d_fwd(in_scale, in_shift) and dh_conv2d_wgrad_bn_in on the PRE-normalisation tensor against the same
+    kernels fed the activation that dh_bn_apply materialises: same values enter the MFMAs (the transform is the same
+    fp32 expression, rounded once), so outputs agree to summation-order level; zero padding stays zero."""
+    N, C, H, W, G = cfg["n"], cfg["cin"], cfg["h"], cfg["w"], cfg["groups"]
+    y = dev(rnd((N, H, W, C), dtype, 701, 1.5), dtype)
+    scale = (rnd((G, C), torch.float32, 702, 0.3) + 1.0).cuda()
+    shift = rnd((G, C), torch.float32, 703, 0.5).cuda()
+    w = rnd((cfg["cout"], C, 3, 3), dtype, 704, (C * 9) ** -0.5)
+    wp, _ = ops.pack_weight(w.cuda(), dtype, want_dgrad=False)
+    b = rnd((cfg["cout"],), torch.float32, 705, 0.1).cuda()
+    act = ops.bn_apply(y, scale, shift, G, ops.ACT_RELU)
+    lazy = ops.BnInput(y, scale, shift, G)
+    want_stats = cfg["cout"] % 16 == 0
+    o0 = ops.conv2d(act, wp, cfg["cout"], 3, 1, 1, bias=b, want_stats=want_stats)
+    o1 = ops.conv2d(lazy, wp, cfg["cout"], 3, 1, 1, bias=b, want_stats=want_stats)
+    if want_stats:
+        assert torch.equal(o0[1], o1[1])
+        o0, o1 = o0[0], o1[0]
+    assert torch.equal(o0, o1), float((o0.float() - o1.float()).abs().max())
+    # against torch: relu(bn) with zero padding AFTER the activation
+    gi = torch.arange(N) // (N // G)
+    ref_act = torch.relu(y.float().cpu() * scale.cpu()[gi][:, None, None, :] + shift.cpu()[gi][:, None, None, :])
+    ref_act = ref_act.to(dtype).float()
+    want = F.conv2d(nchw(ref_act), w, b.cpu(), 1, 1)
+    close(nchw(o1), want, dtype, "conv on BN+ReLU-on-load")
+    # weight gradient
+    dy = dev(rnd((N, H, W, cfg["cout"]), dtype, 706), dtype)
+    dw0 = torch.zeros(cfg["cout"], C, 3, 3, device="cuda")
+    dw1 = torch.zeros_like(dw0)
+    ops.conv2d_wgrad(act, dy, dw0, 3, 1, 1)
+    ops.conv2d_wgrad(lazy, dy, dw1, 3, 1, 1)
+    assert torch.equal(dw0, dw1), float((dw0 - dw1).abs().max())
+    plan = ops.WgradPlan(y.device)
+    dw2 = torch.zeros_like(dw0)
+    with plan:
+        ops.conv2d_wgrad(lazy, dy, dw2, 3, 1, 1, accumulate=True)
+        plan.run()
+    assert torch.equal(dw0, dw2)

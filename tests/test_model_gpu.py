@@ -544,3 +544,24 @@ def test_ragged_shapes_bf16_runs_and_tracks():
     err = float((y.detach().cpu() - ref).abs().max()) / float(ref.abs().max())
     assert err < 0.15, err
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans", R50])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_lazy_batchnorm_activations_equal_materialised(name, dtype, monkeypatch):
+    """BatchNorm-apply + ReLU fused into the consumer's load (forward conv and weight gradient) against the path that
+    writes the normalised activation: the same numbers enter the same MFMAs"""
+    from dahitra_amd.models import losses
+    size = 256 if name == "newUNetTrans" else 64
+    a, b, lab = O.synthetic_batch(2, size, seed=51)
+    res = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("DAHITRA_NO_LAZY_BN", off)
+        net = make_net(name, dtype).train()
+        assert net._engine.lazy_bn == (off == "0")
+        y = net(a.cuda(), b.cuda())
+        losses.focal_loss(y, lab.cuda()).backward()
+        res[off] = (y.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert torch.equal(res["0"][0], res["1"][0])
+    for k, g in res["1"][1].items():
+        assert torch.equal(res["0"][1][k], g), k
