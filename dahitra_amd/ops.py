@@ -4,6 +4,7 @@ torch is used for device memory and the current HIP stream only; every arithmeti
 produced by a kernel of libdahitra_hip.so.  All activations are NHWC tensors of dtype float32
 (parity mode) or bfloat16 (throughput mode)."""
 import ctypes
+import os
 
 import torch
 
@@ -465,6 +466,20 @@ def bn_apply(x, scale, shift, groups=1, act=ACT_NONE, residual=None):
     return y
 
 
+_BN_SYNC = {}
+BN_BWD_PERSIST = os.environ.get("DAHITRA_NO_PERSIST_BN", "0") != "1"      # True: where faster; "force": wherever supported (tests)
+
+
+def bn_sync_words(device):
+    """the zeroed state of dh_bn_bwd_persist's device-wide barrier + fixed-point accumulators (one set per device, lives
+    forever: captured HIP graphs point at it)"""
+    key = str(device)
+    t = _BN_SYNC.get(key)
+    if t is None:
+        t = _BN_SYNC[key] = torch.zeros(8192, dtype=torch.int32, device=device)
+    return t
+
+
 def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accumulate=False, want_dres=False,
            mask_scale=None, mask_shift=None):
     C = x.shape[-1]
@@ -473,6 +488,14 @@ def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accu
     dres = torch.empty_like(x) if want_dres else None
     L = _lib.lib()
     ws = workspace(L.dh_bn_bwd_workspace_size(_cl(npix), C, groups), x.device)
+    if BN_BWD_PERSIST and (L.dh_bn_bwd_persist_preferred if BN_BWD_PERSIST is True else L.dh_bn_bwd_persist_supported)(
+            _ci(dt(x)), _cl(npix), C, groups):
+        # one persistent launch, tensors held on chip across a device-wide barrier: every tensor is read once
+        with _Prof("bn_bwd", 0, _nb(dout, out_relu, x) + _nb(dx, dres)):
+            _call("dh_bn_bwd_persist", P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
+                  _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(mask_scale), P(mask_shift),
+                  P(ws), P(bn_sync_words(x.device)), S())
+        return (dx, dres) if want_dres else dx
     # two passes (reduce, apply): dout / x (/ out) are read twice, dx (/ dres) written once
     with _Prof("bn_bwd", 0, 2 * _nb(dout, out_relu, x) + _nb(dx, dres)):
         _call("dh_bn_bwd", _ci(dt(x)), P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),

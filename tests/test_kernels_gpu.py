@@ -622,3 +622,50 @@ def test_batchnorm_relu_on_load_equals_materialised_activation(ops, dtype, cfg):
         ops.conv2d_wgrad(lazy, dy, dw2, 3, 1, 1, accumulate=True)
         plan.run()
     assert torch.equal(dw0, dw2)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=64, h=64, w=64, c=64, groups=2, mode="out"),        # layer1 bn2 (residual: mask from the stored output), full chip
+    dict(n=64, h=64, w=64, c=64, groups=2, mode="recompute"),  # layer1 bn1 (mask recomputed from x)
+    dict(n=64, h=32, w=32, c=256, groups=2, mode="out"),       # layer3
+    dict(n=64, h=32, w=32, c=128, groups=2, mode="none"),      # downsample BN (no ReLU)
+    dict(n=6, h=24, w=40, c=64, groups=2, mode="out"),         # small, ragged: partly filled workgroups, idle workgroups
+    dict(n=3, h=20, w=20, c=128, groups=1, mode="recompute"),
+])
+def test_batchnorm_backward_persistent_launch_equals_two_pass(ops, cfg, monkeypatch):
+    """csrc/bn_bwd_persist.hip (tensors held on chip across a device-wide barrier) against the reduce / finalize / apply
+    kernels: same formula, different summation order; repeated launches re-arm the barrier words"""
+    from dahitra_amd import _lib
+    dtype = torch.bfloat16
+    N, H, W, C, G = cfg["n"], cfg["h"], cfg["w"], cfg["c"], cfg["groups"]
+    assert _lib.lib().dh_bn_bwd_persist_supported(1, N * H * W, C, G)
+    x = dev(rnd((N, H, W, C), dtype, 801, 1.5), dtype)
+    dout = dev(rnd((N, H, W, C), dtype, 802), dtype)
+    mean = rnd((G, C), torch.float32, 803, 0.2).cuda()
+    invstd = (rnd((G, C), torch.float32, 804, 0.1) + 0.9).cuda()
+    gamma = (rnd((C,), torch.float32, 805, 0.1) + 1.0).cuda()
+    scale = (rnd((G, C), torch.float32, 806, 0.2) + 1.0).cuda()
+    shift = rnd((G, C), torch.float32, 807, 0.5).cuda()
+    out = torch.relu(dev(rnd((N, H, W, C), dtype, 808), dtype)) if cfg["mode"] == "out" else None
+    kw = dict(mask_scale=scale, mask_shift=shift) if cfg["mode"] == "recompute" else {}
+    res = {}
+    for persist in (False, True, True, True):
+        monkeypatch.setattr(ops, "BN_BWD_PERSIST", "force" if persist else False)
+        dg, db = torch.full((C,), 0.5, device="cuda"), torch.full((C,), -0.25, device="cuda")
+        r = ops.bn_bwd(dout, out, x, mean, invstd, gamma, dg, db, G, accumulate=True, want_dres=(out is not None), **kw)
+        dx, dres = r if out is not None else (r, None)
+        cur = (dx.float(), dg - 0.5, db + 0.25, None if dres is None else dres.float())
+        if persist and True in res:
+            for a, b in zip(cur, res[True]):          # repeated persistent launches: bitwise identical
+                assert a is None or torch.equal(a, b)
+        res[persist] = cur
+    assert int(ops.bn_sync_words(x.device)[2]) == 0, "the device-wide barrier timed out"
+    assert ops.bn_sync_words(x.device)[:2].abs().sum().item() == 0, "barrier words not re-armed"
+    two, per = res[False], res[True]
+    s = float(two[0].abs().max())
+    assert float((two[0] - per[0]).abs().max()) <= 2 ** -7 * s, "dx"                 # one bf16 ulp of the output scale
+    assert float((two[0] - per[0]).abs().mean()) <= 2e-4 * s
+    assert float((two[1] - per[1]).abs().max()) <= 2e-4 * float(two[1].abs().max()) + 1e-4, "dgamma"
+    assert float((two[2] - per[2]).abs().max()) <= 2e-4 * float(two[2].abs().max()) + 1e-4, "dbeta"
+    if two[3] is not None:
+        assert torch.equal(two[3], per[3]), "dres"
