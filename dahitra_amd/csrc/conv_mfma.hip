@@ -11,7 +11,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
                              int OH, int OW, int Cout, int CoutPad, int ks, int stride, int pad, int act,
                              int npix_valid, long w_image_stride, void* y_preact, int dilation, const void* gate_out,
                              const void* gate_y, const float* gate_mean, const float* gate_invstd, int gate_groups,
-                             const float* in_scale, const float* in_shift, int in_groups, void* stream) {
+                             const float* in_scale, const float* in_shift, int in_groups, int phase_mode, void* stream) {
     const int esz = dtype == DH_DTYPE_BF16 ? 2 : 4;
     DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "conv2d_fwd: bad dtype %d", dtype);
     DH_REQUIRE((Cin * esz) % 64 == 0, "conv2d_fwd: Cin=%d must be a multiple of %d", Cin, 64 / esz);
@@ -33,6 +33,14 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_groups = in_groups > 0 ? in_groups : 1;
     if (in_scale) DH_REQUIRE(in_shift && N % a.in_groups == 0 && w_image_stride == 0,
                              "conv2d_fwd: BatchNorm-on-load needs in_shift and N %% in_groups == 0");
+    a.phase_mode = phase_mode;
+    if (phase_mode) {
+        DH_REQUIRE(ks == 2 && stride == 1 && pad == 1 && dilation == 1 && !residual && !stats_partial && !y_preact && !gate_y &&
+                   !in_scale && w_image_stride == 0 && npix_valid == 0 && H == OH && W == OW && act != DH_ACT_GELU,
+                   "conv2d_fwd: phase mode is a plain 2x2 pad-1 convolution on equal input / output grids");
+        DH_REQUIRE(phase_mode == 1 ? (Cout == 128 && CoutPad == 128) : (phase_mode == 2 && Cin == 128 && Cout % 64 == 0),
+                   "conv2d_fwd: phase mode %d with Cin=%d Cout=%d", phase_mode, Cin, Cout);
+    }
     a.rw = pick_rw(N, OH, OW, Cin, ks, stride);
     a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, 4 * a.rw);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

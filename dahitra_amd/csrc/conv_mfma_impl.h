@@ -73,6 +73,14 @@ struct ConvArgs {
     const float* in_scale;      // [in_groups][Cin], or null: off
     const float* in_shift;
     int in_groups;
+    // 2x2 PHASE convolutions (KS = 2 only): conv3x3(nearest-upsample-x2(x)) == four 2x2 convolutions on x, one per output
+    // parity (a, b), with the 3x3 taps that fall on the same source pixel pre-summed (models/networks.py:251-256).
+    //   1: forward.  Logical Cout = 4 * 32 (one NT = 32 block per phase); block (a, b) reads rows oy + t + a - 1 and its
+    //      pixel (oy, ox) is STORED at (2 oy + a, 2 ox + b) of the [N][2 OH][2 OW][32] output (depth-to-space).
+    //   2: data gradient.  Logical Cin = 4 * 32: 32-channel group (a, b) is GATHERED from the [N][2 H][2 W][32] gradient at
+    //      (2 (iy + 1 - a) + a, 2 (ix + 1 - b) + b) (space-to-depth with a per-phase shift), so that all four phases share
+    //      the tap geometry of a 2x2 convolution with pad 1.
+    int phase_mode;
 };
 
 namespace {
@@ -121,7 +129,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     const int n = bt / p.tilesY;
     const int co0 = blockIdx.y * NT;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
+    int pad_y = p.pad, pad_x = p.pad;
+    if constexpr (KS == 2) {
+        if (p.phase_mode == 1) { pad_y = p.pad - (int)(blockIdx.y >> 1); pad_x = p.pad - (int)(blockIdx.y & 1); }
+    }
+    const int iy0 = oy0 * STRIDE - pad_y, ix0 = ox0 * STRIDE - pad_x;
 
     const unsigned char* xin = reinterpret_cast<const unsigned char*>(p.x) +
                                (size_t)n * p.H * p.W * p.Cin * sizeof(T);
@@ -142,14 +154,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     // SIMD the prologue runs as one dependent instruction chain (~10 cycles per instruction), so its length is time.
     // An out-of-image halo piece loads offset 0 (always mapped) and is zeroed by a select.
     unsigned hoff[NHV];      // ~0u: piece outside the image (or past the tile)
+    auto set_hoff = [&](int ph) {
 #pragma unroll
-    for (int i = 0; i < NHV; ++i) {
-        const int idx = tid + i * 256, px = idx >> 2, q = idx & 3;
-        const int hy = px / HWD, hx = px - hy * HWD;
-        const int iy = iy0 + hy, ix = ix0 + hx, lin = iy * p.W + ix;
-        const bool ok = idx < HH * HWD * 4 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && lin < p.in_npix;
-        hoff[i] = ok ? (unsigned)(lin * p.Cin) * (unsigned)sizeof(T) + q * 16 : ~0u;
-    }
+        for (int i = 0; i < NHV; ++i) {
+            const int idx = tid + i * 256, px = idx >> 2, q = idx & 3;
+            const int hy = px / HWD, hx = px - hy * HWD;
+            const int iy = iy0 + hy, ix = ix0 + hx, lin = iy * p.W + ix;
+            if (KS == 2 && p.phase_mode == 2) {
+                // phase (a, b) of the fine-grid gradient, shifted by (1 - a, 1 - b) coarse pixels; 32 channels per fine pixel
+                const int a = ph >> 1, b = ph & 1, ci = iy + 1 - a, cj = ix + 1 - b;
+                const bool ok = idx < HH * HWD * 4 && (unsigned)ci < (unsigned)p.H && (unsigned)cj < (unsigned)p.W;
+                hoff[i] = ok ? (unsigned)(((2 * ci + a) * (2 * p.W) + 2 * cj + b) * 32) * (unsigned)sizeof(T) + q * 16 : ~0u;
+            } else {
+                const bool ok = idx < HH * HWD * 4 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && lin < p.in_npix;
+                hoff[i] = ok ? (unsigned)(lin * p.Cin) * (unsigned)sizeof(T) + q * 16 : ~0u;
+            }
+        }
+    };
+    set_hoff(0);
     // weight piece i of a thread is row tid/4 + 64*i of the [TAPS*NT] staged rows: tap advances by 64/NT per piece,
     // the output channel stays -- one per-lane offset plus a uniform step
     static_assert(64 % NT == 0, "weight staging assumes NT divides 64");
@@ -159,6 +181,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     auto fetch = [&](int c0) {
         const unsigned char* xb = xin + (size_t)c0 * sizeof(T);
         const unsigned char* wb = wgt + (size_t)c0 * sizeof(T);
+        if constexpr (KS == 2) {
+            if (p.phase_mode == 2) {       // chunk -> (phase, channel offset inside the phase's 32 channels)
+                if (c0 > 0 && (c0 & 31) == 0) set_hoff(c0 >> 5);
+                xb = xin + (size_t)(c0 & 31) * sizeof(T);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NHV; ++i) {
             const bool ok = hoff[i] != ~0u;
@@ -432,9 +460,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
         for (int i = tid; i < TH * TW * PPR; i += 256) {
             const int px = i / PPR, q = i - px * PPR;
             const int oy = oy0 + px / TW, ox = ox0 + px % TW, c = co0 + q * PIECE;
-            if (oy < p.OH && ox < p.OW && oy * p.OW + ox < p.npix && c < p.Cout)
-                *reinterpret_cast<uint4*>(yout + (size_t)(oy * p.OW + ox) * p.Cout + c) =
-                    *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
+            if (oy < p.OH && ox < p.OW && oy * p.OW + ox < p.npix && c < p.Cout) {
+                size_t dst = (size_t)(oy * p.OW + ox) * p.Cout + c;
+                if (KS == 2 && p.phase_mode == 1)        // depth-to-space: phase (a, b) = this cout block, NT physical channels
+                    dst = (size_t)((2 * oy + (int)(blockIdx.y >> 1)) * (2 * p.OW) + 2 * ox + (int)(blockIdx.y & 1)) * NT + q * PIECE;
+                *reinterpret_cast<uint4*>(yout + dst) = *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
+            }
         }
     }
     if (p.stats) {
@@ -453,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
 // chip -- half the weight staging per FLOP and 8 instead of 6 LDS fragment reads per 16 MFMAs
 static inline int pick_rw(int N, int OH, int OW, int Cin, int ks, int stride) {
     // (layers with 1-2 channel chunks have nothing to pipeline and prefer more, smaller workgroups)
-    if (ks == 3 && stride == 1 && Cin >= 128 && OH >= 16 && (long)N * dh_cdiv(OH, 16) * dh_cdiv(OW, TW) >= 256) return 4;
+    if ((ks == 3 || ks == 2) && stride == 1 && Cin >= 128 && OH >= 16 && (long)N * dh_cdiv(OH, 16) * dh_cdiv(OW, TW) >= 256) return 4;
     return 2;
 }
 
@@ -513,11 +544,18 @@ int launch(const ConvArgs& a, hipStream_t st) {
         if (a.dil == 2) return a.rw == 4 ? launch_rw<T, KS, STRIDE, NT, 4, 2>(a, st) : launch_rw<T, KS, STRIDE, NT, 2, 2>(a, st);
         if (a.rw == 4) return launch_rw<T, KS, STRIDE, NT, 4, 1>(a, st);
     }
+    if constexpr (KS == 2) {
+        if (a.rw == 4) return launch_rw<T, KS, STRIDE, NT, 4, 1>(a, st);
+    }
     return launch_rw<T, KS, STRIDE, NT, 2, 1>(a, st);
 }
 
 template <typename T, int KS, int STRIDE>
 int launch_nt(const ConvArgs& a, hipStream_t st) {
+    if constexpr (KS == 2) {      // the phase convolutions: forward = one 32-channel cout block per phase
+        if (a.phase_mode == 1) return launch<T, KS, STRIDE, 32>(a, st);
+        return launch<T, KS, STRIDE, 64>(a, st);
+    }
     if (a.CoutPad % 64 == 0) return launch<T, KS, STRIDE, 64>(a, st);
     if (a.CoutPad % 32 == 0) return launch<T, KS, STRIDE, 32>(a, st);
     return launch<T, KS, STRIDE, 16>(a, st);
@@ -530,6 +568,7 @@ int launch_ks(const ConvArgs& a, int ks, int stride, hipStream_t st) {
     if (ks == 1 && stride == 1) return launch_nt<T, 1, 1>(a, st);
     if (ks == 1 && stride == 2) return launch_nt<T, 1, 2>(a, st);
     if (ks == 4 && stride == 1) return launch_nt<T, 4, 1>(a, st);     // space-to-depth stem
+    if (ks == 2 && stride == 1 && a.phase_mode) return launch_nt<T, 2, 1>(a, st);      // phase convs of upsample-x2 + 3x3
     DH_FAIL("conv_mfma: unsupported kernel %dx%d stride %d", ks, ks, stride);
 }
 

@@ -38,6 +38,9 @@ struct WgArgs {
     const float* in_scale;      // [in_groups][Cin] or null
     const float* in_shift;
     int in_groups;
+    // phase mode (KS = 2; see ConvArgs::phase_mode): blockIdx.z = output parity (a, b); dY is gathered from the fine grid at
+    // (2 oy + a, 2 ox + b) of [N][2 OH][2 OW][Cout], x is read with pad (1 - a, 1 - b); one slab set per phase
+    int phase_mode;
 };
 
 constexpr int lds_pitch(int row_bytes) { return ((row_bytes / 32) & 1) ? row_bytes : row_bytes + 32; }
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     const int cot = blockIdx.x / p.ci_tiles, cit = blockIdx.x % p.ci_tiles;
     const int co0 = cot * CT, ci0 = cit * ITT;
     const int kz = blockIdx.y, grp = blockIdx.z;
+    const int ph_a = (KS == 2 && p.phase_mode) ? (int)(blockIdx.z >> 1) : 0, ph_b = (KS == 2 && p.phase_mode) ? (int)(blockIdx.z & 1) : 0;
     const int imgs_per_group = p.N / p.groups;
     const int tiles_per_img = p.tilesX * p.tilesY;
     const int ntiles = imgs_per_group * tiles_per_img;
@@ -145,16 +149,16 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     unsigned x_okmask = 0;    // pieces of the fetched halo that lie inside the image (BatchNorm-on-load leaves padding zero)
     int c_bng = 0;            // BatchNorm group of the fetched tile's image
     auto fetch = [&]() {      // loads the tile the counter points at, then advances the counter
-        const int n = grp * imgs_per_group + f_n;
+        const int n = ((KS == 2 && p.phase_mode) ? 0 : grp * imgs_per_group) + f_n;
         x_okmask = 0;
         c_bng = p.in_scale ? n / (p.N / p.in_groups) : 0;
         const int oy0 = f_ty * TH, ox0 = f_tx * TW;
-        const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
+        const int iy0 = oy0 * STRIDE - p.pad + ph_a, ix0 = ox0 * STRIDE - p.pad + ph_b;
         if (fast) {
             const unsigned char* xb = reinterpret_cast<const unsigned char*>(
                 reinterpret_cast<const T*>(p.x) + (size_t)n * p.H * p.W * p.CinPitch);
             const unsigned char* db = reinterpret_cast<const unsigned char*>(
-                reinterpret_cast<const T*>(p.dy) + (size_t)n * p.OH * p.OW * p.Cout);
+                reinterpret_cast<const T*>(p.dy) + (size_t)n * p.OH * p.OW * p.Cout * ((KS == 2 && p.phase_mode) ? 4 : 1));
             const unsigned xps = (unsigned)p.CinPitch * (unsigned)sizeof(T), dps = (unsigned)p.Cout * (unsigned)sizeof(T);
 #pragma unroll
             for (int i = 0; i < NXV; ++i) {
@@ -166,8 +170,9 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
             }
 #pragma unroll
             for (int i = 0; i < NDV; ++i) {
-                const int oy = oy0 + d_py[i], ox = ox0 + d_px[i], lin = oy * p.OW + ox;
-                const bool ok = d_mode[i] != 0 && oy < p.OH && ox < p.OW && lin < p.npix;
+                const int oy = oy0 + d_py[i], ox = ox0 + d_px[i];
+                const int lin = (KS == 2 && p.phase_mode) ? (2 * oy + ph_a) * (2 * p.OW) + 2 * ox + ph_b : oy * p.OW + ox;
+                const bool ok = d_mode[i] != 0 && oy < p.OH && ox < p.OW && ((KS == 2 && p.phase_mode) || lin < p.npix);
                 const uint4 v = *reinterpret_cast<const uint4*>(db + (ok ? (unsigned)lin * dps + (unsigned)dcb * (unsigned)sizeof(T) : 0u));
                 rd[i] = ok ? v : make_uint4(0, 0, 0, 0);
             }
@@ -472,7 +477,7 @@ int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
         const size_t red = (size_t)(CT / 16) * KS * KS * (IT / 16) * 64 * 16;
         if (lds < red) lds = red;
     }
-    dim3 grid(dh_cdiv(a.CoutUse, CT) * a.ci_tiles, a.splitk, a.groups);
+    dim3 grid(dh_cdiv(a.CoutUse, CT) * a.ci_tiles, a.splitk, a.phase_mode ? 4 : a.groups);
     auto go = [&](auto kern) -> int {
         static bool attr_done = false;      // once per instantiation (and never inside a graph capture)
         if (lds > 64 * 1024 && !attr_done) {
@@ -517,6 +522,7 @@ int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
     if (ks == 1 && stride == 1) return wide ? launch<T, 1, 1, 64>(a, tr, st) : launch<T, 1, 1, 32>(a, tr, st);
     if (ks == 1 && stride == 2) return launch<T, 1, 2, 32>(a, tr, st);
     if (ks == 4 && stride == 1) return launch<T, 4, 1, 16>(a, tr, st);     // space-to-depth stem (12 real channels)
+    if (ks == 2 && stride == 1 && a.phase_mode) return launch<T, 2, 1, 32>(a, tr, st);
     DH_FAIL("conv_wgrad: unsupported kernel %d stride %d", ks, stride);
 }
 
@@ -557,6 +563,7 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
     DH_REQUIRE(dilation == 1 || (dilation == 2 && ks == 3 && stride == 1), "conv2d_wgrad: dilation %d unsupported here", dilation);
     a.dil = dilation;
+    a.phase_mode = 0;
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_groups = in_groups > 0 ? in_groups : 1;
     if (in_scale) DH_REQUIRE(in_shift && groups == 1 && N % a.in_groups == 0 && (Cin * (dtype == DH_DTYPE_BF16 ? 2 : 4)) % 16 == 0,
                              "conv2d_wgrad: BatchNorm-on-load needs in_shift, one weight group, N %% in_groups == 0, 16-byte channel pieces");
@@ -624,5 +631,121 @@ extern "C" int dh_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const WgReduceJob*>(jobs_dev), njobs);
     DH_CHECK_LAUNCH("wgrad_reduce_multi");
+    return 0;
+}
+
+// ---- 2x2 phase form of conv3x3(nearest-upsample-x2(x)) with 32 output channels: weight gradient per output parity ----
+static int phase_splitk(int N, int H, int W, int Cin) {
+    const long tiles = (long)N * dh_cdiv(W, TW) * dh_cdiv(H, TH);
+    const long slabs = (long)dh_cdiv(Cin, 32);                 // one 32-wide co tile x ci tiles, per phase
+    long sk = (128 + slabs - 1) / slabs;                       // 4 phases x slabs x sk ~ 512 workgroups
+    if (sk > tiles / 8) sk = tiles / 8;
+    return (int)(sk < 1 ? 1 : sk);
+}
+extern "C" long dh_conv2d_wgrad_phase_workspace_size(int N, int H, int W, int Cin) {
+    return (long)4 * phase_splitk(N, H, W, Cin) * 4 * 32 * Cin * 4;
+}
+extern "C" int dh_conv2d_wgrad_phase(int dtype, const void* x, const void* dy, int N, int H, int W, int Cin, int use_tr,
+                                     void* workspace, int* splitk_out, void* stream) {
+    DH_REQUIRE(splitk_out && workspace, "conv2d_wgrad_phase: workspace / splitk_out missing");
+    DH_REQUIRE((Cin * (dtype == DH_DTYPE_BF16 ? 2 : 4)) % 16 == 0, "conv2d_wgrad_phase: Cin=%d not 16-byte aligned", Cin);
+    WgArgs a;
+    a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
+    a.dil = 1; a.phase_mode = 1;
+    a.in_scale = nullptr; a.in_shift = nullptr; a.in_groups = 1;
+    a.CinPitch = Cin;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W; a.Cout = 32; a.pad = 1;
+    a.tilesX = dh_cdiv(W, TW); a.tilesY = dh_cdiv(H, TH);
+    a.CoutUse = 32;
+    a.groups = 1; a.splitk = phase_splitk(N, H, W, Cin);
+    a.direct = 0;
+    a.npix = H * W; a.in_npix = H * W;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rc = dtype == DH_DTYPE_BF16 ? launch_all<bf16>(a, 2, 1, use_tr != 0, st) : launch_all<float>(a, 2, 1, false, st);
+    if (rc) return rc;
+    *splitk_out = a.splitk;
+    return 0;
+}
+
+namespace {
+// dw[co][ci][kh][kw] (+)= sum over the phase taps (a, t) that read source row kh: kh 0 <- (0,0) (1,0); 1 <- (0,1) (1,0);
+// 2 <- (0,1) (1,1); columns alike.  dwab: [4 phases][32][Cin][2][2]
+__global__ void phase_wgrad_combine_kernel(const float* __restrict__ dwab, float* __restrict__ dw, int Cin, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // (co, ci)
+    if (i >= 32 * Cin) return;
+    const size_t pstride = (size_t)32 * Cin * 4;
+    const float* src = dwab + (size_t)i * 4;
+    float v[4][4];                                               // [phase][t * 2 + u]
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+        const float4 q = *reinterpret_cast<const float4*>(src + ph * pstride);
+        v[ph][0] = q.x; v[ph][1] = q.y; v[ph][2] = q.z; v[ph][3] = q.w;
+    }
+    // row sets: kh -> {(a, t)}
+    const int ra[3][2] = {{0, 1}, {0, 1}, {0, 1}}, rt[3][2] = {{0, 0}, {1, 0}, {1, 1}};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) s += v[ra[kh][m] * 2 + ra[kw][n]][rt[kh][m] * 2 + rt[kw][n]];
+            float* d = dw + (size_t)i * 9 + kh * 3 + kw;
+            if (accumulate) *d += s; else *d = s;
+        }
+}
+
+// W_ab[t][u] = sum of the 3x3 taps (kh, kw) whose source row / column under nearest-x2 upsampling is the same:
+// a = 0: t = 0 <- kh {0}, t = 1 <- kh {1, 2};  a = 1: t = 0 <- kh {0, 1}, t = 1 <- kh {2}
+template <typename T>
+__global__ void pack_phase_weights_kernel(const float* __restrict__ w, const float* __restrict__ bias, int Cin,
+                                          T* __restrict__ fwd, T* __restrict__ dgrad, float* __restrict__ bias4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // (co, ci)
+    if (i < 128 && bias4) bias4[i] = bias ? bias[i & 31] : 0.f;
+    if (i >= 32 * Cin) return;
+    const int co = i / Cin, ci = i % Cin;
+    float k[3][3];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) k[j / 3][j % 3] = w[(size_t)i * 9 + j];
+    const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};      // [a][t] -> kh range [lo, hi]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float s = 0.f;
+                    for (int kh = lo[a][t]; kh <= hi[a][t]; ++kh)
+                        for (int kw = lo[b][u]; kw <= hi[b][u]; ++kw) s += k[kh][kw];
+                    const int ph = a * 2 + b;
+                    // forward: [tap = t * 2 + u][ph * 32 + co][ci]
+                    if (fwd) stf(fwd + ((size_t)(t * 2 + u) * 128 + ph * 32 + co) * Cin + ci, s);
+                    // data gradient (a 2x2 pad-1 conv over the phase-gathered gradient): tap (kh', kw') = (1 - t, 1 - u),
+                    // [tap][ci][ph * 32 + co]
+                    if (dgrad) stf(dgrad + ((size_t)((1 - t) * 2 + (1 - u)) * Cin + ci) * 128 + ph * 32 + co, s);
+                }
+}
+}  // namespace
+
+extern "C" int dh_phase_wgrad_combine(const float* dwab, float* dw_oihw, int Cin, int accumulate, void* stream) {
+    hipLaunchKernelGGL(phase_wgrad_combine_kernel, dim3(dh_cdiv(32 * Cin, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       dwab, dw_oihw, Cin, accumulate);
+    DH_CHECK_LAUNCH("phase_wgrad_combine");
+    return 0;
+}
+extern "C" int dh_pack_phase_weights(int dtype, const float* w_oihw, const float* bias, int Cin, void* fwd, void* dgrad,
+                                     float* bias4, void* stream) {
+    DH_REQUIRE(Cin % 16 == 0, "pack_phase_weights: Cin=%d", Cin);
+    const dim3 grid(dh_cdiv(32 * Cin, 256));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == DH_DTYPE_BF16)
+        hipLaunchKernelGGL(pack_phase_weights_kernel<bf16>, grid, dim3(256), 0, st, w_oihw, bias, Cin, (bf16*)fwd, (bf16*)dgrad, bias4);
+    else
+        hipLaunchKernelGGL(pack_phase_weights_kernel<float>, grid, dim3(256), 0, st, w_oihw, bias, Cin, (float*)fwd, (float*)dgrad, bias4);
+    DH_CHECK_LAUNCH("pack_phase_weights");
     return 0;
 }

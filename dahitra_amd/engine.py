@@ -53,6 +53,9 @@ class Engine:
         # BatchNorm-apply + ReLU fused into the load of the consumer convolution (forward and weight gradient): the
         # normalised activation of conv1 of every BasicBlock / of the head's first conv is never materialised
         self.lazy_bn = os.environ.get("DAHITRA_NO_LAZY_BN", "0") != "1"
+        # conv_pred(nearest-upsample-x2(x)) as four 2x2 phase convolutions on x (exact up to fp re-association: the 3x3 taps
+        # that read the same source pixel are pre-summed): 2.25x fewer FLOPs, no upsampled tensor (models/networks.py:251-256)
+        self.phase_conv_pred = os.environ.get("DAHITRA_NO_PHASE_CONV", "0") != "1"
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -92,6 +95,8 @@ class Engine:
             if key.startswith("conv_a") or key.startswith("conv_token") or key.startswith("resnet.fc") or \
                     key.startswith("resnet.layer4"):
                 continue        # consumed in fp32 by the tokenizer kernels, or unused by the forward
+            if key == "conv_pred.weight" and self.phase_conv_pred and shape[1] % 64 == 0 and self.cfg["kind"] == "bit":
+                continue        # packed in its 2x2 phase form by conv_pred_phase
             if ".to_q." in key or ".to_k." in key or ".to_v." in key or \
                     (".to_out." in key and "transformer_decoder" in key):
                 # cross-attention weights: the token-side prep reads their transposes (coalesced).  The transposes of
@@ -194,6 +199,20 @@ class Engine:
                 ops.colsum(dy.view(-1, cout), self.g[bkey], accumulate=True)
             dx = self.conv_dgrad(dy, wkey, ks, 1, pad, x.shape, residual=dx_res) if need_dx else None
             return dx
+        return out, bwd
+
+    def conv_pred_phase(self, x):
+        """upsamplex2 + conv_pred (models/networks.py:251-256) without the upsampled tensor: ops.conv_up2_*"""
+        wkey, bkey = "conv_pred.weight", "conv_pred.bias"
+        wf, wd, b4 = ops.pack_phase_weights(self.p[wkey], self.p[bkey], self.dtype)
+        out = ops.conv_up2_fwd(x, wf, b4)
+        if not self.need_grad:
+            return out, None
+
+        def bwd(dout):
+            ops.conv_up2_wgrad(x, dout, self.g[wkey], accumulate=True, use_tr=self.use_tr)
+            ops.colsum(dout.view(-1, 32), self.g[bkey], accumulate=True)
+            return ops.conv_up2_dgrad(dout, wd, x.shape[-1])
         return out, bwd
 
     def stem(self, x1, x2, groups, pool=False):
@@ -626,8 +645,12 @@ class Engine:
             l1, b_l1 = self.res_layer(xp, 1, 1, 2)
             l2, b_l2 = self.res_layer(l1, 2, 2, 2)
             l3, b_l3 = self.res_layer(l2, 3, 1, 2)
-        up = ops.upsample2(l3)
-        feat, b_pred = self.conv_act(up, "conv_pred.weight", "conv_pred.bias", 3, 1, NONE)
+        phased = self.phase_conv_pred and l3.shape[-1] % 64 == 0
+        if phased:
+            feat, b_pred = self.conv_pred_phase(l3)
+        else:
+            up = ops.upsample2(l3)
+            feat, b_pred = self.conv_act(up, "conv_pred.weight", "conv_pred.bias", 3, 1, NONE)
         _, fh, fw, _ = feat.shape
         hw = fh * fw
         wa = self.p["conv_a.weight"]
@@ -654,8 +677,7 @@ class Engine:
             dfeat4 = dfeat.view(S2, fh, fw, DIM)
             ops.tokenizer_bwd(feat, wa, tsaved, dtok_cat, dfeat4, self.g["conv_a.weight"], self.g["pos_embedding"],
                               B, L, accumulate=True)
-            dup = b_pred(dfeat4)
-            dl3 = ops.upsample2_bwd(dup)
+            dl3 = b_pred(dfeat4) if phased else ops.upsample2_bwd(b_pred(dfeat4))
             dxp = b_l1(b_l2(b_l3(dl3, next_gate=b_l2.gate), next_gate=b_l1.gate))
             b_stem(ops.maxpool_bwd(xarg, dxp, xshape))
         return logits, bwd

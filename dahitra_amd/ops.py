@@ -167,12 +167,14 @@ class WgradPlan:
     def __init__(self, device):
         self.device, self.slots, self.table, self.sig, self.cur, self.blocks = device, [], None, None, 0, 0
         self._prev = None
+        self.post = []
 
     def __enter__(self):
         global _WGRAD_PLAN
         self._prev, _WGRAD_PLAN = _WGRAD_PLAN, self
         self.cur = 0
         self.jobs = []
+        self.post = []
         self.blocks = 0
         return self
 
@@ -201,6 +203,11 @@ class WgradPlan:
     def run(self):
         if not self.jobs:
             return
+        self._run_reduce()
+        for fn in self.post:          # launches that consume reduced gradients (phase-gradient combine)
+            fn()
+
+    def _run_reduce(self):
         sig = b"".join(bytes(j) for j in self.jobs)
         if self.table is None or sig != self.sig:
             if torch.cuda.is_current_stream_capturing():
@@ -307,7 +314,7 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     with _Prof(key, flops, _nb(x, y, wp, residual, pre)):
         _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
               _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
-              _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), *_bn_in_args(bn_in), S())
+              _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), *_bn_in_args(bn_in), _ci(0), S())
     out = [y]
     if want_stats:
         out.append(stats)
@@ -333,7 +340,7 @@ def linear(x2d, wp, cout, bias=None, residual=None, act=ACT_NONE, want_preact=Fa
     pre = torch.empty_like(y) if want_preact else None
     _call("dh_conv2d_fwd", _ci(dt(x2d)), P(x2d), P(wp), P(y), P(bias), P(residual), _vp(0), _ci(images), _ci(Hh),
           _ci(16), _ci(Cin), _ci(Hh), _ci(16), _ci(cout), _ci(cpad), _ci(1), _ci(1), _ci(0), _ci(act), _ci(rpi),
-          _cl(w_image_stride), P(pre), _ci(1), *_gate_args(None), *_bn_in_args(None), S())
+          _cl(w_image_stride), P(pre), _ci(1), *_gate_args(None), *_bn_in_args(None), _ci(0), S())
     # note: with rows_per_image % 16 != 0 the image stride used by the kernel (Hh*16 rows) would differ
     # from rpi; callers guarantee rpi % 16 == 0 whenever images > 1.
     assert images == 1 or rpi % 16 == 0
@@ -386,6 +393,72 @@ def _conv2d_wgrad_bn_in(b, dy, dw, ks, stride, pad, accumulate, use_tr, cout_rea
               P(b.scale), P(b.shift), _ci(b.groups), P(ws), ctypes.byref(sk) if plan is not None else None, S())
     if plan is not None and sk.value > 0:
         plan.add(ws, dw, sk.value, ks * ks, Cout, cout_real if cout_real else Cout, Cin, accumulate)
+
+
+# ---- conv3x3(nearest-upsample-x2(x)) with 32 output channels as four 2x2 phase convolutions (models/networks.py:251-256) ----
+def pack_phase_weights(w, bias, dtype):
+    """w OIHW fp32 [32, Cin, 3, 3] -> (fwd [4, 128, Cin], dgrad [4, Cin, 128], bias4 [128])"""
+    O, I = w.shape[0], w.shape[1]
+    assert O == 32 and tuple(w.shape[2:]) == (3, 3)
+    fwd = torch.empty(4, 128, I, dtype=dtype, device=w.device)
+    dg = torch.empty(4, I, 128, dtype=dtype, device=w.device)
+    b4 = torch.empty(128, dtype=torch.float32, device=w.device)
+    _call("dh_pack_phase_weights", _ci(_DT[dtype]), P(w), P(bias), _ci(I), P(fwd), P(dg), P(b4), S())
+    return fwd, dg, b4
+
+
+def conv_up2_fwd(x, wfwd, bias4):
+    """conv3x3(nearest-x2(x)) + bias: x [N, H, W, Cin] -> [N, 2H, 2W, 32]; the upsampled tensor is never materialised"""
+    N, H, W, Cin = x.shape
+    y = torch.empty(N, 2 * H, 2 * W, 32, dtype=x.dtype, device=x.device)
+    key = "conv_mfma<%s,ks3,s1,nt32>" % ("bf16" if x.dtype == torch.bfloat16 else "f32")       # the class it replaces
+    with _Prof(key, 2.0 * N * 4 * H * W * 32 * Cin * 9, _nb(x, y, wfwd)):                       # algorithmic FLOPs
+        _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wfwd), P(y), P(bias4), _vp(0), _vp(0), _ci(N), _ci(H), _ci(W), _ci(Cin),
+              _ci(H), _ci(W), _ci(128), _ci(128), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0), _cl(0), _vp(0), _ci(1),
+              *_gate_args(None), *_bn_in_args(None), _ci(1), S())
+    return y
+
+
+def conv_up2_dgrad(dy, wdgrad, cin):
+    """gradient of conv_up2_fwd with respect to x: dy [N, 2H, 2W, 32] -> [N, H, W, cin]"""
+    N, H2, W2, C = dy.shape
+    assert C == 32 and H2 % 2 == 0 and W2 % 2 == 0 and cin % 64 == 0
+    H, W = H2 // 2, W2 // 2
+    dx = torch.empty(N, H, W, cin, dtype=dy.dtype, device=dy.device)
+    key = "conv_mfma<%s,ks3,s1,nt64>" % ("bf16" if dy.dtype == torch.bfloat16 else "f32")
+    with _Prof(key, 2.0 * N * H2 * W2 * 32 * cin * 9, _nb(dy, dx, wdgrad)):
+        _call("dh_conv2d_fwd", _ci(dt(dy)), P(dy), P(wdgrad), P(dx), _vp(0), _vp(0), _vp(0), _ci(N), _ci(H), _ci(W), _ci(128),
+              _ci(H), _ci(W), _ci(cin), _ci(cin), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0), _cl(0), _vp(0), _ci(1),
+              *_gate_args(None), *_bn_in_args(None), _ci(2), S())
+    return dx
+
+
+def conv_up2_wgrad(x, dy, dw, accumulate=True, use_tr=True):
+    """dw (OIHW fp32 [32, Cin, 3, 3]) (+)= weight gradient of conv_up2_fwd: four per-phase 2x2 gradients (one launch), their
+    split-K reduce (with the pass's other reduces when a WgradPlan is active), then the tap combine"""
+    N, H, W, Cin = x.shape
+    L = _lib.lib()
+    plan, own = _WGRAD_PLAN, False
+    if plan is None:
+        plan, own = WgradPlan(x.device), True
+        plan.__enter__()
+    try:
+        ws = plan.slab(L.dh_conv2d_wgrad_phase_workspace_size(N, H, W, Cin))
+        dwab = plan.slab(4 * 32 * Cin * 4 * 4).view(torch.float32)
+        sk = ctypes.c_int(0)
+        with _Prof("conv_wgrad<%s,ks3,s1>" % ("bf16" if x.dtype == torch.bfloat16 else "f32"),
+                   2.0 * N * 4 * H * W * 32 * Cin * 9, _nb(x, dy)):
+            _call("dh_conv2d_wgrad_phase", _ci(dt(x)), P(x), P(dy), _ci(N), _ci(H), _ci(W), _ci(Cin), _ci(int(use_tr)), P(ws),
+                  ctypes.byref(sk), S())
+        per = sk.value * 4 * 32 * Cin * 4            # bytes of one phase's slabs
+        for ph in range(4):
+            plan.add(ws[ph * per:], dwab[ph * 32 * Cin * 4:], sk.value, 4, 32, 32, Cin, False)
+        plan.post.append(lambda: _call("dh_phase_wgrad_combine", P(dwab), P(dw), _ci(Cin), _ci(int(accumulate)), S()))
+        if own:
+            plan.run()
+    finally:
+        if own:
+            plan.__exit__()
 
 
 def linear_wgrad(x2d, dy2d, dw, accumulate=False, images=1, per_image=False, use_tr=True):

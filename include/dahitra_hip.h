@@ -52,7 +52,12 @@ int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const
                   int Cout, int CoutPad, int ks, int stride, int pad, int act, int npix_valid,
                   long w_image_stride, void* y_preact, int dilation, const void* gate_out, const void* gate_y,
                   const float* gate_mean, const float* gate_invstd, int gate_groups, const float* in_scale,
-                  const float* in_shift, int in_groups, void* stream);
+                  const float* in_shift, int in_groups, int phase_mode, void* stream);
+/* phase_mode (0 = off; ks = 2, pad = 1 only): conv3x3(nearest-upsample-x2(x)) -- models/networks.py:251-256, upsamplex2 +
+ * conv_pred -- as four 2x2 convolutions on x, one per output parity, weights from dh_pack_phase_weights (2.25x fewer
+ * FLOPs, the upsampled tensor is never written).  1: forward, logical Cout = 4 * 32, y is the [N][2 OH][2 OW][32] output
+ * (depth-to-space store), bias tiled 4 x.  2: data gradient, x is the [N][2 H][2 W][32] gradient (space-to-depth gather),
+ * logical Cin = 4 * 32, y = [N][H][W][Cout]. */
 /* in_scale / in_shift ([in_groups][Cin] fp32, NULL = off; 3x3 stride-1 convolutions): BatchNorm-apply + ReLU on LOAD.  x is
  * then the PRE-normalisation output of the previous convolution and the kernel consumes relu(x * in_scale[g][ci] +
  * in_shift[g][ci]), g = n / (N / in_groups); zero padding applies to that post-activation tensor.  Replaces the separate
@@ -88,6 +93,19 @@ int dh_conv2d_wgrad_bn_in(int dtype, const void* x, const void* dy, float* dw_oi
                           int dilation, const float* in_scale, const float* in_shift, int in_groups, void* workspace,
                           int* splitk_out, void* stream);
 int dh_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream);
+/* ---- the 2x2 phase form of conv3x3(nearest-upsample-x2(x)) with 32 output channels (dh_conv2d_fwd's phase_mode) ----
+ * dh_pack_phase_weights: OIHW fp32 [32][Cin][3][3] (+ bias [32]) -> fwd [4 taps][4 * 32][Cin] T, data-gradient form
+ * [4 taps][Cin][4 * 32] T, bias4 [128] fp32; W_ab[t][u] = sum of the 3x3 taps that read the same source pixel.
+ * dh_conv2d_wgrad_phase: per-phase weight gradients, x [N][H][W][Cin], dy [N][2H][2W][32] -> partial slabs in `workspace`
+ * ([4 phases][splitk][4 taps][32][Cin] fp32, *splitk_out slabs per phase; reduce each phase with dh_wgrad_reduce_multi /
+ * the returned layout into dwab [4][32][Cin][2][2]).  dh_phase_wgrad_combine: dw_oihw [32][Cin][3][3] (+)= the sums of the
+ * phase gradients that share a 3x3 tap.  (autograd of F.interpolate(nearest) + conv2d's weight.) */
+int dh_pack_phase_weights(int dtype, const float* w_oihw, const float* bias, int Cin, void* fwd, void* dgrad, float* bias4,
+                          void* stream);
+long dh_conv2d_wgrad_phase_workspace_size(int N, int H, int W, int Cin);
+int dh_conv2d_wgrad_phase(int dtype, const void* x, const void* dy, int N, int H, int W, int Cin, int use_tr, void* workspace,
+                          int* splitk_out, void* stream);
+int dh_phase_wgrad_combine(const float* dwab, float* dw_oihw, int Cin, int accumulate, void* stream);
 int dh_wgrad_reduce_job_size(void);
 int dh_wgrad_reduce_outputs_per_block(int Cin);
 int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, int ks, int groups);

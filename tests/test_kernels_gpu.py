@@ -669,3 +669,34 @@ def test_batchnorm_backward_persistent_launch_equals_two_pass(ops, cfg, monkeypa
     assert float((two[2] - per[2]).abs().max()) <= 2e-4 * float(two[2].abs().max()) + 1e-4, "dbeta"
     if two[3] is not None:
         assert torch.equal(two[3], per[3]), "dres"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    dict(n=2, cin=256, h=16, w=16),          # 8-row tiles
+    dict(n=3, cin=64, h=12, w=20),           # ragged coarse map
+    dict(n=64, cin=256, h=32, w=32),         # the bench's conv_pred: 16-row tiles, 4 phases x 256 tiles
+])
+def test_upsample2_conv3x3_as_four_phase_convs(ops, dtype, cfg):
+    """conv3x3(nearest-upsample-x2(x)) (models/networks.py:251-256: upsamplex2 + conv_pred) as four 2x2 phase convolutions:
+    forward, data gradient and weight / bias gradients against torch autograd of F.interpolate + F.conv2d"""
+    N, Cin, H, W = cfg["n"], cfg["cin"], cfg["h"], cfg["w"]
+    x = rnd((N, Cin, H, W), dtype, 901).requires_grad_(True)
+    w = rnd((32, Cin, 3, 3), torch.float32, 902, (Cin * 9) ** -0.5).requires_grad_(True)
+    b = rnd((32,), torch.float32, 903, 0.1)
+    y = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, 1, 1)
+    dy = rnd(tuple(y.shape), dtype, 904)
+    y.backward(dy)
+    wf, wd, b4 = ops.pack_phase_weights(w.detach().cuda(), b.cuda(), dtype)
+    xd = dev(nhwc(x.detach()), dtype)
+    out = ops.conv_up2_fwd(xd, wf, b4)
+    assert tuple(out.shape) == (N, 2 * H, 2 * W, 32)
+    # (bf16: the phase weights are sums of up to four taps rounded once, the reference rounds nothing: same tolerance class)
+    close(nchw(out), y.detach(), dtype, "phase conv forward", factor=2.0)
+    dyd = dev(nhwc(dy), dtype)
+    dx = ops.conv_up2_dgrad(dyd, wd, Cin)
+    close(nchw(dx), x.grad, dtype, "phase conv data gradient", factor=3.0)
+    dw = torch.full((32, Cin, 3, 3), 0.5, device="cuda")
+    ops.conv_up2_wgrad(xd, dyd, dw, accumulate=True)
+    fac = 4.0 if dtype == torch.float32 or N < 64 else 1.0
+    close(dw - 0.5, w.grad, dtype, "phase conv weight gradient", factor=fac)
