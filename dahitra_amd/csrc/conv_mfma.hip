@@ -35,10 +35,10 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
                              "conv2d_fwd: BatchNorm-on-load needs in_shift and N %% in_groups == 0");
     a.phase_mode = phase_mode;
     if (phase_mode) {
-        DH_REQUIRE(ks == 2 && stride == 1 && pad == 1 && dilation == 1 && !residual && !stats_partial && !y_preact && !gate_y &&
+        DH_REQUIRE(ks == 2 && stride == 1 && pad == 1 && dilation == 1 && (!residual || phase_mode == 1) && !stats_partial && !y_preact && !gate_y &&
                    !in_scale && w_image_stride == 0 && npix_valid == 0 && H == OH && W == OW && act != DH_ACT_GELU,
                    "conv2d_fwd: phase mode is a plain 2x2 pad-1 convolution on equal input / output grids");
-        DH_REQUIRE(phase_mode == 1 ? (Cout == 128 && CoutPad == 128) : (phase_mode == 2 && Cin == 128 && Cout % 64 == 0),
+        DH_REQUIRE(phase_mode == 1 ? ((Cout == 128 || Cout == 256) && CoutPad == Cout) : (phase_mode == 2 && Cin == 128 && Cout % 64 == 0),
                    "conv2d_fwd: phase mode %d with Cin=%d Cout=%d", phase_mode, Cin, Cout);
     }
     a.rw = pick_rw(N, OH, OW, Cin, ks, stride);

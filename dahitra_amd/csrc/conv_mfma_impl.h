@@ -75,8 +75,11 @@ struct ConvArgs {
     int in_groups;
     // 2x2 PHASE convolutions (KS = 2 only): conv3x3(nearest-upsample-x2(x)) == four 2x2 convolutions on x, one per output
     // parity (a, b), with the 3x3 taps that fall on the same source pixel pre-summed (models/networks.py:251-256).
-    //   1: forward.  Logical Cout = 4 * 32 (one NT = 32 block per phase); block (a, b) reads rows oy + t + a - 1 and its
-    //      pixel (oy, ox) is STORED at (2 oy + a, 2 ox + b) of the [N][2 OH][2 OW][32] output (depth-to-space).
+    //   1: forward.  Logical Cout = 4 * NT (one NT = 32 / 64 block per phase); block (a, b) reads rows oy + t + a - 1 and its
+    //      pixel (oy, ox) is STORED at (2 oy + a, 2 ox + b) of the [N][2 OH][2 OW][NT] output (depth-to-space).  `res`, if
+    //      given, is a COARSE [N][OH][OW][NT] tensor added to phase (0, 0) only.  The same mode serves the data gradient of
+    //      a 3x3 STRIDE-2 convolution (output parity (a, b) receives 1, 2, 2 or 4 of the 9 taps; weights from
+    //      dh_pack_s2_dgrad_phase_weights; `res` = the coarse data gradient of the block's 1x1 stride-2 shortcut).
     //   2: data gradient.  Logical Cin = 4 * 32: 32-channel group (a, b) is GATHERED from the [N][2 H][2 W][32] gradient at
     //      (2 (iy + 1 - a) + a, 2 (ix + 1 - b) + b) (space-to-depth with a per-phase shift), so that all four phases share
     //      the tap geometry of a 2x2 convolution with pad 1.
@@ -295,6 +298,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     // ---- epilogue ----
     T* yout = reinterpret_cast<T*>(p.y) + (size_t)n * p.OH * p.OW * p.Cout;
     const T* rin = p.res ? reinterpret_cast<const T*>(p.res) + (size_t)n * p.OH * p.OW * p.Cout : nullptr;
+    if constexpr (KS == 2) {
+        if (p.phase_mode == 1)          // coarse residual [N][OH][OW][NT], phase (0, 0) only
+            rin = (p.res && blockIdx.y == 0) ? reinterpret_cast<const T*>(p.res) + (size_t)n * p.OH * p.OW * NT : nullptr;
+    }
     const bool vec_ok = (p.Cout & 3) == 0;
     // Output path: a lane holds 4 channels of one pixel (8 / 16 bytes), i.e. a direct store writes 32-byte runs at a
     // Cout-sized stride -- measured 14-27 us per launch on the trunk layers.  The tile is instead transposed through
@@ -341,7 +348,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
                         const int c = co0 + s * 16 + g * 4;
                         if (pvalid && c < p.Cout) {
                             float rr[4];
-                            ld4(rin + (size_t)(oy * p.OW + ox) * p.Cout + c, rr);
+                            const size_t roff = (KS == 2 && p.phase_mode == 1) ? (size_t)(oy * p.OW + ox) * NT + (c - co0)
+                                                                              : (size_t)(oy * p.OW + ox) * p.Cout + c;
+                            ld4(rin + roff, rr);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] += rr[j];
                         }
@@ -552,8 +561,8 @@ int launch(const ConvArgs& a, hipStream_t st) {
 
 template <typename T, int KS, int STRIDE>
 int launch_nt(const ConvArgs& a, hipStream_t st) {
-    if constexpr (KS == 2) {      // the phase convolutions: forward = one 32-channel cout block per phase
-        if (a.phase_mode == 1) return launch<T, KS, STRIDE, 32>(a, st);
+    if constexpr (KS == 2) {      // the phase convolutions: forward = one cout block (32 or 64 channels) per phase
+        if (a.phase_mode == 1) return a.Cout == 128 ? launch<T, KS, STRIDE, 32>(a, st) : launch<T, KS, STRIDE, 64>(a, st);
         return launch<T, KS, STRIDE, 64>(a, st);
     }
     if (a.CoutPad % 64 == 0) return launch<T, KS, STRIDE, 64>(a, st);

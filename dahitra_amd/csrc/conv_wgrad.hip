@@ -731,6 +731,43 @@ __global__ void pack_phase_weights_kernel(const float* __restrict__ w, const flo
 }
 }  // namespace
 
+namespace {
+// Data gradient of a 3x3 / stride 2 / pad 1 convolution [Co][Ci] as a phase convolution over dY (ConvArgs::phase_mode 1):
+// output parity (a, b) of dX reads dY rows i - 1 + a + t (t = 0, 1) with
+//   a = 0: t = 1 <- kh 1 (t = 0: no tap);   a = 1: t = 0 <- kh 2, t = 1 <- kh 0        (columns alike)
+// out: [tap = t * 2 + u][(a * 2 + b) * Ci + ci][co] T, zeros where a phase has no tap
+template <typename T>
+__global__ void pack_s2_dgrad_phase_kernel(const float* __restrict__ w, int Co, int Ci, T* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // (co, ci)
+    if (i >= Co * Ci) return;
+    const int co = i / Ci, ci = i % Ci;
+    float k[3][3];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) k[j / 3][j % 3] = w[(size_t)i * 9 + j];
+    const int kmap[2][2] = {{-1, 1}, {2, 0}};        // [a][t] -> kh (or none)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kh = kmap[a][t], kw = kmap[b][u];
+                    const float v = (kh >= 0 && kw >= 0) ? k[kh][kw] : 0.f;
+                    stf(out + ((size_t)(t * 2 + u) * 4 * Ci + (a * 2 + b) * Ci + ci) * Co + co, v);
+                }
+}
+}  // namespace
+extern "C" int dh_pack_s2_dgrad_phase_weights(int dtype, const float* w_oihw, int Co, int Ci, void* out, void* stream) {
+    DH_REQUIRE((Ci == 32 || Ci == 64) && Co % 16 == 0, "pack_s2_dgrad_phase_weights: Ci=%d (32 or 64) Co=%d", Ci, Co);
+    const dim3 grid(dh_cdiv(Co * Ci, 256));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(pack_s2_dgrad_phase_kernel<bf16>, grid, dim3(256), 0, st, w_oihw, Co, Ci, (bf16*)out);
+    else hipLaunchKernelGGL(pack_s2_dgrad_phase_kernel<float>, grid, dim3(256), 0, st, w_oihw, Co, Ci, (float*)out);
+    DH_CHECK_LAUNCH("pack_s2_dgrad_phase_weights");
+    return 0;
+}
 extern "C" int dh_phase_wgrad_combine(const float* dwab, float* dw_oihw, int Cin, int accumulate, void* stream) {
     hipLaunchKernelGGL(phase_wgrad_combine_kernel, dim3(dh_cdiv(32 * Cin, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        dwab, dw_oihw, Cin, accumulate);

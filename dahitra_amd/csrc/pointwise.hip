@@ -24,6 +24,20 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict
         stf(dst + i, c < C ? src[(n * C + c) * HW + p] : 0.f);
     }
 }
+// the class-gradient case (C = n_class real channels into ONE 16-byte piece per pixel): a thread per pixel reads its C
+// planes (each coalesced along the pixels) and stores one piece -- the generic form above stored 2-byte elements
+template <typename T>
+__global__ void nchw_to_nhwc_piece_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, long HW) {
+    constexpr int V = V16<T>::N;
+    const long total = (long)N * HW;
+    GSL(i, total) {
+        const long p = i % HW, n = i / HW;
+        float v[V];
+#pragma unroll
+        for (int c = 0; c < V; ++c) v[c] = c < C ? src[(n * C + c) * HW + p] : 0.f;
+        stv(dst + i * V, v);
+    }
+}
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int N, int C, long HW) {
     const long total = (long)N * HW * C;
@@ -87,6 +101,50 @@ __global__ __launch_bounds__(256) void head_dgrad3x3_kernel(const T* __restrict_
             float r4[4] = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
             st4(dst + c, r4);
         }
+    }
+}
+
+// n_class <= 2 (the change-detection heads): the 9 x NC x (channels of one piece) weights fit the registers of a lane that
+// owns ONE 16-byte output piece of a pixel -- no LDS (the form above issues 144 ds_read_b128 per pixel, which bounds it),
+// 16-byte coalesced stores (it stored 8-byte elements at a 64-byte lane stride).  HBM-bound: 16 B read, 64 / 128 B
+// written per pixel.
+template <typename T, int CP, int NC>
+__global__ __launch_bounds__(256) void head_dgrad3x3_reg_kernel(const T* __restrict__ dy, const float* __restrict__ w_oihw,
+                                                                T* __restrict__ dx, int N, int H, int W) {
+    constexpr int V = V16<T>::N;           // channels of one output piece
+    constexpr int LPP = 32 / V;            // lanes per pixel
+    const int cg = threadIdx.x % LPP;
+    float w[9][NC][V];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int co = 0; co < NC; ++co)
+#pragma unroll
+            for (int j = 0; j < V; ++j) w[t][co][j] = w_oihw[((size_t)co * 32 + cg * V + j) * 9 + t];
+    const long total = (long)N * H * W * LPP;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long px = i / LPP;
+        const int x = (int)(px % W), y = (int)((px / W) % H);
+        const long n = px / ((long)W * H);
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int yy = y + 1 - kh, xx = x + 1 - kw;
+                const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+                float v[4];
+                ld4(dy + ((n * H + (ok ? yy : y)) * W + (ok ? xx : x)) * CP, v);      // the first 4 channels hold the NC real ones
+#pragma unroll
+                for (int co = 0; co < NC; ++co) {
+                    const float d = ok ? v[co] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < V; ++j) acc[j] += d * w[kh * 3 + kw][co][j];
+                }
+            }
+        stv(dx + i * V, acc);
     }
 }
 
@@ -604,6 +662,13 @@ extern "C" int dh_reduce_partials(const float* partial, long nt, long n, float s
 extern "C" int dh_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, long HW, int CP, void* stream) {
     if (CP < C) CP = C;
     const long n = (long)N * CP * HW;
+    if (CP * (dtype == DH_DTYPE_BF16 ? 2 : 4) == 16) {
+        const long np = (long)N * HW;
+        if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(nchw_to_nhwc_piece_kernel<bf16>, dim3(ew_grid(np, 256)), dim3(256), 0, ST(stream), src, (bf16*)dst, N, C, HW);
+        else hipLaunchKernelGGL(nchw_to_nhwc_piece_kernel<float>, dim3(ew_grid(np, 256)), dim3(256), 0, ST(stream), src, (float*)dst, N, C, HW);
+        DH_CHECK_LAUNCH("nchw_to_nhwc");
+        return 0;
+    }
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), src, (bf16*)dst, N, C, HW, CP);
     else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), src, (float*)dst, N, C, HW, CP);
     DH_CHECK_LAUNCH("nchw_to_nhwc");
@@ -616,6 +681,17 @@ extern "C" int dh_head_dgrad3x3(int dtype, const void* dy, int CP, const float* 
     DH_REQUIRE(NC >= 1 && NC <= 8 && NC <= CP, "head_dgrad3x3: n_class=%d with CP=%d", NC, CP);
     const long n = (long)N * H * W;
     const int grid = ew_grid(n, 256);
+    if (NC <= 2 && (dtype == DH_DTYPE_BF16 ? CP == 8 : (CP == 4 || CP == 8))) {      // weights in registers
+#define DH_HEAD_REG(T, CPV, NCV, LPP)                                                                                       \
+        hipLaunchKernelGGL((head_dgrad3x3_reg_kernel<T, CPV, NCV>), dim3(ew_grid(n * LPP, 256)), dim3(256), 0, ST(stream), \
+                           (const T*)dy, w_oihw, (T*)dx, N, H, W)
+        if (dtype == DH_DTYPE_BF16) { if (NC == 2) DH_HEAD_REG(bf16, 8, 2, 4); else DH_HEAD_REG(bf16, 8, 1, 4); }
+        else if (CP == 4) { if (NC == 2) DH_HEAD_REG(float, 4, 2, 8); else DH_HEAD_REG(float, 4, 1, 8); }
+        else { if (NC == 2) DH_HEAD_REG(float, 8, 2, 8); else DH_HEAD_REG(float, 8, 1, 8); }
+#undef DH_HEAD_REG
+        DH_CHECK_LAUNCH("head_dgrad3x3");
+        return 0;
+    }
     if (dtype == DH_DTYPE_BF16) {
         DH_REQUIRE(CP == 8, "head_dgrad3x3: bf16 needs 8 channels per pixel (one 16-byte piece), got %d", CP);
         hipLaunchKernelGGL((head_dgrad3x3_kernel<bf16, 8>), dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dy, w_oihw, (bf16*)dx, N, H, W, NC);

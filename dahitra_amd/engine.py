@@ -37,6 +37,15 @@ class Gated:
         self.g, self.partial = g, partial
 
 
+class CoarseRes:
+    """a data gradient that lives on the COARSE grid of a stride-2 layer ([N, OH, OW, C]): the value of the fine-grid
+    gradient at the even-even positions, zero elsewhere (the 1x1 stride-2 shortcut of a BasicBlock)"""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
 class Engine:
     def __init__(self, net_G, dtype=torch.float32, use_tr=True):
         self.net_G = net_G
@@ -56,6 +65,9 @@ class Engine:
         # conv_pred(nearest-upsample-x2(x)) as four 2x2 phase convolutions on x (exact up to fp re-association: the 3x3 taps
         # that read the same source pixel are pre-summed): 2.25x fewer FLOPs, no upsampled tensor (models/networks.py:251-256)
         self.phase_conv_pred = os.environ.get("DAHITRA_NO_PHASE_CONV", "0") != "1"
+        # data gradient of the 3x3 stride-2 convolutions as four output-parity phase convolutions over dY instead of a
+        # stride-1 convolution over the zero-inserted dY (4x the pixels, 75 % zeros)
+        self.phase_s2_dgrad = os.environ.get("DAHITRA_NO_PHASE_S2", "0") != "1"
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -125,11 +137,26 @@ class Engine:
         return pack, pk, xstack
 
     # ---- primitive units -------------------------------------------------------------------------
-    def conv_dgrad(self, dy, wkey, ks, stride, pad, xshape, residual=None, dilation=1, gate=None):
+    def s2_phase_ok(self, ks, stride, pad, xshape, dy):
+        N, H, W, Cin = xshape
+        return self.phase_s2_dgrad and ks == 3 and stride == 2 and pad == 1 and Cin in (32, 64) and \
+            H == 2 * dy.shape[1] and W == 2 * dy.shape[2] and dy.shape[-1] % ops.chunk_channels(self.dtype) == 0
+
+    def conv_dgrad(self, dy, wkey, ks, stride, pad, xshape, residual=None, dilation=1, gate=None, coarse=False):
         """data gradient of a convolution; with `gate` (the .gate of the BN layer that produced this conv's input) the
-        result is a Gated pair instead of the plain gradient"""
+        result is a Gated pair instead of the plain gradient.  coarse=True (1x1 stride 2 only): the gradient on the coarse
+        grid, i.e. without the zero positions.  residual may be a CoarseRes (3x3 stride-2 phase path only)."""
         N, H, W, Cin = xshape
         flops = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * self.shapes[wkey][0] * Cin * ks * ks   # algorithmic
+        if coarse:
+            assert ks == 1 and stride == 2 and residual is None and gate is None
+            return ops.conv2d(dy, self.pk[wkey].dgrad, Cin, 1, 1, 0, alg_flops=flops)
+        if gate is None and self.s2_phase_ok(ks, stride, pad, xshape, dy):
+            wph = ops.pack_s2_dgrad_phase_weights(self.p[wkey], self.dtype)
+            if residual is None or isinstance(residual, CoarseRes):
+                return ops.conv3x3s2_dgrad(dy, wph, Cin, residual.t if residual is not None else None, alg_flops=flops)
+            return ops.add(ops.conv3x3s2_dgrad(dy, wph, Cin, None, alg_flops=flops), residual)
+        assert not isinstance(residual, CoarseRes)
         if stride == 2:
             dy = ops.zero_insert2(dy, H, W)
         r = ops.conv2d(dy, self.pk[wkey].dgrad, Cin, ks, 1, dilation * (ks - 1) - pad, residual=residual,
@@ -163,7 +190,7 @@ class Engine:
             return out, None
         has_res = residual is not None
 
-        def bwd(dout, need_dx=True, dx_res=None, next_gate=None):
+        def bwd(dout, need_dx=True, dx_res=None, next_gate=None, coarse_dx=False):
             if isinstance(dout, Gated):       # ReLU mask and the reduction pass were done by the producer of dout
                 dy = ops.bn_bwd_from_partials(dout.g, y, dout.partial, mean, invstd, gamma, self.g[bnkey + ".weight"],
                                               self.g[bnkey + ".bias"], groups, accumulate=True)
@@ -180,7 +207,7 @@ class Engine:
             ops.conv2d_wgrad(x, dy, self.g[wkey], ks, stride, pad, accumulate=True, use_tr=self.use_tr,
                              dilation=dilation)
             dx = self.conv_dgrad(dy, wkey, ks, stride, pad, x.shape, residual=dx_res, dilation=dilation,
-                                 gate=next_gate) if need_dx else None
+                                 gate=next_gate, coarse=coarse_dx) if need_dx else None
             return dx, dres
         # what an upstream data-gradient launch needs to gate for this layer (None: keep the two-pass backward)
         bwd.gate = (out if relu else None, y, mean, invstd, groups) if (self.fused_bn_bwd and cout % 16 == 0) else None
@@ -272,8 +299,13 @@ class Engine:
         def bwd(dout, next_gate=None):
             dh, dres = b2(dout, next_gate=b1.gate)
             if has_ds:
-                dxds, _ = bds(dres)
-                dx, _ = b1(dh, dx_res=dxds, next_gate=next_gate)
+                if stride == 2 and next_gate is None and self.phase_s2_dgrad and x.shape[-1] in (32, 64):
+                    # shortcut gradient on the coarse grid; conv1's phase data gradient adds it at the even-even positions
+                    dxds, _ = bds(dres, coarse_dx=True)
+                    dx, _ = b1(dh, dx_res=CoarseRes(dxds), next_gate=next_gate)
+                else:
+                    dxds, _ = bds(dres)
+                    dx, _ = b1(dh, dx_res=dxds, next_gate=next_gate)
             else:
                 dx, _ = b1(dh, dx_res=dres, next_gate=next_gate)
             return dx

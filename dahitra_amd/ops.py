@@ -419,6 +419,28 @@ def conv_up2_fwd(x, wfwd, bias4):
     return y
 
 
+def pack_s2_dgrad_phase_weights(w, dtype):
+    """OIHW fp32 [Co, Ci, 3, 3] of a stride-2 conv -> [4, 4 * Ci, Co] phase weights of its data gradient"""
+    Co, Ci = w.shape[0], w.shape[1]
+    out = torch.empty(4, 4 * Ci, Co, dtype=dtype, device=w.device)
+    _call("dh_pack_s2_dgrad_phase_weights", _ci(_DT[dtype]), P(w), _ci(Co), _ci(Ci), P(out), S())
+    return out
+
+
+def conv3x3s2_dgrad(dy, wphase, cin, coarse_residual=None, alg_flops=0):
+    """data gradient of a 3x3 / stride-2 / pad-1 convolution from dy [N, OH, OW, Co] straight to [N, 2 OH, 2 OW, cin]: four
+    output-parity phases (1 + 2 + 2 + 4 of the 9 taps), no zero-inserted tensor; coarse_residual [N, OH, OW, cin] (the data
+    gradient of a parallel 1x1 stride-2 convolution) lands on the even-even positions"""
+    N, OH, OW, Co = dy.shape
+    dx = torch.empty(N, 2 * OH, 2 * OW, cin, dtype=dy.dtype, device=dy.device)
+    key = "conv_mfma<%s,ks3,s1,nt64>" % ("bf16" if dy.dtype == torch.bfloat16 else "f32")
+    with _Prof(key, alg_flops if alg_flops else 2.0 * N * OH * OW * Co * cin * 9, _nb(dy, dx, wphase, coarse_residual)):
+        _call("dh_conv2d_fwd", _ci(dt(dy)), P(dy), P(wphase), P(dx), _vp(0), P(coarse_residual), _vp(0), _ci(N), _ci(OH),
+              _ci(OW), _ci(Co), _ci(OH), _ci(OW), _ci(4 * cin), _ci(4 * cin), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0),
+              _cl(0), _vp(0), _ci(1), *_gate_args(None), *_bn_in_args(None), _ci(1), S())
+    return dx
+
+
 def conv_up2_dgrad(dy, wdgrad, cin):
     """gradient of conv_up2_fwd with respect to x: dy [N, 2H, 2W, 32] -> [N, H, W, cin]"""
     N, H2, W2, C = dy.shape

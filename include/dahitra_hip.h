@@ -106,6 +106,11 @@ long dh_conv2d_wgrad_phase_workspace_size(int N, int H, int W, int Cin);
 int dh_conv2d_wgrad_phase(int dtype, const void* x, const void* dy, int N, int H, int W, int Cin, int use_tr, void* workspace,
                           int* splitk_out, void* stream);
 int dh_phase_wgrad_combine(const float* dwab, float* dw_oihw, int Cin, int accumulate, void* stream);
+/* Data gradient of a 3x3 / stride-2 / pad-1 convolution (models/resnet.py:24-27 with stride 2; autograd convolution_backward)
+ * WITHOUT the zero-inserted gradient: dh_conv2d_fwd(phase_mode = 1, ks = 2, x = dY [N][OH][OW][Co], logical Cout = 4 * Ci,
+ * y = dX [N][2 OH][2 OW][Ci], residual = coarse [N][OH][OW][Ci] gradient of the 1x1 stride-2 shortcut or NULL) over the
+ * weights packed here: [4 taps][4 * Ci][Co] T from OIHW fp32 [Co][Ci][3][3]; Ci = 32 or 64. */
+int dh_pack_s2_dgrad_phase_weights(int dtype, const float* w_oihw, int Co, int Ci, void* out, void* stream);
 int dh_wgrad_reduce_job_size(void);
 int dh_wgrad_reduce_outputs_per_block(int Cin);
 int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, int ks, int groups);

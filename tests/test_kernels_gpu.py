@@ -700,3 +700,34 @@ def test_upsample2_conv3x3_as_four_phase_convs(ops, dtype, cfg):
     ops.conv_up2_wgrad(xd, dyd, dw, accumulate=True)
     fac = 4.0 if dtype == torch.float32 or N < 64 else 1.0
     close(dw - 0.5, w.grad, dtype, "phase conv weight gradient", factor=fac)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    dict(n=2, cin=64, cout=128, h=32, w=32),          # layer2.0.conv1 at small batch (8-row tiles)
+    dict(n=3, cin=32, cout=64, h=20, w=24),           # 32-channel phases, ragged coarse map (10 x 12)
+    dict(n=64, cin=64, cout=128, h=64, w=64),         # the bench's shape: 16-row tiles
+])
+def test_stride2_conv_data_gradient_as_phase_convs(ops, dtype, cfg):
+    """data gradient of conv3x3 / stride 2 / pad 1 without the zero-inserted dY (four output-parity phases), plus the coarse
+    gradient of the block's 1x1 stride-2 shortcut added at the even-even positions, against torch autograd"""
+    N, Cin, Cout, H, W = cfg["n"], cfg["cin"], cfg["cout"], cfg["h"], cfg["w"]
+    x = rnd((N, Cin, H, W), dtype, 911).requires_grad_(True)
+    w = rnd((Cout, Cin, 3, 3), dtype, 912, (Cin * 9) ** -0.5)
+    wds = rnd((Cout, Cin, 1, 1), dtype, 913, Cin ** -0.5)
+    dy = rnd((N, Cout, H // 2, W // 2), dtype, 914)
+    dyds = rnd((N, Cout, H // 2, W // 2), dtype, 915)
+    (F.conv2d(x, w, None, 2, 1) * dy).sum().backward()
+    g_main = x.grad.clone()
+    x.grad = None
+    (F.conv2d(x, wds, None, 2, 0) * dyds).sum().backward()
+    g_both = g_main + x.grad
+    wph = ops.pack_s2_dgrad_phase_weights(w.cuda(), dtype)
+    dyd, dydsd = dev(nhwc(dy), dtype), dev(nhwc(dyds), dtype)
+    dx = ops.conv3x3s2_dgrad(dyd, wph, Cin)
+    close(nchw(dx), g_main, dtype, "stride-2 data gradient (phases)", factor=2.0)
+    _, wd1 = ops.pack_weight(wds.cuda(), dtype, want_dgrad=True, dgrad_inner=Cout)
+    coarse = ops.conv2d(dydsd, wd1, Cin, 1, 1, 0)
+    dx2 = ops.conv3x3s2_dgrad(dyd, wph, Cin, coarse)
+    # (bf16: the coarse shortcut gradient is rounded to bf16 before it is added, as the separate path does too)
+    close(nchw(dx2), g_both, dtype, "stride-2 data gradient + coarse shortcut gradient", factor=3.0)

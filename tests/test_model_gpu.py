@@ -565,3 +565,26 @@ def test_lazy_batchnorm_activations_equal_materialised(name, dtype, monkeypatch)
     assert torch.equal(res["0"][0], res["1"][0])
     for k, g in res["1"][1].items():
         assert torch.equal(res["0"][1][k], g), k
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
+def test_phase_convolution_paths_equal_reference_paths(name, monkeypatch):
+    """conv_pred as 2x2 phase convs and the stride-2 data gradient as output-parity phases (both: pre-summed / re-ordered
+    taps, i.e. fp re-association only) against the upsample / zero-insert paths in fp32 mode"""
+    from dahitra_amd.models import losses
+    size = 256 if name == "newUNetTrans" else 64
+    a, b, lab = O.synthetic_batch(2, size, seed=61)
+    res = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("DAHITRA_NO_PHASE_CONV", off)
+        monkeypatch.setenv("DAHITRA_NO_PHASE_S2", off)
+        net = make_net(name).train()
+        assert net._engine.phase_s2_dgrad == (off == "0")
+        y = net(a.cuda(), b.cuda())
+        losses.focal_loss(y, lab.cuda()).backward()
+        res[off] = (y.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    s = float(res["1"][0].abs().max())
+    assert float((res["0"][0] - res["1"][0]).abs().max()) <= 1e-5 * s
+    for k, g in res["1"][1].items():
+        gs = float(g.abs().max())
+        assert float((res["0"][1][k] - g).abs().max()) <= 2e-3 * gs + 1e-9, k
