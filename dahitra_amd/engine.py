@@ -47,8 +47,10 @@ class CoarseRes:
 
 
 class Engine:
-    def __init__(self, net_G, dtype=torch.float32, use_tr=True):
+    def __init__(self, net_G, dtype=torch.float32, use_tr=True, attn_fp8=False):
         self.net_G = net_G
+        # fp8 (OCP e4m3) MFMA operands in the fused decoder layers' forward products (BASELINE configs[4]); bf16 mode only
+        self.attn_fp8 = bool(attn_fp8) or os.environ.get("DAHITRA_ATTN_FP8", "0") == "1"
         self.cfg = get_config(net_G)
         self.dtype = dtype
         self.use_tr = use_tr
@@ -545,7 +547,7 @@ class Engine:
             ops.XattnPrep(tok, tok_b, tok_s, B, images, L, heads, dim_head, g1, b1, wq, wkT, wvT, woT, self.dtype,
                           ATTN_SCALE, LN_EPS)
         y = ops.decoder_layer_fwd(x0, prep, rpi, g1, b1, bo, g2, b2, self.pk[w1k].fwd, fb1, self.pk[w2k].fwd, fb2, mlp,
-                                  LN_EPS)
+                                  LN_EPS, fp8=self.attn_fp8)
         if not self.need_grad:
             return y, None
 

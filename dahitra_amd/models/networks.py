@@ -79,7 +79,7 @@ class _NetFunction(torch.autograd.Function):
 class CDNet(nn.Module):
     """BASE_Transformer / BASE_Transformer_UNet replacement selected by net_G."""
 
-    def __init__(self, net_G, compute_dtype=None):
+    def __init__(self, net_G, compute_dtype=None, attn_dtype=None):
         super().__init__()
         self.net_G = net_G
         self.cfg = get_config(net_G)
@@ -114,7 +114,12 @@ class CDNet(nn.Module):
                     fan_in = int(math.prod(shape[1:]))
                     t = torch.empty(shape).uniform_(-1.0, 1.0).mul_(fan_in ** -0.5)
                 node.register_parameter(parts[-1], nn.Parameter(t))
-        self._engine = Engine(net_G, self.compute_dtype, use_tr=os.environ.get("DAHITRA_NO_TR", "0") != "1")
+        if attn_dtype not in (None, "bf16", "fp8"):
+            raise ValueError("attn_dtype must be 'bf16' or 'fp8', got %r" % attn_dtype)
+        if attn_dtype == "fp8" and self.compute_dtype != torch.bfloat16:
+            raise ValueError("attn_dtype='fp8' (fp8 MFMA operands in the decoder layers) needs compute_dtype='bf16'")
+        self._engine = Engine(net_G, self.compute_dtype, use_tr=os.environ.get("DAHITRA_NO_TR", "0") != "1",
+                              attn_fp8=attn_dtype == "fp8")
         self._arena = _Arena()
         self._anchor = None
         self.tokens_ = None      # attributes the reference stashes on the module (networks.py:373-374)
@@ -250,7 +255,7 @@ def define_G(args, init_type='normal', init_gain=0.02, gpu_ids=[]):
     """models/networks.py:130-168; reads args.net_G (and the optional args.compute_dtype)."""
     if get_config(args.net_G).get("ctor_only"):   # NotImplementedError for unknown names, as the reference
         raise NotImplementedError("Generator model name [%s] is not recognized" % args.net_G)
-    net = CDNet(args.net_G, getattr(args, "compute_dtype", None))
+    net = CDNet(args.net_G, getattr(args, "compute_dtype", None), getattr(args, "attn_dtype", None))
     return init_net(net, init_type, init_gain, gpu_ids)
 
 
@@ -267,7 +272,7 @@ def BASE_Transformer(input_nc=3, output_nc=2, with_pos='learned', resnet_stages_
         if c["kind"] == "bit" and c.get("backbone", "resnet18") == backbone and \
                 (c["n_class"], c["token_len"], c["enc_depth"], c["dec_depth"], c["dec_dim_head"]) == \
                 (output_nc, token_len, enc_depth, dec_depth, decoder_dim_head):
-            return CDNet(name, kw.get("compute_dtype"))
+            return CDNet(name, kw.get("compute_dtype"), kw.get("attn_dtype"))
     raise NotImplementedError("BASE_Transformer configuration not covered by define_G's net_G table")
 
 

@@ -883,11 +883,12 @@ def xattn_prep_bwd(prep, tok, dtok_accum, ln_g, wqT, wk, wv, wo, dkq, dvoT, dln_
           P(dwk), P(dwv), P(dwo), _ci(int(accumulate)), P(ws), S())
 
 
-def decoder_layer_fwd(x2d, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b, w1, b1, w2, b2, mlp, eps=1e-5):
-    """fused cross-attention + MLP decoder layer (csrc/decoder_fused.hip); x2d [rows, 32] bf16"""
+def decoder_layer_fwd(x2d, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b, w1, b1, w2, b2, mlp, eps=1e-5, fp8=False):
+    """fused cross-attention + MLP decoder layer (csrc/decoder_fused.hip); x2d [rows, 32] bf16.
+    fp8=True: the four MFMA products on OCP e4m3 operands (csrc/decoder_fp8.hip)"""
     y = torch.empty_like(x2d)
     with _Prof("decoder_layer_fwd", 0, _nb(x2d, y)):
-        _call("dh_decoder_layer_fwd", P(x2d), P(y), P(prep.kq), P(prep.voT), P(ln1_g), P(ln1_b), P(bo), P(ln2_g), P(ln2_b),
+        _call("dh_decoder_layer_fwd_fp8" if fp8 else "dh_decoder_layer_fwd", P(x2d), P(y), P(prep.kq), P(prep.voT), P(ln1_g), P(ln1_b), P(bo), P(ln2_g), P(ln2_b),
               P(w1), P(b1), P(w2), P(b2), _cl(x2d.shape[0]), _ci(rows_per_image), _ci(mlp), _cf(eps), S())
     return y
 

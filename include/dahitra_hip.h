@@ -269,6 +269,14 @@ int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, const void* voT
                          const float* ln1_b, const float* bo, const float* ln2_g, const float* ln2_b, const void* w1,
                          const float* b1, const void* w2, const float* b2, long rows, int rows_per_image, int mlp,
                          float eps, void* stream);
+/* the same layer with OCP fp8 (e4m3) operands in its two ATTENTION products (BASELINE configs[4] "fp8 MFMA attention"): Kq /
+ * VoT quantised per output row (absmax / 448) while they are staged, LN(x) / softmax probabilities converted at scale 1,
+ * fp32 accumulation; output within ~3e-2 (relative L2) of dh_decoder_layer_fwd.  Forward only: the backward runs
+ * dh_decoder_layer_bwd. */
+int dh_decoder_layer_fwd_fp8(const void* x, void* y, const void* kq, const void* voT, const float* ln1_g,
+                         const float* ln1_b, const float* bo, const float* ln2_g, const float* ln2_b, const void* w1,
+                         const float* b1, const void* w2, const float* b2, long rows, int rows_per_image, int mlp,
+                         float eps, void* stream);
 int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, const void* kq, const void* voT, const void* vo,
                          const void* kqT, const float* ln1_g, const float* ln1_b, const float* bo, const float* ln2_g,
                          const float* ln2_b, const void* w1, const void* w1T, const float* b1, const void* w2,

@@ -731,3 +731,45 @@ def test_stride2_conv_data_gradient_as_phase_convs(ops, dtype, cfg):
     dx2 = ops.conv3x3s2_dgrad(dyd, wph, Cin, coarse)
     # (bf16: the coarse shortcut gradient is rounded to bf16 before it is added, as the separate path does too)
     close(nchw(dx2), g_both, dtype, "stride-2 data gradient + coarse shortcut gradient", factor=3.0)
+
+
+@pytest.mark.parametrize("mlp", [64, 32])
+def test_decoder_layer_fp8_forward(ops, mlp):
+    """csrc/decoder_fp8.hip (OCP e4m3 MFMA operands, per-row weight scales, fp32 accumulation) against the bf16 fused
+    layer and against a plain torch fp32 evaluation of the same layer (help_funcs.py:66-114, 52-63 in re-associated form).
+    Accuracy contract: relative L2 distance to the bf16 kernel <= 3e-2."""
+    torch.manual_seed(0)
+    images, rpi, D = 3, 256, 32
+    rows = images * rpi
+    dtype = torch.bfloat16
+    x = dev(rnd((rows, D), dtype, 1001, 1.0), dtype)
+
+    class Prep:
+        pass
+    prep = Prep()
+    kq32 = rnd((images, 32, D), dtype, 1002, 0.3)
+    voT32 = rnd((images, D, 32), dtype, 1003, 0.3)
+    prep.kq, prep.voT = dev(kq32, dtype), dev(voT32, dtype)
+    g1, b1 = (1 + 0.1 * rnd((D,), torch.float32, 1004)).cuda(), (0.1 * rnd((D,), torch.float32, 1005)).cuda()
+    g2, b2 = (1 + 0.1 * rnd((D,), torch.float32, 1006)).cuda(), (0.1 * rnd((D,), torch.float32, 1007)).cuda()
+    bo = (0.1 * rnd((D,), torch.float32, 1008)).cuda()
+    w1 = rnd((mlp, D), dtype, 1009, D ** -0.5)
+    w2 = rnd((D, mlp), dtype, 1010, mlp ** -0.5)
+    fb1, fb2 = (0.1 * rnd((mlp,), torch.float32, 1011)).cuda(), (0.1 * rnd((D,), torch.float32, 1012)).cuda()
+    w1p, _ = ops.pack_weight(w1.cuda(), dtype, want_dgrad=False)
+    w2p, _ = ops.pack_weight(w2.cuda(), dtype, want_dgrad=False)
+    y16 = ops.decoder_layer_fwd(x, prep, rpi, g1, b1, bo, g2, b2, w1p, fb1, w2p, fb2, mlp).float().cpu()
+    y8 = ops.decoder_layer_fwd(x, prep, rpi, g1, b1, bo, g2, b2, w1p, fb1, w2p, fb2, mlp, fp8=True).float().cpu()
+    # torch fp32 evaluation: heads * 4 keys = the 32 rows of Kq; softmax over the 4 keys of a head
+    xf = x.float().cpu()
+    xn = F.layer_norm(xf, (D,), g1.cpu(), b1.cpu(), 1e-5).reshape(images, rpi, D)
+    dots = torch.einsum("ipc,ihc->iph", xn, kq32)
+    attn = torch.softmax(dots.reshape(images, rpi, 8, 4), -1).reshape(images, rpi, 32)
+    x1 = torch.einsum("iph,ich->ipc", attn, voT32).reshape(rows, D) + bo.cpu() + xf
+    l2 = F.layer_norm(x1, (D,), g2.cpu(), b2.cpu(), 1e-5)
+    ref = x1 + F.gelu(l2 @ w1.t() + fb1.cpu()) @ w2.t() + fb2.cpu()
+    rel = lambda u, v: float((u - v).norm() / v.norm())
+    print("decoder layer (mlp %d): bf16 vs fp32 %.3e, fp8 vs fp32 %.3e, fp8 vs bf16 %.3e" % (mlp, rel(y16, ref), rel(y8, ref), rel(y8, y16)))
+    assert rel(y16, ref) <= 1e-2
+    assert rel(y8, y16) <= 3e-2 and rel(y8, ref) <= 3e-2
+    assert torch.isfinite(y8).all()

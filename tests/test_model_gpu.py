@@ -588,3 +588,37 @@ def test_phase_convolution_paths_equal_reference_paths(name, monkeypatch):
     for k, g in res["1"][1].items():
         gs = float(g.abs().max())
         assert float((res["0"][1][k] - g).abs().max()) <= 2e-3 * gs + 1e-9, k
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4_dd8", R50])
+def test_fp8_attention_mode_tracks_bf16(name):
+    """attn_dtype='fp8' (BASELINE configs[4]: fp8 MFMA operands in the decoder layers' forward products): logits within a
+    small multiple of the bf16 pipeline's own distance to the fp32 oracle; the train step runs and produces finite grads"""
+    from dahitra_amd.models import losses
+    from dahitra_amd.models.networks import BASE_Transformer, define_G, init_net
+    a, b, lab = O.synthetic_batch(2, 128, seed=71)
+    sd = O.deterministic_state(name)
+    with torch.no_grad():
+        ref = O.forward({k: v.clone() for k, v in sd.items()}, name, a, b, training=False)
+    out = {}
+    for attn in ("bf16", "fp8"):
+        if name == R50:
+            net = init_net(BASE_Transformer(backbone='resnet50', compute_dtype="bf16", attn_dtype=attn), gpu_ids=[0])
+        else:
+            net = define_G(types.SimpleNamespace(net_G=name, compute_dtype="bf16", attn_dtype=attn), gpu_ids=[0])
+        net.load_state_dict(sd)
+        assert net._engine.attn_fp8 == (attn == "fp8")
+        net.eval()
+        with torch.no_grad():
+            out[attn] = net(a.cuda(), b.cuda()).float().cpu()
+        if attn == "fp8":
+            net.train()
+            y = net(a.cuda(), b.cuda())
+            losses.focal_loss(y, lab.cuda()).backward()
+            assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    l2 = lambda u, v: float((u - v).norm() / v.norm())
+    e16, e8, d = l2(out["bf16"], ref), l2(out["fp8"], ref), l2(out["fp8"], out["bf16"])
+    print("%s eval logits: bf16 vs oracle %.3e, fp8-attention vs oracle %.3e, fp8 vs bf16 %.3e" % (name, e16, e8, d))
+    assert e8 <= 4.0 * e16 + 2e-2
+    with pytest.raises(ValueError):
+        define_G(types.SimpleNamespace(net_G="base_transformer_pos_s4", compute_dtype="fp32", attn_dtype="fp8"), gpu_ids=[0])
