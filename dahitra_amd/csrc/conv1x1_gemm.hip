@@ -1,0 +1,220 @@
+// 1x1 / stride-1 convolution with >= 64 input channels as a K-DEEP GEMM on the CDNA4 matrix cores (bf16):
+//
+//   Y[pixel][cout] = act( sum_k X[pixel][k] * W[cout][k] + bias[cout] + residual[pixel][cout] )
+//
+// The ResNet-50 trunk (models/resnet.py:76-122, BASELINE configs[4]) spends two thirds of its FLOPs in such layers with
+// K = 64 .. 1024.  The tap-oriented direct-conv kernel (conv_mfma_impl.h) stages 32 channels per barrier pair, i.e. 8
+// MFMAs per wave between barriers for a 1x1 layer: 10 % of the MFMA peak.  Here a 256-thread workgroup owns a 128-pixel x
+// BN-cout tile (BN = 128 or 64), stages 64 channels (128 B rows) per step for both operands with direct-to-LDS loads
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass), double-buffered, the next step's loads in flight
+// across the barrier (counted vmcnt), 32 MFMAs (v_mfma_f32_16x16x32_bf16) per wave and step.  Both operands are
+// k-contiguous in memory (NHWC activations, [cout][cin] weights), so the LDS image of a step is [row][128 B] filled in
+// linear order with the 16-byte chunk index XOR-swizzled on the SOURCE address (chunk ^= row & 7) and on the fragment
+// reads (cdna_hip_programming.md rule 21): ds_read_b128 without the 8-way conflict of a linear 128-byte pitch.
+// Weights are the MFMA A operand (a lane ends with 4 consecutive couts of one pixel), as in conv_mfma_impl.h, and the
+// epilogue is that kernel's compact one: +bias, +residual, ReLU, per-tile BatchNorm partial sums in the same
+// [2][CoutPad][tiles] layout (tile = 128 consecutive pixels = the 8x16 tile count of the direct kernel, which the host
+// guarantees by OH % 8 == 0, OW % 16 == 0), LDS-transposed 16-byte stores.
+#include "conv_mfma_impl.h"
+
+namespace {
+
+constexpr int GBM = 128;          // pixels per workgroup
+constexpr int GBK = 64;           // channels per step (128-byte rows)
+
+__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(ConvArgs p) {
+    constexpr int ROWS = BN + GBM;                       // LDS rows per stage: weights first, then pixels
+    constexpr int STAGE = ROWS * 128;                    // bytes
+    constexpr int NI = ROWS / 32;                        // glds instructions per wave and stage (8 rows each)
+    constexpr int WC = BN / 64;                          // waves along cout (2 or 1)
+    constexpr int WP = 4 / WC;                           // waves along pixels (2 or 4)
+    constexpr int NT_ = GBM / WP / 16;                   // 16-pixel sub-tiles per wave (4 or 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g = lane >> 4;
+    const int wc = wv % WC, wp = wv / WC;
+    // Workgroup -> (pixel tile, cout tile).  The cout tiles of ONE pixel tile must run back to back on ONE XCD: they re-read
+    // the same 128 x Cin activation tile, which then comes from that XCD's L2 instead of HBM (with the cout tile as the slow
+    // grid dimension a 256 -> 1024 layer fetched its 134 MB input eight times).  Dispatch is round-robin over the 8 XCDs
+    // (block b -> XCD b % 8: a speed assumption only), so XCD x walks pixel tiles x, x + 8, ... with the cout tile fastest.
+    const int nco = p.Cout / BN, npt = (int)gridDim.x / nco;
+    int pt, cot;
+    if ((npt & 7) == 0) {
+        const int b = blockIdx.x, q = b >> 3;
+        cot = q % nco;
+        pt = (q / nco) * 8 + (b & 7);
+    } else {
+        cot = blockIdx.x % nco;
+        pt = blockIdx.x / nco;
+    }
+    const long m0 = (long)pt * GBM;                      // first pixel (flattened over N, OH, OW)
+    const int co0 = cot * BN;
+    const unsigned char* X = reinterpret_cast<const unsigned char*>(p.x);
+    const unsigned char* Wt = reinterpret_cast<const unsigned char*>(p.w);
+    const unsigned rowbytes = (unsigned)p.Cin * 2u;
+
+    // per-lane source row / swizzled chunk of each of this wave's NI loads (the same for every step)
+    const unsigned char* src[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int r = (j * 4 + wv) * 8 + (lane >> 3);                       // LDS row
+        const int c = (lane & 7) ^ (r & 7);                                  // source chunk landing in LDS chunk lane & 7
+        src[j] = (r < BN ? Wt + (size_t)(co0 + r) * rowbytes : X + (size_t)(m0 + r - BN) * rowbytes) + c * 16;
+    }
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) glds16(src[j] + (size_t)k0 * 2, smem + stage * STAGE + (j * 4 + wv) * 1024);
+    };
+
+    f32x4 acc[4][NT_];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < NT_; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = p.Cin / GBK;
+    issue(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool more = kt + 1 < KT;
+        if (more) issue((kt + 1) & 1, (kt + 1) * GBK);
+        // this wave's loads of step kt have landed when at most the NI just-issued ones are outstanding
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // (raw: a __syncthreads would drain the loads in flight)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sa = smem + (kt & 1) * STAGE;
+        const unsigned char* sb = sa + BN * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 4 + g;
+            V16u A[4], B[NT_];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int r = wc * 64 + s * 16 + pl;
+                A[s].u = *reinterpret_cast<const uint4*>(sa + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int t = 0; t < NT_; ++t) {
+                const int r = wp * (GBM / WP) + t * 16 + pl;
+                B[t].u = *reinterpret_cast<const uint4*>(sb + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < NT_; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s].h, B[t].h, acc[s][t], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // every wave is done reading this stage
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- epilogue (the staging LDS is free): +bias, +residual, ReLU, BN partial sums, transposed 16-byte stores ----
+    constexpr int TPITCH = BN * 2 + 16;
+    unsigned char* otile = smem + 4 * 2 * BN * 4;        // below it: the statistics scratch [4 waves][2][BN]
+    bf16* yout = reinterpret_cast<bf16*>(p.y);
+    const bf16* rin = reinterpret_cast<const bf16*>(p.res);
+    const bool relu = p.act == DH_ACT_RELU;
+    float ssum[4][4], ssq[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ssum[s][j] = 0.f; ssq[s][j] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = co0 + wc * 64 + s * 16 + g * 4;
+        float bs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs[j] = p.bias ? p.bias[c + j] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT_; ++t) {
+            const int px = wp * (GBM / WP) + t * 16 + pl;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[s][t][j] + bs[j];
+            if (rin) {
+                float rr[4];
+                ld4(rin + (size_t)(m0 + px) * p.Cout + c, rr);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += rr[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (relu) v[j] = fmaxf(v[j], 0.f);
+                ssum[s][j] += v[j];
+                ssq[s][j] += v[j] * v[j];
+            }
+            st4(reinterpret_cast<bf16*>(otile + px * TPITCH) + (c - co0), v);
+        }
+    }
+    if (p.stats) {
+        float* red = reinterpret_cast<float*>(smem);     // [4 waves][2][BN]
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = row16_sum(ssum[s][j]), b = row16_sum(ssq[s][j]);
+                if (pl == 0) {
+                    red[(wv * 2 + 0) * BN + wc * 64 + s * 16 + g * 4 + j] = a;
+                    red[(wv * 2 + 1) * BN + wc * 64 + s * 16 + g * 4 + j] = b;
+                }
+            }
+    }
+    __syncthreads();
+    constexpr int PPR = BN * 2 / 16;                      // 16-byte pieces per pixel
+    for (int i = tid; i < GBM * PPR; i += 256) {
+        const int px = i / PPR, q = i - px * PPR;
+        *reinterpret_cast<uint4*>(yout + (size_t)(m0 + px) * p.Cout + co0 + q * 8) =
+            *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
+    }
+    if (p.stats && tid < 2 * BN) {
+        const float* red = reinterpret_cast<const float*>(smem);
+        const int which = tid / BN, c = tid - which * BN;
+        // waves that hold couts [wc * 64, +64): wv = wp * WC + wc for every wp, in wave order
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < WP; ++q) t += red[((q * WC + c / 64 % WC) * 2 + which) * BN + c];
+        p.stats[((size_t)which * p.CoutPad + co0 + c) * npt + pt] = t;
+    }
+}
+
+template <int BN>
+int launch_gemm(const ConvArgs& a, hipStream_t st) {
+    constexpr int ROWS = BN + GBM;
+    const size_t staging = (size_t)2 * ROWS * 128;
+    const size_t otile = (size_t)4 * 2 * BN * 4 + (size_t)GBM * (BN * 2 + 16);
+    const size_t lds = staging > otile ? staging : otile;
+    auto kern = conv1x1_gemm_kernel<BN>;
+    static bool attr_done = false;
+    if (lds > 64 * 1024 && !attr_done) {
+        attr_done = true;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            DH_FAIL("conv1x1_gemm: cannot raise dynamic LDS to %zu", lds);
+        }
+    }
+    const long M = (long)a.N * a.OH * a.OW;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M / GBM) * (a.Cout / BN))), dim3(256), lds, st, a);
+    DH_CHECK_LAUNCH("conv1x1_gemm");
+    return 0;
+}
+
+}  // namespace
+
+// the shapes this kernel serves (everything else stays on the direct kernel); bf16 only
+bool dh_conv1x1_gemm_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
+    static const bool off = getenv("DAHITRA_NO_GEMM1X1") != nullptr;
+    return !off && dtype == DH_DTYPE_BF16 && ks == 1 && stride == 1 && a.pad == 0 && a.Cin >= 64 && a.Cin % GBK == 0 &&
+           a.Cout % 64 == 0 && a.CoutPad == a.Cout && a.OH % 8 == 0 && a.OW % 16 == 0 && a.H == a.OH && a.W == a.OW &&
+           !a.gate_y && !a.y2 && !a.in_scale && a.w_nstride == 0 && a.npix == a.OH * a.OW && a.act != DH_ACT_GELU &&
+           !(a.stats && (a.res || a.act != DH_ACT_NONE)) && ((long)a.N * a.OH * a.OW) % GBM == 0;
+}
+int dh_conv1x1_gemm_launch(const ConvArgs& a, hipStream_t st) {
+    return a.Cout % 128 == 0 ? launch_gemm<128>(a, st) : launch_gemm<64>(a, st);
+}

@@ -773,3 +773,39 @@ def test_decoder_layer_fp8_forward(ops, mlp):
     assert rel(y16, ref) <= 1e-2
     assert rel(y8, y16) <= 3e-2 and rel(y8, ref) <= 3e-2
     assert torch.isfinite(y8).all()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=4, cin=256, cout=64, h=16, w=16, stats=True, res=False, relu=False),      # Bottleneck conv1 (64-cout tile)
+    dict(n=2, cin=64, cout=256, h=16, w=32, stats=True, res=False, relu=False),      # conv3, one K step
+    dict(n=2, cin=1024, cout=256, h=16, w=16, stats=False, res=True, relu=True),     # layer3 conv1, eval form, 16 K steps
+    dict(n=16, cin=256, cout=1024, h=32, w=32, stats=True, res=False, relu=False),   # layer3 conv3 at size
+    dict(n=3, cin=128, cout=128, h=8, w=16, stats=False, res=False, relu=False),     # odd image count (M = 3 * 128)
+])
+def test_conv1x1_kdeep_gemm_path(ops, cfg):
+    """csrc/conv1x1_gemm.hip (direct-to-LDS loads, 64 channels per step, swizzled 128-byte rows) through dh_conv2d_fwd, bf16:
+    output, BatchNorm partial sums, bias / residual / ReLU, and the data gradient (a 1x1 conv with transposed weights)"""
+    dtype = torch.bfloat16
+    N, Cin, Cout, H, W = cfg["n"], cfg["cin"], cfg["cout"], cfg["h"], cfg["w"]
+    x = rnd((N, Cin, H, W), dtype, 1101).requires_grad_(True)
+    w = rnd((Cout, Cin, 1, 1), dtype, 1102, Cin ** -0.5)
+    b = rnd((Cout,), torch.float32, 1103, 0.1)
+    want = F.conv2d(x, w, b)
+    r = rnd(tuple(want.shape), dtype, 1104) if cfg["res"] else None
+    out_ref = want if r is None else want + r
+    if cfg["relu"]:
+        out_ref = F.relu(out_ref)
+    wp, wd = ops.pack_weight(w.cuda(), dtype, want_dgrad=True)
+    out = ops.conv2d(dev(nhwc(x.detach()), dtype), wp, Cout, 1, 1, 0, bias=b.cuda(),
+                     residual=dev(nhwc(r), dtype) if r is not None else None,
+                     act=ops.ACT_RELU if cfg["relu"] else ops.ACT_NONE, want_stats=cfg["stats"])
+    y = out[0] if cfg["stats"] else out
+    close(nchw(y), out_ref.detach(), dtype, "1x1 GEMM conv out")
+    if cfg["stats"]:
+        tot = out[1].double().sum(2).float().cpu()
+        close(tot[0, :Cout], out_ref.detach().sum((0, 2, 3)), dtype, "stats sum", scale=float(out_ref.detach().abs().sum((0, 2, 3)).max()))
+        close(tot[1, :Cout], (out_ref.detach() ** 2).sum((0, 2, 3)), dtype, "stats sumsq")
+    dy = rnd(tuple(want.shape), dtype, 1105)
+    want.backward(dy)
+    dx = ops.conv2d(dev(nhwc(dy), dtype), wd, Cin, 1, 1, 0)
+    close(nchw(dx), x.grad, dtype, "1x1 GEMM data gradient", factor=2.0)

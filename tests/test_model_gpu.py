@@ -622,3 +622,38 @@ def test_fp8_attention_mode_tracks_bf16(name):
     assert e8 <= 4.0 * e16 + 2e-2
     with pytest.raises(ValueError):
         define_G(types.SimpleNamespace(net_G="base_transformer_pos_s4", compute_dtype="fp32", attn_dtype="fp8"), gpu_ids=[0])
+
+
+def test_resnet50_trunk_at_1024_matches_reference_golden(golden_dir):
+    """BASELINE configs[4] geometry: ResNet-50 trunk (dilated layer3, K-deep 1x1 convolutions up to 1024 channels), 1024x1024
+    input, batch 1 -- fp32 logits against the fixture the reference wrote (eval and train mode), masks outside the tie band,
+    then the bf16 + fp8-attention configuration runs a train step at this size"""
+    from dahitra_amd.models import losses
+    from dahitra_amd.models.losses import argmax_mask
+    from dahitra_amd.models.networks import BASE_Transformer, init_net
+    g = np.load(os.path.join(golden_dir, "fwd1024_%s.npz" % R50))
+    bs, size, st = int(g["batch"]), int(g["size"]), int(g["stride"])
+    a, b, lab = O.synthetic_batch(bs, size, seed=int(g["seed"]))
+    for mode in ("eval", "train"):
+        net = make_net(R50)
+        net.train(mode == "train")
+        with torch.no_grad():
+            y = net(a.cuda(), b.cuda())
+        scale = float(g["scale_" + mode])
+        err = float((y.cpu()[..., ::st, ::st] - torch.from_numpy(g["logits_" + mode])).abs().max()) / scale
+        assert abs(float(y.double().sum()) - float(g["sum_" + mode])) <= 5e-4 * float(g["abssum_" + mode])
+        mask = argmax_mask(y).cpu().numpy().astype(np.uint8)
+        ref_mask = np.unpackbits(g["mask_" + mode])[:mask.size].reshape(mask.shape)
+        margin = (y[:, 0] - y[:, 1]).abs().cpu().numpy()
+        band = margin <= 1e-3 * scale
+        diff = mask != ref_mask
+        print("resnet50 1024x1024 %s: logits rel err %.2e, mask flips %d (outside the 1e-3 band: %d), band fraction %.5f"
+              % (mode, err, int(diff.sum()), int((diff & ~band).sum()), float(band.mean())))
+        assert err <= 5e-4
+        assert int((diff & ~band).sum()) == 0
+    net = init_net(BASE_Transformer(backbone='resnet50', compute_dtype="bf16", attn_dtype="fp8"), gpu_ids=[0])
+    net.load_state_dict(O.deterministic_state(R50))
+    net.train()
+    y = net(a.cuda(), b.cuda())
+    losses.focal_loss(y, lab.cuda()).backward()
+    assert torch.isfinite(y).all() and all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)

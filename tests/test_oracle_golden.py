@@ -173,3 +173,15 @@ def test_large_margin_fixture_matches_oracle(name, golden_dir):
         assert np.allclose(margin, g["margin_" + mode].astype(np.float32), rtol=2e-3, atol=1e-6)
         assert float((g["margin_" + mode].astype(np.float32) <= 4e-4 * float(g["scale_" + mode])).mean()) < 0.002
         assert abs(float(y.double().sum()) - float(g["sum_" + mode])) <= 1e-6 * float(g["abssum_" + mode])
+
+
+def test_resnet50_1024_fixture_matches_oracle_eval(golden_dir):
+    """BASELINE configs[4] shape (ResNet-50 trunk, 1024x1024, written by the reference): the oracle's eval forward"""
+    g = np.load(os.path.join(golden_dir, "fwd1024_base_transformer_pos_s4_resnet50.npz"))
+    name = "base_transformer_pos_s4_resnet50"
+    a, b, _ = O.synthetic_batch(int(g["batch"]), int(g["size"]), seed=int(g["seed"]))
+    with torch.no_grad():
+        y = O.forward(O.deterministic_state(name), name, a, b, training=False)
+    st = int(g["stride"])
+    assert float((y[..., ::st, ::st] - torch.from_numpy(g["logits_eval"])).abs().max()) <= 1e-5 * float(g["scale_eval"])
+    assert abs(float(y.double().sum()) - float(g["sum_eval"])) <= 1e-6 * float(g["abssum_eval"])
