@@ -148,6 +148,33 @@ __global__ __launch_bounds__(256) void head_dgrad3x3_reg_kernel(const T* __restr
     }
 }
 
+// ---- input pipeline on the device: crop + flips + normalise of pre-decoded uint8 pairs --------------------------------
+// What CDDataAugmentation.transform (datasets/data_utils.py:55-111) does per sample on the host with PIL -- crop window,
+// horizontal / vertical flip, ToTensor + Normalize(0.5, 0.5) -- for a whole batch in one pass: a PIL loader delivers a few
+// hundred pairs/s per worker, the train step consumes ~7 000.  src images [S][H][W][3] uint8 (A and B), labels [S][H][W]
+// uint8; sample n takes source pair idx[n] with params[n] = {x0, y0, hflip, vflip}; outputs A / B fp32 [N][3][h][w] in
+// [-1, 1] and L uint8 [N][1][h][w].  (The reference's random Gaussian blur has no counterpart here.)
+__global__ void augment_pairs_u8_kernel(const unsigned char* __restrict__ a, const unsigned char* __restrict__ b,
+                                        const unsigned char* __restrict__ l, const int* __restrict__ idx,
+                                        const int* __restrict__ params, int N, int H, int W, int h, int w,
+                                        float* __restrict__ oa, float* __restrict__ ob, unsigned char* __restrict__ ol) {
+    const long total = (long)N * h * w;
+    GSL(i, total) {
+        const int x = (int)(i % w), y = (int)((i / w) % h);
+        const int n = (int)(i / ((long)w * h));
+        const int* pr = params + n * 4;
+        const int sx = pr[0] + (pr[2] ? w - 1 - x : x), sy = pr[1] + (pr[3] ? h - 1 - y : y);
+        const long sp = ((long)idx[n] * H + sy) * W + sx;
+        const long plane = (long)h * w, o = (long)n * 3 * plane + (long)y * w + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            oa[o + c * plane] = ((float)a[sp * 3 + c] / 255.f - 0.5f) / 0.5f;       // ToTensor then Normalize: same roundings
+            ob[o + c * plane] = ((float)b[sp * 3 + c] / 255.f - 0.5f) / 0.5f;
+        }
+        if (ol) ol[(long)n * plane + (long)y * w + x] = l[sp];
+    }
+}
+
 // ---- channel-slice copy: dst[p, dc0 + c] = src[p, sc0 + c], c < Cn -------------------------
 template <typename T>
 __global__ void copy_channels_kernel(const T* __restrict__ src, int Cs, int sc0, T* __restrict__ dst, int Cd,
@@ -702,6 +729,16 @@ extern "C" int dh_head_dgrad3x3(int dtype, const void* dy, int CP, const float* 
         hipLaunchKernelGGL((head_dgrad3x3_kernel<float, 8>), dim3(grid), dim3(256), 0, ST(stream), (const float*)dy, w_oihw, (float*)dx, N, H, W, NC);
     }
     DH_CHECK_LAUNCH("head_dgrad3x3");
+    return 0;
+}
+extern "C" int dh_augment_pairs_u8(const unsigned char* a, const unsigned char* b, const unsigned char* l, const int* idx,
+                                   const int* params, int N, int H, int W, int h, int w, float* out_a, float* out_b,
+                                   unsigned char* out_l, void* stream) {
+    DH_REQUIRE(N > 0 && h > 0 && w > 0 && h <= H && w <= W, "augment_pairs_u8: bad sizes N=%d %dx%d -> %dx%d", N, H, W, h, w);
+    const long n = (long)N * h * w;
+    hipLaunchKernelGGL(augment_pairs_u8_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), a, b, l, idx, params, N, H, W,
+                       h, w, out_a, out_b, out_l);
+    DH_CHECK_LAUNCH("augment_pairs_u8");
     return 0;
 }
 extern "C" int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream) {

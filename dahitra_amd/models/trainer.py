@@ -1,21 +1,37 @@
-"""CDTrainer: the train step of the reference's models/trainer.py on the HIP pipelines.
+"""CDTrainer: the training loop of the reference's models/trainer.py on the HIP pipelines.
 
 Mirrored (same names, argument meaning, order of operations):
-    __init__(args, dataloaders)      trainer.py:21-103  net_G = define_G(args, gpu_ids), AdamW, scheduler
-    _forward_pass(batch)             trainer.py:247-252 batch {'A','B','L'} -> self.G_pred
-    _backward_G()                    trainer.py:254-262 B != 1: diceloss(argmax) + focal_loss; B == 1: cross_entropy
-    train_models()                   trainer.py:288-334 forward, zero_grad, backward, step (then the no-op clip)
-Out of scope here (host plumbing): Logger/Timer files, visualisation jpgs,
-numpy accuracy curves.  The running confusion matrix is kept on the device instead of the per-step
-device->host copy of trainer.py:163-173."""
+    __init__(args, dataloaders)      trainer.py:21-103   net_G = define_G(args, gpu_ids), AdamW, scheduler, Logger / Timer,
+                                                         running ConfuseMatrixMeter, accuracy curves, checkpoint / vis dirs
+    _load_checkpoint / _save_checkpoint   :106-158       resume net + optimizer + scheduler + epoch counters
+    _forward_pass(batch)             :247-252            batch {'A','B','L'} -> self.G_pred
+    _backward_G()                    :254-262            B != 1: diceloss(argmax) + focal_loss; B == 1: cross_entropy
+    _update_metric / _collect_running_batch_states / _collect_epoch_states   :163-214
+    _update_checkpoints / _update_*_acc_curve / _update_lr_schedulers        :216-245
+    train_models()                   :288-334            load, per epoch: train batches, scheduler step, val batches, ckpt
+Differences, all on the host side of the step: the confusion matrix of a batch is counted on the device (one kernel:
+arg-max + counts, no logits / mask copy per step; trainer.py:163-173 copies both to the host) and handed to the
+reference's meter as a matrix; `args.checkpoint_dir` / `args.vis_dir` / `args.loss` are optional (no log files without a
+checkpoint_dir); the visualisation grid of trainer.py:194-203 is not assembled (its imsave is commented out there)."""
 import os
 
+import numpy as np
 import torch
 
 from .. import ops
+from ..misc.logger_tool import Logger, Timer
+from ..misc.metric_tool import ConfuseMatrixMeter
 from ..optim import AdamW
 from . import losses
 from .networks import define_G, get_scheduler
+
+
+class _NullLogger:
+    def write(self, message):
+        pass
+
+    def write_dict_str(self, d):
+        pass
 
 
 class CDTrainer:
@@ -27,21 +43,157 @@ class CDTrainer:
             raise RuntimeError("dahitra_amd.CDTrainer needs a GPU id (the reference's CPU mode, gpu_ids=-1, "
                                "has no counterpart: there is no CPU fallback)")
         self.device = torch.device("cuda:%s" % args.gpu_ids[0])
+        print(self.device)
         self.lr = args.lr
         self.optimizer_G = AdamW(self.net_G.parameters(), lr=self.lr, betas=(0.9, 0.999), weight_decay=0.01)
         self.exp_lr_scheduler_G = get_scheduler(self.optimizer_G, args)
-        self.batch_size = args.batch_size
-        self.max_num_epochs = args.max_epochs
-        self.epoch_to_start = 0
+        self.running_metric = ConfuseMatrixMeter(n_class=self.n_class)
         self.checkpoint_dir = getattr(args, "checkpoint_dir", None)
-        self.G_pred = None
-        self.G_loss = None
-        self.batch = None
-        self.is_training = False
+        self.vis_dir = getattr(args, "vis_dir", None)
+        for d in (self.checkpoint_dir, self.vis_dir):
+            if d and not os.path.exists(d):
+                os.makedirs(d, exist_ok=True)
+        if self.checkpoint_dir:
+            self.logger = Logger(os.path.join(self.checkpoint_dir, 'log.txt'))
+            self.logger.write_dict_str(args.__dict__)
+        else:
+            self.logger = _NullLogger()
+        self.timer = Timer()
+        self.batch_size = args.batch_size
+        self.epoch_acc = 0
         self.best_val_acc = 0.0
         self.best_epoch_id = 0
+        self.epoch_to_start = 0
+        self.max_num_epochs = args.max_epochs
+        self.global_step = 0
+        self.steps_per_epoch = len(dataloaders['train']) if dataloaders and hasattr(dataloaders.get('train'), '__len__') else 1
+        self.total_steps = (self.max_num_epochs - self.epoch_to_start) * self.steps_per_epoch
+        self.G_pred = None
+        self.G_final_pred = None
+        self.pred_vis = None
+        self.batch = None
+        self.G_loss = None
+        self.is_training = False
+        self.batch_id = 0
         self.epoch_id = 0
+        loss_name = getattr(args, "loss", "ce")
+        if loss_name == 'ce':
+            self._pxl_loss = losses.cross_entropy
+        elif loss_name == 'focal':
+            self._pxl_loss = losses.focal_loss
+        else:       # ce_multi / ce_dice exist in the reference's table but _backward_G never reads self._pxl_loss
+            raise NotImplementedError(loss_name)
+        self.VAL_ACC = self._load_curve('val_acc.npy')
+        self.TRAIN_ACC = self._load_curve('train_acc.npy')
         self.confusion = torch.zeros(self.n_class, self.n_class, dtype=torch.int64, device=self.device)
+        self._batch_cm = torch.zeros_like(self.confusion)
+
+    def _load_curve(self, name):
+        path = os.path.join(self.checkpoint_dir, name) if self.checkpoint_dir else None
+        return np.load(path) if path and os.path.exists(path) else np.array([], np.float32)
+
+    # ---- checkpoints (trainer.py:106-134, 150-158) ---------------------------------------------------
+    def _load_checkpoint(self, ckpt_name='best_ckpt.pt'):
+        """resume: net, optimizer (flat Adam moments + step count) and scheduler states, epoch counters"""
+        path = os.path.join(self.checkpoint_dir, ckpt_name) if self.checkpoint_dir else None
+        if not path or not os.path.exists(path):
+            print('training from scratch...')
+            return False
+        self.logger.write('loading last checkpoint...\n')
+        checkpoint = torch.load(path, map_location=self.device, weights_only=False)
+        sd = checkpoint['model_G_state_dict']
+        if all(k.startswith('module.') for k in sd):           # written under nn.DataParallel
+            sd = {k[len('module.'):]: v for k, v in sd.items()}
+        self.net_G.load_state_dict(sd)
+        self.net_G.to(self.device)
+        self.optimizer_G.load_state_dict(checkpoint['optimizer_G_state_dict'])
+        self.exp_lr_scheduler_G.load_state_dict(checkpoint['exp_lr_scheduler_G_state_dict'])
+        self.epoch_to_start = checkpoint['epoch_id'] + 1
+        self.best_val_acc = checkpoint['best_val_acc']
+        self.best_epoch_id = checkpoint['best_epoch_id']
+        self.total_steps = (self.max_num_epochs - self.epoch_to_start) * self.steps_per_epoch
+        self.logger.write('Epoch_to_start = %d, Historical_best_acc = %.4f (at epoch %d)\n\n' %
+                          (self.epoch_to_start, self.best_val_acc, self.best_epoch_id))
+        return True
+
+    def _save_checkpoint(self, ckpt_name):
+        os.makedirs(self.checkpoint_dir, exist_ok=True)
+        # (plain python numbers: the file then also loads under torch.load's weights_only default; the reference's own
+        # checkpoints carry numpy scalars, which the loaders here accept with weights_only=False)
+        torch.save({'epoch_id': int(self.epoch_id), 'best_val_acc': float(self.best_val_acc),
+                    'best_epoch_id': int(self.best_epoch_id), 'model_G_state_dict': self.net_G.state_dict(),
+                    'optimizer_G_state_dict': self.optimizer_G.state_dict(),
+                    'exp_lr_scheduler_G_state_dict': self.exp_lr_scheduler_G.state_dict()},
+                   os.path.join(self.checkpoint_dir, ckpt_name))
+
+    # ---- bookkeeping ----------------------------------------------------------------------------------
+    def _timer_update(self):
+        self.global_step = (self.epoch_id - self.epoch_to_start) * self.steps_per_epoch + self.batch_id
+        self.timer.update_progress((self.global_step + 1) / max(self.total_steps, 1))
+        est = self.timer.estimated_remaining()
+        imps = (self.global_step + 1) * self.batch_size / max(self.timer.get_stage_elapsed(), 1e-9)
+        return imps, est
+
+    def _visualize_pred(self):
+        return losses.argmax_mask(self.G_final_pred).unsqueeze(1) * 255
+
+    def _update_lr_schedulers(self):
+        self.exp_lr_scheduler_G.step()
+
+    def _update_metric(self):
+        """arg-max + confusion counts of this batch in one device kernel; the 2x2 (n_class^2) matrix goes to the meter"""
+        gt = self.batch['L'].to(self.device).long().contiguous()
+        self._batch_cm.zero_()
+        ops.confusion_matrix(self.G_final_pred.detach().float().contiguous(), gt, self._batch_cm)
+        self.confusion += self._batch_cm
+        return self.running_metric.update_from_matrix(self._batch_cm.cpu().numpy())
+
+    def _collect_running_batch_states(self):
+        running_acc = self._update_metric()
+        loader = self.dataloaders['train'] if self.is_training else self.dataloaders['val']
+        m = len(loader) if hasattr(loader, '__len__') else -1
+        imps, est = self._timer_update()
+        if np.mod(self.batch_id, 2000) == 1:
+            self.logger.write('Is_training: %s. [%d,%d][%d,%d], imps: %.2f, est: %.2fh, G_loss: %.5f, running_mf1: %.5f\n' %
+                              (self.is_training, self.epoch_id, self.max_num_epochs - 1, self.batch_id, m,
+                               imps * self.batch_size, est, float(self.G_loss.detach()), running_acc))
+
+    def _collect_epoch_states(self):
+        scores = self.running_metric.get_scores()
+        self.epoch_acc = scores['mf1']
+        self.logger.write('Is_training: %s. Epoch %d / %d, epoch_mF1= %.5f\n' %
+                          (self.is_training, self.epoch_id, self.max_num_epochs - 1, self.epoch_acc))
+        self.logger.write(''.join('%s: %.5f ' % (k, v) for k, v in scores.items()) + '\n\n')
+        return scores
+
+    def _update_checkpoints(self):
+        self.logger.write('Lastest model updated. Epoch_acc=%.4f, Historical_best_acc=%.4f (at epoch %d)\n\n'
+                          % (self.epoch_acc, self.best_val_acc, self.best_epoch_id))
+        if self.epoch_acc > self.best_val_acc:              # (last_ckpt.pt is commented out in the reference, trainer.py:219)
+            self.best_val_acc = self.epoch_acc
+            self.best_epoch_id = self.epoch_id
+            if self.checkpoint_dir:
+                self._save_checkpoint(ckpt_name='best_ckpt.pt')
+            self.logger.write('*' * 10 + 'Best model updated!\n\n')
+
+    def _update_training_acc_curve(self):
+        self.TRAIN_ACC = np.append(self.TRAIN_ACC, [self.epoch_acc])
+        if self.checkpoint_dir:
+            np.save(os.path.join(self.checkpoint_dir, 'train_acc.npy'), self.TRAIN_ACC)
+
+    def _update_val_acc_curve(self):
+        self.VAL_ACC = np.append(self.VAL_ACC, [self.epoch_acc])
+        if self.checkpoint_dir:
+            np.save(os.path.join(self.checkpoint_dir, 'val_acc.npy'), self.VAL_ACC)
+
+    def _clear_cache(self):
+        self.running_metric.clear()
+        self.confusion.zero_()
+
+    def scores(self):
+        """acc / mIoU / mF1 / per-class figures of the device-side running confusion matrix (misc/metric_tool.py:96-138)"""
+        from ..misc.metric_tool import cm2score
+        return {k: float(v) for k, v in cm2score(self.confusion.cpu().numpy().astype(np.float64)).items()}
 
     # ---- the hot step --------------------------------------------------------------------------------
     def _forward_pass(self, batch):
@@ -70,74 +222,30 @@ class CDTrainer:
         # trainer.py:308 clips AFTER the step; gradients are zeroed before the next use => no effect
         return self.G_loss
 
-    def _update_metric(self):
-        gt = self.batch['L'].to(self.device).long().contiguous()
-        ops.confusion_matrix(self.G_pred.detach().float().contiguous(), gt, self.confusion)   # arg-max + counts, one kernel
-
-    def scores(self):
-        """acc / mIoU / mF1 from the confusion matrix (misc/metric_tool.py:96-138)"""
-        import numpy as np
-        cm = self.confusion.cpu().numpy().astype(np.float64)
-        tp = np.diag(cm)
-        sum_r, sum_c = cm.sum(1), cm.sum(0)
-        eps = np.finfo(np.float32).eps
-        acc = tp.sum() / (cm.sum() + eps)
-        recall, precision = tp / (sum_r + eps), tp / (sum_c + eps)
-        f1 = 2 * recall * precision / (recall + precision + eps)
-        iou = tp / (sum_r + sum_c - tp + eps)
-        return dict(acc=float(acc), miou=float(np.nanmean(iou)), mf1=float(np.nanmean(f1)))
-
-    # ---- checkpoints (trainer.py:106-134, 150-158) ---------------------------------------------------
-    def _load_checkpoint(self, ckpt_name='best_ckpt.pt'):
-        """resume: net, optimizer (flat Adam moments + step count) and scheduler states, epoch counters"""
-        path = os.path.join(self.checkpoint_dir, ckpt_name) if self.checkpoint_dir else None
-        if not path or not os.path.exists(path):
-            print('training from scratch...')
-            return False
-        checkpoint = torch.load(path, map_location=self.device)
-        sd = checkpoint['model_G_state_dict']
-        if all(k.startswith('module.') for k in sd):           # written under nn.DataParallel
-            sd = {k[len('module.'):]: v for k, v in sd.items()}
-        self.net_G.load_state_dict(sd)
-        self.net_G.to(self.device)
-        self.optimizer_G.load_state_dict(checkpoint['optimizer_G_state_dict'])
-        self.exp_lr_scheduler_G.load_state_dict(checkpoint['exp_lr_scheduler_G_state_dict'])
-        self.epoch_to_start = checkpoint['epoch_id'] + 1
-        self.best_val_acc = checkpoint['best_val_acc']
-        self.best_epoch_id = checkpoint['best_epoch_id']
-        print('Epoch_to_start = %d, Historical_best_acc = %.4f (at epoch %d)' %
-              (self.epoch_to_start, self.best_val_acc, self.best_epoch_id))
-        return True
-
-    def _save_checkpoint(self, ckpt_name):
-        os.makedirs(self.checkpoint_dir, exist_ok=True)
-        torch.save({'epoch_id': self.epoch_id, 'best_val_acc': self.best_val_acc,
-                    'best_epoch_id': self.best_epoch_id, 'model_G_state_dict': self.net_G.state_dict(),
-                    'optimizer_G_state_dict': self.optimizer_G.state_dict(),
-                    'exp_lr_scheduler_G_state_dict': self.exp_lr_scheduler_G.state_dict()},
-                   os.path.join(self.checkpoint_dir, ckpt_name))
-
     def train_models(self):
         self._load_checkpoint()
         for self.epoch_id in range(self.epoch_to_start, self.max_num_epochs):
-            self.confusion.zero_()
+            # ---- train ----
+            self._clear_cache()
             self.is_training = True
             self.net_G.train()
-            for batch in self.dataloaders['train']:
+            self.logger.write('lr: %0.7f\n' % self.optimizer_G.param_groups[0]['lr'])
+            for self.batch_id, batch in enumerate(self.dataloaders['train'], 0):
                 self.train_step(batch)
-                self._update_metric()
-            train_scores = self.scores()
-            self.exp_lr_scheduler_G.step()
-            self.confusion.zero_()
+                self._collect_running_batch_states()
+            self._collect_epoch_states()
+            self._update_training_acc_curve()
+            self._update_lr_schedulers()
+            # ---- eval ----
+            self.logger.write('Begin evaluation...\n')
+            self._clear_cache()
             self.is_training = False
             self.net_G.eval()
-            for batch in self.dataloaders['val']:
+            for self.batch_id, batch in enumerate(self.dataloaders['val'], 0):
                 with torch.no_grad():
                     self._forward_pass(batch)
-                self._update_metric()
-            val = self.scores()
-            print("epoch %d train mF1 %.5f val mF1 %.5f loss %.6f" % (self.epoch_id, train_scores["mf1"], val["mf1"],
-                                                                    float(self.G_loss)))
-            if val["mf1"] > self.best_val_acc and self.checkpoint_dir:      # trainer.py:216-232 (last_ckpt is commented
-                self.best_val_acc, self.best_epoch_id = val["mf1"], self.epoch_id     # out in the reference)
-                self._save_checkpoint('best_ckpt.pt')
+                self._collect_running_batch_states()
+            self._collect_epoch_states()
+            # ---- checkpoints ----
+            self._update_val_acc_curve()
+            self._update_checkpoints()

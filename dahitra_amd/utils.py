@@ -1,0 +1,68 @@
+"""The reference's utils.py surface that main_cd.py / eval_cd.py / the trainers call: get_loader, get_loaders, get_device,
+de_norm, make_numpy_grid (utils.py:10-107), without torchvision (make_numpy_grid tiles the batch itself, with
+torchvision.utils.make_grid's layout: 8 images per row, `padding` pixels of `pad_value` around every tile)."""
+import math
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from . import data_config
+from .datasets.CD_dataset import CDDataset
+
+
+def _dataset(kind, **kw):
+    if kind == 'CDDataset':
+        return CDDataset(**kw)
+    # xBDataset / xBDatasetMulti (datasets/CD_dataset.py:137-) belong to the xBD script zoo, outside the hot path's scope
+    raise NotImplementedError('Wrong dataset name %s (choose one from [CDDataset])' % kind)
+
+
+def get_loader(data_name, img_size=256, batch_size=8, split='test', is_train=False, dataset='CDDataset', patch=None):
+    cfg = data_config.DataConfig().get_data_config(data_name)
+    print(cfg)
+    data_set = _dataset(dataset, root_dir=cfg.root_dir, split=split, img_size=img_size, is_train=is_train,
+                        label_transform=cfg.label_transform, patch=patch)
+    return DataLoader(data_set, batch_size=batch_size, shuffle=False, num_workers=4)
+
+
+def get_loaders(args):
+    cfg = data_config.DataConfig().get_data_config(args.data_name)
+    split_val = getattr(args, 'split_val', 'val')
+    sets = {'train': _dataset(args.dataset, root_dir=cfg.root_dir, split=args.split, img_size=args.img_size, is_train=True,
+                              label_transform=cfg.label_transform),
+            'val': _dataset(args.dataset, root_dir=cfg.root_dir, split=split_val, img_size=args.img_size, is_train=False,
+                            label_transform=cfg.label_transform)}
+    return {k: DataLoader(v, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers) for k, v in sets.items()}
+
+
+def make_numpy_grid(tensor_data, pad_value=0, padding=0):
+    """[B, C, H, W] (or [C, H, W]) -> H' x W' x 3 numpy grid, 8 tiles per row"""
+    t = torch.as_tensor(tensor_data).detach().cpu()
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    if t.shape[1] == 1:
+        t = t.expand(-1, 3, -1, -1)
+    B, C, H, W = t.shape
+    ncol = min(8, B)
+    nrow = int(math.ceil(B / ncol))
+    hh, ww = H + padding, W + padding
+    grid = torch.full((C, hh * nrow + padding, ww * ncol + padding), float(pad_value), dtype=t.dtype)
+    for k in range(B):
+        r, c = divmod(k, ncol)
+        grid[:, r * hh + padding:r * hh + padding + H, c * ww + padding:c * ww + padding + W] = t[k]
+    vis = grid.numpy().transpose((1, 2, 0)).copy()
+    if vis.shape[2] == 1:
+        vis = np.stack([vis, vis, vis], axis=-1)
+    return vis
+
+
+def de_norm(tensor_data):
+    return tensor_data * 0.5 + 0.5
+
+
+def get_device(args):
+    """'0,1' -> args.gpu_ids = [0, 1] (negative ids dropped) and the first one becomes the current device"""
+    args.gpu_ids = [int(s) for s in str(args.gpu_ids).split(',') if int(s) >= 0]
+    if len(args.gpu_ids) > 0:
+        torch.cuda.set_device(args.gpu_ids[0])

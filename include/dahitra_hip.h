@@ -171,6 +171,13 @@ long dh_layernorm_bwd_workspace_size(long rows);
 int dh_reduce_partials(const float* partial, long nt, long n, float scale, float* out, int accumulate, void* stream);
 
 /* ---- pointwise / resampling / layout (models/resnet.py:154; networks.py:199-200,384,1312,1348) ---- */
+/* input pipeline on the device (replaces the per-sample PIL work of datasets/data_utils.py:55-111 -- crop window, h / v
+ * flip, ToTensor + Normalize(0.5, 0.5) -- for pre-decoded pairs): a, b [S][H][W][3] uint8, l [S][H][W] uint8 (or NULL);
+ * output sample n takes source pair idx[n] with params[n] = {x0, y0, hflip, vflip}; out_a / out_b fp32 [N][3][h][w],
+ * out_l uint8 [N][1][h][w]. */
+int dh_augment_pairs_u8(const unsigned char* a, const unsigned char* b, const unsigned char* l, const int* idx,
+                        const int* params, int N, int H, int W, int h, int w, float* out_a, float* out_b,
+                        unsigned char* out_l, void* stream);
 int dh_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, long HW, int CP, void* stream);
 /* data gradient of the class head (3x3 / s1 / p1, 32 -> n_class <= 8 channels; help_funcs.py:13-14, networks.py:1247):
  * dy [N][H][W][CP] (CP = 8 bf16 / 4 or 8 fp32 channels per pixel, the first NC real), w_oihw [NC][32][3][3] fp32,

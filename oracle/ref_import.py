@@ -140,3 +140,75 @@ def build_xbd_model(with_decoder_pos='learned'):
         return model.BASE_Transformer_UNet(input_nc=3, output_nc=5, token_len=4, resnet_stages_num=4,
                                            with_pos='learned', with_decoder_pos=with_decoder_pos,
                                            enc_depth=1, dec_depth=8)
+
+
+# ---------------------------------------------------------------------------------------------------
+# data path of the reference (datasets/CD_dataset.py, datasets/data_utils.py, misc/metric_tool.py)
+# ---------------------------------------------------------------------------------------------------
+_data = {}
+
+
+def load_data():
+    """Returns (CD_dataset module, data_utils module, metric_tool module) of the reference.
+
+    datasets/data_utils.py needs five torchvision.transforms.functional primitives (to_pil_image, hflip, vflip, to_tensor,
+    normalize) and imports cv2 / sklearn it never calls on the CDDataset path.  torchvision is not installed here, so the
+    five primitives are supplied with their documented semantics (PIL transposes, uint8 HWC -> float CHW / 255,
+    (x - mean) / std); every decision of the augmentation -- crop origin, which flips, the blur radius, the order of the
+    `random` draws, PIL's GaussianBlur -- is the reference's own code."""
+    if _data:
+        return _data["cd"], _data["du"], _data["metric"]
+    load()
+    import numpy as np
+    import torch
+    from PIL import Image
+
+    def to_pil_image(img):
+        return img if isinstance(img, Image.Image) else Image.fromarray(np.asarray(img))
+
+    def to_tensor(img):
+        a = np.asarray(img)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+        return t.float().div(255) if t.dtype == torch.uint8 else t.float()
+
+    def normalize(t, mean, std):
+        m = torch.tensor(mean, dtype=t.dtype).view(-1, 1, 1)
+        s = torch.tensor(std, dtype=t.dtype).view(-1, 1, 1)
+        return (t - m) / s
+
+    tf = _stub("torchvision.transforms.functional", to_pil_image=to_pil_image, to_tensor=to_tensor, normalize=normalize,
+               hflip=lambda im: im.transpose(Image.FLIP_LEFT_RIGHT), vflip=lambda im: im.transpose(Image.FLIP_TOP_BOTTOM),
+               rotate=lambda im, angle: im.rotate(angle))
+    tt = _stub("torchvision.transforms", functional=tf)
+    sys.modules["torchvision"].transforms = tt
+    _stub("cv2")
+    if "sklearn.model_selection" not in sys.modules:
+        try:
+            import sklearn.model_selection  # noqa: F401
+        except Exception:
+            _stub("sklearn")
+            _stub("sklearn.model_selection", train_test_split=None)
+    if not hasattr(np, "str"):
+        np.str = str                    # datasets/CD_dataset.py:32 (default argument evaluated lazily, numpy < 1.24 name)
+    for k in [k for k in sys.modules if k == "datasets" or k.startswith("datasets.") or k == "misc" or k.startswith("misc.")]:
+        del sys.modules[k]
+    # the reference's datasets/ and misc/ have no __init__.py (namespace packages): a regular `datasets` package in
+    # site-packages (HuggingFace) would win the import, so the two packages are registered by path
+    for pkg in ("datasets", "misc"):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF_ROOT, pkg)]
+        sys.modules[pkg] = m
+    sys.path.insert(0, REF_ROOT)
+    try:
+        import datasets.data_utils as du
+        import datasets.CD_dataset as cd
+        import misc.metric_tool as metric
+    finally:
+        sys.path.remove(REF_ROOT)
+        for pkg in ("datasets", "misc"):          # leave no shadow of the reference's package names behind
+            for k in [k for k in sys.modules if k == pkg or k.startswith(pkg + ".")]:
+                del sys.modules[k]
+    _data.update(cd=cd, du=du, metric=metric)
+    return cd, du, metric
