@@ -222,6 +222,7 @@ __device__ __forceinline__ void tile_put(unsigned char* tile, int pitch, int pp,
     *reinterpret_cast<uint2*>(tile + pp * pitch + (c0 + 16 + g * 4) * 2) = r.h[1];
 }
 
+// (forcing two waves per SIMD with __launch_bounds__(256, 2) spills 400 - 900 bytes per lane: 34 -> 64 us per launch)
 template <int MLP>
 __global__ __launch_bounds__(256) void dec_bwd_kernel(DecArgs p) {
     constexpr int NM = MLP / 16, NQ = MLP / 32;

@@ -635,6 +635,35 @@ class Engine:
             bwd(dlogits_nchw)
             plan.run()
 
+    # A backward pass in TWO parts (data-parallel overlap, dahitra_amd/graph.py): after backward_first() every gradient
+    # from resnet.layer3 to the end of the arena is final (its split-K reduces have run) and can be all-reduced while
+    # backward_second() computes the stem / layer1 / layer2 gradients.
+    def backward_first(self, dlogits_nchw, bwd):
+        split = getattr(bwd, "split", None)
+        if split is None:
+            raise RuntimeError("dahitra_amd: this net's backward has no split point")
+        plan = self._plans.get(True)
+        if plan is not None:
+            self.pk, self.xstack = plan[1], plan[2]
+        if self._wgrad_plan is None:
+            self._wgrad_plan = ops.WgradPlan(dlogits_nchw.device)
+        self._wgrad_plan.__enter__()
+        try:
+            self._split_state = (split[1], split[0](dlogits_nchw))
+            self._wgrad_plan.run()
+        except BaseException:
+            self._wgrad_plan.__exit__()
+            raise
+
+    def backward_second(self):
+        second, state = self._split_state
+        self._split_state = None
+        try:
+            second(state)
+            self._wgrad_plan.run()
+        finally:
+            self._wgrad_plan.__exit__()
+
     def _head_out(self, h, wkey, bkey):
         """final 3x3 conv to n_class logits, returned as NCHW fp32 (the reference's output layout)"""
         ncls = self.shapes[wkey][0]
@@ -701,7 +730,8 @@ class Engine:
         if not self.need_grad:
             return logits, None
 
-        def bwd(dl):
+        def bwd_first(dl):
+            """head, decoder, tokens, conv_pred, layer3: everything whose parameters sit behind layer2 in the arena"""
             dh = b_out(dl, next_gate=b_c0.gate)
             dupd, _ = b_c0(dh)
             dec_g = torch.empty_like(dec4)
@@ -712,8 +742,15 @@ class Engine:
             ops.tokenizer_bwd(feat, wa, tsaved, dtok_cat, dfeat4, self.g["conv_a.weight"], self.g["pos_embedding"],
                               B, L, accumulate=True)
             dl3 = b_pred(dfeat4) if phased else ops.upsample2_bwd(b_pred(dfeat4))
-            dxp = b_l1(b_l2(b_l3(dl3, next_gate=b_l2.gate), next_gate=b_l1.gate))
+            return b_l3(dl3, next_gate=b_l2.gate)
+
+        def bwd_second(dl2):
+            dxp = b_l1(b_l2(dl2, next_gate=b_l1.gate))
             b_stem(ops.maxpool_bwd(xarg, dxp, xshape))
+
+        def bwd(dl):
+            bwd_second(bwd_first(dl))
+        bwd.split = (bwd_first, bwd_second)
         return logits, bwd
 
     # hierarchical model -------------------------------------------------------------------------

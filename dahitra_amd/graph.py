@@ -6,8 +6,13 @@ hipGraphLaunch (MI355X guidance: capture launch-bound inner loops in hipGraphs, 
     loss = step(a, b, lab)                            # device scalar, same semantics as the eager step
 
 Recorded: forward, zero_grad, focal loss, backward and (single process) the AdamW kernel.  With
-torch.distributed the gradient all-reduce and AdamW run eagerly after the replay (two calls), the
-1/world factor folded into the optimizer's grad_scale.  The warm-up steps torch needs before capture are
+torch.distributed the step is TWO graphs around the exchange (nets with a split backward, i.e. the BiT family):
+    graph 1: forward, loss, backward down to and including resnet.layer3 -> every gradient from layer3 to the end of the
+             flat arena (~77 % of its bytes for base_transformer_pos_s4) is final;
+    all-reduce of that arena tail, ASYNC (RCCL's stream) ..........  } concurrently
+    graph 2: backward of layer2 / layer1 / stem                      }
+    all-reduce of the arena head, wait for both, AdamW (1/world folded into its grad_scale).
+Other nets: one graph, then all-reduce and AdamW.  The warm-up steps torch needs before capture are
 undone (parameters, BN buffers and optimizer state are restored), so the first graphed step is step 1."""
 import torch
 import torch.distributed as dist
@@ -23,6 +28,7 @@ class GraphedTrainStep:
         self.net, self.opt = net, opt
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.exchange = parallel.exchange_enabled()      # gradient all-reduce + AdamW after the replay
+        self.split_off = None                            # arena offset where the overlapped (two-graph) form splits
         self._set_inputs(a, b, lab)
         net._ensure_arena(a.device)
         # ---- snapshot the training state, warm up eagerly on a side stream, restore -------------------
@@ -46,8 +52,16 @@ class GraphedTrainStep:
         # immutable for the life of the process (a later, larger eager call allocates a NEW buffer instead of
         # freeing the one the graph still reads and writes).
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._eager_body(include_opt=not self.exchange)
+        if self.exchange and self._can_split():
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._split_first()
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+                net._engine.backward_second()
+        else:
+            self.split_off = None
+            with torch.cuda.graph(self.graph):
+                self.loss = self._eager_body(include_opt=not self.exchange)
         self._pinned = ops.pin_captured_buffers(net)
         self._generation = net._arena.generation
         torch.cuda.synchronize()
@@ -70,9 +84,52 @@ class GraphedTrainStep:
             self.opt.step()
         return loss.detach()
 
+    # ---- overlapped form ------------------------------------------------------------------------------
+    def _can_split(self):
+        """the net's backward has a split point and the arena is [stem, layer1, layer2 | layer3 ... everything else]"""
+        import os
+        if os.environ.get("DAHITRA_NO_OVERLAP", "0") == "1" or type(self) is not GraphedTrainStep:
+            return False
+        net = self.net
+        if net.cfg["kind"] != "bit":
+            return False
+        off = net._arena.offsets
+        first = [k for k in net._active_keys if k.startswith("resnet.layer3.")]
+        if not first:
+            return False
+        split = min(off[k][0] for k in first)
+        early = ("resnet.conv1.", "resnet.bn1.", "resnet.layer1.", "resnet.layer2.")
+        for k in net._active_keys:
+            if (off[k][0] < split) != k.startswith(early):
+                return False
+        self.split_off = split
+        return True
+
+    def _split_first(self):
+        """forward, loss and the first part of the backward, called under capture (engine level: one autograd-free pass)"""
+        net = self.net
+        logits = net._run_forward(self.a, self.b, need_grad=True)
+        bwd = net._engine.take_backward()
+        self.logits = logits
+        tgt = self.lab[:, 0] if self.lab.dim() == logits.dim() else self.lab
+        loss, dl = ops.focal_loss(logits, tgt.to(torch.int64).contiguous(), want_grad=True)
+        net._arena.grad.zero_()
+        net._engine.backward_first(dl, bwd)
+        return loss
+
     def _after_replay(self):
         """world > 1: the exchange step and the update run eagerly after the replayed forward/backward"""
         parallel.allreduce_net_grads_(self.net)
+        self.opt.step()
+
+    def _replay_overlapped(self):
+        _, grad = self.net.flat_params()
+        self.graph.replay()
+        w1 = dist.all_reduce(grad[self.split_off:], op=dist.ReduceOp.SUM, async_op=True)      # waits for graph 1 only
+        self.graph2.replay()                                                                  # ... while this runs
+        w2 = dist.all_reduce(grad[:self.split_off], op=dist.ReduceOp.SUM, async_op=True)
+        w1.wait()
+        w2.wait()
         self.opt.step()
 
     def __call__(self, *inputs):
@@ -82,6 +139,9 @@ class GraphedTrainStep:
         if inputs and inputs[0] is not None:
             self._copy_inputs(*inputs)
         self.opt.sync_hyper(1.0 / self.world)
+        if self.split_off is not None:
+            self._replay_overlapped()
+            return self.loss
         self.graph.replay()
         if self.exchange:
             self._after_replay()

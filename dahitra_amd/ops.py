@@ -67,7 +67,7 @@ def pin_captured_buffers(net):
     keep = list(_ws.values())
     eng = net._engine
     if eng._wgrad_plan is not None:
-        keep += list(eng._wgrad_plan.slots) + [eng._wgrad_plan.table]
+        keep += list(eng._wgrad_plan.slots) + list(eng._wgrad_plan.tables.values())
     for pack, _, xstack in eng._plans.values():
         keep += [pack.table] + list(pack.keep) + list(xstack.values())
     keep += [net._arena.flat, net._arena.grad]
@@ -165,7 +165,8 @@ class WgradPlan:
                     ("first_block", ctypes.c_int), ("nblocks", ctypes.c_int)]
 
     def __init__(self, device):
-        self.device, self.slots, self.table, self.sig, self.cur, self.blocks = device, [], None, None, 0, 0
+        self.device, self.slots, self.cur, self.blocks = device, [], 0, 0
+        self.tables, self.sigs, self.phase = {}, {}, 0      # one job table per run() of a pass (a split backward runs twice)
         self._prev = None
         self.post = []
 
@@ -176,6 +177,7 @@ class WgradPlan:
         self.jobs = []
         self.post = []
         self.blocks = 0
+        self.phase = 0
         return self
 
     def __exit__(self, *exc):
@@ -188,8 +190,9 @@ class WgradPlan:
         if self.cur == len(self.slots):
             self.slots.append(torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device))
         elif self.slots[self.cur].numel() < nbytes:
+            _PINNED.append(self.slots[self.cur])         # a captured graph may still point at the smaller buffer
             self.slots[self.cur] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-            self.table = None
+            self.tables = {}
         buf = self.slots[self.cur]
         self.cur += 1
         return buf
@@ -201,22 +204,26 @@ class WgradPlan:
         self.blocks += nb
 
     def run(self):
-        if not self.jobs:
-            return
-        self._run_reduce()
+        """reduce every layer deferred since the last run() of this pass (a split backward calls it once per part)"""
+        if self.jobs:
+            self._run_reduce()
         for fn in self.post:          # launches that consume reduced gradients (phase-gradient combine)
             fn()
+        self.jobs, self.post, self.blocks = [], [], 0
+        self.phase += 1
 
     def _run_reduce(self):
         sig = b"".join(bytes(j) for j in self.jobs)
-        if self.table is None or sig != self.sig:
+        if self.tables.get(self.phase) is None or sig != self.sigs.get(self.phase):
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("dahitra_amd: the weight-gradient plan changed during graph capture; run one eager "
                                    "step of the same shapes first")
             assert ctypes.sizeof(self._Job) == _lib.lib().dh_wgrad_reduce_job_size()
-            self.table = torch.frombuffer(bytearray(sig), dtype=torch.uint8).to(self.device)
-            self.sig = sig
-        _call("dh_wgrad_reduce_multi", P(self.table), _ci(len(self.jobs)), _ci(self.blocks), S())
+            if self.tables.get(self.phase) is not None:
+                _PINNED.append(self.tables[self.phase])
+            self.tables[self.phase] = torch.frombuffer(bytearray(sig), dtype=torch.uint8).to(self.device)
+            self.sigs[self.phase] = sig
+        _call("dh_wgrad_reduce_multi", P(self.tables[self.phase]), _ci(len(self.jobs)), _ci(self.blocks), S())
 
 
 _WGRAD_PLAN = None

@@ -48,6 +48,8 @@ def _worker(rank, world, port, steps, use_graph, out):
     a, b, lab = a[lo:hi].cuda(), b[lo:hi].cuda(), lab[lo:hi].cuda()
     opt = AdamW(net.parameters(), lr=0.01, weight_decay=0.01, capturable=use_graph)
     step = GraphedTrainStep(net, opt, a, b, lab) if use_graph else None
+    if step is not None:       # the overlapped form: two graphs around the all-reduce of the arena tail (layer3 .. end)
+        assert step.exchange and step.split_off is not None and 0 < step.split_off < net._arena.n_active
     for _ in range(steps):
         if step is not None:
             step(a, b, lab)
