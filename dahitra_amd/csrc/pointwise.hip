@@ -114,13 +114,24 @@ __global__ __launch_bounds__(256) void head_dgrad3x3_reg_kernel(const T* __restr
     constexpr int V = V16<T>::N;           // channels of one output piece
     constexpr int LPP = 32 / V;            // lanes per pixel
     const int cg = threadIdx.x % LPP;
+    // weights: OIHW global -> LDS [tap][co][ci] once per workgroup (coalesced), then 9 * NC * V registers per lane
+    // (every lane fetching its 144 values from global cost more than the whole rest of the kernel: 141 us)
+    __shared__ __attribute__((aligned(16))) float sw[9 * NC * 32];
+    for (int i = threadIdx.x; i < 9 * NC * 32; i += blockDim.x) {
+        const int ci = i & 31, co = (i >> 5) % NC, tap = i / (32 * NC);
+        sw[i] = w_oihw[((size_t)co * 32 + ci) * 9 + tap];
+    }
+    __syncthreads();
     float w[9][NC][V];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int co = 0; co < NC; ++co)
 #pragma unroll
-            for (int j = 0; j < V; ++j) w[t][co][j] = w_oihw[((size_t)co * 32 + cg * V + j) * 9 + t];
+            for (int j = 0; j < V; j += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(sw + (t * NC + co) * 32 + cg * V + j);
+                w[t][co][j] = q.x; w[t][co][j + 1] = q.y; w[t][co][j + 2] = q.z; w[t][co][j + 3] = q.w;
+            }
     const long total = (long)N * H * W * LPP;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long px = i / LPP;
@@ -172,6 +183,57 @@ __global__ void augment_pairs_u8_kernel(const unsigned char* __restrict__ a, con
             ob[o + c * plane] = ((float)b[sp * 3 + c] / 255.f - 0.5f) / 0.5f;
         }
         if (ol) ol[(long)n * plane + (long)y * w + x] = l[sp];
+    }
+}
+
+// bf16, n_class <= 2: the same data gradient on the matrix cores WITHOUT padding dY in memory.  K = (tap, co) = 18 -> one
+// v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 input channels: the weights are the A operand (two fragments, loaded once
+// per wave), the B operand (k = 8 g + e -> tap 4 g + e / 2, co = e & 1) is gathered straight from dY with one 4-byte
+// load per tap (lane group g = 3 and three quarters of g = 2 hold zeros).  A lane ends with 4 consecutive input channels of
+// one pixel, twice: 8-byte stores, 64 B per pixel.  HBM-bound: 16 B read (x9 from L1 / L2) + 64 B written per pixel.
+__global__ __launch_bounds__(256) void head_dgrad3x3_mfma_kernel(const bf16* __restrict__ dy, const float* __restrict__ w_oihw,
+                                                                 bf16* __restrict__ dx, int N, int H, int W, int NC) {
+    const int lane = threadIdx.x & 63, pl = lane & 15, g = lane >> 4;
+    // A fragments: row ci = s * 16 + pl, k = 8 g + e
+    s16x8 wa[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int tap = 4 * g + (e >> 1), co = e & 1;
+            v[e] = (tap < 9 && co < NC) ? w_oihw[((size_t)co * 32 + s * 16 + pl) * 9 + tap] : 0.f;
+        }
+        union { uint4 u; s16x8 h; } pk;
+        pk.u = make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
+        wa[s] = pk.h;
+    }
+    const long total = (long)N * H * W, groups = (total + 15) / 16;
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long grp = wave0; grp < groups; grp += nwaves) {
+        const long px = grp * 16 + pl;
+        const bool inb = px < total;
+        const int x = (int)(px % W), y = (int)((px / W) % H);
+        const long n = px / ((long)W * H);
+        unsigned bk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tap = 4 * g + q, kh = tap / 3, kw = tap - kh * 3;
+            const int yy = y + 1 - kh, xx = x + 1 - kw;
+            const bool ok = inb && tap < 9 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const unsigned v = *reinterpret_cast<const unsigned*>(dy + ((n * H + (ok ? yy : y)) * W + (ok ? xx : x)) * 8 * (inb ? 1 : 0));
+            bk[q] = ok ? v : 0u;
+        }
+        union { uint4 u; s16x8 h; } b;
+        b.u = make_uint4(bk[0], bk[1], bk[2], bk[3]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s], b.h, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            if (inb) {
+                const float r[4] = {d[0], d[1], d[2], d[3]};
+                st4(dx + px * 32 + s * 16 + g * 4, r);
+            }
+        }
     }
 }
 
@@ -708,9 +770,18 @@ extern "C" int dh_head_dgrad3x3(int dtype, const void* dy, int CP, const float* 
     DH_REQUIRE(NC >= 1 && NC <= 8 && NC <= CP, "head_dgrad3x3: n_class=%d with CP=%d", NC, CP);
     const long n = (long)N * H * W;
     const int grid = ew_grid(n, 256);
+    if (NC <= 2 && dtype == DH_DTYPE_BF16 && CP == 8 && !getenv("DAHITRA_HEAD_DGRAD_VALU")) {      // matrix cores, K = 18
+        const long groups = (n + 15) / 16;
+        long g = (groups * 64 + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(head_dgrad3x3_mfma_kernel, dim3((int)g), dim3(256), 0, ST(stream), (const bf16*)dy, w_oihw, (bf16*)dx,
+                           N, H, W, NC);
+        DH_CHECK_LAUNCH("head_dgrad3x3");
+        return 0;
+    }
     if (NC <= 2 && (dtype == DH_DTYPE_BF16 ? CP == 8 : (CP == 4 || CP == 8))) {      // weights in registers
 #define DH_HEAD_REG(T, CPV, NCV, LPP)                                                                                       \
-        hipLaunchKernelGGL((head_dgrad3x3_reg_kernel<T, CPV, NCV>), dim3(ew_grid(n * LPP, 256)), dim3(256), 0, ST(stream), \
+        hipLaunchKernelGGL((head_dgrad3x3_reg_kernel<T, CPV, NCV>), dim3(ew_grid(n * LPP, 256 * 8)), dim3(256), 0, ST(stream), \
                            (const T*)dy, w_oihw, (T*)dx, N, H, W)
         if (dtype == DH_DTYPE_BF16) { if (NC == 2) DH_HEAD_REG(bf16, 8, 2, 4); else DH_HEAD_REG(bf16, 8, 1, 4); }
         else if (CP == 4) { if (NC == 2) DH_HEAD_REG(float, 4, 2, 8); else DH_HEAD_REG(float, 4, 1, 8); }
