@@ -37,6 +37,8 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     if (in_scale) DH_REQUIRE(in_shift && N % a.in_groups == 0 && w_image_stride == 0,
                              "conv2d_fwd: BatchNorm-on-load needs in_shift and N %% in_groups == 0");
     a.phase_mode = phase_mode;
+    static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
+    a.no_xcd_remap = no_remap;
     if (phase_mode) {
         DH_REQUIRE(ks == 2 && stride == 1 && pad == 1 && dilation == 1 && (!residual || phase_mode == 1) && !stats_partial && !y_preact && !gate_y &&
                    !in_scale && w_image_stride == 0 && npix_valid == 0 && H == OH && W == OW && act != DH_ACT_GELU,

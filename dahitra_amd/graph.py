@@ -37,9 +37,15 @@ class GraphedTrainStep:
         opt0 = opt.snapshot_flat_state(net)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        split = self.exchange and self._can_split()
         with torch.cuda.stream(s):
             for _ in range(warmup):
-                self._eager_body(include_opt=True)
+                if split:      # the same launches the two captures make (the split backward has its own reduce tables)
+                    self._split_first()
+                    net._engine.backward_second()
+                    self.opt.step()
+                else:
+                    self._eager_body(include_opt=True)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         net._arena.flat.copy_(flat0)
@@ -52,7 +58,7 @@ class GraphedTrainStep:
         # immutable for the life of the process (a later, larger eager call allocates a NEW buffer instead of
         # freeing the one the graph still reads and writes).
         self.graph = torch.cuda.CUDAGraph()
-        if self.exchange and self._can_split():
+        if split:
             self.graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.loss = self._split_first()
@@ -86,7 +92,9 @@ class GraphedTrainStep:
 
     # ---- overlapped form ------------------------------------------------------------------------------
     def _can_split(self):
-        """the net's backward has a split point and the arena is [stem, layer1, layer2 | layer3 ... everything else]"""
+        """the net's backward has a split point and every gradient the second graph writes (stem, layer1, layer2) lies
+        below the first layer3 offset: the arena tail [split, end) is complete after the first graph.  Keys below the
+        split that the first graph writes (pos_embedding is registered first) just ride with the second all-reduce."""
         import os
         if os.environ.get("DAHITRA_NO_OVERLAP", "0") == "1" or type(self) is not GraphedTrainStep:
             return False
@@ -100,7 +108,7 @@ class GraphedTrainStep:
         split = min(off[k][0] for k in first)
         early = ("resnet.conv1.", "resnet.bn1.", "resnet.layer1.", "resnet.layer2.")
         for k in net._active_keys:
-            if (off[k][0] < split) != k.startswith(early):
+            if k.startswith(early) and off[k][0] >= split:
                 return False
         self.split_off = split
         return True
@@ -115,6 +123,7 @@ class GraphedTrainStep:
         loss, dl = ops.focal_loss(logits, tgt.to(torch.int64).contiguous(), want_grad=True)
         net._arena.grad.zero_()
         net._engine.backward_first(dl, bwd)
+        net._bind_grad_views()           # the optimizer skips parameters without a .grad, as torch does
         return loss
 
     def _after_replay(self):

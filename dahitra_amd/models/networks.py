@@ -213,6 +213,11 @@ class CDNet(nn.Module):
         if fresh:
             ar.grad.zero_()
         self._engine.backward(dlogits, bwd)
+        self._bind_grad_views(sd_p)
+
+    def _bind_grad_views(self, sd_p=None):
+        """every active parameter's .grad = its view of the flat gradient arena (host bookkeeping, no launch)"""
+        sd_p = sd_p if sd_p is not None else dict(self.named_parameters())
         for k in self._active_keys:
             p = sd_p[k]
             if p.grad is None:
