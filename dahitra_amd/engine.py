@@ -70,6 +70,8 @@ class Engine:
         # data gradient of the 3x3 stride-2 convolutions as four output-parity phase convolutions over dY instead of a
         # stride-1 convolution over the zero-inserted dY (4x the pixels, 75 % zeros)
         self.phase_s2_dgrad = os.environ.get("DAHITRA_NO_PHASE_S2", "0") != "1"
+        # bf16: the 7x7/2 stem as one kernel on the NCHW fp32 images (csrc/stem.hip) instead of space-to-depth + 4x4 conv
+        self.direct_stem = os.environ.get("DAHITRA_NO_DIRECT_STEM", "0") != "1"
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -95,7 +97,8 @@ class Engine:
         pack, self.pk, self.xstack = plan
         pack.run()
         key = "resnet.conv1.weight"
-        self.pk[key] = Packed(ops.stem_pack_weight(self.p[key], self.dtype), None)
+        if not (self.direct_stem and self.dtype == torch.bfloat16):      # the direct stem kernel reads the OIHW weights itself
+            self.pk[key] = Packed(ops.stem_pack_weight(self.p[key], self.dtype), None)
 
     def _build_plan(self):
         ck = ops.chunk_channels(self.dtype)
@@ -251,16 +254,21 @@ class Engine:
         stem's activation is never written."""
         B = x1.shape[0]
         H, W = x1.shape[2], x1.shape[3]
-        cp = ops.chunk_channels(self.dtype)
-        xs = torch.empty(2 * B, H // 2, W // 2, cp, dtype=self.dtype, device=x1.device)
-        ops.stem_space_to_depth_into(x1, xs[:B])
-        ops.stem_space_to_depth_into(x2, xs[B:])
         wkey, bnkey = "resnet.conv1.weight", "resnet.bn1"
         gamma, beta = self.p[bnkey + ".weight"], self.p[bnkey + ".bias"]
         rm, rv = self.p[bnkey + ".running_mean"], self.p[bnkey + ".running_var"]
         oh, ow = H // 2, W // 2
+        direct = self.direct_stem and self.dtype == torch.bfloat16      # one kernel on the NCHW images (csrc/stem.hip)
+        if not direct:
+            cp = ops.chunk_channels(self.dtype)
+            xs = torch.empty(2 * B, H // 2, W // 2, cp, dtype=self.dtype, device=x1.device)
+            ops.stem_space_to_depth_into(x1, xs[:B])
+            ops.stem_space_to_depth_into(x2, xs[B:])
         if self.training:
-            y, st = ops.conv2d(xs, self.pk[wkey].fwd, 64, 4, 1, 2, want_stats=True, out_hw=(oh, ow))
+            if direct:
+                y, st, xs = ops.stem7_fwd(x1, x2, self.p[wkey], want_stats=True, want_xs=self.need_grad, groups=groups)
+            else:
+                y, st = ops.conv2d(xs, self.pk[wkey].fwd, 64, 4, 1, 2, want_stats=True, out_hw=(oh, ow))
             mean, invstd, scale, shift = ops.bn_finalize(st, 64, groups, B * oh * ow, gamma, beta, rm, rv, BN_MOMENTUM,
                                                          BN_EPS, nbt=self.p[bnkey + ".num_batches_tracked"])
             if pool:
@@ -270,8 +278,11 @@ class Engine:
                 out = ops.bn_apply(y, scale, shift, groups, RELU)
         else:
             scale, shift = ops.bn_eval_params(gamma, beta, rm, rv, BN_EPS)
-            wp = ops.stem_pack_weight(self.p[wkey], self.dtype, out_scale=scale)
-            out = ops.conv2d(xs, wp, 64, 4, 1, 2, bias=shift, act=RELU, out_hw=(oh, ow))
+            if direct:
+                out = ops.stem7_fwd(x1, x2, self.p[wkey], out_scale=scale, bias=shift, relu=True)[0]
+            else:
+                wp = ops.stem_pack_weight(self.p[wkey], self.dtype, out_scale=scale)
+                out = ops.conv2d(xs, wp, 64, 4, 1, 2, bias=shift, act=RELU, out_hw=(oh, ow))
             y = mean = invstd = None
             if pool:
                 pooled, parg = ops.maxpool(out), None

@@ -530,6 +530,21 @@ def stem_pack_weight(w, dtype, out_scale=None):
     return out
 
 
+def stem7_fwd(x1, x2, w, out_scale=None, bias=None, relu=False, want_stats=False, want_xs=False, groups=1):
+    """7x7/2 stem on the NCHW fp32 images of both streams (x2 may be None) -> (y bf16 NHWC [N,H/2,W/2,64], stats, xs16)"""
+    B, C, H, W = x1.shape
+    assert C == 3 and x1.dtype == torch.float32 and x1.is_contiguous() and (x2 is None or (x2.shape == x1.shape and x2.is_contiguous()))
+    N = B if x2 is None else 2 * B
+    y = torch.empty(N, H // 2, W // 2, 64, dtype=torch.bfloat16, device=x1.device)
+    nt = _lib.lib().dh_stem7_fwd_num_slots(N, H, W, groups)
+    stats = torch.empty(2, 64, nt, dtype=torch.float32, device=x1.device) if want_stats else None
+    xs = torch.empty(N, H // 2, W // 2, 16, dtype=torch.bfloat16, device=x1.device) if want_xs else None
+    with _Prof("stem7_fwd", 2.0 * N * (H // 2) * (W // 2) * 64 * 147, _nb(x1, x2, y, xs)):
+        _call("dh_stem7_fwd", P(x1), P(x2), _ci(B), _ci(N), _ci(H), _ci(W), P(w), P(out_scale), P(bias), _ci(int(relu)), P(y),
+              P(stats), _ci(groups), P(xs), S())
+    return y, stats, xs
+
+
 def stem_wgrad(x_s2d, dy, dw, accumulate=False, use_tr=True):
     N, H2, W2, cp = x_s2d.shape
     O = dy.shape[-1]

@@ -132,6 +132,16 @@ int dh_zero_insert2(int dtype, const void* dy, void* z, int N, int OH, int OW, i
 int dh_stem_space_to_depth(int dtype, const float* x_nchw, void* y, int N, int H, int W, int CP, void* stream);
 int dh_stem_pack_weight(int dtype, const float* w_oihw, const float* out_scale, void* packed, int O, int CP, void* stream);
 int dh_stem_unpack_grad(const float* dw2, float* dw_oihw, int O, int CP, int accumulate, void* stream);
+/* The same stem (models/resnet.py:150, applied to both images by forward_single, models/networks.py:215-224) as one bf16
+ * kernel on the NCHW fp32 images themselves: images [0, B) from xa, [B, N) from xb (xb may be NULL when B == N).
+ * w_oihw fp32 [64][3][7][7]; out_scale / bias (optional, per cout): eval-mode BatchNorm folded in; relu: 0 / 1.
+ * y: bf16 NHWC [N][H/2][W/2][64].  stats (optional, raw convolution only): [2][64][dh_stem7_fwd_num_slots] sum / sum of
+ * squares per workgroup for dh_bn_finalize (ntiles = slots); a workgroup stays inside one of the `groups` equal image
+ * ranges, slots of group 0 first.  xs16 (optional): the space-to-depth image [N][H/2][W/2][16] bf16 (channel (ry*2+rx)*3 + c, 4 zero
+ * channels) the weight gradient reads (dh_conv2d_wgrad with ks = 4, Cin = 16, pitch 16 + dh_stem_unpack_grad). */
+int dh_stem7_fwd(const float* xa, const float* xb, int B, int N, int H, int W, const float* w_oihw, const float* out_scale,
+                 const float* bias, int relu, void* y, float* stats, int groups, void* xs16, void* stream);
+int dh_stem7_fwd_num_slots(int N, int H, int W, int groups);
 
 /* ---- BatchNorm2d (models/resnet.py:152,40-44; help_funcs.py:11) and LayerNorm(32) (help_funcs.py:34-49) */
 int dh_bn_finalize(const float* partial, int ntiles, int CP, int C, int groups, double count, const float* gamma,

@@ -172,6 +172,41 @@ def test_stem_space_to_depth_conv(ops, dtype):
     close(dw, w.grad, dtype, "stem wgrad", factor=4.0)
 
 
+@pytest.mark.parametrize("hw,B", [((64, 64), 2), ((40, 72), 1), ((256, 256), 3)])
+def test_stem_direct_kernel_on_nchw_images(ops, hw, B):
+    """dh_stem7_fwd (csrc/stem.hip): conv + per-tile BN statistics + the space-to-depth by-product the weight gradient reads,
+    both streams in one launch; ragged tiles (40x72 -> 20x36 outputs); eval form with folded scale / bias / ReLU"""
+    dtype = torch.bfloat16
+    H, W = hw
+    x1, x2 = rnd((B, 3, H, W), torch.float32, 8), rnd((B, 3, H, W), torch.float32, 18)
+    w = rnd((64, 3, 7, 7), dtype, 9, scale=147 ** -0.5).requires_grad_(True)
+    xq = torch.cat([x1, x2]).to(dtype).float()
+    y = F.conv2d(xq, w, None, 2, 3)
+    got, st, xs = ops.stem7_fwd(x1.cuda(), x2.cuda(), w.detach().cuda(), want_stats=True, want_xs=True, groups=2)
+    assert got.shape == (2 * B, H // 2, W // 2, 64) and xs.shape == (2 * B, H // 2, W // 2, 16)
+    close(nchw(got), y.detach(), dtype, "stem7 fwd")
+    # statistics are those of the fp32 accumulators, per workgroup; the first half of the slots is stream 1 (group 0)
+    yd = y.detach()
+    half = st.shape[2] // 2
+    for grp, sl in ((0, slice(0, half)), (1, slice(half, None))):
+        tot, part = st[:, :, sl].sum(dim=2).cpu(), yd[grp * B:(grp + 1) * B]
+        assert torch.allclose(tot[0], part.sum(dim=(0, 2, 3)), rtol=1e-2, atol=4e-4 * float(part.abs().sum(dim=(0, 2, 3)).max()))
+        assert torch.allclose(tot[1], (part * part).sum(dim=(0, 2, 3)), rtol=2e-2)
+    # the by-product equals the stand-alone space-to-depth kernel's first 16 channels, bit for bit
+    ref = ops.stem_space_to_depth(torch.cat([x1, x2]).cuda(), dtype)
+    assert torch.equal(xs, ref[..., :16].contiguous())
+    dy = rnd(tuple(y.shape), dtype, 10)
+    y.backward(dy)
+    dw = torch.zeros(64, 3, 7, 7, device="cuda")
+    ops.stem_wgrad(xs, dev(nhwc(dy), dtype), dw)
+    close(dw, w.grad, dtype, "stem wgrad on the 16-channel by-product", factor=4.0)
+    # one stream only, eval form
+    sc, sh = rnd((64,), torch.float32, 3).abs() + 0.5, rnd((64,), torch.float32, 4)
+    want = F.relu(F.conv2d(x1.to(dtype).float(), (w.detach() * sc.view(-1, 1, 1, 1)).to(dtype).float(), sh, 2, 3))
+    got1 = ops.stem7_fwd(x1.cuda(), None, w.detach().cuda(), out_scale=sc.cuda(), bias=sh.cuda(), relu=True)[0]
+    close(nchw(got1), want, dtype, "stem7 eval form")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_rows_gelu_and_per_image_weights(ops, dtype):
     rows, cin, cout = 40, 32, 64        # rows not a multiple of 16 -> masked tail
