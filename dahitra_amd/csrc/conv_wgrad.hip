@@ -41,6 +41,11 @@ struct WgArgs {
     // phase mode (KS = 2; see ConvArgs::phase_mode): blockIdx.z = output parity (a, b); dY is gathered from the fine grid at
     // (2 oy + a, 2 ox + b) of [N][2 OH][2 OW][Cout], x is read with pad (1 - a, 1 - b); one slab set per phase
     int phase_mode;
+    // DYT (the stem, KS = 4): dy is the masked gradient d of the BatchNorm OUTPUT; the gradient of the convolution output is
+    // formed on load as A * d + B * y + C per channel (BatchNorm backward, coefficients from dh_stem_pool_bn_bwd)
+    const void* dyt_y;          // pre-normalisation convolution output, same layout as dy
+    const float* dyt_coef;      // [dyt_groups][3][Cout]
+    int dyt_groups;
 };
 
 constexpr int lds_pitch(int row_bytes) { return ((row_bytes / 32) & 1) ? row_bytes : row_bytes + 32; }
@@ -55,7 +60,7 @@ union F8 {
 // waves takes the NEXT 32 input channels of the same pixels -- a 64co x 64ci slab per workgroup.  The dY tile is staged
 // once for both halves, and a layer writes (and dh_wgrad_reduce reads) half as many partial slabs at the same number of
 // resident waves: the split-K slab traffic of the bench step was ~500 MB written + ~500 MB read per step.
-template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT, int CIG>
+template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT, int CIG, bool DYT = false>
 __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     constexpr int CT = CTT;
     constexpr int NTHR = 256 * CIG;
@@ -99,6 +104,8 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     constexpr int XQ = ITT * (int)sizeof(T) / 16, DQ = CT * (int)sizeof(T) / 16;
     constexpr int NXV = (HH * HWD * XQ + NTHR - 1) / NTHR, NDV = (TH * TW * DQ + NTHR - 1) / NTHR;
     uint4 rx[NXV], rd[NDV];
+    uint4 ry[DYT ? NDV : 1];
+    unsigned d_okmask = 0;    // DYT: pieces of the fetched dY tile that exist (the others stay zero)
     // Everything about a 16-byte piece that does not depend on the tile is computed ONCE: its halo / tile position,
     // its element offset from the tile origin and how it is loaded (0: zeros, 1: one 16-byte load, 2: ragged channel
     // tail).  Per tile only the scalar tile origin and the border tests remain (no divisions by runtime tile counts,
@@ -151,7 +158,8 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     auto fetch = [&]() {      // loads the tile the counter points at, then advances the counter
         const int n = ((KS == 2 && p.phase_mode) ? 0 : grp * imgs_per_group) + f_n;
         x_okmask = 0;
-        c_bng = p.in_scale ? n / (p.N / p.in_groups) : 0;
+        d_okmask = 0;
+        c_bng = p.in_scale ? n / (p.N / p.in_groups) : (DYT ? n / (p.N / p.dyt_groups) : 0);
         const int oy0 = f_ty * TH, ox0 = f_tx * TW;
         const int iy0 = oy0 * STRIDE - p.pad + ph_a, ix0 = ox0 * STRIDE - p.pad + ph_b;
         if (fast) {
@@ -173,8 +181,14 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
                 const int oy = oy0 + d_py[i], ox = ox0 + d_px[i];
                 const int lin = (KS == 2 && p.phase_mode) ? (2 * oy + ph_a) * (2 * p.OW) + 2 * ox + ph_b : oy * p.OW + ox;
                 const bool ok = d_mode[i] != 0 && oy < p.OH && ox < p.OW && ((KS == 2 && p.phase_mode) || lin < p.npix);
-                const uint4 v = *reinterpret_cast<const uint4*>(db + (ok ? (unsigned)lin * dps + (unsigned)dcb * (unsigned)sizeof(T) : 0u));
+                const unsigned off = ok ? (unsigned)lin * dps + (unsigned)dcb * (unsigned)sizeof(T) : 0u;
+                const uint4 v = *reinterpret_cast<const uint4*>(db + off);
                 rd[i] = ok ? v : make_uint4(0, 0, 0, 0);
+                if constexpr (DYT) {
+                    ry[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(
+                        reinterpret_cast<const T*>(p.dyt_y) + (size_t)n * p.OH * p.OW * p.Cout) + off);
+                    d_okmask |= ok ? (1u << i) : 0u;
+                }
             }
         } else {
             const T* xin = reinterpret_cast<const T*>(p.x) + (size_t)n * p.H * p.W * p.CinPitch +
@@ -230,6 +244,26 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
                 rx[i] = pack16<T>(v);
             }
         }
+        if constexpr (DYT) {       // dy = A * d + B * y + C on its way into LDS; this thread's pieces share their channels
+            float ca[EPV], cb[EPV], cc[EPV];
+            const float* sp = bnp + c_bng * 3 * CT + (tid % DQ) * EPV;
+#pragma unroll
+            for (int j = 0; j < EPV; j += 4) {
+                *reinterpret_cast<float4*>(ca + j) = *reinterpret_cast<const float4*>(sp + j);
+                *reinterpret_cast<float4*>(cb + j) = *reinterpret_cast<const float4*>(sp + CT + j);
+                *reinterpret_cast<float4*>(cc + j) = *reinterpret_cast<const float4*>(sp + 2 * CT + j);
+            }
+#pragma unroll
+            for (int i = 0; i < NDV; ++i) {
+                if (!((d_okmask >> i) & 1u)) continue;
+                float dv[EPV], yv[EPV];
+                unpack16(rd[i], dv);
+                unpack16(ry[i], yv);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) dv[j] = ca[j] * dv[j] + (cb[j] * yv[j] + cc[j]);
+                rd[i] = pack16<T>(dv);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NXV; ++i) {
             const int idx = tid + i * NTHR;
@@ -248,6 +282,13 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
             const bool ok = ci0 + c < p.Cin;
             bnp[(gi * 2 + 0) * ITT + c] = ok ? p.in_scale[gi * p.Cin + ci0 + c] : 0.f;
             bnp[(gi * 2 + 1) * ITT + c] = ok ? p.in_shift[gi * p.Cin + ci0 + c] : 0.f;
+        }
+        __syncthreads();
+    }
+    if constexpr (DYT) {
+        for (int i = tid; i < p.dyt_groups * 3 * CT; i += NTHR) {
+            const int gk = i / CT, c = i % CT;
+            bnp[i] = co0 + c < p.Cout ? p.dyt_coef[(size_t)gk * p.Cout + co0 + c] : 0.f;
         }
         __syncthreads();
     }
@@ -472,7 +513,8 @@ template <typename T, int KS, int STRIDE, int IT, int DIL, int CT, int CIG = 1>
 int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     size_t lds = (size_t)HH * HWD * lds_pitch(IT * CIG * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T)) +
-                 (a.in_scale ? (size_t)a.in_groups * 2 * IT * CIG * sizeof(float) : 0);
+                 (a.in_scale ? (size_t)a.in_groups * 2 * IT * CIG * sizeof(float) : 0) +
+                 (a.dyt_y ? (size_t)a.dyt_groups * 3 * CT * sizeof(float) : 0);
     if (CT < 64) {                                     // the end-of-kernel wave-group combine parks accumulators here
         const size_t red = (size_t)(CT / 16) * KS * KS * (IT / 16) * 64 * 16;
         if (lds < red) lds = red;
@@ -493,6 +535,13 @@ int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
         DH_CHECK_LAUNCH("conv_wgrad");
         return 0;
     };
+    if constexpr (KS == 4 && CT == 64 && sizeof(T) == 2) {
+        if (a.dyt_y) {
+            if (tr) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true, DIL, CT, CIG, true>);
+            return go(conv_wgrad_kernel<T, KS, STRIDE, IT, false, DIL, CT, CIG, true>);
+        }
+    }
+    if (a.dyt_y) DH_FAIL("conv_wgrad: the BatchNorm-backward-on-load form is built for the bf16 stem (4x4, 64 output channels)");
     if (tr) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true, DIL, CT, CIG>);
     return go(conv_wgrad_kernel<T, KS, STRIDE, IT, false, DIL, CT, CIG>);
 }
@@ -557,13 +606,15 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
                              int H, int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad,
                              int groups, int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation,
                              void* workspace, void* stream, int defer, int* splitk_out, const float* in_scale = nullptr,
-                             const float* in_shift = nullptr, int in_groups = 1) {
+                             const float* in_shift = nullptr, int in_groups = 1, const void* dyt_y = nullptr,
+                             const float* dyt_coef = nullptr, int dyt_groups = 1) {
     DH_REQUIRE(groups == 1 || (groups == N && ks == 1), "conv2d_wgrad: groups must be 1 or N (with ks=1)");
     WgArgs a;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
     DH_REQUIRE(dilation == 1 || (dilation == 2 && ks == 3 && stride == 1), "conv2d_wgrad: dilation %d unsupported here", dilation);
     a.dil = dilation;
     a.phase_mode = 0;
+    a.dyt_y = dyt_y; a.dyt_coef = dyt_coef; a.dyt_groups = dyt_groups;
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_groups = in_groups > 0 ? in_groups : 1;
     if (in_scale) DH_REQUIRE(in_shift && groups == 1 && N % a.in_groups == 0 && (Cin * (dtype == DH_DTYPE_BF16 ? 2 : 4)) % 16 == 0,
                              "conv2d_wgrad: BatchNorm-on-load needs in_shift, one weight group, N %% in_groups == 0, 16-byte channel pieces");
@@ -622,6 +673,15 @@ extern "C" int dh_conv2d_wgrad_bn_in(int dtype, const void* x, const void* dy, f
                              Cout_real, 0, dilation, workspace, stream, splitk_out ? 1 : 0, splitk_out, in_scale, in_shift,
                              in_groups);
 }
+// The stem's weight gradient with BatchNorm backward applied on load (see WgArgs::dyt_y): xs16 [N][OH][OW][16] bf16 (the
+// space-to-depth by-product of dh_stem7_fwd), d / y [N][OH][OW][64] bf16, coef [groups][3][64] from dh_stem_pool_bn_bwd;
+// dw2 [64][16][4][4] fp32 is ASSIGNED (dh_stem_unpack_grad folds it into the 7x7 gradient).
+extern "C" int dh_stem_wgrad_bn(const void* xs16, const void* d, const void* y, const float* coef, int groups, int N, int OH,
+                                int OW, float* dw2, int use_tr, void* workspace, void* stream) {
+    DH_REQUIRE(xs16 && d && y && coef && groups >= 1 && N % groups == 0, "stem_wgrad_bn: bad arguments (N=%d groups=%d)", N, groups);
+    return conv2d_wgrad_impl(DH_DTYPE_BF16, xs16, d, dw2, 0, N, OH, OW, 16, OH, OW, 64, 4, 1, 2, 1, 0, use_tr, 0, 16, 1, workspace,
+                             stream, 0, nullptr, nullptr, nullptr, 1, y, coef, groups);
+}
 extern "C" int dh_wgrad_reduce_job_size(void) { return (int)sizeof(WgReduceJob); }
 // outputs served by one workgroup of dh_wgrad_reduce_multi for a layer with `Cin` input channels (job.nblocks =
 // ceil(O * I * taps / this))
@@ -652,6 +712,7 @@ extern "C" int dh_conv2d_wgrad_phase(int dtype, const void* x, const void* dy, i
     WgArgs a;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
     a.dil = 1; a.phase_mode = 1;
+    a.dyt_y = nullptr; a.dyt_coef = nullptr; a.dyt_groups = 1;
     a.in_scale = nullptr; a.in_shift = nullptr; a.in_groups = 1;
     a.CinPitch = Cin;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W; a.Cout = 32; a.pad = 1;

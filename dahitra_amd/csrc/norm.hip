@@ -535,6 +535,121 @@ void launch_bn_apply(const void* x, const void* residual, void* y, const float* 
                            (T*)y, scale, shift, nvec, C, gvec, act);
 }
 
+
+// ---- stem tail backward in one pass (bf16): 3x3/2 max-pool backward from the saved arg-max (the gather of
+// maxpool_bwd_kernel, pointwise.hip) + the ReLU mask of relu(bn(y)) recomputed from y + the BatchNorm-backward reduction.
+// Writes the masked gradient d and per-workgroup partial sums (sum d, sum d * xhat); the separate reduce pass (one more read of
+// d and y, 268 MB at the bench size) disappears.  grid = G * bpg; a workgroup stays inside one group's images.
+__global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const unsigned char* __restrict__ arg, const bf16* __restrict__ dpool,
+                                                                 const bf16* __restrict__ y, const float* __restrict__ mscale,
+                                                                 const float* __restrict__ mshift, bf16* __restrict__ d,
+                                                                 float* __restrict__ partial, int npg, int H, int W, int C, int OH,
+                                                                 int OW, int bpg) {
+    constexpr int V = 8;
+    __shared__ float red[2][256][V];
+    const int g = blockIdx.x / bpg, b = blockIdx.x % bpg;
+    const int vn = C / V, BH = (H + 1) / 2, BW = (W + 1) / 2;
+    const int c = (threadIdx.x % vn) * V;            // 256 % vn == 0 and the loop stride is a multiple of vn: fixed per thread
+    float ms[V], mh[V], s1[V], s2[V];        // s2 = sum d * y: the finalize turns it into sum d * xhat (in double)
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        ms[j] = mscale[g * C + c + j]; mh[j] = mshift[g * C + c + j];
+        s1[j] = s2[j] = 0.f;
+    }
+    const long items = (long)npg * BH * BW * vn;
+    for (long i = (long)b * 256 + threadIdx.x; i < items; i += (long)bpg * 256) {
+        long t = i / vn;
+        const int bx = (int)(t % BW); t /= BW;
+        const int by = (int)(t % BH);
+        const long n = (long)g * npg + t / BH;
+        unsigned long long bits[2][2];
+        float dv[2][2][V];
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int oy = by + wy, ox = bx + wx;
+                bits[wy][wx] = ~0ull;
+#pragma unroll
+                for (int j = 0; j < V; ++j) dv[wy][wx][j] = 0.f;
+                if (oy < OH && ox < OW) {
+                    const long o = ((n * OH + oy) * OW + ox) * C + c;
+                    bits[wy][wx] = *reinterpret_cast<const unsigned long long*>(arg + o);
+                    ldv(dpool + o, dv[wy][wx]);
+                }
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int iy = 2 * by + a, ix = 2 * bx + bb;
+                if (iy >= H || ix >= W) continue;
+                float gs[V], yv[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) gs[j] = 0.f;
+#pragma unroll
+                for (int wy = 0; wy <= a; ++wy)
+#pragma unroll
+                    for (int wx = 0; wx <= bb; ++wx) {
+                        const unsigned kk = (a + 1 - 2 * wy) * 3 + (bb + 1 - 2 * wx);
+#pragma unroll
+                        for (int j = 0; j < V; ++j)
+                            if (((bits[wy][wx] >> (8 * j)) & 0xff) == kk) gs[j] += dv[wy][wx][j];
+                    }
+                const long o = ((n * H + iy) * W + ix) * C + c;
+                ldv(y + o, yv);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float gm = (yv[j] * ms[j] + mh[j]) > 0.f ? gs[j] : 0.f;
+                    gs[j] = gm;
+                    s1[j] += gm;
+                    s2[j] += gm * yv[j];
+                }
+                stv(d + o, gs);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * C) {
+        const int which = threadIdx.x / C, ch = threadIdx.x % C, piece = ch / V, j = ch % V;
+        float t = 0.f;
+        for (int k = piece; k < 256; k += vn) t += red[which][k][j];
+        partial[((size_t)which * C + ch) * gridDim.x + blockIdx.x] = t;       // [2][C][G * bpg]
+    }
+}
+// bn_bwd_finalize_kernel + the per-channel coefficients of dx = A * d + B * y + Cc (= gamma*invstd*(d - (s1 + xhat*s2)/M))
+// that the stem's weight gradient applies while it loads d and y (conv_wgrad.hip, DYT): coef [G][3][C].  partial[1] holds
+// sum d * y (raw), converted here.
+__global__ void bn_bwd_finalize_coef_kernel(const float* __restrict__ partial, int bpg, int G, int C, const float* __restrict__ mean,
+                                            const float* __restrict__ invstd, const float* __restrict__ gamma, float inv_m,
+                                            float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                            int accumulate) {
+    __shared__ double t1[BN_MAXG], t2[BN_MAXG];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, g = threadIdx.x >> 6;      // blockDim = 64 * G
+    double s1 = 0.0, s2 = 0.0;
+    const float* p0 = partial + ((size_t)0 * C + c) * G * bpg + (size_t)g * bpg;
+    const float* p1 = partial + ((size_t)1 * C + c) * G * bpg + (size_t)g * bpg;
+    for (int t = lane; t < bpg; t += 64) { s1 += (double)p0[t]; s2 += (double)p1[t]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane == 0) {
+        s2 = (double)invstd[g * C + c] * (s2 - (double)mean[g * C + c] * s1);        // sum d * y -> sum d * xhat
+        const float is = invstd[g * C + c], A = gamma[c] * is, B = -A * is * inv_m * (float)s2;
+        coef[(g * 3 + 0) * C + c] = A;
+        coef[(g * 3 + 1) * C + c] = B;
+        coef[(g * 3 + 2) * C + c] = -A * inv_m * (float)s1 - B * mean[g * C + c];
+        t1[g] = s1; t2[g] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tb = 0.0, tg = 0.0;
+        for (int k = 0; k < G; ++k) { tb += t1[k]; tg += t2[k]; }
+        if (accumulate) { dgamma[c] += (float)tg; dbeta[c] += (float)tb; }
+        else { dgamma[c] = (float)tg; dbeta[c] = (float)tb; }
+    }
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -574,6 +689,27 @@ extern "C" int dh_bn_apply(int dtype, const void* x, const void* residual, void*
 }
 
 // workspace: partial [groups*bpg][2][C] floats + sums [groups][2][C] floats
+// Stem tail backward (see pool_bn_bwd_reduce_kernel): dpool [N][OH][OW][C] + arg-max -> masked gradient d [N][H][W][C] of the
+// pre-pool activation relu(y * mask_scale + mask_shift); dgamma / dbeta (+)=; coef [groups][3][C] for dh_stem_wgrad_bn.
+// workspace: dh_stem_pool_bn_bwd_workspace_size bytes.
+// 768 workgroups = three per CU, what the kernel's ~150 registers per lane keep resident: one full round, no ragged second one
+extern "C" long dh_stem_pool_bn_bwd_workspace_size(int C, int groups) { return (long)(768 / groups) * groups * 2 * C * 4; }
+extern "C" int dh_stem_pool_bn_bwd(const unsigned char* argmax, const void* dpool, const void* y, const float* mask_scale,
+                                   const float* mask_shift, const float* mean, const float* invstd, const float* gamma, int N,
+                                   int H, int W, int C, int groups, void* d, float* coef, float* dgamma, float* dbeta,
+                                   int accumulate, void* workspace, void* stream) {
+    DH_REQUIRE(C % 8 == 0 && 256 % (C / 8) == 0 && 2 * C <= 256, "stem_pool_bn_bwd: unsupported C=%d", C);
+    DH_REQUIRE(groups >= 1 && groups <= BN_MAXG && N % groups == 0, "stem_pool_bn_bwd: N=%d groups=%d", N, groups);
+    const int bpg = 768 / groups, OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    float* partial = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(pool_bn_bwd_reduce_kernel, dim3(groups * bpg), dim3(256), 0, ST(stream), argmax, (const bf16*)dpool,
+                       (const bf16*)y, mask_scale, mask_shift, (bf16*)d, partial, N / groups, H, W, C, OH, OW, bpg);
+    hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(C), dim3(64 * groups), 0, ST(stream), partial, bpg, groups, C, mean, invstd,
+                       gamma, 1.0f / (float)((long)(N / groups) * H * W), coef, dgamma, dbeta, accumulate);
+    DH_CHECK_LAUNCH("stem_pool_bn_bwd");
+    return 0;
+}
+
 extern "C" long dh_bn_bwd_workspace_size(long npix, int C, int groups) {
     const int bpg = 1024 / groups;      // ~1024 workgroups in total (4 per CU)
     return ((long)groups * bpg * 2 * C + (long)groups * 2 * C) * 4;

@@ -48,6 +48,9 @@ __global__ __launch_bounds__(256, 2) void stem7_fwd_kernel(Stem7Args p) {
     __shared__ float red[4][2][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
 
+    // the pitch padding (columns 37..39) is read as the k-value behind kw' = 7 of the last pixel: its weight is zero, the
+    // padding must merely be finite (never written by a commit, zeroed once; the first commit's barrier orders it)
+    for (int i = tid; i < 3 * PR * (PP - PC); i += 256) patch[(i / (PP - PC)) * PP + PC + i % (PP - PC)] = 0;
     // ---- weights: 4 cout sub-tiles x 6 k-steps, straight from the fp32 OIHW tensor ----
     Frag A[4][6];
 #pragma unroll

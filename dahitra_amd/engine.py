@@ -72,6 +72,8 @@ class Engine:
         self.phase_s2_dgrad = os.environ.get("DAHITRA_NO_PHASE_S2", "0") != "1"
         # bf16: the 7x7/2 stem as one kernel on the NCHW fp32 images (csrc/stem.hip) instead of space-to-depth + 4x4 conv
         self.direct_stem = os.environ.get("DAHITRA_NO_DIRECT_STEM", "0") != "1"
+        # ... and its backward without a BatchNorm pass: reduction fused into the max-pool backward, apply into the weight gradient
+        self.fused_stem_bwd = os.environ.get("DAHITRA_NO_FUSED_STEM_BWD", "0") != "1"
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -292,6 +294,15 @@ class Engine:
             dy = ops.bn_bwd(dout, None, y, mean, invstd, gamma, self.g[bnkey + ".weight"], self.g[bnkey + ".bias"],
                             groups, accumulate=True, mask_scale=scale, mask_shift=shift)
             ops.stem_wgrad(xs, dy, self.g[wkey], accumulate=True, use_tr=self.use_tr)
+
+        def from_pool(parg_, dpool):
+            """backward entered at the max-pool's output: pool backward + ReLU mask + BN sums in one pass, BN backward itself
+            inside the weight gradient's loads (the stem has no data gradient)"""
+            d, coef = ops.stem_pool_bn_bwd(parg_, dpool, y, scale, shift, mean, invstd, gamma, self.g[bnkey + ".weight"],
+                                           self.g[bnkey + ".bias"], groups)
+            ops.stem_wgrad(xs, d, self.g[wkey], accumulate=True, use_tr=self.use_tr, bn=(y, coef, groups))
+        if pool and self.training and direct and self.fused_stem_bwd:
+            bwd.from_pool = from_pool
         if pool:
             return pooled, parg, oshape, (bwd if self.need_grad else None)
         if not self.need_grad:
@@ -757,7 +768,10 @@ class Engine:
 
         def bwd_second(dl2):
             dxp = b_l1(b_l2(dl2, next_gate=b_l1.gate))
-            b_stem(ops.maxpool_bwd(xarg, dxp, xshape))
+            if hasattr(b_stem, "from_pool"):
+                b_stem.from_pool(xarg, dxp)
+            else:
+                b_stem(ops.maxpool_bwd(xarg, dxp, xshape))
 
         def bwd(dl):
             bwd_second(bwd_first(dl))

@@ -545,11 +545,34 @@ def stem7_fwd(x1, x2, w, out_scale=None, bias=None, relu=False, want_stats=False
     return y, stats, xs
 
 
-def stem_wgrad(x_s2d, dy, dw, accumulate=False, use_tr=True):
+def stem_pool_bn_bwd(arg, dpool, y, scale, shift, mean, invstd, gamma, dgamma, dbeta, groups, accumulate=True):
+    """maxpool backward + ReLU mask + BatchNorm-backward sums of the stem's tail in one pass -> (d masked, coef [groups,3,C])"""
+    N, H, W, C = y.shape
+    d = torch.empty_like(y)
+    coef = torch.empty(groups, 3, C, dtype=torch.float32, device=y.device)
+    L = _lib.lib()
+    ws = workspace(L.dh_stem_pool_bn_bwd_workspace_size(C, groups), y.device)
+    with _Prof("bn_bwd", 0, _nb(arg, dpool, y, d)):
+        _call("dh_stem_pool_bn_bwd", P(arg), P(dpool), P(y), P(scale), P(shift), P(mean), P(invstd), P(gamma), _ci(N), _ci(H),
+              _ci(W), _ci(C), _ci(groups), P(d), P(coef), P(dgamma), P(dbeta), _ci(int(accumulate)), P(ws), S())
+    return d, coef
+
+
+def stem_wgrad(x_s2d, dy, dw, accumulate=False, use_tr=True, bn=None):
+    """bn = (y, coef, groups): dy is the masked gradient of the BatchNorm output; BatchNorm backward is applied on load"""
     N, H2, W2, cp = x_s2d.shape
     O = dy.shape[-1]
     dw2 = torch.empty(O, 16, 4, 4, dtype=torch.float32, device=dy.device)     # 12 real + 4 zero channels
-    conv2d_wgrad(x_s2d, dy, dw2, ks=4, stride=1, pad=2, use_tr=use_tr, cin=16, defer=False)     # dw2 is unpacked next
+    if bn is not None:
+        y, coef, groups = bn
+        assert cp == 16 and O == 64 and y.shape == dy.shape
+        L = _lib.lib()
+        ws = workspace(L.dh_conv2d_wgrad_workspace_size(N, H2, W2, 16, O, 4, 1), dy.device)
+        with _Prof("conv_wgrad<bf16,ks4,s1>", 2.0 * N * H2 * W2 * O * 16 * 16, _nb(x_s2d, dy, y)):
+            _call("dh_stem_wgrad_bn", P(x_s2d), P(dy), P(y), P(coef), _ci(groups), _ci(N), _ci(H2), _ci(W2), P(dw2),
+                  _ci(int(use_tr)), P(ws), S())
+    else:
+        conv2d_wgrad(x_s2d, dy, dw2, ks=4, stride=1, pad=2, use_tr=use_tr, cin=16, defer=False)     # dw2 is unpacked next
     _call("dh_stem_unpack_grad", P(dw2), P(dw), _ci(O), _ci(16), _ci(int(accumulate)), S())
 
 

@@ -142,6 +142,19 @@ int dh_stem_unpack_grad(const float* dw2, float* dw_oihw, int O, int CP, int acc
 int dh_stem7_fwd(const float* xa, const float* xb, int B, int N, int H, int W, const float* w_oihw, const float* out_scale,
                  const float* bias, int relu, void* y, float* stats, int groups, void* xs16, void* stream);
 int dh_stem7_fwd_num_slots(int N, int H, int W, int groups);
+/* Backward of the stem's tail maxpool(relu(bn1(conv1(x)))) (models/resnet.py:150-153,198-201) without a BatchNorm pass of its
+ * own (bf16).  dh_stem_pool_bn_bwd: max-pool backward from the saved arg-max, the ReLU mask recomputed from y
+ * (y * mask_scale + mask_shift > 0) and the BatchNorm-backward sums in ONE pass over the 128x128 map: d [N][H][W][C] = masked
+ * gradient of the BatchNorm output, dgamma / dbeta (+)=, coef [groups][3][C] = per-channel (A, B, C) of
+ * dconv = A * d + B * y + C.  dh_stem_wgrad_bn: the weight gradient against the space-to-depth image xs16 with that
+ * expression applied while d and y are loaded; dw2 [64][16][4][4] is assigned (then dh_stem_unpack_grad). */
+long dh_stem_pool_bn_bwd_workspace_size(int C, int groups);
+int dh_stem_pool_bn_bwd(const unsigned char* argmax, const void* dpool, const void* y, const float* mask_scale,
+                        const float* mask_shift, const float* mean, const float* invstd, const float* gamma, int N, int H, int W,
+                        int C, int groups, void* d, float* coef, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                        void* stream);
+int dh_stem_wgrad_bn(const void* xs16, const void* d, const void* y, const float* coef, int groups, int N, int OH, int OW,
+                     float* dw2, int use_tr, void* workspace, void* stream);
 
 /* ---- BatchNorm2d (models/resnet.py:152,40-44; help_funcs.py:11) and LayerNorm(32) (help_funcs.py:34-49) */
 int dh_bn_finalize(const float* partial, int ntiles, int CP, int C, int groups, double count, const float* gamma,

@@ -207,6 +207,61 @@ def test_stem_direct_kernel_on_nchw_images(ops, hw, B):
     close(nchw(got1), want, dtype, "stem7 eval form")
 
 
+@pytest.mark.parametrize("hw,B", [((32, 64), 1), ((128, 128), 2)])
+def test_stem_tail_backward_without_a_batchnorm_pass(ops, hw, B):
+    """dh_stem_pool_bn_bwd + dh_stem_wgrad_bn against autograd through conv7x7/2 -> BatchNorm (batch statistics, two groups)
+    -> ReLU -> maxpool3x3/2: weight, gamma, beta gradients"""
+    dtype = torch.bfloat16
+    H, W = hw
+    x1, x2 = rnd((B, 3, H, W), torch.float32, 8), rnd((B, 3, H, W), torch.float32, 18)
+    w = rnd((64, 3, 7, 7), dtype, 9, scale=147 ** -0.5).requires_grad_(True)
+    gamma = (rnd((64,), torch.float32, 3) * 0.1 + 1.0).requires_grad_(True)
+    beta = (rnd((64,), torch.float32, 4) * 0.1).requires_grad_(True)
+    y_dev, st, xs = ops.stem7_fwd(x1.cuda(), x2.cuda(), w.detach().cuda(), want_stats=True, want_xs=True, groups=2)
+    oh, ow = H // 2, W // 2
+    rm, rv = torch.zeros(64, device="cuda"), torch.ones(64, device="cuda")
+    mean, invstd, scale, shift = ops.bn_finalize(st, 64, 2, B * oh * ow, gamma.detach().cuda(), beta.detach().cuda(), rm, rv)
+    pooled, parg = ops.maxpool(y_dev, want_arg=True, bn=(scale, shift, 2))
+    # reference: the same graph in fp32 on the bf16-rounded conv output the device holds (so masks / arg-max agree)
+    yq = nchw(y_dev.float().cpu()).requires_grad_(True)
+    outs = []
+    for grp in range(2):
+        part = yq[grp * B:(grp + 1) * B]
+        outs.append(F.max_pool2d(F.relu(F.batch_norm(part, None, None, gamma, beta, True, 0.1, 1e-5)), 3, 2, 1))
+    ref_pooled = torch.cat(outs)
+    close(nchw(pooled), ref_pooled.detach(), dtype, "pooled")
+    dpool = rnd(tuple(ref_pooled.shape), dtype, 10)
+    ref_pooled.backward(dpool)
+    dgamma, dbeta = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    d, coef = ops.stem_pool_bn_bwd(parg, dev(nhwc(dpool), dtype), y_dev, scale, shift, mean, invstd, gamma.detach().cuda(),
+                                   dgamma, dbeta, 2)
+    close(dgamma, gamma.grad, dtype, "dgamma", factor=2.0)
+    close(dbeta, beta.grad, dtype, "dbeta", factor=2.0)
+    # dL/dy = A * d + B * y + C per channel and group.  The arg-max of a near-tie may differ between the device's pool (bf16
+    # BatchNorm statistics path) and torch's fp32 graph -- a handful of windows route their gradient to the neighbouring
+    # pixel -- so the element-wise check allows 0.1 % outliers
+    c = coef.view(2, 3, 1, 1, 1, 64).cpu()
+    shp = (2, B, oh, ow, 64)
+    dx = (c[:, 0] * d.float().cpu().view(shp) + c[:, 1] * y_dev.float().cpu().view(shp) + c[:, 2]).view(2 * B, oh, ow, 64)
+    want = nhwc(yq.grad)
+    off = ((dx - want).abs() > tol(dtype) * float(want.abs().max())).float().mean()
+    assert float(off) < 1e-3, float(off)
+    # the weight gradient with that expression applied on load == the two-pass form (pool backward, BatchNorm backward, wgrad)
+    dw = torch.zeros(64, 3, 7, 7, device="cuda")
+    ops.stem_wgrad(xs, d, dw, bn=(y_dev, coef, 2))
+    dg2, db2 = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    dx2 = ops.bn_bwd(ops.maxpool_bwd(parg, dev(nhwc(dpool), dtype), tuple(y_dev.shape)), None, y_dev, mean, invstd,
+                     gamma.detach().cuda(), dg2, db2, 2, mask_scale=scale, mask_shift=shift)
+    close(dgamma, dg2.cpu(), dtype, "dgamma fused vs two-pass", factor=0.1)
+    dw2 = torch.zeros(64, 3, 7, 7, device="cuda")
+    ops.stem_wgrad(xs, dx2, dw2)
+    close(dw, dw2.cpu(), dtype, "fused vs two-pass", factor=0.2)
+    # and against autograd through the convolution on the exact dL/dy of the device (no arg-max ambiguity left)
+    xq = torch.cat([x1, x2]).to(dtype).float()
+    F.conv2d(xq, w, None, 2, 3).backward(nchw(dx2.float().cpu()))
+    close(dw, w.grad, dtype, "stem wgrad with BatchNorm backward on load", factor=1.0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_rows_gelu_and_per_image_weights(ops, dtype):
     rows, cin, cout = 40, 32, 64        # rows not a multiple of 16 -> masked tail
