@@ -290,7 +290,7 @@ def main():
                     "all_wgrad_ms_per_step": round(sum(v[0] for k, v in agg.items() if k.startswith("conv_wgrad")), 3),
                     "all_mfma_conv_tflops": round(sum(v[1] for v in mfma.values()) / (sum(v[0] for v in mfma.values()) * 1e-3) / 1e12, 1)}
         classes = {}
-        for k in ("bn_apply", "bn_bwd", "decoder_layer_fwd", "decoder_layer_bwd"):
+        for k in ("bn_apply", "bn_bwd", "stem7_fwd", "decoder_layer_fwd", "decoder_layer_bwd"):
             if k in agg:
                 ms, _, by, n = agg[k]
                 gbs = by / (ms * 1e-3) / 1e9

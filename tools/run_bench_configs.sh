@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/b3
+mkdir -p gpurun_out/b3; rm -f gpurun_out/b3/*
 python bench.py --steps 30 --warmup 5 > gpurun_out/b3/s4.json 2> gpurun_out/b3/s4.err
 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --net newUNetTrans > gpurun_out/b3/unet.json 2> gpurun_out/b3/unet.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --fwd-only > gpurun_out/b3/s4_fwd.json 2>/dev/null
