@@ -226,6 +226,25 @@ class CDNet(nn.Module):
                 raise RuntimeError("dahitra_amd: parameter %s has a foreign .grad tensor; use zero_grad(set_to_none=True)" % k)
 
 
+def load_pretrained_trunk(net, path_or_state):
+    """Fill the ResNet trunk from a torchvision-style state dict (`conv1.weight`, `layer1.0.bn1.running_mean`, ...), e.g. a
+    saved `torchvision.models.resnet18(pretrained=True).state_dict()` -- what the reference gets from the ImageNet download
+    in models/resnet.py:228-244 (BiT nets) and resnet18(pretrained=True) in xBD_code/zoo/model_transformer_encoding.py:195.
+    No download happens here: pass a file path or the dict.  Keys the net does not have (`fc.*`, `layer4.*` for the BiT nets)
+    and keys of a different shape are skipped; returns the list of loaded keys."""
+    sd = torch.load(path_or_state, map_location="cpu") if isinstance(path_or_state, (str, bytes, os.PathLike)) else path_or_state
+    own = net.state_dict()
+    prefix = "resnet." if any(k.startswith("resnet.") for k in own) else ""
+    picked = {}
+    for k, v in sd.items():
+        k2 = prefix + (k[7:] if k.startswith("module.") else k)
+        if k2 in own and tuple(own[k2].shape) == tuple(v.shape):
+            picked[k2] = v
+    own.update(picked)
+    net.load_state_dict(own)
+    return sorted(picked)
+
+
 def init_weights(net, init_type='normal', init_gain=0.02):
     """models/networks.py:77-108: every Conv / Linear weight ~ N(0, gain), biases 0, BN gamma ~ N(1, gain);
     LayerNorm and positional embeddings untouched."""

@@ -133,3 +133,20 @@ def test_reference_import_names_resolve_through_compat():
             "print('ok')" % (ROOT, os.path.join(ROOT, "dahitra_amd", "compat")))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_pretrained_trunk_loader_fills_matching_keys_only():
+    """load_pretrained_trunk (initialisation differences): torchvision-style keys land in the trunk, keys of
+    another shape or unknown keys are skipped, a 'module.' prefix is accepted"""
+    import types
+    import torch
+    from dahitra_amd.models.networks import define_G, load_pretrained_trunk
+    net = define_G(types.SimpleNamespace(net_G="base_transformer_pos_s4", compute_dtype="fp32"), gpu_ids=[])
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    sd = {"conv1.weight": torch.ones(64, 3, 7, 7), "module.bn1.running_mean": torch.full((64,), 0.5),
+          "layer1.0.conv1.weight": torch.ones(8, 8, 3, 3), "no.such.key": torch.zeros(3)}
+    got = load_pretrained_trunk(net, sd)
+    assert got == ["resnet.bn1.running_mean", "resnet.conv1.weight"]
+    after = net.state_dict()
+    assert float(after["resnet.conv1.weight"].min()) == 1.0 and float(after["resnet.bn1.running_mean"][3]) == 0.5
+    assert torch.equal(after["resnet.layer1.0.conv1.weight"], before["resnet.layer1.0.conv1.weight"])
