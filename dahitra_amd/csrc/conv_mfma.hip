@@ -37,6 +37,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     if (in_scale) DH_REQUIRE(in_shift && N % a.in_groups == 0 && w_image_stride == 0,
                              "conv2d_fwd: BatchNorm-on-load needs in_shift and N %% in_groups == 0");
     a.phase_mode = phase_mode;
+    a.y_nchw = nullptr;
     static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
     a.no_xcd_remap = no_remap;
     if (phase_mode) {
@@ -52,6 +53,31 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     if (dh_conv1x1_gemm_eligible(a, ks, stride, dtype)) return dh_conv1x1_gemm_launch(a, st);
     if (dtype == DH_DTYPE_BF16) return dh_conv_launch_bf16(a, ks, stride, st);
     return dh_conv_launch_f32(a, ks, stride, st);
+}
+
+// The class head (3x3, pad 1, <= 16 classes) with fp32 NCHW logits written by the convolution itself: see ConvArgs::y_nchw.
+extern "C" int dh_conv3x3_head_fwd(int dtype, const void* x, const void* w_packed, const float* bias, int N, int H, int W, int Cin,
+                                   int Cout, const float* in_scale, const float* in_shift, int in_groups, float* logits_nchw,
+                                   void* stream) {
+    const int esz = dtype == DH_DTYPE_BF16 ? 2 : 4;
+    DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "conv3x3_head_fwd: bad dtype %d", dtype);
+    DH_REQUIRE((Cin * esz) % 64 == 0 && Cout >= 1 && Cout <= 16 && logits_nchw && N > 0 && H > 0 && W > 0,
+               "conv3x3_head_fwd: Cin=%d Cout=%d", Cin, Cout);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w_packed; a.bias = bias;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W; a.Cout = Cout; a.CoutPad = 16;
+    a.pad = 1; a.act = DH_ACT_NONE; a.npix = H * W; a.in_npix = H * W; a.dil = 1; a.gate_groups = 1;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_groups = in_groups > 0 ? in_groups : 1;
+    if (in_scale) DH_REQUIRE(in_shift && N % a.in_groups == 0, "conv3x3_head_fwd: BatchNorm-on-load needs in_shift and N %% in_groups == 0");
+    static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
+    a.no_xcd_remap = no_remap;
+    a.y_nchw = logits_nchw;
+    a.rw = pick_rw(N, H, W, Cin, 3, 1);
+    a.tilesX = dh_cdiv(W, TW); a.tilesY = dh_cdiv(H, 4 * a.rw);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == DH_DTYPE_BF16) return dh_conv_launch_bf16(a, 3, 1, st);
+    return dh_conv_launch_f32(a, 3, 1, st);
 }
 
 // number of workgroup tiles along the pixel dimension (= rows of the stats_partial buffer)

@@ -85,6 +85,9 @@ struct ConvArgs {
     //      the tap geometry of a 2x2 convolution with pad 1.
     int phase_mode;
     int no_xcd_remap;       // DAHITRA_NO_XCD_REMAP=1: plain (tile, channel block) = (blockIdx.x, blockIdx.y) order
+    // class head (NT = 16 instantiations only): the Cout real channels (+ bias) are written as fp32 NCHW logits
+    // [N][Cout][OH][OW] straight from the accumulators -- the reference's output layout -- and nothing goes to y
+    float* y_nchw;
 };
 
 namespace {
@@ -307,6 +310,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     }
 
     // ---- epilogue ----
+    if constexpr (NT == 16 && KS == 3 && STRIDE == 1) {
+        if (p.y_nchw) {
+            float* out = p.y_nchw + (size_t)n * p.Cout * p.OH * p.OW;
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int oy = oy0 + RW * wv + r, ox = ox0 + pl;
+                if (oy >= p.OH || ox >= p.OW) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = g * 4 + j;         // NT = 16: one sub-tile, lane group g holds channels 4 g .. 4 g + 3
+                    if (c < p.Cout) out[((size_t)c * p.OH + oy) * p.OW + ox] = acc[0][r][j] + (p.bias ? p.bias[c] : 0.f);
+                }
+            }
+            return;
+        }
+    }
     T* yout = reinterpret_cast<T*>(p.y) + (size_t)n * p.OH * p.OW * p.Cout;
     const T* rin = p.res ? reinterpret_cast<const T*>(p.res) + (size_t)n * p.OH * p.OW * p.Cout : nullptr;
     if constexpr (KS == 2) {
@@ -536,7 +555,7 @@ int launch_fast(const ConvArgs& a, hipStream_t st) {
 template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF>
 int launch_pf(const ConvArgs& a, hipStream_t st) {
     // compact-epilogue instantiation: 16-byte output pieces, no gating / pre-activation copy / GELU
-    const bool fast = (a.Cout % (16 / (int)sizeof(T))) == 0 && !a.gate_y && !a.y2 && a.act != DH_ACT_GELU;
+    const bool fast = ((a.Cout % (16 / (int)sizeof(T))) == 0 || a.y_nchw) && !a.gate_y && !a.y2 && a.act != DH_ACT_GELU;
     if constexpr (KS == 3 && STRIDE == 1 && DIL == 1) {        // BN-apply + ReLU on load: the 3x3 consumers of a BN layer
         if (a.in_scale) {
             if (fast) return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, true, true>(a, st);

@@ -74,6 +74,8 @@ class Engine:
         self.direct_stem = os.environ.get("DAHITRA_NO_DIRECT_STEM", "0") != "1"
         # ... and its backward without a BatchNorm pass: reduction fused into the max-pool backward, apply into the weight gradient
         self.fused_stem_bwd = os.environ.get("DAHITRA_NO_FUSED_STEM_BWD", "0") != "1"
+        # the class head writes its fp32 NCHW logits itself (no NHWC logits tensor, no layout pass)
+        self.fused_head_out = os.environ.get("DAHITRA_NO_FUSED_HEAD", "0") != "1"
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -690,8 +692,10 @@ class Engine:
         """final 3x3 conv to n_class logits, returned as NCHW fp32 (the reference's output layout)"""
         ncls = self.shapes[wkey][0]
         ck = ops.chunk_channels(self.dtype)
-        logits = ops.conv2d(h, self.pk[wkey].fwd, ncls, 3, 1, 1, bias=self.p[bkey])
-        out = ops.nhwc_to_nchw(logits)
+        if self.pk[wkey].fwd.shape[-2] == 16 and self.fused_head_out:
+            out = ops.conv3x3_head(h, self.pk[wkey].fwd, ncls, self.p[bkey])         # fp32 NCHW logits from the conv itself
+        else:
+            out = ops.nhwc_to_nchw(ops.conv2d(h, self.pk[wkey].fwd, ncls, 3, 1, 1, bias=self.p[bkey]))
         if not self.need_grad:
             return out, None
 

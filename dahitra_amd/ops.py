@@ -330,6 +330,22 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     return out[0] if len(out) == 1 else tuple(out)
 
 
+def conv3x3_head(x, wp, ncls, bias):
+    """the class head: 3x3 / pad 1 convolution to `ncls` (<= 16) channels, fp32 NCHW logits written by the kernel itself.
+    x may be a BnInput (BatchNorm-apply + ReLU on load)."""
+    bn_in = x if isinstance(x, BnInput) else None
+    if bn_in is not None:
+        x = bn_in.y
+    N, H, W, Cin = x.shape
+    assert wp.shape[-2] == 16 and ncls <= 16
+    out = torch.empty(N, ncls, H, W, dtype=torch.float32, device=x.device)
+    key = "conv_mfma<%s,ks3,s1,nt16>" % ("bf16" if x.dtype == torch.bfloat16 else "f32")
+    with _Prof(key, 2.0 * N * H * W * ncls * Cin * 9, _nb(x, out, wp)):
+        _call("dh_conv3x3_head_fwd", _ci(dt(x)), P(x), P(wp), P(bias), _ci(N), _ci(H), _ci(W), _ci(Cin), _ci(ncls),
+              *_bn_in_args(bn_in), P(out), S())
+    return out
+
+
 def rows_view(x2d):
     """[rows, C] -> the [1, ceil(rows/16), 16, C] image view used for linear layers (no copy when
     rows % 16 == 0; otherwise the tail rows are masked through npix_valid)."""

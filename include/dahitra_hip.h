@@ -69,6 +69,11 @@ int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const
  * dh_bn_bwd_from_partials consumes (replaces the reduction pass of dh_bn_bwd; torch autograd's native_batch_norm
  * backward + threshold_backward, called from models/resnet.py:58-73 via loss.backward()). */
 int dh_conv2d_fwd_num_tiles(int N, int OH, int OW, int Cin, int ks, int stride);
+/* The class head -- classifier[-1]: nn.Conv2d(32, n_class, 3, padding 1) (models/networks.py:201-204, 1121-1129) -- with the
+ * fp32 NCHW logits [N][Cout][H][W] (the reference's output layout) written by the convolution itself: no NHWC logits tensor,
+ * no layout pass.  w_packed: dh_pack_weight with OPad = 16; in_scale / in_shift (optional): BatchNorm-apply + ReLU on load. */
+int dh_conv3x3_head_fwd(int dtype, const void* x, const void* w_packed, const float* bias, int N, int H, int W, int Cin,
+                        int Cout, const float* in_scale, const float* in_shift, int in_groups, float* logits_nchw, void* stream);
 
 /* weight gradient (autograd convolution_backward / mm for nn.Linear): groups == 1 writes the
  * torch OIHW layout [Cout_real][Cin][ks][ks]; groups == N (ks == 1) one [Cout][Cin] per image. */

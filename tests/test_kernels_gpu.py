@@ -263,6 +263,35 @@ def test_stem_tail_backward_without_a_batchnorm_pass(ops, hw, B):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ncls,hw,lazy", [(2, (64, 64), True), (5, (40, 56), False), (2, (256, 256), True)])
+def test_class_head_writes_nchw_logits_itself(ops, dtype, ncls, hw, lazy):
+    """dh_conv3x3_head_fwd == dh_conv2d_fwd + dh_nhwc_to_nchw (fp32 NCHW logits), plain and with BatchNorm + ReLU on load"""
+    H, W = hw
+    N = 2
+    ck = ops.chunk_channels(dtype)
+    x = rnd((N, 32, H, W), dtype, 21)
+    w = rnd((ncls, 32, 3, 3), dtype, 22, scale=288 ** -0.5)
+    b = rnd((ncls,), torch.float32, 23)
+    xd = dev(nhwc(x), dtype)
+    if ck > 32:
+        xd = torch.cat([xd, torch.zeros(N, H, W, ck - 32, dtype=xd.dtype, device="cuda")], dim=-1).contiguous()
+    wp, _ = ops.pack_weight(torch.cat([w, torch.zeros(ncls, xd.shape[-1] - 32, 3, 3)], 1).cuda() if xd.shape[-1] > 32 else w.cuda(),
+                            dtype, want_dgrad=False)
+    src, ref_in = xd, x
+    if lazy and dtype == torch.bfloat16:
+        sc, sh = (rnd((2, xd.shape[-1]), torch.float32, 24).abs() + 0.5).cuda(), rnd((2, xd.shape[-1]), torch.float32, 25).cuda()
+        src = ops.BnInput(xd, sc, sh, 2)
+        g = torch.arange(N) // (N // 2)
+        ref_in = F.relu(x * sc.cpu()[g][:, :32, None, None] + sh.cpu()[g][:, :32, None, None]).to(dtype).float()
+    got = ops.conv3x3_head(src, wp, ncls, b.cuda())
+    assert got.dtype == torch.float32 and tuple(got.shape) == (N, ncls, H, W)
+    want = F.conv2d(ref_in, w, b, 1, 1)
+    close(got, want, dtype, "class head")
+    two = ops.nhwc_to_nchw(ops.conv2d(src, wp, ncls, 3, 1, 1, bias=b.cuda()))
+    close(got, two.cpu(), dtype, "head vs conv + layout pass", factor=0.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_rows_gelu_and_per_image_weights(ops, dtype):
     rows, cin, cout = 40, 32, 64        # rows not a multiple of 16 -> masked tail
     x = rnd((rows, cin), dtype, 11)
