@@ -41,10 +41,11 @@ struct WgArgs {
     // phase mode (KS = 2; see ConvArgs::phase_mode): blockIdx.z = output parity (a, b); dY is gathered from the fine grid at
     // (2 oy + a, 2 ox + b) of [N][2 OH][2 OW][Cout], x is read with pad (1 - a, 1 - b); one slab set per phase
     int phase_mode;
+    int no_xcd_remap;           // DAHITRA_NO_XCD_REMAP=1
     // DYT (the stem, KS = 4): dy is the masked gradient d of the BatchNorm OUTPUT; the gradient of the convolution output is
     // formed on load as A * d + B * y + C per channel (BatchNorm backward, coefficients from dh_stem_pool_bn_bwd)
     const void* dyt_y;          // pre-normalisation convolution output, same layout as dy
-    const float* dyt_coef;      // [dyt_groups][3][Cout]
+    const float* dytoef;      // [dyt_groups][3][Cout]
     int dyt_groups;
 };
 
@@ -73,11 +74,14 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     constexpr int HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     constexpr int TAPS = KS * KS;
     constexpr int NI = IT / 16;
+    constexpr bool WCI = CIG == 2 && sizeof(T) == 2 && IT == 32 && CTT == 64;       // see the MFMA loop
     // LDS pitches are ODD multiples of 32 B: a half-wave of ds_read_b64_tr_b16 then touches 8 consecutive
     // pixel rows x 32 B = 8 distinct bank windows of the 256-byte bank row (conflict-free)
     constexpr int XP = lds_pitch(ITT * (int)sizeof(T));    // halo pitch (bytes)
     constexpr int DP = lds_pitch(CT * (int)sizeof(T));     // dY tile pitch (bytes)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // (Two staging buffers -- commit of tile t+1 right after the MFMAs of tile t, one barrier per tile -- were measured and
+    // change nothing: layer3 90.3 vs 89.5 us, and the 256-thread forms lose a resident workgroup to the second buffer.)
     unsigned char* halo = smem;                      // [HH*HWD][XP]
     unsigned char* dyt = smem + HH * HWD * XP;       // [128][DP]
     float* bnp = reinterpret_cast<float*>(dyt + TH * TW * DP);      // in_scale: [in_groups][2][ITT] scale | shift
@@ -85,9 +89,17 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, cig = tid >> 8;
     const int pl = lane & 15, g = lane >> 4;
     const int cw = wv % CW, kq = wv / CW;
-    const int cot = blockIdx.x / p.ci_tiles, cit = blockIdx.x % p.ci_tiles;
+    // Workgroups are dispatched x-fastest, round-robin over the 8 XCDs (one L2 each).  Remapped so that all (co, ci) tile
+    // pairs of one pixel split kz -- they read the SAME x / dY tiles -- run back to back on ONE XCD (its L2 serves the re-reads).
+    int bx = blockIdx.x, kz = blockIdx.y;
+    if (gridDim.x > 1 && (gridDim.y & 7) == 0 && !p.no_xcd_remap) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, sq = lin >> 3;
+        bx = (int)(sq % gridDim.x);
+        kz = (int)((sq / gridDim.x) * 8 + xcd);
+    }
+    const int cot = bx / p.ci_tiles, cit = bx % p.ci_tiles;
     const int co0 = cot * CT, ci0 = cit * ITT;
-    const int kz = blockIdx.y, grp = blockIdx.z;
+    const int grp = blockIdx.z;
     const int ph_a = (KS == 2 && p.phase_mode) ? (int)(blockIdx.z >> 1) : 0, ph_b = (KS == 2 && p.phase_mode) ? (int)(blockIdx.z & 1) : 0;
     const int imgs_per_group = p.N / p.groups;
     const int tiles_per_img = p.tilesX * p.tilesY;
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     if constexpr (DYT) {
         for (int i = tid; i < p.dyt_groups * 3 * CT; i += NTHR) {
             const int gk = i / CT, c = i % CT;
-            bnp[i] = co0 + c < p.Cout ? p.dyt_coef[(size_t)gk * p.Cout + co0 + c] : 0.f;
+            bnp[i] = co0 + c < p.Cout ? p.dytoef[(size_t)gk * p.Cout + co0 + c] : 0.f;
         }
         __syncthreads();
     }
@@ -320,48 +332,74 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
             // so the 32 lanes of a half-wave read 8 consecutive pixels per transpose-read (see pitch note).
             // The k-steps are fully unrolled from per-lane base addresses: every LDS read is base + immediate.
             const int c0 = g * 4;
-            const unsigned char* a_base = TR ? dyt + (kq * KPW + c0 + (pl >> 2)) * DP + (cw * 16 + (pl & 3) * 4) * 2
-                                             : dyt + (kq * KPW + c0) * DP + (cw * 16 + pl) * 2;
+            // WCI (the 512-thread 64co x 64ci form): a wave owns ONE 16-wide ci sub-tile (wv) and TWO co sub-tiles (2 cig,
+            // 2 cig + 1) instead of one co sub-tile and two ci sub-tiles -- per k-step it reads 2 dY + 9 x fragments for its 18
+            // MFMAs instead of 1 + 18 (the x fragments were read by all four co waves): 22 instead of 38 transpose reads per
+            // 18 MFMAs, and the LDS pipe was as busy as the matrix pipe.
+            const int a_co = WCI ? 2 * cig * 16 : cw * 16, b_ci = WCI ? wv * 16 : cig * IT;
+            const unsigned char* a_base = TR ? dyt + (kq * KPW + c0 + (pl >> 2)) * DP + (a_co + (pl & 3) * 4) * 2
+                                             : dyt + (kq * KPW + c0) * DP + (a_co + pl) * 2;
             const unsigned char* b_base = ((TR && STRIDE == 1)
                 ? halo + (kq * (KPW / TW) * STRIDE * HWD + c0 * STRIDE + (pl >> 2)) * XP + ((pl & 3) * 4) * 2
-                : halo + (kq * (KPW / TW) * STRIDE * HWD + c0 * STRIDE) * XP + pl * 2) + cig * IT * 2;
+                : halo + (kq * (KPW / TW) * STRIDE * HWD + c0 * STRIDE) * XP + pl * 2) + b_ci * 2;
 #pragma unroll
             for (int kk = 0; kk < KPW; kk += 32) {
-                F8 a;
-                if constexpr (TR) {
-                    // lane p of each 16-lane group points at the 8-byte piece (pixel p/4, channels 4*(p%4)..+3)
-                    a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(a_base + kk * DP));
-                    a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(a_base + (kk + TW) * DP));
-                } else {
+                auto load_a = [&](int cofs) {          // dY fragment of the co sub-tile `cofs` bytes further
+                    F8 a;
+                    if constexpr (TR) {
+                        // lane p of each 16-lane group points at the 8-byte piece (pixel p/4, channels 4*(p%4)..+3)
+                        a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(a_base + kk * DP + cofs));
+                        a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(a_base + (kk + TW) * DP + cofs));
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        a.s[j] = *reinterpret_cast<const unsigned short*>(a_base + (kk + (j >> 2) * TW + (j & 3)) * DP);
-                }
-#pragma unroll
-                for (int kh = 0; kh < KS; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < KS; ++kw) {
-                        const int hp = ((kk / TW) * STRIDE + kh * DIL) * HWD + kw * DIL;      // compile-time
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) {
-                            F8 b;
-                            if constexpr (TR && STRIDE == 1) {
-                                b.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                    (__attribute__((address_space(3))) s16x4*)(b_base + hp * XP + i * 32));
-                                b.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                    (__attribute__((address_space(3))) s16x4*)(b_base + (hp + HWD) * XP + i * 32));
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < 8; ++j)
-                                    b.s[j] = *reinterpret_cast<const unsigned short*>(
-                                        b_base + (hp + (j >> 2) * STRIDE * HWD + (j & 3) * STRIDE) * XP + i * 32);
-                            }
-                            acc[kh * KS + kw][i] =
-                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc[kh * KS + kw][i], 0, 0, 0);
-                        }
+                        for (int j = 0; j < 8; ++j)
+                            a.s[j] = *reinterpret_cast<const unsigned short*>(a_base + (kk + (j >> 2) * TW + (j & 3)) * DP + cofs);
                     }
+                    return a;
+                };
+                auto load_b = [&](int hp, int cofs) {  // x fragment at halo pixel offset hp, ci sub-tile `cofs` bytes further
+                    F8 b;
+                    if constexpr (TR && STRIDE == 1) {
+                        b.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(b_base + hp * XP + cofs));
+                        b.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(b_base + (hp + HWD) * XP + cofs));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            b.s[j] = *reinterpret_cast<const unsigned short*>(
+                                b_base + (hp + (j >> 2) * STRIDE * HWD + (j & 3) * STRIDE) * XP + cofs);
+                    }
+                    return b;
+                };
+                if constexpr (WCI) {
+                    const F8 a0 = load_a(0), a1 = load_a(32);
+#pragma unroll
+                    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < KS; ++kw) {
+                            const int hp = ((kk / TW) * STRIDE + kh * DIL) * HWD + kw * DIL;      // compile-time
+                            const F8 b = load_b(hp, 0);
+                            acc[kh * KS + kw][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, b.v, acc[kh * KS + kw][0], 0, 0, 0);
+                            acc[kh * KS + kw][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, b.v, acc[kh * KS + kw][1], 0, 0, 0);
+                        }
+                } else {
+                    const F8 a = load_a(0);
+#pragma unroll
+                    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < KS; ++kw) {
+                            const int hp = ((kk / TW) * STRIDE + kh * DIL) * HWD + kw * DIL;      // compile-time
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) {
+                                const F8 b = load_b(hp, i * 32);
+                                acc[kh * KS + kw][i] =
+                                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc[kh * KS + kw][i], 0, 0, 0);
+                            }
+                        }
+                }
             }
         }
         __syncthreads();
@@ -394,14 +432,18 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     }
     // partial slab: [grp][kz][tap][Cout][Cin]
     // (one 64-bit base + 32-bit offsets, bounds hoisted: the slab of one workgroup is far below 2^31 elements)
-    const int cob = co0 + cw * 16 + g * 4, cib = ci0 + cig * IT + pl;
+    // accumulator tile i of a lane: rows co = cob + j (j < 4), column ci = cib, advancing by `istep` elements per i:
+    // 16 input channels (the ci sub-tiles of a wave) or, WCI, 16 output channels (its two co sub-tiles)
+    const int cob = co0 + (WCI ? 2 * cig * 16 : cw * 16) + g * 4, cib = ci0 + (WCI ? wv * 16 : cig * IT) + pl;
     float* out = p.part + ((size_t)grp * p.splitk + kz) * TAPS * p.Cout * p.Cin + (size_t)cob * p.Cin + cib;
     const int tstride = p.Cout * p.Cin;
-    bool okj[4], oki[NI];
+    const int istep = WCI ? 16 * p.Cin : 16;
+    bool okij[NI][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) okj[j] = cob + j < p.CoutUse;
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int i = 0; i < NI; ++i) oki[i] = cib + i * 16 < p.Cin;
+        for (int j = 0; j < 4; ++j)
+            okij[i][j] = WCI ? (cob + i * 16 + j < p.CoutUse && cib < p.Cin) : (cob + j < p.CoutUse && cib + i * 16 < p.Cin);
     if (p.direct == 2) {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
@@ -409,7 +451,7 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (okj[j] && oki[i]) out[t * tstride + j * p.Cin + i * 16] += acc[t][i][j];
+                    if (okij[i][j]) out[t * tstride + j * p.Cin + i * istep] += acc[t][i][j];
     } else {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
@@ -417,7 +459,7 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (okj[j] && oki[i]) out[t * tstride + j * p.Cin + i * 16] = acc[t][i][j];
+                    if (okij[i][j]) out[t * tstride + j * p.Cin + i * istep] = acc[t][i][j];
     }
 }
 
@@ -607,14 +649,16 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
                              int groups, int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation,
                              void* workspace, void* stream, int defer, int* splitk_out, const float* in_scale = nullptr,
                              const float* in_shift = nullptr, int in_groups = 1, const void* dyt_y = nullptr,
-                             const float* dyt_coef = nullptr, int dyt_groups = 1) {
+                             const float* dytoef = nullptr, int dyt_groups = 1) {
     DH_REQUIRE(groups == 1 || (groups == N && ks == 1), "conv2d_wgrad: groups must be 1 or N (with ks=1)");
     WgArgs a;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
     DH_REQUIRE(dilation == 1 || (dilation == 2 && ks == 3 && stride == 1), "conv2d_wgrad: dilation %d unsupported here", dilation);
     a.dil = dilation;
     a.phase_mode = 0;
-    a.dyt_y = dyt_y; a.dyt_coef = dyt_coef; a.dyt_groups = dyt_groups;
+    static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
+    a.no_xcd_remap = no_remap;
+    a.dyt_y = dyt_y; a.dytoef = dytoef; a.dyt_groups = dyt_groups;
     a.in_scale = in_scale; a.in_shift = in_shift; a.in_groups = in_groups > 0 ? in_groups : 1;
     if (in_scale) DH_REQUIRE(in_shift && groups == 1 && N % a.in_groups == 0 && (Cin * (dtype == DH_DTYPE_BF16 ? 2 : 4)) % 16 == 0,
                              "conv2d_wgrad: BatchNorm-on-load needs in_shift, one weight group, N %% in_groups == 0, 16-byte channel pieces");
@@ -712,7 +756,8 @@ extern "C" int dh_conv2d_wgrad_phase(int dtype, const void* x, const void* dy, i
     WgArgs a;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
     a.dil = 1; a.phase_mode = 1;
-    a.dyt_y = nullptr; a.dyt_coef = nullptr; a.dyt_groups = 1;
+    a.no_xcd_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
+    a.dyt_y = nullptr; a.dytoef = nullptr; a.dyt_groups = 1;
     a.in_scale = nullptr; a.in_shift = nullptr; a.in_groups = 1;
     a.CinPitch = Cin;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W; a.Cout = 32; a.pad = 1;

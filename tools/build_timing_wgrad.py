@@ -7,12 +7,12 @@ def rep(old, new):
     global s
     assert s.count(old) == 1, old
     s = s.replace(old, new, 1)
-rep("template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT>\n__global__",
+rep("template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT, int CIG, bool DYT = false>\n__global__",
     '''__device__ long long g_tw[8192 * 16];
 #define NOW() ((long long)wall_clock64())
-template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT>
+template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT, int CIG, bool DYT = false>
 __global__''')
-rep("    if (kz < ntiles) fetch();\n    for (int tile = kz; tile < ntiles; tile += p.splitk) {\n        commit();\n        __syncthreads();\n",
+rep("    if (kz < ntiles) fetch();\n    for (int tile = kz; tile < ntiles; tile += p.splitk) {\n        commit();\n        __syncthreads();\n        if (tile + p.splitk < ntiles) fetch();\n",
     '''    long long tsum[6] = {0, 0, 0, 0, 0, 0};
     const long long tstart = NOW();
     if (kz < ntiles) fetch();
@@ -23,6 +23,7 @@ rep("    if (kz < ntiles) fetch();\n    for (int tile = kz; tile < ntiles; tile 
         long long t1 = NOW(); tsum[1] += t1 - t0;
         __syncthreads();
         t0 = NOW(); tsum[2] += t0 - t1;
+        if (tile + p.splitk < ntiles) fetch();
         t1 = NOW(); tsum[3] += t1 - t0;
 ''')
 rep("        __syncthreads();\n    }\n\n    if constexpr (KSPLIT > 1) {",
@@ -33,10 +34,10 @@ rep("        __syncthreads();\n    }\n\n    if constexpr (KSPLIT > 1) {",
     const long long tloop = NOW();
 
     if constexpr (KSPLIT > 1) {''')
-rep('''                    if (okj[j] && oki[i]) out[t * tstride + j * p.Cin + i * 16] = acc[t][i][j];
+rep('''                    if (okij[i][j]) out[t * tstride + j * p.Cin + i * istep] = acc[t][i][j];
     }
 }
-''', '''                    if (okj[j] && oki[i]) out[t * tstride + j * p.Cin + i * 16] = acc[t][i][j];
+''', '''                    if (okij[i][j]) out[t * tstride + j * p.Cin + i * istep] = acc[t][i][j];
     }
     {
         const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
