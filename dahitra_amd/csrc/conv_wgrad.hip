@@ -551,6 +551,239 @@ __global__ void wgrad_reduce_multi_kernel(const WgReduceJob* __restrict__ jobs, 
                        (long)blockIdx.x - job.first_block, red);
 }
 
+// ---- wave-specialised 64co x 64ci weight gradient of the 3x3 stride-1 layers (bf16, Cin % 64 == Cout % 64 == 0) ----------
+// The per-workgroup clock of conv_wgrad_kernel (tools/wgrad_timeline.py) shows 2.24 us per 128-pixel tile against 0.96 us of MFMA
+// issue: 0.5 us of it is the address arithmetic + load issue of the next tile, which every wave runs BEFORE its MFMAs (both
+// waves of a SIMD in lock step, the matrix pipe idle), 0.7 us are two barriers, 0.2 us the LDS commit.  Here the eight waves
+// split the roles: waves 4-7 are PRODUCERS (all global loads, BatchNorm-on-load, LDS commits; no accumulators), waves 0-3 are
+// CONSUMERS (one per SIMD: ci sub-tile wv x all four co sub-tiles = 36 accumulator tiles, 144 MFMAs per tile back to back, 13
+// fragment loads per 36 MFMAs).  Two LDS stages, ONE raw s_barrier per tile (no vmcnt drain): the producers' VALU / memory work
+// runs on the SIMD's other issue slots while its consumer wave keeps the matrix pipe busy.
+#ifdef DH_WS_TIMING
+__device__ long long g_ws[4096 * 16];
+#define WS_NOW() ((long long)wall_clock64())
+#define WS_T(...) __VA_ARGS__
+#else
+#define WS_T(...)
+#endif
+template <int DIL>
+__global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgArgs p) {
+    constexpr int KS = 3, TAPS = 9;
+    constexpr int HH = (TH - 1) + (KS - 1) * DIL + 1, HWD = (TW - 1) + (KS - 1) * DIL + 1;
+    constexpr int XP = lds_pitch(128), DP = lds_pitch(128);           // 64 channels x 2 B, odd multiple of 32 B
+    constexpr int STAGE = HH * HWD * XP + TH * TW * DP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* bnp = reinterpret_cast<float*>(smem + 2 * STAGE);          // in_scale: [in_groups][2][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pl = lane & 15, g = lane >> 4;
+    int bx = blockIdx.x, kz = blockIdx.y;
+    if (gridDim.x > 1 && (gridDim.y & 7) == 0 && !p.no_xcd_remap) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, sq = lin >> 3;
+        bx = (int)(sq % gridDim.x);
+        kz = (int)((sq / gridDim.x) * 8 + xcd);
+    }
+    const int cot = bx / p.ci_tiles, cit = bx % p.ci_tiles;
+    const int co0 = cot * 64, ci0 = cit * 64;
+    const int tiles_per_img = p.tilesX * p.tilesY;
+    const int ntiles = p.N * tiles_per_img;
+    const int my_tiles = kz < ntiles ? (ntiles - kz + p.splitk - 1) / p.splitk : 0;
+
+    if (p.in_scale) {
+        for (int i = tid; i < p.in_groups * 128; i += 512) {
+            const int gi = i >> 7, k = (i >> 6) & 1, c = i & 63;
+            bnp[i] = (k ? p.in_shift : p.in_scale)[gi * p.Cin + ci0 + c];
+        }
+        __syncthreads();
+    }
+
+    if (wv >= 4) {
+        // ================= producers =================
+        const int pt = tid - 256, q = pt & 7, prow = pt >> 3;          // this thread's pieces: channel piece q of pixels prow + 32 i
+        constexpr int NXV = (HH * HWD + 31) / 32, NDV = TH * TW / 32;
+        // two register sets: the loads of tile it + 2 are issued right after tile it is committed, i.e. they have two tile times
+        // (~2 us) to land -- with one set the producers waited on HBM latency every tile
+        struct Regs { uint4 rx[NXV], rd[NDV]; unsigned okmask; int bng; };
+        Regs RA, RB;
+        int x_h[NXV];                                                 // hy << 8 | hx, or -1 past the halo
+#pragma unroll
+        for (int i = 0; i < NXV; ++i) {
+            const int px = prow + 32 * i;
+            x_h[i] = px < HH * HWD ? ((px / HWD) << 8) | (px % HWD) : -1;
+        }
+        const unsigned xps = (unsigned)p.CinPitch * 2u, dps = (unsigned)p.Cout * 2u;
+        const unsigned xcb = (unsigned)(ci0 + q * 8) * 2u, dcb = (unsigned)(co0 + q * 8) * 2u;
+        const int dn = p.splitk / tiles_per_img, drem = p.splitk % tiles_per_img;
+        const int dty = drem / p.tilesX, dtx = drem % p.tilesX;
+        int f_n = kz / tiles_per_img, f_ty = (kz % tiles_per_img) / p.tilesX, f_tx = (kz % tiles_per_img) % p.tilesX;
+        auto fetch = [&](Regs& R) {
+            const int n = f_n;
+            R.bng = p.in_scale ? n / (p.N / p.in_groups) : 0;
+            const int oy0 = f_ty * TH, ox0 = f_tx * TW, iy0 = oy0 - p.pad, ix0 = ox0 - p.pad;
+            const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x) + (size_t)n * p.H * p.W * xps;
+            const unsigned char* db = reinterpret_cast<const unsigned char*>(p.dy) + (size_t)n * p.OH * p.OW * dps;
+            R.okmask = 0;
+#pragma unroll
+            for (int i = 0; i < NXV; ++i) {
+                const int iy = iy0 + (x_h[i] >> 8), ix = ix0 + (x_h[i] & 0xff);
+                const bool ok = x_h[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const uint4 v = *reinterpret_cast<const uint4*>(xb + (ok ? (unsigned)(iy * p.W + ix) * xps + xcb : 0u));
+                R.rx[i] = ok ? v : make_uint4(0, 0, 0, 0);
+                R.okmask |= ok ? (1u << i) : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < NDV; ++i) {
+                const int px = prow + 32 * i, oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+                const bool ok = oy < p.OH && ox < p.OW;
+                const uint4 v = *reinterpret_cast<const uint4*>(db + (ok ? (unsigned)(oy * p.OW + ox) * dps + dcb : 0u));
+                R.rd[i] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
+            f_tx += dtx;
+            if (f_tx >= p.tilesX) { f_tx -= p.tilesX; ++f_ty; }
+            f_ty += dty;
+            if (f_ty >= p.tilesY) { f_ty -= p.tilesY; ++f_n; }
+            f_n += dn;
+        };
+        auto commit = [&](Regs& R, int stage) {
+            unsigned char* halo = smem + stage * STAGE;
+            unsigned char* dyt = halo + HH * HWD * XP;
+            if (p.in_scale) {          // x = relu(x * scale + shift) on its way into LDS (padding stays zero)
+                float sc[8], sh[8];
+                const float* sp = bnp + R.bng * 128 + q * 8;
+#pragma unroll
+                for (int j = 0; j < 8; j += 4) {
+                    *reinterpret_cast<float4*>(sc + j) = *reinterpret_cast<const float4*>(sp + j);
+                    *reinterpret_cast<float4*>(sh + j) = *reinterpret_cast<const float4*>(sp + 64 + j);
+                }
+#pragma unroll
+                for (int i = 0; i < NXV; ++i) {
+                    if (!((R.okmask >> i) & 1u)) continue;
+                    float v[8];
+                    unpack16(R.rx[i], v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * sc[j] + sh[j], 0.f);
+                    R.rx[i] = pack16<bf16>(v);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NXV; ++i)
+                if (x_h[i] >= 0) *reinterpret_cast<uint4*>(halo + (prow + 32 * i) * XP + q * 16) = R.rx[i];
+#pragma unroll
+            for (int i = 0; i < NDV; ++i) *reinterpret_cast<uint4*>(dyt + (prow + 32 * i) * DP + q * 16) = R.rd[i];
+        };
+        WS_T(long long ts[4] = {0, 0, 0, 0}; const long long tbeg = WS_NOW();)
+        if (my_tiles > 0) fetch(RA);
+        if (my_tiles > 1) fetch(RB);
+        for (int it = 0; it < my_tiles; it += 2) {
+            WS_T(long long t0 = WS_NOW();)
+            commit(RA, 0);
+            WS_T(long long t1 = WS_NOW(); ts[0] += t1 - t0;)
+            if (it + 2 < my_tiles) fetch(RA);
+            WS_T(t0 = WS_NOW(); ts[1] += t0 - t1;)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            WS_T(ts[2] += WS_NOW() - t0;)
+            if (it + 1 < my_tiles) {
+                WS_T(t0 = WS_NOW();)
+                commit(RB, 1);
+                WS_T(t1 = WS_NOW(); ts[0] += t1 - t0;)
+                if (it + 3 < my_tiles) fetch(RB);
+                WS_T(t0 = WS_NOW(); ts[1] += t0 - t1;)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                WS_T(ts[2] += WS_NOW() - t0;)
+            }
+        }
+        WS_T(if (tid == 256) { long long* o = g_ws + (blockIdx.y * gridDim.x + blockIdx.x) % 4096 * 16 + 8; o[0] = ts[0]; o[1] = ts[1]; o[2] = ts[2]; o[3] = WS_NOW() - tbeg; })
+        return;
+    }
+
+    // ================= consumers: ci sub-tile wv, co sub-tiles 0..3 =================
+    f32x4 acc[TAPS][4];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[t][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int c0 = g * 4;
+    WS_T(long long tc[3] = {0, 0, 0}; const long long tbeg = WS_NOW();)
+    for (int it = 0; it < my_tiles; ++it) {
+        WS_T(long long t0 = WS_NOW();)
+        __builtin_amdgcn_s_barrier();             // stage it & 1 is committed; the producers now refill the other one
+        WS_T(long long t1 = WS_NOW(); tc[0] += t1 - t0;)
+        const unsigned char* halo = smem + (it & 1) * STAGE;
+        const unsigned char* dyt = halo + HH * HWD * XP;
+        // lane p of each 16-lane group points at the 8-byte piece (pixel p/4, channels 4*(p%4)..+3): ds_read_b64_tr_b16
+        const unsigned char* a_base = dyt + (c0 + (pl >> 2)) * DP + ((pl & 3) * 4) * 2;
+        const unsigned char* b_base = halo + (c0 + (pl >> 2)) * XP + ((pl & 3) * 4) * 2 + wv * 32;
+        // (Left to the compiler's scheduling: a hand-pipelined version -- x fragment two steps ahead, dY fragments of the next
+        // k-step at tap 5, sched_barriers around each MFMA group -- was slower, 1.66 vs 1.44 us per tile.  144 MFMAs are
+        // 0.96 us at 2.4 GHz; the chip runs this phase at ~80 % of that on random operands.)
+#pragma unroll
+        for (int kk = 0; kk < TH * TW; kk += 32) {
+            F8 a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                a[s].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a_base + kk * DP + s * 32));
+                a[s].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a_base + (kk + TW) * DP + s * 32));
+            }
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw) {
+                    const int hp = ((kk / TW) + kh * DIL) * HWD + kw * DIL;      // compile-time
+                    F8 b;
+                    b.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b_base + hp * XP));
+                    b.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b_base + (hp + HWD) * XP));
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc[kh * KS + kw][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s].v, b.v, acc[kh * KS + kw][s], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's LDS reads of the stage are complete
+        WS_T(tc[1] += WS_NOW() - t1;)
+    }
+    WS_T(const long long tloop = WS_NOW();)
+    // partial slab [kz][tap][Cout][Cin]: lane (pl, g) holds rows co = 16 s + 4 g + j, column ci = 16 wv + pl
+    float* out = p.part + (size_t)kz * TAPS * p.Cout * p.Cin + (size_t)(co0 + g * 4) * p.Cin + ci0 + wv * 16 + pl;
+    const int tstride = p.Cout * p.Cin;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[t * tstride + (s * 16 + j) * p.Cin] = acc[t][s][j];
+    WS_T(if (tid == 0) { long long* o = g_ws + (blockIdx.y * gridDim.x + blockIdx.x) % 4096 * 16; o[0] = tc[0]; o[1] = tc[1]; o[2] = tloop - tbeg; o[3] = WS_NOW() - tloop; o[4] = my_tiles; })
+}
+#ifdef DH_WS_TIMING
+extern "C" int dh_debug_ws(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws), (size_t)n * 8); }
+#endif
+template <int DIL>
+int launch_ws(const WgArgs& a, hipStream_t st) {
+    constexpr int HH = (TH - 1) + 2 * DIL + 1, HWD = (TW - 1) + 2 * DIL + 1;
+    const size_t lds = 2 * ((size_t)HH * HWD * lds_pitch(128) + (size_t)TH * TW * lds_pitch(128)) +
+                       (a.in_scale ? (size_t)a.in_groups * 128 * sizeof(float) : 0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        attr_done = true;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_kernel<DIL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds + 4096) != hipSuccess) {
+            (void)hipGetLastError();
+            DH_FAIL("conv_wgrad_ws: cannot raise dynamic LDS to %zu", lds);
+        }
+    }
+    dim3 grid((a.Cout / 64) * a.ci_tiles, a.splitk, 1);
+    hipLaunchKernelGGL(conv_wgrad_ws_kernel<DIL>, grid, dim3(512), lds, st, a);
+    DH_CHECK_LAUNCH("conv_wgrad_ws");
+    return 0;
+}
+// eligibility of the wave-specialised form (DAHITRA_WGRAD_NO_WS=1: A/B switch back to conv_wgrad_kernel)
+static inline bool ws_eligible(const WgArgs& a, int ks, int stride, bool bf16, bool tr) {
+    static const bool off = getenv("DAHITRA_WGRAD_NO_WS") != nullptr;
+    return !off && bf16 && tr && ks == 3 && stride == 1 && a.groups == 1 && !a.phase_mode && !a.dyt_y && a.Cin % 64 == 0 &&
+           a.Cout % 64 == 0 && a.CoutUse == a.Cout && a.CinPitch == a.Cin && a.npix == a.OH * a.OW && a.in_npix == a.H * a.W &&
+           (a.in_scale == nullptr || a.in_groups <= 8);
+}
+
 template <typename T, int KS, int STRIDE, int IT, int DIL, int CT, int CIG = 1>
 int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
@@ -607,6 +840,8 @@ int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
     const bool wide = a.Cin > 32 && ks == 1 && stride == 1;   // 64-wide ci tiles only where accumulators / LDS fit
     const int it = ks == 4 ? 16 : ((wide || (stride == 1 && wide_ci3x3(a.Cin, a.CoutUse, ks))) ? 64 : 32);
     a.ci_tiles = dh_cdiv(a.Cin, it);
+    if (ws_eligible(a, ks, stride, sizeof(T) == 2, tr) && wide_ci3x3(a.Cin, a.CoutUse, ks))
+        return a.dil == 2 ? launch_ws<2>(a, st) : launch_ws<1>(a, st);
     if (ks == 3 && stride == 1 && a.dil == 2) return launch<T, 3, 1, 32, 2>(a, tr, st);
     if (ks == 3 && stride == 1) return launch<T, 3, 1, 32>(a, tr, st);
     if (ks == 3 && stride == 2) return launch<T, 3, 2, 32>(a, tr, st);
