@@ -513,13 +513,23 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecArgs p) {
 
 // sums the workgroup partials: shared parameters over all workgroups (accumulated into the gradient arena),
 // per-image dKq / dVoT over the workgroups of that image (assigned)
+// blockIdx.z = layer of a decoder stack whose backward launches left their partials `pstride` floats apart (layer 0 .. depth-1
+// of the SAME shapes): the layers' parameters sit `gstride` floats apart in the gradient arena, dkq / dvoT `kstride` apart.
 template <int MLP>
 __global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int bpi,
                                                                float* dw1, float* dw2, float* db1, float* db2,
                                                                float* dbo, float* dg1, float* dbe1, float* dg2,
-                                                               float* dbe2, float* dkq, float* dvoT) {
+                                                               float* dbe2, float* dkq, float* dvoT, long pstride,
+                                                               long gstride, long kstride) {
     using P = PL<MLP>;
     __shared__ double red[8][32];
+    {
+        const long z = blockIdx.z;
+        partial += z * pstride;
+        dw1 += z * gstride; dw2 += z * gstride; db1 += z * gstride; db2 += z * gstride; dbo += z * gstride;
+        dg1 += z * gstride; dbe1 += z * gstride; dg2 += z * gstride; dbe2 += z * gstride;
+        dkq += z * kstride; dvoT += z * kstride;
+    }
     const int lane = threadIdx.x & 31, ph = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + lane;                 // element of the shared-parameter part
     if (blockIdx.y == 0) {
@@ -613,6 +623,9 @@ extern "C" long dh_decoder_layer_bwd_workspace_size(long rows, int rows_per_imag
     return nblk * (mlp == 64 ? PL<64>::SIZE : PL<32>::SIZE) * 4;
 }
 
+// dw1 == NULL: only the data-gradient launch runs and the per-workgroup partials stay in `workspace` -- the caller sums the
+// partials of all layers of a decoder stack with ONE dh_decoder_stack_bwd_finalize launch (32 finalize launches of 5.6 us sat on
+// the critical path of the DAHiTra step).
 // dx: [rows][32] bf16.  Shared-parameter gradients are ACCUMULATED into dw1 [mlp][32], dw2 [32][mlp], db1, db2,
 // dbo, dln1_g/b, dln2_g/b (fp32); per-image dkq [images][32][32], dvoT [images][32][32] are assigned.
 extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, const void* kq, const void* voT,
@@ -643,8 +656,8 @@ extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, con
             }
         }
         hipLaunchKernelGGL(dec_bwd_kernel<64>, dim3(nblk), dim3(256), lds, ST(stream), a);
-        hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(dh_cdiv(PL<64>::KQ, 32), 1 + images), dim3(256), 0, ST(stream),
-                           a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT);
+        if (dw1) hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(dh_cdiv(PL<64>::KQ, 32), 1 + images), dim3(256), 0, ST(stream),
+                                    a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, 0L, 0L, 0L);
     } else {
         const size_t lds = bwd_lds_bytes<32>();
         if (!attr32) {
@@ -655,9 +668,30 @@ extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, con
             }
         }
         hipLaunchKernelGGL(dec_bwd_kernel<32>, dim3(nblk), dim3(256), lds, ST(stream), a);
-        hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(dh_cdiv(PL<32>::KQ, 32), 1 + images), dim3(256), 0, ST(stream),
-                           a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT);
+        if (dw1) hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(dh_cdiv(PL<32>::KQ, 32), 1 + images), dim3(256), 0, ST(stream),
+                                    a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, 0L, 0L, 0L);
     }
     DH_CHECK_LAUNCH("decoder_layer_bwd");
+    return 0;
+}
+
+// The finalize of `depth` layers at once: partials of layer l at workspace + l * dh_decoder_layer_bwd_workspace_size bytes,
+// gradients of layer l at (pointer of layer 0) + l * grad_stride floats, dkq / dvoT of layer l at + l * images * 1024 floats.
+extern "C" int dh_decoder_stack_bwd_finalize(const void* workspace, int depth, long rows, int rows_per_image, int mlp, float* dw1,
+                                             float* dw2, float* db1, float* db2, float* dbo, float* dln1_g, float* dln1_b,
+                                             float* dln2_g, float* dln2_b, long grad_stride, float* dkq, float* dvoT, void* stream) {
+    if (check_common(rows, rows_per_image, mlp)) return 1;
+    DH_REQUIRE(depth >= 1 && workspace && dw1 && dkq && dvoT, "decoder_stack_bwd_finalize: bad arguments (depth %d)", depth);
+    const int rpb = dec_rows_per_block(rows_per_image);
+    const int nblk = (int)(rows / rpb), bpi = rows_per_image / rpb, images = (int)(rows / rows_per_image);
+    const float* partial = reinterpret_cast<const float*>(workspace);
+    const long pstride = dh_decoder_layer_bwd_workspace_size(rows, rows_per_image, mlp) / 4, kstride = (long)images * 1024;
+    if (mlp == 64)
+        hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(dh_cdiv(PL<64>::KQ, 32), 1 + images, depth), dim3(256), 0, ST(stream), partial,
+                           nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, pstride, grad_stride, kstride);
+    else
+        hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(dh_cdiv(PL<32>::KQ, 32), 1 + images, depth), dim3(256), 0, ST(stream), partial,
+                           nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, pstride, grad_stride, kstride);
+    DH_CHECK_LAUNCH("decoder_stack_bwd_finalize");
     return 0;
 }

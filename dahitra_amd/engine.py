@@ -11,6 +11,7 @@ ResNet.forward_single :233-257, BasicBlock models/resnet.py:58-73, Transformer /
 models/help_funcs.py:154-186, BASE_Transformer_UNet.forward models/networks.py:1297-1357.
 """
 import os
+import types
 
 import torch
 
@@ -76,6 +77,8 @@ class Engine:
         self.fused_stem_bwd = os.environ.get("DAHITRA_NO_FUSED_STEM_BWD", "0") != "1"
         # the class head writes its fp32 NCHW logits itself (no NHWC logits tensor, no layout pass)
         self.fused_head_out = os.environ.get("DAHITRA_NO_FUSED_HEAD", "0") != "1"
+        # one finalize launch for the parameter gradients of all layers of a fused decoder stack
+        self.defer_dec_finalize = os.environ.get("DAHITRA_NO_DEFER_DEC_FINALIZE", "0") != "1"
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -506,12 +509,23 @@ class Engine:
             and mlp0 in (32, 64)
         stack = self._prep_stack(tok, tok_b, tok_s, B, images, L, heads, dim_head, pfx, depth) if fused and depth > 1 \
             else None
+        # deferred parameter gradients: the fused backward launches of a stack leave their per-workgroup partials in a per-layer
+        # buffer and ONE launch sums them for all layers (needs the layers' parameters at one constant pitch in the arena)
+        defer = None
+        if fused and stack is not None and self.need_grad and self.defer_dec_finalize:
+            gstride = self._layer_grad_stride(pfx, depth)
+            mlps = {self.shapes["%s.layers.%d.1.fn.fn.net.0.weight" % (pfx, i)][0] for i in range(depth)}
+            if gstride is not None and len(mlps) == 1:
+                rows = x.shape[0]
+                defer = types.SimpleNamespace(
+                    partials=torch.empty(depth, ops.decoder_layer_bwd_partial_floats(rows, rpi, mlp0), dtype=torch.float32,
+                                         device=x.device), gstride=gstride, rows=rows)
         for i in range(depth):
             a, f = "%s.layers.%d.0.fn" % (pfx, i), "%s.layers.%d.1.fn" % (pfx, i)
             mlp = self.shapes[f + ".fn.net.0.weight"][0]
             if fused:
                 x, b1 = self._dec_layer_fused(x, images, rpi, tok, tok_b, tok_s, B, dtok, a, f, heads, dim_head, L, mlp,
-                                              stack=stack, li=i)
+                                              stack=stack, li=i, partial=defer.partials[i] if defer is not None else None)
                 bw.append(b1)
                 continue
             x, b1 = self._dec_attn(x, images, tok, tok_b, tok_s, B, dtok, a, heads, dim_head, L)
@@ -523,6 +537,12 @@ class Engine:
         def bwd(d):
             for b in reversed(bw):
                 d = b(d)
+            if defer is not None:
+                a0, f0 = "%s.layers.0.0.fn" % pfx, "%s.layers.0.1.fn" % pfx
+                grads0 = (self.g[f0 + ".fn.net.0.weight"], self.g[f0 + ".fn.net.3.weight"], self.g[f0 + ".fn.net.0.bias"],
+                          self.g[f0 + ".fn.net.3.bias"], self.g[a0 + ".fn.to_out.0.bias"], self.g[a0 + ".norm.weight"],
+                          self.g[a0 + ".norm.bias"], self.g[f0 + ".norm.weight"], self.g[f0 + ".norm.bias"])
+                ops.decoder_stack_bwd_finalize(defer.partials, defer.rows, rpi, mlp0, grads0, defer.gstride, stack.dkq, stack.dvoT)
             if stack is not None:            # token-side backward of ALL layers in one pass (they stored dkq / dvoT)
                 a0 = "%s.layers.0.0.fn" % pfx
                 stack.backward(tok, dtok, self.p[a0 + ".norm.weight"], self.xstack[(pfx, "to_q.weight")],
@@ -531,6 +551,22 @@ class Engine:
                                *(self.g[a0 + ".fn.to_%s.weight" % n] for n in ("q", "k", "v", "out.0")))
             return d
         return x, bwd
+
+    def _layer_grad_stride(self, pfx, depth):
+        """floats between consecutive layers' gradients of the nine tensors the fused decoder backward accumulates, or None"""
+        names = ("1.fn.fn.net.0.weight", "1.fn.fn.net.3.weight", "1.fn.fn.net.0.bias", "1.fn.fn.net.3.bias", "0.fn.fn.to_out.0.bias",
+                 "0.fn.norm.weight", "0.fn.norm.bias", "1.fn.norm.weight", "1.fn.norm.bias")
+        stride = None
+        for n in names:
+            for i in range(1, depth):
+                k0, k1 = "%s.layers.%d.%s" % (pfx, i - 1, n), "%s.layers.%d.%s" % (pfx, i, n)
+                if k0 not in self.g or k1 not in self.g:
+                    return None
+                d = self.g[k1].data_ptr() - self.g[k0].data_ptr()
+                if d % 4 or (stride is not None and d // 4 != stride):
+                    return None
+                stride = d // 4
+        return stride
 
     def _prep_stack(self, tok, tok_b, tok_s, B, images, L, heads, dim_head, pfx, depth):
         """ops.XattnPrepStack for the `depth` layers of decoder `pfx`, or None when the layers' parameters do not sit
@@ -556,7 +592,7 @@ class Engine:
                                   self.xstack[(pfx, "to_out.0.weight")], self.dtype, ATTN_SCALE, LN_EPS)
 
     def _dec_layer_fused(self, x0, images, rpi, tok, tok_b, tok_s, B, dtok, a, f, heads, dim_head, L, mlp, stack=None,
-                         li=0):
+                         li=0, partial=None):
         """one decoder layer = one HIP kernel per direction (csrc/decoder_fused.hip) + the per-image operand prep
         (`stack`: prepared for all layers at once by ops.XattnPrepStack; its backward runs once after the last layer)"""
         g1, b1 = self.p[a + ".norm.weight"], self.p[a + ".norm.bias"]
@@ -582,7 +618,7 @@ class Engine:
             if stack is not None:
                 dx, _, _ = ops.decoder_layer_bwd(x0, dy, prep, rpi, g1, b1, bo, g2, b2, self.pk[w1k].fwd,
                                                  self.pk[w1k].dgrad, fb1, self.pk[w2k].fwd, self.pk[w2k].dgrad, fb2,
-                                                 grads, mlp, LN_EPS, dkq=stack.dkq[li], dvoT=stack.dvoT[li])
+                                                 grads, mlp, LN_EPS, dkq=stack.dkq[li], dvoT=stack.dvoT[li], partial=partial)
                 return dx
             dx, dkq, dvoT = ops.decoder_layer_bwd(x0, dy, prep, rpi, g1, b1, bo, g2, b2, self.pk[w1k].fwd,
                                                   self.pk[w1k].dgrad, fb1, self.pk[w2k].fwd, self.pk[w2k].dgrad, fb2,

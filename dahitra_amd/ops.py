@@ -955,21 +955,37 @@ def decoder_layer_fwd(x2d, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b,
 
 
 def decoder_layer_bwd(x2d, dy, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b, w1, w1T, b1, w2, w2T, b2, grads, mlp,
-                      eps=1e-5, dkq=None, dvoT=None):
+                      eps=1e-5, dkq=None, dvoT=None, partial=None):
     """returns (dx, dkq [S,32,32] fp32, dvoT [S,32,32] fp32); grads = (dw1, dw2, db1, db2, dbo, dg1, dbe1, dg2, dbe2)
-    are accumulated in place"""
+    are accumulated in place.  partial (a per-layer buffer of decoder_layer_bwd_partial_floats floats): only the data
+    gradient runs, the parameter gradients are summed later by decoder_stack_bwd_finalize (grads is ignored)."""
     rows = x2d.shape[0]
     images = rows // rows_per_image
     dx = torch.empty_like(x2d)
     if dkq is None:
         dkq = torch.empty(images, 32, 32, dtype=torch.float32, device=x2d.device)
         dvoT = torch.empty(images, 32, 32, dtype=torch.float32, device=x2d.device)
-    ws = workspace(_lib.lib().dh_decoder_layer_bwd_workspace_size(_cl(rows), rows_per_image, mlp), x2d.device)
+    if partial is not None:
+        ws, gp = partial, [_vp(0)] * 9
+    else:
+        ws = workspace(_lib.lib().dh_decoder_layer_bwd_workspace_size(_cl(rows), rows_per_image, mlp), x2d.device)
+        gp = [P(t) for t in grads]
     with _Prof("decoder_layer_bwd", 0, _nb(x2d, dy, dx)):
         _call("dh_decoder_layer_bwd", P(x2d), P(dy), P(dx), P(prep.kq), P(prep.voT), P(prep.vo), P(prep.kqT), P(ln1_g),
-              P(ln1_b), P(bo), P(ln2_g), P(ln2_b), P(w1), P(w1T), P(b1), P(w2), P(w2T), P(b2), *(P(t) for t in grads),
+              P(ln1_b), P(bo), P(ln2_g), P(ln2_b), P(w1), P(w1T), P(b1), P(w2), P(w2T), P(b2), *gp,
               P(dkq), P(dvoT), _cl(rows), _ci(rows_per_image), _ci(mlp), _cf(eps), P(ws), S())
     return dx, dkq, dvoT
+
+
+def decoder_layer_bwd_partial_floats(rows, rows_per_image, mlp):
+    return _lib.lib().dh_decoder_layer_bwd_workspace_size(_cl(rows), rows_per_image, mlp) // 4
+
+
+def decoder_stack_bwd_finalize(partials, rows, rows_per_image, mlp, grads0, grad_stride, dkq, dvoT):
+    """one launch for the parameter gradients of all layers of a decoder stack: partials [depth, floats], grads0 = the nine
+    gradient tensors of layer 0 (layer l's sit grad_stride floats further), dkq / dvoT [depth, images, 32, 32]"""
+    _call("dh_decoder_stack_bwd_finalize", P(partials), _ci(partials.shape[0]), _cl(rows), _ci(rows_per_image), _ci(mlp),
+          *(P(t) for t in grads0), _cl(grad_stride), P(dkq), P(dvoT), S())
 
 
 def encoder_supported(n, heads, dim_head, mlp):

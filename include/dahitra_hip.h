@@ -318,6 +318,12 @@ int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, const void* kq
                          const void* w2T, const float* b2, float* dw1, float* dw2, float* db1, float* db2, float* dbo,
                          float* dln1_g, float* dln1_b, float* dln2_g, float* dln2_b, float* dkq, float* dvoT, long rows,
                          int rows_per_image, int mlp, float eps, void* workspace, void* stream);
+/* dh_decoder_layer_bwd with dw1 == NULL leaves its per-workgroup partials in `workspace`; this sums the partials of the `depth`
+ * layers of one decoder stack (same shapes; layer l's workspace at + l * dh_decoder_layer_bwd_workspace_size bytes, its gradients
+ * at + l * grad_stride floats from layer 0's, its dkq / dvoT at + l * images * 1024 floats) in ONE launch. */
+int dh_decoder_stack_bwd_finalize(const void* workspace, int depth, long rows, int rows_per_image, int mlp, float* dw1, float* dw2,
+                                  float* db1, float* db2, float* dbo, float* dln1_g, float* dln1_b, float* dln2_g, float* dln2_b,
+                                  long grad_stride, float* dkq, float* dvoT, void* stream);
 long dh_decoder_layer_bwd_workspace_size(long rows, int rows_per_image, int mlp);
 
 /* ---- loss, mask, optimizer (models/losses.py:106-196; trainer.py:39-40,170) ------------------- */
