@@ -10,6 +10,9 @@ int dh_conv1x1_gemm_launch(const ConvArgs& a, hipStream_t st);
 // wave-specialised persistent form of the 3x3 stride-1 convolutions with >= 128 input channels (conv_ws.hip)
 bool dh_conv_ws_eligible(const ConvArgs& a, int ks, int stride, int dtype);
 int dh_conv_ws_launch(const ConvArgs& a, hipStream_t st);
+// 16x32-pixel tiles with 64-channel stages for the >= 128-channel 3x3 stride-1 convolutions (conv_pair.hip)
+bool dh_conv_pair_eligible(const ConvArgs& a, int ks, int stride, int dtype);
+int dh_conv_pair_launch(const ConvArgs& a, hipStream_t st);
 // persistent weights-resident form of the 64 -> 64 channel 3x3 convolutions (conv64.hip)
 bool dh_conv64_eligible(const ConvArgs& a, int ks, int stride, int dtype);
 int dh_conv64_launch(const ConvArgs& a, hipStream_t st);
@@ -58,6 +61,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dh_conv1x1_gemm_eligible(a, ks, stride, dtype)) return dh_conv1x1_gemm_launch(a, st);
     if (dh_conv_ws_eligible(a, ks, stride, dtype)) return dh_conv_ws_launch(a, st);
+    if (dh_conv_pair_eligible(a, ks, stride, dtype)) return dh_conv_pair_launch(a, st);
     if (dh_conv64_eligible(a, ks, stride, dtype)) return dh_conv64_launch(a, st);
     if (dtype == DH_DTYPE_BF16) return dh_conv_launch_bf16(a, ks, stride, st);
     return dh_conv_launch_f32(a, ks, stride, st);
