@@ -265,7 +265,7 @@ bool dh_conv64_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     // path) would be needed to bring this layer to its 13 us of HBM time.
     static const bool off = getenv("DAHITRA_CONV64") == nullptr;
     if (off || dtype != DH_DTYPE_BF16 || ks != 3 || stride != 1 || a.rw != 2 || a.dil != 1 || a.pad != 1) return false;
-    if (a.Cin != 64 || a.CoutPad != 64 || a.Cout % 8 || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride) return false;
+    if (a.Cin != 64 || a.CoutPad != 64 || a.Cout % 8 || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride || a.w_cm) return false;
     if (a.act == DH_ACT_GELU || a.npix != a.OH * a.OW || a.in_npix != a.H * a.W || a.OH != a.H || a.OW != a.W) return false;
     if (a.in_scale && a.in_groups > 2) return false;
     return (long)a.N * a.tilesX * a.tilesY >= 1024;          // enough tiles per persistent workgroup to amortise the weight staging

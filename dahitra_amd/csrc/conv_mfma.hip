@@ -23,7 +23,8 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
                              int OH, int OW, int Cout, int CoutPad, int ks, int stride, int pad, int act,
                              int npix_valid, long w_image_stride, void* y_preact, int dilation, const void* gate_out,
                              const void* gate_y, const float* gate_mean, const float* gate_invstd, int gate_groups,
-                             const float* in_scale, const float* in_shift, int in_groups, int phase_mode, void* stream) {
+                             const float* in_scale, const float* in_shift, int in_groups, int phase_mode, int w_chunk_major,
+                             void* stream) {
     const int esz = dtype == DH_DTYPE_BF16 ? 2 : 4;
     DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "conv2d_fwd: bad dtype %d", dtype);
     DH_REQUIRE((Cin * esz) % 64 == 0, "conv2d_fwd: Cin=%d must be a multiple of %d", Cin, 64 / esz);
@@ -47,6 +48,8 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
                              "conv2d_fwd: BatchNorm-on-load needs in_shift and N %% in_groups == 0");
     a.phase_mode = phase_mode;
     a.y_nchw = nullptr;
+    a.w_cm = w_chunk_major ? 1 : 0;
+    DH_REQUIRE(!w_chunk_major || (ks == 3 && w_image_stride == 0 && !phase_mode), "conv2d_fwd: chunk-major weights are packed for the 3x3 layers only");
     static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
     a.no_xcd_remap = no_remap;
     if (phase_mode) {
@@ -69,8 +72,8 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
 
 // The class head (3x3, pad 1, <= 16 classes) with fp32 NCHW logits written by the convolution itself: see ConvArgs::y_nchw.
 extern "C" int dh_conv3x3_head_fwd(int dtype, const void* x, const void* w_packed, const float* bias, int N, int H, int W, int Cin,
-                                   int Cout, const float* in_scale, const float* in_shift, int in_groups, float* logits_nchw,
-                                   void* stream) {
+                                   int Cout, const float* in_scale, const float* in_shift, int in_groups, int w_chunk_major,
+                                   float* logits_nchw, void* stream) {
     const int esz = dtype == DH_DTYPE_BF16 ? 2 : 4;
     DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "conv3x3_head_fwd: bad dtype %d", dtype);
     DH_REQUIRE((Cin * esz) % 64 == 0 && Cout >= 1 && Cout <= 16 && logits_nchw && N > 0 && H > 0 && W > 0,
@@ -85,6 +88,7 @@ extern "C" int dh_conv3x3_head_fwd(int dtype, const void* x, const void* w_packe
     static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
     a.no_xcd_remap = no_remap;
     a.y_nchw = logits_nchw;
+    a.w_cm = w_chunk_major ? 1 : 0;
     a.rw = pick_rw(N, H, W, Cin, 3, 1);
     a.tilesX = dh_cdiv(W, TW); a.tilesY = dh_cdiv(H, 4 * a.rw);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

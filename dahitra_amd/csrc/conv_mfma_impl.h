@@ -88,6 +88,9 @@ struct ConvArgs {
     // class head (NT = 16 instantiations only): the Cout real channels (+ bias) are written as fp32 NCHW logits
     // [N][Cout][OH][OW] straight from the accumulators -- the reference's output layout -- and nothing goes to y
     float* y_nchw;
+    // weights CHUNK-MAJOR: [Cin / CK][taps][CoutPad][CK] (CK = one 64-byte chunk) instead of [taps][CoutPad][Cin] -- the
+    // staging of a chunk then reads whole cache lines (dh_pack_weights_multi, dtype | 0x100)
+    int w_cm;
 };
 
 namespace {
@@ -193,11 +196,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     // the output channel stays -- one per-lane offset plus a uniform step
     static_assert(64 % NT == 0, "weight staging assumes NT divides 64");
     const int wrow = tid >> 2;
-    const unsigned woff0 = (unsigned)(((wrow / NT) * p.CoutPad + co0 + (wrow % NT)) * p.Cin) * (unsigned)sizeof(T) + (tid & 3) * 16;
-    const unsigned wstep = (unsigned)((64 / NT) * p.CoutPad * p.Cin) * (unsigned)sizeof(T);
+    const unsigned wrowb = p.w_cm ? 64u : (unsigned)p.Cin * (unsigned)sizeof(T);          // bytes per staged weight row in memory
+    const unsigned woff0 = (unsigned)((wrow / NT) * p.CoutPad + co0 + (wrow % NT)) * wrowb + (tid & 3) * 16;
+    const unsigned wstep = (unsigned)((64 / NT) * p.CoutPad) * wrowb;
+    const size_t wchunk = p.w_cm ? (size_t)TAPS * p.CoutPad * 64 / CK : sizeof(T);         // bytes per channel of chunk advance
     auto fetch = [&](int c0) {
         const unsigned char* xb = xin + (size_t)c0 * sizeof(T);
-        const unsigned char* wb = wgt + (size_t)c0 * sizeof(T);
+        const unsigned char* wb = wgt + (size_t)c0 * wchunk;
         if constexpr (KS == 2) {
             if (p.phase_mode == 2) {       // chunk -> (phase, channel offset inside the phase's 32 channels)
                 if (c0 > 0 && (c0 & 31) == 0) set_hoff(c0 >> 5);

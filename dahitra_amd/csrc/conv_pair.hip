@@ -264,7 +264,7 @@ bool dh_conv_pair_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     // generic kernel's small independent workgroups, not a bigger tile, are what this chip rewards at these layer sizes.
     static const bool off = getenv("DAHITRA_CONV_PAIR") == nullptr;
     if (off || dtype != DH_DTYPE_BF16 || ks != 3 || stride != 1 || a.rw != 4 || a.dil != 1 || a.pad != 1) return false;
-    if (a.Cin % 64 || a.Cin < 128 || a.CoutPad % CP_NT || a.Cout % 8 || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride) return false;
+    if (a.Cin % 64 || a.Cin < 128 || a.CoutPad % CP_NT || a.Cout % 8 || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride || a.w_cm) return false;
     if (a.act == DH_ACT_GELU || a.npix != a.OH * a.OW || a.in_npix != a.H * a.W || a.OH != a.H || a.OW != a.W) return false;
     if ((a.tilesX & 1) || (a.in_scale && (size_t)2 * a.Cin * 4 > 8192)) return false;
     return true;

@@ -353,7 +353,7 @@ bool dh_conv_ws_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     // case where the same split wins (conv_wgrad_ws_kernel).
     static const bool off = getenv("DAHITRA_CONV_WS") == nullptr;
     if (off || dtype != DH_DTYPE_BF16 || ks != 3 || stride != 1 || a.rw != 4 || (a.dil != 1 && a.dil != 2)) return false;
-    if (a.Cin % 32 || a.Cin < 128 || a.CoutPad % WS_NT || a.Cout % 8 || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride) return false;
+    if (a.Cin % 32 || a.Cin < 128 || a.CoutPad % WS_NT || a.Cout % 8 || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride || a.w_cm) return false;
     if (a.act == DH_ACT_GELU || a.npix != a.OH * a.OW || a.in_npix != a.H * a.W || a.pad != a.dil || a.OH != a.H || a.OW != a.W) return false;
     if (a.in_scale && (a.dil != 1 || (size_t)a.in_groups * 2 * a.Cin * 4 > 6144)) return false;
     return true;

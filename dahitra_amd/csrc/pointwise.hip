@@ -644,15 +644,40 @@ struct PackJob {
     void* fwd;          // [taps][OPad][I] or null
     void* dgrad;        // [taps][IPad][OK] (flipped taps) or null
     int O, I, KS, OPad, IPad, OK;
-    int dtype;          // DH_DTYPE_*
+    int dtype;          // DH_DTYPE_* | 0x100: CHUNK-MAJOR destinations (see below)
     int first_block, nblocks;
 };
+// Chunk-major: [K / CK][taps][rows][CK] with CK = one 64-byte chunk of the reduction dimension (32 bf16 / 16 fp32 channels)
+// instead of [taps][rows][K].  The conv kernel stages one chunk of all taps and 64 rows at a time: in the row-major form that is a
+// 64-byte piece out of every 2 K-byte row, i.e. HALF of each 128-byte cache line -- the L2 served twice the weight bytes
+// (TCC_HIT + TCC_MISS of the layer3 conv: 7.7 M requests = 986 MB per launch = 14 TB/s, the same ~15 TB/s on every conv shape);
+// chunk-major makes the 4 KB of a (chunk, tap, 64 rows) block contiguous.
 template <typename T>
 __device__ __forceinline__ void pack_job(const PackJob& j, int lb) {
     const int taps = j.KS * j.KS;
     const long step = (long)j.nblocks * blockDim.x;
     T* fwd = reinterpret_cast<T*>(j.fwd);
     T* dgrad = reinterpret_cast<T*>(j.dgrad);
+    if (j.dtype & 0x100) {
+        constexpr int CK = 64 / (int)sizeof(T);
+        if (fwd)
+            for (long i = (long)lb * blockDim.x + threadIdx.x; i < (long)taps * j.OPad * j.I; i += step) {
+                const int cl = (int)(i % CK);
+                const int o = (int)((i / CK) % j.OPad);
+                const int tap = (int)((i / ((long)CK * j.OPad)) % taps);
+                const int ci = (int)(i / ((long)CK * j.OPad * taps)) * CK + cl;
+                stf(fwd + i, o < j.O ? j.w[((long)o * j.I + ci) * taps + tap] : 0.f);
+            }
+        if (dgrad)
+            for (long i = (long)lb * blockDim.x + threadIdx.x; i < (long)taps * j.IPad * j.OK; i += step) {
+                const int ol = (int)(i % CK);
+                const int ci = (int)((i / CK) % j.IPad);
+                const int tap = (int)((i / ((long)CK * j.IPad)) % taps);
+                const int o = (int)(i / ((long)CK * j.IPad * taps)) * CK + ol;
+                stf(dgrad + i, (ci < j.I && o < j.O) ? j.w[((long)o * j.I + ci) * taps + (taps - 1 - tap)] : 0.f);
+            }
+        return;
+    }
     if (fwd)
         for (long i = (long)lb * blockDim.x + threadIdx.x; i < (long)taps * j.OPad * j.I; i += step) {
             const int ci = (int)(i % j.I);
@@ -676,7 +701,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackJob* 
     }
     const PackJob j = jobs[lo];
     const int lb = blockIdx.x - j.first_block;
-    if (j.dtype == DH_DTYPE_BF16) pack_job<bf16>(j, lb); else pack_job<float>(j, lb);
+    if ((j.dtype & 0xff) == DH_DTYPE_BF16) pack_job<bf16>(j, lb); else pack_job<float>(j, lb);
 }
 
 // ---- column sums: out[c] (+)= sum_p x[p, c]  (bias gradients) --------------------------------

@@ -79,6 +79,10 @@ class Engine:
         self.fused_head_out = os.environ.get("DAHITRA_NO_FUSED_HEAD", "0") != "1"
         # one finalize launch for the parameter gradients of all layers of a fused decoder stack
         self.defer_dec_finalize = os.environ.get("DAHITRA_NO_DEFER_DEC_FINALIZE", "0") != "1"
+        # packed 3x3 weights chunk-major ([Cin / 32][tap][Cout][32]): the conv kernel's weight staging reads whole cache lines.
+        # Measured NEUTRAL at the step level (8001 vs 8013 pairs/s; layer3 conv 74.9 -> 72.2 us alone): halving the weight
+        # requests at the L2 does not move a kernel that is bound by the latency of its staging round trips.  Off by default.
+        self.chunk_major_weights = os.environ.get("DAHITRA_CM_WEIGHTS", "0") == "1"
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -144,7 +148,9 @@ class Engine:
                 # |token2 - token1|, which bf16 rounding would wipe out (csrc/tokens.hip header)
                 dt = torch.float32
             c = ops.chunk_channels(dt)
-            f, d = pack.add(self.p[key], dt, want_dgrad=self.need_grad, dgrad_inner=-(-O // c) * c)
+            # 3x3 weights in the chunk-major form (whole cache lines per staged chunk; consumed by ops.conv2d / conv3x3_head only)
+            cm = self.chunk_major_weights and len(shape) == 4 and shape[2] == 3 and shape[1] % c == 0
+            f, d = pack.add(self.p[key], dt, want_dgrad=self.need_grad, dgrad_inner=-(-O // c) * c, chunk_major=cm)
             pk[key] = Packed(f, d)
         return pack, pk, xstack
 

@@ -123,21 +123,29 @@ class PackPlan:
     def __init__(self, device):
         self.device, self.jobs, self.blocks, self.table, self.keep = device, [], 0, None, []
 
-    def add(self, w, dtype, want_fwd=True, want_dgrad=True, dgrad_inner=0, out_dgrad=None):
-        """same contract as pack_weight; returns the (persistent) fwd / dgrad buffers"""
+    def add(self, w, dtype, want_fwd=True, want_dgrad=True, dgrad_inner=0, out_dgrad=None, chunk_major=False):
+        """same contract as pack_weight; returns the (persistent) fwd / dgrad buffers.  chunk_major (3x3 weights, I and
+        dgrad_inner multiples of the 64-byte chunk): 4-D buffers [K / ck, taps, rows, ck] (conv2d recognises them by
+        their rank)"""
         if w.dim() == 2:
             (O, I), ks = w.shape, 1
         else:
             O, I, ks, _ = w.shape
         OPad, IPad, OK = pad16(O), pad16(I), max(O, dgrad_inner)
-        fwd = torch.empty(ks * ks, OPad, I, dtype=dtype, device=w.device) if want_fwd else None
-        dg = out_dgrad if out_dgrad is not None else \
-            (torch.empty(ks * ks, IPad, OK, dtype=dtype, device=w.device) if want_dgrad else None)
+        ck = chunk_channels(dtype)
+        if chunk_major:
+            assert ks == 3 and I % ck == 0 and OK % ck == 0 and out_dgrad is None
+            fwd = torch.empty(I // ck, ks * ks, OPad, ck, dtype=dtype, device=w.device) if want_fwd else None
+            dg = torch.empty(OK // ck, ks * ks, IPad, ck, dtype=dtype, device=w.device) if want_dgrad else None
+        else:
+            fwd = torch.empty(ks * ks, OPad, I, dtype=dtype, device=w.device) if want_fwd else None
+            dg = out_dgrad if out_dgrad is not None else \
+                (torch.empty(ks * ks, IPad, OK, dtype=dtype, device=w.device) if want_dgrad else None)
         n = max(fwd.numel() if fwd is not None else 0, dg.numel() if dg is not None else 0)
         nb = max(1, min(256, cdiv(n, 1024)))
         self.jobs.append(self._Job(w.data_ptr(), fwd.data_ptr() if fwd is not None else None,
-                                   dg.data_ptr() if dg is not None else None, O, I, ks, OPad, IPad, OK, _DT[dtype],
-                                   self.blocks, nb))
+                                   dg.data_ptr() if dg is not None else None, O, I, ks, OPad, IPad, OK,
+                                   _DT[dtype] | (0x100 if chunk_major else 0), self.blocks, nb))
         self.blocks += nb
         self.keep += [w, fwd, dg]
         return fwd, dg
@@ -321,7 +329,8 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     with _Prof(key, flops, _nb(x, y, wp, residual, pre)):
         _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
               _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
-              _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), *_bn_in_args(bn_in), _ci(0), S())
+              _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), *_bn_in_args(bn_in), _ci(0), _ci(int(wp.dim() == 4)),
+              S())
     out = [y]
     if want_stats:
         out.append(stats)
@@ -342,7 +351,7 @@ def conv3x3_head(x, wp, ncls, bias):
     key = "conv_mfma<%s,ks3,s1,nt16>" % ("bf16" if x.dtype == torch.bfloat16 else "f32")
     with _Prof(key, 2.0 * N * H * W * ncls * Cin * 9, _nb(x, out, wp)):
         _call("dh_conv3x3_head_fwd", _ci(dt(x)), P(x), P(wp), P(bias), _ci(N), _ci(H), _ci(W), _ci(Cin), _ci(ncls),
-              *_bn_in_args(bn_in), P(out), S())
+              *_bn_in_args(bn_in), _ci(int(wp.dim() == 4)), P(out), S())
     return out
 
 
@@ -363,7 +372,7 @@ def linear(x2d, wp, cout, bias=None, residual=None, act=ACT_NONE, want_preact=Fa
     pre = torch.empty_like(y) if want_preact else None
     _call("dh_conv2d_fwd", _ci(dt(x2d)), P(x2d), P(wp), P(y), P(bias), P(residual), _vp(0), _ci(images), _ci(Hh),
           _ci(16), _ci(Cin), _ci(Hh), _ci(16), _ci(cout), _ci(cpad), _ci(1), _ci(1), _ci(0), _ci(act), _ci(rpi),
-          _cl(w_image_stride), P(pre), _ci(1), *_gate_args(None), *_bn_in_args(None), _ci(0), S())
+          _cl(w_image_stride), P(pre), _ci(1), *_gate_args(None), *_bn_in_args(None), _ci(0), _ci(0), S())
     # note: with rows_per_image % 16 != 0 the image stride used by the kernel (Hh*16 rows) would differ
     # from rpi; callers guarantee rpi % 16 == 0 whenever images > 1.
     assert images == 1 or rpi % 16 == 0
@@ -438,7 +447,7 @@ def conv_up2_fwd(x, wfwd, bias4):
     with _Prof(key, 2.0 * N * 4 * H * W * 32 * Cin * 9, _nb(x, y, wfwd)):                       # algorithmic FLOPs
         _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wfwd), P(y), P(bias4), _vp(0), _vp(0), _ci(N), _ci(H), _ci(W), _ci(Cin),
               _ci(H), _ci(W), _ci(128), _ci(128), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0), _cl(0), _vp(0), _ci(1),
-              *_gate_args(None), *_bn_in_args(None), _ci(1), S())
+              *_gate_args(None), *_bn_in_args(None), _ci(1), _ci(0), S())
     return y
 
 
@@ -460,7 +469,7 @@ def conv3x3s2_dgrad(dy, wphase, cin, coarse_residual=None, alg_flops=0):
     with _Prof(key, alg_flops if alg_flops else 2.0 * N * OH * OW * Co * cin * 9, _nb(dy, dx, wphase, coarse_residual)):
         _call("dh_conv2d_fwd", _ci(dt(dy)), P(dy), P(wphase), P(dx), _vp(0), P(coarse_residual), _vp(0), _ci(N), _ci(OH),
               _ci(OW), _ci(Co), _ci(OH), _ci(OW), _ci(4 * cin), _ci(4 * cin), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0),
-              _cl(0), _vp(0), _ci(1), *_gate_args(None), *_bn_in_args(None), _ci(1), S())
+              _cl(0), _vp(0), _ci(1), *_gate_args(None), *_bn_in_args(None), _ci(1), _ci(0), S())
     return dx
 
 
@@ -474,7 +483,7 @@ def conv_up2_dgrad(dy, wdgrad, cin):
     with _Prof(key, 2.0 * N * H2 * W2 * 32 * cin * 9, _nb(dy, dx, wdgrad)):
         _call("dh_conv2d_fwd", _ci(dt(dy)), P(dy), P(wdgrad), P(dx), _vp(0), _vp(0), _vp(0), _ci(N), _ci(H), _ci(W), _ci(128),
               _ci(H), _ci(W), _ci(cin), _ci(cin), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0), _cl(0), _vp(0), _ci(1),
-              *_gate_args(None), *_bn_in_args(None), _ci(2), S())
+              *_gate_args(None), *_bn_in_args(None), _ci(2), _ci(0), S())
     return dx
 
 

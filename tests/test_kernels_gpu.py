@@ -292,6 +292,35 @@ def test_class_head_writes_nchw_logits_itself(ops, dtype, ncls, hw, lazy):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 20, 24, 64, 96, 1, 1), (64, 32, 32, 128, 128, 1, 1), (2, 24, 24, 64, 64, 2, 1), (2, 16, 16, 128, 64, 1, 2)])
+def test_chunk_major_packed_weights(ops, dtype, cfg):
+    """dh_pack_weights_multi with dtype | 0x100 + dh_conv2d_fwd(w_chunk_major): forward and data gradient equal the row-major
+    packs' results bit for bit (same products, same order) and the fp32 reference within tolerance"""
+    N, H, W, Cin, Cout, stride, dil = cfg
+    x = rnd((N, Cin, H, W), dtype, 31)
+    w = rnd((Cout, Cin, 3, 3), dtype, 32, scale=(9 * Cin) ** -0.5)
+    ck = ops.chunk_channels(dtype)
+    plan = ops.PackPlan(torch.device("cuda"))
+    wd = w.cuda()
+    fcm, dcm = plan.add(wd, dtype, dgrad_inner=-(-Cout // ck) * ck, chunk_major=True)
+    plan.run()
+    frm, drm = ops.pack_weight(wd, dtype, dgrad_inner=-(-Cout // ck) * ck)
+    assert fcm.dim() == 4 and fcm.shape == (Cin // ck, 9, frm.shape[1], ck)
+    xd = dev(nhwc(x), dtype)
+    pad = dil
+    y_cm = ops.conv2d(xd, fcm, Cout, 3, stride, pad, dilation=dil)
+    y_rm = ops.conv2d(xd, frm, Cout, 3, stride, pad, dilation=dil)
+    assert torch.equal(y_cm, y_rm)
+    close(nchw(y_cm), F.conv2d(x, w, None, stride, pad, dil), dtype, "conv, chunk-major weights")
+    if stride == 1 and Cout % ck == 0:
+        dy = rnd(tuple(nchw(y_cm).shape), dtype, 33)
+        dyd = dev(nhwc(dy), dtype)
+        g_cm = ops.conv2d(dyd, dcm, Cin, 3, 1, dil * 2 - pad, dilation=dil)
+        g_rm = ops.conv2d(dyd, drm, Cin, 3, 1, dil * 2 - pad, dilation=dil)
+        assert torch.equal(g_cm, g_rm)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_linear_rows_gelu_and_per_image_weights(ops, dtype):
     rows, cin, cout = 40, 32, 64        # rows not a multiple of 16 -> masked tail
     x = rnd((rows, cin), dtype, 11)
