@@ -191,8 +191,17 @@ __global__ void augment_pairs_u8_kernel(const unsigned char* __restrict__ a, con
 // per wave), the B operand (k = 8 g + e -> tap 4 g + e / 2, co = e & 1) is gathered straight from dY with one 4-byte
 // load per tap (lane group g = 3 and three quarters of g = 2 hold zeros).  A lane ends with 4 consecutive input channels of
 // one pixel, twice: 8-byte stores, 64 B per pixel.  HBM-bound: 16 B read (x9 from L1 / L2) + 64 B written per pixel.
+// GATE: the 32 output channels feed relu(BatchNorm(y)) (the classifier's TwoLayerConv2d, models/help_funcs.py:7-15): the ReLU
+// mask is recomputed from y (y * mscale + mshift > 0), the MASKED gradient is stored and the per-workgroup partial sums
+// (sum g, sum g * xhat) of that BatchNorm's backward are emitted, [2][32][gridDim.x] -- the separate reduction pass over (g, y)
+// (268 MB at the bench size) disappears (dh_bn_bwd_from_partials does the rest).  A workgroup stays inside one statistics group.
+template <bool GATE>
 __global__ __launch_bounds__(256) void head_dgrad3x3_mfma_kernel(const bf16* __restrict__ dy, const float* __restrict__ w_oihw,
-                                                                 bf16* __restrict__ dx, int N, int H, int W, int NC) {
+                                                                 bf16* __restrict__ dx, int N, int H, int W, int NC,
+                                                                 const bf16* __restrict__ gy, const float* __restrict__ mscale,
+                                                                 const float* __restrict__ mshift, const float* __restrict__ gmean,
+                                                                 const float* __restrict__ ginvstd, int groups,
+                                                                 float* __restrict__ partial) {
     const int lane = threadIdx.x & 63, pl = lane & 15, g = lane >> 4;
     // A fragments: row ci = s * 16 + pl, k = 8 g + e
     s16x8 wa[2];
@@ -208,10 +217,23 @@ __global__ __launch_bounds__(256) void head_dgrad3x3_mfma_kernel(const bf16* __r
         pk.u = make_uint4(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7]));
         wa[s] = pk.h;
     }
-    const long total = (long)N * H * W, groups = (total + 15) / 16;
-    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    for (long grp = wave0; grp < groups; grp += nwaves) {
-        const long px = grp * 16 + pl;
+    // workgroups [bg * gridDim.x / groups, ...) walk the pixels of statistics group bg (groups = 1 without GATE)
+    const int ng = GATE ? groups : 1, bpg = gridDim.x / ng, bg = blockIdx.x / bpg;
+    const long gpix = (long)N * H * W / ng, total = (bg + 1) * gpix, ngrp16 = (gpix + 15) / 16;
+    const long wave0 = ((long)(blockIdx.x - bg * bpg) * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)bpg * blockDim.x) >> 6;
+    float cs[2][4], ch_[2][4], cm[2][4], ci[2][4], s1[2][4], s2[2][4];
+    if constexpr (GATE) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = bg * 32 + s * 16 + g * 4 + j;
+                cs[s][j] = mscale[c]; ch_[s][j] = mshift[c]; cm[s][j] = gmean[c]; ci[s][j] = ginvstd[c];
+                s1[s][j] = s2[s][j] = 0.f;
+            }
+    }
+    for (long grp = wave0; grp < ngrp16; grp += nwaves) {
+        const long px = bg * gpix + grp * 16 + pl;
         const bool inb = px < total;
         const int x = (int)(px % W), y = (int)((px / W) % H);
         const long n = px / ((long)W * H);
@@ -230,9 +252,35 @@ __global__ __launch_bounds__(256) void head_dgrad3x3_mfma_kernel(const bf16* __r
         for (int s = 0; s < 2; ++s) {
             const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s], b.h, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             if (inb) {
-                const float r[4] = {d[0], d[1], d[2], d[3]};
+                float r[4] = {d[0], d[1], d[2], d[3]};
+                if constexpr (GATE) {
+                    float yv[4];
+                    ld4(gy + px * 32 + s * 16 + g * 4, yv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        r[j] = (yv[j] * cs[s][j] + ch_[s][j]) > 0.f ? r[j] : 0.f;
+                        s1[s][j] += r[j];
+                        s2[s][j] += r[j] * ((yv[j] - cm[s][j]) * ci[s][j]);
+                    }
+                }
                 st4(dx + px * 32 + s * 16 + g * 4, r);
             }
+        }
+    }
+    if constexpr (GATE) {
+        __shared__ float red[4][2][32];
+        const int wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = row16_sum(s1[s][j]), b = row16_sum(s2[s][j]);
+                if (pl == 0) { red[wv][0][s * 16 + g * 4 + j] = a; red[wv][1][s * 16 + g * 4 + j] = b; }
+            }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+            partial[((size_t)which * 32 + c) * gridDim.x + blockIdx.x] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
         }
     }
 }
@@ -799,8 +847,9 @@ extern "C" int dh_head_dgrad3x3(int dtype, const void* dy, int CP, const float* 
         const long groups = (n + 15) / 16;
         long g = (groups * 64 + 255) / 256;
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(head_dgrad3x3_mfma_kernel, dim3((int)g), dim3(256), 0, ST(stream), (const bf16*)dy, w_oihw, (bf16*)dx,
-                           N, H, W, NC);
+        hipLaunchKernelGGL(head_dgrad3x3_mfma_kernel<false>, dim3((int)g), dim3(256), 0, ST(stream), (const bf16*)dy, w_oihw, (bf16*)dx,
+                           N, H, W, NC, (const bf16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, 1, (float*)nullptr);
         DH_CHECK_LAUNCH("head_dgrad3x3");
         return 0;
     }
@@ -825,6 +874,27 @@ extern "C" int dh_head_dgrad3x3(int dtype, const void* dy, int CP, const float* 
         hipLaunchKernelGGL((head_dgrad3x3_kernel<float, 8>), dim3(grid), dim3(256), 0, ST(stream), (const float*)dy, w_oihw, (float*)dx, N, H, W, NC);
     }
     DH_CHECK_LAUNCH("head_dgrad3x3");
+    return 0;
+}
+// The gated form (see head_dgrad3x3_mfma_kernel<true>): bf16, n_class <= 2, dy one 16-byte piece per pixel.  g: masked
+// gradient [N][H][W][32]; partial: [2][32][dh_head_dgrad3x3_bn_blocks] for dh_bn_bwd_from_partials (ntiles = blocks).
+extern "C" int dh_head_dgrad3x3_bn_blocks(int N, int H, int W, int groups) {
+    if (groups < 1 || N % groups) return 0;
+    const long n16 = ((long)N * H * W / groups + 15) / 16;
+    long bpg = (n16 * 64 + 255) / 256;
+    const long cap = 2048 / groups;
+    if (bpg > cap) bpg = cap;
+    return (int)(bpg * groups);
+}
+extern "C" int dh_head_dgrad3x3_bn(const void* dy, const float* w_oihw, int NC, const void* y, const float* mask_scale,
+                                   const float* mask_shift, const float* mean, const float* invstd, int groups, void* g,
+                                   float* partial, int N, int H, int W, void* stream) {
+    DH_REQUIRE(NC >= 1 && NC <= 2 && y && mask_scale && mask_shift && mean && invstd && g && partial, "head_dgrad3x3_bn: bad arguments");
+    const int grid = dh_head_dgrad3x3_bn_blocks(N, H, W, groups);
+    DH_REQUIRE(grid > 0, "head_dgrad3x3_bn: %d images do not split into %d groups", N, groups);
+    hipLaunchKernelGGL(head_dgrad3x3_mfma_kernel<true>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dy, w_oihw, (bf16*)g, N, H, W,
+                       NC, (const bf16*)y, mask_scale, mask_shift, mean, invstd, groups, partial);
+    DH_CHECK_LAUNCH("head_dgrad3x3_bn");
     return 0;
 }
 extern "C" int dh_augment_pairs_u8(const unsigned char* a, const unsigned char* b, const unsigned char* l, const int* idx,

@@ -83,6 +83,10 @@ class Engine:
         # Measured NEUTRAL at the step level (8001 vs 8013 pairs/s; layer3 conv 74.9 -> 72.2 us alone): halving the weight
         # requests at the L2 does not move a kernel that is bound by the latency of its staging round trips.  Off by default.
         self.chunk_major_weights = os.environ.get("DAHITRA_CM_WEIGHTS", "0") == "1"
+        # class-head data gradient gated for the classifier's BatchNorm (mask + BN-backward sums in its epilogue).  Measured
+        # neutral (8020 vs 8027 pairs/s: the reduction pass it removes costs what the extra read of y costs the head kernel):
+        # off by default, DAHITRA_GATED_HEAD=1 turns it on.
+        self.gated_head_dgrad = os.environ.get("DAHITRA_GATED_HEAD", "0") == "1"
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -229,6 +233,8 @@ class Engine:
             return dx, dres
         # what an upstream data-gradient launch needs to gate for this layer (None: keep the two-pass backward)
         bwd.gate = (out if relu else None, y, mean, invstd, groups) if (self.fused_bn_bwd and cout % 16 == 0) else None
+        # what the class head's data gradient needs to gate itself for this layer (ReLU mask recomputed from y)
+        bwd.bn = (y, scale, shift, mean, invstd, groups) if (self.training and relu and not has_res) else None
         return out, bwd
 
     def conv_act(self, x, wkey, bkey, ks, pad, act, cpad_grad=False):
@@ -744,7 +750,7 @@ class Engine:
         small = 8 if (self.dtype == torch.bfloat16 or ncls > 4) else 4          # channels of one 16-byte piece
         direct = h.shape[-1] == 32 and ncls <= small
 
-        def bwd(dl_nchw, next_gate=None):
+        def bwd(dl_nchw, next_gate=None, head_bn=None):
             if direct and next_gate is None:
                 # n_class (2..5) real channels: keep dlogits at ONE 16-byte piece per pixel instead of padding them to
                 # a 32-channel K-chunk (4x the bytes, written and read twice), and take the data gradient with the
@@ -754,6 +760,9 @@ class Engine:
                 tmp = torch.empty(small, dtype=torch.float32, device=h.device)
                 ops.colsum(dl.view(-1, small), tmp)
                 ops.reduce_rows(tmp, 1, ncls, self.g[bkey], accumulate=True)
+                if head_bn is not None and self.gated_head_dgrad and self.dtype == torch.bfloat16 and ncls <= 2:
+                    # the BatchNorm behind these 32 channels: mask + reduction here, only its apply pass remains
+                    return Gated(*ops.head_dgrad3x3_bn(dl, self.p[wkey], ncls, *head_bn))
                 return ops.head_dgrad3x3(dl, self.p[wkey], ncls)
             dl = ops.nchw_to_nhwc(dl_nchw, self.dtype, cpad=ck)          # channels zero-padded to one K-chunk
             ops.conv2d_wgrad(h, dl, self.g[wkey], 3, 1, 1, accumulate=True, use_tr=self.use_tr, cout_real=ncls)
@@ -800,7 +809,7 @@ class Engine:
 
         def bwd_first(dl):
             """head, decoder, tokens, conv_pred, layer3: everything whose parameters sit behind layer2 in the arena"""
-            dh = b_out(dl, next_gate=b_c0.gate)
+            dh = b_out(dl, next_gate=b_c0.gate, head_bn=getattr(b_c0, "bn", None))
             dupd, _ = b_c0(dh)
             dec_g = torch.empty_like(dec4)
             ops.absdiff_upsample4_bwd_into(dec4[:B], dec4[B:], dupd, dec_g[:B], dec_g[B:])

@@ -717,6 +717,20 @@ def head_dgrad3x3(dy, w_oihw, ncls):
     return dx
 
 
+def head_dgrad3x3_bn(dy, w_oihw, ncls, y, scale, shift, mean, invstd, groups):
+    """head_dgrad3x3 gated for the BatchNorm + ReLU behind its 32 output channels: returns (g masked [N,H,W,32], partials
+    [2, 32, blocks]) for bn_bwd_from_partials"""
+    N, H, W, CP = dy.shape
+    assert w_oihw.shape == (ncls, 32, 3, 3) and dy.dtype == torch.bfloat16 and CP == 8 and ncls <= 2 and y.shape == (N, H, W, 32)
+    g = torch.empty(N, H, W, 32, dtype=dy.dtype, device=dy.device)
+    nb = _lib.lib().dh_head_dgrad3x3_bn_blocks(N, H, W, groups)
+    partial = torch.empty(2, 32, nb, dtype=torch.float32, device=dy.device)
+    with _Prof("bn_bwd", 0, _nb(dy, y, g)):
+        _call("dh_head_dgrad3x3_bn", P(dy), P(w_oihw), _ci(ncls), P(y), P(scale), P(shift), P(mean), P(invstd), _ci(groups), P(g),
+              P(partial), _ci(N), _ci(H), _ci(W), S())
+    return g, partial
+
+
 def nhwc_to_nchw(x):
     N, H, W, C = x.shape
     y = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)

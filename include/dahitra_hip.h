@@ -216,6 +216,13 @@ int dh_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, long H
  * dx [N][H][W][32] */
 int dh_head_dgrad3x3(int dtype, const void* dy, int CP, const float* w_oihw, int NC, void* dx, int N, int H, int W,
                      void* stream);
+/* The same data gradient GATED for the BatchNorm + ReLU behind the 32 channels (classifier[0..2], models/help_funcs.py:7-15; bf16,
+ * n_class <= 2): g = gradient * (y * mask_scale + mask_shift > 0) and the per-workgroup partials [2][32][blocks] (sum g,
+ * sum g * xhat) for dh_bn_bwd_from_partials -- that BatchNorm's reduction pass disappears. */
+int dh_head_dgrad3x3_bn_blocks(int N, int H, int W, int groups);
+int dh_head_dgrad3x3_bn(const void* dy, const float* w_oihw, int NC, const void* y, const float* mask_scale, const float* mask_shift,
+                        const float* mean, const float* invstd, int groups, void* g, float* partial, int N, int H, int W,
+                        void* stream);
 int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream);
 int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, void* dst, int Cd, int dc0, int Cn, long P, void* stream);
 int dh_add(int dtype, const void* a, const void* b, void* y, long n, void* stream);

@@ -567,6 +567,30 @@ def test_lazy_batchnorm_activations_equal_materialised(name, dtype, monkeypatch)
         assert torch.equal(res["0"][1][k], g), k
 
 
+def test_opt_in_paths_equal_default_paths_bf16(monkeypatch):
+    """the measured-neutral paths kept behind switches stay correct: chunk-major packed 3x3 weights (bit-identical products) and
+    the class-head data gradient gated for the classifier's BatchNorm (sums taken in its epilogue), bf16 train step"""
+    from dahitra_amd.models import losses
+    a, b, lab = O.synthetic_batch(2, 64, seed=71)
+    res = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("DAHITRA_CM_WEIGHTS", on)
+        monkeypatch.setenv("DAHITRA_GATED_HEAD", on)
+        net = make_net("base_transformer_pos_s4", "bf16").train()
+        assert net._engine.chunk_major_weights == (on == "1") and net._engine.gated_head_dgrad == (on == "1")
+        y = net(a.cuda(), b.cuda())
+        losses.focal_loss(y, lab.cuda()).backward()
+        res[on] = (y.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert torch.equal(res["0"][0], res["1"][0])                 # forward: same products in the same order
+    for k, g in res["0"][1].items():
+        h = res["1"][1][k]
+        if float(g.abs().max()) < 1e-10:             # a gradient that cancels exactly (last decoder bias in |x1 - x2|)
+            assert float(h.abs().max()) < 1e-8, k
+            continue
+        cos = float((g * h).sum() / (g.norm() * h.norm() + 1e-30))
+        assert cos >= 0.9995 and float((g - h).abs().max()) <= 3e-2 * float(g.abs().max()) + 1e-9, (k, cos)
+
+
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
 def test_phase_convolution_paths_equal_reference_paths(name, monkeypatch):
     """conv_pred as 2x2 phase convs and the stride-2 data gradient as output-parity phases (both: pre-summed / re-ordered
