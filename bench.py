@@ -347,6 +347,7 @@ def main():
                                       else "fwd+focal+bwd+allreduce+AdamW"),
                        "net_G": args.net, "global_batch": args.batch * world, "img_size": args.img,
                        "parallelism": "dp%d" % world, "final_loss": round(final, 6), "hip_graph": bool(use_graph),
+                       "attn_dtype": "fp8" if os.environ.get("DAHITRA_ATTN_FP8", "0") == "1" and args.dtype == "bf16" else args.dtype,
                        "step_tflops": round(pairs / dt * GFLOP_256[args.net] * (args.img / 256.0) ** 2 / 1e3, 2)
                        if args.net in GFLOP_256 and not args.fwd_only else None},
             "step_ms": step_ms,
