@@ -87,6 +87,13 @@ class Engine:
         # neutral (8020 vs 8027 pairs/s: the reduction pass it removes costs what the extra read of y costs the head kernel):
         # off by default, DAHITRA_GATED_HEAD=1 turns it on.
         self.gated_head_dgrad = os.environ.get("DAHITRA_GATED_HEAD", "0") == "1"
+        # a second stream for the classifier's weight gradient, next to the low-occupancy token-side backward (bf16 training).
+        # Measured: the launch does overlap the encoder's backward in the graph (rocprofv3 trace: 120 us next to encoder_bwd /
+        # encoder_wgrad / tok_bwd instead of 63 us alone), but those kernels slow down by 28 us and the forked graph costs more
+        # than the rest: 7950 vs 8010 pairs/s over five interleaved 150-step runs.  Off by default (DAHITRA_SIDE_STREAM=1).
+        self.use_side = os.environ.get("DAHITRA_SIDE_STREAM", "0") == "1"
+        self.side = None
+        self._deferred_wgrad = None
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
@@ -185,7 +192,7 @@ class Engine:
                        out_hw=(H, W), alg_flops=flops, dilation=dilation, gate=gate)
         return Gated(*r) if gate is not None else r
 
-    def conv_bn(self, x, wkey, bnkey, ks, stride, pad, groups, relu, residual=None, dilation=1, lazy=False):
+    def conv_bn(self, x, wkey, bnkey, ks, stride, pad, groups, relu, residual=None, dilation=1, lazy=False, side_wgrad=False):
         """conv + BatchNorm (+ residual) (+ ReLU).  x may be an ops.BnInput (the previous layer's lazy output).
         lazy=True (train mode, ReLU, no residual; the ONLY consumer must be a 3x3 stride-1 convolution and its weight
         gradient): the normalised activation is never written -- the call returns an ops.BnInput (pre-BN conv output +
@@ -226,8 +233,14 @@ class Engine:
                 r = ops.bn_bwd(dout, out if relu else None, y, mean, invstd, gamma, self.g[bnkey + ".weight"],
                                self.g[bnkey + ".bias"], groups, accumulate=True, want_dres=has_res)
                 dy, dres = r if has_res else (r, None)
-            ops.conv2d_wgrad(x, dy, self.g[wkey], ks, stride, pad, accumulate=True, use_tr=self.use_tr,
-                             dilation=dilation)
+            if side_wgrad and self.side is not None:
+                # Deferred to the side stream: nothing until the batched split-K reduce needs this weight gradient.  It is
+                # launched (run_deferred_wgrad) when the main stream reaches the token encoder's backward -- one workgroup per
+                # image, 3/4 of the CUs idle for ~150 us; forked right here it only competed with the data gradient below.
+                self._deferred_wgrad = (x, dy, wkey, ks, stride, pad, dilation)
+            else:
+                ops.conv2d_wgrad(x, dy, self.g[wkey], ks, stride, pad, accumulate=True, use_tr=self.use_tr,
+                                 dilation=dilation)
             dx = self.conv_dgrad(dy, wkey, ks, stride, pad, x.shape, residual=dx_res, dilation=dilation,
                                  gate=next_gate, coarse=coarse_dx) if need_dx else None
             return dx, dres
@@ -678,6 +691,8 @@ class Engine:
     # ---- whole nets ------------------------------------------------------------------------------
     def forward(self, x1, x2, training, need_grad):
         self.training, self.need_grad = training, need_grad
+        if need_grad and self.use_side and self.side is None and self.dtype == torch.bfloat16:
+            self.side = ops.SideStream(x1.device)
         self._pack_all()
         if self.cfg["kind"] == "bit":
             logits, bwd = self._bit(x1, x2)
@@ -705,6 +720,7 @@ class Engine:
             self._wgrad_plan = ops.WgradPlan(dlogits_nchw.device)
         with self._wgrad_plan as plan:      # the conv layers' split-K reduces: one launch at the end of the pass
             bwd(dlogits_nchw)
+            self._side_join()
             plan.run()
 
     # A backward pass in TWO parts (data-parallel overlap, dahitra_amd/graph.py): after backward_first() every gradient
@@ -722,10 +738,24 @@ class Engine:
         self._wgrad_plan.__enter__()
         try:
             self._split_state = (split[1], split[0](dlogits_nchw))
+            self._side_join()
             self._wgrad_plan.run()
         except BaseException:
             self._wgrad_plan.__exit__()
             raise
+
+    def run_deferred_wgrad(self):
+        d, self._deferred_wgrad = self._deferred_wgrad, None
+        if d is None:
+            return
+        x, dy, wkey, ks, stride, pad, dilation = d
+        with self.side.fork(x.y if isinstance(x, ops.BnInput) else x, dy):
+            ops.conv2d_wgrad(x, dy, self.g[wkey], ks, stride, pad, accumulate=True, use_tr=self.use_tr, dilation=dilation)
+
+    def _side_join(self):
+        if self.side is not None:
+            self.run_deferred_wgrad()
+            self.side.join()
 
     def backward_second(self):
         second, state = self._split_state
@@ -802,7 +832,7 @@ class Engine:
                                   "transformer_decoder", cfg["dec_depth"], BIT_HEADS, cfg["dec_dim_head"], L)
         dec4 = dec.view(S2, fh, fw, DIM)
         upd = ops.absdiff_upsample4(dec4[:B], dec4[B:])
-        h, b_c0 = self.conv_bn(upd, "classifier.0.weight", "classifier.1", 3, 1, 1, 1, True, lazy=True)
+        h, b_c0 = self.conv_bn(upd, "classifier.0.weight", "classifier.1", 3, 1, 1, 1, True, lazy=True, side_wgrad=True)
         logits, b_out = self._head_out(h, "classifier.3.weight", "classifier.3.bias")
         if not self.need_grad:
             return logits, None
@@ -814,6 +844,8 @@ class Engine:
             dec_g = torch.empty_like(dec4)
             ops.absdiff_upsample4_bwd_into(dec4[:B], dec4[B:], dupd, dec_g[:B], dec_g[B:])
             dfeat = b_dec(dec_g.view(S2 * hw, DIM))                    # also fills dtok
+            if self.side is not None:
+                self.run_deferred_wgrad()            # the classifier's weight gradient, next to the encoder's backward
             dtok_cat = b_enc(dtok)
             dfeat4 = dfeat.view(S2, fh, fw, DIM)
             ops.tokenizer_bwd(feat, wa, tsaved, dtok_cat, dfeat4, self.g["conv_a.weight"], self.g["pos_embedding"],

@@ -237,6 +237,38 @@ class WgradPlan:
 _WGRAD_PLAN = None
 
 
+class SideStream:
+    """A second HIP stream for launches that nothing downstream of the current kernel chain waits for (a weight gradient
+    next to the low-occupancy token-side backward kernels).  fork(): the side stream waits for everything enqueued so far
+    on the current stream; launches inside `with side:` go to it; join(): the current stream waits for the side stream.
+    Works under HIP-graph capture (the fork / join become graph dependencies).  Tensors handed to side launches are kept
+    alive until the join (the caching allocator must not give their memory to a later main-stream launch)."""
+
+    def __init__(self, device):
+        self.stream, self.keep, self.active, self._ctx = torch.cuda.Stream(device=device), [], False, None
+
+    def fork(self, *tensors):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.keep += [t for t in tensors if t is not None]
+        self.active = True
+        return self
+
+    def __enter__(self):
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self._ctx.__exit__(*exc)
+        self._ctx = None
+        return False
+
+    def join(self):
+        if self.active:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.keep, self.active = [], False
+
+
 # ---- convolution / linear ------------------------------------------------------------------------
 PROFILE = None       # set to {} by bench.py to collect (events, algorithmic flops, algorithmic bytes) per launch
 
