@@ -665,6 +665,8 @@ def bn_apply(x, scale, shift, groups=1, act=ACT_NONE, residual=None):
 
 _BN_SYNC = {}
 BN_BWD_PERSIST = os.environ.get("DAHITRA_NO_PERSIST_BN", "0") != "1"      # True: where faster; "force": wherever supported (tests)
+if os.environ.get("DAHITRA_PERSIST_BN_FORCE", "0") == "1":
+    BN_BWD_PERSIST = "force"
 
 
 def bn_sync_words(device):
