@@ -339,8 +339,10 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
             const int a_co = WCI ? 2 * cig * 16 : cw * 16, b_ci = WCI ? wv * 16 : cig * IT;
             const unsigned char* a_base = TR ? dyt + (kq * KPW + c0 + (pl >> 2)) * DP + (a_co + (pl & 3) * 4) * 2
                                              : dyt + (kq * KPW + c0) * DP + (a_co + pl) * 2;
-            const unsigned char* b_base = ((TR && STRIDE == 1)
-                ? halo + (kq * (KPW / TW) * STRIDE * HWD + c0 * STRIDE + (pl >> 2)) * XP + ((pl & 3) * 4) * 2
+            // (stride 2: the four pixels of a transpose read are every other halo pixel -- each lane supplies its own address,
+            // so the read serves any stride; the former eight ds_read_u16 per fragment made the stride-2 launches LDS-issue bound)
+            const unsigned char* b_base = (TR
+                ? halo + (kq * (KPW / TW) * STRIDE * HWD + (c0 + (pl >> 2)) * STRIDE) * XP + ((pl & 3) * 4) * 2
                 : halo + (kq * (KPW / TW) * STRIDE * HWD + c0 * STRIDE) * XP + pl * 2) + b_ci * 2;
 #pragma unroll
             for (int kk = 0; kk < KPW; kk += 32) {
@@ -361,11 +363,11 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
                 };
                 auto load_b = [&](int hp, int cofs) {  // x fragment at halo pixel offset hp, ci sub-tile `cofs` bytes further
                     F8 b;
-                    if constexpr (TR && STRIDE == 1) {
+                    if constexpr (TR) {
                         b.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (__attribute__((address_space(3))) s16x4*)(b_base + hp * XP + cofs));
                         b.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(b_base + (hp + HWD) * XP + cofs));
+                            (__attribute__((address_space(3))) s16x4*)(b_base + (hp + STRIDE * HWD) * XP + cofs));
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
