@@ -1054,7 +1054,9 @@ extern "C" int dh_colsum(int dtype, const void* x, long P, int C, float* out, in
     DH_REQUIRE(C >= 1 && C <= 256, "colsum: C=%d out of range", C);
     const long rows_per_pass = 256 / (C >= 4 && (C & 3) == 0 ? C / 4 : C);       // rows one workgroup covers per step
     long want = (P + rows_per_pass * 8 - 1) / (rows_per_pass * 8);               // >= 8 steps per workgroup
-    const int grid = (int)(want < 64 ? 64 : (want > 1024 ? 1024 : want));
+    // at most one workgroup per CU: the second stage (reduce_partials, one workgroup for <= 32 channels) walks the partial
+    // rows as a latency chain -- 1024 rows cost it 9.5 us, 256 rows ~4 us, and the first stage streams at HBM rate either way
+    const int grid = (int)(want < 64 ? 64 : (want > 256 ? 256 : want));
     float* partial = reinterpret_cast<float*>(workspace);
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(colsum_partial_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)x, P, C, partial);
     else hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)x, P, C, partial);
