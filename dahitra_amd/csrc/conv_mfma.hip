@@ -7,15 +7,9 @@ int dh_conv_launch_f32(const ConvArgs& a, int ks, int stride, hipStream_t st);
 // K-deep GEMM form of the 1x1 / stride-1 convolutions with >= 64 input channels (conv1x1_gemm.hip)
 bool dh_conv1x1_gemm_eligible(const ConvArgs& a, int ks, int stride, int dtype);
 int dh_conv1x1_gemm_launch(const ConvArgs& a, hipStream_t st);
-// wave-specialised persistent form of the 3x3 stride-1 convolutions with >= 128 input channels (conv_ws.hip)
-bool dh_conv_ws_eligible(const ConvArgs& a, int ks, int stride, int dtype);
-int dh_conv_ws_launch(const ConvArgs& a, hipStream_t st);
-// 16x32-pixel tiles with 64-channel stages for the >= 128-channel 3x3 stride-1 convolutions (conv_pair.hip)
-bool dh_conv_pair_eligible(const ConvArgs& a, int ks, int stride, int dtype);
-int dh_conv_pair_launch(const ConvArgs& a, hipStream_t st);
-// persistent weights-resident form of the 64 -> 64 channel 3x3 convolutions (conv64.hip)
-bool dh_conv64_eligible(const ConvArgs& a, int ks, int stride, int dtype);
-int dh_conv64_launch(const ConvArgs& a, hipStream_t st);
+// 3x3 stride-1 convolutions with the weights resident in registers, persistent workgroups (conv_wreg.hip)
+bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype);
+int dh_conv_wreg_launch(const ConvArgs& a, hipStream_t st);
 
 // C ABI: see include/dahitra_hip.h
 extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const float* bias,
@@ -63,9 +57,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, 4 * a.rw);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dh_conv1x1_gemm_eligible(a, ks, stride, dtype)) return dh_conv1x1_gemm_launch(a, st);
-    if (dh_conv_ws_eligible(a, ks, stride, dtype)) return dh_conv_ws_launch(a, st);
-    if (dh_conv_pair_eligible(a, ks, stride, dtype)) return dh_conv_pair_launch(a, st);
-    if (dh_conv64_eligible(a, ks, stride, dtype)) return dh_conv64_launch(a, st);
+    if (dh_conv_wreg_eligible(a, ks, stride, dtype)) return dh_conv_wreg_launch(a, st);
     if (dtype == DH_DTYPE_BF16) return dh_conv_launch_bf16(a, ks, stride, st);
     return dh_conv_launch_f32(a, ks, stride, st);
 }

@@ -1,0 +1,438 @@
+// 3x3 / stride-1 / pad-1 NHWC convolution (bf16) with the WEIGHTS RESIDENT IN REGISTERS.
+//
+// The tap-oriented kernel (conv_mfma_impl.h) stages, per 32-channel chunk and per pixel tile, the weights of all nine taps
+// next to the haloed input: 36.9 KB of weights for 11.5 - 20.7 KB of pixels, i.e. 100 - 170 bytes through the L2 -> LDS fill
+// path per MFMA -- and that fill path, not the matrix pipe, bounds it (0.25 - 0.44 of the bf16 peak).
+// Here the roles are turned around.  A wavefront owns 16 * NSUB output channels for ALL input channels and keeps their
+// weights -- 9 taps x NCH chunks x NSUB fragments = 36 * NSUB * NCH registers per lane -- in the (512-entry, unified)
+// register file for the life of a PERSISTENT workgroup; the four wavefronts of a workgroup cover 64 * NSUB output channels
+// and walk through 8x16-pixel tiles.  Only the input halo travels: 11.5 KB per 32-channel chunk, 20 bytes per MFMA, by
+// direct-to-LDS loads (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of stages that runs
+// WR_D - 2 stages ahead of the matrix work behind counted vmcnt waits and ONE raw s_barrier per stage.  The A operand of
+// every MFMA is a register-resident weight fragment, the B operand a halo fragment read once from LDS and used by up to
+// 3 * NSUB MFMAs (the three kernel rows that land on that halo row).
+//
+// Same arithmetic as conv_mfma_kernel<bf16, 3, 1, 64, ...>: the same fragments, and every accumulator receives its products
+// in the same (chunk, kernel column, kernel row) order, so the results are bit-identical; same compact epilogue (+bias,
+// +residual, ReLU, BatchNorm partial sums in the [2][CoutPad][tiles] layout of dh_conv2d_fwd_num_tiles, LDS-transposed
+// 16-byte stores) and the same BatchNorm-apply + ReLU on load (INBN: applied in LDS by the lane whose load brought the piece).
+//
+// Reference: the 3x3 convolutions of models/resnet.py:24-73 (BasicBlock conv1 / conv2) and their data gradients.
+#include "conv_mfma_impl.h"
+
+namespace {
+
+constexpr int WR_TH = 8;                                   // tile rows (TW = 16 pixels wide)
+constexpr int WR_HH = WR_TH + 2, WR_HW = TW + 2;           // halo 10 x 18 pixels
+constexpr int WR_NPX = WR_HH * WR_HW;                      // 180
+constexpr int WR_NI = 3;                                   // 1-KiB load instructions per wave and chunk image: 12 KiB >= 180 * 64 B
+constexpr int WR_IMG = WR_NI * 4 * 1024;                   // bytes of one chunk image in the ring
+constexpr int WR_D = 4;                                    // ring depth in stages; loads run WR_D - 2 stages ahead
+
+__device__ __attribute__((aligned(256))) unsigned int wr_zero[64];      // source of every padding / out-of-stream piece
+
+// One direct-to-LDS load instruction: lane l's 16 bytes at gsrc land at LDS byte address lds_wave_base + 16 l.  Inline asm,
+// not __builtin_amdgcn_global_load_lds: hipcc tracks a builtin LDS-DMA as a pending LDS write and puts s_waitcnt vmcnt(0) in
+// front of the next ds_read of the (may-alias) dynamic LDS array -- which drains the run-ahead ring at every stage.  The
+// loads are therefore invisible to the compiler's counters and are waited for by the counted vmcnt in the stream loop
+// (cdna_hip_programming.md 5.7: M0 is written in the statement that reads it and restored).
+__device__ __forceinline__ void wr_glds16(const unsigned char* gsrc, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_wave_base) : "memory");
+}
+__device__ __forceinline__ unsigned wr_lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+// hide a loop-invariant value from the optimiser, so that what is derived from it is recomputed where it is used instead of
+// being hoisted into (scarce) registers for the life of the stream loop
+__device__ __forceinline__ int wr_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// halo pixel (hy, hx), 16-byte piece q of its 64-byte chunk row -> byte offset in a chunk image.  Pitch 64 with the piece
+// index XORed by bit 2 of the COLUMN: a ds_read_b128 of 16 consecutive columns is conflict-free in every 16-lane service
+// group (MI355X_MICROARCH.md, LDS table), and -- unlike the pixel-index swizzle of conv_mfma_impl.h -- the lane part of a
+// fragment address does not depend on the row, so a halo row is an immediate offset.
+__device__ __forceinline__ int wr_off(int hy, int hx, int q) { return (hy * WR_HW + hx) * 64 + ((q ^ (((hx >> 2) & 1) << 1)) << 4); }
+
+struct WrArgs {
+    ConvArgs c;
+    int ncb;          // output-channel blocks (Cout / (64 * NSUB))
+    int J;            // workgroups per output-channel block
+    int nunits;       // statistics units (= rows of the stats buffer): `subt` vertically adjacent tiles each
+    int subt;         // 8-row tiles per unit: 1, or 2 where dh_conv2d_fwd_num_tiles counts 16-row tiles
+    int tilesX, unitsY;
+};
+
+struct WrTile {       // one 8x16 tile of the stream: per-lane source offsets of its WR_NI pieces (one chunk image)
+    const unsigned char* img;      // image base (uniform)
+    unsigned o0, o1, o2;           // byte offset of this lane's piece k at chunk 0, ~0u: padding (scalars, not an array: the
+                                   // struct must stay in registers)
+    int n, oy0, ox0;
+    __device__ __forceinline__ unsigned off(int i) const { return i == 0 ? o0 : (i == 1 ? o1 : o2); }
+};
+static_assert(WR_NI == 3, "WrTile carries three piece offsets");
+
+template <int NSUB, int NCH, int CPS, bool INBN, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
+    static_assert(NCH % CPS == 0, "chunks per stage must divide the chunk count");
+    constexpr int SPT = NCH / CPS;                         // stages per tile
+    constexpr int STAGE = CPS * WR_IMG;
+    constexpr int NCO = 64 * NSUB;                         // output channels per workgroup
+    constexpr int TPITCH = NCO * 2 + 16;                   // transposed output tile: bytes per pixel
+    constexpr int PPR = NCO * 2 / 16;                      // 16-byte pieces per output pixel
+    const ConvArgs& p = a.c;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;                            // [WR_D][STAGE]
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(wr_lds_addr(smem));
+    unsigned char* otile = smem + WR_D * STAGE;            // [128 px][TPITCH]
+    float* bnp = reinterpret_cast<float*>(otile + WR_TH * TW * TPITCH);      // INBN: [in_groups][2][Cin]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g = lane >> 4;
+    // block -> (output-channel block, stream): the ncb workgroups that walk the SAME tiles sit on one XCD (dispatch is
+    // round-robin over the 8 XCDs: a speed assumption only), so the input is fetched from HBM once and then from that L2
+    const int b = blockIdx.x, xcd = b & 7, qb = b >> 3;
+    const int cb = qb % a.ncb, j0 = (qb / a.ncb) * 8 + xcd;
+    const int co_w = cb * NCO + wv * 16 * NSUB;            // first output channel of this wave
+    const int Cin = p.Cin;
+
+    // ---- this wave's weights: [sub][chunk][tap] fragments, 16 bytes per lane each, loaded once ----
+    s16x8 A[NSUB][NCH][9];
+    {
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    A[s][c][t] = *reinterpret_cast<const s16x8*>(
+                        wb + ((size_t)(t * p.CoutPad + co_w + s * 16 + pl) * Cin + c * 32 + g * 8) * 2);
+    }
+    if constexpr (INBN) {
+        for (int i = tid; i < p.in_groups * 2 * Cin; i += 256) {
+            const int gi = i / (2 * Cin), r = i - gi * 2 * Cin;
+            bnp[i] = r < Cin ? p.in_scale[gi * Cin + r] : p.in_shift[gi * Cin + r - Cin];
+        }
+    }
+    float bs[NSUB][4];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs[s][j] = p.bias ? p.bias[co_w + s * 16 + g * 4 + j] : 0.f;
+
+    // ---- per-lane constants of the staging: piece i = (k * 4 + wave) * 64 + lane of a chunk image ----
+    int hyx[WR_NI];        // (hy << 8) | hx, or -1 past the image;  logical piece in bits 16..17
+#pragma unroll
+    for (int k = 0; k < WR_NI; ++k) {
+        const int i = (k * 4 + wv) * 64 + lane, px = i >> 2, qs = i & 3;
+        const int hy = px / WR_HW, hx = px - hy * WR_HW;
+        hyx[k] = px < WR_NPX ? (((qs ^ (((hx >> 2) & 1) << 1)) << 16) | (hy << 8) | hx) : -1;
+    }
+    // fragment read offsets of this lane for the three kernel columns (the halo row is an immediate)
+    int lo[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) lo[kw] = wr_off(0, pl + kw, g);
+
+    const int K = (a.nunits > j0 ? (a.nunits - j0 + a.J - 1) / a.J : 0) * a.subt;      // tiles of this workgroup's stream
+    auto tile_desc = [&](int k, WrTile& t) {
+        if (k >= K) {
+            t.img = reinterpret_cast<const unsigned char*>(wr_zero);
+            t.o0 = t.o1 = t.o2 = ~0u;
+            t.n = 0; t.oy0 = 0; t.ox0 = 0;
+            return;
+        }
+        const int u = j0 + (k / a.subt) * a.J, half = k % a.subt;
+        const int tx = u % a.tilesX, r = u / a.tilesX, uy = r % a.unitsY, n = r / a.unitsY;
+        t.n = n; t.oy0 = (uy * a.subt + half) * WR_TH; t.ox0 = tx * TW;
+        t.img = reinterpret_cast<const unsigned char*>(p.x) + (size_t)n * p.H * p.W * Cin * 2;
+        auto piece = [&](int code) {
+            code = wr_opaque(code);
+            const int hy = (code >> 8) & 0xff, hx = code & 0xff, q = (code >> 16) & 3;
+            const int iy = t.oy0 - 1 + hy, ix = t.ox0 - 1 + hx;
+            const bool ok = code >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            return ok ? (unsigned)(iy * p.W + ix) * (unsigned)(Cin * 2) + q * 16 : ~0u;
+        };
+        t.o0 = piece(hyx[0]); t.o1 = piece(hyx[1]); t.o2 = piece(hyx[2]);
+    };
+    // loads of stage `st` (0 .. SPT-1) of tile t into ring slot `slot`: CPS chunk images, WR_NI instructions per wave each.
+    // EVERY lane of EVERY wave issues EVERY instruction (padding and past-the-end pieces read the zero block), so the
+    // number of loads in flight is a compile-time constant at every wait.
+    auto issue = [&](const WrTile& t, int st, int slot) {
+#pragma unroll
+        for (int cc = 0; cc < CPS; ++cc)
+#pragma unroll
+            for (int i = 0; i < WR_NI; ++i) {
+                const unsigned char* src = t.off(i) != ~0u ? t.img + t.off(i) + (st * CPS + cc) * 64
+                                                           : reinterpret_cast<const unsigned char*>(wr_zero);
+                wr_glds16(src, ring_lds + slot * STAGE + cc * WR_IMG + (i * 4 + wv) * 1024);
+            }
+    };
+
+    f32x4 acc[NSUB][WR_TH];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int r = 0; r < WR_TH; ++r) acc[s][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ssum[NSUB][4], ssq[NSUB][4];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ssum[s][j] = 0.f; ssq[s][j] = 0.f; }
+
+    // ---- prologue: the first WR_D - 2 stages of the stream ----
+    WrTile cur, nxt;
+    tile_desc(0, cur);
+    tile_desc(1, nxt);
+    int sidx = 0;                                          // stage counter of the stream (slot = sidx % WR_D)
+#pragma unroll
+    for (int s = 0; s < WR_D - 2; ++s) {
+        if (s < SPT) issue(cur, s, s % WR_D);
+        else issue(nxt, s - SPT, s % WR_D);
+    }
+    // The weight and bias loads must be COMPLETE for the compiler's wait-count bookkeeping before the stream loop: a load
+    // still pending at the loop header would put a vmcnt(0) -- a drain of the run-ahead ring -- in front of its first use
+    // in every iteration.  An empty asm that takes each register as an in/out operand forces the one-time wait here.
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(A[s][c][t]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bs[s][j]));
+    }
+    if constexpr (INBN) __syncthreads();                   // bnp staged
+
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int st = 0; st < SPT; ++st) {
+            // -- keep the ring WR_D - 2 stages ahead: stage (k, st) + WR_D - 2 --
+            {
+                constexpr int AH = WR_D - 2;
+                const int tgt = st + AH;                   // relative to tile k
+                const int slot = (sidx + AH) % WR_D;
+                if (tgt < SPT) issue(cur, tgt, slot);
+                else if (tgt < 2 * SPT) issue(nxt, tgt - SPT, slot);
+                else {                                     // (SPT == 1: two tiles ahead)
+                    WrTile far;
+                    tile_desc(k + tgt / SPT, far);
+                    issue(far, tgt % SPT, slot);
+                }
+            }
+            // -- this wave's loads of stage sidx have landed when at most the younger (WR_D - 2) stages are in flight --
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((WR_D - 2) * CPS * WR_NI) : "memory");
+            unsigned char* sb = ring + (sidx % WR_D) * STAGE;
+            if constexpr (INBN) {
+                // BatchNorm-apply + ReLU of the previous layer, in place, by the lane whose load brought the piece
+                // (padding pieces stay zero: they are padding of the POST-activation tensor)
+                const int grp = cur.n / (p.N / p.in_groups);
+#pragma unroll
+                for (int cc = 0; cc < CPS; ++cc)
+#pragma unroll
+                    for (int i = 0; i < WR_NI; ++i) {
+                        if (cur.off(i) == ~0u) continue;
+                        unsigned char* pc = sb + cc * WR_IMG + ((i * 4 + wv) * 64 + lane) * 16;
+                        const float* sp = bnp + grp * 2 * Cin + (st * CPS + cc) * 32 + ((hyx[i] >> 16) & 3) * 8;
+                        float sc[8], sh[8], v[8];
+                        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(sp);
+                        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(sp + 4);
+                        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(sp + Cin);
+                        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(sp + Cin + 4);
+                        unpack16(*reinterpret_cast<const uint4*>(pc), v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+                        *reinterpret_cast<uint4*>(pc) = pack16<bf16>(v);
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // (raw: __syncthreads would drain the loads in flight)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+
+            // -- matrix work of the stage: per chunk 3 kernel columns x 10 halo rows, each fragment feeding <= 3 * NSUB MFMAs --
+#pragma unroll
+            for (int cc = 0; cc < CPS; ++cc) {
+                const int c = st * CPS + cc;
+                const unsigned char* hb = sb + cc * WR_IMG;
+                constexpr int NSTEP = 3 * WR_HH, PFD = 2;
+                V16u B[PFD + 1];
+                auto rd = [&](int step) {
+                    const int kw = step / WR_HH, h = step - kw * WR_HH;
+                    B[step % (PFD + 1)].u = *reinterpret_cast<const uint4*>(hb + lo[kw] + h * (WR_HW * 64));
+                };
+#pragma unroll
+                for (int s0 = 0; s0 < PFD; ++s0) rd(s0);
+#pragma unroll
+                for (int step = 0; step < NSTEP; ++step) {
+                    const int kw = step / WR_HH, h = step - kw * WR_HH;
+                    if (step + PFD < NSTEP) rd(step + PFD);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int r = h - kh;
+                        if (r < 0 || r >= WR_TH) continue;
+#pragma unroll
+                        for (int s = 0; s < NSUB; ++s)
+                            acc[s][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][c][kh * 3 + kw], B[step % (PFD + 1)].h,
+                                                                                acc[s][r], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            ++sidx;
+        }
+
+        // ---- epilogue of tile k: + bias, + residual, ReLU, statistics, transposed 16-byte stores ----
+        {
+            const int n = cur.n, oy0 = cur.oy0, ox0 = cur.ox0;
+            bf16* yout = reinterpret_cast<bf16*>(p.y) + (size_t)n * p.OH * p.OW * p.Cout;
+            const bool relu = p.act == DH_ACT_RELU;
+            // (two straight-line variants: with the residual, all of its loads are issued before the first use)
+            auto body = [&](auto has_res) {
+                constexpr int RG = 4;                      // residual rows in flight (registers)
+#pragma unroll
+                for (int r0 = 0; r0 < WR_TH; r0 += RG) {
+                    float rr[NSUB][RG][4];
+                    if constexpr (decltype(has_res)::value) {
+                        const bf16* rin = reinterpret_cast<const bf16*>(p.res) + (size_t)n * p.OH * p.OW * p.Cout;
+#pragma unroll
+                        for (int r = 0; r < RG; ++r)
+#pragma unroll
+                            for (int s = 0; s < NSUB; ++s)
+                                ld4(rin + (size_t)((oy0 + r0 + r) * p.OW + ox0 + pl) * p.Cout + co_w + s * 16 + g * 4, rr[s][r]);
+                    }
+#pragma unroll
+                    for (int r = r0; r < r0 + RG; ++r) {
+#pragma unroll
+                        for (int s = 0; s < NSUB; ++s) {
+                            float v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                v[j] = acc[s][r][j] + bs[s][j];
+                                if constexpr (decltype(has_res)::value) v[j] += rr[s][r - r0][j];
+                                if (relu) v[j] = fmaxf(v[j], 0.f);
+                                ssum[s][j] += v[j];
+                                ssq[s][j] += v[j] * v[j];
+                            }
+                            acc[s][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            st4(reinterpret_cast<bf16*>(otile + (r * TW + pl) * TPITCH) + wv * 16 * NSUB + s * 16 + g * 4, v);
+                        }
+                    }
+                }
+            };
+            if (p.res) body(std::true_type{});
+            else body(std::false_type{});
+            if (p.stats && (k % a.subt) == a.subt - 1) {
+                const int unit = j0 + (k / a.subt) * a.J;
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float sa = row16_sum(ssum[s][j]), sq = row16_sum(ssq[s][j]);
+                        if (pl == 0) {
+                            const int c = co_w + s * 16 + wr_opaque(g) * 4 + j;
+                            p.stats[((size_t)0 * p.CoutPad + c) * a.nunits + unit] = sa;
+                            p.stats[((size_t)1 * p.CoutPad + c) * a.nunits + unit] = sq;
+                        }
+                        ssum[s][j] = 0.f; ssq[s][j] = 0.f;
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // tile staged (the next tile's first stage barrier orders the reads below
+            asm volatile("" ::: "memory");                 //  before the next epilogue's writes)
+            static_assert((WR_TH * TW * PPR) % 256 == 0, "whole store rounds");
+#pragma unroll
+            for (int it = 0; it < WR_TH * TW * PPR / 256; ++it) {
+                const int i = wr_opaque(tid) + it * 256, px = i / PPR, q = i - px * PPR;
+                *reinterpret_cast<uint4*>(yout + (size_t)((oy0 + (px >> 4)) * p.OW + ox0 + (px & 15)) * p.Cout + cb * NCO + q * 8) =
+                    *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
+            }
+        }
+        cur = nxt;
+        tile_desc(k + 2, nxt);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the run-ahead loads past the end of the stream (zero block)
+}
+
+template <int NSUB, int NCH, int CPS, bool INBN, int WPS>
+int wr_launch(const ConvArgs& c, hipStream_t st, int cus) {
+    constexpr int STAGE = CPS * WR_IMG, NCO = 64 * NSUB;
+    WrArgs a;
+    a.c = c;
+    a.ncb = c.Cout / NCO;
+    a.subt = c.rw == 4 ? 2 : 1;
+    a.tilesX = c.OW / TW;
+    a.unitsY = c.OH / (WR_TH * a.subt);
+    a.nunits = c.N * a.unitsY * a.tilesX;
+    int J = (cus * WPS / a.ncb) & ~7;                      // WPS workgroups per CU, a multiple of 8 per output-channel block
+    if (J > a.nunits) J = (a.nunits + 7) & ~7;
+    if (J < 8) J = 8;
+    a.J = J;
+    const size_t lds = (size_t)WR_D * STAGE + (size_t)WR_TH * TW * (NCO * 2 + 16) + (INBN ? (size_t)c.in_groups * 2 * c.Cin * 4 : 0);
+    auto kern = conv3x3_wreg_kernel<NSUB, NCH, CPS, INBN, WPS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        attr_done = true;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            DH_FAIL("conv_wreg: cannot raise dynamic LDS to 160 KB");
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(a.ncb * J), dim3(256), lds, st, a);
+    DH_CHECK_LAUNCH("conv_wreg");
+    return 0;
+}
+
+template <int NSUB, int NCH, int CPS, int WPS>
+int wr_launch_bn(const ConvArgs& c, hipStream_t st, int cus) {
+    return c.in_scale ? wr_launch<NSUB, NCH, CPS, true, WPS>(c, st, cus) : wr_launch<NSUB, NCH, CPS, false, WPS>(c, st, cus);
+}
+
+int g_wreg_mode = -1;      // dh_conv_wreg_mode: -1 = where it is the faster kernel, 0 = never, 1 = wherever it can run
+
+int wr_variant() {            // DAHITRA_WREG_VARIANT: experiment switch for the 128-input-channel layers (0: 32 couts per wave)
+    static const int v = getenv("DAHITRA_WREG_VARIANT") ? atoi(getenv("DAHITRA_WREG_VARIANT")) : 0;
+    return v;
+}
+
+}  // namespace
+
+// the launches this kernel serves: what conv_mfma_kernel<bf16, 3, 1, 64, *, 1, *, FAST = true, *> serves at 64 / 128 / 256
+// input channels, whole 8x16 tiles, and enough tiles per persistent workgroup to amortise loading the weights
+bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
+    static const bool off = getenv("DAHITRA_NO_WREG") != nullptr;
+    if (off || g_wreg_mode == 0 || dtype != DH_DTYPE_BF16 || ks != 3 || stride != 1 || a.dil != 1 || a.pad != 1) return false;
+    if (a.Cin != 64 && a.Cin != 128 && a.Cin != 256) return false;
+    if (a.Cout % 64 || a.CoutPad != a.Cout || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride || a.w_cm) return false;
+    if (a.act == DH_ACT_GELU || a.npix != a.OH * a.OW || a.in_npix != a.H * a.W || a.OH != a.H || a.OW != a.W) return false;
+    if (a.OH % (a.rw == 4 ? 16 : 8) || a.OW % 16) return false;
+    if (a.in_scale && a.in_groups > 4) return false;
+    if (a.Cin == 128 && a.Cout % 128 && wr_variant() == 0) return false;
+    if (g_wreg_mode != 1) {
+        // measured (tools/wreg_bench.py, 64 images): the shapes on which this kernel is the faster one
+        if (!(a.Cin == 64 && !a.in_scale)) return false;
+    }
+    // every persistent workgroup should see at least two tiles (the weights of a workgroup are 74 - 295 KB)
+    return (long)a.N * (a.OH / 8) * (a.OW / 16) * (a.Cout / 64) >= 2 * 256;
+}
+
+// C ABI (include/dahitra_hip.h): route the eligible 3x3 convolutions through the tap-oriented kernel instead (mode 0), or
+// back through this one (mode -1); returns the previous mode.  For A/B measurements and the bit-identity test.
+extern "C" int dh_conv_wreg_mode(int mode) {
+    const int prev = g_wreg_mode;
+    g_wreg_mode = mode == 0 ? 0 : (mode == 1 ? 1 : -1);
+    return prev;
+}
+
+int dh_conv_wreg_launch(const ConvArgs& a, hipStream_t st) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    }
+    if (a.Cin == 64) return wr_launch_bn<1, 2, 1, 2>(a, st, cus);
+    if (a.Cin == 256) return wr_launch_bn<1, 8, 1, 1>(a, st, cus);
+    if (wr_variant() == 1 || a.Cout % 128) return wr_launch_bn<1, 4, 1, 2>(a, st, cus);
+    return wr_launch_bn<2, 4, 1, 1>(a, st, cus);
+}

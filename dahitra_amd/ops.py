@@ -475,8 +475,8 @@ def conv_up2_fwd(x, wfwd, bias4):
     """conv3x3(nearest-x2(x)) + bias: x [N, H, W, Cin] -> [N, 2H, 2W, 32]; the upsampled tensor is never materialised"""
     N, H, W, Cin = x.shape
     y = torch.empty(N, 2 * H, 2 * W, 32, dtype=x.dtype, device=x.device)
-    key = "conv_mfma<%s,ks3,s1,nt32>" % ("bf16" if x.dtype == torch.bfloat16 else "f32")       # the class it replaces
-    with _Prof(key, 2.0 * N * 4 * H * W * 32 * Cin * 9, _nb(x, y, wfwd)):                       # algorithmic FLOPs
+    key = "conv_phase<%s,up2_fwd>" % ("bf16" if x.dtype == torch.bfloat16 else "f32")         # its own class: KS = 2 launches
+    with _Prof(key, 2.0 * N * 4 * H * W * 32 * Cin * 9, _nb(x, y, wfwd)):                       # algorithmic FLOPs (of the 3x3)
         _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wfwd), P(y), P(bias4), _vp(0), _vp(0), _ci(N), _ci(H), _ci(W), _ci(Cin),
               _ci(H), _ci(W), _ci(128), _ci(128), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0), _cl(0), _vp(0), _ci(1),
               *_gate_args(None), *_bn_in_args(None), _ci(1), _ci(0), S())
@@ -497,7 +497,7 @@ def conv3x3s2_dgrad(dy, wphase, cin, coarse_residual=None, alg_flops=0):
     gradient of a parallel 1x1 stride-2 convolution) lands on the even-even positions"""
     N, OH, OW, Co = dy.shape
     dx = torch.empty(N, 2 * OH, 2 * OW, cin, dtype=dy.dtype, device=dy.device)
-    key = "conv_mfma<%s,ks3,s1,nt64>" % ("bf16" if dy.dtype == torch.bfloat16 else "f32")
+    key = "conv_phase<%s,s2_dgrad>" % ("bf16" if dy.dtype == torch.bfloat16 else "f32")
     with _Prof(key, alg_flops if alg_flops else 2.0 * N * OH * OW * Co * cin * 9, _nb(dy, dx, wphase, coarse_residual)):
         _call("dh_conv2d_fwd", _ci(dt(dy)), P(dy), P(wphase), P(dx), _vp(0), P(coarse_residual), _vp(0), _ci(N), _ci(OH),
               _ci(OW), _ci(Co), _ci(OH), _ci(OW), _ci(4 * cin), _ci(4 * cin), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0),
@@ -511,7 +511,7 @@ def conv_up2_dgrad(dy, wdgrad, cin):
     assert C == 32 and H2 % 2 == 0 and W2 % 2 == 0 and cin % 64 == 0
     H, W = H2 // 2, W2 // 2
     dx = torch.empty(N, H, W, cin, dtype=dy.dtype, device=dy.device)
-    key = "conv_mfma<%s,ks3,s1,nt64>" % ("bf16" if dy.dtype == torch.bfloat16 else "f32")
+    key = "conv_phase<%s,up2_dgrad>" % ("bf16" if dy.dtype == torch.bfloat16 else "f32")
     with _Prof(key, 2.0 * N * H2 * W2 * 32 * cin * 9, _nb(dy, dx, wdgrad)):
         _call("dh_conv2d_fwd", _ci(dt(dy)), P(dy), P(wdgrad), P(dx), _vp(0), _vp(0), _vp(0), _ci(N), _ci(H), _ci(W), _ci(128),
               _ci(H), _ci(W), _ci(cin), _ci(cin), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0), _cl(0), _vp(0), _ci(1),

@@ -72,6 +72,13 @@ int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const
  * dh_bn_bwd_from_partials consumes (replaces the reduction pass of dh_bn_bwd; torch autograd's native_batch_norm
  * backward + threshold_backward, called from models/resnet.py:58-73 via loss.backward()). */
 int dh_conv2d_fwd_num_tiles(int N, int OH, int OW, int Cin, int ks, int stride);
+/* bf16 3x3 / stride-1 / pad-1 convolutions with 64 / 128 / 256 input channels and Cout % 64 == 0 on whole 8x16 tiles run,
+ * inside dh_conv2d_fwd, on the register-resident-weights kernel (csrc/conv_wreg.hip: persistent workgroups, the weights of
+ * a wavefront's output channels stay in its registers, only the input halo is staged) -- same products in the same order as
+ * the tap-oriented kernel, i.e. bit-identical outputs.  mode -1 (default): on the shapes where it is the faster kernel; 0: never
+ * (everything through the tap-oriented kernel); 1: wherever it can run.  Returns the previous mode.  Same reference call sites as dh_conv2d_fwd
+ * (models/resnet.py:24-73: BasicBlock conv1 / conv2 and their input gradients). */
+int dh_conv_wreg_mode(int mode);
 /* The class head -- classifier[-1]: nn.Conv2d(32, n_class, 3, padding 1) (models/networks.py:201-204, 1121-1129) -- with the
  * fp32 NCHW logits [N][Cout][H][W] (the reference's output layout) written by the convolution itself: no NHWC logits tensor,
  * no layout pass.  w_packed: dh_pack_weight with OPad = 16; in_scale / in_shift (optional): BatchNorm-apply + ReLU on load. */

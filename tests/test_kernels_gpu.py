@@ -957,3 +957,69 @@ def test_conv1x1_kdeep_gemm_path(ops, cfg):
     want.backward(dy)
     dx = ops.conv2d(dev(nhwc(dy), dtype), wd, Cin, 1, 1, 0)
     close(nchw(dx), x.grad, dtype, "1x1 GEMM data gradient", factor=2.0)
+
+
+# ---- the register-resident-weights form of the 3x3 convolutions (csrc/conv_wreg.hip) --------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(n=64, cin=64, cout=64, h=64, w=64, stats=True),                         # layer1 convs (8-row statistics units)
+    dict(n=64, cin=64, cout=64, h=64, w=64, res=True),                           # ... their data gradients with the shortcut
+    dict(n=64, cin=64, cout=64, h=64, w=64, stats=True, bn_in=True),             # conv2 of a block: BatchNorm + ReLU on load
+    dict(n=64, cin=128, cout=128, h=32, w=32, stats=True),                       # layer2 (16-row statistics units)
+    dict(n=64, cin=128, cout=128, h=32, w=32, stats=True, bn_in=True),
+    dict(n=64, cin=128, cout=256, h=32, w=32, stats=True),                       # layer3.0.conv1
+    dict(n=64, cin=256, cout=128, h=32, w=32, res=True),                         # its data gradient
+    dict(n=64, cin=256, cout=256, h=32, w=32, stats=True),                       # layer3
+    dict(n=64, cin=256, cout=256, h=32, w=32, stats=True, bn_in=True),
+    dict(n=64, cin=256, cout=256, h=32, w=32, res=True, relu=True, bias=True),   # eval form: bias + residual + ReLU
+    dict(n=6, cin=64, cout=64, h=48, w=80, stats=True, bn_in=True),              # ragged stream: 180 tiles over 512 workgroups
+    dict(n=10, cin=256, cout=64, h=40, w=48, res=True),                          # one output-channel block, odd tile count
+])
+def test_conv3x3_register_resident_weights_equals_tap_kernel(ops, cfg):
+    """dh_conv2d_fwd on the persistent register-resident-weights kernel against the tap-oriented kernel (dh_conv_wreg_mode 0):
+    the same MFMA products accumulated in the same order => bit-identical outputs; statistics to fp32 round-off (their
+    partial sums are taken over other pixel subsets).  And against torch's fp32 convolution."""
+    from dahitra_amd import _lib
+    L = _lib.lib()
+    dtype = torch.bfloat16
+    N, cin, cout, H, W = cfg["n"], cfg["cin"], cfg["cout"], cfg["h"], cfg["w"]
+    x = rnd((N, cin, H, W), dtype, 801)
+    w = rnd((cout, cin, 3, 3), dtype, 802, scale=(cin * 9) ** -0.5)
+    b = rnd((cout,), torch.float32, 803, 0.1) if cfg.get("bias") else None
+    r = rnd((N, cout, H, W), dtype, 804) if cfg.get("res") else None
+    groups = 2
+    xin = x
+    bn = None
+    if cfg.get("bn_in"):
+        scale = rnd((groups, cin), torch.float32, 805, 0.5) + 0.7
+        shift = rnd((groups, cin), torch.float32, 806, 0.5)
+        per = N // groups
+        xin = torch.cat([F.relu(x[g * per:(g + 1) * per] * scale[g].view(1, -1, 1, 1) + shift[g].view(1, -1, 1, 1))
+                         for g in range(groups)]).to(dtype).float()
+        bn = (scale.cuda(), shift.cuda())
+    want = F.conv2d(xin, w, b, 1, 1)
+    if r is not None:
+        want = want + r
+    if cfg.get("relu"):
+        want = F.relu(want)
+    wp, _ = ops.pack_weight(w.cuda(), dtype, want_dgrad=False)
+    xd = dev(nhwc(x), dtype)
+    arg = ops.BnInput(xd, bn[0], bn[1], groups) if bn else xd
+    res = {}
+    for mode in (0, 1):
+        prev = L.dh_conv_wreg_mode(mode)
+        try:
+            res[mode] = ops.conv2d(arg, wp, cout, 3, 1, 1, bias=b.cuda() if b is not None else None,
+                                   residual=dev(nhwc(r), dtype) if r is not None else None,
+                                   act=ops.ACT_RELU if cfg.get("relu") else ops.ACT_NONE, want_stats=bool(cfg.get("stats")))
+        finally:
+            L.dh_conv_wreg_mode(prev)
+    y0, y1 = (res[0][0], res[1][0]) if cfg.get("stats") else (res[0], res[1])
+    assert torch.equal(y0, y1), "outputs differ: max |d| = %g" % float((y0.float() - y1.float()).abs().max())
+    close(nchw(y1), want, dtype, "register-resident conv vs torch")
+    if cfg.get("stats"):
+        s0, s1 = res[0][1].double(), res[1][1].double()
+        assert s0.shape == s1.shape
+        per_g = s0.shape[2] // groups
+        for g in range(groups):          # per BatchNorm group, as bn_finalize sums them
+            a0, a1 = s0[:, :, g * per_g:(g + 1) * per_g].sum(2), s1[:, :, g * per_g:(g + 1) * per_g].sum(2)
+            assert float((a0 - a1).abs().max()) <= 2e-5 * float(a0.abs().max())
