@@ -15,6 +15,10 @@ all: $(LIB)
 ILP_SRCS := decoder_fused encoder_fused tokens
 $(foreach f,$(ILP_SRCS),$(eval $(OBJ)/$(f).o: EXTRA := -mllvm -amdgpu-sched-strategy=max-ilp))
 
+# conv_wreg: its stream loop is ONE fully unrolled tile (up to 1152 steps); the default pragma-unroll budget (16 K instructions)
+# silently falls back to a partial unroll, which turns the register-resident weight array into scratch memory
+$(OBJ)/conv_wreg.o: EXTRA := -mllvm -pragma-unroll-threshold=262144
+
 $(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/conv_mfma_impl.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(FLAGS) $(EXTRA) -c $< -o $@

@@ -7,7 +7,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdahitra_hip.so")
+# DAHITRA_HIP_LIB: an experiment build of the same library (tools/*_timeline.py); the product path is the in-tree one
+LIB_PATH = os.environ.get("DAHITRA_HIP_LIB") or os.path.join(_HERE, "lib", "libdahitra_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dahitra_hip.h")
 
 _lib = None

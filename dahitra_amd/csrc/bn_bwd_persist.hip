@@ -16,8 +16,14 @@
 //
 // HBM traffic per layer: 2 reads + 1 write (+1 write with dres) instead of 4 reads + 1 write (+1), one launch instead of
 // three.  Falls back to the two-pass kernels (same results up to summation order) when the tensors do not fit, the
-// dtype is fp32, or the device has fewer than 256 CUs.  The spin is bounded: on a timeout the error word is set and the
-// workgroup leaves (no hang); dh_bn_bwd_persist_status() reports it.
+// dtype is fp32, or the device has fewer than 256 CUs.
+// Failure is LOUD, twice over.  The barrier needs all 256 workgroups co-resident (one per CU: 148 KB of LDS each); a kernel of
+// another stream holding CUs (a collective, a side-stream launch) can keep workgroups out.  The spin is bounded; a workgroup
+// that gives up sets bit 0 of the error word, and a non-finite partial sum (which the fixed-point accumulators could not
+// carry) sets bit 1.  Whenever the word is non-zero dgamma / dbeta are written as NaN -- the step's loss and parameters turn
+// NaN exactly as an overflow in the two-pass kernels would propagate -- and dh_bn_bwd_persist_status() returns (and clears)
+// the word for the host checks (dahitra_amd.graph / ops.bn_persist_check raise HipLibraryError).  dahitra_amd never
+// launches this kernel where another stream may run beside it (ops.bn_bwd: persist_ok).
 #include "common.h"
 
 namespace {
@@ -38,6 +44,8 @@ struct PersistArgs {
     long pieces_per_group; // 16-byte pieces of one BatchNorm group
     int C, groups, np, accumulate;
     float inv_m;
+    unsigned spin_limit;
+    int expect;            // arrivals the barrier waits for (PG; tests pass PG + 1 to force the timeout)
 };
 
 template <int MASK>      // 0: no ReLU, 1: mask from `out` (post-activation tensor), 2: mask recomputed from x
@@ -154,6 +162,8 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
             for (int r = 0; r < PT / 64; ++r) t += red[r * p.C + c];
             // cross-workgroup sum: 64-bit FIXED-POINT atomics (integer addition is associative, so the result does not
             // depend on the arrival order: deterministic).  2^-30 resolution, |sum| < 8.6e9.
+            if (!(fabsf(t) < 8.0e9f))          // NaN / Inf / out of range: the integer accumulators cannot carry it
+                __hip_atomic_fetch_or(&p.sync[2], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&acc[(size_t)(g * 2 + which) * p.C + c], (long long)__double2ll_rn((double)t * FIX_SCALE),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -173,9 +183,9 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
     if (tid == 0) {
         __hip_atomic_fetch_add(&p.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
-        while (__hip_atomic_load(&p.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)PG) {
+        while (__hip_atomic_load(&p.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.expect) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) {
+            if (++spins > p.spin_limit) {
                 __hip_atomic_store(&p.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -223,12 +233,15 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
     // ---- off the critical path: dgamma / dbeta (first workgroup), departure count, re-arming by the last to leave ----
     if (blockIdx.x == 0 && tid < p.C) {
         double tb = 0.0, tg = 0.0;
+        // a timed-out barrier or a non-finite partial: poison the parameter gradients (in-band, no host round trip)
+        if (__hip_atomic_load(&p.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) tb = __builtin_nan("");
         for (int gg = 0; gg < p.groups; ++gg) {
             const double u1 = (double)__hip_atomic_load(&acc[(size_t)(gg * 2 + 0) * p.C + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * unfix;
             const double ux = (double)__hip_atomic_load(&acc[(size_t)(gg * 2 + 1) * p.C + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * unfix;
             tb += u1;
             tg += (double)p.invstd[gg * p.C + tid] * (ux - (double)p.mean[gg * p.C + tid] * u1);
         }
+        if (tb != tb) tg = tb;
         if (p.accumulate) { p.dgamma[tid] += (float)tg; p.dbeta[tid] += (float)tb; }
         else { p.dgamma[tid] = (float)tg; p.dbeta[tid] = (float)tb; }
     }
@@ -275,6 +288,25 @@ extern "C" int dh_bn_bwd_persist_preferred(int dtype, long npix, int C, int grou
     return (ppg + wpg * PT - 1) / (wpg * PT) >= 12;
 }
 
+// C ABI: see include/dahitra_hip.h.  Returns the error word of a sync block (bit 0: barrier timeout, bit 1: non-finite partial
+// sum) and clears it; < 0: the copy failed.  Synchronises the stream (4-byte device-to-host copy): call it every N steps.
+extern "C" int dh_bn_bwd_persist_status(unsigned* sync, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    unsigned word = 0;
+    if (hipMemcpyAsync(&word, sync + 2, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    if (word && hipMemsetAsync(sync + 2, 0, 4, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return (int)word;
+}
+// test hook: arms / disarms a short spin limit so that tests can force the timeout path (limit 0: the normal 2^22 spins)
+static unsigned g_spin_limit = 0;
+extern "C" int dh_bn_bwd_persist_test_spin_limit(unsigned limit) { g_spin_limit = limit; return 0; }
+
 // C ABI: see include/dahitra_hip.h (dh_bn_bwd with `sync`)
 extern "C" int dh_bn_bwd_persist(const void* dout, const void* out_relu, const void* x, const float* mean,
                                  const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
@@ -294,6 +326,8 @@ extern "C" int dh_bn_bwd_persist(const void* dout, const void* out_relu, const v
     const long wpg = PG / groups;
     a.np = (int)((a.pieces_per_group + wpg * PT - 1) / (wpg * PT));
     a.inv_m = 1.0f / (float)(npix / groups);
+    a.spin_limit = g_spin_limit ? g_spin_limit : SPIN_LIMIT;
+    a.expect = g_spin_limit ? PG + 1 : PG;         // (test hook: one arrival that never comes)
     const size_t lds = (size_t)PNP * PT * 16 + 20 * 1024;      // x pieces + reduction scratch (<= 16 KB + 10 KB used in turn)
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto go = [&](auto kern) -> int {

@@ -22,6 +22,8 @@ from .models import losses
 
 
 class GraphedTrainStep:
+    CHECK_EVERY = 64          # replays between two read-backs of the persistent-BatchNorm error words
+
     def __init__(self, net, opt, a, b, lab, warmup=3):
         if not getattr(opt, "capturable", False):
             raise ValueError("GraphedTrainStep needs dahitra_amd.optim.AdamW(..., capturable=True)")
@@ -42,7 +44,7 @@ class GraphedTrainStep:
             for _ in range(warmup):
                 if split:      # the same launches the two captures make (the split backward has its own reduce tables)
                     self._split_first()
-                    net._engine.backward_second()
+                    self._second()
                     self.opt.step()
                 else:
                     self._eager_body(include_opt=True)
@@ -63,14 +65,16 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph):
                 self.loss = self._split_first()
             with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
-                net._engine.backward_second()
+                self._second()
         else:
             self.split_off = None
             with torch.cuda.graph(self.graph):
                 self.loss = self._eager_body(include_opt=not self.exchange)
         self._pinned = ops.pin_captured_buffers(net)
         self._generation = net._arena.generation
+        self._calls = 0
         torch.cuda.synchronize()
+        ops.bn_persist_check(a.device)         # the warm-up steps and the capture left no barrier timeout behind
 
     def _set_inputs(self, a, b, lab):
         self.a, self.b, self.lab = a.clone(), b.clone(), lab.clone()
@@ -126,6 +130,12 @@ class GraphedTrainStep:
         net._bind_grad_views()           # the optimizer skips parameters without a .grad, as torch does
         return loss
 
+    def _second(self):
+        """graph 2 (layer2 / layer1 / stem backward) replays WHILE the all-reduce of the arena tail runs on RCCL's stream: its
+        BatchNorm backward must not be the persistent one-launch form, whose device-wide barrier needs every CU"""
+        with ops.no_persist_bn():
+            self.net._engine.backward_second()
+
     def _after_replay(self):
         """world > 1: the exchange step and the update run eagerly after the replayed forward/backward"""
         parallel.allreduce_net_grads_(self.net)
@@ -147,6 +157,11 @@ class GraphedTrainStep:
                                "parameters replaced) after this step was captured; build a new GraphedTrainStep")
         if inputs and inputs[0] is not None:
             self._copy_inputs(*inputs)
+        self._calls += 1
+        if self._calls in (2, 8) or self._calls % self.CHECK_EVERY == 0:
+            # the persistent BatchNorm backward's device-wide barrier: a timeout (bit 0) or a non-finite sum (bit 1) of any
+            # replay since the last check raises here (one 4-byte read-back per sync block: a host sync, hence not per step)
+            ops.bn_persist_check(self.a.device)
         self.opt.sync_hyper(1.0 / self.world)
         if self.split_off is not None:
             self._replay_overlapped()

@@ -248,8 +248,11 @@ class SideStream:
         self.stream, self.keep, self.active, self._ctx = torch.cuda.Stream(device=device), [], False, None
 
     def fork(self, *tensors):
+        global _PERSIST_BLOCK
         self.stream.wait_stream(torch.cuda.current_stream())
         self.keep += [t for t in tensors if t is not None]
+        if not self.active:
+            _PERSIST_BLOCK += 1       # until the join: no device-wide-barrier kernels next to the side stream's launches
         self.active = True
         return self
 
@@ -264,9 +267,11 @@ class SideStream:
         return False
 
     def join(self):
+        global _PERSIST_BLOCK
         if self.active:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.keep, self.active = [], False
+            _PERSIST_BLOCK -= 1
 
 
 # ---- convolution / linear ------------------------------------------------------------------------
@@ -667,16 +672,50 @@ _BN_SYNC = {}
 BN_BWD_PERSIST = os.environ.get("DAHITRA_NO_PERSIST_BN", "0") != "1"      # True: where faster; "force": wherever supported (tests)
 if os.environ.get("DAHITRA_PERSIST_BN_FORCE", "0") == "1":
     BN_BWD_PERSIST = "force"
+_PERSIST_BLOCK = 0          # > 0: inside no_persist_bn() -- another stream may run beside the launches made here
+
+
+class no_persist_bn:
+    """`with ops.no_persist_bn():` BatchNorm backward takes the two-pass kernels.  The persistent form (dh_bn_bwd_persist)
+    holds a device-wide barrier across 256 one-per-CU workgroups: it must not be launched where a kernel of another
+    stream -- the RCCL all-reduce of the overlapped data-parallel step, a side-stream weight gradient -- may hold CUs."""
+
+    def __enter__(self):
+        global _PERSIST_BLOCK
+        _PERSIST_BLOCK += 1
+
+    def __exit__(self, *exc):
+        global _PERSIST_BLOCK
+        _PERSIST_BLOCK -= 1
+        return False
 
 
 def bn_sync_words(device):
-    """the zeroed state of dh_bn_bwd_persist's device-wide barrier + fixed-point accumulators (one set per device, lives
-    forever: captured HIP graphs point at it)"""
-    key = str(device)
+    """the zeroed state of dh_bn_bwd_persist's device-wide barrier + fixed-point accumulators: one block per (device, stream)
+    -- two streams must never share the counters -- that lives forever (captured HIP graphs point at it)"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     t = _BN_SYNC.get(key)
     if t is None:
         t = _BN_SYNC[key] = torch.zeros(8192, dtype=torch.int32, device=device)
     return t
+
+
+def bn_persist_check(device=None):
+    """reads and clears the error word of every persistent-BatchNorm sync block of `device` (all devices if None): raises
+    HipLibraryError when a launch since the last check timed out at its device-wide barrier or met a non-finite sum (the
+    affected step's dgamma / dbeta are NaN by then).  One 4-byte device-to-host copy per block: call it every N steps."""
+    bad = []
+    for (dev, stream), t in list(_BN_SYNC.items()):
+        if device is not None and dev != str(device):
+            continue
+        word = _lib.lib().dh_bn_bwd_persist_status(P(t), _vp(torch.cuda.current_stream(t.device).cuda_stream))
+        if word:
+            bad.append((dev, stream, word))
+    if bad:
+        raise _lib.HipLibraryError(
+            "dahitra_amd: the persistent BatchNorm backward failed (device, stream, word): %s -- bit 0: its device-wide "
+            "barrier timed out (another stream's kernel kept workgroups out: set DAHITRA_NO_PERSIST_BN=1 or keep such "
+            "launches inside ops.no_persist_bn()), bit 1: non-finite gradient sums; the gradients of that step are NaN" % bad)
 
 
 def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accumulate=False, want_dres=False,
@@ -687,7 +726,8 @@ def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accu
     dres = torch.empty_like(x) if want_dres else None
     L = _lib.lib()
     ws = workspace(L.dh_bn_bwd_workspace_size(_cl(npix), C, groups), x.device)
-    if BN_BWD_PERSIST and (L.dh_bn_bwd_persist_preferred if BN_BWD_PERSIST is True else L.dh_bn_bwd_persist_supported)(
+    if BN_BWD_PERSIST and not _PERSIST_BLOCK and \
+            (L.dh_bn_bwd_persist_preferred if BN_BWD_PERSIST is True else L.dh_bn_bwd_persist_supported)(
             _ci(dt(x)), _cl(npix), C, groups):
         # one persistent launch, tensors held on chip across a device-wide barrier: every tensor is read once
         with _Prof("bn_bwd", 0, _nb(dout, out_relu, x) + _nb(dx, dres)):

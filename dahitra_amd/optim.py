@@ -98,9 +98,23 @@ class AdamW(torch.optim.Optimizer):
             self._adopt_param_state(st)
             st.host = None                         # hyper-parameters may have changed with the param_groups
 
+    def _group_of(self, net):
+        for group in self.param_groups:
+            if id(net) in self._nets_of(group):
+                return group
+        return None
+
     def snapshot_flat_state(self, net):
+        """(m, v, step count) of `net`, or None when this optimizer does not hold its parameters.  A state that exists
+        only per parameter so far -- load_state_dict() on a fresh optimizer, before any step -- is adopted into the flat
+        arenas first, so that a snapshot / restore round trip (dahitra_amd.graph's warm-up) keeps a resumed checkpoint"""
         st = self._flat_state.get(id(net))
-        return None if st is None else (st.m.clone(), st.v.clone(), st.count())
+        if st is None:
+            group = self._group_of(net)
+            if group is None:
+                return None
+            st = self._state_for(net, group)
+        return st.m.clone(), st.v.clone(), st.count()
 
     def restore_flat_state(self, net, snap):
         st = self._flat_state.get(id(net))

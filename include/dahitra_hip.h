@@ -191,13 +191,18 @@ long dh_bn_bwd_workspace_size(long npix, int C, int groups);
 /* dh_bn_bwd as ONE persistent launch (csrc/bn_bwd_persist.hip): 256 workgroups hold dout (registers) and x (LDS) on chip
  * across a device-wide barrier, so each tensor is read once.  bf16 only; dh_bn_bwd_persist_supported() tells whether the
  * layer fits (otherwise call dh_bn_bwd).  sync: 8192 zero-initialised uint32 words owned by the caller and reused by every
- * call on one stream ([2] != 0 afterwards: the barrier timed out).  workspace: as dh_bn_bwd.  Same autograd call site. */
+ * call on ONE stream.  The barrier needs all 256 workgroups resident: never launch it where a kernel of another stream
+ * (a collective, a side-stream launch) may hold CUs.  Error word sync[2]: bit 0 = the bounded barrier spin timed out, bit 1 =
+ * a non-finite / out-of-range partial sum; when it is set dgamma / dbeta come out NaN.  dh_bn_bwd_persist_status() returns
+ * and clears the word (synchronises the stream; < 0: the copy failed).  workspace: as dh_bn_bwd.  Same autograd call site. */
 int dh_bn_bwd_persist_supported(int dtype, long npix, int C, int groups);
 int dh_bn_bwd_persist_preferred(int dtype, long npix, int C, int groups);   /* supported AND large enough to be faster */
 int dh_bn_bwd_persist(const void* dout, const void* out_relu, const void* x, const float* mean, const float* invstd,
                       const float* gamma, long npix, int C, int groups, void* dx, void* dres, float* dgamma, float* dbeta,
                       int accumulate, const float* mask_scale, const float* mask_shift, void* workspace, unsigned* sync,
                       void* stream);
+int dh_bn_bwd_persist_status(unsigned* sync, void* stream);
+int dh_bn_bwd_persist_test_spin_limit(unsigned limit);   /* tests: limit > 0 forces the timeout path (0 restores 2^22 spins) */
 int dh_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* partial, int ntiles, const float* mean,
                             const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
                             float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream);

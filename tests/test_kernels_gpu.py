@@ -807,7 +807,7 @@ def test_batchnorm_backward_persistent_launch_equals_two_pass(ops, cfg, monkeypa
             for a, b in zip(cur, res[True]):          # repeated persistent launches: bitwise identical
                 assert a is None or torch.equal(a, b)
         res[persist] = cur
-    assert int(ops.bn_sync_words(x.device)[2]) == 0, "the device-wide barrier timed out"
+    ops.bn_persist_check(x.device)                # raises if the device-wide barrier timed out
     assert ops.bn_sync_words(x.device)[:2].abs().sum().item() == 0, "barrier words not re-armed"
     two, per = res[False], res[True]
     s = float(two[0].abs().max())
@@ -817,6 +817,57 @@ def test_batchnorm_backward_persistent_launch_equals_two_pass(ops, cfg, monkeypa
     assert float((two[2] - per[2]).abs().max()) <= 2e-4 * float(two[2].abs().max()) + 1e-4, "dbeta"
     if two[3] is not None:
         assert torch.equal(two[3], per[3]), "dres"
+
+
+def test_batchnorm_backward_persistent_failures_are_loud(ops, monkeypatch):
+    """the device-wide barrier of dh_bn_bwd_persist: a timeout (forced: the barrier waits for one arrival that never comes,
+    with a short spin limit) and a non-finite gradient must both (a) poison dgamma / dbeta with NaN in the same launch and
+    (b) make ops.bn_persist_check() raise; afterwards the words are clear again and a normal launch is clean"""
+    from dahitra_amd import _lib
+    L = _lib.lib()
+    dtype = torch.bfloat16
+    N, H, W, C, G = 64, 32, 32, 128, 2
+    x = dev(rnd((N, H, W, C), dtype, 811, 1.5), dtype)
+    dout = dev(rnd((N, H, W, C), dtype, 812), dtype)
+    mean = rnd((G, C), torch.float32, 813, 0.2).cuda()
+    invstd = (rnd((G, C), torch.float32, 814, 0.1) + 0.9).cuda()
+    gamma = (rnd((C,), torch.float32, 815, 0.1) + 1.0).cuda()
+    monkeypatch.setattr(ops, "BN_BWD_PERSIST", "force")
+
+    def run(d):
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dx = ops.bn_bwd(d, None, x, mean, invstd, gamma, dg, db, G)
+        torch.cuda.synchronize()
+        return dx, dg, db
+    ops.bn_persist_check()                       # clean slate
+    _, dg, db = run(dout)
+    assert torch.isfinite(dg).all() and torch.isfinite(db).all()
+    ops.bn_persist_check()                       # no complaint
+    # (a) forced barrier timeout
+    L.dh_bn_bwd_persist_test_spin_limit(256)
+    try:
+        _, dg, db = run(dout)
+    finally:
+        L.dh_bn_bwd_persist_test_spin_limit(0)
+    assert torch.isnan(dg).all() and torch.isnan(db).all(), "a timed-out barrier must poison the parameter gradients"
+    with pytest.raises(_lib.HipLibraryError, match="barrier"):
+        ops.bn_persist_check()
+    ops.bn_persist_check()                       # the word was cleared by the failed check
+    # (b) a non-finite gradient: the fixed-point accumulators cannot carry it -> flagged, NaN out (as the two-pass path gives)
+    bad = dout.clone()
+    bad.view(-1)[12345] = float("inf")
+    _, dg, db = run(bad)
+    assert torch.isnan(dg).all() and torch.isnan(db).all()
+    with pytest.raises(_lib.HipLibraryError):
+        ops.bn_persist_check()
+    _, dg, db = run(dout)                         # and the barrier words re-armed themselves
+    assert torch.isfinite(dg).all() and torch.isfinite(db).all()
+    ops.bn_persist_check()
+    # no_persist_bn(): the two-pass kernels, whatever the switch says
+    with ops.no_persist_bn():
+        before = {k: v.clone() for k, v in ops._BN_SYNC.items()}
+        run(dout)
+        assert all(torch.equal(before[k], ops._BN_SYNC[k]) for k in before)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -1014,7 +1065,14 @@ def test_conv3x3_register_resident_weights_equals_tap_kernel(ops, cfg):
         finally:
             L.dh_conv_wreg_mode(prev)
     y0, y1 = (res[0][0], res[1][0]) if cfg.get("stats") else (res[0], res[1])
-    assert torch.equal(y0, y1), "outputs differ: max |d| = %g" % float((y0.float() - y1.float()).abs().max())
+    import os
+    if os.environ.get("DAHITRA_WREG_VARIANT") == "2" and cfg["cin"] < 256:
+        # the 32x32x16 forms: a 32-channel chunk is two K = 16 products (fp32 re-association): one bf16 ulp, rarely
+        d = (y0.float() - y1.float()).abs()
+        assert float((d / (torch.maximum(y0.float().abs(), y1.float().abs()) + 1e-3)).max()) <= 2.0 ** -7
+        assert float((d > 0).float().mean()) < 0.02
+    else:
+        assert torch.equal(y0, y1), "outputs differ: max |d| = %g" % float((y0.float() - y1.float()).abs().max())
     close(nchw(y1), want, dtype, "register-resident conv vs torch")
     if cfg.get("stats"):
         s0, s1 = res[0][1].double(), res[1][1].double()

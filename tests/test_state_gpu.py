@@ -175,3 +175,38 @@ def test_two_outstanding_forwards_and_a_no_grad_forward_between():
         for k, p in ref.named_parameters():
             if p.grad is not None:
                 assert torch.equal(p.grad, got[k]), k
+
+
+def test_graphed_step_keeps_an_optimizer_state_loaded_before_the_first_step():
+    """resume order of the reference (models/trainer.py:113-116): load_state_dict() on a FRESH optimizer, then train.  The
+    graphed step's warm-up snapshot / restore must carry the loaded moments and step count (they live only per parameter
+    until the first step adopts them into the flat arenas)"""
+    from dahitra_amd.graph import GraphedTrainStep
+    from dahitra_amd.optim import AdamW
+    a, b, lab = (t.cuda() for t in O.synthetic_batch(2, 64, seed=5))
+    net = make_net()
+    opt = AdamW(net.parameters(), lr=0.01, weight_decay=0.01, capturable=True)
+    for _ in range(3):
+        hip_step(net, opt, a, b, lab)
+    sd = opt.state_dict()
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    # continue eagerly for one step: the reference trajectory
+    hip_step(net, opt, a, b, lab)
+    want = {k: p.detach().clone() for k, p in net.named_parameters()}
+
+    net2 = make_net()
+    net2.load_state_dict(params)
+    opt2 = AdamW(net2.parameters(), lr=0.01, weight_decay=0.01, capturable=True)
+    opt2.load_state_dict(sd)                       # before any step: no flat state exists yet
+    step = GraphedTrainStep(net2, opt2, a, b, lab)
+    assert opt2.step_count(net2) == 3, "the warm-up restore lost the loaded step count"
+    st = opt2._flat_state[id(net2)]
+    ref = opt._flat_state[id(net)]
+    assert float(st.m.abs().max()) > 0 and float(st.v.abs().max()) > 0, "the loaded Adam moments were zeroed"
+    step(a, b, lab)
+    assert opt2.step_count(net2) == 4
+    for k, p in net2.named_parameters():
+        if p.grad is None:
+            continue
+        d = float((p.detach() - want[k]).abs().max())
+        assert d <= 1e-5 * max(float(want[k].abs().max()), 1e-3) + 1e-7, (k, d)
