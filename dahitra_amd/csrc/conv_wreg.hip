@@ -406,342 +406,6 @@ int wr_launch_bn(const ConvArgs& c, hipStream_t st, int cus) {
     return c.in_scale ? wr_launch<NSUB, NCH, D, PFD, true, WPS>(c, st, cus) : wr_launch<NSUB, NCH, D, PFD, false, WPS>(c, st, cus);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same structure on v_mfma_f32_32x32x16_bf16 (32 output channels x 32 pixels x 16 input channels per instruction): the
-// 16x16x32 form peaks at ~2.0 PFLOP/s on this chip, the 32x32x16 form at ~2.5 (MI355X_MICROARCH.md: ~5 vs ~8 cycles per CU
-// for half / the same FLOPs), and the stream loop above already runs within ~15 % of the 16x16x32 rate.  A wavefront owns
-// 32 output channels x 32 * NCH input channels (72 * NCH registers); its pixel operand is a ROW PAIR of the halo (lanes 0-15 /
-// 32-47: row r0, lanes 16-31 / 48-63: row r0 + 1; the lane halves take the two 8-channel pieces of a 16-channel k-step),
-// which serves kernel row 0 of one output row pair and kernel row 2 of the pair above it (even r0) or kernel row 1 (odd r0).
-// PSPLIT = 2 (64 input channels): the four waves are 2 channel groups x 2 tile halves (4 rows each); PSPLIT = 1: 4 channel
-// groups (128 output channels per workgroup), every wave all 8 rows.
-// LDS image of a chunk: as above plus the row parity in the swizzle (slot = piece ^ (bit 2 of the column) << 1 ^ (row & 1)),
-// which makes the two rows of a pair land in different bank groups.
-// Numerics: the same products, but a 32-channel chunk is two K = 16 instructions instead of one K = 32 instruction -- fp32
-// re-association inside a chunk; not bit-identical to the tap kernel (tests: one bf16 ulp).
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-__device__ __forceinline__ int wr32_off(int hy, int hx, int q) {
-    return (hy * WR_HW + hx) * 64 + ((q ^ (((hx >> 2) & 1) << 1) ^ (hy & 1)) << 4);
-}
-
-template <int NCH, int PSPLIT, int D, int PFD, bool INBN, int WPS>
-__global__ __launch_bounds__(256, WPS) void conv3x3_wreg32_kernel(WrArgs a) {
-    constexpr int NCG = 4 / PSPLIT;                        // 32-channel output groups per workgroup
-    constexpr int NCO = 32 * NCG;                          // output channels per workgroup
-    constexpr int ROWS = WR_TH / PSPLIT;                   // output rows of a wave
-    constexpr int NPG = ROWS / 2;                          // row pairs (accumulator tiles) of a wave
-    constexpr int NR0 = ROWS + 1;                          // halo row pairs (r0 = 0 .. ROWS) a wave reads per (kw, k-step)
-    constexpr int NSTEP = 3 * 2 * NR0;                     // fragment reads per stage
-    constexpr int TSTEPS = NCH * NSTEP;
-    constexpr int NB = PFD + 1;
-    static_assert(TSTEPS % NB == 0, "the rolling fragment buffer must line up at a tile change");
-    static_assert(D >= 3 && D - 1 <= 2 * NCH + 1, "ring depth");
-    constexpr int SYNC = INBN ? NSTEP / 3 : NSTEP / 2;     // step of a stage at which the next stage is published
-    constexpr bool STATIC_SLOT = NCH % D == 0;
-    constexpr int TPITCH = NCO * 2 + 16;
-    constexpr int PPR = NCO * 2 / 16;
-    const ConvArgs& p = a.c;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* ring = smem;                            // [D][WR_IMG]
-    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(wr_lds_addr(smem));
-    unsigned char* otile = smem + D * WR_IMG;              // [128 px][TPITCH]
-    float* spart = reinterpret_cast<float*>(otile + WR_TH * TW * TPITCH);     // [PSPLIT][2][NCO]: statistics of a tile (half)
-    float* sacc = spart + PSPLIT * 2 * NCO;                // [2][NCO]: running sums of a statistics unit
-    float* bias_s = sacc + 2 * NCO;                        // [NCO]
-    float* bnp = bias_s + NCO;                             // INBN: [in_groups][2][Cin]
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n32 = lane & 31, kg = lane >> 5;
-    WR_TS(0);
-    const int b = blockIdx.x, xcd = b & 7, qb = b >> 3;
-    const int cb = qb % a.ncb, j0 = (qb / a.ncb) * 8 + xcd;
-    const int cg = wv % NCG, ph = wv / NCG;                // this wave: output channels cb * NCO + cg * 32 .., rows ph * ROWS ..
-    const int co_w = cb * NCO + cg * 32;
-    const int Cin = p.Cin;
-
-    // ---- this wave's weights: [chunk][tap][k-step] fragments (lane: channel row n32, 8 input channels kg) ----
-    s16x8 A[NCH][9][2];
-    {
-        const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    A[c][t][j] = *reinterpret_cast<const s16x8*>(
-                        a.wfrag ? wb + ((size_t)((((co_w >> 5) * NCH + c) * 9 + t) * 2 + j)) * 1024 + lane * 16
-                                : wb + ((size_t)(t * p.CoutPad + co_w + n32) * Cin + c * 32 + j * 16 + kg * 8) * 2);
-    }
-    for (int i = tid; i < NCO; i += 256) bias_s[i] = p.bias ? p.bias[cb * NCO + i] : 0.f;
-    if constexpr (INBN) {
-        for (int i = tid; i < p.in_groups * 2 * Cin; i += 256) {
-            const int gi = i / (2 * Cin), r = i - gi * 2 * Cin;
-            bnp[i] = r < Cin ? p.in_scale[gi * Cin + r] : p.in_shift[gi * Cin + r - Cin];
-        }
-    }
-
-    int hyx[WR_NI];        // (hy << 8) | hx, or -1 past the image;  logical piece in bits 16..17
-#pragma unroll
-    for (int k = 0; k < WR_NI; ++k) {
-        const int i = (k * 4 + wv) * 64 + lane, px = i >> 2, qs = i & 3;
-        const int hy = px / WR_HW, hx = px - hy * WR_HW;
-        hyx[k] = px < WR_NPX ? (((qs ^ (((hx >> 2) & 1) << 1) ^ (hy & 1)) << 16) | (hy << 8) | hx) : -1;
-    }
-    // fragment read offsets of this lane: kernel column kw, parity of the pair's first row (the row enters the swizzle),
-    // k-step 0; the k-step flips address bit 5, the pair's first row is an immediate
-    int lo[3][2];
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int par = 0; par < 2; ++par)
-            lo[kw][par] = wr32_off(par + (n32 >> 4), (n32 & 15) + kw, kg) - par * (WR_HW * 64) + ph * ROWS * (WR_HW * 64);
-
-    const int K = (a.nunits > j0 ? (a.nunits - j0 + a.J - 1) / a.J : 0) * a.subt;
-    auto tile_desc = [&](int k, WrTile& t) {
-        if (k >= K) {
-            t.img = reinterpret_cast<const unsigned char*>(wr_zero);
-            t.o0 = t.o1 = t.o2 = ~0u;
-            t.n = 0; t.oy0 = 0; t.ox0 = 0;
-            return;
-        }
-        const int u = j0 + (k / a.subt) * a.J, half = k % a.subt;
-        const int tx = u % a.tilesX, r = u / a.tilesX, uy = r % a.unitsY, n = r / a.unitsY;
-        t.n = n; t.oy0 = (uy * a.subt + half) * WR_TH; t.ox0 = tx * TW;
-        t.img = reinterpret_cast<const unsigned char*>(p.x) + (size_t)n * p.H * p.W * Cin * 2;
-        auto piece = [&](int code) {
-            code = wr_opaque(code);
-            const int hy = (code >> 8) & 0xff, hx = code & 0xff, q = (code >> 16) & 3;
-            const int iy = t.oy0 - 1 + hy, ix = t.ox0 - 1 + hx;
-            const bool ok = code >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            return ok ? (unsigned)(iy * p.W + ix) * (unsigned)(Cin * 2) + q * 16 : ~0u;
-        };
-        t.o0 = piece(hyx[0]); t.o1 = piece(hyx[1]); t.o2 = piece(hyx[2]);
-    };
-    auto issue = [&](const WrTile& t, int c, int slot) {
-#pragma unroll
-        for (int i = 0; i < WR_NI; ++i) {
-            const unsigned char* src = t.off(i) != ~0u ? t.img + t.off(i) + c * 64 : reinterpret_cast<const unsigned char*>(wr_zero);
-            wr_glds16(src, ring_lds + slot * WR_IMG + (i * 4 + wv) * 1024);
-        }
-    };
-    auto bn_transform = [&](const WrTile& t, int c, int slot) {
-        const int grp = t.n / (p.N / p.in_groups);
-#pragma unroll
-        for (int i = 0; i < WR_NI; ++i) {
-            if (t.off(i) == ~0u) continue;
-            unsigned char* pc = ring + slot * WR_IMG + ((i * 4 + wv) * 64 + lane) * 16;
-            const float* sp = bnp + grp * 2 * Cin + c * 32 + ((wr_opaque(hyx[i]) >> 16) & 3) * 8;
-            float sc[8], sh[8], v[8];
-            *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(sp);
-            *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(sp + 4);
-            *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(sp + Cin);
-            *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(sp + Cin + 4);
-            unpack16(*reinterpret_cast<const uint4*>(pc), v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
-            *reinterpret_cast<uint4*>(pc) = pack16<bf16>(v);
-        }
-    };
-
-    f32x16 acc[NPG];
-#pragma unroll
-    for (int g2 = 0; g2 < NPG; ++g2)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[g2][e] = 0.f;
-
-    WrTile t0, t1, t2;
-    tile_desc(0, t0);
-    tile_desc(1, t1);
-    tile_desc(2, t2);
-    auto tile_at = [&](int dk) -> const WrTile& { return dk == 0 ? t0 : (dk == 1 ? t1 : t2); };
-    int s0 = 0;
-    auto slot_of = [&](int st) { return STATIC_SLOT ? st % D : (s0 + st) % D; };
-#pragma unroll
-    for (int s = 0; s < D - 1; ++s) issue(tile_at(s / NCH), s % NCH, s % D);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(A[c][t][j]));
-    WR_TS(1);
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 2) * WR_NI) : "memory");
-    __syncthreads();                                       // bias_s / bnp staged (every load is long complete)
-    if constexpr (INBN) bn_transform(t0, 0, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    WR_TS(2);
-
-    V16u B[NB];
-    // step gg of the stream: stage st = gg / NSTEP; inside a stage (kw, k-step j, pair row r0) with r0 fastest
-    auto rd = [&](int gg) {
-        const int st = gg / NSTEP, i = gg - st * NSTEP, kw = i / (2 * NR0), j = (i / NR0) & 1, r0 = i % NR0;
-        B[gg % NB].u = *reinterpret_cast<const uint4*>(ring + slot_of(st) * WR_IMG + ((lo[kw][r0 & 1] + r0 * (WR_HW * 64)) ^ (j << 5)));
-    };
-#pragma unroll
-    for (int gg = 0; gg < PFD; ++gg) rd(gg);
-
-    for (int k = 0; k < K; ++k) {
-#pragma unroll
-        for (int st = 0; st < NCH; ++st)
-#pragma unroll
-        for (int i = 0; i < NSTEP; ++i) {
-            const int gg = st * NSTEP + i, kw = i / (2 * NR0), j = (i / NR0) & 1, r0 = i % NR0;
-            if (i == SYNC) {
-                const int nx = st + 1;
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 3) * WR_NI) : "memory");
-                if constexpr (INBN) {
-                    bn_transform(tile_at(nx / NCH), nx % NCH, slot_of(nx));
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                const int far = st + D - 1;
-                issue(tile_at(far / NCH), far % NCH, slot_of(far));
-            }
-            rd(gg + PFD);
-            __builtin_amdgcn_sched_barrier(0);
-            // rows (r0, r0 + 1): kernel row 0 of output pair r0 / 2, kernel row 2 of the pair above (even r0); kernel row 1 (odd)
-            if ((r0 & 1) == 0) {
-                if (r0 / 2 < NPG)
-                    acc[r0 / 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[st][0 * 3 + kw][j], B[gg % NB].h, acc[r0 / 2], 0, 0, 0);
-                if (r0 / 2 - 1 >= 0)
-                    acc[r0 / 2 - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[st][2 * 3 + kw][j], B[gg % NB].h, acc[r0 / 2 - 1], 0, 0, 0);
-            } else {
-                acc[r0 / 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[st][1 * 3 + kw][j], B[gg % NB].h, acc[r0 / 2], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-        // ---- epilogue of tile k ----
-        WR_TS(3 + 3 * k);
-        {
-            const int n = t0.n, oy0 = t0.oy0, ox0 = t0.ox0;
-            bf16* yout = reinterpret_cast<bf16*>(p.y) + (size_t)n * p.OH * p.OW * p.Cout;
-            const bool relu = p.act == DH_ACT_RELU;
-            // accumulator register e of pair g2: pixel (row 2 g2 + (n32 >> 4), column n32 & 15), channel (e & 3) + 8 (e >> 2) + 4 kg
-            auto body = [&](auto has_res) {
-                // channel quad q4 (4 consecutive channels) at a time: 8 statistics registers live instead of 32
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int ch = cg * 32 + 8 * q4 + 4 * wr_opaque(kg);            // within the workgroup's NCO channels
-                    const float4 bq = *reinterpret_cast<const float4*>(bias_s + ch);
-                    const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
-                    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-                    float rr[NPG][4];
-                    if constexpr (decltype(has_res)::value) {
-                        const bf16* rin = reinterpret_cast<const bf16*>(p.res) + (size_t)n * p.OH * p.OW * p.Cout + cb * NCO + ch;
-#pragma unroll
-                        for (int g2 = 0; g2 < NPG; ++g2)
-                            ld4(rin + (size_t)((oy0 + ph * ROWS + 2 * g2 + (n32 >> 4)) * p.OW + ox0 + (n32 & 15)) * p.Cout, rr[g2]);
-                    }
-#pragma unroll
-                    for (int g2 = 0; g2 < NPG; ++g2) {
-                        const int row = ph * ROWS + 2 * g2 + (n32 >> 4), col = n32 & 15;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[g2][q4 * 4 + e] + bv[e];
-                            if constexpr (decltype(has_res)::value) v[e] += rr[g2][e];
-                            if (relu) v[e] = fmaxf(v[e], 0.f);
-                            ssum[e] += v[e];
-                            ssq[e] += v[e] * v[e];
-                            acc[g2][q4 * 4 + e] = 0.f;
-                        }
-                        st4(reinterpret_cast<bf16*>(otile + (row * TW + col) * TPITCH) + ch, v);
-                    }
-                    if (p.stats) {
-                        // sums over the wave's 32 pixels x NPG pairs: the 16 lanes of a DPP row, then the two rows of a lane half
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float sa = row16_sum(ssum[e]), sq = row16_sum(ssq[e]);
-                            sa += __shfl_xor(sa, 16, 64);
-                            sq += __shfl_xor(sq, 16, 64);
-                            if (n32 == 0) {
-                                spart[(ph * 2 + 0) * NCO + ch + e] = sa;
-                                spart[(ph * 2 + 1) * NCO + ch + e] = sq;
-                            }
-                        }
-                    }
-                }
-            };
-            if (p.res) body(std::true_type{});
-            else body(std::false_type{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            WR_TS(4 + 3 * k);
-            static_assert((WR_TH * TW * PPR) % 256 == 0, "whole store rounds");
-#pragma unroll
-            for (int it = 0; it < WR_TH * TW * PPR / 256; ++it) {
-                const int i = wr_opaque(tid) + it * 256, px = i / PPR, q = i - px * PPR;
-                *reinterpret_cast<uint4*>(yout + (size_t)((oy0 + (px >> 4)) * p.OW + ox0 + (px & 15)) * p.Cout + cb * NCO + q * 8) =
-                    *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
-            }
-            if (p.stats && tid < 2 * NCO) {
-                // (sum | sum of squares)[channel] of the tile; a statistics unit of two tiles is combined through sacc
-                const int tsub = k % a.subt;
-                float t = spart[tid];
-                if constexpr (PSPLIT == 2) t += spart[2 * NCO + tid];
-                if (tsub > 0) t += sacc[tid];
-                if (tsub == a.subt - 1) {
-                    const int unit = j0 + (k / a.subt) * a.J, which = tid / NCO, c = tid - which * NCO;
-                    p.stats[((size_t)which * p.CoutPad + cb * NCO + c) * a.nunits + unit] = t;
-                } else {
-                    sacc[tid] = t;
-                }
-            }
-        }
-        WR_TS(5 + 3 * k);
-        t0 = t1;
-        t1 = t2;
-        tile_desc(k + 3, t2);
-        if constexpr (!STATIC_SLOT) s0 = (s0 + NCH) % D;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WR_TS(31);
-}
-
-template <int NCH, int PSPLIT, int D, int PFD, bool INBN, int WPS>
-int wr32_launch(const ConvArgs& c, hipStream_t st, int cus) {
-    constexpr int NCO = 128 / PSPLIT;
-    WrArgs a;
-    a.c = c;
-    a.ncb = c.Cout / NCO;
-    a.subt = c.rw == 4 ? 2 : 1;
-    a.tilesX = c.OW / TW;
-    a.unitsY = c.OH / (WR_TH * a.subt);
-    a.nunits = c.N * a.unitsY * a.tilesX;
-    int J = (cus * WPS / a.ncb) & ~7;
-    if (J > a.nunits) J = (a.nunits + 7) & ~7;
-    if (J < 8) J = 8;
-    a.J = J;
-    static const int wfrag = getenv("DAHITRA_WREG_FRAG") ? 1 : 0;      // experiment (tools/wreg_timeline.py)
-    a.wfrag = wfrag;
-    const size_t lds = (size_t)D * WR_IMG + (size_t)WR_TH * TW * (NCO * 2 + 16) + (size_t)(PSPLIT * 2 + 2 + 1) * NCO * 4 +
-                       (INBN ? (size_t)c.in_groups * 2 * c.Cin * 4 : 0);
-    auto kern = conv3x3_wreg32_kernel<NCH, PSPLIT, D, PFD, INBN, WPS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        attr_done = true;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            (void)hipGetLastError();
-            DH_FAIL("conv_wreg32: cannot raise dynamic LDS to 160 KB");
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3(a.ncb * J), dim3(256), lds, st, a);
-    DH_CHECK_LAUNCH("conv_wreg32");
-    return 0;
-}
-
-template <int NCH, int PSPLIT, int D, int PFD, int WPS>
-int wr32_launch_bn(const ConvArgs& c, hipStream_t st, int cus) {
-    return c.in_scale ? wr32_launch<NCH, PSPLIT, D, PFD, true, WPS>(c, st, cus) : wr32_launch<NCH, PSPLIT, D, PFD, false, WPS>(c, st, cus);
-}
-
 int g_wreg_mode = -1;      // dh_conv_wreg_mode: -1 = where it is the faster kernel, 0 = never, 1 = wherever it can run
 
 int wr_variant() {            // DAHITRA_WREG_VARIANT: experiment switch for the 128-input-channel layers (0: 32 couts per wave)
@@ -763,8 +427,10 @@ bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     if (a.in_scale && a.in_groups > 4) return false;
     if (a.Cin == 128 && a.Cout % 128 && wr_variant() == 0) return false;
     if (g_wreg_mode != 1) {
-        // measured (tools/wreg_bench.py, 64 images): the shapes on which this kernel is the faster one
-        if (!(a.Cin == 64 && !a.in_scale)) return false;
+        // measured (tools/wreg_bench.py, 64 images): the shapes on which this kernel is the faster one -- the 64-channel
+        // layers (x1.10 - 1.19).  On 256 -> 256 it ties the tap kernel (70.4 vs 70.5 us), on 128 input channels it loses
+        // (the 295 KB of weights per workgroup are loaded for two tiles only); DESIGN.md section 6c has the timeline.
+        if (a.Cin != 64) return false;
     }
     // every persistent workgroup should see at least two tiles (the weights of a workgroup are 74 - 295 KB)
     return (long)a.N * (a.OH / 8) * (a.OW / 16) * (a.Cout / 64) >= 2 * 256;
@@ -790,11 +456,6 @@ int dh_conv_wreg_launch(const ConvArgs& a, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     }
     //                                 NSUB NCH D PFD WPS
-    if (wr_variant() == 2) {          // 32x32x16 MFMA forms
-        //                                    NCH PSPLIT D PFD WPS
-        if (a.Cin == 64) return wr32_launch_bn<2, 2, 4, 4, 2>(a, st, cus);
-        if (a.Cin == 128 && a.Cout % 128 == 0) return wr32_launch_bn<4, 1, 4, 5, 1>(a, st, cus);
-    }
     if (a.Cin == 64) return wr_launch_bn<1, 2, 4, 3, 2>(a, st, cus);
     if (a.Cin == 256) return wr_launch_bn<1, 8, 4, 4, 1>(a, st, cus);
     if (wr_variant() == 1 || a.Cout % 128) return wr_launch_bn<1, 4, 4, 3, 2>(a, st, cus);

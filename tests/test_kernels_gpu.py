@@ -1065,14 +1065,7 @@ def test_conv3x3_register_resident_weights_equals_tap_kernel(ops, cfg):
         finally:
             L.dh_conv_wreg_mode(prev)
     y0, y1 = (res[0][0], res[1][0]) if cfg.get("stats") else (res[0], res[1])
-    import os
-    if os.environ.get("DAHITRA_WREG_VARIANT") == "2" and cfg["cin"] < 256:
-        # the 32x32x16 forms: a 32-channel chunk is two K = 16 products (fp32 re-association): one bf16 ulp, rarely
-        d = (y0.float() - y1.float()).abs()
-        assert float((d / (torch.maximum(y0.float().abs(), y1.float().abs()) + 1e-3)).max()) <= 2.0 ** -7
-        assert float((d > 0).float().mean()) < 0.02
-    else:
-        assert torch.equal(y0, y1), "outputs differ: max |d| = %g" % float((y0.float() - y1.float()).abs().max())
+    assert torch.equal(y0, y1), "outputs differ: max |d| = %g" % float((y0.float() - y1.float()).abs().max())
     close(nchw(y1), want, dtype, "register-resident conv vs torch")
     if cfg.get("stats"):
         s0, s1 = res[0][1].double(), res[1][1].double()

@@ -188,7 +188,8 @@ def test_graphed_step_keeps_an_optimizer_state_loaded_before_the_first_step():
     opt = AdamW(net.parameters(), lr=0.01, weight_decay=0.01, capturable=True)
     for _ in range(3):
         hip_step(net, opt, a, b, lab)
-    sd = opt.state_dict()
+    import copy
+    sd = copy.deepcopy(opt.state_dict())           # (state_dict() hands out the live moment views, as torch's does)
     params = {k: v.detach().clone() for k, v in net.state_dict().items()}
     # continue eagerly for one step: the reference trajectory
     hip_step(net, opt, a, b, lab)
