@@ -63,8 +63,8 @@ class CDTrainer:
         self.use_graph = bool(getattr(args, "hip_graph", True)) and os.environ.get("DAHITRA_NO_GRAPH", "0") != "1"
         self.lr = args.lr
         # capturable: lr / step count / bias corrections live on the device, so that the step can be recorded and replayed
-        self.optimizer_G = AdamW(self.net_G.parameters(), lr=self.lr, betas=(0.9, 0.999), weight_decay=0.01,
-                                 capturable=self.use_graph)
+        # (also without the graph: the eager step then runs the very same update kernel, bit for bit)
+        self.optimizer_G = AdamW(self.net_G.parameters(), lr=self.lr, betas=(0.9, 0.999), weight_decay=0.01, capturable=True)
         self._graph, self._graph_key = None, None
         self.exp_lr_scheduler_G = get_scheduler(self.optimizer_G, args)
         self.running_metric = ConfuseMatrixMeter(n_class=self.n_class)
