@@ -702,6 +702,12 @@ class Engine:
             self._bwd = bwd        # a no-grad forward (validation, metrics) leaves a pending backward alone
         return logits
 
+    def split_prefixes(self):
+        """key prefixes of the parameters whose gradients the SECOND part of a split backward writes (backward_second)"""
+        if self.cfg["kind"] == "bit":
+            return ("resnet.conv1.", "resnet.bn1.", "resnet.layer1.", "resnet.layer2.")
+        return ("resnet.",)
+
     def take_backward(self):
         """the backward closure of the forward that just ran (the autograd node of THAT forward keeps it, so several
         grad-enabled forwards may be outstanding, as with the reference's autograd graph)"""
@@ -862,7 +868,7 @@ class Engine:
 
         def bwd(dl):
             bwd_second(bwd_first(dl))
-        bwd.split = (bwd_first, bwd_second)
+        bwd.split = (bwd_first, bwd_second, ("resnet.conv1.", "resnet.bn1.", "resnet.layer1.", "resnet.layer2."))
         return logits, bwd
 
     # hierarchical model -------------------------------------------------------------------------
@@ -998,7 +1004,8 @@ class Engine:
         if not self.need_grad:
             return logits, None
 
-        def bwd(dl):
+        def bwd_first(dl):
+            """head, top-down path and the three levels: everything whose parameters sit behind the trunk in the arena"""
             do2 = b_out(dl)
             dy2 = bu2(do2)                                     # grad of (conv_layer2_0 out + o3)
             ops.conv2d_wgrad(y, dy2, self.g["conv_layer2_0.3.weight"], 3, 1, 1, accumulate=True, use_tr=self.use_tr)
@@ -1013,9 +1020,18 @@ class Engine:
             dsum4 = bu4(dsum3)                                 # d(t4 + o5u)
             ds8 = b4(dsum4)
             ds16 = b5(ops.upsample2_bwd(dsum4))
+            return ds16, ds8, ds4, ds2
+
+        def bwd_second(state):
+            """the trunk: layer3, layer2, layer1, stem (the `resnet.` keys, one contiguous run at the head of the arena)"""
+            ds16, ds8, ds4, ds2 = state
             dp16 = b_l3(ds16)
             ds8 = ops.add(ds8, ops.maxpool_bwd(arg16, dp16, s8.shape))
             ds4 = ops.add(ds4, b_l2(ds8))
             dp4 = b_l1(ds4)
             b_stem(ops.add(ds2, ops.maxpool_bwd(arg4, dp4, s2.shape)))
+
+        def bwd(dl):
+            bwd_second(bwd_first(dl))
+        bwd.split = (bwd_first, bwd_second, ("resnet.",))
         return logits, bwd

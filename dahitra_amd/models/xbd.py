@@ -89,6 +89,15 @@ class ComboLoss(nn.Module):
         return loss
 
 
+def channel_weights_dev(device, channel_weights=CHANNEL_WEIGHTS):
+    """the channel weights as a cached device tensor (no host-to-device copy inside a HIP-graph capture)"""
+    key = (str(device), tuple(float(v) for v in channel_weights))
+    w = _weights.get(key)
+    if w is None:
+        w = _weights[key] = torch.tensor(key[1], dtype=torch.float32, device=device)
+    return w
+
+
 def xbd_loss(out, msks, channel_weights=CHANNEL_WEIGHTS, dice=1.0, focal=8.0, want_channels=False):
     """train.py:348-353 in one pass: sum_c w_c * ComboLoss{dice:1, focal:8}(out[:, c], msks[:, c])"""
     _check(out, msks)

@@ -68,3 +68,22 @@ def broadcast_params_(net, src=0, group=None):
     dist.broadcast(flat, src=src, group=group)
     for b in net.buffers():
         dist.broadcast(b, src=src, group=group)
+
+
+def split_offset(net):
+    """Arena offset (in floats) at which the overlapped data-parallel step cuts the gradient exchange, or None.
+    The backward runs in two parts (Engine.backward_first / backward_second); every gradient the SECOND part writes (BiT nets:
+    stem, layer1, layer2; newUNetTrans / xBD: the whole ResNet trunk -- Engine.split_prefixes) must lie below the offset, so
+    that the tail [offset, end) is final after the first part and can be all-reduced while the second part computes.  None when
+    DAHITRA_NO_OVERLAP=1, when the net has no such parameters, or when less than 1 MB would be overlapped."""
+    if os.environ.get("DAHITRA_NO_OVERLAP", "0") == "1":
+        return None
+    off = net._arena.offsets
+    early = net._engine.split_prefixes()
+    second = [k for k in net._active_keys if k.startswith(early)]
+    if not second or len(second) == len(net._active_keys):
+        return None
+    split = max(off[k][0] + off[k][1] for k in second)           # end of the last gradient the second part writes
+    if (net._arena.n_active - split) * 4 < (1 << 20):
+        return None
+    return split

@@ -67,3 +67,28 @@ def test_shard_batch_and_single_process_noops():
         parallel.shard_batch(10, 0, 4)
     t = torch.ones(5)
     assert parallel.allreduce_sum_(t) == 1.0 and torch.equal(t, torch.ones(5))
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8", "newUNetTrans", "xbd_unet_transformer"])
+def test_gradient_exchange_split_point_of_every_net_family(name, monkeypatch):
+    """the overlapped data-parallel step (dahitra_amd/graph.py) all-reduces the arena tail [split, end) while the second part
+    of the backward runs: every gradient that part writes must lie below the split, the tail must be worth a collective"""
+    import types
+    from dahitra_amd import parallel
+    from dahitra_amd.models.networks import CDNet
+    net = CDNet(name, "fp32")
+    net._ensure_arena(torch.device("cpu"))
+    split = parallel.split_offset(net)
+    assert split is not None and 0 < split < net._arena.n_active
+    second = net._engine.split_prefixes()
+    for k in net._active_keys:
+        o, n = net._arena.offsets[k]
+        if k.startswith(second):
+            assert o + n <= split, k
+    tail = [k for k in net._active_keys if net._arena.offsets[k][0] >= split]
+    assert tail and not any(k.startswith(second) for k in tail)
+    assert (net._arena.n_active - split) * 4 >= (1 << 20)
+    if name.startswith("base_transformer"):        # BiT: layer3 .. end, 77 % of the gradient bytes
+        assert any(k.startswith("resnet.layer3.") for k in tail) and (net._arena.n_active - split) > 0.7 * net._arena.n_active
+    monkeypatch.setenv("DAHITRA_NO_OVERLAP", "1")
+    assert parallel.split_offset(net) is None
