@@ -1,40986 +1,248 @@
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-O        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-O        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-H        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-I        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-P        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-~        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-5        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-~        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-U        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-P        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-G        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-L        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-M        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-I        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-5        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-5        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-X        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-G        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-G        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-S        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-O        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-~        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-7        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-7        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-%        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-;        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-U        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-D        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-5        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-M        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-;        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-S        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-Y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-L        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-'        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-}        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-;        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-}        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-U        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-D        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-}        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-D        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-7        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-7        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-D        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-H        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-I        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-O        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-O        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-V        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-L        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-P        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-G        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-S        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-H        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-K        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-V        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-Y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-6        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-6        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-;        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-'        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-F        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-V        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-G        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-S        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-+        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-S        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-'        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-j        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-U        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-D        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-G        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-U        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-D        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-G        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-D        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-H        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-6        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-6        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-'        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-;        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-K        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-j        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-D        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-H        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-I        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-O        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-O        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-V        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-L        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-P        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-F        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-F        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-+        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
->        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-*        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-<        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-<        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-<        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-F        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-H        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-I        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-L        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-L        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-'        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-U        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
->        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-O        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-S        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-U        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-M        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-O        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-S        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-U        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-M        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-*        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-!        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-'        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-;        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-G        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-S        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-*        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-+        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-8        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-%        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-H        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-K        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-V        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-R        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-Y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-'        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-#        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-G        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-X        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-S        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-G        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-S        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-D        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-D        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-7        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-H        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-I        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-P        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-6        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-L        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-9        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-9        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-9        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-G        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-X        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-S        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-6        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-9        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-9        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-9        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-z        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-T        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-C        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-L        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-B        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-D        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-8        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-5        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-8        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-2        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-8        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-k        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-9        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-9        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-9        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-H        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-O        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-L        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-E        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-A        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-W        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-u        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-y        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-7        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
--        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-3        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-7        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-4        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
->        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-"        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-N        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-:        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-h        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-[        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-1        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-0        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-/        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-]        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-=        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-v        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-w        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-b        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-c        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-i        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-g        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-d        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-,        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-a        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-x        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-_        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-n        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-r        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-m        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-         self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-l        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-f        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-o        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-.        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-s        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-t        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-e        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-p        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-(        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-)        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
-
-        self.split_off = parallel.split_offset(self.net)
-        return self.split_off is not None
-
+"""One train step as ONE HIP graph: ~500 (BiT) to ~2000 (newUNetTrans) kernel launches recorded once and
+replayed per step, so the host cost of a step drops from milliseconds of Python/ctypes to a single
+hipGraphLaunch (MI355X guidance: capture launch-bound inner loops in hipGraphs, not a tracing compiler).
+
+    step = GraphedTrainStep(net, opt, a, b, lab)      # opt = dahitra_amd.optim.AdamW(..., capturable=True)
+    loss = step(a, b, lab)                            # device scalar, same semantics as the eager step
+
+Recorded: forward, zero_grad, focal loss, backward and (single process) the AdamW kernel.  With
+torch.distributed the step is TWO graphs around the exchange:
+    graph 1: forward, loss and the first part of the backward -- BiT nets: down to and including resnet.layer3, so that
+             every gradient from layer3 to the end of the flat arena (~77 % of its bytes for base_transformer_pos_s4) is
+             final; newUNetTrans / the xBD model: head, top-down path and the three transformer levels (the 5 MB behind the
+             trunk in the arena);
+    all-reduce of that arena tail, ASYNC (RCCL's stream) ..........  } concurrently
+    graph 2: the rest of the backward (BiT: layer2 / layer1 / stem;  }
+             newUNetTrans / xBD: the whole ResNet trunk)             }
+    all-reduce of the arena head, wait for both, then the update: AdamW with 1/world folded into its grad_scale, or for the
+    xBD step the mean over ranks, clip_grad_norm_ over the complete arena and the hand-rolled AdamW (train.py:373-374).
+DAHITRA_NO_OVERLAP=1: one graph, then one all-reduce and the update.  The warm-up steps torch needs before capture are
+undone (parameters, BN buffers and optimizer state are restored), so the first graphed step is step 1."""
+import torch
+import torch.distributed as dist
+
+from . import ops, parallel
+from .models import losses
+
+
+class GraphedTrainStep:
+    CHECK_EVERY = 64          # replays between two read-backs of the persistent-BatchNorm error words
+
+    def __init__(self, net, opt, a, b, lab, warmup=3, confusion=None):
+        """confusion: an int64 [n_class, n_class] device tensor; the recorded step then also counts arg-max(logits) against
+        the labels into it (dh_confusion_matrix, one more kernel inside the graph: the running metric of the reference's
+        trainer without any per-step launch or host read)"""
+        if not getattr(opt, "capturable", False):
+            raise ValueError("GraphedTrainStep needs dahitra_amd.optim.AdamW(..., capturable=True)")
+        self.net, self.opt = net, opt
+        self.confusion = confusion
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.exchange = parallel.exchange_enabled()      # gradient all-reduce + AdamW after the replay
+        self.split_off = None                            # arena offset where the overlapped (two-graph) form splits
+        self._set_inputs(a, b, lab)
+        net._ensure_arena(a.device)
+        # ---- snapshot the training state, warm up eagerly on a side stream, restore -------------------
+        flat0 = net._arena.flat.clone()
+        bufs0 = [t.clone() for t in net.buffers()]
+        conf0 = confusion.clone() if confusion is not None else None
+        opt0 = opt.snapshot_flat_state(net)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        split = self.exchange and self._can_split()
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                if split:      # the same launches the two captures make (the split backward has its own reduce tables)
+                    self._split_first()
+                    self._second()
+                    self._update()
+                else:
+                    self._eager_body(include_opt=True)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        net._arena.flat.copy_(flat0)
+        for t, t0 in zip(net.buffers(), bufs0):
+            t.copy_(t0)
+        opt.restore_flat_state(net, opt0)     # the optimizer keeps what it carried (e.g. a resumed checkpoint)
+        if confusion is not None:
+            confusion.copy_(conf0)
+        # ---- capture ---------------------------------------------------------------------------------
+        # A captured graph holds RAW pointers: the shared scratch workspace, the weight-gradient plan's slabs and
+        # job table, the packed-weight buffers.  ops.pin_captured_buffers() makes every buffer the capture touched
+        # immutable for the life of the process (a later, larger eager call allocates a NEW buffer instead of
+        # freeing the one the graph still reads and writes).
+        self.graph = torch.cuda.CUDAGraph()
+        if split:
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._split_first()
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+                self._second()
+        else:
+            self.split_off = None
+            with torch.cuda.graph(self.graph):
+                self.loss = self._eager_body(include_opt=not self.exchange)
+        self._pinned = ops.pin_captured_buffers(net)
+        self._generation = net._arena.generation
+        self._calls = 0
+        torch.cuda.synchronize()
+        ops.bn_persist_check(a.device)         # the warm-up steps and the capture left no barrier timeout behind
+
+    def _set_inputs(self, a, b, lab):
+        self.a, self.b, self.lab = a.clone(), b.clone(), lab.clone()
+
+    def _copy_inputs(self, a, b, lab):
+        self.a.copy_(a, non_blocking=True)
+        self.b.copy_(b, non_blocking=True)
+        self.lab.copy_(lab, non_blocking=True)
+
+    def _eager_body(self, include_opt):
+        logits = self.net(self.a, self.b)
+        self.logits = logits.detach()          # static output buffer of the graph: valid after every replay
+        self.opt.zero_grad()
+        loss = losses.focal_loss(logits, self.lab)
+        loss.backward()
+        self._count(self.logits)
+        if include_opt:
+            self.opt.step()
+        return loss.detach()
+
+    def _forward_split(self):
+        return self.net._run_forward(self.a, self.b, need_grad=True)
+
+    def _loss_and_grad(self, logits):
+        """(loss, dloss/dlogits) at engine level (no autograd graph): focal loss of the BiT / DAHiTra trainers"""
+        tgt = self.lab[:, 0] if self.lab.dim() == logits.dim() else self.lab
+        return ops.focal_loss(logits, tgt.to(torch.int64).contiguous(), want_grad=True)
+
+    def _count(self, logits):
+        if self.confusion is not None:
+            tgt = self.lab[:, 0] if self.lab.dim() == logits.dim() else self.lab
+            ops.confusion_matrix(logits, tgt.to(torch.int64).contiguous(), self.confusion)
+
+    # ---- overlapped form ------------------------------------------------------------------------------
+    def _can_split(self):
+        """the net's backward has a split point and every gradient the second graph writes (bit: stem, layer1, layer2; unet /
+        xbd: the whole trunk) lies below the first offset of what the first graph completes: the arena tail [split, end) is
+        final after the first graph.  Keys below the split that the first graph writes (positional embeddings are registered
+        first) just ride with the second all-reduce."""
+        self.split_off = parallel.split_offset(self.net)
+        return self.split_off is not None
+
+    def _split_first(self):
+        """forward, loss and the first part of the backward, called under capture (engine level: one autograd-free pass)"""
+        net = self.net
+        logits = self._forward_split()
+        bwd = net._engine.take_backward()
+        self.logits = logits
+        loss, dl = self._loss_and_grad(logits)
+        self._count(logits)
+        net._arena.grad.zero_()
+        net._engine.backward_first(dl, bwd)
+        net._bind_grad_views()           # the optimizer skips parameters without a .grad, as torch does
+        return loss
+
+    def _second(self):
+        """graph 2 (layer2 / layer1 / stem backward) replays WHILE the all-reduce of the arena tail runs on RCCL's stream: its
+        BatchNorm backward must not be the persistent one-launch form, whose device-wide barrier needs every CU"""
+        with ops.no_persist_bn():
+            self.net._engine.backward_second()
+
+    def _after_replay(self):
+        """world > 1: the exchange step and the update run eagerly after the replayed forward/backward"""
+        parallel.allreduce_net_grads_(self.net)
+        self._update()
+
+    def _replay_overlapped(self):
+        _, grad = self.net.flat_params()
+        self.graph.replay()
+        w1 = dist.all_reduce(grad[self.split_off:], op=dist.ReduceOp.SUM, async_op=True)      # waits for graph 1 only
+        self.graph2.replay()                                                                  # ... while this runs
+        w2 = dist.all_reduce(grad[:self.split_off], op=dist.ReduceOp.SUM, async_op=True)
+        w1.wait()
+        w2.wait()
+        self._update()
+
+    def _update(self):
+        """after both all-reduces: the (eager) parameter update"""
+        self.opt.step()
+
+    def __call__(self, *inputs):
+        if self.net._arena.generation != self._generation:
+            raise RuntimeError("dahitra_amd: the net's parameter arena was rebuilt (moved to another device / "
+                               "parameters replaced) after this step was captured; build a new GraphedTrainStep")
+        if inputs and inputs[0] is not None:
+            self._copy_inputs(*inputs)
+        self._calls += 1
+        if self._calls in (2, 8) or self._calls % self.CHECK_EVERY == 0:
+            # the persistent BatchNorm backward's device-wide barrier: a timeout (bit 0) or a non-finite sum (bit 1) of any
+            # replay since the last check raises here (one 4-byte read-back per sync block: a host sync, hence not per step)
+            ops.bn_persist_check(self.a.device)
+        self.opt.sync_hyper(1.0 / self.world)
+        if self.split_off is not None:
+            self._replay_overlapped()
+            return self.loss
+        self.graph.replay()
+        if self.exchange:
+            self._after_replay()
+        return self.loss
+
+
+class GraphedXbdStep(GraphedTrainStep):
+    """The xBD step (xBD_code/train.py:331-374) as one HIP graph: forward of the 6-channel model, the five weighted
+    ComboLoss terms, backward, clip_grad_norm_(0.999) and the hand-rolled AdamW.
+
+        step = GraphedXbdStep(net, xbd.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-6, capturable=True), imgs, msks)
+        loss = step(imgs, msks)"""
+
+    def __init__(self, net, opt, imgs, msks, max_norm=0.999, warmup=3):
+        self.max_norm = max_norm
+        super().__init__(net, opt, imgs, None, msks, warmup=warmup)
+
+    def _set_inputs(self, imgs, _unused, msks):
+        self.a, self.lab = imgs.clone(), msks.clone()
+
+    def _copy_inputs(self, imgs, msks):
+        self.a.copy_(imgs, non_blocking=True)
+        self.lab.copy_(msks, non_blocking=True)
+
+    def _eager_body(self, include_opt):
+        from .models import xbd
+        self.net.zero_grad()
+        logits = self.net(self.a)
+        self.logits = logits.detach()
+        loss = xbd.xbd_loss(logits, self.lab)
+        loss.backward()
+        if include_opt:
+            xbd.clip_grad_norm_(self.net.parameters(), self.max_norm)
+            self.opt.step()
+        return loss.detach()
+
+    def _forward_split(self):
+        x = self.a
+        return self.net._run_forward(x[:, :3], x[:, 3:], need_grad=True)
+
+    def _loss_and_grad(self, logits):
+        """the five weighted ComboLoss terms and their gradient at engine level (xBD_code/train.py:348-353)"""
+        from .models import xbd
+        w = xbd.channel_weights_dev(logits.device)
+        lo, ms = logits.float().contiguous(), self.lab.float().contiguous()
+        loss, _, sums = ops.combo_loss_fwd(lo, ms, w, 1.0, 8.0)
+        one = self._one if getattr(self, "_one", None) is not None else torch.ones(1, dtype=torch.float32, device=lo.device)
+        self._one = one
+        return loss, ops.combo_loss_bwd(lo, ms, sums, w, one, 1.0, 8.0)
+
+    def _after_replay(self):
+        parallel.allreduce_net_grads_(self.net)
+        self._update()
+
+    def _update(self):
+        """mean over the ranks, clip_grad_norm_(0.999) over the WHOLE (now complete) arena, then the hand-rolled AdamW:
+        the clip needs the total norm, so it cannot start before both all-reduces have landed (train.py:373-374)"""
+        from .models import xbd
+        _, grad = self.net.flat_params()
+        if self.world > 1:
+            if getattr(self, "_inv_world", None) is None:
+                self._inv_world = torch.tensor([1.0 / self.world], device=grad.device)
+            ops.scale_into(grad, self._inv_world, grad)
+        xbd.clip_grad_norm_(self.net.parameters(), self.max_norm)
+        self.opt.step()
