@@ -28,7 +28,7 @@ def _free_port():
 
 CASES = {                       # net, image size, pairs per rank
     "bit": (NAME, 64, 2),
-    "unet": ("newUNetTrans", 256, 1),
+    "unet": ("newUNetTrans", 256, 2),         # (2 pairs per rank: BatchNorm over ONE image per stream is ill-conditioned)
     "xbd": ("xbd_unet_transformer_nodecpos", 256, 1),
 }
 
