@@ -39,7 +39,14 @@ GFLOP_256 = {"base_transformer_pos_s4": 50.20, "newUNetTrans": 70.13, "base_tran
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_PROFILE = os.path.join("profiles", "r02_pmc_traffic_conv3x3.json")
+ALG_MB_PER_PAIR = 110.0         # fused-layer boundary tensors x 5 + 3 x parameters, bf16, s4 at 256x256
+
+
+def _latest_profile(suffix):
+    """newest committed profiles/r<NN>*<suffix> (the rocprofv3 --pmc summaries tools/profile_round.sh writes)"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*" + suffix)))
+    return os.path.relpath(c[-1], ROOT) if c else None
 
 
 def synthetic(batch, size, seed, device):
@@ -103,6 +110,44 @@ def cpu_baseline(seconds_budget=28.0):
                       "the thread counts in by_threads" % (runs[best][1], bs, NET),
             "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
             "by_threads": {str(t): round(v[0], 3) for t, v in runs.items()}}
+
+
+def bf16_gap(args, dev, local):
+    """How far the headline dtype is from the parity mode ON THE PRODUCT PATH (no oracle): the same freshly initialised weights
+    in a bf16 net, an fp32 net and an fp32 net fed bf16-ROUNDED weights + images (the unavoidable part of computing in bf16),
+    train-mode forward of the bench batch.  `flips_outside_band`: pixels whose bf16 mask differs from the fp32 mask although
+    the fp32 margin exceeds twice the largest bf16 logit error (with random weights the margins are tiny; the large-margin
+    fixtures are in tests/test_model_gpu.py::test_bf16_mode_within_3x_the_bf16_input_rounding_error)."""
+    import contextlib
+    import torch
+    from dahitra_amd.models.networks import define_G
+    a, b, _ = synthetic(args.batch, args.img, 4321, dev)
+    with contextlib.redirect_stdout(sys.stderr):
+        nets = {k: define_G(types.SimpleNamespace(net_G=args.net, compute_dtype=k), gpu_ids=[local]).train() for k in ("fp32", "bf16")}
+    sd = {k: v.clone() for k, v in nets["fp32"].state_dict().items()}
+    nets["bf16"].load_state_dict(sd)
+    out = {}
+    with torch.no_grad():
+        out["fp32"] = nets["fp32"](a, b).float()
+        out["bf16"] = nets["bf16"](a, b).float()
+        rounded = {k: (v.bfloat16().float() if v.dtype.is_floating_point and v.dim() > 1 else v) for k, v in sd.items()}
+        nets["fp32"].load_state_dict(rounded)
+        out["round"] = nets["fp32"](a.bfloat16().float(), b.bfloat16().float()).float()
+    ref = out["fp32"]
+    scale = float(ref.abs().max())
+    l2 = lambda u: float((u - ref).norm() / ref.norm())
+    err = float((out["bf16"] - ref).abs().max())
+    margin = (ref[:, 0] - ref[:, 1]).abs() if ref.shape[1] == 2 else None
+    diff = torch.argmax(out["bf16"], 1) != torch.argmax(ref, 1)
+    res = {"logit_l2": round(l2(out["bf16"]), 5), "logit_l2_fp32_pipeline_on_bf16_rounded_weights_and_images": round(l2(out["round"]), 5),
+           "max_err_over_logit_scale": round(err / scale, 5), "mask_disagreement": round(float(diff.float().mean()), 5),
+           "mask_disagreement_rounded_inputs_only": round(float((torch.argmax(out["round"], 1) != torch.argmax(ref, 1)).float().mean()), 5),
+           "weights": "define_G initialisation (random), train-mode BatchNorm, batch %d" % args.batch}
+    if margin is not None:
+        band = margin <= 2.0 * err
+        res["flips_outside_band"] = int((diff & ~band).sum())
+        res["band_fraction"] = round(float(band.float().mean()), 5)
+    return res
 
 
 def build(args, dtype, dev, local, rank, use_graph):
@@ -285,14 +330,36 @@ def main():
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = fl / (ms * 1e-3) / 1e12
             traffic = source = None      # HBM bytes per launch from committed rocprofv3 --pmc passes of this command
-            tpath = os.path.join(ROOT, TRAFFIC_PROFILE)
-            if args.dtype == "bf16" and args.net == NET and args.img == SIZE and args.batch == PER_GPU_BATCH \
-                    and os.path.exists(tpath):
-                tj = json.load(open(tpath))
+            headline = args.dtype == "bf16" and args.net == NET and args.img == SIZE and args.batch == PER_GPU_BATCH
+            tprof = _latest_profile("_pmc_traffic_conv3x3.json")
+            if headline and tprof:
+                tj = json.load(open(os.path.join(ROOT, tprof)))
                 ln = sum(v["launches"] for v in tj.values())
                 traffic = round(sum(v["launches"] * (v["fetch_MB_per_launch_corrected_x2"] + v["write_MB_per_launch"])
                                     for v in tj.values()) / ln * 1e6)
-                source = TRAFFIC_PROFILE
+                source = tprof
+            # the second-largest MFMA class: the weight gradients (all conv_wgrad launches of the step)
+            wg = {k: v for k, v in agg.items() if k.startswith("conv_wgrad")}
+            wgrad = None
+            if wg:
+                wms, wfl, wn = sum(v[0] for v in wg.values()), sum(v[1] for v in wg.values()), sum(v[3] for v in wg.values())
+                wraw = sum(raw_ms[k] for k in wg)
+                wgrad = {"bound": "mfma", "kernel": "conv_wgrad<*> (every weight-gradient launch of the step)",
+                         "achieved": round(wfl / (wms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(wfl / (wms * 1e-3) / 1e12 / peak, 4), "launches_per_step": wn,
+                         "ms_per_step": round(wms, 3), "achieved_minus_event_overhead": round(wfl / (wraw * 1e-3) / 1e12, 2)}
+            # whole-step HBM traffic against the algorithmic bytes (constant of the newest committed --pmc step profile)
+            step_traffic = None
+            sprof = _latest_profile("_pmc_step_traffic.json")
+            if headline and sprof:
+                sj = json.load(open(os.path.join(ROOT, sprof)))
+                tot = sj.get("total_MB_per_step")
+                if tot:
+                    alg = ALG_MB_PER_PAIR * args.batch
+                    step_traffic = {"total_MB_per_step": round(tot, 1), "algorithmic_MB_per_step": round(alg, 1),
+                                    "ratio": round(tot / alg, 2), "source": sprof,
+                                    "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE summed over every kernel of a step; "
+                                            "a constant of the named committed profile, not measured by this run"}
             roof = {"bound": "mfma", "kernel": key, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": source,
                     "traffic_note": "constant of the named committed rocprofv3 --pmc profile (FETCH_SIZE x2 per the gfx950 "
@@ -303,7 +370,11 @@ def main():
                     "achieved_minus_event_overhead": round(fl / (raw_ms[key] * 1e-3) / 1e12, 2),
                     "all_mfma_conv_ms_per_step": round(sum(v[0] for v in mfma.values()), 3),
                     "all_wgrad_ms_per_step": round(sum(v[0] for k, v in agg.items() if k.startswith("conv_wgrad")), 3),
-                    "all_mfma_conv_tflops": round(sum(v[1] for v in mfma.values()) / (sum(v[0] for v in mfma.values()) * 1e-3) / 1e12, 1)}
+                    "all_mfma_conv_tflops": round(sum(v[1] for v in mfma.values()) / (sum(v[0] for v in mfma.values()) * 1e-3) / 1e12, 1),
+                    "kernels_of_class": "conv_mfma_kernel<bf16,3,1,64,...> (tap-oriented) and conv3x3_wreg_kernel (register-resident "
+                                        "weights, the 64-channel layers): every 3x3 stride-1 convolution and data gradient of the "
+                                        "step; the 2x2 phase convolutions are their own class (conv_phase<...>)",
+                    "weight_gradient": wgrad, "step_traffic": step_traffic}
         classes = {}
         for k in ("bn_apply", "bn_bwd", "stem7_fwd", "decoder_layer_fwd", "decoder_layer_bwd"):
             if k in agg:
@@ -331,7 +402,8 @@ def main():
         parity = {"dtype": "fp32", "value": round(args.batch * k32 / d32, 2), "unit": "image-pairs/s", "steps": k32,
                   "ms_per_step": round(d32 / k32 * 1e3, 3),
                   "bar": "logits within 1e-3 rel of the reference CPU path, masks identical outside the tie band "
-                         "(tests/test_config1_gpu.py, tests/test_model_gpu.py at this mode)"}
+                         "(tests/test_config1_gpu.py, tests/test_model_gpu.py at this mode)",
+                  "bf16_vs_fp32": bf16_gap(args, dev, local)}
         del step32
 
     if rank == 0:

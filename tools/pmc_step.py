@@ -48,7 +48,7 @@ fetch, write, util, lds, prefix = load(sys.argv[1]), load(sys.argv[2]), load(sys
 # ---- per-launch traffic of the dominant conv class ----
 conv = {}
 for k in sorted(fetch):
-    if not k.startswith("conv_mfma_kernel<bf16, 3, 1, 64"):
+    if not (k.startswith("conv_mfma_kernel<bf16, 3, 1, 64") or k.startswith("conv3x3_wreg_kernel")):
         continue
     n, kb = fetch[k]["FETCH_SIZE"]
     wn, wkb = write.get(k, {}).get("WRITE_SIZE", [0, 0.0])
