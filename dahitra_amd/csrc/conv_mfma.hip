@@ -42,6 +42,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
                              "conv2d_fwd: BatchNorm-on-load needs in_shift and N %% in_groups == 0");
     a.phase_mode = phase_mode;
     a.y_nchw = nullptr;
+    a.up4_partial = nullptr;
     a.w_cm = w_chunk_major ? 1 : 0;
     DH_REQUIRE(!w_chunk_major || (ks == 3 && w_image_stride == 0 && !phase_mode), "conv2d_fwd: chunk-major weights are packed for the 3x3 layers only");
     static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
@@ -86,6 +87,29 @@ extern "C" int dh_conv3x3_head_fwd(int dtype, const void* x, const void* w_packe
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == DH_DTYPE_BF16) return dh_conv_launch_bf16(a, 3, 1, st);
     return dh_conv_launch_f32(a, 3, 1, st);
+}
+
+// Data gradient of a 3x3 / pad-1 convolution whose INPUT is a bilinear x4 upsampled map (models/networks.py:387-389:
+// classifier.0 behind nn.Upsample(4, 'bilinear')), taken straight to the COARSE grid: dy [N][H][W][K] (K = the conv's output
+// channels, a multiple of the 64-byte chunk), w_packed = the data-gradient pack [9][32][K]; the kernel reduces every 8x16 tile
+// of the fine-grid gradient to the 4 x 6 coarse pixels it touches and writes partial [N * (H/8) * (W/16)][4][6][32] fp32.
+// The fine-grid gradient (32 channels x H x W) is never stored.  dh_absdiff_up4_combine finishes (sum of <= 4 tiles, sign).
+extern "C" long dh_conv3x3_dgrad_up4_partial_floats(int N, int H, int W) { return (long)N * (H / 8) * (W / 16) * 4 * 6 * 32; }
+extern "C" int dh_conv3x3_dgrad_up4(int dtype, const void* dy, const void* w_packed, int N, int H, int W, int K, float* partial,
+                                    void* stream) {
+    DH_REQUIRE(dtype == DH_DTYPE_BF16, "conv3x3_dgrad_up4: bf16 only (the fp32 mode keeps the two-kernel path)");
+    DH_REQUIRE(K % 32 == 0 && H % 8 == 0 && W % 16 == 0 && partial && N > 0, "conv3x3_dgrad_up4: K=%d H=%d W=%d", K, H, W);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dy; a.w = w_packed;
+    a.N = N; a.H = H; a.W = W; a.Cin = K; a.OH = H; a.OW = W; a.Cout = 32; a.CoutPad = 32;
+    a.pad = 1; a.act = DH_ACT_NONE; a.npix = H * W; a.in_npix = H * W; a.dil = 1; a.gate_groups = 1; a.in_groups = 1;
+    static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
+    a.no_xcd_remap = no_remap;
+    a.up4_partial = partial;
+    a.rw = 2;
+    a.tilesX = W / TW; a.tilesY = H / 8;
+    return dh_conv_launch_bf16(a, 3, 1, reinterpret_cast<hipStream_t>(stream));
 }
 
 // number of workgroup tiles along the pixel dimension (= rows of the stats_partial buffer)

@@ -91,6 +91,11 @@ struct ConvArgs {
     // weights CHUNK-MAJOR: [Cin / CK][taps][CoutPad][CK] (CK = one 64-byte chunk) instead of [taps][CoutPad][Cin] -- the
     // staging of a chunk then reads whole cache lines (dh_pack_weights_multi, dtype | 0x100)
     int w_cm;
+    // Data gradient THROUGH the bilinear x4 upsample in front of this convolution's input (compact epilogue, NT = 32, 8x16
+    // tiles): the tile is not stored; it is reduced, in fp32, to the 4 x 6 coarse pixels its 8 x 16 fine pixels interpolate
+    // from (align_corners = False: fine row o reads coarse rows floor((o + 0.5) / 4 - 0.5) and the next, clamped) and the
+    // per-tile partial [tile][4][6][Cout] goes to up4_partial; dh_absdiff_up4_combine sums the <= 4 tiles of a coarse pixel.
+    float* up4_partial;
 };
 
 namespace {
@@ -410,6 +415,62 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
             else if (inside) body(std::true_type{}, std::false_type{}, relu);
             else body(std::true_type{}, std::true_type{}, relu);
         };
+        if constexpr (NT == 32 && KS == 3 && STRIDE == 1 && RW == 2 && !INBN) {
+            if (p.up4_partial) {
+                // fp32 tile -> LDS, then the 4 x 6 x NT coarse sums of this tile by a SEPARABLE reduction (columns, then rows)
+                // with the interpolation weights of the tile's 16 columns / 8 rows tabulated once (most of them are zero:
+                // a coarse column collects from the 8 fine columns 4 C - 2 .. 4 C + 5)
+                constexpr int FP = NT + 4;                            // floats per pixel: 16-byte aligned float4 reads
+                float* ft = reinterpret_cast<float*>(smem);           // [TH * TW][FP]
+                float* tmp = ft + TH * TW * FP;                       // [TH][6][NT]
+                float* wxT = tmp + TH * 6 * NT;                       // [6][TW]
+                float* wyT = wxT + 6 * TW;                            // [4][TH]
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        float4 v4 = make_float4(acc[s][r][0] + bs[s][0], acc[s][r][1] + bs[s][1], acc[s][r][2] + bs[s][2],
+                                                acc[s][r][3] + bs[s][3]);
+                        *reinterpret_cast<float4*>(ft + ((RW * wv + r) * TW + pl) * FP + s * 16 + g * 4) = v4;
+                    }
+                const int CH = p.OH >> 2, CW = p.OW >> 2;             // coarse grid
+                auto weight = [](int d, int in, int target) {         // weight of fine index d on coarse index `target`
+                    float sc = ((float)d + 0.5f) * 0.25f - 0.5f;      // (= bil_src of pointwise.hip)
+                    if (sc < 0.f) sc = 0.f;
+                    const int i0 = (int)sc, i1 = i0 + (i0 < in - 1 ? 1 : 0);
+                    const float l = sc - (float)i0;
+                    return (i0 == target ? 1.f - l : 0.f) + (i1 == target ? l : 0.f);
+                };
+                if (tid < 6 * TW) wxT[tid] = weight(ox0 + tid % TW, CW, 4 * tx - 1 + tid / TW);
+                else if (tid < 6 * TW + 4 * TH) wyT[tid - 6 * TW] = weight(oy0 + (tid - 6 * TW) % TH, CH, 2 * ty - 1 + (tid - 6 * TW) / TH);
+                __syncthreads();
+                constexpr int C4 = NT / 4;
+                for (int o = tid; o < TH * 6 * C4; o += 256) {        // columns: tmp[r][lc][ch4]
+                    const int c4 = o % C4, lc = (o / C4) % 6, r = o / (C4 * 6);
+                    const int c_lo = 4 * lc - 6 > 0 ? 4 * lc - 6 : 0, c_hi = 4 * lc + 2 < TW ? 4 * lc + 2 : TW;
+                    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int c = c_lo; c < c_hi; ++c) {
+                        const float wgt = wxT[lc * TW + c];
+                        const float4 f = *reinterpret_cast<const float4*>(ft + (r * TW + c) * FP + c4 * 4);
+                        t4.x += wgt * f.x; t4.y += wgt * f.y; t4.z += wgt * f.z; t4.w += wgt * f.w;
+                    }
+                    *reinterpret_cast<float4*>(tmp + (r * 6 + lc) * NT + c4 * 4) = t4;
+                }
+                __syncthreads();
+                for (int o = tid; o < 4 * 6 * C4; o += 256) {         // rows: out[lr][lc][ch4]
+                    const int c4 = o % C4, lc = (o / C4) % 6, lr = o / (C4 * 6);
+                    float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int r = 0; r < TH; ++r) {
+                        const float wgt = wyT[lr * TH + r];
+                        const float4 f = *reinterpret_cast<const float4*>(tmp + (r * 6 + lc) * NT + c4 * 4);
+                        t4.x += wgt * f.x; t4.y += wgt * f.y; t4.z += wgt * f.z; t4.w += wgt * f.w;
+                    }
+                    *reinterpret_cast<float4*>(p.up4_partial + (size_t)tile * (4 * 6 * NT) + (lr * 6 + lc) * NT + c4 * 4) = t4;
+                }
+                return;
+            }
+        }
         if (p.act == DH_ACT_RELU) pick(std::true_type{});
         else pick(std::false_type{});
     } else {

@@ -627,6 +627,51 @@ __global__ void absdiff_up4_bwd_kernel(const T* __restrict__ a, const T* __restr
     }
 }
 
+// Second half of the fused backward of |a - b| -> bilinear x4 -> conv3x3 (dh_conv3x3_dgrad_up4 left per-tile coarse partials
+// [tile][4][6][32] fp32, tile = (n, ty, tx) of 8x16 fine pixels covering coarse rows 2 ty - 1 .. 2 ty + 2, columns
+// 4 tx - 1 .. 4 tx + 4): one thread per coarse pixel piece sums the <= 4 tiles that touch it, in a fixed order, and applies
+// the sign of a - b.
+__global__ void absdiff_up4_combine_kernel(const float* __restrict__ partial, const bf16* __restrict__ a, const bf16* __restrict__ b,
+                                           bf16* __restrict__ da, bf16* __restrict__ db, int N, int H, int W) {
+    const int tilesY = H / 2, tilesX = W / 4;            // fine grid 4H x 4W in 8 x 16 tiles
+    GSL(i, (long)N * H * W * 4) {
+        const int c = (int)(i & 3) * 8;
+        long t = i >> 2;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const long n = t / H;
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = 0.f;
+        for (int ty = (iy - 1) >> 1; ty <= (iy + 1) >> 1; ++ty) {          // tiles with 2 ty - 1 <= iy <= 2 ty + 2
+            if (ty < 0 || ty >= tilesY) continue;
+            const int lr = iy - (2 * ty - 1);
+            if (lr < 0 || lr > 3) continue;
+            for (int tx = (ix - 1) >> 2; tx <= (ix + 1) >> 2; ++tx) {      // tiles with 4 tx - 1 <= ix <= 4 tx + 4
+                if (tx < 0 || tx >= tilesX) continue;
+                const int lc = ix - (4 * tx - 1);
+                if (lc < 0 || lc > 5) continue;
+                const float* src = partial + ((((n * tilesY + ty) * tilesX + tx) * 4 + lr) * 6 + lc) * 32 + c;
+                const float4 u = *reinterpret_cast<const float4*>(src), v = *reinterpret_cast<const float4*>(src + 4);
+                g[0] += u.x; g[1] += u.y; g[2] += u.z; g[3] += u.w;
+                g[4] += v.x; g[5] += v.y; g[6] += v.z; g[7] += v.w;
+            }
+        }
+        float u[8], v[8], ga[8], gb[8];
+        ldv(a + i * 8, u);
+        ldv(b + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float df = u[j] - v[j];
+            const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            ga[j] = sg * g[j];
+            gb[j] = -ga[j];
+        }
+        stv(da + i * 8, ga);
+        stv(db + i * 8, gb);
+    }
+}
+
 // |a-b| on small fp32/T row tensors (token differences, networks.py:1311) and its derivative
 template <typename T>
 __global__ void absdiff_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n) {
@@ -1009,6 +1054,16 @@ extern "C" int dh_absdiff_upsample4_bwd(int dtype, const void* a, const void* b,
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(absdiff_up4_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (const bf16*)dy, (bf16*)da, (bf16*)db, N, H, W, C);
     else hipLaunchKernelGGL(absdiff_up4_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (const float*)dy, (float*)da, (float*)db, N, H, W, C);
     DH_CHECK_LAUNCH("absdiff_up4_bwd");
+    return 0;
+}
+// a, b: [N][H][W][32] bf16 (the COARSE maps); partial from dh_conv3x3_dgrad_up4 on the 4H x 4W grid; da, db like a
+extern "C" int dh_absdiff_up4_combine(const float* partial, const void* a, const void* b, void* da, void* db, int N, int H, int W,
+                                      void* stream) {
+    DH_REQUIRE(H % 2 == 0 && W % 4 == 0, "absdiff_up4_combine: coarse map %dx%d must tile into 8x16 fine tiles", H, W);
+    const long n = (long)N * H * W * 4;
+    hipLaunchKernelGGL(absdiff_up4_combine_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), partial, (const bf16*)a,
+                       (const bf16*)b, (bf16*)da, (bf16*)db, N, H, W);
+    DH_CHECK_LAUNCH("absdiff_up4_combine");
     return 0;
 }
 extern "C" int dh_absdiff(int dtype, const void* a, const void* b, void* y, long n, void* stream) {

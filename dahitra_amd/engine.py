@@ -91,6 +91,9 @@ class Engine:
         # Measured: the launch does overlap the encoder's backward in the graph (rocprofv3 trace: 120 us next to encoder_bwd /
         # encoder_wgrad / tok_bwd instead of 63 us alone), but those kernels slow down by 28 us and the forked graph costs more
         # than the rest: 7950 vs 8010 pairs/s over five interleaved 150-step runs.  Off by default (DAHITRA_SIDE_STREAM=1).
+        # bf16: the data gradient of classifier.0 goes straight to the coarse |A - B| maps (the 32 x 256 x 256 gradient of the
+        # bilinear-upsampled map is never written or re-read): DAHITRA_NO_FUSED_UP4_BWD=1 restores the two-kernel path
+        self.fused_up4_bwd = os.environ.get("DAHITRA_NO_FUSED_UP4_BWD", "0") != "1"
         self.use_side = os.environ.get("DAHITRA_SIDE_STREAM", "0") == "1"
         self.side = None
         self._deferred_wgrad = None
@@ -219,7 +222,8 @@ class Engine:
             return out, None
         has_res = residual is not None
 
-        def bwd(dout, need_dx=True, dx_res=None, next_gate=None, coarse_dx=False):
+        def bwd(dout, need_dx=True, dx_res=None, next_gate=None, coarse_dx=False, through_up4=None):
+            """through_up4 = (a, b, da, db): this conv's input is bilinear_x4(|a - b|); the gradients land in da, db"""
             if isinstance(dout, Gated):       # ReLU mask and the reduction pass were done by the producer of dout
                 dy = ops.bn_bwd_from_partials(dout.g, y, dout.partial, mean, invstd, gamma, self.g[bnkey + ".weight"],
                                               self.g[bnkey + ".bias"], groups, accumulate=True)
@@ -241,6 +245,8 @@ class Engine:
             else:
                 ops.conv2d_wgrad(x, dy, self.g[wkey], ks, stride, pad, accumulate=True, use_tr=self.use_tr,
                                  dilation=dilation)
+            if through_up4 is not None:
+                return ops.conv3x3_dgrad_through_up4(dy, self.pk[wkey].dgrad, *through_up4), dres
             dx = self.conv_dgrad(dy, wkey, ks, stride, pad, x.shape, residual=dx_res, dilation=dilation,
                                  gate=next_gate, coarse=coarse_dx) if need_dx else None
             return dx, dres
@@ -846,9 +852,15 @@ class Engine:
         def bwd_first(dl):
             """head, decoder, tokens, conv_pred, layer3: everything whose parameters sit behind layer2 in the arena"""
             dh = b_out(dl, next_gate=b_c0.gate, head_bn=getattr(b_c0, "bn", None))
-            dupd, _ = b_c0(dh)
-            dec_g = torch.empty_like(dec4)
-            ops.absdiff_upsample4_bwd_into(dec4[:B], dec4[B:], dupd, dec_g[:B], dec_g[B:])
+            fuse = self.fused_up4_bwd and self.dtype == torch.bfloat16 and fh % 2 == 0 and fw % 4 == 0 and \
+                self.pk["classifier.0.weight"].dgrad.dim() == 3 and self.pk["classifier.0.weight"].dgrad.shape[1] == 32
+            if fuse:
+                dec_g = torch.empty_like(dec4)
+                b_c0(dh, through_up4=(dec4[:B], dec4[B:], dec_g[:B], dec_g[B:]))
+            else:
+                dupd, _ = b_c0(dh)
+                dec_g = torch.empty_like(dec4)
+                ops.absdiff_upsample4_bwd_into(dec4[:B], dec4[B:], dupd, dec_g[:B], dec_g[B:])
             dfeat = b_dec(dec_g.view(S2 * hw, DIM))                    # also fills dtok
             if self.side is not None:
                 self.run_deferred_wgrad()            # the classifier's weight gradient, next to the encoder's backward

@@ -888,6 +888,23 @@ def absdiff_upsample4_bwd(a, b, dy):
     return da, db
 
 
+def conv3x3_dgrad_through_up4(dy, wdgrad, a, b, da=None, db=None):
+    """backward of conv3x3(bilinear_x4(|a - b|)) with respect to a and b, from dy [N, 4H, 4W, K] (gradient of the conv's
+    output) and the conv's data-gradient pack [9, 32, K]: the fine-grid gradient [N, 4H, 4W, 32] is never written -- the
+    convolution reduces each tile to the coarse pixels it interpolates from, a second small launch sums and applies the sign.
+    Returns (da, db) like a, b [N, H, W, 32] bf16."""
+    N, H, W, C = a.shape
+    assert C == 32 and a.dtype == torch.bfloat16 and dy.shape[:3] == (N, 4 * H, 4 * W) and wdgrad.shape[-2] == 32
+    L = _lib.lib()
+    partial = torch.empty(L.dh_conv3x3_dgrad_up4_partial_floats(N, 4 * H, 4 * W), dtype=torch.float32, device=a.device)
+    with _Prof("conv_mfma<bf16,ks3,s1,nt32>", 2.0 * N * 16 * H * W * 32 * dy.shape[-1] * 9, _nb(dy, wdgrad, partial)):
+        _call("dh_conv3x3_dgrad_up4", _ci(dt(dy)), P(dy), P(wdgrad), _ci(N), _ci(4 * H), _ci(4 * W), _ci(dy.shape[-1]), P(partial), S())
+    da = torch.empty_like(a) if da is None else da
+    db = torch.empty_like(b) if db is None else db
+    _call("dh_absdiff_up4_combine", P(partial), P(a), P(b), P(da), P(db), _ci(N), _ci(H), _ci(W), S())
+    return da, db
+
+
 def absdiff(a, b):
     y = torch.empty_like(a)
     _call("dh_absdiff", _ci(dt(a)), P(a), P(b), P(y), _cl(a.numel()), S())

@@ -79,6 +79,15 @@ int dh_conv2d_fwd_num_tiles(int N, int OH, int OW, int Cin, int ks, int stride);
  * (everything through the tap-oriented kernel); 1: wherever it can run.  Returns the previous mode.  Same reference call sites as dh_conv2d_fwd
  * (models/resnet.py:24-73: BasicBlock conv1 / conv2 and their input gradients). */
 int dh_conv_wreg_mode(int mode);
+/* The backward of |a - b| -> nn.Upsample(4, 'bilinear') -> conv3x3 (models/networks.py:383-389; autograd's
+ * upsample_bilinear2d_backward + convolution_backward input gradient) WITHOUT the fine-grid gradient tensor: the data-gradient
+ * launch of the 3x3 convolution (dy [N][H][W][K] bf16, w_packed = its data-gradient pack [9][32][K]) reduces each 8x16 tile
+ * to the 4 x 6 coarse pixels it interpolates from and writes fp32 partials (dh_conv3x3_dgrad_up4_partial_floats of them);
+ * dh_absdiff_up4_combine sums the <= 4 tiles of every coarse pixel of the [N][H/4][W/4][32] maps a, b and applies
+ * sign(a - b): da, db.  bf16 mode; H % 8 == 0, W % 16 == 0. */
+long dh_conv3x3_dgrad_up4_partial_floats(int N, int H, int W);
+int dh_conv3x3_dgrad_up4(int dtype, const void* dy, const void* w_packed, int N, int H, int W, int K, float* partial, void* stream);
+int dh_absdiff_up4_combine(const float* partial, const void* a, const void* b, void* da, void* db, int N, int H, int W, void* stream);
 /* The class head -- classifier[-1]: nn.Conv2d(32, n_class, 3, padding 1) (models/networks.py:201-204, 1121-1129) -- with the
  * fp32 NCHW logits [N][Cout][H][W] (the reference's output layout) written by the convolution itself: no NHWC logits tensor,
  * no layout pass.  w_packed: dh_pack_weight with OPad = 16; in_scale / in_shift (optional): BatchNorm-apply + ReLU on load. */

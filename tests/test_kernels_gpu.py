@@ -1074,3 +1074,32 @@ def test_conv3x3_register_resident_weights_equals_tap_kernel(ops, cfg):
         for g in range(groups):          # per BatchNorm group, as bn_finalize sums them
             a0, a1 = s0[:, :, g * per_g:(g + 1) * per_g].sum(2), s1[:, :, g * per_g:(g + 1) * per_g].sum(2)
             assert float((a0 - a1).abs().max()) <= 2e-5 * float(a0.abs().max())
+
+
+@pytest.mark.parametrize("cfg", [dict(n=2, h=16, w=24, k=32), dict(n=32, h=64, w=64, k=32), dict(n=3, h=6, w=8, k=64)])
+def test_conv3x3_data_gradient_through_bilinear_up4_without_the_fine_tensor(ops, cfg):
+    """backward of conv3x3(bilinear_x4(|a - b|)) (models/networks.py:383-389): the fused pair dh_conv3x3_dgrad_up4 +
+    dh_absdiff_up4_combine against (i) the two-kernel path it replaces (data gradient written at 4H x 4W in bf16, then the
+    gather kernel) and (ii) torch autograd in fp32"""
+    dtype = torch.bfloat16
+    N, H, W, K = cfg["n"], cfg["h"], cfg["w"], cfg["k"]
+    a = rnd((N, 32, H, W), dtype, 901).requires_grad_(True)
+    b = rnd((N, 32, H, W), dtype, 902).requires_grad_(True)
+    w = rnd((K, 32, 3, 3), dtype, 903, scale=(32 * 9) ** -0.5)
+    dy = rnd((N, K, 4 * H, 4 * W), dtype, 904)
+    up = F.interpolate((a - b).abs(), scale_factor=4, mode="bilinear", align_corners=False)
+    F.conv2d(up, w, None, 1, 1).backward(dy)
+    _, wd = ops.pack_weight(w.cuda(), dtype, want_dgrad=True, dgrad_inner=K)
+    ad, bd, dyd = dev(nhwc(a.detach()), dtype), dev(nhwc(b.detach()), dtype), dev(nhwc(dy), dtype)
+    da, db = ops.conv3x3_dgrad_through_up4(dyd, wd, ad, bd)
+    dfine = ops.conv2d(dyd, wd, 32, 3, 1, 1)                         # the path it replaces
+    da2, db2 = ops.absdiff_upsample4_bwd(ad, bd, dfine)
+    scale = float(a.grad.abs().max())
+    close(nchw(da), a.grad, dtype, "da (fused) vs torch", scale=scale)
+    close(nchw(db), b.grad, dtype, "db (fused) vs torch", scale=scale)
+    assert float((da.float() - da2.float()).abs().max()) <= 2.0 ** -6 * scale      # the old path rounds the fine gradient to bf16
+    assert torch.equal(db, -da) or float((db.float() + da.float()).abs().max()) == 0.0
+    # more accurate than the path it replaces (fp32 from the accumulators to the coarse sum)
+    e_new = float((nchw(da).float().cpu() - a.grad).abs().mean())
+    e_old = float((nchw(da2).float().cpu() - a.grad).abs().mean())
+    assert e_new <= e_old * 1.05 + 1e-9, (e_new, e_old)
