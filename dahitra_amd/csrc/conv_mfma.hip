@@ -17,7 +17,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
                              int OH, int OW, int Cout, int CoutPad, int ks, int stride, int pad, int act,
                              int npix_valid, long w_image_stride, void* y_preact, int dilation, const void* gate_out,
                              const void* gate_y, const float* gate_mean, const float* gate_invstd, int gate_groups,
-                             const float* in_scale, const float* in_shift, int in_groups, int phase_mode, int w_chunk_major,
+                             const float* in_scale, const float* in_shift, int in_groups, int phase_mode, const void* w_frag,
                              void* stream) {
     const int esz = dtype == DH_DTYPE_BF16 ? 2 : 4;
     DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "conv2d_fwd: bad dtype %d", dtype);
@@ -43,8 +43,9 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     a.phase_mode = phase_mode;
     a.y_nchw = nullptr;
     a.up4_partial = nullptr;
-    a.w_cm = w_chunk_major ? 1 : 0;
-    DH_REQUIRE(!w_chunk_major || (ks == 3 && w_image_stride == 0 && !phase_mode), "conv2d_fwd: chunk-major weights are packed for the 3x3 layers only");
+    a.w_frag = w_frag;
+    DH_REQUIRE(!w_frag || (ks == 3 && w_image_stride == 0 && !phase_mode && dtype == DH_DTYPE_BF16 && Cin % 32 == 0 && CoutPad % 16 == 0),
+               "conv2d_fwd: fragment-order weights exist for the bf16 3x3 layers only");
     static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
     a.no_xcd_remap = no_remap;
     if (phase_mode) {
@@ -65,7 +66,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
 
 // The class head (3x3, pad 1, <= 16 classes) with fp32 NCHW logits written by the convolution itself: see ConvArgs::y_nchw.
 extern "C" int dh_conv3x3_head_fwd(int dtype, const void* x, const void* w_packed, const float* bias, int N, int H, int W, int Cin,
-                                   int Cout, const float* in_scale, const float* in_shift, int in_groups, int w_chunk_major,
+                                   int Cout, const float* in_scale, const float* in_shift, int in_groups,
                                    float* logits_nchw, void* stream) {
     const int esz = dtype == DH_DTYPE_BF16 ? 2 : 4;
     DH_REQUIRE(dtype == DH_DTYPE_F32 || dtype == DH_DTYPE_BF16, "conv3x3_head_fwd: bad dtype %d", dtype);
@@ -81,7 +82,6 @@ extern "C" int dh_conv3x3_head_fwd(int dtype, const void* x, const void* w_packe
     static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
     a.no_xcd_remap = no_remap;
     a.y_nchw = logits_nchw;
-    a.w_cm = w_chunk_major ? 1 : 0;
     a.rw = pick_rw(N, H, W, Cin, 3, 1);
     a.tilesX = dh_cdiv(W, TW); a.tilesY = dh_cdiv(H, 4 * a.rw);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -88,9 +88,9 @@ struct ConvArgs {
     // class head (NT = 16 instantiations only): the Cout real channels (+ bias) are written as fp32 NCHW logits
     // [N][Cout][OH][OW] straight from the accumulators -- the reference's output layout -- and nothing goes to y
     float* y_nchw;
-    // weights CHUNK-MAJOR: [Cin / CK][taps][CoutPad][CK] (CK = one 64-byte chunk) instead of [taps][CoutPad][Cin] -- the
-    // staging of a chunk then reads whole cache lines (dh_pack_weights_multi, dtype | 0x100)
-    int w_cm;
+    // the same weights in FRAGMENT order [CoutPad / 16][Cin / 32][9][64][8] (dh_pack_weights_multi, dtype | 0x200), or null:
+    // read by the register-resident-weights kernel (conv_wreg.hip) only
+    const void* w_frag;
     // Data gradient THROUGH the bilinear x4 upsample in front of this convolution's input (compact epilogue, NT = 32, 8x16
     // tiles): the tile is not stored; it is reduced, in fp32, to the 4 x 6 coarse pixels its 8 x 16 fine pixels interpolate
     // from (align_corners = False: fine row o reads coarse rows floor((o + 0.5) / 4 - 0.5) and the next, clamped) and the
@@ -201,13 +201,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     // the output channel stays -- one per-lane offset plus a uniform step
     static_assert(64 % NT == 0, "weight staging assumes NT divides 64");
     const int wrow = tid >> 2;
-    const unsigned wrowb = p.w_cm ? 64u : (unsigned)p.Cin * (unsigned)sizeof(T);          // bytes per staged weight row in memory
+    const unsigned wrowb = (unsigned)p.Cin * (unsigned)sizeof(T);                          // bytes per staged weight row in memory
     const unsigned woff0 = (unsigned)((wrow / NT) * p.CoutPad + co0 + (wrow % NT)) * wrowb + (tid & 3) * 16;
     const unsigned wstep = (unsigned)((64 / NT) * p.CoutPad) * wrowb;
-    const size_t wchunk = p.w_cm ? (size_t)TAPS * p.CoutPad * 64 / CK : sizeof(T);         // bytes per channel of chunk advance
     auto fetch = [&](int c0) {
         const unsigned char* xb = xin + (size_t)c0 * sizeof(T);
-        const unsigned char* wb = wgt + (size_t)c0 * wchunk;
+        const unsigned char* wb = wgt + (size_t)c0 * sizeof(T);
         if constexpr (KS == 2) {
             if (p.phase_mode == 2) {       // chunk -> (phase, channel offset inside the phase's 32 channels)
                 if (c0 > 0 && (c0 & 31) == 0) set_hoff(c0 >> 5);
@@ -588,6 +587,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
 // rows per wavefront: 16x16-pixel tiles (RW = 4) for 3x3 stride-1 layers with enough tiles to fill the
 // chip -- half the weight staging per FLOP and 8 instead of 6 LDS fragment reads per 16 MFMAs
 static inline int pick_rw(int N, int OH, int OW, int Cin, int ks, int stride) {
+    // (16-row tiles for the 32-channel 256x256 head convolutions: measured neutral, 3.834 vs 3.840 ms per step)
     // (layers with 1-2 channel chunks have nothing to pipeline and prefer more, smaller workgroups)
     if ((ks == 3 || ks == 2) && stride == 1 && Cin >= 128 && OH >= 16 && (long)N * dh_cdiv(OH, 16) * dh_cdiv(OW, TW) >= 256) return 4;
     return 2;

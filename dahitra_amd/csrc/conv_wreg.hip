@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
     constexpr int NB = PFD + 1;                            // fragment registers (rolling)
     static_assert(TSTEPS % NB == 0, "the rolling fragment buffer must line up at a tile change");
     static_assert(D >= 3 && D - 1 <= 2 * NCH + 1, "ring depth");
-    constexpr int SYNC = INBN ? 10 : 14;                   // step of a stage at which the next stage is published
+    constexpr int SYNC = 14;                               // step of a stage at which the next stage is published
+    constexpr int BN0 = 2;                                 // INBN: steps BN0 .. BN0 + 2 WR_NI carry the next stage's transform
     constexpr bool STATIC_SLOT = NCH % D == 0;
     constexpr int NCO = 64 * NSUB;                         // output channels per workgroup
     constexpr int TPITCH = NCO * 2 + 16;                   // transposed output tile: bytes per pixel
@@ -188,23 +189,33 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
     };
     // INBN: BatchNorm-apply + ReLU of the previous layer on chunk image c of tile t, in place, by the lane whose load brought
     // the piece (padding pieces stay zero: they are padding of the POST-activation tensor)
-    auto bn_transform = [&](const WrTile& t, int c, int slot) {
+    // one piece at a time, in two halves that the stream loop places in DIFFERENT steps (the LDS reads of the first half are
+    // under way while the MFMAs of a step issue; the second half's ~30 VALU instructions slot in between the MFMAs of a later
+    // step): done back to back at the publication point it cost ~600 cycles per 1450-cycle stage (85.7 vs 60.0 us on 256 -> 256)
+    uint4 bn_px;
+    float bn_sc[8], bn_sh[8];
+    auto bn_load = [&](const WrTile& t, int c, int slot, int i) {
         const int grp = t.n / (p.N / p.in_groups);
+        const unsigned char* pc = ring + slot * WR_IMG + ((i * 4 + wv) * 64 + lane) * 16;
+        const float* sp = bnp + grp * 2 * Cin + c * 32 + ((wr_opaque(hyx[i]) >> 16) & 3) * 8;
+        *reinterpret_cast<float4*>(bn_sc) = *reinterpret_cast<const float4*>(sp);
+        *reinterpret_cast<float4*>(bn_sc + 4) = *reinterpret_cast<const float4*>(sp + 4);
+        *reinterpret_cast<float4*>(bn_sh) = *reinterpret_cast<const float4*>(sp + Cin);
+        *reinterpret_cast<float4*>(bn_sh + 4) = *reinterpret_cast<const float4*>(sp + Cin + 4);
+        bn_px = *reinterpret_cast<const uint4*>(pc);
+    };
+    auto bn_store = [&](const WrTile& t, int slot, int i) {
+        if (t.off(i) == ~0u) return;                       // padding of the POST-activation tensor stays zero
+        unsigned char* pc = ring + slot * WR_IMG + ((i * 4 + wv) * 64 + lane) * 16;
+        float v[8];
+        unpack16(bn_px, v);
 #pragma unroll
-        for (int i = 0; i < WR_NI; ++i) {
-            if (t.off(i) == ~0u) continue;
-            unsigned char* pc = ring + slot * WR_IMG + ((i * 4 + wv) * 64 + lane) * 16;
-            const float* sp = bnp + grp * 2 * Cin + c * 32 + ((wr_opaque(hyx[i]) >> 16) & 3) * 8;
-            float sc[8], sh[8], v[8];
-            *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(sp);
-            *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(sp + 4);
-            *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(sp + Cin);
-            *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(sp + Cin + 4);
-            unpack16(*reinterpret_cast<const uint4*>(pc), v);
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * bn_sc[e] + bn_sh[e], 0.f);
+        *reinterpret_cast<uint4*>(pc) = pack16<bf16>(v);
+    };
+    auto bn_transform = [&](const WrTile& t, int c, int slot) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
-            *reinterpret_cast<uint4*>(pc) = pack16<bf16>(v);
-        }
+        for (int i = 0; i < WR_NI; ++i) { bn_load(t, c, slot, i); bn_store(t, slot, i); }
     };
 
     f32x4 acc[NSUB][WR_TH];
@@ -266,14 +277,20 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
 #pragma unroll
         for (int i = 0; i < NSTEP; ++i) {
             const int gg = st * NSTEP + i, kw = i / WR_HH, h = i - kw * WR_HH;
+            if constexpr (INBN) {
+                // BatchNorm + ReLU of the NEXT stage's image, spread over steps BN0 .. (see bn_load)
+                const int nx = st + 1;
+                if (i == BN0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 3) * WR_NI) : "memory");      // its loads have landed
+                if (i >= BN0 && i < BN0 + 2 * WR_NI) {
+                    const int k = (i - BN0) >> 1;
+                    if (((i - BN0) & 1) == 0) bn_load(tile_at(nx / NCH), nx % NCH, slot_of(nx), k);
+                    else bn_store(tile_at(nx / NCH), slot_of(nx), k);
+                }
+            }
             if (i == SYNC) {
                 // publish stage st + 1 (of this tile, or stage 0 of the next one), then refill the slot of stage st - 1
-                const int nx = st + 1;
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 3) * WR_NI) : "memory");
-                if constexpr (INBN) {
-                    bn_transform(tile_at(nx / NCH), nx % NCH, slot_of(nx));
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
+                if constexpr (INBN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the transform's writes
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 3) * WR_NI) : "memory");
                 __builtin_amdgcn_s_barrier();              // (raw: __syncthreads would drain the loads in flight)
                 asm volatile("" ::: "memory");
                 const int far = st + D - 1;
@@ -384,8 +401,8 @@ int wr_launch(const ConvArgs& c, hipStream_t st, int cus) {
     if (J > a.nunits) J = (a.nunits + 7) & ~7;
     if (J < 8) J = 8;
     a.J = J;
-    static const int wfrag = getenv("DAHITRA_WREG_FRAG") ? 1 : 0;      // experiment (tools/wreg_timeline.py)
-    a.wfrag = wfrag;
+    a.wfrag = c.w_frag != nullptr;
+    if (a.wfrag) a.c.w = c.w_frag;
     const size_t lds = (size_t)D * WR_IMG + (size_t)WR_TH * TW * (NCO * 2 + 16) + (INBN ? (size_t)c.in_groups * 2 * c.Cin * 4 : 0);
     auto kern = conv3x3_wreg_kernel<NSUB, NCH, D, PFD, INBN, WPS>;
     static bool attr_done = false;
@@ -421,19 +438,23 @@ bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     static const bool off = getenv("DAHITRA_NO_WREG") != nullptr;
     if (off || g_wreg_mode == 0 || dtype != DH_DTYPE_BF16 || ks != 3 || stride != 1 || a.dil != 1 || a.pad != 1) return false;
     if (a.Cin != 64 && a.Cin != 128 && a.Cin != 256) return false;
-    if (a.Cout % 64 || a.CoutPad != a.Cout || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride || a.w_cm) return false;
+    if (a.Cout % 64 || a.CoutPad != a.Cout || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride) return false;
     if (a.act == DH_ACT_GELU || a.npix != a.OH * a.OW || a.in_npix != a.H * a.W || a.OH != a.H || a.OW != a.W) return false;
     if (a.OH % (a.rw == 4 ? 16 : 8) || a.OW % 16) return false;
     if (a.in_scale && a.in_groups > 4) return false;
     if (a.Cin == 128 && a.Cout % 128 && wr_variant() == 0) return false;
     if (g_wreg_mode != 1) {
-        // measured (tools/wreg_bench.py, 64 images): the shapes on which this kernel is the faster one -- the 64-channel
-        // layers (x1.10 - 1.19).  On 256 -> 256 it ties the tap kernel (70.4 vs 70.5 us), on 128 input channels it loses
-        // (the 295 KB of weights per workgroup are loaded for two tiles only); DESIGN.md section 6c has the timeline.
-        if (a.Cin != 64) return false;
+        // measured (tools/wreg_bench.py, 64 images, gpurun_out/wreg_bench_[45]_*.txt): the shapes on which this kernel is the
+        // faster one -- the 64-channel layers (x1.14 - 1.23, also with BatchNorm on load) and, given the fragment-order weights,
+        // 256 input channels without BatchNorm on load (x1.04 - 1.08; with it x0.86: one wave per SIMD cannot hide the in-LDS
+        // transform).  128 input channels lose (x0.7: 295 KB of weights per workgroup for two tiles).  DESIGN.md section 6c.
+        if (!(a.Cin == 64 || (a.Cin == 256 && a.w_frag && !a.in_scale))) return false;
     }
-    // every persistent workgroup should see at least two tiles (the weights of a workgroup are 74 - 295 KB)
-    return (long)a.N * (a.OH / 8) * (a.OW / 16) * (a.Cout / 64) >= 2 * 256;
+    // a persistent workgroup must see enough tiles to amortise loading its weights (74 KB at 64 input channels, two workgroups
+    // per CU; 295 KB at 256, one per CU): measured at 4 resp. 8 tiles per workgroup, required here: >= 4 resp. >= 6
+    const long work = (long)a.N * (a.OH / 8) * (a.OW / 16) * (a.Cout / 64);
+    if (g_wreg_mode == 1) return work >= 2 * 256;
+    return a.Cin == 64 ? work >= 4 * 512 : work >= 6 * 256;
 }
 
 // C ABI (include/dahitra_hip.h): route the eligible 3x3 convolutions through the tap-oriented kernel instead (mode 0), or

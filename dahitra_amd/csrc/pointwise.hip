@@ -737,36 +737,33 @@ struct PackJob {
     void* fwd;          // [taps][OPad][I] or null
     void* dgrad;        // [taps][IPad][OK] (flipped taps) or null
     int O, I, KS, OPad, IPad, OK;
-    int dtype;          // DH_DTYPE_* | 0x100: CHUNK-MAJOR destinations (see below)
+    int dtype;          // DH_DTYPE_* | 0x200: FRAGMENT-ORDER destinations (see below)
     int first_block, nblocks;
 };
-// Chunk-major: [K / CK][taps][rows][CK] with CK = one 64-byte chunk of the reduction dimension (32 bf16 / 16 fp32 channels)
-// instead of [taps][rows][K].  The conv kernel stages one chunk of all taps and 64 rows at a time: in the row-major form that is a
-// 64-byte piece out of every 2 K-byte row, i.e. HALF of each 128-byte cache line -- the L2 served twice the weight bytes
-// (TCC_HIT + TCC_MISS of the layer3 conv: 7.7 M requests = 986 MB per launch = 14 TB/s, the same ~15 TB/s on every conv shape);
-// chunk-major makes the 4 KB of a (chunk, tap, 64 rows) block contiguous.
+// Fragment order (bf16, 3x3): [rows / 16][K / 32][taps][64 lanes][8] -- the 1 KiB a wavefront of csrc/conv_wreg.hip loads as ONE
+// MFMA A fragment (lane (pl = lane & 15, g = lane >> 4): row 16 r + pl, reduction channels 32 c + 8 g .. + 7) is contiguous, so
+// the once-per-workgroup load of the register-resident weights reads whole cache lines (measured: 10.2 -> 5.0 us for the
+// 295 KB of a 64 x 256-channel block).  rows = output channels (forward) / input channels (data gradient, flipped taps).
 template <typename T>
 __device__ __forceinline__ void pack_job(const PackJob& j, int lb) {
     const int taps = j.KS * j.KS;
     const long step = (long)j.nblocks * blockDim.x;
     T* fwd = reinterpret_cast<T*>(j.fwd);
     T* dgrad = reinterpret_cast<T*>(j.dgrad);
-    if (j.dtype & 0x100) {
-        constexpr int CK = 64 / (int)sizeof(T);
+    if (j.dtype & 0x200) {
+        const int nch_f = j.I / 32, nch_d = j.OK / 32;
         if (fwd)
             for (long i = (long)lb * blockDim.x + threadIdx.x; i < (long)taps * j.OPad * j.I; i += step) {
-                const int cl = (int)(i % CK);
-                const int o = (int)((i / CK) % j.OPad);
-                const int tap = (int)((i / ((long)CK * j.OPad)) % taps);
-                const int ci = (int)(i / ((long)CK * j.OPad * taps)) * CK + cl;
+                const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), tap = (int)((i >> 9) % taps);
+                const int c = (int)((i / (512L * taps)) % nch_f), r16 = (int)(i / (512L * taps * nch_f));
+                const int o = r16 * 16 + (lane & 15), ci = c * 32 + (lane >> 4) * 8 + e;
                 stf(fwd + i, o < j.O ? j.w[((long)o * j.I + ci) * taps + tap] : 0.f);
             }
         if (dgrad)
             for (long i = (long)lb * blockDim.x + threadIdx.x; i < (long)taps * j.IPad * j.OK; i += step) {
-                const int ol = (int)(i % CK);
-                const int ci = (int)((i / CK) % j.IPad);
-                const int tap = (int)((i / ((long)CK * j.IPad)) % taps);
-                const int o = (int)(i / ((long)CK * j.IPad * taps)) * CK + ol;
+                const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), tap = (int)((i >> 9) % taps);
+                const int c = (int)((i / (512L * taps)) % nch_d), r16 = (int)(i / (512L * taps * nch_d));
+                const int ci = r16 * 16 + (lane & 15), o = c * 32 + (lane >> 4) * 8 + e;
                 stf(dgrad + i, (ci < j.I && o < j.O) ? j.w[((long)o * j.I + ci) * taps + (taps - 1 - tap)] : 0.f);
             }
         return;

@@ -23,10 +23,12 @@ RELU, GELU, NONE = ops.ACT_RELU, ops.ACT_GELU, ops.ACT_NONE
 
 
 class Packed:
-    __slots__ = ("fwd", "dgrad")
+    """kernel-layout copies of one weight: forward / data-gradient form, and (bf16 3x3 layers the register-resident-weights
+    convolution may serve) the same two in fragment order"""
+    __slots__ = ("fwd", "dgrad", "fwd_frag", "dgrad_frag")
 
-    def __init__(self, fwd, dgrad):
-        self.fwd, self.dgrad = fwd, dgrad
+    def __init__(self, fwd, dgrad, fwd_frag=None, dgrad_frag=None):
+        self.fwd, self.dgrad, self.fwd_frag, self.dgrad_frag = fwd, dgrad, fwd_frag, dgrad_frag
 
 
 class Gated:
@@ -79,10 +81,6 @@ class Engine:
         self.fused_head_out = os.environ.get("DAHITRA_NO_FUSED_HEAD", "0") != "1"
         # one finalize launch for the parameter gradients of all layers of a fused decoder stack
         self.defer_dec_finalize = os.environ.get("DAHITRA_NO_DEFER_DEC_FINALIZE", "0") != "1"
-        # packed 3x3 weights chunk-major ([Cin / 32][tap][Cout][32]): the conv kernel's weight staging reads whole cache lines.
-        # Measured NEUTRAL at the step level (8001 vs 8013 pairs/s; layer3 conv 74.9 -> 72.2 us alone): halving the weight
-        # requests at the L2 does not move a kernel that is bound by the latency of its staging round trips.  Off by default.
-        self.chunk_major_weights = os.environ.get("DAHITRA_CM_WEIGHTS", "0") == "1"
         # class-head data gradient gated for the classifier's BatchNorm (mask + BN-backward sums in its epilogue).  Measured
         # neutral (8020 vs 8027 pairs/s: the reduction pass it removes costs what the extra read of y costs the head kernel):
         # off by default, DAHITRA_GATED_HEAD=1 turns it on.
@@ -162,10 +160,12 @@ class Engine:
                 # |token2 - token1|, which bf16 rounding would wipe out (csrc/tokens.hip header)
                 dt = torch.float32
             c = ops.chunk_channels(dt)
-            # 3x3 weights in the chunk-major form (whole cache lines per staged chunk; consumed by ops.conv2d / conv3x3_head only)
-            cm = self.chunk_major_weights and len(shape) == 4 and shape[2] == 3 and shape[1] % c == 0
-            f, d = pack.add(self.p[key], dt, want_dgrad=self.need_grad, dgrad_inner=-(-O // c) * c, chunk_major=cm)
-            pk[key] = Packed(f, d)
+            f, d = pack.add(self.p[key], dt, want_dgrad=self.need_grad, dgrad_inner=-(-O // c) * c)
+            ff = dd = None
+            if dt == torch.bfloat16 and len(shape) == 4 and shape[2] == 3 and O in (64, 128, 256) and shape[1] in (64, 128, 256):
+                # the layers conv_wreg.hip may serve (it decides per launch): a second copy in fragment order
+                ff, dd = pack.add(self.p[key], dt, want_dgrad=self.need_grad, dgrad_inner=O, frag=True)
+            pk[key] = Packed(f, d, ff, dd)
         return pack, pk, xstack
 
     # ---- primitive units -------------------------------------------------------------------------
@@ -192,7 +192,8 @@ class Engine:
         if stride == 2:
             dy = ops.zero_insert2(dy, H, W)
         r = ops.conv2d(dy, self.pk[wkey].dgrad, Cin, ks, 1, dilation * (ks - 1) - pad, residual=residual,
-                       out_hw=(H, W), alg_flops=flops, dilation=dilation, gate=gate)
+                       out_hw=(H, W), alg_flops=flops, dilation=dilation, gate=gate,
+                       w_frag=self.pk[wkey].dgrad_frag if stride == 1 else None)
         return Gated(*r) if gate is not None else r
 
     def conv_bn(self, x, wkey, bnkey, ks, stride, pad, groups, relu, residual=None, dilation=1, lazy=False, side_wgrad=False):
@@ -207,7 +208,8 @@ class Engine:
         rm, rv = self.p[bnkey + ".running_mean"], self.p[bnkey + ".running_var"]
         act = RELU if relu else NONE
         if self.training:
-            y, st = ops.conv2d(x, self.pk[wkey].fwd, cout, ks, stride, pad, want_stats=True, dilation=dilation)
+            y, st = ops.conv2d(x, self.pk[wkey].fwd, cout, ks, stride, pad, want_stats=True, dilation=dilation,
+                               w_frag=self.pk[wkey].fwd_frag if stride == 1 else None)
             N, OH, OW, _ = y.shape
             mean, invstd, scale, shift = ops.bn_finalize(st, cout, groups, (N // groups) * OH * OW, gamma, beta, rm, rv,
                                                          BN_MOMENTUM, BN_EPS, nbt=self.p[bnkey + ".num_batches_tracked"])

@@ -123,20 +123,21 @@ class PackPlan:
     def __init__(self, device):
         self.device, self.jobs, self.blocks, self.table, self.keep = device, [], 0, None, []
 
-    def add(self, w, dtype, want_fwd=True, want_dgrad=True, dgrad_inner=0, out_dgrad=None, chunk_major=False):
-        """same contract as pack_weight; returns the (persistent) fwd / dgrad buffers.  chunk_major (3x3 weights, I and
-        dgrad_inner multiples of the 64-byte chunk): 4-D buffers [K / ck, taps, rows, ck] (conv2d recognises them by
-        their rank)"""
+    def add(self, w, dtype, want_fwd=True, want_dgrad=True, dgrad_inner=0, out_dgrad=None, frag=False):
+        """same contract as pack_weight; returns the (persistent) fwd / dgrad buffers.  frag (bf16 3x3 weights, I and
+        dgrad_inner multiples of 32): the buffers are in FRAGMENT order [rows / 16, K / 32, taps, 64, 8] -- what the
+        register-resident-weights convolution loads (conv2d's w_frag); add the layer a second time without it for the
+        row-major form every other kernel reads"""
         if w.dim() == 2:
             (O, I), ks = w.shape, 1
         else:
             O, I, ks, _ = w.shape
         OPad, IPad, OK = pad16(O), pad16(I), max(O, dgrad_inner)
         ck = chunk_channels(dtype)
-        if chunk_major:
-            assert ks == 3 and I % ck == 0 and OK % ck == 0 and out_dgrad is None
-            fwd = torch.empty(I // ck, ks * ks, OPad, ck, dtype=dtype, device=w.device) if want_fwd else None
-            dg = torch.empty(OK // ck, ks * ks, IPad, ck, dtype=dtype, device=w.device) if want_dgrad else None
+        if frag:
+            assert ks == 3 and dtype == torch.bfloat16 and I % 32 == 0 and OK % 32 == 0 and out_dgrad is None
+            fwd = torch.empty(OPad // 16, I // 32, ks * ks, 64, 8, dtype=dtype, device=w.device) if want_fwd else None
+            dg = torch.empty(IPad // 16, OK // 32, ks * ks, 64, 8, dtype=dtype, device=w.device) if want_dgrad else None
         else:
             fwd = torch.empty(ks * ks, OPad, I, dtype=dtype, device=w.device) if want_fwd else None
             dg = out_dgrad if out_dgrad is not None else \
@@ -145,7 +146,7 @@ class PackPlan:
         nb = max(1, min(256, cdiv(n, 1024)))
         self.jobs.append(self._Job(w.data_ptr(), fwd.data_ptr() if fwd is not None else None,
                                    dg.data_ptr() if dg is not None else None, O, I, ks, OPad, IPad, OK,
-                                   _DT[dtype] | (0x100 if chunk_major else 0), self.blocks, nb))
+                                   _DT[dtype] | (0x200 if frag else 0), self.blocks, nb))
         self.blocks += nb
         self.keep += [w, fwd, dg]
         return fwd, dg
@@ -338,7 +339,7 @@ class BnInput:
 
 
 def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT_NONE, want_stats=False,
-           want_preact=False, npix_valid=0, w_image_stride=0, out_hw=None, alg_flops=0, dilation=1, gate=None):
+           want_preact=False, npix_valid=0, w_image_stride=0, out_hw=None, alg_flops=0, dilation=1, gate=None, w_frag=None):
     """gate = (out_relu | None, y_pre_bn, mean, invstd, groups): BN-backward gating of a data-gradient launch; the
     call then returns (g, partials) for bn_bwd_from_partials (see include/dahitra_hip.h).
     x may be a BnInput: BatchNorm-apply + ReLU happen on load."""
@@ -366,8 +367,7 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     with _Prof(key, flops, _nb(x, y, wp, residual, pre)):
         _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
               _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
-              _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), *_bn_in_args(bn_in), _ci(0), _ci(int(wp.dim() == 4)),
-              S())
+              _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), *_bn_in_args(bn_in), _ci(0), P(w_frag), S())
     out = [y]
     if want_stats:
         out.append(stats)
@@ -388,7 +388,7 @@ def conv3x3_head(x, wp, ncls, bias):
     key = "conv_mfma<%s,ks3,s1,nt16>" % ("bf16" if x.dtype == torch.bfloat16 else "f32")
     with _Prof(key, 2.0 * N * H * W * ncls * Cin * 9, _nb(x, out, wp)):
         _call("dh_conv3x3_head_fwd", _ci(dt(x)), P(x), P(wp), P(bias), _ci(N), _ci(H), _ci(W), _ci(Cin), _ci(ncls),
-              *_bn_in_args(bn_in), _ci(int(wp.dim() == 4)), P(out), S())
+              *_bn_in_args(bn_in), P(out), S())
     return out
 
 
@@ -409,7 +409,7 @@ def linear(x2d, wp, cout, bias=None, residual=None, act=ACT_NONE, want_preact=Fa
     pre = torch.empty_like(y) if want_preact else None
     _call("dh_conv2d_fwd", _ci(dt(x2d)), P(x2d), P(wp), P(y), P(bias), P(residual), _vp(0), _ci(images), _ci(Hh),
           _ci(16), _ci(Cin), _ci(Hh), _ci(16), _ci(cout), _ci(cpad), _ci(1), _ci(1), _ci(0), _ci(act), _ci(rpi),
-          _cl(w_image_stride), P(pre), _ci(1), *_gate_args(None), *_bn_in_args(None), _ci(0), _ci(0), S())
+          _cl(w_image_stride), P(pre), _ci(1), *_gate_args(None), *_bn_in_args(None), _ci(0), _vp(0), S())
     # note: with rows_per_image % 16 != 0 the image stride used by the kernel (Hh*16 rows) would differ
     # from rpi; callers guarantee rpi % 16 == 0 whenever images > 1.
     assert images == 1 or rpi % 16 == 0
@@ -484,7 +484,7 @@ def conv_up2_fwd(x, wfwd, bias4):
     with _Prof(key, 2.0 * N * 4 * H * W * 32 * Cin * 9, _nb(x, y, wfwd)):                       # algorithmic FLOPs (of the 3x3)
         _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wfwd), P(y), P(bias4), _vp(0), _vp(0), _ci(N), _ci(H), _ci(W), _ci(Cin),
               _ci(H), _ci(W), _ci(128), _ci(128), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0), _cl(0), _vp(0), _ci(1),
-              *_gate_args(None), *_bn_in_args(None), _ci(1), _ci(0), S())
+              *_gate_args(None), *_bn_in_args(None), _ci(1), _vp(0), S())
     return y
 
 
@@ -506,7 +506,7 @@ def conv3x3s2_dgrad(dy, wphase, cin, coarse_residual=None, alg_flops=0):
     with _Prof(key, alg_flops if alg_flops else 2.0 * N * OH * OW * Co * cin * 9, _nb(dy, dx, wphase, coarse_residual)):
         _call("dh_conv2d_fwd", _ci(dt(dy)), P(dy), P(wphase), P(dx), _vp(0), P(coarse_residual), _vp(0), _ci(N), _ci(OH),
               _ci(OW), _ci(Co), _ci(OH), _ci(OW), _ci(4 * cin), _ci(4 * cin), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0),
-              _cl(0), _vp(0), _ci(1), *_gate_args(None), *_bn_in_args(None), _ci(1), _ci(0), S())
+              _cl(0), _vp(0), _ci(1), *_gate_args(None), *_bn_in_args(None), _ci(1), _vp(0), S())
     return dx
 
 
@@ -520,7 +520,7 @@ def conv_up2_dgrad(dy, wdgrad, cin):
     with _Prof(key, 2.0 * N * H2 * W2 * 32 * cin * 9, _nb(dy, dx, wdgrad)):
         _call("dh_conv2d_fwd", _ci(dt(dy)), P(dy), P(wdgrad), P(dx), _vp(0), _vp(0), _vp(0), _ci(N), _ci(H), _ci(W), _ci(128),
               _ci(H), _ci(W), _ci(cin), _ci(cin), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0), _cl(0), _vp(0), _ci(1),
-              *_gate_args(None), *_bn_in_args(None), _ci(2), _ci(0), S())
+              *_gate_args(None), *_bn_in_args(None), _ci(2), _vp(0), S())
     return dx
 
 

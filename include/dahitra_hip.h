@@ -52,10 +52,11 @@ int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const
                   int Cout, int CoutPad, int ks, int stride, int pad, int act, int npix_valid,
                   long w_image_stride, void* y_preact, int dilation, const void* gate_out, const void* gate_y,
                   const float* gate_mean, const float* gate_invstd, int gate_groups, const float* in_scale,
-                  const float* in_shift, int in_groups, int phase_mode, int w_chunk_major, void* stream);
-/* w_chunk_major (3x3 only): w_packed is [Cin / CK][9][CoutPad][CK] (CK = one 64-byte chunk: 32 bf16 / 16 fp32 channels; what
- * dh_pack_weights_multi writes for jobs with dtype | 0x100) instead of [9][CoutPad][Cin]: the staging of a chunk reads whole
- * cache lines. */
+                  const float* in_shift, int in_groups, int phase_mode, const void* w_frag, void* stream);
+/* w_frag (optional; bf16 3x3 only): the SAME weights in fragment order [CoutPad / 16][Cin / 32][9][64][8] (what
+ * dh_pack_weights_multi writes for jobs with dtype | 0x200): lane l of a wavefront finds the 8 reduction channels
+ * 32 c + 8 (l >> 4) .. of output channel 16 r + (l & 15) at [r][c][tap][l], i.e. one MFMA weight fragment is 1 KiB
+ * contiguous.  Read only where the register-resident-weights kernel runs (dh_conv_wreg_mode); NULL = it loads w_packed. */
 /* phase_mode (0 = off; ks = 2, pad = 1 only): conv3x3(nearest-upsample-x2(x)) -- models/networks.py:251-256, upsamplex2 +
  * conv_pred -- as four 2x2 convolutions on x, one per output parity, weights from dh_pack_phase_weights (2.25x fewer
  * FLOPs, the upsampled tensor is never written).  1: forward, logical Cout = 4 * 32, y is the [N][2 OH][2 OW][32] output
@@ -92,8 +93,7 @@ int dh_absdiff_up4_combine(const float* partial, const void* a, const void* b, v
  * fp32 NCHW logits [N][Cout][H][W] (the reference's output layout) written by the convolution itself: no NHWC logits tensor,
  * no layout pass.  w_packed: dh_pack_weight with OPad = 16; in_scale / in_shift (optional): BatchNorm-apply + ReLU on load. */
 int dh_conv3x3_head_fwd(int dtype, const void* x, const void* w_packed, const float* bias, int N, int H, int W, int Cin,
-                        int Cout, const float* in_scale, const float* in_shift, int in_groups, int w_chunk_major, float* logits_nchw,
-                        void* stream);
+                        int Cout, const float* in_scale, const float* in_shift, int in_groups, float* logits_nchw, void* stream);
 
 /* weight gradient (autograd convolution_backward / mm for nn.Linear): groups == 1 writes the
  * torch OIHW layout [Cout_real][Cin][ks][ks]; groups == N (ks == 1) one [Cout][Cin] per image. */
@@ -146,7 +146,7 @@ int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, int ks, int
 int dh_pack_weight(int dtype, const float* w_oihw, const float* out_scale, int O, int I, int ks, int OPad, void* fwd, int IPad,
                    int dgrad_inner, void* dgrad, void* stream);
 /* every weight of a net in one launch.  jobs_dev: njobs records {const float* w; void* fwd; void* dgrad; int O, I, KS,
- * OPad, IPad, OK, dtype (| 0x100: chunk-major destinations, see dh_conv2d_fwd), first_block, nblocks;} (dh_pack_job_size() bytes each) in device memory, sorted by
+ * OPad, IPad, OK, dtype (| 0x200: fragment-order destinations, see dh_conv2d_fwd), first_block, nblocks;} (dh_pack_job_size() bytes each) in device memory, sorted by
  * first_block; record k is served by workgroups [first_block, first_block + nblocks). */
 int dh_pack_weights_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 int dh_pack_job_size(void);

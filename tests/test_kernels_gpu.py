@@ -291,33 +291,41 @@ def test_class_head_writes_nchw_logits_itself(ops, dtype, ncls, hw, lazy):
     close(got, two.cpu(), dtype, "head vs conv + layout pass", factor=0.5)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 20, 24, 64, 96, 1, 1), (64, 32, 32, 128, 128, 1, 1), (2, 24, 24, 64, 64, 2, 1), (2, 16, 16, 128, 64, 1, 2)])
-def test_chunk_major_packed_weights(ops, dtype, cfg):
-    """dh_pack_weights_multi with dtype | 0x100 + dh_conv2d_fwd(w_chunk_major): forward and data gradient equal the row-major
-    packs' results bit for bit (same products, same order) and the fp32 reference within tolerance"""
-    N, H, W, Cin, Cout, stride, dil = cfg
+@pytest.mark.parametrize("cfg", [(64, 64, 64, 64, 64), (64, 32, 32, 256, 256), (64, 32, 32, 128, 256), (64, 32, 32, 256, 128)])
+def test_fragment_order_packed_weights(ops, cfg):
+    """dh_pack_weights_multi with dtype | 0x200: the fragment-order copies hold the same numbers as the row-major packs
+    ([r][c][tap][lane][e] = row 16 r + (lane & 15), reduction channel 32 c + 8 (lane >> 4) + e), and dh_conv2d_fwd(w_frag) on
+    the register-resident-weights kernel gives the bit-identical forward / data gradient"""
+    from dahitra_amd import _lib
+    L = _lib.lib()
+    dtype = torch.bfloat16
+    N, H, W, Cin, Cout = cfg
     x = rnd((N, Cin, H, W), dtype, 31)
     w = rnd((Cout, Cin, 3, 3), dtype, 32, scale=(9 * Cin) ** -0.5)
-    ck = ops.chunk_channels(dtype)
     plan = ops.PackPlan(torch.device("cuda"))
     wd = w.cuda()
-    fcm, dcm = plan.add(wd, dtype, dgrad_inner=-(-Cout // ck) * ck, chunk_major=True)
+    ff, df = plan.add(wd, dtype, dgrad_inner=Cout, frag=True)
     plan.run()
-    frm, drm = ops.pack_weight(wd, dtype, dgrad_inner=-(-Cout // ck) * ck)
-    assert fcm.dim() == 4 and fcm.shape == (Cin // ck, 9, frm.shape[1], ck)
+    frm, drm = ops.pack_weight(wd, dtype, dgrad_inner=Cout)
+    for frag, row in ((ff, frm), (df, drm)):
+        R, K = row.shape[1], row.shape[2]
+        assert tuple(frag.shape) == (R // 16, K // 32, 9, 64, 8)
+        # [r, c, tap, g, pl, e] -> [tap, r, pl, c, g, e]
+        back = frag.view(R // 16, K // 32, 9, 4, 16, 8).permute(2, 0, 4, 1, 3, 5).reshape(9, R, K)
+        assert torch.equal(back, row)
     xd = dev(nhwc(x), dtype)
-    pad = dil
-    y_cm = ops.conv2d(xd, fcm, Cout, 3, stride, pad, dilation=dil)
-    y_rm = ops.conv2d(xd, frm, Cout, 3, stride, pad, dilation=dil)
-    assert torch.equal(y_cm, y_rm)
-    close(nchw(y_cm), F.conv2d(x, w, None, stride, pad, dil), dtype, "conv, chunk-major weights")
-    if stride == 1 and Cout % ck == 0:
-        dy = rnd(tuple(nchw(y_cm).shape), dtype, 33)
+    prev = L.dh_conv_wreg_mode(1)
+    try:
+        y_f = ops.conv2d(xd, frm, Cout, 3, 1, 1, w_frag=ff)
+        y_r = ops.conv2d(xd, frm, Cout, 3, 1, 1)
+        dy = rnd(tuple(nchw(y_f).shape), dtype, 33)
         dyd = dev(nhwc(dy), dtype)
-        g_cm = ops.conv2d(dyd, dcm, Cin, 3, 1, dil * 2 - pad, dilation=dil)
-        g_rm = ops.conv2d(dyd, drm, Cin, 3, 1, dil * 2 - pad, dilation=dil)
-        assert torch.equal(g_cm, g_rm)
+        g_f = ops.conv2d(dyd, drm, Cin, 3, 1, 1, w_frag=df)
+        g_r = ops.conv2d(dyd, drm, Cin, 3, 1, 1)
+    finally:
+        L.dh_conv_wreg_mode(prev)
+    assert torch.equal(y_f, y_r) and torch.equal(g_f, g_r)
+    close(nchw(y_f), F.conv2d(x, w, None, 1, 1), dtype, "conv, fragment-order weights")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -1053,6 +1061,9 @@ def test_conv3x3_register_resident_weights_equals_tap_kernel(ops, cfg):
     if cfg.get("relu"):
         want = F.relu(want)
     wp, _ = ops.pack_weight(w.cuda(), dtype, want_dgrad=False)
+    plan = ops.PackPlan(torch.device("cuda"))
+    wf, _ = plan.add(w.cuda(), dtype, want_dgrad=False, frag=True)       # the fragment-order copy the engine hands over
+    plan.run()
     xd = dev(nhwc(x), dtype)
     arg = ops.BnInput(xd, bn[0], bn[1], groups) if bn else xd
     res = {}
@@ -1061,7 +1072,8 @@ def test_conv3x3_register_resident_weights_equals_tap_kernel(ops, cfg):
         try:
             res[mode] = ops.conv2d(arg, wp, cout, 3, 1, 1, bias=b.cuda() if b is not None else None,
                                    residual=dev(nhwc(r), dtype) if r is not None else None,
-                                   act=ops.ACT_RELU if cfg.get("relu") else ops.ACT_NONE, want_stats=bool(cfg.get("stats")))
+                                   act=ops.ACT_RELU if cfg.get("relu") else ops.ACT_NONE, want_stats=bool(cfg.get("stats")),
+                                   w_frag=wf if (mode == 1 and cfg["n"] != 6) else None)
         finally:
             L.dh_conv_wreg_mode(prev)
     y0, y1 = (res[0][0], res[1][0]) if cfg.get("stats") else (res[0], res[1])

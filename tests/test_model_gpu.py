@@ -568,16 +568,15 @@ def test_lazy_batchnorm_activations_equal_materialised(name, dtype, monkeypatch)
 
 
 def test_opt_in_paths_equal_default_paths_bf16(monkeypatch):
-    """the measured-neutral paths kept behind switches stay correct: chunk-major packed 3x3 weights (bit-identical products) and
-    the class-head data gradient gated for the classifier's BatchNorm (sums taken in its epilogue), bf16 train step"""
+    """the measured-neutral path kept behind a switch stays correct: the class-head data gradient gated for the classifier's
+    BatchNorm (sums taken in its epilogue), bf16 train step"""
     from dahitra_amd.models import losses
     a, b, lab = O.synthetic_batch(2, 64, seed=71)
     res = {}
     for on in ("0", "1"):
-        monkeypatch.setenv("DAHITRA_CM_WEIGHTS", on)
         monkeypatch.setenv("DAHITRA_GATED_HEAD", on)
         net = make_net("base_transformer_pos_s4", "bf16").train()
-        assert net._engine.chunk_major_weights == (on == "1") and net._engine.gated_head_dgrad == (on == "1")
+        assert net._engine.gated_head_dgrad == (on == "1")
         y = net(a.cuda(), b.cuda())
         losses.focal_loss(y, lab.cuda()).backward()
         res[on] = (y.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})

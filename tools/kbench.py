@@ -45,7 +45,6 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--filter", default="")
-    ap.add_argument("--cm", action="store_true", help="3x3 weights in the chunk-major packed form")
     args = ap.parse_args()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     for name, N, H, W, Cin, Cout, ks, stride in SHAPES:
@@ -58,12 +57,7 @@ def main():
             wp = torch.randn(16, Cout, Cin, device="cuda").to(dtype)
             OH, OW = H, W
         else:
-            if args.cm and ks == 3 and Cin % ops.chunk_channels(dtype) == 0:
-                plan = ops.PackPlan(w.device)
-                wp, _ = plan.add(w, dtype, want_dgrad=False, chunk_major=True)
-                plan.run()
-            else:
-                wp, _ = ops.pack_weight(w, dtype, want_dgrad=False)
+            wp, _ = ops.pack_weight(w, dtype, want_dgrad=False)
             OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
         flops = 2.0 * N * OH * OW * Cout * Cin * ks * ks
         line = "%-28s" % name

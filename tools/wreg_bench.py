@@ -39,14 +39,17 @@ def main():
         x = torch.randn(N, H, W, Cin, device="cuda").to(dt)
         w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
         wp, _ = ops.pack_weight(w, dt, want_dgrad=False)
+        plan = ops.PackPlan(w.device)
+        wf, _ = plan.add(w, dt, want_dgrad=False, frag=True)       # fragment-order copy for the register-resident kernel
+        plan.run()
         r = torch.randn(N, H, W, Cout, device="cuda").to(dt)
         sc = (torch.rand(2, Cin, device="cuda") + 0.5)
         sh = torch.randn(2, Cin, device="cuda") * 0.3
         flops = 2.0 * N * H * W * Cout * Cin * 9
-        cases = {"plain": lambda: ops.conv2d(x, wp, Cout, 3, 1, 1),
-                 "stats": lambda: ops.conv2d(x, wp, Cout, 3, 1, 1, want_stats=True),
-                 "bn_in+stats": lambda: ops.conv2d(ops.BnInput(x, sc, sh, 2), wp, Cout, 3, 1, 1, want_stats=True),
-                 "residual": lambda: ops.conv2d(x, wp, Cout, 3, 1, 1, residual=r)}
+        cases = {"plain": lambda: ops.conv2d(x, wp, Cout, 3, 1, 1, w_frag=wf),
+                 "stats": lambda: ops.conv2d(x, wp, Cout, 3, 1, 1, want_stats=True, w_frag=wf),
+                 "bn_in+stats": lambda: ops.conv2d(ops.BnInput(x, sc, sh, 2), wp, Cout, 3, 1, 1, want_stats=True, w_frag=wf),
+                 "residual": lambda: ops.conv2d(x, wp, Cout, 3, 1, 1, residual=r, w_frag=wf)}
         for cname, fn in cases.items():
             t = {0: [], 1: []}
             for mode in (0, 1):

@@ -21,13 +21,14 @@ for name, (N, H, W, Cin, Cout) in SHAPES.items():
     x = torch.randn(N, H, W, Cin, device="cuda").to(torch.bfloat16)
     w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
     wp, _ = ops.pack_weight(w, torch.bfloat16, want_dgrad=False)
-    if os.environ.get("DAHITRA_WREG_FRAG"):      # [9][Cout][Cin] -> fragment order [Cout/16][Cin/32][9][g][pl][8]
-        wp = wp.view(9, Cout // 16, 16, Cin // 32, 4, 8).permute(1, 3, 0, 4, 2, 5).contiguous().view(9, Cout, Cin)
+    plan = ops.PackPlan(w.device)
+    wf, _ = plan.add(w, torch.bfloat16, want_dgrad=False, frag=True)
+    plan.run()
     for _ in range(3):
-        ops.conv2d(x, wp, Cout, 3, 1, 1, want_stats=True)
+        ops.conv2d(x, wp, Cout, 3, 1, 1, want_stats=True, w_frag=wf)
     torch.cuda.synchronize()
     L.dh_debug_wreg_clear()
-    ops.conv2d(x, wp, Cout, 3, 1, 1, want_stats=True)
+    ops.conv2d(x, wp, Cout, 3, 1, 1, want_stats=True, w_frag=wf)
     torch.cuda.synchronize()
     buf = np.zeros(4096 * 32, dtype=np.int64)
     L.dh_debug_wreg_ts(buf.ctypes.data_as(ctypes.c_void_p), buf.size)
