@@ -425,10 +425,6 @@ int wr_launch_bn(const ConvArgs& c, hipStream_t st, int cus) {
 
 int g_wreg_mode = -1;      // dh_conv_wreg_mode: -1 = where it is the faster kernel, 0 = never, 1 = wherever it can run
 
-int wr_variant() {            // DAHITRA_WREG_VARIANT: experiment switch for the 128-input-channel layers (0: 32 couts per wave)
-    static const int v = getenv("DAHITRA_WREG_VARIANT") ? atoi(getenv("DAHITRA_WREG_VARIANT")) : 0;
-    return v;
-}
 
 }  // namespace
 
@@ -442,7 +438,6 @@ bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     if (a.act == DH_ACT_GELU || a.npix != a.OH * a.OW || a.in_npix != a.H * a.W || a.OH != a.H || a.OW != a.W) return false;
     if (a.OH % (a.rw == 4 ? 16 : 8) || a.OW % 16) return false;
     if (a.in_scale && a.in_groups > 4) return false;
-    if (a.Cin == 128 && a.Cout % 128 && wr_variant() == 0) return false;
     if (g_wreg_mode != 1) {
         // measured (tools/wreg_bench.py, 64 images, gpurun_out/wreg_bench_[45]_*.txt): the shapes on which this kernel is the
         // faster one -- the 64-channel layers (x1.14 - 1.23, also with BatchNorm on load) and, given the fragment-order weights,
@@ -477,8 +472,10 @@ int dh_conv_wreg_launch(const ConvArgs& a, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     }
     //                                 NSUB NCH D PFD WPS
-    if (a.Cin == 64) return wr_launch_bn<1, 2, 4, 3, 2>(a, st, cus);
-    if (a.Cin == 256) return wr_launch_bn<1, 8, 4, 4, 1>(a, st, cus);
-    if (wr_variant() == 1 || a.Cout % 128) return wr_launch_bn<1, 4, 4, 3, 2>(a, st, cus);
-    return wr_launch_bn<2, 4, 4, 4, 1>(a, st, cus);
+    if (a.Cin == 64) return wr_launch_bn<1, 2, 4, 3, 2>(a, st, cus);      // 72 weight registers: two workgroups per CU
+    if (a.Cin == 256) return wr_launch_bn<1, 8, 4, 4, 1>(a, st, cus);     // 288: one wave per SIMD
+    // 128 input channels (dh_conv_wreg_mode(1) only: it ties the tap kernel, x1.02 - 1.04, and loses with BatchNorm on load).
+    // Also measured and dropped: 32 output channels per wave (288 registers + 64 accumulators: 60 spills, x0.7), two
+    // workgroups per CU at 144 registers (31 spills, x0.77), deeper rings (D = 5 / 8: no change, cache-cold inputs included).
+    return wr_launch_bn<1, 4, 4, 4, 1>(a, st, cus);
 }

@@ -32,11 +32,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--cold", type=int, default=0, help="rotate over this many distinct input tensors (> 256 MB in total: "
+                    "the Infinity Cache cannot hold them, the loads come from HBM as in the real step)")
     args = ap.parse_args()
     L = _lib.lib()
     dt = torch.bfloat16
     for name, N, H, W, Cin, Cout in SHAPES:
         x = torch.randn(N, H, W, Cin, device="cuda").to(dt)
+        xs = [x] + [torch.randn(N, H, W, Cin, device="cuda").to(dt) for _ in range(max(args.cold - 1, 0))]
+        rot = [0]
+
+        def nx():
+            rot[0] = (rot[0] + 1) % len(xs)
+            return xs[rot[0]]
         w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
         wp, _ = ops.pack_weight(w, dt, want_dgrad=False)
         plan = ops.PackPlan(w.device)
@@ -46,10 +54,10 @@ def main():
         sc = (torch.rand(2, Cin, device="cuda") + 0.5)
         sh = torch.randn(2, Cin, device="cuda") * 0.3
         flops = 2.0 * N * H * W * Cout * Cin * 9
-        cases = {"plain": lambda: ops.conv2d(x, wp, Cout, 3, 1, 1, w_frag=wf),
-                 "stats": lambda: ops.conv2d(x, wp, Cout, 3, 1, 1, want_stats=True, w_frag=wf),
-                 "bn_in+stats": lambda: ops.conv2d(ops.BnInput(x, sc, sh, 2), wp, Cout, 3, 1, 1, want_stats=True, w_frag=wf),
-                 "residual": lambda: ops.conv2d(x, wp, Cout, 3, 1, 1, residual=r, w_frag=wf)}
+        cases = {"plain": lambda: ops.conv2d(nx(), wp, Cout, 3, 1, 1, w_frag=wf),
+                 "stats": lambda: ops.conv2d(nx(), wp, Cout, 3, 1, 1, want_stats=True, w_frag=wf),
+                 "bn_in+stats": lambda: ops.conv2d(ops.BnInput(nx(), sc, sh, 2), wp, Cout, 3, 1, 1, want_stats=True, w_frag=wf),
+                 "residual": lambda: ops.conv2d(nx(), wp, Cout, 3, 1, 1, residual=r, w_frag=wf)}
         for cname, fn in cases.items():
             t = {0: [], 1: []}
             for mode in (0, 1):
