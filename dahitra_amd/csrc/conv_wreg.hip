@@ -26,6 +26,9 @@ constexpr int WR_TH = 8;                                   // tile rows (TW = 16
 constexpr int WR_HH = WR_TH + 2, WR_HW = TW + 2;           // halo 10 x 18 pixels
 constexpr int WR_NPX = WR_HH * WR_HW;                      // 180
 constexpr int WR_NI = 3;                                   // 1-KiB load instructions per wave and chunk image: 12 KiB >= 180 * 64 B
+#ifndef WR_EXP       // experiment builds (tools/wreg_bench.py --only): 1 = no ring loads in the stream, 2 = no stage barrier
+#define WR_EXP 0    //  (wrong results; what the stream loop costs without them)
+#endif
 constexpr int WR_IMG = WR_NI * 4 * 1024;                   // bytes of one chunk image in the ring
 
 __device__ __attribute__((aligned(256))) unsigned int wr_zero[64];      // source of every padding / out-of-stream piece
@@ -43,6 +46,19 @@ __device__ __forceinline__ void wr_glds16(const unsigned char* gsrc, unsigned ld
 __device__ __forceinline__ unsigned wr_lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
+// 8-byte global load / its counted wait as inline asm: a residual row is fetched a whole stage before it is used, across the
+// stream loop's back edge, where a compiler-tracked load would be waited for with vmcnt(0) -- a drain of the run-ahead ring.
+// The wait takes the destination as an in/out operand, so nothing that reads it can be scheduled above the wait; and the
+// destination is an ACCUMULATION register ("a": gfx950 loads into the unified file directly) because, with the vector half
+// full of weights, the register allocator otherwise parks a freshly "defined" value there itself -- copying it out before
+// the load has landed (seen in the ISA).  tools/check_wreg_isa.py verifies that nothing touches the destinations in between.
+__device__ __forceinline__ void wr_gload8(const void* src, unsigned long long& d) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(d) : "v"(src) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wr_wait_for(unsigned long long& d) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+a"(d) : "n"(N) : "memory");
+}
 // hide a loop-invariant value from the optimiser, so that what is derived from it is recomputed where it is used instead of
 // being hoisted into (scarce) registers for the life of the stream loop
 __device__ __forceinline__ int wr_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -57,8 +73,10 @@ __device__ __forceinline__ int wr_off(int hy, int hx, int q) { return (hy * WR_H
 #ifdef WR_TIMING
 __device__ long long wr_ts[4096 * 32];
 #define WR_TS(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && (k) < 32) wr_ts[blockIdx.x * 32 + (k)] = (long long)wall_clock64(); } while (0)
+#define WR_CYC(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) wr_ts[blockIdx.x * 32 + (k)] = (long long)clock64(); } while (0)
 #else
 #define WR_TS(k) do { } while (0)
+#define WR_CYC(k) do { } while (0)
 #endif
 
 struct WrArgs {
@@ -80,7 +98,7 @@ struct WrTile {       // one 8x16 tile of the stream: per-lane source offsets of
 };
 static_assert(WR_NI == 3, "WrTile carries three piece offsets");
 
-template <int NSUB, int NCH, int D, int PFD, bool INBN, int WPS>
+template <int NSUB, int NCH, int D, int PFD, bool INBN, int WPS, bool RES, bool RELU>
 __global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
     // One tile = NCH stages (one 32-channel chunk image each) = NCH * 30 steps; a step = one halo fragment (kernel column kw,
     // halo row h) read from LDS and the <= 3 * NSUB MFMAs it feeds.  The steps of the whole stream form ONE software pipeline:
@@ -262,6 +280,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
     asm volatile("" ::: "memory");
 
     WR_TS(2);
+    WR_CYC(28);                                            // shader cycles at the start / end of the stream (slots 28, 29)
     V16u B[NB];
     // fragment of step gg (0 .. TSTEPS + PFD - 1; past TSTEPS: the next tile's first stage) into its rolling register
     auto rd = [&](int gg) {
@@ -271,12 +290,104 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
 #pragma unroll
     for (int gg = 0; gg < PFD; ++gg) rd(gg);
 
+    // ---- the epilogue of a tile (+ bias, + residual, ReLU, statistics, transposed 16-byte stores), in pieces that ride in
+    // the FIRST STAGE of the next tile: output row r right before step r (whose first MFMA restarts that row's accumulator
+    // from zero), the statistics at step 8, the staged tile published by that stage's one barrier, the cooperative stores in
+    // the steps after it -- the matrix pipe never waits for an epilogue (one wave per SIMD at 256 input channels: 1.1 us of
+    // every 8 us tile before).  The residual rows of a tile are requested at the first step of its LAST stage (inline-asm
+    // loads, see wr_gload8) and waited for row by row with the exact count of younger loads: the rows after it and the
+    // WR_NI ring loads of that stage's publication point.
+    constexpr bool relu = RELU, has_res = RES;             // (compile-time: as run-time flags they doubled the row's instructions)
+    unsigned long long rr[NSUB][WR_TH];                    // residual rows of the tile whose epilogue is pending (4 bf16 each)
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int r = 0; r < WR_TH; ++r) rr[s][r] = 0;
+    auto res_issue = [&](const WrTile& t) {
+        const bf16* rin = reinterpret_cast<const bf16*>(p.res) + (size_t)t.n * p.OH * p.OW * p.Cout;
+#pragma unroll
+        for (int r = 0; r < WR_TH; ++r)
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s)
+                wr_gload8(rin + (size_t)((t.oy0 + r) * p.OW + t.ox0 + pl) * p.Cout + co_w + s * 16 + wr_opaque(g) * 4, rr[s][r]);
+    };
+    int en = 0, eoy0 = 0, eox0 = 0;                        // the tile whose epilogue is pending
+    constexpr int NST = WR_TH * TW * PPR / 256;            // cooperative store rounds
+    static_assert((WR_TH * TW * PPR) % 256 == 0 && SYNC + NST + 1 < NSTEP && WR_TH < SYNC, "epilogue pieces fit the first stage");
+    auto epi_row = [&](int r) {                            // (r is a constant after unrolling: the switch below folds)
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            float v[4], res4[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (has_res) {
+                if (s == 0) {                              // row r of every sub-block has landed
+                    switch (r) {
+                    case 0: wr_wait_for<7 * NSUB + WR_NI>(rr[0][0]); break;
+                    case 1: wr_wait_for<6 * NSUB + WR_NI>(rr[0][1]); break;
+                    case 2: wr_wait_for<5 * NSUB + WR_NI>(rr[0][2]); break;
+                    case 3: wr_wait_for<4 * NSUB + WR_NI>(rr[0][3]); break;
+                    case 4: wr_wait_for<3 * NSUB + WR_NI>(rr[0][4]); break;
+                    case 5: wr_wait_for<2 * NSUB + WR_NI>(rr[0][5]); break;
+                    case 6: wr_wait_for<1 * NSUB + WR_NI>(rr[0][6]); break;
+                    default: wr_wait_for<WR_NI>(rr[0][7]); break;
+                    }
+                }
+                const unsigned lo = (unsigned)rr[s][r], hi = (unsigned)(rr[s][r] >> 32);
+                res4[0] = __uint_as_float(lo << 16); res4[1] = __uint_as_float(lo & 0xffff0000u);
+                res4[2] = __uint_as_float(hi << 16); res4[3] = __uint_as_float(hi & 0xffff0000u);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[s][r][j] + bs[s][j];
+                if constexpr (has_res) v[j] += res4[j];
+                if constexpr (relu) v[j] = fmaxf(v[j], 0.f);
+                ssum[s][j] += v[j];
+                ssq[s][j] += v[j] * v[j];
+            }
+            st4(reinterpret_cast<bf16*>(otile + (r * TW + pl) * TPITCH) + wv * 16 * NSUB + s * 16 + g * 4, v);
+        }
+    };
+    auto epi_stats = [&](int kk) {                         // kk: stream index of the tile whose rows were just added
+        if (p.stats && (kk % a.subt) == a.subt - 1) {
+            const int unit = j0 + (kk / a.subt) * a.J;
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sa = row16_sum(ssum[s][j]), sq = row16_sum(ssq[s][j]);
+                    if (pl == 0) {
+                        const int c = co_w + s * 16 + wr_opaque(g) * 4 + j;
+                        p.stats[((size_t)0 * p.CoutPad + c) * a.nunits + unit] = sa;
+                        p.stats[((size_t)1 * p.CoutPad + c) * a.nunits + unit] = sq;
+                    }
+                    ssum[s][j] = 0.f; ssq[s][j] = 0.f;
+                }
+        }
+    };
+    // round `it` of the staged tile (en, eoy0, eox0) -> y, 16 bytes per lane: read from LDS in one step, stored in the next
+    uint4 ehold;
+    auto epi_fetch = [&](int it) {
+        const int i = wr_opaque(tid) + it * 256, px = i / PPR, q = i - px * PPR;
+        ehold = *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
+    };
+    auto epi_store = [&](int it) {
+        bf16* yout = reinterpret_cast<bf16*>(p.y) + (size_t)en * p.OH * p.OW * p.Cout;
+        const int i = wr_opaque(tid) + it * 256, px = i / PPR, q = i - px * PPR;
+        *reinterpret_cast<uint4*>(yout + (size_t)((eoy0 + (px >> 4)) * p.OW + eox0 + (px & 15)) * p.Cout + cb * NCO + q * 8) = ehold;
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
     for (int k = 0; k < K; ++k) {
+        const bool pend = k > 0;
 #pragma unroll
         for (int st = 0; st < NCH; ++st)
 #pragma unroll
         for (int i = 0; i < NSTEP; ++i) {
             const int gg = st * NSTEP + i, kw = i / WR_HH, h = i - kw * WR_HH;
+            if (st == 0 && i <= WR_TH && pend) {
+                if (i < WR_TH) epi_row(i);
+                else epi_stats(k - 1);
+            }
+            if constexpr (has_res) { if (st == NCH - 1 && i == 0) res_issue(t0); }
             if constexpr (INBN) {
                 // BatchNorm + ReLU of the NEXT stage's image, spread over steps BN0 .. (see bn_load)
                 const int nx = st + 1;
@@ -288,13 +399,24 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
                 }
             }
             if (i == SYNC) {
-                // publish stage st + 1 (of this tile, or stage 0 of the next one), then refill the slot of stage st - 1
+                // publish stage st + 1 (of this tile, or stage 0 of the next one) -- and, in a tile's first stage, the staged
+                // output tile of the one before --, then refill the slot of stage st - 1
                 if constexpr (INBN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the transform's writes
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 3) * WR_NI) : "memory");
-                __builtin_amdgcn_s_barrier();              // (raw: __syncthreads would drain the loads in flight)
+                else {
+                    if constexpr (has_res) { if (st == NCH - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 3) * WR_NI + WR_TH * NSUB) : "memory"); }
+                    if (!(has_res && st == NCH - 1)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 3) * WR_NI) : "memory");
+                    if (st == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the epilogue rows' writes
+                }
+                if (!(WR_EXP & 2)) __builtin_amdgcn_s_barrier();      // (raw: __syncthreads would drain the loads in flight)
                 asm volatile("" ::: "memory");
+                // (the 12 load instructions of a workgroup issued one per step, wave by wave, instead of together here:
+                // 69.6 vs 59.6 us on 256 -> 256 -- the per-wave branches cost more than the queueing in the address path)
                 const int far = st + D - 1;
-                issue(tile_at(far / NCH), far % NCH, slot_of(far));
+                if (!(WR_EXP & 1)) issue(tile_at(far / NCH), far % NCH, slot_of(far));
+            }
+            if (st == 0 && i > SYNC && i <= SYNC + NST + 1 && pend) {
+                if (i > SYNC + 1) epi_store(i - SYNC - 2);
+                if (i <= SYNC + NST) epi_fetch(i - SYNC - 1);
             }
             rd(gg + PFD);
             __builtin_amdgcn_sched_barrier(0);
@@ -302,92 +424,37 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
             for (int kh = 0; kh < 3; ++kh) {
                 const int r = h - kh;
                 if (r < 0 || r >= WR_TH) continue;
+                const bool first = st == 0 && kw == 0 && kh == 0;       // the row's first product of this tile
 #pragma unroll
                 for (int s = 0; s < NSUB; ++s)
-                    acc[s][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][st][kh * 3 + kw], B[gg % NB].h, acc[s][r], 0, 0, 0);
+                    acc[s][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][st][kh * 3 + kw], B[gg % NB].h, first ? zero4 : acc[s][r], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-
-        // ---- epilogue of tile k: + bias, + residual, ReLU, statistics, transposed 16-byte stores ----
         WR_TS(3 + 3 * k);
-        {
-            const int n = t0.n, oy0 = t0.oy0, ox0 = t0.ox0;
-            bf16* yout = reinterpret_cast<bf16*>(p.y) + (size_t)n * p.OH * p.OW * p.Cout;
-            const bool relu = p.act == DH_ACT_RELU;
-            // (two straight-line variants: with the residual, the loads of four rows are issued before their first use)
-            auto body = [&](auto has_res) {
-                constexpr int RG = 4;                      // residual rows in flight (registers)
-#pragma unroll
-                for (int r0 = 0; r0 < WR_TH; r0 += RG) {
-                    float rr[NSUB][RG][4];
-                    if constexpr (decltype(has_res)::value) {
-                        const bf16* rin = reinterpret_cast<const bf16*>(p.res) + (size_t)n * p.OH * p.OW * p.Cout;
-#pragma unroll
-                        for (int r = 0; r < RG; ++r)
-#pragma unroll
-                            for (int s = 0; s < NSUB; ++s)
-                                ld4(rin + (size_t)((oy0 + r0 + r) * p.OW + ox0 + pl) * p.Cout + co_w + s * 16 + g * 4, rr[s][r]);
-                    }
-#pragma unroll
-                    for (int r = r0; r < r0 + RG; ++r) {
-#pragma unroll
-                        for (int s = 0; s < NSUB; ++s) {
-                            float v[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                v[j] = acc[s][r][j] + bs[s][j];
-                                if constexpr (decltype(has_res)::value) v[j] += rr[s][r - r0][j];
-                                if (relu) v[j] = fmaxf(v[j], 0.f);
-                                ssum[s][j] += v[j];
-                                ssq[s][j] += v[j] * v[j];
-                            }
-                            acc[s][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            st4(reinterpret_cast<bf16*>(otile + (r * TW + pl) * TPITCH) + wv * 16 * NSUB + s * 16 + g * 4, v);
-                        }
-                    }
-                }
-            };
-            if (p.res) body(std::true_type{});
-            else body(std::false_type{});
-            if (p.stats && (k % a.subt) == a.subt - 1) {
-                const int unit = j0 + (k / a.subt) * a.J;
-#pragma unroll
-                for (int s = 0; s < NSUB; ++s)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float sa = row16_sum(ssum[s][j]), sq = row16_sum(ssq[s][j]);
-                        if (pl == 0) {
-                            const int c = co_w + s * 16 + wr_opaque(g) * 4 + j;
-                            p.stats[((size_t)0 * p.CoutPad + c) * a.nunits + unit] = sa;
-                            p.stats[((size_t)1 * p.CoutPad + c) * a.nunits + unit] = sq;
-                        }
-                        ssum[s][j] = 0.f; ssq[s][j] = 0.f;
-                    }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                  // tile staged (the next tile's first stage barrier orders the reads below
-            asm volatile("" ::: "memory");                 //  before the next epilogue's writes)
-            WR_TS(4 + 3 * k);
-            static_assert((WR_TH * TW * PPR) % 256 == 0, "whole store rounds");
-#pragma unroll
-            for (int it = 0; it < WR_TH * TW * PPR / 256; ++it) {
-                const int i = wr_opaque(tid) + it * 256, px = i / PPR, q = i - px * PPR;
-                *reinterpret_cast<uint4*>(yout + (size_t)((oy0 + (px >> 4)) * p.OW + ox0 + (px & 15)) * p.Cout + cb * NCO + q * 8) =
-                    *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
-            }
-        }
-        WR_TS(5 + 3 * k);
+        en = t0.n; eoy0 = t0.oy0; eox0 = t0.ox0;
         t0 = t1;
         t1 = t2;
         tile_desc(k + 3, t2);
         if constexpr (!STATIC_SLOT) s0 = (s0 + NCH) % D;
     }
+    WR_CYC(29);
+    WR_TS(30);
+    if (K > 0) {                                           // the last tile's epilogue
+#pragma unroll
+        for (int r = 0; r < WR_TH; ++r) epi_row(r);
+        epi_stats(K - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < NST; ++it) { epi_fetch(it); epi_store(it); }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the run-ahead loads past the end of the stream (zero block)
     WR_TS(31);
 }
 
-template <int NSUB, int NCH, int D, int PFD, bool INBN, int WPS>
+template <int NSUB, int NCH, int D, int PFD, bool INBN, int WPS, bool RES, bool RELU>
 int wr_launch(const ConvArgs& c, hipStream_t st, int cus) {
     constexpr int NCO = 64 * NSUB;
     WrArgs a;
@@ -404,7 +471,7 @@ int wr_launch(const ConvArgs& c, hipStream_t st, int cus) {
     a.wfrag = c.w_frag != nullptr;
     if (a.wfrag) a.c.w = c.w_frag;
     const size_t lds = (size_t)D * WR_IMG + (size_t)WR_TH * TW * (NCO * 2 + 16) + (INBN ? (size_t)c.in_groups * 2 * c.Cin * 4 : 0);
-    auto kern = conv3x3_wreg_kernel<NSUB, NCH, D, PFD, INBN, WPS>;
+    auto kern = conv3x3_wreg_kernel<NSUB, NCH, D, PFD, INBN, WPS, RES, RELU>;
     static bool attr_done = false;
     if (!attr_done) {
         attr_done = true;
@@ -420,7 +487,13 @@ int wr_launch(const ConvArgs& c, hipStream_t st, int cus) {
 
 template <int NSUB, int NCH, int D, int PFD, int WPS>
 int wr_launch_bn(const ConvArgs& c, hipStream_t st, int cus) {
-    return c.in_scale ? wr_launch<NSUB, NCH, D, PFD, true, WPS>(c, st, cus) : wr_launch<NSUB, NCH, D, PFD, false, WPS>(c, st, cus);
+    // (BatchNorm on load comes with neither residual nor ReLU in any caller: dh_conv_wreg_eligible refuses the combination)
+    const bool relu = c.act == DH_ACT_RELU;
+    if (c.in_scale) return wr_launch<NSUB, NCH, D, PFD, true, WPS, false, false>(c, st, cus);
+    if (c.res) return relu ? wr_launch<NSUB, NCH, D, PFD, false, WPS, true, true>(c, st, cus)
+                           : wr_launch<NSUB, NCH, D, PFD, false, WPS, true, false>(c, st, cus);
+    return relu ? wr_launch<NSUB, NCH, D, PFD, false, WPS, false, true>(c, st, cus)
+                : wr_launch<NSUB, NCH, D, PFD, false, WPS, false, false>(c, st, cus);
 }
 
 int g_wreg_mode = -1;      // dh_conv_wreg_mode: -1 = where it is the faster kernel, 0 = never, 1 = wherever it can run
@@ -437,19 +510,19 @@ bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     if (a.Cout % 64 || a.CoutPad != a.Cout || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride) return false;
     if (a.act == DH_ACT_GELU || a.npix != a.OH * a.OW || a.in_npix != a.H * a.W || a.OH != a.H || a.OW != a.W) return false;
     if (a.OH % (a.rw == 4 ? 16 : 8) || a.OW % 16) return false;
-    if (a.in_scale && a.in_groups > 4) return false;
+    if (a.in_scale && (a.in_groups > 4 || a.res || a.act == DH_ACT_RELU)) return false;
     if (g_wreg_mode != 1) {
-        // measured (tools/wreg_bench.py, 64 images, gpurun_out/wreg_bench_[45]_*.txt): the shapes on which this kernel is the
-        // faster one -- the 64-channel layers (x1.14 - 1.23, also with BatchNorm on load) and, given the fragment-order weights,
-        // 256 input channels without BatchNorm on load (x1.04 - 1.08; with it x0.86: one wave per SIMD cannot hide the in-LDS
-        // transform).  128 input channels lose (x0.7: 295 KB of weights per workgroup for two tiles).  DESIGN.md section 6c.
-        if (!(a.Cin == 64 || (a.Cin == 256 && a.w_frag && !a.in_scale))) return false;
+        // measured (tools/wreg_bench.py, 64 images, gpurun_out/wreg_bench_{9,10}*.txt): the shapes on which this kernel is the
+        // faster one -- the 64-channel layers (x1.16 with BatchNorm on load, x1.26 - 1.30 without) and, given the
+        // fragment-order weights, 128 / 256 input channels without BatchNorm on load (x1.04 - 1.13 / x1.07 - 1.11; with it
+        // x0.86 - 0.90: one wave per SIMD cannot hide the in-LDS transform).  DESIGN.md section 6c.
+        if (!(a.Cin == 64 || (a.w_frag && !a.in_scale))) return false;
     }
     // a persistent workgroup must see enough tiles to amortise loading its weights (74 KB at 64 input channels, two workgroups
     // per CU; 295 KB at 256, one per CU): measured at 4 resp. 8 tiles per workgroup, required here: >= 4 resp. >= 6
     const long work = (long)a.N * (a.OH / 8) * (a.OW / 16) * (a.Cout / 64);
     if (g_wreg_mode == 1) return work >= 2 * 256;
-    return a.Cin == 64 ? work >= 4 * 512 : work >= 6 * 256;
+    return a.Cin == 64 ? work >= 4 * 512 : (a.Cin == 128 ? work >= 4 * 256 : work >= 6 * 256);
 }
 
 // C ABI (include/dahitra_hip.h): route the eligible 3x3 convolutions through the tap-oriented kernel instead (mode 0), or
@@ -474,8 +547,7 @@ int dh_conv_wreg_launch(const ConvArgs& a, hipStream_t st) {
     //                                 NSUB NCH D PFD WPS
     if (a.Cin == 64) return wr_launch_bn<1, 2, 4, 3, 2>(a, st, cus);      // 72 weight registers: two workgroups per CU
     if (a.Cin == 256) return wr_launch_bn<1, 8, 4, 4, 1>(a, st, cus);     // 288: one wave per SIMD
-    // 128 input channels (dh_conv_wreg_mode(1) only: it ties the tap kernel, x1.02 - 1.04, and loses with BatchNorm on load).
-    // Also measured and dropped: 32 output channels per wave (288 registers + 64 accumulators: 60 spills, x0.7), two
+    // 128 input channels.  Also measured and dropped: 32 output channels per wave (288 registers + 64 accumulators: 60 spills, x0.7), two
     // workgroups per CU at 144 registers (31 spills, x0.77), deeper rings (D = 5 / 8: no change, cache-cold inputs included).
     return wr_launch_bn<1, 4, 4, 4, 1>(a, st, cus);
 }

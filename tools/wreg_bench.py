@@ -34,10 +34,13 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--cold", type=int, default=0, help="rotate over this many distinct input tensors (> 256 MB in total: "
                     "the Infinity Cache cannot hold them, the loads come from HBM as in the real step)")
+    ap.add_argument("--only", default="", help="substring of the shape name")
     args = ap.parse_args()
     L = _lib.lib()
     dt = torch.bfloat16
     for name, N, H, W, Cin, Cout in SHAPES:
+        if args.only not in name:
+            continue
         x = torch.randn(N, H, W, Cin, device="cuda").to(dt)
         xs = [x] + [torch.randn(N, H, W, Cin, device="cuda").to(dt) for _ in range(max(args.cold - 1, 0))]
         rot = [0]

@@ -36,16 +36,18 @@ for name, (N, H, W, Cin, Cout) in SHAPES.items():
     ts = ts[ts[:, 0] > 0]
     t0 = ts[:, 0].min()
     us = lambda a: (a - t0) / 100.0
-    ntile = int(((ts[:, 3:30:3] > 0).sum(1)).max())
+    ntile = int(((ts[:, 3:28:3] > 0).sum(1)).max())
     print("%s: %d workgroups, %d tiles each, span %.1f us (starts within %.1f us)" %
           (name, len(ts), ntile, us(ts[:, 31]).max(), us(ts[:, 0]).max()))
     print("   weights loaded   +%.2f us (p50) %.2f (p90)" % tuple(np.quantile((ts[:, 1] - ts[:, 0]) / 100.0, [0.5, 0.9])))
     print("   stage 0 ready    +%.2f us (p50)" % np.median((ts[:, 2] - ts[:, 1]) / 100.0))
     prev = ts[:, 2]
-    for k in range(ntile):
-        a, b, c = ts[:, 3 + 3 * k], ts[:, 4 + 3 * k], ts[:, 5 + 3 * k]
+    for k in range(ntile):      # (the epilogue of tile k rides in the first stage of tile k + 1: one stamp per tile)
+        a = ts[:, 3 + 3 * k]
         ok = a > 0
-        print("   tile %d: mfma loop %.2f us | epilogue to barrier %.2f | stores issued %.2f   (p50 over %d wgs)" %
-              (k, np.median((a - prev)[ok]) / 100.0, np.median((b - a)[ok]) / 100.0, np.median((c - b)[ok]) / 100.0, int(ok.sum())))
-        prev = np.where(ok, c, prev)
-    print("   tail (drain)     %.2f us;  lifetime p50 %.2f us" % (np.median((ts[:, 31] - prev) / 100.0), np.median((ts[:, 31] - ts[:, 0]) / 100.0)))
+        print("   tile %d: %.2f us (p50), %.2f (p90)   (%d wgs)" %
+              (k, np.median((a - prev)[ok]) / 100.0, np.quantile((a - prev)[ok], 0.9) / 100.0, int(ok.sum())))
+        prev = np.where(ok, a, prev)
+    cyc, wall = (ts[:, 29] - ts[:, 28]).astype(float), (ts[:, 30] - ts[:, 2]) / 100.0
+    print("   shader clock over the stream: %.2f GHz (p50)" % np.median(cyc / wall / 1e3))
+    print("   last epilogue    %.2f us;  lifetime p50 %.2f us" % (np.median((ts[:, 31] - prev) / 100.0), np.median((ts[:, 31] - ts[:, 0]) / 100.0)))
