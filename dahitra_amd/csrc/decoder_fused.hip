@@ -19,6 +19,7 @@
 // MFMA through wave-private LDS tiles read back with ds_read_b64_tr_b16; biases / LayerNorm gradients are
 // lane-local sums.  Per-workgroup partials are combined deterministically by dec_bwd_finalize_kernel.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -62,10 +63,15 @@ __device__ __forceinline__ s16x8 lds_a(const unsigned short* base, int pitch, in
 __device__ __forceinline__ f32x4 mma(s16x8 a, s16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ float group4_sum(float v) {      // over the 4 lane groups holding one pixel's channels
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+// over the 4 lane groups (rows of 16 lanes) holding one pixel's channels.  v_permlane16_swap / v_permlane32_swap (gfx950)
+// exchange rows between two registers in the VALU: with both operands = v, the two results are (this row pair's even row,
+// its odd row) resp. (lower half, upper half) in every lane -- the xor-16 / xor-32 butterfly without the two ds_bpermute
+// round trips through the LDS unit (16 of them sat in the backward chain of every sub-tile).  Same sums, same bits.
+__device__ __forceinline__ float group4_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 // cooperative copy of a [rows][cols] bf16 matrix (global, dense) into LDS with pitch
 __device__ __forceinline__ void stage(unsigned short* dst, int pitch, const bf16* src, int rows, int cols, int tid) {
@@ -84,7 +90,7 @@ __device__ __forceinline__ void stage(unsigned short* dst, int pitch, const bf16
 __device__ __forceinline__ float gelu_fast(float z, float* dgelu) {
     const float az = fabsf(z);
     const float u = __expf(-0.5f * z * z);
-    const float t = __frcp_rn(1.0f + 0.3275911f * 0.70710678118654752440f * az);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678118654752440f * az);      // (v_rcp_f32, 1 ulp: an IEEE division is ~8 instructions)
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * u;
     const float phi = 0.5f * (1.0f + copysignf(erf_abs, z));
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void dec_fwd_kernel(DecArgs p) {
             float e[4], sum = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { e[j] = __expf(d[j] - m); sum += e[j]; }
-            const float inv = 1.f / sum;
+            const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
             for (int j = 0; j < 4; ++j) at[s][j] = e[j] * inv;
         }
@@ -222,12 +228,46 @@ __device__ __forceinline__ void tile_put(unsigned char* tile, int pitch, int pp,
     *reinterpret_cast<uint2*>(tile + pp * pitch + (c0 + 16 + g * 4) * 2) = r.h[1];
 }
 
-// (forcing two waves per SIMD with __launch_bounds__(256, 2) spills 400 - 900 bytes per lane: 34 -> 64 us per launch)
+// transpose read, K = 16: channel-sub `cs` of a wave-private [16 px][ch] bf16 tile -> fragment with k = the 16 pixels
+// (lane (pl, g): pixels g*4 .. g*4+3 of channel cs*16 + pl -- the operand layout of v_mfma_f32_16x16x16_bf16)
+__device__ __forceinline__ s16x4 tile_frag16(const unsigned char* tile, int pitch, int cs, int pl, int g) {
+    const unsigned char* base = tile + (g * 4 + (pl >> 2)) * pitch + (cs * 16 + (pl & 3) * 4) * 2;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+}
+__device__ __forceinline__ f32x4 mma16(s16x4 a, s16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void lds4(const float* p, float (&o)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+
+// Backward, TWO workgroups per CU (<= 256 registers).  The first form of this kernel carried two 16-pixel sub-tiles per wave
+// through the whole chain so that the pixel-reduction products could use K = 32 MFMAs: 367 registers, one wave per SIMD, and a
+// chain of ~60 dependent stages (LayerNorm shuffles, MFMA results, LDS fragments, exp / rcp, parameter vectors fetched from
+// global memory inside the loop, eight workgroup barriers per iteration around WAVE-PRIVATE tiles) with nothing to overlap
+// it: 1.6k instructions took 13.9k cycles per 32 pixels (57.9 us for 64 x 4096 rows = 0.87 TB/s).  Here a wave carries ONE
+// sub-tile at a time, the pixel reductions use the K = 16 MFMA (v_mfma_f32_16x16x16_bf16: 16 pixels = one sub-tile) right
+// after the chain, the parameter vectors sit in LDS, and no workgroup barrier is left in the loop (a wave's LDS operations
+// execute in order: write tile, read it back transposed); the second wave of each SIMD hides the chain's latencies.
+// -DDEC_TIMING: shader-cycle sums per phase of the sub-tile loop (wave 0 of every workgroup) for tools/dec_timeline.py
+#ifdef DEC_TIMING
+__device__ long long g_dect[4096 * 20];
+#define DEC_T(k) do { const long long now_ = (long long)clock64(); t_acc[k] += now_ - t_last; t_last = now_; } while (0)
+#else
+#define DEC_T(k) do { } while (0)
+#endif
+
 template <int MLP>
-__global__ __launch_bounds__(256) void dec_bwd_kernel(DecArgs p) {
+__global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_kernel(DecArgs p) {
+#ifdef DEC_TIMING
+    long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = (long long)clock64();
+    const long long t_begin = t_last;
+#endif
     constexpr int NM = MLP / 16, NQ = MLP / 32;
     constexpr int TP32 = lds_pitch(64), TPM = lds_pitch(MLP * 2);       // tile pitches (bytes)
-    constexpr int TILE = 32 * (TPM > TP32 ? TPM : TP32);                // bytes per wave-private tile
+    constexpr int TILE = 16 * (TPM > TP32 ? TPM : TP32);                // bytes per wave-private 16-pixel tile
+    using P = PL<MLP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short* sKq = reinterpret_cast<unsigned short*>(smem);
     unsigned short* sVoT = sKq + 32 * WP;
@@ -235,12 +275,14 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecArgs p) {
     unsigned short* sKqT = sVo + 32 * WP;
     unsigned short* sW1 = sKqT + 32 * WP;                   // [MLP][32]
     unsigned short* sW2T = sW1 + MLP * WP;                  // [MLP][32]
-    unsigned short* sW2 = sW2T + MLP * WP;                  // [32][MLP]
-    unsigned short* sW1T = sW2 + 32 * (MLP + 8);            // [32][MLP]
-    unsigned char* tiles = reinterpret_cast<unsigned char*>(sW1T + 32 * (MLP + 8));
+    unsigned short* sW1T = sW2T + MLP * WP;                 // [32][MLP]
+    float* sPar = reinterpret_cast<float*>(sW1T + 32 * (MLP + 8));      // g1, be1, bo, g2, be2, fb1[MLP]: 5 * 32 + MLP floats
+    unsigned char* tiles = reinterpret_cast<unsigned char*>(sPar + 5 * 32 + MLP);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
-    unsigned char* tA = tiles + (wv * 2 + 0) * TILE;
-    unsigned char* tB = tiles + (wv * 2 + 1) * TILE;
+    unsigned char* tA0 = tiles + (wv * 4 + 0) * TILE;
+    unsigned char* tB0 = tiles + (wv * 4 + 1) * TILE;
+    unsigned char* tA1 = tiles + (wv * 4 + 2) * TILE;
+    unsigned char* tB1 = tiles + (wv * 4 + 3) * TILE;
     const long row0 = (long)blockIdx.x * p.rows_per_block;
     const int img = (int)(row0 / p.rows_per_image);
     stage(sKq, WP, p.kq + (size_t)img * 32 * D, 32, D, tid);
@@ -249,9 +291,14 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecArgs p) {
     stage(sKqT, WP, p.kqT + (size_t)img * D * 32, D, 32, tid);
     stage(sW1, WP, p.w1, MLP, D, tid);
     stage(sW2T, WP, p.w2T, MLP, D, tid);
-    stage(sW2, MLP + 8, p.w2, D, MLP, tid);
     stage(sW1T, MLP + 8, p.w1T, D, MLP, tid);
+    if (tid < 32) {
+        sPar[tid] = p.g1[tid]; sPar[32 + tid] = p.be1[tid]; sPar[64 + tid] = p.bo[tid];
+        sPar[96 + tid] = p.g2[tid]; sPar[128 + tid] = p.be2[tid];
+    }
+    if (tid < MLP) sPar[160 + tid] = p.fb1[tid];
     __syncthreads();
+    const float *cG1 = sPar, *cBe1 = sPar + 32, *cBo = sPar + 64, *cG2 = sPar + 96, *cBe2 = sPar + 128, *cFb1 = sPar + 160;
 
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 aW1[NM][2], aW2[2][NM], aKq[2][2], aVoT[2][2];
@@ -269,203 +316,260 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { sb2[a][j] = sbo[a][j] = sg1[a][j] = sbe1[a][j] = sg2[a][j] = sbe2[a][j] = 0.f; }
 
-    for (int it = 0; it < p.rows_per_block / 128; ++it) {
-        // packed operands of the two 16-pixel sub-tiles kept for the pixel-reduction products
-        s16x8 kdy[2], kl2[2], kdd[2], kxn[2], kdx1[2], kat[2], kh[2][NQ], kdz[2][NQ];
+    const int nsub = p.rows_per_block / 64;                 // 16-pixel sub-tiles per wave
+    // x / dy of the NEXT sub-tile are requested while this one is computed (raw bf16: 8 registers): the loop is one
+    // dependent chain, a load at its head would be waited for at HBM latency in every round
+    uint2 nx[2], ndy[2];
+    auto request = [&](int it) {
+        const long row = row0 + (it * 4 + wv) * 16 + pl;
+        const bf16* xr = p.x + row * D;
+        const bf16* gr = p.dy + row * D;
+        nx[0] = *reinterpret_cast<const uint2*>(xr + g * 4);
+        nx[1] = *reinterpret_cast<const uint2*>(xr + 16 + g * 4);
+        ndy[0] = *reinterpret_cast<const uint2*>(gr + g * 4);
+        ndy[1] = *reinterpret_cast<const uint2*>(gr + 16 + g * 4);
+    };
+    auto widen = [](const uint2& u, float (&o)[4]) {
+        o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+        o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+    };
+    request(0);
+    DEC_T(10);
+#pragma unroll 1
+    for (int it = 0; it < nsub; ++it) {
+        const long row = row0 + (it * 4 + wv) * 16 + pl;
+        float x[2][4], dy[2][4];
+        widen(nx[0], x[0]);
+        widen(nx[1], x[1]);
+        widen(ndy[0], dy[0]);
+        widen(ndy[1], dy[1]);
+        if (it + 1 < nsub) request(it + 1);
+        // ---- forward, recomputed from x ----
+        float xh1[2][4], xn[2][4], gam[2][4], bet[2][4];
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const long row = row0 + it * 128 + wv * 32 + ps * 16 + pl;
-            const bf16* xr = p.x + row * D;
-            float x[2][4], xh1[2][4], xn[2][4];
-            ld4(xr + g * 4, x[0]);
-            ld4(xr + 16 + g * 4, x[1]);
-            const LNres n1 = layer_norm(x, p.g1, p.be1, g, p.eps, xh1, xn);
-            kxn[ps] = pack8(xn[0], xn[1]);
-            float at[2][4];
+        for (int s = 0; s < 2; ++s) { lds4(cG1 + s * 16 + g * 4, gam[s]); lds4(cBe1 + s * 16 + g * 4, bet[s]); }
+        LNres n1;
+        {
+            float sm = 0.f;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f32x4 d = mma(lds_a(sKq, WP, s * 16 + pl, 0, g), kxn[ps], zero4);
-                const float m = fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]));
-                float e[4], sum = 0.f;
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { e[j] = __expf(d[j] - m); sum += e[j]; }
-                const float inv = 1.f / sum;
+                for (int j = 0; j < 4; ++j) sm += x[h][j];
+            n1.mean = group4_sum(sm) * (1.f / D);
+            float q = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) at[s][j] = e[j] * inv;
-            }
-            kat[ps] = pack8(at[0], at[1]);
-            float x1[2][4];
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f32x4 o = mma(lds_a(sVoT, WP, s * 16 + pl, 0, g), kat[ps], zero4);
+                for (int j = 0; j < 4; ++j) { const float d = x[h][j] - n1.mean; q += d * d; }
+            n1.rstd = rsqrtf(group4_sum(q) * (1.f / D) + p.eps);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x1[s][j] = o[j] + p.bo[s * 16 + g * 4 + j] + x[s][j];
-            }
-            float xh2[2][4], l2[2][4];
-            const LNres n2 = layer_norm(x1, p.g2, p.be2, g, p.eps, xh2, l2);
-            kl2[ps] = pack8(l2[0], l2[1]);
-            float dg[NM][4], hh[NM][4];              // gelu'(z), gelu(z)
-#pragma unroll
-            for (int s = 0; s < NM; ++s) {
-                f32x4 zz = mma(lds_a(sW1, WP, s * 16 + pl, 0, g), kl2[ps], zero4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) hh[s][j] = gelu_fast(zz[j] + p.fb1[s * 16 + g * 4 + j], &dg[s][j]);
-            }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) kh[ps][q] = pack8(hh[2 * q], hh[2 * q + 1]);
-            // ---- backward chain ----
-            const bf16* gr = p.dy + row * D;
-            float dy[2][4];
-            ld4(gr + g * 4, dy[0]);
-            ld4(gr + 16 + g * 4, dy[1]);
-            kdy[ps] = pack8(dy[0], dy[1]);
-            float dz[NM][4];
-#pragma unroll
-            for (int s = 0; s < NM; ++s) {
-                f32x4 dh = mma(lds_a(sW2T, WP, s * 16 + pl, 0, g), kdy[ps], zero4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { dz[s][j] = dh[j] * dg[s][j]; sb1[s][j] += dz[s][j]; }
-            }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) kdz[ps][q] = pack8(dz[2 * q], dz[2 * q + 1]);
-            f32x4 dl2[2] = {zero4, zero4};
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) dl2[s] = mma(lds_a(sW1T, MLP + 8, s * 16 + pl, 32 * q, g), kdz[ps][q], dl2[s]);
-            // LayerNorm-2 backward (+ residual)
-            float gh[2][4], sa = 0.f, sbb = 0.f, dx1[2][4];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int c = s * 16 + g * 4 + j;
-                    sg2[s][j] += dl2[s][j] * xh2[s][j];
-                    sbe2[s][j] += dl2[s][j];
-                    sb2[s][j] += dy[s][j];
-                    gh[s][j] = dl2[s][j] * p.g2[c];
-                    sa += gh[s][j];
-                    sbb += gh[s][j] * xh2[s][j];
+                    xh1[h][j] = (x[h][j] - n1.mean) * n1.rstd;
+                    xn[h][j] = xh1[h][j] * gam[h][j] + bet[h][j];
                 }
-            sa = group4_sum(sa);
-            sbb = group4_sum(sbb);
+        }
+        const s16x8 kxn = pack8(xn[0], xn[1]);
+        DEC_T(0);
+        float at[2][4];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+            f32x4 d = mma(lds_a(sKq, WP, s * 16 + pl, 0, g), kxn, zero4);
+            const float m = fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]));
+            float e[4], sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { e[j] = __expf(d[j] - m); sum += e[j]; }
+            const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) at[s][j] = e[j] * inv;
+        }
+        const s16x8 kat = pack8(at[0], at[1]);
+        DEC_T(1);
+        float x1[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 o = mma(lds_a(sVoT, WP, s * 16 + pl, 0, g), kat, zero4);
+            float bo4[4];
+            lds4(cBo + s * 16 + g * 4, bo4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x1[s][j] = o[j] + bo4[j] + x[s][j];
+        }
+        float xh2[2][4], l2[2][4], gam2[2][4];
+        LNres n2;
+        {
+            float sm = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sm += x1[h][j];
+            n2.mean = group4_sum(sm) * (1.f / D);
+            float q = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = x1[h][j] - n2.mean; q += d * d; }
+            n2.rstd = rsqrtf(group4_sum(q) * (1.f / D) + p.eps);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float b4[4];
+                lds4(cG2 + h * 16 + g * 4, gam2[h]);
+                lds4(cBe2 + h * 16 + g * 4, b4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    dx1[s][j] = n2.rstd * (gh[s][j] - (sa + xh2[s][j] * sbb) * (1.f / D)) + dy[s][j];
-                    sbo[s][j] += dx1[s][j];
+                    xh2[h][j] = (x1[h][j] - n2.mean) * n2.rstd;
+                    l2[h][j] = xh2[h][j] * gam2[h][j] + b4[j];
                 }
-            kdx1[ps] = pack8(dx1[0], dx1[1]);
-            // attention backward
-            float dd[2][4];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f32x4 da = mma(lds_a(sVo, WP, s * 16 + pl, 0, g), kdx1[ps], zero4);
-                float dot = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dot += at[s][j] * da[j];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dd[s][j] = at[s][j] * (da[j] - dot);
-            }
-            kdd[ps] = pack8(dd[0], dd[1]);
-            float dxn[2][4];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f32x4 t = mma(lds_a(sKqT, WP, s * 16 + pl, 0, g), kdd[ps], zero4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dxn[s][j] = t[j];
-            }
-            sa = 0.f; sbb = 0.f;
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = s * 16 + g * 4 + j;
-                    sg1[s][j] += dxn[s][j] * xh1[s][j];
-                    sbe1[s][j] += dxn[s][j];
-                    gh[s][j] = dxn[s][j] * p.g1[c];
-                    sa += gh[s][j];
-                    sbb += gh[s][j] * xh1[s][j];
-                }
-            sa = group4_sum(sa);
-            sbb = group4_sum(sbb);
-            bf16* dxr = p.y + row * D;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float r[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r[j] = n1.rstd * (gh[s][j] - (sa + xh1[s][j] * sbb) * (1.f / D)) + dx1[s][j];
-                st4(dxr + s * 16 + g * 4, r);
             }
         }
-        // ---- pixel-reduction products over this wave's 32 pixels (K = 32), through wave-private LDS tiles ----
-        // dW2[c][m] += dy^T h
+        const s16x8 kl2 = pack8(l2[0], l2[1]);
+        DEC_T(2);
+        float dg[NM][4], hh[NM][4];                  // gelu'(z), gelu(z)
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            tile_put(tA, TP32, ps * 16 + pl, 0, g, kdy[ps]);
+        for (int s = 0; s < NM; ++s) {
+            f32x4 zz = mma(lds_a(sW1, WP, s * 16 + pl, 0, g), kl2, zero4);
+            float b4[4];
+            lds4(cFb1 + s * 16 + g * 4, b4);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) tile_put(tB, TPM, ps * 16 + pl, 32 * q, g, kh[ps][q]);
+            for (int j = 0; j < 4; ++j) hh[s][j] = gelu_fast(zz[j] + b4[j], &dg[s][j]);
         }
-        __syncthreads();
+        s16x8 kh[NQ], kdz[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) kh[q] = pack8(hh[2 * q], hh[2 * q + 1]);
+        DEC_T(3);
+        // ---- backward chain ----
+        const s16x8 kdy = pack8(dy[0], dy[1]);
+        // dW2[c][m] += dy^T h  (tiles A0 / B0)
+        tile_put(tA0, TP32, pl, 0, g, kdy);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) tile_put(tB0, TPM, pl, 32 * q, g, kh[q]);
+        float dz[NM][4];
+#pragma unroll
+        for (int s = 0; s < NM; ++s) {
+            f32x4 dh = mma(lds_a(sW2T, WP, s * 16 + pl, 0, g), kdy, zero4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dz[s][j] = dh[j] * dg[s][j]; sb1[s][j] += dz[s][j]; }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) kdz[q] = pack8(dz[2 * q], dz[2 * q + 1]);
+        // dW1[m][c] += dz^T l2  (tiles A1 / B1)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) tile_put(tA1, TPM, pl, 32 * q, g, kdz[q]);
+        tile_put(tB1, TP32, pl, 0, g, kl2);
+        DEC_T(4);
 #pragma unroll
         for (int sc = 0; sc < 2; ++sc) {
-            const s16x8 fa = tile_frag(tA, TP32, sc, pl, g);
+            const s16x4 fa = tile_frag16(tA0, TP32, sc, pl, g);
 #pragma unroll
-            for (int sm = 0; sm < NM; ++sm) aW2[sc][sm] = mma(fa, tile_frag(tB, TPM, sm, pl, g), aW2[sc][sm]);
+            for (int sm = 0; sm < NM; ++sm) aW2[sc][sm] = mma16(fa, tile_frag16(tB0, TPM, sm, pl, g), aW2[sc][sm]);
         }
-        __syncthreads();
-        // dW1[m][c] += dz^T l2
+        f32x4 dl2[2] = {zero4, zero4};
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) tile_put(tA, TPM, ps * 16 + pl, 32 * q, g, kdz[ps][q]);
-            tile_put(tB, TP32, ps * 16 + pl, 0, g, kl2[ps]);
-        }
-        __syncthreads();
+            for (int s = 0; s < 2; ++s) dl2[s] = mma(lds_a(sW1T, MLP + 8, s * 16 + pl, 32 * q, g), kdz[q], dl2[s]);
+        DEC_T(5);
+        // LayerNorm-2 backward (+ residual)
+        float gh[2][4], sa = 0.f, sbb = 0.f, dx1[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sg2[s][j] += dl2[s][j] * xh2[s][j];
+                sbe2[s][j] += dl2[s][j];
+                sb2[s][j] += dy[s][j];
+                gh[s][j] = dl2[s][j] * gam2[s][j];
+                sa += gh[s][j];
+                sbb += gh[s][j] * xh2[s][j];
+            }
+        sa = group4_sum(sa);
+        sbb = group4_sum(sbb);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dx1[s][j] = n2.rstd * (gh[s][j] - (sa + xh2[s][j] * sbb) * (1.f / D)) + dy[s][j];
+                sbo[s][j] += dx1[s][j];
+            }
+        const s16x8 kdx1 = pack8(dx1[0], dx1[1]);
+        DEC_T(6);
 #pragma unroll
         for (int sm = 0; sm < NM; ++sm) {
-            const s16x8 fa = tile_frag(tA, TPM, sm, pl, g);
+            const s16x4 fa = tile_frag16(tA1, TPM, sm, pl, g);
 #pragma unroll
-            for (int sc = 0; sc < 2; ++sc) aW1[sm][sc] = mma(fa, tile_frag(tB, TP32, sc, pl, g), aW1[sm][sc]);
+            for (int sc = 0; sc < 2; ++sc) aW1[sm][sc] = mma16(fa, tile_frag16(tB1, TP32, sc, pl, g), aW1[sm][sc]);
         }
-        __syncthreads();
-        // dKq[hl][c] += dd^T xn
+        // dVoT[c][hl] += dx1^T attn  (tiles A0 / B0 again: the reads of dW2 were issued above, LDS runs a wave's operations in order)
+        tile_put(tA0, TP32, pl, 0, g, kdx1);
+        tile_put(tB0, TP32, pl, 0, g, kat);
+        // attention backward
+        float dd[2][4];
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            tile_put(tA, TP32, ps * 16 + pl, 0, g, kdd[ps]);
-            tile_put(tB, TP32, ps * 16 + pl, 0, g, kxn[ps]);
+        for (int s = 0; s < 2; ++s) {
+            f32x4 da = mma(lds_a(sVo, WP, s * 16 + pl, 0, g), kdx1, zero4);
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dot += at[s][j] * da[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dd[s][j] = at[s][j] * (da[j] - dot);
         }
-        __syncthreads();
+        const s16x8 kdd = pack8(dd[0], dd[1]);
+        DEC_T(7);
+        // dKq[hl][c] += dd^T xn  (tiles A1 / B1 again)
+        tile_put(tA1, TP32, pl, 0, g, kdd);
+        tile_put(tB1, TP32, pl, 0, g, kxn);
 #pragma unroll
         for (int sr = 0; sr < 2; ++sr) {
-            const s16x8 fa = tile_frag(tA, TP32, sr, pl, g);
+            const s16x4 fa = tile_frag16(tA0, TP32, sr, pl, g);
 #pragma unroll
-            for (int sc = 0; sc < 2; ++sc) aKq[sr][sc] = mma(fa, tile_frag(tB, TP32, sc, pl, g), aKq[sr][sc]);
+            for (int sc = 0; sc < 2; ++sc) aVoT[sr][sc] = mma16(fa, tile_frag16(tB0, TP32, sc, pl, g), aVoT[sr][sc]);
         }
-        __syncthreads();
-        // dVoT[c][hl] += dx1^T attn
+        float dxn[2][4];
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            tile_put(tA, TP32, ps * 16 + pl, 0, g, kdx1[ps]);
-            tile_put(tB, TP32, ps * 16 + pl, 0, g, kat[ps]);
+        for (int s = 0; s < 2; ++s) {
+            f32x4 t = mma(lds_a(sKqT, WP, s * 16 + pl, 0, g), kdd, zero4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dxn[s][j] = t[j];
         }
-        __syncthreads();
+        sa = 0.f; sbb = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sg1[s][j] += dxn[s][j] * xh1[s][j];
+                sbe1[s][j] += dxn[s][j];
+                gh[s][j] = dxn[s][j] * gam[s][j];
+                sa += gh[s][j];
+                sbb += gh[s][j] * xh1[s][j];
+            }
+        sa = group4_sum(sa);
+        sbb = group4_sum(sbb);
+        bf16* dxr = p.y + row * D;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = n1.rstd * (gh[s][j] - (sa + xh1[s][j] * sbb) * (1.f / D)) + dx1[s][j];
+            st4(dxr + s * 16 + g * 4, r);
+        }
+        DEC_T(8);
 #pragma unroll
         for (int sr = 0; sr < 2; ++sr) {
-            const s16x8 fa = tile_frag(tA, TP32, sr, pl, g);
+            const s16x4 fa = tile_frag16(tA1, TP32, sr, pl, g);
 #pragma unroll
-            for (int sc = 0; sc < 2; ++sc) aVoT[sr][sc] = mma(fa, tile_frag(tB, TP32, sc, pl, g), aVoT[sr][sc]);
+            for (int sc = 0; sc < 2; ++sc) aKq[sr][sc] = mma16(fa, tile_frag16(tB1, TP32, sc, pl, g), aKq[sr][sc]);
         }
-        __syncthreads();
+        DEC_T(9);
     }
 
     // ---- combine the 4 wavefronts deterministically, then write this workgroup's partial ----
-    // Every wave parks its sums in its OWN slot (all four at once; the pixel-lane reductions are DPP row sums) and the
-    // slots are added in wave order.  The former turn-taking read-modify-write of one slot, with 56 ds_bpermute
-    // butterfly chains inside each wave's turn, took 40 of the workgroup's 70 us (tools/dec_timeline.py).
-    using P = PL<MLP>;
-    float* red = reinterpret_cast<float*>(tiles);            // [4][P::SIZE] floats (host sized the LDS)
+    // Every wave parks its sums in its OWN slot (all four at once; the pixel-lane reductions are DPP row sums) and the slots
+    // are added in wave order.  (Measured alternatives: turn-taking through ONE slot with ds_bpermute butterflies inside each
+    // wave's turn took 40 of the first kernel's 70 us; two slots with waves 2 / 3 ADDING onto waves 0 / 1 -- 130 dependent
+    // LDS read-modify-writes the compiler may not reorder -- 17k of this kernel's 74k cycles, tools/dec_timeline.py.)
+    __syncthreads();                                         // every wave is done with the weights / tiles
+    DEC_T(12);
+    float* red = reinterpret_cast<float*>(smem);             // [4][P::SIZE] floats (host sized the LDS)
     float* mine = red + (size_t)wv * P::SIZE;
 #pragma unroll
     for (int sm = 0; sm < NM; ++sm)
@@ -485,31 +589,49 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecArgs p) {
                 mine[P::KQ + (sr * 16 + g * 4 + j) * D + sc * 16 + pl] = aKq[sr][sc][j];
                 mine[P::VOT + (sr * 16 + g * 4 + j) * 32 + sc * 16 + pl] = aVoT[sr][sc][j];
             }
-    // lane-local column sums: over the 16 pixel lanes of the row (the same butterfly sums as four xor-shuffles)
+    DEC_T(13);
+    // lane-local column sums: over the 16 pixel lanes of the row.  All the DPP row sums first (independent chains, full
+    // exec), then ONE masked block of 16-byte stores: a masked 4-byte store after every sum toggled exec 56 times and took
+    // 3.9k of the workgroup's 65k cycles (tools/dec_timeline.py)
 #pragma unroll
     for (int s = 0; s < NM; ++s)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = row16_sum(sb1[s][j]);
-            if (pl == 0) mine[P::B1 + s * 16 + g * 4 + j] = v;
-        }
+        for (int j = 0; j < 4; ++j) sb1[s][j] = row16_sum(sb1[s][j]);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float v[6] = {sb2[s][j], sbo[s][j], sg1[s][j], sbe1[s][j], sg2[s][j], sbe2[s][j]};
-            const int off[6] = {P::B2, P::BO, P::G1, P::BE1, P::G2, P::BE2};
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const float t = row16_sum(v[k]);
-                if (pl == 0) mine[off[k] + s * 16 + g * 4 + j] = t;
-            }
+            sb2[s][j] = row16_sum(sb2[s][j]); sbo[s][j] = row16_sum(sbo[s][j]); sg1[s][j] = row16_sum(sg1[s][j]);
+            sbe1[s][j] = row16_sum(sbe1[s][j]); sg2[s][j] = row16_sum(sg2[s][j]); sbe2[s][j] = row16_sum(sbe2[s][j]);
         }
+    if (pl == 0) {
+        auto put4 = [&](int off, const float (&v)[4]) { *reinterpret_cast<float4*>(mine + off + g * 4) = make_float4(v[0], v[1], v[2], v[3]); };
+#pragma unroll
+        for (int s = 0; s < NM; ++s) put4(P::B1 + s * 16, sb1[s]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            put4(P::B2 + s * 16, sb2[s]); put4(P::BO + s * 16, sbo[s]); put4(P::G1 + s * 16, sg1[s]);
+            put4(P::BE1 + s * 16, sbe1[s]); put4(P::G2 + s * 16, sg2[s]); put4(P::BE2 + s * 16, sbe2[s]);
+        }
+    }
+    DEC_T(14);
     __syncthreads();
+    DEC_T(15);
     float* out = p.partial + (size_t)blockIdx.x * P::SIZE;
     for (int i = tid; i < P::SIZE; i += 256)
         out[i] = ((red[i] + red[P::SIZE + i]) + red[2 * P::SIZE + i]) + red[3 * P::SIZE + i];
+#ifdef DEC_TIMING
+    DEC_T(11);
+    if (tid == 0 && blockIdx.x < 4096) {
+        for (int k = 0; k < 16; ++k) g_dect[blockIdx.x * 20 + k] = t_acc[k];
+        g_dect[blockIdx.x * 20 + 16] = nsub;
+        g_dect[blockIdx.x * 20 + 17] = t_last - t_begin;
+    }
+#endif
 }
+#ifdef DEC_TIMING
+extern "C" int dh_debug_dect(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dect), (size_t)n * 8); }
+#endif
 
 // sums the workgroup partials: shared parameters over all workgroups (accumulated into the gradient arena),
 // per-image dKq / dVoT over the workgroups of that image (assigned)
@@ -581,11 +703,11 @@ __global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(const float* __re
 }
 
 template <int MLP> size_t bwd_lds_bytes() {
-    const size_t w = (size_t)(4 * 32 * WP + 2 * MLP * WP + 2 * 32 * (MLP + 8)) * 2;
-    const size_t tile = 32 * (size_t)(lds_pitch(MLP * 2) > lds_pitch(64) ? lds_pitch(MLP * 2) : lds_pitch(64));
-    size_t t = 8 * tile;
-    if (t < (size_t)PL<MLP>::SIZE * 4 * 4) t = (size_t)PL<MLP>::SIZE * 4 * 4;      // four wave slots of the final combine
-    return w + t;
+    const size_t w = (size_t)(4 * 32 * WP + 2 * MLP * WP + 32 * (MLP + 8)) * 2 + (size_t)(5 * 32 + MLP) * 4;
+    const size_t tile = 16 * (size_t)(lds_pitch(MLP * 2) > lds_pitch(64) ? lds_pitch(MLP * 2) : lds_pitch(64));
+    size_t t = w + 16 * tile;                                 // four tiles per wave
+    if (t < (size_t)PL<MLP>::SIZE * 4 * 4) t = (size_t)PL<MLP>::SIZE * 4 * 4;      // the four wave slots of the final combine
+    return t;
 }
 
 }  // namespace
@@ -616,10 +738,16 @@ extern "C" int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, cons
     return 0;
 }
 
-static inline int dec_rows_per_block(int rows_per_image) { return rows_per_image >= 512 ? 512 : (rows_per_image >= 256 ? 256 : 128); }
+// rows per backward workgroup: 512 at most (every workgroup writes a PL::SIZE partial), fewer while that leaves less than the
+// two workgroups per CU the kernel is resident with; a multiple of 64 (one 16-pixel sub-tile per wave) that divides an image
+static inline int dec_rows_per_block(long rows, int rows_per_image) {
+    int rpb = 512;
+    while (rpb > 64 && (rows_per_image % rpb || rows / rpb < 512)) rpb >>= 1;
+    return rpb;
+}
 
 extern "C" long dh_decoder_layer_bwd_workspace_size(long rows, int rows_per_image, int mlp) {
-    const long nblk = rows / dec_rows_per_block(rows_per_image);
+    const long nblk = rows / dec_rows_per_block(rows, rows_per_image);
     return nblk * (mlp == 64 ? PL<64>::SIZE : PL<32>::SIZE) * 4;
 }
 
@@ -642,7 +770,7 @@ extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, con
     a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2; a.w1T = (const bf16*)w1T; a.w2T = (const bf16*)w2T;
     a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
     a.partial = reinterpret_cast<float*>(workspace);
-    a.rows_per_image = rows_per_image; a.rows_per_block = dec_rows_per_block(rows_per_image); a.rows = rows; a.eps = eps;
+    a.rows_per_image = rows_per_image; a.rows_per_block = dec_rows_per_block(rows, rows_per_image); a.rows = rows; a.eps = eps;
     const int nblk = (int)(rows / a.rows_per_block), bpi = rows_per_image / a.rows_per_block;
     const int images = (int)(rows / rows_per_image);
     static bool attr64 = false, attr32 = false;
@@ -682,7 +810,7 @@ extern "C" int dh_decoder_stack_bwd_finalize(const void* workspace, int depth, l
                                              float* dln2_g, float* dln2_b, long grad_stride, float* dkq, float* dvoT, void* stream) {
     if (check_common(rows, rows_per_image, mlp)) return 1;
     DH_REQUIRE(depth >= 1 && workspace && dw1 && dkq && dvoT, "decoder_stack_bwd_finalize: bad arguments (depth %d)", depth);
-    const int rpb = dec_rows_per_block(rows_per_image);
+    const int rpb = dec_rows_per_block(rows, rows_per_image);
     const int nblk = (int)(rows / rpb), bpi = rows_per_image / rpb, images = (int)(rows / rows_per_image);
     const float* partial = reinterpret_cast<const float*>(workspace);
     const long pstride = dh_decoder_layer_bwd_workspace_size(rows, rows_per_image, mlp) / 4, kstride = (long)images * 1024;
