@@ -372,7 +372,7 @@ def main():
                     "all_wgrad_ms_per_step": round(sum(v[0] for k, v in agg.items() if k.startswith("conv_wgrad")), 3),
                     "all_mfma_conv_tflops": round(sum(v[1] for v in mfma.values()) / (sum(v[0] for v in mfma.values()) * 1e-3) / 1e12, 1),
                     "kernels_of_class": "conv_mfma_kernel<bf16,3,1,64,...> (tap-oriented) and conv3x3_wreg_kernel (register-resident "
-                                        "weights, the 64-channel layers): every 3x3 stride-1 convolution and data gradient of the "
+                                        "weights: the 64-channel layers and, without BatchNorm on load, the 128- and 256-channel ones): every 3x3 stride-1 convolution and data gradient of the "
                                         "step; the 2x2 phase convolutions are their own class (conv_phase<...>)",
                     "weight_gradient": wgrad, "step_traffic": step_traffic}
         classes = {}

@@ -519,10 +519,10 @@ bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
         if (!(a.Cin == 64 || (a.w_frag && !a.in_scale))) return false;
     }
     // a persistent workgroup must see enough tiles to amortise loading its weights (74 KB at 64 input channels, two workgroups
-    // per CU; 295 KB at 256, one per CU): measured at 4 resp. 8 tiles per workgroup, required here: >= 4 resp. >= 6
+    // per CU; 147 / 295 KB at 128 / 256, one per CU): measured down to 4 tiles per workgroup (256 -> 128 at 64 images: x1.08)
     const long work = (long)a.N * (a.OH / 8) * (a.OW / 16) * (a.Cout / 64);
     if (g_wreg_mode == 1) return work >= 2 * 256;
-    return a.Cin == 64 ? work >= 4 * 512 : (a.Cin == 128 ? work >= 4 * 256 : work >= 6 * 256);
+    return a.Cin == 64 ? work >= 4 * 512 : work >= 4 * 256;
 }
 
 // C ABI (include/dahitra_hip.h): route the eligible 3x3 convolutions through the tap-oriented kernel instead (mode 0), or
