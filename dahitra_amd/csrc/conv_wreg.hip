@@ -496,6 +496,345 @@ int wr_launch_bn(const ConvArgs& c, hipStream_t st, int cus) {
                 : wr_launch<NSUB, NCH, D, PFD, false, WPS, false, false>(c, st, cus);
 }
 
+// ---- 32 -> 32 channels (classifier.0, the 32-channel convolutions of the UNet up path) ----------------------------------------
+// One 32-channel chunk, 32 output channels: the whole layer is 18 KB of weights, which the tap kernel stages next to EVERY
+// 11.5 KB halo (447 TFLOP/s on 32 x 256 x 256 pixels, 86 us where the tensors' HBM time is 54).  Same stream as above with
+// one stage per tile; the four waves split a tile as (16-channel half) x (4-row half), nine weight fragments = 36 registers
+// per lane, two workgroups per CU.  The two row halves of a channel meet in the BatchNorm partial sums: the upper half
+// parks its row sums in LDS, the lower half adds them after the stage barrier (so the sums are (rows 0-3) + (rows 4-7), not
+// the tap kernel's running sum over eight rows: equal up to fp32 rounding, unlike y, which is bit-identical).
+// UP4: the data gradient of conv3x3(bilinear_x4(.)) (ConvArgs::up4_partial, see conv_mfma_impl.h): the fp32 tile goes to LDS and
+// is reduced to the 4 x 6 coarse pixels it touches (separable: columns, then rows); y is never stored.  This epilogue runs
+// whole at the end of its tile (two extra barriers), not pipelined into the next one.
+template <bool RES, bool RELU, int WPS, bool UP4>
+__global__ __launch_bounds__(256, WPS) void conv3x3_wreg32_kernel(WrArgs a) {
+    constexpr int D = 3, PFD = 2, NB = PFD + 1;
+    constexpr int RH = 4, HR = RH + 2;                     // output rows / halo rows per wave
+    constexpr int NSTEP = 3 * HR;                          // 18 steps per tile and wave
+    constexpr int SYNC = 8;
+    constexpr int NCO = 32, TPITCH = NCO * 2 + 16, PPR = NCO * 2 / 16;
+    constexpr int NST = WR_TH * TW * PPR / 256;            // 2 cooperative store rounds
+    static_assert(NSTEP % NB == 0 && SYNC + NST + 1 < NSTEP && RH < SYNC, "pipeline shape");
+    const ConvArgs& p = a.c;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane(wr_lds_addr(smem));
+    // The staged output tile and the parked sums are DOUBLE-BUFFERED by tile parity: with one stage per tile there is no
+    // barrier between the cooperative reads of tile k - 1 (steps 9 .. 11 of tile k) and the row writes of tile k (steps 0 .. 3
+    // of tile k + 1); a wave can be at most one barrier ahead of another, so two buffers are enough.
+    constexpr int OT = WR_TH * TW * TPITCH;
+    unsigned char* otile0 = smem + D * WR_IMG;             // [2][128 px][TPITCH]
+    float* spart0 = reinterpret_cast<float*>(otile0 + 2 * OT);      // [2][2 channel halves][4 groups][2][4]: upper rows' sums
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g = lane >> 4;
+    const int ch = wv & 1, rh = wv >> 1;
+    const int j0 = blockIdx.x;
+    const int co_w = ch * 16;
+    const int Cin = p.Cin;                                 // 32
+
+    s16x8 A[9];
+    {
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            A[t] = *reinterpret_cast<const s16x8*>(
+                a.wfrag ? wb + ((size_t)ch * 9 + t) * 1024 + lane * 16
+                        : wb + ((size_t)(t * p.CoutPad + co_w + pl) * Cin + g * 8) * 2);
+    }
+    float bs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bs[j] = p.bias ? p.bias[co_w + g * 4 + j] : 0.f;
+
+    int hyx[WR_NI];
+#pragma unroll
+    for (int k = 0; k < WR_NI; ++k) {
+        const int i = (k * 4 + wv) * 64 + lane, px = i >> 2, qs = i & 3;
+        const int hy = px / WR_HW, hx = px - hy * WR_HW;
+        hyx[k] = px < WR_NPX ? (((qs ^ (((hx >> 2) & 1) << 1)) << 16) | (hy << 8) | hx) : -1;
+    }
+    int lo[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) lo[kw] = wr_off(rh * RH, pl + kw, g);
+
+    const int K = a.nunits > j0 ? (a.nunits - j0 + a.J - 1) / a.J : 0;      // tiles of this workgroup's stream
+    auto tile_desc = [&](int k, WrTile& t) {
+        if (k >= K) {
+            t.img = reinterpret_cast<const unsigned char*>(wr_zero);
+            t.o0 = t.o1 = t.o2 = ~0u;
+            t.n = 0; t.oy0 = 0; t.ox0 = 0;
+            return;
+        }
+        const int u = j0 + k * a.J;
+        const int tx = u % a.tilesX, r = u / a.tilesX, uy = r % a.unitsY, n = r / a.unitsY;
+        t.n = n; t.oy0 = uy * WR_TH; t.ox0 = tx * TW;
+        t.img = reinterpret_cast<const unsigned char*>(p.x) + (size_t)n * p.H * p.W * Cin * 2;
+        auto piece = [&](int code) {
+            code = wr_opaque(code);
+            const int hy = (code >> 8) & 0xff, hx = code & 0xff, q = (code >> 16) & 3;
+            const int iy = t.oy0 - 1 + hy, ix = t.ox0 - 1 + hx;
+            const bool ok = code >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            return ok ? (unsigned)(iy * p.W + ix) * (unsigned)(Cin * 2) + q * 16 : ~0u;
+        };
+        t.o0 = piece(hyx[0]); t.o1 = piece(hyx[1]); t.o2 = piece(hyx[2]);
+    };
+    auto issue = [&](const WrTile& t, int slot) {
+#pragma unroll
+        for (int i = 0; i < WR_NI; ++i) {
+            const unsigned char* src = t.off(i) != ~0u ? t.img + t.off(i) : reinterpret_cast<const unsigned char*>(wr_zero);
+            wr_glds16(src, ring_lds + slot * WR_IMG + (i * 4 + wv) * 1024);
+        }
+    };
+
+    f32x4 acc[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ssum[4], ssq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+
+    WrTile t0, t1, t2;
+    tile_desc(0, t0);
+    tile_desc(1, t1);
+    tile_desc(2, t2);
+    int s0 = 0;                                            // ring slot of the current tile
+    issue(t0, 0);
+    issue(t1, 1);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(A[t]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bs[j]));
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WR_NI) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    V16u B[NB];
+    auto rd = [&](int gg) {                                // fragment of step gg (>= NSTEP: the next tile)
+        const int st = gg / NSTEP, i = gg - st * NSTEP, kw = i / HR, hh = i - kw * HR;
+        int slot = s0 + st;
+        slot = slot >= D ? slot - D : slot;
+        B[gg % NB].u = *reinterpret_cast<const uint4*>(ring + slot * WR_IMG + lo[kw] + hh * (WR_HW * 64));
+    };
+#pragma unroll
+    for (int gg = 0; gg < PFD; ++gg) rd(gg);
+
+    int en = 0, eoy0 = 0, eox0 = 0;                        // the tile whose epilogue is pending
+    unsigned long long rr[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) rr[r] = 0;
+    auto res_issue = [&](const WrTile& t) {
+        const bf16* rin = reinterpret_cast<const bf16*>(p.res) + (size_t)t.n * p.OH * p.OW * p.Cout;
+#pragma unroll
+        for (int r = 0; r < RH; ++r)
+            wr_gload8(rin + (size_t)((t.oy0 + rh * RH + r) * p.OW + t.ox0 + pl) * p.Cout + co_w + wr_opaque(g) * 4, rr[r]);
+    };
+    unsigned char* otile = otile0;                         // buffers of the pending tile
+    float* spart = spart0;
+    auto epi_row = [&](int r) {                            // r: row of this wave's half (constant after unrolling)
+        float v[4], res4[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (RES) {
+            switch (r) {                                   // younger loads: the rows after it and the WR_NI ring loads of the stage
+            case 0: wr_wait_for<3 + WR_NI>(rr[0]); break;
+            case 1: wr_wait_for<2 + WR_NI>(rr[1]); break;
+            case 2: wr_wait_for<1 + WR_NI>(rr[2]); break;
+            default: wr_wait_for<WR_NI>(rr[3]); break;
+            }
+            const unsigned lo32 = (unsigned)rr[r], hi32 = (unsigned)(rr[r] >> 32);
+            res4[0] = __uint_as_float(lo32 << 16); res4[1] = __uint_as_float(lo32 & 0xffff0000u);
+            res4[2] = __uint_as_float(hi32 << 16); res4[3] = __uint_as_float(hi32 & 0xffff0000u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = acc[r][j] + bs[j];
+            if constexpr (RES) v[j] += res4[j];
+            if constexpr (RELU) v[j] = fmaxf(v[j], 0.f);
+            ssum[j] += v[j];
+            ssq[j] += v[j] * v[j];
+        }
+        st4(reinterpret_cast<bf16*>(otile + ((rh * RH + r) * TW + pl) * TPITCH) + co_w + g * 4, v);
+    };
+    float tsum[4], tsq[4];                                 // this wave's row sums of the pending tile (statistics)
+    auto epi_stats_park = [&]() {
+        if (!p.stats) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tsum[j] = row16_sum(ssum[j]); tsq[j] = row16_sum(ssq[j]);
+            ssum[j] = 0.f; ssq[j] = 0.f;
+        }
+        if (rh == 1 && pl == 0) {
+            *reinterpret_cast<float4*>(spart + ((ch * 4 + g) * 2 + 0) * 4) = make_float4(tsum[0], tsum[1], tsum[2], tsum[3]);
+            *reinterpret_cast<float4*>(spart + ((ch * 4 + g) * 2 + 1) * 4) = make_float4(tsq[0], tsq[1], tsq[2], tsq[3]);
+        }
+    };
+    auto epi_stats_write = [&](int kk) {                   // after the stage barrier: lower half + parked upper half
+        if (!p.stats || rh != 0 || pl != 0) return;
+        const int unit = j0 + kk * a.J;
+        const float4 us = *reinterpret_cast<const float4*>(spart + ((ch * 4 + g) * 2 + 0) * 4);
+        const float4 uq = *reinterpret_cast<const float4*>(spart + ((ch * 4 + g) * 2 + 1) * 4);
+        const float hs[4] = {us.x, us.y, us.z, us.w}, hq[4] = {uq.x, uq.y, uq.z, uq.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = co_w + wr_opaque(g) * 4 + j;
+            p.stats[((size_t)0 * p.CoutPad + c) * a.nunits + unit] = tsum[j] + hs[j];
+            p.stats[((size_t)1 * p.CoutPad + c) * a.nunits + unit] = tsq[j] + hq[j];
+        }
+    };
+    uint4 ehold;
+    auto epi_fetch = [&](int it) {
+        const int i = wr_opaque(tid) + it * 256, px = i / PPR, q = i - px * PPR;
+        ehold = *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
+    };
+    auto epi_store = [&](int it) {
+        bf16* yout = reinterpret_cast<bf16*>(p.y) + (size_t)en * p.OH * p.OW * p.Cout;
+        const int i = wr_opaque(tid) + it * 256, px = i / PPR, q = i - px * PPR;
+        *reinterpret_cast<uint4*>(yout + (size_t)((eoy0 + (px >> 4)) * p.OW + eox0 + (px & 15)) * p.Cout + q * 8) = ehold;
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int k = 0; k < K; ++k) {
+        const bool pend = !UP4 && k > 0;
+        otile = otile0 + ((k - 1) & 1) * OT;               // (the pending tile is k - 1)
+        spart = spart0 + ((k - 1) & 1) * 64;
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) {
+            const int kw = i / HR, hh = i - kw * HR;
+            if (i <= RH && pend) {
+                if (i < RH) epi_row(i);
+                else epi_stats_park();
+            }
+            if constexpr (RES) { if (i == RH) res_issue(t0); }         // (after the pending tile's rows have used rr)
+            if (i == SYNC) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RES ? RH : 0) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                int far = s0 + 2;
+                far = far >= D ? far - D : far;
+                if (!(WR_EXP & 1)) issue(t2, far);
+            }
+            if (i == SYNC + 1 && pend) epi_stats_write(k - 1);
+            if (i > SYNC && i <= SYNC + NST + 1 && pend) {
+                if (i > SYNC + 1) epi_store(i - SYNC - 2);
+                if (i <= SYNC + NST) epi_fetch(i - SYNC - 1);
+            }
+            rd(i + PFD);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int r = hh - kh;
+                if (r < 0 || r >= RH) continue;
+                const bool first = kw == 0 && kh == 0;
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kh * 3 + kw], B[i % NB].h, first ? zero4 : acc[r], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (UP4) {
+            constexpr int FP = NCO + 4;                        // floats per pixel: 16-byte aligned float4 reads
+            float* ft = reinterpret_cast<float*>(otile0);      // [8 * 16][FP]
+            float* tmp = ft + WR_TH * TW * FP;                 // [8][6][NCO]
+            float* wxT = tmp + WR_TH * 6 * NCO;                // [6][16]
+            float* wyT = wxT + 6 * TW;                         // [4][8]
+#pragma unroll
+            for (int r = 0; r < RH; ++r)
+                *reinterpret_cast<float4*>(ft + ((rh * RH + r) * TW + pl) * FP + co_w + g * 4) =
+                    make_float4(acc[r][0] + bs[0], acc[r][1] + bs[1], acc[r][2] + bs[2], acc[r][3] + bs[3]);
+            const int CHh = p.OH >> 2, CWw = p.OW >> 2;        // coarse grid
+            const int tx = t0.ox0 / TW, ty = t0.oy0 / WR_TH;
+            auto weight = [](int d, int in, int target) {      // weight of fine index d on coarse index `target` (bil_src)
+                float sc = ((float)d + 0.5f) * 0.25f - 0.5f;
+                if (sc < 0.f) sc = 0.f;
+                const int i0 = (int)sc, i1 = i0 + (i0 < in - 1 ? 1 : 0);
+                const float l = sc - (float)i0;
+                return (i0 == target ? 1.f - l : 0.f) + (i1 == target ? l : 0.f);
+            };
+            if (tid < 6 * TW) wxT[tid] = weight(t0.ox0 + tid % TW, CWw, 4 * tx - 1 + tid / TW);
+            else if (tid < 6 * TW + 4 * WR_TH) wyT[tid - 6 * TW] = weight(t0.oy0 + (tid - 6 * TW) % WR_TH, CHh, 2 * ty - 1 + (tid - 6 * TW) / WR_TH);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            constexpr int C4 = NCO / 4;
+            for (int o = tid; o < WR_TH * 6 * C4; o += 256) {  // columns: tmp[r][lc][ch4]
+                const int c4 = o % C4, lc = (o / C4) % 6, r = o / (C4 * 6);
+                const int c_lo = 4 * lc - 6 > 0 ? 4 * lc - 6 : 0, c_hi = 4 * lc + 2 < TW ? 4 * lc + 2 : TW;
+                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c = c_lo; c < c_hi; ++c) {
+                    const float wgt = wxT[lc * TW + c];
+                    const float4 f = *reinterpret_cast<const float4*>(ft + (r * TW + c) * FP + c4 * 4);
+                    t4.x += wgt * f.x; t4.y += wgt * f.y; t4.z += wgt * f.z; t4.w += wgt * f.w;
+                }
+                *reinterpret_cast<float4*>(tmp + (r * 6 + lc) * NCO + c4 * 4) = t4;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int tile = j0 + k * a.J;                     // (= (n * tilesY + ty) * tilesX + tx)
+            for (int o = tid; o < 4 * 6 * C4; o += 256) {      // rows: out[lr][lc][ch4]
+                const int c4 = o % C4, lc = (o / C4) % 6, lr = o / (C4 * 6);
+                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int r = 0; r < WR_TH; ++r) {
+                    const float wgt = wyT[lr * WR_TH + r];
+                    const float4 f = *reinterpret_cast<const float4*>(tmp + (r * 6 + lc) * NCO + c4 * 4);
+                    t4.x += wgt * f.x; t4.y += wgt * f.y; t4.z += wgt * f.z; t4.w += wgt * f.w;
+                }
+                *reinterpret_cast<float4*>(p.up4_partial + (size_t)tile * (4 * 6 * NCO) + (lr * 6 + lc) * NCO + c4 * 4) = t4;
+            }
+        }
+        en = t0.n; eoy0 = t0.oy0; eox0 = t0.ox0;
+        t0 = t1;
+        t1 = t2;
+        tile_desc(k + 3, t2);
+        s0 = s0 + 1 >= D ? 0 : s0 + 1;
+    }
+    if (!UP4 && K > 0) {                                   // the last tile's epilogue
+        otile = otile0 + ((K - 1) & 1) * OT;
+        spart = spart0 + ((K - 1) & 1) * 64;
+#pragma unroll
+        for (int r = 0; r < RH; ++r) epi_row(r);
+        epi_stats_park();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        epi_stats_write(K - 1);
+#pragma unroll
+        for (int it = 0; it < NST; ++it) { epi_fetch(it); epi_store(it); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool RES, bool RELU, bool UP4 = false>
+int wr32_launch(const ConvArgs& c, hipStream_t st, int cus) {
+    constexpr int WPS = 2;                                 // (57 KB of LDS per workgroup)
+    WrArgs a;
+    a.c = c;
+    a.ncb = 1;
+    a.subt = 1;
+    a.tilesX = c.OW / TW;
+    a.unitsY = c.OH / WR_TH;
+    a.nunits = c.N * a.unitsY * a.tilesX;
+    int J = (cus * WPS) & ~7;
+    if (J > a.nunits) J = (a.nunits + 7) & ~7;
+    if (J < 8) J = 8;
+    a.J = J;
+    a.wfrag = c.w_frag != nullptr;
+    if (a.wfrag) a.c.w = c.w_frag;
+    const size_t lds = (size_t)3 * WR_IMG + (UP4 ? (size_t)(WR_TH * TW * 36 + WR_TH * 6 * 32 + 6 * TW + 4 * WR_TH) * 4
+                                                 : (size_t)2 * WR_TH * TW * (32 * 2 + 16) + 2 * 64 * 4);
+    auto kern = conv3x3_wreg32_kernel<RES, RELU, WPS, UP4>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        attr_done = true;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            DH_FAIL("conv_wreg32: cannot raise dynamic LDS");
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(J), dim3(256), lds, st, a);
+    DH_CHECK_LAUNCH("conv_wreg32");
+    return 0;
+}
+
 int g_wreg_mode = -1;      // dh_conv_wreg_mode: -1 = where it is the faster kernel, 0 = never, 1 = wherever it can run
 
 
@@ -506,6 +845,15 @@ int g_wreg_mode = -1;      // dh_conv_wreg_mode: -1 = where it is the faster ker
 bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     static const bool off = getenv("DAHITRA_NO_WREG") != nullptr;
     if (off || g_wreg_mode == 0 || dtype != DH_DTYPE_BF16 || ks != 3 || stride != 1 || a.dil != 1 || a.pad != 1) return false;
+    if (a.Cin == 32) {
+        // the 32 -> 32 kernel: no BatchNorm on load, whole 8x16 tiles, 8-row statistics units, enough tiles for its 768 streams
+        if (a.Cout != 32 || a.CoutPad != 32 || a.in_scale || a.rw != 2 || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride ||
+            a.act == DH_ACT_GELU)
+            return false;
+        if (a.up4_partial && (a.res || a.stats || a.act != DH_ACT_NONE)) return false;
+        if (a.npix != a.OH * a.OW || a.in_npix != a.H * a.W || a.OH != a.H || a.OW != a.W || a.OH % 8 || a.OW % 16) return false;
+        return (long)a.N * (a.OH / 8) * (a.OW / 16) >= (g_wreg_mode == 1 ? 16 : 4 * 512);
+    }
     if (a.Cin != 64 && a.Cin != 128 && a.Cin != 256) return false;
     if (a.Cout % 64 || a.CoutPad != a.Cout || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride) return false;
     if (a.act == DH_ACT_GELU || a.npix != a.OH * a.OW || a.in_npix != a.H * a.W || a.OH != a.H || a.OW != a.W) return false;
@@ -543,6 +891,12 @@ int dh_conv_wreg_launch(const ConvArgs& a, hipStream_t st) {
     if (!cus) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    }
+    if (a.Cin == 32) {
+        const bool relu = a.act == DH_ACT_RELU;
+        if (a.up4_partial) return wr32_launch<false, false, true>(a, st, cus);
+        if (a.res) return relu ? wr32_launch<true, true>(a, st, cus) : wr32_launch<true, false>(a, st, cus);
+        return relu ? wr32_launch<false, true>(a, st, cus) : wr32_launch<false, false>(a, st, cus);
     }
     //                                 NSUB NCH D PFD WPS
     if (a.Cin == 64) return wr_launch_bn<1, 2, 4, 3, 2>(a, st, cus);      // 72 weight registers: two workgroups per CU

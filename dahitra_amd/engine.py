@@ -162,7 +162,8 @@ class Engine:
             c = ops.chunk_channels(dt)
             f, d = pack.add(self.p[key], dt, want_dgrad=self.need_grad, dgrad_inner=-(-O // c) * c)
             ff = dd = None
-            if dt == torch.bfloat16 and len(shape) == 4 and shape[2] == 3 and O in (64, 128, 256) and shape[1] in (64, 128, 256):
+            if dt == torch.bfloat16 and len(shape) == 4 and shape[2] == 3 and \
+                    ((O in (64, 128, 256) and shape[1] in (64, 128, 256)) or (O == 32 and shape[1] == 32)):
                 # the layers conv_wreg.hip may serve (it decides per launch): a second copy in fragment order
                 ff, dd = pack.add(self.p[key], dt, want_dgrad=self.need_grad, dgrad_inner=O, frag=True)
             pk[key] = Packed(f, d, ff, dd)

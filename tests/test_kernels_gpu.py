@@ -1032,6 +1032,9 @@ def test_conv1x1_kdeep_gemm_path(ops, cfg):
     dict(n=64, cin=256, cout=256, h=32, w=32, res=True, relu=True, bias=True),   # eval form: bias + residual + ReLU
     dict(n=6, cin=64, cout=64, h=48, w=80, stats=True, bn_in=True),              # ragged stream: 180 tiles over 512 workgroups
     dict(n=10, cin=256, cout=64, h=40, w=48, res=True),                          # one output-channel block, odd tile count
+    dict(n=8, cin=32, cout=32, h=256, w=256, stats=True),                        # classifier.0 (the 32 -> 32 kernel: row halves)
+    dict(n=8, cin=32, cout=32, h=128, w=128, res=True, relu=True, bias=True),
+    dict(n=3, cin=32, cout=32, h=72, w=112, stats=True),                         # ragged stream
 ])
 def test_conv3x3_register_resident_weights_equals_tap_kernel(ops, cfg):
     """dh_conv2d_fwd on the persistent register-resident-weights kernel against the tap-oriented kernel (dh_conv_wreg_mode 0):

@@ -15,7 +15,7 @@ from dahitra_amd import _lib, ops  # noqa: E402
 
 SHAPES = [("64->64 @64x64", 64, 64, 64, 64, 64), ("128->128 @32x32", 64, 32, 32, 128, 128),
           ("128->256 @32x32", 64, 32, 32, 128, 256), ("256->128 @32x32", 64, 32, 32, 256, 128),
-          ("256->256 @32x32", 64, 32, 32, 256, 256)]
+          ("256->256 @32x32", 64, 32, 32, 256, 256), ("32->32 @256x256", 32, 256, 256, 32, 32)]
 
 
 def timeit(fn, reps):
