@@ -324,6 +324,171 @@ __global__ __launch_bounds__(1024) void xattn_prep_kernel(PrepArgs a) {
     }
 }
 
+// ---- the same preparation on the matrix cores (bf16 nets, L = 4 tokens, images in groups of 4) -------------------------------
+// The kernel above is one workgroup per (image, layer): every image's workgroup re-reads the layer's four weight matrices
+// with 2- and 4-byte loads in dependent batches -- 400 MB of L2 -> L1 traffic and ~190 load instructions per thread for
+// 0.3 MFLOP: 30 us per launch, on the critical path of the step.  Here a workgroup takes FOUR images = 16 token columns, i.e.
+// the N of one MFMA, and each wave its share of the heads:
+//   k_h, v_h  = W_{k,v}[head rows] . LN(tokens)      rows = inner index (16 per MFMA), K = the 32 channels
+//   kq_h      = scale Wq_h^T . k_h                   rows = channel, K = the head's inner indices
+//   vo_h      = Wo_h . v_h
+// The D layout of two consecutive 16-row results IS the B operand of the next product (the k-permutation kappa of
+// decoder_fused.hip), so nothing goes through LDS; weight fragments come straight from the fp32 masters (rounded to bf16 on
+// the way, as the packed copies are) or from the stacked bf16 transposes.  k and v are rounded to bf16 between the two
+// products (the separate-kernel path rounds them there too).
+struct PrepMArgs {
+    PrepArgs a;
+    const float *wk, *wv, *wo;      // fp32 masters [inner][32], [inner][32], [32][inner] (first layer; + ls_param per layer)
+    const bf16* wqT;                // stacked transposes [layers][32][inner]
+};
+union PU8 {
+    uint4 u;
+    uint2 h[2];
+    s16x8 v;
+};
+__device__ __forceinline__ s16x8 ppack8(const float (&a)[4], const float (&b)[4]) {
+    PU8 r;
+    r.u.x = f2bf2(a[0], a[1]); r.u.y = f2bf2(a[2], a[3]); r.u.z = f2bf2(b[0], b[1]); r.u.w = f2bf2(b[2], b[3]);
+    return r.v;
+}
+__device__ __forceinline__ s16x8 ppack8(const f32x4& a, const f32x4& b) {
+    PU8 r;
+    r.u.x = f2bf2(a[0], a[1]); r.u.y = f2bf2(a[2], a[3]); r.u.z = f2bf2(b[0], b[1]); r.u.w = f2bf2(b[2], b[3]);
+    return r.v;
+}
+// A / B fragment of a 32-wide k range starting at `row32` (fp32 or bf16 source): elements kappa(g, e) = g*4+e | 16+g*4+(e-4)
+__device__ __forceinline__ s16x8 frag32(const float* row32, int g) {
+    const float4 lo = *reinterpret_cast<const float4*>(row32 + g * 4), hi = *reinterpret_cast<const float4*>(row32 + 16 + g * 4);
+    const float a[4] = {lo.x, lo.y, lo.z, lo.w}, b[4] = {hi.x, hi.y, hi.z, hi.w};
+    return ppack8(a, b);
+}
+__device__ __forceinline__ s16x8 frag32(const bf16* row32, int g) {
+    PU8 r;
+    r.h[0] = *reinterpret_cast<const uint2*>(row32 + g * 4);
+    r.h[1] = *reinterpret_cast<const uint2*>(row32 + 16 + g * 4);
+    return r.v;
+}
+__device__ __forceinline__ float rows4_sum(float v) {      // over the 4 rows of 16 lanes (decoder_fused.hip: group4_sum)
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void st4bf(bf16* p, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]));
+}
+
+template <int DH>        // dim_head: 32 or 64
+__global__ __launch_bounds__(256) void xattn_prep_mfma_kernel(PrepMArgs m) {
+    PrepArgs& a = m.a;
+    constexpr int L = 4, NBLK = DH / 16, NKS = DH / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
+    const int inner = a.heads * DH, HL = a.heads * L;
+    {
+        const size_t ly = blockIdx.y;
+        a.ln_g += ly * a.ls_param; a.ln_b += ly * a.ls_param;
+        m.wk += ly * a.ls_param; m.wv += ly * a.ls_param; m.wo += ly * a.ls_param;
+        m.wqT += ly * a.ls_pack;
+        a.mn += ly * a.S * L * D; a.mstats += ly * a.S * L * 2;
+        a.k += ly * a.S * L * inner; a.v += ly * a.S * L * inner;
+        a.kq = reinterpret_cast<bf16*>(a.kq) + ly * a.S * a.HLP * D; a.kqT = reinterpret_cast<bf16*>(a.kqT) + ly * a.S * a.HLP * D;
+        a.vo = reinterpret_cast<bf16*>(a.vo) + ly * a.S * a.HLP * D; a.voT = reinterpret_cast<bf16*>(a.voT) + ly * a.S * a.HLP * D;
+    }
+    // column pl of the MFMAs = token l of image s
+    const int s = blockIdx.x * 4 + (pl >> 2), l = pl & 3;
+    const float* tok = reinterpret_cast<const float*>(a.tok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride + l * D;
+    float x[2][4], mnv[2][4];
+    {
+        const float4 lo = *reinterpret_cast<const float4*>(tok + g * 4), hi = *reinterpret_cast<const float4*>(tok + 16 + g * 4);
+        x[0][0] = lo.x; x[0][1] = lo.y; x[0][2] = lo.z; x[0][3] = lo.w;
+        x[1][0] = hi.x; x[1][1] = hi.y; x[1][2] = hi.z; x[1][3] = hi.w;
+    }
+    // LayerNorm of the token row (shared LN of PreNorm2, help_funcs.py:48-49): 8 channels per lane, 4 lane rows per token
+    float sm = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm += x[h][j];
+    const float mu = rows4_sum(sm) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = x[h][j] - mu; q += d * d; }
+    const float rstd = rsqrtf(rows4_sum(q) * (1.f / D) + a.eps);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = h * 16 + g * 4 + j;
+            mnv[h][j] = (x[h][j] - mu) * rstd * a.ln_g[c] + a.ln_b[c];
+        }
+    if (wv == 0) {
+        float* mo = a.mn + ((size_t)s * L + l) * D;
+        *reinterpret_cast<float4*>(mo + g * 4) = make_float4(mnv[0][0], mnv[0][1], mnv[0][2], mnv[0][3]);
+        *reinterpret_cast<float4*>(mo + 16 + g * 4) = make_float4(mnv[1][0], mnv[1][1], mnv[1][2], mnv[1][3]);
+        if (g == 0) { a.mstats[((size_t)s * L + l) * 2] = mu; a.mstats[((size_t)s * L + l) * 2 + 1] = rstd; }
+    }
+    const s16x8 bmn = ppack8(mnv[0], mnv[1]);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    bf16* kq = reinterpret_cast<bf16*>(a.kq) + (size_t)s * a.HLP * D;
+    bf16* kqT = reinterpret_cast<bf16*>(a.kqT) + (size_t)s * a.HLP * D;
+    bf16* vo = reinterpret_cast<bf16*>(a.vo) + (size_t)s * a.HLP * D;
+    bf16* voT = reinterpret_cast<bf16*>(a.voT) + (size_t)s * a.HLP * D;
+    for (int h = wv; h < a.heads; h += 4) {
+        f32x4 kb[NBLK], vb[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const int hd = h * DH + b * 16 + pl;                     // A row of this lane
+            kb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wk + (size_t)hd * D, g), bmn, zero4, 0, 0, 0);
+            vb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wv + (size_t)hd * D, g), bmn, zero4, 0, 0, 0);
+        }
+        // saved for the backward: k, v [S][L][inner] fp32 (this lane: 4 consecutive inner indices of its token)
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const size_t o = ((size_t)s * L + l) * inner + h * DH + b * 16 + g * 4;
+            *reinterpret_cast<float4*>(a.k + o) = make_float4(kb[b][0], kb[b][1], kb[b][2], kb[b][3]);
+            *reinterpret_cast<float4*>(a.v + o) = make_float4(vb[b][0], vb[b][1], vb[b][2], vb[b][3]);
+        }
+        s16x8 kB[NKS], vB[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) { kB[ks] = ppack8(kb[2 * ks], kb[2 * ks + 1]); vB[ks] = ppack8(vb[2 * ks], vb[2 * ks + 1]); }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            f32x4 aq = zero4, ao = zero4;
+            const int c_row = rb * 16 + pl;                          // A row of this lane: output channel
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                aq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wqT + (size_t)c_row * inner + h * DH + ks * 32, g), kB[ks], aq, 0, 0, 0);
+                ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wo + (size_t)c_row * inner + h * DH + ks * 32, g), vB[ks], ao, 0, 0, 0);
+            }
+            const int hl = h * L + l, c0 = rb * 16 + g * 4;          // this lane: channels c0 .. c0 + 3 of row hl
+            float qv[4], ov[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { qv[j] = aq[j] * a.scale; ov[j] = ao[j]; }
+            st4bf(kq + hl * D + c0, qv);
+            st4bf(vo + hl * D + c0, ov);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                stf(kqT + (c0 + j) * a.HLP + hl, qv[j]);
+                stf(voT + (c0 + j) * a.HLP + hl, ov[j]);
+            }
+        }
+    }
+    // rows hl >= heads * L of the HLP-row operands are zero
+    if (HL < a.HLP) {
+        const int pad = a.HLP - HL;
+        for (int i = tid; i < 4 * pad * D; i += 256) {
+            const int c = i % D, r = (i / D) % pad, si = i / (D * pad);
+            const size_t base = (size_t)(blockIdx.x * 4 + si) * a.HLP * D;
+            bf16* q0 = reinterpret_cast<bf16*>(a.kq) + base; bf16* o0 = reinterpret_cast<bf16*>(a.vo) + base;
+            bf16* qT = reinterpret_cast<bf16*>(a.kqT) + base; bf16* oT = reinterpret_cast<bf16*>(a.voT) + base;
+            stf(q0 + (HL + r) * D + c, 0.f); stf(o0 + (HL + r) * D + c, 0.f);
+            stf(qT + c * a.HLP + HL + r, 0.f); stf(oT + c * a.HLP + HL + r, 0.f);
+        }
+    }
+}
+
 struct PrepBwdArgs {
     long tok_bstride, tok_sstride;
     int B, S, L, heads, dh, HLP;
@@ -444,6 +609,134 @@ __global__ __launch_bounds__(1024) void xattn_prep_bwd_kernel(PrepBwdArgs a) {
         float t = 0.f;
         for (int l = 0; l < L; ++l) t += sred[(which * 8 + l) * D + c];
         a.ln_partial[((size_t)s * 2 + which) * D + c] = t;
+    }
+}
+
+// ---- the backward of the preparation on the matrix cores (same decomposition as xattn_prep_mfma_kernel) ----------------------
+//   dk_h = scale Wq[head rows] . dKq_h^T        rows = inner index, K = channel      (B operand: the image's dKq rows, bf16)
+//   dv_h = Wo^T[head rows] . dVoT_h
+//   dmn  = sum_h Wk_h^T . dk_h + Wv_h^T . dv_h   rows = channel, K = the head's inner indices (B = the D layout of dk / dv)
+// then the shared LayerNorm's backward per token row (lane-local + the cross-row swaps), its per-image dgamma / dbeta
+// partials, and the token gradient.  The four waves' dmn parts meet in LDS.
+struct PrepBwdMArgs {
+    PrepBwdArgs a;
+    const float* wq;                 // fp32 master [inner][32] (first layer)
+    const bf16 *woT, *wkT, *wvT;     // stacked transposes [layers][inner][32], [layers][32][inner] x2
+};
+__device__ __forceinline__ float quad_sum(float v) {       // over the 4 lanes of a quad (the L = 4 tokens of an image)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    return v;
+}
+template <int DH>
+__global__ __launch_bounds__(256) void xattn_prep_bwd_mfma_kernel(PrepBwdMArgs m) {
+    PrepBwdArgs& a = m.a;
+    constexpr int L = 4, NBLK = DH / 16, NKS = DH / 32;
+    __shared__ __attribute__((aligned(16))) float red[4][2][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
+    const int inner = a.heads * DH;
+    {
+        const size_t ly = blockIdx.y;
+        a.ln_g += ly * a.ls_param; m.wq += ly * a.ls_param;
+        m.woT += ly * a.ls_pack; m.wkT += ly * a.ls_pack; m.wvT += ly * a.ls_pack;
+        a.mn += ly * a.S * L * D; a.mstats += ly * a.S * L * 2;
+        a.dkq += ly * a.S * a.HLP * D; a.dvoT += ly * a.S * a.HLP * D;
+        a.dk += ly * a.S * L * inner; a.dv += ly * a.S * L * inner;
+        a.ln_partial += ly * a.S * 2 * D;
+        if (a.dtok_part) a.dtok_part += ly * a.S * L * D;
+    }
+    const int s = blockIdx.x * 4 + (pl >> 2), l = pl & 3;
+    const float* dkq = a.dkq + (size_t)s * a.HLP * D;
+    const float* dvoT = a.dvoT + (size_t)s * a.HLP * D;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2] = {zero4, zero4};
+    for (int h = wv; h < a.heads; h += 4) {
+        const int hl = h * L + l;
+        const s16x8 bdq = frag32(dkq + (size_t)hl * D, g);
+        float o0[4], o1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o0[j] = dvoT[(size_t)(g * 4 + j) * a.HLP + hl];
+            o1[j] = dvoT[(size_t)(16 + g * 4 + j) * a.HLP + hl];
+        }
+        const s16x8 bdo = ppack8(o0, o1);
+        f32x4 dkb[NBLK], dvb[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const int hd = h * DH + b * 16 + pl;
+            dkb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wq + (size_t)hd * D, g), bdq, zero4, 0, 0, 0);
+            dvb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.woT + (size_t)hd * D, g), bdo, zero4, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dkb[b][j] *= a.scale;
+            const size_t o = ((size_t)s * L + l) * inner + h * DH + b * 16 + g * 4;
+            *reinterpret_cast<float4*>(a.dk + o) = make_float4(dkb[b][0], dkb[b][1], dkb[b][2], dkb[b][3]);
+            *reinterpret_cast<float4*>(a.dv + o) = make_float4(dvb[b][0], dvb[b][1], dvb[b][2], dvb[b][3]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const s16x8 dkB = ppack8(dkb[2 * ks], dkb[2 * ks + 1]), dvB = ppack8(dvb[2 * ks], dvb[2 * ks + 1]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const size_t wo_ = (size_t)(rb * 16 + pl) * inner + h * DH + ks * 32;
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wkT + wo_, g), dkB, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wvT + wo_, g), dvB, acc[rb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+        *reinterpret_cast<float4*>(&red[wv][rb][lane][0]) = make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
+    __syncthreads();
+    if (wv != 0) return;
+    float dmn[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const float4 p0 = *reinterpret_cast<const float4*>(&red[0][rb][lane][0]), p1 = *reinterpret_cast<const float4*>(&red[1][rb][lane][0]);
+        const float4 p2 = *reinterpret_cast<const float4*>(&red[2][rb][lane][0]), p3 = *reinterpret_cast<const float4*>(&red[3][rb][lane][0]);
+        dmn[rb][0] = ((p0.x + p1.x) + p2.x) + p3.x; dmn[rb][1] = ((p0.y + p1.y) + p2.y) + p3.y;
+        dmn[rb][2] = ((p0.z + p1.z) + p2.z) + p3.z; dmn[rb][3] = ((p0.w + p1.w) + p2.w) + p3.w;
+    }
+    // LayerNorm backward of token row (s, l): this lane holds channels rb * 16 + g * 4 + j
+    const size_t toff = (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride + l * D;
+    const float* tok = reinterpret_cast<const float*>(a.tok) + toff;
+    const float mu = a.mstats[((size_t)s * L + l) * 2], rstd = a.mstats[((size_t)s * L + l) * 2 + 1];
+    float xh[2][4], gh[2][4], sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const float4 xv = *reinterpret_cast<const float4*>(tok + rb * 16 + g * 4);
+        const float4 gv = *reinterpret_cast<const float4*>(a.ln_g + rb * 16 + g * 4);
+        const float x4[4] = {xv.x, xv.y, xv.z, xv.w}, g4[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xh[rb][j] = (x4[j] - mu) * rstd;
+            gh[rb][j] = dmn[rb][j] * g4[j];
+            sa += gh[rb][j];
+            sb += gh[rb][j] * xh[rb][j];
+        }
+    }
+    sa = rows4_sum(sa);
+    sb = rows4_sum(sb);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        float dt[4], pg[4], pb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dt[j] = rstd * (gh[rb][j] - (sa + xh[rb][j] * sb) * (1.f / D));
+            pg[j] = quad_sum(dmn[rb][j] * xh[rb][j]);          // over the image's L tokens: per-image dgamma / dbeta parts
+            pb[j] = quad_sum(dmn[rb][j]);
+        }
+        const int c0 = rb * 16 + g * 4;
+        if (a.dtok_part) {
+            *reinterpret_cast<float4*>(a.dtok_part + ((size_t)s * L + l) * D + c0) = make_float4(dt[0], dt[1], dt[2], dt[3]);
+        } else {
+            float* dm = reinterpret_cast<float*>(a.dtok) + toff + c0;
+            const float4 o = *reinterpret_cast<const float4*>(dm);
+            *reinterpret_cast<float4*>(dm) = make_float4(o.x + dt[0], o.y + dt[1], o.z + dt[2], o.w + dt[3]);
+        }
+        if (l == 0) {
+            *reinterpret_cast<float4*>(a.ln_partial + ((size_t)s * 2 + 0) * D + c0) = make_float4(pg[0], pg[1], pg[2], pg[3]);
+            *reinterpret_cast<float4*>(a.ln_partial + ((size_t)s * 2 + 1) * D + c0) = make_float4(pb[0], pb[1], pb[2], pb[3]);
+        }
     }
 }
 
@@ -758,6 +1051,33 @@ extern "C" int dh_xattn_prep_fwd(int dtype, const void* tok, long tok_bstride, l
                                    ln_g, ln_b, wq, wkT, wvT, woT, mn, mstats, k, v, kq, kqT, vo, voT, stream);
 }
 
+// C ABI (include/dahitra_hip.h): does the matrix-core preparation serve this shape?
+extern "C" int dh_xattn_prep_mfma_supported(int dtype, int S, int L, int heads, int dim_head, int HLP) {
+    static const bool off = getenv("DAHITRA_NO_PREP_MFMA") != nullptr;
+    return !off && dtype == DH_DTYPE_BF16 && L == 4 && S % 4 == 0 && (dim_head == 32 || dim_head == 64) && heads >= 1 &&
+           heads * L <= HLP && HLP == 32;
+}
+extern "C" int dh_xattn_prep_fwd_stack_mfma(const void* tok, long tok_bstride, long tok_sstride, int B, int S, int heads,
+                                            int dim_head, int HLP, float scale, float eps, int layers, long param_stride,
+                                            const float* ln_g, const float* ln_b, const float* wk, const float* wv,
+                                            const float* wo, const void* wqT, float* mn, float* mstats, float* k, float* v,
+                                            void* kq, void* kqT, void* vo, void* voT, void* stream) {
+    DH_REQUIRE(dh_xattn_prep_mfma_supported(DH_DTYPE_BF16, S, 4, heads, dim_head, HLP) && layers >= 1,
+               "xattn_prep_mfma: unsupported shape S=%d heads=%d dim_head=%d HLP=%d", S, heads, dim_head, HLP);
+    PrepMArgs m;
+    PrepArgs& a = m.a;
+    memset(&m, 0, sizeof(m));
+    a.tok = tok; a.tok_bstride = tok_bstride; a.tok_sstride = tok_sstride; a.B = B; a.S = S; a.L = 4;
+    a.heads = heads; a.dh = dim_head; a.HLP = HLP; a.scale = scale; a.eps = eps; a.ln_g = ln_g; a.ln_b = ln_b;
+    a.mn = mn; a.mstats = mstats; a.k = k; a.v = v; a.kq = kq; a.kqT = kqT; a.vo = vo; a.voT = voT;
+    a.ls_param = param_stride; a.ls_pack = 32L * heads * dim_head;
+    m.wk = wk; m.wv = wv; m.wo = wo; m.wqT = reinterpret_cast<const bf16*>(wqT);
+    if (dim_head == 64) hipLaunchKernelGGL(xattn_prep_mfma_kernel<64>, dim3(S / 4, layers), dim3(256), 0, ST(stream), m);
+    else hipLaunchKernelGGL(xattn_prep_mfma_kernel<32>, dim3(S / 4, layers), dim3(256), 0, ST(stream), m);
+    DH_CHECK_LAUNCH("xattn_prep_fwd_mfma");
+    return 0;
+}
+
 // workspace: ln_partial [layers][S][2][32] floats (+ dtok_part [layers][S][L][32] floats when layers > 1)
 extern "C" long dh_xattn_prep_bwd_stack_workspace_size(int S, int L, int layers) {
     return ((long)layers * S * 64 + 64 + (layers > 1 ? (long)layers * S * L * 32 : 0)) * 4;
@@ -792,6 +1112,44 @@ extern "C" int dh_xattn_prep_bwd_stack(int dtype, const void* tok, void* dtok_ac
     DH_REQUIRE(dim_head % 8 == 0, "xattn_prep_bwd: dim_head=%d must be a multiple of 8", dim_head);
     hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(inner / 8, 5, layers), dim3(256), 0, ST(stream), w);
     DH_CHECK_LAUNCH("xattn_prep_bwd");
+    return 0;
+}
+// the matrix-core form of dh_xattn_prep_bwd_stack (dh_xattn_prep_mfma_supported shapes): wq is the first layer's fp32 master,
+// woT ([inner][32]), wkT, wvT ([32][inner]) the stacked bf16 transposes; everything else as in dh_xattn_prep_bwd_stack
+extern "C" int dh_xattn_prep_bwd_stack_mfma(const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride, int B, int S,
+                                            int heads, int dim_head, int HLP, float scale, int layers, long param_stride,
+                                            const float* ln_g, const float* wq, const void* woT, const void* wkT,
+                                            const void* wvT, const float* mn, const float* mstats, const float* k, const float* v,
+                                            const float* dkq, const float* dvoT, float* dk, float* dv, float* dln_g,
+                                            float* dln_b, float* dwq, float* dwk, float* dwv, float* dwo, int accumulate,
+                                            void* workspace, void* stream) {
+    const int L = 4;
+    DH_REQUIRE(dh_xattn_prep_mfma_supported(DH_DTYPE_BF16, S, L, heads, dim_head, HLP) && layers >= 1,
+               "xattn_prep_bwd_mfma: unsupported shape S=%d heads=%d dim_head=%d HLP=%d", S, heads, dim_head, HLP);
+    PrepBwdMArgs m;
+    memset(&m, 0, sizeof(m));
+    PrepBwdArgs& a = m.a;
+    a.tok_bstride = tok_bstride; a.tok_sstride = tok_sstride; a.B = B; a.S = S; a.L = L; a.heads = heads;
+    a.dh = dim_head; a.HLP = HLP; a.scale = scale; a.tok = tok; a.dtok = dtok_accum; a.ln_g = ln_g;
+    a.mn = mn; a.mstats = mstats; a.dkq = dkq; a.dvoT = dvoT; a.dk = dk; a.dv = dv;
+    a.ln_partial = reinterpret_cast<float*>(workspace);
+    a.dtok_part = layers > 1 ? a.ln_partial + (long)layers * S * 64 + 64 : nullptr;
+    a.ls_param = param_stride; a.ls_pack = 32L * heads * dim_head;
+    m.wq = wq; m.woT = reinterpret_cast<const bf16*>(woT); m.wkT = reinterpret_cast<const bf16*>(wkT);
+    m.wvT = reinterpret_cast<const bf16*>(wvT);
+    const int inner = heads * dim_head;
+    if (dim_head == 64) hipLaunchKernelGGL(xattn_prep_bwd_mfma_kernel<64>, dim3(S / 4, layers), dim3(256), 0, ST(stream), m);
+    else hipLaunchKernelGGL(xattn_prep_bwd_mfma_kernel<32>, dim3(S / 4, layers), dim3(256), 0, ST(stream), m);
+    if (layers > 1)
+        hipLaunchKernelGGL(dtok_reduce_kernel, dim3(S), dim3(L * 32), 0, ST(stream), a.dtok_part, layers, S, L, B,
+                           tok_bstride, tok_sstride, reinterpret_cast<float*>(dtok_accum));
+    PrepWgArgs w;
+    w.S = S; w.L = L; w.heads = heads; w.dh = dim_head; w.HLP = HLP; w.scale = scale; w.mn = mn; w.k = k; w.v = v;
+    w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;
+    w.ln_partial = a.ln_partial; w.dln_g = dln_g; w.dln_b = dln_b;
+    w.accumulate = accumulate; w.ls_param = param_stride;
+    hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(inner / 8, 5, layers), dim3(256), 0, ST(stream), w);
+    DH_CHECK_LAUNCH("xattn_prep_bwd_mfma");
     return 0;
 }
 extern "C" int dh_xattn_prep_bwd(int dtype, const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride,

@@ -623,7 +623,9 @@ class Engine:
         return ops.XattnPrepStack(tok, tok_b, tok_s, B, images, L, heads, dim_head, depth, stride,
                                   self.p[a0 + ".norm.weight"], self.p[a0 + ".norm.bias"], self.p[a0 + ".fn.to_q.weight"],
                                   self.xstack[(pfx, "to_k.weight")], self.xstack[(pfx, "to_v.weight")],
-                                  self.xstack[(pfx, "to_out.0.weight")], self.dtype, ATTN_SCALE, LN_EPS)
+                                  self.xstack[(pfx, "to_out.0.weight")], self.dtype, ATTN_SCALE, LN_EPS,
+                                  masters=(self.p[a0 + ".fn.to_k.weight"], self.p[a0 + ".fn.to_v.weight"],
+                                           self.p[a0 + ".fn.to_out.0.weight"], self.xstack[(pfx, "to_q.weight")]))
 
     def _dec_layer_fused(self, x0, images, rpi, tok, tok_b, tok_s, B, dtok, a, f, heads, dim_head, L, mlp, stack=None,
                          li=0, partial=None):
@@ -639,7 +641,7 @@ class Engine:
         woT = self.pk[a + ".fn.to_out.0.weight"].dgrad
         prep = stack.layer(li) if stack is not None else \
             ops.XattnPrep(tok, tok_b, tok_s, B, images, L, heads, dim_head, g1, b1, wq, wkT, wvT, woT, self.dtype,
-                          ATTN_SCALE, LN_EPS)
+                          ATTN_SCALE, LN_EPS, masters=(wk, wv, wo, wqT))
         y = ops.decoder_layer_fwd(x0, prep, rpi, g1, b1, bo, g2, b2, self.pk[w1k].fwd, fb1, self.pk[w2k].fwd, fb2, mlp,
                                   LN_EPS, fp8=self.attn_fp8)
         if not self.need_grad:

@@ -963,11 +963,16 @@ def tokenizer_bwd(x, wa, saved, dtok_cat, dx_accum, dwa, dpos, B, L, accumulate=
           P(dtok_cat), P(dx_accum), P(dwa), P(dpos), _ci(int(accumulate)), P(ws), S())
 
 
+def prep_mfma_supported(dtype, Sn, L, heads, dim_head, HLP):
+    return bool(_lib.lib().dh_xattn_prep_mfma_supported(_ci(_DT[dtype]), _ci(Sn), _ci(L), _ci(heads), _ci(dim_head), _ci(HLP)))
+
+
 class XattnPrep:
     """Per-image operands of the re-associated cross attention (see csrc/tokens.hip)."""
 
     def __init__(self, tok, bstride, sstride, B, Sn, L, heads, dim_head, ln_g, ln_b, wq, wkT, wvT, woT, dtype,
-                 scale=32 ** -0.5, eps=1e-5):
+                 scale=32 ** -0.5, eps=1e-5, masters=None):
+        """masters = (wk, wv, wo fp32 masters, wqT in `dtype`): lets the matrix-core form run where it serves the shape"""
         dev = tok.device
         assert tok.dtype == torch.float32, "tokens are fp32 in every compute mode"
         inner = heads * dim_head
@@ -982,6 +987,15 @@ class XattnPrep:
         self.kqT = torch.empty(Sn, 32, self.HLP, dtype=dtype, device=dev)
         self.vo = torch.empty(Sn, self.HLP, 32, dtype=dtype, device=dev)
         self.voT = torch.empty(Sn, 32, self.HLP, dtype=dtype, device=dev)
+        self.mfma = masters is not None and prep_mfma_supported(dtype, Sn, L, heads, dim_head, self.HLP)
+        self._bwd_ops = (wq, woT, wkT, wvT)
+        if self.mfma:
+            wk, wv, wo, wqT = masters
+            _call("dh_xattn_prep_fwd_stack_mfma", P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(heads),
+                  _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), _ci(1), _cl(0), P(ln_g), P(ln_b), P(wk), P(wv), P(wo),
+                  P(wqT), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq), P(self.kqT), P(self.vo),
+                  P(self.voT), S())
+            return
         _call("dh_xattn_prep_fwd", _ci(_DT[dtype]), P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(L),
               _ci(heads), _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), P(ln_g), P(ln_b), P(wq), P(wkT), P(wvT),
               P(woT), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq), P(self.kqT), P(self.vo),
@@ -999,7 +1013,8 @@ class XattnPrepStack:
     wkT / wvT / woT are stacked [layers, 32 * inner] transposes in `dtype`."""
 
     def __init__(self, tok, bstride, sstride, B, Sn, L, heads, dim_head, layers, param_stride, ln_g0, ln_b0, wq0, wkT, wvT,
-                 woT, dtype, scale=32 ** -0.5, eps=1e-5):
+                 woT, dtype, scale=32 ** -0.5, eps=1e-5, masters=None):
+        """masters = (wk0, wv0, wo0 fp32 masters of the first layer, stacked wqT): see XattnPrep"""
         dev = tok.device
         assert tok.dtype == torch.float32, "tokens are fp32 in every compute mode"
         inner = heads * dim_head
@@ -1019,6 +1034,15 @@ class XattnPrepStack:
         # per-image weight gradients of every layer, filled by the layers' backward kernels
         self.dkq = torch.empty(layers, Sn, self.HLP, 32, **f32)
         self.dvoT = torch.empty(layers, Sn, 32, self.HLP, **f32)
+        self.mfma = masters is not None and prep_mfma_supported(dtype, Sn, L, heads, dim_head, self.HLP)
+        self._bwd_ops = (wq0, woT, wkT, wvT)          # what the matrix-core backward reads
+        if self.mfma:
+            wk0, wv0, wo0, wqT = masters
+            _call("dh_xattn_prep_fwd_stack_mfma", P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(heads),
+                  _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), _ci(layers), _cl(param_stride), P(ln_g0), P(ln_b0),
+                  P(wk0), P(wv0), P(wo0), P(wqT), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq), P(self.kqT),
+                  P(self.vo), P(self.voT), S())
+            return
         _call("dh_xattn_prep_fwd_stack", _ci(_DT[dtype]), P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(L),
               _ci(heads), _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), _ci(layers), _cl(param_stride), P(ln_g0),
               P(ln_b0), P(wq0), P(wkT), P(wvT), P(woT), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq),
@@ -1038,6 +1062,13 @@ class XattnPrepStack:
         dk = torch.empty_like(self.k)
         dv = torch.empty_like(self.v)
         ws = workspace(_lib.lib().dh_xattn_prep_bwd_stack_workspace_size(Sn, L, self.layers), tok.device)
+        if self.mfma:
+            wq0, woT, wkT, wvT = self._bwd_ops
+            _call("dh_xattn_prep_bwd_stack_mfma", P(tok), P(dtok_accum), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn),
+                  _ci(heads), _ci(dim_head), _ci(self.HLP), _cf(self.scale), _ci(self.layers), _cl(self.param_stride),
+                  P(ln_g0), P(wq0), P(woT), P(wkT), P(wvT), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.dkq),
+                  P(self.dvoT), P(dk), P(dv), P(dln_g0), P(dln_b0), P(dwq0), P(dwk0), P(dwv0), P(dwo0), _ci(1), P(ws), S())
+            return
         _call("dh_xattn_prep_bwd_stack", _ci(_DT[self.dtype]), P(tok), P(dtok_accum), _cl(bstride), _cl(sstride), _ci(B),
               _ci(Sn), _ci(L), _ci(heads), _ci(dim_head), _ci(self.HLP), _cf(self.scale), _ci(self.layers),
               _cl(self.param_stride), P(ln_g0), P(wqT), P(wk0), P(wv0), P(wo0), P(self.mn), P(self.mstats), P(self.k),
@@ -1051,6 +1082,14 @@ def xattn_prep_bwd(prep, tok, dtok_accum, ln_g, wqT, wk, wv, wo, dkq, dvoT, dln_
     dk = torch.empty_like(prep.k)
     dv = torch.empty_like(prep.v)
     Lb = _lib.lib()
+    if getattr(prep, "mfma", False):
+        wq0, woT, wkT, wvT = prep._bwd_ops
+        ws = workspace(Lb.dh_xattn_prep_bwd_stack_workspace_size(Sn, L, 1), tok.device)
+        _call("dh_xattn_prep_bwd_stack_mfma", P(tok), P(dtok_accum), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(heads),
+              _ci(dim_head), _ci(prep.HLP), _cf(prep.scale), _ci(1), _cl(0), P(ln_g), P(wq0), P(woT), P(wkT), P(wvT),
+              P(prep.mn), P(prep.mstats), P(prep.k), P(prep.v), P(dkq), P(dvoT), P(dk), P(dv), P(dln_g), P(dln_b), P(dwq),
+              P(dwk), P(dwv), P(dwo), _ci(int(accumulate)), P(ws), S())
+        return
     ws = workspace(Lb.dh_xattn_prep_bwd_workspace_size(Sn), tok.device)
     _call("dh_xattn_prep_bwd", _ci(_DT[dtype]), P(tok), P(dtok_accum), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn),
           _ci(L), _ci(heads), _ci(dim_head), _ci(prep.HLP), _cf(prep.scale), P(ln_g), P(wqT), P(wk), P(wv), P(wo),

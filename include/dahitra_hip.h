@@ -288,6 +288,21 @@ int dh_xattn_prep_fwd_stack(int dtype, const void* tok, long tok_bstride, long t
                             const float* ln_g, const float* ln_b, const float* wq, const void* wkT, const void* wvT,
                             const void* woT, float* mn, float* mstats, float* k, float* v, void* kq, void* kqT, void* vo,
                             void* voT, void* stream);
+/* The same preparation on the matrix cores (csrc/tokens.hip: four images = the 16 columns of one MFMA per workgroup, heads over
+ * the waves) for bf16 nets with L = 4, S a multiple of 4, dim_head 32 / 64, HLP = 32 (dh_xattn_prep_mfma_supported).  wk / wv
+ * ([inner][32]) and wo ([32][inner]) are the first layer's fp32 masters, wqT the stacked bf16 transposes [layers][32][inner]. */
+int dh_xattn_prep_mfma_supported(int dtype, int S, int L, int heads, int dim_head, int HLP);
+int dh_xattn_prep_fwd_stack_mfma(const void* tok, long tok_bstride, long tok_sstride, int B, int S, int heads, int dim_head,
+                                 int HLP, float scale, float eps, int layers, long param_stride, const float* ln_g,
+                                 const float* ln_b, const float* wk, const float* wv, const float* wo, const void* wqT,
+                                 float* mn, float* mstats, float* k, float* v, void* kq, void* kqT, void* vo, void* voT,
+                                 void* stream);
+int dh_xattn_prep_bwd_stack_mfma(const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride, int B, int S, int heads,
+                                 int dim_head, int HLP, float scale, int layers, long param_stride, const float* ln_g,
+                                 const float* wq, const void* woT, const void* wkT, const void* wvT, const float* mn,
+                                 const float* mstats, const float* k, const float* v, const float* dkq, const float* dvoT,
+                                 float* dk, float* dv, float* dln_g, float* dln_b, float* dwq, float* dwk, float* dwv,
+                                 float* dwo, int accumulate, void* workspace, void* stream);
 int dh_xattn_prep_bwd_stack(int dtype, const void* tok, void* dtok_accum, long tok_bstride, long tok_sstride, int B, int S,
                             int L, int heads, int dim_head, int HLP, float scale, int layers, long param_stride,
                             const float* ln_g, const void* wqT, const float* wk, const float* wv, const float* wo,
