@@ -1,6 +1,7 @@
 """Per-kernel parity: every C-ABI entry point against a plain torch fp32 computation of the same op
 on the CPU (same seeded inputs).  fp32 mode must agree to fp32 round-off (the parity mode of the
 product); bf16 mode to bf16 round-off of inputs/outputs (2^-8 relative)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -1118,3 +1119,50 @@ def test_conv3x3_data_gradient_through_bilinear_up4_without_the_fine_tensor(ops,
     e_new = float((nchw(da).float().cpu() - a.grad).abs().mean())
     e_old = float((nchw(da2).float().cpu() - a.grad).abs().mean())
     assert e_new <= e_old * 1.05 + 1e-9, (e_new, e_old)
+
+
+# ---- cross-attention operand preparation on the matrix cores (csrc/tokens.hip: xattn_prep_mfma_kernel / _bwd_) ------------------
+@pytest.mark.parametrize("cfg", [dict(heads=8, dh=64, S=64, layers=8), dict(heads=4, dh=64, S=8, layers=4),
+                                 dict(heads=1, dh=32, S=12, layers=1)])
+def test_cross_attention_prep_on_the_matrix_cores_matches_the_scalar_kernels(ops, cfg):
+    """ops.XattnPrepStack with `masters` (four images per workgroup = the 16 columns of an MFMA, bf16 operands, fp32
+    accumulation) against the one-workgroup-per-image fp32-FMA kernels it replaces: saved LayerNorm rows bit-level, k / v /
+    Kq / Vo and every gradient of the backward to bf16 operand rounding (help_funcs.py:66-114 re-associated)"""
+    heads, dh, S, layers = cfg["heads"], cfg["dh"], cfg["S"], cfg["layers"]
+    B, L, inner, dt = S // 2, 4, heads * dh, torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(77)
+    tok = torch.randn(B, 2 * L, 32, device="cuda", generator=g)
+    bstride, sstride = 2 * L * 32, L * 32
+    stride = 4 * inner * 32 + 64
+    arena = torch.randn(layers * stride, device="cuda", generator=g) * 0.2
+    offs = dict(wq=0, wk=inner * 32, wv=2 * inner * 32, wo=3 * inner * 32, g=4 * inner * 32, b=4 * inner * 32 + 32)
+    shp = dict(wq=(inner, 32), wk=(inner, 32), wv=(inner, 32), wo=(32, inner), g=(32,), b=(32,))
+
+    def view(buf, l, name):
+        n = int(np.prod(shp[name]))
+        return buf[l * stride + offs[name]: l * stride + offs[name] + n].view(*shp[name])
+    T = {n: torch.stack([view(arena, l, n).t().contiguous().to(dt).reshape(-1) for l in range(layers)]) for n in ("wq", "wk", "wv", "wo")}
+    p0 = {n: view(arena, 0, n) for n in shp}
+    mk = lambda masters: ops.XattnPrepStack(tok, bstride, sstride, B, S, L, heads, dh, layers, stride, p0["g"], p0["b"], p0["wq"],
+                                            T["wk"], T["wv"], T["wo"], dt, masters=masters)
+    old, new = mk(None), mk((p0["wk"], p0["wv"], p0["wo"], T["wq"]))
+    assert new.mfma and not old.mfma
+    for n in ("mn", "mstats"):
+        assert float((getattr(old, n) - getattr(new, n)).abs().max()) <= 1e-6
+    for n in ("k", "v", "kq", "kqT", "vo", "voT"):
+        a, b = getattr(old, n).float(), getattr(new, n).float()
+        assert float((a - b).abs().max()) <= 1e-2 * float(a.abs().max()), n
+    res = {}
+    for name, st in (("old", old), ("new", new)):
+        g2 = torch.Generator(device="cuda").manual_seed(5)
+        st.dkq.copy_(torch.randn(st.dkq.shape, device="cuda", generator=g2))
+        st.dvoT.copy_(torch.randn(st.dvoT.shape, device="cuda", generator=g2))
+        st.dkq[:, :, heads * L:, :] = 0
+        st.dvoT[:, :, :, heads * L:] = 0
+        dtok, garena = torch.zeros_like(tok), torch.zeros_like(arena)
+        st.backward(tok, dtok, p0["g"], T["wq"], p0["wk"], p0["wv"], p0["wo"], view(garena, 0, "g"), view(garena, 0, "b"),
+                    view(garena, 0, "wq"), view(garena, 0, "wk"), view(garena, 0, "wv"), view(garena, 0, "wo"))
+        res[name] = (dtok, garena)
+    for i, n in enumerate(("token gradient", "parameter gradients")):
+        a, b = res["old"][i], res["new"][i]
+        assert float((a - b).abs().max()) <= 1.5e-2 * float(a.abs().max()), n
