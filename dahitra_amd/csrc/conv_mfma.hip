@@ -109,7 +109,6 @@ extern "C" int dh_conv3x3_dgrad_up4(int dtype, const void* dy, const void* w_pac
     a.up4_partial = partial;
     a.rw = 2;
     a.tilesX = W / TW; a.tilesY = H / 8;
-    if (dh_conv_wreg_eligible(a, 3, 1, dtype)) return dh_conv_wreg_launch(a, reinterpret_cast<hipStream_t>(stream));
     return dh_conv_launch_bf16(a, 3, 1, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -503,10 +503,9 @@ int wr_launch_bn(const ConvArgs& c, hipStream_t st, int cus) {
 // per lane, two workgroups per CU.  The two row halves of a channel meet in the BatchNorm partial sums: the upper half
 // parks its row sums in LDS, the lower half adds them after the stage barrier (so the sums are (rows 0-3) + (rows 4-7), not
 // the tap kernel's running sum over eight rows: equal up to fp32 rounding, unlike y, which is bit-identical).
-// UP4: the data gradient of conv3x3(bilinear_x4(.)) (ConvArgs::up4_partial, see conv_mfma_impl.h): the fp32 tile goes to LDS and
-// is reduced to the 4 x 6 coarse pixels it touches (separable: columns, then rows); y is never stored.  This epilogue runs
-// whole at the end of its tile (two extra barriers), not pipelined into the next one.
-template <bool RES, bool RELU, int WPS, bool UP4>
+// (The bilinear-x4 footprint epilogue of classifier.0's data gradient, ConvArgs::up4_partial, was tried here too -- whole at the
+// end of its tile, two extra barriers: 98.6 us in the step against the tap kernel's 86 -- and stays with the tap kernel.)
+template <bool RES, bool RELU, int WPS>
 __global__ __launch_bounds__(256, WPS) void conv3x3_wreg32_kernel(WrArgs a) {
     constexpr int D = 3, PFD = 2, NB = PFD + 1;
     constexpr int RH = 4, HR = RH + 2;                     // output rows / halo rows per wave
@@ -693,7 +692,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg32_kernel(WrArgs a) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     for (int k = 0; k < K; ++k) {
-        const bool pend = !UP4 && k > 0;
+        const bool pend = k > 0;
         otile = otile0 + ((k - 1) & 1) * OT;               // (the pending tile is k - 1)
         spart = spart0 + ((k - 1) & 1) * 64;
 #pragma unroll
@@ -729,65 +728,13 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg32_kernel(WrArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (UP4) {
-            constexpr int FP = NCO + 4;                        // floats per pixel: 16-byte aligned float4 reads
-            float* ft = reinterpret_cast<float*>(otile0);      // [8 * 16][FP]
-            float* tmp = ft + WR_TH * TW * FP;                 // [8][6][NCO]
-            float* wxT = tmp + WR_TH * 6 * NCO;                // [6][16]
-            float* wyT = wxT + 6 * TW;                         // [4][8]
-#pragma unroll
-            for (int r = 0; r < RH; ++r)
-                *reinterpret_cast<float4*>(ft + ((rh * RH + r) * TW + pl) * FP + co_w + g * 4) =
-                    make_float4(acc[r][0] + bs[0], acc[r][1] + bs[1], acc[r][2] + bs[2], acc[r][3] + bs[3]);
-            const int CHh = p.OH >> 2, CWw = p.OW >> 2;        // coarse grid
-            const int tx = t0.ox0 / TW, ty = t0.oy0 / WR_TH;
-            auto weight = [](int d, int in, int target) {      // weight of fine index d on coarse index `target` (bil_src)
-                float sc = ((float)d + 0.5f) * 0.25f - 0.5f;
-                if (sc < 0.f) sc = 0.f;
-                const int i0 = (int)sc, i1 = i0 + (i0 < in - 1 ? 1 : 0);
-                const float l = sc - (float)i0;
-                return (i0 == target ? 1.f - l : 0.f) + (i1 == target ? l : 0.f);
-            };
-            if (tid < 6 * TW) wxT[tid] = weight(t0.ox0 + tid % TW, CWw, 4 * tx - 1 + tid / TW);
-            else if (tid < 6 * TW + 4 * WR_TH) wyT[tid - 6 * TW] = weight(t0.oy0 + (tid - 6 * TW) % WR_TH, CHh, 2 * ty - 1 + (tid - 6 * TW) / WR_TH);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            constexpr int C4 = NCO / 4;
-            for (int o = tid; o < WR_TH * 6 * C4; o += 256) {  // columns: tmp[r][lc][ch4]
-                const int c4 = o % C4, lc = (o / C4) % 6, r = o / (C4 * 6);
-                const int c_lo = 4 * lc - 6 > 0 ? 4 * lc - 6 : 0, c_hi = 4 * lc + 2 < TW ? 4 * lc + 2 : TW;
-                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int c = c_lo; c < c_hi; ++c) {
-                    const float wgt = wxT[lc * TW + c];
-                    const float4 f = *reinterpret_cast<const float4*>(ft + (r * TW + c) * FP + c4 * 4);
-                    t4.x += wgt * f.x; t4.y += wgt * f.y; t4.z += wgt * f.z; t4.w += wgt * f.w;
-                }
-                *reinterpret_cast<float4*>(tmp + (r * 6 + lc) * NCO + c4 * 4) = t4;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const int tile = j0 + k * a.J;                     // (= (n * tilesY + ty) * tilesX + tx)
-            for (int o = tid; o < 4 * 6 * C4; o += 256) {      // rows: out[lr][lc][ch4]
-                const int c4 = o % C4, lc = (o / C4) % 6, lr = o / (C4 * 6);
-                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int r = 0; r < WR_TH; ++r) {
-                    const float wgt = wyT[lr * WR_TH + r];
-                    const float4 f = *reinterpret_cast<const float4*>(tmp + (r * 6 + lc) * NCO + c4 * 4);
-                    t4.x += wgt * f.x; t4.y += wgt * f.y; t4.z += wgt * f.z; t4.w += wgt * f.w;
-                }
-                *reinterpret_cast<float4*>(p.up4_partial + (size_t)tile * (4 * 6 * NCO) + (lr * 6 + lc) * NCO + c4 * 4) = t4;
-            }
-        }
         en = t0.n; eoy0 = t0.oy0; eox0 = t0.ox0;
         t0 = t1;
         t1 = t2;
         tile_desc(k + 3, t2);
         s0 = s0 + 1 >= D ? 0 : s0 + 1;
     }
-    if (!UP4 && K > 0) {                                   // the last tile's epilogue
+    if (K > 0) {                                           // the last tile's epilogue
         otile = otile0 + ((K - 1) & 1) * OT;
         spart = spart0 + ((K - 1) & 1) * 64;
 #pragma unroll
@@ -803,7 +750,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg32_kernel(WrArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <bool RES, bool RELU, bool UP4 = false>
+template <bool RES, bool RELU>
 int wr32_launch(const ConvArgs& c, hipStream_t st, int cus) {
     constexpr int WPS = 2;                                 // (57 KB of LDS per workgroup)
     WrArgs a;
@@ -819,9 +766,8 @@ int wr32_launch(const ConvArgs& c, hipStream_t st, int cus) {
     a.J = J;
     a.wfrag = c.w_frag != nullptr;
     if (a.wfrag) a.c.w = c.w_frag;
-    const size_t lds = (size_t)3 * WR_IMG + (UP4 ? (size_t)(WR_TH * TW * 36 + WR_TH * 6 * 32 + 6 * TW + 4 * WR_TH) * 4
-                                                 : (size_t)2 * WR_TH * TW * (32 * 2 + 16) + 2 * 64 * 4);
-    auto kern = conv3x3_wreg32_kernel<RES, RELU, WPS, UP4>;
+    const size_t lds = (size_t)3 * WR_IMG + (size_t)2 * WR_TH * TW * (32 * 2 + 16) + 2 * 64 * 4;
+    auto kern = conv3x3_wreg32_kernel<RES, RELU, WPS>;
     static bool attr_done = false;
     if (!attr_done) {
         attr_done = true;
@@ -848,9 +794,8 @@ bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     if (a.Cin == 32) {
         // the 32 -> 32 kernel: no BatchNorm on load, whole 8x16 tiles, 8-row statistics units, enough tiles for its 768 streams
         if (a.Cout != 32 || a.CoutPad != 32 || a.in_scale || a.rw != 2 || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride ||
-            a.act == DH_ACT_GELU)
+            a.up4_partial || a.act == DH_ACT_GELU)
             return false;
-        if (a.up4_partial && (a.res || a.stats || a.act != DH_ACT_NONE)) return false;
         if (a.npix != a.OH * a.OW || a.in_npix != a.H * a.W || a.OH != a.H || a.OW != a.W || a.OH % 8 || a.OW % 16) return false;
         return (long)a.N * (a.OH / 8) * (a.OW / 16) >= (g_wreg_mode == 1 ? 16 : 4 * 512);
     }
@@ -894,7 +839,6 @@ int dh_conv_wreg_launch(const ConvArgs& a, hipStream_t st) {
     }
     if (a.Cin == 32) {
         const bool relu = a.act == DH_ACT_RELU;
-        if (a.up4_partial) return wr32_launch<false, false, true>(a, st, cus);
         if (a.res) return relu ? wr32_launch<true, true>(a, st, cus) : wr32_launch<true, false>(a, st, cus);
         return relu ? wr32_launch<false, true>(a, st, cus) : wr32_launch<false, false>(a, st, cus);
     }
