@@ -749,6 +749,7 @@ struct PrepWgArgs {
     float *dwq, *dwk, *dwv, *dwo, *dln_g, *dln_b;
     int accumulate;
     long ls_param;                   // stacked form: blockIdx.z = layer (inputs stacked, gradients at the arena's layer pitch)
+    int ln_only;                     // 1: grid (2, 1, layers) -- only the LayerNorm sums (the matrices went to the MFMA kernel)
 };
 __global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
     // one workgroup per (matrix, block of HB = 8 consecutive inner columns hd): 8 image phases x 32 channels, every
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
         a.dln_g += ly * a.ls_param; a.dln_b += ly * a.ls_param;
     }
     const int c = threadIdx.x & 31, ph = threadIdx.x >> 5;
-    const int which = blockIdx.y, hd0 = blockIdx.x * HB;
+    const int which = a.ln_only ? 4 : blockIdx.y, hd0 = blockIdx.x * HB;
     float acc[HB];
 #pragma unroll
     for (int j = 0; j < HB; ++j) acc[j] = 0.f;
@@ -814,6 +815,73 @@ __global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
         const size_t o = which == 3 ? (size_t)c * inner + hd : (size_t)hd * D + c;     // to_out weight is [32][inner]
         if (a.accumulate) out[o] += t; else out[o] = t;
     }
+}
+
+// The same weight gradients on the matrix cores (bf16 nets, dim_head = 64, L = 4, S a multiple of 8): every one of the four is
+//   dW[hd][c] = sum over the K = S * L token rows of col[K][hd] * row[K][c]
+// (col = k / dk / dv / v, row = dKq rows / LN(tokens) / dVoT columns).  One workgroup per (matrix, 64 inner indices = one head):
+// per 32 token rows both operands are staged as bf16 [K][channel] tiles (coalesced 16-byte loads) and read back k-contiguous
+// with ds_read_b64_tr_b16 -- the pixel-reduction idiom of decoder_fused.hip; wave w owns inner indices 16 w .. 16 w + 15.
+// 2560 workgroups of the FMA form, each a chain of dependent 4-byte loads, become 256 with eight 32-row steps.
+constexpr int wg_pitch(int row_bytes) { return ((row_bytes / 32) & 1) ? row_bytes : row_bytes + 32; }
+__device__ __forceinline__ s16x8 wg_tile_frag(const unsigned char* tile, int pitch, int cs, int pl, int g) {
+    const unsigned char* base = tile + (g * 4 + (pl >> 2)) * pitch + (cs * 16 + (pl & 3) * 4) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 16 * pitch));
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__global__ __launch_bounds__(256) void xattn_prep_wgrad_mfma_kernel(PrepWgArgs a) {
+    constexpr int L = 4, DH = 64, CP = wg_pitch(128), RP = wg_pitch(64);
+    __shared__ __attribute__((aligned(16))) unsigned char colT[32 * CP], rowT[32 * RP];
+    const int inner = a.heads * DH;
+    {
+        const size_t ly = blockIdx.z;
+        a.mn += ly * a.S * L * D; a.k += ly * a.S * L * inner; a.v += ly * a.S * L * inner;
+        a.dk += ly * a.S * L * inner; a.dv += ly * a.S * L * inner;
+        a.dkq += ly * a.S * a.HLP * D; a.dvoT += ly * a.S * a.HLP * D;
+        a.dwq += ly * a.ls_param; a.dwk += ly * a.ls_param; a.dwv += ly * a.ls_param; a.dwo += ly * a.ls_param;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
+    const int which = blockIdx.y, h = blockIdx.x, hd0 = h * DH;
+    const float* colsrc = which == 0 ? a.k : (which == 1 ? a.dk : (which == 2 ? a.dv : a.v));
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2] = {zero4, zero4};
+    for (int s0 = 0; s0 < a.S; s0 += 8) {
+        // col tile: 32 token rows x 64 inner indices (two 16-byte pieces per thread)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (tid >> 4) + 16 * i, q = tid & 15;
+            const float4 v = *reinterpret_cast<const float4*>(colsrc + ((size_t)(s0 * L + r)) * inner + hd0 + q * 4);
+            *reinterpret_cast<uint2*>(colT + r * CP + q * 8) = make_uint2(f2bf2(v.x, v.y), f2bf2(v.z, v.w));
+        }
+        // row tile: 32 token rows x 32 channels
+        {
+            const int r = tid >> 3, q = tid & 7, s = s0 + (r >> 2), l = r & 3;
+            float4 v;
+            if (which == 0) v = *reinterpret_cast<const float4*>(a.dkq + ((size_t)s * a.HLP + h * L + l) * D + q * 4);
+            else if (which == 3) {
+                const float* p = a.dvoT + ((size_t)s * D + q * 4) * a.HLP + h * L + l;
+                v = make_float4(p[0], p[a.HLP], p[2 * a.HLP], p[3 * a.HLP]);
+            } else v = *reinterpret_cast<const float4*>(a.mn + ((size_t)s * L + l) * D + q * 4);
+            *reinterpret_cast<uint2*>(rowT + r * RP + q * 8) = make_uint2(f2bf2(v.x, v.y), f2bf2(v.z, v.w));
+        }
+        __syncthreads();
+        const s16x8 fa = wg_tile_frag(colT, CP, wv, pl, g);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wg_tile_frag(rowT, RP, cb, pl, g), acc[cb], 0, 0, 0);
+        __syncthreads();
+    }
+    float* out = which == 0 ? a.dwq : (which == 1 ? a.dwk : (which == 2 ? a.dwv : a.dwo));
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hd = hd0 + wv * 16 + g * 4 + j, c = cb * 16 + pl;
+            const float t = which == 0 ? acc[cb][j] * a.scale : acc[cb][j];
+            const size_t o = which == 3 ? (size_t)c * inner + hd : (size_t)hd * D + c;     // to_out weight is [32][inner]
+            if (a.accumulate) out[o] += t; else out[o] = t;
+        }
 }
 
 // dtok[token rows of image s] += sum over the layers of dtok_part[layer][s]   (fixed order: deterministic)
@@ -1108,7 +1176,7 @@ extern "C" int dh_xattn_prep_bwd_stack(int dtype, const void* tok, void* dtok_ac
     w.S = S; w.L = L; w.heads = heads; w.dh = dim_head; w.HLP = HLP; w.scale = scale; w.mn = mn; w.k = k; w.v = v;
     w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;
     w.ln_partial = a.ln_partial; w.dln_g = dln_g; w.dln_b = dln_b;
-    w.accumulate = accumulate; w.ls_param = param_stride;
+    w.accumulate = accumulate; w.ls_param = param_stride; w.ln_only = 0;
     DH_REQUIRE(dim_head % 8 == 0, "xattn_prep_bwd: dim_head=%d must be a multiple of 8", dim_head);
     hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(inner / 8, 5, layers), dim3(256), 0, ST(stream), w);
     DH_CHECK_LAUNCH("xattn_prep_bwd");
@@ -1147,8 +1215,15 @@ extern "C" int dh_xattn_prep_bwd_stack_mfma(const void* tok, void* dtok_accum, l
     w.S = S; w.L = L; w.heads = heads; w.dh = dim_head; w.HLP = HLP; w.scale = scale; w.mn = mn; w.k = k; w.v = v;
     w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;
     w.ln_partial = a.ln_partial; w.dln_g = dln_g; w.dln_b = dln_b;
-    w.accumulate = accumulate; w.ls_param = param_stride;
-    hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(inner / 8, 5, layers), dim3(256), 0, ST(stream), w);
+    w.accumulate = accumulate; w.ls_param = param_stride; w.ln_only = 0;
+    static const bool wg_fma = getenv("DAHITRA_PREP_WGRAD_FMA") != nullptr;
+    if (dim_head == 64 && S % 8 == 0 && !wg_fma) {
+        hipLaunchKernelGGL(xattn_prep_wgrad_mfma_kernel, dim3(heads, 4, layers), dim3(256), 0, ST(stream), w);
+        w.ln_only = 1;
+        hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(2, 1, layers), dim3(256), 0, ST(stream), w);      // LayerNorm dgamma / dbeta only
+    } else {
+        hipLaunchKernelGGL(xattn_prep_wgrad_kernel, dim3(inner / 8, 5, layers), dim3(256), 0, ST(stream), w);
+    }
     DH_CHECK_LAUNCH("xattn_prep_bwd_mfma");
     return 0;
 }
