@@ -104,24 +104,22 @@ struct LNres {
 // LayerNorm of one pixel held as v[2][4] across 4 lane groups; returns xhat in place of v and the affine in o
 __device__ __forceinline__ LNres layer_norm(const float (&v)[2][4], const float* gam, const float* bet, int g,
                                             float eps, float (&xh)[2][4], float (&o)[2][4]) {
-    float s = 0.f;
+    // sum and sum of squares in ONE pass: the two cross-row reductions run side by side instead of one after the other (these
+    // kernels are chains of dependent steps), and x_hat = x * rstd - mean * rstd is one FMA per channel
+    float s = 0.f, q = 0.f;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s += v[h][j];
+        for (int j = 0; j < 4; ++j) { s += v[h][j]; q += v[h][j] * v[h][j]; }
     const float mean = group4_sum(s) * (1.f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float d = v[h][j] - mean; q += d * d; }
-    const float rstd = rsqrtf(group4_sum(q) * (1.f / D) + eps);
+    const float var = fmaxf(group4_sum(q) * (1.f / D) - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps), nmr = -mean * rstd;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = h * 16 + g * 4 + j;
-            xh[h][j] = (v[h][j] - mean) * rstd;
+            xh[h][j] = v[h][j] * rstd + nmr;
             o[h][j] = xh[h][j] * gam[c] + bet[c];
         }
     return LNres{mean, rstd};
@@ -350,23 +348,19 @@ __global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_kernel(DecArgs
         for (int s = 0; s < 2; ++s) { lds4(cG1 + s * 16 + g * 4, gam[s]); lds4(cBe1 + s * 16 + g * 4, bet[s]); }
         LNres n1;
         {
-            float sm = 0.f;
+            float sm = 0.f, q = 0.f;                   // (one pass: see layer_norm)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sm += x[h][j];
+                for (int j = 0; j < 4; ++j) { sm += x[h][j]; q += x[h][j] * x[h][j]; }
             n1.mean = group4_sum(sm) * (1.f / D);
-            float q = 0.f;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float d = x[h][j] - n1.mean; q += d * d; }
-            n1.rstd = rsqrtf(group4_sum(q) * (1.f / D) + p.eps);
+            n1.rstd = rsqrtf(fmaxf(group4_sum(q) * (1.f / D) - n1.mean * n1.mean, 0.f) + p.eps);
+            const float nmr = -n1.mean * n1.rstd;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    xh1[h][j] = (x[h][j] - n1.mean) * n1.rstd;
+                    xh1[h][j] = x[h][j] * n1.rstd + nmr;
                     xn[h][j] = xh1[h][j] * gam[h][j] + bet[h][j];
                 }
         }
@@ -398,18 +392,14 @@ __global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_kernel(DecArgs
         float xh2[2][4], l2[2][4], gam2[2][4];
         LNres n2;
         {
-            float sm = 0.f;
+            float sm = 0.f, q = 0.f;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sm += x1[h][j];
+                for (int j = 0; j < 4; ++j) { sm += x1[h][j]; q += x1[h][j] * x1[h][j]; }
             n2.mean = group4_sum(sm) * (1.f / D);
-            float q = 0.f;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float d = x1[h][j] - n2.mean; q += d * d; }
-            n2.rstd = rsqrtf(group4_sum(q) * (1.f / D) + p.eps);
+            n2.rstd = rsqrtf(fmaxf(group4_sum(q) * (1.f / D) - n2.mean * n2.mean, 0.f) + p.eps);
+            const float nmr = -n2.mean * n2.rstd;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float b4[4];
@@ -417,7 +407,7 @@ __global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_kernel(DecArgs
                 lds4(cBe2 + h * 16 + g * 4, b4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    xh2[h][j] = (x1[h][j] - n2.mean) * n2.rstd;
+                    xh2[h][j] = x1[h][j] * n2.rstd + nmr;
                     l2[h][j] = xh2[h][j] * gam2[h][j] + b4[j];
                 }
             }
