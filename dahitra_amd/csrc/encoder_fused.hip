@@ -175,12 +175,19 @@ __device__ __forceinline__ void layer_forward(const EncArgs& a, const Lds& l, in
         const int e0 = sub * (a.dh >> 2), e1 = e0 + (a.dh >> 2);
         float sc[MAXN];
         if (pair < npair) {
+            // 16-byte LDS reads (dh / 4 is a multiple of 4): with scalar reads this phase was 256 dependent-latency
+            // ds_read_b32 per thread, 11.3 of the forward's 39 us (tools/build_timing_barriers.py + barrier_timeline.py)
             const float* q = l.qkv + t * 3 * inner + h * a.dh;
-            for (int s = 0; s < n; ++s) {
-                const float* k = l.qkv + s * 3 * inner + inner + h * a.dh;
-                float d = 0.f;
-                for (int e = e0; e < e1; ++e) d += q[e] * k[e];
-                sc[s] = d;
+#pragma unroll
+            for (int s = 0; s < MAXN; ++s) sc[s] = 0.f;
+            for (int e = e0; e < e1; e += 4) {
+                const float4 q4 = *reinterpret_cast<const float4*>(q + e);
+#pragma unroll
+                for (int s = 0; s < MAXN; ++s)
+                    if (s < n) {
+                        const float4 k4 = *reinterpret_cast<const float4*>(l.qkv + s * 3 * inner + inner + h * a.dh + e);
+                        sc[s] += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+                    }
             }
         }
 #pragma unroll
@@ -487,7 +494,7 @@ int set_lds(const void* kern, size_t lds, bool& done) {
 
 // largest inner width whose backward working set (forward buffers + gradient scratch) fits the 160 KB LDS
 extern "C" int dh_encoder_supported(int n, int heads, int dim_head, int mlp) {
-    if (n < 1 || n > MAXN || mlp > 64 || mlp < 1 || heads < 1 || dim_head % 4) return 0;
+    if (n < 1 || n > MAXN || mlp > 64 || mlp < 1 || heads < 1 || dim_head % 16) return 0;      // (16-byte LDS reads of a quarter head)
     const int inner = heads * dim_head;
     const size_t bwd = (fwd_lds_floats(n, inner, heads, mlp) + (size_t)n * D * 4 + (size_t)n * mlp + (size_t)n * inner +
                         (size_t)n * 3 * inner + (size_t)heads * n * n) * 4;
