@@ -302,10 +302,12 @@ def main():
             step()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
-        # An event pair costs time of its own: two records with NOTHING between them are 4.6 - 5.8 us apart on this stack (a
-        # 2 us kernel between them: 6.8 us), which is why the per-launch figures sit ~4 us above rocprofv3's kernel durations
-        # (profiles/*_kernel_stats.csv).  `achieved` stays on the raw (conservative) event time; the empty-pair time is
-        # measured here and the figure with it taken off is reported next to it.
+        # An event pair costs time of its own: two records with NOTHING between them are 4.6 - 12.7 us apart depending on the
+        # box (a 2 us kernel between them: 6.8 us), which is why the per-launch figures sit 2 - 12 us above rocprofv3's kernel
+        # durations (profiles/*_kernel_stats.csv: 40.7 - 42.0 us for the class on every box, where this raw figure moved
+        # between 42.6 and 53.5 us).  `achieved` stays on the raw (conservative) event time; the empty-pair time is measured
+        # here and the figure with it taken off is reported next to it -- as information only: on one box it over-corrected
+        # (12.7 us measured for the empty pair, 33.1 us "net" per launch against rocprofv3's 40.7 us of the same build).
         cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
         for e0, e1 in cal:
             e0.record()
