@@ -308,6 +308,41 @@ def main():
         # between 42.6 and 53.5 us).  `achieved` stays on the raw (conservative) event time; the empty-pair time is measured
         # here and the figure with it taken off is reported next to it -- as information only: on one box it over-corrected
         # (12.7 us measured for the empty pair, 33.1 us "net" per launch against rocprofv3's 40.7 us of the same build).
+        # ... and a measurement without any per-launch event: the launches of the dominant class of ONE more eager step are
+        # recorded as closures (their tensors kept alive) and re-issued back to back, in program order, inside a recorded HIP
+        # graph; one event pair around `reps` replays.  22 launches x ~66 MB of distinct operands per round: cache-cold like
+        # the step itself.  Reported as `graph_replay` next to the per-launch figures (same FLOPs, duration = elapsed / launches).
+        def class_replay(key, reps=10):
+            ops.REPLAY, ops.PROFILE = {"key": key, "calls": []}, {}       # (PROFILE set: `step` takes its eager path)
+            try:
+                step()
+            finally:
+                rp, ops.REPLAY, ops.PROFILE = ops.REPLAY, None, None
+            torch.cuda.synchronize()
+            calls = rp["calls"]
+            if not calls:
+                return None
+            side, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                for c, _, _ in calls:
+                    c(ops.S())
+                with torch.cuda.graph(graph, stream=side):
+                    for c, _, _ in calls:
+                        c(ops.S())
+            torch.cuda.synchronize()
+            graph.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            fl = sum(f for _, _, f in calls)
+            return {"launches": len(calls), "ms_per_round": round(ms, 4), "avg_launch_us": round(ms * 1e3 / len(calls), 2),
+                    "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                    "how": "the class's launches of one step re-issued back to back inside a recorded HIP graph, one event pair "
+                           "around %d replays (no per-launch event; includes the graph's launch-to-launch gaps)" % reps}
         cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
         for e0, e1 in cal:
             e0.record()
@@ -331,6 +366,9 @@ def main():
             ms, fl, _, n = mfma[key]
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = fl / (ms * 1e-3) / 1e12
+            replay = class_replay(key)
+            if replay:
+                replay["frac"] = round(replay["achieved"] / peak, 4)
             traffic = source = None      # HBM bytes per launch from committed rocprofv3 --pmc passes of this command
             headline = args.dtype == "bf16" and args.net == NET and args.img == SIZE and args.batch == PER_GPU_BATCH
             tprof = _latest_profile("_pmc_traffic_conv3x3.json")
@@ -376,7 +414,7 @@ def main():
                     "kernels_of_class": "conv_mfma_kernel<bf16,3,1,64,...> (tap-oriented) and conv3x3_wreg_kernel (register-resident "
                                         "weights: the 64-channel layers and, without BatchNorm on load, the 128- and 256-channel ones): every 3x3 stride-1 convolution and data gradient of the "
                                         "step; the 2x2 phase convolutions are their own class (conv_phase<...>)",
-                    "weight_gradient": wgrad, "step_traffic": step_traffic}
+                    "graph_replay": replay, "weight_gradient": wgrad, "step_traffic": step_traffic}
         classes = {}
         for k in ("bn_apply", "bn_bwd", "stem7_fwd", "decoder_layer_fwd", "decoder_layer_bwd"):
             if k in agg:

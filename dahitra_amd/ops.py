@@ -277,6 +277,8 @@ class SideStream:
 
 # ---- convolution / linear ------------------------------------------------------------------------
 PROFILE = None       # set to {} by bench.py to collect (events, algorithmic flops, algorithmic bytes) per launch
+REPLAY = None        # set to {"key": class, "calls": []} by bench.py for ONE eager step: the C calls of that kernel class as
+                     # closures (stream -> launch) with their tensors kept alive, to be re-issued back to back in a recorded graph
 
 
 class _Prof:
@@ -364,10 +366,14 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     nt_ = 64 if cpad % 64 == 0 else (32 if cpad % 32 == 0 else 16)
     key = "conv_mfma<%s,ks%d,s%d,nt%d>" % ("bf16" if x.dtype == torch.bfloat16 else "f32", ks, stride, nt_)
     flops = alg_flops if alg_flops else 2.0 * N * OH * OW * cout * Cin * ks * ks
+    fixed = (_ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
+             _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
+             _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), *_bn_in_args(bn_in), _ci(0), P(w_frag))
     with _Prof(key, flops, _nb(x, y, wp, residual, pre)):
-        _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wp), P(y), P(bias), P(residual), P(stats), _ci(N), _ci(H), _ci(W),
-              _ci(Cin), _ci(OH), _ci(OW), _ci(cout), _ci(cpad), _ci(ks), _ci(stride), _ci(pad), _ci(act), _ci(npix_valid),
-              _cl(w_image_stride), P(pre), _ci(dilation), *_gate_args(gate), *_bn_in_args(bn_in), _ci(0), P(w_frag), S())
+        _call("dh_conv2d_fwd", *fixed, S())
+    if REPLAY is not None and key == REPLAY["key"]:
+        REPLAY["calls"].append((lambda stream, fixed=fixed: _call("dh_conv2d_fwd", *fixed, stream),
+                                (x, wp, y, bias, residual, stats, pre, w_frag, gate, bn_in), flops))
     out = [y]
     if want_stats:
         out.append(stats)
