@@ -32,78 +32,51 @@ __device__ __forceinline__ float quad_sum(float v) {       // over the 4 lanes o
 // tokenizer
 // ------------------------------------------------------------------------------------------
 template <typename T, int L>
-__global__ __launch_bounds__(256) void tok_logits_kernel(const T* __restrict__ x, const float* __restrict__ wa,
-                                                         float* __restrict__ logits, long P) {
-    // four lanes per pixel row (8 channels = one 16-byte piece of x for bf16 each), the channel sums meet over the quad
-    const int q = threadIdx.x & 3;
-    const long p = (long)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
-    const bool live = p < P;
-    const long row = live ? p : 0;
-    float w[L][8], xv[8];
+__global__ void tok_logits_kernel(const T* __restrict__ x, const float* __restrict__ wa, float* __restrict__ logits,
+                                  long P) {
+    __shared__ float w[L * D];
+    for (int i = threadIdx.x; i < L * D; i += blockDim.x) w[i] = wa[i];
+    __syncthreads();
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float acc[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l)
+    for (int l = 0; l < L; ++l) acc[l] = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) w[l][c] = wa[l * D + q * 8 + c];
-#pragma unroll
-    for (int c = 0; c < 8; c += 4) {
+    for (int c = 0; c < D; c += 4) {
         float v[4];
-        ld4(x + row * D + q * 8 + c, v);
+        ld4(x + p * D + c, v);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xv[c + j] = v[j];
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[l] += v[j] * w[l * D + c + j];
     }
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc += xv[c] * w[l][c];
-        acc = quad_sum(acc);
-        if (live && (l & 3) == q) logits[row * L + l] = acc;
-    }
+    for (int l = 0; l < L; ++l) logits[p * L + l] = acc[l];
 }
 
-// softmax statistics over the HW pixels of one image, all L tokens at once: one 256-thread workgroup per image reading whole
-// logit rows (16-byte loads).  (One workgroup per (image, token) read every cache line L times, 4 bytes out of 16.)
+// softmax statistics over the HW pixels of one (image, token): one 256-thread workgroup each
 template <int L>
 __global__ __launch_bounds__(256) void tok_stats_kernel(const float* __restrict__ logits, int HW,
                                                         float* __restrict__ stats /*[S][L][2]*/) {
-    __shared__ float red[4][L], rede[4][L];
-    const int s = blockIdx.x, tid = threadIdx.x;
-    const float* lg = logits + (size_t)s * HW * L;
-    float m[L], e[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) m[l] = -INFINITY;
-    for (int n = tid; n < HW; n += 256) {
-#pragma unroll
-        for (int l4 = 0; l4 < L; l4 += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(lg + (size_t)n * L + l4);
-            m[l4] = fmaxf(m[l4], v.x); m[l4 + 1] = fmaxf(m[l4 + 1], v.y); m[l4 + 2] = fmaxf(m[l4 + 2], v.z); m[l4 + 3] = fmaxf(m[l4 + 3], v.w);
-        }
-    }
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        m[l] = wave_max(m[l]);
-        if ((tid & 63) == 0) red[tid >> 6][l] = m[l];
-    }
+    __shared__ float red[4];
+    const int s = blockIdx.x / L, l = blockIdx.x % L, tid = threadIdx.x;
+    const float* lg = logits + (size_t)s * HW * L + l;
+    float m = -INFINITY;
+    for (int n = tid; n < HW; n += 256) m = fmaxf(m, lg[(size_t)n * L]);
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-#pragma unroll
-    for (int l = 0; l < L; ++l) { m[l] = fmaxf(fmaxf(red[0][l], red[1][l]), fmaxf(red[2][l], red[3][l])); e[l] = 0.f; }
-    for (int n = tid; n < HW; n += 256) {
-#pragma unroll
-        for (int l4 = 0; l4 < L; l4 += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(lg + (size_t)n * L + l4);
-            e[l4] += __expf(v.x - m[l4]); e[l4 + 1] += __expf(v.y - m[l4 + 1]);
-            e[l4 + 2] += __expf(v.z - m[l4 + 2]); e[l4 + 3] += __expf(v.w - m[l4 + 3]);
-        }
-    }
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        e[l] = wave_sum(e[l]);
-        if ((tid & 63) == 0) rede[tid >> 6][l] = e[l];
-    }
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
-    if (tid < L) {
-        stats[((size_t)s * L + tid) * 2 + 0] = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
-        stats[((size_t)s * L + tid) * 2 + 1] = 1.f / (rede[0][tid] + rede[1][tid] + rede[2][tid] + rede[3][tid]);
+    float e = 0.f;
+    for (int n = tid; n < HW; n += 256) e += __expf(lg[(size_t)n * L] - m);
+    e = wave_sum(e);
+    if ((tid & 63) == 0) red[tid >> 6] = e;
+    __syncthreads();
+    if (tid == 0) {
+        stats[(size_t)blockIdx.x * 2 + 0] = m;
+        stats[(size_t)blockIdx.x * 2 + 1] = 1.f / (red[0] + red[1] + red[2] + red[3]);
     }
 }
 
@@ -1110,9 +1083,9 @@ extern "C" int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const
     float* part = reinterpret_cast<float*>(workspace);
 #define TOKF(TT, LL)                                                                                              \
     do {                                                                                                          \
-        hipLaunchKernelGGL((tok_logits_kernel<TT, LL>), dim3(dh_cdiv(P, 64)), dim3(256), 0, ST(stream),           \
+        hipLaunchKernelGGL((tok_logits_kernel<TT, LL>), dim3(dh_cdiv(P, 256)), dim3(256), 0, ST(stream),          \
                            (const TT*)x, wa, logits, P);                                                          \
-        hipLaunchKernelGGL((tok_stats_kernel<LL>), dim3(S), dim3(256), 0, ST(stream), logits, HW, stats);          \
+        hipLaunchKernelGGL((tok_stats_kernel<LL>), dim3(S * LL), dim3(256), 0, ST(stream), logits, HW, stats);     \
         hipLaunchKernelGGL((tok_pool_partial_kernel<TT, LL>), dim3(nch, S), dim3(256), 0, ST(stream),             \
                            (const TT*)x, logits, stats, HW, chunk, part);                                         \
         hipLaunchKernelGGL((tok_finish_kernel<TT, LL>), dim3(S), dim3(LL * 32), 0, ST(stream), part, stats, pos,  \
