@@ -227,6 +227,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--net", default=NET)
+    ap.add_argument("--no-class-replay", action="store_true",
+                    help="skip roofline.graph_replay (profiler runs: its launches would be counted into the kernel statistics)")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="pairs per GPU")
     ap.add_argument("--img", type=int, default=SIZE, help="image side (the headline metric is quoted at 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -366,7 +368,7 @@ def main():
             ms, fl, _, n = mfma[key]
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = fl / (ms * 1e-3) / 1e12
-            replay = class_replay(key)
+            replay = class_replay(key) if not args.no_class_replay else None
             if replay:
                 replay["frac"] = round(replay["achieved"] / peak, 4)
             traffic = source = None      # HBM bytes per launch from committed rocprofv3 --pmc passes of this command

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --net newUNetTrans --steps 6 --warmup 2 --no-cpu-baseline --no-parity-mode > $O/prof_bench.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --net newUNetTrans --steps 6 --warmup 2 --no-cpu-baseline --no-parity-mode --no-class-replay > $O/prof_bench.json 2> $O/stats.err
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/${tag}_bench_newUNetTrans_kernel_stats.csv
 python3 - $O/stats $O/${tag}_decoder_launches.txt <<'PY'
 import csv, glob, sys, collections

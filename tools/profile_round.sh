@@ -7,9 +7,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity-mode > $O/${tag}_prof_bench.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity-mode --no-class-replay > $O/${tag}_prof_bench.json 2> $O/stats.err
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/${tag}_bench_bf16_b32_kernel_stats.csv
-B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-graph"
+B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-class-replay --no-graph"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B > /dev/null 2> $O/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B > /dev/null 2> $O/write.err
 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/util -- $B > /dev/null 2> $O/util.err

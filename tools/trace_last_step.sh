@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity-mode "$@" > /dev/null 2> $O/tr.err
+rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity-mode --no-class-replay "$@" > /dev/null 2> $O/tr.err
 python3 - $O/tr $R/gpurun_out/${tag}_last_step.txt <<'PY'
 import csv, glob, sys, re
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
