@@ -334,6 +334,44 @@ __global__ void add_pos_bwd_kernel(const T* __restrict__ dy, float* __restrict__
         if (accumulate) dpos[i] += s; else dpos[i] = s;
     }
 }
+// the same for bf16 rows of C = 32 channels: a lane owns one 16-byte piece (8 channels) of a pixel and a quarter of the images
+// (4 loads in flight), the four image groups of a workgroup meet in LDS; 16 pixels per 256-thread workgroup.  (One lane per
+// (channel, pixel) with 2-byte loads 64 bytes apart and N dependent iterations: 17.6 us for 16.8 MB.)
+__global__ __launch_bounds__(256) void add_pos_bwd32_kernel(const bf16* __restrict__ dy, float* __restrict__ dpos, int N, long HW,
+                                                            int accumulate) {
+    constexpr int C = 32;
+    __shared__ float red[4][64][8];
+    const int tid = threadIdx.x, q = tid & 3, px = (tid >> 2) & 15, ng = tid >> 6;
+    const long p = (long)blockIdx.x * 16 + px;
+    float s[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[u][j] = 0.f;
+    if (p < HW) {
+        const int per = (N + 3) / 4, n0 = ng * per, n1 = n0 + per < N ? n0 + per : N;
+        auto row = [&](int n, float (&acc)[8]) {
+            float v[8];
+            unpack16(*reinterpret_cast<const uint4*>(dy + ((long)n * HW + p) * C + q * 8), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        };
+        int n = n0;
+        for (; n + 3 < n1; n += 4) { row(n, s[0]); row(n + 1, s[1]); row(n + 2, s[2]); row(n + 3, s[3]); }
+        for (int u = 0; n < n1; ++n, ++u) row(n, s[u & 3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[ng][tid & 63][j] = (s[0][j] + s[1][j]) + (s[2][j] + s[3][j]);
+    __syncthreads();
+    if (ng == 0 && p < HW) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = ((red[0][tid][j] + red[1][tid][j]) + red[2][tid][j]) + red[3][tid][j];
+            float* o = dpos + (long)(q * 8 + j) * HW + p;
+            if (accumulate) *o += t; else *o = t;
+        }
+    }
+}
 
 // ---- activation derivative: dx = dy * f'(.) ---------------------------------------------------
 // mode RELU: ref = post-activation output (mask ref > 0); mode GELU: ref = pre-activation.
@@ -981,7 +1019,8 @@ extern "C" int dh_add_pos(int dtype, const void* x, const float* pos, void* y, i
 }
 extern "C" int dh_add_pos_bwd(int dtype, const void* dy, float* dpos, int N, long HW, int C, int accumulate, void* stream) {
     const long n = HW * C;
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(add_pos_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)dy, dpos, N, HW, C, accumulate);
+    if (dtype == DH_DTYPE_BF16 && C == 32) hipLaunchKernelGGL(add_pos_bwd32_kernel, dim3((unsigned)((HW + 15) / 16)), dim3(256), 0, ST(stream), (const bf16*)dy, dpos, N, HW, accumulate);
+    else if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(add_pos_bwd_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)dy, dpos, N, HW, C, accumulate);
     else hipLaunchKernelGGL(add_pos_bwd_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)dy, dpos, N, HW, C, accumulate);
     DH_CHECK_LAUNCH("add_pos_bwd");
     return 0;
