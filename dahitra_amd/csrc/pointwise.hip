@@ -298,6 +298,18 @@ __global__ void copy_channels_kernel(const T* __restrict__ src, int Cs, int sc0,
         st4(dst + p * Cd + dc0 + c, v);
     }
 }
+// the same with one 16-byte piece per lane (every channel count and offset a multiple of the piece)
+template <typename T>
+__global__ void copy_channels16_kernel(const T* __restrict__ src, int Cs, int sc0, T* __restrict__ dst, int Cd,
+                                       int dc0, int Cn, long P) {
+    constexpr int V = V16<T>::N;
+    const int vn = Cn / V;
+    GSL(i, P * vn) {
+        const long p = i / vn;
+        const int c = (int)(i % vn) * V;
+        *reinterpret_cast<uint4*>(dst + p * Cd + dc0 + c) = *reinterpret_cast<const uint4*>(src + p * Cs + sc0 + c);
+    }
+}
 
 // ---- y = a + b ------------------------------------------------------------------------------
 template <typename T>
@@ -311,6 +323,18 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
         st4(y + i * 4, u);
     }
 }
+template <typename T>
+__global__ void add16_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long npiece) {
+    constexpr int V = V16<T>::N;      // one 16-byte piece per lane
+    GSL(i, npiece) {
+        float u[V], v[V];
+        ldv(a + i * V, u);
+        ldv(b + i * V, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) u[j] += v[j];
+        stv(y + i * V, u);
+    }
+}
 
 // y[n,p,c] = x[n,p,c] + pos[c,p]  (pos is an NCHW fp32 parameter [1,C,h,w]; networks.py:1291)
 template <typename T>
@@ -320,6 +344,21 @@ __global__ void add_pos_kernel(const T* __restrict__ x, const float* __restrict_
         const int c = (int)(i % C);
         const long p = (i / C) % HW;
         stf(y + i, ldf(x + i) + pos[c * HW + p]);
+    }
+}
+template <typename T>
+__global__ void add_pos16_kernel(const T* __restrict__ x, const float* __restrict__ pos, T* __restrict__ y, int N,
+                                 long HW, int C) {
+    constexpr int V = V16<T>::N;      // one 16-byte piece of x per lane; its V embedding values are L2-resident gathers
+    const int vn = C / V;
+    GSL(i, (long)N * HW * vn) {
+        const int c = (int)(i % vn) * V;
+        const long p = (i / vn) % HW;
+        float v[V];
+        ldv(x + i * V, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] += pos[(long)(c + j) * HW + p];
+        stv(y + i * V, v);
     }
 }
 // dpos[c,p] (+)= sum_n dy[n,p,c]
@@ -385,6 +424,19 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ r
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[j] = act == DH_ACT_RELU ? (r[j] > 0.f ? g[j] : 0.f) : g[j] * gelu_erf_grad(r[j]);
         st4(dx + i * 4, g);
+    }
+}
+template <typename T>
+__global__ void act_bwd16_kernel(const T* __restrict__ dy, const T* __restrict__ ref, T* __restrict__ dx, long npiece,
+                                 int act) {
+    constexpr int V = V16<T>::N;      // one 16-byte piece per lane
+    GSL(i, npiece) {
+        float g[V], r[V];
+        ldv(dy + i * V, g);
+        ldv(ref + i * V, r);
+#pragma unroll
+        for (int j = 0; j < V; ++j) g[j] = act == DH_ACT_RELU ? (r[j] > 0.f ? g[j] : 0.f) : g[j] * gelu_erf_grad(r[j]);
+        stv(dx + i * V, g);
     }
 }
 
@@ -997,7 +1049,9 @@ extern "C" int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, voi
                                 long P, void* stream) {
     DH_REQUIRE(Cn % 4 == 0 && sc0 % 4 == 0 && dc0 % 4 == 0 && Cs % 4 == 0 && Cd % 4 == 0, "copy_channels: channel counts must be multiples of 4");
     const long n = P * (Cn / 4);
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(copy_channels_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)src, Cs, sc0, (bf16*)dst, Cd, dc0, Cn, P);
+    if (dtype == DH_DTYPE_BF16 && !((Cs | sc0 | Cd | dc0 | Cn) & 7))
+        hipLaunchKernelGGL(copy_channels16_kernel<bf16>, dim3(ew_grid(P * (Cn / 8), 256)), dim3(256), 0, ST(stream), (const bf16*)src, Cs, sc0, (bf16*)dst, Cd, dc0, Cn, P);
+    else if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(copy_channels_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)src, Cs, sc0, (bf16*)dst, Cd, dc0, Cn, P);
     else hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)src, Cs, sc0, (float*)dst, Cd, dc0, Cn, P);
     DH_CHECK_LAUNCH("copy_channels");
     return 0;
@@ -1005,14 +1059,16 @@ extern "C" int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, voi
 extern "C" int dh_add(int dtype, const void* a, const void* b, void* y, long n, void* stream) {
     DH_REQUIRE(n % 4 == 0, "add: n must be a multiple of 4");
     const long nv = n / 4;
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(add_kernel<bf16>, dim3(ew_grid(nv, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (bf16*)y, nv);
+    if (dtype == DH_DTYPE_BF16 && n % 8 == 0) hipLaunchKernelGGL(add16_kernel<bf16>, dim3(ew_grid(n / 8, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (bf16*)y, n / 8);
+    else if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(add_kernel<bf16>, dim3(ew_grid(nv, 256)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (bf16*)y, nv);
     else hipLaunchKernelGGL(add_kernel<float>, dim3(ew_grid(nv, 256)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (float*)y, nv);
     DH_CHECK_LAUNCH("add");
     return 0;
 }
 extern "C" int dh_add_pos(int dtype, const void* x, const float* pos, void* y, int N, long HW, int C, void* stream) {
     const long n = (long)N * HW * C;
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(add_pos_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, pos, (bf16*)y, N, HW, C);
+    if (dtype == DH_DTYPE_BF16 && C % 8 == 0) hipLaunchKernelGGL(add_pos16_kernel<bf16>, dim3(ew_grid(n / 8, 256)), dim3(256), 0, ST(stream), (const bf16*)x, pos, (bf16*)y, N, HW, C);
+    else if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(add_pos_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)x, pos, (bf16*)y, N, HW, C);
     else hipLaunchKernelGGL(add_pos_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)x, pos, (float*)y, N, HW, C);
     DH_CHECK_LAUNCH("add_pos");
     return 0;
@@ -1028,7 +1084,8 @@ extern "C" int dh_add_pos_bwd(int dtype, const void* dy, float* dpos, int N, lon
 extern "C" int dh_act_bwd(int dtype, const void* dy, const void* ref, void* dx, long n, int act, void* stream) {
     DH_REQUIRE(n % 4 == 0 && (act == DH_ACT_RELU || act == DH_ACT_GELU), "act_bwd: bad arguments");
     const long nv = n / 4;
-    if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(ew_grid(nv, 256)), dim3(256), 0, ST(stream), (const bf16*)dy, (const bf16*)ref, (bf16*)dx, nv, act);
+    if (dtype == DH_DTYPE_BF16 && n % 8 == 0) hipLaunchKernelGGL(act_bwd16_kernel<bf16>, dim3(ew_grid(n / 8, 256)), dim3(256), 0, ST(stream), (const bf16*)dy, (const bf16*)ref, (bf16*)dx, n / 8, act);
+    else if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(ew_grid(nv, 256)), dim3(256), 0, ST(stream), (const bf16*)dy, (const bf16*)ref, (bf16*)dx, nv, act);
     else hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(ew_grid(nv, 256)), dim3(256), 0, ST(stream), (const float*)dy, (const float*)ref, (float*)dx, nv, act);
     DH_CHECK_LAUNCH("act_bwd");
     return 0;
