@@ -7,7 +7,8 @@
 //
 //   phase 1   every workgroup (one per CU, 512 threads) loads its slice of dout / x (/ out) ONCE, keeps g in
 //             registers and x in LDS, accumulates (sum g, sum g * x) per channel, writes dres = g if asked, and adds
-//             its [2][C] partial into 64-bit FIXED-POINT accumulators (integer atomics: order-independent, deterministic);
+//             its [2][C] partial into FIXED-POINT accumulators (two 64-bit words per sum, integer atomics: order-independent,
+//             deterministic, and exact for fp32 partials down to 2^-74);
 //   barrier   one device-wide arrival counter (agent-scope release / acquire, MI355X_MICROARCH.md "barrier-counter";
 //             256 workgroups = the chip's 256 CUs, one resident workgroup each: registers and LDS admit exactly one);
 //   phase 2   every workgroup reads its BatchNorm group's sums, the first one also writes dgamma / dbeta, and
@@ -32,7 +33,11 @@ constexpr int PG = 256;            // workgroups = CUs of an MI355X
 constexpr int PT = 512;            // threads per workgroup (8 waves, 2 per SIMD: 256 VGPRs per lane, 64 of them hold g)
 constexpr int PNP = 16;            // 16-byte pieces of each tensor per thread (16 x 512 x 16 B = 128 KB of x in LDS)
 constexpr unsigned SPIN_LIMIT = 1u << 22;
-constexpr double FIX_SCALE = 1073741824.0;      // 2^30
+// A partial sum t (fp32) is split as t = H * 2^-20 + L * 2^-74 with integers H = rint(t * 2^20) and L = (t - H * 2^-20) * 2^74
+// (|L| <= 2^53: exact for every fp32 t with |t| >= 2^-50, i.e. nothing of a small late-training gradient is rounded away);
+// the two words are accumulated separately.  256 workgroups x |t| < 8e9 keep sum H below 2^61, sum L below 2^62.
+constexpr double FIX_HI = 1048576.0;                          // 2^20
+constexpr double FIX_LO = 18889465931478580854784.0;          // 2^74
 
 struct PersistArgs {
     const bf16* dout; const bf16* out; const bf16* x;
@@ -40,7 +45,7 @@ struct PersistArgs {
     bf16* dx; bf16* dres;
     float* dgamma; float* dbeta;
     unsigned* sync;        // [0] arrivals, [1] departures, [2] error word (timeout); from word 16 on: the fixed-point
-                           // accumulators long long [groups][2][C] (all zero between launches)
+                           // accumulators long long [2 words: H, L][groups][2][C] (all zero between launches)
     long pieces_per_group; // 16-byte pieces of one BatchNorm group
     int C, groups, np, accumulate;
     float inv_m;
@@ -64,6 +69,7 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
     const int g = blockIdx.x / wpg, w = blockIdx.x % wpg;
     const long R = (long)p.np * PT;                  // pieces per workgroup
     long long* acc = reinterpret_cast<long long*>(p.sync + 16);
+    long long* accl = acc + (size_t)p.groups * 2 * p.C;            // the low words
     const long base = (long)g * p.pieces_per_group;  // first piece of this group
     const long first = (long)w * R;
 
@@ -160,12 +166,15 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < PT / 64; ++r) t += red[r * p.C + c];
-            // cross-workgroup sum: 64-bit FIXED-POINT atomics (integer addition is associative, so the result does not
-            // depend on the arrival order: deterministic).  2^-30 resolution, |sum| < 8.6e9.
+            // cross-workgroup sum: FIXED-POINT integer atomics (integer addition is associative, so the result does not
+            // depend on the arrival order: deterministic), two words per sum (see FIX_HI / FIX_LO)
             if (!(fabsf(t) < 8.0e9f))          // NaN / Inf / out of range: the integer accumulators cannot carry it
                 __hip_atomic_fetch_or(&p.sync[2], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&acc[(size_t)(g * 2 + which) * p.C + c], (long long)__double2ll_rn((double)t * FIX_SCALE),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double td = (double)t;
+            const long long hi = __double2ll_rn(td * FIX_HI);
+            const long long lo = __double2ll_rn((td - (double)hi * (1.0 / FIX_HI)) * FIX_LO);
+            __hip_atomic_fetch_add(&acc[(size_t)(g * 2 + which) * p.C + c], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lo != 0) __hip_atomic_fetch_add(&accl[(size_t)(g * 2 + which) * p.C + c], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
@@ -197,10 +206,13 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
     //   s1 = sum g, sgx = sum g x, s2 = sum g xhat = invstd * (sgx - mean * s1)
     //   dx = A * (g - (s1 + xhat * s2) / M) = A g + B x + K,  A = gamma * invstd,  xhat = (x - mean) * invstd
     float* coef = red;                                       // [3][C]: A, B, K
-    const double unfix = 1.0 / FIX_SCALE;
+    auto total = [&](int i) -> double {      // the sum behind accumulator i
+        return (double)__hip_atomic_load(&acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.0 / FIX_HI) +
+               (double)__hip_atomic_load(&accl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * (1.0 / FIX_LO);
+    };
     if (tid < p.C) {
-        const double t1 = (double)__hip_atomic_load(&acc[(size_t)(g * 2 + 0) * p.C + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * unfix;
-        const double tgx = (double)__hip_atomic_load(&acc[(size_t)(g * 2 + 1) * p.C + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * unfix;
+        const double t1 = total((g * 2 + 0) * p.C + tid);
+        const double tgx = total((g * 2 + 1) * p.C + tid);
         const double mean = (double)k_mean, isd = (double)k_isd;
         const double t2 = isd * (tgx - mean * t1);
         const double A = (double)k_gamma * isd, im = (double)p.inv_m;
@@ -236,8 +248,8 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
         // a timed-out barrier or a non-finite partial: poison the parameter gradients (in-band, no host round trip)
         if (__hip_atomic_load(&p.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) tb = __builtin_nan("");
         for (int gg = 0; gg < p.groups; ++gg) {
-            const double u1 = (double)__hip_atomic_load(&acc[(size_t)(gg * 2 + 0) * p.C + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * unfix;
-            const double ux = (double)__hip_atomic_load(&acc[(size_t)(gg * 2 + 1) * p.C + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * unfix;
+            const double u1 = total((gg * 2 + 0) * p.C + tid);
+            const double ux = total((gg * 2 + 1) * p.C + tid);
             tb += u1;
             tg += (double)p.invstd[gg * p.C + tid] * (ux - (double)p.mean[gg * p.C + tid] * u1);
         }
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
         *last = __hip_atomic_fetch_add(&p.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)PG - 1;
     __syncthreads();
     if (*last) {       // the last workgroup to leave: all its threads zero the accumulators, then the counters
-        for (int i = tid; i < p.groups * 2 * p.C; i += PT)
+        for (int i = tid; i < p.groups * 4 * p.C; i += PT)         // high and low words
             __hip_atomic_store(&acc[i], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) {
             __hip_atomic_store(&p.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -267,6 +279,7 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
 extern "C" int dh_bn_bwd_persist_supported(int dtype, long npix, int C, int groups) {
     if (dtype != DH_DTYPE_BF16 || C % 8 || C < 8 || C > 256 || 64 % (C / 8) || groups < 1 || PG % groups || npix % groups)
         return 0;
+    if ((long)groups * 4 * C * 8 + 64 > 8192 * 4) return 0;      // the accumulators live in the caller's 8192-word sync block
     static int cus = -1;
     if (cus < 0) {
         int dev = 0;

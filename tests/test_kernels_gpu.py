@@ -828,6 +828,34 @@ def test_batchnorm_backward_persistent_launch_equals_two_pass(ops, cfg, monkeypa
         assert torch.equal(two[3], per[3]), "dres"
 
 
+def test_batchnorm_backward_persistent_keeps_small_gradients(ops, monkeypatch):
+    """the cross-workgroup sums of dh_bn_bwd_persist are integer (order-independent) but must not round small partial sums
+    away: a gradient scaled by 2^-30 gives dgamma / dbeta scaled by exactly 2^-30 (every step of the fp32 chain scales
+    exactly, and the two-word fixed point carries fp32 partials down to 2^-74), and both agree with an fp64 sum"""
+    dtype = torch.bfloat16
+    N, H, W, C, G = 64, 32, 32, 128, 2
+    x = dev(rnd((N, H, W, C), dtype, 821, 1.5), dtype)
+    dout = dev(rnd((N, H, W, C), dtype, 822), dtype)
+    mean = rnd((G, C), torch.float32, 823, 0.2).cuda()
+    invstd = (rnd((G, C), torch.float32, 824, 0.1) + 0.9).cuda()
+    gamma = (rnd((C,), torch.float32, 825, 0.1) + 1.0).cuda()
+    monkeypatch.setattr(ops, "BN_BWD_PERSIST", "force")
+    got = {}
+    for e in (0, 30):
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        ops.bn_bwd((dout.float() * 2.0 ** -e).to(dtype), None, x, mean, invstd, gamma, dg, db, G)
+        got[e] = (dg.double() * 2.0 ** e, db.double() * 2.0 ** e)
+    ops.bn_persist_check(x.device)
+    g64 = dout.double().view(G, -1, C)
+    xh = (x.double().view(G, -1, C) - mean.double()[:, None, :]) * invstd.double()[:, None, :]
+    want = ((g64 * xh).sum((0, 1)), g64.sum((0, 1)))
+    for name, a, b, w in zip(("dgamma", "dbeta"), got[0], got[30], want):
+        s = float(w.abs().max())
+        assert float((a - w).abs().max()) <= 1e-5 * s, name
+        assert float((b - w).abs().max()) <= 1e-5 * s, name + " of the 2^-30 gradient"
+        assert float((a - b).abs().max()) <= 3e-7 * s, name + ": scaling the gradient must scale the sums"
+
+
 def test_batchnorm_backward_persistent_failures_are_loud(ops, monkeypatch):
     """the device-wide barrier of dh_bn_bwd_persist: a timeout (forced: the barrier waits for one arrival that never comes,
     with a short spin limit) and a non-finite gradient must both (a) poison dgamma / dbeta with NaN in the same launch and
