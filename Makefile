@@ -11,9 +11,14 @@ FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-resul
 all: $(LIB)
 
 # the token-side kernels are long dependent chains at one or two waves per SIMD: schedule them for ILP, not occupancy
-# (fused decoder backward 39.9 -> 34.9 us, fused encoder forward 66.9 -> 50.7 us)
-ILP_SRCS := decoder_fused encoder_fused tokens
+# (fused encoder forward 66.9 -> 50.7 us)
+ILP_SRCS := encoder_fused tokens
 $(foreach f,$(ILP_SRCS),$(eval $(OBJ)/$(f).o: EXTRA := -mllvm -amdgpu-sched-strategy=max-ilp))
+
+# fused decoder: MFMA results in VGPRs (its small products feed VALU chains at once: the AGPR form costs a v_accvgpr_read per
+# value, 8 % of the forward's instructions, and two waves per SIMD of occupancy at MLP 64); since the two-workgroups-per-CU
+# rewrite the default scheduler beats max-ilp on the backward (no scratch at 248 registers: 38.5 -> 37.3 / 8.8 -> 7.9 us)
+$(OBJ)/decoder_fused.o: EXTRA := -mllvm -amdgpu-mfma-vgpr-form
 
 # conv_wreg: its stream loop is ONE fully unrolled tile (up to 1152 steps); the default pragma-unroll budget (16 K instructions)
 # silently falls back to a partial unroll, which turns the register-resident weight array into scratch memory

@@ -126,24 +126,24 @@ __device__ __forceinline__ LNres layer_norm(const float (&v)[2][4], const float*
 }
 
 // ------------------------------------------------------------------------------------------------------
-// forward: 256 threads, 128 pixel rows per workgroup (one 16-pixel sub-tile pair per wavefront)
+// forward: 256 threads, rows_per_block pixel rows per workgroup (16-pixel sub-tiles, wave after wave)
 // ------------------------------------------------------------------------------------------------------
 template <int MLP>
 __global__ __launch_bounds__(256) void dec_fwd_kernel(DecArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned short sKq[32 * WP], sVoT[32 * WP], sW1[MLP * WP],
         sW2[32 * (MLP + 8)];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
-    const long row0 = (long)blockIdx.x * 128;
+    const long row0 = (long)blockIdx.x * p.rows_per_block;
     const int img = (int)(row0 / p.rows_per_image);
     stage(sKq, WP, p.kq + (size_t)img * 32 * D, 32, D, tid);
     stage(sVoT, WP, p.voT + (size_t)img * D * 32, D, 32, tid);
     stage(sW1, WP, p.w1, MLP, D, tid);
     stage(sW2, MLP + 8, p.w2, D, MLP, tid);
     __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        const long row = row0 + wv * 32 + ps * 16 + pl;
-        if (row >= p.rows) continue;               // (never splits a wave's MFMA: rows % 16 == 0 is required)
+    const int nsub = p.rows_per_block / 64;          // 16-pixel sub-tiles per wave
+    for (int ps = 0; ps < nsub; ++ps) {
+        const long row = row0 + (ps * 4 + wv) * 16 + pl;
+        if (row >= p.rows) break;                  // (never splits a wave's MFMA: rows % 16 == 0 is required)
         const bf16* xr = p.x + row * D;
         float x[2][4], xh[2][4], xn[2][4];
         ld4(xr + g * 4, x[0]);
@@ -710,6 +710,15 @@ static int check_common(long rows, int rows_per_image, int mlp) {
     return 0;
 }
 
+// rows per forward workgroup: every workgroup stages the image's kq / voT and the two weight matrices first (a quarter of the
+// instructions of a 128-row workgroup), so large launches take more rows per workgroup while >= 1024 workgroups remain
+static inline int dec_fwd_rows_per_block(long rows, int rows_per_image) {
+    static const long minblk = getenv("DAHITRA_DEC_FWD_MINBLK") ? atol(getenv("DAHITRA_DEC_FWD_MINBLK")) : 1024;
+    int rpb = 512;
+    while (rpb > 64 && (rows_per_image % rpb || rows / rpb < minblk)) rpb >>= 1;
+    return rpb;
+}
+
 // x, y: [rows][32] bf16; kq, voT: [images][32][32] bf16 (dh_xattn_prep_fwd); w1: [mlp][32], w2: [32][mlp] bf16
 extern "C" int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, const void* voT, const float* ln1_g,
                                     const float* ln1_b, const float* bo, const float* ln2_g, const float* ln2_b,
@@ -721,7 +730,8 @@ extern "C" int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, cons
     a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2;
     a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
     a.rows_per_image = rows_per_image; a.rows = rows; a.eps = eps;
-    const int grid = (int)(rows / 128);
+    a.rows_per_block = dec_fwd_rows_per_block(rows, rows_per_image);
+    const int grid = (int)(rows / a.rows_per_block);
     if (mlp == 64) hipLaunchKernelGGL(dec_fwd_kernel<64>, dim3(grid), dim3(256), 0, ST(stream), a);
     else hipLaunchKernelGGL(dec_fwd_kernel<32>, dim3(grid), dim3(256), 0, ST(stream), a);
     DH_CHECK_LAUNCH("decoder_layer_fwd");
