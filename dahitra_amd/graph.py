@@ -5,7 +5,8 @@ hipGraphLaunch (MI355X guidance: capture launch-bound inner loops in hipGraphs, 
     step = GraphedTrainStep(net, opt, a, b, lab)      # opt = dahitra_amd.optim.AdamW(..., capturable=True)
     loss = step(a, b, lab)                            # device scalar, same semantics as the eager step
 
-Recorded: forward, zero_grad, focal loss, backward and (single process) the AdamW kernel.  With
+Recorded: forward, zero_grad, focal loss, backward (at engine level, no autograd graph) and (single process) the AdamW
+kernel.  With
 torch.distributed the step is TWO graphs around the exchange:
     graph 1: forward, loss and the first part of the backward -- BiT nets: down to and including resnet.layer3, so that
              every gradient from layer3 to the end of the flat arena (~77 % of its bytes for base_transformer_pos_s4) is
@@ -18,6 +19,8 @@ torch.distributed the step is TWO graphs around the exchange:
     xBD step the mean over ranks, clip_grad_norm_ over the complete arena and the hand-rolled AdamW (train.py:373-374).
 DAHITRA_NO_OVERLAP=1: one graph, then one all-reduce and the update.  The warm-up steps torch needs before capture are
 undone (parameters, BN buffers and optimizer state are restored), so the first graphed step is step 1."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -56,7 +59,7 @@ class GraphedTrainStep:
                     self._second()
                     self._update()
                 else:
-                    self._eager_body(include_opt=True)
+                    self._body(include_opt=True)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         net._arena.flat.copy_(flat0)
@@ -80,7 +83,7 @@ class GraphedTrainStep:
         else:
             self.split_off = None
             with torch.cuda.graph(self.graph):
-                self.loss = self._eager_body(include_opt=not self.exchange)
+                self.loss = self._body(include_opt=not self.exchange)
         self._pinned = ops.pin_captured_buffers(net)
         self._generation = net._arena.generation
         self._calls = 0
@@ -105,6 +108,25 @@ class GraphedTrainStep:
         if include_opt:
             self.opt.step()
         return loss.detach()
+
+    def _body(self, include_opt):
+        """the one-graph step.  The focal-loss step runs at engine level (no autograd graph): the same kernels as
+        `_eager_body` minus what autograd adds around them -- the fill of the upstream gradient 1.0 and the pass that scales
+        dloss/dlogits by it (two launches, 34 MB per step at batch 32).  Subclasses with their own `_eager_body` keep it."""
+        if type(self)._eager_body is not GraphedTrainStep._eager_body or os.environ.get("DAHITRA_GRAPH_AUTOGRAD") == "1":
+            return self._eager_body(include_opt)           # (DAHITRA_GRAPH_AUTOGRAD=1: A/B switch back to the autograd step)
+        net = self.net
+        logits = self._forward_split()
+        bwd = net._engine.take_backward()
+        self.logits = logits
+        loss, dl = self._loss_and_grad(logits)
+        self._count(logits)
+        net._arena.grad.zero_()
+        net._engine.backward(dl, bwd)
+        net._bind_grad_views()           # the optimizer skips parameters without a .grad, as torch does
+        if include_opt:
+            self.opt.step()
+        return loss
 
     def _forward_split(self):
         return self.net._run_forward(self.a, self.b, need_grad=True)
