@@ -389,7 +389,10 @@ def main():
                 wgrad = {"bound": "mfma", "kernel": "conv_wgrad<*> (every weight-gradient launch of the step)",
                          "achieved": round(wfl / (wms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(wfl / (wms * 1e-3) / 1e12 / peak, 4), "launches_per_step": wn,
-                         "ms_per_step": round(wms, 3), "achieved_minus_event_overhead": round(wfl / (wraw * 1e-3) / 1e12, 2)}
+                         "ms_per_step": round(wms, 3), "achieved_minus_event_overhead": round(wfl / (wraw * 1e-3) / 1e12, 2),
+                         "note": "per-launch events need one launch per layer: these eager profiling steps run with the batched "
+                                 "weight gradient off (ops.WgradPlan: PROFILE set); the timed steps issue the wave-specialised "
+                                 "3x3 layers of a pass as ONE launch (conv_wgrad_ws_multi_kernel, profiles/*_kernel_stats.csv)"}
             # whole-step HBM traffic against the algorithmic bytes (constant of the newest committed --pmc step profile)
             step_traffic = None
             sprof = _latest_profile("_pmc_step_traffic.json")

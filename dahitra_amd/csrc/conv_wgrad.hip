@@ -568,22 +568,21 @@ __device__ long long g_ws[4096 * 16];
 #else
 #define WS_T(...)
 #endif
+// the workgroup (bx, kz) of an nbx x nkz grid (nkz = p.splitk): 64co x 64ci block bx, K slice kz
 template <int DIL>
-__global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgArgs p) {
+__device__ __forceinline__ void ws_body(const WgArgs& p, int bx, int kz, const int nbx, const int nkz, unsigned char* smem) {
     constexpr int KS = 3, TAPS = 9;
     constexpr int HH = (TH - 1) + (KS - 1) * DIL + 1, HWD = (TW - 1) + (KS - 1) * DIL + 1;
     constexpr int XP = lds_pitch(128), DP = lds_pitch(128);           // 64 channels x 2 B, odd multiple of 32 B
     constexpr int STAGE = HH * HWD * XP + TH * TW * DP;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bnp = reinterpret_cast<float*>(smem + 2 * STAGE);          // in_scale: [in_groups][2][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pl = lane & 15, g = lane >> 4;
-    int bx = blockIdx.x, kz = blockIdx.y;
-    if (gridDim.x > 1 && (gridDim.y & 7) == 0 && !p.no_xcd_remap) {
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, sq = lin >> 3;
-        bx = (int)(sq % gridDim.x);
-        kz = (int)((sq / gridDim.x) * 8 + xcd);
+    if (nbx > 1 && (nkz & 7) == 0 && !p.no_xcd_remap) {
+        const unsigned lin = (unsigned)(kz * nbx + bx), xcd = lin & 7, sq = lin >> 3;
+        bx = (int)(sq % nbx);
+        kz = (int)((sq / nbx) * 8 + xcd);
     }
     const int cot = bx / p.ci_tiles, cit = bx % p.ci_tiles;
     const int co0 = cot * 64, ci0 = cit * 64;
@@ -756,6 +755,32 @@ __global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgArgs p) {
             for (int j = 0; j < 4; ++j) out[t * tstride + (s * 16 + j) * p.Cin] = acc[t][s][j];
     WS_T(if (tid == 0) { long long* o = g_ws + (blockIdx.y * gridDim.x + blockIdx.x) % 4096 * 16; o[0] = tc[0]; o[1] = tc[1]; o[2] = tloop - tbeg; o[3] = WS_NOW() - tloop; o[4] = my_tiles; })
 }
+template <int DIL>
+__global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ws_body<DIL>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
+}
+// The weight gradients of SEVERAL layers in one launch (dh_wgrad_batch_*): the layers' arguments travel by value in the kernel
+// argument block (a recorded HIP graph keeps them; no device table whose activation pointers would differ between the warm-up
+// pass and the capture), workgroups [first[j], first[j + 1]) serve layer j.  One launch per backward pass instead of one per
+// layer lets every layer take FEWER, LONGER K slices (a launch of its own needs 256 workgroups to fill the chip: 8 pixel tiles
+// per workgroup on the 64-channel layers, and a 147 KB partial slab each) -- the chip is filled by the sum of the layers.
+constexpr int WS_MAXJ = 16;
+struct WsMulti {
+    int njobs;
+    int first[WS_MAXJ + 1];       // multiples of 8 (the XCD-aware order inside a layer relies on it)
+    WgArgs a[WS_MAXJ];
+};
+static_assert(sizeof(WsMulti) <= 4096, "the kernel argument block");
+__global__ __launch_bounds__(512) void conv_wgrad_ws_multi_kernel(WsMulti m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int j = 0;
+    while (j + 1 < m.njobs && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    const WgArgs p = m.a[j];
+    const int nbx = (p.Cout / 64) * p.ci_tiles, local = (int)blockIdx.x - m.first[j];
+    if (local >= nbx * p.splitk) return;              // padding up to the next multiple of 8
+    ws_body<1>(p, local % nbx, local / nbx, nbx, p.splitk, smem);
+}
 #ifdef DH_WS_TIMING
 extern "C" int dh_debug_ws(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ws), (size_t)n * 8); }
 #endif
@@ -784,6 +809,60 @@ static inline bool ws_eligible(const WgArgs& a, int ks, int stride, bool bf16, b
     return !off && bf16 && tr && ks == 3 && stride == 1 && a.groups == 1 && !a.phase_mode && !a.dyt_y && a.Cin % 64 == 0 &&
            a.Cout % 64 == 0 && a.CoutUse == a.Cout && a.CinPitch == a.Cin && a.npix == a.OH * a.OW && a.in_npix == a.H * a.W &&
            (a.in_scale == nullptr || a.in_groups <= 8);
+}
+
+// ---- batched form (dh_wgrad_batch_begin / _launch / _end): eligible layers are collected, one conv_wgrad_ws_multi_kernel serves them
+struct WsBatch {
+    bool on = false;
+    int n = 0;
+    size_t lds = 0;
+    WsMulti m;
+};
+static thread_local WsBatch g_wsb;
+// K slices of a layer inside a batch: ~tiles_per_wg pixel tiles per workgroup (DAHITRA_WGRAD_TPW, default 32), never more
+// slices than the layer's own launch would take, a multiple of 8 from 8 on (XCD-aware order)
+static int ws_batch_splitk(const WgArgs& a) {
+    static const int tpw = getenv("DAHITRA_WGRAD_TPW") ? atoi(getenv("DAHITRA_WGRAD_TPW")) : 32;
+    const long tiles = (long)a.N * a.tilesX * a.tilesY;
+    long sk = tiles / (tpw > 0 ? tpw : 32);
+    if (sk > a.splitk) sk = a.splitk;
+    if (sk >= 8) sk &= ~7L;
+    return (int)(sk < 1 ? 1 : sk);
+}
+static int ws_batch_flush(hipStream_t st) {
+    WsBatch& b = g_wsb;
+    if (b.n == 0) return 0;
+    b.m.njobs = b.n;
+    const int total = b.m.first[b.n];
+    static size_t attr_lds = 0;
+    if (b.lds > attr_lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)b.lds + 4096) != hipSuccess) {
+            (void)hipGetLastError();
+            DH_FAIL("conv_wgrad_ws_multi: cannot raise dynamic LDS to %zu", b.lds);
+        }
+        attr_lds = b.lds;
+    }
+    hipLaunchKernelGGL(conv_wgrad_ws_multi_kernel, dim3(total), dim3(512), b.lds, st, b.m);
+    b.n = 0; b.lds = 0;
+    DH_CHECK_LAUNCH("conv_wgrad_ws_multi");
+    return 0;
+}
+// takes the layer into the open batch (a.splitk becomes its in-batch slice count); a full batch is launched first
+static int ws_batch_add(WgArgs& a, hipStream_t st) {
+    WsBatch& b = g_wsb;
+    if (b.n == WS_MAXJ) { const int rc = ws_batch_flush(st); if (rc) return rc; }
+    a.splitk = ws_batch_splitk(a);
+    if (b.n == 0) b.m.first[0] = 0;
+    const int nblocks = (a.Cout / 64) * a.ci_tiles * a.splitk;
+    b.m.a[b.n] = a;
+    b.m.first[b.n + 1] = b.m.first[b.n] + ((nblocks + 7) & ~7);
+    constexpr int HH = (TH - 1) + 2 + 1, HWD = (TW - 1) + 2 + 1;
+    const size_t lds = 2 * ((size_t)HH * HWD * lds_pitch(128) + (size_t)TH * TW * lds_pitch(128)) +
+                       (a.in_scale ? (size_t)a.in_groups * 128 * sizeof(float) : 0);
+    if (lds > b.lds) b.lds = lds;
+    ++b.n;
+    return 0;
 }
 
 template <typename T, int KS, int STRIDE, int IT, int DIL, int CT, int CIG = 1>
@@ -842,8 +921,10 @@ int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
     const bool wide = a.Cin > 32 && ks == 1 && stride == 1;   // 64-wide ci tiles only where accumulators / LDS fit
     const int it = ks == 4 ? 16 : ((wide || (stride == 1 && wide_ci3x3(a.Cin, a.CoutUse, ks))) ? 64 : 32);
     a.ci_tiles = dh_cdiv(a.Cin, it);
-    if (ws_eligible(a, ks, stride, sizeof(T) == 2, tr) && wide_ci3x3(a.Cin, a.CoutUse, ks))
+    if (ws_eligible(a, ks, stride, sizeof(T) == 2, tr) && wide_ci3x3(a.Cin, a.CoutUse, ks)) {
+        if (g_wsb.on && a.dil == 1 && !a.direct) return ws_batch_add(a, st);
         return a.dil == 2 ? launch_ws<2>(a, st) : launch_ws<1>(a, st);
+    }
     if (ks == 3 && stride == 1 && a.dil == 2) return launch<T, 3, 1, 32, 2>(a, tr, st);
     if (ks == 3 && stride == 1) return launch<T, 3, 1, 32>(a, tr, st);
     if (ks == 3 && stride == 2) return launch<T, 3, 2, 32>(a, tr, st);
@@ -910,8 +991,11 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
     a.npix = npix_valid > 0 ? npix_valid : OH * OW;
     a.in_npix = npix_valid > 0 ? npix_valid : H * W;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool batching = g_wsb.on;
+    if (!defer) g_wsb.on = false;           // this call reduces right after its launch: never recorded into a batch
     int rc = dtype == DH_DTYPE_BF16 ? launch_all<bf16>(a, ks, stride, use_tr != 0, st)
                                     : launch_all<float>(a, ks, stride, false, st);
+    g_wsb.on = batching;
     if (rc) return rc;
     if (splitk_out) *splitk_out = a.direct ? 0 : a.splitk;
     if (a.direct || defer) return 0;
@@ -922,6 +1006,19 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
                        taps, Cout, oreal, Cin, dw_oihw, accumulate);
     DH_CHECK_LAUNCH("wgrad_reduce");
     return 0;
+}
+
+// Batched weight gradients (one backward pass = one launch for the wave-specialised 3x3 layers).  Between _begin and _end,
+// dh_conv2d_wgrad_partial / dh_conv2d_wgrad_bn_in calls (deferred form: splitk_out given) for eligible layers only RECORD
+// their launch; dh_wgrad_batch_launch issues everything recorded so far (their x / dy / workspace must be alive and unchanged
+// until then), dh_wgrad_batch_pending tells how many layers wait.  Thread-local state; a 17th layer launches the first 16.
+extern "C" int dh_wgrad_batch_begin() { g_wsb.on = true; g_wsb.n = 0; g_wsb.lds = 0; return 0; }
+extern "C" int dh_wgrad_batch_pending() { return g_wsb.n; }
+extern "C" int dh_wgrad_batch_launch(void* stream) { return ws_batch_flush(reinterpret_cast<hipStream_t>(stream)); }
+extern "C" int dh_wgrad_batch_end(void* stream) {
+    const int rc = ws_batch_flush(reinterpret_cast<hipStream_t>(stream));
+    g_wsb.on = false;
+    return rc;
 }
 
 extern "C" int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N,

@@ -734,7 +734,7 @@ class Engine:
         if plan is not None:       # a no-grad forward in between switched self.pk to the forward-only packed weights
             self.pk, self.xstack = plan[1], plan[2]
         if self._wgrad_plan is None:
-            self._wgrad_plan = ops.WgradPlan(dlogits_nchw.device)
+            self._wgrad_plan = ops.WgradPlan(dlogits_nchw.device, batch=True)
         with self._wgrad_plan as plan:      # the conv layers' split-K reduces: one launch at the end of the pass
             bwd(dlogits_nchw)
             self._side_join()
@@ -751,7 +751,7 @@ class Engine:
         if plan is not None:
             self.pk, self.xstack = plan[1], plan[2]
         if self._wgrad_plan is None:
-            self._wgrad_plan = ops.WgradPlan(dlogits_nchw.device)
+            self._wgrad_plan = ops.WgradPlan(dlogits_nchw.device, batch=True)
         self._wgrad_plan.__enter__()
         try:
             self._split_state = (split[1], split[0](dlogits_nchw))

@@ -173,11 +173,17 @@ class WgradPlan:
                     ("Oslab", ctypes.c_int), ("O", ctypes.c_int), ("I", ctypes.c_int), ("accumulate", ctypes.c_int),
                     ("first_block", ctypes.c_int), ("nblocks", ctypes.c_int)]
 
-    def __init__(self, device):
+    def __init__(self, device, batch=False):
+        """batch: the wave-specialised 3x3 weight gradients of the pass are RECORDED by conv2d_wgrad and issued as one launch by
+        run() (dh_wgrad_batch_*: fewer, longer K slices per layer, a quarter of the partial-slab traffic); their x / dy are
+        kept alive until then.  Off under ops.PROFILE (the per-launch events need one launch per layer) and with
+        DAHITRA_WGRAD_BATCH=0."""
         self.device, self.slots, self.cur, self.blocks = device, [], 0, 0
         self.tables, self.sigs, self.phase = {}, {}, 0      # one job table per run() of a pass (a split backward runs twice)
         self._prev = None
         self.post = []
+        self.batch = batch and os.environ.get("DAHITRA_WGRAD_BATCH", "1") != "0"
+        self.batching, self.keep = False, []
 
     def __enter__(self):
         global _WGRAD_PLAN
@@ -187,12 +193,29 @@ class WgradPlan:
         self.post = []
         self.blocks = 0
         self.phase = 0
+        self.keep = []
+        self.batching = self.batch and PROFILE is None
+        if self.batching:
+            _call("dh_wgrad_batch_begin")
         return self
 
     def __exit__(self, *exc):
         global _WGRAD_PLAN
         _WGRAD_PLAN = self._prev
+        if self.batching:
+            self.batching = False
+            if exc and exc[0] is not None:
+                _lib.lib().dh_wgrad_batch_begin()      # drop what an aborted pass recorded ...
+                _lib.lib().dh_wgrad_batch_end(None)    # ... (nothing pending: no launch) and close the batch
+            else:
+                _call("dh_wgrad_batch_end", S())
+            self.keep = []
         return False
+
+    def hold(self, *tensors):
+        """operands of a recorded (not yet issued) weight-gradient launch"""
+        if self.batching:
+            self.keep += [t for t in tensors if t is not None]
 
     def slab(self, nbytes):
         """persistent workspace of the cur-th deferred layer of the pass"""
@@ -214,6 +237,9 @@ class WgradPlan:
 
     def run(self):
         """reduce every layer deferred since the last run() of this pass (a split backward calls it once per part)"""
+        if self.batching:
+            _call("dh_wgrad_batch_launch", S())      # the recorded weight gradients, one launch
+            self.keep = []
         if self.jobs:
             self._run_reduce()
         for fn in self.post:          # launches that consume reduced gradients (phase-gradient combine)
@@ -444,6 +470,7 @@ def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=
             _call("dh_conv2d_wgrad_partial", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W),
                   _ci(Cin), _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(1), _ci(0), _ci(int(use_tr)),
                   _ci(cout_real), _ci(pitch), _ci(dilation), P(ws), ctypes.byref(sk), S())
+        plan.hold(x, dy)
         if sk.value > 0:
             plan.add(ws, dw, sk.value, ks * ks, Cout, cout_real if cout_real else Cout, Cin, accumulate)
         return
@@ -466,6 +493,8 @@ def _conv2d_wgrad_bn_in(b, dy, dw, ks, stride, pad, accumulate, use_tr, cout_rea
         _call("dh_conv2d_wgrad_bn_in", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W), _ci(Cin),
               _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(int(use_tr)), _ci(cout_real), _ci(dilation),
               P(b.scale), P(b.shift), _ci(b.groups), P(ws), ctypes.byref(sk) if plan is not None else None, S())
+    if plan is not None:
+        plan.hold(x, dy, b.scale, b.shift)
     if plan is not None and sk.value > 0:
         plan.add(ws, dw, sk.value, ks * ks, Cout, cout_real if cout_real else Cout, Cin, accumulate)
 

@@ -117,6 +117,18 @@ int dh_conv2d_wgrad_bn_in(int dtype, const void* x, const void* dy, float* dw_oi
                           int Cin, int OH, int OW, int Cout, int ks, int stride, int pad, int use_tr, int Cout_real,
                           int dilation, const float* in_scale, const float* in_shift, int in_groups, void* workspace,
                           int* splitk_out, void* stream);
+/* Batched weight gradients: the wave-specialised 3x3 layers (bf16, stride 1, Cin and Cout multiples of 64) of one backward
+ * pass as ONE launch.  Between dh_wgrad_batch_begin() and dh_wgrad_batch_end(), dh_conv2d_wgrad_partial /
+ * dh_conv2d_wgrad_bn_in (with splitk_out) only RECORD an eligible layer -- *splitk_out is its in-batch slice count, smaller
+ * than a launch of its own would take -- and every other layer launches as before; dh_wgrad_batch_launch(stream) issues what
+ * has been recorded (x / dy / scale / shift / workspace must stay alive and unchanged until then; a 17th layer issues the
+ * first 16), dh_wgrad_batch_pending() counts the recorded layers.  The reduce (dh_wgrad_reduce_multi) follows as before.
+ * The state is per host thread.  Replaces nothing in the reference (autograd computes each layer's gradient on its own):
+ * it exists because a launch per layer needs 256 workgroups each to fill the chip. */
+int dh_wgrad_batch_begin(void);
+int dh_wgrad_batch_pending(void);
+int dh_wgrad_batch_launch(void* stream);
+int dh_wgrad_batch_end(void* stream);
 int dh_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 /* ---- the 2x2 phase form of conv3x3(nearest-upsample-x2(x)) with 32 output channels (dh_conv2d_fwd's phase_mode) ----
  * dh_pack_phase_weights: OIHW fp32 [32][Cin][3][3] (+ bias [32]) -> fwd [4 taps][4 * 32][Cin] T, data-gradient form
