@@ -819,12 +819,16 @@ struct WsBatch {
     WsMulti m;
 };
 static thread_local WsBatch g_wsb;
-// K slices of a layer inside a batch: ~tiles_per_wg pixel tiles per workgroup (DAHITRA_WGRAD_TPW, default 32), never more
-// slices than the layer's own launch would take, a multiple of 8 from 8 on (XCD-aware order)
+// K slices of a layer inside a batch: ~32 pixel tiles per workgroup (DAHITRA_WGRAD_TPW), 64 for the layers of >= 16 blocks
+// (DAHITRA_WGRAD_TPW_BIG: they come first in a backward pass, the shorter workgroups of the later layers fill the tail; measured
+// 32 / 32: 9017 + 5620 pairs/s (s4 + newUNetTrans), 32 / 64: 9085 + 5621, 32 / 128: 9117 + 5565, 64 / 64: 9018 + 5553, 16 / 16:
+// 8923), never more slices than the layer's own launch would take, a multiple of 8 from 8 on (XCD-aware order)
 static int ws_batch_splitk(const WgArgs& a) {
     static const int tpw = getenv("DAHITRA_WGRAD_TPW") ? atoi(getenv("DAHITRA_WGRAD_TPW")) : 32;
+    static const int tpw_big = getenv("DAHITRA_WGRAD_TPW_BIG") ? atoi(getenv("DAHITRA_WGRAD_TPW_BIG")) : 2 * tpw;
     const long tiles = (long)a.N * a.tilesX * a.tilesY;
-    long sk = tiles / (tpw > 0 ? tpw : 32);
+    const int t = (a.Cout / 64) * a.ci_tiles >= 16 ? tpw_big : tpw;
+    long sk = tiles / (t > 0 ? t : 32);
     if (sk > a.splitk) sk = a.splitk;
     if (sk >= 8) sk &= ~7L;
     return (int)(sk < 1 ? 1 : sk);
