@@ -61,8 +61,10 @@ union F8 {
 // waves takes the NEXT 32 input channels of the same pixels -- a 64co x 64ci slab per workgroup.  The dY tile is staged
 // once for both halves, and a layer writes (and dh_wgrad_reduce reads) half as many partial slabs at the same number of
 // resident waves: the split-K slab traffic of the bench step was ~500 MB written + ~500 MB read per step.
-template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT, int CIG, bool DYT = false>
-__global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
+// (the body: workgroup (bx, kz, bz) of an nbx x nkz x . grid; conv_wgrad_kernel / conv_wgrad_multi_kernel below are the entry points)
+template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT, int CIG, bool DYT>
+__device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const int nbx, const int nkz, const int bz,
+                                        unsigned char* smem) {
     constexpr int CT = CTT;
     constexpr int NTHR = 256 * CIG;
     constexpr int ITT = IT * CIG;                  // input channels per workgroup
@@ -79,7 +81,6 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     // pixel rows x 32 B = 8 distinct bank windows of the 256-byte bank row (conflict-free)
     constexpr int XP = lds_pitch(ITT * (int)sizeof(T));    // halo pitch (bytes)
     constexpr int DP = lds_pitch(CT * (int)sizeof(T));     // dY tile pitch (bytes)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // (Two staging buffers -- commit of tile t+1 right after the MFMAs of tile t, one barrier per tile -- were measured and
     // change nothing: layer3 90.3 vs 89.5 us, and the 256-thread forms lose a resident workgroup to the second buffer.)
     unsigned char* halo = smem;                      // [HH*HWD][XP]
@@ -91,16 +92,15 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
     const int cw = wv % CW, kq = wv / CW;
     // Workgroups are dispatched x-fastest, round-robin over the 8 XCDs (one L2 each).  Remapped so that all (co, ci) tile
     // pairs of one pixel split kz -- they read the SAME x / dY tiles -- run back to back on ONE XCD (its L2 serves the re-reads).
-    int bx = blockIdx.x, kz = blockIdx.y;
-    if (gridDim.x > 1 && (gridDim.y & 7) == 0 && !p.no_xcd_remap) {
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, sq = lin >> 3;
-        bx = (int)(sq % gridDim.x);
-        kz = (int)((sq / gridDim.x) * 8 + xcd);
+    if (nbx > 1 && (nkz & 7) == 0 && !p.no_xcd_remap) {
+        const unsigned lin = (unsigned)(kz * nbx + bx), xcd = lin & 7, sq = lin >> 3;
+        bx = (int)(sq % nbx);
+        kz = (int)((sq / nbx) * 8 + xcd);
     }
     const int cot = bx / p.ci_tiles, cit = bx % p.ci_tiles;
     const int co0 = cot * CT, ci0 = cit * ITT;
-    const int grp = blockIdx.z;
-    const int ph_a = (KS == 2 && p.phase_mode) ? (int)(blockIdx.z >> 1) : 0, ph_b = (KS == 2 && p.phase_mode) ? (int)(blockIdx.z & 1) : 0;
+    const int grp = bz;
+    const int ph_a = (KS == 2 && p.phase_mode) ? (bz >> 1) : 0, ph_b = (KS == 2 && p.phase_mode) ? (bz & 1) : 0;
     const int imgs_per_group = p.N / p.groups;
     const int tiles_per_img = p.tilesX * p.tilesY;
     const int ntiles = imgs_per_group * tiles_per_img;
@@ -464,6 +464,29 @@ __global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
                     if (okij[i][j]) out[t * tstride + j * p.Cin + i * istep] = acc[t][i][j];
     }
 }
+template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT, int CIG, bool DYT = false>
+__global__ __launch_bounds__(256 * CIG) void conv_wgrad_kernel(WgArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    wg_body<T, KS, STRIDE, IT, TR, DIL, CTT, CIG, DYT>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, blockIdx.z, smem);
+}
+// several layers of ONE instantiation in one launch (see conv_wgrad_ws_multi_kernel, whose argument block this shares)
+constexpr int WS_MAXJ = 16;
+struct WsMulti {
+    int njobs;
+    int first[WS_MAXJ + 1];       // multiples of 8 (the XCD-aware order inside a layer relies on it)
+    WgArgs a[WS_MAXJ];
+};
+static_assert(sizeof(WsMulti) <= 4096, "the kernel argument block");
+template <typename T, int KS, int STRIDE, int IT, bool TR, int DIL, int CTT, int CIG>
+__global__ __launch_bounds__(256 * CIG) void conv_wgrad_multi_kernel(WsMulti m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int j = 0;
+    while (j + 1 < m.njobs && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    const WgArgs p = m.a[j];
+    const int nbx = ((p.CoutUse + CTT - 1) / CTT) * p.ci_tiles, local = (int)blockIdx.x - m.first[j];
+    if (local >= nbx * p.splitk) return;              // padding up to the next multiple of 8
+    wg_body<T, KS, STRIDE, IT, TR, DIL, CTT, CIG, false>(p, local % nbx, local / nbx, nbx, p.splitk, 0, smem);
+}
 
 // dw_oihw[g][o][i][tap] (+)= sum_kz part[g][kz][tap][o][i].  A workgroup = 8 split-K phases x 32 lanes; a lane owns FOUR
 // consecutive slab elements (one 16-byte load per slab; Cin % 4 == 0) or one (ragged Cin), i.e. 128 / 32 outputs per
@@ -765,13 +788,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgArgs p) {
 // pass and the capture), workgroups [first[j], first[j + 1]) serve layer j.  One launch per backward pass instead of one per
 // layer lets every layer take FEWER, LONGER K slices (a launch of its own needs 256 workgroups to fill the chip: 8 pixel tiles
 // per workgroup on the 64-channel layers, and a 147 KB partial slab each) -- the chip is filled by the sum of the layers.
-constexpr int WS_MAXJ = 16;
-struct WsMulti {
-    int njobs;
-    int first[WS_MAXJ + 1];       // multiples of 8 (the XCD-aware order inside a layer relies on it)
-    WgArgs a[WS_MAXJ];
-};
-static_assert(sizeof(WsMulti) <= 4096, "the kernel argument block");
 __global__ __launch_bounds__(512) void conv_wgrad_ws_multi_kernel(WsMulti m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int j = 0;
@@ -818,7 +834,8 @@ struct WsBatch {
     size_t lds = 0;
     WsMulti m;
 };
-static thread_local WsBatch g_wsb;
+static thread_local WsBatch g_wsb;       // wave-specialised 64co x 64ci layers (`on` = a batch is open, for both)
+static thread_local WsBatch g_c32b;      // 3x3 stride-1 bf16 layers with a 32-wide co tile (conv_wgrad_kernel<bf16, 3, 1, 32, true, 1, 32, 1>)
 // K slices of a layer inside a batch: ~32 pixel tiles per workgroup (DAHITRA_WGRAD_TPW), 64 for the layers of >= 16 blocks
 // (DAHITRA_WGRAD_TPW_BIG: they come first in a backward pass, the shorter workgroups of the later layers fill the tail; measured
 // 32 / 32: 9017 + 5620 pairs/s (s4 + newUNetTrans), 32 / 64: 9085 + 5621, 32 / 128: 9117 + 5565, 64 / 64: 9018 + 5553, 16 / 16:
@@ -864,6 +881,56 @@ static int ws_batch_add(WgArgs& a, hipStream_t st) {
     constexpr int HH = (TH - 1) + 2 + 1, HWD = (TW - 1) + 2 + 1;
     const size_t lds = 2 * ((size_t)HH * HWD * lds_pitch(128) + (size_t)TH * TW * lds_pitch(128)) +
                        (a.in_scale ? (size_t)a.in_groups * 128 * sizeof(float) : 0);
+    if (lds > b.lds) b.lds = lds;
+    ++b.n;
+    return 0;
+}
+
+static inline bool c32_batch_on() { static const bool off = getenv("DAHITRA_WGRAD_BATCH32") && atoi(getenv("DAHITRA_WGRAD_BATCH32")) == 0; return !off; }
+// the second family a batch takes: the 32-channel 3x3 layers (DAHiTra's top-down path: seven launches of ~32 us per step)
+static inline bool c32_eligible(const WgArgs& a, int ks, int stride, bool bf16, bool tr) {
+    return bf16 && tr && ks == 3 && stride == 1 && a.dil == 1 && a.groups == 1 && !a.phase_mode && !a.dyt_y && !a.direct &&
+           co_tile(a.CoutUse) == 32 && a.npix == a.OH * a.OW && a.in_npix == a.H * a.W;
+}
+static size_t c32_lds(const WgArgs& a) {
+    constexpr int HH = (TH - 1) + 2 + 1, HWD = (TW - 1) + 2 + 1;
+    size_t lds = (size_t)HH * HWD * lds_pitch(32 * 2) + (size_t)TH * TW * lds_pitch(32 * 2) +
+                 (a.in_scale ? (size_t)a.in_groups * 2 * 32 * sizeof(float) : 0);
+    const size_t red = (size_t)(32 / 16) * 9 * (32 / 16) * 64 * 16;      // the end-of-kernel wave-group combine (launch_ct)
+    return lds < red ? red : lds;
+}
+static int c32_batch_flush(hipStream_t st) {
+    WsBatch& b = g_c32b;
+    if (b.n == 0) return 0;
+    b.m.njobs = b.n;
+    const int total = b.m.first[b.n];
+    auto kern = conv_wgrad_multi_kernel<bf16, 3, 1, 32, true, 1, 32, 1>;
+    static size_t attr_lds = 64 * 1024;
+    if (b.lds > attr_lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.lds) != hipSuccess) {
+            (void)hipGetLastError();
+            DH_FAIL("conv_wgrad_multi: cannot raise dynamic LDS to %zu", b.lds);
+        }
+        attr_lds = b.lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(total), dim3(256), b.lds, st, b.m);
+    b.n = 0; b.lds = 0;
+    DH_CHECK_LAUNCH("conv_wgrad_multi");
+    return 0;
+}
+static int c32_batch_add(WgArgs& a, hipStream_t st) {
+    WsBatch& b = g_c32b;
+    if (b.n == WS_MAXJ) { const int rc = c32_batch_flush(st); if (rc) return rc; }
+    static const int tpw = getenv("DAHITRA_WGRAD_TPW32") ? atoi(getenv("DAHITRA_WGRAD_TPW32")) : 32;
+    long sk = ((long)a.N * a.tilesX * a.tilesY) / (tpw > 0 ? tpw : 32);
+    if (sk > a.splitk) sk = a.splitk;
+    if (sk >= 8) sk &= ~7L;
+    a.splitk = (int)(sk < 1 ? 1 : sk);
+    if (b.n == 0) b.m.first[0] = 0;
+    const int nblocks = dh_cdiv(a.CoutUse, 32) * a.ci_tiles * a.splitk;
+    b.m.a[b.n] = a;
+    b.m.first[b.n + 1] = b.m.first[b.n] + ((nblocks + 7) & ~7);
+    const size_t lds = c32_lds(a);
     if (lds > b.lds) b.lds = lds;
     ++b.n;
     return 0;
@@ -930,6 +997,7 @@ int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
         return a.dil == 2 ? launch_ws<2>(a, st) : launch_ws<1>(a, st);
     }
     if (ks == 3 && stride == 1 && a.dil == 2) return launch<T, 3, 1, 32, 2>(a, tr, st);
+    if (g_wsb.on && c32_batch_on() && c32_eligible(a, ks, stride, sizeof(T) == 2, tr)) return c32_batch_add(a, st);
     if (ks == 3 && stride == 1) return launch<T, 3, 1, 32>(a, tr, st);
     if (ks == 3 && stride == 2) return launch<T, 3, 2, 32>(a, tr, st);
     if (ks == 1 && stride == 1) return wide ? launch<T, 1, 1, 64>(a, tr, st) : launch<T, 1, 1, 32>(a, tr, st);
@@ -1016,11 +1084,14 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
 // dh_conv2d_wgrad_partial / dh_conv2d_wgrad_bn_in calls (deferred form: splitk_out given) for eligible layers only RECORD
 // their launch; dh_wgrad_batch_launch issues everything recorded so far (their x / dy / workspace must be alive and unchanged
 // until then), dh_wgrad_batch_pending tells how many layers wait.  Thread-local state; a 17th layer launches the first 16.
-extern "C" int dh_wgrad_batch_begin() { g_wsb.on = true; g_wsb.n = 0; g_wsb.lds = 0; return 0; }
-extern "C" int dh_wgrad_batch_pending() { return g_wsb.n; }
-extern "C" int dh_wgrad_batch_launch(void* stream) { return ws_batch_flush(reinterpret_cast<hipStream_t>(stream)); }
-extern "C" int dh_wgrad_batch_end(void* stream) {
+extern "C" int dh_wgrad_batch_begin() { g_wsb.on = true; g_wsb.n = 0; g_wsb.lds = 0; g_c32b.n = 0; g_c32b.lds = 0; return 0; }
+extern "C" int dh_wgrad_batch_pending() { return g_wsb.n + g_c32b.n; }
+extern "C" int dh_wgrad_batch_launch(void* stream) {
     const int rc = ws_batch_flush(reinterpret_cast<hipStream_t>(stream));
+    return rc ? rc : c32_batch_flush(reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int dh_wgrad_batch_end(void* stream) {
+    const int rc = dh_wgrad_batch_launch(stream);
     g_wsb.on = false;
     return rc;
 }

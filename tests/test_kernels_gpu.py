@@ -784,13 +784,15 @@ def test_batchnorm_relu_on_load_equals_materialised_activation(ops, dtype, cfg):
 def test_weight_gradients_of_a_pass_in_one_launch(ops):
     """dh_wgrad_batch_*: the wave-specialised 3x3 weight gradients of a backward pass recorded and issued as ONE launch (fewer,
     longer K slices per layer) against the same layers launched one by one: same products, another split of the pixel sum.
-    Covers a BatchNorm-on-load input, a ragged image size, accumulate into an existing gradient, a layer the batch does not
-    take (32 channels), and the pass repeated on the same plan (the recorded graph does exactly that)."""
+    Covers both batched families (64-wide wave-specialised blocks, 32-channel layers), a BatchNorm-on-load input, a ragged
+    image size, accumulate into an existing gradient, a layer the batch does not take (16 output channels), and the pass
+    repeated on the same plan (the recorded graph does exactly that)."""
     from dahitra_amd import _lib
     dtype = torch.bfloat16
     layers = [dict(n=64, c=64, o=64, h=64, w=64, bn=False), dict(n=64, c=128, o=128, h=32, w=32, bn=True),
               dict(n=16, c=256, o=256, h=32, w=32, bn=False), dict(n=6, c=64, o=128, h=24, w=40, bn=True),
-              dict(n=8, c=32, o=32, h=32, w=32, bn=False)]
+              dict(n=8, c=32, o=32, h=32, w=32, bn=False), dict(n=32, c=64, o=32, h=64, w=64, bn=True),
+              dict(n=4, c=32, o=16, h=32, w=32, bn=False)]
     xs, dys = [], []
     for i, L in enumerate(layers):
         x = dev(rnd((L["n"], L["h"], L["w"], L["c"]), dtype, 1200 + i, 1.0), dtype)
@@ -809,7 +811,7 @@ def test_weight_gradients_of_a_pass_in_one_launch(ops):
                 for x, dy, dw in zip(xs, dys, dws):
                     ops.conv2d_wgrad(x, dy, dw, 3, 1, 1, accumulate=True)
                 if rep == 0:
-                    assert _lib.lib().dh_wgrad_batch_pending() == (4 if batch else 0)
+                    assert _lib.lib().dh_wgrad_batch_pending() == (6 if batch else 0)
                 plan.run()
                 assert _lib.lib().dh_wgrad_batch_pending() == 0
             torch.cuda.synchronize()
@@ -819,7 +821,7 @@ def test_weight_gradients_of_a_pass_in_one_launch(ops):
     for i, (a, b) in enumerate(zip(out[False], out[True])):
         s = float((a - 0.25).abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * s + 1e-6, (i, float((a - b).abs().max()), s)
-    assert torch.equal(out[False][4], out[True][4])          # the 32-channel layer never entered the batch
+    assert torch.equal(out[False][6], out[True][6])          # the 16-channel layer never entered a batch
 
 
 @pytest.mark.parametrize("cfg", [
