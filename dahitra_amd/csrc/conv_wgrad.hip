@@ -1086,6 +1086,8 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
 // until then), dh_wgrad_batch_pending tells how many layers wait.  Thread-local state; a 17th layer launches the first 16.
 extern "C" int dh_wgrad_batch_begin() { g_wsb.on = true; g_wsb.n = 0; g_wsb.lds = 0; g_c32b.n = 0; g_c32b.lds = 0; return 0; }
 extern "C" int dh_wgrad_batch_pending() { return g_wsb.n + g_c32b.n; }
+// closes the batch WITHOUT launching what it recorded (an aborted pass: the recorded operands may be gone)
+extern "C" int dh_wgrad_batch_abort() { g_wsb.on = false; g_wsb.n = 0; g_wsb.lds = 0; g_c32b.n = 0; g_c32b.lds = 0; return 0; }
 extern "C" int dh_wgrad_batch_launch(void* stream) {
     const int rc = ws_batch_flush(reinterpret_cast<hipStream_t>(stream));
     return rc ? rc : c32_batch_flush(reinterpret_cast<hipStream_t>(stream));

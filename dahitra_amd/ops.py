@@ -197,6 +197,8 @@ class WgradPlan:
         self.batching = self.batch and PROFILE is None
         if self.batching:
             _call("dh_wgrad_batch_begin")
+        elif self._prev is None:
+            _call("dh_wgrad_batch_abort")       # a pass that never finished must not leave its batch open behind it
         return self
 
     def __exit__(self, *exc):
@@ -205,8 +207,7 @@ class WgradPlan:
         if self.batching:
             self.batching = False
             if exc and exc[0] is not None:
-                _lib.lib().dh_wgrad_batch_begin()      # drop what an aborted pass recorded ...
-                _lib.lib().dh_wgrad_batch_end(None)    # ... (nothing pending: no launch) and close the batch
+                _lib.lib().dh_wgrad_batch_abort()      # drop what an aborted pass recorded
             else:
                 _call("dh_wgrad_batch_end", S())
             self.keep = []

@@ -129,6 +129,7 @@ int dh_wgrad_batch_begin(void);
 int dh_wgrad_batch_pending(void);
 int dh_wgrad_batch_launch(void* stream);
 int dh_wgrad_batch_end(void* stream);
+int dh_wgrad_batch_abort(void);        /* closes the batch without launching (an aborted pass) */
 int dh_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 /* ---- the 2x2 phase form of conv3x3(nearest-upsample-x2(x)) with 32 output channels (dh_conv2d_fwd's phase_mode) ----
  * dh_pack_phase_weights: OIHW fp32 [32][Cin][3][3] (+ bias [32]) -> fwd [4 taps][4 * 32][Cin] T, data-gradient form

@@ -822,6 +822,14 @@ def test_weight_gradients_of_a_pass_in_one_launch(ops):
         s = float((a - 0.25).abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * s + 1e-6, (i, float((a - b).abs().max()), s)
     assert torch.equal(out[False][6], out[True][6])          # the 16-channel layer never entered a batch
+    # a batch left open by a pass that never finished must not swallow the launches of the next (plain) plan
+    _lib.lib().dh_wgrad_batch_begin()
+    dw = torch.full((64, 64, 3, 3), 0.25, device="cuda")
+    with ops.WgradPlan("cuda") as plan:
+        ops.conv2d_wgrad(xs[0], dys[0], dw, 3, 1, 1, accumulate=True)
+        assert _lib.lib().dh_wgrad_batch_pending() == 0
+        plan.run()
+    assert torch.equal(dw, out[False][0])
 
 
 @pytest.mark.parametrize("cfg", [
