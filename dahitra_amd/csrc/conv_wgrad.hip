@@ -850,10 +850,23 @@ static int ws_batch_splitk(const WgArgs& a) {
     if (sk >= 8) sk &= ~7L;
     return (int)(sk < 1 ? 1 : sk);
 }
+// longest workgroups first (the dispatcher hands out workgroups in index order: the short ones then fill the tail of the launch)
+static void batch_sort(WsBatch& b, int co_tile_) {
+    if (getenv("DAHITRA_WGRAD_NO_SORT")) return;
+    auto tpw = [](const WgArgs& a) { return ((long)a.N * a.tilesX * a.tilesY + a.splitk - 1) / a.splitk; };
+    for (int i = 1; i < b.n; ++i)                  // insertion sort, stable: at most 16 entries
+        for (int j = i; j > 0 && tpw(b.m.a[j]) > tpw(b.m.a[j - 1]); --j) { const WgArgs t = b.m.a[j]; b.m.a[j] = b.m.a[j - 1]; b.m.a[j - 1] = t; }
+    b.m.first[0] = 0;
+    for (int i = 0; i < b.n; ++i) {
+        const int nblocks = dh_cdiv(b.m.a[i].CoutUse, co_tile_) * b.m.a[i].ci_tiles * b.m.a[i].splitk;
+        b.m.first[i + 1] = b.m.first[i] + ((nblocks + 7) & ~7);
+    }
+}
 static int ws_batch_flush(hipStream_t st) {
     WsBatch& b = g_wsb;
     if (b.n == 0) return 0;
     b.m.njobs = b.n;
+    batch_sort(b, 64);
     const int total = b.m.first[b.n];
     static size_t attr_lds = 0;
     if (b.lds > attr_lds) {
@@ -903,6 +916,7 @@ static int c32_batch_flush(hipStream_t st) {
     WsBatch& b = g_c32b;
     if (b.n == 0) return 0;
     b.m.njobs = b.n;
+    batch_sort(b, 32);
     const int total = b.m.first[b.n];
     auto kern = conv_wgrad_multi_kernel<bf16, 3, 1, 32, true, 1, 32, 1>;
     static size_t attr_lds = 64 * 1024;
