@@ -837,40 +837,42 @@ struct PackJob {
 template <typename T>
 __device__ __forceinline__ void pack_job(const PackJob& j, int lb) {
     const int taps = j.KS * j.KS;
-    const long step = (long)j.nblocks * blockDim.x;
+    // 32-bit index arithmetic: a layer's packed forms hold < 2^31 elements (ops.PackPlan.add refuses anything
+    // larger; 3x3 x 2048 x 2048 is 3.8e7), and 64-bit divisions by run-time values cost ~100 instructions each
+    const unsigned step = (unsigned)j.nblocks * blockDim.x;
     T* fwd = reinterpret_cast<T*>(j.fwd);
     T* dgrad = reinterpret_cast<T*>(j.dgrad);
     if (j.dtype & 0x200) {
         const int nch_f = j.I / 32, nch_d = j.OK / 32;
         if (fwd)
-            for (long i = (long)lb * blockDim.x + threadIdx.x; i < (long)taps * j.OPad * j.I; i += step) {
-                const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), tap = (int)((i >> 9) % taps);
-                const int c = (int)((i / (512L * taps)) % nch_f), r16 = (int)(i / (512L * taps * nch_f));
+            for (unsigned i = (unsigned)lb * blockDim.x + threadIdx.x; i < (unsigned)(taps * j.OPad * j.I); i += step) {
+                const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), tap = (int)((i >> 9) % (unsigned)taps);
+                const int c = (int)((i / (512u * (unsigned)taps)) % (unsigned)nch_f), r16 = (int)(i / (512u * (unsigned)taps * (unsigned)nch_f));
                 const int o = r16 * 16 + (lane & 15), ci = c * 32 + (lane >> 4) * 8 + e;
-                stf(fwd + i, o < j.O ? j.w[((long)o * j.I + ci) * taps + tap] : 0.f);
+                stf(fwd + i, o < j.O ? j.w[(unsigned)((o * j.I + ci) * taps + tap)] : 0.f);
             }
         if (dgrad)
-            for (long i = (long)lb * blockDim.x + threadIdx.x; i < (long)taps * j.IPad * j.OK; i += step) {
-                const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), tap = (int)((i >> 9) % taps);
-                const int c = (int)((i / (512L * taps)) % nch_d), r16 = (int)(i / (512L * taps * nch_d));
+            for (unsigned i = (unsigned)lb * blockDim.x + threadIdx.x; i < (unsigned)(taps * j.IPad * j.OK); i += step) {
+                const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), tap = (int)((i >> 9) % (unsigned)taps);
+                const int c = (int)((i / (512u * (unsigned)taps)) % (unsigned)nch_d), r16 = (int)(i / (512u * (unsigned)taps * (unsigned)nch_d));
                 const int ci = r16 * 16 + (lane & 15), o = c * 32 + (lane >> 4) * 8 + e;
-                stf(dgrad + i, (ci < j.I && o < j.O) ? j.w[((long)o * j.I + ci) * taps + (taps - 1 - tap)] : 0.f);
+                stf(dgrad + i, (ci < j.I && o < j.O) ? j.w[(unsigned)((o * j.I + ci) * taps + (taps - 1 - tap))] : 0.f);
             }
         return;
     }
     if (fwd)
-        for (long i = (long)lb * blockDim.x + threadIdx.x; i < (long)taps * j.OPad * j.I; i += step) {
-            const int ci = (int)(i % j.I);
-            const int o = (int)((i / j.I) % j.OPad);
-            const int tap = (int)(i / ((long)j.I * j.OPad));
-            stf(fwd + i, o < j.O ? j.w[((long)o * j.I + ci) * taps + tap] : 0.f);
+        for (unsigned i = (unsigned)lb * blockDim.x + threadIdx.x; i < (unsigned)(taps * j.OPad * j.I); i += step) {
+            const int ci = (int)(i % (unsigned)j.I);
+            const int o = (int)((i / (unsigned)j.I) % (unsigned)j.OPad);
+            const int tap = (int)(i / (unsigned)(j.I * j.OPad));
+            stf(fwd + i, o < j.O ? j.w[(unsigned)((o * j.I + ci) * taps + tap)] : 0.f);
         }
     if (dgrad)
-        for (long i = (long)lb * blockDim.x + threadIdx.x; i < (long)taps * j.IPad * j.OK; i += step) {
-            const int o = (int)(i % j.OK);
-            const int ci = (int)((i / j.OK) % j.IPad);
-            const int tap = (int)(i / ((long)j.OK * j.IPad));
-            stf(dgrad + i, (ci < j.I && o < j.O) ? j.w[((long)o * j.I + ci) * taps + (taps - 1 - tap)] : 0.f);
+        for (unsigned i = (unsigned)lb * blockDim.x + threadIdx.x; i < (unsigned)(taps * j.IPad * j.OK); i += step) {
+            const int o = (int)(i % (unsigned)j.OK);
+            const int ci = (int)((i / (unsigned)j.OK) % (unsigned)j.IPad);
+            const int tap = (int)(i / (unsigned)(j.OK * j.IPad));
+            stf(dgrad + i, (ci < j.I && o < j.O) ? j.w[(unsigned)((o * j.I + ci) * taps + (taps - 1 - tap))] : 0.f);
         }
 }
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {

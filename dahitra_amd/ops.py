@@ -143,6 +143,7 @@ class PackPlan:
             dg = out_dgrad if out_dgrad is not None else \
                 (torch.empty(ks * ks, IPad, OK, dtype=dtype, device=w.device) if want_dgrad else None)
         n = max(fwd.numel() if fwd is not None else 0, dg.numel() if dg is not None else 0)
+        assert n < 2 ** 31 and w.numel() < 2 ** 31, "pack_weights_multi indexes a layer with 32-bit arithmetic"
         nb = max(1, min(256, cdiv(n, 1024)))
         self.jobs.append(self._Job(w.data_ptr(), fwd.data_ptr() if fwd is not None else None,
                                    dg.data_ptr() if dg is not None else None, O, I, ks, OPad, IPad, OK,
