@@ -868,14 +868,16 @@ static int ws_batch_flush(hipStream_t st) {
     b.m.njobs = b.n;
     batch_sort(b, 64);
     const int total = b.m.first[b.n];
-    static size_t attr_lds = 0;
-    if (b.lds > attr_lds) {
+    static bool attr_done = false;      // once, for the largest form (ws_eligible: at most 8 BatchNorm groups): never inside a capture
+    if (!attr_done) {
+        attr_done = true;
+        constexpr int HH = (TH - 1) + 2 + 1, HWD = (TW - 1) + 2 + 1;
+        const size_t max_lds = 2 * ((size_t)HH * HWD * lds_pitch(128) + (size_t)TH * TW * lds_pitch(128)) + 8 * 128 * sizeof(float);
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)b.lds + 4096) != hipSuccess) {
+                                (int)max_lds + 4096) != hipSuccess) {
             (void)hipGetLastError();
-            DH_FAIL("conv_wgrad_ws_multi: cannot raise dynamic LDS to %zu", b.lds);
+            DH_FAIL("conv_wgrad_ws_multi: cannot raise dynamic LDS to %zu", max_lds);
         }
-        attr_lds = b.lds;
     }
     hipLaunchKernelGGL(conv_wgrad_ws_multi_kernel, dim3(total), dim3(512), b.lds, st, b.m);
     b.n = 0; b.lds = 0;
