@@ -117,8 +117,8 @@ int dh_conv2d_wgrad_bn_in(int dtype, const void* x, const void* dy, float* dw_oi
                           int Cin, int OH, int OW, int Cout, int ks, int stride, int pad, int use_tr, int Cout_real,
                           int dilation, const float* in_scale, const float* in_shift, int in_groups, void* workspace,
                           int* splitk_out, void* stream);
-/* Batched weight gradients: the wave-specialised 3x3 layers (bf16, stride 1, Cin and Cout multiples of 64) of one backward
- * pass as ONE launch.  Between dh_wgrad_batch_begin() and dh_wgrad_batch_end(), dh_conv2d_wgrad_partial /
+/* Batched weight gradients: the 3x3 stride-1 bf16 layers of one backward pass as ONE launch per kernel family (the
+ * wave-specialised 64co x 64ci form: Cin and Cout multiples of 64; the 32-wide output tile: 16 < Cout <= 32).  Between dh_wgrad_batch_begin() and dh_wgrad_batch_end(), dh_conv2d_wgrad_partial /
  * dh_conv2d_wgrad_bn_in (with splitk_out) only RECORD an eligible layer -- *splitk_out is its in-batch slice count, smaller
  * than a launch of its own would take -- and every other layer launches as before; dh_wgrad_batch_launch(stream) issues what
  * has been recorded (x / dy / scale / shift / workspace must stay alive and unchanged until then; a 17th layer issues the
