@@ -245,9 +245,8 @@ __device__ __forceinline__ void layer_forward(const EncArgs& a, const Lds& l, in
     __syncthreads();
 }
 
-__global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(EncArgs a) {
-    extern __shared__ float sm[];
-    const int b = blockIdx.x, tid = threadIdx.x, n = a.n;
+__device__ __forceinline__ void enc_fwd_body(const EncArgs& a, const int b, float* sm) {
+    const int tid = threadIdx.x, n = a.n;
     const Lds l = carve(sm, n, a.heads * a.dh, a.heads, a.mlp);
     if (tid < n * D) l.x[tid] = a.x[(size_t)b * n * D + tid];
     __syncthreads();
@@ -267,11 +266,30 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(EncArgs a) {
     }
     if (tid < n * D) a.y[(size_t)b * n * D + tid] = l.x[tid];
 }
+__global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_kernel(EncArgs a) {
+    extern __shared__ float sm[];
+    enc_fwd_body(a, blockIdx.x, sm);
+}
+// Several encoder stacks in one launch (dh_encoder_batch_*): a stack occupies B workgroups of one image each -- 32 of the chip's
+// 256 CUs at the bench batch -- for 26 - 60 us of dependent-latency work; DAHiTra's three levels are independent of each other,
+// so their stacks share a launch (arguments by value, workgroups [first[j], first[j + 1]) run stack j).
+constexpr int ENC_MAXJ = 4;
+struct EncMulti {
+    int n;
+    int first[ENC_MAXJ + 1];
+    EncArgs a[ENC_MAXJ];
+};
+__global__ __launch_bounds__(ENC_THREADS) void encoder_fwd_multi_kernel(EncMulti m) {
+    extern __shared__ float sm[];
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    const EncArgs a = m.a[j];
+    enc_fwd_body(a, (int)blockIdx.x - m.first[j], sm);
+}
 
 // data gradient: per image, layers in reverse, from each layer's saved forward image
-__global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(EncArgs a) {
-    extern __shared__ float sm[];
-    const int b = blockIdx.x, tid = threadIdx.x, n = a.n, inner = a.heads * a.dh, mlp = a.mlp;
+__device__ __forceinline__ void enc_bwd_body(const EncArgs& a, const int b, float* sm) {
+    const int tid = threadIdx.x, n = a.n, inner = a.heads * a.dh, mlp = a.mlp;
     const Lds l = carve(sm, n, inner, a.heads, mlp);
     float* g = l.red + 8 * n * D;            // gradient scratch after the forward buffers
     float* dx2 = g; g += n * D;              // gradient of the layer output
@@ -420,6 +438,17 @@ __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(EncArgs a) {
     __syncthreads();
     if (tid < n * D) a.y[(size_t)b * n * D + tid] = dx2[tid];
 }
+__global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(EncArgs a) {
+    extern __shared__ float sm[];
+    enc_bwd_body(a, blockIdx.x, sm);
+}
+__global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_multi_kernel(EncMulti m) {
+    extern __shared__ float sm[];
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    const EncArgs a = m.a[j];
+    enc_bwd_body(a, (int)blockIdx.x - m.first[j], sm);
+}
 
 // every parameter gradient of the stack in one launch: blockIdx.y = layer, a workgroup = 64 outputs x 4 row groups of
 //   dWqkv[j][c] = sum_r dqkv[r][j] xn[r][c]     dWo[c][j] = sum_r dx1[r][c] o[r][j]      dbo[c] = sum_r dx1[r][c]
@@ -432,14 +461,13 @@ struct EncWgArgs {
     long pstride;
     int B, n, inner, mlp;
 };
-__global__ __launch_bounds__(256) void encoder_wgrad_kernel(EncWgArgs a) {
-    __shared__ float red[4][64];
-    const int ly = blockIdx.y, R = a.B * a.n, inner = a.inner, mlp = a.mlp;
+__device__ __forceinline__ void enc_wgrad_body(const EncWgArgs& a, const int bx, const int ly, float (*red)[64]) {
+    const int R = a.B * a.n, inner = a.inner, mlp = a.mlp;
     const long ps = (long)ly * a.pstride;
     const long nq = 3L * inner * D, no = (long)D * inner, n1 = (long)mlp * D, n2 = (long)D * mlp;
     const long total = nq + no + n1 + n2 + D + mlp + D + 4 * D;
     const int ol = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * 64 + ol;
+    const long i = (long)bx * 64 + ol;
     const float *A = nullptr, *Bm = nullptr;
     int wa = 0, wb = 0, ia = 0, ib = 0, mode = 0;      // mode 0: nothing, 1: product, 2: column sum, 3: LayerNorm partials
     float* dst = nullptr;
@@ -476,6 +504,21 @@ __global__ __launch_bounds__(256) void encoder_wgrad_kernel(EncWgArgs a) {
     __syncthreads();
     if (rg == 0 && mode != 0) *dst += red[0][ol] + red[1][ol] + red[2][ol] + red[3][ol];
 }
+__global__ __launch_bounds__(256) void encoder_wgrad_kernel(EncWgArgs a) {
+    __shared__ float red[4][64];
+    enc_wgrad_body(a, blockIdx.x, blockIdx.y, red);
+}
+struct EncWgMulti {
+    int depth[ENC_MAXJ], nbx[ENC_MAXJ];
+    EncWgArgs a[ENC_MAXJ];
+};
+__global__ __launch_bounds__(256) void encoder_wgrad_multi_kernel(EncWgMulti m) {      // blockIdx.z = stack
+    __shared__ float red[4][64];
+    const int j = blockIdx.z;
+    if ((int)blockIdx.y >= m.depth[j] || (int)blockIdx.x >= m.nbx[j]) return;      // (uniform per workgroup)
+    const EncWgArgs a = m.a[j];
+    enc_wgrad_body(a, blockIdx.x, blockIdx.y, red);
+}
 
 inline hipStream_t ST(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -490,7 +533,49 @@ int set_lds(const void* kern, size_t lds, bool& done) {
     return 0;
 }
 
+// ---- batched launches ----
+struct EncBatch {
+    bool on = false;
+    int nf = 0, nb = 0;
+    size_t flds = 0, blds = 0;
+    EncMulti f, b;
+    EncWgMulti g;
+};
+thread_local EncBatch g_eb;
+int enc_batch_flush(hipStream_t st) {
+    EncBatch& e = g_eb;
+    static bool done_f = false, done_b = false;
+    if (e.nf) {
+        e.f.n = e.nf;
+        if (set_lds(reinterpret_cast<const void*>(encoder_fwd_multi_kernel), 160 * 1024, done_f)) return 1;
+        hipLaunchKernelGGL(encoder_fwd_multi_kernel, dim3(e.f.first[e.nf]), dim3(ENC_THREADS), e.flds, st, e.f);
+        e.nf = 0; e.flds = 0;
+        DH_CHECK_LAUNCH("encoder_fwd_multi");
+    }
+    if (e.nb) {
+        e.b.n = e.nb;
+        if (set_lds(reinterpret_cast<const void*>(encoder_bwd_multi_kernel), 160 * 1024, done_b)) return 1;
+        hipLaunchKernelGGL(encoder_bwd_multi_kernel, dim3(e.b.first[e.nb]), dim3(ENC_THREADS), e.blds, st, e.b);
+        int mx = 0, my = 0;
+        for (int j = 0; j < e.nb; ++j) { if (e.g.nbx[j] > mx) mx = e.g.nbx[j]; if (e.g.depth[j] > my) my = e.g.depth[j]; }
+        hipLaunchKernelGGL(encoder_wgrad_multi_kernel, dim3(mx, my, e.nb), dim3(256), 0, st, e.g);
+        e.nb = 0; e.blds = 0;
+        DH_CHECK_LAUNCH("encoder_bwd_multi");
+    }
+    return 0;
+}
+
 }  // namespace
+
+// Batched encoder stacks: between dh_encoder_batch_begin() and _end(), dh_encoder_fwd / dh_encoder_bwd only RECORD their
+// launches (up to 4 of each direction; a fifth issues the first four); dh_encoder_batch_launch(stream) issues what has been
+// recorded as one forward launch and / or one backward + one parameter-gradient launch.  Every buffer of a recorded call
+// (including its own workspace) must stay alive and unchanged until then.  Per host thread.
+extern "C" int dh_encoder_batch_begin() { g_eb.on = true; g_eb.nf = g_eb.nb = 0; g_eb.flds = g_eb.blds = 0; return 0; }
+extern "C" int dh_encoder_batch_pending() { return g_eb.nf + g_eb.nb; }
+extern "C" int dh_encoder_batch_launch(void* stream) { return enc_batch_flush(ST(stream)); }
+extern "C" int dh_encoder_batch_end(void* stream) { const int rc = enc_batch_flush(ST(stream)); g_eb.on = false; return rc; }
+extern "C" int dh_encoder_batch_abort() { g_eb.on = false; g_eb.nf = g_eb.nb = 0; g_eb.flds = g_eb.blds = 0; return 0; }
 
 // largest inner width whose backward working set (forward buffers + gradient scratch) fits the 160 KB LDS
 extern "C" int dh_encoder_supported(int n, int heads, int dim_head, int mlp) {
@@ -516,6 +601,16 @@ extern "C" int dh_encoder_fwd(const float* x, float* y, float* saved_inputs, int
     a.ln2_g = ln2_g; a.ln2_b = ln2_b; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.pstride = param_stride;
     a.depth = depth; a.B = B; a.n = n; a.heads = heads; a.dh = dim_head; a.mlp = mlp; a.scale = scale; a.eps = eps;
     const size_t lds = fwd_lds_floats(n, heads * dim_head, heads, mlp) * 4;
+    if (g_eb.on) {
+        EncBatch& e = g_eb;
+        if (e.nf == ENC_MAXJ && enc_batch_flush(ST(stream))) return 1;
+        if (e.nf == 0) e.f.first[0] = 0;
+        e.f.a[e.nf] = a;
+        e.f.first[e.nf + 1] = e.f.first[e.nf] + B;
+        if (lds > e.flds) e.flds = lds;
+        ++e.nf;
+        return 0;
+    }
     static bool done = false;
     if (set_lds(reinterpret_cast<const void*>(encoder_fwd_kernel), lds, done)) return 1;
     hipLaunchKernelGGL(encoder_fwd_kernel, dim3(B), dim3(ENC_THREADS), lds, ST(stream), a);
@@ -566,14 +661,27 @@ extern "C" int dh_encoder_bwd(const float* dy, float* dx, const float* saved_inp
     const size_t lds = (fwd_lds_floats(n, inner, heads, mlp) + (size_t)n * D * 4 + (size_t)n * mlp + (size_t)n * inner +
                         (size_t)n * 3 * inner + (size_t)heads * n * n) * 4;
     static bool done = false;
-    if (set_lds(reinterpret_cast<const void*>(encoder_bwd_kernel), lds, done)) return 1;
-    hipLaunchKernelGGL(encoder_bwd_kernel, dim3(B), dim3(ENC_THREADS), lds, ST(stream), a);
+    if (!g_eb.on) {
+        if (set_lds(reinterpret_cast<const void*>(encoder_bwd_kernel), lds, done)) return 1;
+        hipLaunchKernelGGL(encoder_bwd_kernel, dim3(B), dim3(ENC_THREADS), lds, ST(stream), a);
+    }
     EncWgArgs g = {};
     g.r_xn = a.r_xn; g.r_dqkv = a.r_dqkv; g.r_o = a.r_o; g.r_dx1 = a.r_dx1; g.r_x1n = a.r_x1n; g.r_dz = a.r_dz;
     g.r_h = a.r_h; g.r_dx2 = a.r_dx2; g.r_ln = a.r_ln;
     g.dln1_g = dln1_g; g.dln1_b = dln1_b; g.dwqkv = dwqkv; g.dwo = dwo; g.dbo = dbo; g.dln2_g = dln2_g; g.dln2_b = dln2_b;
     g.dw1 = dw1; g.db1 = db1; g.dw2 = dw2; g.db2 = db2; g.pstride = param_stride; g.B = B; g.n = n; g.inner = inner; g.mlp = mlp;
     const long total = 3L * inner * D + (long)D * inner + 2L * mlp * D + D + mlp + D + 4 * D;
+    if (g_eb.on) {
+        EncBatch& e = g_eb;
+        if (e.nb == ENC_MAXJ && enc_batch_flush(ST(stream))) return 1;
+        if (e.nb == 0) e.b.first[0] = 0;
+        e.b.a[e.nb] = a;
+        e.b.first[e.nb + 1] = e.b.first[e.nb] + B;
+        e.g.a[e.nb] = g; e.g.depth[e.nb] = depth; e.g.nbx[e.nb] = dh_cdiv(total, 64);
+        if (lds > e.blds) e.blds = lds;
+        ++e.nb;
+        return 0;
+    }
     hipLaunchKernelGGL(encoder_wgrad_kernel, dim3(dh_cdiv(total, 64), depth), dim3(256), 0, ST(stream), g);
     DH_CHECK_LAUNCH("encoder_bwd");
     return 0;

@@ -889,8 +889,29 @@ class Engine:
         return logits, bwd
 
     # hierarchical model -------------------------------------------------------------------------
+    @staticmethod
+    def _run_staged(gens):
+        """GENERATORS that pause once, right after their token-encoder call (forward: `_level`; backward: the `bwd` it
+        returns): all of them run up to that point inside one ops.EncoderBatch -- the encoder stacks of the levels are
+        independent and occupy 2 x batch workgroups each, so they are recorded and issued as ONE launch per direction --
+        then each runs to its end.  Returns their return values."""
+        with ops.EncoderBatch() as eb:
+            for g in gens:
+                next(g)
+            eb.launch()
+        out = []
+        for g in gens:
+            try:
+                next(g)
+            except StopIteration as e:
+                out.append(e.value)
+            else:
+                raise RuntimeError("dahitra_amd: a staged level paused twice")
+        return out
+
     def _level(self, l, xa_b, B):
-        """one _forward_trans_module (networks.py:1297-1318) on the [A;B] batch of trunk taps"""
+        """one _forward_trans_module (networks.py:1297-1318) on the [A;B] batch of trunk taps.  A generator (see _run_staged):
+        pauses after the encoder call, returns (out4, bwd) where bwd(dout4) is a generator of the same kind"""
         lv, L = UNET_LEVELS[l], self.cfg["token_len"]
         S2 = 2 * B
         sq, b_sq = self.conv_act(xa_b, "conv_squeeze_%d.0.weight" % l, None, 1, 0, RELU)
@@ -900,6 +921,7 @@ class Engine:
         tok_cat, tsaved = ops.tokenizer_fwd(sq, wa, self.p["pos_embedding_%d" % l], B, L)
         tok2d, b_enc = self.encoder(tok_cat.view(B * 2 * L, DIM), "transformer_%d" % l, self.cfg["enc_depth"],
                                     lv["heads"], lv["dim_head"], B, 2 * L)
+        yield                       # tok2d is valid from here on (_run_staged)
         dtok = torch.zeros_like(tok2d) if self.need_grad else None
         pos = self.p["pos_embedding_decoder_%d" % l]
         dp = "transformer_decoder_%d" % l
@@ -935,13 +957,14 @@ class Engine:
             dxin = b_dec(ddec.view(S2 * hw, DIM)).view(S2, fh, fw, DIM)
             ops.add_pos_bwd(dxin, gpos, accumulate=True)
             dtok_cat = b_enc(dtok)
+            yield                   # dtok_cat is valid from here on (_run_staged)
             ops.tokenizer_bwd(sq, wa, tsaved, dtok_cat, dxin, self.g["conv_token_%d.weight" % l],
                               self.g["pos_embedding_%d" % l], B, L, accumulate=True)
             return b_sq(dxin)
         return out4, bwd
 
     def _xbd_level(self, l, xa_b, B):
-        """_forward_trans_module of the xBD copy (xBD_code/zoo/model_transformer_encoding.py:385-406): squeeze, tokens,
+        """(a generator like _level) _forward_trans_module of the xBD copy (xBD_code/zoo/model_transformer_encoding.py:385-406): squeeze, tokens,
         encoder, then ONE decoder pass on conv_decode(cat[x1, x2]) against |token2 - token1|.  Positional terms exist
         only in the level-5 call, which receives the *_3 embeddings (layer index 3, lines 358-383)."""
         lv, L = UNET_LEVELS[l], self.cfg["token_len"]
@@ -954,6 +977,7 @@ class Engine:
         tok_cat, tsaved = ops.tokenizer_fwd(sq, wa, pos_tok, B, L)
         tok2d, b_enc = self.encoder(tok_cat.view(B * 2 * L, DIM), "transformer_%d" % l, self.cfg["enc_depth"],
                                     lv["heads"], lv["dim_head"], B, 2 * L)
+        yield                       # tok2d is valid from here on (_run_staged)
         tk3 = tok2d.view(B, 2, L * DIM)
         dtk = torch.empty(B, L, DIM, dtype=torch.float32, device=sq.device)
         ops.absdiff_halves(tk3, dtk)
@@ -978,6 +1002,7 @@ class Engine:
             dtok = torch.zeros_like(tok2d)
             ops.absdiff_halves_bwd(tk3, ddtk, dtok)
             dtok_cat = b_enc(dtok)
+            yield                   # dtok_cat is valid from here on (_run_staged)
             dsq = torch.empty_like(sq)
             ops.copy_channels(dcat, 0, dsq[:B], 0, DIM)
             ops.copy_channels(dcat, DIM, dsq[B:], 0, DIM)
@@ -1003,11 +1028,9 @@ class Engine:
         p16, arg16 = ops.maxpool(s8, want_arg=True)
         s16, b_l3 = self.res_layer(p16, 3, 1, 2)               # 16x16x256
         level = self._xbd_level if self.cfg["kind"] == "xbd" else self._level
-        o5, b5 = level(5, s16, B)
+        (o5, b5), (t4, b4), (t3, b3) = self._run_staged([level(5, s16, B), level(4, s8, B), level(3, s4, B)])
         o5u = ops.upsample2(o5)
-        t4, b4 = level(4, s8, B)
         o4, bu4 = self._up_conv(4, ops.add(t4, o5u))
-        t3, b3 = level(3, s4, B)
         o3, bu3 = self._up_conv(3, ops.add(t3, o4))
         _, h2, w2, c2 = s2.shape
         cat2 = torch.empty(B, h2, w2, 2 * c2, dtype=self.dtype, device=s2.device)
@@ -1033,10 +1056,8 @@ class Engine:
             ops.copy_channels(dcat2, 0, ds2[:B], 0, c2)
             ops.copy_channels(dcat2, c2, ds2[B:], 0, c2)
             dsum3 = bu3(dy2)                                   # d(t3 + o4)
-            ds4 = b3(dsum3)
             dsum4 = bu4(dsum3)                                 # d(t4 + o5u)
-            ds8 = b4(dsum4)
-            ds16 = b5(ops.upsample2_bwd(dsum4))
+            ds4, ds8, ds16 = self._run_staged([b3(dsum3), b4(dsum4), b5(ops.upsample2_bwd(dsum4))])
             return ds16, ds8, ds4, ds2
 
         def bwd_second(state):

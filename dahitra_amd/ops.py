@@ -1191,16 +1191,58 @@ def encoder_fwd(tok2d, B, n, depth, heads, dim_head, mlp, pstride, params, save,
                      device=tok2d.device) if save else None          # [depth][B][forward image]
     _call("dh_encoder_fwd", P(tok2d), P(y), P(xs), _ci(B), _ci(n), _ci(depth), _ci(heads), _ci(dim_head), _ci(mlp),
           _cf(scale), _cf(eps), _cl(pstride), *(P(t) for t in params), S())
+    if _ENC_BATCH is not None:
+        _ENC_BATCH.extend((tok2d, y, xs))
     return y, xs
 
 
 def encoder_bwd(dy, xs, B, n, depth, heads, dim_head, mlp, pstride, params, grads, scale=32 ** -0.5, eps=1e-5):
     """dx of the fused encoder; `grads` (same order as params, first layer, in the gradient arena) are accumulated"""
     dx = torch.empty_like(dy)
-    ws = workspace(_lib.lib().dh_encoder_bwd_workspace_size(B, n, depth, heads, dim_head, mlp), dy.device)
+    nbytes = _lib.lib().dh_encoder_bwd_workspace_size(B, n, depth, heads, dim_head, mlp)
+    if _ENC_BATCH is not None:         # recorded, issued later with other stacks: a workspace of its own, alive until then
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dy.device)
+        _ENC_BATCH.extend((dy, dx, xs, ws))
+    else:
+        ws = workspace(nbytes, dy.device)
     _call("dh_encoder_bwd", P(dy), P(dx), P(xs), _ci(B), _ci(n), _ci(depth), _ci(heads), _ci(dim_head), _ci(mlp),
           _cf(scale), _cf(eps), _cl(pstride), *(P(t) for t in params), *(P(t) for t in grads), P(ws), S())
     return dx
+
+
+_ENC_BATCH = None        # while an EncoderBatch is open: the tensors of the recorded launches
+
+
+class EncoderBatch:
+    """`with EncoderBatch() as eb:` -- encoder_fwd / encoder_bwd calls inside only RECORD their launches (dh_encoder_batch_*);
+    eb.launch() issues them together (one workgroup per image each: stacks of independent levels share the chip).  Their
+    outputs are valid after launch().  Inert under ops.PROFILE (per-launch events) and with DAHITRA_ENC_BATCH=0."""
+
+    def __init__(self):
+        self.on = PROFILE is None and os.environ.get("DAHITRA_ENC_BATCH", "1") != "0"
+
+    def __enter__(self):
+        global _ENC_BATCH
+        if self.on:
+            assert _ENC_BATCH is None, "EncoderBatch is not re-entrant"
+            _ENC_BATCH = []
+            _call("dh_encoder_batch_begin")
+        return self
+
+    def launch(self):
+        if self.on:
+            _call("dh_encoder_batch_launch", S())
+            del _ENC_BATCH[:]
+
+    def __exit__(self, *exc):
+        global _ENC_BATCH
+        if self.on:
+            if exc and exc[0] is not None:
+                _lib.lib().dh_encoder_batch_abort()
+            else:
+                _call("dh_encoder_batch_end", S())
+            _ENC_BATCH = None
+        return False
 
 
 def softmax_groups(x2d, heads, L):

@@ -351,6 +351,18 @@ int dh_encoder_bwd(const float* dy, float* dx, const float* saved_inputs, int B,
                    const float* ln2_b, const float* w1, const float* b1, const float* w2, const float* b2,
                    float* dln1_g, float* dln1_b, float* dwqkv, float* dwo, float* dbo, float* dln2_g, float* dln2_b,
                    float* dw1, float* db1, float* dw2, float* db2, void* workspace, void* stream);
+/* Batched encoder stacks (csrc/encoder_fused.hip): a stack runs one workgroup per image, i.e. a launch of its own keeps B of
+ * the 256 CUs busy; the three levels of the hierarchical model are independent, so their stacks can share a launch.  Between
+ * dh_encoder_batch_begin() and _end(), dh_encoder_fwd / dh_encoder_bwd only RECORD (up to four of each direction; a fifth
+ * issues the first four); dh_encoder_batch_launch(stream) issues the recorded forward stacks as one launch and / or the
+ * recorded backward stacks as one data-gradient + one parameter-gradient launch.  Every buffer of a recorded call (its
+ * workspace included: one per call) must stay alive and unchanged until then.  State per host thread; _abort drops the
+ * recorded calls without launching. */
+int dh_encoder_batch_begin(void);
+int dh_encoder_batch_pending(void);
+int dh_encoder_batch_launch(void* stream);
+int dh_encoder_batch_end(void* stream);
+int dh_encoder_batch_abort(void);
 long dh_encoder_bwd_workspace_size(int B, int n, int depth, int heads, int dim_head, int mlp);
 /* floats of `saved_inputs` (non-null in training): per (layer, image) the forward's intermediates -- layer input, LayerNorm
  * outputs and statistics, qkv, attention probabilities and output, MLP activations -- which dh_encoder_bwd reads back

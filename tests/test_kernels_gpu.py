@@ -781,6 +781,65 @@ def test_batchnorm_relu_on_load_equals_materialised_activation(ops, dtype, cfg):
     assert torch.equal(dw0, dw2)
 
 
+def test_encoder_stacks_of_independent_levels_in_one_launch(ops):
+    """ops.EncoderBatch (dh_encoder_batch_*): the token-encoder stacks of DAHiTra's three levels (different heads, batch and
+    token counts) recorded and issued as ONE forward launch and one backward + one parameter-gradient launch -- bit-identical
+    to the three separate launches (same kernel bodies, one workgroup per image)"""
+    from dahitra_amd import _lib
+    cases = [(6, 8, 1, 8, 64, 64), (5, 8, 2, 4, 64, 64), (3, 6, 1, 4, 64, 32)]      # B, n, depth, heads, dim_head, mlp
+    data = []
+    for k, (B, n, depth, heads, dh, mlp) in enumerate(cases):
+        inner = heads * dh
+        shapes = [(32,), (32,), (3 * inner, 32), (32, inner), (32,), (32,), (32,), (mlp, 32), (mlp,), (32, mlp), (32,)]
+        stride = sum(int(np.prod(sh)) for sh in shapes)
+        flat = (rnd((depth * stride,), torch.float32, 1300 + k, 0.2)).cuda()
+        params, off = [], 0
+        for i, sh in enumerate(shapes):
+            nsh = int(np.prod(sh))
+            for d in range(depth):
+                if i in (0, 5):
+                    flat[d * stride + off:d * stride + off + nsh] += 1.0
+            params.append(flat[off:off + nsh].view(sh))
+            off += nsh
+        x = rnd((B * n, 32), torch.float32, 1310 + k).cuda()
+        dy = rnd((B * n, 32), torch.float32, 1320 + k).cuda()
+        data.append((x, dy, params, stride, flat))
+
+    def run(batched):
+        outs, gflat = [], [torch.zeros_like(d[4]) for d in data]
+        grads = []
+        for (x, dy, params, stride, flat), gf, (B, n, depth, heads, dh, mlp) in zip(data, gflat, cases):
+            off, gl = 0, []
+            for p in params:
+                gl.append(gf[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            grads.append(gl)
+        with ops.EncoderBatch() as eb:
+            assert eb.on == batched
+            fw = [ops.encoder_fwd(x, B, n, depth, heads, dh, mlp, stride if depth > 1 else 0, params, True)
+                  for (x, dy, params, stride, flat), (B, n, depth, heads, dh, mlp) in zip(data, cases)]
+            assert _lib.lib().dh_encoder_batch_pending() == (3 if batched else 0)
+            eb.launch()
+            dxs = [ops.encoder_bwd(dy, xs, B, n, depth, heads, dh, mlp, stride if depth > 1 else 0, params, gl)
+                   for (x, dy, params, stride, flat), (y, xs), gl, (B, n, depth, heads, dh, mlp) in zip(data, fw, grads, cases)]
+            assert _lib.lib().dh_encoder_batch_pending() == (3 if batched else 0)
+            eb.launch()
+        torch.cuda.synchronize()
+        return [y for y, _ in fw], dxs, gflat
+
+    import os
+    os.environ["DAHITRA_ENC_BATCH"] = "0"
+    try:
+        ref = run(False)
+    finally:
+        del os.environ["DAHITRA_ENC_BATCH"]
+    got = run(True)
+    for group_r, group_g in zip(ref, got):
+        for a, b in zip(group_r, group_g):
+            assert torch.equal(a, b)
+    assert all(float(g.abs().max()) > 0 for g in got[2])
+
+
 def test_weight_gradients_of_a_pass_in_one_launch(ops):
     """dh_wgrad_batch_*: the wave-specialised 3x3 weight gradients of a backward pass recorded and issued as ONE launch (fewer,
     longer K slices per layer) against the same layers launched one by one: same products, another split of the pixel sum.
