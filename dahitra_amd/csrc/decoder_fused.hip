@@ -129,11 +129,11 @@ __device__ __forceinline__ LNres layer_norm(const float (&v)[2][4], const float*
 // forward: 256 threads, rows_per_block pixel rows per workgroup (16-pixel sub-tiles, wave after wave)
 // ------------------------------------------------------------------------------------------------------
 template <int MLP>
-__global__ __launch_bounds__(256) void dec_fwd_kernel(DecArgs p) {
+__device__ __forceinline__ void dec_fwd_body(const DecArgs& p, const int bid) {
     __shared__ __attribute__((aligned(16))) unsigned short sKq[32 * WP], sVoT[32 * WP], sW1[MLP * WP],
         sW2[32 * (MLP + 8)];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
-    const long row0 = (long)blockIdx.x * p.rows_per_block;
+    const long row0 = (long)bid * p.rows_per_block;
     const int img = (int)(row0 / p.rows_per_image);
     stage(sKq, WP, p.kq + (size_t)img * 32 * D, 32, D, tid);
     stage(sVoT, WP, p.voT + (size_t)img * D * 32, D, 32, tid);
@@ -198,6 +198,23 @@ __global__ __launch_bounds__(256) void dec_fwd_kernel(DecArgs p) {
         }
     }
 }
+template <int MLP>
+__global__ __launch_bounds__(256) void dec_fwd_kernel(DecArgs p) { dec_fwd_body<MLP>(p, blockIdx.x); }
+// Layers of several decoder stacks in one launch (dh_decoder_batch_*): DAHiTra's levels are independent, the launches of the small
+// ones (16 x 16 and 32 x 32 maps: 128 - 512 workgroups, 3.5 - 16 us) ride with the large one's.  Arguments by value.
+constexpr int DEC_MAXJ = 4;
+struct DecMulti {
+    int n;
+    int first[DEC_MAXJ + 1];
+    DecArgs a[DEC_MAXJ];
+};
+template <int MLP>
+__global__ __launch_bounds__(256) void dec_fwd_multi_kernel(DecMulti m) {
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    const DecArgs p = m.a[j];
+    dec_fwd_body<MLP>(p, (int)blockIdx.x - m.first[j]);
+}
 
 // ------------------------------------------------------------------------------------------------------
 // backward
@@ -257,7 +274,7 @@ __device__ long long g_dect[4096 * 20];
 #endif
 
 template <int MLP>
-__global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_kernel(DecArgs p) {
+__device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, unsigned char* smem) {
 #ifdef DEC_TIMING
     long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = (long long)clock64();
     const long long t_begin = t_last;
@@ -266,7 +283,6 @@ __global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_kernel(DecArgs
     constexpr int TP32 = lds_pitch(64), TPM = lds_pitch(MLP * 2);       // tile pitches (bytes)
     constexpr int TILE = 16 * (TPM > TP32 ? TPM : TP32);                // bytes per wave-private 16-pixel tile
     using P = PL<MLP>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short* sKq = reinterpret_cast<unsigned short*>(smem);
     unsigned short* sVoT = sKq + 32 * WP;
     unsigned short* sVo = sVoT + 32 * WP;
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_kernel(DecArgs
     unsigned char* tB0 = tiles + (wv * 4 + 1) * TILE;
     unsigned char* tA1 = tiles + (wv * 4 + 2) * TILE;
     unsigned char* tB1 = tiles + (wv * 4 + 3) * TILE;
-    const long row0 = (long)blockIdx.x * p.rows_per_block;
+    const long row0 = (long)bid * p.rows_per_block;
     const int img = (int)(row0 / p.rows_per_image);
     stage(sKq, WP, p.kq + (size_t)img * 32 * D, 32, D, tid);
     stage(sVoT, WP, p.voT + (size_t)img * D * 32, D, 32, tid);
@@ -607,7 +623,7 @@ __global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_kernel(DecArgs
     DEC_T(14);
     __syncthreads();
     DEC_T(15);
-    float* out = p.partial + (size_t)blockIdx.x * P::SIZE;
+    float* out = p.partial + (size_t)bid * P::SIZE;
     for (int i = tid; i < P::SIZE; i += 256)
         out[i] = ((red[i] + red[P::SIZE + i]) + red[2 * P::SIZE + i]) + red[3 * P::SIZE + i];
 #ifdef DEC_TIMING
@@ -622,6 +638,20 @@ __global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_kernel(DecArgs
 #ifdef DEC_TIMING
 extern "C" int dh_debug_dect(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dect), (size_t)n * 8); }
 #endif
+
+template <int MLP>
+__global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_kernel(DecArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    dec_bwd_body<MLP>(p, blockIdx.x, smem);
+}
+template <int MLP>
+__global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_multi_kernel(DecMulti m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    const DecArgs p = m.a[j];
+    dec_bwd_body<MLP>(p, (int)blockIdx.x - m.first[j], smem);
+}
 
 // sums the workgroup partials: shared parameters over all workgroups (accumulated into the gradient arena),
 // per-image dKq / dVoT over the workgroups of that image (assigned)
@@ -704,6 +734,59 @@ template <int MLP> size_t bwd_lds_bytes() {
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
+// ---- batched launches (dh_decoder_batch_*): index 0 = MLP 32, 1 = MLP 64; forward and backward each
+struct DecBatch {
+    bool on = false;
+    int nf[2] = {0, 0}, nb[2] = {0, 0};
+    DecMulti f[2], b[2];
+};
+static thread_local DecBatch g_db;
+template <int MLP> static int dec_set_bwd_lds(const void* kern, bool& done) {
+    if (!done) {
+        done = true;
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bwd_lds_bytes<MLP>()) != hipSuccess) {
+            (void)hipGetLastError();
+            DH_FAIL("decoder_layer_bwd: cannot raise dynamic LDS to %zu", bwd_lds_bytes<MLP>());
+        }
+    }
+    return 0;
+}
+static int dec_batch_flush(hipStream_t st) {
+    DecBatch& d = g_db;
+    static bool m32 = false, m64 = false;
+    for (int k = 0; k < 2; ++k) {
+        if (d.nf[k]) {
+            d.f[k].n = d.nf[k];
+            const int total = d.f[k].first[d.nf[k]];
+            if (k == 0) hipLaunchKernelGGL(dec_fwd_multi_kernel<32>, dim3(total), dim3(256), 0, st, d.f[k]);
+            else hipLaunchKernelGGL(dec_fwd_multi_kernel<64>, dim3(total), dim3(256), 0, st, d.f[k]);
+            d.nf[k] = 0;
+        }
+        if (d.nb[k]) {
+            d.b[k].n = d.nb[k];
+            const int total = d.b[k].first[d.nb[k]];
+            if (k == 0) {
+                if (dec_set_bwd_lds<32>(reinterpret_cast<const void*>(dec_bwd_multi_kernel<32>), m32)) return 1;
+                hipLaunchKernelGGL(dec_bwd_multi_kernel<32>, dim3(total), dim3(256), bwd_lds_bytes<32>(), st, d.b[k]);
+            } else {
+                if (dec_set_bwd_lds<64>(reinterpret_cast<const void*>(dec_bwd_multi_kernel<64>), m64)) return 1;
+                hipLaunchKernelGGL(dec_bwd_multi_kernel<64>, dim3(total), dim3(256), bwd_lds_bytes<64>(), st, d.b[k]);
+            }
+            d.nb[k] = 0;
+        }
+    }
+    DH_CHECK_LAUNCH("decoder_batch");
+    return 0;
+}
+static int dec_batch_record(DecMulti* m, int* n, const DecArgs& a, int nblk, hipStream_t st) {
+    if (*n == DEC_MAXJ) { const int rc = dec_batch_flush(st); if (rc) return rc; }
+    if (*n == 0) m->first[0] = 0;
+    m->a[*n] = a;
+    m->first[*n + 1] = m->first[*n] + nblk;
+    ++*n;
+    return 0;
+}
+
 static int check_common(long rows, int rows_per_image, int mlp) {
     DH_REQUIRE(mlp == 32 || mlp == 64, "decoder_fused: mlp_dim must be 32 or 64, got %d", mlp);
     DH_REQUIRE(rows_per_image % 128 == 0 && rows % rows_per_image == 0, "decoder_fused: rows per image (%d) must be a multiple of 128", rows_per_image);
@@ -732,6 +815,7 @@ extern "C" int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, cons
     a.rows_per_image = rows_per_image; a.rows = rows; a.eps = eps;
     a.rows_per_block = dec_fwd_rows_per_block(rows, rows_per_image);
     const int grid = (int)(rows / a.rows_per_block);
+    if (g_db.on) return dec_batch_record(&g_db.f[mlp == 64], &g_db.nf[mlp == 64], a, grid, ST(stream));
     if (mlp == 64) hipLaunchKernelGGL(dec_fwd_kernel<64>, dim3(grid), dim3(256), 0, ST(stream), a);
     else hipLaunchKernelGGL(dec_fwd_kernel<32>, dim3(grid), dim3(256), 0, ST(stream), a);
     DH_CHECK_LAUNCH("decoder_layer_fwd");
@@ -745,6 +829,17 @@ static inline int dec_rows_per_block(long rows, int rows_per_image) {
     while (rpb > 64 && (rows_per_image % rpb || rows / rpb < 512)) rpb >>= 1;
     return rpb;
 }
+
+// Batched decoder layers: between dh_decoder_batch_begin() and _end(), dh_decoder_layer_fwd and the data-gradient-only form of
+// dh_decoder_layer_bwd (dw1 == NULL: partials left for dh_decoder_stack_bwd_finalize) only RECORD their launch (up to 4 per
+// direction and MLP width; a fifth issues the first four); dh_decoder_batch_launch(stream) issues the recorded layers of
+// INDEPENDENT stacks as one launch per direction and width.  Every buffer of a recorded call stays alive and unchanged until
+// then.  Per host thread; _abort drops the recorded calls.
+extern "C" int dh_decoder_batch_begin() { g_db.on = true; g_db.nf[0] = g_db.nf[1] = g_db.nb[0] = g_db.nb[1] = 0; return 0; }
+extern "C" int dh_decoder_batch_pending() { return g_db.nf[0] + g_db.nf[1] + g_db.nb[0] + g_db.nb[1]; }
+extern "C" int dh_decoder_batch_launch(void* stream) { return dec_batch_flush(ST(stream)); }
+extern "C" int dh_decoder_batch_end(void* stream) { const int rc = dec_batch_flush(ST(stream)); g_db.on = false; return rc; }
+extern "C" int dh_decoder_batch_abort() { g_db.on = false; g_db.nf[0] = g_db.nf[1] = g_db.nb[0] = g_db.nb[1] = 0; return 0; }
 
 extern "C" long dh_decoder_layer_bwd_workspace_size(long rows, int rows_per_image, int mlp) {
     const long nblk = rows / dec_rows_per_block(rows, rows_per_image);
@@ -773,6 +868,7 @@ extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, con
     a.rows_per_image = rows_per_image; a.rows_per_block = dec_rows_per_block(rows, rows_per_image); a.rows = rows; a.eps = eps;
     const int nblk = (int)(rows / a.rows_per_block), bpi = rows_per_image / a.rows_per_block;
     const int images = (int)(rows / rows_per_image);
+    if (g_db.on && !dw1) return dec_batch_record(&g_db.b[mlp == 64], &g_db.nb[mlp == 64], a, nblk, ST(stream));
     static bool attr64 = false, attr32 = false;
     if (mlp == 64) {
         const size_t lds = bwd_lds_bytes<64>();

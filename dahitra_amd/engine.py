@@ -22,6 +22,16 @@ from .netspec import (ATTN_SCALE, BIT_DIM_HEAD, BIT_HEADS, BN_EPS, BN_MOMENTUM, 
 RELU, GELU, NONE = ops.ACT_RELU, ops.ACT_GELU, ops.ACT_NONE
 
 
+
+def _drain(gen):
+    """runs a staged generator (Engine._decoder_gen and friends) straight through and returns its value"""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        return e.value
+
+
 class Packed:
     """kernel-layout copies of one weight: forward / data-gradient form, and (bf16 3x3 layers the register-resident-weights
     convolution may serve) the same two in fragment order"""
@@ -532,9 +542,16 @@ class Engine:
                                      dx_add=dx1, accumulate=True)
         return x1, bwd
 
-    def decoder(self, x2d, images, tok, tok_b, tok_s, B, dtok, pfx, depth, heads, dim_head, L):
+    def decoder(self, *args):
         """cross-attention stack: pixel rows x2d [images*HW, 32] attend to the L tokens of their image
-        (help_funcs.py:170-186); dtok accumulates the token gradients."""
+        (help_funcs.py:170-186); dtok accumulates the token gradients.  (_decoder_gen run straight through.)"""
+        x, bg = _drain(self._decoder_gen(*args))
+        return x, (None if bg is None else (lambda d: _drain(bg(d))))
+
+    def _decoder_gen(self, x2d, images, tok, tok_b, tok_s, B, dtok, pfx, depth, heads, dim_head, L):
+        """decoder() as a GENERATOR that pauses after every fused layer launch, forward and (the generator its second return
+        value makes) backward: inside an ops.EncoderBatch(decoder=True) those launches are only recorded, and _run_staged
+        issues the layers the independent levels have reached as one launch"""
         bw = []
         x = x2d
         rpi = x2d.shape[0] // images
@@ -561,6 +578,7 @@ class Engine:
                 x, b1 = self._dec_layer_fused(x, images, rpi, tok, tok_b, tok_s, B, dtok, a, f, heads, dim_head, L, mlp,
                                               stack=stack, li=i, partial=defer.partials[i] if defer is not None else None)
                 bw.append(b1)
+                yield               # x is valid from here on
                 continue
             x, b1 = self._dec_attn(x, images, tok, tok_b, tok_s, B, dtok, a, heads, dim_head, L)
             x, b2 = self.mlp_block(x, f)
@@ -571,6 +589,8 @@ class Engine:
         def bwd(d):
             for b in reversed(bw):
                 d = b(d)
+                if fused:
+                    yield           # d is valid from here on
             if defer is not None:
                 a0, f0 = "%s.layers.0.0.fn" % pfx, "%s.layers.0.1.fn" % pfx
                 grads0 = (self.g[f0 + ".fn.net.0.weight"], self.g[f0 + ".fn.net.3.weight"], self.g[f0 + ".fn.net.0.bias"],
@@ -891,23 +911,25 @@ class Engine:
     # hierarchical model -------------------------------------------------------------------------
     @staticmethod
     def _run_staged(gens):
-        """GENERATORS that pause once, right after their token-encoder call (forward: `_level`; backward: the `bwd` it
-        returns): all of them run up to that point inside one ops.EncoderBatch -- the encoder stacks of the levels are
-        independent and occupy 2 x batch workgroups each, so they are recorded and issued as ONE launch per direction --
-        then each runs to its end.  Returns their return values."""
-        with ops.EncoderBatch() as eb:
-            for g in gens:
-                next(g)
-            eb.launch()
-        out = []
-        for g in gens:
-            try:
-                next(g)
-            except StopIteration as e:
-                out.append(e.value)
-            else:
-                raise RuntimeError("dahitra_amd: a staged level paused twice")
-        return out
+        """GENERATORS that pause right after every token-encoder call and every fused decoder layer (forward: `_level`;
+        backward: the `bwd` it returns).  They run in rounds inside one ops.EncoderBatch: the launches they reach are only
+        RECORDED, and after each round the recorded ones go out together -- the levels are independent, an encoder stack
+        occupies 2 x batch workgroups, the decoder layers of the 16 x 16 and 32 x 32 levels a fraction of the chip.
+        Returns the generators' return values."""
+        vals = {}
+        with ops.EncoderBatch(decoder=True) as eb:
+            live = list(gens)
+            while live:
+                paused = []
+                for g in live:
+                    try:
+                        next(g)
+                        paused.append(g)
+                    except StopIteration as e:
+                        vals[id(g)] = e.value
+                eb.launch()          # what the levels recorded in this round: one launch per kernel family
+                live = paused
+        return [vals[id(g)] for g in gens]
 
     def _level(self, l, xa_b, B):
         """one _forward_trans_module (networks.py:1297-1318) on the [A;B] batch of trunk taps.  A generator (see _run_staged):
@@ -926,8 +948,8 @@ class Engine:
         pos = self.p["pos_embedding_decoder_%d" % l]
         dp = "transformer_decoder_%d" % l
         xin = ops.add_pos(sq, pos)
-        dec, b_dec = self.decoder(xin.view(S2 * hw, DIM), S2, tok2d, 2 * L * DIM, L * DIM, B, dtok, dp,
-                                  lv["dec_depth"], lv["heads"], lv["dim_head"], L)
+        dec, b_dec = yield from self._decoder_gen(xin.view(S2 * hw, DIM), S2, tok2d, 2 * L * DIM, L * DIM, B, dtok, dp,
+                                                  lv["dec_depth"], lv["heads"], lv["dim_head"], L)
         dec4 = dec.view(S2, fh, fw, DIM)
         # third pass: decoder(conv_decode(cat[x1, x2]), |tok2 - tok1|) with the SAME weights
         cat = torch.empty(B, fh, fw, 2 * DIM, dtype=self.dtype, device=sq.device)
@@ -939,22 +961,22 @@ class Engine:
         ddtk = torch.zeros_like(dtk) if self.need_grad else None
         dxc, b_cd = self.conv_act(cat, "conv_decode_%d.weight" % l, None, 3, 1, NONE)
         xin3 = ops.add_pos(dxc, pos)
-        out, b_dec3 = self.decoder(xin3.view(B * hw, DIM), B, dtk.view(B * L, DIM), L * DIM, 0, B, ddtk, dp,
-                                   lv["dec_depth"], lv["heads"], lv["dim_head"], L)
+        out, b_dec3 = yield from self._decoder_gen(xin3.view(B * hw, DIM), B, dtk.view(B * L, DIM), L * DIM, 0, B, ddtk, dp,
+                                                   lv["dec_depth"], lv["heads"], lv["dim_head"], L)
         out4 = out.view(B, fh, fw, DIM)
         if not self.need_grad:
             return out4, None
         gpos = self.g["pos_embedding_decoder_%d" % l]
 
         def bwd(dout4):
-            dxin3 = b_dec3(dout4.reshape(B * hw, DIM)).view(B, fh, fw, DIM)
+            dxin3 = (yield from b_dec3(dout4.reshape(B * hw, DIM))).view(B, fh, fw, DIM)
             ops.add_pos_bwd(dxin3, gpos, accumulate=True)
             dcat = b_cd(dxin3)
             ops.absdiff_halves_bwd(tk3, ddtk, dtok)                    # accumulates into both token halves
             ddec = torch.empty_like(dec4)
             ops.copy_channels(dcat, 0, ddec[:B], 0, DIM)
             ops.copy_channels(dcat, DIM, ddec[B:], 0, DIM)
-            dxin = b_dec(ddec.view(S2 * hw, DIM)).view(S2, fh, fw, DIM)
+            dxin = (yield from b_dec(ddec.view(S2 * hw, DIM))).view(S2, fh, fw, DIM)
             ops.add_pos_bwd(dxin, gpos, accumulate=True)
             dtok_cat = b_enc(dtok)
             yield                   # dtok_cat is valid from here on (_run_staged)
@@ -988,14 +1010,14 @@ class Engine:
         dxc, b_cd = self.conv_act(cat, "conv_decode_%d.weight" % l, None, 3, 1, NONE)
         pos = self.p["pos_embedding_decoder_3"] if (with_pos and self.cfg["decoder_pos"]) else None
         xin = ops.add_pos(dxc, pos) if pos is not None else dxc
-        out, b_dec = self.decoder(xin.view(B * hw, DIM), B, dtk.view(B * L, DIM), L * DIM, 0, B, ddtk,
-                                  "transformer_decoder_%d" % l, lv["dec_depth"], lv["heads"], lv["dim_head"], L)
+        out, b_dec = yield from self._decoder_gen(xin.view(B * hw, DIM), B, dtk.view(B * L, DIM), L * DIM, 0, B, ddtk,
+                                                  "transformer_decoder_%d" % l, lv["dec_depth"], lv["heads"], lv["dim_head"], L)
         out4 = out.view(B, fh, fw, DIM)
         if not self.need_grad:
             return out4, None
 
         def bwd(dout4):
-            dxin = b_dec(dout4.reshape(B * hw, DIM)).view(B, fh, fw, DIM)
+            dxin = (yield from b_dec(dout4.reshape(B * hw, DIM))).view(B, fh, fw, DIM)
             if pos is not None:
                 ops.add_pos_bwd(dxin, self.g["pos_embedding_decoder_3"], accumulate=True)
             dcat = b_cd(dxin)

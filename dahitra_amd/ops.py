@@ -1141,6 +1141,8 @@ def decoder_layer_fwd(x2d, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b,
     with _Prof("decoder_layer_fwd", 0, _nb(x2d, y)):
         _call("dh_decoder_layer_fwd_fp8" if fp8 else "dh_decoder_layer_fwd", P(x2d), P(y), P(prep.kq), P(prep.voT), P(ln1_g), P(ln1_b), P(bo), P(ln2_g), P(ln2_b),
               P(w1), P(b1), P(w2), P(b2), _cl(x2d.shape[0]), _ci(rows_per_image), _ci(mlp), _cf(eps), S())
+    if _DEC_BATCH is not None and not fp8:        # recorded: operands alive until the batch is issued
+        _DEC_BATCH.extend((x2d, y, prep.kq, prep.voT))
     return y
 
 
@@ -1164,6 +1166,8 @@ def decoder_layer_bwd(x2d, dy, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln
         _call("dh_decoder_layer_bwd", P(x2d), P(dy), P(dx), P(prep.kq), P(prep.voT), P(prep.vo), P(prep.kqT), P(ln1_g),
               P(ln1_b), P(bo), P(ln2_g), P(ln2_b), P(w1), P(w1T), P(b1), P(w2), P(w2T), P(b2), *gp,
               P(dkq), P(dvoT), _cl(rows), _ci(rows_per_image), _ci(mlp), _cf(eps), P(ws), S())
+    if _DEC_BATCH is not None and partial is not None:
+        _DEC_BATCH.extend((x2d, dy, dx, ws, prep.kq, prep.voT, prep.vo, prep.kqT))
     return dx, dkq, dvoT
 
 
@@ -1211,6 +1215,7 @@ def encoder_bwd(dy, xs, B, n, depth, heads, dim_head, mlp, pstride, params, grad
 
 
 _ENC_BATCH = None        # while an EncoderBatch is open: the tensors of the recorded launches
+_DEC_BATCH = None        # ... and of its recorded decoder layers
 
 
 class EncoderBatch:
@@ -1218,30 +1223,47 @@ class EncoderBatch:
     eb.launch() issues them together (one workgroup per image each: stacks of independent levels share the chip).  Their
     outputs are valid after launch().  Inert under ops.PROFILE (per-launch events) and with DAHITRA_ENC_BATCH=0."""
 
-    def __init__(self):
+    def __init__(self, decoder=False):
+        """decoder=True: the fused decoder layers (decoder_layer_fwd, and decoder_layer_bwd with `partial`) are recorded too
+        (dh_decoder_batch_*): layers of independent stacks share a launch.  DAHITRA_DEC_BATCH=0 switches that part off."""
         self.on = PROFILE is None and os.environ.get("DAHITRA_ENC_BATCH", "1") != "0"
+        self.dec = decoder and PROFILE is None and os.environ.get("DAHITRA_DEC_BATCH", "1") != "0"
 
     def __enter__(self):
-        global _ENC_BATCH
+        global _ENC_BATCH, _DEC_BATCH
+        if self.on or self.dec:
+            assert _ENC_BATCH is None and _DEC_BATCH is None, "EncoderBatch is not re-entrant"
         if self.on:
-            assert _ENC_BATCH is None, "EncoderBatch is not re-entrant"
             _ENC_BATCH = []
             _call("dh_encoder_batch_begin")
+        if self.dec:
+            _DEC_BATCH = []
+            _call("dh_decoder_batch_begin")
         return self
 
     def launch(self):
         if self.on:
             _call("dh_encoder_batch_launch", S())
             del _ENC_BATCH[:]
+        if self.dec:
+            _call("dh_decoder_batch_launch", S())
+            del _DEC_BATCH[:]
 
     def __exit__(self, *exc):
-        global _ENC_BATCH
+        global _ENC_BATCH, _DEC_BATCH
+        failed = bool(exc) and exc[0] is not None
         if self.on:
-            if exc and exc[0] is not None:
+            if failed:
                 _lib.lib().dh_encoder_batch_abort()
             else:
                 _call("dh_encoder_batch_end", S())
             _ENC_BATCH = None
+        if self.dec:
+            if failed:
+                _lib.lib().dh_decoder_batch_abort()
+            else:
+                _call("dh_decoder_batch_end", S())
+            _DEC_BATCH = None
         return False
 
 

@@ -363,6 +363,15 @@ int dh_encoder_batch_pending(void);
 int dh_encoder_batch_launch(void* stream);
 int dh_encoder_batch_end(void* stream);
 int dh_encoder_batch_abort(void);
+/* The same for the fused decoder layers (csrc/decoder_fused.hip): between _begin and _end, dh_decoder_layer_fwd and the
+ * data-gradient-only form of dh_decoder_layer_bwd (dw1 == NULL) only RECORD (up to four per direction and MLP width);
+ * dh_decoder_batch_launch issues the recorded layers -- of INDEPENDENT stacks: never two layers of one stack -- as one launch
+ * per direction and width. */
+int dh_decoder_batch_begin(void);
+int dh_decoder_batch_pending(void);
+int dh_decoder_batch_launch(void* stream);
+int dh_decoder_batch_end(void* stream);
+int dh_decoder_batch_abort(void);
 long dh_encoder_bwd_workspace_size(int B, int n, int depth, int heads, int dim_head, int mlp);
 /* floats of `saved_inputs` (non-null in training): per (layer, image) the forward's intermediates -- layer input, LayerNorm
  * outputs and statistics, qkv, attention probabilities and output, MLP activations -- which dh_encoder_bwd reads back

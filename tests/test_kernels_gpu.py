@@ -840,6 +840,53 @@ def test_encoder_stacks_of_independent_levels_in_one_launch(ops):
     assert all(float(g.abs().max()) > 0 for g in got[2])
 
 
+def test_decoder_layers_of_independent_stacks_in_one_launch(ops):
+    """ops.EncoderBatch(decoder=True) (dh_decoder_batch_*): fused decoder layers of independent stacks -- different image
+    counts and map sizes, both MLP widths -- recorded and issued as one launch per direction and width: bit-identical to the
+    separate launches (forward output, data gradient, per-workgroup parameter-gradient partials)"""
+    from dahitra_amd import _lib
+    dtype, D = torch.bfloat16, 32
+    cases = [(6, 1024, 32), (4, 256, 32), (2, 4096, 32), (3, 512, 64)]          # images, rows per image, mlp
+
+    class Prep:
+        pass
+    data = []
+    for k, (images, rpi, mlp) in enumerate(cases):
+        rows = images * rpi
+        prep = Prep()
+        kq, voT = rnd((images, 32, D), dtype, 1402 + 10 * k, 0.3), rnd((images, D, 32), dtype, 1403 + 10 * k, 0.3)
+        prep.kq, prep.voT = dev(kq, dtype), dev(voT, dtype)
+        prep.vo, prep.kqT = dev(voT.transpose(1, 2).contiguous(), dtype), dev(kq.transpose(1, 2).contiguous(), dtype)
+        vec = lambda n, seed, base=0.0: (base + 0.1 * rnd((n,), torch.float32, seed)).cuda()
+        g1, b1, g2, b2, bo = vec(D, 1404 + 10 * k, 1.0), vec(D, 1405 + 10 * k), vec(D, 1406 + 10 * k, 1.0), vec(D, 1407 + 10 * k), vec(D, 1408 + 10 * k)
+        fb1, fb2 = vec(mlp, 1409 + 10 * k), vec(D, 1400 + 10 * k)
+        w1p, w1T = ops.pack_weight(rnd((mlp, D), dtype, 1401 + 10 * k, D ** -0.5).cuda(), dtype, want_dgrad=True)
+        w2p, w2T = ops.pack_weight(rnd((D, mlp), dtype, 1391 + 10 * k, mlp ** -0.5).cuda(), dtype, want_dgrad=True)
+        x = dev(rnd((rows, D), dtype, 1392 + 10 * k, 1.0), dtype)
+        dy = dev(rnd((rows, D), dtype, 1393 + 10 * k, 1.0), dtype)
+        data.append((x, dy, prep, rpi, g1, b1, bo, g2, b2, w1p, w1T, fb1, w2p, w2T, fb2, mlp))
+
+    def run(batched):
+        parts = [torch.zeros(ops.decoder_layer_bwd_partial_floats(d[0].shape[0], d[3], d[15]), dtype=torch.float32, device="cuda")
+                 for d in data]
+        with ops.EncoderBatch(decoder=batched) as eb:
+            ys = [ops.decoder_layer_fwd(x, prep, rpi, g1, b1, bo, g2, b2, w1p, fb1, w2p, fb2, mlp)
+                  for (x, dy, prep, rpi, g1, b1, bo, g2, b2, w1p, w1T, fb1, w2p, w2T, fb2, mlp) in data]
+            assert _lib.lib().dh_decoder_batch_pending() == (4 if batched else 0)
+            eb.launch()
+            dxs = [ops.decoder_layer_bwd(x, dy, prep, rpi, g1, b1, bo, g2, b2, w1p, w1T, fb1, w2p, w2T, fb2, None, mlp, partial=pt)[0]
+                   for (x, dy, prep, rpi, g1, b1, bo, g2, b2, w1p, w1T, fb1, w2p, w2T, fb2, mlp), pt in zip(data, parts)]
+            assert _lib.lib().dh_decoder_batch_pending() == (4 if batched else 0)
+            eb.launch()
+        torch.cuda.synchronize()
+        return ys, dxs, parts
+    ref, got = run(False), run(True)
+    for gr, gg in zip(ref, got):
+        for a, b in zip(gr, gg):
+            assert torch.equal(a, b)
+    assert all(float(p.abs().max()) > 0 for p in got[2])
+
+
 def test_weight_gradients_of_a_pass_in_one_launch(ops):
     """dh_wgrad_batch_*: the wave-specialised 3x3 weight gradients of a backward pass recorded and issued as ONE launch (fewer,
     longer K slices per layer) against the same layers launched one by one: same products, another split of the pixel sum.
