@@ -150,3 +150,48 @@ def test_pretrained_trunk_loader_fills_matching_keys_only():
     after = net.state_dict()
     assert float(after["resnet.conv1.weight"].min()) == 1.0 and float(after["resnet.bn1.running_mean"][3]) == 0.5
     assert torch.equal(after["resnet.layer1.0.conv1.weight"], before["resnet.layer1.0.conv1.weight"])
+
+
+def test_staged_levels_advance_in_rounds_and_launch_between_them(monkeypatch):
+    """Engine._run_staged (host logic of the batched per-level launches, no GPU): every live generator advances ONE pause per
+    round, the recorded launches go out after each round, finished generators drop out, return values keep the order of
+    the generators; the batch state of the C library opens and closes around it (nothing recorded: nothing launched)."""
+    from dahitra_amd import _lib, engine, ops
+    log = []
+
+    class FakeBatch:
+        def __init__(self, decoder=False):
+            log.append(("open", decoder))
+
+        def __enter__(self):
+            return self
+
+        def launch(self):
+            log.append("launch")
+
+        def __exit__(self, *exc):
+            log.append("close")
+            return False
+
+    def level(name, pauses):
+        for k in range(pauses):
+            log.append((name, k))
+            yield
+        return name.upper()
+
+    monkeypatch.setattr(ops, "EncoderBatch", FakeBatch)
+    out = engine.Engine._run_staged([level("a", 1), level("b", 3), level("c", 0)])
+    assert out == ["A", "B", "C"]
+    assert log == [("open", True), ("a", 0), ("b", 0), "launch", ("b", 1), "launch", ("b", 2), "launch", "launch", "close"]
+    # the real batch object on a machine without a GPU: opening it and leaving it through an exception are host-side state only
+    # (begin / abort; launching needs the HIP stream)
+    monkeypatch.undo()
+    lib = _lib.lib()
+    with pytest.raises(ZeroDivisionError):
+        with ops.EncoderBatch(decoder=True):
+            assert ops._ENC_BATCH == [] and ops._DEC_BATCH == []
+            assert lib.dh_encoder_batch_pending() == 0 and lib.dh_decoder_batch_pending() == 0
+            1 / 0
+    assert ops._ENC_BATCH is None and ops._DEC_BATCH is None
+    # engine._drain: a staged generator run straight through
+    assert engine._drain(level("d", 2)) == "D"
