@@ -195,3 +195,23 @@ def test_staged_levels_advance_in_rounds_and_launch_between_them(monkeypatch):
     assert ops._ENC_BATCH is None and ops._DEC_BATCH is None
     # engine._drain: a staged generator run straight through
     assert engine._drain(level("d", 2)) == "D"
+
+
+def test_weight_gradient_plan_closes_its_batch_when_a_pass_fails():
+    """ops.WgradPlan(batch=True) without a GPU: opening the plan opens the C library's batch (host-side state), an
+    exception inside the pass aborts it (nothing recorded is launched later), and a plain plan entered afterwards finds
+    no batch open"""
+    from dahitra_amd import _lib, ops
+    lib = _lib.lib()
+    plan = ops.WgradPlan("cpu", batch=True)
+    with pytest.raises(ZeroDivisionError):
+        with plan:
+            assert plan.batching and lib.dh_wgrad_batch_pending() == 0
+            1 / 0
+    assert not plan.batching and ops._WGRAD_PLAN is None
+    lib.dh_wgrad_batch_begin()                       # a batch somebody left open ...
+    with pytest.raises(ZeroDivisionError):
+        with ops.WgradPlan("cpu") as plain:          # ... is closed by the next plain plan (dh_wgrad_batch_abort)
+            assert not plain.batching
+            1 / 0
+    assert lib.dh_wgrad_batch_pending() == 0
