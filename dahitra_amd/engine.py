@@ -11,6 +11,7 @@ ResNet.forward_single :233-257, BasicBlock models/resnet.py:58-73, Transformer /
 models/help_funcs.py:154-186, BASE_Transformer_UNet.forward models/networks.py:1297-1357.
 """
 import os
+import sys
 import types
 
 import torch
@@ -778,7 +779,7 @@ class Engine:
             self._side_join()
             self._wgrad_plan.run()
         except BaseException:
-            self._wgrad_plan.__exit__()
+            self._wgrad_plan.__exit__(*sys.exc_info())      # abort: what the failed pass recorded must not be launched
             raise
 
     def run_deferred_wgrad(self):
@@ -801,7 +802,7 @@ class Engine:
             second(state)
             self._wgrad_plan.run()
         finally:
-            self._wgrad_plan.__exit__()
+            self._wgrad_plan.__exit__(*sys.exc_info())      # (None, None, None) on success; an exception aborts the batch
 
     def _head_out(self, h, wkey, bkey):
         """final 3x3 conv to n_class logits, returned as NCHW fp32 (the reference's output layout)"""

@@ -5,7 +5,8 @@ Logger   a tee: every message goes to stdout and is appended to a log file (the 
 Timer    progress bookkeeping for the "imps / est" figures of the batch log line (models/trainer.py:136-142): from the
          fraction of work done it extrapolates the hours that remain; a separate stage clock measures throughput.
 
-Only what `CDTrainer`, `CDEvaluator` and the reference's scripts call is provided (import names: misc/logger_tool.py)."""
+The reference's whole public surface is kept (import names: misc/logger_tool.py), including the Timer's context-manager form
+and its `str_estimated_*` helpers, which none of the reference's own scripts call."""
 import sys
 import time
 
@@ -48,12 +49,29 @@ class Timer:
         if starting_msg is not None:
             print(starting_msg, time.ctime(now))
 
+    # `with Timer(...) as t:` is accepted (misc/logger_tool.py:41-45: the context manager does nothing on either side)
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return None
+
     def update_progress(self, progress):
-        spent = time.time() - self.start
-        self.est_remaining = spent / progress - spent if progress > 0 else float("inf")
+        self.elapsed = spent = time.time() - self.start
+        self.est_total = spent / progress if progress > 0 else float("inf")
+        self.est_remaining = self.est_total - spent
+        self.est_finish = int(self.start + self.est_total) if progress > 0 else None
 
     def estimated_remaining(self):
         return self.est_remaining / 3600
+
+    def str_estimated_remaining(self):
+        return "%sh" % self.estimated_remaining()
+
+    def str_estimated_complete(self):
+        if getattr(self, "est_finish", None) is None:
+            raise AttributeError("Timer.str_estimated_complete() before update_progress()")     # as the reference: no est_finish yet
+        return time.ctime(self.est_finish)
 
     def get_stage_elapsed(self):
         return time.time() - self.stage_start

@@ -20,7 +20,9 @@ Differences, all on the host side of the step:
   * `args.compute_dtype` ('fp32' parity mode | 'bf16' throughput mode), `args.gpu_loader` (utils.get_loaders: the
     device-resident input pipeline) have no counterpart in the reference;
   * under torchrun (WORLD_SIZE > 1) the trainer joins the process group (dahitra_amd.parallel): replicas start from rank
-    0's parameters, gradients are averaged per step (inside the graphed step, or after the eager backward);
+    0's parameters, gradients are averaged per step (inside the graphed step, or after the eager backward); the epoch's
+    confusion matrix is summed over the ranks (all ranks see the same epoch_acc / best_val_acc), and only rank 0 writes
+    log.txt, the accuracy curves and the checkpoints (the others wait at a barrier for the file);
   * `args.checkpoint_dir` / `args.vis_dir` / `args.loss` are optional (no log files without a checkpoint_dir); the
     visualisation grid of trainer.py:194-203 is not assembled (its imsave is commented out there)."""
 import os
@@ -73,7 +75,10 @@ class CDTrainer:
         for d in (self.checkpoint_dir, self.vis_dir):
             if d and not os.path.exists(d):
                 os.makedirs(d, exist_ok=True)
-        if self.checkpoint_dir:
+        # one process per GPU: only rank 0 owns the files of the run (log.txt, *_acc.npy, best_ckpt.pt) -- N ranks appending to
+        # one log and racing torch.save() on one path leave torn files behind; the other ranks log nowhere
+        self.is_main = self.rank == 0
+        if self.checkpoint_dir and self.is_main:
             self.logger = Logger(os.path.join(self.checkpoint_dir, 'log.txt'))
             self.logger.write_dict_str(args.__dict__)
         else:
@@ -139,14 +144,22 @@ class CDTrainer:
         return True
 
     def _save_checkpoint(self, ckpt_name):
+        """rank 0 writes (to a temporary name, then an atomic rename); every rank waits for the file before going on, so a
+        resume on any rank never sees a half-written checkpoint"""
+        if self.is_main:
+            self._write_checkpoint(ckpt_name)
+        parallel.barrier()
+
+    def _write_checkpoint(self, ckpt_name):
         os.makedirs(self.checkpoint_dir, exist_ok=True)
+        path = os.path.join(self.checkpoint_dir, ckpt_name)
         # (plain python numbers: the file then also loads under torch.load's weights_only default; the reference's own
         # checkpoints carry numpy scalars, which the loaders here accept with weights_only=False)
         torch.save({'epoch_id': int(self.epoch_id), 'best_val_acc': float(self.best_val_acc),
                     'best_epoch_id': int(self.best_epoch_id), 'model_G_state_dict': self.net_G.state_dict(),
                     'optimizer_G_state_dict': self.optimizer_G.state_dict(),
-                    'exp_lr_scheduler_G_state_dict': self.exp_lr_scheduler_G.state_dict()},
-                   os.path.join(self.checkpoint_dir, ckpt_name))
+                    'exp_lr_scheduler_G_state_dict': self.exp_lr_scheduler_G.state_dict()}, path + '.tmp')
+        os.replace(path + '.tmp', path)
 
     # ---- bookkeeping ----------------------------------------------------------------------------------
     def _timer_update(self):
@@ -170,10 +183,16 @@ class CDTrainer:
             ops.confusion_matrix(self.G_final_pred.detach().float().contiguous(), gt, self.confusion)
             self._counted = True
 
-    def _sync_metric(self):
+    def _sync_metric(self, all_ranks=False):
         """hand what the device has counted since the last call to the reference's meter (ONE read-back of n_class^2 numbers);
-        returns the mean F1 of that increment (for a per-batch call: the batch's F1, the reference's `running_mf1`)"""
-        cm = self.confusion.cpu().numpy()
+        returns the mean F1 of that increment (for a per-batch call: the batch's F1, the reference's `running_mf1`).
+        all_ranks (the epoch's last call): the counts of every rank's shard are summed first, so that all ranks hold the SAME
+        epoch scores and take the same best-model decision"""
+        cm = self.confusion
+        if all_ranks and parallel.exchange_enabled():
+            cm = cm.clone()
+            parallel.allreduce_counts_(cm)
+        cm = cm.cpu().numpy().copy()            # (a copy also when `confusion` is host memory: _synced must not alias it)
         inc, self._synced = cm - self._synced, cm
         return self.running_metric.update_from_matrix(inc) if inc.sum() > 0 else 0.0
 
@@ -211,7 +230,7 @@ class CDTrainer:
                                running_acc))
 
     def _collect_epoch_states(self):
-        self._sync_metric()                       # the one device read of the epoch
+        self._sync_metric(all_ranks=True)         # the one device read of the epoch (+ one 4-number all-reduce under torchrun)
         scores = self.running_metric.get_scores()
         self.epoch_acc = scores['mf1']
         self.logger.write('Is_training: %s. Epoch %d / %d, epoch_mF1= %.5f\n' %
@@ -231,12 +250,12 @@ class CDTrainer:
 
     def _update_training_acc_curve(self):
         self.TRAIN_ACC = np.append(self.TRAIN_ACC, [self.epoch_acc])
-        if self.checkpoint_dir:
+        if self.checkpoint_dir and self.is_main:
             np.save(os.path.join(self.checkpoint_dir, 'train_acc.npy'), self.TRAIN_ACC)
 
     def _update_val_acc_curve(self):
         self.VAL_ACC = np.append(self.VAL_ACC, [self.epoch_acc])
-        if self.checkpoint_dir:
+        if self.checkpoint_dir and self.is_main:
             np.save(os.path.join(self.checkpoint_dir, 'val_acc.npy'), self.VAL_ACC)
 
     def _clear_cache(self):
@@ -314,6 +333,9 @@ class CDTrainer:
             self.is_training = True
             self.net_G.train()
             self.logger.write('lr: %0.7f\n' % self.optimizer_G.param_groups[0]['lr'])
+            sampler = getattr(self.dataloaders['train'], 'sampler', None)
+            if hasattr(sampler, 'set_epoch'):           # DistributedSampler (utils.get_loaders under torchrun)
+                sampler.set_epoch(self.epoch_id)
             for self.batch_id, batch in enumerate(self.dataloaders['train'], 0):
                 self._step(batch)
                 self._collect_running_batch_states()

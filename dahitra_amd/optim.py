@@ -181,8 +181,11 @@ class AdamW(torch.optim.Optimizer):
                 param, grad = net.flat_params()
                 st = self._state_for(net, group)
                 if self.capturable:
-                    if st.host is None or (grad_scale is not None and float(grad_scale) != st.host[5]):
-                        self.sync_hyper(grad_scale)          # raises inside a capture if anything changed
+                    # ALWAYS compare the group's lr / betas / eps / weight_decay with what the device holds (a host tuple
+                    # compare): an lr scheduler changes group['lr'] between steps, and the eager step has to see it exactly
+                    # as the graphed step does (GraphedTrainStep syncs before every replay).  Inside a capture nothing may
+                    # change; sync_hyper raises there if it did.
+                    self.sync_hyper(grad_scale)
                     if self._rule == "xbd":
                         ops._call("dh_adamw_xbd_step_graph", ops.P(param), ops.P(grad), ops.P(st.m), ops.P(st.v),
                                   ctypes.c_long(param.numel()), ops.P(st.hyper), ops.P(st.step), ops.P(None), ops.S())

@@ -87,3 +87,16 @@ def split_offset(net):
     if (net._arena.n_active - split) * 4 < (1 << 20):
         return None
     return split
+
+
+def allreduce_counts_(counts, group=None):
+    """in-place SUM of an integer count tensor (the trainers' device-side confusion matrix) over the ranks"""
+    if exchange_enabled(group):
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    return counts
+
+
+def barrier(group=None):
+    """no-op without a process group"""
+    if dist.is_initialized():
+        dist.barrier(group=group)

@@ -50,6 +50,18 @@ def get_loaders(args):
                               label_transform=cfg.label_transform),
             'val': _dataset(args.dataset, root_dir=cfg.root_dir, split=split_val, img_size=args.img_size, is_train=False,
                             label_transform=cfg.label_transform)}
+    from . import parallel
+    rank, _, world = parallel.init_from_env()
+    if world > 1:
+        # one process per GPU: every rank draws its own 1/world of the TRAIN split (DistributedSampler, re-seeded per epoch by
+        # CDTrainer.train_models via set_epoch) -- without it all ranks would iterate the identical batches and the all-reduced
+        # mean gradient would be the single-rank gradient at N times the cost.  The validation split is sharded too (no
+        # shuffle): the trainer sums the ranks' confusion matrices at the end of the epoch.
+        from torch.utils.data.distributed import DistributedSampler
+        samplers = {'train': DistributedSampler(sets['train'], num_replicas=world, rank=rank, shuffle=True, drop_last=True),
+                    'val': DistributedSampler(sets['val'], num_replicas=world, rank=rank, shuffle=False)}
+        return {k: DataLoader(v, batch_size=args.batch_size, sampler=samplers[k], num_workers=args.num_workers)
+                for k, v in sets.items()}
     return {k: DataLoader(v, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers) for k, v in sets.items()}
 
 

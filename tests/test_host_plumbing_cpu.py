@@ -116,6 +116,12 @@ def test_utils_surface(tmp_path, monkeypatch):
     tm = Timer()
     tm.update_progress(0.5)
     assert tm.est_remaining >= 0 and tm.estimated_remaining() == tm.est_remaining / 3600 and tm.lapse() >= 0
+    # the rest of the reference's Timer surface (misc/logger_tool.py:41-65)
+    assert tm.str_estimated_remaining() == "%sh" % tm.estimated_remaining() and tm.est_total >= tm.elapsed
+    assert isinstance(tm.str_estimated_complete(), str) and tm.est_finish >= int(tm.start)
+    with Timer("stage") as t2:
+        t2.reset_stage()
+    assert t2.get_stage_elapsed() >= 0
 
 
 def test_reference_import_names_resolve_through_compat():

@@ -166,12 +166,12 @@ def _synthetic_pipe(n, size, seed):
     return GpuPairPipeline(a.cuda(), b.cuda(), lab.cuda())
 
 
-def _trainer(dtype, batch, loaders, graph, lr=0.001, seed=3):
+def _trainer(dtype, batch, loaders, graph, lr=0.001, seed=3, max_epochs=1, lr_policy="linear"):
     from dahitra_amd.models.trainer import CDTrainer
     torch.manual_seed(seed)
     torch.cuda.manual_seed(seed)
-    args = types.SimpleNamespace(net_G=NAME, gpu_ids=[0], lr=lr, batch_size=batch, max_epochs=1, n_class=2, lr_policy="linear",
-                                 compute_dtype=dtype, hip_graph=graph)
+    args = types.SimpleNamespace(net_G=NAME, gpu_ids=[0], lr=lr, batch_size=batch, max_epochs=max_epochs, n_class=2,
+                                 lr_policy=lr_policy, lr_decay_iters=1, compute_dtype=dtype, hip_graph=graph)
     tr = CDTrainer(args, dataloaders=loaders)
     tr.net_G.load_state_dict(O.deterministic_state(NAME))
     return tr
@@ -199,6 +199,38 @@ def test_trainer_graph_path_equals_eager_path_bit_for_bit_at_batch_32():
     assert torch.equal(g[0], e[0]), "parameters differ: max |d| = %g" % float((g[0] - e[0]).abs().max())
     assert all(torch.equal(x, y) for x, y in zip(g[1], e[1])) and torch.equal(g[2], e[2])
     assert np.array_equal(g[4], e[4]) and np.array_equal(g[5], e[5])
+
+
+@pytest.mark.parametrize("policy", ["linear", "step"])
+def test_lr_schedule_reaches_the_eager_step_as_it_reaches_the_graphed_step(policy):
+    """three epochs with an lr schedule that changes the rate after every epoch (models/networks.py:35-49, stepped per epoch at
+    models/trainer.py:314): the eager trainer (args.hip_graph=False; its AdamW keeps lr on the device as the graphed one
+    does) must pick the new rate up exactly as the graph replay does -- bit-identical parameters and Adam moments, the
+    device-side lr equal to the scheduler's last value, and parameters that DIFFER from a run whose rate never changed"""
+    from dahitra_amd.datasets.gpu_pipeline import GpuPairLoader
+    pipe = _synthetic_pipe(16, 64, seed=21)
+    out = {}
+    for tag, graph, pol in (("graph", True, policy), ("eager", False, policy), ("flat", False, None)):
+        loaders = {"train": GpuPairLoader(pipe, 8, 64, True, torch.Generator().manual_seed(9)),
+                   "val": GpuPairLoader(pipe, 8, 64, False)}
+        tr = _trainer("fp32", 8, loaders, graph, max_epochs=3, lr_policy=pol or policy)
+        if pol is None:                 # the same loop with the schedule's effect removed
+            tr._update_lr_schedulers = lambda: None
+        tr.train_models()
+        st = tr.optimizer_G._flat_state[id(tr.net_G)]
+        out[tag] = (tr.net_G._arena.flat.clone(), st.m.clone(), float(st.hyper[0]), tr.optimizer_G.param_groups[0]["lr"],
+                    tr.optimizer_G.step_count(tr.net_G))
+    g, e, f = out["graph"], out["eager"], out["flat"]
+    assert g[4] == e[4] == f[4] == 6
+    assert g[3] == e[3] and g[3] < 0.001                       # the scheduler lowered the rate ...
+    # ... the LAST step ran at the rate of epoch 2 (the scheduler's final step() only prepares a fourth epoch)
+    lr_epoch2 = 0.001 * ((1.0 - 2 / 4.0) if policy == "linear" else 0.1 ** 2)
+    for tag in ("graph", "eager"):
+        assert out[tag][2] == pytest.approx(lr_epoch2, rel=1e-6), (tag, out[tag][2], lr_epoch2)
+    assert f[2] == pytest.approx(0.001, rel=1e-6)
+    assert torch.equal(g[0], e[0]), "parameters differ: max |d| = %g" % float((g[0] - e[0]).abs().max())
+    assert torch.equal(g[1], e[1])
+    assert not torch.equal(e[0], f[0])                         # the schedule is visible in the parameters
 
 
 def test_trainer_loop_reaches_the_bench_step_rate():

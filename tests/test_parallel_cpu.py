@@ -92,3 +92,82 @@ def test_gradient_exchange_split_point_of_every_net_family(name, monkeypatch):
         assert any(k.startswith("resnet.layer3.") for k in tail) and (net._arena.n_active - split) > 0.7 * net._arena.n_active
     monkeypatch.setenv("DAHITRA_NO_OVERLAP", "1")
     assert parallel.split_offset(net) is None
+
+
+def _trainer_host_worker(rank, world, port, out):
+    """the rank-dependent host side of CDTrainer on a stand-in object (the trainer itself needs a GPU): epoch metrics summed
+    over the ranks, files written by rank 0 only, every rank past the barrier sees the finished checkpoint"""
+    import types
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from dahitra_amd import parallel
+    from dahitra_amd.misc.metric_tool import ConfuseMatrixMeter
+    from dahitra_amd.models.trainer import CDTrainer
+    parallel.init_from_env("gloo")
+
+    class Dummy:
+        def state_dict(self):
+            return {"w": torch.full((3,), float(rank))}
+    cm = torch.tensor([[90 + rank, 3], [2 * rank + 1, 5]], dtype=torch.int64)
+    fake = types.SimpleNamespace(confusion=cm.clone(), _synced=np.zeros((2, 2), np.int64), running_metric=ConfuseMatrixMeter(2),
+                                 checkpoint_dir=out, is_main=rank == 0, epoch_id=3, best_val_acc=0.5, best_epoch_id=2,
+                                 net_G=Dummy(), optimizer_G=Dummy(), exp_lr_scheduler_G=Dummy())
+    fake._write_checkpoint = lambda name: CDTrainer._write_checkpoint(fake, name)
+    # a per-batch sync stays local, the epoch's sync is global
+    f1_local = CDTrainer._sync_metric(fake)
+    assert np.array_equal(fake.running_metric.sum, cm.numpy())
+    fake.confusion += cm                                   # a second batch
+    CDTrainer._sync_metric(fake, all_ranks=True)
+    total = sum(2 * torch.tensor([[90 + r, 3], [2 * r + 1, 5]]) for r in range(world)).numpy()
+    assert np.array_equal(fake.running_metric.sum, total), (fake.running_metric.sum, total)
+    assert torch.equal(fake.confusion, 2 * cm)             # the device-side running matrix itself stays this rank's
+    CDTrainer._save_checkpoint(fake, "best_ckpt.pt")
+    ck = torch.load(os.path.join(out, "best_ckpt.pt"))     # present and complete on EVERY rank right after the call
+    assert ck["epoch_id"] == 3 and torch.equal(ck["model_G_state_dict"]["w"], torch.zeros(3))      # rank 0's
+    assert not os.path.exists(os.path.join(out, "best_ckpt.pt.tmp"))
+    torch.save({"mf1": float(fake.running_metric.get_scores()["mf1"]), "f1_local": float(f1_local)}, os.path.join(out, "m%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_host_outputs_are_rank_guarded_and_epoch_scores_agree(tmp_path):
+    port = _free_port()
+    mp.spawn(_trainer_host_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    m0, m1 = (torch.load(os.path.join(tmp_path, "m%d.pt" % r)) for r in (0, 1))
+    assert m0["mf1"] == m1["mf1"]                          # same epoch score => same best-model decision on all ranks
+    assert m0["f1_local"] != m1["f1_local"]                # while the shards' own counts differ
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("best")) == ["best_ckpt.pt"]
+
+
+def test_pil_loaders_are_sharded_by_rank_under_torchrun(tmp_path, monkeypatch):
+    """utils.get_loaders with WORLD_SIZE > 1 (no process group needed to BUILD the loaders): the default DataLoader path hands
+    each rank a disjoint 1/world of the train split"""
+    import types
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, ROOT)
+    from dahitra_amd import utils
+    root = tmp_path / "data" / "LEVIR_CD"
+    names = ["im%02d.png" % i for i in range(8)]
+    for split in ("train", "val"):                     # <root>/<split>/{A,B,label}/<name> (datasets/CD_dataset.py:21-30)
+        for d in ("A", "B", "label"):
+            (root / split / d).mkdir(parents=True)
+        for n in names:
+            for d in ("A", "B"):
+                Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(root / split / d / n)
+            Image.fromarray(np.zeros((16, 16), np.uint8)).save(root / split / "label" / n)
+    monkeypatch.setenv("DAHITRA_DATA_ROOT", str(tmp_path))
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr("dahitra_amd.parallel.init_from_env", lambda backend=None: (int(os.environ["RANK"]), 0, 2))
+    seen = []
+    for rank in (0, 1):
+        monkeypatch.setenv("RANK", str(rank))
+        ld = utils.get_loaders(types.SimpleNamespace(data_name="LEVIR", dataset="CDDataset", split="train", img_size=16,
+                                                     batch_size=2, num_workers=0))
+        ld["train"].sampler.set_epoch(1)
+        seen.append(sorted(n for b in ld["train"] for n in b["name"]))
+        assert len(ld["train"]) == 2 and len(ld["val"]) == 2
+    assert len(seen[0]) == len(seen[1]) == 4 and not set(seen[0]) & set(seen[1])
+    assert sorted(seen[0] + seen[1]) == names

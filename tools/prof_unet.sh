@@ -13,7 +13,7 @@ f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    if "dec_bwd_kernel" in n or "dec_fwd_kernel" in n:
+    if "dec_bwd" in n or "dec_fwd" in n:          # dec_{fwd,bwd}_kernel and the staged levels' dec_{fwd,bwd}_multi_kernel, keyed by name
         key = (n.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", ""), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1))
         acc[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 with open(sys.argv[2], "w") as o:
