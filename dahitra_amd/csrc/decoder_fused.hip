@@ -24,7 +24,14 @@
 namespace {
 
 constexpr int D = 32;
-constexpr int WP = 40;           // LDS pitch (elements) of 32-wide weight rows: 80 B, conflict-free 8-byte reads
+// Weight rows sit in LDS in FRAGMENT ORDER: the eight elements kappa(g, 0..7) a lane multiplies are contiguous, so an A
+// fragment is ONE ds_read_b128.  (The first form read them as two 8-byte halves 32 bytes apart; hipcc merged each pair into a
+// ds_read2_b64, which is banked modulo 32 dwords over 16 CONTIGUOUS lanes and runs at half the ds_read_b128 rate: at the
+// 80-byte pitch chosen for ds_read_b64, rows pl and pl + 8 met on one bank -- SQ_LDS_BANK_CONFLICT was 50 % of the LDS cycles
+// of both kernels, profiles/r03q_pmc_mfma_util.json.)  ds_read_b128 is served in four non-contiguous 16-lane groups
+// (MI355X_MICROARCH.md, LDS); enumerating them, rows of 32 elements are conflict-free at a pitch of 96 bytes, rows of 64 at 160.
+constexpr int WP = 48;           // LDS pitch (elements) of 32-wide weight rows
+constexpr int wide_pitch(int cols) { return cols == 32 ? 48 : 80; }      // ... of [32][MLP] rows
 
 struct DecArgs {
     const bf16* x;
@@ -53,11 +60,10 @@ __device__ __forceinline__ s16x8 pack8(const float (&a)[4], const float (&b)[4])
     r.u.w = f2bf2(b[2], b[3]);
     return r.v;
 }
-// A fragment of weight row `row`, logical k = koff + kappa(g, e): two 8-byte LDS reads
+// A fragment of weight row `row`, logical k = koff + kappa(g, e): one 16-byte LDS read (rows staged by stage() in fragment order)
 __device__ __forceinline__ s16x8 lds_a(const unsigned short* base, int pitch, int row, int koff, int g) {
     U8 r;
-    r.h[0] = *reinterpret_cast<const uint2*>(base + row * pitch + koff + g * 4);
-    r.h[1] = *reinterpret_cast<const uint2*>(base + row * pitch + koff + 16 + g * 4);
+    r.u = *reinterpret_cast<const uint4*>(base + row * pitch + koff + g * 8);
     return r.v;
 }
 __device__ __forceinline__ f32x4 mma(s16x8 a, s16x8 b, f32x4 c) {
@@ -73,36 +79,41 @@ __device__ __forceinline__ float group4_sum(float v) {
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// cooperative copy of a [rows][cols] bf16 matrix (global, dense) into LDS with pitch
+// cooperative copy of a [rows][cols] bf16 matrix (global, dense) into LDS with pitch, every 32-column block in fragment order:
+// logical columns 4q .. 4q+3 (q = 0..7) land at position 8 (q & 3) + 4 (q >> 2), i.e. kappa(g, e) at g * 8 + e
 __device__ __forceinline__ void stage(unsigned short* dst, int pitch, const bf16* src, int rows, int cols, int tid) {
     const int vec = cols / 4;
     for (int i = tid; i < rows * vec; i += 256) {
-        const int r = i / vec, c = (i % vec) * 4;
-        *reinterpret_cast<uint2*>(dst + r * pitch + c) = *reinterpret_cast<const uint2*>(src + (size_t)r * cols + c);
+        const int r = i / vec, q = i % vec, c = (q & ~7) * 4 + (q & 3) * 8 + ((q >> 2) & 1) * 4;
+        *reinterpret_cast<uint2*>(dst + r * pitch + c) = *reinterpret_cast<const uint2*>(src + (size_t)r * cols + q * 4);
     }
 }
 
-// GELU (erf form, help_funcs.py:57 nn.GELU) and its derivative from ONE exponential: with u = exp(-z^2/2),
-//   erf(|z|/sqrt2) = 1 - (a1 t + ... + a5 t^5) u,  t = 1/(1 + p |z|/sqrt2)      (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7)
-//   Phi(z) = 0.5 (1 + sign(z) erf),   gelu = z Phi,   gelu' = Phi + z u / sqrt(2 pi)
-// ~20 VALU instructions instead of the ~200 of erff + expf: these kernels are VALU-bound on exactly this (the bf16
-// result is rounded at 4e-3, far above the approximation error).  The fp32 parity path keeps erff (common.h).
+// GELU (erf form, help_funcs.py:57 nn.GELU) for the bf16 path: gelu(z) = z Phi(z) with Phi approximated by a logistic function
+// of an odd quintic,  Phi(z) ~ sigma(z (k0 + k1 t + k2 t^2)),  t = min(z^2, 36)  (the three coefficients fitted to the erf form
+// over |z| <= 12, tools/gelu_fit.py: max |error| 2.7e-5 in gelu, 1.1e-4 in gelu' -- the bf16 result is rounded at 4e-3
+// relative; with the textbook tanh constants the same form is 4.7e-4 / 8.7e-4 off).  7 VALU + exp2 + rcp per value, 12 with
+// the derivative; the Abramowitz-Stegun erf of the previous build (error 1.5e-7) took 14 + 2 resp. 18 + 2 and was 40 % of the
+// forward kernel's VALU work (tools/dec_timeline.py).  The fp32 parity path keeps erff (common.h); the clamp keeps
+// the quintic monotone (k2 < 0) where sigma is already 0 / 1 in fp32.
 __device__ __forceinline__ float gelu_fast(float z, float* dgelu) {
-    const float az = fabsf(z);
-    const float u = __expf(-0.5f * z * z);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678118654752440f * az);      // (v_rcp_f32, 1 ulp: an IEEE division is ~8 instructions)
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * u;
-    const float phi = 0.5f * (1.0f + copysignf(erf_abs, z));
-    if (dgelu) *dgelu = phi + z * u * 0.39894228040143267794f;
-    return z * phi;
+    constexpr float K0 = 1.5950013121464464f, K1 = 0.07399967641212012f, K2 = -0.0007003036283985342f;
+    constexpr float NL2E = -1.4426950408889634f;                       // exp(-a) = exp2(a * NL2E)
+    const float t = fminf(z * z, 36.0f);
+    const float w = z * ((K0 * NL2E) + t * ((K1 * NL2E) + t * (K2 * NL2E)));
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w));      // sigma(a); exp2 -> inf gives rcp -> 0
+    if (dgelu) {
+        const float ap = K0 + t * (3.0f * K1 + t * (5.0f * K2));       // da/dz (where t is clamped, s (1 - s) is 0 anyway)
+        *dgelu = s + (z * ap) * (s - s * s);
+    }
+    return z * s;
 }
 
 struct LNres {
     float mean, rstd;
 };
-// LayerNorm of one pixel held as v[2][4] across 4 lane groups; returns xhat in place of v and the affine in o
-__device__ __forceinline__ LNres layer_norm(const float (&v)[2][4], const float* gam, const float* bet, int g,
+// LayerNorm of one pixel held as v[2][4] across 4 lane groups (gam / bet: this lane's 8 channels); returns xhat in xh and the affine in o
+__device__ __forceinline__ LNres layer_norm(const float (&v)[2][4], const float (&gam)[2][4], const float (&bet)[2][4],
                                             float eps, float (&xh)[2][4], float (&o)[2][4]) {
     // sum and sum of squares in ONE pass: the two cross-row reductions run side by side instead of one after the other (these
     // kernels are chains of dependent steps), and x_hat = x * rstd - mean * rstd is one FMA per channel
@@ -118,9 +129,8 @@ __device__ __forceinline__ LNres layer_norm(const float (&v)[2][4], const float*
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = h * 16 + g * 4 + j;
             xh[h][j] = v[h][j] * rstd + nmr;
-            o[h][j] = xh[h][j] * gam[c] + bet[c];
+            o[h][j] = xh[h][j] * gam[h][j] + bet[h][j];
         }
     return LNres{mean, rstd};
 }
@@ -130,15 +140,26 @@ __device__ __forceinline__ LNres layer_norm(const float (&v)[2][4], const float*
 // ------------------------------------------------------------------------------------------------------
 template <int MLP>
 __device__ __forceinline__ void dec_fwd_body(const DecArgs& p, const int bid) {
-    __shared__ __attribute__((aligned(16))) unsigned short sKq[32 * WP], sVoT[32 * WP], sW1[MLP * WP],
-        sW2[32 * (MLP + 8)];
+    constexpr int W2P = wide_pitch(MLP);
+    __shared__ __attribute__((aligned(16))) unsigned short sKq[32 * WP], sVoT[32 * WP], sW1[MLP * WP], sW2[32 * W2P];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
     const long row0 = (long)bid * p.rows_per_block;
     const int img = (int)(row0 / p.rows_per_image);
     stage(sKq, WP, p.kq + (size_t)img * 32 * D, 32, D, tid);
     stage(sVoT, WP, p.voT + (size_t)img * D * 32, D, 32, tid);
     stage(sW1, WP, p.w1, MLP, D, tid);
-    stage(sW2, MLP + 8, p.w2, D, MLP, tid);
+    stage(sW2, W2P, p.w2, D, MLP, tid);
+    // the seven parameter vectors: this lane's 8 (fb1: MLP / 4) channels, in registers for the whole workgroup.  (Read through
+    // the pointers inside the loop they were 14 global loads per sub-tile: the store to y may alias them for all the compiler knows.)
+    float cg1[2][4], cbe1[2][4], cbo[2][4], cg2[2][4], cbe2[2][4], cfb2[2][4], cfb1[MLP / 16][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = h * 16 + g * 4;
+        ld4(p.g1 + c, cg1[h]); ld4(p.be1 + c, cbe1[h]); ld4(p.bo + c, cbo[h]);
+        ld4(p.g2 + c, cg2[h]); ld4(p.be2 + c, cbe2[h]); ld4(p.fb2 + c, cfb2[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < MLP / 16; ++h) ld4(p.fb1 + h * 16 + g * 4, cfb1[h]);
     __syncthreads();
     const int nsub = p.rows_per_block / 64;          // 16-pixel sub-tiles per wave
     for (int ps = 0; ps < nsub; ++ps) {
@@ -148,7 +169,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& p, const int bid) {
         float x[2][4], xh[2][4], xn[2][4];
         ld4(xr + g * 4, x[0]);
         ld4(xr + 16 + g * 4, x[1]);
-        layer_norm(x, p.g1, p.be1, g, p.eps, xh, xn);
+        layer_norm(x, cg1, cbe1, p.eps, xh, xn);
         // dots -> softmax over the 4 keys of each head (lane-local)
         const s16x8 bxn = pack8(xn[0], xn[1]);
         float at[2][4];
@@ -169,31 +190,31 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& p, const int bid) {
         for (int s = 0; s < 2; ++s) {
             f32x4 o = mma(lds_a(sVoT, WP, s * 16 + pl, 0, g), bat, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x1[s][j] = o[j] + p.bo[s * 16 + g * 4 + j] + x[s][j];
+            for (int j = 0; j < 4; ++j) x1[s][j] = o[j] + cbo[s][j] + x[s][j];
         }
         float xh2[2][4], l2[2][4];
-        layer_norm(x1, p.g2, p.be2, g, p.eps, xh2, l2);
+        layer_norm(x1, cg2, cbe2, p.eps, xh2, l2);
         const s16x8 bl2 = pack8(l2[0], l2[1]);
         float hh[MLP / 16][4];
 #pragma unroll
         for (int s = 0; s < MLP / 16; ++s) {
             f32x4 z = mma(lds_a(sW1, WP, s * 16 + pl, 0, g), bl2, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hh[s][j] = gelu_fast(z[j] + p.fb1[s * 16 + g * 4 + j], nullptr);
+            for (int j = 0; j < 4; ++j) hh[s][j] = gelu_fast(z[j] + cfb1[s][j], nullptr);
         }
         f32x4 out[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int q = 0; q < MLP / 32; ++q) {
             const s16x8 bh = pack8(hh[2 * q], hh[2 * q + 1]);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) out[s] = mma(lds_a(sW2, MLP + 8, s * 16 + pl, 32 * q, g), bh, out[s]);
+            for (int s = 0; s < 2; ++s) out[s] = mma(lds_a(sW2, W2P, s * 16 + pl, 32 * q, g), bh, out[s]);
         }
         bf16* yr = p.y + row * D;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float r[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = out[s][j] + p.fb2[s * 16 + g * 4 + j] + x1[s][j];
+            for (int j = 0; j < 4; ++j) r[j] = out[s][j] + cfb2[s][j] + x1[s][j];
             st4(yr + s * 16 + g * 4, r);
         }
     }
@@ -226,27 +247,26 @@ template <int MLP> struct PL {
 };
 constexpr int lds_pitch(int row_bytes) { return ((row_bytes / 32) & 1) ? row_bytes : row_bytes + 32; }
 
-// transpose read: channel-sub `cs` of a wave-private [32 px][ch] bf16 tile -> fragment with k = pixels
-__device__ __forceinline__ s16x8 tile_frag(const unsigned char* tile, int pitch, int cs, int pl, int g) {
-    const unsigned char* base = tile + (g * 4 + (pl >> 2)) * pitch + (cs * 16 + (pl & 3) * 4) * 2;
-    U8 r;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 16 * pitch));
-    r.v = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return r.v;
-}
-// write a packed (kappa-ordered) 32-channel operand of pixel `pp` into a tile at channel offset c0
+// write a packed (kappa-ordered) 32-channel operand of pixel `pp` into a tile at channel offset c0.
+// The 8-byte units of a pixel row (4 channels each) are XOR-swizzled by (pixel >> 2) & 3 in their low two bits: the tile
+// pitches (96 / 160 bytes: odd multiples of 32, what ds_read_b64_tr_b16 wants) put the 16 pixel rows a ds_write_b64 lane group
+// writes (same g, pl = 0..15; banked modulo 32 dwords) on 4 bank groups, a 4-way conflict on every tile write -- 16 of them per
+// sub-tile; with the swizzle the four rows of one bank group take four different units: conflict-free.  The transpose reads
+// undo it in their address (a lane reads ONE unit of ONE row) and keep their own conflict-free pattern (a row's four units are
+// only permuted among the four lanes that read them).
 __device__ __forceinline__ void tile_put(unsigned char* tile, int pitch, int pp, int c0, int g, s16x8 v) {
     U8 r;
     r.v = v;
-    *reinterpret_cast<uint2*>(tile + pp * pitch + (c0 + g * 4) * 2) = r.h[0];
-    *reinterpret_cast<uint2*>(tile + pp * pitch + (c0 + 16 + g * 4) * 2) = r.h[1];
+    unsigned char* dst = tile + pp * pitch + (c0 + (g ^ ((pp >> 2) & 3)) * 4) * 2;
+    *reinterpret_cast<uint2*>(dst) = r.h[0];
+    *reinterpret_cast<uint2*>(dst + 32) = r.h[1];
 }
 
 // transpose read, K = 16: channel-sub `cs` of a wave-private [16 px][ch] bf16 tile -> fragment with k = the 16 pixels
 // (lane (pl, g): pixels g*4 .. g*4+3 of channel cs*16 + pl -- the operand layout of v_mfma_f32_16x16x16_bf16)
 __device__ __forceinline__ s16x4 tile_frag16(const unsigned char* tile, int pitch, int cs, int pl, int g) {
-    const unsigned char* base = tile + (g * 4 + (pl >> 2)) * pitch + (cs * 16 + (pl & 3) * 4) * 2;
+    // pixel row g * 4 + (pl >> 2): its swizzle key (row >> 2) & 3 is g (tile_put)
+    const unsigned char* base = tile + (g * 4 + (pl >> 2)) * pitch + (cs * 16 + ((pl & 3) ^ g) * 4) * 2;
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
 }
 __device__ __forceinline__ f32x4 mma16(s16x4 a, s16x4 b, f32x4 c) {
@@ -290,7 +310,8 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
     unsigned short* sW1 = sKqT + 32 * WP;                   // [MLP][32]
     unsigned short* sW2T = sW1 + MLP * WP;                  // [MLP][32]
     unsigned short* sW1T = sW2T + MLP * WP;                 // [32][MLP]
-    float* sPar = reinterpret_cast<float*>(sW1T + 32 * (MLP + 8));      // g1, be1, bo, g2, be2, fb1[MLP]: 5 * 32 + MLP floats
+    constexpr int W1TP = wide_pitch(MLP);
+    float* sPar = reinterpret_cast<float*>(sW1T + 32 * W1TP);           // g1, be1, bo, g2, be2, fb1[MLP]: 5 * 32 + MLP floats
     unsigned char* tiles = reinterpret_cast<unsigned char*>(sPar + 5 * 32 + MLP);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
     unsigned char* tA0 = tiles + (wv * 4 + 0) * TILE;
@@ -305,7 +326,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
     stage(sKqT, WP, p.kqT + (size_t)img * D * 32, D, 32, tid);
     stage(sW1, WP, p.w1, MLP, D, tid);
     stage(sW2T, WP, p.w2T, MLP, D, tid);
-    stage(sW1T, MLP + 8, p.w1T, D, MLP, tid);
+    stage(sW1T, W1TP, p.w1T, D, MLP, tid);
     if (tid < 32) {
         sPar[tid] = p.g1[tid]; sPar[32 + tid] = p.be1[tid]; sPar[64 + tid] = p.bo[tid];
         sPar[96 + tid] = p.g2[tid]; sPar[128 + tid] = p.be2[tid];
@@ -473,7 +494,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) dl2[s] = mma(lds_a(sW1T, MLP + 8, s * 16 + pl, 32 * q, g), kdz[q], dl2[s]);
+            for (int s = 0; s < 2; ++s) dl2[s] = mma(lds_a(sW1T, W1TP, s * 16 + pl, 32 * q, g), kdz[q], dl2[s]);
         DEC_T(5);
         // LayerNorm-2 backward (+ residual)
         float gh[2][4], sa = 0.f, sbb = 0.f, dx1[2][4];
@@ -723,7 +744,7 @@ __global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(const float* __re
 }
 
 template <int MLP> size_t bwd_lds_bytes() {
-    const size_t w = (size_t)(4 * 32 * WP + 2 * MLP * WP + 32 * (MLP + 8)) * 2 + (size_t)(5 * 32 + MLP) * 4;
+    const size_t w = (size_t)(4 * 32 * WP + 2 * MLP * WP + 32 * wide_pitch(MLP)) * 2 + (size_t)(5 * 32 + MLP) * 4;
     const size_t tile = 16 * (size_t)(lds_pitch(MLP * 2) > lds_pitch(64) ? lds_pitch(MLP * 2) : lds_pitch(64));
     size_t t = w + 16 * tile;                                 // four tiles per wave
     if (t < (size_t)PL<MLP>::SIZE * 4 * 4) t = (size_t)PL<MLP>::SIZE * 4 * 4;      // the four wave slots of the final combine

@@ -42,6 +42,7 @@ class GraphedTrainStep:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.exchange = parallel.exchange_enabled()      # gradient all-reduce + AdamW after the replay
         self.split_off = None                            # arena offset where the overlapped (two-graph) form splits
+        self.persist_bn_launches = None                  # (graph 1, graph 2) counts of the overlapped form
         self._set_inputs(a, b, lab)
         net._ensure_arena(a.device)
         # ---- snapshot the training state, warm up eagerly on a side stream, restore -------------------
@@ -76,10 +77,17 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         if split:
             self.graph2 = torch.cuda.CUDAGraph()
+            n0 = ops.BN_PERSIST_LAUNCHES
             with torch.cuda.graph(self.graph):
                 self.loss = self._split_first()
+            n1 = ops.BN_PERSIST_LAUNCHES
             with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
                 self._second()
+            # persistent BatchNorm launches recorded into (graph 1, graph 2): graph 2 replays beside RCCL's kernels and must hold none
+            self.persist_bn_launches = (n1 - n0, ops.BN_PERSIST_LAUNCHES - n1)
+            if self.persist_bn_launches[1]:
+                raise RuntimeError("dahitra_amd: %d persistent BatchNorm launches were recorded into the graph that overlaps the "
+                                   "gradient all-reduce" % self.persist_bn_launches[1])
         else:
             self.split_off = None
             with torch.cuda.graph(self.graph):

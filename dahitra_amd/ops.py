@@ -710,6 +710,7 @@ BN_BWD_PERSIST = os.environ.get("DAHITRA_NO_PERSIST_BN", "0") != "1"      # True
 if os.environ.get("DAHITRA_PERSIST_BN_FORCE", "0") == "1":
     BN_BWD_PERSIST = "force"
 _PERSIST_BLOCK = 0          # > 0: inside no_persist_bn() -- another stream may run beside the launches made here
+BN_PERSIST_LAUNCHES = 0     # persistent launches issued (or recorded into a graph) by this process: what tests assert the guard on
 
 
 class no_persist_bn:
@@ -767,6 +768,8 @@ def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accu
             (L.dh_bn_bwd_persist_preferred if BN_BWD_PERSIST is True else L.dh_bn_bwd_persist_supported)(
             _ci(dt(x)), _cl(npix), C, groups):
         # one persistent launch, tensors held on chip across a device-wide barrier: every tensor is read once
+        global BN_PERSIST_LAUNCHES
+        BN_PERSIST_LAUNCHES += 1
         with _Prof("bn_bwd", 0, _nb(dout, out_relu, x) + _nb(dx, dres)):
             _call("dh_bn_bwd_persist", P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
                   _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(mask_scale), P(mask_shift),

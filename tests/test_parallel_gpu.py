@@ -253,3 +253,70 @@ def test_bench_multi_gpu_code_path_runs_over_rccl_with_one_rank():
     assert dist_line["config"]["hip_graph"] is True
     a, b = dist_line["config"]["final_loss"], plain["config"]["final_loss"]
     assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (a, b)
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus 2` WITHOUT torchrun on this one-GPU box: it must not benchmark one GPU under an n_gpus = 2
+    label (and not print n_gpus = 1 either) -- non-zero exit, no JSON line, the reason on stderr.  With enough GPUs the same
+    command starts its own torchrun (covered by the driver's scaling run)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    have = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(have + 1), "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "--gpus %d" % (have + 1) in r.stderr and "%d GPU" % have in r.stderr
+    # a torchrun environment that disagrees with --gpus is refused as well (in either direction)
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def _bench_size_rank(out):
+    """one RCCL rank at the BENCH size (32 pairs, 256 x 256, bf16) through the overlapped two-graph step"""
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                      DAHITRA_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    from dahitra_amd import ops, parallel
+    from dahitra_amd.graph import GraphedTrainStep
+    from dahitra_amd.models.networks import define_G
+    from dahitra_amd.optim import AdamW
+    parallel.init_from_env("nccl")
+    res = {}
+    for name in (NAME, "newUNetTrans"):
+        torch.manual_seed(5)
+        net = define_G(types.SimpleNamespace(net_G=name, compute_dtype="bf16"), gpu_ids=[0]).train()
+        net.load_state_dict(O.deterministic_state(name))
+        a, b, lab = (t.cuda() for t in O.synthetic_batch(32, 256, seed=61))
+        opt = AdamW(net.parameters(), lr=1e-3, weight_decay=0.01, capturable=True)
+        step = GraphedTrainStep(net, opt, a, b, lab)
+        losses_ = [float(step()) for _ in range(4)]
+        torch.cuda.synchronize()
+        ops.bn_persist_check()
+        res[name] = dict(split=step.split_off, n_active=net._arena.n_active, persist=step.persist_bn_launches, losses=losses_,
+                         finite=bool(torch.isfinite(net._arena.flat).all()), steps=opt.step_count(net))
+    torch.save(res, out)
+    dist.barrier(device_ids=[0])
+    dist.destroy_process_group()
+
+
+def test_overlapped_step_at_bench_size_keeps_the_persistent_batchnorm_out_of_the_second_graph(tmp_path):
+    """configs[2]'s per-rank workload (32 pairs, bf16) through the data-parallel form bench.py times for N > 1 -- RCCL process
+    group, graph 1 | all-reduce of the arena tail beside graph 2 | all-reduce of the head | AdamW -- with one rank on this
+    box's one GPU.  At this size the persistent one-launch BatchNorm backward IS what graph 1 records (>= 24 MB tensors); graph
+    2, which replays while RCCL's kernels hold CUs, must record NONE (ops.no_persist_bn), and no barrier timeout may be left
+    behind after the replays."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res.pt")
+    mp.start_processes(_bench_size_rank, args=(out,), nprocs=1, join=True, start_method="spawn")
+    res = torch.load(out)
+    for name, r in res.items():
+        assert r["split"] is not None and 0 < r["split"] < r["n_active"], name
+        print(name, "persistent BatchNorm launches recorded into (graph 1, graph 2):", r["persist"])
+        assert r["persist"][1] == 0 and (r["persist"][0] > 0 or name != NAME), (name, r["persist"])
+        assert r["finite"] and r["steps"] == 4 and all(l == l and l > 0 for l in r["losses"]), (name, r)
+        assert r["losses"][-1] < r["losses"][0], (name, r["losses"])
