@@ -43,6 +43,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     a.phase_mode = phase_mode;
     a.y_nchw = nullptr;
     a.up4_partial = nullptr;
+    a.x_split = a.y_split = 0;
     a.w_frag = w_frag;
     DH_REQUIRE(!w_frag || (ks == 3 && w_image_stride == 0 && !phase_mode && dtype == DH_DTYPE_BF16 && Cin % 32 == 0 && CoutPad % 16 == 0),
                "conv2d_fwd: fragment-order weights exist for the bf16 3x3 layers only");
@@ -52,7 +53,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
         DH_REQUIRE(ks == 2 && stride == 1 && pad == 1 && dilation == 1 && (!residual || phase_mode == 1) && !stats_partial && !y_preact && !gate_y &&
                    !in_scale && w_image_stride == 0 && npix_valid == 0 && H == OH && W == OW && act != DH_ACT_GELU,
                    "conv2d_fwd: phase mode is a plain 2x2 pad-1 convolution on equal input / output grids");
-        DH_REQUIRE(phase_mode == 1 ? ((Cout == 128 || Cout == 256) && CoutPad == Cout) : (phase_mode == 2 && Cin == 128 && Cout % 64 == 0),
+        DH_REQUIRE(phase_mode == 1 ? ((Cout == 128 || Cout == 256) && CoutPad == Cout) : (phase_mode == 2 && Cin == 128 && (Cout % 64 == 0 || Cout == 32)),
                    "conv2d_fwd: phase mode %d with Cin=%d Cout=%d", phase_mode, Cin, Cout);
     }
     a.rw = pick_rw(N, OH, OW, Cin, ks, stride);
@@ -62,6 +63,47 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     if (dh_conv_wreg_eligible(a, ks, stride, dtype)) return dh_conv_wreg_launch(a, st);
     if (dtype == DH_DTYPE_BF16) return dh_conv_launch_bf16(a, ks, stride, st);
     return dh_conv_launch_f32(a, ks, stride, st);
+}
+
+// 3x3 / stride 1 / pad 1 convolution (bf16) over a channel concatenation that is never materialised, see ConvArgs::x_split /
+// y_split: conv_layer2_0 of the hierarchical model reads torch.cat([a_128, b_128], 1) (models/networks.py:1344) -- the two
+// temporal streams' stem outputs, which here are the two halves of one [2 N]-image tensor -- and its data gradient writes
+// the two halves of that tensor's gradient.  Without this the concatenation and its gradient cost four channel-copy passes
+// of 134 MB each per step at batch 32.  x_split_bytes / y_split_bytes: byte distance from the first to the second tensor
+// (0: plain tensor on that side).  No bias, residual or activation; stats_partial as dh_conv2d_fwd.  Served by the
+// register-resident-weights kernel only: dh_conv3x3_split_supported says whether a shape is (callers fall back to
+// dh_copy_channels + dh_conv2d_fwd otherwise).
+static bool split_conv_args(ConvArgs& a, const void* x, long x_split, const void* w_packed, const void* w_frag, void* y, long y_split,
+                            float* stats, int N, int H, int W, int Cin, int Cout) {
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w_packed; a.w_frag = w_frag; a.y = y; a.stats = stats;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W; a.Cout = Cout; a.CoutPad = Cout;
+    a.pad = 1; a.act = DH_ACT_NONE; a.npix = H * W; a.in_npix = H * W; a.dil = 1; a.gate_groups = 1; a.in_groups = 1;
+    a.x_split = x_split; a.y_split = y_split;
+    a.rw = pick_rw(N, H, W, Cin, 3, 1);
+    a.tilesX = dh_cdiv(W, TW); a.tilesY = dh_cdiv(H, 4 * a.rw);
+    return dh_conv_wreg_eligible(a, 3, 1, DH_DTYPE_BF16);
+}
+bool dh_wgrad_split_supported(int N, int H, int W, int Cin, int Cout);      // conv_wgrad.hip
+extern "C" int dh_conv3x3_split_supported(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin % 128 || Cout % 64) return 0;
+    ConvArgs a;
+    static unsigned char dummy[16];
+    // forward (split input), data gradient (split output, channel counts exchanged; both need the fragment-order weights)
+    if (!split_conv_args(a, dummy, 16, dummy, dummy, dummy, 0, nullptr, N, H, W, Cin, Cout)) return 0;
+    if (!split_conv_args(a, dummy, 0, dummy, dummy, dummy, 16, nullptr, N, H, W, Cout, Cin)) return 0;
+    return dh_wgrad_split_supported(N, H, W, Cin, Cout) ? 1 : 0;
+}
+extern "C" int dh_conv3x3_split_fwd(const void* x, long x_split_bytes, const void* w_packed, const void* w_frag, void* y,
+                                    long y_split_bytes, float* stats_partial, int N, int H, int W, int Cin, int Cout, void* stream) {
+    DH_REQUIRE(x && w_packed && y && N > 0 && (x_split_bytes || y_split_bytes), "conv3x3_split_fwd: bad arguments");
+    DH_REQUIRE((!x_split_bytes || Cin % 128 == 0) && (!y_split_bytes || Cout % 128 == 0) && x_split_bytes % 16 == 0 && y_split_bytes % 16 == 0,
+               "conv3x3_split_fwd: a split side needs a multiple of 128 channels (Cin=%d Cout=%d) and 16-byte aligned tensors", Cin, Cout);
+    ConvArgs a;
+    if (!split_conv_args(a, x, x_split_bytes, w_packed, w_frag, y, y_split_bytes, stats_partial, N, H, W, Cin, Cout))
+        DH_FAIL("conv3x3_split_fwd: %d x %dx%d, %d -> %d channels is outside the register-resident-weights kernel "
+                "(dh_conv3x3_split_supported)", N, H, W, Cin, Cout);
+    return dh_conv_wreg_launch(a, reinterpret_cast<hipStream_t>(stream));
 }
 
 // The class head (3x3, pad 1, <= 16 classes) with fp32 NCHW logits written by the convolution itself: see ConvArgs::y_nchw.

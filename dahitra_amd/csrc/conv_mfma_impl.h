@@ -96,6 +96,11 @@ struct ConvArgs {
     // from (align_corners = False: fine row o reads coarse rows floor((o + 0.5) / 4 - 0.5) and the next, clamped) and the
     // per-tile partial [tile][4][6][Cout] goes to up4_partial; dh_absdiff_up4_combine sums the <= 4 tiles of a coarse pixel.
     float* up4_partial;
+    // Channel concatenation WITHOUT the concatenated tensor (conv_wreg.hip only; dh_conv3x3_split_fwd).  x_split != 0: the input
+    // is cat([A, B], channel) of two [N][H][W][Cin / 2] tensors, A at x and B at x + x_split bytes (torch.cat([a_128, b_128], 1),
+    // models/networks.py:1344: the two temporal streams are the two halves of ONE [2N] batch).  y_split != 0: the output's
+    // channel halves go to two [N][OH][OW][Cout / 2] tensors, y and y + y_split bytes (the data gradient of such a layer).
+    long x_split, y_split;
 };
 
 namespace {
@@ -659,7 +664,7 @@ template <typename T, int KS, int STRIDE>
 int launch_nt(const ConvArgs& a, hipStream_t st) {
     if constexpr (KS == 2) {      // the phase convolutions: forward = one cout block (32 or 64 channels) per phase
         if (a.phase_mode == 1) return a.Cout == 128 ? launch<T, KS, STRIDE, 32>(a, st) : launch<T, KS, STRIDE, 64>(a, st);
-        return launch<T, KS, STRIDE, 64>(a, st);
+        return a.Cout % 64 ? launch<T, KS, STRIDE, 32>(a, st) : launch<T, KS, STRIDE, 64>(a, st);     // data gradient: Cout = the 3x3's Cin
     }
     if (a.CoutPad % 64 == 0) return launch<T, KS, STRIDE, 64>(a, st);
     if (a.CoutPad % 32 == 0) return launch<T, KS, STRIDE, 32>(a, st);

@@ -47,6 +47,9 @@ struct WgArgs {
     const void* dyt_y;          // pre-normalisation convolution output, same layout as dy
     const float* dytoef;      // [dyt_groups][3][Cout]
     int dyt_groups;
+    // x = cat([A, B], channel) of two [N][H][W][Cin / 2] tensors, B at x + x_split bytes (0: off), never materialised
+    // (ConvArgs::x_split; wave-specialised kernel only: a 64-channel ci tile lies in one of the two)
+    long x_split;
 };
 
 constexpr int lds_pitch(int row_bytes) { return ((row_bytes / 32) & 1) ? row_bytes : row_bytes + 32; }
@@ -636,7 +639,10 @@ __device__ __forceinline__ void ws_body(const WgArgs& p, int bx, int kz, const i
             x_h[i] = px < HH * HWD ? ((px / HWD) << 8) | (px % HWD) : -1;
         }
         const unsigned xps = (unsigned)p.CinPitch * 2u, dps = (unsigned)p.Cout * 2u;
-        const unsigned xcb = (unsigned)(ci0 + q * 8) * 2u, dcb = (unsigned)(co0 + q * 8) * 2u;
+        // split input: this ci tile's 64 channels lie in ONE of the two tensors (CinPitch = Cin / 2 channels per pixel)
+        const bool upper = p.x_split && ci0 >= p.Cin / 2;
+        const long xsel = upper ? p.x_split : 0L;
+        const unsigned xcb = (unsigned)((upper ? ci0 - p.Cin / 2 : ci0) + q * 8) * 2u, dcb = (unsigned)(co0 + q * 8) * 2u;
         const int dn = p.splitk / tiles_per_img, drem = p.splitk % tiles_per_img;
         const int dty = drem / p.tilesX, dtx = drem % p.tilesX;
         int f_n = kz / tiles_per_img, f_ty = (kz % tiles_per_img) / p.tilesX, f_tx = (kz % tiles_per_img) % p.tilesX;
@@ -644,7 +650,7 @@ __device__ __forceinline__ void ws_body(const WgArgs& p, int bx, int kz, const i
             const int n = f_n;
             R.bng = p.in_scale ? n / (p.N / p.in_groups) : 0;
             const int oy0 = f_ty * TH, ox0 = f_tx * TW, iy0 = oy0 - p.pad, ix0 = ox0 - p.pad;
-            const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x) + (size_t)n * p.H * p.W * xps;
+            const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x) + xsel + (size_t)n * p.H * p.W * xps;
             const unsigned char* db = reinterpret_cast<const unsigned char*>(p.dy) + (size_t)n * p.OH * p.OW * dps;
             R.okmask = 0;
 #pragma unroll
@@ -823,7 +829,8 @@ int launch_ws(const WgArgs& a, hipStream_t st) {
 static inline bool ws_eligible(const WgArgs& a, int ks, int stride, bool bf16, bool tr) {
     static const bool off = getenv("DAHITRA_WGRAD_NO_WS") != nullptr;
     return !off && bf16 && tr && ks == 3 && stride == 1 && a.groups == 1 && !a.phase_mode && !a.dyt_y && a.Cin % 64 == 0 &&
-           a.Cout % 64 == 0 && a.CoutUse == a.Cout && a.CinPitch == a.Cin && a.npix == a.OH * a.OW && a.in_npix == a.H * a.W &&
+           a.Cout % 64 == 0 && a.CoutUse == a.Cout && a.npix == a.OH * a.OW && a.in_npix == a.H * a.W &&
+           (a.x_split ? (a.CinPitch * 2 == a.Cin && a.Cin % 128 == 0 && a.in_scale == nullptr) : a.CinPitch == a.Cin) &&
            (a.in_scale == nullptr || a.in_groups <= 8);
 }
 
@@ -1055,10 +1062,11 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
                              int groups, int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation,
                              void* workspace, void* stream, int defer, int* splitk_out, const float* in_scale = nullptr,
                              const float* in_shift = nullptr, int in_groups = 1, const void* dyt_y = nullptr,
-                             const float* dytoef = nullptr, int dyt_groups = 1) {
+                             const float* dytoef = nullptr, int dyt_groups = 1, long x_split = 0) {
     DH_REQUIRE(groups == 1 || (groups == N && ks == 1), "conv2d_wgrad: groups must be 1 or N (with ks=1)");
     WgArgs a;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
+    a.x_split = x_split;
     DH_REQUIRE(dilation == 1 || (dilation == 2 && ks == 3 && stride == 1), "conv2d_wgrad: dilation %d unsupported here", dilation);
     a.dil = dilation;
     a.phase_mode = 0;
@@ -1079,6 +1087,11 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
     a.npix = npix_valid > 0 ? npix_valid : OH * OW;
     a.in_npix = npix_valid > 0 ? npix_valid : H * W;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (x_split) {
+        a.ci_tiles = dh_cdiv(Cin, 64);
+        DH_REQUIRE(dtype == DH_DTYPE_BF16 && ws_eligible(a, ks, stride, true, use_tr != 0) && wide_ci3x3(Cin, a.CoutUse, ks),
+                   "conv2d_wgrad: a split input is served by the wave-specialised 3x3 kernel only (Cin=%d Cout=%d ks=%d)", Cin, Cout, ks);
+    }
     const bool batching = g_wsb.on;
     if (!defer) g_wsb.on = false;           // this call reduces right after its launch: never recorded into a batch
     int rc = dtype == DH_DTYPE_BF16 ? launch_all<bf16>(a, ks, stride, use_tr != 0, st)
@@ -1131,6 +1144,22 @@ extern "C" int dh_conv2d_wgrad_partial(int dtype, const void* x, const void* dy,
     DH_REQUIRE(groups == 1 && splitk_out, "conv2d_wgrad_partial: one group only");
     return conv2d_wgrad_impl(dtype, x, dy, dw_oihw, accumulate, N, H, W, Cin, OH, OW, Cout, ks, stride, pad, groups,
                              npix_valid, use_tr, Cout_real, cin_pitch, dilation, workspace, stream, 1, splitk_out);
+}
+// dh_conv2d_wgrad_partial for a 3x3 / stride 1 / pad 1 layer whose input is cat([A, B], channel) of two [N][H][W][Cin / 2]
+// tensors, A at x and B at x + x_split_bytes, never materialised (see dh_conv3x3_split_fwd; models/networks.py:1344).
+bool dh_wgrad_split_supported(int N, int H, int W, int Cin, int Cout) {
+    WgArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dil = 1; a.in_groups = 1; a.dyt_groups = 1;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W; a.Cout = Cout; a.CoutUse = Cout; a.pad = 1; a.groups = 1;
+    a.CinPitch = Cin / 2; a.x_split = 16; a.npix = H * W; a.in_npix = H * W;
+    return ws_eligible(a, 3, 1, true, true) && wide_ci3x3(Cin, Cout, 3);
+}
+extern "C" int dh_conv2d_wgrad_split(const void* x, long x_split_bytes, const void* dy, float* dw_oihw, int accumulate, int N, int H,
+                                     int W, int Cin, int Cout, void* workspace, int* splitk_out, void* stream) {
+    DH_REQUIRE(x_split_bytes > 0 && x_split_bytes % 16 == 0 && Cin % 128 == 0 && splitk_out, "conv2d_wgrad_split: bad arguments (Cin=%d)", Cin);
+    return conv2d_wgrad_impl(DH_DTYPE_BF16, x, dy, dw_oihw, accumulate, N, H, W, Cin, H, W, Cout, 3, 1, 1, 1, 0, 1, 0, Cin / 2, 1,
+                             workspace, stream, 1, splitk_out, nullptr, nullptr, 1, nullptr, nullptr, 1, x_split_bytes);
 }
 // dh_conv2d_wgrad / dh_conv2d_wgrad_partial (splitk_out != NULL: deferred) with BatchNorm-apply + ReLU on the load of x:
 // x is the PRE-normalisation output of the previous convolution, the gradient is taken against
@@ -1190,6 +1219,7 @@ extern "C" int dh_conv2d_wgrad_phase(int dtype, const void* x, const void* dy, i
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.OH = H; a.OW = W; a.Cout = 32; a.pad = 1;
     a.tilesX = dh_cdiv(W, TW); a.tilesY = dh_cdiv(H, TH);
     a.CoutUse = 32;
+    a.x_split = 0;
     a.groups = 1; a.splitk = phase_splitk(N, H, W, Cin);
     a.direct = 0;
     a.npix = H * W; a.in_npix = H * W;

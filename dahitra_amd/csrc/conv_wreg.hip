@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
     const int cb = qb % a.ncb, j0 = (qb / a.ncb) * 8 + xcd;
     const int co_w = cb * NCO + wv * 16 * NSUB;            // first output channel of this wave
     const int Cin = p.Cin;
+    const int xps = p.x_split ? Cin : Cin * 2;             // bytes per pixel of an input tensor (split input: Cin / 2 channels each)
 
     // ---- this wave's weights: [sub][chunk][tap] fragments, 16 bytes per lane each, loaded once ----
     s16x8 A[NSUB][NCH][9];
@@ -185,23 +186,25 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
         const int u = j0 + (k / a.subt) * a.J, half = k % a.subt;
         const int tx = u % a.tilesX, r = u / a.tilesX, uy = r % a.unitsY, n = r / a.unitsY;
         t.n = n; t.oy0 = (uy * a.subt + half) * WR_TH; t.ox0 = tx * TW;
-        t.img = reinterpret_cast<const unsigned char*>(p.x) + (size_t)n * p.H * p.W * Cin * 2;
+        t.img = reinterpret_cast<const unsigned char*>(p.x) + (size_t)n * p.H * p.W * xps;
         auto piece = [&](int code) {
             code = wr_opaque(code);
             const int hy = (code >> 8) & 0xff, hx = code & 0xff, q = (code >> 16) & 3;
             const int iy = t.oy0 - 1 + hy, ix = t.ox0 - 1 + hx;
             const bool ok = code >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            return ok ? (unsigned)(iy * p.W + ix) * (unsigned)(Cin * 2) + q * 16 : ~0u;
+            return ok ? (unsigned)(iy * p.W + ix) * (unsigned)xps + q * 16 : ~0u;
         };
         t.o0 = piece(hyx[0]); t.o1 = piece(hyx[1]); t.o2 = piece(hyx[2]);
     };
     // loads of chunk image `c` of tile t into ring slot `slot`: WR_NI instructions per wave.  EVERY lane of EVERY wave issues
     // EVERY instruction (padding and past-the-end pieces read the zero block), so the number of loads in flight is a
-    // compile-time constant at every wait.
+    // compile-time constant at every wait.  Split input (ConvArgs::x_split): the chunks of the upper channel half come from the
+    // second tensor -- the same pixel offsets (both have Cin / 2 channels per pixel) from another, uniform, base.
     auto issue = [&](const WrTile& t, int c, int slot) {
+        const long coff = (NCH >= 2 && p.x_split && c >= NCH / 2) ? p.x_split + (c - NCH / 2) * 64 : (long)c * 64;
 #pragma unroll
         for (int i = 0; i < WR_NI; ++i) {
-            const unsigned char* src = t.off(i) != ~0u ? t.img + t.off(i) + c * 64 : reinterpret_cast<const unsigned char*>(wr_zero);
+            const unsigned char* src = t.off(i) != ~0u ? t.img + t.off(i) + coff : reinterpret_cast<const unsigned char*>(wr_zero);
             wr_glds16(src, ring_lds + slot * WR_IMG + (i * 4 + wv) * 1024);
         }
     };
@@ -370,9 +373,12 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wreg_kernel(WrArgs a) {
         ehold = *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
     };
     auto epi_store = [&](int it) {
-        bf16* yout = reinterpret_cast<bf16*>(p.y) + (size_t)en * p.OH * p.OW * p.Cout;
+        // split output (ConvArgs::y_split): this workgroup's channel block lies in one of two [N][OH][OW][Cout / 2] tensors
+        const int half = p.Cout >> 1, upper = (p.y_split && cb * NCO >= half) ? 1 : 0;
+        const int ypitch = p.y_split ? half : p.Cout, cbase = cb * NCO - upper * half;
+        bf16* yout = reinterpret_cast<bf16*>(reinterpret_cast<unsigned char*>(p.y) + (upper ? p.y_split : 0L)) + (size_t)en * p.OH * p.OW * ypitch;
         const int i = wr_opaque(tid) + it * 256, px = i / PPR, q = i - px * PPR;
-        *reinterpret_cast<uint4*>(yout + (size_t)((eoy0 + (px >> 4)) * p.OW + eox0 + (px & 15)) * p.Cout + cb * NCO + q * 8) = ehold;
+        *reinterpret_cast<uint4*>(yout + (size_t)((eoy0 + (px >> 4)) * p.OW + eox0 + (px & 15)) * ypitch + cbase + q * 8) = ehold;
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -793,6 +799,7 @@ bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     if (off || g_wreg_mode == 0 || dtype != DH_DTYPE_BF16 || ks != 3 || stride != 1 || a.dil != 1 || a.pad != 1) return false;
     if (a.Cin == 32) {
         // the 32 -> 32 kernel: no BatchNorm on load, whole 8x16 tiles, 8-row statistics units, enough tiles for its 768 streams
+        if (a.x_split || a.y_split) return false;
         if (a.Cout != 32 || a.CoutPad != 32 || a.in_scale || a.rw != 2 || a.phase_mode || a.gate_y || a.y2 || a.y_nchw || a.w_nstride ||
             a.up4_partial || a.act == DH_ACT_GELU)
             return false;
@@ -804,6 +811,7 @@ bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     if (a.act == DH_ACT_GELU || a.npix != a.OH * a.OW || a.in_npix != a.H * a.W || a.OH != a.H || a.OW != a.W) return false;
     if (a.OH % (a.rw == 4 ? 16 : 8) || a.OW % 16) return false;
     if (a.in_scale && (a.in_groups > 4 || a.res || a.act == DH_ACT_RELU)) return false;
+    if ((a.x_split && (a.Cin % 128 || a.in_scale)) || (a.y_split && (a.Cout % 128 || a.res))) return false;   // halves = whole chunks / blocks
     if (g_wreg_mode != 1) {
         // measured (tools/wreg_bench.py, 64 images, gpurun_out/wreg_bench_{9,10}*.txt): the shapes on which this kernel is the
         // faster one -- the 64-channel layers (x1.16 with BatchNorm on load, x1.26 - 1.30 without) and, given the

@@ -195,7 +195,10 @@ __global__ void augment_pairs_u8_kernel(const unsigned char* __restrict__ a, con
 // mask is recomputed from y (y * mscale + mshift > 0), the MASKED gradient is stored and the per-workgroup partial sums
 // (sum g, sum g * xhat) of that BatchNorm's backward are emitted, [2][32][gridDim.x] -- the separate reduction pass over (g, y)
 // (268 MB at the bench size) disappears (dh_bn_bwd_from_partials does the rest).  A workgroup stays inside one statistics group.
-template <bool GATE>
+// RELUREF (without GATE): the 32 channels are the output of a ReLU whose result `gy` is at hand (conv_layer2 of the
+// hierarchical model, models/networks.py:1351-1355): the gradient is stored already masked (gy > 0), and the separate
+// activation-backward pass over (gradient, output) -- 402 MB at the bench size -- disappears.
+template <bool GATE, bool RELUREF = false>
 __global__ __launch_bounds__(256) void head_dgrad3x3_mfma_kernel(const bf16* __restrict__ dy, const float* __restrict__ w_oihw,
                                                                  bf16* __restrict__ dx, int N, int H, int W, int NC,
                                                                  const bf16* __restrict__ gy, const float* __restrict__ mscale,
@@ -262,6 +265,12 @@ __global__ __launch_bounds__(256) void head_dgrad3x3_mfma_kernel(const bf16* __r
                         s1[s][j] += r[j];
                         s2[s][j] += r[j] * ((yv[j] - cm[s][j]) * ci[s][j]);
                     }
+                }
+                if constexpr (RELUREF && !GATE) {
+                    float yv[4];
+                    ld4(gy + px * 32 + s * 16 + g * 4, yv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[j] = yv[j] > 0.f ? r[j] : 0.f;
                 }
                 st4(dx + px * 32 + s * 16 + g * 4, r);
             }
@@ -1007,6 +1016,20 @@ extern "C" int dh_head_dgrad3x3(int dtype, const void* dy, int CP, const float* 
         hipLaunchKernelGGL((head_dgrad3x3_kernel<float, 8>), dim3(grid), dim3(256), 0, ST(stream), (const float*)dy, w_oihw, (float*)dx, N, H, W, NC);
     }
     DH_CHECK_LAUNCH("head_dgrad3x3");
+    return 0;
+}
+// dh_head_dgrad3x3 for a head that sits behind a ReLU (bf16, n_class <= 2, dy one 16-byte piece per pixel): relu_out
+// [N][H][W][32] is that ReLU's output, dx = (relu_out > 0) * gradient -- the activation's backward folded into this kernel.
+extern "C" int dh_head_dgrad3x3_relu(const void* dy, const float* w_oihw, int NC, const void* relu_out, void* dx, int N, int H,
+                                     int W, void* stream) {
+    DH_REQUIRE(NC >= 1 && NC <= 2 && dy && relu_out && dx, "head_dgrad3x3_relu: bad arguments (n_class=%d)", NC);
+    const long groups = ((long)N * H * W + 15) / 16;
+    long g = (groups * 64 + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL((head_dgrad3x3_mfma_kernel<false, true>), dim3((int)g), dim3(256), 0, ST(stream), (const bf16*)dy, w_oihw,
+                       (bf16*)dx, N, H, W, NC, (const bf16*)relu_out, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, 1, (float*)nullptr);
+    DH_CHECK_LAUNCH("head_dgrad3x3_relu");
     return 0;
 }
 // The gated form (see head_dgrad3x3_mfma_kernel<true>): bf16, n_class <= 2, dy one 16-byte piece per pixel.  g: masked

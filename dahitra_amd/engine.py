@@ -84,6 +84,10 @@ class Engine:
         # data gradient of the 3x3 stride-2 convolutions as four output-parity phase convolutions over dY instead of a
         # stride-1 convolution over the zero-inserted dY (4x the pixels, 75 % zeros)
         self.phase_s2_dgrad = os.environ.get("DAHITRA_NO_PHASE_S2", "0") != "1"
+        # the UNet up path's relu(conv3x3(nearest-upsample-x2(x))) (32 -> 32 channels) in the same phase form (_up_conv)
+        self.phase_up_conv = os.environ.get("DAHITRA_NO_PHASE_UPCONV", "0") != "1"
+        # conv_layer2_0 reads cat([a_128, b_128], 1) in place (ops.SplitCat) instead of through two channel copies each way
+        self.split_cat = os.environ.get("DAHITRA_NO_SPLIT_CAT", "0") != "1"
         # bf16: the 7x7/2 stem as one kernel on the NCHW fp32 images (csrc/stem.hip) instead of space-to-depth + 4x4 conv
         self.direct_stem = os.environ.get("DAHITRA_NO_DIRECT_STEM", "0") != "1"
         # ... and its backward without a BatchNorm pass: reduction fused into the max-pool backward, apply into the weight gradient
@@ -148,6 +152,9 @@ class Engine:
                 continue        # consumed in fp32 by the tokenizer kernels, or unused by the forward
             if key == "conv_pred.weight" and self.phase_conv_pred and shape[1] % 64 == 0 and self.cfg["kind"] == "bit":
                 continue        # packed in its 2x2 phase form by conv_pred_phase
+            if self.phase_up_conv and key in ("conv_layer2.0.weight", "conv_layer3.0.weight", "conv_layer4.0.weight") and \
+                    tuple(shape[:2]) == (32, 32):
+                continue        # packed in its 2x2 phase form by _up_conv
             if ".to_q." in key or ".to_k." in key or ".to_v." in key or \
                     (".to_out." in key and "transformer_decoder" in key):
                 # cross-attention weights: the token-side prep reads their transposes (coalesced).  The transposes of
@@ -219,9 +226,15 @@ class Engine:
         gamma, beta = self.p[bnkey + ".weight"], self.p[bnkey + ".bias"]
         rm, rv = self.p[bnkey + ".running_mean"], self.p[bnkey + ".running_var"]
         act = RELU if relu else NONE
+        split = isinstance(x, ops.SplitCat)          # cat([A, B], channel) read in place (3x3 / stride 1, train mode, bf16)
+        if split and not (self.training and ks == 3 and stride == 1 and pad == 1 and dilation == 1 and residual is None):
+            x, split = x.materialize(), False
         if self.training:
-            y, st = ops.conv2d(x, self.pk[wkey].fwd, cout, ks, stride, pad, want_stats=True, dilation=dilation,
-                               w_frag=self.pk[wkey].fwd_frag if stride == 1 else None)
+            if split:
+                y, st = ops.conv3x3_split(x, self.pk[wkey].fwd, self.pk[wkey].fwd_frag, cout, want_stats=True)
+            else:
+                y, st = ops.conv2d(x, self.pk[wkey].fwd, cout, ks, stride, pad, want_stats=True, dilation=dilation,
+                                   w_frag=self.pk[wkey].fwd_frag if stride == 1 else None)
             N, OH, OW, _ = y.shape
             mean, invstd, scale, shift = ops.bn_finalize(st, cout, groups, (N // groups) * OH * OW, gamma, beta, rm, rv,
                                                          BN_MOMENTUM, BN_EPS, nbt=self.p[bnkey + ".num_batches_tracked"])
@@ -261,6 +274,12 @@ class Engine:
                                  dilation=dilation)
             if through_up4 is not None:
                 return ops.conv3x3_dgrad_through_up4(dy, self.pk[wkey].dgrad, *through_up4), dres
+            if split and need_dx:
+                # the gradient of the concatenation, as the two batch halves of ONE [2B, H, W, C / 2] tensor (ops.SplitCat)
+                assert dx_res is None and next_gate is None and not coarse_dx
+                cin = x.shape[-1]
+                return ops.conv3x3_split(dy, self.pk[wkey].dgrad, self.pk[wkey].dgrad_frag, cin, split_out=True,
+                                         alg_flops=2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * cout * cin * 9), dres
             dx = self.conv_dgrad(dy, wkey, ks, stride, pad, x.shape, residual=dx_res, dilation=dilation,
                                  gate=next_gate, coarse=coarse_dx) if need_dx else None
             return dx, dres
@@ -276,8 +295,8 @@ class Engine:
         if not self.need_grad:
             return out, None
 
-        def bwd(dout, need_dx=True, dx_res=None):
-            dy = ops.act_bwd(dout, out, RELU) if act == RELU else dout
+        def bwd(dout, need_dx=True, dx_res=None, masked=False):
+            dy = ops.act_bwd(dout, out, RELU) if (act == RELU and not masked) else dout
             ops.conv2d_wgrad(x, dy, self.g[wkey], ks, 1, pad, accumulate=True, use_tr=self.use_tr)
             if bkey:
                 ops.colsum(dy.view(-1, cout), self.g[bkey], accumulate=True)
@@ -818,7 +837,8 @@ class Engine:
         small = 8 if (self.dtype == torch.bfloat16 or ncls > 4) else 4          # channels of one 16-byte piece
         direct = h.shape[-1] == 32 and ncls <= small
 
-        def bwd(dl_nchw, next_gate=None, head_bn=None):
+        def bwd(dl_nchw, next_gate=None, head_bn=None, relu_out=None):
+            """relu_out: `h` is the output of a ReLU (the tensor itself): the returned gradient is already masked by it"""
             if direct and next_gate is None:
                 # n_class (2..5) real channels: keep dlogits at ONE 16-byte piece per pixel instead of padding them to
                 # a 32-channel K-chunk (4x the bytes, written and read twice), and take the data gradient with the
@@ -831,13 +851,14 @@ class Engine:
                 if head_bn is not None and self.gated_head_dgrad and self.dtype == torch.bfloat16 and ncls <= 2:
                     # the BatchNorm behind these 32 channels: mask + reduction here, only its apply pass remains
                     return Gated(*ops.head_dgrad3x3_bn(dl, self.p[wkey], ncls, *head_bn))
-                return ops.head_dgrad3x3(dl, self.p[wkey], ncls)
+                return ops.head_dgrad3x3(dl, self.p[wkey], ncls, relu_out=relu_out)
             dl = ops.nchw_to_nhwc(dl_nchw, self.dtype, cpad=ck)          # channels zero-padded to one K-chunk
             ops.conv2d_wgrad(h, dl, self.g[wkey], 3, 1, 1, accumulate=True, use_tr=self.use_tr, cout_real=ncls)
             tmp = torch.empty(ck, dtype=torch.float32, device=h.device)
             ops.colsum(dl.view(-1, ck), tmp)
             ops.reduce_rows(tmp, 1, ncls, self.g[bkey], accumulate=True)
-            return self.conv_dgrad(dl, wkey, 3, 1, 1, h.shape, gate=next_gate)
+            dh = self.conv_dgrad(dl, wkey, 3, 1, 1, h.shape, gate=next_gate)
+            return ops.act_bwd(dh, relu_out, RELU) if relu_out is not None else dh
         return out, bwd
 
     def _bit(self, x1, x2):
@@ -1036,11 +1057,29 @@ class Engine:
         return out4, bwd
 
     def _up_conv(self, l, x):
-        up = ops.upsample2(x)
-        out, b = self.conv_act(up, "conv_layer%d.0.weight" % l, "conv_layer%d.0.bias" % l, 3, 1, RELU)
+        """relu(conv_layer<l>(nearest-upsample-x2(x))) (models/networks.py:1341-1351).  Default: the four 2x2 phase convolutions
+        of conv_pred_phase on x itself -- the upsampled tensor (134 MB at 256 x 256, batch 32) is neither written nor read, by
+        the forward, the data gradient or the weight gradient, and the matrix work is 2.25x smaller.  DAHITRA_NO_PHASE_UPCONV=1:
+        upsample kernel + 3x3 convolution."""
+        wkey, bkey = "conv_layer%d.0.weight" % l, "conv_layer%d.0.bias" % l
+        if not (self.phase_up_conv and x.shape[-1] == 32 and self.shapes[wkey][0] == 32):
+            up = ops.upsample2(x)
+            out, b = self.conv_act(up, wkey, bkey, 3, 1, RELU)
+            if not self.need_grad:
+                return out, None
+            return out, (lambda d, masked=False: ops.upsample2_bwd(b(d, masked=masked)))
+        wf, wd, b4 = ops.pack_phase_weights(self.p[wkey], self.p[bkey], self.dtype)
+        out = ops.conv_up2_fwd(x, wf, b4, act=RELU)
         if not self.need_grad:
             return out, None
-        return out, (lambda d: ops.upsample2_bwd(b(d)))
+
+        def bwd(dout, masked=False):
+            """masked: dout already carries this layer's ReLU mask (the class head's data gradient applied it)"""
+            dy = dout if masked else ops.act_bwd(dout, out, RELU)
+            ops.conv_up2_wgrad(x, dy, self.g[wkey], accumulate=True, use_tr=self.use_tr)
+            ops.colsum(dy.view(-1, 32), self.g[bkey], accumulate=True)
+            return ops.conv_up2_dgrad(dy, wd, 32)
+        return out, bwd
 
     def _unet(self, x1, x2):
         B = x1.shape[0]
@@ -1056,10 +1095,14 @@ class Engine:
         o4, bu4 = self._up_conv(4, ops.add(t4, o5u))
         o3, bu3 = self._up_conv(3, ops.add(t3, o4))
         _, h2, w2, c2 = s2.shape
-        cat2 = torch.empty(B, h2, w2, 2 * c2, dtype=self.dtype, device=s2.device)
-        ops.copy_channels(s2[:B], 0, cat2, 0, c2)
-        ops.copy_channels(s2[B:], 0, cat2, c2, c2)
-        y, b20 = self.conv_bn(cat2, "conv_layer2_0.0.weight", "conv_layer2_0.1", 3, 1, 1, 1, True, lazy=True)
+        # cat([a_128, b_128], 1) (networks.py:1344) is read IN PLACE by conv_layer2_0.0, its weight gradient, and written in
+        # place by its data gradient (ops.SplitCat: the two streams are the halves of s2); otherwise two channel copies each way
+        k20 = "conv_layer2_0.0.weight"
+        split2 = self.split_cat and self.training and self.pk[k20].fwd_frag is not None and \
+            (not self.need_grad or self.pk[k20].dgrad_frag is not None) and \
+            ops.conv3x3_split_supported(B, h2, w2, 2 * c2, self.shapes[k20][0], self.dtype)
+        cat2 = ops.SplitCat(s2) if split2 else ops.SplitCat(s2).materialize()
+        y, b20 = self.conv_bn(cat2, k20, "conv_layer2_0.1", 3, 1, 1, 1, True, lazy=True)
         y2 = ops.conv2d(y, self.pk["conv_layer2_0.3.weight"].fwd, 32, 3, 1, 1, bias=self.p["conv_layer2_0.3.bias"],
                         residual=o3)
         o2, bu2 = self._up_conv(2, y2)
@@ -1069,15 +1112,18 @@ class Engine:
 
         def bwd_first(dl):
             """head, top-down path and the three levels: everything whose parameters sit behind the trunk in the arena"""
-            do2 = b_out(dl)
-            dy2 = bu2(do2)                                     # grad of (conv_layer2_0 out + o3)
+            do2 = b_out(dl, relu_out=o2)                       # (the ReLU of conv_layer2 applied to the gradient in that kernel)
+            dy2 = bu2(do2, masked=True)                        # grad of (conv_layer2_0 out + o3)
             ops.conv2d_wgrad(y, dy2, self.g["conv_layer2_0.3.weight"], 3, 1, 1, accumulate=True, use_tr=self.use_tr)
             ops.colsum(dy2.view(-1, 32), self.g["conv_layer2_0.3.bias"], accumulate=True)
             dy = self.conv_dgrad(dy2, "conv_layer2_0.3.weight", 3, 1, 1, y.shape, gate=b20.gate)
             dcat2, _ = b20(dy)
-            ds2 = torch.empty_like(s2)
-            ops.copy_channels(dcat2, 0, ds2[:B], 0, c2)
-            ops.copy_channels(dcat2, c2, ds2[B:], 0, c2)
+            if split2:
+                ds2 = dcat2                                    # already the [2B, H, W, c2] gradient of s2's two halves
+            else:
+                ds2 = torch.empty_like(s2)
+                ops.copy_channels(dcat2, 0, ds2[:B], 0, c2)
+                ops.copy_channels(dcat2, c2, ds2[B:], 0, c2)
             dsum3 = bu3(dy2)                                   # d(t3 + o4)
             dsum4 = bu4(dsum3)                                 # d(t4 + o5u)
             ds4, ds8, ds16 = self._run_staged([b3(dsum3), b4(dsum4), b5(ops.upsample2_bwd(dsum4))])

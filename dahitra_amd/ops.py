@@ -5,6 +5,7 @@ produced by a kernel of libdahitra_hip.so.  All activations are NHWC tensors of 
 (parity mode) or bfloat16 (throughput mode)."""
 import ctypes
 import os
+import sys
 
 import torch
 
@@ -410,6 +411,68 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     return out[0] if len(out) == 1 else tuple(out)
 
 
+class SplitCat:
+    """torch.cat([t[:B], t[B:]], channel) of a [2B, H, W, C] tensor WITHOUT the concatenated tensor (models/networks.py:1344:
+    cat([a_128, b_128], 1) -- the two temporal streams are the two halves of one batch here).  conv3x3_split / conv2d_wgrad
+    read the two halves in place; `.shape` is the shape the concatenation would have."""
+    __slots__ = ("t", "B")
+
+    def __init__(self, t):
+        assert t.dim() == 4 and t.shape[0] % 2 == 0 and t.is_contiguous()
+        self.t, self.B = t, t.shape[0] // 2
+
+    @property
+    def shape(self):
+        n, h, w, c = self.t.shape
+        return torch.Size((n // 2, h, w, 2 * c))
+
+    @property
+    def split_bytes(self):
+        return self.t[self.B:].data_ptr() - self.t.data_ptr()
+
+    def materialize(self):
+        n, h, w, c = self.t.shape
+        cat = torch.empty(self.B, h, w, 2 * c, dtype=self.t.dtype, device=self.t.device)
+        copy_channels(self.t[:self.B], 0, cat, 0, c)
+        copy_channels(self.t[self.B:], 0, cat, c, c)
+        return cat
+
+
+def conv3x3_split_supported(B, H, W, cin, cout, dtype):
+    """can the 3x3 / stride 1 / pad 1 layer cin -> cout on B x H x W pixels run with a SplitCat input (forward and weight
+    gradient) and a split data-gradient output?  (bf16, register-resident-weights + wave-specialised kernels; dahitra_hip.h)"""
+    return dtype == torch.bfloat16 and os.environ.get("DAHITRA_NO_SPLIT_CAT", "0") != "1" and \
+        bool(_lib.lib().dh_conv3x3_split_supported(_ci(B), _ci(H), _ci(W), _ci(cin), _ci(cout)))
+
+
+def conv3x3_split(x, wp, w_frag, cout, want_stats=False, split_out=False, alg_flops=0):
+    """3x3 / stride 1 / pad 1 convolution with a SplitCat input and / or (split_out) an output whose channel halves are the two
+    batch halves of a [2N, H, W, cout / 2] tensor (the data gradient of a layer that read a SplitCat)."""
+    xs = x if isinstance(x, SplitCat) else None
+    N, H, W, Cin = x.shape
+    xt = xs.t if xs is not None else x
+    assert xt.dtype == torch.bfloat16 and w_frag is not None and (xs is not None or split_out)
+    if split_out:
+        y = torch.empty(2 * N, H, W, cout // 2, dtype=xt.dtype, device=xt.device)
+        ysplit = y[N:].data_ptr() - y.data_ptr()
+    else:
+        y = torch.empty(N, H, W, cout, dtype=xt.dtype, device=xt.device)
+        ysplit = 0
+    stats = None
+    if want_stats:
+        nt = _lib.lib().dh_conv2d_fwd_num_tiles(N, H, W, Cin, 3, 1)
+        stats = torch.empty(2, cout, nt, dtype=torch.float32, device=xt.device)
+    flops = alg_flops if alg_flops else 2.0 * N * H * W * cout * Cin * 9
+    fixed = (P(xt), _cl(xs.split_bytes if xs is not None else 0), P(wp), P(w_frag), P(y), _cl(ysplit), P(stats), _ci(N), _ci(H),
+             _ci(W), _ci(Cin), _ci(cout))
+    key = "conv_mfma<bf16,ks3,s1,nt64>"
+    with _Prof(key, flops, _nb(xt, y, wp)):
+        _call("dh_conv3x3_split_fwd", *fixed, S())
+    if REPLAY is not None and key == REPLAY["key"]:
+        REPLAY["calls"].append((lambda stream, fixed=fixed: _call("dh_conv3x3_split_fwd", *fixed, stream), (xt, wp, w_frag, y, stats), flops))
+    return (y, stats) if want_stats else y
+
+
 def conv3x3_head(x, wp, ncls, bias):
     """the class head: 3x3 / pad 1 convolution to `ncls` (<= 16) channels, fp32 NCHW logits written by the kernel itself.
     x may be a BnInput (BatchNorm-apply + ReLU on load)."""
@@ -457,6 +520,8 @@ def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=
     x may be a BnInput (gradient against relu(y * scale + shift), computed on load)."""
     if isinstance(x, BnInput):
         return _conv2d_wgrad_bn_in(x, dy, dw, ks, stride, pad, accumulate, use_tr, cout_real, dilation, defer)
+    if isinstance(x, SplitCat):
+        return _conv2d_wgrad_split(x, dy, dw, ks, stride, pad, accumulate, defer)
     N, H, W, pitch = x.shape
     Cin = cin if cin else pitch
     _, OH, OW, Cout = dy.shape
@@ -480,6 +545,31 @@ def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=
     _call("dh_conv2d_wgrad", _ci(dt(x)), P(x), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W), _ci(Cin),
           _ci(OH), _ci(OW), _ci(Cout), _ci(ks), _ci(stride), _ci(pad), _ci(groups), _ci(0), _ci(int(use_tr)),
           _ci(cout_real), _ci(pitch), _ci(dilation), P(ws), S())
+
+
+def _conv2d_wgrad_split(xs, dy, dw, ks, stride, pad, accumulate, defer):
+    """weight gradient against a SplitCat input (3x3 / stride 1 / pad 1, bf16): the two tensors are read in place"""
+    assert ks == 3 and stride == 1 and pad == 1
+    N, H, W, Cin = xs.shape
+    Cout = dy.shape[-1]
+    nbytes = _lib.lib().dh_conv2d_wgrad_workspace_size(N, H, W, Cin, Cout, 3, 1)
+    plan, own = (_WGRAD_PLAN if defer else None), False
+    if plan is None:
+        plan, own = WgradPlan(dy.device), True
+        plan.__enter__()
+    try:
+        ws = plan.slab(nbytes)
+        sk = ctypes.c_int(0)
+        with _Prof("conv_wgrad<bf16,ks3,s1>", 2.0 * N * H * W * Cout * Cin * 9, _nb(xs.t, dy)):
+            _call("dh_conv2d_wgrad_split", P(xs.t), _cl(xs.split_bytes), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W),
+                  _ci(Cin), _ci(Cout), P(ws), ctypes.byref(sk), S())
+        plan.hold(xs.t, dy)
+        plan.add(ws, dw, sk.value, 9, Cout, Cout, Cin, accumulate)
+        if own:
+            plan.run()
+    finally:
+        if own:
+            plan.__exit__(*sys.exc_info())
 
 
 def _conv2d_wgrad_bn_in(b, dy, dw, ks, stride, pad, accumulate, use_tr, cout_real, dilation, defer):
@@ -513,14 +603,14 @@ def pack_phase_weights(w, bias, dtype):
     return fwd, dg, b4
 
 
-def conv_up2_fwd(x, wfwd, bias4):
-    """conv3x3(nearest-x2(x)) + bias: x [N, H, W, Cin] -> [N, 2H, 2W, 32]; the upsampled tensor is never materialised"""
+def conv_up2_fwd(x, wfwd, bias4, act=ACT_NONE):
+    """act(conv3x3(nearest-x2(x)) + bias): x [N, H, W, Cin] -> [N, 2H, 2W, 32]; the upsampled tensor is never materialised"""
     N, H, W, Cin = x.shape
     y = torch.empty(N, 2 * H, 2 * W, 32, dtype=x.dtype, device=x.device)
     key = "conv_phase<%s,up2_fwd>" % ("bf16" if x.dtype == torch.bfloat16 else "f32")         # its own class: KS = 2 launches
     with _Prof(key, 2.0 * N * 4 * H * W * 32 * Cin * 9, _nb(x, y, wfwd)):                       # algorithmic FLOPs (of the 3x3)
         _call("dh_conv2d_fwd", _ci(dt(x)), P(x), P(wfwd), P(y), P(bias4), _vp(0), _vp(0), _ci(N), _ci(H), _ci(W), _ci(Cin),
-              _ci(H), _ci(W), _ci(128), _ci(128), _ci(2), _ci(1), _ci(1), _ci(ACT_NONE), _ci(0), _cl(0), _vp(0), _ci(1),
+              _ci(H), _ci(W), _ci(128), _ci(128), _ci(2), _ci(1), _ci(1), _ci(act), _ci(0), _cl(0), _vp(0), _ci(1),
               *_gate_args(None), *_bn_in_args(None), _ci(1), _vp(0), S())
     return y
 
@@ -550,7 +640,7 @@ def conv3x3s2_dgrad(dy, wphase, cin, coarse_residual=None, alg_flops=0):
 def conv_up2_dgrad(dy, wdgrad, cin):
     """gradient of conv_up2_fwd with respect to x: dy [N, 2H, 2W, 32] -> [N, H, W, cin]"""
     N, H2, W2, C = dy.shape
-    assert C == 32 and H2 % 2 == 0 and W2 % 2 == 0 and cin % 64 == 0
+    assert C == 32 and H2 % 2 == 0 and W2 % 2 == 0 and (cin % 64 == 0 or cin == 32)
     H, W = H2 // 2, W2 // 2
     dx = torch.empty(N, H, W, cin, dtype=dy.dtype, device=dy.device)
     key = "conv_phase<%s,up2_dgrad>" % ("bf16" if dy.dtype == torch.bfloat16 else "f32")
@@ -822,11 +912,17 @@ def nchw_to_nhwc(x, dtype, cpad=0):
     return y
 
 
-def head_dgrad3x3(dy, w_oihw, ncls):
-    """data gradient of the 3x3 class head (32 -> ncls): dy [N,H,W,CP] with one 16-byte piece per pixel -> [N,H,W,32]"""
+def head_dgrad3x3(dy, w_oihw, ncls, relu_out=None):
+    """data gradient of the 3x3 class head (32 -> ncls): dy [N,H,W,CP] with one 16-byte piece per pixel -> [N,H,W,32].
+    relu_out: the head's input is the output of a ReLU (given here); the gradient comes back already masked by it"""
     N, H, W, CP = dy.shape
     assert w_oihw.shape == (ncls, 32, 3, 3) and w_oihw.dtype == torch.float32
     dx = torch.empty(N, H, W, 32, dtype=dy.dtype, device=dy.device)
+    if relu_out is not None:
+        if dy.dtype == torch.bfloat16 and CP == 8 and ncls <= 2:
+            _call("dh_head_dgrad3x3_relu", P(dy), P(w_oihw), _ci(ncls), P(relu_out), P(dx), _ci(N), _ci(H), _ci(W), S())
+            return dx
+        return act_bwd(head_dgrad3x3(dy, w_oihw, ncls), relu_out, ACT_RELU)
     _call("dh_head_dgrad3x3", _ci(dt(dy)), P(dy), _ci(CP), P(w_oihw), _ci(ncls), P(dx), _ci(N), _ci(H), _ci(W), S())
     return dx
 

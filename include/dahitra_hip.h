@@ -117,6 +117,22 @@ int dh_conv2d_wgrad_bn_in(int dtype, const void* x, const void* dy, float* dw_oi
                           int Cin, int OH, int OW, int Cout, int ks, int stride, int pad, int use_tr, int Cout_real,
                           int dilation, const float* in_scale, const float* in_shift, int in_groups, void* workspace,
                           int* splitk_out, void* stream);
+/* Channel concatenation without the concatenated tensor (bf16, 3x3 / stride 1 / pad 1): models/networks.py:1344,
+ * conv_layer2_0(torch.cat([a_128, b_128], 1)) -- here the two temporal streams are the two halves of ONE [2N]-image tensor.
+ *   dh_conv3x3_split_fwd   x_split_bytes != 0: the input is cat([A, B], channel) of two [N][H][W][Cin / 2] tensors, A at x, B
+ *                          at x + x_split_bytes; y_split_bytes != 0: the output's channel halves go to two
+ *                          [N][H][W][Cout / 2] tensors, y and y + y_split_bytes (the data gradient of such a layer, with
+ *                          w_packed / w_frag its data-gradient packs).  No bias / residual / activation; stats_partial as
+ *                          dh_conv2d_fwd (rows = dh_conv2d_fwd_num_tiles).  w_frag (fragment-order pack) is required.
+ *   dh_conv2d_wgrad_split  dh_conv2d_wgrad_partial against such an input (joins an open weight-gradient batch).
+ *   dh_conv3x3_split_supported  1 when all three run for a layer Cin -> Cout on N x H x W pixels; callers otherwise
+ *                          materialise the concatenation with dh_copy_channels.
+ * (replaces torch.cat + F.conv2d and their autograd terms; the copies were 4 x 134 MB per step at batch 32) */
+int dh_conv3x3_split_supported(int N, int H, int W, int Cin, int Cout);
+int dh_conv3x3_split_fwd(const void* x, long x_split_bytes, const void* w_packed, const void* w_frag, void* y, long y_split_bytes,
+                         float* stats_partial, int N, int H, int W, int Cin, int Cout, void* stream);
+int dh_conv2d_wgrad_split(const void* x, long x_split_bytes, const void* dy, float* dw_oihw, int accumulate, int N, int H, int W,
+                          int Cin, int Cout, void* workspace, int* splitk_out, void* stream);
 /* Batched weight gradients: the 3x3 stride-1 bf16 layers of one backward pass as ONE launch per kernel family (the
  * wave-specialised 64co x 64ci form: Cin and Cout multiples of 64; the 32-wide output tile: 16 < Cout <= 32).  Between dh_wgrad_batch_begin() and dh_wgrad_batch_end(), dh_conv2d_wgrad_partial /
  * dh_conv2d_wgrad_bn_in (with splitk_out) only RECORD an eligible layer -- *splitk_out is its in-batch slice count, smaller
@@ -250,6 +266,11 @@ int dh_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, long H
  * dx [N][H][W][32] */
 int dh_head_dgrad3x3(int dtype, const void* dy, int CP, const float* w_oihw, int NC, void* dx, int N, int H, int W,
                      void* stream);
+/* The same data gradient for a head whose 32 input channels are the output of a ReLU (classifier(conv_layer2(...)),
+ * models/networks.py:1351-1355; bf16, n_class <= 2, CP = 8): relu_out [N][H][W][32] is that output and
+ * dx = gradient * (relu_out > 0) -- the activation's backward pass (3 x 134 MB at batch 32) folded into this kernel. */
+int dh_head_dgrad3x3_relu(const void* dy, const float* w_oihw, int NC, const void* relu_out, void* dx, int N, int H, int W,
+                          void* stream);
 /* The same data gradient GATED for the BatchNorm + ReLU behind the 32 channels (classifier[0..2], models/help_funcs.py:7-15; bf16,
  * n_class <= 2): g = gradient * (y * mask_scale + mask_shift > 0) and the per-workgroup partials [2][32][blocks] (sum g,
  * sum g * xhat) for dh_bn_bwd_from_partials -- that BatchNorm's reduction pass disappears. */

@@ -1069,24 +1069,33 @@ def test_batchnorm_backward_persistent_failures_are_loud(ops, monkeypatch):
     dict(n=2, cin=256, h=16, w=16),          # 8-row tiles
     dict(n=3, cin=64, h=12, w=20),           # ragged coarse map
     dict(n=64, cin=256, h=32, w=32),         # the bench's conv_pred: 16-row tiles, 4 phases x 256 tiles
+    dict(n=2, cin=32, h=16, w=16, relu=True),         # the UNet up path (conv_layer4 / 3 / 2: 32 -> 32 channels + ReLU)
+    dict(n=3, cin=32, h=12, w=20, relu=True),         # ... on a ragged coarse map
+    dict(n=8, cin=32, h=128, w=128, relu=True),       # ... conv_layer2's map at batch 8
 ])
 def test_upsample2_conv3x3_as_four_phase_convs(ops, dtype, cfg):
-    """conv3x3(nearest-upsample-x2(x)) (models/networks.py:251-256: upsamplex2 + conv_pred) as four 2x2 phase convolutions:
-    forward, data gradient and weight / bias gradients against torch autograd of F.interpolate + F.conv2d"""
+    """conv3x3(nearest-upsample-x2(x)) (models/networks.py:251-256: upsamplex2 + conv_pred; :1341-1351 with a ReLU: upsamplex2 +
+    conv_layer<l>) as four 2x2 phase convolutions: forward, data gradient and weight / bias gradients against torch autograd
+    of F.interpolate + F.conv2d (+ relu: the gradient then goes through the activation's backward first, as the engine does)"""
     N, Cin, H, W = cfg["n"], cfg["cin"], cfg["h"], cfg["w"]
+    relu = cfg.get("relu", False)
     x = rnd((N, Cin, H, W), dtype, 901).requires_grad_(True)
     w = rnd((32, Cin, 3, 3), torch.float32, 902, (Cin * 9) ** -0.5).requires_grad_(True)
     b = rnd((32,), torch.float32, 903, 0.1)
     y = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, 1, 1)
+    if relu:
+        y = F.relu(y)
     dy = rnd(tuple(y.shape), dtype, 904)
     y.backward(dy)
     wf, wd, b4 = ops.pack_phase_weights(w.detach().cuda(), b.cuda(), dtype)
     xd = dev(nhwc(x.detach()), dtype)
-    out = ops.conv_up2_fwd(xd, wf, b4)
+    out = ops.conv_up2_fwd(xd, wf, b4, act=ops.ACT_RELU if relu else ops.ACT_NONE)
     assert tuple(out.shape) == (N, 2 * H, 2 * W, 32)
     # (bf16: the phase weights are sums of up to four taps rounded once, the reference rounds nothing: same tolerance class)
     close(nchw(out), y.detach(), dtype, "phase conv forward", factor=2.0)
     dyd = dev(nhwc(dy), dtype)
+    if relu:        # the mask of the REFERENCE's output (an element within rounding of zero may differ between the two)
+        dyd = ops.act_bwd(dyd, dev(nhwc(y.detach()), dtype), ops.ACT_RELU)
     dx = ops.conv_up2_dgrad(dyd, wd, Cin)
     close(nchw(dx), x.grad, dtype, "phase conv data gradient", factor=3.0)
     dw = torch.full((32, Cin, 3, 3), 0.5, device="cuda")
@@ -1351,3 +1360,64 @@ def test_cross_attention_prep_on_the_matrix_cores_matches_the_scalar_kernels(ops
     for i, n in enumerate(("token gradient", "parameter gradients")):
         a, b = res["old"][i], res["new"][i]
         assert float((a - b).abs().max()) <= 1.5e-2 * float(a.abs().max()), n
+
+
+def test_conv3x3_over_a_channel_concatenation_in_place(ops):
+    """conv_layer2_0(torch.cat([a_128, b_128], 1)) (models/networks.py:1344) without the concatenated tensor: forward with
+    BatchNorm statistics, data gradient (written as the two halves of the [2B] gradient) and weight gradient read / write the
+    two batch halves in place (ops.SplitCat); each must equal -- bit for bit: same kernels, same order of products -- the
+    path through the materialised concatenation, which itself is checked against torch autograd here."""
+    B, H, W, C = 4, 128, 128, 64
+    dtype = torch.bfloat16
+    assert ops.conv3x3_split_supported(B, H, W, 2 * C, 128, dtype)
+    assert not ops.conv3x3_split_supported(B, H, W, 2 * C, 128, torch.float32)
+    t = rnd((2 * B, C, H, W), dtype, 1201)
+    w = rnd((128, 2 * C, 3, 3), dtype, 1202, (2 * C * 9) ** -0.5)
+    dy = rnd((B, 128, H, W), dtype, 1203)
+    td, dyd = dev(nhwc(t), dtype), dev(nhwc(dy), dtype)
+    plan = ops.PackPlan(td.device)
+    f, d = plan.add(w.cuda(), dtype, want_dgrad=True, dgrad_inner=128)
+    ff, dd = plan.add(w.cuda(), dtype, want_dgrad=True, dgrad_inner=128, frag=True)
+    plan.run()
+    sc = ops.SplitCat(td)
+    assert tuple(sc.shape) == (B, H, W, 2 * C)
+    cat = sc.materialize()
+    assert torch.equal(cat[..., :C], td[:B]) and torch.equal(cat[..., C:], td[B:])
+    # forward (+ statistics)
+    y_ref, st_ref = ops.conv2d(cat, f, 128, 3, 1, 1, want_stats=True, w_frag=ff)
+    y, st = ops.conv3x3_split(sc, f, ff, 128, want_stats=True)
+    assert torch.equal(y, y_ref) and torch.equal(st, st_ref)
+    xc = torch.cat([t[:B], t[B:]], 1).requires_grad_(True)
+    wt = w.clone().requires_grad_(True)
+    yt = F.conv2d(xc, wt, None, 1, 1)
+    close(nchw(y), yt.detach(), dtype, "split conv forward")
+    yt.backward(dy)
+    # data gradient into the two halves
+    dx_ref = ops.conv2d(dyd, d, 2 * C, 3, 1, 1, w_frag=dd)
+    dx = ops.conv3x3_split(dyd, d, dd, 2 * C, split_out=True)
+    assert tuple(dx.shape) == (2 * B, H, W, C)
+    assert torch.equal(dx[:B], dx_ref[..., :C]) and torch.equal(dx[B:], dx_ref[..., C:])
+    close(nchw(dx[:B]), xc.grad[:, :C], dtype, "split conv data gradient (first half)", factor=2.0)
+    close(nchw(dx[B:]), xc.grad[:, C:], dtype, "split conv data gradient (second half)", factor=2.0)
+    # weight gradient
+    dw_ref = torch.zeros(128, 2 * C, 3, 3, device="cuda")
+    dw = torch.full_like(dw_ref, 0.25)
+    ops.conv2d_wgrad(cat, dyd, dw_ref, 3, 1, 1)
+    ops.conv2d_wgrad(sc, dyd, dw, 3, 1, 1, accumulate=True)
+    assert torch.equal(dw - 0.25, dw_ref) or float((dw - 0.25 - dw_ref).abs().max()) <= 1e-6 * float(dw_ref.abs().max())
+    close(dw_ref, wt.grad, dtype, "split conv weight gradient", factor=4.0)
+
+
+def test_head_data_gradient_with_the_relu_in_front_of_it_folded_in(ops):
+    """dh_head_dgrad3x3_relu: the class head's data gradient already masked by the ReLU that produced the head's input
+    (classifier(conv_layer2(...)), models/networks.py:1351-1355) == the plain data gradient followed by the activation's backward"""
+    N, H, W = 3, 64, 48
+    dtype = torch.bfloat16
+    dl = dev(rnd((N, H, W, 8), dtype, 1301), dtype)
+    dl[..., 2:] = 0
+    w = rnd((2, 32, 3, 3), torch.float32, 1302, 0.1).cuda()
+    out = dev(rnd((N, H, W, 32), dtype, 1303), dtype).clamp_(min=0)
+    want = ops.act_bwd(ops.head_dgrad3x3(dl, w, 2), out, ops.ACT_RELU)
+    got = ops.head_dgrad3x3(dl, w, 2, relu_out=out)
+    assert torch.equal(got, want)
+    assert float((got != 0).float().mean()) < float((ops.head_dgrad3x3(dl, w, 2) != 0).float().mean())

@@ -3,13 +3,13 @@ against (a) the golden fixtures produced by the reference and (b) the CPU oracle
 inputs.  fp32 mode: logits within 1e-3 relative (north-star bar; we assert 2e-4), masks identical
 outside the tie band; bf16 mode: worst logit within 0.15 of the logit scale, mask disagreement < 3 %.
 
-Gradient tolerances are calibrated to the measured fp32 noise floor of THIS computation: the oracle run
-in fp64 vs fp32 on the same inputs differs by 4e-3 (median over parameters) and up to 6e-2 (layer3
-convs) of max|grad|, because ReLU / max-pool / |a-b| make the gradient discontinuous in the
-activations.  GRAD_TOL below is that floor; forward quantities keep the tight bounds.  The 50-layer
-ResNet-50 variant has a higher floor (same measurement: median 1e-2, worst 0.13 in layer3.5.conv3 /
-conv2); two fp32 implementations each carry that deviation, so their worst-tensor distance is bounded
-by twice it (GRAD_TOL_R50), while the median over tensors and the per-tensor cosine stay tight."""
+Gradient tolerances come from the MEASURED fp32 noise floor of this computation: tools/grad_noise_floor.py runs the oracle
+in float64 and float32 on the inputs of the gradient test and commits the per-tensor distances
+(tests/golden/grad_noise_floor.json; tests/test_oracle_golden.py re-measures them on the CPU).  With the well-conditioned
+fixture weights the floor of the ResNet-18 nets is ~1e-5 (median) / 1e-3 (worst tensor, relative L2); the 50-layer ResNet-50
+variant amplifies rounding to 1e-2 / 1.3e-2.  test_gradients_match_oracle_fp32 bounds the HIP gradients by a stated multiple
+of those figures; the fixture-based train test keeps looser per-tensor bounds (GRAD_TOL*) because the fixture stores a
+subset of the gradients only."""
 import os
 import types
 
@@ -21,6 +21,7 @@ import torch.nn.functional as F
 import cdnet_ref as O
 
 pytestmark = pytest.mark.gpu
+BF16_MAX_ERR = 0.10    # a-priori bound on the worst bf16 logit error, in units of the reference's max |logit| (measured: 0.03 - 0.08)
 GRAD_TOL = 6e-2        # of max|grad| per tensor (see module docstring)
 GRAD_TOL_R50 = 0.26
 NORM_TOL = 3e-2
@@ -130,34 +131,60 @@ def test_train_steps_match_reference_golden_fp32(name, golden_dir):
     assert int(sd["resnet.bn1.num_batches_tracked"]) == int(g["nbt"])
 
 
-@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_t8_e2d4", R50])
-def test_gradients_match_oracle_fp32(name):
-    """every parameter gradient against the oracle's autograd on a non-square, odd-batch case"""
+def _floor(name, golden_dir):
+    """tests/golden/grad_noise_floor.json (tools/grad_noise_floor.py): the oracle's own float32-vs-float64 gradient distances"""
+    import json
+    return json.load(open(os.path.join(golden_dir, "grad_noise_floor.json")))[name]
+
+
+# How far the HIP gradients may be from the oracle's, as multiples of the oracle's OWN float32-vs-float64 distance on the
+# same inputs (the committed floor file): both sides carry that noise, and the HIP path is a different fp32 implementation
+# (other summation orders, BatchNorm statistics from per-tile partials, re-associated attention), so its activations differ
+# from the oracle's by ~1e-5 where float32 and float64 of the SAME code differ by 1e-7 -- more ties of ReLU / max-pool /
+# |a - b| flip.  Per tensor, against the floor's worst tensor; median over tensors, against the floor's median.
+FLOOR_X_WORST, FLOOR_X_MEDIAN = 8.0, 8.0
+FLOOR_MIN_L2, FLOOR_MIN_MEDIAN = 2e-3, 1e-4        # (absolute lower ends: the well-conditioned nets' floors are ~1e-5)
+
+
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_t8_e2d4", "newUNetTrans", R50])
+def test_gradients_match_oracle_fp32(name, golden_dir):
+    """every parameter gradient against the oracle's autograd on the case of tools/grad_noise_floor.py (odd batch, 64 x 64;
+    newUNetTrans: 2 x 256 x 256), bounded by the measured fp32 noise floor of this computation: per-tensor relative L2 and
+    the median over tensors, plus the per-tensor cosine"""
     from dahitra_amd.models import losses
+    fl = _floor(name, golden_dir)
     cfg = O.get_config(name)
-    a, b, lab = O.synthetic_batch(3, 64, seed=77, n_class=cfg["n_class"])
+    a, b, lab = O.synthetic_batch(fl["case"]["batch"], fl["case"]["size"], seed=fl["case"]["seed"], n_class=cfg["n_class"])
     st = O.TrainState(name, O.deterministic_state(name), lr=0.01)
     logits = O.forward(st.sd, name, a, b, training=True)
     O.focal_loss(logits, lab).backward()
     net = make_net(name).train()
     y = net(a.cuda(), b.cuda())
     losses.focal_loss(y, lab.cuda()).backward()
-    bad, rels, coss = [], [], []
+    rl2, rmax, coss, worst = [], [], [], ("", 0.0)
     for k, p in net.named_parameters():
         ref = st.sd[k].grad
         assert (p.grad is None) == (ref is None), k
-        if ref is None:
+        if ref is None or float(ref.abs().max()) < 1e-12:
             continue
-        e = float((p.grad.cpu() - ref).abs().max())
-        s = float(ref.abs().max())
-        rels.append(e / max(s, 1e-30))
+        d = p.grad.cpu().double() - ref.double()
+        r2 = float(d.norm() / ref.double().norm())
+        rl2.append(r2)
+        rmax.append(float(d.abs().max()) / float(ref.abs().max()))
+        if r2 > worst[1]:
+            worst = (k, r2)
         if ref.numel() >= 64:
             coss.append(float(F.cosine_similarity(p.grad.cpu().double().flatten(), ref.double().flatten(), dim=0)))
-        if e > (GRAD_TOL_R50 if name == R50 else GRAD_TOL) * s + 1e-7:
-            bad.append((k, e, s))
-    assert not bad, bad[:10]
-    assert float(np.median(rels)) <= 2e-2, float(np.median(rels))
-    assert min(coss) >= 0.995, min(coss)
+    med, top = float(np.median(rl2)), max(rl2)
+    bound_top = max(FLOOR_X_WORST * fl["rel_l2"]["max"], FLOOR_MIN_L2)
+    bound_med = max(FLOOR_X_MEDIAN * fl["rel_l2"]["median"], FLOOR_MIN_MEDIAN)
+    print("%s: gradient rel-L2 vs oracle: median %.2e (floor %.2e, bound %.2e), worst %.2e in %s (floor %.2e, bound %.2e); "
+          "rel-max worst %.2e (floor %.2e); min cosine %.7f (floor %.7f)"
+          % (name, med, fl["rel_l2"]["median"], bound_med, top, worst[0], fl["rel_l2"]["max"], bound_top, max(rmax),
+             fl["rel_max"]["max"], min(coss), fl["cos_min"]))
+    assert med <= bound_med, (med, bound_med)
+    assert top <= bound_top, (worst, bound_top)
+    assert min(coss) >= 1.0 - 8.0 * max(1.0 - fl["cos_min"], 1e-5), min(coss)
 
 
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
@@ -200,7 +227,8 @@ def test_bf16_mode_within_3x_the_bf16_input_rounding_error(name):
     its weights and images are rounded to bf16 (the unavoidable part of computing in bf16): relative L2 distance of
     the logits <= 3x that (measured on MI355X: 2.3x for base_transformer_pos_s4 at 128x128 -- the bf16 pipeline also
     rounds ~40 activation tensors, the comparison pipeline none; the ResNet-50 test uses the same 3x), mask flips
-    outside a band of 2x the measured bf16 logit error = 0 on the large-margin state."""
+    with a reference margin above 2 x BF16_MAX_ERR (a fixed, a-priori bound on the worst bf16 logit error, asserted) = 0 on the
+    large-margin state; flips above 0.05 of the logit scale: at most 0.2 % of the pixels."""
     cfg = O.get_config(name)
     size = 256 if name == "newUNetTrans" else 128
     a, b, lab = O.synthetic_batch(2, size, seed=5, n_class=cfg["n_class"])
@@ -223,16 +251,26 @@ def test_bf16_mode_within_3x_the_bf16_input_rounding_error(name):
     scale = float(ref.abs().max())
     err = float((y - ref).abs().max()) / scale
     err_round = float((y_round - ref).abs().max()) / scale
-    margin = (ref[:, 0] - ref[:, 1]).abs()
+    # masks: FIXED bands from the reference-pinned margins (the oracle's logits; scale = its max |logit|), not from the error
+    # measured here.  BF16_MAX_ERR bounds the worst bf16 logit a priori; a pixel whose margin exceeds twice that cannot flip
+    # while the bound holds, and the bound is asserted.  Between 0.05 and 2 x BF16_MAX_ERR of the scale flips are possible
+    # only where the error is near its maximum: a small, stated share.
+    margin = (ref[:, 0] - ref[:, 1]).abs() / scale
     diff = torch.argmax(y, 1) != torch.argmax(ref, 1)
-    band = margin <= 2.0 * err * scale
+    outside = diff & (margin > 2.0 * BF16_MAX_ERR)
+    mid = diff & (margin > 0.05)
     print("bf16 %s: logits l2 %.3e (fp32 pipeline on bf16-rounded inputs: %.3e, fp32 pipeline: %.1e); max err %.3e "
-          "(rounded inputs %.3e); mask flips %d of %d, outside the 2*err band %d, band fraction %.4f"
-          % (name, got, sens, l2(y32, ref), err, err_round, int(diff.sum()), diff.numel(), int((diff & ~band).sum()),
-             float(band.float().mean())))
+          "(rounded inputs %.3e, a-priori bound %.2f); mask flips %d of %d (%.3f %%); with reference margin > 0.05: %d (of %.1f %% "
+          "of the pixels), > %.2f: %d (of %.1f %%)"
+          % (name, got, sens, l2(y32, ref), err, err_round, BF16_MAX_ERR, int(diff.sum()), diff.numel(),
+             100 * float(diff.float().mean()), int(mid.sum()), 100 * float((margin > 0.05).float().mean()), 2 * BF16_MAX_ERR,
+             int(outside.sum()), 100 * float((margin > 2 * BF16_MAX_ERR).float().mean())))
     assert l2(y32, ref) <= 2e-4
     assert got <= 3.0 * sens, (got, sens)
-    assert int((diff & ~band).sum()) == 0
+    assert err <= BF16_MAX_ERR, err
+    assert int(outside.sum()) == 0
+    assert float((margin > 2.0 * BF16_MAX_ERR).float().mean()) > 0.3          # the band leaves a real share of the pixels to check
+    assert int(mid.sum()) <= 2e-3 * diff.numel(), int(mid.sum())
     assert float(diff.float().mean()) < 0.03
 
 
