@@ -44,6 +44,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     a.y_nchw = nullptr;
     a.up4_partial = nullptr;
     a.x_split = a.y_split = 0;
+    a.up4_a = a.up4_b = nullptr;
     a.w_frag = w_frag;
     DH_REQUIRE(!w_frag || (ks == 3 && w_image_stride == 0 && !phase_mode && dtype == DH_DTYPE_BF16 && Cin % 32 == 0 && CoutPad % 16 == 0),
                "conv2d_fwd: fragment-order weights exist for the bf16 3x3 layers only");
@@ -152,6 +153,28 @@ extern "C" int dh_conv3x3_dgrad_up4(int dtype, const void* dy, const void* w_pac
     a.rw = 2;
     a.tilesX = W / TW; a.tilesY = H / 8;
     return dh_conv_launch_bf16(a, 3, 1, reinterpret_cast<hipStream_t>(stream));
+}
+
+// classifier.0 on the bilinear-x4 upsampled |A - B| map WITHOUT that map (ConvArgs::up4_a; models/networks.py:383-389,
+// models/help_funcs.py:9): a, b [N][H / 4][W / 4][32] bf16 (the two streams' decoder outputs), y [N][H][W][32] bf16 =
+// act(conv3x3(upsample4(|a - b|)) + bias); stats_partial as dh_conv2d_fwd with dh_conv2d_fwd_num_tiles(N, H, W, 32, 3, 1) rows.
+// The interpolation is dh_absdiff_upsample4_fwd's (same terms, same order, rounded to bf16 as that kernel's output is), so the
+// result equals dh_conv2d_fwd on its output bit for bit.
+extern "C" int dh_conv3x3_up4_fwd(const void* a, const void* b, const void* w_packed, const float* bias, int act, void* y,
+                                  float* stats_partial, int N, int H, int W, void* stream) {
+    DH_REQUIRE(a && b && w_packed && y && N > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "conv3x3_up4_fwd: N=%d H=%d W=%d", N, H, W);
+    DH_REQUIRE(act == DH_ACT_NONE || act == DH_ACT_RELU, "conv3x3_up4_fwd: activation %d", act);
+    ConvArgs c;
+    memset(&c, 0, sizeof(c));
+    c.w = w_packed; c.y = y; c.bias = bias; c.stats = stats_partial;
+    c.N = N; c.H = H; c.W = W; c.Cin = 32; c.OH = H; c.OW = W; c.Cout = 32; c.CoutPad = 32;
+    c.pad = 1; c.act = act; c.npix = H * W; c.in_npix = H * W; c.dil = 1; c.gate_groups = 1; c.in_groups = 1;
+    static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
+    c.no_xcd_remap = no_remap;
+    c.up4_a = a; c.up4_b = b;
+    c.rw = 2;
+    c.tilesX = dh_cdiv(W, TW); c.tilesY = dh_cdiv(H, 8);
+    return dh_conv_launch_bf16(c, 3, 1, reinterpret_cast<hipStream_t>(stream));
 }
 
 // number of workgroup tiles along the pixel dimension (= rows of the stats_partial buffer)

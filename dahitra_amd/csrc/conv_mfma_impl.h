@@ -101,6 +101,13 @@ struct ConvArgs {
     // models/networks.py:1344: the two temporal streams are the two halves of ONE [2N] batch).  y_split != 0: the output's
     // channel halves go to two [N][OH][OW][Cout / 2] tensors, y and y + y_split bytes (the data gradient of such a layer).
     long x_split, y_split;
+    // |A - B| + bilinear x4 ON LOAD (bf16, 3x3 / stride 1 / pad 1, 32 -> 32 channels: classifier.0 behind
+    // nn.Upsample(4, 'bilinear') of abs(x1 - x2), models/networks.py:383-389): x is not read; the haloed input tile is
+    // interpolated (align_corners = False) from the 4 x 6 coarse pixels of up4_a / up4_b [N][H / 4][W / 4][32] it depends on, with
+    // the terms and their order of dh_absdiff_upsample4_fwd -- the 32 x H x W map (134 MB at the bench size) is never
+    // written or read.  H, W stay the FINE sizes.
+    const void* up4_a;
+    const void* up4_b;
 };
 
 namespace {
@@ -126,7 +133,16 @@ template <> struct Mma<bf16> {
     }
 };
 
-template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST, bool INBN = false>
+// source rows / columns and weight of a bilinear x4 destination index (align_corners = False; = bil_src of pointwise.hip)
+__device__ __forceinline__ void up4_src(int d, int in, int& i0, int& i1, float& l) {
+    float s = ((float)d + 0.5f) * 0.25f - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l = s - (float)i0;
+}
+
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST, bool INBN = false, bool INUP4 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     constexpr int TH = 4 * RW;
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
@@ -139,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     unsigned char* halo = smem;                                  // [HH*HWD] rows, HL layout
     unsigned char* wts = smem + HH * HWD * HL::PITCH;            // [TAPS*NT] rows, swizzled pitch 64
     float* bnp = reinterpret_cast<float*>(wts + TAPS * NT * WPITCH);   // INBN: [2][Cin] scale | shift of this image's group
+                                                                       // INUP4: [4][6][32] |A - B| of the tile's coarse footprint
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -218,11 +235,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
                 xb = xin + (size_t)(c0 & 31) * sizeof(T);
             }
         }
+        if constexpr (!INUP4) {
 #pragma unroll
-        for (int i = 0; i < NHV; ++i) {
-            const bool ok = hoff[i] != ~0u;
-            const uint4 v = *reinterpret_cast<const uint4*>(xb + (ok ? hoff[i] : 0u));
-            rh[i] = ok ? v : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < NHV; ++i) {
+                const bool ok = hoff[i] != ~0u;
+                const uint4 v = *reinterpret_cast<const uint4*>(xb + (ok ? hoff[i] : 0u));
+                rh[i] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
@@ -232,6 +251,40 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
         }
     };
     auto commit = [&](int c0) {
+        if constexpr (INUP4) {
+            // halo piece = 8 channels of one fine pixel: the four bilinear terms in the order of absdiff_up4_fwd_kernel
+            // (rows (y0, y1) x columns (x0, x1); a clamped border index carries weight exactly 0), from the staged footprint
+            constexpr int PC = 16 / (int)sizeof(T);
+            const int CH = p.H >> 2, CW = p.W >> 2, cyb = (oy0 >> 2) - 1, cxb = (ox0 >> 2) - 1;
+#pragma unroll
+            for (int i = 0; i < NHV; ++i) {
+                rh[i] = make_uint4(0, 0, 0, 0);
+                if (hoff[i] == ~0u) continue;            // padding of the upsampled tensor
+                const int idx = tid + i * 256, px = idx >> 2, q = idx & 3;
+                const int hy = px / HWD, hx = px - hy * HWD;
+                int y0, y1, x0, x1;
+                float ly, lx;
+                up4_src(iy0 + hy, CH, y0, y1, ly);
+                up4_src(ix0 + hx, CW, x0, x1, lx);
+                const float wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+                const int rr[2] = {y0 - cyb, y1 - cyb}, cc[2] = {x0 - cxb, x1 - cxb};
+                float acc[PC];
+#pragma unroll
+                for (int j = 0; j < PC; ++j) acc[j] = 0.f;
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const float* d = bnp + (rr[pp] * 6 + cc[qq]) * 32 + q * PC;
+                        float dv[PC];
+#pragma unroll
+                        for (int j = 0; j < PC; j += 4) *reinterpret_cast<float4*>(dv + j) = *reinterpret_cast<const float4*>(d + j);
+#pragma unroll
+                        for (int j = 0; j < PC; ++j) acc[j] += wy[pp] * wx[qq] * dv[j];
+                    }
+                rh[i] = pack16<T>(acc);
+            }
+        }
         if constexpr (INBN) {
             // this thread's pieces all hold the same channels (piece index = tid & 3): c0 + (tid & 3) * PIECE ..
             constexpr int PC = 16 / (int)sizeof(T);
@@ -271,6 +324,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
         for (int c = tid; c < p.Cin; c += 256) {
             bnp[c] = p.in_scale[grp * p.Cin + c];
             bnp[p.Cin + c] = p.in_shift[grp * p.Cin + c];
+        }
+        __syncthreads();
+    }
+    if constexpr (INUP4) {
+        // |A - B| of the 4 x 6 coarse pixels this tile's 10 x 18 halo interpolates from (coarse rows oy0 / 4 - 1 .. + 2, columns
+        // ox0 / 4 - 1 .. + 4, clamped to the map: a clamped entry is only ever read with weight 0), fp32, once per workgroup
+        const int CH = p.H >> 2, CW = p.W >> 2;
+        if (tid < 4 * 6 * 4) {
+            const int fp = tid >> 2, q = tid & 3, r = fp / 6, c = fp - r * 6;
+            int cy = (oy0 >> 2) - 1 + r, cx = (ox0 >> 2) - 1 + c;
+            cy = cy < 0 ? 0 : (cy > CH - 1 ? CH - 1 : cy);
+            cx = cx < 0 ? 0 : (cx > CW - 1 ? CW - 1 : cx);
+            const size_t off = (((size_t)n * CH + cy) * CW + cx) * 32 + q * 8;
+            float u[8], v[8];
+            unpack16(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.up4_a) + off), u);
+            unpack16(*reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.up4_b) + off), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bnp[fp * 32 + q * 8 + j] = fabsf(u[j] - v[j]);
         }
         __syncthreads();
     }
@@ -598,15 +669,15 @@ static inline int pick_rw(int N, int OH, int OW, int Cin, int ks, int stride) {
     return 2;
 }
 
-template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST, bool INBN = false>
+template <typename T, int KS, int STRIDE, int NT, int RW, int DIL, bool PF, bool FAST, bool INBN = false, bool INUP4 = false>
 int launch_fast(const ConvArgs& a, hipStream_t st) {
     constexpr int TH = 4 * RW;
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     const size_t staging = (size_t)HH * HWD * HaloLayout<STRIDE>::PITCH + (size_t)KS * KS * NT * WPITCH +
-                           (INBN ? (size_t)2 * a.Cin * sizeof(float) : 0);
+                           (INBN ? (size_t)2 * a.Cin * sizeof(float) : 0) + (INUP4 ? (size_t)4 * 6 * 32 * sizeof(float) : 0);
     const size_t otile = (size_t)4 * 2 * NT * 4 + (size_t)TH * TW * (NT * sizeof(T) + 16);     // epilogue: stats scratch + transposed tile
     const size_t lds = staging > otile ? staging : otile;
-    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW, DIL, PF, FAST, INBN>;
+    auto kern = conv_mfma_kernel<T, KS, STRIDE, NT, RW, DIL, PF, FAST, INBN, INUP4>;
     static bool attr_done = false;      // once per instantiation (and never inside a graph capture)
     if (lds > 64 * 1024 && !attr_done) {
         attr_done = true;
@@ -635,6 +706,13 @@ int launch_pf(const ConvArgs& a, hipStream_t st) {
     } else if (a.in_scale) {
         DH_FAIL("conv_mfma: BatchNorm-on-load is built for 3x3 stride-1 dilation-1 convolutions (got %dx%d s%d d%d)", KS, KS, STRIDE, DIL);
     }
+    if constexpr (KS == 3 && STRIDE == 1 && DIL == 1 && NT == 32 && RW == 2 && !PF && sizeof(T) == 2) {
+        if (a.up4_a) {
+            if (!fast || a.in_scale) DH_FAIL("conv_mfma: the bilinear-x4-on-load form has the compact epilogue and no BatchNorm on load");
+            return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, true, false, true>(a, st);
+        }
+    }
+    if (a.up4_a) DH_FAIL("conv_mfma: bilinear x4 on load is built for the bf16 3x3 / stride 1, 32 -> 32 channel convolution on 8-row tiles");
     if (fast) return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, true>(a, st);
     return launch_fast<T, KS, STRIDE, NT, RW, DIL, PF, false>(a, st);
 }

@@ -540,7 +540,11 @@ void launch_bn_apply(const void* x, const void* residual, void* y, const float* 
 // maxpool_bwd_kernel, pointwise.hip) + the ReLU mask of relu(bn(y)) recomputed from y + the BatchNorm-backward reduction.
 // Writes the masked gradient d and per-workgroup partial sums (sum d, sum d * xhat); the separate reduce pass (one more read of
 // d and y, 268 MB at the bench size) disappears.  grid = G * bpg; a workgroup stays inside one group's images.
+// extra (optional, [N][H][W][C]): a second gradient of the SAME pre-pool activation, added before the mask -- the hierarchical
+// model taps the stem's output twice (max-pool -> layer1 and cat([a_128, b_128]) -> conv_layer2_0, models/networks.py:1118-1128,
+// 1344): its sum with the pool gradient, the mask and the reduction were add + max-pool backward + two BatchNorm passes.
 __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const unsigned char* __restrict__ arg, const bf16* __restrict__ dpool,
+                                                                 const bf16* __restrict__ extra,
                                                                  const bf16* __restrict__ y, const float* __restrict__ mscale,
                                                                  const float* __restrict__ mshift, bf16* __restrict__ d,
                                                                  float* __restrict__ partial, int npg, int H, int W, int C, int OH,
@@ -598,6 +602,12 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const unsigned 
                     }
                 const long o = ((n * H + iy) * W + ix) * C + c;
                 ldv(y + o, yv);
+                if (extra) {
+                    float ev[V];
+                    ldv(extra + o, ev);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) gs[j] += ev[j];
+                }
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     const float gm = (yv[j] * ms[j] + mh[j]) > 0.f ? gs[j] : 0.f;
@@ -694,16 +704,28 @@ extern "C" int dh_bn_apply(int dtype, const void* x, const void* residual, void*
 // workspace: dh_stem_pool_bn_bwd_workspace_size bytes.
 // 768 workgroups = three per CU, what the kernel's ~150 registers per lane keep resident: one full round, no ragged second one
 extern "C" long dh_stem_pool_bn_bwd_workspace_size(int C, int groups) { return (long)(768 / groups) * groups * 2 * C * 4; }
+extern "C" int dh_stem_pool_bn_bwd_plus(const unsigned char* argmax, const void* dpool, const void* extra, const void* y,
+                                        const float* mask_scale, const float* mask_shift, const float* mean, const float* invstd,
+                                        const float* gamma, int N, int H, int W, int C, int groups, void* d, float* coef,
+                                        float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream);
 extern "C" int dh_stem_pool_bn_bwd(const unsigned char* argmax, const void* dpool, const void* y, const float* mask_scale,
                                    const float* mask_shift, const float* mean, const float* invstd, const float* gamma, int N,
                                    int H, int W, int C, int groups, void* d, float* coef, float* dgamma, float* dbeta,
                                    int accumulate, void* workspace, void* stream) {
+    return dh_stem_pool_bn_bwd_plus(argmax, dpool, nullptr, y, mask_scale, mask_shift, mean, invstd, gamma, N, H, W, C, groups, d,
+                                    coef, dgamma, dbeta, accumulate, workspace, stream);
+}
+// ... with a second gradient `extra` [N][H][W][C] of the pre-pool activation (or NULL) added before the mask
+extern "C" int dh_stem_pool_bn_bwd_plus(const unsigned char* argmax, const void* dpool, const void* extra, const void* y,
+                                        const float* mask_scale, const float* mask_shift, const float* mean, const float* invstd,
+                                        const float* gamma, int N, int H, int W, int C, int groups, void* d, float* coef,
+                                        float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream) {
     DH_REQUIRE(C % 8 == 0 && 256 % (C / 8) == 0 && 2 * C <= 256, "stem_pool_bn_bwd: unsupported C=%d", C);
     DH_REQUIRE(groups >= 1 && groups <= BN_MAXG && N % groups == 0, "stem_pool_bn_bwd: N=%d groups=%d", N, groups);
     const int bpg = 768 / groups, OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     float* partial = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(pool_bn_bwd_reduce_kernel, dim3(groups * bpg), dim3(256), 0, ST(stream), argmax, (const bf16*)dpool,
-                       (const bf16*)y, mask_scale, mask_shift, (bf16*)d, partial, N / groups, H, W, C, OH, OW, bpg);
+                       (const bf16*)extra, (const bf16*)y, mask_scale, mask_shift, (bf16*)d, partial, N / groups, H, W, C, OH, OW, bpg);
     hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(C), dim3(64 * groups), 0, ST(stream), partial, bpg, groups, C, mean, invstd,
                        gamma, 1.0f / (float)((long)(N / groups) * H * W), coef, dgamma, dbeta, accumulate);
     DH_CHECK_LAUNCH("stem_pool_bn_bwd");

@@ -107,6 +107,12 @@ class Engine:
         # bf16: the data gradient of classifier.0 goes straight to the coarse |A - B| maps (the 32 x 256 x 256 gradient of the
         # bilinear-upsampled map is never written or re-read): DAHITRA_NO_FUSED_UP4_BWD=1 restores the two-kernel path
         self.fused_up4_bwd = os.environ.get("DAHITRA_NO_FUSED_UP4_BWD", "0") != "1"
+        # ... and in the forward / weight gradient |A - B| + bilinear x4 can be formed inside classifier.0's loads (ops.Up4Input:
+        # bit-identical, the 134 MB map is neither written nor read).  Measured on MI355X (profiles/r04*_up4_ab.txt): the
+        # interpolation is ~70 VALU instructions per 16-byte halo piece in kernels that run one tile per workgroup round --
+        # convolution 121 us against absdiff_up4_fwd 32 + the register-resident-weights kernel 76, weight gradient 94 against
+        # 67: 8479 vs 8567 pairs/s.  OFF by default; DAHITRA_FUSED_UP4_FWD=1 turns it on.
+        self.fused_up4_fwd = os.environ.get("DAHITRA_FUSED_UP4_FWD", "0") == "1"
         self.use_side = os.environ.get("DAHITRA_SIDE_STREAM", "0") == "1"
         self.side = None
         self._deferred_wgrad = None
@@ -364,14 +370,15 @@ class Engine:
                             groups, accumulate=True, mask_scale=scale, mask_shift=shift)
             ops.stem_wgrad(xs, dy, self.g[wkey], accumulate=True, use_tr=self.use_tr)
 
-        def from_pool(parg_, dpool):
+        def from_pool(parg_, dpool, extra=None):
             """backward entered at the max-pool's output: pool backward + ReLU mask + BN sums in one pass, BN backward itself
-            inside the weight gradient's loads (the stem has no data gradient)"""
+            inside the weight gradient's loads (the stem has no data gradient).  extra: a second gradient of the stem's output
+            (the hierarchical model's level-2 tap), summed in the same pass"""
             d, coef = ops.stem_pool_bn_bwd(parg_, dpool, y, scale, shift, mean, invstd, gamma, self.g[bnkey + ".weight"],
-                                           self.g[bnkey + ".bias"], groups)
+                                           self.g[bnkey + ".bias"], groups, extra=extra)
             ops.stem_wgrad(xs, d, self.g[wkey], accumulate=True, use_tr=self.use_tr, bn=(y, coef, groups))
-        if pool and self.training and direct and self.fused_stem_bwd:
-            bwd.from_pool = from_pool
+        if self.training and direct and self.fused_stem_bwd and self.need_grad:
+            bwd.from_pool = from_pool        # (pool=False: the caller pooled the materialised output itself and kept the arg-max)
         if pool:
             return pooled, parg, oshape, (bwd if self.need_grad else None)
         if not self.need_grad:
@@ -806,7 +813,7 @@ class Engine:
         if d is None:
             return
         x, dy, wkey, ks, stride, pad, dilation = d
-        with self.side.fork(x.y if isinstance(x, ops.BnInput) else x, dy):
+        with self.side.fork(x.y if isinstance(x, ops.BnInput) else (x.a if isinstance(x, ops.Up4Input) else x), dy):
             ops.conv2d_wgrad(x, dy, self.g[wkey], ks, stride, pad, accumulate=True, use_tr=self.use_tr, dilation=dilation)
 
     def _side_join(self):
@@ -890,8 +897,15 @@ class Engine:
         dec, b_dec = self.decoder(feat.view(S2 * hw, DIM), S2, tok2d, 2 * L * DIM, L * DIM, B, dtok,
                                   "transformer_decoder", cfg["dec_depth"], BIT_HEADS, cfg["dec_dim_head"], L)
         dec4 = dec.view(S2, fh, fw, DIM)
-        upd = ops.absdiff_upsample4(dec4[:B], dec4[B:])
-        h, b_c0 = self.conv_bn(upd, "classifier.0.weight", "classifier.1", 3, 1, 1, 1, True, lazy=True, side_wgrad=True)
+        # bf16: |A - B| + bilinear x4 happen inside classifier.0's loads (ops.Up4Input: forward and weight gradient; the data
+        # gradient goes straight to the coarse maps below) -- the 32 x 4h x 4w map is never written or read
+        k0 = "classifier.0.weight"
+        if self.fused_up4_fwd and self.dtype == torch.bfloat16 and DIM == 32 and tuple(self.shapes[k0][:2]) == (32, 32) and \
+                tuple(self.pk[k0].fwd.shape) == (9, 32, 32):
+            upd = ops.Up4Input(dec4[:B].contiguous(), dec4[B:].contiguous())
+        else:
+            upd = ops.absdiff_upsample4(dec4[:B], dec4[B:])
+        h, b_c0 = self.conv_bn(upd, k0, "classifier.1", 3, 1, 1, 1, True, lazy=True, side_wgrad=True)
         logits, b_out = self._head_out(h, "classifier.3.weight", "classifier.3.bias")
         if not self.need_grad:
             return logits, None
@@ -1136,7 +1150,10 @@ class Engine:
             ds8 = ops.add(ds8, ops.maxpool_bwd(arg16, dp16, s8.shape))
             ds4 = ops.add(ds4, b_l2(ds8))
             dp4 = b_l1(ds4)
-            b_stem(ops.add(ds2, ops.maxpool_bwd(arg4, dp4, s2.shape)))
+            if hasattr(b_stem, "from_pool") and os.environ.get("DAHITRA_NO_FUSED_STEM_BWD_UNET", "0") != "1":
+                b_stem.from_pool(arg4, dp4, extra=ds2)             # add + max-pool backward + both BatchNorm passes in one
+            else:
+                b_stem(ops.add(ds2, ops.maxpool_bwd(arg4, dp4, s2.shape)))
 
         def bwd(dl):
             bwd_second(bwd_first(dl))

@@ -374,6 +374,9 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     """gate = (out_relu | None, y_pre_bn, mean, invstd, groups): BN-backward gating of a data-gradient launch; the
     call then returns (g, partials) for bn_bwd_from_partials (see include/dahitra_hip.h).
     x may be a BnInput: BatchNorm-apply + ReLU happen on load."""
+    if isinstance(x, Up4Input):
+        assert ks == 3 and stride == 1 and pad == 1 and dilation == 1 and residual is None and gate is None and not want_preact
+        return _conv3x3_up4(x, wp, cout, bias, act, want_stats)
     bn_in = x if isinstance(x, BnInput) else None
     if bn_in is not None:
         x = bn_in.y
@@ -409,6 +412,42 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     if want_preact:
         out.append(pre)
     return out[0] if len(out) == 1 else tuple(out)
+
+
+class Up4Input:
+    """nn.Upsample(4, 'bilinear')(|a - b|) of two [N, h, w, 32] bf16 maps WITHOUT the [N, 4h, 4w, 32] tensor (models/networks.py:
+    383-389: the input of classifier.0): conv2d and conv2d_wgrad interpolate their tiles from a and b while they load
+    (dh_conv3x3_up4_fwd / dh_conv2d_wgrad_up4); `.shape` is the shape the upsampled tensor would have."""
+    __slots__ = ("a", "b")
+
+    def __init__(self, a, b):
+        assert a.shape == b.shape and a.dim() == 4 and a.shape[-1] == 32 and a.dtype == torch.bfloat16
+        assert a.is_contiguous() and b.is_contiguous()
+        self.a, self.b = a, b
+
+    @property
+    def shape(self):
+        n, h, w, c = self.a.shape
+        return torch.Size((n, 4 * h, 4 * w, c))
+
+    def materialize(self):
+        return absdiff_upsample4(self.a, self.b)
+
+
+def _conv3x3_up4(u, wp, cout, bias, act, want_stats):
+    N, H, W, _ = u.shape
+    assert cout == 32 and tuple(wp.shape) == (9, 32, 32) and wp.dtype == torch.bfloat16
+    y = torch.empty(N, H, W, 32, dtype=torch.bfloat16, device=u.a.device)
+    stats = None
+    if want_stats:
+        stats = torch.empty(2, 32, _lib.lib().dh_conv2d_fwd_num_tiles(N, H, W, 32, 3, 1), dtype=torch.float32, device=y.device)
+    key, flops = "conv_mfma<bf16,ks3,s1,nt32>", 2.0 * N * H * W * 32 * 32 * 9
+    fixed = (P(u.a), P(u.b), P(wp), P(bias), _ci(act), P(y), P(stats), _ci(N), _ci(H), _ci(W))
+    with _Prof(key, flops, _nb(u.a, u.b, y, wp)):
+        _call("dh_conv3x3_up4_fwd", *fixed, S())
+    if REPLAY is not None and key == REPLAY["key"]:
+        REPLAY["calls"].append((lambda stream, fixed=fixed: _call("dh_conv3x3_up4_fwd", *fixed, stream), (u.a, u.b, wp, bias, y, stats), flops))
+    return (y, stats) if want_stats else y
 
 
 class SplitCat:
@@ -522,6 +561,8 @@ def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=
         return _conv2d_wgrad_bn_in(x, dy, dw, ks, stride, pad, accumulate, use_tr, cout_real, dilation, defer)
     if isinstance(x, SplitCat):
         return _conv2d_wgrad_split(x, dy, dw, ks, stride, pad, accumulate, defer)
+    if isinstance(x, Up4Input):
+        return _conv2d_wgrad_up4(x, dy, dw, ks, stride, pad, accumulate, defer)
     N, H, W, pitch = x.shape
     Cin = cin if cin else pitch
     _, OH, OW, Cout = dy.shape
@@ -564,6 +605,31 @@ def _conv2d_wgrad_split(xs, dy, dw, ks, stride, pad, accumulate, defer):
             _call("dh_conv2d_wgrad_split", P(xs.t), _cl(xs.split_bytes), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W),
                   _ci(Cin), _ci(Cout), P(ws), ctypes.byref(sk), S())
         plan.hold(xs.t, dy)
+        plan.add(ws, dw, sk.value, 9, Cout, Cout, Cin, accumulate)
+        if own:
+            plan.run()
+    finally:
+        if own:
+            plan.__exit__(*sys.exc_info())
+
+
+def _conv2d_wgrad_up4(u, dy, dw, ks, stride, pad, accumulate, defer):
+    """weight gradient against an Up4Input (3x3 / stride 1 / pad 1, bf16): the upsampled map is formed on load"""
+    assert ks == 3 and stride == 1 and pad == 1
+    N, H, W, Cin = u.shape
+    Cout = dy.shape[-1]
+    nbytes = _lib.lib().dh_conv2d_wgrad_workspace_size(N, H, W, Cin, Cout, 3, 1)
+    plan, own = (_WGRAD_PLAN if defer else None), False
+    if plan is None:
+        plan, own = WgradPlan(dy.device), True
+        plan.__enter__()
+    try:
+        ws = plan.slab(nbytes)
+        sk = ctypes.c_int(0)
+        with _Prof("conv_wgrad<bf16,ks3,s1>", 2.0 * N * H * W * Cout * Cin * 9, _nb(u.a, u.b, dy)):
+            _call("dh_conv2d_wgrad_up4", P(u.a), P(u.b), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W), _ci(Cout),
+                  P(ws), ctypes.byref(sk), S())
+        plan.hold(u.a, u.b, dy)
         plan.add(ws, dw, sk.value, 9, Cout, Cout, Cin, accumulate)
         if own:
             plan.run()
@@ -734,15 +800,17 @@ def stem7_fwd(x1, x2, w, out_scale=None, bias=None, relu=False, want_stats=False
     return y, stats, xs
 
 
-def stem_pool_bn_bwd(arg, dpool, y, scale, shift, mean, invstd, gamma, dgamma, dbeta, groups, accumulate=True):
-    """maxpool backward + ReLU mask + BatchNorm-backward sums of the stem's tail in one pass -> (d masked, coef [groups,3,C])"""
+def stem_pool_bn_bwd(arg, dpool, y, scale, shift, mean, invstd, gamma, dgamma, dbeta, groups, accumulate=True, extra=None):
+    """maxpool backward + ReLU mask + BatchNorm-backward sums of the stem's tail in one pass -> (d masked, coef [groups,3,C]).
+    extra: a second gradient of the pre-pool activation (same shape as y), added before the mask"""
     N, H, W, C = y.shape
     d = torch.empty_like(y)
     coef = torch.empty(groups, 3, C, dtype=torch.float32, device=y.device)
     L = _lib.lib()
     ws = workspace(L.dh_stem_pool_bn_bwd_workspace_size(C, groups), y.device)
-    with _Prof("bn_bwd", 0, _nb(arg, dpool, y, d)):
-        _call("dh_stem_pool_bn_bwd", P(arg), P(dpool), P(y), P(scale), P(shift), P(mean), P(invstd), P(gamma), _ci(N), _ci(H),
+    assert extra is None or (extra.shape == y.shape and extra.dtype == y.dtype)
+    with _Prof("bn_bwd", 0, _nb(arg, dpool, y, d, extra)):
+        _call("dh_stem_pool_bn_bwd_plus", P(arg), P(dpool), P(extra), P(y), P(scale), P(shift), P(mean), P(invstd), P(gamma), _ci(N), _ci(H),
               _ci(W), _ci(C), _ci(groups), P(d), P(coef), P(dgamma), P(dbeta), _ci(int(accumulate)), P(ws), S())
     return d, coef
 

@@ -133,6 +133,19 @@ int dh_conv3x3_split_fwd(const void* x, long x_split_bytes, const void* w_packed
                          float* stats_partial, int N, int H, int W, int Cin, int Cout, void* stream);
 int dh_conv2d_wgrad_split(const void* x, long x_split_bytes, const void* dy, float* dw_oihw, int accumulate, int N, int H, int W,
                           int Cin, int Cout, void* workspace, int* splitk_out, void* stream);
+/* classifier.0 on nn.Upsample(4, 'bilinear')(abs(x1 - x2)) WITHOUT that map (models/networks.py:383-389, models/help_funcs.py:9;
+ * bf16): a, b [N][H / 4][W / 4][32] are the two streams' decoder outputs, H x W the fine size (multiples of 4).
+ *   dh_conv3x3_up4_fwd   y [N][H][W][32] = act(conv3x3(upsample4(|a - b|)) + bias), act 0 / ReLU; w_packed [9][32][32]
+ *                        (dh_pack_weight forward form); stats_partial as dh_conv2d_fwd, dh_conv2d_fwd_num_tiles(N, H, W, 32, 3, 1)
+ *                        rows.  The 8 x 16-pixel tile's haloed input is interpolated from its 4 x 6 coarse footprint with the
+ *                        terms and order of dh_absdiff_upsample4_fwd: equal to dh_conv2d_fwd on that kernel's output, bit for bit.
+ *   dh_conv2d_wgrad_up4  dh_conv2d_wgrad_partial of that layer (17 <= Cout <= 32) with the same interpolation on load.
+ * (the data gradient through the upsample is dh_conv3x3_dgrad_up4; together the 32 x H x W map -- 134 MB at batch 32 -- is
+ * neither written nor read: F.interpolate + abs + F.conv2d and their autograd terms) */
+int dh_conv3x3_up4_fwd(const void* a, const void* b, const void* w_packed, const float* bias, int act, void* y, float* stats_partial,
+                       int N, int H, int W, void* stream);
+int dh_conv2d_wgrad_up4(const void* a, const void* b, const void* dy, float* dw_oihw, int accumulate, int N, int H, int W, int Cout,
+                        void* workspace, int* splitk_out, void* stream);
 /* Batched weight gradients: the 3x3 stride-1 bf16 layers of one backward pass as ONE launch per kernel family (the
  * wave-specialised 64co x 64ci form: Cin and Cout multiples of 64; the 32-wide output tile: 16 < Cout <= 32).  Between dh_wgrad_batch_begin() and dh_wgrad_batch_end(), dh_conv2d_wgrad_partial /
  * dh_conv2d_wgrad_bn_in (with splitk_out) only RECORD an eligible layer -- *splitk_out is its in-batch slice count, smaller
@@ -207,6 +220,13 @@ int dh_stem_pool_bn_bwd(const unsigned char* argmax, const void* dpool, const vo
                         const float* mask_shift, const float* mean, const float* invstd, const float* gamma, int N, int H, int W,
                         int C, int groups, void* d, float* coef, float* dgamma, float* dbeta, int accumulate, void* workspace,
                         void* stream);
+/* dh_stem_pool_bn_bwd with a second gradient of the same pre-pool activation, extra [N][H][W][C] (or NULL), added before the
+ * mask: the hierarchical model reads the stem's output twice (models/networks.py:1118-1128 max-pool -> layer1, :1344
+ * cat([a_128, b_128]) -> conv_layer2_0), so the add, the max-pool backward and both BatchNorm-backward passes are this one. */
+int dh_stem_pool_bn_bwd_plus(const unsigned char* argmax, const void* dpool, const void* extra, const void* y,
+                             const float* mask_scale, const float* mask_shift, const float* mean, const float* invstd,
+                             const float* gamma, int N, int H, int W, int C, int groups, void* d, float* coef, float* dgamma,
+                             float* dbeta, int accumulate, void* workspace, void* stream);
 int dh_stem_wgrad_bn(const void* xs16, const void* d, const void* y, const float* coef, int groups, int N, int OH, int OW,
                      float* dw2, int use_tr, void* workspace, void* stream);
 

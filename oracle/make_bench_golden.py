@@ -9,7 +9,9 @@ finalize, 32x the rows per fused decoder launch.  Each case here is ONE train-mo
 seeded inputs of oracle/cdnet_ref.synthetic_batch with the deterministic weights:
     strided train-mode logits + their sum / abs-sum, the loss, the set of gradient-less parameters, every parameter's
     gradient norm, the small gradients in full (xBD additionally: channel losses, total gradient norm).
-The ResNet-50 case is forward only (train-mode BatchNorm, batch statistics) -- its backward does not fit this container.
+The ResNet-50 case at 1024 x 1024, batch 8 is forward only (its backward does not fit this container); r50_512_b8_train is the
+full step at the largest size that does (15.5 GB peak): 16 images of 64 x 64 layer3 maps = 256 sixteen-row tiles, i.e. the
+dilation-2 data / weight gradients run the tile forms of the benchmarked size; every large gradient is sampled element-wise.
 tests/test_bench_sizes_gpu.py runs the HIP path (the recorded graph where bench.py uses one) against them."""
 import os
 import resource
@@ -31,7 +33,11 @@ CASES = {   # case -> (net, batch, size, logit stride, seed)
     "o5_512_b8": ("base_transformer_pos_s4_dd8_o5", 8, 512, 16, 1234),
     "xbd_1024_b4": ("xbd_unet_transformer", 4, 1024, 32, 11),
     "r50_1024_b8": ("base_transformer_pos_s4_resnet50", 8, 1024, 32, 2024),
+    # the ResNet-50 trunk's BACKWARD at the largest size the container holds (see R50_TRAIN): the dilation-2 3x3 layers'
+    # data / weight gradients on 16-row tiles (>= 256 tiles of 16 x 16 pixels on the 64 x 64 layer3 maps of 16 images)
+    "r50_512_b8_train": ("base_transformer_pos_s4_resnet50", 8, 512, 16, 2025),
 }
+SAMPLE = 997       # R50 train cases: every SAMPLE-th element of each large gradient is stored as well
 
 
 def _sub(t, stride):
@@ -77,6 +83,19 @@ def main():
             rec["channel_losses"] = np.array([float(l) for l in per], dtype=np.float64)
             _grads(net, rec)
             rec["total_norm"] = np.float64(float(torch.nn.utils.clip_grad_norm_(net.parameters(), 0.999)))
+            y = out.detach()
+        elif cfg.get("backbone") == "resnet50" and case.endswith("_train"):
+            net = ref_import.build_resnet50_variant()
+            net.load_state_dict(O.deterministic_state(name))
+            net.train()
+            out = net(a, b)
+            loss = ref_losses.focal_loss(out, lab)
+            loss.backward()
+            _grads(net, rec)
+            for k, p in net.named_parameters():          # element-wise samples of the large gradients (conv weights)
+                if p.grad is not None and p.numel() > SMALL:
+                    rec["gsample/" + k] = p.grad.flatten()[::SAMPLE].numpy().copy()
+            rec["sample_stride"] = SAMPLE
             y = out.detach()
         elif cfg.get("backbone") == "resnet50":
             net = ref_import.build_resnet50_variant()

@@ -160,3 +160,53 @@ def test_resnet50_trunk_at_1024_batch_8_forward_and_fp8_train_step(golden_dir):
     y = net(a.cuda(), b.cuda())
     losses.focal_loss(y, lab.cuda()).backward()
     assert torch.isfinite(y).all() and all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+
+
+def test_resnet50_trunk_backward_on_sixteen_row_tiles_matches_the_reference(golden_dir):
+    """The ResNet-50 variant's BACKWARD at a size where its dilation-2 3x3 layers (models/resnet.py:76-122, layer3 blocks 1-5)
+    run the tile forms of the benchmarked configuration: 512 x 512, batch 8 = 16 images of 64 x 64 layer3 maps = 256
+    sixteen-row tiles (asserted), the full-chip weight-gradient split, 33 MB BatchNorm tensors.  Fixture written by the
+    reference (oracle/make_bench_golden.py r50_512_b8_train, 15.5 GB peak on the CPU): train-mode logits, loss, every gradient
+    norm, the small gradients in full and every 997th element of each large one.  Bounds: multiples of the measured fp32 noise
+    floor of this net (tests/golden/grad_noise_floor.json: this 50-layer trunk amplifies rounding to 1e-2 relative L2 per tensor)."""
+    import json
+    from dahitra_amd import _lib
+    from dahitra_amd.models import losses
+    g, name, stride, a, b, lab = load(golden_dir, "r50_512_b8_train")
+    fl = json.load(open(os.path.join(golden_dir, "grad_noise_floor.json")))[name]
+    L = _lib.lib()
+    assert L.dh_conv2d_fwd_num_tiles(16, 64, 64, 256, 3, 1) == 16 * 4 * 4          # layer3's 3x3 convolutions: 16-row tiles
+    net = make_net(name, "fp32")
+    y = net(a.cuda(), b.cuda())
+    loss = losses.focal_loss(y, lab.cuda())
+    loss.backward()
+    check_logits(g, y.detach().float().cpu(), stride, 6e-4, "resnet50 512x512 batch 8 fp32")
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * max(1.0, float(g["loss"]))
+    params = dict(net.named_parameters())
+    assert sorted(k for k, p in params.items() if p.grad is None) == sorted(g["nograd_keys"].tolist())
+    nrel = []
+    for k, v in zip(g["gradnorm_keys"].tolist(), g["gradnorm_vals"].tolist()):
+        nrel.append(abs(float(params[k].grad.double().norm()) - v) / max(v, 1e-12))
+    # element-wise: the sampled large gradients (relative L2 over the sample) and the small ones in full
+    rl2, worst = [], ("", 0.0)
+    st = int(g["sample_stride"])
+    for k in g.files:
+        if k.startswith("gsample/") or k.startswith("grad0/"):
+            key = k.split("/", 1)[1]
+            got = params[key].grad.detach().cpu().double().flatten()
+            got = got[::st] if k.startswith("gsample/") else got
+            want = torch.from_numpy(g[k]).double().flatten()
+            if float(want.norm()) == 0:
+                continue
+            r = float((got - want).norm() / want.norm())
+            rl2.append(r)
+            if r > worst[1]:
+                worst = (key, r)
+    dil = [r for k, r in zip([k for k in g.files if k.startswith("gsample/")], rl2) if "layer3" in k and "conv2" in k]
+    print("resnet50 512x512 batch 8: gradient norms rel err median %.2e max %.2e; element-wise rel-L2 median %.2e, worst %.2e (%s); "
+          "%d dilated 3x3 weight gradients sampled; floor of this net: rel-L2 median %.2e max %.2e"
+          % (float(np.median(nrel)), max(nrel), float(np.median(rl2)), worst[1], worst[0], len(dil), fl["rel_l2"]["median"],
+             fl["rel_l2"]["max"]))
+    assert len(dil) >= 5
+    assert float(np.median(rl2)) <= 5.0 * fl["rel_l2"]["median"] and worst[1] <= 8.0 * fl["rel_l2"]["max"], (worst, float(np.median(rl2)))
+    assert max(nrel) <= 8.0 * fl["rel_l2"]["max"] and float(np.median(nrel)) <= 5.0 * fl["rel_l2"]["median"]

@@ -1421,3 +1421,48 @@ def test_head_data_gradient_with_the_relu_in_front_of_it_folded_in(ops):
     got = ops.head_dgrad3x3(dl, w, 2, relu_out=out)
     assert torch.equal(got, want)
     assert float((got != 0).float().mean()) < float((ops.head_dgrad3x3(dl, w, 2) != 0).float().mean())
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=2, h=16, w=16),          # 64 x 64 fine map
+    dict(n=3, h=6, w=10),           # 24 x 40: ragged tiles in both directions, odd batch
+    dict(n=1, h=1, w=2),            # one coarse row: every bilinear index clamps
+    dict(n=32, h=64, w=64),         # the bench's classifier.0: 32 x 256 x 256
+])
+def test_classifier0_on_the_upsampled_absdiff_map_formed_on_load(ops, cfg):
+    """abs(x1 - x2) -> nn.Upsample(4, 'bilinear') -> classifier.0 (models/networks.py:383-389, help_funcs.py:9) with the
+    upsampled map formed inside the convolution's and the weight gradient's loads (ops.Up4Input): equal -- bit for bit for the
+    forward and its BatchNorm partial sums -- to the two-kernel path through the materialised map, which is checked against
+    F.interpolate(..., 'bilinear', align_corners=False) + F.conv2d in fp32 and their autograd weight gradient."""
+    N, h, w = cfg["n"], cfg["h"], cfg["w"]
+    dtype = torch.bfloat16
+    a, b = rnd((N, 32, h, w), dtype, 1401), rnd((N, 32, h, w), dtype, 1402)
+    wt = rnd((32, 32, 3, 3), dtype, 1403, (32 * 9) ** -0.5).requires_grad_(True)
+    bias = rnd((32,), torch.float32, 1404, 0.1)
+    up = F.interpolate((a - b).abs(), scale_factor=4, mode="bilinear", align_corners=False)
+    y_t = F.conv2d(up, wt, None, 1, 1)
+    dy = rnd(tuple(y_t.shape), dtype, 1405)
+    y_t.backward(dy)
+    ad, bd, dyd = dev(nhwc(a), dtype), dev(nhwc(b), dtype), dev(nhwc(dy), dtype)
+    wp, _ = ops.pack_weight(wt.detach().cuda(), dtype, want_dgrad=False)
+    u = ops.Up4Input(ad, bd)
+    assert tuple(u.shape) == (N, 4 * h, 4 * w, 32)
+    mat = u.materialize()
+    y_ref, st_ref = ops.conv2d(mat, wp, 32, 3, 1, 1, want_stats=True)
+    y, st = ops.conv2d(u, wp, 32, 3, 1, 1, want_stats=True)
+    assert torch.equal(y, y_ref), float((y.float() - y_ref.float()).abs().max())
+    # (the materialised path may take the register-resident-weights kernel, whose per-tile sums add the two row halves of a
+    # tile in another order: equal up to fp32 rounding there, bit-identical against the tap kernel)
+    assert torch.equal(st, st_ref) or float((st - st_ref).abs().max()) <= 1e-5 * float(st_ref.abs().max())
+    close(nchw(y), y_t.detach(), dtype, "conv over the upsampled |a - b| (formed on load)", factor=2.0)
+    # bias + ReLU epilogue (the eval-mode form: BatchNorm folded into the weights, its shift as the bias)
+    y2 = ops.conv2d(u, wp, 32, 3, 1, 1, bias=bias.cuda(), act=ops.ACT_RELU)
+    assert torch.equal(y2, ops.conv2d(mat, wp, 32, 3, 1, 1, bias=bias.cuda(), act=ops.ACT_RELU))
+    # weight gradient
+    dw_ref = torch.zeros(32, 32, 3, 3, device="cuda")
+    dw = torch.full_like(dw_ref, -0.5)
+    ops.conv2d_wgrad(mat, dyd, dw_ref, 3, 1, 1)
+    ops.conv2d_wgrad(u, dyd, dw, 3, 1, 1, accumulate=True)
+    err = float((dw + 0.5 - dw_ref).abs().max())
+    assert err <= 2e-5 * float(dw_ref.abs().max()), err
+    close(dw_ref, wt.grad, dtype, "weight gradient over the upsampled |a - b|", factor=4.0)

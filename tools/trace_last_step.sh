@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/trace_last_step.sh <tag> [bench.py args]  -- kernel sequence of the LAST step of a bench run
+# usage (GPU box): bash tools/trace_last_step.sh <tag> [bench.py args]  -- kernel sequence of the fastest (graph-replayed) step of a bench run
 # (rocprofv3 --kernel-trace), written to gpurun_out/<tag>_last_step.txt: index, duration us, gap to the previous kernel, name
 tag=$1; shift
 R=$GRAFT_REPO_ROOT
@@ -11,7 +11,11 @@ import csv, glob, sys, re
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "adamw_tick" in r["Kernel_Name"] or "adamw_kernel" in r["Kernel_Name"]]
-lo, hi = idx[-2] + 1, idx[-1] + 1
+# the step with the SHORTEST span between two optimizer launches: a replay of the recorded graph (the run's last steps are the
+# eager profiling steps of bench.py, whose launches come from Python one by one)
+span = lambda k: int(rows[idx[k + 1]]["End_Timestamp"]) - int(rows[idx[k] + 1]["Start_Timestamp"])
+k = min(range(len(idx) - 1), key=span)
+lo, hi = idx[k] + 1, idx[k + 1] + 1
 prev = int(rows[lo - 1]["End_Timestamp"])
 with open(sys.argv[2], "w") as o:
     tot = gaps = 0
