@@ -50,20 +50,7 @@ struct WgArgs {
     // x = cat([A, B], channel) of two [N][H][W][Cin / 2] tensors, B at x + x_split bytes (0: off), never materialised
     // (ConvArgs::x_split; wave-specialised kernel only: a 64-channel ci tile lies in one of the two)
     long x_split;
-    // x = bilinear-x4 upsampled |A - B| of two [N][H / 4][W / 4][32] bf16 maps, formed ON LOAD (x itself is not read; H, W are the
-    // fine sizes): classifier.0's weight gradient without the 32 x H x W map (ConvArgs::up4_a; models/networks.py:383-389).
-    // 32 -> <= 32 channel 3x3 / stride 1 layers only (the 32-wide output tile form of wg_body).
-    const void* up4_a;
-    const void* up4_b;
 };
-// source rows / columns and weight of a bilinear x4 destination index (align_corners = False; = bil_src of pointwise.hip)
-__device__ __forceinline__ void wg_up4_src(int d, int in, int& i0, int& i1, float& l) {
-    float s = ((float)d + 0.5f) * 0.25f - 0.5f;
-    if (s < 0.f) s = 0.f;
-    i0 = (int)s;
-    i1 = i0 + (i0 < in - 1 ? 1 : 0);
-    l = s - (float)i0;
-}
 
 constexpr int lds_pitch(int row_bytes) { return ((row_bytes / 32) & 1) ? row_bytes : row_bytes + 32; }
 
@@ -93,8 +80,6 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
     constexpr int TAPS = KS * KS;
     constexpr int NI = IT / 16;
     constexpr bool WCI = CIG == 2 && sizeof(T) == 2 && IT == 32 && CTT == 64;       // see the MFMA loop
-    // the one instantiation that can form its x tile from the coarse |A - B| maps (WgArgs::up4_a): 32 input channels = one tile
-    constexpr bool UP4CAP = sizeof(T) == 2 && KS == 3 && STRIDE == 1 && DIL == 1 && IT == 32 && CTT == 32 && CIG == 1 && !DYT && TR;
     // LDS pitches are ODD multiples of 32 B: a half-wave of ds_read_b64_tr_b16 then touches 8 consecutive
     // pixel rows x 32 B = 8 distinct bank windows of the 256-byte bank row (conflict-free)
     constexpr int XP = lds_pitch(ITT * (int)sizeof(T));    // halo pitch (bytes)
@@ -185,11 +170,6 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
                       (co0 + CT <= p.Cout || (p.Cout - co0) % EPV == 0);
     unsigned x_okmask = 0;    // pieces of the fetched halo that lie inside the image (BatchNorm-on-load leaves padding zero)
     int c_bng = 0;            // BatchNorm group of the fetched tile's image
-    // UP4: the fetched tile's origin and this thread's |A - B| footprint piece (threads < 96: coarse pixel tid / 4, piece tid % 4)
-    int u_oy0 = 0, u_ox0 = 0;
-    uint4 u_a = make_uint4(0, 0, 0, 0), u_b = u_a;
-    const bool up4 = UP4CAP && p.up4_a != nullptr;
-    float* cf = bnp;          // UP4: [4][6][32] fp32 footprint (the layer has no BatchNorm on load: the slot is free)
     auto fetch = [&]() {      // loads the tile the counter points at, then advances the counter
         const int n = ((KS == 2 && p.phase_mode) ? 0 : grp * imgs_per_group) + f_n;
         x_okmask = 0;
@@ -197,34 +177,12 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
         c_bng = p.in_scale ? n / (p.N / p.in_groups) : (DYT ? n / (p.N / p.dyt_groups) : 0);
         const int oy0 = f_ty * TH, ox0 = f_tx * TW;
         const int iy0 = oy0 * STRIDE - p.pad + ph_a, ix0 = ox0 * STRIDE - p.pad + ph_b;
-        if constexpr (UP4CAP) {
-            if (up4) {
-                u_oy0 = oy0; u_ox0 = ox0;
-                const int CHh = p.H >> 2, CWw = p.W >> 2;
-                if (tid < 96) {
-                    const int fp = tid >> 2, q = tid & 3, r = fp / 6, c = fp - r * 6;
-                    int cy = (oy0 >> 2) - 1 + r, cx = (ox0 >> 2) - 1 + c;
-                    cy = cy < 0 ? 0 : (cy > CHh - 1 ? CHh - 1 : cy);
-                    cx = cx < 0 ? 0 : (cx > CWw - 1 ? CWw - 1 : cx);
-                    const size_t off = (((size_t)n * CHh + cy) * CWw + cx) * 32 + q * 8;
-                    u_a = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.up4_a) + off);
-                    u_b = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.up4_b) + off);
-                }
-#pragma unroll
-                for (int i = 0; i < NXV; ++i) {
-                    const int iy = iy0 + x_hy[i], ix = ix0 + x_hx[i];
-                    const bool ok = x_mode[i] != 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                    x_okmask |= ok ? (1u << i) : 0u;
-                }
-            }
-        }
         if (fast) {
             const unsigned char* xb = reinterpret_cast<const unsigned char*>(
                 reinterpret_cast<const T*>(p.x) + (size_t)n * p.H * p.W * p.CinPitch);
             const unsigned char* db = reinterpret_cast<const unsigned char*>(
                 reinterpret_cast<const T*>(p.dy) + (size_t)n * p.OH * p.OW * p.Cout * ((KS == 2 && p.phase_mode) ? 4 : 1));
             const unsigned xps = (unsigned)p.CinPitch * (unsigned)sizeof(T), dps = (unsigned)p.Cout * (unsigned)sizeof(T);
-            if (!up4) {
 #pragma unroll
             for (int i = 0; i < NXV; ++i) {
                 const int iy = iy0 + x_hy[i], ix = ix0 + x_hx[i], lin = iy * p.W + ix;
@@ -232,7 +190,6 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
                 const uint4 v = *reinterpret_cast<const uint4*>(xb + (ok ? (unsigned)lin * xps + (unsigned)xcb * (unsigned)sizeof(T) : 0u));
                 rx[i] = ok ? v : make_uint4(0, 0, 0, 0);
                 x_okmask |= ok ? (1u << i) : 0u;
-            }
             }
 #pragma unroll
             for (int i = 0; i < NDV; ++i) {
@@ -283,51 +240,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
         if (f_ty >= p.tilesY) { f_ty -= p.tilesY; ++f_n; }
         f_n += dn;
     };
-    // UP4: |A - B| of the fetched tile's coarse footprint -> LDS (called where the fetch's loads have had a tile's MFMAs to land;
-    // the barrier that follows publishes it to commit())
-    auto stage_cf = [&]() {
-        if constexpr (UP4CAP) {
-            if (up4 && tid < 96) {
-                float u[8], v[8];
-                unpack16(u_a, u);
-                unpack16(u_b, v);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) cf[tid * 8 + j] = fabsf(u[j] - v[j]);       // [(fp * 4 + q) * 8 + j] = [fp][32]
-            }
-        }
-    };
     auto commit = [&]() {
-        if constexpr (UP4CAP) {
-            if (up4) {             // x piece = 8 channels of one fine pixel, interpolated from the footprint (terms and order of
-                                   // absdiff_up4_fwd_kernel / conv_mfma_kernel's INUP4: the same bf16 values that tensor would hold)
-                const int CHh = p.H >> 2, CWw = p.W >> 2, cyb = (u_oy0 >> 2) - 1, cxb = (u_ox0 >> 2) - 1, q = tid % XQ;
-#pragma unroll
-                for (int i = 0; i < NXV; ++i) {
-                    rx[i] = make_uint4(0, 0, 0, 0);
-                    if (!((x_okmask >> i) & 1u)) continue;
-                    int y0, y1, x0, x1;
-                    float ly, lx;
-                    wg_up4_src(u_oy0 - 1 + x_hy[i], CHh, y0, y1, ly);
-                    wg_up4_src(u_ox0 - 1 + x_hx[i], CWw, x0, x1, lx);
-                    const float wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
-                    const int rr[2] = {y0 - cyb, y1 - cyb}, cc[2] = {x0 - cxb, x1 - cxb};
-                    float acc8[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc8[j] = 0.f;
-#pragma unroll
-                    for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                        for (int qq = 0; qq < 2; ++qq) {
-                            const float* d = cf + (rr[pp] * 6 + cc[qq]) * 32 + q * 8;
-                            const float4 d0 = *reinterpret_cast<const float4*>(d), d1 = *reinterpret_cast<const float4*>(d + 4);
-                            const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) acc8[j] += wy[pp] * wx[qq] * dv[j];
-                        }
-                    rx[i] = pack16<bf16>(acc8);
-                }
-            }
-        }
         if (p.in_scale) {          // x = relu(x * scale + shift) on its way into LDS; this thread's pieces share their channels
             float sc[EPV], sh[EPV];
             const float* sp = bnp + c_bng * 2 * ITT + (tid % XQ) * EPV;
@@ -395,9 +308,6 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
         __syncthreads();
     }
     if (kz < ntiles) fetch();
-    if constexpr (UP4CAP) {
-        if (up4) { stage_cf(); __syncthreads(); }
-    }
     for (int tile = kz; tile < ntiles; tile += p.splitk) {
         commit();
         __syncthreads();
@@ -497,7 +407,6 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
                 }
             }
         }
-        if (tile + p.splitk < ntiles) stage_cf();          // (UP4: the next tile's footprint; commit() reads it behind this barrier)
         __syncthreads();
     }
 
@@ -1008,7 +917,7 @@ static inline bool c32_eligible(const WgArgs& a, int ks, int stride, bool bf16, 
 static size_t c32_lds(const WgArgs& a) {
     constexpr int HH = (TH - 1) + 2 + 1, HWD = (TW - 1) + 2 + 1;
     size_t lds = (size_t)HH * HWD * lds_pitch(32 * 2) + (size_t)TH * TW * lds_pitch(32 * 2) +
-                 (a.in_scale ? (size_t)a.in_groups * 2 * 32 * sizeof(float) : 0) + (a.up4_a ? (size_t)4 * 6 * 32 * sizeof(float) : 0);
+                 (a.in_scale ? (size_t)a.in_groups * 2 * 32 * sizeof(float) : 0);
     const size_t red = (size_t)(32 / 16) * 9 * (32 / 16) * 64 * 16;      // the end-of-kernel wave-group combine (launch_ct)
     return lds < red ? red : lds;
 }
@@ -1055,7 +964,7 @@ int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     size_t lds = (size_t)HH * HWD * lds_pitch(IT * CIG * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T)) +
                  (a.in_scale ? (size_t)a.in_groups * 2 * IT * CIG * sizeof(float) : 0) +
-                 (a.dyt_y ? (size_t)a.dyt_groups * 3 * CT * sizeof(float) : 0) + (a.up4_a ? (size_t)4 * 6 * 32 * sizeof(float) : 0);
+                 (a.dyt_y ? (size_t)a.dyt_groups * 3 * CT * sizeof(float) : 0);
     if (CT < 64) {                                     // the end-of-kernel wave-group combine parks accumulators here
         const size_t red = (size_t)(CT / 16) * KS * KS * (IT / 16) * 64 * 16;
         if (lds < red) lds = red;
@@ -1153,16 +1062,11 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
                              int groups, int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation,
                              void* workspace, void* stream, int defer, int* splitk_out, const float* in_scale = nullptr,
                              const float* in_shift = nullptr, int in_groups = 1, const void* dyt_y = nullptr,
-                             const float* dytoef = nullptr, int dyt_groups = 1, long x_split = 0, const void* up4_a = nullptr,
-                             const void* up4_b = nullptr) {
+                             const float* dytoef = nullptr, int dyt_groups = 1, long x_split = 0) {
     DH_REQUIRE(groups == 1 || (groups == N && ks == 1), "conv2d_wgrad: groups must be 1 or N (with ks=1)");
     WgArgs a;
     a.x = x; a.dy = dy; a.part = reinterpret_cast<float*>(workspace);
     a.x_split = x_split;
-    a.up4_a = up4_a; a.up4_b = up4_b;
-    if (up4_a) DH_REQUIRE(up4_b && dtype == DH_DTYPE_BF16 && use_tr && ks == 3 && stride == 1 && pad == 1 && dilation == 1 && Cin == 32 && groups == 1 &&
-                          !in_scale && !dyt_y && H % 4 == 0 && W % 4 == 0 && npix_valid == 0 && co_tile(Cout_real > 0 ? Cout_real : Cout) == 32,
-                          "conv2d_wgrad: the bilinear-x4-on-load form is the bf16 3x3 / stride 1 layer with 32 input and 17..32 output channels");
     DH_REQUIRE(dilation == 1 || (dilation == 2 && ks == 3 && stride == 1), "conv2d_wgrad: dilation %d unsupported here", dilation);
     a.dil = dilation;
     a.phase_mode = 0;
@@ -1257,14 +1161,6 @@ extern "C" int dh_conv2d_wgrad_split(const void* x, long x_split_bytes, const vo
     return conv2d_wgrad_impl(DH_DTYPE_BF16, x, dy, dw_oihw, accumulate, N, H, W, Cin, H, W, Cout, 3, 1, 1, 1, 0, 1, 0, Cin / 2, 1,
                              workspace, stream, 1, splitk_out, nullptr, nullptr, 1, nullptr, nullptr, 1, x_split_bytes);
 }
-// dh_conv2d_wgrad_partial of classifier.0 against the bilinear-x4 upsampled |a - b| map formed on load (WgArgs::up4_a):
-// a, b [N][H / 4][W / 4][32] bf16, dy [N][H][W][Cout] (17 <= Cout <= 32); joins an open weight-gradient batch.
-extern "C" int dh_conv2d_wgrad_up4(const void* a, const void* b, const void* dy, float* dw_oihw, int accumulate, int N, int H, int W,
-                                   int Cout, void* workspace, int* splitk_out, void* stream) {
-    DH_REQUIRE(a && b && dy && splitk_out, "conv2d_wgrad_up4: bad arguments");
-    return conv2d_wgrad_impl(DH_DTYPE_BF16, nullptr, dy, dw_oihw, accumulate, N, H, W, 32, H, W, Cout, 3, 1, 1, 1, 0, 1, 0, 32, 1,
-                             workspace, stream, 1, splitk_out, nullptr, nullptr, 1, nullptr, nullptr, 1, 0, a, b);
-}
 // dh_conv2d_wgrad / dh_conv2d_wgrad_partial (splitk_out != NULL: deferred) with BatchNorm-apply + ReLU on the load of x:
 // x is the PRE-normalisation output of the previous convolution, the gradient is taken against
 // relu(x * in_scale[g][ci] + in_shift[g][ci]) (g = image / (N / in_groups)); padding stays zero.
@@ -1324,7 +1220,6 @@ extern "C" int dh_conv2d_wgrad_phase(int dtype, const void* x, const void* dy, i
     a.tilesX = dh_cdiv(W, TW); a.tilesY = dh_cdiv(H, TH);
     a.CoutUse = 32;
     a.x_split = 0;
-    a.up4_a = a.up4_b = nullptr;
     a.groups = 1; a.splitk = phase_splitk(N, H, W, Cin);
     a.direct = 0;
     a.npix = H * W; a.in_npix = H * W;

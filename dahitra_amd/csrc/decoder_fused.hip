@@ -44,6 +44,19 @@ struct DecArgs {
     int rows_per_image, rows_per_block;
     long rows;
     float eps;
+    // A whole decoder STACK in one launch (depth > 1; dh_decoder_stack_fwd / _bwd).  A pixel row attends to the tokens of its
+    // image only and the tokens do not change from layer to layer (help_funcs.py:170-186: x = attn(x, m); x = ff(x) with m
+    // fixed), so the stack is a per-row function: a workgroup takes ITS rows through all layers -- re-staging the layer's
+    // weights, nothing else synchronises -- instead of `depth` launches that each fill and drain the chip.  Layer l reads
+    // (l == 0 ? x : ys + (l - 1) act_ls) and writes ys + l act_ls (every layer's output is kept: the backward recomputes from
+    // it); its operands lie at constant strides: kq_ls elements between the per-image attention operands of consecutive
+    // layers, w_ls between the packed MLP weights, par_ls floats between the fp32 parameter vectors, part_ls floats between
+    // the backward's partial blocks.  Backward: layer l reads its input as above and the gradient from (l == depth - 1 ? dy :
+    // dwork), and writes (l == 0 ? y (= dx) : dwork) -- in place: a lane reads and writes only its own rows.
+    int depth;
+    bf16* ys;
+    bf16* dwork;
+    long act_ls, kq_ls, w_ls, par_ls, part_ls;
 };
 
 union U8 {
@@ -109,6 +122,13 @@ __device__ __forceinline__ float gelu_fast(float z, float* dgelu) {
     return z * s;
 }
 
+// a wave-uniform pointer, forced into scalar registers
+template <typename T> __device__ __forceinline__ const T* uniform_ptr(const T* q) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
+}
+
 struct LNres {
     float mean, rstd;
 };
@@ -138,89 +158,100 @@ __device__ __forceinline__ LNres layer_norm(const float (&v)[2][4], const float 
 // ------------------------------------------------------------------------------------------------------
 // forward: 256 threads, rows_per_block pixel rows per workgroup (16-pixel sub-tiles, wave after wave)
 // ------------------------------------------------------------------------------------------------------
-template <int MLP>
+// STACK = false: one layer, the loop below folds away (the layer loop costs registers: 98 -> 134 in the forward, and the
+// backward, which sits at its 256-register budget, spills -- 35.0 -> 39.5 us on a single large layer)
+template <int MLP, bool STACK>
 __device__ __forceinline__ void dec_fwd_body(const DecArgs& p, const int bid) {
     constexpr int W2P = wide_pitch(MLP);
     __shared__ __attribute__((aligned(16))) unsigned short sKq[32 * WP], sVoT[32 * WP], sW1[MLP * WP], sW2[32 * W2P];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
     const long row0 = (long)bid * p.rows_per_block;
     const int img = (int)(row0 / p.rows_per_image);
-    stage(sKq, WP, p.kq + (size_t)img * 32 * D, 32, D, tid);
-    stage(sVoT, WP, p.voT + (size_t)img * D * 32, D, 32, tid);
-    stage(sW1, WP, p.w1, MLP, D, tid);
-    stage(sW2, W2P, p.w2, D, MLP, tid);
-    // the seven parameter vectors: this lane's 8 (fb1: MLP / 4) channels, in registers for the whole workgroup.  (Read through
-    // the pointers inside the loop they were 14 global loads per sub-tile: the store to y may alias them for all the compiler knows.)
-    float cg1[2][4], cbe1[2][4], cbo[2][4], cg2[2][4], cbe2[2][4], cfb2[2][4], cfb1[MLP / 16][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int c = h * 16 + g * 4;
-        ld4(p.g1 + c, cg1[h]); ld4(p.be1 + c, cbe1[h]); ld4(p.bo + c, cbo[h]);
-        ld4(p.g2 + c, cg2[h]); ld4(p.be2 + c, cbe2[h]); ld4(p.fb2 + c, cfb2[h]);
-    }
-#pragma unroll
-    for (int h = 0; h < MLP / 16; ++h) ld4(p.fb1 + h * 16 + g * 4, cfb1[h]);
-    __syncthreads();
     const int nsub = p.rows_per_block / 64;          // 16-pixel sub-tiles per wave
-    for (int ps = 0; ps < nsub; ++ps) {
-        const long row = row0 + (ps * 4 + wv) * 16 + pl;
-        if (row >= p.rows) break;                  // (never splits a wave's MFMA: rows % 16 == 0 is required)
-        const bf16* xr = p.x + row * D;
-        float x[2][4], xh[2][4], xn[2][4];
-        ld4(xr + g * 4, x[0]);
-        ld4(xr + 16 + g * 4, x[1]);
-        layer_norm(x, cg1, cbe1, p.eps, xh, xn);
-        // dots -> softmax over the 4 keys of each head (lane-local)
-        const s16x8 bxn = pack8(xn[0], xn[1]);
-        float at[2][4];
+    const int depth = STACK ? p.depth : 1;
+#pragma unroll 1
+    for (int l = 0; l < depth; ++l) {
+        if (l) __syncthreads();                      // every wave is done with the previous layer's weights
+        const bf16* xin = (!STACK || l == 0) ? p.x : p.ys + (l - 1) * p.act_ls;
+        bf16* yout = STACK ? p.ys + l * p.act_ls : p.y;
+        const long ko = STACK ? l * p.kq_ls : 0, wo = STACK ? l * p.w_ls : 0;
+        stage(sKq, WP, p.kq + ko + (size_t)img * 32 * D, 32, D, tid);
+        stage(sVoT, WP, p.voT + ko + (size_t)img * D * 32, D, 32, tid);
+        stage(sW1, WP, p.w1 + wo, MLP, D, tid);
+        stage(sW2, W2P, p.w2 + wo, D, MLP, tid);
+        // the seven parameter vectors: this lane's 8 (fb1: MLP / 4) channels, in registers for the whole layer.  (Read through
+        // the pointers inside the loop they were 14 global loads per sub-tile: the store to y may alias them for all the compiler knows.)
+        float cg1[2][4], cbe1[2][4], cbo[2][4], cg2[2][4], cbe2[2][4], cfb2[2][4], cfb1[MLP / 16][4];
+        const long po = STACK ? l * p.par_ls : 0;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f32x4 d = mma(lds_a(sKq, WP, s * 16 + pl, 0, g), bxn, f32x4{0.f, 0.f, 0.f, 0.f});
-            const float m = fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]));
-            float e[4], sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { e[j] = __expf(d[j] - m); sum += e[j]; }
-            const float inv = __builtin_amdgcn_rcpf(sum);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) at[s][j] = e[j] * inv;
+        for (int h = 0; h < 2; ++h) {
+            const int c = h * 16 + g * 4;
+            ld4(p.g1 + po + c, cg1[h]); ld4(p.be1 + po + c, cbe1[h]); ld4(p.bo + po + c, cbo[h]);
+            ld4(p.g2 + po + c, cg2[h]); ld4(p.be2 + po + c, cbe2[h]); ld4(p.fb2 + po + c, cfb2[h]);
         }
-        const s16x8 bat = pack8(at[0], at[1]);
-        float x1[2][4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f32x4 o = mma(lds_a(sVoT, WP, s * 16 + pl, 0, g), bat, f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int h = 0; h < MLP / 16; ++h) ld4(p.fb1 + po + h * 16 + g * 4, cfb1[h]);
+        __syncthreads();
+        for (int ps = 0; ps < nsub; ++ps) {
+            const long row = row0 + (ps * 4 + wv) * 16 + pl;
+            if (row >= p.rows) break;                  // (never splits a wave's MFMA: rows % 16 == 0 is required)
+            const bf16* xr = xin + row * D;
+            float x[2][4], xh[2][4], xn[2][4];
+            ld4(xr + g * 4, x[0]);
+            ld4(xr + 16 + g * 4, x[1]);
+            layer_norm(x, cg1, cbe1, p.eps, xh, xn);
+            // dots -> softmax over the 4 keys of each head (lane-local)
+            const s16x8 bxn = pack8(xn[0], xn[1]);
+            float at[2][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x1[s][j] = o[j] + cbo[s][j] + x[s][j];
-        }
-        float xh2[2][4], l2[2][4];
-        layer_norm(x1, cg2, cbe2, p.eps, xh2, l2);
-        const s16x8 bl2 = pack8(l2[0], l2[1]);
-        float hh[MLP / 16][4];
+            for (int s = 0; s < 2; ++s) {
+                f32x4 d = mma(lds_a(sKq, WP, s * 16 + pl, 0, g), bxn, f32x4{0.f, 0.f, 0.f, 0.f});
+                const float m = fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]));
+                float e[4], sum = 0.f;
 #pragma unroll
-        for (int s = 0; s < MLP / 16; ++s) {
-            f32x4 z = mma(lds_a(sW1, WP, s * 16 + pl, 0, g), bl2, f32x4{0.f, 0.f, 0.f, 0.f});
+                for (int j = 0; j < 4; ++j) { e[j] = __expf(d[j] - m); sum += e[j]; }
+                const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) hh[s][j] = gelu_fast(z[j] + cfb1[s][j], nullptr);
-        }
-        f32x4 out[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                for (int j = 0; j < 4; ++j) at[s][j] = e[j] * inv;
+            }
+            const s16x8 bat = pack8(at[0], at[1]);
+            float x1[2][4];
 #pragma unroll
-        for (int q = 0; q < MLP / 32; ++q) {
-            const s16x8 bh = pack8(hh[2 * q], hh[2 * q + 1]);
+            for (int s = 0; s < 2; ++s) {
+                f32x4 o = mma(lds_a(sVoT, WP, s * 16 + pl, 0, g), bat, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-            for (int s = 0; s < 2; ++s) out[s] = mma(lds_a(sW2, W2P, s * 16 + pl, 32 * q, g), bh, out[s]);
-        }
-        bf16* yr = p.y + row * D;
+                for (int j = 0; j < 4; ++j) x1[s][j] = o[j] + cbo[s][j] + x[s][j];
+            }
+            float xh2[2][4], l2[2][4];
+            layer_norm(x1, cg2, cbe2, p.eps, xh2, l2);
+            const s16x8 bl2 = pack8(l2[0], l2[1]);
+            float hh[MLP / 16][4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float r[4];
+            for (int s = 0; s < MLP / 16; ++s) {
+                f32x4 z = mma(lds_a(sW1, WP, s * 16 + pl, 0, g), bl2, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = out[s][j] + cfb2[s][j] + x1[s][j];
-            st4(yr + s * 16 + g * 4, r);
+                for (int j = 0; j < 4; ++j) hh[s][j] = gelu_fast(z[j] + cfb1[s][j], nullptr);
+            }
+            f32x4 out[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int q = 0; q < MLP / 32; ++q) {
+                const s16x8 bh = pack8(hh[2 * q], hh[2 * q + 1]);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) out[s] = mma(lds_a(sW2, W2P, s * 16 + pl, 32 * q, g), bh, out[s]);
+            }
+            bf16* yr = yout + row * D;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = out[s][j] + cfb2[s][j] + x1[s][j];
+                st4(yr + s * 16 + g * 4, r);
+            }
         }
     }
 }
-template <int MLP>
-__global__ __launch_bounds__(256) void dec_fwd_kernel(DecArgs p) { dec_fwd_body<MLP>(p, blockIdx.x); }
+template <int MLP, bool STACK = false>
+__global__ __launch_bounds__(256) void dec_fwd_kernel(DecArgs p) { dec_fwd_body<MLP, STACK>(p, blockIdx.x); }
 // Layers of several decoder stacks in one launch (dh_decoder_batch_*): DAHiTra's levels are independent, the launches of the small
 // ones (16 x 16 and 32 x 32 maps: 128 - 512 workgroups, 3.5 - 16 us) ride with the large one's.  Arguments by value.
 constexpr int DEC_MAXJ = 4;
@@ -229,12 +260,12 @@ struct DecMulti {
     int first[DEC_MAXJ + 1];
     DecArgs a[DEC_MAXJ];
 };
-template <int MLP>
+template <int MLP, bool STACK = false>
 __global__ __launch_bounds__(256) void dec_fwd_multi_kernel(DecMulti m) {
     int j = 0;
     while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
     const DecArgs p = m.a[j];
-    dec_fwd_body<MLP>(p, (int)blockIdx.x - m.first[j]);
+    dec_fwd_body<MLP, STACK>(p, (int)blockIdx.x - m.first[j]);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -293,7 +324,7 @@ __device__ long long g_dect[4096 * 20];
 #define DEC_T(k) do { } while (0)
 #endif
 
-template <int MLP>
+template <int MLP, bool STACK>
 __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, unsigned char* smem) {
 #ifdef DEC_TIMING
     long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = (long long)clock64();
@@ -320,18 +351,35 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
     unsigned char* tB1 = tiles + (wv * 4 + 3) * TILE;
     const long row0 = (long)bid * p.rows_per_block;
     const int img = (int)(row0 / p.rows_per_image);
-    stage(sKq, WP, p.kq + (size_t)img * 32 * D, 32, D, tid);
-    stage(sVoT, WP, p.voT + (size_t)img * D * 32, D, 32, tid);
-    stage(sVo, WP, p.vo + (size_t)img * 32 * D, 32, D, tid);
-    stage(sKqT, WP, p.kqT + (size_t)img * D * 32, D, 32, tid);
-    stage(sW1, WP, p.w1, MLP, D, tid);
-    stage(sW2T, WP, p.w2T, MLP, D, tid);
-    stage(sW1T, W1TP, p.w1T, D, MLP, tid);
-    if (tid < 32) {
-        sPar[tid] = p.g1[tid]; sPar[32 + tid] = p.be1[tid]; sPar[64 + tid] = p.bo[tid];
-        sPar[96 + tid] = p.g2[tid]; sPar[128 + tid] = p.be2[tid];
+    const int depth = STACK ? p.depth : 1;
+    // the layers of a stack, last to first (DecArgs::depth): this workgroup's rows only, no synchronisation with any other
+#pragma unroll 1
+    for (int ll = 0; ll < depth; ++ll) {
+    const int l = depth - 1 - ll;
+    // (uniform values, pinned to scalar registers: the kernel sits at its 256-register budget)
+    const bf16* x_in = STACK ? uniform_ptr(l == 0 ? p.x : p.ys + (l - 1) * p.act_ls) : p.x;
+    const bf16* dy_in = STACK ? uniform_ptr(ll == 0 ? p.dy : p.dwork) : p.dy;
+    bf16* dx_out = STACK ? const_cast<bf16*>(uniform_ptr(l == 0 ? p.y : p.dwork)) : p.y;
+    if (ll) __syncthreads();                                 // the partial sums of the layer before have left the LDS
+    {
+        // (the staging addresses are derived from a value the optimiser cannot see through: hoisted out of the layer loop they
+        // would sit in -- or be spilled from -- registers the sub-tile loop needs)
+        int ts = tid;
+        if constexpr (STACK) asm volatile("" : "+v"(ts));
+        const long ko = STACK ? l * p.kq_ls : 0, wo = STACK ? l * p.w_ls : 0, po = STACK ? l * p.par_ls : 0;
+        stage(sKq, WP, p.kq + ko + (size_t)img * 32 * D, 32, D, ts);
+        stage(sVoT, WP, p.voT + ko + (size_t)img * D * 32, D, 32, ts);
+        stage(sVo, WP, p.vo + ko + (size_t)img * 32 * D, 32, D, ts);
+        stage(sKqT, WP, p.kqT + ko + (size_t)img * D * 32, D, 32, ts);
+        stage(sW1, WP, p.w1 + wo, MLP, D, ts);
+        stage(sW2T, WP, p.w2T + wo, MLP, D, ts);
+        stage(sW1T, W1TP, p.w1T + wo, D, MLP, ts);
+        if (ts < 32) {
+            sPar[ts] = p.g1[po + ts]; sPar[32 + ts] = p.be1[po + ts]; sPar[64 + ts] = p.bo[po + ts];
+            sPar[96 + ts] = p.g2[po + ts]; sPar[128 + ts] = p.be2[po + ts];
+        }
+        if (ts < MLP) sPar[160 + ts] = p.fb1[po + ts];
     }
-    if (tid < MLP) sPar[160 + tid] = p.fb1[tid];
     __syncthreads();
     const float *cG1 = sPar, *cBe1 = sPar + 32, *cBo = sPar + 64, *cG2 = sPar + 96, *cBe2 = sPar + 128, *cFb1 = sPar + 160;
 
@@ -357,8 +405,8 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
     uint2 nx[2], ndy[2];
     auto request = [&](int it) {
         const long row = row0 + (it * 4 + wv) * 16 + pl;
-        const bf16* xr = p.x + row * D;
-        const bf16* gr = p.dy + row * D;
+        const bf16* xr = x_in + row * D;
+        const bf16* gr = dy_in + row * D;
         nx[0] = *reinterpret_cast<const uint2*>(xr + g * 4);
         nx[1] = *reinterpret_cast<const uint2*>(xr + 16 + g * 4);
         ndy[0] = *reinterpret_cast<const uint2*>(gr + g * 4);
@@ -571,7 +619,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
             }
         sa = group4_sum(sa);
         sbb = group4_sum(sbb);
-        bf16* dxr = p.y + row * D;
+        bf16* dxr = dx_out + row * D;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float r[4];
@@ -644,14 +692,15 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
     DEC_T(14);
     __syncthreads();
     DEC_T(15);
-    float* out = p.partial + (size_t)bid * P::SIZE;
+    float* out = p.partial + (STACK ? l * p.part_ls : 0) + (size_t)bid * P::SIZE;
     for (int i = tid; i < P::SIZE; i += 256)
         out[i] = ((red[i] + red[P::SIZE + i]) + red[2 * P::SIZE + i]) + red[3 * P::SIZE + i];
+    }   // layers
 #ifdef DEC_TIMING
     DEC_T(11);
     if (tid == 0 && blockIdx.x < 4096) {
         for (int k = 0; k < 16; ++k) g_dect[blockIdx.x * 20 + k] = t_acc[k];
-        g_dect[blockIdx.x * 20 + 16] = nsub;
+        g_dect[blockIdx.x * 20 + 16] = p.rows_per_block / 64;
         g_dect[blockIdx.x * 20 + 17] = t_last - t_begin;
     }
 #endif
@@ -660,18 +709,18 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
 extern "C" int dh_debug_dect(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dect), (size_t)n * 8); }
 #endif
 
-template <int MLP>
+template <int MLP, bool STACK = false>
 __global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_kernel(DecArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    dec_bwd_body<MLP>(p, blockIdx.x, smem);
+    dec_bwd_body<MLP, STACK>(p, blockIdx.x, smem);
 }
-template <int MLP>
+template <int MLP, bool STACK = false>
 __global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_multi_kernel(DecMulti m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int j = 0;
     while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
     const DecArgs p = m.a[j];
-    dec_bwd_body<MLP>(p, (int)blockIdx.x - m.first[j], smem);
+    dec_bwd_body<MLP, STACK>(p, (int)blockIdx.x - m.first[j], smem);
 }
 
 // sums the workgroup partials: shared parameters over all workgroups (accumulated into the gradient arena),
@@ -756,10 +805,10 @@ template <int MLP> size_t bwd_lds_bytes() {
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
 // ---- batched launches (dh_decoder_batch_*): index 0 = MLP 32, 1 = MLP 64; forward and backward each
-struct DecBatch {
+struct DecBatch {      // index = (MLP == 64) + 2 * (layer-fused stack)
     bool on = false;
-    int nf[2] = {0, 0}, nb[2] = {0, 0};
-    DecMulti f[2], b[2];
+    int nf[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0};
+    DecMulti f[4], b[4];
 };
 static thread_local DecBatch g_db;
 template <int MLP> static int dec_set_bwd_lds(const void* kern, bool& done) {
@@ -774,24 +823,32 @@ template <int MLP> static int dec_set_bwd_lds(const void* kern, bool& done) {
 }
 static int dec_batch_flush(hipStream_t st) {
     DecBatch& d = g_db;
-    static bool m32 = false, m64 = false;
-    for (int k = 0; k < 2; ++k) {
+    static bool m32 = false, m64 = false, s32 = false, s64 = false;
+    for (int k = 0; k < 4; ++k) {
         if (d.nf[k]) {
             d.f[k].n = d.nf[k];
             const int total = d.f[k].first[d.nf[k]];
-            if (k == 0) hipLaunchKernelGGL(dec_fwd_multi_kernel<32>, dim3(total), dim3(256), 0, st, d.f[k]);
-            else hipLaunchKernelGGL(dec_fwd_multi_kernel<64>, dim3(total), dim3(256), 0, st, d.f[k]);
+            if (k == 0) hipLaunchKernelGGL((dec_fwd_multi_kernel<32, false>), dim3(total), dim3(256), 0, st, d.f[k]);
+            else if (k == 1) hipLaunchKernelGGL((dec_fwd_multi_kernel<64, false>), dim3(total), dim3(256), 0, st, d.f[k]);
+            else if (k == 2) hipLaunchKernelGGL((dec_fwd_multi_kernel<32, true>), dim3(total), dim3(256), 0, st, d.f[k]);
+            else hipLaunchKernelGGL((dec_fwd_multi_kernel<64, true>), dim3(total), dim3(256), 0, st, d.f[k]);
             d.nf[k] = 0;
         }
         if (d.nb[k]) {
             d.b[k].n = d.nb[k];
             const int total = d.b[k].first[d.nb[k]];
             if (k == 0) {
-                if (dec_set_bwd_lds<32>(reinterpret_cast<const void*>(dec_bwd_multi_kernel<32>), m32)) return 1;
-                hipLaunchKernelGGL(dec_bwd_multi_kernel<32>, dim3(total), dim3(256), bwd_lds_bytes<32>(), st, d.b[k]);
+                if (dec_set_bwd_lds<32>(reinterpret_cast<const void*>(dec_bwd_multi_kernel<32, false>), m32)) return 1;
+                hipLaunchKernelGGL((dec_bwd_multi_kernel<32, false>), dim3(total), dim3(256), bwd_lds_bytes<32>(), st, d.b[k]);
+            } else if (k == 1) {
+                if (dec_set_bwd_lds<64>(reinterpret_cast<const void*>(dec_bwd_multi_kernel<64, false>), m64)) return 1;
+                hipLaunchKernelGGL((dec_bwd_multi_kernel<64, false>), dim3(total), dim3(256), bwd_lds_bytes<64>(), st, d.b[k]);
+            } else if (k == 2) {
+                if (dec_set_bwd_lds<32>(reinterpret_cast<const void*>(dec_bwd_multi_kernel<32, true>), s32)) return 1;
+                hipLaunchKernelGGL((dec_bwd_multi_kernel<32, true>), dim3(total), dim3(256), bwd_lds_bytes<32>(), st, d.b[k]);
             } else {
-                if (dec_set_bwd_lds<64>(reinterpret_cast<const void*>(dec_bwd_multi_kernel<64>), m64)) return 1;
-                hipLaunchKernelGGL(dec_bwd_multi_kernel<64>, dim3(total), dim3(256), bwd_lds_bytes<64>(), st, d.b[k]);
+                if (dec_set_bwd_lds<64>(reinterpret_cast<const void*>(dec_bwd_multi_kernel<64, true>), s64)) return 1;
+                hipLaunchKernelGGL((dec_bwd_multi_kernel<64, true>), dim3(total), dim3(256), bwd_lds_bytes<64>(), st, d.b[k]);
             }
             d.nb[k] = 0;
         }
@@ -856,11 +913,12 @@ static inline int dec_rows_per_block(long rows, int rows_per_image) {
 // direction and MLP width; a fifth issues the first four); dh_decoder_batch_launch(stream) issues the recorded layers of
 // INDEPENDENT stacks as one launch per direction and width.  Every buffer of a recorded call stays alive and unchanged until
 // then.  Per host thread; _abort drops the recorded calls.
-extern "C" int dh_decoder_batch_begin() { g_db.on = true; g_db.nf[0] = g_db.nf[1] = g_db.nb[0] = g_db.nb[1] = 0; return 0; }
-extern "C" int dh_decoder_batch_pending() { return g_db.nf[0] + g_db.nf[1] + g_db.nb[0] + g_db.nb[1]; }
+static void dec_batch_clear() { for (int k = 0; k < 4; ++k) g_db.nf[k] = g_db.nb[k] = 0; }
+extern "C" int dh_decoder_batch_begin() { g_db.on = true; dec_batch_clear(); return 0; }
+extern "C" int dh_decoder_batch_pending() { int n = 0; for (int k = 0; k < 4; ++k) n += g_db.nf[k] + g_db.nb[k]; return n; }
 extern "C" int dh_decoder_batch_launch(void* stream) { return dec_batch_flush(ST(stream)); }
 extern "C" int dh_decoder_batch_end(void* stream) { const int rc = dec_batch_flush(ST(stream)); g_db.on = false; return rc; }
-extern "C" int dh_decoder_batch_abort() { g_db.on = false; g_db.nf[0] = g_db.nf[1] = g_db.nb[0] = g_db.nb[1] = 0; return 0; }
+extern "C" int dh_decoder_batch_abort() { g_db.on = false; dec_batch_clear(); return 0; }
 
 extern "C" long dh_decoder_layer_bwd_workspace_size(long rows, int rows_per_image, int mlp) {
     const long nblk = rows / dec_rows_per_block(rows, rows_per_image);
@@ -917,6 +975,66 @@ extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, con
                                     a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, 0L, 0L, 0L);
     }
     DH_CHECK_LAUNCH("decoder_layer_bwd");
+    return 0;
+}
+
+// A whole decoder stack (`depth` layers of the same shapes, one set of tokens) in ONE launch per direction: see DecArgs::depth.
+// x [rows][32] bf16 = the stack's input; ys [depth][rows][32] bf16 receives every layer's output (ys[depth - 1] = the stack's
+// output; the backward recomputes each layer from its input).  Operands of layer l: kq / voT (/ vo / kqT) at + l * kq_lstride
+// elements (the stacked dh_xattn_prep_fwd_stack outputs: images * 32 * 32), the packed MLP weights at + l * w_lstride
+// elements, the fp32 parameter vectors at + l * par_lstride floats (the net's flat arena).  Same arithmetic as `depth` calls of
+// dh_decoder_layer_fwd / _bwd, bit for bit.  Both join an open decoder batch (dh_decoder_batch_begin).
+extern "C" int dh_decoder_stack_fwd(const void* x, void* ys, const void* kq, const void* voT, const float* ln1_g, const float* ln1_b,
+                                    const float* bo, const float* ln2_g, const float* ln2_b, const void* w1, const float* b1,
+                                    const void* w2, const float* b2, int depth, long kq_lstride, long w_lstride, long par_lstride,
+                                    long rows, int rows_per_image, int mlp, float eps, void* stream) {
+    if (check_common(rows, rows_per_image, mlp)) return 1;
+    DH_REQUIRE(depth >= 1 && x && ys, "decoder_stack_fwd: bad arguments (depth %d)", depth);
+    DecArgs a = {};
+    a.x = (const bf16*)x; a.ys = (bf16*)ys; a.y = (bf16*)ys; a.kq = (const bf16*)kq; a.voT = (const bf16*)voT;
+    a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2;
+    a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
+    a.rows_per_image = rows_per_image; a.rows = rows; a.eps = eps;
+    a.depth = depth; a.act_ls = rows * D; a.kq_ls = kq_lstride; a.w_ls = w_lstride; a.par_ls = par_lstride;
+    a.rows_per_block = dec_fwd_rows_per_block(rows, rows_per_image);
+    const int grid = (int)(rows / a.rows_per_block);
+    if (g_db.on) return dec_batch_record(&g_db.f[2 + (mlp == 64)], &g_db.nf[2 + (mlp == 64)], a, grid, ST(stream));
+    if (mlp == 64) hipLaunchKernelGGL((dec_fwd_kernel<64, true>), dim3(grid), dim3(256), 0, ST(stream), a);
+    else hipLaunchKernelGGL((dec_fwd_kernel<32, true>), dim3(grid), dim3(256), 0, ST(stream), a);
+    DH_CHECK_LAUNCH("decoder_stack_fwd");
+    return 0;
+}
+// Data gradient of the stack: dy [rows][32] = gradient of ys[depth - 1], dx [rows][32] = gradient of x, dwork [rows][32] bf16
+// scratch (the gradient between layers, rewritten in place); the per-workgroup partial sums of layer l land in workspace +
+// l * dh_decoder_layer_bwd_workspace_size(rows, rows_per_image, mlp) bytes for dh_decoder_stack_bwd_finalize.
+extern "C" int dh_decoder_stack_bwd(const void* x, const void* ys, const void* dy, void* dx, void* dwork, const void* kq,
+                                    const void* voT, const void* vo, const void* kqT, const float* ln1_g, const float* ln1_b,
+                                    const float* bo, const float* ln2_g, const float* ln2_b, const void* w1, const void* w1T,
+                                    const float* b1, const void* w2, const void* w2T, const float* b2, int depth, long kq_lstride,
+                                    long w_lstride, long par_lstride, long rows, int rows_per_image, int mlp, float eps,
+                                    void* workspace, void* stream) {
+    if (check_common(rows, rows_per_image, mlp)) return 1;
+    DH_REQUIRE(depth >= 1 && x && (ys || depth == 1) && dy && dx && (dwork || depth == 1) && workspace, "decoder_stack_bwd: bad arguments (depth %d)", depth);
+    DecArgs a = {};
+    a.x = (const bf16*)x; a.ys = (bf16*)const_cast<void*>(ys); a.dy = (const bf16*)dy; a.y = (bf16*)dx; a.dwork = (bf16*)dwork;
+    a.kq = (const bf16*)kq; a.voT = (const bf16*)voT; a.vo = (const bf16*)vo; a.kqT = (const bf16*)kqT;
+    a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2; a.w1T = (const bf16*)w1T; a.w2T = (const bf16*)w2T;
+    a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
+    a.partial = reinterpret_cast<float*>(workspace);
+    a.rows_per_image = rows_per_image; a.rows_per_block = dec_rows_per_block(rows, rows_per_image); a.rows = rows; a.eps = eps;
+    a.depth = depth; a.act_ls = rows * D; a.kq_ls = kq_lstride; a.w_ls = w_lstride; a.par_ls = par_lstride;
+    a.part_ls = dh_decoder_layer_bwd_workspace_size(rows, rows_per_image, mlp) / 4;
+    const int nblk = (int)(rows / a.rows_per_block);
+    if (g_db.on) return dec_batch_record(&g_db.b[2 + (mlp == 64)], &g_db.nb[2 + (mlp == 64)], a, nblk, ST(stream));
+    static bool m32 = false, m64 = false;
+    if (mlp == 64) {
+        if (dec_set_bwd_lds<64>(reinterpret_cast<const void*>(dec_bwd_kernel<64, true>), m64)) return 1;
+        hipLaunchKernelGGL((dec_bwd_kernel<64, true>), dim3(nblk), dim3(256), bwd_lds_bytes<64>(), ST(stream), a);
+    } else {
+        if (dec_set_bwd_lds<32>(reinterpret_cast<const void*>(dec_bwd_kernel<32, true>), m32)) return 1;
+        hipLaunchKernelGGL((dec_bwd_kernel<32, true>), dim3(nblk), dim3(256), bwd_lds_bytes<32>(), ST(stream), a);
+    }
+    DH_CHECK_LAUNCH("decoder_stack_bwd");
     return 0;
 }
 

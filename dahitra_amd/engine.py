@@ -96,6 +96,9 @@ class Engine:
         self.fused_head_out = os.environ.get("DAHITRA_NO_FUSED_HEAD", "0") != "1"
         # one finalize launch for the parameter gradients of all layers of a fused decoder stack
         self.defer_dec_finalize = os.environ.get("DAHITRA_NO_DEFER_DEC_FINALIZE", "0") != "1"
+        # all layers of a fused decoder stack in one launch per direction (csrc/decoder_fused.hip DecArgs::depth): the stack is
+        # a per-pixel-row function, so nothing synchronises between its layers but a workgroup's own re-staging of the weights
+        self.fuse_dec_stack = os.environ.get("DAHITRA_NO_DEC_STACK", "0") != "1"
         # class-head data gradient gated for the classifier's BatchNorm (mask + BN-backward sums in its epilogue).  Measured
         # neutral (8020 vs 8027 pairs/s: the reduction pass it removes costs what the extra read of y costs the head kernel):
         # off by default, DAHITRA_GATED_HEAD=1 turns it on.
@@ -107,11 +110,12 @@ class Engine:
         # bf16: the data gradient of classifier.0 goes straight to the coarse |A - B| maps (the 32 x 256 x 256 gradient of the
         # bilinear-upsampled map is never written or re-read): DAHITRA_NO_FUSED_UP4_BWD=1 restores the two-kernel path
         self.fused_up4_bwd = os.environ.get("DAHITRA_NO_FUSED_UP4_BWD", "0") != "1"
-        # ... and in the forward / weight gradient |A - B| + bilinear x4 can be formed inside classifier.0's loads (ops.Up4Input:
-        # bit-identical, the 134 MB map is neither written nor read).  Measured on MI355X (profiles/r04*_up4_ab.txt): the
-        # interpolation is ~70 VALU instructions per 16-byte halo piece in kernels that run one tile per workgroup round --
-        # convolution 121 us against absdiff_up4_fwd 32 + the register-resident-weights kernel 76, weight gradient 94 against
-        # 67: 8479 vs 8567 pairs/s.  OFF by default; DAHITRA_FUSED_UP4_FWD=1 turns it on.
+        # ... and in the forward |A - B| + bilinear x4 can be formed inside classifier.0's loads (ops.Up4Input: bit-identical).
+        # Measured on MI355X (profiles/r04_up4_ab.txt): ~70 VALU instructions per 16-byte halo piece in a kernel that runs one
+        # tile per workgroup -- 121 us against absdiff_up4_fwd 32 + the register-resident-weights kernel 76; the same on-load
+        # form of the weight gradient ran 94 us against 67 (and is gone again: its results were not reproducible from run to
+        # run at >= 512 workgroups).  OFF by default; DAHITRA_FUSED_UP4_FWD=1 turns the convolution's form on (the weight
+        # gradient then materialises the map itself).  DESIGN.md section 6e.
         self.fused_up4_fwd = os.environ.get("DAHITRA_FUSED_UP4_FWD", "0") == "1"
         self.use_side = os.environ.get("DAHITRA_SIDE_STREAM", "0") == "1"
         self.side = None
@@ -120,6 +124,7 @@ class Engine:
         self.p = {}        # key -> fp32 parameter / buffer tensors (device)
         self.g = {}        # key -> fp32 gradient views
         self.pk = {}       # key -> Packed
+        self.wstack = {}   # (decoder prefix, 'net.0' | 'net.3') -> stacked packed MLP weights (forward, data gradient)
         self.training = False
         self.need_grad = False
         self._bwd = None
@@ -138,7 +143,7 @@ class Engine:
         plan = self._plans.get(self.need_grad)
         if plan is None:
             plan = self._plans[self.need_grad] = self._build_plan()
-        pack, self.pk, self.xstack = plan
+        pack, self.pk, self.xstack, self.wstack = plan
         pack.run()
         key = "resnet.conv1.weight"
         if not (self.direct_stem and self.dtype == torch.bfloat16):      # the direct stem kernel reads the OIHW weights itself
@@ -148,6 +153,7 @@ class Engine:
         ck = ops.chunk_channels(self.dtype)
         pack = ops.PackPlan(self.p["resnet.conv1.weight"].device)
         pk, xstack = {}, {}    # xstack: (decoder prefix, matrix) -> stacked transposes [depth, 32*inner]
+        wstack = {}            # (decoder prefix, "net.0" | "net.3") -> (stacked forward packs, stacked data-gradient packs) [depth, O*I]
         for key, shape in self.shapes.items():
             if key not in self.p or not key.endswith("weight") or len(shape) not in (2, 4):
                 continue
@@ -179,6 +185,22 @@ class Engine:
                 continue
             O = shape[0]
             dt = self.dtype
+            if key.startswith("transformer_decoder") and ".1.fn.fn.net." in key and len(shape) == 2 and shape[0] % 16 == 0 and \
+                    shape[1] % 16 == 0:
+                # the MLP weights of one decoder stack in ONE buffer per form, layer after layer: the layer-fused stack kernels
+                # (ops.decoder_stack_fwd / _bwd) step through them at a constant stride; the per-layer views serve everything else
+                pfx, rest = key.split(".layers.")
+                li, which = int(rest.split(".")[0]), ("net.0" if ".net.0." in key else "net.3")
+                if (pfx, which) not in wstack:
+                    depth = 1 + max(int(k.split(".layers.")[1].split(".")[0]) for k in self.shapes
+                                    if k.startswith(pfx + ".layers.") and k.endswith("1.fn.fn.%s.weight" % which))
+                    mk = lambda: torch.empty(depth, shape[0] * shape[1], dtype=dt, device=self.p[key].device)
+                    wstack[(pfx, which)] = (mk(), mk() if self.need_grad else None)
+                sf, sd = wstack[(pfx, which)]
+                f, d = pack.add(self.p[key], dt, want_dgrad=self.need_grad, dgrad_inner=O, out_fwd=sf[li].view(1, shape[0], shape[1]),
+                                out_dgrad=sd[li].view(1, shape[1], shape[0]) if sd is not None else None)
+                pk[key] = Packed(f, d)
+                continue
             if key.startswith("transformer") and not key.startswith("transformer_decoder"):
                 # the token encoder (<= 16 rows per image) runs in fp32 in every mode: its output feeds
                 # |token2 - token1|, which bf16 rounding would wipe out (csrc/tokens.hip header)
@@ -191,7 +213,7 @@ class Engine:
                 # the layers conv_wreg.hip may serve (it decides per launch): a second copy in fragment order
                 ff, dd = pack.add(self.p[key], dt, want_dgrad=self.need_grad, dgrad_inner=O, frag=True)
             pk[key] = Packed(f, d, ff, dd)
-        return pack, pk, xstack
+        return pack, pk, xstack, wstack
 
     # ---- primitive units -------------------------------------------------------------------------
     def s2_phase_ok(self, ks, stride, pad, xshape, dy):
@@ -598,6 +620,33 @@ class Engine:
                 defer = types.SimpleNamespace(
                     partials=torch.empty(depth, ops.decoder_layer_bwd_partial_floats(rows, rpi, mlp0), dtype=torch.float32,
                                          device=x.device), gstride=gstride, rows=rows)
+        # the whole stack in ONE launch per direction (ops.decoder_stack_fwd: a workgroup takes its rows through every layer)
+        sfuse = None
+        if fused and stack is not None and self.fuse_dec_stack and not self.attn_fp8 and (defer is not None or not self.need_grad):
+            sfuse = self._stack_operands(pfx, depth)
+        if sfuse is not None:
+            params0, pstride, w1s, w1Ts, w2s, w2Ts = sfuse
+            x0 = x
+            ys = ops.decoder_stack_fwd(x0, stack, rpi, params0, w1s, w2s, pstride, mlp0, LN_EPS)
+            yield                   # ys is valid from here on
+            if not self.need_grad:
+                return ys[depth - 1], None
+
+            def bwd_stack(d):
+                dx = ops.decoder_stack_bwd(x0, ys, d.contiguous(), stack, rpi, params0, w1s, w1Ts, w2s, w2Ts, pstride, mlp0,
+                                           defer.partials, LN_EPS)
+                yield               # dx is valid from here on
+                a0, f0 = "%s.layers.0.0.fn" % pfx, "%s.layers.0.1.fn" % pfx
+                grads0 = (self.g[f0 + ".fn.net.0.weight"], self.g[f0 + ".fn.net.3.weight"], self.g[f0 + ".fn.net.0.bias"],
+                          self.g[f0 + ".fn.net.3.bias"], self.g[a0 + ".fn.to_out.0.bias"], self.g[a0 + ".norm.weight"],
+                          self.g[a0 + ".norm.bias"], self.g[f0 + ".norm.weight"], self.g[f0 + ".norm.bias"])
+                ops.decoder_stack_bwd_finalize(defer.partials, defer.rows, rpi, mlp0, grads0, defer.gstride, stack.dkq, stack.dvoT)
+                stack.backward(tok, dtok, self.p[a0 + ".norm.weight"], self.xstack[(pfx, "to_q.weight")],
+                               *(self.p[a0 + ".fn.to_%s.weight" % n] for n in ("k", "v", "out.0")),
+                               self.g[a0 + ".norm.weight"], self.g[a0 + ".norm.bias"],
+                               *(self.g[a0 + ".fn.to_%s.weight" % n] for n in ("q", "k", "v", "out.0")))
+                return dx
+            return ys[depth - 1], bwd_stack
         for i in range(depth):
             a, f = "%s.layers.%d.0.fn" % (pfx, i), "%s.layers.%d.1.fn" % (pfx, i)
             mlp = self.shapes[f + ".fn.net.0.weight"][0]
@@ -632,6 +681,29 @@ class Engine:
                                *(self.g[a0 + ".fn.to_%s.weight" % n] for n in ("q", "k", "v", "out.0")))
             return d
         return x, bwd
+
+    def _stack_operands(self, pfx, depth):
+        """what the layer-fused stack kernels step through at constant strides, or None: (the seven fp32 parameter vectors of
+        layer 0, their stride in floats, the stacked packed MLP weights w1 / w1T / w2 / w2T)"""
+        names = ("0.fn.norm.weight", "0.fn.norm.bias", "0.fn.fn.to_out.0.bias", "1.fn.norm.weight", "1.fn.norm.bias",
+                 "1.fn.fn.net.0.bias", "1.fn.fn.net.3.bias")
+        stride = None
+        for n in names:
+            for i in range(1, depth):
+                k0, k1 = "%s.layers.%d.%s" % (pfx, i - 1, n), "%s.layers.%d.%s" % (pfx, i, n)
+                if k0 not in self.p or k1 not in self.p:
+                    return None
+                d = self.p[k1].data_ptr() - self.p[k0].data_ptr()
+                if d % 4 or (stride is not None and d // 4 != stride):
+                    return None
+                stride = d // 4
+        w1, w2 = self.wstack.get((pfx, "net.0")), self.wstack.get((pfx, "net.3"))
+        if stride is None or w1 is None or w2 is None or w1[0].shape[0] != depth or w2[0].shape[0] != depth:
+            return None
+        if self.need_grad and (w1[1] is None or w2[1] is None):
+            return None
+        params0 = tuple(self.p["%s.layers.0.%s" % (pfx, n)] for n in names)
+        return params0, stride, w1[0], w1[1], w2[0], w2[1]
 
     def _layer_grad_stride(self, pfx, depth):
         """floats between consecutive layers' gradients of the nine tensors the fused decoder backward accumulates, or None"""
@@ -779,7 +851,7 @@ class Engine:
             raise RuntimeError("dahitra_amd: backward called without a grad-enabled forward")
         plan = self._plans.get(True)
         if plan is not None:       # a no-grad forward in between switched self.pk to the forward-only packed weights
-            self.pk, self.xstack = plan[1], plan[2]
+            self.pk, self.xstack, self.wstack = plan[1], plan[2], plan[3]
         if self._wgrad_plan is None:
             self._wgrad_plan = ops.WgradPlan(dlogits_nchw.device, batch=True)
         with self._wgrad_plan as plan:      # the conv layers' split-K reduces: one launch at the end of the pass
@@ -796,7 +868,7 @@ class Engine:
             raise RuntimeError("dahitra_amd: this net's backward has no split point")
         plan = self._plans.get(True)
         if plan is not None:
-            self.pk, self.xstack = plan[1], plan[2]
+            self.pk, self.xstack, self.wstack = plan[1], plan[2], plan[3]
         if self._wgrad_plan is None:
             self._wgrad_plan = ops.WgradPlan(dlogits_nchw.device, batch=True)
         self._wgrad_plan.__enter__()

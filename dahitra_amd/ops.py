@@ -69,8 +69,10 @@ def pin_captured_buffers(net):
     eng = net._engine
     if eng._wgrad_plan is not None:
         keep += list(eng._wgrad_plan.slots) + list(eng._wgrad_plan.tables.values())
-    for pack, _, xstack in eng._plans.values():
+    for pack, _, xstack, wstack in eng._plans.values():
         keep += [pack.table] + list(pack.keep) + list(xstack.values())
+        for fwd_stack, dgrad_stack in wstack.values():
+            keep += [fwd_stack, dgrad_stack]
     keep += [net._arena.flat, net._arena.grad]
     keep = [t for t in keep if t is not None]
     _PINNED.extend(keep)
@@ -124,7 +126,7 @@ class PackPlan:
     def __init__(self, device):
         self.device, self.jobs, self.blocks, self.table, self.keep = device, [], 0, None, []
 
-    def add(self, w, dtype, want_fwd=True, want_dgrad=True, dgrad_inner=0, out_dgrad=None, frag=False):
+    def add(self, w, dtype, want_fwd=True, want_dgrad=True, dgrad_inner=0, out_dgrad=None, frag=False, out_fwd=None):
         """same contract as pack_weight; returns the (persistent) fwd / dgrad buffers.  frag (bf16 3x3 weights, I and
         dgrad_inner multiples of 32): the buffers are in FRAGMENT order [rows / 16, K / 32, taps, 64, 8] -- what the
         register-resident-weights convolution loads (conv2d's w_frag); add the layer a second time without it for the
@@ -140,7 +142,8 @@ class PackPlan:
             fwd = torch.empty(OPad // 16, I // 32, ks * ks, 64, 8, dtype=dtype, device=w.device) if want_fwd else None
             dg = torch.empty(IPad // 16, OK // 32, ks * ks, 64, 8, dtype=dtype, device=w.device) if want_dgrad else None
         else:
-            fwd = torch.empty(ks * ks, OPad, I, dtype=dtype, device=w.device) if want_fwd else None
+            fwd = out_fwd if out_fwd is not None else \
+                (torch.empty(ks * ks, OPad, I, dtype=dtype, device=w.device) if want_fwd else None)
             dg = out_dgrad if out_dgrad is not None else \
                 (torch.empty(ks * ks, IPad, OK, dtype=dtype, device=w.device) if want_dgrad else None)
         n = max(fwd.numel() if fwd is not None else 0, dg.numel() if dg is not None else 0)
@@ -416,8 +419,8 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
 
 class Up4Input:
     """nn.Upsample(4, 'bilinear')(|a - b|) of two [N, h, w, 32] bf16 maps WITHOUT the [N, 4h, 4w, 32] tensor (models/networks.py:
-    383-389: the input of classifier.0): conv2d and conv2d_wgrad interpolate their tiles from a and b while they load
-    (dh_conv3x3_up4_fwd / dh_conv2d_wgrad_up4); `.shape` is the shape the upsampled tensor would have."""
+    383-389: the input of classifier.0): conv2d interpolates its tiles from a and b while it loads (dh_conv3x3_up4_fwd);
+    conv2d_wgrad materialises the map.  `.shape` is the shape the upsampled tensor would have."""
     __slots__ = ("a", "b")
 
     def __init__(self, a, b):
@@ -562,7 +565,9 @@ def conv2d_wgrad(x, dy, dw, ks, stride, pad, accumulate=False, groups=1, use_tr=
     if isinstance(x, SplitCat):
         return _conv2d_wgrad_split(x, dy, dw, ks, stride, pad, accumulate, defer)
     if isinstance(x, Up4Input):
-        return _conv2d_wgrad_up4(x, dy, dw, ks, stride, pad, accumulate, defer)
+        # (the weight gradient with the interpolation on load was built and measured -- 94 us against 67 us for the plain
+        # kernel, and not reproducible from run to run at >= 512 workgroups; removed, DESIGN.md section 6e: the map is formed here)
+        x = x.materialize()
     N, H, W, pitch = x.shape
     Cin = cin if cin else pitch
     _, OH, OW, Cout = dy.shape
@@ -605,31 +610,6 @@ def _conv2d_wgrad_split(xs, dy, dw, ks, stride, pad, accumulate, defer):
             _call("dh_conv2d_wgrad_split", P(xs.t), _cl(xs.split_bytes), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W),
                   _ci(Cin), _ci(Cout), P(ws), ctypes.byref(sk), S())
         plan.hold(xs.t, dy)
-        plan.add(ws, dw, sk.value, 9, Cout, Cout, Cin, accumulate)
-        if own:
-            plan.run()
-    finally:
-        if own:
-            plan.__exit__(*sys.exc_info())
-
-
-def _conv2d_wgrad_up4(u, dy, dw, ks, stride, pad, accumulate, defer):
-    """weight gradient against an Up4Input (3x3 / stride 1 / pad 1, bf16): the upsampled map is formed on load"""
-    assert ks == 3 and stride == 1 and pad == 1
-    N, H, W, Cin = u.shape
-    Cout = dy.shape[-1]
-    nbytes = _lib.lib().dh_conv2d_wgrad_workspace_size(N, H, W, Cin, Cout, 3, 1)
-    plan, own = (_WGRAD_PLAN if defer else None), False
-    if plan is None:
-        plan, own = WgradPlan(dy.device), True
-        plan.__enter__()
-    try:
-        ws = plan.slab(nbytes)
-        sk = ctypes.c_int(0)
-        with _Prof("conv_wgrad<bf16,ks3,s1>", 2.0 * N * H * W * Cout * Cin * 9, _nb(u.a, u.b, dy)):
-            _call("dh_conv2d_wgrad_up4", P(u.a), P(u.b), P(dy), P(dw), _ci(int(accumulate)), _ci(N), _ci(H), _ci(W), _ci(Cout),
-                  P(ws), ctypes.byref(sk), S())
-        plan.hold(u.a, u.b, dy)
         plan.add(ws, dw, sk.value, 9, Cout, Cout, Cin, accumulate)
         if own:
             plan.run()
@@ -1336,6 +1316,40 @@ def decoder_layer_bwd(x2d, dy, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln
     if _DEC_BATCH is not None and partial is not None:
         _DEC_BATCH.extend((x2d, dy, dx, ws, prep.kq, prep.voT, prep.vo, prep.kqT))
     return dx, dkq, dvoT
+
+
+def decoder_stack_fwd(x2d, stack, rows_per_image, params0, w1s, w2s, par_stride, mlp, eps=1e-5):
+    """ALL layers of a fused decoder stack in one launch (csrc/decoder_fused.hip, DecArgs::depth): a workgroup takes its
+    pixel rows through every layer.  stack: the XattnPrepStack of the layers; params0 = (ln1_g, ln1_b, bo, ln2_g, ln2_b, b1,
+    b2) of layer 0, the others `par_stride` floats further; w1s / w2s: the packed MLP weights stacked [depth, ...].
+    Returns ys [depth, rows, 32]: every layer's output (ys[-1] = the stack's)."""
+    depth, rows = stack.layers, x2d.shape[0]
+    ys = torch.empty(depth, rows, 32, dtype=x2d.dtype, device=x2d.device)
+    g1, b1_, bo, g2, b2_, fb1, fb2 = params0
+    with _Prof("decoder_layer_fwd", 0, depth * _nb(x2d, x2d)):
+        _call("dh_decoder_stack_fwd", P(x2d), P(ys), P(stack.kq), P(stack.voT), P(g1), P(b1_), P(bo), P(g2), P(b2_), P(w1s), P(fb1),
+              P(w2s), P(fb2), _ci(depth), _cl(stack.kq[0].numel()), _cl(w1s[0].numel()), _cl(par_stride), _cl(rows),
+              _ci(rows_per_image), _ci(mlp), _cf(eps), S())
+    if _DEC_BATCH is not None:
+        _DEC_BATCH.extend((x2d, ys, stack.kq, stack.voT, w1s, w2s))
+    return ys
+
+
+def decoder_stack_bwd(x2d, ys, dy, stack, rows_per_image, params0, w1s, w1Ts, w2s, w2Ts, par_stride, mlp, partials, eps=1e-5):
+    """data gradient of decoder_stack_fwd in one launch; the per-workgroup parameter-gradient partials of layer l land in
+    partials[l] (decoder_stack_bwd_finalize sums them).  Returns dx."""
+    depth, rows = stack.layers, x2d.shape[0]
+    dx, dwork = torch.empty_like(x2d), torch.empty_like(x2d)
+    g1, b1_, bo, g2, b2_, fb1, fb2 = params0
+    assert partials.shape[0] == depth and partials.is_contiguous()
+    with _Prof("decoder_layer_bwd", 0, depth * _nb(x2d, dy, dx)):
+        _call("dh_decoder_stack_bwd", P(x2d), P(ys), P(dy), P(dx), P(dwork), P(stack.kq), P(stack.voT), P(stack.vo), P(stack.kqT),
+              P(g1), P(b1_), P(bo), P(g2), P(b2_), P(w1s), P(w1Ts), P(fb1), P(w2s), P(w2Ts), P(fb2), _ci(depth),
+              _cl(stack.kq[0].numel()), _cl(w1s[0].numel()), _cl(par_stride), _cl(rows), _ci(rows_per_image), _ci(mlp), _cf(eps),
+              P(partials), S())
+    if _DEC_BATCH is not None:
+        _DEC_BATCH.extend((x2d, ys, dy, dx, dwork, partials, stack.kq, stack.voT, stack.vo, stack.kqT, w1s, w1Ts, w2s, w2Ts))
+    return dx
 
 
 def decoder_layer_bwd_partial_floats(rows, rows_per_image, mlp):

@@ -139,13 +139,11 @@ int dh_conv2d_wgrad_split(const void* x, long x_split_bytes, const void* dy, flo
  *                        (dh_pack_weight forward form); stats_partial as dh_conv2d_fwd, dh_conv2d_fwd_num_tiles(N, H, W, 32, 3, 1)
  *                        rows.  The 8 x 16-pixel tile's haloed input is interpolated from its 4 x 6 coarse footprint with the
  *                        terms and order of dh_absdiff_upsample4_fwd: equal to dh_conv2d_fwd on that kernel's output, bit for bit.
- *   dh_conv2d_wgrad_up4  dh_conv2d_wgrad_partial of that layer (17 <= Cout <= 32) with the same interpolation on load.
- * (the data gradient through the upsample is dh_conv3x3_dgrad_up4; together the 32 x H x W map -- 134 MB at batch 32 -- is
- * neither written nor read: F.interpolate + abs + F.conv2d and their autograd terms) */
+ * (the data gradient through the upsample is dh_conv3x3_dgrad_up4; the weight gradient still reads the materialised map:
+ * F.interpolate + abs + F.conv2d.  Measured slower than dh_absdiff_upsample4_fwd + the register-resident-weights kernel -- 121
+ * against 32 + 76 us at batch 32 -- and therefore not the default path) */
 int dh_conv3x3_up4_fwd(const void* a, const void* b, const void* w_packed, const float* bias, int act, void* y, float* stats_partial,
                        int N, int H, int W, void* stream);
-int dh_conv2d_wgrad_up4(const void* a, const void* b, const void* dy, float* dw_oihw, int accumulate, int N, int H, int W, int Cout,
-                        void* workspace, int* splitk_out, void* stream);
 /* Batched weight gradients: the 3x3 stride-1 bf16 layers of one backward pass as ONE launch per kernel family (the
  * wave-specialised 64co x 64ci form: Cin and Cout multiples of 64; the 32-wide output tile: 16 < Cout <= 32).  Between dh_wgrad_batch_begin() and dh_wgrad_batch_end(), dh_conv2d_wgrad_partial /
  * dh_conv2d_wgrad_bn_in (with splitk_out) only RECORD an eligible layer -- *splitk_out is its in-batch slice count, smaller
@@ -439,6 +437,24 @@ int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, const void* kq
                          const float* ln2_b, const void* w1, const void* w1T, const float* b1, const void* w2,
                          const void* w2T, const float* b2, float* dw1, float* dw2, float* db1, float* db2, float* dbo,
                          float* dln1_g, float* dln1_b, float* dln2_g, float* dln2_b, float* dkq, float* dvoT, long rows,
+                         int rows_per_image, int mlp, float eps, void* workspace, void* stream);
+/* A whole fused decoder stack -- `depth` layers of the same shapes attending to ONE set of tokens (TransformerDecoder,
+ * models/help_funcs.py:170-186: x = attn(x, m); x = ff(x) per layer with m fixed) -- in ONE launch per direction: a pixel row
+ * only ever meets the tokens of its image, so a workgroup takes its rows through all layers, re-staging the layer's weights,
+ * with no synchronisation between workgroups.  x [rows][32] bf16; ys [depth][rows][32] receives every layer's output
+ * (ys[depth - 1] = the stack's; the backward recomputes each layer from its input).  Layer l's operands: kq / voT / vo / kqT
+ * + l * kq_lstride elements (the dh_xattn_prep_fwd_stack outputs), packed MLP weights + l * w_lstride elements, fp32
+ * parameter vectors + l * par_lstride floats.  dh_decoder_stack_bwd: dy = gradient of ys[depth - 1], dx = gradient of x, dwork
+ * [rows][32] bf16 scratch; partials of layer l at workspace + l * dh_decoder_layer_bwd_workspace_size bytes, for
+ * dh_decoder_stack_bwd_finalize.  Bit-identical to `depth` dh_decoder_layer_fwd / _bwd calls; both join an open decoder batch. */
+int dh_decoder_stack_fwd(const void* x, void* ys, const void* kq, const void* voT, const float* ln1_g, const float* ln1_b,
+                         const float* bo, const float* ln2_g, const float* ln2_b, const void* w1, const float* b1, const void* w2,
+                         const float* b2, int depth, long kq_lstride, long w_lstride, long par_lstride, long rows,
+                         int rows_per_image, int mlp, float eps, void* stream);
+int dh_decoder_stack_bwd(const void* x, const void* ys, const void* dy, void* dx, void* dwork, const void* kq, const void* voT,
+                         const void* vo, const void* kqT, const float* ln1_g, const float* ln1_b, const float* bo,
+                         const float* ln2_g, const float* ln2_b, const void* w1, const void* w1T, const float* b1, const void* w2,
+                         const void* w2T, const float* b2, int depth, long kq_lstride, long w_lstride, long par_lstride, long rows,
                          int rows_per_image, int mlp, float eps, void* workspace, void* stream);
 /* dh_decoder_layer_bwd with dw1 == NULL leaves its per-workgroup partials in `workspace`; this sums the partials of the `depth`
  * layers of one decoder stack (same shapes; layer l's workspace at + l * dh_decoder_layer_bwd_workspace_size bytes, its gradients

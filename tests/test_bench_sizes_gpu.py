@@ -185,8 +185,12 @@ def test_resnet50_trunk_backward_on_sixteen_row_tiles_matches_the_reference(gold
     params = dict(net.named_parameters())
     assert sorted(k for k, p in params.items() if p.grad is None) == sorted(g["nograd_keys"].tolist())
     nrel = []
+    vmax = max(g["gradnorm_vals"].tolist())
     for k, v in zip(g["gradnorm_keys"].tolist(), g["gradnorm_vals"].tolist()):
-        nrel.append(abs(float(params[k].grad.double().norm()) - v) / max(v, 1e-12))
+        if v < 1e-6 * vmax:          # a gradient that is zero in exact arithmetic (e.g. a bias that cancels in |t2 - t1|): noise only
+            assert float(params[k].grad.double().norm()) < 1e-4 * vmax, k
+            continue
+        nrel.append(abs(float(params[k].grad.double().norm()) - v) / v)
     # element-wise: the sampled large gradients (relative L2 over the sample) and the small ones in full
     rl2, worst = [], ("", 0.0)
     st = int(g["sample_stride"])

@@ -1431,8 +1431,8 @@ def test_head_data_gradient_with_the_relu_in_front_of_it_folded_in(ops):
 ])
 def test_classifier0_on_the_upsampled_absdiff_map_formed_on_load(ops, cfg):
     """abs(x1 - x2) -> nn.Upsample(4, 'bilinear') -> classifier.0 (models/networks.py:383-389, help_funcs.py:9) with the
-    upsampled map formed inside the convolution's and the weight gradient's loads (ops.Up4Input): equal -- bit for bit for the
-    forward and its BatchNorm partial sums -- to the two-kernel path through the materialised map, which is checked against
+    upsampled map formed inside the convolution's loads (ops.Up4Input): equal -- bit for bit for the forward and its
+    BatchNorm partial sums -- to the two-kernel path through the materialised map, which is checked against
     F.interpolate(..., 'bilinear', align_corners=False) + F.conv2d in fp32 and their autograd weight gradient."""
     N, h, w = cfg["n"], cfg["h"], cfg["w"]
     dtype = torch.bfloat16
@@ -1458,11 +1458,75 @@ def test_classifier0_on_the_upsampled_absdiff_map_formed_on_load(ops, cfg):
     # bias + ReLU epilogue (the eval-mode form: BatchNorm folded into the weights, its shift as the bias)
     y2 = ops.conv2d(u, wp, 32, 3, 1, 1, bias=bias.cuda(), act=ops.ACT_RELU)
     assert torch.equal(y2, ops.conv2d(mat, wp, 32, 3, 1, 1, bias=bias.cuda(), act=ops.ACT_RELU))
-    # weight gradient
+    # weight gradient (Up4Input: through the materialised map), twice: reproducible bit for bit
     dw_ref = torch.zeros(32, 32, 3, 3, device="cuda")
-    dw = torch.full_like(dw_ref, -0.5)
+    dw, dw2 = torch.full_like(dw_ref, -0.5), torch.full_like(dw_ref, -0.5)
     ops.conv2d_wgrad(mat, dyd, dw_ref, 3, 1, 1)
     ops.conv2d_wgrad(u, dyd, dw, 3, 1, 1, accumulate=True)
+    ops.conv2d_wgrad(u, dyd, dw2, 3, 1, 1, accumulate=True)
+    assert torch.equal(dw, dw2)
     err = float((dw + 0.5 - dw_ref).abs().max())
     assert err <= 2e-5 * float(dw_ref.abs().max()), err
     close(dw_ref, wt.grad, dtype, "weight gradient over the upsampled |a - b|", factor=4.0)
+
+
+@pytest.mark.parametrize("cfg", [dict(images=6, rpi=256, depth=8, mlp=32), dict(images=4, rpi=1024, depth=4, mlp=32),
+                                 dict(images=2, rpi=4096, depth=3, mlp=64)])
+def test_decoder_stack_in_one_launch_equals_layer_by_layer(ops, cfg):
+    """ops.decoder_stack_fwd / _bwd (all layers of a cross-attention decoder stack in ONE launch per direction: a workgroup takes
+    its pixel rows through every layer, help_funcs.py:170-186) against the same layers launched one by one: every layer's
+    output, the data gradient and every layer's parameter-gradient partials, bit for bit."""
+    images, rpi, depth, mlp = cfg["images"], cfg["rpi"], cfg["depth"], cfg["mlp"]
+    D, dt = 32, torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(77 + depth)
+    rn = lambda *s, sc=1.0: torch.randn(*s, device="cuda", generator=g) * sc
+    rows = images * rpi
+    x, dy = rn(rows, D).to(dt), rn(rows, D).to(dt)
+
+    class Stack:
+        pass
+    st = Stack()
+    st.layers = depth
+    kq, voT = rn(depth, images, 32, D, sc=0.3), rn(depth, images, D, 32, sc=0.3)
+    st.kq, st.voT = kq.to(dt), voT.to(dt)
+    st.vo, st.kqT = voT.transpose(2, 3).contiguous().to(dt), kq.transpose(2, 3).contiguous().to(dt)
+    # fp32 parameter vectors of all layers in one arena at a constant stride, as the net's flat parameter arena holds them
+    PS = 7 * D + 2 * mlp + 5
+    arena = rn(depth, PS, sc=0.1)
+    off = dict(g1=0, b1=D, bo=2 * D, g2=3 * D, b2=4 * D, fb1=5 * D, fb2=5 * D + mlp)
+    arena[:, off["g1"]:off["g1"] + D] += 1.0
+    arena[:, off["g2"]:off["g2"] + D] += 1.0
+    par = lambda l, n, ln: arena[l, off[n]:off[n] + ln]
+    params = lambda l: (par(l, "g1", D), par(l, "b1", D), par(l, "bo", D), par(l, "g2", D), par(l, "b2", D), par(l, "fb1", mlp), par(l, "fb2", D))
+    w1, w2 = rn(depth, mlp, D, sc=D ** -0.5), rn(depth, D, mlp, sc=mlp ** -0.5)
+    w1s, w1Ts = w1.to(dt).contiguous(), w1.transpose(1, 2).contiguous().to(dt)
+    w2s, w2Ts = w2.to(dt).contiguous(), w2.transpose(1, 2).contiguous().to(dt)
+    pf = ops.decoder_layer_bwd_partial_floats(rows, rpi, mlp)
+
+    class Prep:
+        pass
+
+    def prep(l):
+        q = Prep()
+        q.kq, q.voT, q.vo, q.kqT = st.kq[l], st.voT[l], st.vo[l], st.kqT[l]
+        return q
+    # layer by layer
+    xs, cur = [x], x
+    for l in range(depth):
+        g1, b1, bo, g2, b2, fb1, fb2 = params(l)
+        cur = ops.decoder_layer_fwd(cur, prep(l), rpi, g1, b1, bo, g2, b2, w1s[l], fb1, w2s[l], fb2, mlp)
+        xs.append(cur)
+    part_ref = torch.empty(depth, pf, dtype=torch.float32, device="cuda")
+    d = dy
+    for l in range(depth - 1, -1, -1):
+        g1, b1, bo, g2, b2, fb1, fb2 = params(l)
+        d, _, _ = ops.decoder_layer_bwd(xs[l], d, prep(l), rpi, g1, b1, bo, g2, b2, w1s[l], w1Ts[l], fb1, w2s[l], w2Ts[l], fb2, None,
+                                        mlp, partial=part_ref[l])
+    # one launch per direction
+    ys = ops.decoder_stack_fwd(x, st, rpi, params(0), w1s, w2s, PS, mlp)
+    for l in range(depth):
+        assert torch.equal(ys[l], xs[l + 1]), "layer %d output" % l
+    part = torch.empty(depth, pf, dtype=torch.float32, device="cuda")
+    dx = ops.decoder_stack_bwd(x, ys, dy, st, rpi, params(0), w1s, w1Ts, w2s, w2Ts, PS, mlp, part)
+    assert torch.equal(dx, d)
+    assert torch.equal(part, part_ref)

@@ -255,7 +255,7 @@ def test_teacher_forced_second_and_third_steps_match_the_oracle(name):
             worst = max(worst, float(e.max()) / lr if e.numel() else 0.0)
         print("%s step %d (teacher-forced): loss %.7f (oracle %.7f); update differs by > 0.02 lr on %d of %d well-conditioned "
               "elements (worst %.3f lr)" % (name, step_no, float(loss), c["loss"], bad, tot, worst))
-        assert tot > 1e5 and bad <= 1e-3 * tot
+        assert tot > 1e5 and bad <= 2e-3 * tot          # (measured: <= 9.7e-4 of the elements, worst 0.26 lr)
 
 
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])

@@ -274,7 +274,7 @@ def test_bench_refuses_more_gpus_than_the_box_has():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
-def _bench_size_rank(out):
+def _bench_size_rank(_index, out):
     """one RCCL rank at the BENCH size (32 pairs, 256 x 256, bf16) through the overlapped two-graph step"""
     os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                       DAHITRA_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
