@@ -99,6 +99,9 @@ class Engine:
         # all layers of a fused decoder stack in one launch per direction (csrc/decoder_fused.hip DecArgs::depth): the stack is
         # a per-pixel-row function, so nothing synchronises between its layers but a workgroup's own re-staging of the weights
         self.fuse_dec_stack = os.environ.get("DAHITRA_NO_DEC_STACK", "0") != "1"
+        # the three levels' small kernels on streams of their own between the shared launches (_run_staged)
+        self.level_streams = os.environ.get("DAHITRA_LEVEL_STREAMS", "0") == "1"
+        self._lstreams = []
         # class-head data gradient gated for the classifier's BatchNorm (mask + BN-backward sums in its epilogue).  Measured
         # neutral (8020 vs 8027 pairs/s: the reduction pass it removes costs what the extra read of y costs the head kernel):
         # off by default, DAHITRA_GATED_HEAD=1 turns it on.
@@ -1017,24 +1020,41 @@ class Engine:
         return logits, bwd
 
     # hierarchical model -------------------------------------------------------------------------
-    @staticmethod
-    def _run_staged(gens):
-        """GENERATORS that pause right after every token-encoder call and every fused decoder layer (forward: `_level`;
+    def _run_staged(self, gens):
+        """GENERATORS that pause right after every token-encoder call and every fused decoder stack (forward: `_level`;
         backward: the `bwd` it returns).  They run in rounds inside one ops.EncoderBatch: the launches they reach are only
         RECORDED, and after each round the recorded ones go out together -- the levels are independent, an encoder stack
-        occupies 2 x batch workgroups, the decoder layers of the 16 x 16 and 32 x 32 levels a fraction of the chip.
+        occupies 2 x batch workgroups, the decoder stacks of the 16 x 16 and 32 x 32 levels a fraction of the chip.
+        Between two such launches every level issues its OWN small kernels (1x1 squeeze, tokenizer, cross-attention operand
+        preparation and its gradients, positional adds, channel copies: 138 launches under 8 us in the DAHiTra step, most of
+        them a few dozen workgroups): with `level_streams` each level's segment goes to a stream of its own, forked from and
+        joined into the main stream around the round -- in the recorded step they are parallel branches of the graph and run
+        side by side instead of one after the other.
         Returns the generators' return values."""
         vals = {}
+        streams = None
+        if self.level_streams and len(gens) > 1 and ops.PROFILE is None:
+            dev = torch.cuda.current_device()
+            while len(self._lstreams) < len(gens):
+                self._lstreams.append(ops.SideStream(torch.device("cuda", dev)))
+            streams = self._lstreams
         with ops.EncoderBatch(decoder=True) as eb:
-            live = list(gens)
+            live = list(enumerate(gens))
             while live:
                 paused = []
-                for g in live:
+                for i, g in live:
                     try:
-                        next(g)
-                        paused.append(g)
+                        if streams is not None:
+                            with streams[i].fork():
+                                next(g)
+                        else:
+                            next(g)
+                        paused.append((i, g))
                     except StopIteration as e:
                         vals[id(g)] = e.value
+                if streams is not None:
+                    for st in streams:
+                        st.join()
                 eb.launch()          # what the levels recorded in this round: one launch per kernel family
                 live = paused
         return [vals[id(g)] for g in gens]

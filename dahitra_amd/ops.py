@@ -47,7 +47,9 @@ _ws = {}
 
 
 def workspace(nbytes, device):
-    key = str(device)
+    """scratch for ONE launch at a time per stream (keyed by device AND current stream: the levels of the hierarchical model
+    run on streams of their own, Engine._run_staged, and must not share it)"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream) if torch.device(device).type == "cuda" else str(device)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
