@@ -727,24 +727,31 @@ __global__ __launch_bounds__(256, MLP == 32 ? 2 : 1) void dec_bwd_multi_kernel(D
 // per-image dKq / dVoT over the workgroups of that image (assigned)
 // blockIdx.z = layer of a decoder stack whose backward launches left their partials `pstride` floats apart (layer 0 .. depth-1
 // of the SAME shapes): the layers' parameters sit `gstride` floats apart in the gradient arena, dkq / dvoT `kstride` apart.
+struct FinArgs {
+    const float* partial;
+    int nblk, bpi;
+    float *dw1, *dw2, *db1, *db2, *dbo, *dg1, *dbe1, *dg2, *dbe2, *dkq, *dvoT;
+    long pstride, gstride, kstride;
+};
 template <int MLP>
-__global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int bpi,
-                                                               float* dw1, float* dw2, float* db1, float* db2,
-                                                               float* dbo, float* dg1, float* dbe1, float* dg2,
-                                                               float* dbe2, float* dkq, float* dvoT, long pstride,
-                                                               long gstride, long kstride) {
+__device__ __forceinline__ void dec_bwd_finalize_body(const FinArgs& fa, const uint3 bid) {
     using P = PL<MLP>;
     __shared__ double red[8][32];
+    const float* partial = fa.partial;
+    const int nblk = fa.nblk, bpi = fa.bpi;
+    float *dw1 = fa.dw1, *dw2 = fa.dw2, *db1 = fa.db1, *db2 = fa.db2, *dbo = fa.dbo, *dg1 = fa.dg1, *dbe1 = fa.dbe1,
+          *dg2 = fa.dg2, *dbe2 = fa.dbe2, *dkq = fa.dkq, *dvoT = fa.dvoT;
+    const long pstride = fa.pstride, gstride = fa.gstride, kstride = fa.kstride;
     {
-        const long z = blockIdx.z;
+        const long z = bid.z;
         partial += z * pstride;
         dw1 += z * gstride; dw2 += z * gstride; db1 += z * gstride; db2 += z * gstride; dbo += z * gstride;
         dg1 += z * gstride; dbe1 += z * gstride; dg2 += z * gstride; dbe2 += z * gstride;
         dkq += z * kstride; dvoT += z * kstride;
     }
     const int lane = threadIdx.x & 31, ph = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + lane;                 // element of the shared-parameter part
-    if (blockIdx.y == 0) {
+    const int i = bid.x * 32 + lane;                 // element of the shared-parameter part
+    if (bid.y == 0) {
         double s = 0.0;
         if (i < P::KQ) {
             // four independent partial sums: the loop is otherwise one chain of dependent-latency loads
@@ -779,8 +786,8 @@ __global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(const float* __re
             dst[o] += (float)t;
         }
     } else {
-        const int img = blockIdx.y - 1;
-        const int e = blockIdx.x * 256 + threadIdx.x;     // element of [dKq | dVoT] (2048)
+        const int img = bid.y - 1;
+        const int e = bid.x * 256 + threadIdx.x;     // element of [dKq | dVoT] (2048)
         if (e < 2048) {
             float s = 0.f;
             const float* src = partial + (size_t)img * bpi * P::SIZE + P::KQ + e;
@@ -790,6 +797,28 @@ __global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(const float* __re
             else dvoT[(size_t)img * 1024 + e - 1024] = s;
         }
     }
+}
+template <int MLP>
+__global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(FinArgs fa) {
+    dec_bwd_finalize_body<MLP>(fa, make_uint3(blockIdx.x, blockIdx.y, blockIdx.z));
+}
+// the finalizes of several independent stacks in one launch (dh_decoder_batch_*): workgroups [first[j], first[j + 1]) run job j's
+// gx x gy[j] x depth grid
+struct FinMulti {
+    int n;
+    int first[DEC_MAXJ + 1], gx[DEC_MAXJ], gy[DEC_MAXJ];
+    FinArgs a[DEC_MAXJ];
+};
+template <int MLP>
+__global__ __launch_bounds__(256) void dec_bwd_finalize_multi_kernel(FinMulti m) {
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    int local = (int)blockIdx.x - m.first[j];
+    uint3 bid;
+    bid.x = local % m.gx[j]; local /= m.gx[j];
+    bid.y = local % m.gy[j];
+    bid.z = local / m.gy[j];
+    dec_bwd_finalize_body<MLP>(m.a[j], bid);
 }
 
 template <int MLP> size_t bwd_lds_bytes() {
@@ -809,6 +838,8 @@ struct DecBatch {      // index = (MLP == 64) + 2 * (layer-fused stack)
     bool on = false;
     int nf[4] = {0, 0, 0, 0}, nb[4] = {0, 0, 0, 0};
     DecMulti f[4], b[4];
+    int nfin[2] = {0, 0};      // recorded stack finalizes (MLP 32 / 64): issued after the backward launches
+    FinMulti fin[2];
 };
 static thread_local DecBatch g_db;
 template <int MLP> static int dec_set_bwd_lds(const void* kern, bool& done) {
@@ -874,6 +905,14 @@ static int dec_batch_flush(hipStream_t st) {
             d.nb[k] = 0;
         }
     }
+    for (int k = 0; k < 2; ++k)
+        if (d.nfin[k]) {
+            d.fin[k].n = d.nfin[k];
+            const int total = d.fin[k].first[d.nfin[k]];
+            if (k == 0) hipLaunchKernelGGL(dec_bwd_finalize_multi_kernel<32>, dim3(total), dim3(256), 0, st, d.fin[k]);
+            else hipLaunchKernelGGL(dec_bwd_finalize_multi_kernel<64>, dim3(total), dim3(256), 0, st, d.fin[k]);
+            d.nfin[k] = 0;
+        }
     DH_CHECK_LAUNCH("decoder_batch");
     return 0;
 }
@@ -934,9 +973,9 @@ static inline int dec_rows_per_block(long rows, int rows_per_image) {
 // direction and MLP width; a fifth issues the first four); dh_decoder_batch_launch(stream) issues the recorded layers of
 // INDEPENDENT stacks as one launch per direction and width.  Every buffer of a recorded call stays alive and unchanged until
 // then.  Per host thread; _abort drops the recorded calls.
-static void dec_batch_clear() { for (int k = 0; k < 4; ++k) g_db.nf[k] = g_db.nb[k] = 0; }
+static void dec_batch_clear() { for (int k = 0; k < 4; ++k) g_db.nf[k] = g_db.nb[k] = 0; g_db.nfin[0] = g_db.nfin[1] = 0; }
 extern "C" int dh_decoder_batch_begin() { g_db.on = true; dec_batch_clear(); return 0; }
-extern "C" int dh_decoder_batch_pending() { int n = 0; for (int k = 0; k < 4; ++k) n += g_db.nf[k] + g_db.nb[k]; return n; }
+extern "C" int dh_decoder_batch_pending() { int n = g_db.nfin[0] + g_db.nfin[1]; for (int k = 0; k < 4; ++k) n += g_db.nf[k] + g_db.nb[k]; return n; }
 extern "C" int dh_decoder_batch_launch(void* stream) { return dec_batch_flush(ST(stream)); }
 extern "C" int dh_decoder_batch_end(void* stream) { const int rc = dec_batch_flush(ST(stream)); g_db.on = false; return rc; }
 extern "C" int dh_decoder_batch_abort() { g_db.on = false; dec_batch_clear(); return 0; }
@@ -980,8 +1019,10 @@ extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, con
             }
         }
         hipLaunchKernelGGL(dec_bwd_kernel<64>, dim3(nblk), dim3(256), lds, ST(stream), a);
-        if (dw1) hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(dh_cdiv(PL<64>::KQ, 32), 1 + images), dim3(256), 0, ST(stream),
-                                    a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, 0L, 0L, 0L);
+        if (dw1) {
+            const FinArgs fa = {a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, 0L, 0L, 0L};
+            hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(dh_cdiv(PL<64>::KQ, 32), 1 + images), dim3(256), 0, ST(stream), fa);
+        }
     } else {
         const size_t lds = bwd_lds_bytes<32>();
         if (!attr32) {
@@ -992,8 +1033,10 @@ extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, con
             }
         }
         hipLaunchKernelGGL(dec_bwd_kernel<32>, dim3(nblk), dim3(256), lds, ST(stream), a);
-        if (dw1) hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(dh_cdiv(PL<32>::KQ, 32), 1 + images), dim3(256), 0, ST(stream),
-                                    a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, 0L, 0L, 0L);
+        if (dw1) {
+            const FinArgs fa = {a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, 0L, 0L, 0L};
+            hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(dh_cdiv(PL<32>::KQ, 32), 1 + images), dim3(256), 0, ST(stream), fa);
+        }
     }
     DH_CHECK_LAUNCH("decoder_layer_bwd");
     return 0;
@@ -1070,12 +1113,22 @@ extern "C" int dh_decoder_stack_bwd_finalize(const void* workspace, int depth, l
     const int nblk = (int)(rows / rpb), bpi = rows_per_image / rpb, images = (int)(rows / rows_per_image);
     const float* partial = reinterpret_cast<const float*>(workspace);
     const long pstride = dh_decoder_layer_bwd_workspace_size(rows, rows_per_image, mlp) / 4, kstride = (long)images * 1024;
+    const FinArgs fa = {partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, pstride, grad_stride, kstride};
+    if (g_db.on) {          // recorded: issued with the other stacks' finalizes, after the recorded backward launches
+        const int k = mlp == 64, gx = dh_cdiv(mlp == 64 ? PL<64>::KQ : PL<32>::KQ, 32);
+        if (g_db.nfin[k] == DEC_MAXJ) { const int rc = dec_batch_flush(ST(stream)); if (rc) return rc; }
+        FinMulti& fm = g_db.fin[k];
+        int& n = g_db.nfin[k];
+        if (n == 0) fm.first[0] = 0;
+        fm.a[n] = fa; fm.gx[n] = gx; fm.gy[n] = 1 + images;
+        fm.first[n + 1] = fm.first[n] + gx * (1 + images) * depth;
+        ++n;
+        return 0;
+    }
     if (mlp == 64)
-        hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(dh_cdiv(PL<64>::KQ, 32), 1 + images, depth), dim3(256), 0, ST(stream), partial,
-                           nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, pstride, grad_stride, kstride);
+        hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(dh_cdiv(PL<64>::KQ, 32), 1 + images, depth), dim3(256), 0, ST(stream), fa);
     else
-        hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(dh_cdiv(PL<32>::KQ, 32), 1 + images, depth), dim3(256), 0, ST(stream), partial,
-                           nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, pstride, grad_stride, kstride);
+        hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(dh_cdiv(PL<32>::KQ, 32), 1 + images, depth), dim3(256), 0, ST(stream), fa);
     DH_CHECK_LAUNCH("decoder_stack_bwd_finalize");
     return 0;
 }

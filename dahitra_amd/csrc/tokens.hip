@@ -270,6 +270,27 @@ __global__ void tok_dpos_kernel(const float* __restrict__ dtok_cat, int B, int n
 // ------------------------------------------------------------------------------------------
 // Weight access is coalesced everywhere: thread index runs along the contiguous dimension of whichever form
 // (fp32 master [out][in], or the packed transpose in T produced by dh_pack_weight) makes that possible.
+// ---- the small per-image token-side kernels of SEVERAL independent decoder stacks in one launch (dh_xprep_batch_*): every
+// kernel below is a body function of (arguments, virtual block index) with two entry points -- its own launch, and a
+// multi-launch whose workgroups [first[j], first[j + 1]) run job j's gx[j] x gy[j] x . grid (arguments by value).  DAHiTra's three
+// levels each issue these 11 - 13 us, few-dozen-workgroup launches twice per direction; alone they are latency, together one.
+constexpr int XB_MAXJ = 4;
+template <typename A> struct XMulti {
+    int n;
+    int first[XB_MAXJ + 1], gx[XB_MAXJ], gy[XB_MAXJ];
+    A a[XB_MAXJ];
+};
+template <typename A> __device__ __forceinline__ int xb_locate(const XMulti<A>& m, uint3& bid) {
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    int local = (int)blockIdx.x - m.first[j];
+    bid.x = local % m.gx[j]; local /= m.gx[j];
+    bid.y = local % m.gy[j];
+    bid.z = local / m.gy[j];
+    return j;
+}
+#define XB_BID make_uint3(blockIdx.x, blockIdx.y, blockIdx.z)
+
 struct PrepArgs {
     const void* tok;        // token rows, fp32
     long tok_bstride, tok_sstride;   // elements between batch items / streams
@@ -427,13 +448,13 @@ __device__ __forceinline__ void st4bf(bf16* p, const float (&v)[4]) {
 }
 
 template <int DH>        // dim_head: 32 or 64
-__global__ __launch_bounds__(256) void xattn_prep_mfma_kernel(PrepMArgs m) {
+__device__ __forceinline__ void xattn_prep_mfma_body(PrepMArgs m, const uint3 bid) {
     PrepArgs& a = m.a;
     constexpr int L = 4, NBLK = DH / 16, NKS = DH / 32;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
     const int inner = a.heads * DH, HL = a.heads * L;
     {
-        const size_t ly = blockIdx.y;
+        const size_t ly = bid.y;
         a.ln_g += ly * a.ls_param; a.ln_b += ly * a.ls_param;
         m.wk += ly * a.ls_param; m.wv += ly * a.ls_param; m.wo += ly * a.ls_param;
         m.wqT += ly * a.ls_pack;
@@ -443,7 +464,7 @@ __global__ __launch_bounds__(256) void xattn_prep_mfma_kernel(PrepMArgs m) {
         a.vo = reinterpret_cast<bf16*>(a.vo) + ly * a.S * a.HLP * D; a.voT = reinterpret_cast<bf16*>(a.voT) + ly * a.S * a.HLP * D;
     }
     // column pl of the MFMAs = token l of image s
-    const int s = blockIdx.x * 4 + (pl >> 2), l = pl & 3;
+    const int s = bid.x * 4 + (pl >> 2), l = pl & 3;
     const float* tok = reinterpret_cast<const float*>(a.tok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride + l * D;
     float x[2][4], mnv[2][4];
     {
@@ -528,13 +549,21 @@ __global__ __launch_bounds__(256) void xattn_prep_mfma_kernel(PrepMArgs m) {
         const int pad = a.HLP - HL;
         for (int i = tid; i < 4 * pad * D; i += 256) {
             const int c = i % D, r = (i / D) % pad, si = i / (D * pad);
-            const size_t base = (size_t)(blockIdx.x * 4 + si) * a.HLP * D;
+            const size_t base = (size_t)(bid.x * 4 + si) * a.HLP * D;
             bf16* q0 = reinterpret_cast<bf16*>(a.kq) + base; bf16* o0 = reinterpret_cast<bf16*>(a.vo) + base;
             bf16* qT = reinterpret_cast<bf16*>(a.kqT) + base; bf16* oT = reinterpret_cast<bf16*>(a.voT) + base;
             stf(q0 + (HL + r) * D + c, 0.f); stf(o0 + (HL + r) * D + c, 0.f);
             stf(qT + c * a.HLP + HL + r, 0.f); stf(oT + c * a.HLP + HL + r, 0.f);
         }
     }
+}
+template <int DH>
+__global__ __launch_bounds__(256) void xattn_prep_mfma_kernel(PrepMArgs m) { xattn_prep_mfma_body<DH>(m, XB_BID); }
+template <int DH>
+__global__ __launch_bounds__(256) void xattn_prep_mfma_multi_kernel(XMulti<PrepMArgs> mm) {
+    uint3 bid;
+    const int j = xb_locate(mm, bid);
+    xattn_prep_mfma_body<DH>(mm.a[j], bid);
 }
 
 struct PrepBwdArgs {
@@ -672,14 +701,14 @@ struct PrepBwdMArgs {
     const bf16 *woT, *wkT, *wvT;     // stacked transposes [layers][inner][32], [layers][32][inner] x2
 };
 template <int DH>
-__global__ __launch_bounds__(256) void xattn_prep_bwd_mfma_kernel(PrepBwdMArgs m) {
+__device__ __forceinline__ void xattn_prep_bwd_mfma_body(PrepBwdMArgs m, const uint3 bid) {
     PrepBwdArgs& a = m.a;
     constexpr int L = 4, NBLK = DH / 16, NKS = DH / 32;
     __shared__ __attribute__((aligned(16))) float red[4][2][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
     const int inner = a.heads * DH;
     {
-        const size_t ly = blockIdx.y;
+        const size_t ly = bid.y;
         a.ln_g += ly * a.ls_param; m.wq += ly * a.ls_param;
         m.woT += ly * a.ls_pack; m.wkT += ly * a.ls_pack; m.wvT += ly * a.ls_pack;
         a.mn += ly * a.S * L * D; a.mstats += ly * a.S * L * 2;
@@ -688,7 +717,7 @@ __global__ __launch_bounds__(256) void xattn_prep_bwd_mfma_kernel(PrepBwdMArgs m
         a.ln_partial += ly * a.S * 2 * D;
         if (a.dtok_part) a.dtok_part += ly * a.S * L * D;
     }
-    const int s = blockIdx.x * 4 + (pl >> 2), l = pl & 3;
+    const int s = bid.x * 4 + (pl >> 2), l = pl & 3;
     const float* dkq = a.dkq + (size_t)s * a.HLP * D;
     const float* dvoT = a.dvoT + (size_t)s * a.HLP * D;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -782,6 +811,14 @@ __global__ __launch_bounds__(256) void xattn_prep_bwd_mfma_kernel(PrepBwdMArgs m
         }
     }
 }
+template <int DH>
+__global__ __launch_bounds__(256) void xattn_prep_bwd_mfma_kernel(PrepBwdMArgs m) { xattn_prep_bwd_mfma_body<DH>(m, XB_BID); }
+template <int DH>
+__global__ __launch_bounds__(256) void xattn_prep_bwd_mfma_multi_kernel(XMulti<PrepBwdMArgs> mm) {
+    uint3 bid;
+    const int j = xb_locate(mm, bid);
+    xattn_prep_bwd_mfma_body<DH>(mm.a[j], bid);
+}
 
 // weight gradients of to_q / to_k / to_v / to_out: one workgroup per (matrix, hd); 8 image phases x 32 channels,
 // LDS reduce.  blockIdx.y == 4: the shared LayerNorm's dgamma / dbeta from the per-image partials.
@@ -794,7 +831,7 @@ struct PrepWgArgs {
     long ls_param;                   // stacked form: blockIdx.z = layer (inputs stacked, gradients at the arena's layer pitch)
     int ln_only;                     // 1: grid (2, 1, layers) -- only the LayerNorm sums (the matrices went to the MFMA kernel)
 };
-__global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
+__device__ __forceinline__ void xattn_prep_wgrad_body(PrepWgArgs a, const uint3 bid) {
     // one workgroup per (matrix, block of HB = 8 consecutive inner columns hd): 8 image phases x 32 channels, every
     // thread carries the 8 columns (their k / v / dk / dv values are two 16-byte broadcast loads).  One workgroup per
     // single column was 2560 - 10240 tiny workgroups per launch: dispatch-bound (72 us for 17 MFLOP).
@@ -802,7 +839,7 @@ __global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
     __shared__ float red[8][HB][33];
     const int inner = a.heads * a.dh, L = a.L;
     {
-        const size_t ly = blockIdx.z;
+        const size_t ly = bid.z;
         a.mn += ly * a.S * L * D; a.k += ly * a.S * L * inner; a.v += ly * a.S * L * inner;
         a.dk += ly * a.S * L * inner; a.dv += ly * a.S * L * inner;
         a.dkq += ly * a.S * a.HLP * D; a.dvoT += ly * a.S * a.HLP * D; a.ln_partial += ly * a.S * 2 * D;
@@ -810,13 +847,13 @@ __global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
         a.dln_g += ly * a.ls_param; a.dln_b += ly * a.ls_param;
     }
     const int c = threadIdx.x & 31, ph = threadIdx.x >> 5;
-    const int which = a.ln_only ? 4 : blockIdx.y, hd0 = blockIdx.x * HB;
+    const int which = a.ln_only ? 4 : bid.y, hd0 = bid.x * HB;
     float acc[HB];
 #pragma unroll
     for (int j = 0; j < HB; ++j) acc[j] = 0.f;
     if (which == 4) {
-        if (blockIdx.x >= 2) return;                           // blockIdx.x = 0: dgamma, 1: dbeta
-        for (int s = ph; s < a.S; s += 8) acc[0] += a.ln_partial[((size_t)s * 2 + blockIdx.x) * D + c];
+        if (bid.x >= 2) return;                           // bid.x = 0: dgamma, 1: dbeta
+        for (int s = ph; s < a.S; s += 8) acc[0] += a.ln_partial[((size_t)s * 2 + bid.x) * D + c];
     } else {
         const int h = hd0 / a.dh;                              // HB divides dh: the block lies inside one head
         const float* colsrc = which == 0 ? a.k : (which == 1 ? a.dk : (which == 2 ? a.dv : a.v));
@@ -842,7 +879,7 @@ __global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) t += red[r][0][c];
-            float* out = blockIdx.x == 0 ? a.dln_g : a.dln_b;
+            float* out = bid.x == 0 ? a.dln_g : a.dln_b;
             out[c] += t;                                       // the pixel-side LN backward wrote its part already
         }
         return;
@@ -859,6 +896,12 @@ __global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) {
         if (a.accumulate) out[o] += t; else out[o] = t;
     }
 }
+__global__ __launch_bounds__(256) void xattn_prep_wgrad_kernel(PrepWgArgs a) { xattn_prep_wgrad_body(a, XB_BID); }
+__global__ __launch_bounds__(256) void xattn_prep_wgrad_multi_kernel(XMulti<PrepWgArgs> mm) {
+    uint3 bid;
+    const int j = xb_locate(mm, bid);
+    xattn_prep_wgrad_body(mm.a[j], bid);
+}
 
 // The same weight gradients on the matrix cores (bf16 nets, dim_head = 64, L = 4, S a multiple of 8): every one of the four is
 //   dW[hd][c] = sum over the K = S * L token rows of col[K][hd] * row[K][c]
@@ -873,19 +916,19 @@ __device__ __forceinline__ s16x8 wg_tile_frag(const unsigned char* tile, int pit
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 16 * pitch));
     return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-__global__ __launch_bounds__(256) void xattn_prep_wgrad_mfma_kernel(PrepWgArgs a) {
+__device__ __forceinline__ void xattn_prep_wgrad_mfma_body(PrepWgArgs a, const uint3 bid) {
     constexpr int L = 4, DH = 64, CP = wg_pitch(128), RP = wg_pitch(64);
     __shared__ __attribute__((aligned(16))) unsigned char colT[32 * CP], rowT[32 * RP];
     const int inner = a.heads * DH;
     {
-        const size_t ly = blockIdx.z;
+        const size_t ly = bid.z;
         a.mn += ly * a.S * L * D; a.k += ly * a.S * L * inner; a.v += ly * a.S * L * inner;
         a.dk += ly * a.S * L * inner; a.dv += ly * a.S * L * inner;
         a.dkq += ly * a.S * a.HLP * D; a.dvoT += ly * a.S * a.HLP * D;
         a.dwq += ly * a.ls_param; a.dwk += ly * a.ls_param; a.dwv += ly * a.ls_param; a.dwo += ly * a.ls_param;
     }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
-    const int which = blockIdx.y, h = blockIdx.x, hd0 = h * DH;
+    const int which = bid.y, h = bid.x, hd0 = h * DH;
     const float* colsrc = which == 0 ? a.k : (which == 1 ? a.dk : (which == 2 ? a.dv : a.v));
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[2] = {zero4, zero4};
@@ -926,15 +969,32 @@ __global__ __launch_bounds__(256) void xattn_prep_wgrad_mfma_kernel(PrepWgArgs a
             if (a.accumulate) out[o] += t; else out[o] = t;
         }
 }
+__global__ __launch_bounds__(256) void xattn_prep_wgrad_mfma_kernel(PrepWgArgs a) { xattn_prep_wgrad_mfma_body(a, XB_BID); }
+__global__ __launch_bounds__(256) void xattn_prep_wgrad_mfma_multi_kernel(XMulti<PrepWgArgs> mm) {
+    uint3 bid;
+    const int j = xb_locate(mm, bid);
+    xattn_prep_wgrad_mfma_body(mm.a[j], bid);
+}
 
 // dtok[token rows of image s] += sum over the layers of dtok_part[layer][s]   (fixed order: deterministic)
-__global__ void dtok_reduce_kernel(const float* __restrict__ part, int layers, int S, int L, int B, long bstride,
-                                   long sstride, float* __restrict__ dtok) {
-    const int s = blockIdx.x, i = threadIdx.x;           // blockDim = L*32
+struct DtokArgs {
+    const float* part;
+    int layers, S, L, B;
+    long bstride, sstride;
+    float* dtok;
+};
+__device__ __forceinline__ void dtok_reduce_body(const DtokArgs& a, const uint3 bid) {
+    const int s = bid.x, i = threadIdx.x;           // blockDim = L*32
     float t = 0.f;
-    for (int ly = 0; ly < layers; ++ly) t += part[((size_t)ly * S + s) * L * D + i];
-    float* dm = dtok + (size_t)(s % B) * bstride + (size_t)(s / B) * sstride;
+    for (int ly = 0; ly < a.layers; ++ly) t += a.part[((size_t)ly * a.S + s) * a.L * D + i];
+    float* dm = a.dtok + (size_t)(s % a.B) * a.bstride + (size_t)(s / a.B) * a.sstride;
     dm[i] += t;
+}
+__global__ void dtok_reduce_kernel(DtokArgs a) { dtok_reduce_body(a, XB_BID); }
+__global__ void dtok_reduce_multi_kernel(XMulti<DtokArgs> mm) {
+    uint3 bid;
+    const int j = xb_locate(mm, bid);
+    dtok_reduce_body(mm.a[j], bid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1135,6 +1195,83 @@ extern "C" int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S
 // ln_g / wk / wv / wo and all gradient outputs (backward) are the FIRST layer's pointers, consecutive layers lie
 // param_stride floats apart (the net's flat arena); wkT / wvT / woT / wqT are stacked [layers][32*inner]; every saved /
 // output tensor is stacked [layers][...] with the single-layer shape.
+// ---- batched launches of the matrix-core preparation family (dh_xprep_batch_*) ---------------------------------------------------
+// Between dh_xprep_batch_begin() and _end(), dh_xattn_prep_fwd_stack_mfma and dh_xattn_prep_bwd_stack_mfma only RECORD their
+// kernels (dim_head 64, up to XB_MAXJ stacks per family).  dh_xprep_batch_launch_fwd(stream) issues the recorded forward
+// preparations as one launch (call it BEFORE the decoder launches that read their outputs); dh_xprep_batch_launch_bwd(stream)
+// issues, in dependency order, one launch per family: operand gradients -> token-gradient reduce -> weight gradients on the matrix
+// cores -> LayerNorm sums (call it AFTER the decoder-stack finalize that writes dkq / dvoT).  Every buffer of a recorded call --
+// its workspace included: one per call -- stays alive and unchanged until then.  Per host thread; _abort drops what was recorded.
+template <typename A> struct XBatch {
+    int n = 0;
+    XMulti<A> m;
+    bool full() const { return n == XB_MAXJ; }
+    void add(const A& a, int gx, int gy, int gz) {
+        if (n == 0) m.first[0] = 0;
+        m.a[n] = a; m.gx[n] = gx; m.gy[n] = gy;
+        m.first[n + 1] = m.first[n] + gx * gy * gz;
+        ++n;
+    }
+};
+struct XprepBatch {
+    bool on = false, paused = false;       // paused: calls launch at once although a batch is open (dh_xprep_batch_pause)
+    XBatch<PrepMArgs> fwd;
+    XBatch<PrepBwdMArgs> bwd;
+    XBatch<DtokArgs> dtok;
+    XBatch<PrepWgArgs> wg_mfma, wg_ln;
+};
+static thread_local XprepBatch g_xb;
+extern "C" int dh_decoder_batch_pending();                // csrc/decoder_fused.hip
+extern "C" int dh_decoder_batch_launch(void* stream);
+static int xprep_flush_fwd(hipStream_t st) {
+    XprepBatch& b = g_xb;
+    if (b.fwd.n) {
+        b.fwd.m.n = b.fwd.n;
+        hipLaunchKernelGGL(xattn_prep_mfma_multi_kernel<64>, dim3(b.fwd.m.first[b.fwd.n]), dim3(256), 0, st, b.fwd.m);
+        b.fwd.n = 0;
+        DH_CHECK_LAUNCH("xprep_batch_fwd");
+    }
+    return 0;
+}
+static int xprep_flush_bwd(hipStream_t st) {
+    XprepBatch& b = g_xb;
+    if (b.bwd.n) {
+        b.bwd.m.n = b.bwd.n;
+        hipLaunchKernelGGL(xattn_prep_bwd_mfma_multi_kernel<64>, dim3(b.bwd.m.first[b.bwd.n]), dim3(256), 0, st, b.bwd.m);
+        b.bwd.n = 0;
+    }
+    if (b.dtok.n) {
+        b.dtok.m.n = b.dtok.n;
+        hipLaunchKernelGGL(dtok_reduce_multi_kernel, dim3(b.dtok.m.first[b.dtok.n]), dim3(4 * 32), 0, st, b.dtok.m);
+        b.dtok.n = 0;
+    }
+    if (b.wg_mfma.n) {
+        b.wg_mfma.m.n = b.wg_mfma.n;
+        hipLaunchKernelGGL(xattn_prep_wgrad_mfma_multi_kernel, dim3(b.wg_mfma.m.first[b.wg_mfma.n]), dim3(256), 0, st, b.wg_mfma.m);
+        b.wg_mfma.n = 0;
+    }
+    if (b.wg_ln.n) {
+        b.wg_ln.m.n = b.wg_ln.n;
+        hipLaunchKernelGGL(xattn_prep_wgrad_multi_kernel, dim3(b.wg_ln.m.first[b.wg_ln.n]), dim3(256), 0, st, b.wg_ln.m);
+        b.wg_ln.n = 0;
+    }
+    DH_CHECK_LAUNCH("xprep_batch_bwd");
+    return 0;
+}
+static void xprep_clear() { g_xb.fwd.n = g_xb.bwd.n = g_xb.dtok.n = g_xb.wg_mfma.n = g_xb.wg_ln.n = 0; }
+extern "C" int dh_xprep_batch_begin() { g_xb.on = true; g_xb.paused = false; xprep_clear(); return 0; }
+extern "C" int dh_xprep_batch_pause(int paused) { g_xb.paused = paused != 0; return 0; }
+extern "C" int dh_xprep_batch_pending() { return g_xb.fwd.n + g_xb.bwd.n + g_xb.dtok.n + g_xb.wg_mfma.n + g_xb.wg_ln.n; }
+extern "C" int dh_xprep_batch_launch_fwd(void* stream) { return xprep_flush_fwd(ST(stream)); }
+extern "C" int dh_xprep_batch_launch_bwd(void* stream) { return xprep_flush_bwd(ST(stream)); }
+extern "C" int dh_xprep_batch_end(void* stream) {
+    int rc = xprep_flush_fwd(ST(stream));
+    if (!rc) rc = xprep_flush_bwd(ST(stream));
+    g_xb.on = false;
+    return rc;
+}
+extern "C" int dh_xprep_batch_abort() { g_xb.on = false; xprep_clear(); return 0; }
+
 extern "C" int dh_xattn_prep_fwd_stack(int dtype, const void* tok, long tok_bstride, long tok_sstride, int B, int S, int L,
                                        int heads, int dim_head, int HLP, float scale, float eps, int layers,
                                        long param_stride, const float* ln_g, const float* ln_b, const float* wq,
@@ -1184,6 +1321,11 @@ extern "C" int dh_xattn_prep_fwd_stack_mfma(const void* tok, long tok_bstride, l
     a.mn = mn; a.mstats = mstats; a.k = k; a.v = v; a.kq = kq; a.kqT = kqT; a.vo = vo; a.voT = voT;
     a.ls_param = param_stride; a.ls_pack = 32L * heads * dim_head;
     m.wk = wk; m.wv = wv; m.wo = wo; m.wqT = reinterpret_cast<const bf16*>(wqT);
+    if (g_xb.on && !g_xb.paused && dim_head == 64) {                 // recorded: issued with the other stacks' by dh_xprep_batch_launch_fwd
+        if (g_xb.fwd.full()) { const int rc = xprep_flush_fwd(ST(stream)); if (rc) return rc; }
+        g_xb.fwd.add(m, S / 4, layers, 1);
+        return 0;
+    }
     if (dim_head == 64) hipLaunchKernelGGL(xattn_prep_mfma_kernel<64>, dim3(S / 4, layers), dim3(256), 0, ST(stream), m);
     else hipLaunchKernelGGL(xattn_prep_mfma_kernel<32>, dim3(S / 4, layers), dim3(256), 0, ST(stream), m);
     DH_CHECK_LAUNCH("xattn_prep_fwd_mfma");
@@ -1213,9 +1355,12 @@ extern "C" int dh_xattn_prep_bwd_stack(int dtype, const void* tok, void* dtok_ac
     const size_t lds = (size_t)(2 * L * inner + L * 32 + 2 * HLP * 32 + 16 * 32 + 32 * L * 32) * 4;
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(xattn_prep_bwd_kernel<bf16>, dim3(S, layers), dim3(1024), lds, ST(stream), a);
     else hipLaunchKernelGGL(xattn_prep_bwd_kernel<float>, dim3(S, layers), dim3(1024), lds, ST(stream), a);
-    if (layers > 1)
-        hipLaunchKernelGGL(dtok_reduce_kernel, dim3(S), dim3(L * 32), 0, ST(stream), a.dtok_part, layers, S, L, B,
-                           tok_bstride, tok_sstride, reinterpret_cast<float*>(dtok_accum));
+    if (layers > 1) {
+        DtokArgs dt;
+        dt.part = a.dtok_part; dt.layers = layers; dt.S = S; dt.L = L; dt.B = B; dt.bstride = tok_bstride; dt.sstride = tok_sstride;
+        dt.dtok = reinterpret_cast<float*>(dtok_accum);
+        hipLaunchKernelGGL(dtok_reduce_kernel, dim3(S), dim3(L * 32), 0, ST(stream), dt);
+    }
     PrepWgArgs w;
     w.S = S; w.L = L; w.heads = heads; w.dh = dim_head; w.HLP = HLP; w.scale = scale; w.mn = mn; w.k = k; w.v = v;
     w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;
@@ -1250,11 +1395,33 @@ extern "C" int dh_xattn_prep_bwd_stack_mfma(const void* tok, void* dtok_accum, l
     m.wq = wq; m.woT = reinterpret_cast<const bf16*>(woT); m.wkT = reinterpret_cast<const bf16*>(wkT);
     m.wvT = reinterpret_cast<const bf16*>(wvT);
     const int inner = heads * dim_head;
+    DtokArgs dt;
+    dt.part = a.dtok_part; dt.layers = layers; dt.S = S; dt.L = L; dt.B = B; dt.bstride = tok_bstride; dt.sstride = tok_sstride;
+    dt.dtok = reinterpret_cast<float*>(dtok_accum);
+    static const bool wg_fma_ = getenv("DAHITRA_PREP_WGRAD_FMA") != nullptr;
+    if (g_xb.on && !g_xb.paused && dim_head == 64 && S % 8 == 0 && !wg_fma_) {
+        // recorded: the four kernels of this stack join the other stacks' in dh_xprep_batch_launch_bwd's four launches
+        if (g_xb.bwd.full() || g_xb.dtok.full() || g_xb.wg_mfma.full() || g_xb.wg_ln.full()) {
+            const int rc = xprep_flush_bwd(ST(stream));
+            if (rc) return rc;
+        }
+        g_xb.bwd.add(m, S / 4, layers, 1);
+        if (layers > 1) g_xb.dtok.add(dt, S, 1, 1);
+        PrepWgArgs w;
+        w.S = S; w.L = L; w.heads = heads; w.dh = dim_head; w.HLP = HLP; w.scale = scale; w.mn = mn; w.k = k; w.v = v;
+        w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;
+        w.ln_partial = a.ln_partial; w.dln_g = dln_g; w.dln_b = dln_b;
+        w.accumulate = accumulate; w.ls_param = param_stride; w.ln_only = 0;
+        g_xb.wg_mfma.add(w, heads, 4, layers);
+        w.ln_only = 1;
+        g_xb.wg_ln.add(w, 2, 1, layers);
+        return 0;
+    }
+    // launched at once: a recorded stack finalize (the decoder batch holds it back) produces the dkq / dvoT read here
+    if (dh_decoder_batch_pending()) { const int rc = dh_decoder_batch_launch(stream); if (rc) return rc; }
     if (dim_head == 64) hipLaunchKernelGGL(xattn_prep_bwd_mfma_kernel<64>, dim3(S / 4, layers), dim3(256), 0, ST(stream), m);
     else hipLaunchKernelGGL(xattn_prep_bwd_mfma_kernel<32>, dim3(S / 4, layers), dim3(256), 0, ST(stream), m);
-    if (layers > 1)
-        hipLaunchKernelGGL(dtok_reduce_kernel, dim3(S), dim3(L * 32), 0, ST(stream), a.dtok_part, layers, S, L, B,
-                           tok_bstride, tok_sstride, reinterpret_cast<float*>(dtok_accum));
+    if (layers > 1) hipLaunchKernelGGL(dtok_reduce_kernel, dim3(S), dim3(L * 32), 0, ST(stream), dt);
     PrepWgArgs w;
     w.S = S; w.L = L; w.heads = heads; w.dh = dim_head; w.HLP = HLP; w.scale = scale; w.mn = mn; w.k = k; w.v = v;
     w.dk = dk; w.dv = dv; w.dkq = dkq; w.dvoT = dvoT; w.dwq = dwq; w.dwk = dwk; w.dwv = dwv; w.dwo = dwo;

@@ -648,6 +648,7 @@ class Engine:
                                *(self.p[a0 + ".fn.to_%s.weight" % n] for n in ("k", "v", "out.0")),
                                self.g[a0 + ".norm.weight"], self.g[a0 + ".norm.bias"],
                                *(self.g[a0 + ".fn.to_%s.weight" % n] for n in ("q", "k", "v", "out.0")))
+                yield               # (the finalize and the token-side backward may only be recorded) dtok is valid from here on
                 return dx
             return ys[depth - 1], bwd_stack
         for i in range(depth):
@@ -682,6 +683,8 @@ class Engine:
                                *(self.p[a0 + ".fn.to_%s.weight" % n] for n in ("k", "v", "out.0")),
                                self.g[a0 + ".norm.weight"], self.g[a0 + ".norm.bias"],
                                *(self.g[a0 + ".fn.to_%s.weight" % n] for n in ("q", "k", "v", "out.0")))
+                if fused:
+                    yield           # (may only be recorded) dtok is valid from here on
             return d
         return x, bwd
 
@@ -747,7 +750,8 @@ class Engine:
                                   self.xstack[(pfx, "to_k.weight")], self.xstack[(pfx, "to_v.weight")],
                                   self.xstack[(pfx, "to_out.0.weight")], self.dtype, ATTN_SCALE, LN_EPS,
                                   masters=(self.p[a0 + ".fn.to_k.weight"], self.p[a0 + ".fn.to_v.weight"],
-                                           self.p[a0 + ".fn.to_out.0.weight"], self.xstack[(pfx, "to_q.weight")]))
+                                           self.p[a0 + ".fn.to_out.0.weight"], self.xstack[(pfx, "to_q.weight")]),
+                                  record=not self.attn_fp8)      # the fp8 layers launch at once: so must what they read
 
     def _dec_layer_fused(self, x0, images, rpi, tok, tok_b, tok_s, B, dtok, a, f, heads, dim_head, L, mlp, stack=None,
                          li=0, partial=None):

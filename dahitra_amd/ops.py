@@ -1177,10 +1177,11 @@ class XattnPrep:
         self._bwd_ops = (wq, woT, wkT, wvT)
         if self.mfma:
             wk, wv, wo, wqT = masters
-            _call("dh_xattn_prep_fwd_stack_mfma", P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(heads),
-                  _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), _ci(1), _cl(0), P(ln_g), P(ln_b), P(wk), P(wv), P(wo),
-                  P(wqT), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq), P(self.kqT), P(self.vo),
-                  P(self.voT), S())
+            with _XprepPaused():
+                _call("dh_xattn_prep_fwd_stack_mfma", P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(heads),
+                      _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), _ci(1), _cl(0), P(ln_g), P(ln_b), P(wk), P(wv), P(wo),
+                      P(wqT), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq), P(self.kqT), P(self.vo),
+                      P(self.voT), S())
             return
         _call("dh_xattn_prep_fwd", _ci(_DT[dtype]), P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(L),
               _ci(heads), _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), P(ln_g), P(ln_b), P(wq), P(wkT), P(wvT),
@@ -1199,8 +1200,9 @@ class XattnPrepStack:
     wkT / wvT / woT are stacked [layers, 32 * inner] transposes in `dtype`."""
 
     def __init__(self, tok, bstride, sstride, B, Sn, L, heads, dim_head, layers, param_stride, ln_g0, ln_b0, wq0, wkT, wvT,
-                 woT, dtype, scale=32 ** -0.5, eps=1e-5, masters=None):
-        """masters = (wk0, wv0, wo0 fp32 masters of the first layer, stacked wqT): see XattnPrep"""
+                 woT, dtype, scale=32 ** -0.5, eps=1e-5, masters=None, record=True):
+        """masters = (wk0, wv0, wo0 fp32 masters of the first layer, stacked wqT): see XattnPrep.
+        record=False: launch at once even inside an EncoderBatch (the caller's next launch is not a recorded one)"""
         dev = tok.device
         assert tok.dtype == torch.float32, "tokens are fp32 in every compute mode"
         inner = heads * dim_head
@@ -1224,10 +1226,18 @@ class XattnPrepStack:
         self._bwd_ops = (wq0, woT, wkT, wvT)          # what the matrix-core backward reads
         if self.mfma:
             wk0, wv0, wo0, wqT = masters
-            _call("dh_xattn_prep_fwd_stack_mfma", P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(heads),
-                  _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), _ci(layers), _cl(param_stride), P(ln_g0), P(ln_b0),
-                  P(wk0), P(wv0), P(wo0), P(wqT), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq), P(self.kqT),
-                  P(self.vo), P(self.voT), S())
+            if _XPREP_BATCH is not None and not record:
+                _lib.lib().dh_xprep_batch_pause(1)
+            try:
+                _call("dh_xattn_prep_fwd_stack_mfma", P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(heads),
+                      _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), _ci(layers), _cl(param_stride), P(ln_g0), P(ln_b0),
+                      P(wk0), P(wv0), P(wo0), P(wqT), P(self.mn), P(self.mstats), P(self.k), P(self.v), P(self.kq), P(self.kqT),
+                      P(self.vo), P(self.voT), S())
+            finally:
+                if _XPREP_BATCH is not None and not record:
+                    _lib.lib().dh_xprep_batch_pause(0)
+            if _XPREP_BATCH is not None and record:
+                _XPREP_BATCH.append(tok)
             return
         _call("dh_xattn_prep_fwd_stack", _ci(_DT[dtype]), P(tok), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(L),
               _ci(heads), _ci(dim_head), _ci(self.HLP), _cf(scale), _cf(eps), _ci(layers), _cl(param_stride), P(ln_g0),
@@ -1247,7 +1257,15 @@ class XattnPrepStack:
         bstride, sstride, B, Sn, L, heads, dim_head = self.args
         dk = torch.empty_like(self.k)
         dv = torch.empty_like(self.v)
-        ws = workspace(_lib.lib().dh_xattn_prep_bwd_stack_workspace_size(Sn, L, self.layers), tok.device)
+        nws = _lib.lib().dh_xattn_prep_bwd_stack_workspace_size(Sn, L, self.layers)
+        if _XPREP_BATCH is not None and self.mfma:
+            # recorded (EncoderBatch): the launch comes later, next to other stacks' -- scratch of its own until then
+            ws = torch.empty(max(int(nws), 1), dtype=torch.uint8, device=tok.device)
+            _XPREP_BATCH.extend((ws, dk, dv, tok, dtok_accum))
+        else:
+            ws = workspace(nws, tok.device)
+            if _DEC_BATCH is not None:            # launched at once: a held-back stack finalize produces the dkq / dvoT read here
+                _call("dh_decoder_batch_launch", S())
         if self.mfma:
             wq0, woT, wkT, wvT = self._bwd_ops
             _call("dh_xattn_prep_bwd_stack_mfma", P(tok), P(dtok_accum), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn),
@@ -1271,10 +1289,11 @@ def xattn_prep_bwd(prep, tok, dtok_accum, ln_g, wqT, wk, wv, wo, dkq, dvoT, dln_
     if getattr(prep, "mfma", False):
         wq0, woT, wkT, wvT = prep._bwd_ops
         ws = workspace(Lb.dh_xattn_prep_bwd_stack_workspace_size(Sn, L, 1), tok.device)
-        _call("dh_xattn_prep_bwd_stack_mfma", P(tok), P(dtok_accum), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(heads),
-              _ci(dim_head), _ci(prep.HLP), _cf(prep.scale), _ci(1), _cl(0), P(ln_g), P(wq0), P(woT), P(wkT), P(wvT),
-              P(prep.mn), P(prep.mstats), P(prep.k), P(prep.v), P(dkq), P(dvoT), P(dk), P(dv), P(dln_g), P(dln_b), P(dwq),
-              P(dwk), P(dwv), P(dwo), _ci(int(accumulate)), P(ws), S())
+        with _XprepPaused():
+            _call("dh_xattn_prep_bwd_stack_mfma", P(tok), P(dtok_accum), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn), _ci(heads),
+                  _ci(dim_head), _ci(prep.HLP), _cf(prep.scale), _ci(1), _cl(0), P(ln_g), P(wq0), P(woT), P(wkT), P(wvT),
+                  P(prep.mn), P(prep.mstats), P(prep.k), P(prep.v), P(dkq), P(dvoT), P(dk), P(dv), P(dln_g), P(dln_b), P(dwq),
+                  P(dwk), P(dwv), P(dwo), _ci(int(accumulate)), P(ws), S())
         return
     ws = workspace(Lb.dh_xattn_prep_bwd_workspace_size(Sn), tok.device)
     _call("dh_xattn_prep_bwd", _ci(_DT[dtype]), P(tok), P(dtok_accum), _cl(bstride), _cl(sstride), _ci(B), _ci(Sn),
@@ -1399,6 +1418,25 @@ def encoder_bwd(dy, xs, B, n, depth, heads, dim_head, mlp, pstride, params, grad
 
 _ENC_BATCH = None        # while an EncoderBatch is open: the tensors of the recorded launches
 _DEC_BATCH = None        # ... and of its recorded decoder layers
+_XPREP_BATCH = None      # ... and of its recorded cross-attention preparations (their own workspaces, dk / dv)
+
+
+def xprep_recording():
+    """True while XattnPrepStack launches are only recorded: their results are valid after the EncoderBatch's next launch()"""
+    return _XPREP_BATCH is not None
+
+
+class _XprepPaused:
+    """the single-layer preparation calls launch at once even inside an open batch (their callers read the result next)"""
+
+    def __enter__(self):
+        if _XPREP_BATCH is not None:
+            _lib.lib().dh_xprep_batch_pause(1)
+
+    def __exit__(self, *exc):
+        if _XPREP_BATCH is not None:
+            _lib.lib().dh_xprep_batch_pause(0)
+        return False
 
 
 class EncoderBatch:
@@ -1411,30 +1449,49 @@ class EncoderBatch:
         (dh_decoder_batch_*): layers of independent stacks share a launch.  DAHITRA_DEC_BATCH=0 switches that part off."""
         self.on = PROFILE is None and os.environ.get("DAHITRA_ENC_BATCH", "1") != "0"
         self.dec = decoder and PROFILE is None and os.environ.get("DAHITRA_DEC_BATCH", "1") != "0"
+        # with the decoder stacks, their token-side preparation (XattnPrepStack and its backward, dh_xprep_batch_*) and the
+        # stack's parameter-gradient finalize are recorded as well.  DAHITRA_XPREP_BATCH=0 switches that part off.
+        self.xprep = self.dec and os.environ.get("DAHITRA_XPREP_BATCH", "1") != "0"
 
     def __enter__(self):
-        global _ENC_BATCH, _DEC_BATCH
+        global _ENC_BATCH, _DEC_BATCH, _XPREP_BATCH
         if self.on or self.dec:
-            assert _ENC_BATCH is None and _DEC_BATCH is None, "EncoderBatch is not re-entrant"
+            assert _ENC_BATCH is None and _DEC_BATCH is None and _XPREP_BATCH is None, "EncoderBatch is not re-entrant"
         if self.on:
             _ENC_BATCH = []
             _call("dh_encoder_batch_begin")
         if self.dec:
             _DEC_BATCH = []
             _call("dh_decoder_batch_begin")
+        if self.xprep:
+            _XPREP_BATCH = []
+            _call("dh_xprep_batch_begin")
         return self
 
     def launch(self):
+        """program order of what one round may have recorded: a stack's preparation before its forward; a stack's finalize
+        (which the decoder batch issues after its backward launches) before the preparation's backward"""
+        if self.xprep:
+            _call("dh_xprep_batch_launch_fwd", S())
         if self.on:
             _call("dh_encoder_batch_launch", S())
             del _ENC_BATCH[:]
         if self.dec:
             _call("dh_decoder_batch_launch", S())
             del _DEC_BATCH[:]
+        if self.xprep:
+            _call("dh_xprep_batch_launch_bwd", S())
+            del _XPREP_BATCH[:]
 
     def __exit__(self, *exc):
-        global _ENC_BATCH, _DEC_BATCH
+        global _ENC_BATCH, _DEC_BATCH, _XPREP_BATCH
         failed = bool(exc) and exc[0] is not None
+        if self.xprep:
+            if failed:
+                _lib.lib().dh_xprep_batch_abort()
+                _XPREP_BATCH = None
+            else:
+                _call("dh_xprep_batch_launch_fwd", S())
         if self.on:
             if failed:
                 _lib.lib().dh_encoder_batch_abort()
@@ -1447,6 +1504,9 @@ class EncoderBatch:
             else:
                 _call("dh_decoder_batch_end", S())
             _DEC_BATCH = None
+        if self.xprep and not failed:
+            _call("dh_xprep_batch_end", S())      # after the decoder batch: a pending finalize precedes the preparation's backward
+            _XPREP_BATCH = None
         return False
 
 

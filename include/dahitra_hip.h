@@ -411,6 +411,21 @@ int dh_decoder_batch_pending(void);
 int dh_decoder_batch_launch(void* stream);
 int dh_decoder_batch_end(void* stream);
 int dh_decoder_batch_abort(void);
+/* And for the cross-attention operand preparation of a decoder stack (csrc/tokens.hip; models/help_funcs.py:118-160, the
+ * token side of Cross_Attention): between _begin and _end, dh_xattn_prep_fwd_stack_mfma and dh_xattn_prep_bwd_stack_mfma with
+ * dim_head 64 only RECORD (up to four each).  _launch_fwd issues the recorded preparations as ONE launch; _launch_bwd the
+ * recorded gradients as one launch per kernel of the family (operand gradients, token-gradient reduction, projection weight
+ * gradients, LayerNorm gradients).  A recorded backward needs a workspace and dk / dv of its OWN until then.
+ * dh_decoder_stack_bwd_finalize is recorded by the decoder batch in the same way and issued after its backward launches, so
+ * the order `dh_xprep_batch_launch_fwd, dh_decoder_batch_launch, dh_xprep_batch_launch_bwd` is right for calls recorded
+ * in program order.  _pause(1): calls launch at once although a batch is open; _pause(0) records again. */
+int dh_xprep_batch_begin(void);
+int dh_xprep_batch_pending(void);
+int dh_xprep_batch_pause(int paused);
+int dh_xprep_batch_launch_fwd(void* stream);
+int dh_xprep_batch_launch_bwd(void* stream);
+int dh_xprep_batch_end(void* stream);
+int dh_xprep_batch_abort(void);
 long dh_encoder_bwd_workspace_size(int B, int n, int depth, int heads, int dim_head, int mlp);
 /* floats of `saved_inputs` (non-null in training): per (layer, image) the forward's intermediates -- layer input, LayerNorm
  * outputs and statistics, qkv, attention probabilities and output, MLP activations -- which dh_encoder_bwd reads back

@@ -186,7 +186,9 @@ def test_staged_levels_advance_in_rounds_and_launch_between_them(monkeypatch):
         return name.upper()
 
     monkeypatch.setattr(ops, "EncoderBatch", FakeBatch)
-    out = engine.Engine._run_staged([level("a", 1), level("b", 3), level("c", 0)])
+    import types
+    host = types.SimpleNamespace(level_streams=False, _lstreams=[])          # the two attributes the method reads
+    out = engine.Engine._run_staged(host, [level("a", 1), level("b", 3), level("c", 0)])
     assert out == ["A", "B", "C"]
     assert log == [("open", True), ("a", 0), ("b", 0), "launch", ("b", 1), "launch", ("b", 2), "launch", "launch", "close"]
     # the real batch object on a machine without a GPU: opening it and leaving it through an exception are host-side state only
@@ -195,10 +197,11 @@ def test_staged_levels_advance_in_rounds_and_launch_between_them(monkeypatch):
     lib = _lib.lib()
     with pytest.raises(ZeroDivisionError):
         with ops.EncoderBatch(decoder=True):
-            assert ops._ENC_BATCH == [] and ops._DEC_BATCH == []
+            assert ops._ENC_BATCH == [] and ops._DEC_BATCH == [] and ops._XPREP_BATCH == [] and ops.xprep_recording()
             assert lib.dh_encoder_batch_pending() == 0 and lib.dh_decoder_batch_pending() == 0
+            assert lib.dh_xprep_batch_pending() == 0
             1 / 0
-    assert ops._ENC_BATCH is None and ops._DEC_BATCH is None
+    assert ops._ENC_BATCH is None and ops._DEC_BATCH is None and ops._XPREP_BATCH is None and not ops.xprep_recording()
     # engine._drain: a staged generator run straight through
     assert engine._drain(level("d", 2)) == "D"
 

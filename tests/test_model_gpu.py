@@ -670,6 +670,29 @@ def test_fused_token_encoder_equals_layerwise_kernels(name, dtype, monkeypatch):
             assert float((g0[k] - g1[k]).abs().max()) <= (1e-3 if dtype == "fp32" else 5e-2) * s + 1e-9, k
 
 
+def test_recorded_token_side_launches_equal_the_separate_ones(monkeypatch):
+    """the three levels' cross-attention operand preparations (forward, and the four kernels of their backward) and stack
+    finalizes issued as one launch per kernel (ops.EncoderBatch -> dh_xprep_batch_*, the held-back
+    dh_decoder_stack_bwd_finalize) against every level launching its own: the same workgroups on the same data --
+    bit-identical logits and gradients"""
+    from dahitra_amd.models import losses
+    name = "newUNetTrans"
+    a, b, lab = O.synthetic_batch(2, 256, seed=47)
+    res = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("DAHITRA_XPREP_BATCH", on)
+        net = make_net(name, "bf16").train()
+        y = net(a.cuda(), b.cuda())
+        losses.focal_loss(y, lab.cuda()).backward()
+        torch.cuda.synchronize()
+        res[on] = (y.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert torch.equal(res["0"][0], res["1"][0])
+    assert res["0"][1].keys() == res["1"][1].keys()
+    for k, g in res["0"][1].items():
+        assert torch.equal(g, res["1"][1][k]), k
+    assert any(float(g.abs().max()) > 0 for k, g in res["1"][1].items() if k.startswith("transformer_decoder"))
+
+
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_o5"])
 def test_ragged_shapes_match_oracle_fp32(name):
     """non-square input whose feature maps are not multiples of the kernel tiles (96x160: 24x40 / 12x20 maps, the
