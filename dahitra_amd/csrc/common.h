@@ -143,6 +143,39 @@ extern "C" void dh_set_error(const char* msg);
     } while (0)
 static inline int dh_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// out[i] (+)= scale * sum_t partial[t][i], t < nt, for the 32 outputs of (virtual) workgroup `bx`: 256 threads = 8 row phases x
+// 32 consecutive outputs (coalesced rows), fp64 accumulation in a fixed order.  reduce_partials_kernel (norm.hip) and the
+// batched tokenizer backward (tokens.hip) share it, so both give the same bits.
+__device__ __forceinline__ void dh_reduce_partials_body(const float* __restrict__ partial, long nt, long n, float scale,
+                                                        float* __restrict__ out, int accumulate, int bx, double (*red)[32]) {
+    const int lane = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    const long i = (long)bx * 32 + lane;
+    double s = 0.0;
+    if (i < n) {
+        // four independent partial sums: the row loop is otherwise one chain of dependent-latency loads
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        long t = ph;
+        for (; t + 24 < nt; t += 32) {
+            s += (double)partial[t * n + i];
+            s1 += (double)partial[(t + 8) * n + i];
+            s2 += (double)partial[(t + 16) * n + i];
+            s3 += (double)partial[(t + 24) * n + i];
+        }
+        for (; t < nt; t += 8) s += (double)partial[t * n + i];
+        s = (s + s1) + (s2 + s3);
+    }
+    red[ph][lane] = s;
+    __syncthreads();
+    if (ph == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][lane];
+        const float v = (float)(t * scale);
+        if (accumulate) out[i] += v; else out[i] = v;
+    }
+}
+
+
 // fp64 sum over a workgroup of whole wavefronts (<= 1024 threads); every thread must call it; the result is valid
 // in thread 0.  `sh` is a __shared__ double[16].
 __device__ __forceinline__ double dh_block_sum_f64(double v, double* sh) {

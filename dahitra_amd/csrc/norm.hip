@@ -444,31 +444,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, long nt, long n,
                                                               float scale, float* __restrict__ out, int accumulate) {
     __shared__ double red[8][32];
-    const int lane = threadIdx.x & 31, ph = threadIdx.x >> 5;
-    const long i = (long)blockIdx.x * 32 + lane;
-    double s = 0.0;
-    if (i < n) {
-        // four independent partial sums: the row loop is otherwise one chain of dependent-latency loads
-        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        long t = ph;
-        for (; t + 24 < nt; t += 32) {
-            s += (double)partial[t * n + i];
-            s1 += (double)partial[(t + 8) * n + i];
-            s2 += (double)partial[(t + 16) * n + i];
-            s3 += (double)partial[(t + 24) * n + i];
-        }
-        for (; t < nt; t += 8) s += (double)partial[t * n + i];
-        s = (s + s1) + (s2 + s3);
-    }
-    red[ph][lane] = s;
-    __syncthreads();
-    if (ph == 0 && i < n) {
-        double t = 0.0;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) t += red[r][lane];
-        const float v = (float)(t * scale);
-        if (accumulate) out[i] += v; else out[i] = v;
-    }
+    dh_reduce_partials_body(partial, nt, n, scale, out, accumulate, blockIdx.x, red);
 }
 inline void launch_reduce(const float* partial, long nt, long n, float scale, float* out, int accumulate,
                           hipStream_t st) {

@@ -320,6 +320,22 @@ __global__ void copy_channels16_kernel(const T* __restrict__ src, int Cs, int sc
     }
 }
 
+// both halves of torch.cat([t[:P], t[P:]], channel) in one launch: cat[p, h * C + c] = t[h * P + p, c] (INVERSE: the other
+// way round, the two batch halves of the concatenation's gradient); one 16-byte piece per lane
+template <typename T, bool INVERSE>
+__global__ void cat_halves_kernel(T* __restrict__ t, T* __restrict__ cat, int C, long P) {
+    constexpr int V = V16<T>::N;
+    const int vn = 2 * C / V;
+    GSL(i, P * vn) {
+        const long p = i / vn;
+        const int c2 = (int)(i % vn) * V, h = c2 >= C, c = c2 - h * C;
+        uint4* a = reinterpret_cast<uint4*>(t + (h * P + p) * C + c);
+        uint4* b = reinterpret_cast<uint4*>(cat + p * 2 * C + c2);
+        if (INVERSE) *a = *b;
+        else *b = *a;
+    }
+}
+
 // ---- y = a + b ------------------------------------------------------------------------------
 template <typename T>
 __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long nvec) {
@@ -1079,6 +1095,22 @@ extern "C" int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, voi
     else if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(copy_channels_kernel<bf16>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const bf16*)src, Cs, sc0, (bf16*)dst, Cd, dc0, Cn, P);
     else hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (const float*)src, Cs, sc0, (float*)dst, Cd, dc0, Cn, P);
     DH_CHECK_LAUNCH("copy_channels");
+    return 0;
+}
+// t: [2 P][C], cat: [P][2 C] (models/networks.py:1309, 1344: cat([x1, x2], 1) of the two temporal streams, which are the two
+// batch halves here).  inverse = 0: cat <- t; 1: t <- cat (the gradient's way back)
+extern "C" int dh_cat_halves(int dtype, void* t, void* cat, int C, long P, int inverse, void* stream) {
+    const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;
+    DH_REQUIRE(C % V == 0, "cat_halves: C=%d must be a multiple of %d", C, V);
+    const long n = P * (2 * C / V);
+    if (dtype == DH_DTYPE_BF16) {
+        if (inverse) hipLaunchKernelGGL((cat_halves_kernel<bf16, true>), dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (bf16*)t, (bf16*)cat, C, P);
+        else hipLaunchKernelGGL((cat_halves_kernel<bf16, false>), dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (bf16*)t, (bf16*)cat, C, P);
+    } else {
+        if (inverse) hipLaunchKernelGGL((cat_halves_kernel<float, true>), dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (float*)t, (float*)cat, C, P);
+        else hipLaunchKernelGGL((cat_halves_kernel<float, false>), dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), (float*)t, (float*)cat, C, P);
+    }
+    DH_CHECK_LAUNCH("cat_halves");
     return 0;
 }
 extern "C" int dh_add(int dtype, const void* a, const void* b, void* y, long n, void* stream) {

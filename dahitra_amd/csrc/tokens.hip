@@ -31,13 +31,35 @@ __device__ __forceinline__ float quad_sum(float v) {       // over the 4 lanes o
 // ------------------------------------------------------------------------------------------
 // tokenizer
 // ------------------------------------------------------------------------------------------
+// One tokenizer call (forward: stages 0-3, backward: stages 4-7), by value in the launch: the stages are body functions of
+// (job, virtual block index), launched through tok_multi_kernel for one call or for the recorded calls of several independent
+// levels (dh_xprep_batch_*: DAHiTra's three levels tokenize 64 images each -- 12 + 12 launches of a few dozen workgroups).
+struct TokJob {
+    const void* x;                       // [S*HW][32]
+    const float *wa, *pos;               // [L][32]; [2L][32] or null
+    float *logits, *stats, *pooled;      // [S*HW][L], [S][L][2], [S][L][32]: written forward, read backward
+    float *tok_cat, *part;               // forward: [B][2L][32]; partial pooled sums [S][nch][L*32]
+    const float* dtok_cat;               // backward
+    void* dx;
+    float *dlogits, *partial, *dwa, *dpos;
+    long P;
+    int S, B, HW, nch, chunk, nblk, accumulate;
+};
+constexpr int TB_MAXJ = 4;
+struct TokMulti {
+    int n;
+    int first[TB_MAXJ + 1];
+    TokJob j[TB_MAXJ];
+};
+constexpr int TOK_DWA_CHUNK = 1024;      // pixel rows per tok_dwa workgroup (16 per thread)
+
 template <typename T, int L>
-__global__ void tok_logits_kernel(const T* __restrict__ x, const float* __restrict__ wa, float* __restrict__ logits,
-                                  long P) {
+__device__ __forceinline__ void tok_logits_body(const T* __restrict__ x, const float* __restrict__ wa, float* __restrict__ logits,
+                                                long P, int bx) {
     __shared__ float w[L * D];
-    for (int i = threadIdx.x; i < L * D; i += blockDim.x) w[i] = wa[i];
+    for (int i = threadIdx.x; i < L * D; i += 256) w[i] = wa[i];
     __syncthreads();
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long p = (long)bx * 256 + threadIdx.x;
     if (p >= P) return;
     float acc[L];
 #pragma unroll
@@ -57,10 +79,10 @@ __global__ void tok_logits_kernel(const T* __restrict__ x, const float* __restri
 
 // softmax statistics over the HW pixels of one (image, token): one 256-thread workgroup each
 template <int L>
-__global__ __launch_bounds__(256) void tok_stats_kernel(const float* __restrict__ logits, int HW,
-                                                        float* __restrict__ stats /*[S][L][2]*/) {
+__device__ __forceinline__ void tok_stats_body(const float* __restrict__ logits, int HW, float* __restrict__ stats /*[S][L][2]*/,
+                                               int bx) {
     __shared__ float red[4];
-    const int s = blockIdx.x / L, l = blockIdx.x % L, tid = threadIdx.x;
+    const int s = bx / L, l = bx % L, tid = threadIdx.x;
     const float* lg = logits + (size_t)s * HW * L + l;
     float m = -INFINITY;
     for (int n = tid; n < HW; n += 256) m = fmaxf(m, lg[(size_t)n * L]);
@@ -75,8 +97,8 @@ __global__ __launch_bounds__(256) void tok_stats_kernel(const float* __restrict_
     if ((tid & 63) == 0) red[tid >> 6] = e;
     __syncthreads();
     if (tid == 0) {
-        stats[(size_t)blockIdx.x * 2 + 0] = m;
-        stats[(size_t)blockIdx.x * 2 + 1] = 1.f / (red[0] + red[1] + red[2] + red[3]);
+        stats[(size_t)bx * 2 + 0] = m;
+        stats[(size_t)bx * 2 + 1] = 1.f / (red[0] + red[1] + red[2] + red[3]);
     }
 }
 
@@ -135,30 +157,30 @@ __device__ __forceinline__ void weighted_colsum(const T* __restrict__ xs, long n
 
 // partial pooled sums over one chunk of pixels; grid (chunks, S), 256 threads
 template <typename T, int L>
-__global__ __launch_bounds__(256) void tok_pool_partial_kernel(const T* __restrict__ x, const float* __restrict__ logits,
-                                                               const float* __restrict__ stats, int HW, int chunk,
-                                                               float* __restrict__ partial /*[S][chunks][L*32]*/) {
-    __shared__ float red[32 * L * D];
-    const int s = blockIdx.y;
+__device__ __forceinline__ void tok_pool_partial_body(const T* __restrict__ x, const float* __restrict__ logits,
+                                                      const float* __restrict__ stats, int HW, int chunk, int nch,
+                                                      float* __restrict__ partial /*[S][chunks][L*32]*/, int bx, int by, float* red) {
+    const int s = by;
     const float* lg = logits + (size_t)s * HW * L;
     float mx[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) mx[l] = stats[((size_t)s * L + l) * 2];
-    const int n0 = blockIdx.x * chunk, n1 = min(n0 + chunk, HW);
+    const int n0 = bx * chunk, n1 = min(n0 + chunk, HW);
     weighted_colsum<T, L>(x + (size_t)s * HW * D, n0, n1,
                           [&](long n, float (&wl)[L]) {
 #pragma unroll
                               for (int l = 0; l < L; ++l) wl[l] = __expf(lg[(size_t)n * L + l] - mx[l]);
                           },
-                          red, partial + ((size_t)s * gridDim.x + blockIdx.x) * (L * D));
+                          red, partial + ((size_t)s * nch + bx) * (L * D));
 }
 
 // combine chunks, normalise, add the learned positional embedding and place into [B][2L][32]
 template <typename T, int L>
-__global__ void tok_finish_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
-                                  const float* __restrict__ pos /*[2L][32] or null*/, int chunks, int B,
-                                  float* __restrict__ pooled, float* __restrict__ tok_cat) {
-    const int s = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void tok_finish_body(const float* __restrict__ partial, const float* __restrict__ stats,
+                                                const float* __restrict__ pos /*[2L][32] or null*/, int chunks, int B,
+                                                float* __restrict__ pooled, float* __restrict__ tok_cat, int bx) {
+    const int s = bx, tid = threadIdx.x;
+    if (tid >= L * D) return;                                // (launched with 256 threads)
     const int l = tid / D, c = tid % D;
     float acc = 0.f;
     for (int k = 0; k < chunks; ++k) acc += partial[((size_t)s * chunks + k) * (L * D) + tid];
@@ -171,17 +193,17 @@ __global__ void tok_finish_kernel(const float* __restrict__ partial, const float
 
 // per pixel: dlogit and the tokenizer's contribution to dx (accumulated into dx in place)
 template <typename T, int L>
-__global__ __launch_bounds__(256) void tok_bwd_kernel(const T* __restrict__ x, const float* __restrict__ logits,
-                                                      const float* __restrict__ stats, const float* __restrict__ pooled,
-                                                      const float* __restrict__ dtok_cat, const float* __restrict__ wa, int HW, int B,
-                                                      T* __restrict__ dx, float* __restrict__ dlogits) {
+__device__ __forceinline__ void tok_bwd_body(const T* __restrict__ x, const float* __restrict__ logits,
+                                             const float* __restrict__ stats, const float* __restrict__ pooled,
+                                             const float* __restrict__ dtok_cat, const float* __restrict__ wa, int HW, int B,
+                                             T* __restrict__ dx, float* __restrict__ dlogits, int bx, int by) {
     // FOUR lanes per pixel row, 8 channels (one 16-byte piece of x / dx for bf16) each: a wave's loads are 64 consecutive
     // pieces.  (One lane per pixel walked its 64-byte row with eight 8-byte loads 64 bytes apart: 34 us for 55 MB.)  The
     // channel dot products meet over the quad (DPP); every lane keeps its 8 channels of dtok / Wa in registers.
     __shared__ float sdt[L * D], sw[L * D], sdot[L], smx[L], siv[L];
-    const int s = blockIdx.y;
+    const int s = by;
     const int b = s % B, stream = s / B;
-    for (int i = threadIdx.x; i < L * D; i += blockDim.x) {
+    for (int i = threadIdx.x; i < L * D; i += 256) {
         sdt[i] = dtok_cat[((size_t)b * 2 * L + stream * L) * D + i];
         sw[i] = wa[i];
     }
@@ -194,7 +216,7 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(const T* __restrict__ x, c
         siv[threadIdx.x] = stats[((size_t)s * L + threadIdx.x) * 2 + 1];
     }
     __syncthreads();
-    const int q = threadIdx.x & 3, n = blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
+    const int q = threadIdx.x & 3, n = bx * 64 + (threadIdx.x >> 2);
     const bool live = n < HW;                            // (dead lanes keep running: the quad sums are DPP moves)
     const size_t row = (size_t)s * HW + (live ? n : 0);
     float dt[L][8], w[L][8];
@@ -244,25 +266,57 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(const T* __restrict__ x, c
 
 // partial dWa[l][c] = sum over a chunk of pixel rows of dlogits[p][l] * x[p][c] (weighted_colsum)
 template <typename T, int L>
-__global__ __launch_bounds__(256) void tok_dwa_kernel(const T* __restrict__ x, const float* __restrict__ dlogits, long P,
-                                                      long chunk, float* __restrict__ partial) {
-    __shared__ float red[32 * L * D];
-    const long p0 = (long)blockIdx.x * chunk, p1 = (p0 + chunk < P) ? p0 + chunk : P;
+__device__ __forceinline__ void tok_dwa_body(const T* __restrict__ x, const float* __restrict__ dlogits, long P, long chunk,
+                                             float* __restrict__ partial, int bx, float* red) {
+    const long p0 = (long)bx * chunk, p1 = (p0 + chunk < P) ? p0 + chunk : P;
     weighted_colsum<T, L>(x, p0, p1,
                           [&](long p, float (&wl)[L]) {
 #pragma unroll
                               for (int l = 0; l < L; ++l) wl[l] = dlogits[p * L + l];
                           },
-                          red, partial + (size_t)blockIdx.x * (L * D));
+                          red, partial + (size_t)bx * (L * D));
 }
 
 // dpos[j][c] (+)= sum_b dtok_cat[b][j][c]
-__global__ void tok_dpos_kernel(const float* __restrict__ dtok_cat, int B, int n, float* __restrict__ dpos, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void tok_dpos_body(const float* __restrict__ dtok_cat, int B, int n, float* __restrict__ dpos,
+                                              int accumulate, int bx) {
+    const int i = bx * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
     for (int b = 0; b < B; ++b) s += dtok_cat[(size_t)b * n + i];
     if (accumulate) dpos[i] += s; else dpos[i] = s;
+}
+
+// workgroups of stage STAGE that job `a` needs
+template <int L> __host__ __device__ inline int tok_stage_blocks(const TokJob& a, int stage) {
+    switch (stage) {
+        case 0: return (int)((a.P + 255) / 256);            // logits
+        case 1: return a.S * L;                             // softmax statistics
+        case 2: return a.nch * a.S;                         // partial pooled sums
+        case 3: return a.S;                                 // finish
+        case 4: return ((a.HW + 63) / 64) * a.S;            // dlogits, dx
+        case 5: return a.nblk;                              // dWa partials
+        case 6: return a.dpos ? (2 * L * 32 + 255) / 256 : 0;
+        default: return (L * 32 + 31) / 32;                 // dWa reduction
+    }
+}
+template <typename T, int L, int STAGE>
+__global__ __launch_bounds__(256) void tok_multi_kernel(TokMulti m) {
+    __shared__ __attribute__((aligned(16))) float red[(STAGE == 2 || STAGE == 5) ? 32 * L * D : (STAGE == 7 ? 8 * 32 * 2 : 1)];
+    int j = 0;
+    while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
+    const TokJob& a = m.j[j];
+    const int local = (int)blockIdx.x - m.first[j];
+    if constexpr (STAGE == 0) tok_logits_body<T, L>((const T*)a.x, a.wa, a.logits, a.P, local);
+    else if constexpr (STAGE == 1) tok_stats_body<L>(a.logits, a.HW, a.stats, local);
+    else if constexpr (STAGE == 2) tok_pool_partial_body<T, L>((const T*)a.x, a.logits, a.stats, a.HW, a.chunk, a.nch, a.part, local % a.nch, local / a.nch, red);
+    else if constexpr (STAGE == 3) tok_finish_body<T, L>(a.part, a.stats, a.pos, a.nch, a.B, a.pooled, a.tok_cat, local);
+    else if constexpr (STAGE == 4) {
+        const int gx = (a.HW + 63) / 64;
+        tok_bwd_body<T, L>((const T*)a.x, a.logits, a.stats, a.pooled, a.dtok_cat, a.wa, a.HW, a.B, (T*)a.dx, a.dlogits, local % gx, local / gx);
+    } else if constexpr (STAGE == 5) tok_dwa_body<T, L>((const T*)a.x, a.dlogits, a.P, (long)TOK_DWA_CHUNK, a.partial, local, red);
+    else if constexpr (STAGE == 6) tok_dpos_body(a.dtok_cat, a.B, 2 * L * 32, a.dpos, a.accumulate, local);
+    else dh_reduce_partials_body(a.partial, a.nblk, (long)L * 32, 1.0f, a.dwa, a.accumulate, local, reinterpret_cast<double(*)[32]>(red));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1133,32 +1187,66 @@ extern "C" int dh_reduce_partials(const float* partial, long nt, long n, float s
 // logits [S*HW][L] fp32, stats [S][L][2], pooled [S][L][32] are saved for backward
 static inline int tok_chunks(int HW) { int c = HW / 1024; return c < 1 ? 1 : (c > 64 ? 64 : c); }      // 1024 rows per workgroup
 extern "C" long dh_tokenizer_fwd_workspace_size(int S, int HW, int L) { return (long)S * tok_chunks(HW) * L * 32 * 4; }
+
+// recorded tokenizer calls (dh_xprep_batch_*: same switch as the cross-attention preparation).  One batch holds calls of ONE
+// (dtype, token_len): a call of another kind issues what is recorded first.
+struct TokBatch {
+    int nf = 0, nb = 0, dtype_f = 0, L_f = 0, dtype_b = 0, L_b = 0;
+    TokJob f[TB_MAXJ], b[TB_MAXJ];
+};
+static thread_local TokBatch g_tb;
+template <typename T, int L, int STAGE> static void tok_launch_stage(const TokJob* jobs, int n, hipStream_t st) {
+    TokMulti m;
+    m.n = n;
+    m.first[0] = 0;
+    for (int j = 0; j < n; ++j) { m.j[j] = jobs[j]; m.first[j + 1] = m.first[j] + tok_stage_blocks<L>(jobs[j], STAGE); }
+    if (m.first[n] > 0) hipLaunchKernelGGL((tok_multi_kernel<T, L, STAGE>), dim3(m.first[n]), dim3(256), 0, st, m);
+}
+template <typename T, int L> static void tok_launch_fwd(const TokJob* jobs, int n, hipStream_t st) {
+    tok_launch_stage<T, L, 0>(jobs, n, st);
+    tok_launch_stage<T, L, 1>(jobs, n, st);
+    tok_launch_stage<T, L, 2>(jobs, n, st);
+    tok_launch_stage<T, L, 3>(jobs, n, st);
+}
+template <typename T, int L> static void tok_launch_bwd(const TokJob* jobs, int n, hipStream_t st) {
+    tok_launch_stage<T, L, 4>(jobs, n, st);
+    tok_launch_stage<T, L, 5>(jobs, n, st);
+    tok_launch_stage<T, L, 6>(jobs, n, st);
+    tok_launch_stage<T, L, 7>(jobs, n, st);
+}
+static int tok_issue(bool fwd, int dtype, int L, const TokJob* jobs, int n, hipStream_t st) {
+    if (!n) return 0;
+#define TOKGO(TT, LL) do { if (fwd) tok_launch_fwd<TT, LL>(jobs, n, st); else tok_launch_bwd<TT, LL>(jobs, n, st); } while (0)
+    if (dtype == DH_DTYPE_BF16) { if (L == 4) TOKGO(bf16, 4); else TOKGO(bf16, 8); }
+    else { if (L == 4) TOKGO(float, 4); else TOKGO(float, 8); }
+#undef TOKGO
+    DH_CHECK_LAUNCH(fwd ? "tokenizer_fwd" : "tokenizer_bwd");
+    return 0;
+}
+static int tok_flush_fwd(hipStream_t st) { const int n = g_tb.nf; g_tb.nf = 0; return tok_issue(true, g_tb.dtype_f, g_tb.L_f, g_tb.f, n, st); }
+static int tok_flush_bwd(hipStream_t st) { const int n = g_tb.nb; g_tb.nb = 0; return tok_issue(false, g_tb.dtype_b, g_tb.L_b, g_tb.b, n, st); }
+static bool xprep_recording();
+
 extern "C" int dh_tokenizer_fwd(int dtype, const void* x, const float* wa, const float* pos, int S, int B, int HW,
                                 int L, float* logits, float* stats, float* pooled, float* tok_cat, void* workspace,
                                 void* stream) {
     DH_REQUIRE(L == 4 || L == 8, "tokenizer: token_len must be 4 or 8, got %d", L);
     DH_REQUIRE(S % B == 0 && S / B <= 2, "tokenizer: S=%d must be B or 2B (B=%d)", S, B);
-    const long P = (long)S * HW;
-    const int nch = tok_chunks(HW), chunk = dh_cdiv(HW, nch);
-    float* part = reinterpret_cast<float*>(workspace);
-#define TOKF(TT, LL)                                                                                              \
-    do {                                                                                                          \
-        hipLaunchKernelGGL((tok_logits_kernel<TT, LL>), dim3(dh_cdiv(P, 256)), dim3(256), 0, ST(stream),          \
-                           (const TT*)x, wa, logits, P);                                                          \
-        hipLaunchKernelGGL((tok_stats_kernel<LL>), dim3(S * LL), dim3(256), 0, ST(stream), logits, HW, stats);     \
-        hipLaunchKernelGGL((tok_pool_partial_kernel<TT, LL>), dim3(nch, S), dim3(256), 0, ST(stream),             \
-                           (const TT*)x, logits, stats, HW, chunk, part);                                         \
-        hipLaunchKernelGGL((tok_finish_kernel<TT, LL>), dim3(S), dim3(LL * 32), 0, ST(stream), part, stats, pos,  \
-                           nch, B, pooled, tok_cat);                                                         \
-    } while (0)
-    if (dtype == DH_DTYPE_BF16) { if (L == 4) TOKF(bf16, 4); else TOKF(bf16, 8); }
-    else { if (L == 4) TOKF(float, 4); else TOKF(float, 8); }
-#undef TOKF
-    DH_CHECK_LAUNCH("tokenizer_fwd");
-    return 0;
+    TokJob a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.wa = wa; a.pos = pos; a.logits = logits; a.stats = stats; a.pooled = pooled; a.tok_cat = tok_cat;
+    a.part = reinterpret_cast<float*>(workspace);
+    a.P = (long)S * HW; a.S = S; a.B = B; a.HW = HW; a.nch = tok_chunks(HW); a.chunk = dh_cdiv(HW, a.nch);
+    if (xprep_recording()) {            // issued with the other levels' calls by dh_xprep_batch_launch_fwd
+        if (g_tb.nf && (g_tb.nf == TB_MAXJ || g_tb.dtype_f != dtype || g_tb.L_f != L)) { const int rc = tok_flush_fwd(ST(stream)); if (rc) return rc; }
+        g_tb.dtype_f = dtype; g_tb.L_f = L;
+        g_tb.f[g_tb.nf++] = a;
+        return 0;
+    }
+    return tok_issue(true, dtype, L, &a, 1, ST(stream));
 }
 
-// workspace: dlogits [S*HW][L] floats + partial [nblk][L*32] floats, nblk = ceil(S*HW / 256)
+// workspace: dlogits [S*HW][L] floats + partial [nblk][L*32] floats, nblk = ceil(S*HW / 1024)
 extern "C" long dh_tokenizer_bwd_workspace_size(int S, int HW, int L) {
     const long P = (long)S * HW;
     return (P * L + (long)dh_cdiv(P, 256) * L * 32) * 4;
@@ -1168,27 +1256,21 @@ extern "C" int dh_tokenizer_bwd(int dtype, const void* x, const float* wa, int S
                                 void* dx_accum, float* dwa, float* dpos, int accumulate, void* workspace,
                                 void* stream) {
     DH_REQUIRE(L == 4 || L == 8, "tokenizer_bwd: token_len must be 4 or 8, got %d", L);
-    const long P = (long)S * HW;
-    float* dlogits = reinterpret_cast<float*>(workspace);
-    float* partial = dlogits + P * L;
-    constexpr int DWA_CHUNK = 1024;                       // pixel rows per tok_dwa workgroup (16 per thread)
-    const int nblk = dh_cdiv(P, DWA_CHUNK);
-#define TOKB(TT, LL)                                                                                              \
-    do {                                                                                                          \
-        hipLaunchKernelGGL((tok_bwd_kernel<TT, LL>), dim3(dh_cdiv(HW, 64), S), dim3(256), 0, ST(stream),          \
-                           (const TT*)x, logits, stats, pooled, dtok_cat, wa, HW, B, (TT*)dx_accum,              \
-                           dlogits);                                                                              \
-        hipLaunchKernelGGL((tok_dwa_kernel<TT, LL>), dim3(nblk), dim3(256), 0, ST(stream), (const TT*)x, dlogits, \
-                           P, (long)DWA_CHUNK, partial);                                                          \
-        if (dpos)                                                                                                 \
-            hipLaunchKernelGGL(tok_dpos_kernel, dim3(dh_cdiv(2 * LL * 32, 64)), dim3(64), 0, ST(stream),          \
-                               dtok_cat, B, 2 * LL * 32, dpos, accumulate);                                       \
-    } while (0)
-    if (dtype == DH_DTYPE_BF16) { if (L == 4) TOKB(bf16, 4); else TOKB(bf16, 8); }
-    else { if (L == 4) TOKB(float, 4); else TOKB(float, 8); }
-#undef TOKB
-    DH_CHECK_LAUNCH("tokenizer_bwd");
-    return dh_reduce_partials(partial, nblk, (long)L * 32, 1.0f, dwa, accumulate, stream);
+    TokJob a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.wa = wa; a.logits = const_cast<float*>(logits); a.stats = const_cast<float*>(stats); a.pooled = const_cast<float*>(pooled);
+    a.dtok_cat = dtok_cat; a.dx = dx_accum; a.dwa = dwa; a.dpos = dpos; a.accumulate = accumulate;
+    a.P = (long)S * HW; a.S = S; a.B = B; a.HW = HW;
+    a.dlogits = reinterpret_cast<float*>(workspace);
+    a.partial = a.dlogits + a.P * L;
+    a.nblk = dh_cdiv(a.P, TOK_DWA_CHUNK);
+    if (xprep_recording()) {            // issued with the other levels' calls by dh_xprep_batch_launch_bwd
+        if (g_tb.nb && (g_tb.nb == TB_MAXJ || g_tb.dtype_b != dtype || g_tb.L_b != L)) { const int rc = tok_flush_bwd(ST(stream)); if (rc) return rc; }
+        g_tb.dtype_b = dtype; g_tb.L_b = L;
+        g_tb.b[g_tb.nb++] = a;
+        return 0;
+    }
+    return tok_issue(false, dtype, L, &a, 1, ST(stream));
 }
 
 // layers > 1: one launch prepares every layer of a decoder stack (same tokens): parameters ln_g / ln_b / wq (forward),
@@ -1223,6 +1305,7 @@ struct XprepBatch {
 static thread_local XprepBatch g_xb;
 extern "C" int dh_decoder_batch_pending();                // csrc/decoder_fused.hip
 extern "C" int dh_decoder_batch_launch(void* stream);
+static bool xprep_recording() { return g_xb.on && !g_xb.paused; }
 static int xprep_flush_fwd(hipStream_t st) {
     XprepBatch& b = g_xb;
     if (b.fwd.n) {
@@ -1258,15 +1341,21 @@ static int xprep_flush_bwd(hipStream_t st) {
     DH_CHECK_LAUNCH("xprep_batch_bwd");
     return 0;
 }
-static void xprep_clear() { g_xb.fwd.n = g_xb.bwd.n = g_xb.dtok.n = g_xb.wg_mfma.n = g_xb.wg_ln.n = 0; }
+static void xprep_clear() { g_xb.fwd.n = g_xb.bwd.n = g_xb.dtok.n = g_xb.wg_mfma.n = g_xb.wg_ln.n = 0; g_tb.nf = g_tb.nb = 0; }
 extern "C" int dh_xprep_batch_begin() { g_xb.on = true; g_xb.paused = false; xprep_clear(); return 0; }
 extern "C" int dh_xprep_batch_pause(int paused) { g_xb.paused = paused != 0; return 0; }
-extern "C" int dh_xprep_batch_pending() { return g_xb.fwd.n + g_xb.bwd.n + g_xb.dtok.n + g_xb.wg_mfma.n + g_xb.wg_ln.n; }
-extern "C" int dh_xprep_batch_launch_fwd(void* stream) { return xprep_flush_fwd(ST(stream)); }
-extern "C" int dh_xprep_batch_launch_bwd(void* stream) { return xprep_flush_bwd(ST(stream)); }
+extern "C" int dh_xprep_batch_pending() { return g_xb.fwd.n + g_xb.bwd.n + g_xb.dtok.n + g_xb.wg_mfma.n + g_xb.wg_ln.n + g_tb.nf + g_tb.nb; }
+extern "C" int dh_xprep_batch_launch_fwd(void* stream) {
+    const int rc = tok_flush_fwd(ST(stream));
+    return rc ? rc : xprep_flush_fwd(ST(stream));
+}
+extern "C" int dh_xprep_batch_launch_bwd(void* stream) {
+    const int rc = xprep_flush_bwd(ST(stream));
+    return rc ? rc : tok_flush_bwd(ST(stream));
+}
 extern "C" int dh_xprep_batch_end(void* stream) {
-    int rc = xprep_flush_fwd(ST(stream));
-    if (!rc) rc = xprep_flush_bwd(ST(stream));
+    int rc = dh_xprep_batch_launch_fwd(stream);
+    if (!rc) rc = dh_xprep_batch_launch_bwd(stream);
     g_xb.on = false;
     return rc;
 }

@@ -523,6 +523,7 @@ class Engine:
         fused = self._encoder_fused(tok, pfx, depth, heads, dim_head, B, n) if self.fused_encoder else None
         if fused is not None:
             return fused
+        ops.flush_recorded_tokens()          # (staged levels) the layer-wise kernels below launch at once
         x = tok
         bw = []
         for i in range(depth):
@@ -1024,6 +1025,15 @@ class Engine:
         return logits, bwd
 
     # hierarchical model -------------------------------------------------------------------------
+    def _zeros_like(self, t):
+        """zeros of t's shape (fp32): a slice of the pool _unet zeroed with one launch while it lasts, else torch.zeros_like"""
+        zp, n = getattr(self, "_zpool", None), t.numel()
+        if zp is not None and t.dtype == torch.float32 and zp[1] + n <= zp[0].numel():
+            out = zp[0][zp[1]:zp[1] + n].view(t.shape)
+            zp[1] += (n + 63) // 64 * 64
+            return out
+        return torch.zeros_like(t)
+
     def _run_staged(self, gens):
         """GENERATORS that pause right after every token-encoder call and every fused decoder stack (forward: `_level`;
         backward: the `bwd` it returns).  They run in rounds inside one ops.EncoderBatch: the launches they reach are only
@@ -1076,7 +1086,7 @@ class Engine:
         tok2d, b_enc = self.encoder(tok_cat.view(B * 2 * L, DIM), "transformer_%d" % l, self.cfg["enc_depth"],
                                     lv["heads"], lv["dim_head"], B, 2 * L)
         yield                       # tok2d is valid from here on (_run_staged)
-        dtok = torch.zeros_like(tok2d) if self.need_grad else None
+        dtok = self._zeros_like(tok2d) if self.need_grad else None
         pos = self.p["pos_embedding_decoder_%d" % l]
         dp = "transformer_decoder_%d" % l
         xin = ops.add_pos(sq, pos)
@@ -1084,13 +1094,11 @@ class Engine:
                                                   lv["dec_depth"], lv["heads"], lv["dim_head"], L)
         dec4 = dec.view(S2, fh, fw, DIM)
         # third pass: decoder(conv_decode(cat[x1, x2]), |tok2 - tok1|) with the SAME weights
-        cat = torch.empty(B, fh, fw, 2 * DIM, dtype=self.dtype, device=sq.device)
-        ops.copy_channels(dec4[:B], 0, cat, 0, DIM)
-        ops.copy_channels(dec4[B:], 0, cat, DIM, DIM)
+        cat = ops.cat_halves(dec4)
         tk3 = tok2d.view(B, 2, L * DIM)                      # [b][stream][L*32]
         dtk = torch.empty(B, L, DIM, dtype=torch.float32, device=sq.device)
         ops.absdiff_halves(tk3, dtk)
-        ddtk = torch.zeros_like(dtk) if self.need_grad else None
+        ddtk = self._zeros_like(dtk) if self.need_grad else None
         dxc, b_cd = self.conv_act(cat, "conv_decode_%d.weight" % l, None, 3, 1, NONE)
         xin3 = ops.add_pos(dxc, pos)
         out, b_dec3 = yield from self._decoder_gen(xin3.view(B * hw, DIM), B, dtk.view(B * L, DIM), L * DIM, 0, B, ddtk, dp,
@@ -1105,15 +1113,14 @@ class Engine:
             ops.add_pos_bwd(dxin3, gpos, accumulate=True)
             dcat = b_cd(dxin3)
             ops.absdiff_halves_bwd(tk3, ddtk, dtok)                    # accumulates into both token halves
-            ddec = torch.empty_like(dec4)
-            ops.copy_channels(dcat, 0, ddec[:B], 0, DIM)
-            ops.copy_channels(dcat, DIM, ddec[B:], 0, DIM)
+            ddec = ops.split_halves(dcat)
             dxin = (yield from b_dec(ddec.view(S2 * hw, DIM))).view(S2, fh, fw, DIM)
             ops.add_pos_bwd(dxin, gpos, accumulate=True)
             dtok_cat = b_enc(dtok)
             yield                   # dtok_cat is valid from here on (_run_staged)
             ops.tokenizer_bwd(sq, wa, tsaved, dtok_cat, dxin, self.g["conv_token_%d.weight" % l],
                               self.g["pos_embedding_%d" % l], B, L, accumulate=True)
+            yield                   # (may only be recorded) dxin is complete from here on
             return b_sq(dxin)
         return out4, bwd
 
@@ -1135,10 +1142,8 @@ class Engine:
         tk3 = tok2d.view(B, 2, L * DIM)
         dtk = torch.empty(B, L, DIM, dtype=torch.float32, device=sq.device)
         ops.absdiff_halves(tk3, dtk)
-        ddtk = torch.zeros_like(dtk) if self.need_grad else None
-        cat = torch.empty(B, fh, fw, 2 * DIM, dtype=self.dtype, device=sq.device)
-        ops.copy_channels(sq[:B], 0, cat, 0, DIM)
-        ops.copy_channels(sq[B:], 0, cat, DIM, DIM)
+        ddtk = self._zeros_like(dtk) if self.need_grad else None
+        cat = ops.cat_halves(sq)
         dxc, b_cd = self.conv_act(cat, "conv_decode_%d.weight" % l, None, 3, 1, NONE)
         pos = self.p["pos_embedding_decoder_3"] if (with_pos and self.cfg["decoder_pos"]) else None
         xin = ops.add_pos(dxc, pos) if pos is not None else dxc
@@ -1157,12 +1162,11 @@ class Engine:
             ops.absdiff_halves_bwd(tk3, ddtk, dtok)
             dtok_cat = b_enc(dtok)
             yield                   # dtok_cat is valid from here on (_run_staged)
-            dsq = torch.empty_like(sq)
-            ops.copy_channels(dcat, 0, dsq[:B], 0, DIM)
-            ops.copy_channels(dcat, DIM, dsq[B:], 0, DIM)
+            dsq = ops.split_halves(dcat)
             gpos = self.g["pos_embedding_3"] if with_pos else torch.zeros(1, 2 * L, DIM, device=sq.device)
             ops.tokenizer_bwd(sq, wa, tsaved, dtok_cat, dsq, self.g["conv_token_%d.weight" % l], gpos, B, L,
                               accumulate=True)
+            yield                   # (may only be recorded) dsq is complete from here on
             return b_sq(dsq)
         return out4, bwd
 
@@ -1200,7 +1204,11 @@ class Engine:
         p16, arg16 = ops.maxpool(s8, want_arg=True)
         s16, b_l3 = self.res_layer(p16, 3, 1, 2)               # 16x16x256
         level = self._xbd_level if self.cfg["kind"] == "xbd" else self._level
+        if self.need_grad:
+            # the levels' token-gradient accumulators (dtok, ddtk: 3 B L 32 floats per level) from ONE zeroed buffer
+            self._zpool = [torch.zeros(3 * 3 * B * self.cfg["token_len"] * DIM, dtype=torch.float32, device=s4.device), 0]
         (o5, b5), (t4, b4), (t3, b3) = self._run_staged([level(5, s16, B), level(4, s8, B), level(3, s4, B)])
+        self._zpool = None
         o5u = ops.upsample2(o5)
         o4, bu4 = self._up_conv(4, ops.add(t4, o5u))
         o3, bu3 = self._up_conv(3, ops.add(t3, o4))
@@ -1231,9 +1239,7 @@ class Engine:
             if split2:
                 ds2 = dcat2                                    # already the [2B, H, W, c2] gradient of s2's two halves
             else:
-                ds2 = torch.empty_like(s2)
-                ops.copy_channels(dcat2, 0, ds2[:B], 0, c2)
-                ops.copy_channels(dcat2, c2, ds2[B:], 0, c2)
+                ds2 = ops.split_halves(dcat2)
             dsum3 = bu3(dy2)                                   # d(t3 + o4)
             dsum4 = bu4(dsum3)                                 # d(t4 + o5u)
             ds4, ds8, ds16 = self._run_staged([b3(dsum3), b4(dsum4), b5(ops.upsample2_bwd(dsum4))])

@@ -475,11 +475,7 @@ class SplitCat:
         return self.t[self.B:].data_ptr() - self.t.data_ptr()
 
     def materialize(self):
-        n, h, w, c = self.t.shape
-        cat = torch.empty(self.B, h, w, 2 * c, dtype=self.t.dtype, device=self.t.device)
-        copy_channels(self.t[:self.B], 0, cat, 0, c)
-        copy_channels(self.t[self.B:], 0, cat, c, c)
-        return cat
+        return cat_halves(self.t)
 
 
 def conv3x3_split_supported(B, H, W, cin, cout, dtype):
@@ -1004,6 +1000,22 @@ def copy_channels(src, sc0, dst, dc0, cn):
     _call("dh_copy_channels", _ci(dt(src)), P(src), _ci(Cs), _ci(sc0), P(dst), _ci(Cd), _ci(dc0), _ci(cn), _cl(Pn), S())
 
 
+def cat_halves(t):
+    """torch.cat([t[:B], t[B:]], channel) of a contiguous [2B, H, W, C] tensor, one launch"""
+    n, h, w, c = t.shape
+    cat = torch.empty(n // 2, h, w, 2 * c, dtype=t.dtype, device=t.device)
+    _call("dh_cat_halves", _ci(dt(t)), P(t), P(cat), _ci(c), _cl((n // 2) * h * w), _ci(0), S())
+    return cat
+
+
+def split_halves(cat):
+    """the inverse: [B, H, W, 2C] -> [2B, H, W, C] (the gradient of cat_halves)"""
+    n, h, w, c2 = cat.shape
+    t = torch.empty(2 * n, h, w, c2 // 2, dtype=cat.dtype, device=cat.device)
+    _call("dh_cat_halves", _ci(dt(cat)), P(t), P(cat), _ci(c2 // 2), _cl(n * h * w), _ci(1), S())
+    return t
+
+
 def add(a, b):
     y = torch.empty_like(a)
     _call("dh_add", _ci(dt(a)), P(a), P(b), P(y), _cl(a.numel()), S())
@@ -1132,10 +1144,27 @@ def tokenizer_fwd(x, wa, pos, B, L):
     stats = torch.empty(Sn, L, 2, dtype=torch.float32, device=dev)
     pooled = torch.empty(Sn, L, 32, dtype=torch.float32, device=dev)
     tok = torch.empty(B, 2 * L, 32, dtype=torch.float32, device=dev)
-    ws = workspace(_lib.lib().dh_tokenizer_fwd_workspace_size(Sn, HW, L), dev)
-    _call("dh_tokenizer_fwd", _ci(dt(x)), P(x), P(wa), P(pos), _ci(Sn), _ci(B), _ci(HW), _ci(L), P(logits), P(stats),
-          P(pooled), P(tok), P(ws), S())
+    nws = _lib.lib().dh_tokenizer_fwd_workspace_size(Sn, HW, L)
+    args = lambda ws: (_ci(dt(x)), P(x), P(wa), P(pos), _ci(Sn), _ci(B), _ci(HW), _ci(L), P(logits), P(stats), P(pooled),
+                       P(tok), P(ws), S())
+    if _XPREP_BATCH is not None and _ENC_BATCH is not None:
+        # recorded (EncoderBatch): issued with the other levels' tokenizers, right before the recorded encoder stacks that read
+        # the tokens -- scratch of its own until then.  (A caller that reads `tok` with an immediate launch instead calls
+        # flush_recorded_tokens() first: Engine.encoder's layer-wise path.)
+        ws = torch.empty(max(int(nws), 1), dtype=torch.uint8, device=dev)
+        _XPREP_BATCH.extend((ws, x, pos))
+        _call("dh_tokenizer_fwd", *args(ws))
+    else:
+        with _XprepPaused():
+            _call("dh_tokenizer_fwd", *args(workspace(nws, dev)))
     return tok, (logits, stats, pooled)
+
+
+def flush_recorded_tokens():
+    """inside an EncoderBatch: issue the recorded tokenizer / preparation forward launches now (their results are read next by
+    a launch that is not a recorded one)"""
+    if _XPREP_BATCH is not None:
+        _call("dh_xprep_batch_launch_fwd", S())
 
 
 def tokenizer_bwd(x, wa, saved, dtok_cat, dx_accum, dwa, dpos, B, L, accumulate=False):
@@ -1143,7 +1172,12 @@ def tokenizer_bwd(x, wa, saved, dtok_cat, dx_accum, dwa, dpos, B, L, accumulate=
     HW = H * W
     logits, stats, pooled = saved
     Lb = _lib.lib()
-    ws = workspace(Lb.dh_tokenizer_bwd_workspace_size(Sn, HW, L), x.device)
+    nws = Lb.dh_tokenizer_bwd_workspace_size(Sn, HW, L)
+    if _XPREP_BATCH is not None:          # recorded: dx_accum / dwa / dpos are valid after the EncoderBatch's next launch()
+        ws = torch.empty(max(int(nws), 1), dtype=torch.uint8, device=x.device)
+        _XPREP_BATCH.extend((ws, dtok_cat, dx_accum, dpos))
+    else:
+        ws = workspace(nws, x.device)
     assert dtok_cat.dtype == torch.float32
     _call("dh_tokenizer_bwd", _ci(dt(x)), P(x), P(wa), _ci(Sn), _ci(B), _ci(HW), _ci(L), P(logits), P(stats), P(pooled),
           P(dtok_cat), P(dx_accum), P(dwa), P(dpos), _ci(int(accumulate)), P(ws), S())

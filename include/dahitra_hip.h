@@ -298,6 +298,10 @@ int dh_head_dgrad3x3_bn(const void* dy, const float* w_oihw, int NC, const void*
                         void* stream);
 int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream);
 int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, void* dst, int Cd, int dc0, int Cn, long P, void* stream);
+/* torch.cat([x1, x2], 1) of the two temporal streams (models/networks.py:1309, 1344), which are the two batch halves of
+ * t [2 P][C] here: cat [P][2 C] <- t (inverse = 0), or t <- cat (inverse = 1: the concatenation's gradient back to the
+ * streams); both halves in one launch.  C a multiple of the 16-byte piece (8 bf16 / 4 fp32). */
+int dh_cat_halves(int dtype, void* t, void* cat, int C, long P, int inverse, void* stream);
 int dh_add(int dtype, const void* a, const void* b, void* y, long n, void* stream);
 int dh_add_pos(int dtype, const void* x, const float* pos, void* y, int N, long HW, int C, void* stream);
 int dh_add_pos_bwd(int dtype, const void* dy, float* dpos, int N, long HW, int C, int accumulate, void* stream);

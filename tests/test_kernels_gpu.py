@@ -840,6 +840,16 @@ def test_encoder_stacks_of_independent_levels_in_one_launch(ops):
     assert all(float(g.abs().max()) > 0 for g in got[2])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_cat_of_the_two_streams_and_its_gradient_in_one_launch(ops, dtype):
+    """ops.cat_halves / split_halves (dh_cat_halves): torch.cat([t[:B], t[B:]], channel) of the two temporal streams
+    (models/networks.py:1309, 1344) and the way back, exact copies"""
+    t = dev(rnd((6, 5, 7, 32), dtype, 2201), dtype)
+    cat = ops.cat_halves(t)
+    assert torch.equal(cat, torch.cat([t[:3], t[3:]], dim=3))
+    assert torch.equal(ops.split_halves(cat), t)
+
+
 def test_decoder_layers_of_independent_stacks_in_one_launch(ops):
     """ops.EncoderBatch(decoder=True) (dh_decoder_batch_*): fused decoder layers of independent stacks -- different image
     counts and map sizes, both MLP widths -- recorded and issued as one launch per direction and width: bit-identical to the
