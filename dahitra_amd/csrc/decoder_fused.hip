@@ -97,7 +97,11 @@ __device__ __forceinline__ float group4_sum(float v) {
 __device__ __forceinline__ void stage(unsigned short* dst, int pitch, const bf16* src, int rows, int cols, int tid) {
     const int vec = cols / 4;
     for (int i = tid; i < rows * vec; i += 256) {
-        const int r = i / vec, q = i % vec, c = (q & ~7) * 4 + (q & 3) * 8 + ((q >> 2) & 1) * 4;
+        // 32-column rows: a ds_write_b64 lane group (16 lanes, banks modulo 32 dwords) covers two rows of 16 dwords, and rows r,
+        // r + 1 lie 24 dwords apart (pitch 48 elements): half of their banks coincide.  Rows r, r + 2 (48 dwords apart) do not:
+        // the groups take rows in the order 0 2 1 3 (bits 0 and 1 of the row index swapped; rows is a multiple of 4)
+        const int r0 = i / vec, q = i % vec, c = (q & ~7) * 4 + (q & 3) * 8 + ((q >> 2) & 1) * 4;
+        const int r = vec == 8 ? ((r0 & ~3) | ((r0 & 1) << 1) | ((r0 >> 1) & 1)) : r0;
         *reinterpret_cast<uint2*>(dst + r * pitch + c) = *reinterpret_cast<const uint2*>(src + (size_t)r * cols + q * 4);
     }
 }
@@ -798,27 +802,38 @@ __device__ __forceinline__ void dec_bwd_finalize_body(const FinArgs& fa, const u
         }
     }
 }
+// The finalize's workgroups as ONE line: first the gx x depth column sums of the shared parameters (bid.y = 0), then the 8 x images
+// x depth workgroups of the per-image dKq / dVoT sums.  (As a gx x (1 + images) x depth grid 63 of the 71 workgroups of every image
+// row had nothing to do: 73 840 workgroups for the three levels of a DAHiTra pass, 8 800 of them with work.)
+__host__ __device__ inline int fin_blocks(int gx, int images, int depth) { return (gx + 8 * images) * depth; }
+__device__ __forceinline__ uint3 fin_locate(int local, int gx, int images, int depth) {
+    uint3 bid;
+    if (local < gx * depth) { bid.x = local % gx; bid.y = 0; bid.z = local / gx; }
+    else {
+        local -= gx * depth;
+        bid.x = local % 8; local /= 8;
+        bid.y = 1 + local % images;
+        bid.z = local / images;
+    }
+    return bid;
+}
 template <int MLP>
-__global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(FinArgs fa) {
-    dec_bwd_finalize_body<MLP>(fa, make_uint3(blockIdx.x, blockIdx.y, blockIdx.z));
+__global__ __launch_bounds__(256) void dec_bwd_finalize_kernel(FinArgs fa, int gx, int images, int depth) {
+    dec_bwd_finalize_body<MLP>(fa, fin_locate((int)blockIdx.x, gx, images, depth));
 }
 // the finalizes of several independent stacks in one launch (dh_decoder_batch_*): workgroups [first[j], first[j + 1]) run job j's
 // gx x gy[j] x depth grid
 struct FinMulti {
     int n;
-    int first[DEC_MAXJ + 1], gx[DEC_MAXJ], gy[DEC_MAXJ];
+    int first[DEC_MAXJ + 1], gx[DEC_MAXJ], gy[DEC_MAXJ], depth[DEC_MAXJ];
     FinArgs a[DEC_MAXJ];
 };
 template <int MLP>
 __global__ __launch_bounds__(256) void dec_bwd_finalize_multi_kernel(FinMulti m) {
     int j = 0;
     while (j + 1 < m.n && (int)blockIdx.x >= m.first[j + 1]) ++j;
-    int local = (int)blockIdx.x - m.first[j];
-    uint3 bid;
-    bid.x = local % m.gx[j]; local /= m.gx[j];
-    bid.y = local % m.gy[j];
-    bid.z = local / m.gy[j];
-    dec_bwd_finalize_body<MLP>(m.a[j], bid);
+    const int local = (int)blockIdx.x - m.first[j];
+    dec_bwd_finalize_body<MLP>(m.a[j], fin_locate(local, m.gx[j], m.gy[j] - 1, m.depth[j]));
 }
 
 template <int MLP> size_t bwd_lds_bytes() {
@@ -1021,7 +1036,8 @@ extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, con
         hipLaunchKernelGGL(dec_bwd_kernel<64>, dim3(nblk), dim3(256), lds, ST(stream), a);
         if (dw1) {
             const FinArgs fa = {a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, 0L, 0L, 0L};
-            hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(dh_cdiv(PL<64>::KQ, 32), 1 + images), dim3(256), 0, ST(stream), fa);
+            const int gx = dh_cdiv(PL<64>::KQ, 32);
+            hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(fin_blocks(gx, images, 1)), dim3(256), 0, ST(stream), fa, gx, images, 1);
         }
     } else {
         const size_t lds = bwd_lds_bytes<32>();
@@ -1035,7 +1051,8 @@ extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, con
         hipLaunchKernelGGL(dec_bwd_kernel<32>, dim3(nblk), dim3(256), lds, ST(stream), a);
         if (dw1) {
             const FinArgs fa = {a.partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, 0L, 0L, 0L};
-            hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(dh_cdiv(PL<32>::KQ, 32), 1 + images), dim3(256), 0, ST(stream), fa);
+            const int gx = dh_cdiv(PL<32>::KQ, 32);
+            hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(fin_blocks(gx, images, 1)), dim3(256), 0, ST(stream), fa, gx, images, 1);
         }
     }
     DH_CHECK_LAUNCH("decoder_layer_bwd");
@@ -1120,15 +1137,17 @@ extern "C" int dh_decoder_stack_bwd_finalize(const void* workspace, int depth, l
         FinMulti& fm = g_db.fin[k];
         int& n = g_db.nfin[k];
         if (n == 0) fm.first[0] = 0;
-        fm.a[n] = fa; fm.gx[n] = gx; fm.gy[n] = 1 + images;
-        fm.first[n + 1] = fm.first[n] + gx * (1 + images) * depth;
+        fm.a[n] = fa; fm.gx[n] = gx; fm.gy[n] = 1 + images; fm.depth[n] = depth;
+        fm.first[n + 1] = fm.first[n] + fin_blocks(gx, images, depth);
         ++n;
         return 0;
     }
     if (mlp == 64)
-        hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(dh_cdiv(PL<64>::KQ, 32), 1 + images, depth), dim3(256), 0, ST(stream), fa);
+        hipLaunchKernelGGL(dec_bwd_finalize_kernel<64>, dim3(fin_blocks(dh_cdiv(PL<64>::KQ, 32), images, depth)), dim3(256), 0, ST(stream), fa,
+                           dh_cdiv(PL<64>::KQ, 32), images, depth);
     else
-        hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(dh_cdiv(PL<32>::KQ, 32), 1 + images, depth), dim3(256), 0, ST(stream), fa);
+        hipLaunchKernelGGL(dec_bwd_finalize_kernel<32>, dim3(fin_blocks(dh_cdiv(PL<32>::KQ, 32), images, depth)), dim3(256), 0, ST(stream), fa,
+                           dh_cdiv(PL<32>::KQ, 32), images, depth);
     DH_CHECK_LAUNCH("decoder_stack_bwd_finalize");
     return 0;
 }

@@ -14,12 +14,12 @@ acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
     if "dec_bwd" in n or "dec_fwd" in n:          # dec_{fwd,bwd}_kernel and the staged levels' dec_{fwd,bwd}_multi_kernel, keyed by name
-        key = (n.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", ""), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1))
+        key = (n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0], int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1))
         acc[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 with open(sys.argv[2], "w") as o:
     for k in sorted(acc):
         v = sorted(acc[k])
-        o.write("%-24s grid %5d: %4d launches, median %.1f us, min %.1f\n" % (k[0], k[1], len(v), v[len(v) // 2], v[0]))
+        o.write("%-44s grid %5d: %4d launches, median %.1f us, min %.1f\n" % (k[0], k[1], len(v), v[len(v) // 2], v[0]))
 print(open(sys.argv[2]).read())
 PY
 rm -rf $O/stats
