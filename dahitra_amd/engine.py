@@ -121,6 +121,8 @@ class Engine:
         # gradient then materialises the map itself).  DESIGN.md section 6e.
         self.fused_up4_fwd = os.environ.get("DAHITRA_FUSED_UP4_FWD", "0") == "1"
         self.use_side = os.environ.get("DAHITRA_SIDE_STREAM", "0") == "1"
+        self.pack_side = os.environ.get("DAHITRA_PACK_SIDE", "0") == "1"
+        self._pack_stream = None
         self.side = None
         self._deferred_wgrad = None
         self.shapes = {k: s for k, s, _ in state_spec(net_G)}
@@ -147,10 +149,23 @@ class Engine:
         if plan is None:
             plan = self._plans[self.need_grad] = self._build_plan()
         pack, self.pk, self.xstack, self.wstack = plan
-        pack.run()
+        # the per-step re-pack (one launch, 37 - 42 us of strided gathers) next to the stem, which reads the OIHW weights itself:
+        # a side stream forked here and joined after the stem (_pack_join) -- in the recorded step two parallel branches
+        if self.pack_side and self.training and self.direct_stem and self.dtype == torch.bfloat16 and ops.PROFILE is None:
+            if self._pack_stream is None:
+                self._pack_stream = ops.SideStream(self.p["resnet.conv1.weight"].device)
+            with self._pack_stream.fork():
+                pack.run()
+        else:
+            pack.run()
         key = "resnet.conv1.weight"
         if not (self.direct_stem and self.dtype == torch.bfloat16):      # the direct stem kernel reads the OIHW weights itself
             self.pk[key] = Packed(ops.stem_pack_weight(self.p[key], self.dtype), None)
+
+    def _pack_join(self):
+        """the current stream waits for the re-pack issued on the side stream (no-op otherwise): before the first packed weight is read"""
+        if self._pack_stream is not None:
+            self._pack_stream.join()
 
     def _build_plan(self):
         ck = ops.chunk_channels(self.dtype)
@@ -953,6 +968,7 @@ class Engine:
         B = x1.shape[0]
         S2 = 2 * B
         xp, xarg, xshape, b_stem = self.stem(x1, x2, 2, pool=True)
+        self._pack_join()
         if cfg.get("backbone") == "resnet50":
             l1, b_l1 = self.res50_layer(xp, 1, 1, 1, 1, 2)
             l2, b_l2 = self.res50_layer(l1, 2, 2, 1, 1, 2)
@@ -1198,6 +1214,7 @@ class Engine:
     def _unet(self, x1, x2):
         B = x1.shape[0]
         s2, b_stem = self.stem(x1, x2, 2)                      # [2B,128,128,64] (post-ReLU tap)
+        self._pack_join()
         p4, arg4 = ops.maxpool(s2, want_arg=True)
         s4, b_l1 = self.res_layer(p4, 1, 1, 2)                 # 64x64x64
         s8, b_l2 = self.res_layer(s4, 2, 2, 2)                 # 32x32x128
