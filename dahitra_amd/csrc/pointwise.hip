@@ -859,6 +859,91 @@ struct PackJob {
 // MFMA A fragment (lane (pl = lane & 15, g = lane >> 4): row 16 r + pl, reduction channels 32 c + 8 g .. + 7) is contiguous, so
 // the once-per-workgroup load of the register-resident weights reads whole cache lines (measured: 10.2 -> 5.0 us for the
 // 295 KB of a 64 x 256-channel block).  rows = output channels (forward) / input channels (data gradient, flipped taps).
+// eight consecutive destination elements from eight sources `stride` floats apart (ok[e] false: zero): the index arithmetic of a
+// destination element (three divisions by run-time values) is paid once per 16-byte store instead of once per element -- the
+// kernel was bound by exactly that (37 us for 12 M elements, ~100 integer instructions each)
+template <typename T>
+__device__ __forceinline__ void pack_store8(T* dst, const float* __restrict__ src, unsigned stride, unsigned okmask) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ((okmask >> e) & 1) ? src[(size_t)e * stride] : 0.f;
+    if constexpr (sizeof(T) == 2) {
+        uint4 u;
+        u.x = f2bf2(v[0], v[1]); u.y = f2bf2(v[2], v[3]); u.z = f2bf2(v[4], v[5]); u.w = f2bf2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(dst) = u;
+    } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+template <typename T> __device__ __forceinline__ void pack_put8(T* dst, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        uint4 u;
+        u.x = f2bf2(v[0], v[1]); u.y = f2bf2(v[2], v[3]); u.z = f2bf2(v[4], v[5]); u.w = f2bf2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(dst) = u;
+    } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+// 3x3 layers with O, I multiples of 32 and no padding (all but the class head and the stem: 95 % of the weights): a workgroup takes
+// a 32 (o) x 32 (ci) x 9 tile -- 32 runs of 288 CONSECUTIVE floats of the OIHW master, 16-byte loads -- through LDS and writes
+// every destination in 16-byte pieces.  The element-wise form reads the master at a 36-byte stride: one cache-line transaction
+// per 4-byte element, 40 us per step for 3 M weights whatever the index arithmetic costs (8 elements per lane and store: 39.7).
+constexpr int PK_T = 32, PK_ROW = PK_T * 9, PK_PITCH = PK_ROW + 1;
+__host__ __device__ inline bool pack_tiled(const PackJob& j) {
+    // (the master is a view at any float offset of the parameter arena: the 16-byte loads need it aligned)
+    return j.KS == 3 && j.O % PK_T == 0 && j.I % PK_T == 0 && j.OPad == j.O && j.IPad == j.I && j.OK == j.O &&
+           (reinterpret_cast<unsigned long long>(j.w) & 15) == 0;
+}
+template <typename T>
+__device__ __forceinline__ void pack_job_tiled(const PackJob& j, int lb, float* t /*[32][PK_PITCH]*/) {
+    const int tid = threadIdx.x, nti = j.I / PK_T, ntiles = (j.O / PK_T) * nti;
+    T* fwd = reinterpret_cast<T*>(j.fwd);
+    T* dgrad = reinterpret_cast<T*>(j.dgrad);
+    const bool frag = (j.dtype & 0x200) != 0;
+    for (int tile = lb; tile < ntiles; tile += j.nblocks) {
+        const int o0 = (tile / nti) * PK_T, c0 = (tile % nti) * PK_T;
+        __syncthreads();                                  // the previous tile's readers are done
+        for (int q = tid; q < PK_T * (PK_ROW / 4); q += 256) {
+            const int r = q / (PK_ROW / 4), k = (q % (PK_ROW / 4)) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(j.w + ((size_t)(o0 + r) * j.I + c0) * 9 + k);
+            float* d = t + r * PK_PITCH + k;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        // 1152 pieces of 8 elements per destination
+        for (int q = tid; q < 9 * PK_T * 4; q += 256) {
+            float v[8];
+            if (frag) {
+                const int lane = q & 63, tap = (q >> 6) % 9, blk = q / (64 * 9);             // blk: 16-row block of the tile
+                const int rr = blk * 16 + (lane & 15), kk = (lane >> 4) * 8;
+                if (fwd) {                                // rows = o, reduction = ci
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = t[rr * PK_PITCH + (kk + e) * 9 + tap];
+                    pack_put8(fwd + ((((size_t)(o0 / 16 + blk) * (j.I / 32) + c0 / 32) * 9 + tap) * 64 + lane) * 8, v);
+                }
+                if (dgrad) {                              // rows = ci, reduction = o, taps flipped
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = t[(kk + e) * PK_PITCH + rr * 9 + (8 - tap)];
+                    pack_put8(dgrad + ((((size_t)(c0 / 16 + blk) * (j.OK / 32) + o0 / 32) * 9 + tap) * 64 + lane) * 8, v);
+                }
+            } else {
+                const int pc = q & 3, r = (q >> 2) & 31, tap = q >> 7;                          // piece, row, tap
+                if (fwd) {                                // [tap][o][ci]
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = t[r * PK_PITCH + (pc * 8 + e) * 9 + tap];
+                    pack_put8(fwd + ((size_t)tap * j.OPad + o0 + r) * j.I + c0 + pc * 8, v);
+                }
+                if (dgrad) {                              // [tap][ci][o], taps flipped
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = t[(pc * 8 + e) * PK_PITCH + r * 9 + (8 - tap)];
+                    pack_put8(dgrad + ((size_t)tap * j.IPad + c0 + r) * j.OK + o0 + pc * 8, v);
+                }
+            }
+        }
+    }
+}
 template <typename T>
 __device__ __forceinline__ void pack_job(const PackJob& j, int lb) {
     const int taps = j.KS * j.KS;
@@ -867,38 +952,70 @@ __device__ __forceinline__ void pack_job(const PackJob& j, int lb) {
     const unsigned step = (unsigned)j.nblocks * blockDim.x;
     T* fwd = reinterpret_cast<T*>(j.fwd);
     T* dgrad = reinterpret_cast<T*>(j.dgrad);
+    const unsigned t0 = (unsigned)lb * blockDim.x + threadIdx.x;
     if (j.dtype & 0x200) {
+        // (fragment order: the 8 elements of a lane are 8 consecutive reduction channels -- I % 32 == OK % 32 == 0)
         const int nch_f = j.I / 32, nch_d = j.OK / 32;
         if (fwd)
-            for (unsigned i = (unsigned)lb * blockDim.x + threadIdx.x; i < (unsigned)(taps * j.OPad * j.I); i += step) {
-                const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), tap = (int)((i >> 9) % (unsigned)taps);
+            for (unsigned i8 = t0; i8 < (unsigned)(taps * j.OPad * j.I) / 8; i8 += step) {
+                const unsigned i = i8 * 8;
+                const int lane = (int)((i >> 3) & 63), tap = (int)((i >> 9) % (unsigned)taps);
                 const int c = (int)((i / (512u * (unsigned)taps)) % (unsigned)nch_f), r16 = (int)(i / (512u * (unsigned)taps * (unsigned)nch_f));
-                const int o = r16 * 16 + (lane & 15), ci = c * 32 + (lane >> 4) * 8 + e;
-                stf(fwd + i, o < j.O ? j.w[(unsigned)((o * j.I + ci) * taps + tap)] : 0.f);
+                const int o = r16 * 16 + (lane & 15), ci = c * 32 + (lane >> 4) * 8;
+                pack_store8(fwd + i, j.w + (unsigned)((o * j.I + ci) * taps + tap), (unsigned)taps, o < j.O ? 0xffu : 0u);
             }
         if (dgrad)
-            for (unsigned i = (unsigned)lb * blockDim.x + threadIdx.x; i < (unsigned)(taps * j.IPad * j.OK); i += step) {
-                const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), tap = (int)((i >> 9) % (unsigned)taps);
+            for (unsigned i8 = t0; i8 < (unsigned)(taps * j.IPad * j.OK) / 8; i8 += step) {
+                const unsigned i = i8 * 8;
+                const int lane = (int)((i >> 3) & 63), tap = (int)((i >> 9) % (unsigned)taps);
                 const int c = (int)((i / (512u * (unsigned)taps)) % (unsigned)nch_d), r16 = (int)(i / (512u * (unsigned)taps * (unsigned)nch_d));
-                const int ci = r16 * 16 + (lane & 15), o = c * 32 + (lane >> 4) * 8 + e;
-                stf(dgrad + i, (ci < j.I && o < j.O) ? j.w[(unsigned)((o * j.I + ci) * taps + (taps - 1 - tap))] : 0.f);
+                const int ci = r16 * 16 + (lane & 15), o = c * 32 + (lane >> 4) * 8;
+                unsigned ok = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ok |= (unsigned)(ci < j.I && o + e < j.O) << e;
+                pack_store8(dgrad + i, j.w + (unsigned)((o * j.I + ci) * taps + (taps - 1 - tap)), (unsigned)(j.I * taps), ok);
             }
         return;
     }
-    if (fwd)
-        for (unsigned i = (unsigned)lb * blockDim.x + threadIdx.x; i < (unsigned)(taps * j.OPad * j.I); i += step) {
-            const int ci = (int)(i % (unsigned)j.I);
-            const int o = (int)((i / (unsigned)j.I) % (unsigned)j.OPad);
-            const int tap = (int)(i / (unsigned)(j.I * j.OPad));
-            stf(fwd + i, o < j.O ? j.w[(unsigned)((o * j.I + ci) * taps + tap)] : 0.f);
+    if (fwd) {
+        if (j.I % 8 == 0) {
+            for (unsigned i8 = t0; i8 < (unsigned)(taps * j.OPad * j.I) / 8; i8 += step) {
+                const unsigned i = i8 * 8;
+                const int ci = (int)(i % (unsigned)j.I);
+                const int o = (int)((i / (unsigned)j.I) % (unsigned)j.OPad);
+                const int tap = (int)(i / (unsigned)(j.I * j.OPad));
+                pack_store8(fwd + i, j.w + (unsigned)((o * j.I + ci) * taps + tap), (unsigned)taps, o < j.O ? 0xffu : 0u);
+            }
+        } else {
+            for (unsigned i = t0; i < (unsigned)(taps * j.OPad * j.I); i += step) {
+                const int ci = (int)(i % (unsigned)j.I);
+                const int o = (int)((i / (unsigned)j.I) % (unsigned)j.OPad);
+                const int tap = (int)(i / (unsigned)(j.I * j.OPad));
+                stf(fwd + i, o < j.O ? j.w[(unsigned)((o * j.I + ci) * taps + tap)] : 0.f);
+            }
         }
-    if (dgrad)
-        for (unsigned i = (unsigned)lb * blockDim.x + threadIdx.x; i < (unsigned)(taps * j.IPad * j.OK); i += step) {
-            const int o = (int)(i % (unsigned)j.OK);
-            const int ci = (int)((i / (unsigned)j.OK) % (unsigned)j.IPad);
-            const int tap = (int)(i / (unsigned)(j.OK * j.IPad));
-            stf(dgrad + i, (ci < j.I && o < j.O) ? j.w[(unsigned)((o * j.I + ci) * taps + (taps - 1 - tap))] : 0.f);
+    }
+    if (dgrad) {
+        if (j.OK % 8 == 0) {
+            for (unsigned i8 = t0; i8 < (unsigned)(taps * j.IPad * j.OK) / 8; i8 += step) {
+                const unsigned i = i8 * 8;
+                const int o = (int)(i % (unsigned)j.OK);
+                const int ci = (int)((i / (unsigned)j.OK) % (unsigned)j.IPad);
+                const int tap = (int)(i / (unsigned)(j.OK * j.IPad));
+                unsigned ok = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ok |= (unsigned)(ci < j.I && o + e < j.O) << e;
+                pack_store8(dgrad + i, j.w + (unsigned)((o * j.I + ci) * taps + (taps - 1 - tap)), (unsigned)(j.I * taps), ok);
+            }
+        } else {
+            for (unsigned i = t0; i < (unsigned)(taps * j.IPad * j.OK); i += step) {
+                const int o = (int)(i % (unsigned)j.OK);
+                const int ci = (int)((i / (unsigned)j.OK) % (unsigned)j.IPad);
+                const int tap = (int)(i / (unsigned)(j.OK * j.IPad));
+                stf(dgrad + i, (ci < j.I && o < j.O) ? j.w[(unsigned)((o * j.I + ci) * taps + (taps - 1 - tap))] : 0.f);
+            }
         }
+    }
 }
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
     int lo = 0, hi = njobs - 1;
@@ -908,6 +1025,11 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackJob* 
     }
     const PackJob j = jobs[lo];
     const int lb = blockIdx.x - j.first_block;
+    __shared__ __attribute__((aligned(16))) float tile[PK_T * PK_PITCH];
+    if (pack_tiled(j)) {
+        if ((j.dtype & 0xff) == DH_DTYPE_BF16) pack_job_tiled<bf16>(j, lb, tile); else pack_job_tiled<float>(j, lb, tile);
+        return;
+    }
     if ((j.dtype & 0xff) == DH_DTYPE_BF16) pack_job<bf16>(j, lb); else pack_job<float>(j, lb);
 }
 

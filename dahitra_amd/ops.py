@@ -150,7 +150,9 @@ class PackPlan:
                 (torch.empty(ks * ks, IPad, OK, dtype=dtype, device=w.device) if want_dgrad else None)
         n = max(fwd.numel() if fwd is not None else 0, dg.numel() if dg is not None else 0)
         assert n < 2 ** 31 and w.numel() < 2 ** 31, "pack_weights_multi indexes a layer with 32-bit arithmetic"
-        nb = max(1, min(256, cdiv(n, 1024)))
+        nb = max(1, min(256, cdiv(n, 2048)))        # a lane packs 8 elements per pass (16-byte store): one pass per lane
+        if ks == 3 and O % 32 == 0 and I % 32 == 0 and OK == O:
+            nb = min(256, (O // 32) * (I // 32))       # the tiled form (csrc/pointwise.hip pack_job_tiled): one 32 x 32 x 9 tile per workgroup
         self.jobs.append(self._Job(w.data_ptr(), fwd.data_ptr() if fwd is not None else None,
                                    dg.data_ptr() if dg is not None else None, O, I, ks, OPad, IPad, OK,
                                    _DT[dtype] | (0x200 if frag else 0), self.blocks, nb))

@@ -292,6 +292,34 @@ def test_class_head_writes_nchw_logits_itself(ops, dtype, ncls, hw, lazy):
     close(got, two.cpu(), dtype, "head vs conv + layout pass", factor=0.5)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_weight_repack_of_a_step_equals_the_permutation_it_states(ops, dtype):
+    """ops.PackPlan (dh_pack_weights_multi, one launch per step for every layer): forward form [tap][OPad][I] = w[o][ci][tap],
+    data-gradient form [tap][IPad][OK] = w[o][ci][taps - 1 - tap], zero padding; shapes with and without the 8-element
+    vector path (I or OK not a multiple of 8), padded rows, a 1x1 and a linear layer, several jobs in one plan"""
+    shapes = [(64, 64, 3), (2, 32, 3), (40, 24, 3), (32, 12, 3), (128, 64, 1), (20, 36, 1), (64, 32, 0)]      # O, I, kernel (0: linear)
+    plan = ops.PackPlan(torch.device("cuda"))
+    jobs = []
+    for k, (O, I, ks) in enumerate(shapes):
+        w = rnd((O, I, ks, ks) if ks else (O, I), dtype, 4100 + k).cuda().float()
+        inner = 48 if (O, I) == (40, 24) else 0
+        jobs.append((w, inner) + plan.add(w, dtype, dgrad_inner=inner))
+    plan.run()
+    torch.cuda.synchronize()
+    for w, inner, fwd, dg in jobs:
+        O, I = w.shape[:2]
+        taps = w[0, 0].numel() if w.dim() == 4 else 1
+        w3 = w.reshape(O, I, taps)
+        OPad, IPad, OK = fwd.shape[1], dg.shape[1], dg.shape[2]
+        assert OK == max(O, inner) and OPad % 16 == 0 and IPad % 16 == 0
+        want_f = torch.zeros(taps, OPad, I, device="cuda")
+        want_f[:, :O] = w3.permute(2, 0, 1)
+        want_d = torch.zeros(taps, IPad, OK, device="cuda")
+        want_d[:, :I, :O] = w3.flip(2).permute(2, 1, 0)
+        assert torch.equal(fwd.float(), want_f.to(dtype).float()), (O, I, taps)
+        assert torch.equal(dg.float(), want_d.to(dtype).float()), (O, I, taps)
+
+
 @pytest.mark.parametrize("cfg", [(64, 64, 64, 64, 64), (64, 32, 32, 256, 256), (64, 32, 32, 128, 256), (64, 32, 32, 256, 128)])
 def test_fragment_order_packed_weights(ops, cfg):
     """dh_pack_weights_multi with dtype | 0x200: the fragment-order copies hold the same numbers as the row-major packs
