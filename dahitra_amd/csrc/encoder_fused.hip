@@ -97,22 +97,36 @@ __device__ __forceinline__ void layer_norm_rows(const float* src, const float* g
 // The caller reads the result from red[0 .. n*32) after the trailing barrier.
 __device__ __forceinline__ void ksplit_rows(const float* in, int in_pitch, const float* __restrict__ W, long sj, long sc, int K,
                                             int n, float* red) {
-    const int kg = threadIdx.x >> 5, c = threadIdx.x & 31;       // (threads beyond the 8 x 32 mapping only pass the barriers)
-    const int per = (K + 7) >> 3, j0 = kg < 8 ? kg * per : K, j1 = min(K, j0 + per);
+    // 16 K-groups: wave w (ENC_THREADS / 64 = 8) x lane half h; the two halves of a wave meet by one cross-half shuffle, so `red`
+    // still combines 8 partial sums.  (The first form ran on 8 groups of 32 lanes -- half of the workgroup idle -- with 8 loads in
+    // flight per lane: 24 rounds of L2 latency for K = 1536, 21.9 of the data-gradient kernel's 60 us; tools/enc_timeline.py.)
+    const int w = threadIdx.x >> 6, h = (threadIdx.x >> 5) & 1, c = threadIdx.x & 31, kg = w * 2 + h;
+    const int per = (((K + 15) >> 4) + 3) & ~3, j0 = min(K, kg * per), j1 = min(K, j0 + per);     // multiples of 4: 16-byte LDS reads
     float acc[MAXN];
 #pragma unroll
     for (int t = 0; t < MAXN; ++t) acc[t] = 0.f;
     int j = j0;
-    for (; j + 7 < j1; j += 8) {              // eight weight loads in flight per step (the loop is load-latency-bound)
-        float w[8];
+    for (; j + 15 < j1; j += 16) {            // sixteen weight loads in flight per step (the loop is load-latency-bound)
+        float wv[16];
+        if (sj == 1) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = W[(long)(j + u) * sj + (long)c * sc];
+            for (int u = 0; u < 16; u += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(W + (long)c * sc + j + u);
+                wv[u] = v.x; wv[u + 1] = v.y; wv[u + 2] = v.z; wv[u + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = W[(long)(j + u) * sj + (long)c * sc];
+        }
 #pragma unroll
         for (int t = 0; t < MAXN; ++t)
             if (t < n) {
                 const float* r = in + t * in_pitch + j;
-                acc[t] += r[0] * w[0] + r[1] * w[1] + r[2] * w[2] + r[3] * w[3];
-                acc[t] += r[4] * w[4] + r[5] * w[5] + r[6] * w[6] + r[7] * w[7];
+#pragma unroll
+                for (int u = 0; u < 16; u += 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(r + u);
+                    acc[t] += x.x * wv[u] + x.y * wv[u + 1] + x.z * wv[u + 2] + x.w * wv[u + 3];
+                }
             }
     }
     for (; j + 3 < j1; j += 4) {
@@ -121,38 +135,53 @@ __device__ __forceinline__ void ksplit_rows(const float* in, int in_pitch, const
 #pragma unroll
         for (int t = 0; t < MAXN; ++t)
             if (t < n) {
-                const float* r = in + t * in_pitch + j;
-                acc[t] += r[0] * w0 + r[1] * w1 + r[2] * w2 + r[3] * w3;
+                const float4 x = *reinterpret_cast<const float4*>(in + t * in_pitch + j);
+                acc[t] += x.x * w0 + x.y * w1 + x.z * w2 + x.w * w3;
             }
     }
     for (; j < j1; ++j) {
-        const float w = W[(long)j * sj + (long)c * sc];
+        const float wj = W[(long)j * sj + (long)c * sc];
 #pragma unroll
         for (int t = 0; t < MAXN; ++t)
-            if (t < n) acc[t] += in[t * in_pitch + j] * w;
+            if (t < n) acc[t] += in[t * in_pitch + j] * wj;
     }
 #pragma unroll
-    for (int t = 0; t < MAXN; ++t)
-        if (t < n && kg < 8) red[(kg * n + t) * D + c] = acc[t];
+    for (int t = 0; t < MAXN; ++t) {
+        acc[t] += __shfl_xor(acc[t], 32, 64);
+        if (t < n && h == 0) red[(w * n + t) * D + c] = acc[t];
+    }
     __syncthreads();
     if (threadIdx.x < n * D) {
-        float s = 0.f;
+        float sum = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) s += red[g * n * D + threadIdx.x];
-        red[threadIdx.x] = s;               // slot [0][t][c]: only this thread reads/writes it
+        for (int g = 0; g < 8; ++g) sum += red[g * n * D + threadIdx.x];
+        red[threadIdx.x] = sum;             // slot [0][t][c]: only this thread reads/writes it
     }
     __syncthreads();
 }
 
+// -DENC_TIMING (tools/enc_timeline.py; never in the product build): wall-clock stamps of thread 0 after every phase of the LAST layer
+#ifdef ENC_TIMING
+__device__ long long g_enct[1024 * 16];
+#define ENC_T(k) do { if (threadIdx.x == 0) g_enct[b * 16 + (k)] = (long long)wall_clock64(); } while (0)
+#define ENC_TF(k) do { if (threadIdx.x == 0) g_enct[512 * 16 + blockIdx.x * 16 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define ENC_T(k) do { } while (0)
+#define ENC_TF(k) do { } while (0)
+#endif
 // one layer forward on the tokens in l.x; leaves every intermediate in LDS; the layer output goes to `out`
 // (LDS [n][32], may alias l.x)
 __device__ __forceinline__ void layer_forward(const EncArgs& a, const Lds& l, int ly, float* out) {
     const int tid = threadIdx.x, n = a.n, inner = a.heads * a.dh, mlp = a.mlp;
     const long ps = (long)ly * a.pstride;
+    ENC_TF(0);
     layer_norm_rows(l.x, a.ln1_g + ps, a.ln1_b + ps, a.eps, n, l.xn, l.xh1, l.st);
     __syncthreads();
+    ENC_TF(1);
     // qkv[t][j] = sum_c xn[t][c] * Wqkv[j][c]: a thread owns column j (its 128-byte weight row stays in registers)
     const float* wqkv = a.wqkv + ps;
+    // (all of a lane's weight rows requested before the first use -- one L2 round trip instead of three at inner = 512 -- was
+    // measured and lost: 205 registers, 12.2 instead of 7.4 us for this phase)
     for (int j = tid; j < 3 * inner; j += blockDim.x) {
         float w[D];
 #pragma unroll
@@ -163,11 +192,15 @@ __device__ __forceinline__ void layer_forward(const EncArgs& a, const Lds& l, in
         for (int t = 0; t < n; ++t) {
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < D; ++c) s += l.xn[t * D + c] * w[c];
+            for (int c = 0; c < D; c += 4) {          // (same order of the 32 products; one ds_read_b128 per four)
+                const float4 x = *reinterpret_cast<const float4*>(l.xn + t * D + c);
+                s += x.x * w[c]; s += x.y * w[c + 1]; s += x.z * w[c + 2]; s += x.w * w[c + 3];
+            }
             l.qkv[t * 3 * inner + j] = s;
         }
     }
     __syncthreads();
+    ENC_TF(2);
     // attention probabilities p[h][t][s] = softmax_s(scale * <q_t, k_s>): 4 lanes per (h, t) split the dh-long dots
     {
         const int pair = tid >> 2, sub = tid & 3, npair = a.heads * n;
@@ -206,20 +239,44 @@ __device__ __forceinline__ void layer_forward(const EncArgs& a, const Lds& l, in
         }
     }
     __syncthreads();
+    ENC_TF(3);
     // o[t][h*dh+e] = sum_s p[h][t][s] * v[s][h*dh+e]
-    for (int i = tid; i < n * inner; i += blockDim.x) {
-        const int t = i / inner, j = i % inner, h = j / a.dh;
-        float s = 0.f;
-        for (int u = 0; u < n; ++u) s += l.p[(h * n + t) * n + u] * l.qkv[u * 3 * inner + 2 * inner + j];
-        l.o[i] = s;
+    if (n == MAXN) {
+        // a thread owns column j for all 8 tokens: v of the column once, then row t of p by two 16-byte reads (the same address for
+        // the 64 lanes of a head) -- 24 LDS reads per lane instead of 128; same order of the sums
+        for (int j = tid; j < inner; j += blockDim.x) {
+            const int h = j / a.dh;
+            float vv[MAXN];
+#pragma unroll
+            for (int u = 0; u < MAXN; ++u) vv[u] = l.qkv[u * 3 * inner + 2 * inner + j];
+#pragma unroll
+            for (int t = 0; t < MAXN; ++t) {
+                const float* pr = l.p + (h * MAXN + t) * MAXN;
+                const float4 p0 = *reinterpret_cast<const float4*>(pr), p1 = *reinterpret_cast<const float4*>(pr + 4);
+                float s = 0.f;
+                s += p0.x * vv[0]; s += p0.y * vv[1]; s += p0.z * vv[2]; s += p0.w * vv[3];
+                s += p1.x * vv[4]; s += p1.y * vv[5]; s += p1.z * vv[6]; s += p1.w * vv[7];
+                l.o[t * inner + j] = s;
+            }
+        }
+    } else {
+        for (int i = tid; i < n * inner; i += blockDim.x) {
+            const int t = i / inner, j = i % inner, h = j / a.dh;
+            float s = 0.f;
+            for (int u = 0; u < n; ++u) s += l.p[(h * n + t) * n + u] * l.qkv[u * 3 * inner + 2 * inner + j];
+            l.o[i] = s;
+        }
     }
     __syncthreads();
+    ENC_TF(4);
     // x1 = o Wo^T + bo + x      (K = inner, split)
     ksplit_rows(l.o, inner, a.wo + ps, 1, inner, inner, n, l.red);
     if (tid < n * D) l.x1[tid] = l.red[tid] + a.bo[ps + (tid & 31)] + l.x[tid];
     __syncthreads();
+    ENC_TF(5);
     layer_norm_rows(l.x1, a.ln2_g + ps, a.ln2_b + ps, a.eps, n, l.x1n, l.xh2, l.st + 2 * n);
     __syncthreads();
+    ENC_TF(6);
     // z = x1n W1^T + b1, h = gelu(z)
     const float* w1 = a.w1 + ps;
     for (int i = tid; i < n * mlp; i += blockDim.x) {
@@ -231,6 +288,7 @@ __device__ __forceinline__ void layer_forward(const EncArgs& a, const Lds& l, in
         l.h[i] = gelu_erf(s);
     }
     __syncthreads();
+    ENC_TF(7);
     // out = h W2^T + b2 + x1    (K = mlp <= 64)
     const float* w2 = a.w2 + ps;
     float r = 0.f;
@@ -243,6 +301,7 @@ __device__ __forceinline__ void layer_forward(const EncArgs& a, const Lds& l, in
     __syncthreads();
     if (tid < n * D) out[tid] = r;
     __syncthreads();
+    ENC_TF(8);
 }
 
 __device__ __forceinline__ void enc_fwd_body(const EncArgs& a, const int b, float* sm) {
@@ -300,6 +359,7 @@ __device__ __forceinline__ void enc_bwd_body(const EncArgs& a, const int b, floa
     float* dqkv = g; g += n * 3 * inner;
     float* dxn = g; g += n * D;
     float* dp = g;                           // [heads][n][n] dS
+    ENC_T(10);
     if (tid < n * D) dx2[tid] = a.dy[(size_t)b * n * D + tid];
     for (int ly = a.depth - 1; ly >= 0; --ly) {
         const long ps = (long)ly * a.pstride;
@@ -312,7 +372,9 @@ __device__ __forceinline__ void enc_bwd_body(const EncArgs& a, const int b, floa
 #pragma unroll 8
             for (int i = tid; i < img / 4; i += blockDim.x) dst[i] = src[i];      // the forward's LDS image of this layer
         }
+        ENC_T(0);
         __syncthreads();
+        ENC_T(1);
         // ---- feed-forward backward ----
         const float* w2 = a.w2 + ps;
         for (int i = tid; i < n * mlp; i += blockDim.x) {
@@ -323,15 +385,17 @@ __device__ __forceinline__ void enc_bwd_body(const EncArgs& a, const int b, floa
             dz[i] = s * gelu_erf_grad(l.z[i]);
         }
         __syncthreads();
+        ENC_T(2);
         const float* w1 = a.w1 + ps;
         if (tid < n * D) {
             const int t = tid / D, c = tid % D;
             float s = 0.f;
-#pragma unroll 8
-            for (int m = 0; m < mlp; ++m) s += dz[t * mlp + m] * w1[(size_t)m * D + c];
+#pragma unroll 32
+            for (int m = 0; m < mlp; ++m) s += dz[t * mlp + m] * w1[(size_t)m * D + c];      // (32 weight loads in flight: was 8, 5.5 us)
             dx1n[tid] = s;
         }
         __syncthreads();
+        ENC_T(3);
         // LayerNorm-2 backward + residual: dx1 = rstd * (gh - mean(gh) - xh * mean(gh * xh)) + dx2
         if (tid < n * D) {
             const int t = tid / D, c = tid % D;
@@ -342,6 +406,7 @@ __device__ __forceinline__ void enc_bwd_body(const EncArgs& a, const int b, floa
             dx1[tid] = l.st[2 * n + t * 2 + 1] * (gh - (sa + xh * sb) * (1.f / D)) + dx2[tid];
         }
         __syncthreads();
+        ENC_T(4);
         // ---- attention backward ----
         // do[t][j] = sum_c dx1[t][c] * Wo[c][j]: a thread owns column j (coalesced reads of Wo rows)
         const float* wo = a.wo + ps;
@@ -352,22 +417,34 @@ __device__ __forceinline__ void enc_bwd_body(const EncArgs& a, const int b, floa
             for (int t = 0; t < n; ++t) {
                 float s = 0.f;
 #pragma unroll
-                for (int c = 0; c < D; ++c) s += dx1[t * D + c] * w[c];
+                for (int c = 0; c < D; c += 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(dx1 + t * D + c);
+                    s += x.x * w[c]; s += x.y * w[c + 1]; s += x.z * w[c + 2]; s += x.w * w[c + 3];
+                }
                 d_o[t * inner + j] = s;
             }
         }
         __syncthreads();
+        ENC_T(5);
         // dS[h][t][s] = p * (dP - sum_s' dP p),  dP[t][s] = <do_t, v_s>: 4 lanes per (h, t)
         {
             const int pair = tid >> 2, sub = tid & 3, npair = a.heads * n;
             const int h = pair / n, t = pair % n;
             const int e0 = sub * (a.dh >> 2), e1 = e0 + (a.dh >> 2);
             float dpv[MAXN];
+#pragma unroll
+            for (int s = 0; s < MAXN; ++s) dpv[s] = 0.f;
             if (pair < npair) {
-                for (int s = 0; s < n; ++s) {
-                    float d = 0.f;
-                    for (int e = e0; e < e1; ++e) d += d_o[t * inner + h * a.dh + e] * l.qkv[s * 3 * inner + 2 * inner + h * a.dh + e];
-                    dpv[s] = d;
+                // 16-byte LDS reads, as in the forward's dots (scalar: 256 dependent-latency reads per lane, 10.5 us)
+                const float* dor = d_o + t * inner + h * a.dh;
+                for (int e = e0; e < e1; e += 4) {
+                    const float4 d4 = *reinterpret_cast<const float4*>(dor + e);
+#pragma unroll
+                    for (int s = 0; s < MAXN; ++s)
+                        if (s < n) {
+                            const float4 v4 = *reinterpret_cast<const float4*>(l.qkv + s * 3 * inner + 2 * inner + h * a.dh + e);
+                            dpv[s] += d4.x * v4.x + d4.y * v4.y + d4.z * v4.z + d4.w * v4.w;
+                        }
                 }
             }
 #pragma unroll
@@ -384,23 +461,66 @@ __device__ __forceinline__ void enc_bwd_body(const EncArgs& a, const int b, floa
             }
         }
         __syncthreads();
-        for (int i = tid; i < n * inner; i += blockDim.x) {
-            const int t = i / inner, j = i % inner, h = j / a.dh;
-            float dq = 0.f, dk = 0.f, dv = 0.f;
-            for (int s = 0; s < n; ++s) {
-                dq += dp[(h * n + t) * n + s] * l.qkv[s * 3 * inner + inner + j];      // dS[t][s] k_s
-                dk += dp[(h * n + s) * n + t] * l.qkv[s * 3 * inner + j];              // dS[s][t] q_s
-                dv += l.p[(h * n + s) * n + t] * d_o[s * inner + j];                   // p[s][t] do_s
+        ENC_T(6);
+        if (n == MAXN) {
+            // a thread owns column j for all 8 tokens: q, k, do of the column once (24 reads), then row r of dS and of p (two 16-byte
+            // reads each, the same address for the 64 lanes of a head): dq[r] from the row, dk / dv accumulate over r in the same
+            // order as the per-element form below (384 scalar reads per lane, 8 us)
+            for (int j = tid; j < inner; j += blockDim.x) {
+                const int h = j / a.dh;
+                float qv[MAXN], kv[MAXN], dov[MAXN], dk[MAXN], dv[MAXN];
+#pragma unroll
+                for (int u = 0; u < MAXN; ++u) {
+                    qv[u] = l.qkv[u * 3 * inner + j]; kv[u] = l.qkv[u * 3 * inner + inner + j]; dov[u] = d_o[u * inner + j];
+                    dk[u] = 0.f; dv[u] = 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < MAXN; ++r) {
+                    float ds[MAXN], pr[MAXN];
+                    const float* dsr = dp + (h * MAXN + r) * MAXN;
+                    const float* prr = l.p + (h * MAXN + r) * MAXN;
+#pragma unroll
+                    for (int u = 0; u < MAXN; u += 4) {
+                        const float4 x = *reinterpret_cast<const float4*>(dsr + u), y = *reinterpret_cast<const float4*>(prr + u);
+                        ds[u] = x.x; ds[u + 1] = x.y; ds[u + 2] = x.z; ds[u + 3] = x.w;
+                        pr[u] = y.x; pr[u + 1] = y.y; pr[u + 2] = y.z; pr[u + 3] = y.w;
+                    }
+                    float dq = 0.f;
+#pragma unroll
+                    for (int u = 0; u < MAXN; ++u) {
+                        dq += ds[u] * kv[u];              // dS[r][u] k_u
+                        dk[u] += ds[u] * qv[r];           // dS[r][u] q_r   -> dk[u], summed over r
+                        dv[u] += pr[u] * dov[r];          // p[r][u] do_r   -> dv[u]
+                    }
+                    dqkv[r * 3 * inner + j] = dq * a.scale;
+                }
+#pragma unroll
+                for (int u = 0; u < MAXN; ++u) {
+                    dqkv[u * 3 * inner + inner + j] = dk[u] * a.scale;
+                    dqkv[u * 3 * inner + 2 * inner + j] = dv[u];
+                }
             }
-            dqkv[t * 3 * inner + j] = dq * a.scale;
-            dqkv[t * 3 * inner + inner + j] = dk * a.scale;
-            dqkv[t * 3 * inner + 2 * inner + j] = dv;
+        } else {
+            for (int i = tid; i < n * inner; i += blockDim.x) {
+                const int t = i / inner, j = i % inner, h = j / a.dh;
+                float dq = 0.f, dk = 0.f, dv = 0.f;
+                for (int s = 0; s < n; ++s) {
+                    dq += dp[(h * n + t) * n + s] * l.qkv[s * 3 * inner + inner + j];      // dS[t][s] k_s
+                    dk += dp[(h * n + s) * n + t] * l.qkv[s * 3 * inner + j];              // dS[s][t] q_s
+                    dv += l.p[(h * n + s) * n + t] * d_o[s * inner + j];                   // p[s][t] do_s
+                }
+                dqkv[t * 3 * inner + j] = dq * a.scale;
+                dqkv[t * 3 * inner + inner + j] = dk * a.scale;
+                dqkv[t * 3 * inner + 2 * inner + j] = dv;
+            }
         }
         __syncthreads();
+        ENC_T(7);
         // dxn = dqkv Wqkv   (K = 3*inner, split)
         ksplit_rows(dqkv, 3 * inner, a.wqkv + ps, D, 1, 3 * inner, n, l.red);
         if (tid < n * D) dxn[tid] = l.red[tid];
         __syncthreads();
+        ENC_T(8);
         // LayerNorm-1 backward + residual -> gradient of the layer input (next iteration's dx2)
         float dxin = 0.f;
         if (tid < n * D) {
@@ -433,10 +553,12 @@ __device__ __forceinline__ void enc_bwd_body(const EncArgs& a, const int b, floa
             a.r_ln[(((size_t)ly * a.B + b) * 4 + which) * D + c] = s;
         }
         __syncthreads();
+        ENC_T(9);
         if (tid < n * D) dx2[tid] = dxin;
     }
     __syncthreads();
     if (tid < n * D) a.y[(size_t)b * n * D + tid] = dx2[tid];
+    ENC_T(11);
 }
 __global__ __launch_bounds__(ENC_THREADS) void encoder_bwd_kernel(EncArgs a) {
     extern __shared__ float sm[];
@@ -493,9 +615,12 @@ __device__ __forceinline__ void enc_wgrad_body(const EncWgArgs& a, const int bx,
     if (mode == 1) {
         A += (size_t)ly * R * wa;
         Bm += (size_t)ly * R * wb;
+        // (16 rows' loads in flight: the plain loop is 64 rounds of dependent L2 latency, 22 us for a 12 MFLOP launch)
+#pragma unroll 16
         for (int r = rg; r < R; r += 4) s += A[(size_t)r * wa + ia] * Bm[(size_t)r * wb + ib];
     } else if (mode == 2) {
         A += (size_t)ly * R * wa;
+#pragma unroll 16
         for (int r = rg; r < R; r += 4) s += A[(size_t)r * wa + ia];
     } else if (mode == 3) {
         for (int b = rg; b < a.B; b += 4) s += a.r_ln[(((size_t)ly * a.B + b) * 4 + ia) * D + ib];
@@ -686,3 +811,7 @@ extern "C" int dh_encoder_bwd(const float* dy, float* dx, const float* saved_inp
     DH_CHECK_LAUNCH("encoder_bwd");
     return 0;
 }
+
+#ifdef ENC_TIMING
+extern "C" int dh_debug_enct(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_enct), (size_t)n * 8); }
+#endif
