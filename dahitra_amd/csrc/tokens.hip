@@ -559,12 +559,28 @@ __device__ __forceinline__ void xattn_prep_mfma_body(PrepMArgs m, const uint3 bi
     bf16* vo = reinterpret_cast<bf16*>(a.vo) + (size_t)s * a.HLP * D;
     bf16* voT = reinterpret_cast<bf16*>(a.voT) + (size_t)s * a.HLP * D;
     for (int h = wv; h < a.heads; h += 4) {
-        f32x4 kb[NBLK], vb[NBLK];
+        // every weight fragment of the head is requested before the first product: the stores below may alias the weights for all
+        // the compiler knows, so loads placed at their use sat behind them -- four L2 round trips per head in a 16-workgroup launch
+        s16x8 kA[NBLK], vA[NBLK], qA[2][NKS], oA[2][NKS];
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
             const int hd = h * DH + b * 16 + pl;                     // A row of this lane
-            kb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wk + (size_t)hd * D, g), bmn, zero4, 0, 0, 0);
-            vb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wv + (size_t)hd * D, g), bmn, zero4, 0, 0, 0);
+            kA[b] = frag32(m.wk + (size_t)hd * D, g);
+            vA[b] = frag32(m.wv + (size_t)hd * D, g);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int c_row = rb * 16 + pl;                      // A row of this lane: output channel
+                qA[rb][ks] = frag32(m.wqT + (size_t)c_row * inner + h * DH + ks * 32, g);
+                oA[rb][ks] = frag32(m.wo + (size_t)c_row * inner + h * DH + ks * 32, g);
+            }
+        f32x4 kb[NBLK], vb[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            kb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kA[b], bmn, zero4, 0, 0, 0);
+            vb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vA[b], bmn, zero4, 0, 0, 0);
         }
         // saved for the backward: k, v [S][L][inner] fp32 (this lane: 4 consecutive inner indices of its token)
 #pragma unroll
@@ -579,11 +595,10 @@ __device__ __forceinline__ void xattn_prep_mfma_body(PrepMArgs m, const uint3 bi
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             f32x4 aq = zero4, ao = zero4;
-            const int c_row = rb * 16 + pl;                          // A row of this lane: output channel
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                aq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wqT + (size_t)c_row * inner + h * DH + ks * 32, g), kB[ks], aq, 0, 0, 0);
-                ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wo + (size_t)c_row * inner + h * DH + ks * 32, g), vB[ks], ao, 0, 0, 0);
+                aq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qA[rb][ks], kB[ks], aq, 0, 0, 0);
+                ao = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oA[rb][ks], vB[ks], ao, 0, 0, 0);
             }
             const int hl = h * L + l, c0 = rb * 16 + g * 4;          // this lane: channels c0 .. c0 + 3 of row hl
             float qv[4], ov[4];
@@ -786,12 +801,27 @@ __device__ __forceinline__ void xattn_prep_bwd_mfma_body(PrepBwdMArgs m, const u
             o1[j] = dvoT[(size_t)(16 + g * 4 + j) * a.HLP + hl];
         }
         const s16x8 bdo = ppack8(o0, o1);
-        f32x4 dkb[NBLK], dvb[NBLK];
+        // (every weight fragment of the head requested before the first product, as in the forward: the dk / dv stores may alias them)
+        s16x8 qA[NBLK], oA[NBLK], kA[NKS][2], vA[NKS][2];
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
             const int hd = h * DH + b * 16 + pl;
-            dkb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wq + (size_t)hd * D, g), bdq, zero4, 0, 0, 0);
-            dvb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.woT + (size_t)hd * D, g), bdo, zero4, 0, 0, 0);
+            qA[b] = frag32(m.wq + (size_t)hd * D, g);
+            oA[b] = frag32(m.woT + (size_t)hd * D, g);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const size_t wo_ = (size_t)(rb * 16 + pl) * inner + h * DH + ks * 32;
+                kA[ks][rb] = frag32(m.wkT + wo_, g);
+                vA[ks][rb] = frag32(m.wvT + wo_, g);
+            }
+        f32x4 dkb[NBLK], dvb[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            dkb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qA[b], bdq, zero4, 0, 0, 0);
+            dvb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oA[b], bdo, zero4, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) dkb[b][j] *= a.scale;
             const size_t o = ((size_t)s * L + l) * inner + h * DH + b * 16 + g * 4;
@@ -803,9 +833,8 @@ __device__ __forceinline__ void xattn_prep_bwd_mfma_body(PrepBwdMArgs m, const u
             const s16x8 dkB = ppack8(dkb[2 * ks], dkb[2 * ks + 1]), dvB = ppack8(dvb[2 * ks], dvb[2 * ks + 1]);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                const size_t wo_ = (size_t)(rb * 16 + pl) * inner + h * DH + ks * 32;
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wkT + wo_, g), dkB, acc[rb], 0, 0, 0);
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag32(m.wvT + wo_, g), dvB, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kA[ks][rb], dkB, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vA[ks][rb], dvB, acc[rb], 0, 0, 0);
             }
         }
     }
@@ -986,26 +1015,37 @@ __device__ __forceinline__ void xattn_prep_wgrad_mfma_body(PrepWgArgs a, const u
     const float* colsrc = which == 0 ? a.k : (which == 1 ? a.dk : (which == 2 ? a.dv : a.v));
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[2] = {zero4, zero4};
+    // the tiles of step s0 + 8 are requested before the products of step s0 (registers: three 16-byte pieces per lane): a step was
+    // one exposed L2 round trip + two barriers, 8 steps for 64 images in a 32-workgroup launch
+    float4 cv[2], rv;
+    auto request = [&](int s0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {       // col tile: 32 token rows x 64 inner indices (two 16-byte pieces per thread)
+            const int r = (tid >> 4) + 16 * i, q = tid & 15;
+            cv[i] = *reinterpret_cast<const float4*>(colsrc + ((size_t)(s0 * L + r)) * inner + hd0 + q * 4);
+        }
+        {                                   // row tile: 32 token rows x 32 channels
+            const int r = tid >> 3, q = tid & 7, s = s0 + (r >> 2), l = r & 3;
+            if (which == 0) rv = *reinterpret_cast<const float4*>(a.dkq + ((size_t)s * a.HLP + h * L + l) * D + q * 4);
+            else if (which == 3) {
+                const float* p = a.dvoT + ((size_t)s * D + q * 4) * a.HLP + h * L + l;
+                rv = make_float4(p[0], p[a.HLP], p[2 * a.HLP], p[3 * a.HLP]);
+            } else rv = *reinterpret_cast<const float4*>(a.mn + ((size_t)s * L + l) * D + q * 4);
+        }
+    };
+    request(0);
     for (int s0 = 0; s0 < a.S; s0 += 8) {
-        // col tile: 32 token rows x 64 inner indices (two 16-byte pieces per thread)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = (tid >> 4) + 16 * i, q = tid & 15;
-            const float4 v = *reinterpret_cast<const float4*>(colsrc + ((size_t)(s0 * L + r)) * inner + hd0 + q * 4);
-            *reinterpret_cast<uint2*>(colT + r * CP + q * 8) = make_uint2(f2bf2(v.x, v.y), f2bf2(v.z, v.w));
+            *reinterpret_cast<uint2*>(colT + r * CP + q * 8) = make_uint2(f2bf2(cv[i].x, cv[i].y), f2bf2(cv[i].z, cv[i].w));
         }
-        // row tile: 32 token rows x 32 channels
         {
-            const int r = tid >> 3, q = tid & 7, s = s0 + (r >> 2), l = r & 3;
-            float4 v;
-            if (which == 0) v = *reinterpret_cast<const float4*>(a.dkq + ((size_t)s * a.HLP + h * L + l) * D + q * 4);
-            else if (which == 3) {
-                const float* p = a.dvoT + ((size_t)s * D + q * 4) * a.HLP + h * L + l;
-                v = make_float4(p[0], p[a.HLP], p[2 * a.HLP], p[3 * a.HLP]);
-            } else v = *reinterpret_cast<const float4*>(a.mn + ((size_t)s * L + l) * D + q * 4);
-            *reinterpret_cast<uint2*>(rowT + r * RP + q * 8) = make_uint2(f2bf2(v.x, v.y), f2bf2(v.z, v.w));
+            const int r = tid >> 3, q = tid & 7;
+            *reinterpret_cast<uint2*>(rowT + r * RP + q * 8) = make_uint2(f2bf2(rv.x, rv.y), f2bf2(rv.z, rv.w));
         }
         __syncthreads();
+        if (s0 + 8 < a.S) request(s0 + 8);
         const s16x8 fa = wg_tile_frag(colT, CP, wv, pl, g);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
