@@ -155,7 +155,8 @@ __device__ __forceinline__ void dh_reduce_partials_body(const float* __restrict_
         // four independent partial sums: the row loop is otherwise one chain of dependent-latency loads
         double s1 = 0.0, s2 = 0.0, s3 = 0.0;
         long t = ph;
-        for (; t + 24 < nt; t += 32) {
+#pragma unroll 4
+        for (; t + 24 < nt; t += 32) {      // (16 loads in flight; a single output -- the loss -- is 8 lanes x 128 rows: 10 us at four)
             s += (double)partial[t * n + i];
             s1 += (double)partial[(t + 8) * n + i];
             s2 += (double)partial[(t + 16) * n + i];

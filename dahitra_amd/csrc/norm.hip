@@ -36,7 +36,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int ntiles
         const float* p1 = partial + ((size_t)1 * CP + c) * ntiles + (size_t)g * tpg;
         const int step = 64 * wpg;
         int t = slice * 64 + lane;
-        for (; t + step < tpg; t += 2 * step) {
+#pragma unroll 4
+        for (; t + step < tpg; t += 2 * step) {      // (16 loads in flight: classifier.1 has 32 channels x 16 K tiles, 14.5 us at four)
             s += (double)p0[t]; q += (double)p1[t];
             s2 += (double)p0[t + step]; q2 += (double)p1[t + step];
         }

@@ -283,7 +283,8 @@ __device__ __forceinline__ void tok_dpos_body(const float* __restrict__ dtok_cat
     const int i = bx * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dtok_cat[(size_t)b * n + i];
+#pragma unroll 16
+    for (int b = 0; b < B; ++b) s += dtok_cat[(size_t)b * n + i];       // (one workgroup: the loads in flight, the adds in order)
     if (accumulate) dpos[i] += s; else dpos[i] = s;
 }
 
@@ -501,6 +502,13 @@ __device__ __forceinline__ void st4bf(bf16* p, const float (&v)[4]) {
     *reinterpret_cast<uint2*>(p) = make_uint2(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]));
 }
 
+// -DXP_TIMING (debug builds only, tools/xprep_timeline.py): wall-clock stamps of lane 0 of wave 0
+#ifdef XP_TIMING
+__device__ long long g_xpt[256 * 16];
+#define XP_T(k) do { if (threadIdx.x == 0) g_xpt[bid.x * 16 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define XP_T(k) do { } while (0)
+#endif
 template <int DH>        // dim_head: 32 or 64
 __device__ __forceinline__ void xattn_prep_mfma_body(PrepMArgs m, const uint3 bid) {
     PrepArgs& a = m.a;
@@ -518,6 +526,7 @@ __device__ __forceinline__ void xattn_prep_mfma_body(PrepMArgs m, const uint3 bi
         a.vo = reinterpret_cast<bf16*>(a.vo) + ly * a.S * a.HLP * D; a.voT = reinterpret_cast<bf16*>(a.voT) + ly * a.S * a.HLP * D;
     }
     // column pl of the MFMAs = token l of image s
+    XP_T(0);
     const int s = bid.x * 4 + (pl >> 2), l = pl & 3;
     const float* tok = reinterpret_cast<const float*>(a.tok) + (size_t)(s % a.B) * a.tok_bstride + (size_t)(s / a.B) * a.tok_sstride + l * D;
     float x[2][4], mnv[2][4];
@@ -553,6 +562,7 @@ __device__ __forceinline__ void xattn_prep_mfma_body(PrepMArgs m, const uint3 bi
         if (g == 0) { a.mstats[((size_t)s * L + l) * 2] = mu; a.mstats[((size_t)s * L + l) * 2 + 1] = rstd; }
     }
     const s16x8 bmn = ppack8(mnv[0], mnv[1]);
+    XP_T(1);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     bf16* kq = reinterpret_cast<bf16*>(a.kq) + (size_t)s * a.HLP * D;
     bf16* kqT = reinterpret_cast<bf16*>(a.kqT) + (size_t)s * a.HLP * D;
@@ -582,6 +592,7 @@ __device__ __forceinline__ void xattn_prep_mfma_body(PrepMArgs m, const uint3 bi
             kb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kA[b], bmn, zero4, 0, 0, 0);
             vb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vA[b], bmn, zero4, 0, 0, 0);
         }
+        XP_T(2 + 4 * (h >> 2));
         // saved for the backward: k, v [S][L][inner] fp32 (this lane: 4 consecutive inner indices of its token)
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
@@ -592,6 +603,7 @@ __device__ __forceinline__ void xattn_prep_mfma_body(PrepMArgs m, const uint3 bi
         s16x8 kB[NKS], vB[NKS];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) { kB[ks] = ppack8(kb[2 * ks], kb[2 * ks + 1]); vB[ks] = ppack8(vb[2 * ks], vb[2 * ks + 1]); }
+        XP_T(3 + 4 * (h >> 2));
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             f32x4 aq = zero4, ao = zero4;
@@ -611,8 +623,10 @@ __device__ __forceinline__ void xattn_prep_mfma_body(PrepMArgs m, const uint3 bi
                 stf(kqT + (c0 + j) * a.HLP + hl, qv[j]);
                 stf(voT + (c0 + j) * a.HLP + hl, ov[j]);
             }
+            XP_T(4 + rb + 4 * (h >> 2));
         }
     }
+    XP_T(10);
     // rows hl >= heads * L of the HLP-row operands are zero
     if (HL < a.HLP) {
         const int pad = a.HLP - HL;
@@ -1617,3 +1631,7 @@ extern "C" int dh_self_attn_bwd(int dtype, const void* qkv, const float* attn, c
     DH_CHECK_LAUNCH("self_attn_bwd");
     return 0;
 }
+
+#ifdef XP_TIMING
+extern "C" int dh_debug_xpt(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_xpt), (size_t)n * 8); }
+#endif
