@@ -242,7 +242,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int bp
     double s1 = 0.0, s2 = 0.0;
     const float* p0 = partial + ((size_t)0 * C + c) * G * bpg + (size_t)g * bpg;
     const float* p1 = partial + ((size_t)1 * C + c) * G * bpg + (size_t)g * bpg;
-    for (int t = lane; t < bpg; t += 64) { s1 += (double)p0[t]; s2 += (double)p1[t]; }
+#pragma unroll 8
+    for (int t = lane; t < bpg; t += 64) { s1 += (double)p0[t]; s2 += (double)p1[t]; }      // (loads in flight; adds in order)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
     if (lane == 0) {
@@ -617,7 +618,8 @@ __global__ void bn_bwd_finalize_coef_kernel(const float* __restrict__ partial, i
     double s1 = 0.0, s2 = 0.0;
     const float* p0 = partial + ((size_t)0 * C + c) * G * bpg + (size_t)g * bpg;
     const float* p1 = partial + ((size_t)1 * C + c) * G * bpg + (size_t)g * bpg;
-    for (int t = lane; t < bpg; t += 64) { s1 += (double)p0[t]; s2 += (double)p1[t]; }
+#pragma unroll 8
+    for (int t = lane; t < bpg; t += 64) { s1 += (double)p0[t]; s2 += (double)p1[t]; }      // (loads in flight; adds in order)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
     if (lane == 0) {
