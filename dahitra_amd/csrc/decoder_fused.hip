@@ -975,11 +975,15 @@ extern "C" int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, cons
     return 0;
 }
 
-// rows per backward workgroup: 512 at most (every workgroup writes a PL::SIZE partial), fewer while that leaves less than the
-// two workgroups per CU the kernel is resident with; a multiple of 64 (one 16-pixel sub-tile per wave) that divides an image
+// rows per backward workgroup: 512 at most (every workgroup writes a PL::SIZE partial), fewer while that leaves less than 256
+// workgroups; a multiple of 64 (one 16-pixel sub-tile per wave) that divides an image.  Per layer a workgroup spends ~9.2 k cycles
+// outside its sub-tile loop (staging, parking and reducing the parameter-gradient partials, writing them: tools/dec_timeline.py)
+// against 5.5 k per sub-tile, so the small levels of a staged launch want rows, not workgroups: with 512 as the floor (two per
+// CU, the residency) the 32 x 32 / 16 x 16 levels ran 2 / 1 sub-tiles per wave and layer; 256: +0.7 % on the DAHiTra step (128: +0.4 %)
 static inline int dec_rows_per_block(long rows, int rows_per_image) {
+    static const long minblk = getenv("DAHITRA_DEC_BWD_MINBLK") ? atol(getenv("DAHITRA_DEC_BWD_MINBLK")) : 256;
     int rpb = 512;
-    while (rpb > 64 && (rows_per_image % rpb || rows / rpb < 512)) rpb >>= 1;
+    while (rpb > 64 && (rows_per_image % rpb || rows / rpb < minblk)) rpb >>= 1;
     return rpb;
 }
 
