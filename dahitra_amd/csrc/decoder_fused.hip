@@ -980,9 +980,11 @@ extern "C" int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, cons
 // outside its sub-tile loop (staging, parking and reducing the parameter-gradient partials, writing them: tools/dec_timeline.py)
 // against 5.5 k per sub-tile, so the small levels of a staged launch want rows, not workgroups: with 512 as the floor (two per
 // CU, the residency) the 32 x 32 / 16 x 16 levels ran 2 / 1 sub-tiles per wave and layer; 256: +0.7 % on the DAHiTra step (128: +0.4 %)
-static inline int dec_rows_per_block(long rows, int rows_per_image) {
+// MLP = 64 (one workgroup per CU at 344 registers: 256 resident) may take 1024 rows -- switch DAHITRA_DEC_BWD_MAXRPB64 (experiment)
+static inline int dec_rows_per_block(long rows, int rows_per_image, int mlp) {
     static const long minblk = getenv("DAHITRA_DEC_BWD_MINBLK") ? atol(getenv("DAHITRA_DEC_BWD_MINBLK")) : 256;
-    int rpb = 512;
+    static const int max64 = getenv("DAHITRA_DEC_BWD_MAXRPB64") ? atoi(getenv("DAHITRA_DEC_BWD_MAXRPB64")) : 512;
+    int rpb = mlp == 64 ? max64 : 512;
     while (rpb > 64 && (rows_per_image % rpb || rows / rpb < minblk)) rpb >>= 1;
     return rpb;
 }
@@ -1000,7 +1002,7 @@ extern "C" int dh_decoder_batch_end(void* stream) { const int rc = dec_batch_flu
 extern "C" int dh_decoder_batch_abort() { g_db.on = false; dec_batch_clear(); return 0; }
 
 extern "C" long dh_decoder_layer_bwd_workspace_size(long rows, int rows_per_image, int mlp) {
-    const long nblk = rows / dec_rows_per_block(rows, rows_per_image);
+    const long nblk = rows / dec_rows_per_block(rows, rows_per_image, mlp);
     return nblk * (mlp == 64 ? PL<64>::SIZE : PL<32>::SIZE) * 4;
 }
 
@@ -1023,7 +1025,7 @@ extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, con
     a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2; a.w1T = (const bf16*)w1T; a.w2T = (const bf16*)w2T;
     a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
     a.partial = reinterpret_cast<float*>(workspace);
-    a.rows_per_image = rows_per_image; a.rows_per_block = dec_rows_per_block(rows, rows_per_image); a.rows = rows; a.eps = eps;
+    a.rows_per_image = rows_per_image; a.rows_per_block = dec_rows_per_block(rows, rows_per_image, mlp); a.rows = rows; a.eps = eps;
     const int nblk = (int)(rows / a.rows_per_block), bpi = rows_per_image / a.rows_per_block;
     const int images = (int)(rows / rows_per_image);
     if (g_db.on && !dw1) return dec_batch_record(&g_db.b[mlp == 64], &g_db.nb[mlp == 64], a, nblk, ST(stream));
@@ -1106,7 +1108,7 @@ extern "C" int dh_decoder_stack_bwd(const void* x, const void* ys, const void* d
     a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2; a.w1T = (const bf16*)w1T; a.w2T = (const bf16*)w2T;
     a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
     a.partial = reinterpret_cast<float*>(workspace);
-    a.rows_per_image = rows_per_image; a.rows_per_block = dec_rows_per_block(rows, rows_per_image); a.rows = rows; a.eps = eps;
+    a.rows_per_image = rows_per_image; a.rows_per_block = dec_rows_per_block(rows, rows_per_image, mlp); a.rows = rows; a.eps = eps;
     a.depth = depth; a.act_ls = rows * D; a.kq_ls = kq_lstride; a.w_ls = w_lstride; a.par_ls = par_lstride;
     a.part_ls = dh_decoder_layer_bwd_workspace_size(rows, rows_per_image, mlp) / 4;
     const int nblk = (int)(rows / a.rows_per_block);
@@ -1130,7 +1132,7 @@ extern "C" int dh_decoder_stack_bwd_finalize(const void* workspace, int depth, l
                                              float* dln2_g, float* dln2_b, long grad_stride, float* dkq, float* dvoT, void* stream) {
     if (check_common(rows, rows_per_image, mlp)) return 1;
     DH_REQUIRE(depth >= 1 && workspace && dw1 && dkq && dvoT, "decoder_stack_bwd_finalize: bad arguments (depth %d)", depth);
-    const int rpb = dec_rows_per_block(rows, rows_per_image);
+    const int rpb = dec_rows_per_block(rows, rows_per_image, mlp);
     const int nblk = (int)(rows / rpb), bpi = rows_per_image / rpb, images = (int)(rows / rows_per_image);
     const float* partial = reinterpret_cast<const float*>(workspace);
     const long pstride = dh_decoder_layer_bwd_workspace_size(rows, rows_per_image, mlp) / 4, kstride = (long)images * 1024;
