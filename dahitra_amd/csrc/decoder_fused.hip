@@ -980,10 +980,11 @@ extern "C" int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, cons
 // outside its sub-tile loop (staging, parking and reducing the parameter-gradient partials, writing them: tools/dec_timeline.py)
 // against 5.5 k per sub-tile, so the small levels of a staged launch want rows, not workgroups: with 512 as the floor (two per
 // CU, the residency) the 32 x 32 / 16 x 16 levels ran 2 / 1 sub-tiles per wave and layer; 256: +0.7 % on the DAHiTra step (128: +0.4 %)
-// MLP = 64 (one workgroup per CU at 344 registers: 256 resident) may take 1024 rows -- switch DAHITRA_DEC_BWD_MAXRPB64 (experiment)
+// MLP = 64 (one workgroup per CU at 344 registers: 256 resident) takes up to 1024 rows: 256 workgroups in ONE round instead of 512 in
+// two, half the per-layer overhead per row (+0.3 % on the s4 step; DAHITRA_DEC_BWD_MAXRPB64=512 restores the old rule)
 static inline int dec_rows_per_block(long rows, int rows_per_image, int mlp) {
     static const long minblk = getenv("DAHITRA_DEC_BWD_MINBLK") ? atol(getenv("DAHITRA_DEC_BWD_MINBLK")) : 256;
-    static const int max64 = getenv("DAHITRA_DEC_BWD_MAXRPB64") ? atoi(getenv("DAHITRA_DEC_BWD_MAXRPB64")) : 512;
+    static const int max64 = getenv("DAHITRA_DEC_BWD_MAXRPB64") ? atoi(getenv("DAHITRA_DEC_BWD_MAXRPB64")) : 1024;
     int rpb = mlp == 64 ? max64 : 512;
     while (rpb > 64 && (rows_per_image % rpb || rows / rpb < minblk)) rpb >>= 1;
     return rpb;
