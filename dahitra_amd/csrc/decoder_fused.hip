@@ -73,7 +73,7 @@ __device__ __forceinline__ s16x8 pack8(const float (&a)[4], const float (&b)[4])
     r.u.w = f2bf2(b[2], b[3]);
     return r.v;
 }
-// A fragment of weight row `row`, logical k = koff + kappa(g, e): one 16-byte LDS read (rows staged by stage() in fragment order)
+// A fragment of weight row `row`, logical k = koff + kappa(g, e): one 16-byte LDS read (rows staged by stage_ld / stage_st in fragment order)
 __device__ __forceinline__ s16x8 lds_a(const unsigned short* base, int pitch, int row, int koff, int g) {
     U8 r;
     r.u = *reinterpret_cast<const uint4*>(base + row * pitch + koff + g * 8);
@@ -92,17 +92,40 @@ __device__ __forceinline__ float group4_sum(float v) {
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// cooperative copy of a [rows][cols] bf16 matrix (global, dense) into LDS with pitch, every 32-column block in fragment order:
-// logical columns 4q .. 4q+3 (q = 0..7) land at position 8 (q & 3) + 4 (q >> 2), i.e. kappa(g, e) at g * 8 + e
-__device__ __forceinline__ void stage(unsigned short* dst, int pitch, const bf16* src, int rows, int cols, int tid) {
-    const int vec = cols / 4;
-    for (int i = tid; i < rows * vec; i += 256) {
-        // 32-column rows: a ds_write_b64 lane group (16 lanes, banks modulo 32 dwords) covers two rows of 16 dwords, and rows r,
-        // r + 1 lie 24 dwords apart (pitch 48 elements): half of their banks coincide.  Rows r, r + 2 (48 dwords apart) do not:
-        // the groups take rows in the order 0 2 1 3 (bits 0 and 1 of the row index swapped; rows is a multiple of 4)
-        const int r0 = i / vec, q = i % vec, c = (q & ~7) * 4 + (q & 3) * 8 + ((q >> 2) & 1) * 4;
-        const int r = vec == 8 ? ((r0 & ~3) | ((r0 & 1) << 1) | ((r0 >> 1) & 1)) : r0;
-        *reinterpret_cast<uint2*>(dst + r * pitch + c) = *reinterpret_cast<const uint2*>(src + (size_t)r * cols + q * 4);
+// cooperative copy of a [ROWS][COLS] bf16 matrix (global, dense) into LDS with pitch, every 32-column block in fragment order:
+// logical columns 4q .. 4q+3 (q = 0..7) land at position 8 (q & 3) + 4 (q >> 2), i.e. kappa(g, e) at g * 8 + e.
+// 32-column rows: a ds_write_b64 lane group (16 lanes, banks modulo 32 dwords) covers two rows of 16 dwords, and rows r, r + 1
+// lie 24 dwords apart (pitch 48 elements): half of their banks coincide.  Rows r, r + 2 (48 dwords apart) do not: the groups
+// take rows in the order 0 2 1 3 (bits 0 and 1 of the row index swapped; ROWS is a multiple of 4).
+// Two phases with compile-time shapes: every matrix of a layer is REQUESTED (stage_ld, 8-byte pieces into
+// registers) before the first is committed (stage_st).  As one run-time-shaped loop per matrix it was load -> wait -> store per
+// matrix: seven L2 round trips in a row at the head of every layer of the backward (3.1 k of the ~9 k cycles a workgroup spends
+// per layer outside its sub-tile loop, tools/dec_timeline.py), four in the forward.
+template <int ROWS, int COLS> struct StageRegs { uint2 v[(ROWS * COLS / 4 + 255) / 256]; };
+template <int ROWS, int COLS>
+__device__ __forceinline__ void stage_ld(StageRegs<ROWS, COLS>& s, const bf16* src, int tid) {
+    constexpr int VEC = COLS / 4, N = (ROWS * VEC + 255) / 256;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int i = tid + k * 256;
+        if (ROWS * VEC % 256 == 0 || i < ROWS * VEC) {
+            const int r0 = i / VEC, q = i % VEC;
+            const int r = VEC == 8 ? ((r0 & ~3) | ((r0 & 1) << 1) | ((r0 >> 1) & 1)) : r0;
+            s.v[k] = *reinterpret_cast<const uint2*>(src + (size_t)r * COLS + q * 4);
+        }
+    }
+}
+template <int ROWS, int COLS>
+__device__ __forceinline__ void stage_st(unsigned short* dst, int pitch, const StageRegs<ROWS, COLS>& s, int tid) {
+    constexpr int VEC = COLS / 4, N = (ROWS * VEC + 255) / 256;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int i = tid + k * 256;
+        if (ROWS * VEC % 256 == 0 || i < ROWS * VEC) {
+            const int r0 = i / VEC, q = i % VEC, c = (q & ~7) * 4 + (q & 3) * 8 + ((q >> 2) & 1) * 4;
+            const int r = VEC == 8 ? ((r0 & ~3) | ((r0 & 1) << 1) | ((r0 >> 1) & 1)) : r0;
+            *reinterpret_cast<uint2*>(dst + r * pitch + c) = s.v[k];
+        }
     }
 }
 
@@ -179,10 +202,19 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& p, const int bid) {
         const bf16* xin = (!STACK || l == 0) ? p.x : p.ys + (l - 1) * p.act_ls;
         bf16* yout = STACK ? p.ys + l * p.act_ls : p.y;
         const long ko = STACK ? l * p.kq_ls : 0, wo = STACK ? l * p.w_ls : 0;
-        stage(sKq, WP, p.kq + ko + (size_t)img * 32 * D, 32, D, tid);
-        stage(sVoT, WP, p.voT + ko + (size_t)img * D * 32, D, 32, tid);
-        stage(sW1, WP, p.w1 + wo, MLP, D, tid);
-        stage(sW2, W2P, p.w2 + wo, D, MLP, tid);
+        {
+            StageRegs<32, D> rKq, rVoT;
+            StageRegs<MLP, D> rW1;
+            StageRegs<D, MLP> rW2;
+            stage_ld(rKq, p.kq + ko + (size_t)img * 32 * D, tid);
+            stage_ld(rVoT, p.voT + ko + (size_t)img * D * 32, tid);
+            stage_ld(rW1, p.w1 + wo, tid);
+            stage_ld(rW2, p.w2 + wo, tid);
+            stage_st(sKq, WP, rKq, tid);
+            stage_st(sVoT, WP, rVoT, tid);
+            stage_st(sW1, WP, rW1, tid);
+            stage_st(sW2, W2P, rW2, tid);
+        }
         // the seven parameter vectors: this lane's 8 (fb1: MLP / 4) channels, in registers for the whole layer.  (Read through
         // the pointers inside the loop they were 14 global loads per sub-tile: the store to y may alias them for all the compiler knows.)
         float cg1[2][4], cbe1[2][4], cbo[2][4], cg2[2][4], cbe2[2][4], cfb2[2][4], cfb1[MLP / 16][4];
@@ -196,13 +228,28 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& p, const int bid) {
 #pragma unroll
         for (int h = 0; h < MLP / 16; ++h) ld4(p.fb1 + po + h * 16 + g * 4, cfb1[h]);
         __syncthreads();
+        // x of the NEXT sub-tile is requested while this one is computed (raw bf16: 4 registers), as in the backward: a load at the
+        // head of the chain was waited for at memory latency in every round
+        uint2 nx[2];
+        auto request = [&](int ps) {
+            const long row = row0 + (ps * 4 + wv) * 16 + pl;
+            if (row < p.rows) {
+                const bf16* xr = xin + row * D;
+                nx[0] = *reinterpret_cast<const uint2*>(xr + g * 4);
+                nx[1] = *reinterpret_cast<const uint2*>(xr + 16 + g * 4);
+            }
+        };
+        request(0);
         for (int ps = 0; ps < nsub; ++ps) {
             const long row = row0 + (ps * 4 + wv) * 16 + pl;
             if (row >= p.rows) break;                  // (never splits a wave's MFMA: rows % 16 == 0 is required)
-            const bf16* xr = xin + row * D;
             float x[2][4], xh[2][4], xn[2][4];
-            ld4(xr + g * 4, x[0]);
-            ld4(xr + 16 + g * 4, x[1]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                x[h][0] = __uint_as_float(nx[h].x << 16); x[h][1] = __uint_as_float(nx[h].x & 0xffff0000u);
+                x[h][2] = __uint_as_float(nx[h].y << 16); x[h][3] = __uint_as_float(nx[h].y & 0xffff0000u);
+            }
+            if (ps + 1 < nsub) request(ps + 1);
             layer_norm(x, cg1, cbe1, p.eps, xh, xn);
             // dots -> softmax over the 4 keys of each head (lane-local)
             const s16x8 bxn = pack8(xn[0], xn[1]);
@@ -371,13 +418,25 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
         int ts = tid;
         if constexpr (STACK) asm volatile("" : "+v"(ts));
         const long ko = STACK ? l * p.kq_ls : 0, wo = STACK ? l * p.w_ls : 0, po = STACK ? l * p.par_ls : 0;
-        stage(sKq, WP, p.kq + ko + (size_t)img * 32 * D, 32, D, ts);
-        stage(sVoT, WP, p.voT + ko + (size_t)img * D * 32, D, 32, ts);
-        stage(sVo, WP, p.vo + ko + (size_t)img * 32 * D, 32, D, ts);
-        stage(sKqT, WP, p.kqT + ko + (size_t)img * D * 32, D, 32, ts);
-        stage(sW1, WP, p.w1 + wo, MLP, D, ts);
-        stage(sW2T, WP, p.w2T + wo, MLP, D, ts);
-        stage(sW1T, W1TP, p.w1T + wo, D, MLP, ts);
+        {
+            StageRegs<32, D> rKq, rVoT, rVo, rKqT;
+            StageRegs<MLP, D> rW1, rW2T;
+            StageRegs<D, MLP> rW1T;
+            stage_ld(rKq, p.kq + ko + (size_t)img * 32 * D, ts);
+            stage_ld(rVoT, p.voT + ko + (size_t)img * D * 32, ts);
+            stage_ld(rVo, p.vo + ko + (size_t)img * 32 * D, ts);
+            stage_ld(rKqT, p.kqT + ko + (size_t)img * D * 32, ts);
+            stage_ld(rW1, p.w1 + wo, ts);
+            stage_ld(rW2T, p.w2T + wo, ts);
+            stage_ld(rW1T, p.w1T + wo, ts);
+            stage_st(sKq, WP, rKq, ts);
+            stage_st(sVoT, WP, rVoT, ts);
+            stage_st(sVo, WP, rVo, ts);
+            stage_st(sKqT, WP, rKqT, ts);
+            stage_st(sW1, WP, rW1, ts);
+            stage_st(sW2T, WP, rW2T, ts);
+            stage_st(sW1T, W1TP, rW1T, ts);
+        }
         if (ts < 32) {
             sPar[ts] = p.g1[po + ts]; sPar[32 + ts] = p.be1[po + ts]; sPar[64 + ts] = p.bo[po + ts];
             sPar[96 + ts] = p.g2[po + ts]; sPar[128 + ts] = p.be2[po + ts];
