@@ -85,13 +85,15 @@ __device__ __forceinline__ void tok_stats_body(const float* __restrict__ logits,
     const int s = bx / L, l = bx % L, tid = threadIdx.x;
     const float* lg = logits + (size_t)s * HW * L + l;
     float m = -INFINITY;
-    for (int n = tid; n < HW; n += 256) m = fmaxf(m, lg[(size_t)n * L]);
+#pragma unroll 8
+    for (int n = tid; n < HW; n += 256) m = fmaxf(m, lg[(size_t)n * L]);        // (loads in flight; same order)
     m = wave_max(m);
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float e = 0.f;
+#pragma unroll 8
     for (int n = tid; n < HW; n += 256) e += __expf(lg[(size_t)n * L] - m);
     e = wave_sum(e);
     if ((tid & 63) == 0) red[tid >> 6] = e;
@@ -117,7 +119,8 @@ __device__ __forceinline__ void weighted_colsum(const T* __restrict__ xs, long n
     for (int l = 0; l < L; ++l)
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[l][c] = 0.f;
-    for (long n = n0 + ph; n < n1; n += 64) {
+#pragma unroll 4
+    for (long n = n0 + ph; n < n1; n += 64) {      // (four rows' loads in flight; the sums keep their order)
         float xv[8], wl[L];
 #pragma unroll
         for (int c = 0; c < 8; c += 4) {
