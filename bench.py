@@ -236,7 +236,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"],
+                    help="bf16 (throughput mode), fp32 (parity mode, exact-fp32 MFMA), bf16x3 (parity mode, split-bf16 matrix products)")
     ap.add_argument("--net", default=NET)
     ap.add_argument("--no-class-replay", action="store_true",
                     help="skip roofline.graph_replay (profiler runs: its launches would be counted into the kernel statistics)")

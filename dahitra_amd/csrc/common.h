@@ -15,6 +15,34 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define DH_DTYPE_F32 0
 #define DH_DTYPE_BF16 1
 
+// Split-bf16 forms of the fp32 mode (dh_set_f32_mma_mode): tensors stay fp32 in memory (T = f32x3 / f32x6 have float's size and
+// layout), but the matrix products of an fp32 launch run on the bf16 matrix cores.  While a tile is staged every operand element
+// x becomes NPL bf16 planes in LDS -- x = p0 + p1 (+ p2), p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1): 8 more
+// mantissa bits per plane, the remainders are exact in fp32 -- and a product a * b is the sum, in the fp32 accumulator, of the
+// v_mfma_f32_16x16x32_bf16 products a_i * b_j with i + j < NPL:
+//   f32x3  NPL = 2: a0 b0 + a1 b0 + a0 b1               unit roundoff ~2^-17   3/16 of the exact fp32 MFMA's cycles
+//   f32x6  NPL = 3: + a2 b0 + a1 b1 + a0 b2             unit roundoff ~2^-23   6/16
+// (fp32: 2^-24).  f32x6 serves the FORWARD products of the "bf16x3" compute mode -- the activation error is what the gradients
+// are sensitive to (measured: forward at 2^-17 puts the gradients 150x above their fp32 distance from the oracle, backward at
+// 2^-17 leaves them at it) -- f32x3 the data and weight gradients.
+struct f32x3 { float v; };
+struct f32x6 { float v; };
+template <typename T> struct Prec {
+    static constexpr int NPL = 1;                      // LDS planes per staged operand tile
+    static constexpr bool X3 = false;
+    static constexpr int CK = 64 / (int)sizeof(T);     // channels of one 64-byte LDS row
+};
+template <> struct Prec<f32x3> {
+    static constexpr int NPL = 2;
+    static constexpr bool X3 = true;
+    static constexpr int CK = 32;                       // one 64-byte bf16 row per plane
+};
+template <> struct Prec<f32x6> {
+    static constexpr int NPL = 3;
+    static constexpr bool X3 = true;
+    static constexpr int CK = 32;
+};
+
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 // fp32 -> bf16, round to nearest even: gfx950 converts two values per instruction (v_cvt_pk_bf16_f32).  The former
 // software rounding cost ~7 VALU + an exec-mask branch (NaN case) per value in every bf16 store of every kernel.
@@ -50,6 +78,14 @@ __device__ __forceinline__ void st4(bf16* p, const float (&o)[4]) {
     v.y = f2bf2(o[2], o[3]);
     *reinterpret_cast<uint2*>(p) = v;
 }
+__device__ __forceinline__ float ldf(const f32x3* p) { return p->v; }
+__device__ __forceinline__ void stf(f32x3* p, float v) { p->v = v; }
+__device__ __forceinline__ void ld4(const f32x3* p, float (&o)[4]) { ld4(reinterpret_cast<const float*>(p), o); }
+__device__ __forceinline__ void st4(f32x3* p, const float (&o)[4]) { st4(reinterpret_cast<float*>(p), o); }
+__device__ __forceinline__ float ldf(const f32x6* p) { return p->v; }
+__device__ __forceinline__ void stf(f32x6* p, float v) { p->v = v; }
+__device__ __forceinline__ void ld4(const f32x6* p, float (&o)[4]) { ld4(reinterpret_cast<const float*>(p), o); }
+__device__ __forceinline__ void st4(f32x6* p, const float (&o)[4]) { st4(reinterpret_cast<float*>(p), o); }
 // 8 consecutive elements for bf16 (16 B), 4 for fp32 (16 B): the 16-byte vector unit "V16" -- one dwordx4 per lane
 // (measured on the BatchNorm passes: no faster than 8-byte lanes, both sit at ~3.5-4 TB/s of mixed read/write).
 template <typename T> struct V16 { static constexpr int N = 16 / sizeof(T); };
@@ -87,6 +123,45 @@ template <> __device__ __forceinline__ uint4 pack16<bf16>(const float (&o)[8]) {
 }
 template <> __device__ __forceinline__ uint4 pack16<float>(const float (&o)[4]) {
     return make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
+}
+
+template <> __device__ __forceinline__ uint4 pack16<f32x3>(const float (&o)[4]) { return pack16<float>(o); }
+template <> __device__ __forceinline__ uint4 pack16<f32x6>(const float (&o)[4]) { return pack16<float>(o); }
+// the NPL bf16 planes of 8 fp32 values (see f32x3 / f32x6 above): one 16-byte piece per plane
+template <int NPL> __device__ __forceinline__ void split_bf16_planes(const float (&x)[8], uint4 (&pl)[NPL]) {
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = x[j];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+        pl[p] = pack16<bf16>(r);
+        if (p + 1 < NPL) {
+            float h[8];
+            unpack16(pl[p], h);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] -= h[j];
+        }
+    }
+}
+template <int NPL> __device__ __forceinline__ void split_bf16_planes(const uint4& a, const uint4& b, uint4 (&pl)[NPL]) {
+    const float x[8] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                        __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
+    split_bf16_planes<NPL>(x, pl);
+}
+// bf16x3 operand split of 8 fp32 values: hi = bf16(x) (round to nearest even), lo = bf16(x - hi) -- one 16-byte piece per
+// plane (x - hi is exact in fp32; 24 VALU instructions per 8 values)
+__device__ __forceinline__ void split_bf16x3(const float (&x)[8], uint4& hi, uint4& lo) {
+    hi = pack16<bf16>(x);
+    float h[8], r[8];
+    unpack16(hi, h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = x[j] - h[j];
+    lo = pack16<bf16>(r);
+}
+__device__ __forceinline__ void split_bf16x3(const uint4& a, const uint4& b, uint4& hi, uint4& lo) {
+    const float x[8] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                        __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
+    split_bf16x3(x, hi, lo);
 }
 
 // sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane of the row: four row-rotate adds on

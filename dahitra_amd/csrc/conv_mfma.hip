@@ -4,6 +4,39 @@
 
 int dh_conv_launch_bf16(const ConvArgs& a, int ks, int stride, hipStream_t st);
 int dh_conv_launch_f32(const ConvArgs& a, int ks, int stride, hipStream_t st);
+int dh_conv_launch_x3(const ConvArgs& a, int ks, int stride, hipStream_t st);      // conv_mfma_x3.hip
+int dh_conv_launch_x6(const ConvArgs& a, int ks, int stride, hipStream_t st);      // conv_mfma_x6.hip
+
+// How the matrix products of fp32 (DH_DTYPE_F32) launches are computed -- per host thread, read at launch time (so a recorded
+// graph keeps the form it was captured with):
+//   0  exact fp32 on v_mfma_f32_16x16x4_f32 (default);
+//   1  split-bf16, two planes (common.h f32x3): three v_mfma_f32_16x16x32_bf16 products per operand pair on (hi, lo) bf16
+//      splits formed while staging, unit roundoff 2^-17 -- tensors, accumulation and everything that is not a matrix product
+//      stay fp32;
+//   2  split-bf16, three planes (f32x6): six products, unit roundoff 2^-23 (convolutions / linears only; weight-gradient
+//      launches issued in this mode run form 1).
+// Launches whose input-channel count is not a multiple of 32 (the 16-channel space-to-depth stem) or whose planes do not fit
+// the LDS (form 2 at stride 2 with 3x3 taps) keep the exact form.
+// (DAHITRA_F32_MMA=bf16x3 makes mode 1 the initial value: the whole fp32 test suite can then run on the split form)
+static int f32_mma_env_default() {
+    const char* e = getenv("DAHITRA_F32_MMA");
+    return e && !strcmp(e, "bf16x3") ? 1 : (e && !strcmp(e, "bf16x6") ? 2 : 0);
+}
+static thread_local int g_f32_mma_mode = f32_mma_env_default();
+extern "C" int dh_set_f32_mma_mode(int mode) {
+    DH_REQUIRE(mode >= 0 && mode <= 2, "set_f32_mma_mode: mode %d (0 = exact fp32 MFMA, 1 / 2 = split-bf16 three- / six-product form)", mode);
+    g_f32_mma_mode = mode;
+    return 0;
+}
+extern "C" int dh_get_f32_mma_mode(void) { return g_f32_mma_mode; }
+// fp32 launch -> its kernel family under the current mode
+static int launch_f32_family(const ConvArgs& a, int ks, int stride, hipStream_t st) {
+    if (g_f32_mma_mode != 0 && a.Cin % 32 == 0) {
+        const int rc = g_f32_mma_mode == 2 ? dh_conv_launch_x6(a, ks, stride, st) : dh_conv_launch_x3(a, ks, stride, st);
+        if (rc != DH_CONV_NO_FIT) return rc;
+    }
+    return dh_conv_launch_f32(a, ks, stride, st);
+}
 // K-deep GEMM form of the 1x1 / stride-1 convolutions with >= 64 input channels (conv1x1_gemm.hip)
 bool dh_conv1x1_gemm_eligible(const ConvArgs& a, int ks, int stride, int dtype);
 int dh_conv1x1_gemm_launch(const ConvArgs& a, hipStream_t st);
@@ -63,7 +96,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
     if (dh_conv1x1_gemm_eligible(a, ks, stride, dtype)) return dh_conv1x1_gemm_launch(a, st);
     if (dh_conv_wreg_eligible(a, ks, stride, dtype)) return dh_conv_wreg_launch(a, st);
     if (dtype == DH_DTYPE_BF16) return dh_conv_launch_bf16(a, ks, stride, st);
-    return dh_conv_launch_f32(a, ks, stride, st);
+    return launch_f32_family(a, ks, stride, st);
 }
 
 // 3x3 / stride 1 / pad 1 convolution (bf16) over a channel concatenation that is never materialised, see ConvArgs::x_split /
@@ -129,7 +162,7 @@ extern "C" int dh_conv3x3_head_fwd(int dtype, const void* x, const void* w_packe
     a.tilesX = dh_cdiv(W, TW); a.tilesY = dh_cdiv(H, 4 * a.rw);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == DH_DTYPE_BF16) return dh_conv_launch_bf16(a, 3, 1, st);
-    return dh_conv_launch_f32(a, 3, 1, st);
+    return launch_f32_family(a, 3, 1, st);
 }
 
 // Data gradient of a 3x3 / pad-1 convolution whose INPUT is a bilinear x4 upsampled map (models/networks.py:387-389:

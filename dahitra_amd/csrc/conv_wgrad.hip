@@ -79,16 +79,24 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
     constexpr int HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     constexpr int TAPS = KS * KS;
     constexpr int NI = IT / 16;
-    constexpr bool WCI = CIG == 2 && sizeof(T) == 2 && IT == 32 && CTT == 64;       // see the MFMA loop
+    // bf16x3 (T = f32x3, common.h): fp32 tensors in memory, staged as TWO bf16 planes (hi | lo) of the bf16 layout; the
+    // bf16 fragment code below runs the three products ah * bh + al * bh + ah * bl
+    constexpr bool X3 = Prec<T>::X3;
+    constexpr int LE = X3 ? 2 : (int)sizeof(T);    // bytes per LDS element
+    constexpr int NPL = X3 ? 2 : 1;                // LDS planes
+    constexpr int LV = X3 ? 2 : 1;                 // 16-byte global loads per staged 16-byte LDS piece
+    static_assert(!(X3 && (DYT || !TR)), "bf16x3: transpose reads, no BatchNorm-backward-on-load form");
+    constexpr bool WCI = CIG == 2 && LE == 2 && IT == 32 && CTT == 64;       // see the MFMA loop
     // LDS pitches are ODD multiples of 32 B: a half-wave of ds_read_b64_tr_b16 then touches 8 consecutive
     // pixel rows x 32 B = 8 distinct bank windows of the 256-byte bank row (conflict-free)
-    constexpr int XP = lds_pitch(ITT * (int)sizeof(T));    // halo pitch (bytes)
-    constexpr int DP = lds_pitch(CT * (int)sizeof(T));     // dY tile pitch (bytes)
+    constexpr int XP = lds_pitch(ITT * LE);    // halo pitch (bytes)
+    constexpr int DP = lds_pitch(CT * LE);     // dY tile pitch (bytes)
+    constexpr int HPB = HH * HWD * XP, DPB = TH * TW * DP;       // bytes per halo / dY plane
     // (Two staging buffers -- commit of tile t+1 right after the MFMAs of tile t, one barrier per tile -- were measured and
     // change nothing: layer3 90.3 vs 89.5 us, and the 256-thread forms lose a resident workgroup to the second buffer.)
-    unsigned char* halo = smem;                      // [HH*HWD][XP]
-    unsigned char* dyt = smem + HH * HWD * XP;       // [128][DP]
-    float* bnp = reinterpret_cast<float*>(dyt + TH * TW * DP);      // in_scale: [in_groups][2][ITT] scale | shift
+    unsigned char* halo = smem;                      // [NPL][HH*HWD][XP]
+    unsigned char* dyt = smem + NPL * HPB;           // [NPL][128][DP]
+    float* bnp = reinterpret_cast<float*>(dyt + NPL * DPB);      // in_scale: [in_groups][2][ITT] scale | shift
 
     const int tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, cig = tid >> 8;
     const int pl = lane & 15, g = lane >> 4;
@@ -116,9 +124,9 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
 
     // Software pipeline: the global loads of tile t+1 are issued into registers before the MFMAs of tile t
     // and committed to LDS after them, so HBM/L2 latency hides under the matrix work (T14-style split stage).
-    constexpr int XQ = ITT * (int)sizeof(T) / 16, DQ = CT * (int)sizeof(T) / 16;
+    constexpr int XQ = ITT * LE / 16, DQ = CT * LE / 16;
     constexpr int NXV = (HH * HWD * XQ + NTHR - 1) / NTHR, NDV = (TH * TW * DQ + NTHR - 1) / NTHR;
-    uint4 rx[NXV], rd[NDV];
+    uint4 rx[NXV * LV], rd[NDV * LV];
     uint4 ry[DYT ? NDV : 1];
     unsigned d_okmask = 0;    // DYT: pieces of the fetched dY tile that exist (the others stay zero)
     // Everything about a 16-byte piece that does not depend on the tile is computed ONCE: its halo / tile position,
@@ -127,7 +135,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
     // no 64-bit products per piece).
     int x_hy[NXV], x_hx[NXV], x_mode[NXV];
     int d_py[NDV], d_px[NDV], d_mode[NDV];
-    constexpr int EPV = 16 / (int)sizeof(T);
+    constexpr int EPV = 16 / LE;
     const bool xal_ = ((p.Cin * (int)sizeof(T)) & 15) == 0 && ((p.CinPitch * (int)sizeof(T)) & 15) == 0;
     const bool dal_ = ((p.Cout * (int)sizeof(T)) & 15) == 0;
     {
@@ -187,8 +195,11 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
             for (int i = 0; i < NXV; ++i) {
                 const int iy = iy0 + x_hy[i], ix = ix0 + x_hx[i], lin = iy * p.W + ix;
                 const bool ok = x_mode[i] != 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && lin < p.in_npix;
-                const uint4 v = *reinterpret_cast<const uint4*>(xb + (ok ? (unsigned)lin * xps + (unsigned)xcb * (unsigned)sizeof(T) : 0u));
-                rx[i] = ok ? v : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int l = 0; l < LV; ++l) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(xb + (ok ? (unsigned)lin * xps + (unsigned)xcb * (unsigned)sizeof(T) : 0u) + 16 * l);
+                    rx[i * LV + l] = ok ? v : make_uint4(0, 0, 0, 0);
+                }
                 x_okmask |= ok ? (1u << i) : 0u;
             }
 #pragma unroll
@@ -197,15 +208,18 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
                 const int lin = (KS == 2 && p.phase_mode) ? (2 * oy + ph_a) * (2 * p.OW) + 2 * ox + ph_b : oy * p.OW + ox;
                 const bool ok = d_mode[i] != 0 && oy < p.OH && ox < p.OW && ((KS == 2 && p.phase_mode) || lin < p.npix);
                 const unsigned off = ok ? (unsigned)lin * dps + (unsigned)dcb * (unsigned)sizeof(T) : 0u;
-                const uint4 v = *reinterpret_cast<const uint4*>(db + off);
-                rd[i] = ok ? v : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int l = 0; l < LV; ++l) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(db + off + 16 * l);
+                    rd[i * LV + l] = ok ? v : make_uint4(0, 0, 0, 0);
+                }
                 if constexpr (DYT) {
                     ry[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(
                         reinterpret_cast<const T*>(p.dyt_y) + (size_t)n * p.OH * p.OW * p.Cout) + off);
                     d_okmask |= ok ? (1u << i) : 0u;
                 }
             }
-        } else {
+        } else if constexpr (!X3) {       // (bf16x3 launches have whole, aligned pieces: wgrad_x3_eligible)
             const T* xin = reinterpret_cast<const T*>(p.x) + (size_t)n * p.H * p.W * p.CinPitch +
                            ((long)iy0 * p.W + ix0) * p.CinPitch;
             const T* dyin = reinterpret_cast<const T*>(p.dy) + (size_t)n * p.OH * p.OW * p.Cout +
@@ -241,6 +255,42 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
         f_n += dn;
     };
     auto commit = [&]() {
+        if constexpr (X3) {
+            float sc[8], sh[8];
+            if (p.in_scale) {
+                const float* sp = bnp + c_bng * 2 * ITT + (tid % XQ) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; j += 4) {
+                    *reinterpret_cast<float4*>(sc + j) = *reinterpret_cast<const float4*>(sp + j);
+                    *reinterpret_cast<float4*>(sh + j) = *reinterpret_cast<const float4*>(sp + ITT + j);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NXV; ++i) {
+                const int idx = tid + i * NTHR;
+                if (idx >= HH * HWD * XQ) continue;
+                float v[8];
+                unpack16(rx[2 * i], reinterpret_cast<float(&)[4]>(v[0]));
+                unpack16(rx[2 * i + 1], reinterpret_cast<float(&)[4]>(v[4]));
+                if (p.in_scale && ((x_okmask >> i) & 1u)) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * sc[j] + sh[j], 0.f);
+                }
+                uint4 hi, lo;
+                split_bf16x3(v, hi, lo);
+                *reinterpret_cast<uint4*>(halo + (idx / XQ) * XP + (idx % XQ) * 16) = hi;
+                *reinterpret_cast<uint4*>(halo + HPB + (idx / XQ) * XP + (idx % XQ) * 16) = lo;
+            }
+#pragma unroll
+            for (int i = 0; i < NDV; ++i) {
+                const int idx = tid + i * NTHR;
+                if (idx >= TH * TW * DQ) continue;
+                uint4 hi, lo;
+                split_bf16x3(rd[2 * i], rd[2 * i + 1], hi, lo);
+                *reinterpret_cast<uint4*>(dyt + (idx / DQ) * DP + (idx % DQ) * 16) = hi;
+                *reinterpret_cast<uint4*>(dyt + DPB + (idx / DQ) * DP + (idx % DQ) * 16) = lo;
+            }
+        } else {
         if (p.in_scale) {          // x = relu(x * scale + shift) on its way into LDS; this thread's pieces share their channels
             float sc[EPV], sh[EPV];
             const float* sp = bnp + c_bng * 2 * ITT + (tid % XQ) * EPV;
@@ -289,6 +339,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
             const int idx = tid + i * NTHR;
             if (idx < TH * TW * DQ) *reinterpret_cast<uint4*>(dyt + (idx / DQ) * DP + (idx % DQ) * 16) = rd[i];
         }
+        }      // !X3
     };
 
     if (p.in_scale) {
@@ -313,7 +364,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
         __syncthreads();
         if (tile + p.splitk < ntiles) fetch();
 
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (LE == 4) {
             // 4 pixels per MFMA: lane (pl, g) supplies pixel k0+g, channel pl
             for (int k0 = kq * KPW; k0 < (kq + 1) * KPW; k0 += 4) {
                 const int k = k0 + g, row = k / TW, col = k % TW;
@@ -349,14 +400,14 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
                 : halo + (kq * (KPW / TW) * STRIDE * HWD + c0 * STRIDE) * XP + pl * 2) + b_ci * 2;
 #pragma unroll
             for (int kk = 0; kk < KPW; kk += 32) {
-                auto load_a = [&](int cofs) {          // dY fragment of the co sub-tile `cofs` bytes further
+                auto load_a = [&](int cofs, int plane = 0) {          // dY fragment of the co sub-tile `cofs` bytes further
                     F8 a;
                     if constexpr (TR) {
                         // lane p of each 16-lane group points at the 8-byte piece (pixel p/4, channels 4*(p%4)..+3)
                         a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(a_base + kk * DP + cofs));
+                            (__attribute__((address_space(3))) s16x4*)(a_base + plane * DPB + kk * DP + cofs));
                         a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(a_base + (kk + TW) * DP + cofs));
+                            (__attribute__((address_space(3))) s16x4*)(a_base + plane * DPB + (kk + TW) * DP + cofs));
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
@@ -364,13 +415,13 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
                     }
                     return a;
                 };
-                auto load_b = [&](int hp, int cofs) {  // x fragment at halo pixel offset hp, ci sub-tile `cofs` bytes further
+                auto load_b = [&](int hp, int cofs, int plane = 0) {  // x fragment at halo pixel offset hp, ci sub-tile `cofs` bytes further
                     F8 b;
                     if constexpr (TR) {
                         b.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(b_base + hp * XP + cofs));
+                            (__attribute__((address_space(3))) s16x4*)(b_base + plane * HPB + hp * XP + cofs));
                         b.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(b_base + (hp + STRIDE * HWD) * XP + cofs));
+                            (__attribute__((address_space(3))) s16x4*)(b_base + plane * HPB + (hp + STRIDE * HWD) * XP + cofs));
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
@@ -379,7 +430,40 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
                     }
                     return b;
                 };
-                if constexpr (WCI) {
+                if constexpr (X3 && WCI) {
+                    const F8 a0 = load_a(0), a1 = load_a(32), a0l = load_a(0, 1), a1l = load_a(32, 1);
+#pragma unroll
+                    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < KS; ++kw) {
+                            const int hp = ((kk / TW) * STRIDE + kh * DIL) * HWD + kw * DIL;      // compile-time
+                            const F8 b = load_b(hp, 0), bl = load_b(hp, 0, 1);
+                            f32x4& c0_ = acc[kh * KS + kw][0];
+                            f32x4& c1_ = acc[kh * KS + kw][1];
+                            c0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, b.v, c0_, 0, 0, 0);
+                            c1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, b.v, c1_, 0, 0, 0);
+                            c0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l.v, b.v, c0_, 0, 0, 0);
+                            c1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l.v, b.v, c1_, 0, 0, 0);
+                            c0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, bl.v, c0_, 0, 0, 0);
+                            c1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, bl.v, c1_, 0, 0, 0);
+                        }
+                } else if constexpr (X3) {
+                    const F8 a = load_a(0), al = load_a(0, 1);
+#pragma unroll
+                    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < KS; ++kw) {
+                            const int hp = ((kk / TW) * STRIDE + kh * DIL) * HWD + kw * DIL;      // compile-time
+#pragma unroll
+                            for (int i = 0; i < NI; ++i) {
+                                const F8 b = load_b(hp, i * 32), bl = load_b(hp, i * 32, 1);
+                                f32x4& c_ = acc[kh * KS + kw][i];
+                                c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c_, 0, 0, 0);
+                                c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al.v, b.v, c_, 0, 0, 0);
+                                c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bl.v, c_, 0, 0, 0);
+                            }
+                        }
+                } else if constexpr (WCI) {
                     const F8 a0 = load_a(0), a1 = load_a(32);
 #pragma unroll
                     for (int kh = 0; kh < KS; ++kh)
@@ -962,7 +1046,8 @@ static int c32_batch_add(WgArgs& a, hipStream_t st) {
 template <typename T, int KS, int STRIDE, int IT, int DIL, int CT, int CIG = 1>
 int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
     constexpr int HH = (TH - 1) * STRIDE + (KS - 1) * DIL + 1, HWD = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
-    size_t lds = (size_t)HH * HWD * lds_pitch(IT * CIG * (int)sizeof(T)) + (size_t)TH * TW * lds_pitch(CT * (int)sizeof(T)) +
+    constexpr int LE = Prec<T>::X3 ? 2 : (int)sizeof(T), NPL = Prec<T>::X3 ? 2 : 1;      // LDS element bytes, planes (wg_body)
+    size_t lds = NPL * ((size_t)HH * HWD * lds_pitch(IT * CIG * LE) + (size_t)TH * TW * lds_pitch(CT * LE)) +
                  (a.in_scale ? (size_t)a.in_groups * 2 * IT * CIG * sizeof(float) : 0) +
                  (a.dyt_y ? (size_t)a.dyt_groups * 3 * CT * sizeof(float) : 0);
     if (CT < 64) {                                     // the end-of-kernel wave-group combine parks accumulators here
@@ -992,8 +1077,11 @@ int launch_ct(const WgArgs& a, bool tr, hipStream_t st) {
         }
     }
     if (a.dyt_y) DH_FAIL("conv_wgrad: the BatchNorm-backward-on-load form is built for the bf16 stem (4x4, 64 output channels)");
-    if (tr) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true, DIL, CT, CIG>);
-    return go(conv_wgrad_kernel<T, KS, STRIDE, IT, false, DIL, CT, CIG>);
+    if constexpr (Prec<T>::X3) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true, DIL, CT, CIG>);
+    else {
+        if (tr) return go(conv_wgrad_kernel<T, KS, STRIDE, IT, true, DIL, CT, CIG>);
+        return go(conv_wgrad_kernel<T, KS, STRIDE, IT, false, DIL, CT, CIG>);
+    }
 }
 // 3x3 layers with >= 64 input channels and a 64-wide co tile run the 512-thread, 64co x 64ci variant (CIG = 2)
 static inline bool wide_ci3x3(int Cin, int CoutUse, int ks) {
@@ -1031,6 +1119,14 @@ int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
 }
 
 }  // namespace
+
+// dh_set_f32_mma_mode(1) (conv_mfma.hip): fp32 launches with whole, 16-byte aligned 8-channel pieces on both operands take the
+// split-bf16 three-product form (wg_body<f32x3>); the others keep the exact fp32 MFMA
+extern "C" int dh_get_f32_mma_mode(void);
+static inline bool wgrad_x3(int dtype, const WgArgs& a) {
+    static const bool skip = getenv("DAHITRA_X3_NO_WGRAD") != nullptr;      // experiment switch
+    return !skip && dtype == DH_DTYPE_F32 && dh_get_f32_mma_mode() != 0 && a.Cin % 8 == 0 && a.Cout % 8 == 0 && a.CinPitch % 4 == 0;
+}
 
 // split-K factor: one resident round of workgroups, never more slabs than pixel tiles
 extern "C" int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, int ks, int groups) {
@@ -1095,6 +1191,7 @@ static int conv2d_wgrad_impl(int dtype, const void* x, const void* dy, float* dw
     const bool batching = g_wsb.on;
     if (!defer) g_wsb.on = false;           // this call reduces right after its launch: never recorded into a batch
     int rc = dtype == DH_DTYPE_BF16 ? launch_all<bf16>(a, ks, stride, use_tr != 0, st)
+             : wgrad_x3(dtype, a)   ? launch_all<f32x3>(a, ks, stride, true, st)
                                     : launch_all<float>(a, ks, stride, false, st);
     g_wsb.on = batching;
     if (rc) return rc;
@@ -1224,7 +1321,8 @@ extern "C" int dh_conv2d_wgrad_phase(int dtype, const void* x, const void* dy, i
     a.direct = 0;
     a.npix = H * W; a.in_npix = H * W;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int rc = dtype == DH_DTYPE_BF16 ? launch_all<bf16>(a, 2, 1, use_tr != 0, st) : launch_all<float>(a, 2, 1, false, st);
+    const int rc = dtype == DH_DTYPE_BF16 ? launch_all<bf16>(a, 2, 1, use_tr != 0, st)
+                   : wgrad_x3(dtype, a)   ? launch_all<f32x3>(a, 2, 1, true, st) : launch_all<float>(a, 2, 1, false, st);
     if (rc) return rc;
     *splitk_out = a.splitk;
     return 0;

@@ -61,8 +61,18 @@ class CoarseRes:
 
 
 class Engine:
-    def __init__(self, net_G, dtype=torch.float32, use_tr=True, attn_fp8=False):
+    def __init__(self, net_G, dtype=torch.float32, use_tr=True, attn_fp8=False, mma_x3=False):
         self.net_G = net_G
+        # fp32 nets only (compute_dtype="bf16x3"): matrix products on the bf16 matrix cores as split-bf16 products
+        # (ops.set_f32_mma_mode, csrc/common.h f32x3 / f32x6).  The FORWARD takes the three-plane, six-product form (unit
+        # roundoff 2^-23): the gradients are ~20x more sensitive to activation error than the logits are -- with the forward
+        # at 2^-17 they sit 150x above their fp32 distance from the oracle (median 1.9e-3 vs 1.3e-5 on
+        # base_transformer_pos_s4), with only the BACKWARD at 2^-17 they stay at it (2.2e-5), measured on MI355X.  So data and
+        # weight gradients take the two-plane, three-product form.  DAHITRA_X3_FWD / DAHITRA_X3_BWD = 0 | 1 | 2 override
+        # the form of a pass (A/B switches).
+        self.mma_x3 = bool(mma_x3) and dtype == torch.float32
+        self.mma_fwd = int(os.environ.get("DAHITRA_X3_FWD", "2")) if self.mma_x3 else 0
+        self.mma_bwd = int(os.environ.get("DAHITRA_X3_BWD", "1")) if self.mma_x3 else 0
         # fp8 (OCP e4m3) MFMA operands in the fused decoder layers' forward products (BASELINE configs[4]); bf16 mode only
         self.attn_fp8 = bool(attn_fp8) or os.environ.get("DAHITRA_ATTN_FP8", "0") == "1"
         self.cfg = get_config(net_G)
@@ -843,6 +853,7 @@ class Engine:
 
     # ---- whole nets ------------------------------------------------------------------------------
     def forward(self, x1, x2, training, need_grad):
+        ops.set_f32_mma_mode(self.mma_fwd)        # library state per host thread: every entry point sets it
         self.training, self.need_grad = training, need_grad
         if need_grad and self.use_side and self.side is None and self.dtype == torch.bfloat16:
             self.side = ops.SideStream(x1.device)
@@ -868,6 +879,7 @@ class Engine:
         return bwd
 
     def backward(self, dlogits_nchw, bwd=None):
+        ops.set_f32_mma_mode(self.mma_bwd)
         if bwd is None:
             bwd, self._bwd = self._bwd, None
         if bwd is None:
@@ -886,6 +898,7 @@ class Engine:
     # from resnet.layer3 to the end of the arena is final (its split-K reduces have run) and can be all-reduced while
     # backward_second() computes the stem / layer1 / layer2 gradients.
     def backward_first(self, dlogits_nchw, bwd):
+        ops.set_f32_mma_mode(self.mma_bwd)
         split = getattr(bwd, "split", None)
         if split is None:
             raise RuntimeError("dahitra_amd: this net's backward has no split point")
@@ -917,6 +930,7 @@ class Engine:
             self.side.join()
 
     def backward_second(self):
+        ops.set_f32_mma_mode(self.mma_bwd)
         second, state = self._split_state
         self._split_state = None
         try:

@@ -11,9 +11,10 @@ backward run the HIP pipelines of dahitra_amd.engine.  Parameters live as views 
 arena per net (grad-carrying parameters first) so that the optimizer step and the data-parallel
 gradient all-reduce are single launches over contiguous memory.
 
-Compute type: args.compute_dtype / DAHITRA_DTYPE in {"fp32", "bf16"}.  fp32 is the parity mode
-(exact-fp32 MFMA); bf16 is the throughput mode (bf16 activations + MFMA, fp32 accumulation / master
-weights)."""
+Compute type: args.compute_dtype / DAHITRA_DTYPE in {"fp32", "bf16x3", "bf16"}.  fp32 is the parity mode
+(exact-fp32 MFMA); bf16x3 is the same fp32 pipeline with every matrix product on the bf16 matrix cores as
+three split-bf16 products (dh_set_f32_mma_mode: fp32 tensors, error 2^-17 per term -- the fast parity
+mode); bf16 is the throughput mode (bf16 activations + MFMA, fp32 accumulation / master weights)."""
 import math
 import os
 
@@ -25,7 +26,8 @@ from .. import _lib
 from ..engine import Engine
 from ..netspec import get_config, is_active, is_alias, is_buffer, state_spec
 
-_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+           "bf16x3": torch.float32}
 
 
 def get_scheduler(optimizer, args):
@@ -85,8 +87,10 @@ class CDNet(nn.Module):
         self.cfg = get_config(net_G)
         name = compute_dtype or os.environ.get("DAHITRA_DTYPE", "fp32")
         if name not in _DTYPES:
-            raise ValueError("compute dtype must be fp32 or bf16, got %r" % name)
+            raise ValueError("compute dtype must be fp32, bf16x3 or bf16, got %r" % name)
         self.compute_dtype = _DTYPES[name]
+        # fp32 tensors, split-bf16 matrix products (DAHITRA_F32_MMA=bf16x3: every fp32 net of the process, an A/B switch)
+        self.mma_x3 = name == "bf16x3" or (self.compute_dtype == torch.float32 and os.environ.get("DAHITRA_F32_MMA", "") == "bf16x3")
         self._spec = state_spec(net_G)
         for key, shape, role in self._spec:
             node = self
@@ -119,7 +123,7 @@ class CDNet(nn.Module):
         if attn_dtype == "fp8" and self.compute_dtype != torch.bfloat16:
             raise ValueError("attn_dtype='fp8' (fp8 MFMA operands in the decoder layers) needs compute_dtype='bf16'")
         self._engine = Engine(net_G, self.compute_dtype, use_tr=os.environ.get("DAHITRA_NO_TR", "0") != "1",
-                              attn_fp8=attn_dtype == "fp8")
+                              attn_fp8=attn_dtype == "fp8", mma_x3=self.mma_x3)
         self._arena = _Arena()
         self._anchor = None
         self.tokens_ = None      # attributes the reference stashes on the module (networks.py:373-374)

@@ -27,6 +27,33 @@ def dt(t):
         raise TypeError("dahitra_amd: unsupported activation dtype %s" % t.dtype)
 
 
+def set_f32_mma_mode(mode):
+    """dh_set_f32_mma_mode: 0 = exact fp32 MFMA, 1 = split-bf16 three-product form (two planes, unit roundoff 2^-17), 2 = the
+    six-product form (three planes, 2^-23) for the matrix products of every fp32 launch this host thread issues from now on
+    (the Engine sets it at each of its entry points: compute_dtype="bf16x3" = form 2 forward, form 1 backward)."""
+    _lib.check(_lib.lib().dh_set_f32_mma_mode(int(mode)), "dh_set_f32_mma_mode")
+
+
+def get_f32_mma_mode():
+    return int(_lib.lib().dh_get_f32_mma_mode())
+
+
+class f32_mma_mode:
+    """with ops.f32_mma_mode(1): ...  -- the mode for the block, the previous one restored after it"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_f32_mma_mode()
+        set_f32_mma_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_f32_mma_mode(self.prev)
+        return False
+
+
 def chunk_channels(dtype):
     """channels per 64-byte MFMA K-chunk: the granularity of Cin for dh_conv2d_fwd"""
     return 32 if dtype == torch.bfloat16 else 16

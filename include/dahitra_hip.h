@@ -80,6 +80,22 @@ int dh_conv2d_fwd_num_tiles(int N, int OH, int OW, int Cin, int ks, int stride);
  * (everything through the tap-oriented kernel); 1: wherever it can run.  Returns the previous mode.  Same reference call sites as dh_conv2d_fwd
  * (models/resnet.py:24-73: BasicBlock conv1 / conv2 and their input gradients). */
 int dh_conv_wreg_mode(int mode);
+/* How the matrix products of DH_F32 launches are computed (dh_conv2d_fwd, dh_conv3x3_head_fwd, dh_conv2d_wgrad* and the
+ * kernels that call them), per host thread, read when a launch is issued:
+ *   0 (default)  exact fp32: v_mfma_f32_16x16x4_f32;
+ *   1            split-bf16, two planes: while an operand tile is staged every fp32 element x becomes hi = bf16(x),
+ *                lo = bf16(x - hi) and a product is ah*bh + al*bh + ah*bl on v_mfma_f32_16x16x32_bf16 with fp32 accumulation
+ *                (unit roundoff 2^-17 against fp32's 2^-24; 3/16 of the exact form's matrix-core cycles);
+ *   2            split-bf16, three planes (x = p0 + p1 + p2, 8 mantissa bits each): the six products a_i*b_j, i + j < 3
+ *                (unit roundoff 2^-23; 6/16 of the cycles).  Convolution / linear launches only: a weight-gradient launch
+ *                issued in mode 2 runs form 1.
+ * Tensors, accumulators, statistics, everything that is not a matrix product, launches with Cin % 32 != 0 and launches
+ * whose staging planes would not fit the LDS are unchanged, so DH_F32 buffers, packs and workspaces are interchangeable
+ * between the modes.  The reference computes these products in fp32 (models/networks.py:358-392,
+ * models/help_funcs.py:66-114, loss.backward()): compute_dtype="bf16x3" (form 2 in the forward, form 1 in the backward)
+ * is the parity mode's fast form. */
+int dh_set_f32_mma_mode(int mode);
+int dh_get_f32_mma_mode(void);
 /* The backward of |a - b| -> nn.Upsample(4, 'bilinear') -> conv3x3 (models/networks.py:383-389; autograd's
  * upsample_bilinear2d_backward + convolution_backward input gradient) WITHOUT the fine-grid gradient tensor: the data-gradient
  * launch of the 3x3 convolution (dy [N][H][W][K] bf16, w_packed = its data-gradient pack [9][32][K]) reduces each 8x16 tile

@@ -44,13 +44,16 @@ def graphed(dtype, a, b, lab, state=None):
     return net, step, loss
 
 
-def test_config1_full_size_fp32_graphed_step_matches_oracle(oracle_step):
+@pytest.mark.parametrize("cdtype", ["fp32", "bf16x3"])
+def test_config1_full_size_fp32_graphed_step_matches_oracle(oracle_step, cdtype):
+    """both parity modes: exact fp32 MFMA and the split-bf16 three-product form (compute_dtype="bf16x3", what bench.py's
+    parity_mode times) -- same bounds"""
     r = oracle_step
-    net, step, loss = graphed("fp32", r["a"], r["b"], r["lab"])
+    net, step, loss = graphed(cdtype, r["a"], r["b"], r["lab"])
     y = step.logits.float().cpu()
     scale = float(r["logits"].abs().max())
     err = float((y - r["logits"]).abs().max()) / scale
-    print("configs[1] fp32: logits rel err %.3e, loss %.7f (oracle %.7f)" % (err, loss, r["loss"]))
+    print("configs[1] " + cdtype + ": logits rel err %.3e, loss %.7f (oracle %.7f)" % (err, loss, r["loss"]))
     assert err <= 2e-4
     assert abs(loss - r["loss"]) <= 2e-5 * max(1.0, abs(r["loss"]))
     # gradients (the arena still holds them after the replay): every tensor by cosine, the set by median distance
@@ -66,7 +69,7 @@ def test_config1_full_size_fp32_graphed_step_matches_oracle(oracle_step):
         rels.append(e / max(s, 1e-30))
         if ref.numel() >= 64 and float(ref.norm()) > 0:
             coss.append((float(F.cosine_similarity(g.double().flatten(), ref.double().flatten(), dim=0)), k))
-    print("configs[1] fp32: grad rel err median %.2e, p90 %.2e, max %.2e; min cosine %.5f (%s)"
+    print("configs[1] " + cdtype + ": grad rel err median %.2e, p90 %.2e, max %.2e; min cosine %.5f (%s)"
           % (float(np.median(rels)), float(np.quantile(rels, 0.9)), max(rels), min(coss)[0], min(coss)[1]))
     assert float(np.median(rels)) <= 2e-2
     assert min(coss)[0] >= 0.995, min(coss)
@@ -81,7 +84,7 @@ def test_config1_full_size_fp32_graphed_step_matches_oracle(oracle_step):
         want = r["after"][k][sel]
         bad += int(((got - want).abs() > 0.2 * LR).sum())
         tot += int(sel.sum())
-    print("configs[1] fp32: first AdamW update differs on %d of %d well-conditioned elements" % (bad, tot))
+    print("configs[1] " + cdtype + ": first AdamW update differs on %d of %d well-conditioned elements" % (bad, tot))
     assert bad <= 1e-3 * tot
 
 

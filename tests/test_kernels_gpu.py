@@ -9,6 +9,10 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DTYPES = [torch.float32, torch.bfloat16]
+# the matrix-product kernels additionally in the split-bf16 form of the fp32 mode (dh_set_f32_mma_mode(1), "bf16x3": fp32
+# tensors, three bf16 MFMA products per operand pair, unit roundoff 2^-17): same inputs, same fp32 tolerance (measured 5e-6)
+DTYPES_MMA = [pytest.param(torch.float32, 0, id="float32"), pytest.param(torch.bfloat16, 0, id="bfloat16"),
+              pytest.param(torch.float32, 1, id="bf16x3")]
 
 
 def tol(dtype):
@@ -46,7 +50,15 @@ def ops():
     return o
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.fixture(autouse=True)
+def _f32_mma_mode(request, ops):
+    """tests parametrized with `mma` (DTYPES_MMA) run with that dh_set_f32_mma_mode; every other test with the exact form"""
+    cs = getattr(request.node, "callspec", None)
+    with ops.f32_mma_mode(cs.params.get("mma", 0) if cs is not None else 0):
+        yield
+
+
+@pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("cfg", [
     dict(ks=3, stride=1, pad=1, cin=64, cout=64, h=24, w=40),
     dict(ks=3, stride=2, pad=1, cin=64, cout=128, h=32, w=32),
@@ -59,7 +71,7 @@ def ops():
     dict(ks=3, stride=1, pad=2, dil=2, cin=256, cout=256, h=16, w=32),    # 8-row tile at this N (16-row: bench-scale test below)
     dict(ks=1, stride=1, pad=0, cin=1024, cout=256, h=8, w=8),
 ])
-def test_conv2d_fwd(ops, dtype, cfg):
+def test_conv2d_fwd(ops, dtype, mma, cfg):
     N = 3
     x = rnd((N, cfg["cin"], cfg["h"], cfg["w"]), dtype, 1)
     w = rnd((cfg["cout"], cfg["cin"], cfg["ks"], cfg["ks"]), dtype, 2, scale=(cfg["cin"] * cfg["ks"] ** 2) ** -0.5)
@@ -79,7 +91,7 @@ def test_conv2d_fwd(ops, dtype, cfg):
     close(tot[1, :cfg["cout"]], (want * want).sum((0, 2, 3)), dtype, "stats sumsq")
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("want_stats", [False, True])
 @pytest.mark.parametrize("cfg", [
@@ -91,7 +103,7 @@ def test_conv2d_fwd(ops, dtype, cfg):
     dict(ks=1, stride=1, pad=0, cin=128, cout=32, h=16, w=16),      # 32-channel tile
     dict(ks=3, stride=1, pad=1, cin=32, cout=16, h=16, w=20),       # 16-channel tile
 ])
-def test_conv2d_fwd_compact_epilogue(ops, dtype, cfg, want_stats, relu):
+def test_conv2d_fwd_compact_epilogue(ops, dtype, mma, cfg, want_stats, relu):
     """the host-selected compact-epilogue instantiation of conv_mfma_kernel (no pre-activation copy, no gating, no
     GELU, Cout a multiple of the 16-byte piece): bias, residual, optional ReLU, optional statistics, LDS-transposed
     16-byte stores -- every straight-line variant of it"""
@@ -118,7 +130,7 @@ def test_conv2d_fwd_compact_epilogue(ops, dtype, cfg, want_stats, relu):
     close(nchw(y2), F.conv2d(x, w, None, cfg["stride"], cfg["pad"]), dtype, "conv2d out (plain)")
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("cfg", [
     dict(ks=3, stride=1, pad=1, cin=64, cout=64, h=24, w=24),
     dict(ks=3, stride=2, pad=1, cin=64, cout=128, h=32, w=32),
@@ -128,7 +140,7 @@ def test_conv2d_fwd_compact_epilogue(ops, dtype, cfg, want_stats, relu):
     dict(ks=3, stride=1, pad=2, dil=2, cin=64, cout=64, h=20, w=24),
     dict(ks=3, stride=1, pad=2, dil=2, cin=128, cout=128, h=8, w=8),      # dilation reaches past a whole 8x8 map edge
 ])
-def test_conv2d_dgrad_and_wgrad(ops, dtype, cfg):
+def test_conv2d_dgrad_and_wgrad(ops, dtype, mma, cfg):
     N = 2
     x = rnd((N, cfg["cin"], cfg["h"], cfg["w"]), dtype, 5).requires_grad_(True)
     w = rnd((cfg["cout"], cfg["cin"], cfg["ks"], cfg["ks"]), dtype, 6, scale=(cfg["cin"] * cfg["ks"] ** 2) ** -0.5)
@@ -263,9 +275,9 @@ def test_stem_tail_backward_without_a_batchnorm_pass(ops, hw, B):
     close(dw, w.grad, dtype, "stem wgrad with BatchNorm backward on load", factor=1.0)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("ncls,hw,lazy", [(2, (64, 64), True), (5, (40, 56), False), (2, (256, 256), True)])
-def test_class_head_writes_nchw_logits_itself(ops, dtype, ncls, hw, lazy):
+def test_class_head_writes_nchw_logits_itself(ops, dtype, mma, ncls, hw, lazy):
     """dh_conv3x3_head_fwd == dh_conv2d_fwd + dh_nhwc_to_nchw (fp32 NCHW logits), plain and with BatchNorm + ReLU on load"""
     H, W = hw
     N = 2
@@ -357,8 +369,8 @@ def test_fragment_order_packed_weights(ops, cfg):
     close(nchw(y_f), F.conv2d(x, w, None, 1, 1), dtype, "conv, fragment-order weights")
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-def test_linear_rows_gelu_and_per_image_weights(ops, dtype):
+@pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
+def test_linear_rows_gelu_and_per_image_weights(ops, dtype, mma):
     rows, cin, cout = 40, 32, 64        # rows not a multiple of 16 -> masked tail
     x = rnd((rows, cin), dtype, 11)
     w = rnd((cout, cin), dtype, 12, cin ** -0.5).requires_grad_(True)
@@ -584,9 +596,9 @@ def test_cross_entropy_branch_and_dice_constant(ops):
     assert float(losses.diceloss(torch.randn(2, 2, 32, 32, generator=g).cuda(), empty.cuda())) == 0.0   # empty-target mask
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("relu", [True, False])
-def test_bn_backward_gated_in_the_dgrad_epilogue_equals_two_pass(ops, dtype, relu):
+def test_bn_backward_gated_in_the_dgrad_epilogue_equals_two_pass(ops, dtype, mma, relu):
     """conv2d(..., gate=...) + bn_bwd_from_partials against the separate (conv2d -> bn_bwd) passes, two BN groups"""
     N, H, W, Cin, Cout = 4, 24, 40, 64, 64           # the data-gradient conv maps Cout -> Cin; BN layer has Cin channels
     dy = dev(rnd((N, H, W, Cout), dtype, 201), dtype)
@@ -676,7 +688,7 @@ def _is_rw4(ops, N, OH, OW, cin, ks=3, stride=1):
     return nt == N * ops.cdiv(OH, 16) * ops.cdiv(OW, 16) and nt != N * ops.cdiv(OH, 8) * ops.cdiv(OW, 16)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("cfg", [
     dict(cin=128, cout=128, h=32, w=32, stats=True, relu=False, res=False),     # layer2 conv (+BN statistics)
     dict(cin=128, cout=256, h=32, w=32, stats=True, relu=False, res=False),     # layer3.0.conv1
@@ -687,7 +699,7 @@ def _is_rw4(ops, N, OH, OW, cin, ks=3, stride=1):
     dict(cin=256, cout=256, h=32, w=32, dil=2, stats=True, relu=False, res=False),   # ResNet-50 layer3 3x3, 16-row tile
     dict(cin=128, cout=128, h=24, w=40, n=96, stats=True, relu=True, res=True),      # 16-row tiles, ragged map
 ])
-def test_conv2d_fwd_bench_scale_16row_tiles(ops, dtype, cfg):
+def test_conv2d_fwd_bench_scale_16row_tiles(ops, dtype, mma, cfg):
     N = cfg.get("n", BENCH_N)
     dil = cfg.get("dil", 1)
     assert _is_rw4(ops, N, cfg["h"], cfg["w"], cfg["cin"]), "case does not select the 16-row tile"
@@ -712,7 +724,7 @@ def test_conv2d_fwd_bench_scale_16row_tiles(ops, dtype, cfg):
         close(tot[1, :cfg["cout"]], (want * want).sum((0, 2, 3)), dtype, "stats sumsq")
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("cfg", [
     dict(cin=256, cout=256, h=32, w=32),       # layer3: dgrad on the 16-row tile, wgrad at the one-resident-round split
     dict(cin=128, cout=256, h=32, w=32),
@@ -720,7 +732,7 @@ def test_conv2d_fwd_bench_scale_16row_tiles(ops, dtype, cfg):
     dict(cin=64, cout=64, h=64, w=64, n=32),   # layer1 shape (8-row tile; the wgrad split of the 64-channel layers)
     dict(cin=256, cout=32, h=64, w=64, n=32),  # conv_pred: 32-wide output-channel tile of the weight gradient
 ])
-def test_conv2d_dgrad_wgrad_bench_scale(ops, dtype, cfg):
+def test_conv2d_dgrad_wgrad_bench_scale(ops, dtype, mma, cfg):
     """data gradient through the same RW = 4 instantiation, weight gradient at the 512-workgroup split, both the direct
     (dh_conv2d_wgrad) and the deferred (dh_conv2d_wgrad_partial + dh_wgrad_reduce_multi) reductions"""
     N = cfg.get("n", BENCH_N)
@@ -760,7 +772,7 @@ def test_conv2d_dgrad_wgrad_bench_scale(ops, dtype, cfg):
     assert torch.equal(dw3, dw - 0.5) or float((dw3 - (dw - 0.5)).abs().max()) <= 1e-6 * gscale
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("cfg", [
     dict(n=4, cin=64, cout=64, h=24, w=40, groups=2),          # layer1 conv2 shape class (8-row tile, no prefetch), ragged
     dict(n=64, cin=128, cout=128, h=32, w=32, groups=2),       # 16-row tile
@@ -768,7 +780,7 @@ def test_conv2d_dgrad_wgrad_bench_scale(ops, dtype, cfg):
     dict(n=2, cin=32, cout=2, h=40, w=56, groups=1),           # class head: one chunk, generic epilogue
     dict(n=3, cin=32, cout=32, h=20, w=20, groups=1),
 ])
-def test_batchnorm_relu_on_load_equals_materialised_activation(ops, dtype, cfg):
+def test_batchnorm_relu_on_load_equals_materialised_activation(ops, dtype, mma, cfg):
     """dh_conv2d_fwd(in_scale, in_shift) and dh_conv2d_wgrad_bn_in on the PRE-normalisation tensor against the same
     kernels fed the activation that dh_bn_apply materialises: same values enter the MFMAs (the transform is the same
     fp32 expression, rounded once), so outputs agree to summation-order level; zero padding stays zero."""
@@ -1102,7 +1114,7 @@ def test_batchnorm_backward_persistent_failures_are_loud(ops, monkeypatch):
         assert all(torch.equal(before[k], ops._BN_SYNC[k]) for k in before)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("cfg", [
     dict(n=2, cin=256, h=16, w=16),          # 8-row tiles
     dict(n=3, cin=64, h=12, w=20),           # ragged coarse map
@@ -1111,7 +1123,7 @@ def test_batchnorm_backward_persistent_failures_are_loud(ops, monkeypatch):
     dict(n=3, cin=32, h=12, w=20, relu=True),         # ... on a ragged coarse map
     dict(n=8, cin=32, h=128, w=128, relu=True),       # ... conv_layer2's map at batch 8
 ])
-def test_upsample2_conv3x3_as_four_phase_convs(ops, dtype, cfg):
+def test_upsample2_conv3x3_as_four_phase_convs(ops, dtype, mma, cfg):
     """conv3x3(nearest-upsample-x2(x)) (models/networks.py:251-256: upsamplex2 + conv_pred; :1341-1351 with a ReLU: upsamplex2 +
     conv_layer<l>) as four 2x2 phase convolutions: forward, data gradient and weight / bias gradients against torch autograd
     of F.interpolate + F.conv2d (+ relu: the gradient then goes through the activation's backward first, as the engine does)"""
@@ -1142,13 +1154,13 @@ def test_upsample2_conv3x3_as_four_phase_convs(ops, dtype, cfg):
     close(dw - 0.5, w.grad, dtype, "phase conv weight gradient", factor=fac)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("cfg", [
     dict(n=2, cin=64, cout=128, h=32, w=32),          # layer2.0.conv1 at small batch (8-row tiles)
     dict(n=3, cin=32, cout=64, h=20, w=24),           # 32-channel phases, ragged coarse map (10 x 12)
     dict(n=64, cin=64, cout=128, h=64, w=64),         # the bench's shape: 16-row tiles
 ])
-def test_stride2_conv_data_gradient_as_phase_convs(ops, dtype, cfg):
+def test_stride2_conv_data_gradient_as_phase_convs(ops, dtype, mma, cfg):
     """data gradient of conv3x3 / stride 2 / pad 1 without the zero-inserted dY (four output-parity phases), plus the coarse
     gradient of the block's 1x1 stride-2 shortcut added at the even-even positions, against torch autograd"""
     N, Cin, Cout, H, W = cfg["n"], cfg["cin"], cfg["cout"], cfg["h"], cfg["w"]

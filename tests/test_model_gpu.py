@@ -25,6 +25,14 @@ BF16_MAX_ERR = 0.15    # a-priori bound on the worst bf16 logit error, in units 
 GRAD_TOL = 6e-2        # of max|grad| per tensor (see module docstring)
 GRAD_TOL_R50 = 0.26
 NORM_TOL = 3e-2
+# The two parity modes, held to the SAME bounds: "fp32" = exact fp32 MFMA; "bf16x3" = the same fp32
+# pipeline with every matrix product on the bf16 matrix cores as split-bf16 products (dh_set_f32_mma_mode) -- the forward in
+# the three-plane / six-product form (unit roundoff 2^-23), data and weight gradients in the two-plane / three-product form
+# (2^-17).  Measured on MI355X: logits 4e-6 .. 1.3e-5 of the logit scale (ResNet-50 train mode 8.5e-5), gradients of
+# base_transformer_pos_s4 at 2.2e-5 median / 3.2e-5 worst tensor relative L2 from the oracle (exact mode: 1.3e-5 / 7.0e-4).
+# (With the forward in the three-product form too the logits still pass -- 4e-5 .. 1.4e-4 -- but the gradients sit at
+# 1.9e-3: they are ~20x more sensitive to activation error than the logits are.)
+PARITY_MODES = ["fp32", "bf16x3"]
 
 R50 = "base_transformer_pos_s4_resnet50"      # ctor-only model (networks.py:192-195): ResNet-50 trunk, dilation 2
 NETS = ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8", "base_transformer_pos_s4_dd8_o5",
@@ -42,14 +50,15 @@ def make_net(name, dtype="fp32"):
     return net
 
 
+@pytest.mark.parametrize("cdtype", PARITY_MODES)
 @pytest.mark.parametrize("name", NETS)
-def test_forward_matches_reference_golden_fp32(name, golden_dir):
+def test_forward_matches_reference_golden_fp32(name, cdtype, golden_dir):
     g = np.load(os.path.join(golden_dir, "fwd_%s.npz" % name))
     cfg = O.get_config(name)
     bs, size, stride = int(g["batch"]), int(g["size"]), int(g["stride"])
     a, b, lab = O.synthetic_batch(bs, size, n_class=cfg["n_class"])
     for mode in ("eval", "train"):
-        net = make_net(name)
+        net = make_net(name, cdtype)
         net.train(mode == "train")
         with torch.no_grad():
             y = net(a.cuda(), b.cuda()).cpu()
@@ -57,8 +66,10 @@ def test_forward_matches_reference_golden_fp32(name, golden_dir):
         got = y[..., ::stride, ::stride]
         scale = float(want.abs().max())
         err = float((got - want).abs().max()) / scale
-        assert err <= 2e-4, "%s %s: logits rel err %.3e" % (name, mode, err)
-        assert abs(float(y.double().sum()) - float(g["sum_" + mode])) <= 2e-4 * float(g["abssum_" + mode])
+        tol = 2e-4          # both modes (north star: 1e-3)
+        print("%s %s %s: logits rel err %.3e (bound %.1e)" % (name, cdtype, mode, err, tol))
+        assert err <= tol, "%s %s %s: logits rel err %.3e" % (name, cdtype, mode, err)
+        assert abs(float(y.double().sum()) - float(g["sum_" + mode])) <= tol * float(g["abssum_" + mode])
         # class masks: identical wherever the reference margin is outside the fp32 tie band
         from dahitra_amd.models.losses import argmax_mask
         mask = argmax_mask(y.cuda()).cpu().numpy().astype(np.uint8)
@@ -71,7 +82,7 @@ def test_forward_matches_reference_golden_fp32(name, golden_dir):
         else:
             top2 = y.topk(2, dim=1).values
             margin = (top2[:, 0] - top2[:, 1]).numpy()
-        band = margin <= 4e-4 * scale
+        band = margin <= 2 * tol * scale
         diff = (mask != ref_mask)
         print("%s %s: mask flips total %d, outside the tie band %d, band fraction %.5f (reference margins: %s)"
               % (name, mode, int(diff.sum()), int((diff & ~band).sum()), float(band.mean()), stride == 1))
@@ -85,15 +96,16 @@ def test_forward_matches_reference_golden_fp32(name, golden_dir):
             assert abs(float(focal_loss(y.cuda(), lab.cuda())) - float(g["focal"])) < 2e-5
 
 
+@pytest.mark.parametrize("cdtype", PARITY_MODES)
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans", R50])
-def test_train_steps_match_reference_golden_fp32(name, golden_dir):
+def test_train_steps_match_reference_golden_fp32(name, cdtype, golden_dir):
     from dahitra_amd.models import losses
     from dahitra_amd.optim import AdamW
     g = np.load(os.path.join(golden_dir, "train_%s.npz" % name))
     cfg = O.get_config(name)
     a, b, lab = O.synthetic_batch(int(g["batch"]), int(g["size"]), n_class=cfg["n_class"])
     a, b, lab = a.cuda(), b.cuda(), lab.cuda()
-    net = make_net(name).train()
+    net = make_net(name, cdtype).train()
     opt = AdamW(net.parameters(), lr=float(g["lr"]), betas=(0.9, 0.999), weight_decay=0.01)
     got_losses = []
     for it in range(int(g["steps"])):
@@ -114,9 +126,7 @@ def test_train_steps_match_reference_golden_fp32(name, golden_dir):
             # the gradients the fixture stores in full (small tensors: BatchNorm / LayerNorm / bias gradients, where ONE flipped
             # tie of a ReLU or max-pool moves an element by percents of the tensor's maximum: measured worst 2.4e-2 on MI355X);
             # the oracle-based test below holds every tensor to a multiple of the measured noise floor
-            fl = _floor(name, golden_dir)
             tol = GRAD_TOL_R50 if name == R50 else GRAD_TOL      # (the fixture's inputs are not the floor file's: its own bound)
-            del fl
             worst_g = 0.0
             for k in g.files:
                 if k.startswith("grad0/"):
@@ -154,11 +164,13 @@ FLOOR_X_WORST, FLOOR_X_MEDIAN = 5.0, 5.0      # (measured on MI355X: worst tenso
 FLOOR_MIN_L2, FLOOR_MIN_MEDIAN = 2e-3, 1e-4        # (absolute lower ends: the well-conditioned nets' floors are ~1e-5)
 
 
+@pytest.mark.parametrize("cdtype", PARITY_MODES)
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_t8_e2d4", "newUNetTrans", R50])
-def test_gradients_match_oracle_fp32(name, golden_dir):
+def test_gradients_match_oracle_fp32(name, cdtype, golden_dir):
     """every parameter gradient against the oracle's autograd on the case of tools/grad_noise_floor.py (odd batch, 64 x 64;
     newUNetTrans: 2 x 256 x 256), bounded by the measured fp32 noise floor of this computation: per-tensor relative L2 and
-    the median over tensors, plus the per-tensor cosine"""
+    the median over tensors, plus the per-tensor cosine.
+    Both parity modes at the same bounds (bf16x3 measured: s4 median 2.2e-5, worst tensor 3.2e-5)."""
     from dahitra_amd.models import losses
     fl = _floor(name, golden_dir)
     cfg = O.get_config(name)
@@ -166,7 +178,7 @@ def test_gradients_match_oracle_fp32(name, golden_dir):
     st = O.TrainState(name, O.deterministic_state(name), lr=0.01)
     logits = O.forward(st.sd, name, a, b, training=True)
     O.focal_loss(logits, lab).backward()
-    net = make_net(name).train()
+    net = make_net(name, cdtype).train()
     y = net(a.cuda(), b.cuda())
     losses.focal_loss(y, lab.cuda()).backward()
     rl2, rmax, coss, worst = [], [], [], ("", 0.0)
@@ -186,13 +198,14 @@ def test_gradients_match_oracle_fp32(name, golden_dir):
     med, top = float(np.median(rl2)), max(rl2)
     bound_top = max(FLOOR_X_WORST * fl["rel_l2"]["max"], FLOOR_MIN_L2)
     bound_med = max(FLOOR_X_MEDIAN * fl["rel_l2"]["median"], FLOOR_MIN_MEDIAN)
-    print("%s: gradient rel-L2 vs oracle: median %.2e (floor %.2e, bound %.2e), worst %.2e in %s (floor %.2e, bound %.2e); "
+    bound_cos = 8.0 * max(1.0 - fl["cos_min"], 1e-5)
+    print("%s %s: gradient rel-L2 vs oracle: median %.2e (floor %.2e, bound %.2e), worst %.2e in %s (floor %.2e, bound %.2e); "
           "rel-max worst %.2e (floor %.2e); min cosine %.7f (floor %.7f)"
-          % (name, med, fl["rel_l2"]["median"], bound_med, top, worst[0], fl["rel_l2"]["max"], bound_top, max(rmax),
+          % (name, cdtype, med, fl["rel_l2"]["median"], bound_med, top, worst[0], fl["rel_l2"]["max"], bound_top, max(rmax),
              fl["rel_max"]["max"], min(coss), fl["cos_min"]))
     assert med <= bound_med, (med, bound_med)
     assert top <= bound_top, (worst, bound_top)
-    assert min(coss) >= 1.0 - 8.0 * max(1.0 - fl["cos_min"], 1e-5), min(coss)
+    assert min(coss) >= 1.0 - bound_cos, min(coss)
 
 
 @pytest.mark.parametrize("name", ["newUNetTrans", "base_transformer_pos_s4_dd8"])
@@ -258,8 +271,9 @@ def test_teacher_forced_second_and_third_steps_match_the_oracle(name):
         assert tot > 1e5 and bad <= 2e-3 * tot          # (measured: <= 9.7e-4 of the elements, worst 0.26 lr)
 
 
+@pytest.mark.parametrize("cdtype", PARITY_MODES)
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
-def test_masks_bit_exact_on_large_margin_fixture_fp32(name, golden_dir):
+def test_masks_bit_exact_on_large_margin_fixture_fp32(name, cdtype, golden_dir):
     """north star: "class masks bit-exact".  Fixture written by the reference with an antisymmetric head
     (oracle/cdnet_ref.large_margin_state): the reference's own per-pixel margins put < 0.1 % of the pixels inside the
     4e-4 * max|logit| band that a 2e-4 logit bound cannot decide; every other pixel must carry the reference's class."""
@@ -268,7 +282,7 @@ def test_masks_bit_exact_on_large_margin_fixture_fp32(name, golden_dir):
     a, b, _ = O.synthetic_batch(bs, size, seed=int(g["seed"]))
     from dahitra_amd.models.losses import argmax_mask
     for mode in ("eval", "train"):
-        net = make_net(name)
+        net = make_net(name, cdtype)
         net.load_state_dict(O.large_margin_state(name))
         net.train(mode == "train")
         with torch.no_grad():
@@ -282,8 +296,8 @@ def test_masks_bit_exact_on_large_margin_fixture_fp32(name, golden_dir):
         margin = np.asarray(g["margin_" + mode]).astype(np.float32)
         band = margin <= 4e-4 * scale
         diff = mask != ref_mask
-        print("%s %s (large margins): flips total %d, outside band %d, band fraction %.5f, logits rel err %.2e"
-              % (name, mode, int(diff.sum()), int((diff & ~band).sum()), float(band.mean()), err))
+        print("%s %s %s (large margins): flips total %d, outside band %d, band fraction %.5f, logits rel err %.2e"
+              % (name, cdtype, mode, int(diff.sum()), int((diff & ~band).sum()), float(band.mean()), err))
         assert float(band.mean()) < 0.002
         assert int((diff & ~band).sum()) == 0
 
@@ -693,8 +707,9 @@ def test_recorded_token_side_launches_equal_the_separate_ones(monkeypatch):
     assert any(float(g.abs().max()) > 0 for k, g in res["1"][1].items() if k.startswith("transformer_decoder"))
 
 
+@pytest.mark.parametrize("cdtype", PARITY_MODES)
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_o5"])
-def test_ragged_shapes_match_oracle_fp32(name):
+def test_ragged_shapes_match_oracle_fp32(name, cdtype):
     """non-square input whose feature maps are not multiples of the kernel tiles (96x160: 24x40 / 12x20 maps, the
     fused decoder's 128-row blocks do not divide 960 rows -> layer-at-a-time path), odd batch"""
     from dahitra_amd.models import losses
@@ -706,7 +721,7 @@ def test_ragged_shapes_match_oracle_fp32(name):
     st = O.TrainState(name, O.deterministic_state(name), lr=0.01)
     ref = O.forward(st.sd, name, a, b, training=True)
     O.focal_loss(ref, lab).backward()
-    net = make_net(name).train()
+    net = make_net(name, cdtype).train()
     y = net(a.cuda(), b.cuda())
     losses.focal_loss(y, lab.cuda()).backward()
     err = float((y.detach().cpu() - ref.detach()).abs().max()) / float(ref.abs().max())
@@ -724,6 +739,8 @@ def test_ragged_shapes_match_oracle_fp32(name):
             rels.append(e / max(s, 1e-30))
             if r.numel() >= 64:
                 coss.append(float(F.cosine_similarity(p.grad.cpu().double().flatten(), r.double().flatten(), dim=0)))
+    print("%s %s ragged: logits %.2e, gradient rel-max median %.2e, p90 %.2e, min cosine %.5f"
+          % (name, cdtype, err, float(np.median(rels)), float(np.quantile(rels, 0.9)), min(coss)))
     assert float(np.median(rels)) <= 1e-2, float(np.median(rels))
     assert float(np.quantile(rels, 0.9)) <= 6e-2, float(np.quantile(rels, 0.9))
     assert min(coss) >= 0.995, min(coss)
