@@ -15,6 +15,12 @@
 // epilogue is that kernel's compact one: +bias, +residual, ReLU, per-tile BatchNorm partial sums in the same
 // [2][CoutPad][tiles] layout (tile = 128 consecutive pixels = the 8x16 tile count of the direct kernel, which the host
 // guarantees by OH % 8 == 0, OW % 16 == 0), LDS-transposed 16-byte stores.
+//
+// Tile size is the lever (round 5): every staged byte crosses the L2 -> LDS fill path, which delivers ~40 GB/s per CU (~10 TB/s
+// over the chip), and a BM x BN tile does BM * BN / (BM + BN) FLOP per staged byte-pair: 64 for 128 x 128 (ceiling ~650
+// TFLOP/s -- rocprofv3 showed the ResNet-50 launches at 565), 85 for 256 x 128, 128 for 256 x 256.  The layers with >= 256
+// pixels x {256, 128} output channels per tile run 512-thread workgroups on 256-pixel tiles (one per CU: 128 KB of stages);
+// the per-wave work (64 couts x 64 or 128 pixels) and the LDS image are unchanged.
 #include "conv_mfma_impl.h"
 
 namespace {
@@ -27,14 +33,17 @@ __device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char*
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(ConvArgs p) {
+template <int BN, int BM = GBM>
+__global__ __launch_bounds__(2 * BM, 256 / BM) void conv1x1_gemm_kernel(ConvArgs p) {
+    constexpr int GBM = BM;                              // pixels per workgroup (128: 4 waves, 256: 8 waves)
+    constexpr int NW = BM / 32, NTHR = 64 * NW;
     constexpr int ROWS = BN + GBM;                       // LDS rows per stage: weights first, then pixels
     constexpr int STAGE = ROWS * 128;                    // bytes
-    constexpr int NI = ROWS / 32;                        // glds instructions per wave and stage (8 rows each)
-    constexpr int WC = BN / 64;                          // waves along cout (2 or 1)
-    constexpr int WP = 4 / WC;                           // waves along pixels (2 or 4)
-    constexpr int NT_ = GBM / WP / 16;                   // 16-pixel sub-tiles per wave (4 or 2)
+    constexpr int NI = ROWS / (8 * NW);                  // glds instructions per wave and stage (8 rows each)
+    constexpr int WC = BN / 64;                          // waves along cout (1, 2 or 4)
+    constexpr int WP = NW / WC;                          // waves along pixels
+    constexpr int NT_ = GBM / WP / 16;                   // 16-pixel sub-tiles per wave (2, 4 or 8)
+    static_assert(ROWS % (8 * NW) == 0 && WP >= 1 && (GBM / WP) % 16 == 0 && (128 % (GBM / WP) == 0 || (GBM / WP) % 128 == 0), "tile / wave layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, g = lane >> 4;
@@ -63,13 +72,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(ConvArgs p) {
     const unsigned char* src[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        const int r = (j * 4 + wv) * 8 + (lane >> 3);                       // LDS row
+        const int r = (j * NW + wv) * 8 + (lane >> 3);                      // LDS row
         const int c = (lane & 7) ^ (r & 7);                                  // source chunk landing in LDS chunk lane & 7
         src[j] = (r < BN ? Wt + (size_t)(co0 + r) * rowbytes : X + (size_t)(m0 + r - BN) * rowbytes) + c * 16;
     }
     auto issue = [&](int stage, int k0) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) glds16(src[j] + (size_t)k0 * 2, smem + stage * STAGE + (j * 4 + wv) * 1024);
+        for (int j = 0; j < NI; ++j) glds16(src[j] + (size_t)k0 * 2, smem + stage * STAGE + (j * NW + wv) * 1024);
     };
 
     f32x4 acc[4][NT_];
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(ConvArgs p) {
 
     // ---- epilogue (the staging LDS is free): +bias, +residual, ReLU, BN partial sums, transposed 16-byte stores ----
     constexpr int TPITCH = BN * 2 + 16;
-    unsigned char* otile = smem + 4 * 2 * BN * 4;        // below it: the statistics scratch [4 waves][2][BN]
+    unsigned char* otile = smem + NW * 2 * BN * 4;       // below it: the statistics scratch [NW waves][2][BN]
     bf16* yout = reinterpret_cast<bf16*>(p.y);
     const bf16* rin = reinterpret_cast<const bf16*>(p.res);
     const bool relu = p.act == DH_ACT_RELU;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(ConvArgs p) {
         }
     }
     if (p.stats) {
-        float* red = reinterpret_cast<float*>(smem);     // [4 waves][2][BN]
+        float* red = reinterpret_cast<float*>(smem);     // [NW waves][2][BN]
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -168,29 +177,35 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(ConvArgs p) {
     }
     __syncthreads();
     constexpr int PPR = BN * 2 / 16;                      // 16-byte pieces per pixel
-    for (int i = tid; i < GBM * PPR; i += 256) {
+    for (int i = tid; i < GBM * PPR; i += NTHR) {
         const int px = i / PPR, q = i - px * PPR;
         *reinterpret_cast<uint4*>(yout + (size_t)(m0 + px) * p.Cout + co0 + q * 8) =
             *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
     }
-    if (p.stats && tid < 2 * BN) {
+    // one partial per 128-pixel HALF of the tile: the [2][CoutPad][tiles] layout counts 128-pixel tiles whatever BM is
+    constexpr int HALVES = GBM / 128, WPH = WP / HALVES;      // pixel-wave rows per half
+    static_assert(WP % HALVES == 0, "a wave's pixels lie in one 128-pixel half");
+    if (p.stats) {
         const float* red = reinterpret_cast<const float*>(smem);
-        const int which = tid / BN, c = tid - which * BN;
-        // waves that hold couts [wc * 64, +64): wv = wp * WC + wc for every wp, in wave order
-        float t = 0.f;
+        for (int i = tid; i < HALVES * 2 * BN; i += NTHR) {
+            const int half = i / (2 * BN), which = (i / BN) & 1, c = i % BN;
+            // waves that hold couts [wc * 64, +64) of this half: wv = wp * WC + wc for wp in [half * WPH, +WPH), in wave order
+            float t = 0.f;
 #pragma unroll
-        for (int q = 0; q < WP; ++q) t += red[((q * WC + c / 64 % WC) * 2 + which) * BN + c];
-        p.stats[((size_t)which * p.CoutPad + co0 + c) * npt + pt] = t;
+            for (int q = 0; q < WPH; ++q) t += red[(((half * WPH + q) * WC + c / 64 % WC) * 2 + which) * BN + c];
+            p.stats[((size_t)which * p.CoutPad + co0 + c) * ((size_t)npt * HALVES) + (size_t)pt * HALVES + half] = t;
+        }
     }
 }
 
-template <int BN>
+template <int BN, int BM = GBM>
 int launch_gemm(const ConvArgs& a, hipStream_t st) {
+    constexpr int GBM = BM;
     constexpr int ROWS = BN + GBM;
     const size_t staging = (size_t)2 * ROWS * 128;
-    const size_t otile = (size_t)4 * 2 * BN * 4 + (size_t)GBM * (BN * 2 + 16);
+    const size_t otile = (size_t)(BM / 32) * 2 * BN * 4 + (size_t)GBM * (BN * 2 + 16);
     const size_t lds = staging > otile ? staging : otile;
-    auto kern = conv1x1_gemm_kernel<BN>;
+    auto kern = conv1x1_gemm_kernel<BN, BM>;
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
         attr_done = true;
@@ -200,7 +215,7 @@ int launch_gemm(const ConvArgs& a, hipStream_t st) {
         }
     }
     const long M = (long)a.N * a.OH * a.OW;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((M / GBM) * (a.Cout / BN))), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M / GBM) * (a.Cout / BN))), dim3(2 * BM), lds, st, a);
     DH_CHECK_LAUNCH("conv1x1_gemm");
     return 0;
 }
@@ -216,5 +231,10 @@ bool dh_conv1x1_gemm_eligible(const ConvArgs& a, int ks, int stride, int dtype) 
            !(a.stats && (a.res || a.act != DH_ACT_NONE)) && ((long)a.N * a.OH * a.OW) % GBM == 0;
 }
 int dh_conv1x1_gemm_launch(const ConvArgs& a, hipStream_t st) {
+    static const bool small = getenv("DAHITRA_GEMM1X1_SMALL") != nullptr;       // A/B switch: 128-pixel tiles only
+    const long M = (long)a.N * a.OH * a.OW;
+    // 256-pixel tiles where they still give the chip at least two rounds of workgroups
+    if (!small && M % 256 == 0 && a.Cout % 128 == 0 && (M / 256) * (a.Cout / (a.Cout % 256 == 0 ? 256 : 128)) >= 512)
+        return a.Cout % 256 == 0 ? launch_gemm<256, 256>(a, st) : launch_gemm<128, 256>(a, st);
     return a.Cout % 128 == 0 ? launch_gemm<128>(a, st) : launch_gemm<64>(a, st);
 }

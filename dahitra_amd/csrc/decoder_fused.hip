@@ -991,7 +991,9 @@ static int dec_batch_flush(hipStream_t st) {
     return 0;
 }
 static int dec_batch_record(DecMulti* m, int* n, const DecArgs& a, int nblk, hipStream_t st) {
-    if (*n == DEC_MAXJ) { const int rc = dec_batch_flush(st); if (rc) return rc; }
+    // (no flush on overflow: a recorded stack launch may depend on a recorded operand preparation of tokens.hip that only
+    // dh_xprep_batch_launch_fwd issues first -- more than DEC_MAXJ independent stacks per round is an error, not a reorder)
+    DH_REQUIRE(*n < DEC_MAXJ, "decoder_batch: more than %d stacks recorded in one round (dh_decoder_batch_launch first)", DEC_MAXJ);
     if (*n == 0) m->first[0] = 0;
     m->a[*n] = a;
     m->first[*n + 1] = m->first[*n] + nblk;
@@ -1199,7 +1201,7 @@ extern "C" int dh_decoder_stack_bwd_finalize(const void* workspace, int depth, l
     const FinArgs fa = {partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, pstride, grad_stride, kstride};
     if (g_db.on) {          // recorded: issued with the other stacks' finalizes, after the recorded backward launches
         const int k = mlp == 64, gx = dh_cdiv(mlp == 64 ? PL<64>::KQ : PL<32>::KQ, 32);
-        if (g_db.nfin[k] == DEC_MAXJ) { const int rc = dec_batch_flush(ST(stream)); if (rc) return rc; }
+        DH_REQUIRE(g_db.nfin[k] < DEC_MAXJ, "decoder_batch: more than %d stack finalizes recorded in one round", DEC_MAXJ);
         FinMulti& fm = g_db.fin[k];
         int& n = g_db.nfin[k];
         if (n == 0) fm.first[0] = 0;

@@ -1468,7 +1468,9 @@ extern "C" int dh_xattn_prep_fwd_stack_mfma(const void* tok, long tok_bstride, l
     a.ls_param = param_stride; a.ls_pack = 32L * heads * dim_head;
     m.wk = wk; m.wv = wv; m.wo = wo; m.wqT = reinterpret_cast<const bf16*>(wqT);
     if (g_xb.on && !g_xb.paused && dim_head == 64) {                 // recorded: issued with the other stacks' by dh_xprep_batch_launch_fwd
-        if (g_xb.fwd.full()) { const int rc = xprep_flush_fwd(ST(stream)); if (rc) return rc; }
+        // (a full family cannot be flushed here: the recorded decoder / finalize launches of the other families depend on an
+        // order only dh_xprep_batch_launch_* keeps -- more independent stacks per round than XB_MAXJ must fail, not reorder)
+        DH_REQUIRE(!g_xb.fwd.full(), "xattn_prep_fwd_stack: more than %d stacks recorded in one round (dh_xprep_batch_launch_fwd first)", XB_MAXJ);
         g_xb.fwd.add(m, S / 4, layers, 1);
         return 0;
     }
@@ -1547,10 +1549,9 @@ extern "C" int dh_xattn_prep_bwd_stack_mfma(const void* tok, void* dtok_accum, l
     static const bool wg_fma_ = getenv("DAHITRA_PREP_WGRAD_FMA") != nullptr;
     if (g_xb.on && !g_xb.paused && dim_head == 64 && S % 8 == 0 && !wg_fma_) {
         // recorded: the four kernels of this stack join the other stacks' in dh_xprep_batch_launch_bwd's four launches
-        if (g_xb.bwd.full() || g_xb.dtok.full() || g_xb.wg_mfma.full() || g_xb.wg_ln.full()) {
-            const int rc = xprep_flush_bwd(ST(stream));
-            if (rc) return rc;
-        }
+        // (see the forward: flushing here would run before the recorded decoder finalize that produces dkq / dvoT)
+        DH_REQUIRE(!(g_xb.bwd.full() || g_xb.dtok.full() || g_xb.wg_mfma.full() || g_xb.wg_ln.full()),
+                   "xattn_prep_bwd_stack: more than %d stacks recorded in one round (dh_xprep_batch_launch_bwd first)", XB_MAXJ);
         g_xb.bwd.add(m, S / 4, layers, 1);
         if (layers > 1) g_xb.dtok.add(dt, S, 1, 1);
         PrepWgArgs w;

@@ -74,14 +74,18 @@ class GraphedTrainStep:
         # job table, the packed-weight buffers.  ops.pin_captured_buffers() makes every buffer the capture touched
         # immutable for the life of the process (a later, larger eager call allocates a NEW buffer instead of
         # freeing the one the graph still reads and writes).
+        # The capture runs on a stream of our own that inherits the warm-up stream's scratch workspace (ops.workspace is keyed
+        # by stream): sized by the warm-up, allocated outside the graph's private pool, and no entry of a dead stream remains.
+        cs = torch.cuda.Stream()
+        ops.rekey_workspace(a.device, s, cs)
         self.graph = torch.cuda.CUDAGraph()
         if split:
             self.graph2 = torch.cuda.CUDAGraph()
             n0 = ops.BN_PERSIST_LAUNCHES
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=cs):
                 self.loss = self._split_first()
             n1 = ops.BN_PERSIST_LAUNCHES
-            with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool(), stream=cs):
                 self._second()
             # persistent BatchNorm launches recorded into (graph 1, graph 2): graph 2 replays beside RCCL's kernels and must hold none
             self.persist_bn_launches = (n1 - n0, ops.BN_PERSIST_LAUNCHES - n1)
@@ -90,7 +94,7 @@ class GraphedTrainStep:
                                    "gradient all-reduce" % self.persist_bn_launches[1])
         else:
             self.split_off = None
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=cs):
                 self.loss = self._body(include_opt=not self.exchange)
         self._pinned = ops.pin_captured_buffers(net)
         self._generation = net._arena.generation

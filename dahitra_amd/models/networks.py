@@ -144,8 +144,14 @@ class CDNet(nn.Module):
         own = [k for k, _, r in self._spec if not is_buffer(r) and not is_alias(r)]
         active = [k for k in own if is_active(self.net_G, k)]
         inactive = [k for k in own if not is_active(self.net_G, k)]
-        total = sum(sd_p[k].numel() for k in active + inactive)
-        flat = torch.empty(total, dtype=torch.float32, device=device)
+        # every parameter starts on a 16-byte boundary (4 floats): kernels read the fp32 masters with 16-byte vector loads
+        # straight from the arena (encoder_fused.hip ksplit_rows, the tiled weight re-pack), and e.g. classifier.3.bias (2
+        # floats) would otherwise leave everything behind it 8-byte aligned.  Padding floats are zero, carry zero gradients and
+        # stay zero under AdamW; the per-layer sizes of the transformer stacks are multiples of 32, so their constant layer
+        # pitch is unchanged.
+        pad4 = lambda n: (n + 3) & ~3
+        total = sum(pad4(sd_p[k].numel()) for k in active + inactive)
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
         off = 0
         ar.offsets = {}
         for k in active + inactive:
@@ -155,7 +161,7 @@ class CDNet(nn.Module):
             p.data = flat[off:off + n].view(p.shape)
             p.grad = None
             ar.offsets[k] = (off, n)
-            off += n
+            off += pad4(n)
             if k == active[-1]:
                 ar.n_active = off
         ar.flat = flat

@@ -347,6 +347,10 @@ class CDTrainer:
             self._clear_cache()
             self.is_training = False
             self.net_G.eval()
+            # under torchrun the replicas' BatchNorm running statistics differ (per-replica BN, as nn.DataParallel) while the
+            # validation split is sharded over the ranks and best_ckpt.pt stores rank 0's buffers: every rank scores rank
+            # 0's model, so that the logged epoch score IS the score of the checkpointed model
+            parallel.broadcast_buffers_(self.net_G)
             for self.batch_id, batch in enumerate(self.dataloaders['val'], 0):
                 with torch.no_grad():
                     self._forward_pass(batch)

@@ -84,6 +84,17 @@ def workspace(nbytes, device):
     return buf
 
 
+def rekey_workspace(device, old_stream, new_stream):
+    """hand the scratch buffer that `old_stream` grew (a graph's eager warm-up) to `new_stream` (its capture stream): the
+    capture then finds a buffer of the right size that lives OUTSIDE the graph's private pool, and the warm-up stream --
+    which is gone after the capture -- leaves no entry behind"""
+    buf = _ws.pop((str(device), old_stream.cuda_stream), None)
+    if buf is not None:
+        cur = _ws.get((str(device), new_stream.cuda_stream))
+        if cur is None or cur.numel() < buf.numel():
+            _ws[(str(device), new_stream.cuda_stream)] = buf
+
+
 _PINNED = []        # buffers a captured HIP graph points into: kept alive for the life of the process
 
 

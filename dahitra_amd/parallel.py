@@ -9,6 +9,7 @@ import os
 
 import torch
 import torch.distributed as dist
+import torch.utils.data
 
 
 def init_from_env(backend=None):
@@ -68,6 +69,32 @@ def broadcast_params_(net, src=0, group=None):
     dist.broadcast(flat, src=src, group=group)
     for b in net.buffers():
         dist.broadcast(b, src=src, group=group)
+
+
+def broadcast_buffers_(net, src=0, group=None):
+    """BatchNorm running statistics (and num_batches_tracked) of rank `src` on every rank.  They stay per replica during
+    training (the reference's nn.DataParallel keeps device 0's, models/networks.py:121-125); before an evaluation pass that
+    is sharded over the ranks, and before a checkpoint, every rank must score / store the SAME model -- rank 0's, the one
+    best_ckpt.pt holds."""
+    if not exchange_enabled(group):
+        return
+    for b in net.buffers():
+        dist.broadcast(b, src=src, group=group)
+
+
+class ShardSampler(torch.utils.data.Sampler):
+    """indices rank, rank + world, ... of a dataset, in order, WITHOUT the padding of DistributedSampler (which repeats
+    samples until every rank has the same count: a summed confusion matrix would count them twice).  Ragged per-rank
+    lengths are fine where no collective runs inside the loop (the trainers' evaluation pass)."""
+
+    def __init__(self, n, rank, world):
+        self.idx = list(range(int(rank), int(n), int(world)))
+
+    def __iter__(self):
+        return iter(self.idx)
+
+    def __len__(self):
+        return len(self.idx)
 
 
 def split_offset(net):

@@ -55,11 +55,12 @@ def get_loaders(args):
     if world > 1:
         # one process per GPU: every rank draws its own 1/world of the TRAIN split (DistributedSampler, re-seeded per epoch by
         # CDTrainer.train_models via set_epoch) -- without it all ranks would iterate the identical batches and the all-reduced
-        # mean gradient would be the single-rank gradient at N times the cost.  The validation split is sharded too (no
-        # shuffle): the trainer sums the ranks' confusion matrices at the end of the epoch.
+        # mean gradient would be the single-rank gradient at N times the cost.  The validation split is sharded too, every
+        # sample exactly once (parallel.ShardSampler: no padding to equal lengths -- no collective runs inside the evaluation
+        # loop): the trainer broadcasts rank 0's BatchNorm buffers before the pass and sums the ranks' confusion matrices after it.
         from torch.utils.data.distributed import DistributedSampler
         samplers = {'train': DistributedSampler(sets['train'], num_replicas=world, rank=rank, shuffle=True, drop_last=True),
-                    'val': DistributedSampler(sets['val'], num_replicas=world, rank=rank, shuffle=False)}
+                    'val': parallel.ShardSampler(len(sets['val']), rank, world)}
         return {k: DataLoader(v, batch_size=args.batch_size, sampler=samplers[k], num_workers=args.num_workers)
                 for k, v in sets.items()}
     return {k: DataLoader(v, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers) for k, v in sets.items()}

@@ -1233,6 +1233,9 @@ def test_decoder_layer_fp8_forward(ops, mlp):
     dict(n=2, cin=1024, cout=256, h=16, w=16, stats=False, res=True, relu=True),     # layer3 conv1, eval form, 16 K steps
     dict(n=16, cin=256, cout=1024, h=32, w=32, stats=True, res=False, relu=False),   # layer3 conv3 at size
     dict(n=3, cin=128, cout=128, h=8, w=16, stats=False, res=False, relu=False),     # odd image count (M = 3 * 128)
+    dict(n=64, cin=256, cout=1024, h=32, w=32, stats=True, res=False, relu=False),   # 256 x 256 tiles (8 waves; two statistics halves)
+    dict(n=64, cin=1024, cout=256, h=32, w=32, stats=False, res=True, relu=True),    # ... 16 K steps, eval form
+    dict(n=32, cin=512, cout=128, h=64, w=64, stats=True, res=False, relu=False),    # 256 x 128 tiles (layer2 conv1)
 ])
 def test_conv1x1_kdeep_gemm_path(ops, cfg):
     """csrc/conv1x1_gemm.hip (direct-to-LDS loads, 64 channels per step, swizzled 128-byte rows) through dh_conv2d_fwd, bf16:

@@ -169,5 +169,47 @@ def test_pil_loaders_are_sharded_by_rank_under_torchrun(tmp_path, monkeypatch):
         ld["train"].sampler.set_epoch(1)
         seen.append(sorted(n for b in ld["train"] for n in b["name"]))
         assert len(ld["train"]) == 2 and len(ld["val"]) == 2
+        assert type(ld["val"].sampler).__name__ == "ShardSampler"
     assert len(seen[0]) == len(seen[1]) == 4 and not set(seen[0]) & set(seen[1])
     assert sorted(seen[0] + seen[1]) == names
+
+
+def test_validation_shards_cover_every_sample_exactly_once():
+    """parallel.ShardSampler: no padding to equal per-rank lengths (DistributedSampler repeats samples when len % world != 0,
+    which a confusion matrix summed over the ranks would count twice)"""
+    sys.path.insert(0, ROOT)
+    from dahitra_amd import parallel
+    for n, world in ((7, 2), (8, 2), (10, 4), (3, 8)):
+        shards = [list(parallel.ShardSampler(n, r, world)) for r in range(world)]
+        assert sorted(i for s in shards for i in s) == list(range(n)), (n, world, shards)
+        assert all(len(parallel.ShardSampler(n, r, world)) == len(shards[r]) for r in range(world))
+
+
+def _buffer_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from dahitra_amd import parallel
+    from dahitra_amd.models.networks import CDNet
+    parallel.init_from_env("gloo")
+    net = CDNet(NAME, "fp32")
+    with torch.no_grad():
+        for i, b in enumerate(net.buffers()):          # per-replica BatchNorm statistics after an epoch: they differ
+            b.fill_(rank + 1) if b.dtype.is_floating_point else b.fill_(10 * (rank + 1))
+    w_before = net.state_dict()["resnet.conv1.weight"].clone()
+    parallel.broadcast_buffers_(net)                      # what CDTrainer.train_models does right before the evaluation pass
+    sd = net.state_dict()
+    torch.save({"rm": sd["resnet.bn1.running_mean"].clone(), "nbt": int(sd["resnet.bn1.num_batches_tracked"]),
+                "params_untouched": bool(torch.equal(sd["resnet.conv1.weight"], w_before))}, os.path.join(out, "b%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluation_uses_rank0_batchnorm_statistics_on_every_rank(tmp_path):
+    """the sharded validation pass must score the model best_ckpt.pt stores -- rank 0's BatchNorm buffers"""
+    port = _free_port()
+    mp.spawn(_buffer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    b0, b1 = (torch.load(os.path.join(tmp_path, "b%d.pt" % r)) for r in (0, 1))
+    assert torch.equal(b0["rm"], b1["rm"]) and float(b1["rm"][0]) == 1.0         # rank 0 filled its buffers with 1
+    assert b0["nbt"] == b1["nbt"] == 10
+    assert b0["params_untouched"] and b1["params_untouched"]
