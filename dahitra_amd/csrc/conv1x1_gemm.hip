@@ -20,7 +20,13 @@
 // over the chip), and a BM x BN tile does BM * BN / (BM + BN) FLOP per staged byte-pair: 64 for 128 x 128 (ceiling ~650
 // TFLOP/s -- rocprofv3 showed the ResNet-50 launches at 565), 85 for 256 x 128, 128 for 256 x 256.  The layers with >= 256
 // pixels x {256, 128} output channels per tile run 512-thread workgroups on 256-pixel tiles (one per CU: 128 KB of stages);
-// the per-wave work (64 couts x 64 or 128 pixels) and the LDS image are unchanged.
+// the per-wave work (64 couts x 64 or 128 pixels) and the LDS image are unchanged.  Measured (tools/gemm1x1_bench.py, 16 x 128 x 128
+// pixels): 1024 -> 256: 245 -> 214 us, 256 -> 1024: 311 -> 289, 512 -> 1024: 453 -> 423.  What did NOT help, each built, verified
+// against torch and timed (experiments/conv1x1_gemm_deep.inc): 3 - 5 stages of 32 channels with one barrier per step (250 us),
+// the same with the next step's fragments read during this step's MFMAs (256 - 288 us), a per-workgroup rotation of the K
+// order (211 vs 214).  The streaming shapes track the row pitch of the activation -- 6.6 TB/s algorithmic at 128-byte rows
+// (64 -> 64), 5.4 at 512 B, 4.2 at 1 KB, 3.1 at 2 KB (1024 -> 256) -- i.e. what one step fetches per row (128 B) against the
+// DRAM page it opens, not the loop structure, bounds the K >= 512 layers.
 #include "conv_mfma_impl.h"
 
 namespace {
@@ -31,6 +37,87 @@ constexpr int GBK = 64;           // channels per step (128-byte rows)
 __device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// +bias, +residual, ReLU, BN partial sums (one per 128-pixel half of the tile), LDS-transposed 16-byte stores; the staging LDS
+// must be free (all waves past their last fragment read)
+template <int BN, int BM, int NT_>
+__device__ __forceinline__ void gemm_epilogue(const ConvArgs& p, f32x4 (&acc)[4][NT_], unsigned char* smem, long m0, int co0, int pt,
+                                              int npt, int tid, int lane, int wv, int wc, int wp) {
+    constexpr int GBM = BM, NW = BM / 32, NTHR = 64 * NW, WC = BN / 64, WP = NW / WC;
+    const int pl = lane & 15, g = lane >> 4;
+    // ---- epilogue (the staging LDS is free): +bias, +residual, ReLU, BN partial sums, transposed 16-byte stores ----
+    constexpr int TPITCH = BN * 2 + 16;
+    unsigned char* otile = smem + NW * 2 * BN * 4;       // below it: the statistics scratch [NW waves][2][BN]
+    bf16* yout = reinterpret_cast<bf16*>(p.y);
+    const bf16* rin = reinterpret_cast<const bf16*>(p.res);
+    const bool relu = p.act == DH_ACT_RELU;
+    float ssum[4][4], ssq[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ssum[s][j] = 0.f; ssq[s][j] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = co0 + wc * 64 + s * 16 + g * 4;
+        float bs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs[j] = p.bias ? p.bias[c + j] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT_; ++t) {
+            const int px = wp * (GBM / WP) + t * 16 + pl;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[s][t][j] + bs[j];
+            if (rin) {
+                float rr[4];
+                ld4(rin + (size_t)(m0 + px) * p.Cout + c, rr);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += rr[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (relu) v[j] = fmaxf(v[j], 0.f);
+                ssum[s][j] += v[j];
+                ssq[s][j] += v[j] * v[j];
+            }
+            st4(reinterpret_cast<bf16*>(otile + px * TPITCH) + (c - co0), v);
+        }
+    }
+    if (p.stats) {
+        float* red = reinterpret_cast<float*>(smem);     // [NW waves][2][BN]
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = row16_sum(ssum[s][j]), b = row16_sum(ssq[s][j]);
+                if (pl == 0) {
+                    red[(wv * 2 + 0) * BN + wc * 64 + s * 16 + g * 4 + j] = a;
+                    red[(wv * 2 + 1) * BN + wc * 64 + s * 16 + g * 4 + j] = b;
+                }
+            }
+    }
+    __syncthreads();
+    constexpr int PPR = BN * 2 / 16;                      // 16-byte pieces per pixel
+    for (int i = tid; i < GBM * PPR; i += NTHR) {
+        const int px = i / PPR, q = i - px * PPR;
+        *reinterpret_cast<uint4*>(yout + (size_t)(m0 + px) * p.Cout + co0 + q * 8) =
+            *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
+    }
+    // one partial per 128-pixel HALF of the tile: the [2][CoutPad][tiles] layout counts 128-pixel tiles whatever BM is
+    constexpr int HALVES = GBM / 128, WPH = WP / HALVES;      // pixel-wave rows per half
+    static_assert(WP % HALVES == 0, "a wave's pixels lie in one 128-pixel half");
+    if (p.stats) {
+        const float* red = reinterpret_cast<const float*>(smem);
+        for (int i = tid; i < HALVES * 2 * BN; i += NTHR) {
+            const int half = i / (2 * BN), which = (i / BN) & 1, c = i % BN;
+            // waves that hold couts [wc * 64, +64) of this half: wv = wp * WC + wc for wp in [half * WPH, +WPH), in wave order
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < WPH; ++q) t += red[(((half * WPH + q) * WC + c / 64 % WC) * 2 + which) * BN + c];
+            p.stats[((size_t)which * p.CoutPad + co0 + c) * ((size_t)npt * HALVES) + (size_t)pt * HALVES + half] = t;
+        }
+    }
 }
 
 template <int BN, int BM = GBM>
@@ -124,79 +211,9 @@ __global__ __launch_bounds__(2 * BM, 256 / BM) void conv1x1_gemm_kernel(ConvArgs
         asm volatile("" ::: "memory");
     }
 
-    // ---- epilogue (the staging LDS is free): +bias, +residual, ReLU, BN partial sums, transposed 16-byte stores ----
-    constexpr int TPITCH = BN * 2 + 16;
-    unsigned char* otile = smem + NW * 2 * BN * 4;       // below it: the statistics scratch [NW waves][2][BN]
-    bf16* yout = reinterpret_cast<bf16*>(p.y);
-    const bf16* rin = reinterpret_cast<const bf16*>(p.res);
-    const bool relu = p.act == DH_ACT_RELU;
-    float ssum[4][4], ssq[4][4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { ssum[s][j] = 0.f; ssq[s][j] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int c = co0 + wc * 64 + s * 16 + g * 4;
-        float bs[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bs[j] = p.bias ? p.bias[c + j] : 0.f;
-#pragma unroll
-        for (int t = 0; t < NT_; ++t) {
-            const int px = wp * (GBM / WP) + t * 16 + pl;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[s][t][j] + bs[j];
-            if (rin) {
-                float rr[4];
-                ld4(rin + (size_t)(m0 + px) * p.Cout + c, rr);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += rr[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (relu) v[j] = fmaxf(v[j], 0.f);
-                ssum[s][j] += v[j];
-                ssq[s][j] += v[j] * v[j];
-            }
-            st4(reinterpret_cast<bf16*>(otile + px * TPITCH) + (c - co0), v);
-        }
-    }
-    if (p.stats) {
-        float* red = reinterpret_cast<float*>(smem);     // [NW waves][2][BN]
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a = row16_sum(ssum[s][j]), b = row16_sum(ssq[s][j]);
-                if (pl == 0) {
-                    red[(wv * 2 + 0) * BN + wc * 64 + s * 16 + g * 4 + j] = a;
-                    red[(wv * 2 + 1) * BN + wc * 64 + s * 16 + g * 4 + j] = b;
-                }
-            }
-    }
-    __syncthreads();
-    constexpr int PPR = BN * 2 / 16;                      // 16-byte pieces per pixel
-    for (int i = tid; i < GBM * PPR; i += NTHR) {
-        const int px = i / PPR, q = i - px * PPR;
-        *reinterpret_cast<uint4*>(yout + (size_t)(m0 + px) * p.Cout + co0 + q * 8) =
-            *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
-    }
-    // one partial per 128-pixel HALF of the tile: the [2][CoutPad][tiles] layout counts 128-pixel tiles whatever BM is
-    constexpr int HALVES = GBM / 128, WPH = WP / HALVES;      // pixel-wave rows per half
-    static_assert(WP % HALVES == 0, "a wave's pixels lie in one 128-pixel half");
-    if (p.stats) {
-        const float* red = reinterpret_cast<const float*>(smem);
-        for (int i = tid; i < HALVES * 2 * BN; i += NTHR) {
-            const int half = i / (2 * BN), which = (i / BN) & 1, c = i % BN;
-            // waves that hold couts [wc * 64, +64) of this half: wv = wp * WC + wc for wp in [half * WPH, +WPH), in wave order
-            float t = 0.f;
-#pragma unroll
-            for (int q = 0; q < WPH; ++q) t += red[(((half * WPH + q) * WC + c / 64 % WC) * 2 + which) * BN + c];
-            p.stats[((size_t)which * p.CoutPad + co0 + c) * ((size_t)npt * HALVES) + (size_t)pt * HALVES + half] = t;
-        }
-    }
+    gemm_epilogue<BN, BM>(p, acc, smem, m0, co0, pt, npt, tid, lane, wv, wc, wp);
 }
+
 
 template <int BN, int BM = GBM>
 int launch_gemm(const ConvArgs& a, hipStream_t st) {
