@@ -145,7 +145,8 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
             const int px = idx / XQ, q = idx % XQ;
             x_hy[i] = px / HWD; x_hx[i] = px % HWD;
             const int c = ci0 + q * EPV;
-            x_mode[i] = (idx >= HH * HWD * XQ || c >= p.Cin) ? 0 : ((xal_ && c + EPV <= p.Cin) ? 1 : 2);
+            // (bf16x3: a piece is two 16-byte halves of 4 fp32 channels, each loaded or zeroed on its own -- no ragged mode)
+            x_mode[i] = (idx >= HH * HWD * XQ || c >= p.Cin) ? 0 : ((X3 || (xal_ && c + EPV <= p.Cin)) ? 1 : 2);
         }
 #pragma unroll
         for (int i = 0; i < NDV; ++i) {
@@ -153,7 +154,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
             const int px = idx / DQ, q = idx % DQ;
             d_py[i] = px / TW; d_px[i] = px % TW;
             const int c = co0 + q * EPV;
-            d_mode[i] = (idx >= TH * TW * DQ || c >= p.Cout) ? 0 : ((dal_ && c + EPV <= p.Cout) ? 1 : 2);
+            d_mode[i] = (idx >= TH * TW * DQ || c >= p.Cout) ? 0 : ((X3 || (dal_ && c + EPV <= p.Cout)) ? 1 : 2);
         }
     }
     // ragged channel tail of one piece: element loads, zeros past `nvalid` elements
@@ -174,8 +175,8 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
     // at 32-bit byte offsets from the image base -- an out-of-range piece reads offset 0 and is zeroed by a select.
     // At two to three waves per SIMD this per-tile code is one dependent chain, so its length is time.
     const int xcb = (ci0 + (tid % XQ) * EPV), dcb = (co0 + (tid % DQ) * EPV);            // channel of this thread's pieces
-    const bool fast = xal_ && dal_ && (ci0 + ITT <= p.Cin || (p.Cin - ci0) % EPV == 0) &&
-                      (co0 + CT <= p.Cout || (p.Cout - co0) % EPV == 0);
+    const bool fast = X3 || (xal_ && dal_ && (ci0 + ITT <= p.Cin || (p.Cin - ci0) % EPV == 0) &&
+                             (co0 + CT <= p.Cout || (p.Cout - co0) % EPV == 0));
     unsigned x_okmask = 0;    // pieces of the fetched halo that lie inside the image (BatchNorm-on-load leaves padding zero)
     int c_bng = 0;            // BatchNorm group of the fetched tile's image
     auto fetch = [&]() {      // loads the tile the counter points at, then advances the counter
@@ -197,8 +198,9 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
                 const bool ok = x_mode[i] != 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && lin < p.in_npix;
 #pragma unroll
                 for (int l = 0; l < LV; ++l) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(xb + (ok ? (unsigned)lin * xps + (unsigned)xcb * (unsigned)sizeof(T) : 0u) + 16 * l);
-                    rx[i * LV + l] = ok ? v : make_uint4(0, 0, 0, 0);
+                    const bool okl = ok && (!X3 || xcb + 4 * l < p.Cin);       // (bf16x3: the half past a Cin % 8 == 4 tail is zero)
+                    const uint4 v = *reinterpret_cast<const uint4*>(xb + (okl ? (unsigned)lin * xps + (unsigned)xcb * (unsigned)sizeof(T) + 16 * l : 0u));
+                    rx[i * LV + l] = okl ? v : make_uint4(0, 0, 0, 0);
                 }
                 x_okmask |= ok ? (1u << i) : 0u;
             }
@@ -210,8 +212,9 @@ __device__ __forceinline__ void wg_body(const WgArgs& p, int bx, int kz, const i
                 const unsigned off = ok ? (unsigned)lin * dps + (unsigned)dcb * (unsigned)sizeof(T) : 0u;
 #pragma unroll
                 for (int l = 0; l < LV; ++l) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(db + off + 16 * l);
-                    rd[i * LV + l] = ok ? v : make_uint4(0, 0, 0, 0);
+                    const bool okl = ok && (!X3 || dcb + 4 * l < p.Cout);
+                    const uint4 v = *reinterpret_cast<const uint4*>(db + (okl ? off + 16 * l : 0u));
+                    rd[i * LV + l] = okl ? v : make_uint4(0, 0, 0, 0);
                 }
                 if constexpr (DYT) {
                     ry[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(
@@ -1120,12 +1123,13 @@ int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
 
 }  // namespace
 
-// dh_set_f32_mma_mode(1) (conv_mfma.hip): fp32 launches with whole, 16-byte aligned 8-channel pieces on both operands take the
-// split-bf16 three-product form (wg_body<f32x3>); the others keep the exact fp32 MFMA
+// dh_set_f32_mma_mode(1 / 2) (conv_mfma.hip): fp32 launches whose channel counts are multiples of 4 (16-byte aligned half
+// pieces: the class head's one-piece-per-pixel dlogits have 4) take the split-bf16 three-product form (wg_body<f32x3>); the
+// others keep the exact fp32 MFMA
 extern "C" int dh_get_f32_mma_mode(void);
 static inline bool wgrad_x3(int dtype, const WgArgs& a) {
     static const bool skip = getenv("DAHITRA_X3_NO_WGRAD") != nullptr;      // experiment switch
-    return !skip && dtype == DH_DTYPE_F32 && dh_get_f32_mma_mode() != 0 && a.Cin % 8 == 0 && a.Cout % 8 == 0 && a.CinPitch % 4 == 0;
+    return !skip && dtype == DH_DTYPE_F32 && dh_get_f32_mma_mode() != 0 && a.Cin % 4 == 0 && a.Cout % 4 == 0 && a.CinPitch % 4 == 0;
 }
 
 // split-K factor: one resident round of workgroups, never more slabs than pixel tiles

@@ -117,3 +117,24 @@ def test_product_never_imports_oracle():
                 if "cdnet_ref" in txt or "ref_import" in txt or "import oracle" in txt:
                     bad.append(fn)
     assert not bad, bad
+
+
+def test_every_test_name_the_documents_cite_exists():
+    """DESIGN.md / README.md / INTEGRATION.md cite tests as evidence: every `test_...` name in them must resolve to a test
+    function (names ending in `_` or `_*` are prefixes) or a test file of this tree"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    defined, files = set(), set()
+    for f in glob.glob(os.path.join(root, "tests", "test_*.py")):
+        files.add(os.path.basename(f)[:-3])
+        defined.update(re.findall(r"^def (test_[A-Za-z0-9_]+)\(", open(f).read(), flags=re.M))
+    missing = []
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md"):
+        for name in sorted(set(re.findall(r"\btest_[A-Za-z0-9_]+", open(os.path.join(root, doc)).read()))):
+            if name in defined or name in files:
+                continue
+            if name.endswith("_") and any(d.startswith(name) for d in defined | files):
+                continue
+            missing.append((doc, name))
+    assert not missing, missing

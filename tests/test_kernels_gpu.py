@@ -167,6 +167,24 @@ def test_conv2d_dgrad_and_wgrad(ops, dtype, mma, cfg):
         close(dw - 0.5, w.grad, dtype, "wgrad tr=%s" % tr, factor=4.0)
 
 
+@pytest.mark.parametrize("mma", [0, 1])
+def test_weight_gradient_of_the_class_head_from_one_piece_per_pixel_dlogits(ops, mma):
+    """fp32: the class head's dlogits are ONE 16-byte piece per pixel (4 floats, n_class = 2 real channels); its weight gradient
+    under both fp32 matrix-product forms -- the split-bf16 form stages 8-channel pieces and zero-fills the half past the 4th
+    channel (csrc/conv_wgrad.hip wg_body<f32x3>)"""
+    N, H, W = 3, 40, 48
+    x = rnd((N, 32, H, W), torch.float32, 31).requires_grad_(False)
+    w = rnd((2, 32, 3, 3), torch.float32, 32, scale=288 ** -0.5).requires_grad_(True)
+    y = F.conv2d(x, w, None, 1, 1)
+    dy = rnd(tuple(y.shape), torch.float32, 33)
+    y.backward(dy)
+    dy4 = torch.zeros(N, H, W, 4)
+    dy4[..., :2] = nhwc(dy)
+    dw = torch.zeros(2, 32, 3, 3, device="cuda")
+    ops.conv2d_wgrad(nhwc(x).cuda(), dy4.cuda(), dw, 3, 1, 1, cout_real=2, defer=False)
+    close(dw, w.grad, torch.float32, "class-head weight gradient (mma mode %d)" % mma, factor=2.0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_stem_space_to_depth_conv(ops, dtype):
     N = 2
@@ -1225,6 +1243,65 @@ def test_decoder_layer_fp8_forward(ops, mlp):
     assert rel(y16, ref) <= 1e-2
     assert rel(y8, y16) <= 3e-2 and rel(y8, ref) <= 3e-2
     assert torch.isfinite(y8).all()
+
+
+@pytest.mark.parametrize("mlp", [64, 32])
+@pytest.mark.parametrize("rpi", [256, 1024])
+def test_decoder_layer_bf16_backward_against_torch_autograd(ops, mlp, rpi):
+    """csrc/decoder_fused.hip, bf16, BACKWARD: dx, the operand gradients dKq / dVo^T and every parameter gradient of one fused
+    cross-attention + MLP layer against torch autograd (fp32, CPU) of the same layer -- models/help_funcs.py:52-63 (FeedForward
+    with nn.GELU, i.e. the erf form), :66-114 (Cross_Attention in the re-associated Kq / Vo form), :170-186 (the residual
+    wiring of TransformerDecoder).  The kernel recomputes the forward chain from x in bf16 and uses the fitted logistic-quintic
+    `gelu_fast` and its derivative (tools/gelu_fit.py: 2.7e-5 / 1.1e-4 from the erf form), so the bounds are bf16 bounds:
+    relative L2 <= 1e-2 for y and dx, <= 1.5e-2 for every other tensor (measured on MI355X: y 2.3e-3, dx 2.5e-3, dKq 3.7e-3,
+    dVo^T 3.0e-3, dW1 / dW2 3.0e-3, LayerNorm gradients <= 5.2e-3)."""
+    torch.manual_seed(0)
+    images, D = 3, 32
+    rows = images * rpi
+    dtype = torch.bfloat16
+    x = rnd((rows, D), dtype, 2001, 1.0)
+    dy = rnd((rows, D), dtype, 2002, 1.0)
+    kq = rnd((images, 32, D), dtype, 2003, 0.3)
+    voT = rnd((images, D, 32), dtype, 2004, 0.3)
+    g1, b1 = 1 + 0.1 * rnd((D,), torch.float32, 2005), 0.1 * rnd((D,), torch.float32, 2006)
+    g2, b2 = 1 + 0.1 * rnd((D,), torch.float32, 2007), 0.1 * rnd((D,), torch.float32, 2008)
+    bo = 0.1 * rnd((D,), torch.float32, 2009)
+    w1 = rnd((mlp, D), dtype, 2010, D ** -0.5)
+    w2 = rnd((D, mlp), dtype, 2011, mlp ** -0.5)
+    fb1, fb2 = 0.1 * rnd((mlp,), torch.float32, 2012), 0.1 * rnd((D,), torch.float32, 2013)
+    # ---- torch autograd, fp32 ----
+    leaves = [t.clone().requires_grad_(True) for t in (x, kq, voT, g1, b1, bo, g2, b2, w1, fb1, w2, fb2)]
+    tx, tkq, tvoT, tg1, tb1, tbo, tg2, tb2, tw1, tfb1, tw2, tfb2 = leaves
+    xn = F.layer_norm(tx, (D,), tg1, tb1, 1e-5).reshape(images, rpi, D)
+    dots = torch.einsum("ipc,ihc->iph", xn, tkq)
+    attn = torch.softmax(dots.reshape(images, rpi, 8, 4), -1).reshape(images, rpi, 32)
+    x1 = torch.einsum("iph,ich->ipc", attn, tvoT).reshape(rows, D) + tbo + tx
+    l2 = F.layer_norm(x1, (D,), tg2, tb2, 1e-5)
+    y = x1 + F.gelu(l2 @ tw1.t() + tfb1) @ tw2.t() + tfb2
+    y.backward(dy)
+    # ---- the kernel ----
+
+    class Prep:
+        pass
+    prep = Prep()
+    prep.kq, prep.voT = dev(kq, dtype), dev(voT, dtype)
+    prep.kqT, prep.vo = dev(kq.transpose(1, 2), dtype), dev(voT.transpose(1, 2), dtype)
+    w1p, w1T = ops.pack_weight(w1.cuda(), dtype, want_dgrad=True)
+    w2p, w2T = ops.pack_weight(w2.cuda(), dtype, want_dgrad=True)
+    cu = lambda t: t.cuda().contiguous()
+    grads = [torch.zeros_like(t).cuda() for t in (w1, w2, fb1, fb2, bo, g1, b1, g2, b2)]
+    yk = ops.decoder_layer_fwd(dev(x, dtype), prep, rpi, cu(g1), cu(b1), cu(bo), cu(g2), cu(b2), w1p, cu(fb1), w2p, cu(fb2), mlp)
+    dx, dkq, dvoT = ops.decoder_layer_bwd(dev(x, dtype), dev(dy, dtype), prep, rpi, cu(g1), cu(b1), cu(bo), cu(g2), cu(b2),
+                                          w1p, w1T, cu(fb1), w2p, w2T, cu(fb2), grads, mlp)
+    rel = lambda u, v: float((u.float().cpu() - v).norm() / v.norm())
+    got = dict(y=(yk, y.detach()), dx=(dx, tx.grad), dkq=(dkq, tkq.grad), dvoT=(dvoT, tvoT.grad), dw1=(grads[0], tw1.grad),
+               dw2=(grads[1], tw2.grad), db1=(grads[2], tfb1.grad), db2=(grads[3], tfb2.grad), dbo=(grads[4], tbo.grad),
+               dln1_g=(grads[5], tg1.grad), dln1_b=(grads[6], tb1.grad), dln2_g=(grads[7], tg2.grad), dln2_b=(grads[8], tb2.grad))
+    errs = {k: rel(u.reshape(v.shape), v) for k, (u, v) in got.items()}
+    print("decoder layer backward (mlp %d, %d rows per image): " % (mlp, rpi) + ", ".join("%s %.2e" % kv for kv in errs.items()))
+    assert errs["y"] <= 1e-2 and errs["dx"] <= 1e-2, errs
+    for k, e in errs.items():
+        assert e <= 1.5e-2, (k, e)
 
 
 @pytest.mark.parametrize("cfg", [

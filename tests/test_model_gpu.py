@@ -22,8 +22,8 @@ import cdnet_ref as O
 
 pytestmark = pytest.mark.gpu
 BF16_MAX_ERR = 0.15    # a-priori bound on the worst bf16 logit error, in units of the reference's max |logit| (measured: 0.036 / 0.090)
-GRAD_TOL = 6e-2        # of max|grad| per tensor (see module docstring)
-GRAD_TOL_R50 = 0.26
+GRAD_TOL = 6e-2        # of max|grad| per tensor (see module docstring; measured: 4.2e-2 / 5.4e-3 exact mode, 7.5e-4 / 4.8e-3 bf16x3)
+GRAD_TOL_R50 = 0.15    # (measured: 6.8e-2 exact mode, 8.8e-2 bf16x3; the oracle's own fp32-vs-fp64 floor for this net is 0.13 rel-max)
 NORM_TOL = 3e-2
 # The two parity modes, held to the SAME bounds: "fp32" = exact fp32 MFMA; "bf16x3" = the same fp32
 # pipeline with every matrix product on the bf16 matrix cores as split-bf16 products (dh_set_f32_mma_mode) -- the forward in
