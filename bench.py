@@ -286,7 +286,10 @@ def main():
     rehearsal = None
     headline_run = args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.dtype == "bf16" and args.net == NET \
         and args.img == SIZE and not args.fwd_only and not args.no_graph
-    if headline_run and not args.no_ddp_rehearsal and os.environ.get("DAHITRA_FORCE_DIST", "0") != "1":
+    # (never under a profiler: rocprofv3's preloaded library has initialised the GPU before this program starts, and a process
+    # that holds the GPU must not start another program)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if headline_run and not args.no_ddp_rehearsal and not profiled and os.environ.get("DAHITRA_FORCE_DIST", "0") != "1":
         import socket
         import subprocess
         with socket.socket() as sk:

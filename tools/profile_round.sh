@@ -1,4 +1,6 @@
-# usage (on the GPU box): bash tools/profile_round.sh <tag> [net]
+# usage (on the GPU box): bash tools/profile_round.sh <tag> [net] [label extra bench args...]
+#   e.g.  bash tools/profile_round.sh r05k base_transformer_pos_s4_resnet50 r50_1024 --img 1024 --batch 8
+#         bash tools/profile_round.sh r05k base_transformer_pos_s4 s4_bf16x3 --dtype bf16x3
 # Every profile the bench line quotes, in one go, written under gpurun_out/<tag>/ with the names they get in profiles/
 # (<tag>_... for the headline net, <tag>_<net>_... for any other: bench.py's _profile() looks them up by profiles/CURRENT):
 #   kernel-trace stats of the bench command, the four --pmc passes (FETCH_SIZE, WRITE_SIZE, MFMA busy, LDS conflicts;
@@ -6,14 +8,18 @@
 #   sequence of one graph-replayed step (launch count, kernel time, gaps).
 tag=$1
 net=${2:-base_transformer_pos_s4}
+label=$3
+if [ $# -ge 3 ]; then shift 3; else shift $#; fi
+EXTRA="$@"
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
 pre=${tag}
 stats=${tag}_bench_bf16_b32
 if [ "$net" != "base_transformer_pos_s4" ]; then pre=${tag}_${net}; stats=${tag}_bench_${net}; fi
+if [ -n "$label" ]; then pre=${tag}_${label}; stats=${tag}_bench_${label}; fi
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --net $net --steps 6 --warmup 2 --no-cpu-baseline --no-parity-mode --no-class-replay > $O/${pre}_prof_bench.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --net $net $EXTRA --steps 6 --warmup 2 --no-cpu-baseline --no-parity-mode --no-class-replay --no-secondary --no-ddp-rehearsal > $O/${pre}_prof_bench.json 2> $O/stats.err
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/${stats}_kernel_stats.csv
 python3 - $O/stats $O/${pre}_graph_step.txt <<'PY'
 import csv, glob, sys, re
@@ -38,7 +44,7 @@ with open(sys.argv[2], "w") as o:
             % (hi - lo, small, copies, tot / 1e3, gaps / 1e3, (int(rows[hi - 1]["End_Timestamp"]) - int(rows[lo]["Start_Timestamp"])) / 1e3))
 print(open(sys.argv[2]).read().splitlines()[-1])
 PY
-B="python3 $R/bench.py --net $net --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-class-replay --no-graph"
+B="python3 $R/bench.py --net $net $EXTRA --steps 3 --warmup 1 --no-cpu-baseline --no-parity-mode --no-class-replay --no-secondary --no-ddp-rehearsal --no-graph"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B > /dev/null 2> $O/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B > /dev/null 2> $O/write.err
 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/util -- $B > /dev/null 2> $O/util.err
