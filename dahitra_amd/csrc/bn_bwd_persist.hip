@@ -53,7 +53,8 @@ struct PersistArgs {
     int expect;            // arrivals the barrier waits for (PG; tests pass PG + 1 to force the timeout)
 };
 
-template <int MASK>      // 0: no ReLU, 1: mask from `out` (post-activation tensor), 2: mask recomputed from x
+template <int MASK>      // 0: no ReLU, 1: mask from `out` (post-activation tensor), 2: mask recomputed from x, 3: mask BYTES (`out` =
+                         // relu_bits of dh_bn_apply_bits: one byte per 16-byte piece)
 __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* xl = reinterpret_cast<uint4*>(smem);                                   // [PNP][PT] pieces of x
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
     const unsigned char* dout_w = reinterpret_cast<const unsigned char*>(p.dout) + wb;
     const unsigned char* x_w = reinterpret_cast<const unsigned char*>(p.x) + wb;
     const unsigned char* out_w = reinterpret_cast<const unsigned char*>(MASK == 1 ? p.out : p.x) + wb;
+    const unsigned char* bits_w = reinterpret_cast<const unsigned char*>(p.out) + (wb >> 4);        // MASK == 3: byte = piece
     unsigned char* dres_w = reinterpret_cast<unsigned char*>(p.dres) + wb;
     unsigned char* dx_w = reinterpret_cast<unsigned char*>(p.dx) + wb;
     // ---- phase 1: load once, keep g in registers / x in LDS, accumulate ----
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
 #pragma unroll
     for (int h = 0; h < PNP; h += HB) {
         uint4 xr[HB], orr[HB];
+        unsigned mb[HB];
 #pragma unroll
         for (int kk = 0; kk < HB; ++kk) {
             const int k = h + kk;
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
             gk[k] = *reinterpret_cast<const uint4*>(dout_w + off);
             xr[kk] = *reinterpret_cast<const uint4*>(x_w + off);
             if (MASK == 1) orr[kk] = *reinterpret_cast<const uint4*>(out_w + off);
+            if (MASK == 3) mb[kk] = bits_w[off >> 4];
             if (!ok) { gk[k] = zero; xr[kk] = zero; if (MASK == 1) orr[kk] = zero; }
         }
 #pragma unroll
@@ -125,6 +129,10 @@ __global__ __launch_bounds__(PT) void bn_bwd_persist_kernel(PersistArgs p) {
             if (MASK == 2) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d[j] = (xv[j] * ms[j] + mh[j]) > 0.f ? d[j] : 0.f;
+            }
+            if (MASK == 3) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = ((mb[kk] >> j) & 1u) ? d[j] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -321,10 +329,10 @@ static unsigned g_spin_limit = 0;
 extern "C" int dh_bn_bwd_persist_test_spin_limit(unsigned limit) { g_spin_limit = limit; return 0; }
 
 // C ABI: see include/dahitra_hip.h (dh_bn_bwd with `sync`)
-extern "C" int dh_bn_bwd_persist(const void* dout, const void* out_relu, const void* x, const float* mean,
-                                 const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
-                                 void* dres, float* dgamma, float* dbeta, int accumulate, const float* mask_scale,
-                                 const float* mask_shift, void* workspace, unsigned* sync, void* stream) {
+static int bn_bwd_persist_impl(const void* dout, const void* out_relu, bool bits, const void* x, const float* mean,
+                               const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
+                               void* dres, float* dgamma, float* dbeta, int accumulate, const float* mask_scale,
+                               const float* mask_shift, void* workspace, unsigned* sync, void* stream) {
     DH_REQUIRE(dh_bn_bwd_persist_supported(DH_DTYPE_BF16, npix, C, groups), "bn_bwd_persist: unsupported shape npix=%ld C=%d groups=%d",
                npix, C, groups);
     DH_REQUIRE(!(out_relu && mask_scale), "bn_bwd_persist: give the ReLU mask either as out_relu or as mask_scale/shift");
@@ -356,7 +364,24 @@ extern "C" int dh_bn_bwd_persist(const void* dout, const void* out_relu, const v
         DH_CHECK_LAUNCH("bn_bwd_persist");
         return 0;
     };
+    if (out_relu && bits) return go(bn_bwd_persist_kernel<3>);
     if (out_relu) return go(bn_bwd_persist_kernel<1>);
     if (mask_scale) return go(bn_bwd_persist_kernel<2>);
     return go(bn_bwd_persist_kernel<0>);
+}
+extern "C" int dh_bn_bwd_persist(const void* dout, const void* out_relu, const void* x, const float* mean,
+                                 const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
+                                 void* dres, float* dgamma, float* dbeta, int accumulate, const float* mask_scale,
+                                 const float* mask_shift, void* workspace, unsigned* sync, void* stream) {
+    return bn_bwd_persist_impl(dout, out_relu, false, x, mean, invstd, gamma, npix, C, groups, dx, dres, dgamma, dbeta, accumulate,
+                               mask_scale, mask_shift, workspace, sync, stream);
+}
+// C ABI: dh_bn_bwd_bits with `sync` (the ReLU mask as the bytes of dh_bn_apply_bits)
+extern "C" int dh_bn_bwd_persist_bits(const void* dout, const unsigned char* relu_bits, const void* x, const float* mean,
+                                      const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
+                                      void* dres, float* dgamma, float* dbeta, int accumulate, void* workspace, unsigned* sync,
+                                      void* stream) {
+    DH_REQUIRE(relu_bits, "bn_bwd_persist_bits: relu_bits missing");
+    return bn_bwd_persist_impl(dout, relu_bits, true, x, mean, invstd, gamma, npix, C, groups, dx, dres, dgamma, dbeta, accumulate,
+                               nullptr, nullptr, workspace, sync, stream);
 }

@@ -88,10 +88,18 @@ __global__ void bn_eval_params_kernel(const float* gamma, const float* beta, con
 }
 
 // ---- y = act(x*scale[g][c] + shift[g][c] (+ res)) -------------------------------------------
+// relu_bits (optional, 8-element pieces only): byte i = the ReLU mask of piece i, bit j = (y[8 i + j] > 0) -- what the backward
+// of a BatchNorm + residual + ReLU layer needs of `y` (one sixteenth of the tensor instead of the tensor, twice)
+template <int V> __device__ __forceinline__ unsigned relu_mask_byte(const float (&v)[V]) {
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) m |= (v[j] > 0.f ? 1u : 0u) << j;
+    return m;
+}
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                 const float* __restrict__ scale, const float* __restrict__ shift, long nvec,
-                                int C, long group_vec, int act) {
+                                int C, long group_vec, int act, unsigned char* __restrict__ relu_bits) {
     constexpr int V = V16<T>::N;        // one 16-byte piece per lane
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * V) % C);
@@ -111,6 +119,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ r
             for (int j = 0; j < V; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         stv(y + i * V, v);
+        if constexpr (V == 8) { if (relu_bits) relu_bits[i] = (unsigned char)relu_mask_byte(v); }
     }
 }
 
@@ -121,7 +130,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_hoist_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                              T* __restrict__ y, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, int C, long group_vec,
-                                                             int act) {
+                                                             int act, unsigned char* __restrict__ relu_bits) {
     constexpr int V = V16<T>::N;
     const int g = blockIdx.y;
     const long stride = (long)gridDim.x * 256;
@@ -133,6 +142,7 @@ __global__ __launch_bounds__(256) void bn_apply_hoist_kernel(const T* __restrict
     const size_t base = (size_t)g * group_vec * V;
     x += base; y += base;
     if (res) res += base;
+    if (relu_bits) relu_bits += (size_t)g * group_vec;
     const bool relu = act == DH_ACT_RELU;
     for (; i + stride < group_vec; i += 2 * stride) {
         float a[V], b[V], ra[V], rb[V];
@@ -148,6 +158,9 @@ __global__ __launch_bounds__(256) void bn_apply_hoist_kernel(const T* __restrict
         }
         stv(y + i * V, a);
         stv(y + (i + stride) * V, b);
+        if constexpr (V == 8) {
+            if (relu_bits) { relu_bits[i] = (unsigned char)relu_mask_byte(a); relu_bits[i + stride] = (unsigned char)relu_mask_byte(b); }
+        }
     }
     if (i < group_vec) {
         float a[V], ra[V];
@@ -160,13 +173,14 @@ __global__ __launch_bounds__(256) void bn_apply_hoist_kernel(const T* __restrict
             if (relu) a[j] = fmaxf(a[j], 0.f);
         }
         stv(y + i * V, a);
+        if constexpr (V == 8) { if (relu_bits) relu_bits[i] = (unsigned char)relu_mask_byte(a); }
     }
 }
 
 // ---- backward, pass 1: per-workgroup partial sums of dy and dy*xhat -------------------------
 // dy = dout * (out > 0) when `out` (the post-ReLU activation) is given.
 // partial: [2][C][G*bpg]; a workgroup never straddles two groups.
-template <typename T, int MASK>      // MASK: 0 none, 1 from `out`, 2 recomputed from x
+template <typename T, int MASK>      // MASK: 0 none, 1 from `out`, 2 recomputed from x, 3 from the forward's mask BYTES (`out` = relu_bits)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                             const T* __restrict__ x,
                                                             const float* __restrict__ mean,
@@ -194,11 +208,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         ldv(dout + off, d);
         ldv(x + off, xv);
         if (MASK == 1) ldv(out + off, o);
+        if (MASK == 3) o[0] = __uint_as_float((unsigned)reinterpret_cast<const unsigned char*>(out)[off / V]);
     };
     auto accum = [&](float (&d)[V], float (&xv)[V], float (&o)[V]) {
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             if (MASK == 1) d[j] = o[j] > 0.f ? d[j] : 0.f;
+            if (MASK == 3) d[j] = ((__float_as_uint(o[0]) >> j) & 1u) ? d[j] : 0.f;
             // MASK 2: ReLU mask recomputed from the pre-normalisation input (layers without a residual): the same
             // x * scale + shift the forward evaluated, so one tensor read less in each backward pass
             if (MASK == 2) d[j] = (xv[j] * ms[j] + mh[j]) > 0.f ? d[j] : 0.f;
@@ -266,7 +282,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ sums, float inv_m,
                                     long nvec, int C, long group_vec, T* __restrict__ dx, T* __restrict__ dres,
-                                    const float* __restrict__ mscale, const float* __restrict__ mshift) {
+                                    const float* __restrict__ mscale, const float* __restrict__ mshift, int out_is_bits) {
     constexpr int V = V16<T>::N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * V) % C);
@@ -274,7 +290,11 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
         float d[V], xv[V], r[V];
         ldv(dout + i * V, d);
         ldv(x + i * V, xv);
-        if (out) {
+        if (out && out_is_bits) {
+            const unsigned m = reinterpret_cast<const unsigned char*>(out)[i];
+#pragma unroll
+            for (int j = 0; j < V; ++j) d[j] = ((m >> j) & 1u) ? d[j] : 0.f;
+        } else if (out) {
             float o[V];
             ldv(out + i * V, o);
 #pragma unroll
@@ -295,7 +315,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
 }
 
 // The same expression with the per-channel operands hoisted (see bn_apply_hoist_kernel); grid = (workgroups per group, groups)
-template <typename T, int MASK>     // MASK: 0 none, 1 from `out` (post-ReLU activation), 2 recomputed from x
+template <typename T, int MASK>     // MASK: 0 none, 1 from `out` (post-ReLU activation), 2 recomputed from x, 3 from mask bytes (`out`)
 __global__ __launch_bounds__(256) void bn_bwd_apply_hoist_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                                  const T* __restrict__ x, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd,
@@ -319,11 +339,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_hoist_kernel(const T* __rest
     const size_t base = (size_t)g * group_vec * V;
     dout += base; x += base; dx += base;
     if (MASK == 1) out += base;
+    const unsigned char* bits = reinterpret_cast<const unsigned char*>(out) + (size_t)g * group_vec;      // MASK == 3
     if (dres) dres += base;
     auto piece = [&](long k, float (&d)[V], float (&xv)[V], float (&o)[V]) {
         ldv(dout + k * V, d);
         ldv(x + k * V, xv);
         if (MASK == 1) ldv(out + k * V, o);
+        if (MASK == 3) o[0] = __uint_as_float((unsigned)bits[k]);
     };
     auto finish = [&](long k, float (&d)[V], float (&xv)[V], float (&o)[V]) {
         float r[V];
@@ -331,6 +353,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_hoist_kernel(const T* __rest
         for (int j = 0; j < V; ++j) {
             if (MASK == 1) d[j] = o[j] > 0.f ? d[j] : 0.f;
             if (MASK == 2) d[j] = (xv[j] * ms[j] + mh[j]) > 0.f ? d[j] : 0.f;
+            if (MASK == 3) d[j] = ((__float_as_uint(o[0]) >> j) & 1u) ? d[j] : 0.f;
             const float xh = (xv[j] - mu[j]) * is[j];
             r[j] = ga[j] * is[j] * (d[j] - (s1[j] + xh * s2[j]) * inv_m);
         }
@@ -467,7 +490,7 @@ inline int hoist_grid(long gvec, int groups) {
 template <typename T>
 void launch_bn_bwd_apply(const void* dout, const void* out_relu, const void* x, const float* mean, const float* invstd,
                          const float* gamma, const float* sums, long ppg, long nvec, int C, int groups, void* dx, void* dres,
-                         const float* mask_scale, const float* mask_shift, hipStream_t st) {
+                         const float* mask_scale, const float* mask_shift, hipStream_t st, bool out_is_bits = false) {
     constexpr int V = V16<T>::N;
     const long gvec = nvec / groups;
     const float inv_m = 1.0f / (float)ppg;
@@ -476,25 +499,27 @@ void launch_bn_bwd_apply(const void* dout, const void* out_relu, const void* x, 
 #define DH_BWD_APPLY(M)                                                                                              \
         hipLaunchKernelGGL((bn_bwd_apply_hoist_kernel<T, M>), grid, dim3(256), 0, st, (const T*)dout, (const T*)out_relu, \
                            (const T*)x, mean, invstd, gamma, sums, inv_m, C, gvec, (T*)dx, (T*)dres, mask_scale, mask_shift)
-        if (out_relu) DH_BWD_APPLY(1);
+        if (out_relu && out_is_bits) DH_BWD_APPLY(3);
+        else if (out_relu) DH_BWD_APPLY(1);
         else if (mask_scale) DH_BWD_APPLY(2);
         else DH_BWD_APPLY(0);
 #undef DH_BWD_APPLY
     } else {
         hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(nvec, 256)), dim3(256), 0, st, (const T*)dout,
                            (const T*)out_relu, (const T*)x, mean, invstd, gamma, sums, inv_m, nvec, C, gvec, (T*)dx, (T*)dres,
-                           mask_scale, mask_shift);
+                           mask_scale, mask_shift, out_is_bits ? 1 : 0);
     }
 }
 
 template <typename T>
 void launch_bn_bwd_reduce(const void* dout, const void* out_relu, const void* x, const float* mean, const float* invstd, int C,
                           long ppg, int bpg, int groups, float* partial, const float* mask_scale, const float* mask_shift,
-                          hipStream_t st) {
+                          hipStream_t st, bool out_is_bits = false) {
 #define DH_BWD_REDUCE(M)                                                                                                  \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), dim3(groups * bpg), dim3(256), 0, st, (const T*)dout, (const T*)out_relu, \
                        (const T*)x, mean, invstd, C, ppg, bpg, partial, mask_scale, mask_shift)
-    if (out_relu) DH_BWD_REDUCE(1);
+    if (out_relu && out_is_bits) DH_BWD_REDUCE(3);
+    else if (out_relu) DH_BWD_REDUCE(1);
     else if (mask_scale) DH_BWD_REDUCE(2);
     else DH_BWD_REDUCE(0);
 #undef DH_BWD_REDUCE
@@ -502,15 +527,15 @@ void launch_bn_bwd_reduce(const void* dout, const void* out_relu, const void* x,
 
 template <typename T>
 void launch_bn_apply(const void* x, const void* residual, void* y, const float* scale, const float* shift, long nvec, int C,
-                     int groups, int act, hipStream_t st) {
+                     int groups, int act, hipStream_t st, unsigned char* relu_bits = nullptr) {
     constexpr int V = V16<T>::N;
     const long gvec = nvec / groups;
     if ((256 * V) % C == 0)
         hipLaunchKernelGGL(bn_apply_hoist_kernel<T>, dim3(hoist_grid(gvec, groups), groups), dim3(256), 0, st, (const T*)x,
-                           (const T*)residual, (T*)y, scale, shift, C, gvec, act);
+                           (const T*)residual, (T*)y, scale, shift, C, gvec, act, relu_bits);
     else
         hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_grid(nvec, 256)), dim3(256), 0, st, (const T*)x, (const T*)residual,
-                           (T*)y, scale, shift, nvec, C, gvec, act);
+                           (T*)y, scale, shift, nvec, C, gvec, act, relu_bits);
 }
 
 
@@ -665,16 +690,28 @@ extern "C" int dh_bn_eval_params(const float* gamma, const float* beta, const fl
     return 0;
 }
 
-extern "C" int dh_bn_apply(int dtype, const void* x, const void* residual, void* y, const float* scale,
-                           const float* shift, long npix, int C, int groups, int act, void* stream) {
+static int bn_apply_impl(int dtype, const void* x, const void* residual, void* y, const float* scale, const float* shift, long npix,
+                         int C, int groups, int act, unsigned char* relu_bits, void* stream) {
     const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;       // elements of one 16-byte piece
     DH_REQUIRE(C % V == 0 && npix % groups == 0, "bn_apply: C=%d npix=%ld groups=%d", C, npix, groups);
+    DH_REQUIRE(!relu_bits || (dtype == DH_DTYPE_BF16 && act == DH_ACT_RELU), "bn_apply: the ReLU mask bytes exist for bf16 + ReLU (8-element pieces)");
     const long nvec = npix * C / V, gvec = nvec / groups;
     (void)gvec;
-    if (dtype == DH_DTYPE_BF16) launch_bn_apply<bf16>(x, residual, y, scale, shift, nvec, C, groups, act, ST(stream));
+    if (dtype == DH_DTYPE_BF16) launch_bn_apply<bf16>(x, residual, y, scale, shift, nvec, C, groups, act, ST(stream), relu_bits);
     else launch_bn_apply<float>(x, residual, y, scale, shift, nvec, C, groups, act, ST(stream));
     DH_CHECK_LAUNCH("bn_apply");
     return 0;
+}
+extern "C" int dh_bn_apply(int dtype, const void* x, const void* residual, void* y, const float* scale,
+                           const float* shift, long npix, int C, int groups, int act, void* stream) {
+    return bn_apply_impl(dtype, x, residual, y, scale, shift, npix, C, groups, act, nullptr, stream);
+}
+// ... + relu_bits [npix * C / 8] bytes: byte i = the ReLU mask of the 8-element piece i of y (bit j: y[8 i + j] > 0), for
+// dh_bn_bwd_bits / dh_bn_bwd_persist_bits (bf16, act = DH_ACT_RELU)
+extern "C" int dh_bn_apply_bits(int dtype, const void* x, const void* residual, void* y, const float* scale, const float* shift,
+                                long npix, int C, int groups, int act, unsigned char* relu_bits, void* stream) {
+    DH_REQUIRE(relu_bits, "bn_apply_bits: relu_bits missing");
+    return bn_apply_impl(dtype, x, residual, y, scale, shift, npix, C, groups, act, relu_bits, stream);
 }
 
 // workspace: partial [groups*bpg][2][C] floats + sums [groups][2][C] floats
@@ -716,11 +753,12 @@ extern "C" long dh_bn_bwd_workspace_size(long npix, int C, int groups) {
     return ((long)groups * bpg * 2 * C + (long)groups * 2 * C) * 4;
 }
 
-extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, const void* x, const float* mean,
-                         const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
-                         void* dres, float* dgamma, float* dbeta, int accumulate, const float* mask_scale,
-                         const float* mask_shift, void* workspace, void* stream) {
+static int bn_bwd_impl(int dtype, const void* dout, const void* out_relu, bool bits, const void* x, const float* mean,
+                       const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
+                       void* dres, float* dgamma, float* dbeta, int accumulate, const float* mask_scale,
+                       const float* mask_shift, void* workspace, void* stream) {
     DH_REQUIRE(!(out_relu && mask_scale), "bn_bwd: give the ReLU mask either as out_relu or as mask_scale/shift");
+    DH_REQUIRE(!bits || (dtype == DH_DTYPE_BF16 && out_relu), "bn_bwd: mask bytes exist for bf16 (8-element pieces)");
     const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;       // elements of one 16-byte piece
     DH_REQUIRE(C % V == 0 && (256 * V) % C == 0, "bn_bwd: unsupported C=%d", C);
     DH_REQUIRE(npix % groups == 0 && groups <= BN_MAXG, "bn_bwd: npix %% groups, at most %d groups", BN_MAXG);
@@ -730,11 +768,11 @@ extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, cons
     float* sums = partial + (long)groups * bpg * 2 * C;
     const long nvec = npix * C / V;
     if (dtype == DH_DTYPE_BF16) {
-        launch_bn_bwd_reduce<bf16>(dout, out_relu, x, mean, invstd, C, ppg, bpg, groups, partial, mask_scale, mask_shift, ST(stream));
+        launch_bn_bwd_reduce<bf16>(dout, out_relu, x, mean, invstd, C, ppg, bpg, groups, partial, mask_scale, mask_shift, ST(stream), bits);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * groups), 0, ST(stream), partial, bpg, groups, C, sums,
                            dgamma, dbeta, accumulate);
         launch_bn_bwd_apply<bf16>(dout, out_relu, x, mean, invstd, gamma, sums, ppg, nvec, C, groups, dx, dres, mask_scale,
-                                  mask_shift, ST(stream));
+                                  mask_shift, ST(stream), bits);
     } else {
         launch_bn_bwd_reduce<float>(dout, out_relu, x, mean, invstd, C, ppg, bpg, groups, partial, mask_scale, mask_shift, ST(stream));
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * groups), 0, ST(stream), partial, bpg, groups, C, sums,
@@ -744,6 +782,22 @@ extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, cons
     }
     DH_CHECK_LAUNCH("bn_bwd");
     return 0;
+}
+extern "C" int dh_bn_bwd(int dtype, const void* dout, const void* out_relu, const void* x, const float* mean,
+                         const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
+                         void* dres, float* dgamma, float* dbeta, int accumulate, const float* mask_scale,
+                         const float* mask_shift, void* workspace, void* stream) {
+    return bn_bwd_impl(dtype, dout, out_relu, false, x, mean, invstd, gamma, npix, C, groups, dx, dres, dgamma, dbeta, accumulate,
+                       mask_scale, mask_shift, workspace, stream);
+}
+// the same with the ReLU mask given as the mask BYTES dh_bn_apply_bits wrote (bf16): the two passes read npix * C / 8 bytes
+// where dh_bn_bwd reads the post-activation tensor (npix * C * 2 bytes), twice
+extern "C" int dh_bn_bwd_bits(int dtype, const void* dout, const unsigned char* relu_bits, const void* x, const float* mean,
+                              const float* invstd, const float* gamma, long npix, int C, int groups, void* dx,
+                              void* dres, float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream) {
+    DH_REQUIRE(relu_bits, "bn_bwd_bits: relu_bits missing");
+    return bn_bwd_impl(dtype, dout, relu_bits, true, x, mean, invstd, gamma, npix, C, groups, dx, dres, dgamma, dbeta, accumulate,
+                       nullptr, nullptr, workspace, stream);
 }
 
 // BN backward when the producer of dout (a gated data-gradient launch of conv_mfma) already applied the ReLU mask and

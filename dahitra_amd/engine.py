@@ -285,6 +285,7 @@ class Engine:
         split = isinstance(x, ops.SplitCat)          # cat([A, B], channel) read in place (3x3 / stride 1, train mode, bf16)
         if split and not (self.training and ks == 3 and stride == 1 and pad == 1 and dilation == 1 and residual is None):
             x, split = x.materialize(), False
+        relu_bits = None
         if self.training:
             if split:
                 y, st = ops.conv3x3_split(x, self.pk[wkey].fwd, self.pk[wkey].fwd_frag, cout, want_stats=True)
@@ -294,7 +295,14 @@ class Engine:
             N, OH, OW, _ = y.shape
             mean, invstd, scale, shift = ops.bn_finalize(st, cout, groups, (N // groups) * OH * OW, gamma, beta, rm, rv,
                                                          BN_MOMENTUM, BN_EPS, nbt=self.p[bnkey + ".num_batches_tracked"])
-            out = ops.BnInput(y, scale, shift, groups) if lazy else ops.bn_apply(y, scale, shift, groups, act, residual)
+            if lazy:
+                out = ops.BnInput(y, scale, shift, groups)
+            elif relu and residual is not None and self.need_grad:
+                # BatchNorm + residual + ReLU: the backward needs the ReLU mask only -- written here as one byte per 8 elements
+                # (bf16) and read there in place of `out` (one tensor read less in each of its passes)
+                out, relu_bits = ops.bn_apply(y, scale, shift, groups, act, residual, want_bits=True)
+            else:
+                out = ops.bn_apply(y, scale, shift, groups, act, residual)
         else:
             # eval: BatchNorm folds into the convolution -- scale into the packed weights, shift as the bias
             scale, shift = ops.bn_eval_params(gamma, beta, rm, rv, BN_EPS)
@@ -318,7 +326,7 @@ class Engine:
                                       mask_shift=shift), None
             else:
                 r = ops.bn_bwd(dout, out if relu else None, y, mean, invstd, gamma, self.g[bnkey + ".weight"],
-                               self.g[bnkey + ".bias"], groups, accumulate=True, want_dres=has_res)
+                               self.g[bnkey + ".bias"], groups, accumulate=True, want_dres=has_res, bits=relu_bits)
                 dy, dres = r if has_res else (r, None)
             if side_wgrad and self.side is not None:
                 # Deferred to the side stream: nothing until the batched split-K reduce needs this weight gradient.  It is

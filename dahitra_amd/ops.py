@@ -871,14 +871,26 @@ def bn_eval_params(gamma, beta, rm, rv, eps=1e-5):
     return scale, shift
 
 
-def bn_apply(x, scale, shift, groups=1, act=ACT_NONE, residual=None):
+RELU_BITS = os.environ.get("DAHITRA_NO_RELU_BITS", "0") != "1"      # A/B switch of bn_apply(want_bits=True)
+
+
+def bn_apply(x, scale, shift, groups=1, act=ACT_NONE, residual=None, want_bits=False):
+    """want_bits (bf16 + ReLU): also returns the ReLU mask of y as bytes [numel / 8] (dh_bn_apply_bits) -- what bn_bwd(bits=...)
+    reads in place of the post-activation tensor; None where the form does not exist (fp32, or DAHITRA_NO_RELU_BITS=1)"""
     C = x.shape[-1]
     npix = x.numel() // C
     y = torch.empty_like(x)
+    bits = None
+    if want_bits and RELU_BITS and x.dtype == torch.bfloat16 and act == ACT_RELU and C % 8 == 0:
+        bits = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device)
     with _Prof("bn_apply", 0, _nb(x, residual, y)):
-        _call("dh_bn_apply", _ci(dt(x)), P(x), P(residual), P(y), P(scale), P(shift), _cl(npix), _ci(C), _ci(groups),
-              _ci(act), S())
-    return y
+        if bits is not None:
+            _call("dh_bn_apply_bits", _ci(dt(x)), P(x), P(residual), P(y), P(scale), P(shift), _cl(npix), _ci(C), _ci(groups),
+                  _ci(act), P(bits), S())
+        else:
+            _call("dh_bn_apply", _ci(dt(x)), P(x), P(residual), P(y), P(scale), P(shift), _cl(npix), _ci(C), _ci(groups),
+                  _ci(act), S())
+    return (y, bits) if want_bits else y
 
 
 _BN_SYNC = {}
@@ -933,7 +945,8 @@ def bn_persist_check(device=None):
 
 
 def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accumulate=False, want_dres=False,
-           mask_scale=None, mask_shift=None):
+           mask_scale=None, mask_shift=None, bits=None):
+    """bits: the ReLU mask bytes of bn_apply(want_bits=True), used in place of out_relu"""
     C = x.shape[-1]
     npix = x.numel() // C
     dx = torch.empty_like(x)
@@ -946,15 +959,23 @@ def bn_bwd(dout, out_relu, x, mean, invstd, gamma, dgamma, dbeta, groups=1, accu
         # one persistent launch, tensors held on chip across a device-wide barrier: every tensor is read once
         global BN_PERSIST_LAUNCHES
         BN_PERSIST_LAUNCHES += 1
-        with _Prof("bn_bwd", 0, _nb(dout, out_relu, x) + _nb(dx, dres)):
-            _call("dh_bn_bwd_persist", P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
-                  _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(mask_scale), P(mask_shift),
-                  P(ws), P(bn_sync_words(x.device)), S())
+        with _Prof("bn_bwd", 0, _nb(dout, bits if bits is not None else out_relu, x) + _nb(dx, dres)):
+            if bits is not None:
+                _call("dh_bn_bwd_persist_bits", P(dout), P(bits), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
+                      _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(ws), P(bn_sync_words(x.device)), S())
+            else:
+                _call("dh_bn_bwd_persist", P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
+                      _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(mask_scale), P(mask_shift),
+                      P(ws), P(bn_sync_words(x.device)), S())
         return (dx, dres) if want_dres else dx
     # two passes (reduce, apply): dout / x (/ out) are read twice, dx (/ dres) written once
-    with _Prof("bn_bwd", 0, 2 * _nb(dout, out_relu, x) + _nb(dx, dres)):
-        _call("dh_bn_bwd", _ci(dt(x)), P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
-              _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(mask_scale), P(mask_shift), P(ws), S())
+    with _Prof("bn_bwd", 0, 2 * _nb(dout, bits if bits is not None else out_relu, x) + _nb(dx, dres)):
+        if bits is not None:
+            _call("dh_bn_bwd_bits", _ci(dt(x)), P(dout), P(bits), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
+                  _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(ws), S())
+        else:
+            _call("dh_bn_bwd", _ci(dt(x)), P(dout), P(out_relu), P(x), P(mean), P(invstd), P(gamma), _cl(npix), _ci(C),
+                  _ci(groups), P(dx), P(dres), P(dgamma), P(dbeta), _ci(int(accumulate)), P(mask_scale), P(mask_shift), P(ws), S())
     return (dx, dres) if want_dres else dx
 
 

@@ -273,6 +273,20 @@ int dh_bn_bwd_persist(const void* dout, const void* out_relu, const void* x, con
                       const float* gamma, long npix, int C, int groups, void* dx, void* dres, float* dgamma, float* dbeta,
                       int accumulate, const float* mask_scale, const float* mask_shift, void* workspace, unsigned* sync,
                       void* stream);
+/* The ReLU mask of a BatchNorm + residual + ReLU layer (models/resnet.py:56-71, 104-121: out = relu(bn(y) + identity)) as BYTES
+ * instead of the post-activation tensor (bf16): dh_bn_apply_bits = dh_bn_apply that also writes relu_bits [npix * C / 8] -- byte i
+ * holds the mask of the 8-element piece i of y, bit j = (y[8 i + j] > 0) -- and dh_bn_bwd_bits / dh_bn_bwd_persist_bits =
+ * dh_bn_bwd / dh_bn_bwd_persist reading those bytes where the latter read out_relu: one sixteenth of a tensor pass instead of
+ * one (persistent form) or two (two-pass form).  Same results bit for bit.  Replaces the same autograd nodes as dh_bn_bwd
+ * (native_batch_norm_backward + threshold_backward). */
+int dh_bn_apply_bits(int dtype, const void* x, const void* residual, void* y, const float* scale, const float* shift, long npix,
+                     int C, int groups, int act, unsigned char* relu_bits, void* stream);
+int dh_bn_bwd_bits(int dtype, const void* dout, const unsigned char* relu_bits, const void* x, const float* mean, const float* invstd,
+                   const float* gamma, long npix, int C, int groups, void* dx, void* dres, float* dgamma, float* dbeta, int accumulate,
+                   void* workspace, void* stream);
+int dh_bn_bwd_persist_bits(const void* dout, const unsigned char* relu_bits, const void* x, const float* mean, const float* invstd,
+                           const float* gamma, long npix, int C, int groups, void* dx, void* dres, float* dgamma, float* dbeta,
+                           int accumulate, void* workspace, unsigned* sync, void* stream);
 int dh_bn_bwd_persist_status(unsigned* sync, void* stream);
 int dh_bn_bwd_persist_test_spin_limit(unsigned limit);   /* tests: limit > 0 forces the timeout path (0 restores 2^22 spins) */
 int dh_bn_bwd_from_partials(int dtype, const void* g, const void* x, const float* partial, int ntiles, const float* mean,
