@@ -88,8 +88,8 @@ __global__ void bn_eval_params_kernel(const float* gamma, const float* beta, con
 }
 
 // ---- y = act(x*scale[g][c] + shift[g][c] (+ res)) -------------------------------------------
-// relu_bits (optional, 8-element pieces only): byte i = the ReLU mask of piece i, bit j = (y[8 i + j] > 0) -- what the backward
-// of a BatchNorm + residual + ReLU layer needs of `y` (one sixteenth of the tensor instead of the tensor, twice)
+// relu_bits (optional): byte i = the ReLU mask of the 16-byte piece i (V = 8 bf16 / 4 fp32 elements), bit j = (y[V i + j] > 0) --
+// what the backward of a BatchNorm + residual + ReLU layer needs of `y` (one sixteenth of the tensor instead of the tensor, twice)
 template <int V> __device__ __forceinline__ unsigned relu_mask_byte(const float (&v)[V]) {
     unsigned m = 0;
 #pragma unroll
@@ -119,7 +119,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ r
             for (int j = 0; j < V; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         stv(y + i * V, v);
-        if constexpr (V == 8) { if (relu_bits) relu_bits[i] = (unsigned char)relu_mask_byte(v); }
+        if (relu_bits) relu_bits[i] = (unsigned char)relu_mask_byte(v);
     }
 }
 
@@ -158,9 +158,7 @@ __global__ __launch_bounds__(256) void bn_apply_hoist_kernel(const T* __restrict
         }
         stv(y + i * V, a);
         stv(y + (i + stride) * V, b);
-        if constexpr (V == 8) {
-            if (relu_bits) { relu_bits[i] = (unsigned char)relu_mask_byte(a); relu_bits[i + stride] = (unsigned char)relu_mask_byte(b); }
-        }
+        if (relu_bits) { relu_bits[i] = (unsigned char)relu_mask_byte(a); relu_bits[i + stride] = (unsigned char)relu_mask_byte(b); }
     }
     if (i < group_vec) {
         float a[V], ra[V];
@@ -173,7 +171,7 @@ __global__ __launch_bounds__(256) void bn_apply_hoist_kernel(const T* __restrict
             if (relu) a[j] = fmaxf(a[j], 0.f);
         }
         stv(y + i * V, a);
-        if constexpr (V == 8) { if (relu_bits) relu_bits[i] = (unsigned char)relu_mask_byte(a); }
+        if (relu_bits) relu_bits[i] = (unsigned char)relu_mask_byte(a);
     }
 }
 
@@ -694,11 +692,11 @@ static int bn_apply_impl(int dtype, const void* x, const void* residual, void* y
                          int C, int groups, int act, unsigned char* relu_bits, void* stream) {
     const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;       // elements of one 16-byte piece
     DH_REQUIRE(C % V == 0 && npix % groups == 0, "bn_apply: C=%d npix=%ld groups=%d", C, npix, groups);
-    DH_REQUIRE(!relu_bits || (dtype == DH_DTYPE_BF16 && act == DH_ACT_RELU), "bn_apply: the ReLU mask bytes exist for bf16 + ReLU (8-element pieces)");
+    DH_REQUIRE(!relu_bits || act == DH_ACT_RELU, "bn_apply: the ReLU mask bytes go with act = DH_ACT_RELU");
     const long nvec = npix * C / V, gvec = nvec / groups;
     (void)gvec;
     if (dtype == DH_DTYPE_BF16) launch_bn_apply<bf16>(x, residual, y, scale, shift, nvec, C, groups, act, ST(stream), relu_bits);
-    else launch_bn_apply<float>(x, residual, y, scale, shift, nvec, C, groups, act, ST(stream));
+    else launch_bn_apply<float>(x, residual, y, scale, shift, nvec, C, groups, act, ST(stream), relu_bits);
     DH_CHECK_LAUNCH("bn_apply");
     return 0;
 }
@@ -706,8 +704,8 @@ extern "C" int dh_bn_apply(int dtype, const void* x, const void* residual, void*
                            const float* shift, long npix, int C, int groups, int act, void* stream) {
     return bn_apply_impl(dtype, x, residual, y, scale, shift, npix, C, groups, act, nullptr, stream);
 }
-// ... + relu_bits [npix * C / 8] bytes: byte i = the ReLU mask of the 8-element piece i of y (bit j: y[8 i + j] > 0), for
-// dh_bn_bwd_bits / dh_bn_bwd_persist_bits (bf16, act = DH_ACT_RELU)
+// ... + relu_bits [npix * C / V] bytes (V = 8 bf16 / 4 fp32 elements per 16-byte piece): byte i = the ReLU mask of piece i of y
+// (bit j: y[V i + j] > 0), for dh_bn_bwd_bits / dh_bn_bwd_persist_bits (act = DH_ACT_RELU)
 extern "C" int dh_bn_apply_bits(int dtype, const void* x, const void* residual, void* y, const float* scale, const float* shift,
                                 long npix, int C, int groups, int act, unsigned char* relu_bits, void* stream) {
     DH_REQUIRE(relu_bits, "bn_apply_bits: relu_bits missing");
@@ -758,7 +756,7 @@ static int bn_bwd_impl(int dtype, const void* dout, const void* out_relu, bool b
                        void* dres, float* dgamma, float* dbeta, int accumulate, const float* mask_scale,
                        const float* mask_shift, void* workspace, void* stream) {
     DH_REQUIRE(!(out_relu && mask_scale), "bn_bwd: give the ReLU mask either as out_relu or as mask_scale/shift");
-    DH_REQUIRE(!bits || (dtype == DH_DTYPE_BF16 && out_relu), "bn_bwd: mask bytes exist for bf16 (8-element pieces)");
+    DH_REQUIRE(!bits || out_relu, "bn_bwd: mask bytes missing");
     const int V = dtype == DH_DTYPE_BF16 ? 8 : 4;       // elements of one 16-byte piece
     DH_REQUIRE(C % V == 0 && (256 * V) % C == 0, "bn_bwd: unsupported C=%d", C);
     DH_REQUIRE(npix % groups == 0 && groups <= BN_MAXG, "bn_bwd: npix %% groups, at most %d groups", BN_MAXG);
@@ -774,11 +772,11 @@ static int bn_bwd_impl(int dtype, const void* dout, const void* out_relu, bool b
         launch_bn_bwd_apply<bf16>(dout, out_relu, x, mean, invstd, gamma, sums, ppg, nvec, C, groups, dx, dres, mask_scale,
                                   mask_shift, ST(stream), bits);
     } else {
-        launch_bn_bwd_reduce<float>(dout, out_relu, x, mean, invstd, C, ppg, bpg, groups, partial, mask_scale, mask_shift, ST(stream));
+        launch_bn_bwd_reduce<float>(dout, out_relu, x, mean, invstd, C, ppg, bpg, groups, partial, mask_scale, mask_shift, ST(stream), bits);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * groups), 0, ST(stream), partial, bpg, groups, C, sums,
                            dgamma, dbeta, accumulate);
         launch_bn_bwd_apply<float>(dout, out_relu, x, mean, invstd, gamma, sums, ppg, nvec, C, groups, dx, dres, mask_scale,
-                                   mask_shift, ST(stream));
+                                   mask_shift, ST(stream), bits);
     }
     DH_CHECK_LAUNCH("bn_bwd");
     return 0;

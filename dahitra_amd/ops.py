@@ -875,14 +875,15 @@ RELU_BITS = os.environ.get("DAHITRA_NO_RELU_BITS", "0") != "1"      # A/B switch
 
 
 def bn_apply(x, scale, shift, groups=1, act=ACT_NONE, residual=None, want_bits=False):
-    """want_bits (bf16 + ReLU): also returns the ReLU mask of y as bytes [numel / 8] (dh_bn_apply_bits) -- what bn_bwd(bits=...)
-    reads in place of the post-activation tensor; None where the form does not exist (fp32, or DAHITRA_NO_RELU_BITS=1)"""
+    """want_bits (ReLU): also returns the ReLU mask of y as one byte per 16-byte piece (dh_bn_apply_bits) -- what bn_bwd(bits=...)
+    reads in place of the post-activation tensor; None with DAHITRA_NO_RELU_BITS=1"""
     C = x.shape[-1]
     npix = x.numel() // C
     y = torch.empty_like(x)
     bits = None
-    if want_bits and RELU_BITS and x.dtype == torch.bfloat16 and act == ACT_RELU and C % 8 == 0:
-        bits = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device)
+    v = 8 if x.dtype == torch.bfloat16 else 4
+    if want_bits and RELU_BITS and act == ACT_RELU and C % v == 0:
+        bits = torch.empty(x.numel() // v, dtype=torch.uint8, device=x.device)
     with _Prof("bn_apply", 0, _nb(x, residual, y)):
         if bits is not None:
             _call("dh_bn_apply_bits", _ci(dt(x)), P(x), P(residual), P(y), P(scale), P(shift), _cl(npix), _ci(C), _ci(groups),

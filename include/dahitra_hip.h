@@ -274,8 +274,9 @@ int dh_bn_bwd_persist(const void* dout, const void* out_relu, const void* x, con
                       int accumulate, const float* mask_scale, const float* mask_shift, void* workspace, unsigned* sync,
                       void* stream);
 /* The ReLU mask of a BatchNorm + residual + ReLU layer (models/resnet.py:56-71, 104-121: out = relu(bn(y) + identity)) as BYTES
- * instead of the post-activation tensor (bf16): dh_bn_apply_bits = dh_bn_apply that also writes relu_bits [npix * C / 8] -- byte i
- * holds the mask of the 8-element piece i of y, bit j = (y[8 i + j] > 0) -- and dh_bn_bwd_bits / dh_bn_bwd_persist_bits =
+ * instead of the post-activation tensor: dh_bn_apply_bits = dh_bn_apply that also writes relu_bits [npix * C / V] (V = 8 bf16 /
+ * 4 fp32 elements per 16-byte piece) -- byte i holds the mask of piece i of y, bit j = (y[V i + j] > 0) -- and dh_bn_bwd_bits /
+ * dh_bn_bwd_persist_bits (bf16) =
  * dh_bn_bwd / dh_bn_bwd_persist reading those bytes where the latter read out_relu: one sixteenth of a tensor pass instead of
  * one (persistent form) or two (two-pass form).  Same results bit for bit.  Replaces the same autograd nodes as dh_bn_bwd
  * (native_batch_norm_backward + threshold_backward). */

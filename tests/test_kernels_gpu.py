@@ -1662,13 +1662,14 @@ def test_decoder_stack_in_one_launch_equals_layer_by_layer(ops, cfg):
     assert torch.equal(part, part_ref)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [dict(n=4, h=16, w=24, c=64, groups=2), dict(n=2, h=8, w=8, c=256, groups=1),
-                                 dict(n=64, h=64, w=64, c=64, groups=2)])       # the last: the persistent one-launch form
-def test_batchnorm_residual_relu_mask_as_bytes_equals_the_tensor_form(ops, cfg, monkeypatch):
+                                 dict(n=64, h=64, w=64, c=64, groups=2)])       # the last: the persistent one-launch form (bf16)
+def test_batchnorm_residual_relu_mask_as_bytes_equals_the_tensor_form(ops, cfg, dtype):
     """dh_bn_apply_bits / dh_bn_bwd_bits / dh_bn_bwd_persist_bits (bf16): the ReLU mask of out = relu(bn(y) + identity) as one
     byte per 8 elements -- the forward output is unchanged, the bytes are the mask of that output, and the backward that reads
     them equals the backward that reads the post-activation tensor BIT FOR BIT (two-pass and persistent forms)"""
-    dtype = torch.bfloat16
+    V = 8 if dtype == torch.bfloat16 else 4
     N, H, W, C, G = cfg["n"], cfg["h"], cfg["w"], cfg["c"], cfg["groups"]
     y = dev(rnd((N, H, W, C), dtype, 3001), dtype)
     res = dev(rnd((N, H, W, C), dtype, 3002), dtype)
@@ -1680,12 +1681,12 @@ def test_batchnorm_residual_relu_mask_as_bytes_equals_the_tensor_form(ops, cfg, 
     gamma = (1 + 0.1 * rnd((C,), torch.float32, 3008)).cuda()
     out0 = ops.bn_apply(y, scale, shift, G, ops.ACT_RELU, res)
     out1, bits = ops.bn_apply(y, scale, shift, G, ops.ACT_RELU, res, want_bits=True)
-    assert bits is not None and bits.numel() == y.numel() // 8 and torch.equal(out0, out1)
-    want = (out0.float().reshape(-1, 8) > 0).to(torch.int32)
-    got = (bits.to(torch.int32).unsqueeze(1) >> torch.arange(8, device="cuda", dtype=torch.int32)) & 1
+    assert bits is not None and bits.numel() == y.numel() // V and torch.equal(out0, out1)
+    want = (out0.float().reshape(-1, V) > 0).to(torch.int32)
+    got = (bits.to(torch.int32).unsqueeze(1) >> torch.arange(V, device="cuda", dtype=torch.int32)) & 1
     assert torch.equal(got, want)
-    persist = bool(ops._lib.lib().dh_bn_bwd_persist_preferred(1, N * H * W, C, G))
-    assert persist == (N == 64)
+    persist = bool(ops._lib.lib().dh_bn_bwd_persist_preferred(1 if dtype == torch.bfloat16 else 0, N * H * W, C, G))
+    assert persist == (N == 64 and dtype == torch.bfloat16)
     for want_dres in (True, False):
         outs = []
         for b in (None, bits):
