@@ -120,7 +120,17 @@ __device__ __forceinline__ void gemm_epilogue(const ConvArgs& p, f32x4 (&acc)[4]
     }
 }
 
-template <int BN, int BM = GBM>
+// XDEEP (256-pixel tiles): the ACTIVATION rows are staged three steps deep, the weights two.  The activation is what comes from
+// HBM (every byte once, ~2 us away); the weights come from L2.  With both two deep a CU has one 32 KB activation stage in
+// flight, bursty; with three, two are in flight at any time.  Measured: 222 -> 214 us on the pure-streaming 1024 -> 256 shape and
+// nothing elsewhere -- every K >= 512 shape sits at ~3.3 us per 64-channel step whether its activation comes from HBM or from
+// L2 (512 -> 1024: four cout tiles per pixel tile), i.e. the two-barrier step itself (LDS fragment reads, then MFMAs, all
+// eight waves in lock step) is the bound, ~650 TFLOP/s, as the guide's tile table says of this structure (792 TFLOP/s at
+// 256 x 256 on L2-resident operands).  (A plain streaming kernel reads HBM at 6 TB/s for any row pitch and any bytes per row
+// and step: experiments/microbench/dram_pitch.hip -- the access pattern is not the problem either.)  Loads
+// retire in issue order per wave (vmcnt), so a step issues the weights of step k + 1 BEFORE the activation of step k + 2: the
+// wait for step k's data then leaves the younger activation loads outstanding.
+template <int BN, int BM = GBM, bool XDEEP = false>
 __global__ __launch_bounds__(2 * BM, 256 / BM) void conv1x1_gemm_kernel(ConvArgs p) {
     constexpr int GBM = BM;                              // pixels per workgroup (128: 4 waves, 256: 8 waves)
     constexpr int NW = BM / 32, NTHR = 64 * NW;
@@ -167,6 +177,19 @@ __global__ __launch_bounds__(2 * BM, 256 / BM) void conv1x1_gemm_kernel(ConvArgs
 #pragma unroll
         for (int j = 0; j < NI; ++j) glds16(src[j] + (size_t)k0 * 2, smem + stage * STAGE + (j * NW + wv) * 1024);
     };
+    // XDEEP: weight rows = instructions j < NIW of a wave (rows [0, BN)), activation rows the others; their own stage rings
+    constexpr int NIW = BN / (8 * NW), NIX = GBM / (8 * NW);
+    constexpr int WSTAGE = BN * 128, XSTAGE = GBM * 128, XBASE = 2 * WSTAGE;         // LDS: [2 weight stages][3 activation stages]
+    static_assert(!XDEEP || (NIW >= 1 && NIX >= 1 && NIW + NIX == NI), "a wave's loads split into whole weight / activation instructions");
+    auto issue_w = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) glds16(src[j] + (size_t)kt * (GBK * 2), smem + (kt & 1) * WSTAGE + (j * NW + wv) * 1024);
+    };
+    auto issue_x = [&](int kt) {
+#pragma unroll
+        for (int j = NIW; j < NI; ++j)
+            glds16(src[j] + (size_t)kt * (GBK * 2), smem + XBASE + (kt % 3) * XSTAGE + ((j - NIW) * NW + wv) * 1024);
+    };
 
     f32x4 acc[4][NT_];
 #pragma unroll
@@ -175,18 +198,34 @@ __global__ __launch_bounds__(2 * BM, 256 / BM) void conv1x1_gemm_kernel(ConvArgs
         for (int t = 0; t < NT_; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = p.Cin / GBK;
-    issue(0, 0);
+    if constexpr (XDEEP) {
+        issue_w(0);
+        issue_x(0);
+        if (KT > 1) issue_x(1);
+    } else {
+        issue(0, 0);
+    }
     for (int kt = 0; kt < KT; ++kt) {
         const bool more = kt + 1 < KT;
-        if (more) issue((kt + 1) & 1, (kt + 1) * GBK);
-        // this wave's loads of step kt have landed when at most the NI just-issued ones are outstanding
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (XDEEP) {
+            // issue order [W(kt+1), X(kt+2)] after [.., W(kt), X(kt+1)]: everything up to X(kt) and W(kt) has landed when only
+            // X(kt+1), W(kt+1), X(kt+2) are outstanding
+            if (more) issue_w(kt + 1);
+            if (kt + 2 < KT) issue_x(kt + 2);
+            if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIX + NIW + NIX) : "memory");
+            else if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIX + NIW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (more) issue((kt + 1) & 1, (kt + 1) * GBK);
+            // this wave's loads of step kt have landed when at most the NI just-issued ones are outstanding
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                    // (raw: a __syncthreads would drain the loads in flight)
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* sa = smem + (kt & 1) * STAGE;
-        const unsigned char* sb = sa + BN * 128;
+        const unsigned char* sa = XDEEP ? smem + (kt & 1) * WSTAGE : smem + (kt & 1) * STAGE;
+        const unsigned char* sb = XDEEP ? smem + XBASE + (kt % 3) * XSTAGE : sa + BN * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + g;
@@ -215,14 +254,14 @@ __global__ __launch_bounds__(2 * BM, 256 / BM) void conv1x1_gemm_kernel(ConvArgs
 }
 
 
-template <int BN, int BM = GBM>
+template <int BN, int BM = GBM, bool XDEEP = false>
 int launch_gemm(const ConvArgs& a, hipStream_t st) {
     constexpr int GBM = BM;
     constexpr int ROWS = BN + GBM;
-    const size_t staging = (size_t)2 * ROWS * 128;
+    const size_t staging = XDEEP ? (size_t)(2 * BN + 3 * GBM) * 128 : (size_t)2 * ROWS * 128;
     const size_t otile = (size_t)(BM / 32) * 2 * BN * 4 + (size_t)GBM * (BN * 2 + 16);
     const size_t lds = staging > otile ? staging : otile;
-    auto kern = conv1x1_gemm_kernel<BN, BM>;
+    auto kern = conv1x1_gemm_kernel<BN, BM, XDEEP>;
     static bool attr_done = false;
     if (lds > 64 * 1024 && !attr_done) {
         attr_done = true;
@@ -251,7 +290,11 @@ int dh_conv1x1_gemm_launch(const ConvArgs& a, hipStream_t st) {
     static const bool small = getenv("DAHITRA_GEMM1X1_SMALL") != nullptr;       // A/B switch: 128-pixel tiles only
     const long M = (long)a.N * a.OH * a.OW;
     // 256-pixel tiles where they still give the chip at least two rounds of workgroups
-    if (!small && M % 256 == 0 && a.Cout % 128 == 0 && (M / 256) * (a.Cout / (a.Cout % 256 == 0 ? 256 : 128)) >= 512)
-        return a.Cout % 256 == 0 ? launch_gemm<256, 256>(a, st) : launch_gemm<128, 256>(a, st);
+    static const bool shallow = getenv("DAHITRA_GEMM1X1_SHALLOW") != nullptr;   // A/B switch: activation two stages deep as the weights
+    if (!small && M % 256 == 0 && a.Cout % 128 == 0 && (M / 256) * (a.Cout / (a.Cout % 256 == 0 ? 256 : 128)) >= 512) {
+        if (shallow) return a.Cout % 256 == 0 ? launch_gemm<256, 256>(a, st) : launch_gemm<128, 256>(a, st);
+        // (the three-deep activation ring: 222 -> 214 us on 1024 -> 256, neutral on the others, slower at 128 couts: 83 -> 86)
+        return a.Cout % 256 == 0 ? launch_gemm<256, 256, true>(a, st) : launch_gemm<128, 256>(a, st);
+    }
     return a.Cout % 128 == 0 ? launch_gemm<128>(a, st) : launch_gemm<64>(a, st);
 }
