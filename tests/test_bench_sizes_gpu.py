@@ -78,11 +78,12 @@ def check_grads(g, net, floor=0.0):
     print("   %d gradient norms (worst rel err %.2e), %d small gradients element-wise" % (len(g["gradnorm_keys"]), worst, full))
 
 
+@pytest.mark.parametrize("cdtype", ["fp32", "bf16x3"])       # both parity modes at the same bounds (tests/test_model_gpu.py)
 @pytest.mark.parametrize("case", ["newUNetTrans_b32", "o5_512_b8"])
-def test_benchmarked_size_fp32_graphed_step_matches_the_reference(case, golden_dir):
+def test_benchmarked_size_fp32_graphed_step_matches_the_reference(case, cdtype, golden_dir):
     g, name, stride, a, b, lab = load(golden_dir, case)
-    net, step, loss = graphed(name, "fp32", a, b, lab)
-    check_logits(g, step.logits.float().cpu(), stride, 3e-4, "%s fp32" % case)
+    net, step, loss = graphed(name, cdtype, a, b, lab)
+    check_logits(g, step.logits.float().cpu(), stride, 3e-4, "%s %s" % (case, cdtype))
     print("   focal loss %.7f (reference %.7f)" % (loss, float(g["loss"])))
     assert abs(loss - float(g["loss"])) <= 3e-5 * max(1.0, abs(float(g["loss"])))
     check_grads(g, net)
@@ -111,20 +112,21 @@ def test_benchmarked_size_bf16_graphed_step_within_3x_input_rounding_error(case,
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
 
 
-def test_xbd_step_at_1024_batch_4_matches_the_reference(golden_dir):
+@pytest.mark.parametrize("cdtype", ["fp32", "bf16x3"])
+def test_xbd_step_at_1024_batch_4_matches_the_reference(cdtype, golden_dir):
     """xBD_code/train.py's step (6-channel input, 5 weighted ComboLoss terms, clip_grad_norm_ 0.999, hand-rolled AdamW) as ONE
     recorded graph at batch 4: logits, channel losses, gradient norms, total norm"""
     from dahitra_amd.graph import GraphedXbdStep
     from dahitra_amd.models import xbd
     g, name, stride, a, b, lab = load(golden_dir, "xbd_1024_b4")
     x6, msk = torch.cat([a, b], 1).cuda(), O.xbd_masks(lab).cuda()
-    net = xbd.BASE_Transformer_UNet(with_decoder_pos='learned', compute_dtype="fp32").cuda()
+    net = xbd.BASE_Transformer_UNet(with_decoder_pos='learned', compute_dtype=cdtype).cuda()
     net.load_state_dict(O.deterministic_state(name))
     net.train()
     opt = xbd.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-6, capturable=True)
     step = GraphedXbdStep(net, opt, x6, msk)
     loss = float(step())
-    check_logits(g, step.logits.float().cpu(), stride, 6e-4, "xbd 1024x1024 batch 4 fp32")
+    check_logits(g, step.logits.float().cpu(), stride, 6e-4, "xbd 1024x1024 batch 4 " + cdtype)
     _, ch = xbd.xbd_loss(step.logits, msk, want_channels=True)
     assert np.allclose(ch.cpu().numpy(), g["channel_losses"], rtol=2e-3)
     assert abs(loss - float(g["loss"])) <= 2e-3 * abs(float(g["loss"]))

@@ -85,14 +85,14 @@ def test_adamw_rule_and_clip_match_the_hand_rolled_reference_rule():
     assert float((md.cpu() - m).abs().max()) <= 1e-6 * float(m.abs().max())
 
 
-def _train_case(name, golden_dir, check_delta, logit_tol=2e-4):
+def _train_case(name, golden_dir, check_delta, logit_tol=2e-4, cdtype="fp32"):
     from dahitra_amd.models import xbd
     g = np.load(os.path.join(golden_dir, "xbd_%s.npz" % name))
     bs, size, stride = int(g["batch"]), int(g["size"]), int(g["stride"])
     a, b, lab = O.synthetic_batch(bs, size, seed=11, n_class=5)
     x6, msk = torch.cat([a, b], 1).cuda(), O.xbd_masks(lab).cuda()
     # eval-mode logits
-    net = make(name).eval()
+    net = make(name, cdtype).eval()
     with torch.no_grad():
         y = net(x6).cpu()
     want = torch.from_numpy(g["logits_eval"])
@@ -100,7 +100,7 @@ def _train_case(name, golden_dir, check_delta, logit_tol=2e-4):
     assert err <= logit_tol, "eval logits rel err %.3e" % err
     assert abs(float(y.double().sum()) - float(g["sum_eval"])) <= 2e-4 * float(g["abssum_eval"])
     # train steps (train.py:331-374)
-    net = make(name).train()
+    net = make(name, cdtype).train()
     opt = xbd.AdamW(net.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
     losses, norms = [], []
     for it in range(int(g["steps"])):
@@ -152,14 +152,16 @@ def _train_case(name, golden_dir, check_delta, logit_tol=2e-4):
     assert sd["conv_squeeze_layers.3.0.weight"].data_ptr() == sd["conv_squeeze_5.0.weight"].data_ptr()
 
 
-def test_train_steps_match_reference_golden_256_no_decoder_pos(golden_dir):
-    _train_case("xbd_unet_transformer_nodecpos", golden_dir, False)
+@pytest.mark.parametrize("cdtype", ["fp32", "bf16x3"])       # both parity modes at the same bounds
+def test_train_steps_match_reference_golden_256_no_decoder_pos(cdtype, golden_dir):
+    _train_case("xbd_unet_transformer_nodecpos", golden_dir, False, cdtype=cdtype)
 
 
-def test_train_step_matches_reference_golden_1024(golden_dir):
+@pytest.mark.parametrize("cdtype", ["fp32", "bf16x3"])
+def test_train_step_matches_reference_golden_1024(cdtype, golden_dir):
     # 1024x1024: BN statistics over 2*512*512 samples and token softmaxes over up to 65 536 pixels -- the fp32
     # summation-order distance grows with the reduction length (north-star bar: 1e-3)
-    _train_case("xbd_unet_transformer", golden_dir, True, logit_tol=5e-4)
+    _train_case("xbd_unet_transformer", golden_dir, True, logit_tol=5e-4, cdtype=cdtype)
 
 
 def test_input_contract():
