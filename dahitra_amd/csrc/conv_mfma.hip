@@ -18,6 +18,14 @@ int dh_conv_launch_x6(const ConvArgs& a, int ks, int stride, hipStream_t st);   
 // Launches whose input-channel count is not a multiple of 32 (the 16-channel space-to-depth stem) or whose planes do not fit
 // the LDS (form 2 at stride 2 with 3x3 taps) keep the exact form.
 // (DAHITRA_F32_MMA=bf16x3 makes mode 1 the initial value: the whole fp32 test suite can then run on the split form)
+// Split-bf16 launches take 16-row tiles for every 3x3 stride-1 layer with enough tiles, not only from 128 input channels on:
+// they run one workgroup per CU whatever the tile (the planes), and a 16-row tile stages -- and splits -- the weight tile once
+// per 256 pixels instead of once per 128 (bf16x3 step 3043 / 3020 -> 3100 pairs/s same-box; from 64 channels on only: 3064).
+// DAHITRA_X_RW4=<min Cin> moves the threshold, 0 switches it off.
+static int x_rw4_cin_min() {
+    const char* e = getenv("DAHITRA_X_RW4");
+    return e ? atoi(e) : 32;
+}
 static int f32_mma_env_default() {
     const char* e = getenv("DAHITRA_F32_MMA");
     return e && !strcmp(e, "bf16x3") ? 1 : (e && !strcmp(e, "bf16x6") ? 2 : 0);
@@ -29,6 +37,13 @@ extern "C" int dh_set_f32_mma_mode(int mode) {
     return 0;
 }
 extern "C" int dh_get_f32_mma_mode(void) { return g_f32_mma_mode; }
+static inline int pick_rw_mode(int dtype, int N, int OH, int OW, int Cin, int ks, int stride) {
+    static const int cmin = x_rw4_cin_min();
+    if (cmin && dtype == DH_DTYPE_F32 && g_f32_mma_mode != 0 && Cin % 32 == 0 && Cin >= cmin && ks == 3 && stride == 1 && OH >= 16 &&
+        (long)N * dh_cdiv(OH, 16) * dh_cdiv(OW, TW) >= 256)
+        return 4;
+    return pick_rw(N, OH, OW, Cin, ks, stride);
+}
 // fp32 launch -> its kernel family under the current mode
 static int launch_f32_family(const ConvArgs& a, int ks, int stride, hipStream_t st) {
     if (g_f32_mma_mode != 0 && a.Cin % 32 == 0) {
@@ -90,7 +105,7 @@ extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, voi
         DH_REQUIRE(phase_mode == 1 ? ((Cout == 128 || Cout == 256) && CoutPad == Cout) : (phase_mode == 2 && Cin == 128 && (Cout % 64 == 0 || Cout == 32)),
                    "conv2d_fwd: phase mode %d with Cin=%d Cout=%d", phase_mode, Cin, Cout);
     }
-    a.rw = pick_rw(N, OH, OW, Cin, ks, stride);
+    a.rw = pick_rw_mode(dtype, N, OH, OW, Cin, ks, stride);
     a.tilesX = dh_cdiv(OW, TW); a.tilesY = dh_cdiv(OH, 4 * a.rw);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dh_conv1x1_gemm_eligible(a, ks, stride, dtype)) return dh_conv1x1_gemm_launch(a, st);
@@ -158,7 +173,7 @@ extern "C" int dh_conv3x3_head_fwd(int dtype, const void* x, const void* w_packe
     static const int no_remap = getenv("DAHITRA_NO_XCD_REMAP") ? 1 : 0;
     a.no_xcd_remap = no_remap;
     a.y_nchw = logits_nchw;
-    a.rw = pick_rw(N, H, W, Cin, 3, 1);
+    a.rw = pick_rw_mode(dtype, N, H, W, Cin, 3, 1);
     a.tilesX = dh_cdiv(W, TW); a.tilesY = dh_cdiv(H, 4 * a.rw);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == DH_DTYPE_BF16) return dh_conv_launch_bf16(a, 3, 1, st);
@@ -212,5 +227,8 @@ extern "C" int dh_conv3x3_up4_fwd(const void* a, const void* b, const void* w_pa
 
 // number of workgroup tiles along the pixel dimension (= rows of the stats_partial buffer)
 extern "C" int dh_conv2d_fwd_num_tiles(int N, int OH, int OW, int Cin, int ks, int stride) {
+    // (the fp32 split forms may pick other tiles: the count is for an fp32 launch under the current mode when that matters)
+    static const int cmin = x_rw4_cin_min();
+    if (cmin && g_f32_mma_mode != 0) return N * dh_cdiv(OW, TW) * dh_cdiv(OH, 4 * pick_rw_mode(DH_DTYPE_F32, N, OH, OW, Cin, ks, stride));
     return N * dh_cdiv(OW, TW) * dh_cdiv(OH, 4 * pick_rw(N, OH, OW, Cin, ks, stride));
 }
