@@ -138,3 +138,31 @@ def test_every_test_name_the_documents_cite_exists():
                 continue
             missing.append((doc, name))
     assert not missing, missing
+
+
+def test_bf16x3_compute_mode_is_the_fp32_pipeline_with_split_products(monkeypatch):
+    """compute_dtype="bf16x3" (host logic, no GPU): fp32 tensors, the forward in the six-product form, the backward in the
+    three-product form; DAHITRA_F32_MMA=bf16x3 switches every fp32 net; an unknown name is refused like the reference refuses
+    an unknown net_G"""
+    from dahitra_amd.models.networks import CDNet
+    net = CDNet("base_transformer_pos_s4", "bf16x3")
+    assert net.compute_dtype == torch.float32 and net.mma_x3
+    assert (net._engine.dtype, net._engine.mma_fwd, net._engine.mma_bwd) == (torch.float32, 2, 1)
+    plain = CDNet("base_transformer_pos_s4", "fp32")
+    assert not plain.mma_x3 and (plain._engine.mma_fwd, plain._engine.mma_bwd) == (0, 0)
+    assert not CDNet("base_transformer_pos_s4", "bf16").mma_x3
+    monkeypatch.setenv("DAHITRA_F32_MMA", "bf16x3")
+    assert CDNet("base_transformer_pos_s4", "fp32").mma_x3 and not CDNet("base_transformer_pos_s4", "bf16").mma_x3
+    with pytest.raises(ValueError):
+        CDNet("base_transformer_pos_s4", "fp16x3")
+
+
+def test_bench_line_contract_fields_are_produced_by_the_source():
+    """bench.py (static check, no GPU): the sub-records the driver's line carries since round 5 and the switches that drop them"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    for key in ('"parity_mode"', '"secondary"', '"ddp_rehearsal"', '"exact_fp32"', '"bf16x3_vs_fp32"', '"roofline"', '"cpu_baseline"'):
+        assert key in src, key
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True).stdout
+    for flag in ("--no-secondary", "--no-ddp-rehearsal", "--no-roofline", "--no-parity-mode", "bf16x3"):
+        assert flag in out, flag
