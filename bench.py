@@ -511,7 +511,7 @@ def main():
             hbm = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "classes": classes}
 
     # ---- parity mode: the modes that meet the 1e-3 logit bar, timed by the same driver run.  "bf16x3" = the fp32 pipeline with
-    # its matrix products on the bf16 matrix cores as split-bf16 products (six-product forward, three-product backward: the same
+    # its matrix products on the 16-bit matrix cores as three split products (fp16 planes forward, bf16 planes backward: the same
     # test bounds as the exact mode, tests/test_model_gpu.py PARITY_MODES); "fp32" = exact fp32 MFMA, reported next to it ----
     parity = None
     if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_parity_mode and not args.fwd_only \
@@ -531,9 +531,9 @@ def main():
         d32 = timed("fp32", k32)
         parity = {"dtype": "bf16x3", "value": round(args.batch * kx / dx, 2), "unit": "image-pairs/s", "steps": kx,
                   "ms_per_step": round(dx / kx * 1e3, 3),
-                  "how": "fp32 tensors and pipeline; every matrix product as split-bf16 products on v_mfma_f32_16x16x32_bf16 "
-                         "(forward: three planes / six products, unit roundoff 2^-23; data and weight gradients: two planes / "
-                         "three products, 2^-17), dh_set_f32_mma_mode",
+                  "how": "fp32 tensors and pipeline; every matrix product as three split products on the 16-bit matrix cores "
+                         "(forward: fp16 planes, v_mfma_f32_16x16x32_f16, ~2^-21; data and weight gradients: bf16 planes, "
+                         "v_mfma_f32_16x16x32_bf16, 2^-17), dh_set_f32_mma_mode",
                   "bar": "logits within 1e-3 rel of the reference CPU path, masks identical outside the tie band, gradients at the "
                          "oracle's fp32 noise floor (tests/test_config1_gpu.py, tests/test_model_gpu.py: both parity modes at the same bounds)",
                   "exact_fp32": {"dtype": "fp32", "value": round(args.batch * k32 / d32, 2), "unit": "image-pairs/s", "steps": k32,

@@ -27,6 +27,13 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // 2^-17 leaves them at it) -- f32x3 the data and weight gradients.
 struct f32x3 { float v; };
 struct f32x6 { float v; };
+// f32h3: the two-plane / three-product form on FP16 planes (v_mfma_f32_16x16x32_f16): hi = fp16(x), lo = fp16(x - hi) carry 11
+// mantissa bits each, so three products reach ~2^-21 where bf16 planes reach 2^-17 -- for operands inside fp16's RANGE (|x| <
+// 65504; values below ~1e-4 lose the lo plane to the subnormals).  That rules it out for gradients, and makes it the form of the
+// FORWARD products: activations are O(1), and the weight tile is staged times 2^8 (exact; the accumulators are scaled back by
+// 2^-8 before the epilogue) so that weights of size 1e-2 keep a normal lo plane.  |w| must stay below 255.
+struct f32h3 { float v; };
+constexpr float F32H3_WSCALE = 256.f;
 template <typename T> struct Prec {
     static constexpr int NPL = 1;                      // LDS planes per staged operand tile
     static constexpr bool X3 = false;
@@ -39,6 +46,11 @@ template <> struct Prec<f32x3> {
 };
 template <> struct Prec<f32x6> {
     static constexpr int NPL = 3;
+    static constexpr bool X3 = true;
+    static constexpr int CK = 32;
+};
+template <> struct Prec<f32h3> {
+    static constexpr int NPL = 2;
     static constexpr bool X3 = true;
     static constexpr int CK = 32;
 };
@@ -82,6 +94,10 @@ __device__ __forceinline__ float ldf(const f32x3* p) { return p->v; }
 __device__ __forceinline__ void stf(f32x3* p, float v) { p->v = v; }
 __device__ __forceinline__ void ld4(const f32x3* p, float (&o)[4]) { ld4(reinterpret_cast<const float*>(p), o); }
 __device__ __forceinline__ void st4(f32x3* p, const float (&o)[4]) { st4(reinterpret_cast<float*>(p), o); }
+__device__ __forceinline__ float ldf(const f32h3* p) { return p->v; }
+__device__ __forceinline__ void stf(f32h3* p, float v) { p->v = v; }
+__device__ __forceinline__ void ld4(const f32h3* p, float (&o)[4]) { ld4(reinterpret_cast<const float*>(p), o); }
+__device__ __forceinline__ void st4(f32h3* p, const float (&o)[4]) { st4(reinterpret_cast<float*>(p), o); }
 __device__ __forceinline__ float ldf(const f32x6* p) { return p->v; }
 __device__ __forceinline__ void stf(f32x6* p, float v) { p->v = v; }
 __device__ __forceinline__ void ld4(const f32x6* p, float (&o)[4]) { ld4(reinterpret_cast<const float*>(p), o); }
@@ -127,6 +143,26 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float (&o)[4]) 
 
 template <> __device__ __forceinline__ uint4 pack16<f32x3>(const float (&o)[4]) { return pack16<float>(o); }
 template <> __device__ __forceinline__ uint4 pack16<f32x6>(const float (&o)[4]) { return pack16<float>(o); }
+template <> __device__ __forceinline__ uint4 pack16<f32h3>(const float (&o)[4]) { return pack16<float>(o); }
+// fp16 planes of 8 fp32 values (f32h3): hi = fp16(x) and lo = fp16(x - hi), both round to nearest even
+typedef __attribute__((ext_vector_type(2))) _Float16 dh_f16x2;
+__device__ __forceinline__ unsigned f2h2(float lo, float hi) {
+    const dh_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dh_f16x2));
+}
+__device__ __forceinline__ void split_f16_planes(const float (&x)[8], uint4 (&pl)[2]) {
+    unsigned h[4];
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = f2h2(x[2 * j], x[2 * j + 1]);
+        const dh_f32x2 back = __builtin_convertvector(__builtin_bit_cast(dh_f16x2, h[j]), dh_f32x2);
+        r[2 * j] = x[2 * j] - back[0];
+        r[2 * j + 1] = x[2 * j + 1] - back[1];
+    }
+    pl[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    pl[1] = make_uint4(f2h2(r[0], r[1]), f2h2(r[2], r[3]), f2h2(r[4], r[5]), f2h2(r[6], r[7]));
+}
 // the NPL bf16 planes of 8 fp32 values (see f32x3 / f32x6 above): one 16-byte piece per plane
 template <int NPL> __device__ __forceinline__ void split_bf16_planes(const float (&x)[8], uint4 (&pl)[NPL]) {
     float r[8];

@@ -6,6 +6,7 @@ int dh_conv_launch_bf16(const ConvArgs& a, int ks, int stride, hipStream_t st);
 int dh_conv_launch_f32(const ConvArgs& a, int ks, int stride, hipStream_t st);
 int dh_conv_launch_x3(const ConvArgs& a, int ks, int stride, hipStream_t st);      // conv_mfma_x3.hip
 int dh_conv_launch_x6(const ConvArgs& a, int ks, int stride, hipStream_t st);      // conv_mfma_x6.hip
+int dh_conv_launch_h3(const ConvArgs& a, int ks, int stride, hipStream_t st);      // conv_mfma_h3.hip
 
 // How the matrix products of fp32 (DH_DTYPE_F32) launches are computed -- per host thread, read at launch time (so a recorded
 // graph keeps the form it was captured with):
@@ -32,7 +33,7 @@ static int f32_mma_env_default() {
 }
 static thread_local int g_f32_mma_mode = f32_mma_env_default();
 extern "C" int dh_set_f32_mma_mode(int mode) {
-    DH_REQUIRE(mode >= 0 && mode <= 2, "set_f32_mma_mode: mode %d (0 = exact fp32 MFMA, 1 / 2 = split-bf16 three- / six-product form)", mode);
+    DH_REQUIRE(mode >= 0 && mode <= 3, "set_f32_mma_mode: mode %d (0 = exact fp32 MFMA, 1 / 2 = split-bf16 three- / six-product form, 3 = split-fp16 three-product form)", mode);
     g_f32_mma_mode = mode;
     return 0;
 }
@@ -47,7 +48,8 @@ static inline int pick_rw_mode(int dtype, int N, int OH, int OW, int Cin, int ks
 // fp32 launch -> its kernel family under the current mode
 static int launch_f32_family(const ConvArgs& a, int ks, int stride, hipStream_t st) {
     if (g_f32_mma_mode != 0 && a.Cin % 32 == 0) {
-        const int rc = g_f32_mma_mode == 2 ? dh_conv_launch_x6(a, ks, stride, st) : dh_conv_launch_x3(a, ks, stride, st);
+        const int rc = g_f32_mma_mode == 3 ? dh_conv_launch_h3(a, ks, stride, st)
+                     : g_f32_mma_mode == 2 ? dh_conv_launch_x6(a, ks, stride, st) : dh_conv_launch_x3(a, ks, stride, st);
         if (rc != DH_CONV_NO_FIT) return rc;
     }
     return dh_conv_launch_f32(a, ks, stride, st);

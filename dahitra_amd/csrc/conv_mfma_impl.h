@@ -135,6 +135,17 @@ template <> struct Mma<bf16> {
 };
 template <> struct Mma<f32x3> : Mma<bf16> {};         // one product of the three / six; the tap loop pairs the planes
 template <> struct Mma<f32x6> : Mma<bf16> {};
+typedef __attribute__((ext_vector_type(8))) _Float16 dh_f16x8;
+template <> struct Mma<f32h3> {                          // fp16 planes (common.h f32h3)
+    static __device__ __forceinline__ void run(const V16u& a, const V16u& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dh_f16x8, a.u), __builtin_bit_cast(dh_f16x8, b.u), c, 0, 0, 0);
+    }
+};
+// the planes of 8 staged fp32 values, by form
+template <typename T, int NPL> __device__ __forceinline__ void split_planes(const float (&v)[8], uint4 (&pl)[NPL]) {
+    if constexpr (std::is_same<T, f32h3>::value) split_f16_planes(v, pl);
+    else split_bf16_planes<NPL>(v, pl);
+}
 
 // source rows / columns and weight of a bilinear x4 destination index (align_corners = False; = bil_src of pointwise.hip)
 __device__ __forceinline__ void up4_src(int d, int in, int& i0, int& i1, float& l) {
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(256, conv_min_wgs<T>()) void conv_mfma_kernel(ConvA
                     }
                 }
                 uint4 pls[NPL];
-                split_bf16_planes<NPL>(v, pls);
+                split_planes<T, NPL>(v, pls);
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint4*>(halo + q * HB + HL::off(idx >> 2, idx & 3)) = pls[q];
             }
@@ -303,7 +314,14 @@ __global__ __launch_bounds__(256, conv_min_wgs<T>()) void conv_mfma_kernel(ConvA
                 const int idx = tid + i * 256;
                 if (idx >= TAPS * NT * 4) continue;
                 uint4 pls[NPL];
-                split_bf16_planes<NPL>(rw[2 * i], rw[2 * i + 1], pls);
+                float wv_[8];
+                unpack16(rw[2 * i], reinterpret_cast<float(&)[4]>(wv_[0]));
+                unpack16(rw[2 * i + 1], reinterpret_cast<float(&)[4]>(wv_[4]));
+                if constexpr (std::is_same<T, f32h3>::value) {          // weights times 2^8: a normal lo plane for |w| ~ 1e-2
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wv_[j] *= F32H3_WSCALE;
+                }
+                split_planes<T, NPL>(wv_, pls);
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint4*>(wts + q * WB + wt_off(idx >> 2, idx & 3)) = pls[q];
             }
@@ -463,6 +481,14 @@ __global__ __launch_bounds__(256, conv_min_wgs<T>()) void conv_mfma_kernel(ConvA
     }
 
     // ---- epilogue ----
+    if constexpr (std::is_same<T, f32h3>::value) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[s][r][j] *= (1.f / F32H3_WSCALE);
+    }
     if constexpr (NT == 16 && KS == 3 && STRIDE == 1) {
         if (p.y_nchw) {
             float* out = p.y_nchw + (size_t)n * p.Cout * p.OH * p.OW;

@@ -63,15 +63,17 @@ class CoarseRes:
 class Engine:
     def __init__(self, net_G, dtype=torch.float32, use_tr=True, attn_fp8=False, mma_x3=False):
         self.net_G = net_G
-        # fp32 nets only (compute_dtype="bf16x3"): matrix products on the bf16 matrix cores as split-bf16 products
-        # (ops.set_f32_mma_mode, csrc/common.h f32x3 / f32x6).  The FORWARD takes the three-plane, six-product form (unit
-        # roundoff 2^-23): the gradients are ~20x more sensitive to activation error than the logits are -- with the forward
-        # at 2^-17 they sit 150x above their fp32 distance from the oracle (median 1.9e-3 vs 1.3e-5 on
-        # base_transformer_pos_s4), with only the BACKWARD at 2^-17 they stay at it (2.2e-5), measured on MI355X.  So data and
-        # weight gradients take the two-plane, three-product form.  DAHITRA_X3_FWD / DAHITRA_X3_BWD = 0 | 1 | 2 override
-        # the form of a pass (A/B switches).
+        # fp32 nets only (compute_dtype="bf16x3"): matrix products on the 16-bit matrix cores as THREE split products per operand
+        # pair (ops.set_f32_mma_mode, csrc/common.h f32x3 / f32h3 / f32x6).  The gradients are ~20x more sensitive to activation
+        # error than the logits are: with the forward on bf16 planes (unit roundoff 2^-17) they sit 150x above their fp32 distance
+        # from the oracle (median 1.9e-3 vs 1.3e-5 on base_transformer_pos_s4), with only the BACKWARD at 2^-17 they stay at it
+        # (2.2e-5), measured on MI355X.  So the FORWARD splits into FP16 planes (form 3: 11 mantissa bits per plane, ~2^-21 with
+        # three products; activations are O(1) and the weight tile is staged times 2^8, which keeps both inside fp16's range) and
+        # the data / weight gradients, whose operands span fp32's range, into BF16 planes (form 1).  Form 2 (three bf16 planes,
+        # six products, 2^-23) is the forward's alternative for nets whose activations or weights leave fp16's range (|x| < 65504,
+        # |w| < 255): DAHITRA_X3_FWD=2.  DAHITRA_X3_FWD / DAHITRA_X3_BWD = 0 .. 3 override the form of a pass (A/B switches).
         self.mma_x3 = bool(mma_x3) and dtype == torch.float32
-        self.mma_fwd = int(os.environ.get("DAHITRA_X3_FWD", "2")) if self.mma_x3 else 0
+        self.mma_fwd = int(os.environ.get("DAHITRA_X3_FWD", "3")) if self.mma_x3 else 0
         self.mma_bwd = int(os.environ.get("DAHITRA_X3_BWD", "1")) if self.mma_x3 else 0
         # fp8 (OCP e4m3) MFMA operands in the fused decoder layers' forward products (BASELINE configs[4]); bf16 mode only
         self.attn_fp8 = bool(attn_fp8) or os.environ.get("DAHITRA_ATTN_FP8", "0") == "1"

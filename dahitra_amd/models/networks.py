@@ -12,9 +12,9 @@ arena per net (grad-carrying parameters first) so that the optimizer step and th
 gradient all-reduce are single launches over contiguous memory.
 
 Compute type: args.compute_dtype / DAHITRA_DTYPE in {"fp32", "bf16x3", "bf16"}.  fp32 is the parity mode
-(exact-fp32 MFMA); bf16x3 is the same fp32 pipeline with every matrix product on the bf16 matrix cores as
-three split-bf16 products (dh_set_f32_mma_mode: fp32 tensors, error 2^-17 per term -- the fast parity
-mode); bf16 is the throughput mode (bf16 activations + MFMA, fp32 accumulation / master weights)."""
+(exact-fp32 MFMA); bf16x3 is the same fp32 pipeline with every matrix product on the 16-bit matrix cores as
+three split products (dh_set_f32_mma_mode: fp32 tensors; fp16 planes in the forward, bf16 planes in the
+backward -- the fast parity mode, held to the exact mode's test bounds); bf16 is the throughput mode (bf16 activations + MFMA, fp32 accumulation / master weights)."""
 import math
 import os
 

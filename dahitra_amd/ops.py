@@ -28,9 +28,10 @@ def dt(t):
 
 
 def set_f32_mma_mode(mode):
-    """dh_set_f32_mma_mode: 0 = exact fp32 MFMA, 1 = split-bf16 three-product form (two planes, unit roundoff 2^-17), 2 = the
-    six-product form (three planes, 2^-23) for the matrix products of every fp32 launch this host thread issues from now on
-    (the Engine sets it at each of its entry points: compute_dtype="bf16x3" = form 2 forward, form 1 backward)."""
+    """dh_set_f32_mma_mode: 0 = exact fp32 MFMA, 1 = split-bf16 three-product form (two bf16 planes, unit roundoff 2^-17), 2 = the
+    six-product form (three bf16 planes, 2^-23), 3 = the split-fp16 three-product form (two fp16 planes, ~2^-21; operands inside
+    fp16's range) for the matrix products of every fp32 launch this host thread issues from now on (the Engine sets it at each
+    of its entry points: compute_dtype="bf16x3" = form 3 forward, form 1 backward)."""
     _lib.check(_lib.lib().dh_set_f32_mma_mode(int(mode)), "dh_set_f32_mma_mode")
 
 

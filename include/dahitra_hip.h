@@ -88,11 +88,15 @@ int dh_conv_wreg_mode(int mode);
  *                (unit roundoff 2^-17 against fp32's 2^-24; 3/16 of the exact form's matrix-core cycles);
  *   2            split-bf16, three planes (x = p0 + p1 + p2, 8 mantissa bits each): the six products a_i*b_j, i + j < 3
  *                (unit roundoff 2^-23; 6/16 of the cycles).  Convolution / linear launches only: a weight-gradient launch
- *                issued in mode 2 runs form 1.
+ *                issued in mode 2 or 3 runs form 1.
+ *   3            split-fp16, two planes (hi = fp16(x), lo = fp16(x - hi), 11 mantissa bits each): three products on
+ *                v_mfma_f32_16x16x32_f16, ~2^-21 at the cycles of form 1 -- for operands inside fp16's RANGE: |x| < 65504, and
+ *                |w| < 255 for the weights, which are staged times 2^8 (exact; undone on the accumulators) so that weights of
+ *                size 1e-2 keep a normal lo plane.  The forward's form (activations are O(1)); not for gradients.
  * Tensors, accumulators, statistics, everything that is not a matrix product, launches with Cin % 32 != 0 and launches
  * whose staging planes would not fit the LDS are unchanged, so DH_F32 buffers, packs and workspaces are interchangeable
  * between the modes.  The reference computes these products in fp32 (models/networks.py:358-392,
- * models/help_funcs.py:66-114, loss.backward()): compute_dtype="bf16x3" (form 2 in the forward, form 1 in the backward)
+ * models/help_funcs.py:66-114, loss.backward()): compute_dtype="bf16x3" (form 3 in the forward, form 1 in the backward)
  * is the parity mode's fast form. */
 int dh_set_f32_mma_mode(int mode);
 int dh_get_f32_mma_mode(void);

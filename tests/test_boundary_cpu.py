@@ -141,13 +141,13 @@ def test_every_test_name_the_documents_cite_exists():
 
 
 def test_bf16x3_compute_mode_is_the_fp32_pipeline_with_split_products(monkeypatch):
-    """compute_dtype="bf16x3" (host logic, no GPU): fp32 tensors, the forward in the six-product form, the backward in the
-    three-product form; DAHITRA_F32_MMA=bf16x3 switches every fp32 net; an unknown name is refused like the reference refuses
+    """compute_dtype="bf16x3" (host logic, no GPU): fp32 tensors, the forward in the fp16-plane three-product form, the backward
+    in the bf16-plane three-product form; DAHITRA_F32_MMA=bf16x3 switches every fp32 net; an unknown name is refused like the reference refuses
     an unknown net_G"""
     from dahitra_amd.models.networks import CDNet
     net = CDNet("base_transformer_pos_s4", "bf16x3")
     assert net.compute_dtype == torch.float32 and net.mma_x3
-    assert (net._engine.dtype, net._engine.mma_fwd, net._engine.mma_bwd) == (torch.float32, 2, 1)
+    assert (net._engine.dtype, net._engine.mma_fwd, net._engine.mma_bwd) == (torch.float32, 3, 1)
     plain = CDNet("base_transformer_pos_s4", "fp32")
     assert not plain.mma_x3 and (plain._engine.mma_fwd, plain._engine.mma_bwd) == (0, 0)
     assert not CDNet("base_transformer_pos_s4", "bf16").mma_x3

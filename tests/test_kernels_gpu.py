@@ -9,10 +9,12 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DTYPES = [torch.float32, torch.bfloat16]
-# the matrix-product kernels additionally in the split-bf16 form of the fp32 mode (dh_set_f32_mma_mode(1), "bf16x3": fp32
-# tensors, three bf16 MFMA products per operand pair, unit roundoff 2^-17): same inputs, same fp32 tolerance (measured 5e-6)
+# the matrix-product kernels additionally in the split forms of the fp32 mode (dh_set_f32_mma_mode 1 / 2 / 3: fp32 tensors; three
+# products on two bf16 planes, six on three bf16 planes, three on two fp16 planes): same inputs, same fp32 tolerance (measured
+# 5e-6 / 1e-6 / 8e-7 of the output scale)
 DTYPES_MMA = [pytest.param(torch.float32, 0, id="float32"), pytest.param(torch.bfloat16, 0, id="bfloat16"),
-              pytest.param(torch.float32, 1, id="bf16x3")]
+              pytest.param(torch.float32, 1, id="bf16x3"), pytest.param(torch.float32, 2, id="bf16x6"),
+              pytest.param(torch.float32, 3, id="f16x3")]
 
 
 def tol(dtype):

@@ -35,7 +35,7 @@ for cfg in [dict(ks=3, s=1, p=1, ci=64, co=64, h=64, w=64, n=8), dict(ks=3, s=1,
     wp, _ = ops.pack_weight(w, torch.float32, want_dgrad=False)
     xs = nhwc(x)
     res = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         with ops.f32_mma_mode(mode):
             y = ops.conv2d(xs, wp, cfg["co"], cfg["ks"], cfg["s"], cfg["p"], dilation=d)
             dw = torch.zeros_like(w)
@@ -48,8 +48,8 @@ for cfg in [dict(ks=3, s=1, p=1, ci=64, co=64, h=64, w=64, n=8), dict(ks=3, s=1,
     wantw = torch.autograd.grad(F.conv2d(x.double(), w.double().requires_grad_(), None, cfg["s"], cfg["p"], d), [], allow_unused=True) if False else None
     wd = w.double().requires_grad_()
     F.conv2d(x.double(), wd, None, cfg["s"], cfg["p"], d).backward(dy.double())
-    print(cfg, "fwd rel err fp32 %.2e x3 %.2e x6 %.2e | wgrad fp32 %.2e x3 %.2e" % (
-        rel(res[0][0], want), rel(res[1][0], want), rel(res[2][0], want), rel(res[0][1], wd.grad), rel(res[1][1], wd.grad)), flush=True)
+    print(cfg, "fwd rel err fp32 %.2e x3 %.2e x6 %.2e h3 %.2e | wgrad fp32 %.2e x3 %.2e" % (
+        rel(res[0][0], want), rel(res[1][0], want), rel(res[2][0], want), rel(res[3][0], want), rel(res[0][1], wd.grad), rel(res[1][1], wd.grad)), flush=True)
 
 net_G = sys.argv[1] if len(sys.argv) > 1 else "base_transformer_pos_s4"
 B = 8
