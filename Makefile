@@ -20,6 +20,9 @@ $(foreach f,$(ILP_SRCS),$(eval $(OBJ)/$(f).o: EXTRA := -mllvm -amdgpu-sched-stra
 # rewrite the default scheduler beats max-ilp on the backward (no scratch at 248 registers: 38.5 -> 37.3 / 8.8 -> 7.9 us)
 $(OBJ)/decoder_fused.o: EXTRA := -mllvm -amdgpu-mfma-vgpr-form
 
+# norm: its one MFMA kernel (head_bn_bwd_kernel) hands every result to the vector ALU at once
+$(OBJ)/norm.o: EXTRA := -mllvm -amdgpu-mfma-vgpr-form
+
 # conv_wreg: its stream loop is ONE fully unrolled tile (up to 1152 steps); the default pragma-unroll budget (16 K instructions)
 # silently falls back to a partial unroll, which turns the register-resident weight array into scratch memory
 $(OBJ)/conv_wreg.o: EXTRA := -mllvm -pragma-unroll-threshold=262144

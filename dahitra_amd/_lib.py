@@ -26,7 +26,7 @@ def declared_symbols():
 
 
 _LONG_RET = {"dh_conv3x3_dgrad_up4_partial_floats", "dh_encoder_bwd_workspace_size", "dh_encoder_saved_floats", "dh_xattn_prep_bwd_stack_workspace_size", "dh_combo_loss_workspace_size", "dh_grad_norm_workspace_size", "dh_conv2d_wgrad_workspace_size", "dh_bn_bwd_workspace_size", "dh_layernorm_bwd_workspace_size",
-             "dh_stem_pool_bn_bwd_workspace_size", "dh_conv2d_wgrad_phase_workspace_size", "dh_tokenizer_bwd_workspace_size", "dh_decoder_layer_bwd_workspace_size", "dh_tokenizer_fwd_workspace_size", "dh_xattn_prep_bwd_workspace_size"}
+             "dh_stem_pool_bn_bwd_workspace_size", "dh_conv2d_wgrad_phase_workspace_size", "dh_tokenizer_bwd_workspace_size", "dh_decoder_layer_bwd_workspace_size", "dh_tokenizer_fwd_workspace_size", "dh_xattn_prep_bwd_workspace_size", "dh_head_bn_bwd_workspace_size"}
 
 
 def lib():

@@ -662,6 +662,149 @@ __global__ void bn_bwd_finalize_coef_kernel(const float* __restrict__ partial, i
     }
 }
 
+
+// ---- class head: data gradient of the 3x3 head convolution + the BatchNorm backward behind it, nothing in between ----------
+// The classifier (TwoLayerConv2d, models/help_funcs.py:7-15) is conv0 -> BatchNorm -> ReLU -> conv1 (32 -> n_class).  The
+// gradient of relu(BN(y)) with respect to its 32 channels is conv1's data gradient: K = (tap, class) = 18 products per element,
+// i.e. ONE v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels from a 16-byte-per-pixel dlogits tensor (the form of
+// head_dgrad3x3_mfma_kernel, pointwise.hip).  That is cheaper to RECOMPUTE than to keep: written once and read by the two
+// passes of the BatchNorm backward it is 3 x 134 MB at the bench size.  So the two passes form it themselves:
+//   pass 1 (APPLY = false): g = mask * (W1^T (*) dlogits); per-workgroup partial sums (sum g, sum g * y) -> [2][32][blocks]
+//   (bn_bwd_finalize_coef_kernel: dgamma, dbeta and the coefficients of dx = A g + B y + C)
+//   pass 2 (APPLY = true):  the same g again, dx = A g + B y + C written as bf16
+// mask = (y * mscale + mshift > 0) recomputed from the pre-BatchNorm activation y, the only tensor either pass reads.
+// An MFMA leaves a lane with channels 4 g + j of the 16-channel half s; one v_permlane16_swap per register pairs the halves of
+// neighbouring lane groups so that a lane owns EIGHT consecutive channels of its pixel -- one 16-byte load of y, one 16-byte
+// store of dx per lane, a wave instruction covers 1 KiB of consecutive addresses.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) void head_bn_bwd_kernel(const bf16* __restrict__ dl, const float* __restrict__ w_oihw, int N, int H,
+                                                          int W, int NC, const bf16* __restrict__ y, const float* __restrict__ mscale,
+                                                          const float* __restrict__ mshift, int groups, float* __restrict__ partial,
+                                                          const float* __restrict__ coef, bf16* __restrict__ dx) {
+    const int lane = threadIdx.x & 63, pl = lane & 15, g = lane >> 4;
+    s16x8 wa[2];          // A fragments: row ci = s * 16 + pl, k = 8 g + e -> tap 4 g + e / 2, class e & 1
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int tap = 4 * g + (e >> 1), co = e & 1;
+            v[e] = (tap < 9 && co < NC) ? w_oihw[((size_t)co * 32 + s * 16 + pl) * 9 + tap] : 0.f;
+        }
+        union { uint4 u; s16x8 h; } pk;
+        pk.u = pack16<bf16>(v);
+        wa[s] = pk.h;
+    }
+    const int bpg = gridDim.x / groups, bg = blockIdx.x / bpg;
+    const long gpix = (long)N * H * W / groups, total = (bg + 1) * gpix, ngrp16 = (gpix + 15) / 16;
+    // a wave takes CONSECUTIVE 16-pixel groups: its pixel coordinates advance by additions (the grid-stride form spent more
+    // on three 64-bit divisions per group than on everything else)
+    const long wave = ((long)(blockIdx.x - bg * bpg) * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)bpg * blockDim.x) >> 6;
+    const long gpw = (ngrp16 + nwaves - 1) / nwaves, grp0 = wave * gpw;
+    const int ngr = (int)(grp0 >= ngrp16 ? 0 : (grp0 + gpw > ngrp16 ? ngrp16 - grp0 : gpw));
+    // after the swap: lane group g owns channels cb .. cb + 7 (g = 0: 0, 1: 16, 2: 8, 3: 24)
+    const int cb = (g & 1) ? 16 + (g - 1) * 4 : g * 4;
+    float ms[8], mh[8], cA[8], cB[8], cC[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = bg * 32 + cb + e;
+        ms[e] = mscale[c]; mh[e] = mshift[c];
+        s1[e] = s2[e] = 0.f;
+        if constexpr (APPLY) { cA[e] = coef[(bg * 3 + 0) * 32 + cb + e]; cB[e] = coef[(bg * 3 + 1) * 32 + cb + e]; cC[e] = coef[(bg * 3 + 2) * 32 + cb + e]; }
+    }
+    // Every access goes through a buffer descriptor with a 32-bit byte offset: a load that must deliver zeros (image border, a
+    // tap that does not exist, a group past the wave's share) gets an offset past the end -- the hardware returns 0, no select
+    // touches a loaded value before the group is USED, and the loads of group i + 1 stay in flight under group i; a store of a
+    // pixel that does not exist is dropped the same way.  (dh_head_bn_bwd requires the tensors below 2 GiB.)
+    const unsigned npx_all = (unsigned)((long)N * H * W);
+    const auto rs_dl = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(dl), 0, (int)(npx_all * 16u), 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(y), 0, (int)(npx_all * 64u), 0x00020000);
+    const auto rs_dx = __builtin_amdgcn_make_buffer_rsrc(dx, 0, APPLY ? (int)(npx_all * 64u) : 0, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const long pxl = bg * gpix + grp0 * 16 + pl;            // this lane's first pixel; (cx, cy) its column / row inside its image
+    unsigned px = (unsigned)pxl;
+    int cx = (int)(pxl % W), cy = (int)((pxl / W) % H);
+    int toff[4], tdy[4], tdx[4];                            // this lane group's taps: byte offset in dl, row / column shift
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tap = 4 * g + q, kh = tap / 3, kw = tap - kh * 3;
+        tdy[q] = tap < 9 ? 1 - kh : 1 << 20;                // (a tap that does not exist fails the bounds test)
+        tdx[q] = 1 - kw;
+        toff[q] = tap < 9 ? ((1 - kh) * W + (1 - kw)) * 16 : 0;
+    }
+    struct Grp { unsigned bk[4]; u32x4 yraw; unsigned at; };
+    auto request = [&](Grp& q_, bool valid) {
+        const bool inb = valid & (px < (unsigned)total);
+        q_.at = inb ? px * 64u + cb * 2u : OOB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = inb & ((unsigned)(cy + tdy[q]) < (unsigned)H) & ((unsigned)(cx + tdx[q]) < (unsigned)W);      // (no short circuit: no branches)
+            q_.bk[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_dl, ok ? px * 16u + toff[q] : OOB, 0, 0);
+        }
+        q_.yraw = __builtin_amdgcn_raw_buffer_load_b128(rs_y, q_.at, 0, 0);
+        px += 16; cx += 16;
+        if (W >= 16) {                                      // (uniform)
+            const bool wrap = cx >= W;
+            cx -= wrap ? W : 0;
+            cy += wrap ? 1 : 0;
+            cy = cy == H ? 0 : cy;
+        } else {
+            while (cx >= W) { cx -= W; if (++cy == H) cy = 0; }
+        }
+    };
+    auto use = [&](const Grp& q_) {
+        union { uint4 u; s16x8 h; } b;
+        b.u = make_uint4(q_.bk[0], q_.bk[1], q_.bk[2], q_.bk[3]);
+        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], b.h, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], b.h, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        float r[8], yv[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(d0[j]), __float_as_uint(d1[j]), false, false);
+            r[j] = __uint_as_float(sw[0]);
+            r[4 + j] = __uint_as_float(sw[1]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { yv[2 * k] = __uint_as_float(q_.yraw[k] << 16); yv[2 * k + 1] = __uint_as_float(q_.yraw[k] & 0xffff0000u); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (yv[e] * ms[e] + mh[e]) > 0.f ? r[e] : 0.f;     // (a group of zeros has r = 0 already)
+        if constexpr (APPLY) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = cA[e] * r[e] + cB[e] * yv[e] + cC[e];
+            const uint4 pk = pack16<bf16>(o);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk.x, pk.y, pk.z, pk.w}, rs_dx, q_.at, 0, 0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += r[e]; s2[e] += r[e] * yv[e]; }
+        }
+    };
+    Grp ga, gb;
+    request(ga, ngr > 0);
+    for (int i = 0; i < ngr; i += 2) {
+        request(gb, i + 1 < ngr);
+        use(ga);
+        request(ga, i + 2 < ngr);
+        use(gb);
+    }
+    if constexpr (!APPLY) {
+        __shared__ float red[4][2][32];
+        const int wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = row16_sum(s1[e]), b = row16_sum(s2[e]);
+            if (pl == 0) { red[wv][0][cb + e] = a; red[wv][1][cb + e] = b; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+            partial[((size_t)which * 32 + c) * gridDim.x + blockIdx.x] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+        }
+    }
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -866,5 +1009,43 @@ extern "C" int dh_reduce_partials(const float* partial, long nt, long n, float s
     if (n == 0) return 0;
     launch_reduce(partial, nt, n, scale, out, accumulate, ST(stream));
     DH_CHECK_LAUNCH("reduce_partials");
+    return 0;
+}
+
+// dh_head_dgrad3x3 + dh_bn_bwd in two passes that never materialise the head's data gradient (head_bn_bwd_kernel): bf16,
+// n_class <= 2, 32 channels.  dl [N][H][W][8] (one 16-byte piece per pixel), w_oihw [n_class][32][3][3] fp32, y the
+// pre-BatchNorm activation [N][H][W][32], mask_scale / mask_shift / mean / invstd [groups][32] as dh_bn_finalize left them;
+// dx [N][H][W][32] = the gradient of y; dgamma / dbeta (+)=.  workspace: dh_head_bn_bwd_workspace_size bytes.
+// Replaces: the autograd of Conv2d(32, n_class, 3) -> ReLU -> BatchNorm2d(32) in models/help_funcs.py:7-15.
+extern "C" int dh_head_bn_bwd_blocks(int N, int H, int W, int groups) {
+    if (groups < 1 || N % groups) return 0;
+    const long n16 = ((long)N * H * W / groups + 15) / 16;
+    long bpg = (n16 * 64 + 255) / 256;
+    const long cap = 2048 / groups;
+    if (bpg > cap) bpg = cap;
+    return (int)(bpg * groups);
+}
+extern "C" long dh_head_bn_bwd_workspace_size(int N, int H, int W, int groups) {
+    return ((long)dh_head_bn_bwd_blocks(N, H, W, groups) * 2 * 32 + (long)groups * 3 * 32) * 4;
+}
+extern "C" int dh_head_bn_bwd(const void* dl, const float* w_oihw, int NC, const void* y, const float* mask_scale,
+                              const float* mask_shift, const float* mean, const float* invstd, const float* gamma, int groups,
+                              void* dx, float* dgamma, float* dbeta, int accumulate, int N, int H, int W, void* workspace,
+                              void* stream) {
+    DH_REQUIRE(NC >= 1 && NC <= 2 && dl && y && mask_scale && mask_shift && mean && invstd && gamma && dx && dgamma && dbeta && workspace,
+               "head_bn_bwd: bad arguments (n_class=%d)", NC);
+    const int grid = dh_head_bn_bwd_blocks(N, H, W, groups);
+    DH_REQUIRE(grid > 0 && groups <= BN_MAXG, "head_bn_bwd: %d images do not split into %d groups", N, groups);
+    DH_REQUIRE((long)N * H * W * 64 < (1L << 31), "head_bn_bwd: %d x %d x %d pixels x 64 bytes do not fit a 2 GiB buffer descriptor", N, H, W);
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* coef = partial + (size_t)grid * 2 * 32;
+    const float inv_m = (float)(1.0 / ((double)N * H * W / groups));
+    hipLaunchKernelGGL(head_bn_bwd_kernel<false>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dl, w_oihw, N, H, W, NC,
+                       (const bf16*)y, mask_scale, mask_shift, groups, partial, (const float*)nullptr, (bf16*)nullptr);
+    hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(32), dim3(64 * groups), 0, ST(stream), partial, grid / groups, groups, 32, mean,
+                       invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(head_bn_bwd_kernel<true>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dl, w_oihw, N, H, W, NC,
+                       (const bf16*)y, mask_scale, mask_shift, groups, (float*)nullptr, coef, (bf16*)dx);
+    DH_CHECK_LAUNCH("head_bn_bwd");
     return 0;
 }

@@ -51,6 +51,15 @@ class Gated:
         self.g, self.partial = g, partial
 
 
+class HeadGrad:
+    """The class head's data gradient NOT formed: the 16-byte-per-pixel dlogits and the head's weights, for a BatchNorm + ReLU
+    backward that recomputes it in both of its passes (ops.head_bn_bwd) instead of reading a 32-channel tensor twice."""
+    __slots__ = ("dl", "w", "ncls")
+
+    def __init__(self, dl, w, ncls):
+        self.dl, self.w, self.ncls = dl, w, ncls
+
+
 class CoarseRes:
     """a data gradient that lives on the COARSE grid of a stride-2 layer ([N, OH, OW, C]): the value of the fine-grid
     gradient at the even-even positions, zero elsewhere (the 1x1 stride-2 shortcut of a BasicBlock)"""
@@ -118,6 +127,10 @@ class Engine:
         # neutral (8020 vs 8027 pairs/s: the reduction pass it removes costs what the extra read of y costs the head kernel):
         # off by default, DAHITRA_GATED_HEAD=1 turns it on.
         self.gated_head_dgrad = os.environ.get("DAHITRA_GATED_HEAD", "0") == "1"
+        # the class head's data gradient never written: both passes of the classifier's BatchNorm backward recompute it from the
+        # 16-byte-per-pixel dlogits (one MFMA per 16 pixels x 16 channels) -- 3 x 134 MB less at the bench size
+        # (DAHITRA_NO_FUSED_HEAD_BN=1: the three-kernel path)
+        self.fused_head_bn = os.environ.get("DAHITRA_NO_FUSED_HEAD_BN", "0") != "1"
         # a second stream for the classifier's weight gradient, next to the low-occupancy token-side backward (bf16 training).
         # Measured: the launch does overlap the encoder's backward in the graph (rocprofv3 trace: 120 us next to encoder_bwd /
         # encoder_wgrad / tok_bwd instead of 63 us alone), but those kernels slow down by 28 us and the forked graph costs more
@@ -317,7 +330,11 @@ class Engine:
 
         def bwd(dout, need_dx=True, dx_res=None, next_gate=None, coarse_dx=False, through_up4=None):
             """through_up4 = (a, b, da, db): this conv's input is bilinear_x4(|a - b|); the gradients land in da, db"""
-            if isinstance(dout, Gated):       # ReLU mask and the reduction pass were done by the producer of dout
+            if isinstance(dout, HeadGrad):    # the class head's gradient, recomputed by both passes of this backward
+                dy = ops.head_bn_bwd(dout.dl, dout.w, dout.ncls, y, scale, shift, mean, invstd, gamma,
+                                     self.g[bnkey + ".weight"], self.g[bnkey + ".bias"], groups)
+                dres = None
+            elif isinstance(dout, Gated):     # ReLU mask and the reduction pass were done by the producer of dout
                 dy = ops.bn_bwd_from_partials(dout.g, y, dout.partial, mean, invstd, gamma, self.g[bnkey + ".weight"],
                                               self.g[bnkey + ".bias"], groups, accumulate=True)
                 dres = dout.g if has_res else None
@@ -974,6 +991,8 @@ class Engine:
                 tmp = torch.empty(small, dtype=torch.float32, device=h.device)
                 ops.colsum(dl.view(-1, small), tmp)
                 ops.reduce_rows(tmp, 1, ncls, self.g[bkey], accumulate=True)
+                if head_bn is not None and self.fused_head_bn and self.dtype == torch.bfloat16 and ncls <= 2:
+                    return HeadGrad(dl, self.p[wkey], ncls)
                 if head_bn is not None and self.gated_head_dgrad and self.dtype == torch.bfloat16 and ncls <= 2:
                     # the BatchNorm behind these 32 channels: mask + reduction here, only its apply pass remains
                     return Gated(*ops.head_dgrad3x3_bn(dl, self.p[wkey], ncls, *head_bn))

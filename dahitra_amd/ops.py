@@ -1050,6 +1050,19 @@ def head_dgrad3x3_bn(dy, w_oihw, ncls, y, scale, shift, mean, invstd, groups):
     return g, partial
 
 
+def head_bn_bwd(dl, w_oihw, ncls, y, scale, shift, mean, invstd, gamma, dgamma, dbeta, groups, accumulate=True):
+    """class head's data gradient + the backward of the BatchNorm + ReLU behind it without the gradient tensor in between
+    (dh_head_bn_bwd): dl [N,H,W,8] bf16 -> the gradient of the pre-BatchNorm activation y [N,H,W,32]"""
+    N, H, W, CP = dl.shape
+    assert w_oihw.shape == (ncls, 32, 3, 3) and dl.dtype == torch.bfloat16 and CP == 8 and ncls <= 2 and y.shape == (N, H, W, 32)
+    dx = torch.empty_like(y)
+    ws = workspace(_lib.lib().dh_head_bn_bwd_workspace_size(N, H, W, groups), dl.device)
+    with _Prof("bn_bwd", 0, _nb(y, y, dx)):
+        _call("dh_head_bn_bwd", P(dl), P(w_oihw), _ci(ncls), P(y), P(scale), P(shift), P(mean), P(invstd), P(gamma), _ci(groups),
+              P(dx), P(dgamma), P(dbeta), _ci(1 if accumulate else 0), _ci(N), _ci(H), _ci(W), P(ws), S())
+    return dx
+
+
 def nhwc_to_nchw(x):
     N, H, W, C = x.shape
     y = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)

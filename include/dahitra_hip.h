@@ -331,6 +331,16 @@ int dh_head_dgrad3x3_bn_blocks(int N, int H, int W, int groups);
 int dh_head_dgrad3x3_bn(const void* dy, const float* w_oihw, int NC, const void* y, const float* mask_scale, const float* mask_shift,
                         const float* mean, const float* invstd, int groups, void* g, float* partial, int N, int H, int W,
                         void* stream);
+/* The head's data gradient AND the backward of the BatchNorm + ReLU behind its 32 channels in two passes that never write the
+ * gradient in between (bf16, n_class <= 2; the autograd of Conv2d(32, n_class, 3) <- ReLU <- BatchNorm2d(32),
+ * models/help_funcs.py:7-15): each pass forms g = (y * mask_scale + mask_shift > 0) * (W^T (*) dl) on the matrix cores from the
+ * 16-byte-per-pixel dl; pass 1 reduces (sum g, sum g y), pass 2 writes dx = gamma invstd (g - (s1 + xhat s2) / M).  y
+ * [N][H][W][32] pre-BatchNorm, statistics [groups][32] as dh_bn_finalize left them; dgamma / dbeta [32] (+)= when accumulate. */
+int dh_head_bn_bwd_blocks(int N, int H, int W, int groups);
+long dh_head_bn_bwd_workspace_size(int N, int H, int W, int groups);
+int dh_head_bn_bwd(const void* dl, const float* w_oihw, int NC, const void* y, const float* mask_scale, const float* mask_shift,
+                   const float* mean, const float* invstd, const float* gamma, int groups, void* dx, float* dgamma, float* dbeta,
+                   int accumulate, int N, int H, int W, void* workspace, void* stream);
 int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream);
 int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, void* dst, int Cd, int dc0, int Cn, long P, void* stream);
 /* torch.cat([x1, x2], 1) of the two temporal streams (models/networks.py:1309, 1344), which are the two batch halves of

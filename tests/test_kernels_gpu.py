@@ -661,6 +661,60 @@ def test_head_data_gradient_kernel(ops, dtype, ncls):
     close(nchw(dx), x.grad, dtype, "head dgrad", factor=2.0)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(n=2, h=20, w=36, groups=1, ncls=2),
+    dict(n=4, h=17, w=23, groups=2, ncls=2),         # ragged 16-pixel groups, two statistics groups
+    dict(n=1, h=3, w=5, groups=1, ncls=1),           # fewer pixels than one wave round
+    dict(n=8, h=128, w=128, groups=1, ncls=2),       # more 16-pixel groups than waves: the two-group rounds wrap
+])
+def test_head_gradient_recomputed_inside_the_batchnorm_backward(ops, cfg):
+    """dh_head_bn_bwd (the class head's data gradient formed by both passes of the BatchNorm + ReLU backward behind it, never
+    written) against (a) torch autograd of conv2(relu(batch_norm(y))) in fp32 (models/help_funcs.py:7-15) and (b) the
+    three-kernel path dh_head_dgrad3x3 -> dh_bn_bwd, whose intermediate is rounded to bf16"""
+    N, H, W, G, ncls = cfg["n"], cfg["h"], cfg["w"], cfg["groups"], cfg["ncls"]
+    dtype = torch.bfloat16
+    y = rnd((N, 32, H, W), dtype, 2101, 1.5)
+    w = rnd((ncls, 32, 3, 3), torch.float32, 2102, 0.1)
+    dlog = rnd((N, ncls, H, W), dtype, 2103)
+    gamma = (rnd((32,), torch.float32, 2104, 0.2) + 1.0)
+    beta = rnd((32,), torch.float32, 2105, 0.3)
+    # torch: per statistics group (the reference's two forward_single calls), train-mode BatchNorm
+    yt = y.float().requires_grad_(True)
+    gm = gamma.clone().requires_grad_(True)
+    bt = beta.clone().requires_grad_(True)
+    outs = []
+    for k in range(G):
+        sl = slice(k * N // G, (k + 1) * N // G)
+        outs.append(F.conv2d(torch.relu(F.batch_norm(yt[sl], None, None, gm, bt, True, 0.1, 1e-5)), w, None, 1, 1))
+    torch.cat(outs).backward(dlog.float())
+    # device: statistics as dh_bn_finalize leaves them
+    yd = dev(nhwc(y), dtype)
+    yg = yd.float().view(G, -1, 32)
+    mean = yg.mean(1)
+    var = yg.var(1, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    scale = gamma.cuda()[None] * invstd
+    shift = beta.cuda()[None] - mean * scale
+    mean, invstd, scale, shift = (t.contiguous() for t in (mean, invstd, scale, shift))
+    dl = ops.nchw_to_nhwc(dlog.float().cuda().contiguous(), dtype, cpad=8)
+    dg1, db1 = torch.zeros(32, device="cuda"), torch.zeros(32, device="cuda")
+    dx1 = ops.head_bn_bwd(dl, w.cuda(), ncls, yd, scale, shift, mean, invstd, gamma.cuda(), dg1, db1, G, accumulate=False)
+    close(nchw(dx1), yt.grad, dtype, "dx vs autograd", factor=2.0)
+    close(dg1, gm.grad, dtype, "dgamma vs autograd", factor=4.0)
+    close(db1, bt.grad, dtype, "dbeta vs autograd", factor=4.0)
+    # the three-kernel path
+    g0 = ops.head_dgrad3x3(dl, w.cuda(), ncls)
+    dg0, db0 = torch.zeros(32, device="cuda"), torch.zeros(32, device="cuda")
+    dx0 = ops.bn_bwd(g0, None, yd, mean, invstd, gamma.cuda(), dg0, db0, G, accumulate=False, mask_scale=scale, mask_shift=shift)
+    close(dx1, dx0.float().cpu(), dtype, "dx vs three kernels", factor=2.0)
+    close(dg1, dg0.cpu(), dtype, "dgamma vs three kernels", factor=2.0)
+    close(db1, db0.cpu(), dtype, "dbeta vs three kernels", factor=2.0)
+    # accumulate: (+)= into the parameter gradients
+    dx2 = ops.head_bn_bwd(dl, w.cuda(), ncls, yd, scale, shift, mean, invstd, gamma.cuda(), dg1, db1, G, accumulate=True)
+    assert torch.equal(dx2, dx1)
+    close(dg1, 2 * gm.grad, dtype, "dgamma accumulated", factor=4.0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_bn_backward_mask_recomputed_from_input(ops, dtype):
     """ReLU mask as x * scale + shift > 0 (layers without a residual) == mask from the stored post-ReLU output"""

@@ -806,6 +806,29 @@ def test_opt_in_paths_equal_default_paths_bf16(monkeypatch):
         assert cos >= 0.9995 and float((g - h).abs().max()) <= 3e-2 * float(g.abs().max()) + 1e-9, (k, cos)
 
 
+def test_head_gradient_inside_the_batchnorm_backward_equals_three_kernel_path_bf16(monkeypatch):
+    """default bf16 step (the class head's data gradient recomputed by both passes of classifier.1's backward, engine.HeadGrad)
+    against DAHITRA_NO_FUSED_HEAD_BN=1 (head_dgrad3x3 -> bn_bwd: the same gradient rounded to bf16 in between)"""
+    from dahitra_amd.models import losses
+    a, b, lab = O.synthetic_batch(2, 64, seed=73)
+    res = {}
+    for off in ("0", "1"):
+        monkeypatch.setenv("DAHITRA_NO_FUSED_HEAD_BN", off)
+        net = make_net("base_transformer_pos_s4", "bf16").train()
+        assert net._engine.fused_head_bn == (off == "0")
+        y = net(a.cuda(), b.cuda())
+        losses.focal_loss(y, lab.cuda()).backward()
+        res[off] = (y.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert torch.equal(res["0"][0], res["1"][0])
+    for k, g in res["0"][1].items():
+        h = res["1"][1][k]
+        if float(g.abs().max()) < 1e-10:
+            assert float(h.abs().max()) < 1e-8, k
+            continue
+        cos = float((g * h).sum() / (g.norm() * h.norm() + 1e-30))
+        assert cos >= 0.9995 and float((g - h).abs().max()) <= 3e-2 * float(g.abs().max()) + 1e-9, (k, cos)
+
+
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
 def test_phase_convolution_paths_equal_reference_paths(name, monkeypatch):
     """conv_pred as 2x2 phase convs and the stride-2 data gradient as output-parity phases (both: pre-summed / re-ordered
