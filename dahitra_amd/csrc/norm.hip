@@ -632,20 +632,21 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const unsigned 
 // bn_bwd_finalize_kernel + the per-channel coefficients of dx = A * d + B * y + Cc (= gamma*invstd*(d - (s1 + xhat*s2)/M))
 // that the stem's weight gradient applies while it loads d and y (conv_wgrad.hip, DYT): coef [G][3][C].  partial[1] holds
 // sum d * y (raw), converted here.
-__global__ void bn_bwd_finalize_coef_kernel(const float* __restrict__ partial, int bpg, int G, int C, const float* __restrict__ mean,
-                                            const float* __restrict__ invstd, const float* __restrict__ gamma, float inv_m,
-                                            float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                            int accumulate) {
+__device__ __forceinline__ void bn_bwd_finalize_coef_body(const int c, const float* __restrict__ partial, int bpg, int G, int C,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, float inv_m, float* __restrict__ coef,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
     __shared__ double t1[BN_MAXG], t2[BN_MAXG];
-    const int c = blockIdx.x, lane = threadIdx.x & 63, g = threadIdx.x >> 6;      // blockDim = 64 * G
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;      // wavefronts [0, G) take part (blockDim >= 64 * G)
+    const bool act = g < G;
     double s1 = 0.0, s2 = 0.0;
-    const float* p0 = partial + ((size_t)0 * C + c) * G * bpg + (size_t)g * bpg;
-    const float* p1 = partial + ((size_t)1 * C + c) * G * bpg + (size_t)g * bpg;
+    const float* p0 = partial + ((size_t)0 * C + c) * G * bpg + (size_t)(act ? g : 0) * bpg;
+    const float* p1 = partial + ((size_t)1 * C + c) * G * bpg + (size_t)(act ? g : 0) * bpg;
 #pragma unroll 8
-    for (int t = lane; t < bpg; t += 64) { s1 += (double)p0[t]; s2 += (double)p1[t]; }      // (loads in flight; adds in order)
+    for (int t = lane; t < (act ? bpg : 0); t += 64) { s1 += (double)p0[t]; s2 += (double)p1[t]; }      // (loads in flight; adds in order)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    if (lane == 0) {
+    if (lane == 0 && act) {
         s2 = (double)invstd[g * C + c] * (s2 - (double)mean[g * C + c] * s1);        // sum d * y -> sum d * xhat
         const float is = invstd[g * C + c], A = gamma[c] * is, B = -A * is * inv_m * (float)s2;
         coef[(g * 3 + 0) * C + c] = A;
@@ -660,6 +661,12 @@ __global__ void bn_bwd_finalize_coef_kernel(const float* __restrict__ partial, i
         if (accumulate) { dgamma[c] += (float)tg; dbeta[c] += (float)tb; }
         else { dgamma[c] = (float)tg; dbeta[c] = (float)tb; }
     }
+}
+__global__ void bn_bwd_finalize_coef_kernel(const float* __restrict__ partial, int bpg, int G, int C, const float* __restrict__ mean,
+                                            const float* __restrict__ invstd, const float* __restrict__ gamma, float inv_m,
+                                            float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                            int accumulate) {
+    bn_bwd_finalize_coef_body(blockIdx.x, partial, bpg, G, C, mean, invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate);
 }
 
 
@@ -678,12 +685,53 @@ __global__ void bn_bwd_finalize_coef_kernel(const float* __restrict__ partial, i
 // store of dx per lane, a wave instruction covers 1 KiB of consecutive addresses.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-template <bool APPLY>
-__global__ __launch_bounds__(256) void head_bn_bwd_kernel(const bf16* __restrict__ dl, const float* __restrict__ w_oihw, int N, int H,
+// dlogits [N][NC <= 2][H][W] fp32 (the loss kernel's layout) -> [N][H + 2][W + 2] bf16 pairs (class 0 low, class 1 high) inside a
+// border of zeros: what head_bn_bwd_kernel gathers its nine taps from, 4 bytes per tap and no bounds test
+__global__ void head_dlogits_pack_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int N, int NC, int H, int W) {
+    const int Wp = W + 2, Hp = H + 2;
+    const long total = (long)N * Hp * Wp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % Wp) - 1, yy = (int)((i / Wp) % Hp) - 1;
+        const long n = i / ((long)Wp * Hp);
+        unsigned v = 0u;
+        if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
+            const float a = src[((n * NC) * H + yy) * (long)W + xx];
+            const float b = NC > 1 ? src[((n * NC + 1) * H + yy) * (long)W + xx] : 0.f;
+            v = f2bf2(a, b);
+        }
+        dst[i] = v;
+    }
+}
+
+// WGRAD (pass 1 only): the head convolution's own weight gradient from the same loads.  dW1[ci][tap][class] = sum over pixels
+// of relu(BN(y))[pixel][ci] * dlogits[pixel - tap offset][class] -- for the INPUT pixel a lane holds, the nine dlogits it has
+// just gathered ARE those neighbours (k = (tap, class)).  Pixels are the K dimension of that product: both operands go through
+// a wave-private LDS tile ([16 px][32] bf16, pitch 96 bytes) and come back transposed (ds_read_b64_tr_b16, four pixels of one
+// channel / one k per lane) for v_mfma_f32_16x16x16_bf16; a wave's LDS operations execute in order, no barrier in the loop.
+// Per-workgroup partials [578][blocks] (576 = ci * 18 + tap * 2 + class, 576 / 577 = the bias gradient, sum of dlogits):
+// head_bwd_finalize_kernel.  What this replaces read y a third time (conv_wgrad_kernel, 54 us at the bench size).
+constexpr int HB_WCOLS = 32 * 18 + 2;
+constexpr int HB_TP = 96;                                // tile pitch (bytes): odd multiple of 32 -- conflict-free transpose reads
+
+// MODE 2 (dh_head_relu_bwd): no BatchNorm -- `y` is the OUTPUT of the ReLU in front of the head (classifier(conv_layer2(...)),
+// models/networks.py:1351-1355), dx = (y > 0) * g in one pass, with the head's weight gradient (WGRAD) from the same loads.
+template <int MODE, bool WGRAD>
+__global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __restrict__ dlp, const float* __restrict__ w_oihw, int N, int H,
                                                           int W, int NC, const bf16* __restrict__ y, const float* __restrict__ mscale,
                                                           const float* __restrict__ mshift, int groups, float* __restrict__ partial,
-                                                          const float* __restrict__ coef, bf16* __restrict__ dx) {
+                                                          const float* __restrict__ coef, bf16* __restrict__ dx,
+                                                          float* __restrict__ wpartial) {
+    constexpr bool APPLY = MODE == 1, RELU = MODE == 2, STORE = MODE != 0;
+    constexpr int HB_DEPTH = 2;      // groups in flight per wave (depths 3 and 4 measured: no faster, more registers)
+    static_assert(!(APPLY && WGRAD), "the weight gradient rides on the reduction pass");
+    __shared__ __attribute__((aligned(16))) unsigned char hb_tiles[WGRAD ? 4 * 2 * 16 * HB_TP : 16];
     const int lane = threadIdx.x & 63, pl = lane & 15, g = lane >> 4;
+    unsigned char* tH = hb_tiles + (WGRAD ? (threadIdx.x >> 6) * 2 * 16 * HB_TP : 0);
+    unsigned char* tN = tH + (WGRAD ? 16 * HB_TP : 0);
+    f32x4 wacc[2][2];
+    float bsum0 = 0.f, bsum1 = 0.f;
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_) wacc[a_][0] = wacc[a_][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     s16x8 wa[2];          // A fragments: row ci = s * 16 + pl, k = 8 g + e -> tap 4 g + e / 2, class e & 1
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -710,7 +758,7 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const bf16* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = bg * 32 + cb + e;
-        ms[e] = mscale[c]; mh[e] = mshift[c];
+        if constexpr (!RELU) { ms[e] = mscale[c]; mh[e] = mshift[c]; }
         s1[e] = s2[e] = 0.f;
         if constexpr (APPLY) { cA[e] = coef[(bg * 3 + 0) * 32 + cb + e]; cB[e] = coef[(bg * 3 + 1) * 32 + cb + e]; cC[e] = coef[(bg * 3 + 2) * 32 + cb + e]; }
     }
@@ -719,20 +767,24 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const bf16* __restrict
     // touches a loaded value before the group is USED, and the loads of group i + 1 stay in flight under group i; a store of a
     // pixel that does not exist is dropped the same way.  (dh_head_bn_bwd requires the tensors below 2 GiB.)
     const unsigned npx_all = (unsigned)((long)N * H * W);
-    const auto rs_dl = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(dl), 0, (int)(npx_all * 16u), 0x00020000);
+    const int Wp = W + 2;
+    const auto rs_dl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(dlp), 0, N * (H + 2) * Wp * 4, 0x00020000);
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(y), 0, (int)(npx_all * 64u), 0x00020000);
-    const auto rs_dx = __builtin_amdgcn_make_buffer_rsrc(dx, 0, APPLY ? (int)(npx_all * 64u) : 0, 0x00020000);
+    const auto rs_dx = __builtin_amdgcn_make_buffer_rsrc(dx, 0, STORE ? (int)(npx_all * 64u) : 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const long pxl = bg * gpix + grp0 * 16 + pl;            // this lane's first pixel; (cx, cy) its column / row inside its image
     unsigned px = (unsigned)pxl;
     int cx = (int)(pxl % W), cy = (int)((pxl / W) % H);
-    int toff[4], tdy[4], tdx[4];                            // this lane group's taps: byte offset in dl, row / column shift
+    // dlogits come as dh_head_dlogits_pack left them: [N][H + 2][W + 2] bf16 pairs with a border of zeros -- a tap needs no bounds
+    // test, only an offset from the lane's own (padded) position pc4 (bytes)
+    unsigned pc4 = (unsigned)(((pxl / ((long)W * H)) * (H + 2) + cy + 1) * Wp + cx + 1) * 4u;
+    int toff[4];                                            // this lane group's taps: byte offset from pc4
+    bool thave[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int tap = 4 * g + q, kh = tap / 3, kw = tap - kh * 3;
-        tdy[q] = tap < 9 ? 1 - kh : 1 << 20;                // (a tap that does not exist fails the bounds test)
-        tdx[q] = 1 - kw;
-        toff[q] = tap < 9 ? ((1 - kh) * W + (1 - kw)) * 16 : 0;
+        thave[q] = tap < 9;
+        toff[q] = ((1 - kh) * Wp + (1 - kw)) * 4;
     }
     struct Grp { unsigned bk[4]; u32x4 yraw; unsigned at; };
     auto request = [&](Grp& q_, bool valid) {
@@ -740,18 +792,13 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const bf16* __restrict
         q_.at = inb ? px * 64u + cb * 2u : OOB;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const bool ok = inb & ((unsigned)(cy + tdy[q]) < (unsigned)H) & ((unsigned)(cx + tdx[q]) < (unsigned)W);      // (no short circuit: no branches)
-            q_.bk[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_dl, ok ? px * 16u + toff[q] : OOB, 0, 0);
+            q_.bk[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_dl, (inb & thave[q]) ? pc4 + toff[q] : OOB, 0, 0);
         }
         q_.yraw = __builtin_amdgcn_raw_buffer_load_b128(rs_y, q_.at, 0, 0);
-        px += 16; cx += 16;
-        if (W >= 16) {                                      // (uniform)
-            const bool wrap = cx >= W;
-            cx -= wrap ? W : 0;
-            cy += wrap ? 1 : 0;
-            cy = cy == H ? 0 : cy;
-        } else {
-            while (cx >= W) { cx -= W; if (++cy == H) cy = 0; }
+        px += 16; cx += 16; pc4 += 64;
+        while (cx >= W) {                                   // next row: over the two border pixels; next image: over two border rows
+            cx -= W; pc4 += 8;
+            if (++cy == H) { cy = 0; pc4 += 2 * Wp * 4; }
         }
     };
     auto use = [&](const Grp& q_) {
@@ -768,39 +815,127 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const bf16* __restrict
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) { yv[2 * k] = __uint_as_float(q_.yraw[k] << 16); yv[2 * k + 1] = __uint_as_float(q_.yraw[k] & 0xffff0000u); }
+        float z[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = (yv[e] * ms[e] + mh[e]) > 0.f ? r[e] : 0.f;     // (a group of zeros has r = 0 already)
+        for (int e = 0; e < 8; ++e) {
+            z[e] = RELU ? yv[e] : yv[e] * ms[e] + mh[e];
+            r[e] = z[e] > 0.f ? r[e] : 0.f;          // (a group of zeros has r = 0 already)
+        }
+        if constexpr (WGRAD) {
+            if constexpr (RELU) {                    // the head's input is y itself
+                *reinterpret_cast<uint4*>(tH + pl * HB_TP + cb * 2) = make_uint4(q_.yraw[0], q_.yraw[1], q_.yraw[2], q_.yraw[3]);
+            } else {
+                float hv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = fmaxf(z[e], 0.f);        // (a group of zeros: its dlogits are zero)
+                *reinterpret_cast<uint4*>(tH + pl * HB_TP + cb * 2) = pack16<bf16>(hv);
+            }
+            *reinterpret_cast<uint4*>(tN + pl * HB_TP + g * 16) = b.u;
+            asm volatile("" ::: "memory");
+            // lane (pl, g): pixels 4 g .. 4 g + 3 of column 16 c + pl of a tile
+            auto frag = [&](const unsigned char* t, int c) {
+                const unsigned char* base = t + (g * 4 + (pl >> 2)) * HB_TP + (c * 16 + (pl & 3) * 4) * 2;
+                return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+            };
+            const s16x4 h0 = frag(tH, 0), h1 = frag(tH, 1), n0 = frag(tN, 0), n1 = frag(tN, 1);
+            asm volatile("" ::: "memory");
+            wacc[0][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h0, n0, wacc[0][0], 0, 0, 0);
+            wacc[0][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h0, n1, wacc[0][1], 0, 0, 0);
+            wacc[1][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h1, n0, wacc[1][0], 0, 0, 0);
+            wacc[1][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h1, n1, wacc[1][1], 0, 0, 0);
+            // the centre tap (4: lane group 1, its first load) is the pixel's own dlogits: the bias gradient
+            bsum0 += __uint_as_float(q_.bk[0] << 16);
+            bsum1 += __uint_as_float(q_.bk[0] & 0xffff0000u);
+        }
         if constexpr (APPLY) {
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = cA[e] * r[e] + cB[e] * yv[e] + cC[e];
             const uint4 pk = pack16<bf16>(o);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk.x, pk.y, pk.z, pk.w}, rs_dx, q_.at, 0, 0);
+        } else if constexpr (RELU) {
+            const uint4 pk = pack16<bf16>(r);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk.x, pk.y, pk.z, pk.w}, rs_dx, q_.at, 0, 0);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s1[e] += r[e]; s2[e] += r[e] * yv[e]; }
         }
     };
-    Grp ga, gb;
-    request(ga, ngr > 0);
-    for (int i = 0; i < ngr; i += 2) {
-        request(gb, i + 1 < ngr);
-        use(ga);
-        request(ga, i + 2 < ngr);
-        use(gb);
+    // HB_DEPTH groups in flight per wave (9 registers each)
+    Grp gq[HB_DEPTH];
+#pragma unroll
+    for (int d = 0; d < HB_DEPTH - 1; ++d) request(gq[d], d < ngr);
+    for (int i = 0; i < ngr; i += HB_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < HB_DEPTH; ++d) {
+            request(gq[(d + HB_DEPTH - 1) % HB_DEPTH], i + d + HB_DEPTH - 1 < ngr);
+            use(gq[d]);
+        }
     }
     if constexpr (!APPLY) {
-        __shared__ float red[4][2][32];
         const int wv = threadIdx.x >> 6;
+        if constexpr (!RELU) {
+            __shared__ float red[4][2][32];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float a = row16_sum(s1[e]), b = row16_sum(s2[e]);
-            if (pl == 0) { red[wv][0][cb + e] = a; red[wv][1][cb + e] = b; }
+            for (int e = 0; e < 8; ++e) {
+                const float a = row16_sum(s1[e]), b = row16_sum(s2[e]);
+                if (pl == 0) { red[wv][0][cb + e] = a; red[wv][1][cb + e] = b; }
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+                partial[((size_t)which * 32 + c) * gridDim.x + blockIdx.x] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+            }
         }
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
-            partial[((size_t)which * 32 + c) * gridDim.x + blockIdx.x] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+        if constexpr (WGRAD) {
+            __shared__ float wred[4][HB_WCOLS];
+            // D: lane (pl, g) holds rows ci = 16 cs + 4 g + j of column k = 16 ks + pl
+#pragma unroll
+            for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = ks * 16 + pl, ci = cs * 16 + 4 * g + j;
+                        if (k < 18) wred[wv][ci * 18 + k] = wacc[cs][ks][j];
+                    }
+            const float b0 = row16_sum(bsum0), b1 = row16_sum(bsum1);
+            if (lane == 16) { wred[wv][576] = b0; wred[wv][577] = b1; }
+            __syncthreads();
+            for (int i = threadIdx.x; i < HB_WCOLS; i += 256)
+                wpartial[(size_t)i * gridDim.x + blockIdx.x] = wred[0][i] + wred[1][i] + wred[2][i] + wred[3][i];
+        }
+    }
+}
+
+// blocks [0, bn_blocks = 32 or 0): the BatchNorm's channels (bn_bwd_finalize_coef_body); then HB_WCOLS blocks: one column of the head's
+// weight-gradient partials each -> dw [n_class][32][3][3] / db [n_class] (+)=
+__global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ partial, int bpg, int G,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, float inv_m, float* __restrict__ coef,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                                const float* __restrict__ wpartial, int NC, float* __restrict__ dw,
+                                                                float* __restrict__ db, int bn_blocks) {
+    if ((int)blockIdx.x < bn_blocks) {
+        bn_bwd_finalize_coef_body(blockIdx.x, partial, bpg, G, 32, mean, invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate);
+        return;
+    }
+    __shared__ float red[4];
+    const int col = blockIdx.x - bn_blocks, rows = bpg * G;
+    const float* p = wpartial + (size_t)col * rows;
+    float a = 0.f;
+    for (int t = threadIdx.x; t < rows; t += 256) a += p[t];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = red[0] + red[1] + red[2] + red[3];
+        if (col < 576) {
+            const int ci = col / 18, k = col % 18, tap = k >> 1, co = k & 1;
+            if (co < NC) { float* o = dw + ((size_t)co * 32 + ci) * 9 + tap; *o = accumulate ? *o + v : v; }
+        } else if (col - 576 < NC) {
+            float* o = db + (col - 576);
+            *o = accumulate ? *o + v : v;
         }
     }
 }
@@ -1013,7 +1148,7 @@ extern "C" int dh_reduce_partials(const float* partial, long nt, long n, float s
 }
 
 // dh_head_dgrad3x3 + dh_bn_bwd in two passes that never materialise the head's data gradient (head_bn_bwd_kernel): bf16,
-// n_class <= 2, 32 channels.  dl [N][H][W][8] (one 16-byte piece per pixel), w_oihw [n_class][32][3][3] fp32, y the
+// n_class <= 2, 32 channels.  dlp [N][H + 2][W + 2] bf16 pairs (dh_head_dlogits_pack), w_oihw [n_class][32][3][3] fp32, y the
 // pre-BatchNorm activation [N][H][W][32], mask_scale / mask_shift / mean / invstd [groups][32] as dh_bn_finalize left them;
 // dx [N][H][W][32] = the gradient of y; dgamma / dbeta (+)=.  workspace: dh_head_bn_bwd_workspace_size bytes.
 // Replaces: the autograd of Conv2d(32, n_class, 3) -> ReLU -> BatchNorm2d(32) in models/help_funcs.py:7-15.
@@ -1021,31 +1156,82 @@ extern "C" int dh_head_bn_bwd_blocks(int N, int H, int W, int groups) {
     if (groups < 1 || N % groups) return 0;
     const long n16 = ((long)N * H * W / groups + 15) / 16;
     long bpg = (n16 * 64 + 255) / 256;
-    const long cap = 2048 / groups;
+    // pass 1: every workgroup leaves 642 partial sums, one per row of the finalize kernel's columns (512 / 768 / 1024 / 2048
+    // workgroups measured: 116 / 123 / 121 / 131 us for the three launches at 32 x 256 x 256 pixels)
+    static const long cap1 = [] { const char* e = getenv("DAHITRA_HB_GRID1"); return e ? atol(e) : 512L; }();
+    const long cap = cap1 / groups;
+    if (bpg > cap) bpg = cap;
+    return (int)(bpg * groups);
+}
+static int head_bn_bwd_apply_blocks(int N, int H, int W, int groups) {
+    const long n16 = ((long)N * H * W / groups + 15) / 16;
+    long bpg = (n16 * 64 + 255) / 256;
+    static const long cap2 = [] { const char* e = getenv("DAHITRA_HB_GRID2"); return e ? atol(e) : 2048L; }();
+    const long cap = cap2 / groups;
     if (bpg > cap) bpg = cap;
     return (int)(bpg * groups);
 }
 extern "C" long dh_head_bn_bwd_workspace_size(int N, int H, int W, int groups) {
-    return ((long)dh_head_bn_bwd_blocks(N, H, W, groups) * 2 * 32 + (long)groups * 3 * 32) * 4;
+    return ((long)dh_head_bn_bwd_blocks(N, H, W, groups) * (2 * 32 + HB_WCOLS) + (long)groups * 3 * 32) * 4;
 }
-extern "C" int dh_head_bn_bwd(const void* dl, const float* w_oihw, int NC, const void* y, const float* mask_scale,
+// dw [n_class][32][3][3] / db [n_class] (both or neither; (+)= when accumulate): the head convolution's own weight and bias
+// gradient, taken by pass 1 from the loads it makes anyway (input = relu(BatchNorm(y)), rounded to bf16 as the convolution saw it)
+extern "C" int dh_head_dlogits_pack(const float* dlogits_nchw, int N, int NC, int H, int W, void* dlp, void* stream) {
+    DH_REQUIRE(NC >= 1 && NC <= 2 && dlogits_nchw && dlp, "head_dlogits_pack: n_class=%d", NC);
+    const long n = (long)N * (H + 2) * (W + 2);
+    DH_REQUIRE(n * 4 < (1L << 31), "head_dlogits_pack: %d x %d x %d does not fit a 2 GiB buffer descriptor", N, H, W);
+    hipLaunchKernelGGL(head_dlogits_pack_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), dlogits_nchw, (unsigned*)dlp, N, NC, H, W);
+    DH_CHECK_LAUNCH("head_dlogits_pack");
+    return 0;
+}
+extern "C" int dh_head_bn_bwd(const void* dlp, const float* w_oihw, int NC, const void* y, const float* mask_scale,
                               const float* mask_shift, const float* mean, const float* invstd, const float* gamma, int groups,
-                              void* dx, float* dgamma, float* dbeta, int accumulate, int N, int H, int W, void* workspace,
-                              void* stream) {
-    DH_REQUIRE(NC >= 1 && NC <= 2 && dl && y && mask_scale && mask_shift && mean && invstd && gamma && dx && dgamma && dbeta && workspace,
+                              void* dx, float* dgamma, float* dbeta, float* dw, float* db, int accumulate, int N, int H, int W,
+                              void* workspace, void* stream) {
+    DH_REQUIRE(NC >= 1 && NC <= 2 && dlp && y && mask_scale && mask_shift && mean && invstd && gamma && dx && dgamma && dbeta && workspace,
                "head_bn_bwd: bad arguments (n_class=%d)", NC);
+    DH_REQUIRE((dw == nullptr) == (db == nullptr), "head_bn_bwd: dw and db come together");
     const int grid = dh_head_bn_bwd_blocks(N, H, W, groups);
     DH_REQUIRE(grid > 0 && groups <= BN_MAXG, "head_bn_bwd: %d images do not split into %d groups", N, groups);
     DH_REQUIRE((long)N * H * W * 64 < (1L << 31), "head_bn_bwd: %d x %d x %d pixels x 64 bytes do not fit a 2 GiB buffer descriptor", N, H, W);
     float* partial = reinterpret_cast<float*>(workspace);
     float* coef = partial + (size_t)grid * 2 * 32;
+    float* wpartial = coef + (size_t)groups * 3 * 32;
     const float inv_m = (float)(1.0 / ((double)N * H * W / groups));
-    hipLaunchKernelGGL(head_bn_bwd_kernel<false>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dl, w_oihw, N, H, W, NC,
-                       (const bf16*)y, mask_scale, mask_shift, groups, partial, (const float*)nullptr, (bf16*)nullptr);
-    hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(32), dim3(64 * groups), 0, ST(stream), partial, grid / groups, groups, 32, mean,
-                       invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate);
-    hipLaunchKernelGGL(head_bn_bwd_kernel<true>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dl, w_oihw, N, H, W, NC,
-                       (const bf16*)y, mask_scale, mask_shift, groups, (float*)nullptr, coef, (bf16*)dx);
+    const int grid2 = head_bn_bwd_apply_blocks(N, H, W, groups);
+    if (dw) {
+        hipLaunchKernelGGL((head_bn_bwd_kernel<0, true>), dim3(grid), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
+                           (const bf16*)y, mask_scale, mask_shift, groups, partial, (const float*)nullptr, (bf16*)nullptr, wpartial);
+        hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(32 + HB_WCOLS), dim3(256), 0, ST(stream), partial, grid / groups, groups, mean,
+                           invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate, wpartial, NC, dw, db, 32);
+    } else {
+        hipLaunchKernelGGL((head_bn_bwd_kernel<0, false>), dim3(grid), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
+                           (const bf16*)y, mask_scale, mask_shift, groups, partial, (const float*)nullptr, (bf16*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(32), dim3(64 * groups), 0, ST(stream), partial, grid / groups, groups, 32, mean,
+                           invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate);
+    }
+    hipLaunchKernelGGL((head_bn_bwd_kernel<1, false>), dim3(grid2), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
+                       (const bf16*)y, mask_scale, mask_shift, groups, (float*)nullptr, coef, (bf16*)dx, (float*)nullptr);
     DH_CHECK_LAUNCH("head_bn_bwd");
+    return 0;
+}
+
+// The class head behind a ReLU (classifier(conv_layer2(...)), models/networks.py:1351-1355; bf16, n_class <= 2): dx = (relu_out
+// > 0) * (W^T (*) dlogits) [N][H][W][32] -- dh_head_dgrad3x3_relu from the zero-bordered pair map dlp (dh_head_dlogits_pack) --
+// AND the head's own weight / bias gradient dw [n_class][32][3][3] / db [n_class] ((+)= when accumulate) from the same loads
+// of relu_out, which is the head's input (head_bn_bwd_kernel<2, true>).  workspace: dh_head_bn_bwd_workspace_size(N, H, W, 1).
+extern "C" int dh_head_relu_bwd(const void* dlp, const float* w_oihw, int NC, const void* relu_out, void* dx, float* dw, float* db,
+                                int accumulate, int N, int H, int W, void* workspace, void* stream) {
+    DH_REQUIRE(NC >= 1 && NC <= 2 && dlp && relu_out && dx && dw && db && workspace, "head_relu_bwd: bad arguments (n_class=%d)", NC);
+    DH_REQUIRE((long)N * H * W * 64 < (1L << 31), "head_relu_bwd: %d x %d x %d pixels x 64 bytes do not fit a 2 GiB buffer descriptor", N, H, W);
+    const int grid = dh_head_bn_bwd_blocks(N, H, W, 1);
+    float* wpartial = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL((head_bn_bwd_kernel<2, true>), dim3(grid), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
+                       (const bf16*)relu_out, (const float*)nullptr, (const float*)nullptr, 1, (float*)nullptr, (const float*)nullptr,
+                       (bf16*)dx, wpartial);
+    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(HB_WCOLS), dim3(256), 0, ST(stream), (const float*)nullptr, grid, 1,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, accumulate, wpartial, NC, dw, db, 0);
+    DH_CHECK_LAUNCH("head_relu_bwd");
     return 0;
 }

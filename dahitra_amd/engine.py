@@ -52,12 +52,12 @@ class Gated:
 
 
 class HeadGrad:
-    """The class head's data gradient NOT formed: the 16-byte-per-pixel dlogits and the head's weights, for a BatchNorm + ReLU
+    """The class head's data gradient NOT formed: the dlogits as zero-bordered bf16 pairs (ops.head_dlogits_pack) and the head's weights, for a BatchNorm + ReLU
     backward that recomputes it in both of its passes (ops.head_bn_bwd) instead of reading a 32-channel tensor twice."""
-    __slots__ = ("dl", "w", "ncls")
+    __slots__ = ("dl", "w", "ncls", "gw", "gb")
 
-    def __init__(self, dl, w, ncls):
-        self.dl, self.w, self.ncls = dl, w, ncls
+    def __init__(self, dl, w, ncls, gw, gb):
+        self.dl, self.w, self.ncls, self.gw, self.gb = dl, w, ncls, gw, gb        # gw / gb: the head's own gradients, (+)= there
 
 
 class CoarseRes:
@@ -332,7 +332,7 @@ class Engine:
             """through_up4 = (a, b, da, db): this conv's input is bilinear_x4(|a - b|); the gradients land in da, db"""
             if isinstance(dout, HeadGrad):    # the class head's gradient, recomputed by both passes of this backward
                 dy = ops.head_bn_bwd(dout.dl, dout.w, dout.ncls, y, scale, shift, mean, invstd, gamma,
-                                     self.g[bnkey + ".weight"], self.g[bnkey + ".bias"], groups)
+                                     self.g[bnkey + ".weight"], self.g[bnkey + ".bias"], groups, dw=dout.gw, db=dout.gb)
                 dres = None
             elif isinstance(dout, Gated):     # ReLU mask and the reduction pass were done by the producer of dout
                 dy = ops.bn_bwd_from_partials(dout.g, y, dout.partial, mean, invstd, gamma, self.g[bnkey + ".weight"],
@@ -986,13 +986,19 @@ class Engine:
                 # n_class (2..5) real channels: keep dlogits at ONE 16-byte piece per pixel instead of padding them to
                 # a 32-channel K-chunk (4x the bytes, written and read twice), and take the data gradient with the
                 # dedicated head kernel instead of an MFMA convolution over 94 % zeros
+                if head_bn is not None and self.fused_head_bn and self.dtype == torch.bfloat16 and ncls <= 2 and \
+                        self.g[wkey].is_contiguous():
+                    # data gradient, weight and bias gradient of this convolution: all inside the BatchNorm backward behind it
+                    return HeadGrad(ops.head_dlogits_pack(dl_nchw), self.p[wkey], ncls, self.g[wkey], self.g[bkey])
+                if relu_out is not None and self.fused_head_bn and self.dtype == torch.bfloat16 and ncls <= 2 and \
+                        self.g[wkey].is_contiguous() and relu_out is h:
+                    # the head behind a ReLU: data gradient (masked) + weight / bias gradient in one pass over the head's input
+                    return ops.head_relu_bwd(ops.head_dlogits_pack(dl_nchw), self.p[wkey], ncls, h, self.g[wkey], self.g[bkey])
                 dl = ops.nchw_to_nhwc(dl_nchw, self.dtype, cpad=small)
                 ops.conv2d_wgrad(h, dl, self.g[wkey], 3, 1, 1, accumulate=True, use_tr=self.use_tr, cout_real=ncls)
                 tmp = torch.empty(small, dtype=torch.float32, device=h.device)
                 ops.colsum(dl.view(-1, small), tmp)
                 ops.reduce_rows(tmp, 1, ncls, self.g[bkey], accumulate=True)
-                if head_bn is not None and self.fused_head_bn and self.dtype == torch.bfloat16 and ncls <= 2:
-                    return HeadGrad(dl, self.p[wkey], ncls)
                 if head_bn is not None and self.gated_head_dgrad and self.dtype == torch.bfloat16 and ncls <= 2:
                     # the BatchNorm behind these 32 channels: mask + reduction here, only its apply pass remains
                     return Gated(*ops.head_dgrad3x3_bn(dl, self.p[wkey], ncls, *head_bn))

@@ -333,14 +333,25 @@ int dh_head_dgrad3x3_bn(const void* dy, const float* w_oihw, int NC, const void*
                         void* stream);
 /* The head's data gradient AND the backward of the BatchNorm + ReLU behind its 32 channels in two passes that never write the
  * gradient in between (bf16, n_class <= 2; the autograd of Conv2d(32, n_class, 3) <- ReLU <- BatchNorm2d(32),
- * models/help_funcs.py:7-15): each pass forms g = (y * mask_scale + mask_shift > 0) * (W^T (*) dl) on the matrix cores from the
- * 16-byte-per-pixel dl; pass 1 reduces (sum g, sum g y), pass 2 writes dx = gamma invstd (g - (s1 + xhat s2) / M).  y
+ * models/help_funcs.py:7-15): each pass forms g = (y * mask_scale + mask_shift > 0) * (W^T (*) dlogits) on the matrix cores from
+ * dlp, the dlogits as [N][H + 2][W + 2] bf16 pairs inside a border of zeros (dh_head_dlogits_pack from the loss kernel's
+ * [N][n_class][H][W] fp32: a tap is one 4-byte load, no bounds test); pass 1 reduces (sum g, sum g y), pass 2 writes dx = gamma invstd (g - (s1 + xhat s2) / M).  y
  * [N][H][W][32] pre-BatchNorm, statistics [groups][32] as dh_bn_finalize left them; dgamma / dbeta [32] (+)= when accumulate. */
 int dh_head_bn_bwd_blocks(int N, int H, int W, int groups);
 long dh_head_bn_bwd_workspace_size(int N, int H, int W, int groups);
-int dh_head_bn_bwd(const void* dl, const float* w_oihw, int NC, const void* y, const float* mask_scale, const float* mask_shift,
+/* dw [n_class][32][3][3] / db [n_class] (both or NULL): the head convolution's own weight and bias gradient (input =
+ * relu(BatchNorm(y)) as bf16), taken by pass 1 from the loads it makes anyway -- pixels are the K dimension of an MFMA through
+ * wave-private LDS tiles read back transposed; (+)= when accumulate. */
+int dh_head_dlogits_pack(const float* dlogits_nchw, int N, int NC, int H, int W, void* dlp, void* stream);
+int dh_head_bn_bwd(const void* dlp, const float* w_oihw, int NC, const void* y, const float* mask_scale, const float* mask_shift,
                    const float* mean, const float* invstd, const float* gamma, int groups, void* dx, float* dgamma, float* dbeta,
-                   int accumulate, int N, int H, int W, void* workspace, void* stream);
+                   float* dw, float* db, int accumulate, int N, int H, int W, void* workspace, void* stream);
+/* The class head behind a ReLU (classifier(conv_layer2(...)), models/networks.py:1351-1355; bf16, n_class <= 2): the data gradient
+ * dx = (relu_out > 0) * (W^T (*) dlogits) of dh_head_dgrad3x3_relu, from the pair map dlp (dh_head_dlogits_pack), AND the head's
+ * own weight / bias gradient dw [n_class][32][3][3] / db [n_class] ((+)= when accumulate) from the same loads of relu_out --
+ * the head's input.  workspace: dh_head_bn_bwd_workspace_size(N, H, W, 1) bytes. */
+int dh_head_relu_bwd(const void* dlp, const float* w_oihw, int NC, const void* relu_out, void* dx, float* dw, float* db,
+                     int accumulate, int N, int H, int W, void* workspace, void* stream);
 int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream);
 int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, void* dst, int Cd, int dc0, int Cn, long P, void* stream);
 /* torch.cat([x1, x2], 1) of the two temporal streams (models/networks.py:1309, 1344), which are the two batch halves of

@@ -674,7 +674,8 @@ def test_head_gradient_recomputed_inside_the_batchnorm_backward(ops, cfg):
     N, H, W, G, ncls = cfg["n"], cfg["h"], cfg["w"], cfg["groups"], cfg["ncls"]
     dtype = torch.bfloat16
     y = rnd((N, 32, H, W), dtype, 2101, 1.5)
-    w = rnd((ncls, 32, 3, 3), torch.float32, 2102, 0.1)
+    w = rnd((ncls, 32, 3, 3), torch.float32, 2102, 0.1).requires_grad_(True)
+    hb = torch.zeros(ncls, requires_grad=True)
     dlog = rnd((N, ncls, H, W), dtype, 2103)
     gamma = (rnd((32,), torch.float32, 2104, 0.2) + 1.0)
     beta = rnd((32,), torch.float32, 2105, 0.3)
@@ -685,8 +686,9 @@ def test_head_gradient_recomputed_inside_the_batchnorm_backward(ops, cfg):
     outs = []
     for k in range(G):
         sl = slice(k * N // G, (k + 1) * N // G)
-        outs.append(F.conv2d(torch.relu(F.batch_norm(yt[sl], None, None, gm, bt, True, 0.1, 1e-5)), w, None, 1, 1))
+        outs.append(F.conv2d(torch.relu(F.batch_norm(yt[sl], None, None, gm, bt, True, 0.1, 1e-5)), w, hb, 1, 1))
     torch.cat(outs).backward(dlog.float())
+    w, wg = w.detach(), w.grad
     # device: statistics as dh_bn_finalize leaves them
     yd = dev(nhwc(y), dtype)
     yg = yd.float().view(G, -1, 32)
@@ -697,8 +699,11 @@ def test_head_gradient_recomputed_inside_the_batchnorm_backward(ops, cfg):
     shift = beta.cuda()[None] - mean * scale
     mean, invstd, scale, shift = (t.contiguous() for t in (mean, invstd, scale, shift))
     dl = ops.nchw_to_nhwc(dlog.float().cuda().contiguous(), dtype, cpad=8)
+    dlp = ops.head_dlogits_pack(dlog.float().cuda().contiguous())
+    assert int(dlp[:, 0].abs().max()) == 0 and int(dlp[:, :, -1].abs().max()) == 0          # the border of zeros
+    assert torch.equal(dlp[:, 1:-1, 1:-1].contiguous().view(torch.bfloat16).view(N, H, W, 2)[..., :ncls], dl[..., :ncls])
     dg1, db1 = torch.zeros(32, device="cuda"), torch.zeros(32, device="cuda")
-    dx1 = ops.head_bn_bwd(dl, w.cuda(), ncls, yd, scale, shift, mean, invstd, gamma.cuda(), dg1, db1, G, accumulate=False)
+    dx1 = ops.head_bn_bwd(dlp, w.cuda(), ncls, yd, scale, shift, mean, invstd, gamma.cuda(), dg1, db1, G, accumulate=False)
     close(nchw(dx1), yt.grad, dtype, "dx vs autograd", factor=2.0)
     close(dg1, gm.grad, dtype, "dgamma vs autograd", factor=4.0)
     close(db1, bt.grad, dtype, "dbeta vs autograd", factor=4.0)
@@ -709,10 +714,21 @@ def test_head_gradient_recomputed_inside_the_batchnorm_backward(ops, cfg):
     close(dx1, dx0.float().cpu(), dtype, "dx vs three kernels", factor=2.0)
     close(dg1, dg0.cpu(), dtype, "dgamma vs three kernels", factor=2.0)
     close(db1, db0.cpu(), dtype, "dbeta vs three kernels", factor=2.0)
-    # accumulate: (+)= into the parameter gradients
-    dx2 = ops.head_bn_bwd(dl, w.cuda(), ncls, yd, scale, shift, mean, invstd, gamma.cuda(), dg1, db1, G, accumulate=True)
+    # accumulate: (+)= into the parameter gradients; with the head convolution's own weight / bias gradient from the same pass
+    dw = torch.full((ncls, 32, 3, 3), 0.5, device="cuda")
+    dbias = torch.full((ncls,), -2.0, device="cuda")
+    dx2 = ops.head_bn_bwd(dlp, w.cuda(), ncls, yd, scale, shift, mean, invstd, gamma.cuda(), dg1, db1, G, accumulate=True,
+                          dw=dw, db=dbias)
     assert torch.equal(dx2, dx1)
     close(dg1, 2 * gm.grad, dtype, "dgamma accumulated", factor=4.0)
+    close(dw - 0.5, wg, dtype, "head weight gradient vs autograd", factor=2.0)
+    close(dbias + 2.0, hb.grad, dtype, "head bias gradient vs autograd", factor=2.0)
+    dw2, dbias2 = torch.zeros_like(dw), torch.zeros_like(dbias)
+    ops.head_bn_bwd(dlp, w.cuda(), ncls, yd, scale, shift, mean, invstd, gamma.cuda(), dg1, db1, G, accumulate=False, dw=dw2, db=dbias2)
+    # ... against the weight-gradient kernel it replaces (input = the BatchNorm + ReLU applied on load)
+    dw0 = torch.zeros_like(dw)
+    ops.conv2d_wgrad(ops.BnInput(yd, scale, shift, G), dl, dw0, 3, 1, 1, accumulate=False, cout_real=ncls)
+    close(dw2, dw0.cpu(), dtype, "head weight gradient vs conv2d_wgrad", factor=1.0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -1607,6 +1623,33 @@ def test_head_data_gradient_with_the_relu_in_front_of_it_folded_in(ops):
     got = ops.head_dgrad3x3(dl, w, 2, relu_out=out)
     assert torch.equal(got, want)
     assert float((got != 0).float().mean()) < float((ops.head_dgrad3x3(dl, w, 2) != 0).float().mean())
+
+
+@pytest.mark.parametrize("cfg", [dict(n=3, h=64, w=48, ncls=2), dict(n=2, h=9, w=21, ncls=1), dict(n=8, h=128, w=128, ncls=2)])
+def test_head_behind_a_relu_data_weight_and_bias_gradient_in_one_pass(ops, cfg):
+    """dh_head_relu_bwd against torch autograd of conv2d(relu_out, W, b) with the gradient masked by relu_out > 0
+    (classifier(conv_layer2(...)), models/networks.py:1351-1355) and against the kernels it replaces"""
+    N, H, W, ncls = cfg["n"], cfg["h"], cfg["w"], cfg["ncls"]
+    dtype = torch.bfloat16
+    pre = rnd((N, 32, H, W), dtype, 1311).float().requires_grad_(True)
+    w = rnd((ncls, 32, 3, 3), torch.float32, 1312, 0.1).requires_grad_(True)
+    hb = torch.zeros(ncls, requires_grad=True)
+    dlog = rnd((N, ncls, H, W), dtype, 1313)
+    F.conv2d(torch.relu(pre), w, hb, 1, 1).backward(dlog.float())
+    out = dev(nhwc(torch.relu(pre).detach()), dtype)
+    dlp = ops.head_dlogits_pack(dlog.float().cuda().contiguous())
+    dw, db = torch.full((ncls, 32, 3, 3), 0.25, device="cuda"), torch.full((ncls,), 1.0, device="cuda")
+    dx = ops.head_relu_bwd(dlp, w.detach().cuda(), ncls, out, dw, db, accumulate=True)
+    close(nchw(dx), pre.grad, dtype, "dx vs autograd", factor=2.0)
+    close(dw - 0.25, w.grad, dtype, "dw vs autograd", factor=2.0)
+    close(db - 1.0, hb.grad, dtype, "db vs autograd", factor=2.0)
+    dl = ops.nchw_to_nhwc(dlog.float().cuda().contiguous(), dtype, cpad=8)
+    assert torch.equal(dx, ops.head_dgrad3x3(dl, w.detach().cuda(), ncls, relu_out=out))          # same products, same order
+    dw0 = torch.zeros_like(dw)
+    ops.conv2d_wgrad(out, dl, dw0, 3, 1, 1, accumulate=False, cout_real=ncls)
+    dw1, db1 = torch.zeros_like(dw), torch.zeros_like(db)
+    ops.head_relu_bwd(dlp, w.detach().cuda(), ncls, out, dw1, db1, accumulate=False)
+    close(dw1, dw0.cpu(), dtype, "dw vs conv2d_wgrad", factor=1.0)
 
 
 @pytest.mark.parametrize("cfg", [

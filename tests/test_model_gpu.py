@@ -806,15 +806,18 @@ def test_opt_in_paths_equal_default_paths_bf16(monkeypatch):
         assert cos >= 0.9995 and float((g - h).abs().max()) <= 3e-2 * float(g.abs().max()) + 1e-9, (k, cos)
 
 
-def test_head_gradient_inside_the_batchnorm_backward_equals_three_kernel_path_bf16(monkeypatch):
-    """default bf16 step (the class head's data gradient recomputed by both passes of classifier.1's backward, engine.HeadGrad)
-    against DAHITRA_NO_FUSED_HEAD_BN=1 (head_dgrad3x3 -> bn_bwd: the same gradient rounded to bf16 in between)"""
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
+def test_head_gradient_inside_the_batchnorm_backward_equals_three_kernel_path_bf16(name, monkeypatch):
+    """default bf16 step against DAHITRA_NO_FUSED_HEAD_BN=1.  s4: the class head's data gradient recomputed by both passes of
+    classifier.1's backward with the head's weight / bias gradient from the first (engine.HeadGrad) against head_dgrad3x3 ->
+    bn_bwd + conv2d_wgrad + colsum (the same gradient rounded to bf16 in between); newUNetTrans: the head behind a ReLU, data +
+    weight + bias gradient in one pass (ops.head_relu_bwd) against head_dgrad3x3(relu_out) + conv2d_wgrad + colsum"""
     from dahitra_amd.models import losses
-    a, b, lab = O.synthetic_batch(2, 64, seed=73)
+    a, b, lab = O.synthetic_batch(2, 256 if name == "newUNetTrans" else 64, seed=73)
     res = {}
     for off in ("0", "1"):
         monkeypatch.setenv("DAHITRA_NO_FUSED_HEAD_BN", off)
-        net = make_net("base_transformer_pos_s4", "bf16").train()
+        net = make_net(name, "bf16").train()
         assert net._engine.fused_head_bn == (off == "0")
         y = net(a.cuda(), b.cuda())
         losses.focal_loss(y, lab.cuda()).backward()
