@@ -686,20 +686,27 @@ __global__ void bn_bwd_finalize_coef_kernel(const float* __restrict__ partial, i
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 // dlogits [N][NC <= 2][H][W] fp32 (the loss kernel's layout) -> [N][H + 2][W + 2] bf16 pairs (class 0 low, class 1 high) inside a
-// border of zeros: what head_bn_bwd_kernel gathers its nine taps from, 4 bytes per tap and no bounds test
+// border of zeros: what head_bn_bwd_kernel gathers its nine taps from, 4 bytes per tap and no bounds test.  PL = 2 (the
+// split-product fp32 mode): two words per pixel, the pair of the values' bf16 heads and the pair of their bf16 remainders.
+template <int PL>
 __global__ void head_dlogits_pack_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int N, int NC, int H, int W) {
     const int Wp = W + 2, Hp = H + 2;
     const long total = (long)N * Hp * Wp;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int xx = (int)(i % Wp) - 1, yy = (int)((i / Wp) % Hp) - 1;
         const long n = i / ((long)Wp * Hp);
-        unsigned v = 0u;
+        float a = 0.f, b = 0.f;
         if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
-            const float a = src[((n * NC) * H + yy) * (long)W + xx];
-            const float b = NC > 1 ? src[((n * NC + 1) * H + yy) * (long)W + xx] : 0.f;
-            v = f2bf2(a, b);
+            a = src[((n * NC) * H + yy) * (long)W + xx];
+            b = NC > 1 ? src[((n * NC + 1) * H + yy) * (long)W + xx] : 0.f;
         }
-        dst[i] = v;
+        const unsigned hi = f2bf2(a, b);
+        if constexpr (PL == 1) {
+            dst[i] = hi;
+        } else {
+            const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+            reinterpret_cast<uint2*>(dst)[i] = make_uint2(hi, f2bf2(ra, rb));
+        }
     }
 }
 
@@ -715,24 +722,31 @@ constexpr int HB_TP = 96;                                // tile pitch (bytes): 
 
 // MODE 2 (dh_head_relu_bwd): no BatchNorm -- `y` is the OUTPUT of the ReLU in front of the head (classifier(conv_layer2(...)),
 // models/networks.py:1351-1355), dx = (y > 0) * g in one pass, with the head's weight gradient (WGRAD) from the same loads.
-template <int MODE, bool WGRAD>
+// T = float (the bf16x3 mode of the fp32 pipeline, dh_set_f32_mma_mode != 0): y / dx are fp32 (32 bytes per lane), every matrix
+// product is the three split products hi.hi + hi.lo + lo.hi of bf16 planes (x = hi + lo, ~2^-17: what that mode's backward
+// convolutions and weight gradients compute): the weights' planes are formed once, the dlogits' planes come from the pair map
+// (PL = 2), the planes of relu(BN(y)) are formed per group for the weight gradient's tiles.
+template <typename T, int MODE, bool WGRAD>
 __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __restrict__ dlp, const float* __restrict__ w_oihw, int N, int H,
-                                                          int W, int NC, const bf16* __restrict__ y, const float* __restrict__ mscale,
+                                                          int W, int NC, const T* __restrict__ y, const float* __restrict__ mscale,
                                                           const float* __restrict__ mshift, int groups, float* __restrict__ partial,
-                                                          const float* __restrict__ coef, bf16* __restrict__ dx,
+                                                          const float* __restrict__ coef, T* __restrict__ dx,
                                                           float* __restrict__ wpartial) {
-    constexpr bool APPLY = MODE == 1, RELU = MODE == 2, STORE = MODE != 0;
+    constexpr bool APPLY = MODE == 1, RELU = MODE == 2, STORE = MODE != 0, F32 = sizeof(T) == 4;
+    constexpr int PL = F32 ? 2 : 1;  // operand planes
     constexpr int HB_DEPTH = 2;      // groups in flight per wave (depths 3 and 4 measured: no faster, more registers)
+    constexpr int PXB = 32 * (int)sizeof(T);                 // bytes of a pixel of y / dx
     static_assert(!(APPLY && WGRAD), "the weight gradient rides on the reduction pass");
-    __shared__ __attribute__((aligned(16))) unsigned char hb_tiles[WGRAD ? 4 * 2 * 16 * HB_TP : 16];
+    constexpr int TILE = 16 * HB_TP;
+    __shared__ __attribute__((aligned(16))) unsigned char hb_tiles[WGRAD ? 4 * 2 * PL * TILE : 16];
     const int lane = threadIdx.x & 63, pl = lane & 15, g = lane >> 4;
-    unsigned char* tH = hb_tiles + (WGRAD ? (threadIdx.x >> 6) * 2 * 16 * HB_TP : 0);
-    unsigned char* tN = tH + (WGRAD ? 16 * HB_TP : 0);
+    unsigned char* tH = hb_tiles + (WGRAD ? (threadIdx.x >> 6) * 2 * PL * TILE : 0);      // [PL] tiles of the head's input
+    unsigned char* tN = tH + (WGRAD ? PL * TILE : 0);                                     // [PL] tiles of the dlogits neighbourhood
     f32x4 wacc[2][2];
     float bsum0 = 0.f, bsum1 = 0.f;
 #pragma unroll
     for (int a_ = 0; a_ < 2; ++a_) wacc[a_][0] = wacc[a_][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    s16x8 wa[2];          // A fragments: row ci = s * 16 + pl, k = 8 g + e -> tap 4 g + e / 2, class e & 1
+    s16x8 wa[PL][2];      // A fragments (planes): row ci = s * 16 + pl, k = 8 g + e -> tap 4 g + e / 2, class e & 1
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         float v[8];
@@ -741,9 +755,14 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __rest
             const int tap = 4 * g + (e >> 1), co = e & 1;
             v[e] = (tap < 9 && co < NC) ? w_oihw[((size_t)co * 32 + s * 16 + pl) * 9 + tap] : 0.f;
         }
-        union { uint4 u; s16x8 h; } pk;
-        pk.u = pack16<bf16>(v);
-        wa[s] = pk.h;
+        uint4 wp[PL];
+        split_bf16_planes<PL>(v, wp);
+#pragma unroll
+        for (int p = 0; p < PL; ++p) {
+            union { uint4 u; s16x8 h; } pk;
+            pk.u = wp[p];
+            wa[p][s] = pk.h;
+        }
     }
     const int bpg = gridDim.x / groups, bg = blockIdx.x / bpg;
     const long gpix = (long)N * H * W / groups, total = (bg + 1) * gpix, ngrp16 = (gpix + 15) / 16;
@@ -762,50 +781,70 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __rest
         s1[e] = s2[e] = 0.f;
         if constexpr (APPLY) { cA[e] = coef[(bg * 3 + 0) * 32 + cb + e]; cB[e] = coef[(bg * 3 + 1) * 32 + cb + e]; cC[e] = coef[(bg * 3 + 2) * 32 + cb + e]; }
     }
-    // Every access goes through a buffer descriptor with a 32-bit byte offset: a load that must deliver zeros (image border, a
-    // tap that does not exist, a group past the wave's share) gets an offset past the end -- the hardware returns 0, no select
-    // touches a loaded value before the group is USED, and the loads of group i + 1 stay in flight under group i; a store of a
-    // pixel that does not exist is dropped the same way.  (dh_head_bn_bwd requires the tensors below 2 GiB.)
+    // Every access goes through a buffer descriptor with a 32-bit byte offset: a load that must deliver zeros (a tap that does
+    // not exist, a group past the wave's share) gets an offset past the end -- the hardware returns 0, no select touches a
+    // loaded value before the group is USED, and the loads of group i + 1 stay in flight under group i; a store of a pixel that
+    // does not exist is dropped the same way.  (The entry points require the tensors below 2 GiB.)
     const unsigned npx_all = (unsigned)((long)N * H * W);
     const int Wp = W + 2;
-    const auto rs_dl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(dlp), 0, N * (H + 2) * Wp * 4, 0x00020000);
-    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(y), 0, (int)(npx_all * 64u), 0x00020000);
-    const auto rs_dx = __builtin_amdgcn_make_buffer_rsrc(dx, 0, STORE ? (int)(npx_all * 64u) : 0, 0x00020000);
+    const auto rs_dl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(dlp), 0, N * (H + 2) * Wp * 4 * PL, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(y), 0, (int)(npx_all * (unsigned)PXB), 0x00020000);
+    const auto rs_dx = __builtin_amdgcn_make_buffer_rsrc(dx, 0, STORE ? (int)(npx_all * (unsigned)PXB) : 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const long pxl = bg * gpix + grp0 * 16 + pl;            // this lane's first pixel; (cx, cy) its column / row inside its image
     unsigned px = (unsigned)pxl;
     int cx = (int)(pxl % W), cy = (int)((pxl / W) % H);
-    // dlogits come as dh_head_dlogits_pack left them: [N][H + 2][W + 2] bf16 pairs with a border of zeros -- a tap needs no bounds
-    // test, only an offset from the lane's own (padded) position pc4 (bytes)
-    unsigned pc4 = (unsigned)(((pxl / ((long)W * H)) * (H + 2) + cy + 1) * Wp + cx + 1) * 4u;
+    // dlogits come as dh_head_dlogits_pack left them: [N][H + 2][W + 2] bf16 pairs (x PL planes) with a border of zeros -- a tap
+    // needs no bounds test, only an offset from the lane's own (padded) position pc4 (bytes)
+    constexpr int PB = 4 * PL;                              // bytes of a pixel of the pair map
+    unsigned pc4 = (unsigned)(((pxl / ((long)W * H)) * (H + 2) + cy + 1) * Wp + cx + 1) * (unsigned)PB;
     int toff[4];                                            // this lane group's taps: byte offset from pc4
     bool thave[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int tap = 4 * g + q, kh = tap / 3, kw = tap - kh * 3;
         thave[q] = tap < 9;
-        toff[q] = ((1 - kh) * Wp + (1 - kw)) * 4;
+        toff[q] = ((1 - kh) * Wp + (1 - kw)) * PB;
     }
-    struct Grp { unsigned bk[4]; u32x4 yraw; unsigned at; };
+    struct Grp { unsigned bk[PL][4]; u32x4 yraw[PL]; unsigned at; };      // (fp32: yraw = the lane's 8 values; bf16: one piece)
     auto request = [&](Grp& q_, bool valid) {
         const bool inb = valid & (px < (unsigned)total);
-        q_.at = inb ? px * 64u + cb * 2u : OOB;
+        q_.at = inb ? px * (unsigned)PXB + cb * (unsigned)sizeof(T) : OOB;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            q_.bk[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_dl, (inb & thave[q]) ? pc4 + toff[q] : OOB, 0, 0);
+            const unsigned off = (inb & thave[q]) ? pc4 + toff[q] : OOB;
+            if constexpr (F32) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_dl, off, 0, 0);
+                q_.bk[0][q] = v[0]; q_.bk[PL - 1][q] = v[1];
+            } else {
+                q_.bk[0][q] = __builtin_amdgcn_raw_buffer_load_b32(rs_dl, off, 0, 0);
+            }
         }
-        q_.yraw = __builtin_amdgcn_raw_buffer_load_b128(rs_y, q_.at, 0, 0);
-        px += 16; cx += 16; pc4 += 64;
+        q_.yraw[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, q_.at, 0, 0);
+        if constexpr (F32) q_.yraw[PL - 1] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, q_.at + 16u, 0, 0);      // (OOB + 16 stays out of range)
+        px += 16; cx += 16; pc4 += 16 * PB;
         while (cx >= W) {                                   // next row: over the two border pixels; next image: over two border rows
-            cx -= W; pc4 += 8;
-            if (++cy == H) { cy = 0; pc4 += 2 * Wp * 4; }
+            cx -= W; pc4 += 2 * PB;
+            if (++cy == H) { cy = 0; pc4 += 2 * Wp * PB; }
         }
     };
+    // lane (pl, g): pixels 4 g .. 4 g + 3 of column 16 c + pl of a tile
+    auto frag = [&](const unsigned char* t, int c) {
+        const unsigned char* base = t + (g * 4 + (pl >> 2)) * HB_TP + (c * 16 + (pl & 3) * 4) * 2;
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+    };
     auto use = [&](const Grp& q_) {
-        union { uint4 u; s16x8 h; } b;
-        b.u = make_uint4(q_.bk[0], q_.bk[1], q_.bk[2], q_.bk[3]);
-        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], b.h, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], b.h, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        union { uint4 u; s16x8 h; } b[PL];
+#pragma unroll
+        for (int p = 0; p < PL; ++p) b[p].u = make_uint4(q_.bk[p][0], q_.bk[p][1], q_.bk[p][2], q_.bk[p][3]);
+        f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][0], b[0].h, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][1], b[0].h, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if constexpr (F32) {
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][0], b[PL - 1].h, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][1], b[PL - 1].h, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[PL - 1][0], b[0].h, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[PL - 1][1], b[0].h, d1, 0, 0, 0);
+        }
         float r[8], yv[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -813,8 +852,13 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __rest
             r[j] = __uint_as_float(sw[0]);
             r[4 + j] = __uint_as_float(sw[1]);
         }
+        if constexpr (F32) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { yv[2 * k] = __uint_as_float(q_.yraw[k] << 16); yv[2 * k + 1] = __uint_as_float(q_.yraw[k] & 0xffff0000u); }
+            for (int k = 0; k < 4; ++k) { yv[k] = __uint_as_float(q_.yraw[0][k]); yv[4 + k] = __uint_as_float(q_.yraw[PL - 1][k]); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { yv[2 * k] = __uint_as_float(q_.yraw[0][k] << 16); yv[2 * k + 1] = __uint_as_float(q_.yraw[0][k] & 0xffff0000u); }
+        }
         float z[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -822,46 +866,65 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __rest
             r[e] = z[e] > 0.f ? r[e] : 0.f;          // (a group of zeros has r = 0 already)
         }
         if constexpr (WGRAD) {
-            if constexpr (RELU) {                    // the head's input is y itself
-                *reinterpret_cast<uint4*>(tH + pl * HB_TP + cb * 2) = make_uint4(q_.yraw[0], q_.yraw[1], q_.yraw[2], q_.yraw[3]);
+            if constexpr (RELU && !F32) {            // the head's input is y itself
+                *reinterpret_cast<uint4*>(tH + pl * HB_TP + cb * 2) = make_uint4(q_.yraw[0][0], q_.yraw[0][1], q_.yraw[0][2], q_.yraw[0][3]);
             } else {
                 float hv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hv[e] = fmaxf(z[e], 0.f);        // (a group of zeros: its dlogits are zero)
-                *reinterpret_cast<uint4*>(tH + pl * HB_TP + cb * 2) = pack16<bf16>(hv);
+                uint4 hp[PL];
+                split_bf16_planes<PL>(hv, hp);
+#pragma unroll
+                for (int p = 0; p < PL; ++p) *reinterpret_cast<uint4*>(tH + p * TILE + pl * HB_TP + cb * 2) = hp[p];
             }
-            *reinterpret_cast<uint4*>(tN + pl * HB_TP + g * 16) = b.u;
+#pragma unroll
+            for (int p = 0; p < PL; ++p) *reinterpret_cast<uint4*>(tN + p * TILE + pl * HB_TP + g * 16) = b[p].u;
             asm volatile("" ::: "memory");
-            // lane (pl, g): pixels 4 g .. 4 g + 3 of column 16 c + pl of a tile
-            auto frag = [&](const unsigned char* t, int c) {
-                const unsigned char* base = t + (g * 4 + (pl >> 2)) * HB_TP + (c * 16 + (pl & 3) * 4) * 2;
-                return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
-            };
-            const s16x4 h0 = frag(tH, 0), h1 = frag(tH, 1), n0 = frag(tN, 0), n1 = frag(tN, 1);
+            s16x4 hf[PL][2], nf[PL][2];
+#pragma unroll
+            for (int p = 0; p < PL; ++p)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) { hf[p][c] = frag(tH + p * TILE, c); nf[p][c] = frag(tN + p * TILE, c); }
             asm volatile("" ::: "memory");
-            wacc[0][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h0, n0, wacc[0][0], 0, 0, 0);
-            wacc[0][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h0, n1, wacc[0][1], 0, 0, 0);
-            wacc[1][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h1, n0, wacc[1][0], 0, 0, 0);
-            wacc[1][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(h1, n1, wacc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    wacc[cs][ks] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hf[0][cs], nf[0][ks], wacc[cs][ks], 0, 0, 0);
+                    if constexpr (F32) {
+                        wacc[cs][ks] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hf[0][cs], nf[PL - 1][ks], wacc[cs][ks], 0, 0, 0);
+                        wacc[cs][ks] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hf[PL - 1][cs], nf[0][ks], wacc[cs][ks], 0, 0, 0);
+                    }
+                }
             // the centre tap (4: lane group 1, its first load) is the pixel's own dlogits: the bias gradient
-            bsum0 += __uint_as_float(q_.bk[0] << 16);
-            bsum1 += __uint_as_float(q_.bk[0] & 0xffff0000u);
+#pragma unroll
+            for (int p = 0; p < PL; ++p) {
+                bsum0 += __uint_as_float(q_.bk[p][0] << 16);
+                bsum1 += __uint_as_float(q_.bk[p][0] & 0xffff0000u);
+            }
         }
+        auto store8 = [&](const float (&o)[8]) {
+            if constexpr (F32) {
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])}, rs_dx, q_.at, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(o[4]), __float_as_uint(o[5]), __float_as_uint(o[6]), __float_as_uint(o[7])}, rs_dx, q_.at + 16u, 0, 0);
+            } else {
+                const uint4 pk = pack16<bf16>(o);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk.x, pk.y, pk.z, pk.w}, rs_dx, q_.at, 0, 0);
+            }
+        };
         if constexpr (APPLY) {
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = cA[e] * r[e] + cB[e] * yv[e] + cC[e];
-            const uint4 pk = pack16<bf16>(o);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk.x, pk.y, pk.z, pk.w}, rs_dx, q_.at, 0, 0);
+            store8(o);
         } else if constexpr (RELU) {
-            const uint4 pk = pack16<bf16>(r);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk.x, pk.y, pk.z, pk.w}, rs_dx, q_.at, 0, 0);
+            store8(r);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s1[e] += r[e]; s2[e] += r[e] * yv[e]; }
         }
     };
-    // HB_DEPTH groups in flight per wave (9 registers each)
+    // HB_DEPTH groups in flight per wave
     Grp gq[HB_DEPTH];
 #pragma unroll
     for (int d = 0; d < HB_DEPTH - 1; ++d) request(gq[d], d < ngr);
@@ -1176,15 +1239,45 @@ extern "C" long dh_head_bn_bwd_workspace_size(int N, int H, int W, int groups) {
 }
 // dw [n_class][32][3][3] / db [n_class] (both or neither; (+)= when accumulate): the head convolution's own weight and bias
 // gradient, taken by pass 1 from the loads it makes anyway (input = relu(BatchNorm(y)), rounded to bf16 as the convolution saw it)
-extern "C" int dh_head_dlogits_pack(const float* dlogits_nchw, int N, int NC, int H, int W, void* dlp, void* stream) {
+// dtype = DH_DTYPE_BF16: one word per pixel; DH_DTYPE_F32 (the split-product mode): two (bf16 heads, bf16 remainders)
+extern "C" int dh_head_dlogits_pack(int dtype, const float* dlogits_nchw, int N, int NC, int H, int W, void* dlp, void* stream) {
     DH_REQUIRE(NC >= 1 && NC <= 2 && dlogits_nchw && dlp, "head_dlogits_pack: n_class=%d", NC);
     const long n = (long)N * (H + 2) * (W + 2);
-    DH_REQUIRE(n * 4 < (1L << 31), "head_dlogits_pack: %d x %d x %d does not fit a 2 GiB buffer descriptor", N, H, W);
-    hipLaunchKernelGGL(head_dlogits_pack_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), dlogits_nchw, (unsigned*)dlp, N, NC, H, W);
+    DH_REQUIRE(n * 8 < (1L << 31), "head_dlogits_pack: %d x %d x %d does not fit a 2 GiB buffer descriptor", N, H, W);
+    if (dtype == DH_DTYPE_BF16)
+        hipLaunchKernelGGL(head_dlogits_pack_kernel<1>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), dlogits_nchw, (unsigned*)dlp, N, NC, H, W);
+    else
+        hipLaunchKernelGGL(head_dlogits_pack_kernel<2>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), dlogits_nchw, (unsigned*)dlp, N, NC, H, W);
     DH_CHECK_LAUNCH("head_dlogits_pack");
     return 0;
 }
-extern "C" int dh_head_bn_bwd(const void* dlp, const float* w_oihw, int NC, const void* y, const float* mask_scale,
+template <typename T>
+static int head_bn_bwd_launch(const void* dlp, const float* w_oihw, int NC, const void* y, const float* mask_scale, const float* mask_shift,
+                              const float* mean, const float* invstd, const float* gamma, int groups, void* dx, float* dgamma, float* dbeta,
+                              float* dw, float* db, int accumulate, int N, int H, int W, void* workspace, hipStream_t st) {
+    const int grid = dh_head_bn_bwd_blocks(N, H, W, groups), grid2 = head_bn_bwd_apply_blocks(N, H, W, groups);
+    float* partial = reinterpret_cast<float*>(workspace);
+    float* coef = partial + (size_t)grid * 2 * 32;
+    float* wpartial = coef + (size_t)groups * 3 * 32;
+    const float inv_m = (float)(1.0 / ((double)N * H * W / groups));
+    if (dw) {
+        hipLaunchKernelGGL((head_bn_bwd_kernel<T, 0, true>), dim3(grid), dim3(256), 0, st, (const unsigned*)dlp, w_oihw, N, H, W, NC,
+                           (const T*)y, mask_scale, mask_shift, groups, partial, (const float*)nullptr, (T*)nullptr, wpartial);
+        hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(32 + HB_WCOLS), dim3(256), 0, st, partial, grid / groups, groups, mean,
+                           invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate, wpartial, NC, dw, db, 32);
+    } else {
+        hipLaunchKernelGGL((head_bn_bwd_kernel<T, 0, false>), dim3(grid), dim3(256), 0, st, (const unsigned*)dlp, w_oihw, N, H, W, NC,
+                           (const T*)y, mask_scale, mask_shift, groups, partial, (const float*)nullptr, (T*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(32), dim3(64 * groups), 0, st, partial, grid / groups, groups, 32, mean,
+                           invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate);
+    }
+    hipLaunchKernelGGL((head_bn_bwd_kernel<T, 1, false>), dim3(grid2), dim3(256), 0, st, (const unsigned*)dlp, w_oihw, N, H, W, NC,
+                       (const T*)y, mask_scale, mask_shift, groups, (float*)nullptr, coef, (T*)dx, (float*)nullptr);
+    return 0;
+}
+// dtype = DH_DTYPE_F32: y / dx fp32, dlp two words per pixel, every product as three split bf16 products (the bf16x3 mode's
+// arithmetic: callers use it only under dh_set_f32_mma_mode != 0)
+extern "C" int dh_head_bn_bwd(int dtype, const void* dlp, const float* w_oihw, int NC, const void* y, const float* mask_scale,
                               const float* mask_shift, const float* mean, const float* invstd, const float* gamma, int groups,
                               void* dx, float* dgamma, float* dbeta, float* dw, float* db, int accumulate, int N, int H, int W,
                               void* workspace, void* stream) {
@@ -1193,42 +1286,35 @@ extern "C" int dh_head_bn_bwd(const void* dlp, const float* w_oihw, int NC, cons
     DH_REQUIRE((dw == nullptr) == (db == nullptr), "head_bn_bwd: dw and db come together");
     const int grid = dh_head_bn_bwd_blocks(N, H, W, groups);
     DH_REQUIRE(grid > 0 && groups <= BN_MAXG, "head_bn_bwd: %d images do not split into %d groups", N, groups);
-    DH_REQUIRE((long)N * H * W * 64 < (1L << 31), "head_bn_bwd: %d x %d x %d pixels x 64 bytes do not fit a 2 GiB buffer descriptor", N, H, W);
-    float* partial = reinterpret_cast<float*>(workspace);
-    float* coef = partial + (size_t)grid * 2 * 32;
-    float* wpartial = coef + (size_t)groups * 3 * 32;
-    const float inv_m = (float)(1.0 / ((double)N * H * W / groups));
-    const int grid2 = head_bn_bwd_apply_blocks(N, H, W, groups);
-    if (dw) {
-        hipLaunchKernelGGL((head_bn_bwd_kernel<0, true>), dim3(grid), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
-                           (const bf16*)y, mask_scale, mask_shift, groups, partial, (const float*)nullptr, (bf16*)nullptr, wpartial);
-        hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(32 + HB_WCOLS), dim3(256), 0, ST(stream), partial, grid / groups, groups, mean,
-                           invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate, wpartial, NC, dw, db, 32);
-    } else {
-        hipLaunchKernelGGL((head_bn_bwd_kernel<0, false>), dim3(grid), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
-                           (const bf16*)y, mask_scale, mask_shift, groups, partial, (const float*)nullptr, (bf16*)nullptr, (float*)nullptr);
-        hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(32), dim3(64 * groups), 0, ST(stream), partial, grid / groups, groups, 32, mean,
-                           invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate);
-    }
-    hipLaunchKernelGGL((head_bn_bwd_kernel<1, false>), dim3(grid2), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
-                       (const bf16*)y, mask_scale, mask_shift, groups, (float*)nullptr, coef, (bf16*)dx, (float*)nullptr);
+    DH_REQUIRE((long)N * H * W * 128 < (1L << 31), "head_bn_bwd: %d x %d x %d pixels x 128 bytes do not fit a 2 GiB buffer descriptor", N, H, W);
+    if (dtype == DH_DTYPE_BF16)
+        head_bn_bwd_launch<bf16>(dlp, w_oihw, NC, y, mask_scale, mask_shift, mean, invstd, gamma, groups, dx, dgamma, dbeta, dw, db,
+                                 accumulate, N, H, W, workspace, ST(stream));
+    else
+        head_bn_bwd_launch<float>(dlp, w_oihw, NC, y, mask_scale, mask_shift, mean, invstd, gamma, groups, dx, dgamma, dbeta, dw, db,
+                                  accumulate, N, H, W, workspace, ST(stream));
     DH_CHECK_LAUNCH("head_bn_bwd");
     return 0;
 }
 
-// The class head behind a ReLU (classifier(conv_layer2(...)), models/networks.py:1351-1355; bf16, n_class <= 2): dx = (relu_out
+// The class head behind a ReLU (classifier(conv_layer2(...)), models/networks.py:1351-1355; n_class <= 2): dx = (relu_out
 // > 0) * (W^T (*) dlogits) [N][H][W][32] -- dh_head_dgrad3x3_relu from the zero-bordered pair map dlp (dh_head_dlogits_pack) --
 // AND the head's own weight / bias gradient dw [n_class][32][3][3] / db [n_class] ((+)= when accumulate) from the same loads
-// of relu_out, which is the head's input (head_bn_bwd_kernel<2, true>).  workspace: dh_head_bn_bwd_workspace_size(N, H, W, 1).
-extern "C" int dh_head_relu_bwd(const void* dlp, const float* w_oihw, int NC, const void* relu_out, void* dx, float* dw, float* db,
-                                int accumulate, int N, int H, int W, void* workspace, void* stream) {
+// of relu_out, which is the head's input (head_bn_bwd_kernel<T, 2, true>).  workspace: dh_head_bn_bwd_workspace_size(N, H, W, 1).
+extern "C" int dh_head_relu_bwd(int dtype, const void* dlp, const float* w_oihw, int NC, const void* relu_out, void* dx, float* dw,
+                                float* db, int accumulate, int N, int H, int W, void* workspace, void* stream) {
     DH_REQUIRE(NC >= 1 && NC <= 2 && dlp && relu_out && dx && dw && db && workspace, "head_relu_bwd: bad arguments (n_class=%d)", NC);
-    DH_REQUIRE((long)N * H * W * 64 < (1L << 31), "head_relu_bwd: %d x %d x %d pixels x 64 bytes do not fit a 2 GiB buffer descriptor", N, H, W);
+    DH_REQUIRE((long)N * H * W * 128 < (1L << 31), "head_relu_bwd: %d x %d x %d pixels x 128 bytes do not fit a 2 GiB buffer descriptor", N, H, W);
     const int grid = dh_head_bn_bwd_blocks(N, H, W, 1);
     float* wpartial = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL((head_bn_bwd_kernel<2, true>), dim3(grid), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
-                       (const bf16*)relu_out, (const float*)nullptr, (const float*)nullptr, 1, (float*)nullptr, (const float*)nullptr,
-                       (bf16*)dx, wpartial);
+    if (dtype == DH_DTYPE_BF16)
+        hipLaunchKernelGGL((head_bn_bwd_kernel<bf16, 2, true>), dim3(grid), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
+                           (const bf16*)relu_out, (const float*)nullptr, (const float*)nullptr, 1, (float*)nullptr, (const float*)nullptr,
+                           (bf16*)dx, wpartial);
+    else
+        hipLaunchKernelGGL((head_bn_bwd_kernel<float, 2, true>), dim3(grid), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
+                           (const float*)relu_out, (const float*)nullptr, (const float*)nullptr, 1, (float*)nullptr, (const float*)nullptr,
+                           (float*)dx, wpartial);
     hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(HB_WCOLS), dim3(256), 0, ST(stream), (const float*)nullptr, grid, 1,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr,
                        (float*)nullptr, accumulate, wpartial, NC, dw, db, 0);

@@ -986,14 +986,16 @@ class Engine:
                 # n_class (2..5) real channels: keep dlogits at ONE 16-byte piece per pixel instead of padding them to
                 # a 32-channel K-chunk (4x the bytes, written and read twice), and take the data gradient with the
                 # dedicated head kernel instead of an MFMA convolution over 94 % zeros
-                if head_bn is not None and self.fused_head_bn and self.dtype == torch.bfloat16 and ncls <= 2 and \
-                        self.g[wkey].is_contiguous():
+                # bf16, or the fp32 pipeline in its split-product mode (three bf16 products: NOT the exact fp32 mode)
+                fuse = self.fused_head_bn and ncls <= 2 and self.g[wkey].is_contiguous() and \
+                    (self.dtype == torch.bfloat16 or (self.dtype == torch.float32 and ops.get_f32_mma_mode() != 0))
+                if head_bn is not None and fuse:
                     # data gradient, weight and bias gradient of this convolution: all inside the BatchNorm backward behind it
-                    return HeadGrad(ops.head_dlogits_pack(dl_nchw), self.p[wkey], ncls, self.g[wkey], self.g[bkey])
-                if relu_out is not None and self.fused_head_bn and self.dtype == torch.bfloat16 and ncls <= 2 and \
-                        self.g[wkey].is_contiguous() and relu_out is h:
+                    return HeadGrad(ops.head_dlogits_pack(dl_nchw, self.dtype), self.p[wkey], ncls, self.g[wkey], self.g[bkey])
+                if relu_out is not None and fuse and relu_out is h:
                     # the head behind a ReLU: data gradient (masked) + weight / bias gradient in one pass over the head's input
-                    return ops.head_relu_bwd(ops.head_dlogits_pack(dl_nchw), self.p[wkey], ncls, h, self.g[wkey], self.g[bkey])
+                    return ops.head_relu_bwd(ops.head_dlogits_pack(dl_nchw, self.dtype), self.p[wkey], ncls, h, self.g[wkey],
+                                             self.g[bkey])
                 dl = ops.nchw_to_nhwc(dl_nchw, self.dtype, cpad=small)
                 ops.conv2d_wgrad(h, dl, self.g[wkey], 3, 1, 1, accumulate=True, use_tr=self.use_tr, cout_real=ncls)
                 tmp = torch.empty(small, dtype=torch.float32, device=h.device)

@@ -1050,43 +1050,50 @@ def head_dgrad3x3_bn(dy, w_oihw, ncls, y, scale, shift, mean, invstd, groups):
     return g, partial
 
 
-def head_dlogits_pack(dl_nchw):
-    """dlogits [N, ncls <= 2, H, W] fp32 -> [N, H + 2, W + 2] bf16 pairs (int32) inside a border of zeros, for head_bn_bwd"""
+def head_dlogits_pack(dl_nchw, dtype=torch.bfloat16):
+    """dlogits [N, ncls <= 2, H, W] fp32 -> [N, H + 2, W + 2] bf16 pairs (int32) inside a border of zeros, for head_bn_bwd /
+    head_relu_bwd; dtype float32 (the bf16x3 mode): [N, H + 2, W + 2, 2], the pairs of bf16 heads and of bf16 remainders"""
     N, C, H, W = dl_nchw.shape
     assert C <= 2 and dl_nchw.dtype == torch.float32
-    dlp = torch.empty(N, H + 2, W + 2, dtype=torch.int32, device=dl_nchw.device)
-    _call("dh_head_dlogits_pack", P(dl_nchw), _ci(N), _ci(C), _ci(H), _ci(W), P(dlp), S())
+    shape = (N, H + 2, W + 2) if dtype == torch.bfloat16 else (N, H + 2, W + 2, 2)
+    dlp = torch.empty(shape, dtype=torch.int32, device=dl_nchw.device)
+    _call("dh_head_dlogits_pack", _ci(_DT[dtype]), P(dl_nchw), _ci(N), _ci(C), _ci(H), _ci(W), P(dlp), S())
     return dlp
+
+
+def _head_dlp_ok(dlp, y):
+    N, H, W, C = y.shape
+    want = (N, H + 2, W + 2) if y.dtype == torch.bfloat16 else (N, H + 2, W + 2, 2)
+    return dlp.dtype == torch.int32 and tuple(dlp.shape) == want and C == 32 and y.dtype in (torch.bfloat16, torch.float32)
 
 
 def head_bn_bwd(dlp, w_oihw, ncls, y, scale, shift, mean, invstd, gamma, dgamma, dbeta, groups, accumulate=True, dw=None, db=None):
     """class head's data gradient + the backward of the BatchNorm + ReLU behind it without the gradient tensor in between
-    (dh_head_bn_bwd): dlp = head_dlogits_pack(dlogits) -> the gradient of the pre-BatchNorm activation y [N,H,W,32] bf16.
-    dw [ncls,32,3,3] / db [ncls]: the head convolution's own weight / bias gradient from the same pass"""
+    (dh_head_bn_bwd): dlp = head_dlogits_pack(dlogits, y.dtype) -> the gradient of the pre-BatchNorm activation y [N,H,W,32].
+    dw [ncls,32,3,3] / db [ncls]: the head convolution's own weight / bias gradient from the same pass.  y fp32: the bf16x3
+    mode's arithmetic (three split bf16 products) -- not for the exact fp32 mode"""
     assert (dw is None) == (db is None) and (dw is None or (dw.shape == (ncls, 32, 3, 3) and dw.is_contiguous()))
     N, H, W, _ = y.shape
-    assert w_oihw.shape == (ncls, 32, 3, 3) and dlp.dtype == torch.int32 and dlp.shape == (N, H + 2, W + 2) and ncls <= 2 and \
-        y.shape[-1] == 32 and y.dtype == torch.bfloat16
-    dl = dlp
+    assert w_oihw.shape == (ncls, 32, 3, 3) and ncls <= 2 and _head_dlp_ok(dlp, y)
     dx = torch.empty_like(y)
-    ws = workspace(_lib.lib().dh_head_bn_bwd_workspace_size(N, H, W, groups), dl.device)
+    ws = workspace(_lib.lib().dh_head_bn_bwd_workspace_size(N, H, W, groups), y.device)
     with _Prof("bn_bwd", 0, _nb(y, y, dx)):
-        _call("dh_head_bn_bwd", P(dl), P(w_oihw), _ci(ncls), P(y), P(scale), P(shift), P(mean), P(invstd), P(gamma), _ci(groups),
-              P(dx), P(dgamma), P(dbeta), P(dw), P(db), _ci(1 if accumulate else 0), _ci(N), _ci(H), _ci(W), P(ws), S())
+        _call("dh_head_bn_bwd", _ci(dt(y)), P(dlp), P(w_oihw), _ci(ncls), P(y), P(scale), P(shift), P(mean), P(invstd), P(gamma),
+              _ci(groups), P(dx), P(dgamma), P(dbeta), P(dw), P(db), _ci(1 if accumulate else 0), _ci(N), _ci(H), _ci(W), P(ws), S())
     return dx
 
 
 def head_relu_bwd(dlp, w_oihw, ncls, relu_out, dw, db, accumulate=True):
     """class head behind a ReLU: data gradient (masked by relu_out > 0) + the head's weight / bias gradient in one pass over
-    relu_out [N,H,W,32] bf16 (dh_head_relu_bwd); dlp = head_dlogits_pack(dlogits)"""
+    relu_out [N,H,W,32] (dh_head_relu_bwd); dlp = head_dlogits_pack(dlogits, relu_out.dtype)"""
     N, H, W, C = relu_out.shape
-    assert w_oihw.shape == (ncls, 32, 3, 3) and dlp.dtype == torch.int32 and dlp.shape == (N, H + 2, W + 2) and ncls <= 2 and \
-        C == 32 and relu_out.dtype == torch.bfloat16 and dw.shape == (ncls, 32, 3, 3) and dw.is_contiguous()
+    assert w_oihw.shape == (ncls, 32, 3, 3) and ncls <= 2 and _head_dlp_ok(dlp, relu_out) and dw.shape == (ncls, 32, 3, 3) and \
+        dw.is_contiguous()
     dx = torch.empty_like(relu_out)
     ws = workspace(_lib.lib().dh_head_bn_bwd_workspace_size(N, H, W, 1), dlp.device)
     with _Prof("act_bwd", 0, _nb(relu_out, dx)):
-        _call("dh_head_relu_bwd", P(dlp), P(w_oihw), _ci(ncls), P(relu_out), P(dx), P(dw), P(db), _ci(1 if accumulate else 0),
-              _ci(N), _ci(H), _ci(W), P(ws), S())
+        _call("dh_head_relu_bwd", _ci(dt(relu_out)), P(dlp), P(w_oihw), _ci(ncls), P(relu_out), P(dx), P(dw), P(db),
+              _ci(1 if accumulate else 0), _ci(N), _ci(H), _ci(W), P(ws), S())
     return dx
 
 

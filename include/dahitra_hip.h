@@ -342,15 +342,17 @@ long dh_head_bn_bwd_workspace_size(int N, int H, int W, int groups);
 /* dw [n_class][32][3][3] / db [n_class] (both or NULL): the head convolution's own weight and bias gradient (input =
  * relu(BatchNorm(y)) as bf16), taken by pass 1 from the loads it makes anyway -- pixels are the K dimension of an MFMA through
  * wave-private LDS tiles read back transposed; (+)= when accumulate. */
-int dh_head_dlogits_pack(const float* dlogits_nchw, int N, int NC, int H, int W, void* dlp, void* stream);
-int dh_head_bn_bwd(const void* dlp, const float* w_oihw, int NC, const void* y, const float* mask_scale, const float* mask_shift,
+/* dtype DH_DTYPE_BF16: dlp one word per pixel; DH_DTYPE_F32 (the fp32 pipeline under dh_set_f32_mma_mode != 0): y / dx fp32, dlp two
+ * words per pixel (bf16 heads, bf16 remainders) and every product as the three split bf16 products of that mode. */
+int dh_head_dlogits_pack(int dtype, const float* dlogits_nchw, int N, int NC, int H, int W, void* dlp, void* stream);
+int dh_head_bn_bwd(int dtype, const void* dlp, const float* w_oihw, int NC, const void* y, const float* mask_scale, const float* mask_shift,
                    const float* mean, const float* invstd, const float* gamma, int groups, void* dx, float* dgamma, float* dbeta,
                    float* dw, float* db, int accumulate, int N, int H, int W, void* workspace, void* stream);
 /* The class head behind a ReLU (classifier(conv_layer2(...)), models/networks.py:1351-1355; bf16, n_class <= 2): the data gradient
  * dx = (relu_out > 0) * (W^T (*) dlogits) of dh_head_dgrad3x3_relu, from the pair map dlp (dh_head_dlogits_pack), AND the head's
  * own weight / bias gradient dw [n_class][32][3][3] / db [n_class] ((+)= when accumulate) from the same loads of relu_out --
  * the head's input.  workspace: dh_head_bn_bwd_workspace_size(N, H, W, 1) bytes. */
-int dh_head_relu_bwd(const void* dlp, const float* w_oihw, int NC, const void* relu_out, void* dx, float* dw, float* db,
+int dh_head_relu_bwd(int dtype, const void* dlp, const float* w_oihw, int NC, const void* relu_out, void* dx, float* dw, float* db,
                      int accumulate, int N, int H, int W, void* workspace, void* stream);
 int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream);
 int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, void* dst, int Cd, int dc0, int Cn, long P, void* stream);

@@ -667,12 +667,13 @@ def test_head_data_gradient_kernel(ops, dtype, ncls):
     dict(n=1, h=3, w=5, groups=1, ncls=1),           # fewer pixels than one wave round
     dict(n=8, h=128, w=128, groups=1, ncls=2),       # more 16-pixel groups than waves: the two-group rounds wrap
 ])
-def test_head_gradient_recomputed_inside_the_batchnorm_backward(ops, cfg):
+@pytest.mark.parametrize("dtype,mma", [pytest.param(torch.bfloat16, 0, id="bfloat16"), pytest.param(torch.float32, 1, id="bf16x3")])
+def test_head_gradient_recomputed_inside_the_batchnorm_backward(ops, cfg, dtype, mma):
     """dh_head_bn_bwd (the class head's data gradient formed by both passes of the BatchNorm + ReLU backward behind it, never
     written) against (a) torch autograd of conv2(relu(batch_norm(y))) in fp32 (models/help_funcs.py:7-15) and (b) the
-    three-kernel path dh_head_dgrad3x3 -> dh_bn_bwd, whose intermediate is rounded to bf16"""
+    three-kernel path dh_head_dgrad3x3 -> dh_bn_bwd, whose intermediate is rounded to bf16; fp32 tensors: the split-product
+    form (three bf16 products per matrix product, the bf16x3 mode's backward arithmetic) at the fp32 tolerance"""
     N, H, W, G, ncls = cfg["n"], cfg["h"], cfg["w"], cfg["groups"], cfg["ncls"]
-    dtype = torch.bfloat16
     y = rnd((N, 32, H, W), dtype, 2101, 1.5)
     w = rnd((ncls, 32, 3, 3), torch.float32, 2102, 0.1).requires_grad_(True)
     hb = torch.zeros(ncls, requires_grad=True)
@@ -699,9 +700,13 @@ def test_head_gradient_recomputed_inside_the_batchnorm_backward(ops, cfg):
     shift = beta.cuda()[None] - mean * scale
     mean, invstd, scale, shift = (t.contiguous() for t in (mean, invstd, scale, shift))
     dl = ops.nchw_to_nhwc(dlog.float().cuda().contiguous(), dtype, cpad=8)
-    dlp = ops.head_dlogits_pack(dlog.float().cuda().contiguous())
+    dlp = ops.head_dlogits_pack(dlog.float().cuda().contiguous(), dtype)
     assert int(dlp[:, 0].abs().max()) == 0 and int(dlp[:, :, -1].abs().max()) == 0          # the border of zeros
-    assert torch.equal(dlp[:, 1:-1, 1:-1].contiguous().view(torch.bfloat16).view(N, H, W, 2)[..., :ncls], dl[..., :ncls])
+    if dtype == torch.bfloat16:
+        assert torch.equal(dlp[:, 1:-1, 1:-1].contiguous().view(torch.bfloat16).view(N, H, W, 2)[..., :ncls], dl[..., :ncls])
+    else:       # heads + remainders = the fp32 values to 2^-17
+        pl = dlp[:, 1:-1, 1:-1].contiguous().view(torch.bfloat16).view(N, H, W, 2, 2).float().sum(3)
+        assert float((pl[..., :ncls] - dl[..., :ncls]).abs().max()) <= 2.0 ** -16 * float(dl.abs().max())
     dg1, db1 = torch.zeros(32, device="cuda"), torch.zeros(32, device="cuda")
     dx1 = ops.head_bn_bwd(dlp, w.cuda(), ncls, yd, scale, shift, mean, invstd, gamma.cuda(), dg1, db1, G, accumulate=False)
     close(nchw(dx1), yt.grad, dtype, "dx vs autograd", factor=2.0)
@@ -1626,25 +1631,28 @@ def test_head_data_gradient_with_the_relu_in_front_of_it_folded_in(ops):
 
 
 @pytest.mark.parametrize("cfg", [dict(n=3, h=64, w=48, ncls=2), dict(n=2, h=9, w=21, ncls=1), dict(n=8, h=128, w=128, ncls=2)])
-def test_head_behind_a_relu_data_weight_and_bias_gradient_in_one_pass(ops, cfg):
+@pytest.mark.parametrize("dtype,mma", [pytest.param(torch.bfloat16, 0, id="bfloat16"), pytest.param(torch.float32, 1, id="bf16x3")])
+def test_head_behind_a_relu_data_weight_and_bias_gradient_in_one_pass(ops, cfg, dtype, mma):
     """dh_head_relu_bwd against torch autograd of conv2d(relu_out, W, b) with the gradient masked by relu_out > 0
     (classifier(conv_layer2(...)), models/networks.py:1351-1355) and against the kernels it replaces"""
     N, H, W, ncls = cfg["n"], cfg["h"], cfg["w"], cfg["ncls"]
-    dtype = torch.bfloat16
     pre = rnd((N, 32, H, W), dtype, 1311).float().requires_grad_(True)
     w = rnd((ncls, 32, 3, 3), torch.float32, 1312, 0.1).requires_grad_(True)
     hb = torch.zeros(ncls, requires_grad=True)
     dlog = rnd((N, ncls, H, W), dtype, 1313)
     F.conv2d(torch.relu(pre), w, hb, 1, 1).backward(dlog.float())
     out = dev(nhwc(torch.relu(pre).detach()), dtype)
-    dlp = ops.head_dlogits_pack(dlog.float().cuda().contiguous())
+    dlp = ops.head_dlogits_pack(dlog.float().cuda().contiguous(), dtype)
     dw, db = torch.full((ncls, 32, 3, 3), 0.25, device="cuda"), torch.full((ncls,), 1.0, device="cuda")
     dx = ops.head_relu_bwd(dlp, w.detach().cuda(), ncls, out, dw, db, accumulate=True)
     close(nchw(dx), pre.grad, dtype, "dx vs autograd", factor=2.0)
     close(dw - 0.25, w.grad, dtype, "dw vs autograd", factor=2.0)
     close(db - 1.0, hb.grad, dtype, "db vs autograd", factor=2.0)
-    dl = ops.nchw_to_nhwc(dlog.float().cuda().contiguous(), dtype, cpad=8)
-    assert torch.equal(dx, ops.head_dgrad3x3(dl, w.detach().cuda(), ncls, relu_out=out))          # same products, same order
+    dl = ops.nchw_to_nhwc(dlog.float().cuda().contiguous(), dtype, cpad=8 if dtype == torch.bfloat16 else 4)
+    if dtype == torch.bfloat16:
+        assert torch.equal(dx, ops.head_dgrad3x3(dl, w.detach().cuda(), ncls, relu_out=out))      # same products, same order
+    else:
+        close(dx, ops.head_dgrad3x3(dl, w.detach().cuda(), ncls, relu_out=out).cpu(), dtype, "dx vs head_dgrad3x3", factor=1.0)
     dw0 = torch.zeros_like(dw)
     ops.conv2d_wgrad(out, dl, dw0, 3, 1, 1, accumulate=False, cout_real=ncls)
     dw1, db1 = torch.zeros_like(dw), torch.zeros_like(db)
