@@ -971,7 +971,7 @@ class Engine:
         ncls = self.shapes[wkey][0]
         ck = ops.chunk_channels(self.dtype)
         if self.pk[wkey].fwd.shape[-2] == 16 and self.fused_head_out:
-            out = ops.conv3x3_head(h, self.pk[wkey].fwd, ncls, self.p[bkey])         # fp32 NCHW logits from the conv itself
+            out = ops.conv3x3_head(h, self.pk[wkey].fwd, ncls, self.p[bkey], w_oihw=self.p[wkey])      # fp32 NCHW logits from the conv itself
         else:
             out = ops.nhwc_to_nchw(ops.conv2d(h, self.pk[wkey].fwd, ncls, 3, 1, 1, bias=self.p[bkey]))
         if not self.need_grad:

@@ -354,6 +354,15 @@ int dh_head_bn_bwd(int dtype, const void* dlp, const float* w_oihw, int NC, cons
  * the head's input.  workspace: dh_head_bn_bwd_workspace_size(N, H, W, 1) bytes. */
 int dh_head_relu_bwd(int dtype, const void* dlp, const float* w_oihw, int NC, const void* relu_out, void* dx, float* dw, float* db,
                      int accumulate, int N, int H, int W, void* workspace, void* stream);
+/* The class head's forward (nn.Conv2d(32, n_class, 3, padding=1): models/help_funcs.py:13-14, networks.py:1247 / 1355) for
+ * n_class <= 2 and bf16 activations: x [N][H][W][32] (pre-BatchNorm when in_scale / in_shift [in_groups][32] are given: the
+ * head's input is relu(x * scale + shift)), w_oihw [n_class][32][3][3] fp32, bias [n_class] or NULL -> logits [N][n_class][H][W]
+ * fp32.  The contraction over the input channels is done once per input pixel for all nine taps (M = (tap, class) = 18), the
+ * convolution is a nine-term gather from a ring of rows in LDS: no halo, no padded output channels.  dh_head_fwd_supported:
+ * whether (n_class, W) is this kernel's shape (else dh_conv3x3_head_fwd). */
+int dh_head_fwd_supported(int NC, int W);
+int dh_head_fwd(const void* x, const float* w_oihw, const float* bias, int NC, const float* in_scale, const float* in_shift,
+                int in_groups, float* logits_nchw, int N, int H, int W, void* stream);
 int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream);
 int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, void* dst, int Cd, int dc0, int Cn, long P, void* stream);
 /* torch.cat([x1, x2], 1) of the two temporal streams (models/networks.py:1309, 1344), which are the two batch halves of

@@ -324,6 +324,35 @@ def test_class_head_writes_nchw_logits_itself(ops, dtype, mma, ncls, hw, lazy):
     close(got, two.cpu(), dtype, "head vs conv + layout pass", factor=0.5)
 
 
+@pytest.mark.parametrize("lazy", [False, True])
+@pytest.mark.parametrize("cfg", [dict(n=2, h=20, w=36, ncls=2), dict(n=4, h=7, w=23, ncls=1), dict(n=2, h=1, w=5, ncls=2),
+                                 dict(n=6, h=256, w=256, ncls=2), dict(n=2, h=33, w=270, ncls=2)])
+def test_class_head_forward_as_one_product_per_input_pixel(ops, cfg, lazy):
+    """dh_head_fwd (P[pixel][tap][class] by one MFMA per 16 input pixels, the convolution as a nine-term gather from LDS rows)
+    against F.conv2d in fp32 (models/help_funcs.py:13-14) and against dh_conv3x3_head_fwd, plain and with BatchNorm + ReLU on
+    load (two statistics groups); ragged 16-pixel groups, strips of several rows per workgroup, fewer rows than a strip"""
+    N, H, W, ncls = cfg["n"], cfg["h"], cfg["w"], cfg["ncls"]
+    dtype = torch.bfloat16
+    assert ops._lib.lib().dh_head_fwd_supported(ncls, W) and not ops._lib.lib().dh_head_fwd_supported(3, W) \
+        and not ops._lib.lib().dh_head_fwd_supported(2, 2048)
+    x = rnd((N, 32, H, W), dtype, 2201)
+    w = rnd((ncls, 32, 3, 3), torch.float32, 2202, scale=288 ** -0.5)
+    b = rnd((ncls,), torch.float32, 2203)
+    xd = dev(nhwc(x), dtype)
+    wp, _ = ops.pack_weight(w.cuda(), dtype, want_dgrad=False)
+    src, ref_in = xd, x
+    if lazy:
+        sc, sh = (rnd((2, 32), torch.float32, 2204).abs() + 0.5).cuda(), rnd((2, 32), torch.float32, 2205).cuda()
+        src = ops.BnInput(xd, sc, sh, 2)
+        g = torch.arange(N) // (N // 2)
+        ref_in = F.relu(x * sc.cpu()[g][:, :, None, None] + sh.cpu()[g][:, :, None, None]).to(dtype).float()
+    got = ops.conv3x3_head(src, wp, ncls, b.cuda(), w_oihw=w.cuda())
+    assert got.dtype == torch.float32 and tuple(got.shape) == (N, ncls, H, W)
+    close(got, F.conv2d(ref_in, w.to(dtype).float(), b, 1, 1), dtype, "class head vs conv2d", factor=0.25)
+    old = ops.conv3x3_head(src, wp, ncls, b.cuda())
+    close(got, old.cpu(), dtype, "class head vs the tile convolution", factor=0.01)      # same bf16 operands, fp32 sums re-ordered
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_weight_repack_of_a_step_equals_the_permutation_it_states(ops, dtype):
     """ops.PackPlan (dh_pack_weights_multi, one launch per step for every layer): forward form [tap][OPad][I] = w[o][ci][tap],
