@@ -560,18 +560,18 @@ HEAD_FWD = os.environ.get("DAHITRA_NO_HEAD_FWD", "0") != "1"
 def conv3x3_head(x, wp, ncls, bias, w_oihw=None):
     """the class head: 3x3 / pad 1 convolution to `ncls` (<= 16) channels, fp32 NCHW logits written by the kernel itself.
     x may be a BnInput (BatchNorm-apply + ReLU on load).  With the fp32 master weights w_oihw [ncls, 32, 3, 3] at hand, bf16
-    activations of 32 channels and ncls <= 2 go to dh_head_fwd (one MFMA per input pixel group for all nine taps, no halo)."""
+    activations (or fp32 ones under f32_mma_mode 3) of 32 channels and ncls <= 2 go to dh_head_fwd (one MFMA per input pixel group for all nine taps, no halo)."""
     bn_in = x if isinstance(x, BnInput) else None
     if bn_in is not None:
         x = bn_in.y
     N, H, W, Cin = x.shape
     assert wp.shape[-2] == 16 and ncls <= 16
     out = torch.empty(N, ncls, H, W, dtype=torch.float32, device=x.device)
-    if HEAD_FWD and w_oihw is not None and x.dtype == torch.bfloat16 and Cin == 32 and N * H * W * 64 < 2 ** 31 and \
-            _lib.lib().dh_head_fwd_supported(ncls, W):
+    if HEAD_FWD and w_oihw is not None and Cin == 32 and N * H * W * 128 < 2 ** 31 and _lib.lib().dh_head_fwd_supported(ncls, W) and \
+            (x.dtype == torch.bfloat16 or (x.dtype == torch.float32 and get_f32_mma_mode() == 3)):
         assert w_oihw.shape == (ncls, 32, 3, 3) and w_oihw.dtype == torch.float32
         with _Prof("head_fwd", 2.0 * N * H * W * ncls * Cin * 9, _nb(x, out)):
-            _call("dh_head_fwd", P(x), P(w_oihw), P(bias), _ci(ncls), *_bn_in_args(bn_in), P(out), _ci(N), _ci(H), _ci(W), S())
+            _call("dh_head_fwd", _ci(dt(x)), P(x), P(w_oihw), P(bias), _ci(ncls), *_bn_in_args(bn_in), P(out), _ci(N), _ci(H), _ci(W), S())
         return out
     key = "conv_mfma<%s,ks3,s1,nt16>" % ("bf16" if x.dtype == torch.bfloat16 else "f32")
     with _Prof(key, 2.0 * N * H * W * ncls * Cin * 9, _nb(x, out, wp)):

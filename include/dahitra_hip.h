@@ -361,7 +361,9 @@ int dh_head_relu_bwd(int dtype, const void* dlp, const float* w_oihw, int NC, co
  * convolution is a nine-term gather from a ring of rows in LDS: no halo, no padded output channels.  dh_head_fwd_supported:
  * whether (n_class, W) is this kernel's shape (else dh_conv3x3_head_fwd). */
 int dh_head_fwd_supported(int NC, int W);
-int dh_head_fwd(const void* x, const float* w_oihw, const float* bias, int NC, const float* in_scale, const float* in_shift,
+/* dtype DH_DTYPE_F32: x fp32 and every product as three fp16-plane products -- the arithmetic of dh_set_f32_mma_mode(3), for
+ * callers in that mode only. */
+int dh_head_fwd(int dtype, const void* x, const float* w_oihw, const float* bias, int NC, const float* in_scale, const float* in_shift,
                 int in_groups, float* logits_nchw, int N, int H, int W, void* stream);
 int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream);
 int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, void* dst, int Cd, int dc0, int Cn, long P, void* stream);
