@@ -1,5 +1,6 @@
-"""usage (GPU box): python3 tools/head_bwd_bench.py  -- ops.head_bn_bwd at the bench size (32 x 256 x 256 pixels, 32 channels), each call
-after a 512 MB fill that evicts y from the infinity cache: total time of its launches per DAHITRA_HB_CFG (set by the caller)."""
+"""usage (GPU box): [DAHITRA_HB_GRID1=.. DAHITRA_HB_GRID2=..] python3 tools/head_bwd_bench.py  -- ops.head_bn_bwd at the bench size
+(32 x 256 x 256 pixels, 32 channels), each call after a 512 MB fill that evicts y from the infinity cache: total time of its
+three launches (events; with and without the head's weight gradient) for the workgroup counts of pass 1 / pass 2 in the environment."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dahitra_amd import ops
@@ -28,4 +29,4 @@ for wg in (True, False):
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) * 1e3)
     ts = sorted(ts[2:])
-    print("cfg %s wgrad %d: median %.1f us, min %.1f us" % (os.environ.get("DAHITRA_HB_CFG", "-"), wg, ts[len(ts) // 2], ts[0]))
+    print("grids %s / %s wgrad %d: median %.1f us, min %.1f us" % (os.environ.get("DAHITRA_HB_GRID1", "512"), os.environ.get("DAHITRA_HB_GRID2", "2048"), wg, ts[len(ts) // 2], ts[0]))
