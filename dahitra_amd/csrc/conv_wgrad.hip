@@ -1101,11 +1101,170 @@ int launch(const WgArgs& a, bool tr, hipStream_t st) {
     return launch_ct<T, KS, STRIDE, IT, DIL, 64>(a, tr, st);
 }
 
+// ---- 1x1 / stride 1, bf16, large layers: a workgroup owns a CT x IT block of dW (256 x 128 and its relatives) -----------------
+// dW[co][ci] = sum over pixels of dY[p][co] X[p][ci] streams both tensors once per (co tile, ci tile) PAIR: with the 64 x 64
+// slabs of wg_body the 1024 x 256 layers of a ResNet-50 trunk are 64 pairs -- 2.1 GB of operand reads for a 335 MB operand
+// pair, 333 us per launch at the 1024 x 1024 bench size, HBM-bound.  Here the four waves of a workgroup are a 2 x 2 grid over a
+// block CT x IT = 256 x 128 / 128 x 256 / 256 x 64 / 64 x 256 (32 accumulator tiles per wave at most): 8 pairs for that layer.
+// Pixels are flat (p = ((n H) + y) W + x: a 1x1 stride-1 layer has no halo), 64 per stage: the next stage's 16-byte pieces are
+// requested into registers before the MFMAs of this one and committed to LDS after them (pitches odd multiples of 32 bytes,
+// fragments by ds_read_b64_tr_b16 as in wg_body); same partial-slab layout [splitk][Cout][Cin], same reduce.
+struct W1Args {
+    const bf16* x;
+    const bf16* dy;
+    float* part;
+    long P;                   // pixels
+    int Cin, CinPitch, Cout, CoutUse, splitk, ci_tiles, no_xcd_remap;
+};
+constexpr int W1_PS = 64;     // pixels per stage
+
+template <int CT, int IT>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(W1Args p) {
+    constexpr int DP = lds_pitch(CT * 2), XP = lds_pitch(IT * 2);
+    constexpr int DQ = CT * 2 / 16, XQ = IT * 2 / 16;                   // 16-byte pieces per pixel
+    constexpr int ND = W1_PS * DQ / 256, NX = W1_PS * XQ / 256;         // pieces per thread and stage
+    constexpr int NA = CT / 32, NB = IT / 32;                           // 16-wide sub-tiles per wave (2 x 2 waves)
+    static_assert(ND >= 1 && NX >= 1 && NA * NB <= 32, "block shape");
+    __shared__ __attribute__((aligned(16))) unsigned char dyt[W1_PS * DP];
+    __shared__ __attribute__((aligned(16))) unsigned char xt[W1_PS * XP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
+    // Workgroups are dispatched x-fastest, round-robin over the 8 XCDs (one L2 each): remapped so that all blocks of one pixel
+    // split -- they read the same dY / X stages at about the same time -- run on ONE XCD, whose L2 then serves the re-reads
+    int bx = blockIdx.x, kz = blockIdx.y;
+    if (gridDim.x > 1 && (gridDim.y & 7) == 0 && !p.no_xcd_remap) {
+        const unsigned lin = (unsigned)(kz * gridDim.x + bx), xcd = lin & 7, sq = lin >> 3;
+        bx = (int)(sq % gridDim.x);
+        kz = (int)((sq / gridDim.x) * 8 + xcd);
+    }
+    const int cot = bx / p.ci_tiles, cit = bx - cot * p.ci_tiles;
+    const int co0 = cot * CT, ci0 = cit * IT;
+    const int cow = (wv >> 1) * (CT / 2), ciw = (wv & 1) * (IT / 2);    // this wave's corner inside the block
+    f32x4 acc[NA][NB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this thread's pieces of a stage: pixel row and channel piece, fixed for the launch
+    const int dq = tid % DQ, dpx = tid / DQ, xq = tid % XQ, xpx = tid / XQ;            // piece i: pixel dpx + i * (256 / DQ)
+    const bool dch = co0 + dq * 8 < p.Cout, xch = ci0 + xq * 8 < p.Cin;
+    const long nchunk = (p.P + W1_PS - 1) / W1_PS;
+    uint4 rd[ND], rx[NX];
+    auto fetch = [&](long chunk) {
+        const long p0 = chunk * W1_PS;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const long px = p0 + dpx + i * (256 / DQ);
+            const bool ok = dch && px < p.P;
+            const uint4 v = *reinterpret_cast<const uint4*>(p.dy + (ok ? px * p.Cout + co0 + dq * 8 : 0));
+            rd[i] = ok ? v : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const long px = p0 + xpx + i * (256 / XQ);
+            const bool ok = xch && px < p.P;
+            const uint4 v = *reinterpret_cast<const uint4*>(p.x + (ok ? px * p.CinPitch + ci0 + xq * 8 : 0));
+            rx[i] = ok ? v : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) *reinterpret_cast<uint4*>(dyt + (dpx + i * (256 / DQ)) * DP + dq * 16) = rd[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) *reinterpret_cast<uint4*>(xt + (xpx + i * (256 / XQ)) * XP + xq * 16) = rx[i];
+    };
+    // fragment of 32 pixels (k) x 16 channels: lane (pl, g) supplies pixels 4 g .. 4 g + 3 and 16 + 4 g .. + 3 (wg_body's form)
+    const unsigned char* a_base = dyt + (4 * g + (pl >> 2)) * DP + (cow + (pl & 3) * 4) * 2;
+    const unsigned char* b_base = xt + (4 * g + (pl >> 2)) * XP + (ciw + (pl & 3) * 4) * 2;
+    auto frag = [&](const unsigned char* base, int pitch, int kk, int ch) {
+        F8 f;
+        f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + kk * pitch + ch * 2));
+        f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + (kk + 16) * pitch + ch * 2));
+        return f;
+    };
+    long chunk = kz;
+    if (chunk < nchunk) fetch(chunk);
+    for (; chunk < nchunk; chunk += p.splitk) {
+        commit();
+        __syncthreads();
+        if (chunk + p.splitk < nchunk) fetch(chunk + p.splitk);
+#pragma unroll
+        for (int kk = 0; kk < W1_PS; kk += 32) {
+            F8 bf[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bf[b] = frag(b_base, XP, kk, b * 16);
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const F8 af = frag(a_base, DP, kk, a * 16);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf[b].v, acc[a][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // partial slab [kz][Cout][Cin]: lane (pl, g) holds rows co = 4 g + j of column ci = pl of every sub-tile
+    float* out = p.part + (size_t)kz * p.Cout * p.Cin;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int ci = ci0 + ciw + b * 16 + pl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + cow + a * 16 + 4 * g + j;
+                if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Cin + ci] = acc[a][b][j];
+            }
+        }
+}
+
+// block shape by operand traffic: dY is read once per ci tile, X once per co tile
+static inline void w1_pick(long Cout, long Cin, int& ct, int& it) {
+    const int cand[4][2] = {{256, 128}, {128, 256}, {256, 64}, {64, 256}};
+    double best = 1e30;
+    for (auto& c : cand) {
+        const double t = (double)Cout * dh_cdiv((int)Cin, c[1]) + (double)Cin * dh_cdiv((int)Cout, c[0]) +
+                         0.25 * ((double)dh_cdiv((int)Cout, c[0]) * c[0] - Cout + (double)dh_cdiv((int)Cin, c[1]) * c[1] - Cin);
+        if (t < best) { best = t; ct = c[0]; it = c[1]; }
+    }
+}
+static inline bool w1_shape(int Cin, int Cout, int ks) {
+    static const bool on = getenv("DAHITRA_WGRAD_1X1_BIG") ? atoi(getenv("DAHITRA_WGRAD_1X1_BIG")) != 0 : true;
+    return on && ks == 1 && Cin % 8 == 0 && Cout % 8 == 0 && (long)Cin * Cout >= 128 * 128 && (Cin >= 256 || Cout >= 256);
+}
+static inline bool w1_eligible(const WgArgs& a, int ks, int stride, bool bf16_, bool tr) {
+    return bf16_ && tr && stride == 1 && w1_shape(a.Cin, a.Cout, ks) && a.groups == 1 && !a.in_scale && !a.x_split && !a.direct &&
+           !a.dyt_y && !a.phase_mode && a.CoutUse == a.Cout && a.CinPitch % 8 == 0 && a.H == a.OH && a.W == a.OW && a.pad == 0 &&
+           a.npix == a.OH * a.OW && a.in_npix == a.H * a.W;
+}
+static int launch_w1(const WgArgs& a, hipStream_t st) {
+    int ct = 256, it = 128;
+    w1_pick(a.Cout, a.Cin, ct, it);
+    W1Args w;
+    w.x = reinterpret_cast<const bf16*>(a.x); w.dy = reinterpret_cast<const bf16*>(a.dy); w.part = a.part;
+    w.P = (long)a.N * a.H * a.W; w.Cin = a.Cin; w.CinPitch = a.CinPitch; w.Cout = a.Cout; w.CoutUse = a.CoutUse;
+    w.splitk = a.splitk; w.ci_tiles = dh_cdiv(a.Cin, it); w.no_xcd_remap = a.no_xcd_remap;
+    dim3 grid(dh_cdiv(a.Cout, ct) * w.ci_tiles, a.splitk);
+    if (ct == 256 && it == 128) hipLaunchKernelGGL((wgrad1x1_kernel<256, 128>), grid, dim3(256), 0, st, w);
+    else if (ct == 128) hipLaunchKernelGGL((wgrad1x1_kernel<128, 256>), grid, dim3(256), 0, st, w);
+    else if (it == 64) hipLaunchKernelGGL((wgrad1x1_kernel<256, 64>), grid, dim3(256), 0, st, w);
+    else hipLaunchKernelGGL((wgrad1x1_kernel<64, 256>), grid, dim3(256), 0, st, w);
+    DH_CHECK_LAUNCH("conv_wgrad 1x1");
+    return 0;
+}
+
+// 1x1 layers with >= 128 input channels and a 64-wide co tile: the 512-thread form, 64co x 128ci per workgroup (CIG = 2 on the
+// 64-wide ci tile) -- the dY slice of a co tile is staged once for 128 input channels instead of twice.  The Bottleneck layers of
+// the ResNet-50 trunk (1024 x 256 at 128 x 128 x 8 pixels: 16 x 4 tile pairs re-read a 335 MB operand pair)
+static inline bool wide_ci1x1(int Cin, int CoutUse, int ks) {
+    static const bool on = getenv("DAHITRA_WGRAD_1X1_CIG2") ? atoi(getenv("DAHITRA_WGRAD_1X1_CIG2")) != 0 : true;
+    return on && ks == 1 && Cin >= 128 && Cin % 128 == 0 && co_tile(CoutUse) == 64;
+}
 template <typename T>
 int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
     const bool wide = a.Cin > 32 && ks == 1 && stride == 1;   // 64-wide ci tiles only where accumulators / LDS fit
-    const int it = ks == 4 ? 16 : ((wide || (stride == 1 && wide_ci3x3(a.Cin, a.CoutUse, ks))) ? 64 : 32);
+    const bool wide2 = wide && wide_ci1x1(a.Cin, a.CoutUse, ks);
+    const int it = ks == 4 ? 16 : (wide2 ? 128 : ((wide || (stride == 1 && wide_ci3x3(a.Cin, a.CoutUse, ks))) ? 64 : 32));
     a.ci_tiles = dh_cdiv(a.Cin, it);
+    if (w1_eligible(a, ks, stride, std::is_same<T, bf16>::value, tr)) return launch_w1(a, st);
     if (ws_eligible(a, ks, stride, sizeof(T) == 2, tr) && wide_ci3x3(a.Cin, a.CoutUse, ks)) {
         if (g_wsb.on && a.dil == 1 && !a.direct) return ws_batch_add(a, st);
         return a.dil == 2 ? launch_ws<2>(a, st) : launch_ws<1>(a, st);
@@ -1114,6 +1273,7 @@ int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
     if (g_wsb.on && c32_batch_on() && c32_eligible(a, ks, stride, sizeof(T) == 2, tr)) return c32_batch_add(a, st);
     if (ks == 3 && stride == 1) return launch<T, 3, 1, 32>(a, tr, st);
     if (ks == 3 && stride == 2) return launch<T, 3, 2, 32>(a, tr, st);
+    if (ks == 1 && stride == 1 && wide2) return launch_ct<T, 1, 1, 64, 1, 64, 2>(a, tr, st);
     if (ks == 1 && stride == 1) return wide ? launch<T, 1, 1, 64>(a, tr, st) : launch<T, 1, 1, 32>(a, tr, st);
     if (ks == 1 && stride == 2) return launch<T, 1, 2, 32>(a, tr, st);
     if (ks == 4 && stride == 1) return launch<T, 4, 1, 16>(a, tr, st);     // space-to-depth stem (12 real channels)
@@ -1138,12 +1298,20 @@ extern "C" int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, 
     // NOTE: stride is not known here; the 64-wide ci tile is only used at stride 1, where this
     // estimate is exact; at stride 2 it under-estimates the slab count (harmless: more workgroups)
     const bool big = wide_ci3x3(Cin, Cout, ks);       // 512-thread workgroups, one per CU
-    const int it = ks == 4 ? 16 : (((Cin > 32 && ks == 1) || big) ? 64 : 32);
-    const long slabs = (long)dh_cdiv(Cout, co_tile(Cout)) * dh_cdiv(Cin, it) * (groups > 0 ? groups : 1);
+    const int it = ks == 4 ? 16 : (wide_ci1x1(Cin, Cout, ks) ? 128 : (((Cin > 32 && ks == 1) || big) ? 64 : 32));
+    long slabs = (long)dh_cdiv(Cout, co_tile(Cout)) * dh_cdiv(Cin, it) * (groups > 0 ? groups : 1);
+    bool w1 = false;
+    if (groups <= 1 && w1_shape(Cin, Cout, ks)) {      // (dtype / stride unknown here: a launch that takes another kernel just gets fewer, fatter slabs)
+        int ct = 256, it1 = 128;
+        w1_pick(Cout, Cin, ct, it1);
+        slabs = (long)dh_cdiv(Cout, ct) * dh_cdiv(Cin, it1);
+        w1 = true;
+    }
     // workgroups in flight: the 3x3 / 4x4 kernels hold two workgroups per CU (168+ registers per lane), so 512 fill the
     // chip in ONE round -- a second round only doubles the partial-slab traffic and the per-workgroup prologue / slab
     // write (measured: layer3 115.6 -> 107.6 us, classifier 75.7 -> 65.1 us); the light 1x1 kernels fit four per CU
-    const long target = ks == 1 ? 1024 : (big ? 256 : 512);
+    static const long w1_target = getenv("DAHITRA_W1_TARGET") ? atol(getenv("DAHITRA_W1_TARGET")) : 512;
+    const long target = w1 ? w1_target : (ks == 1 ? 1024 : (big ? 256 : 512));
     long sk = (target + slabs - 1) / slabs;      // ... however small Cout x Cin is ...
     if (sk > tiles / 8) sk = tiles / 8;        // ... but at least 8 pixel tiles per workgroup (slab write amortised)
     if (sk > 1024) sk = 1024;

@@ -899,6 +899,41 @@ def test_conv2d_dgrad_wgrad_bench_scale(ops, dtype, mma, cfg):
     assert torch.equal(dw3, dw - 0.5) or float((dw3 - (dw - 0.5)).abs().max()) <= 1e-6 * gscale
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(cin=64, cout=256, n=2, h=24, w=20),        # 256 x 64 block, 960 pixels = 15 stages
+    dict(cin=256, cout=64, n=2, h=24, w=20),        # 64 x 256
+    dict(cin=128, cout=512, n=3, h=13, w=11),       # 256 x 128, two co tiles; 429 pixels: a ragged last stage
+    dict(cin=512, cout=128, n=3, h=13, w=11),       # 128 x 256
+    dict(cin=256, cout=1024, n=8, h=32, w=32),      # 4 x 2 blocks, split-K over 128 stages
+    dict(cin=1024, cout=256, n=8, h=32, w=32),
+    dict(cin=264, cout=136, n=2, h=16, w=16),       # channel counts that are multiples of 8 only: ragged blocks both ways
+])
+def test_weight_gradient_of_wide_1x1_layers_in_256_by_128_blocks(ops, cfg):
+    """dh_conv2d_wgrad for the bf16 1x1 / stride-1 layers of a Bottleneck (models/resnet.py:76-122) -- wgrad1x1_kernel, a CT x IT
+    block of dW per workgroup over flat pixels -- against autograd of F.conv2d in fp32: direct (+)= / (=) and deferred"""
+    dtype = torch.bfloat16
+    N, H, W, Cin, Cout = cfg["n"], cfg["h"], cfg["w"], cfg["cin"], cfg["cout"]
+    x = rnd((N, Cin, H, W), dtype, 2301)
+    w = rnd((Cout, Cin, 1, 1), dtype, 2302, scale=Cin ** -0.5).requires_grad_(True)
+    y = F.conv2d(x, w)
+    dy = rnd(tuple(y.shape), dtype, 2303)
+    y.backward(dy)
+    xd, dyd = dev(nhwc(x), dtype), dev(nhwc(dy), dtype)
+    gscale = float(w.grad.abs().max())
+    dw = torch.full(tuple(w.shape), 0.5, device="cuda")
+    ops.conv2d_wgrad(xd, dyd, dw, 1, 1, 0, accumulate=True)
+    close(dw - 0.5, w.grad, dtype, "wgrad 1x1 (+=)", scale=gscale)
+    dw2 = torch.full(tuple(w.shape), 7.0, device="cuda")
+    ops.conv2d_wgrad(xd, dyd, dw2, 1, 1, 0, accumulate=False)
+    assert torch.equal(dw2, dw - 0.5) or float((dw2 - (dw - 0.5)).abs().max()) <= 1e-6 * gscale
+    plan = ops.WgradPlan(xd.device)
+    dw3 = torch.zeros(tuple(w.shape), device="cuda")
+    with plan:
+        ops.conv2d_wgrad(xd, dyd, dw3, 1, 1, 0, accumulate=False)
+        plan.run()
+    close(dw3, w.grad, dtype, "wgrad 1x1 deferred", scale=gscale)
+
+
 @pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("cfg", [
     dict(n=4, cin=64, cout=64, h=24, w=40, groups=2),          # layer1 conv2 shape class (8-row tile, no prefetch), ragged
