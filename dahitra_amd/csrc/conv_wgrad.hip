@@ -1311,7 +1311,8 @@ extern "C" int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, 
     // chip in ONE round -- a second round only doubles the partial-slab traffic and the per-workgroup prologue / slab
     // write (measured: layer3 115.6 -> 107.6 us, classifier 75.7 -> 65.1 us); the light 1x1 kernels fit four per CU
     static const long w1_target = getenv("DAHITRA_W1_TARGET") ? atol(getenv("DAHITRA_W1_TARGET")) : 512;
-    const long target = w1 ? w1_target : (ks == 1 ? 1024 : (big ? 256 : 512));
+    static const long w1_target1 = getenv("DAHITRA_W1_TARGET1") ? atol(getenv("DAHITRA_W1_TARGET1")) : 512;
+    const long target = w1 ? (slabs == 1 ? w1_target1 : w1_target) : (ks == 1 ? 1024 : (big ? 256 : 512));
     long sk = (target + slabs - 1) / slabs;      // ... however small Cout x Cin is ...
     if (sk > tiles / 8) sk = tiles / 8;        // ... but at least 8 pixel tiles per workgroup (slab write amortised)
     if (sk > 1024) sk = 1024;
