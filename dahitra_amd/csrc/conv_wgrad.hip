@@ -1235,6 +1235,13 @@ static inline bool w1_eligible(const WgArgs& a, int ks, int stride, bool bf16_, 
            !a.dyt_y && !a.phase_mode && a.CoutUse == a.Cout && a.CinPitch % 8 == 0 && a.H == a.OH && a.W == a.OW && a.pad == 0 &&
            a.npix == a.OH * a.OW && a.in_npix == a.H * a.W;
 }
+// ... and only where its few fat blocks still fill the chip (blocks x pixel splits >= 256 workgroups; the split count is capped by
+// 8 pixel tiles per workgroup, so a 256 x 128 layer at 64 x 32 x 32 pixels would be 64 workgroups: that one stays with wg_body)
+static inline bool w1_fills(const WgArgs& a) {
+    int ct = 256, it = 128;
+    w1_pick(a.Cout, a.Cin, ct, it);
+    return (long)dh_cdiv(a.Cout, ct) * dh_cdiv(a.Cin, it) * a.splitk >= 256;
+}
 static int launch_w1(const WgArgs& a, hipStream_t st) {
     int ct = 256, it = 128;
     w1_pick(a.Cout, a.Cin, ct, it);
@@ -1264,7 +1271,7 @@ int launch_all(WgArgs& a, int ks, int stride, bool tr, hipStream_t st) {
     const bool wide2 = wide && wide_ci1x1(a.Cin, a.CoutUse, ks);
     const int it = ks == 4 ? 16 : (wide2 ? 128 : ((wide || (stride == 1 && wide_ci3x3(a.Cin, a.CoutUse, ks))) ? 64 : 32));
     a.ci_tiles = dh_cdiv(a.Cin, it);
-    if (w1_eligible(a, ks, stride, std::is_same<T, bf16>::value, tr)) return launch_w1(a, st);
+    if (w1_eligible(a, ks, stride, std::is_same<T, bf16>::value, tr) && w1_fills(a)) return launch_w1(a, st);
     if (ws_eligible(a, ks, stride, sizeof(T) == 2, tr) && wide_ci3x3(a.Cin, a.CoutUse, ks)) {
         if (g_wsb.on && a.dil == 1 && !a.direct) return ws_batch_add(a, st);
         return a.dil == 2 ? launch_ws<2>(a, st) : launch_ws<1>(a, st);
@@ -1317,6 +1324,16 @@ extern "C" int dh_conv2d_wgrad_splitk(int N, int OH, int OW, int Cin, int Cout, 
     if (sk > tiles / 8) sk = tiles / 8;        // ... but at least 8 pixel tiles per workgroup (slab write amortised)
     if (sk > 1024) sk = 1024;
     return (int)(sk < 1 ? 1 : sk);
+}
+
+// whether a plain bf16 1x1 / stride-1 weight gradient of this shape (one group, no BatchNorm on load) runs as wgrad1x1_kernel
+// blocks -- for tests and tools: the rule of launch_all, w1_eligible and w1_fills
+extern "C" int dh_conv2d_wgrad_1x1_blocks(int N, int H, int W, int Cin, int Cout) {
+    if (!w1_shape(Cin, Cout, 1)) return 0;
+    int ct = 256, it = 128;
+    w1_pick(Cout, Cin, ct, it);
+    const long blocks = (long)dh_cdiv(Cout, ct) * dh_cdiv(Cin, it);
+    return blocks * dh_conv2d_wgrad_splitk(N, H, W, Cin, Cout, 1, 1) >= 256 ? (int)blocks : 0;
 }
 
 extern "C" long dh_conv2d_wgrad_workspace_size(int N, int OH, int OW, int Cin, int Cout, int ks, int groups) {

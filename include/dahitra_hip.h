@@ -120,6 +120,10 @@ int dh_conv3x3_head_fwd(int dtype, const void* x, const void* w_packed, const fl
 int dh_conv2d_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int accumulate, int N, int H,
                     int W, int Cin, int OH, int OW, int Cout, int ks, int stride, int pad, int groups,
                     int npix_valid, int use_tr, int Cout_real, int cin_pitch, int dilation, void* workspace, void* stream);
+/* > 0: a plain bf16 1x1 / stride-1 weight gradient of this shape runs in the block form (wgrad1x1_kernel: a 256 x 128 / 128 x 256 /
+ * 256 x 64 / 64 x 256 block of dW per workgroup over flat pixels, all blocks of a pixel split on one XCD); the value = blocks per
+ * split.  0: the 64 x 64-slab kernel (too few pixels to fill the chip with fat blocks, or a small layer). */
+int dh_conv2d_wgrad_1x1_blocks(int N, int H, int W, int Cin, int Cout);
 long dh_conv2d_wgrad_workspace_size(int N, int OH, int OW, int Cin, int Cout, int ks, int groups);
 /* The weight gradient with its split-K reduce deferred: only the partial slabs are written into `workspace` (which
  * must stay alive until the batched reduce) and *splitk_out receives their count (0: the single-slab 1x1 case wrote

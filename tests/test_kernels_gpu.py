@@ -900,19 +900,21 @@ def test_conv2d_dgrad_wgrad_bench_scale(ops, dtype, mma, cfg):
 
 
 @pytest.mark.parametrize("cfg", [
-    dict(cin=64, cout=256, n=2, h=24, w=20),        # 256 x 64 block, 960 pixels = 15 stages
-    dict(cin=256, cout=64, n=2, h=24, w=20),        # 64 x 256
-    dict(cin=128, cout=512, n=3, h=13, w=11),       # 256 x 128, two co tiles; 429 pixels: a ragged last stage
-    dict(cin=512, cout=128, n=3, h=13, w=11),       # 128 x 256
-    dict(cin=256, cout=1024, n=8, h=32, w=32),      # 4 x 2 blocks, split-K over 128 stages
-    dict(cin=1024, cout=256, n=8, h=32, w=32),
-    dict(cin=264, cout=136, n=2, h=16, w=16),       # channel counts that are multiples of 8 only: ragged blocks both ways
+    dict(cin=64, cout=256, n=16, h=128, w=129, blocks=1),      # 256 x 64 block, one per pixel split
+    dict(cin=256, cout=64, n=16, h=128, w=128, blocks=1),      # 64 x 256
+    dict(cin=128, cout=512, n=8, h=127, w=129, blocks=2),      # 256 x 128, two co tiles; a ragged last stage
+    dict(cin=512, cout=128, n=8, h=128, w=128, blocks=2),      # 128 x 256
+    dict(cin=256, cout=1024, n=8, h=64, w=64, blocks=8),       # 4 x 2 blocks (the layer3 shape of a ResNet-50 trunk)
+    dict(cin=1024, cout=256, n=8, h=64, w=64, blocks=8),
+    dict(cin=264, cout=520, n=8, h=64, w=66, blocks=9),        # channel counts that are multiples of 8 only: ragged blocks both ways
+    dict(cin=256, cout=1024, n=8, h=32, w=32, blocks=0),       # too few pixels to fill the chip with fat blocks: the slab kernel
 ])
 def test_weight_gradient_of_wide_1x1_layers_in_256_by_128_blocks(ops, cfg):
     """dh_conv2d_wgrad for the bf16 1x1 / stride-1 layers of a Bottleneck (models/resnet.py:76-122) -- wgrad1x1_kernel, a CT x IT
     block of dW per workgroup over flat pixels -- against autograd of F.conv2d in fp32: direct (+)= / (=) and deferred"""
     dtype = torch.bfloat16
     N, H, W, Cin, Cout = cfg["n"], cfg["h"], cfg["w"], cfg["cin"], cfg["cout"]
+    assert ops._lib.lib().dh_conv2d_wgrad_1x1_blocks(N, H, W, Cin, Cout) == cfg["blocks"]
     x = rnd((N, Cin, H, W), dtype, 2301)
     w = rnd((Cout, Cin, 1, 1), dtype, 2302, scale=Cin ** -0.5).requires_grad_(True)
     y = F.conv2d(x, w)
