@@ -322,11 +322,12 @@ __global__ void copy_channels16_kernel(const T* __restrict__ src, int Cs, int sc
 
 // both halves of torch.cat([t[:P], t[P:]], channel) in one launch: cat[p, h * C + c] = t[h * P + p, c] (INVERSE: the other
 // way round, the two batch halves of the concatenation's gradient); one 16-byte piece per lane
+#define GSLB(i, n, bid, nb) for (long i = (long)(bid) * blockDim.x + threadIdx.x; i < (n); i += (long)(nb) * blockDim.x)
 template <typename T, bool INVERSE>
-__global__ void cat_halves_kernel(T* __restrict__ t, T* __restrict__ cat, int C, long P) {
+__device__ __forceinline__ void cat_halves_body(T* __restrict__ t, T* __restrict__ cat, int C, long P, int bid, int nb) {
     constexpr int V = V16<T>::N;
     const int vn = 2 * C / V;
-    GSL(i, P * vn) {
+    GSLB(i, P * vn, bid, nb) {
         const long p = i / vn;
         const int c2 = (int)(i % vn) * V, h = c2 >= C, c = c2 - h * C;
         uint4* a = reinterpret_cast<uint4*>(t + (h * P + p) * C + c);
@@ -334,6 +335,10 @@ __global__ void cat_halves_kernel(T* __restrict__ t, T* __restrict__ cat, int C,
         if (INVERSE) *a = *b;
         else *b = *a;
     }
+}
+template <typename T, bool INVERSE>
+__global__ void cat_halves_kernel(T* __restrict__ t, T* __restrict__ cat, int C, long P) {
+    cat_halves_body<T, INVERSE>(t, cat, C, P, blockIdx.x, gridDim.x);
 }
 
 // ---- y = a + b ------------------------------------------------------------------------------
@@ -372,11 +377,11 @@ __global__ void add_pos_kernel(const T* __restrict__ x, const float* __restrict_
     }
 }
 template <typename T>
-__global__ void add_pos16_kernel(const T* __restrict__ x, const float* __restrict__ pos, T* __restrict__ y, int N,
-                                 long HW, int C) {
+__device__ __forceinline__ void add_pos16_body(const T* __restrict__ x, const float* __restrict__ pos, T* __restrict__ y, int N,
+                                               long HW, int C, int bid, int nb) {
     constexpr int V = V16<T>::N;      // one 16-byte piece of x per lane; its V embedding values are L2-resident gathers
     const int vn = C / V;
-    GSL(i, (long)N * HW * vn) {
+    GSLB(i, (long)N * HW * vn, bid, nb) {
         const int c = (int)(i % vn) * V;
         const long p = (i / vn) % HW;
         float v[V];
@@ -385,6 +390,11 @@ __global__ void add_pos16_kernel(const T* __restrict__ x, const float* __restric
         for (int j = 0; j < V; ++j) v[j] += pos[(long)(c + j) * HW + p];
         stv(y + i * V, v);
     }
+}
+template <typename T>
+__global__ void add_pos16_kernel(const T* __restrict__ x, const float* __restrict__ pos, T* __restrict__ y, int N,
+                                 long HW, int C) {
+    add_pos16_body<T>(x, pos, y, N, HW, C, blockIdx.x, gridDim.x);
 }
 // dpos[c,p] (+)= sum_n dy[n,p,c]
 template <typename T>
@@ -401,12 +411,12 @@ __global__ void add_pos_bwd_kernel(const T* __restrict__ dy, float* __restrict__
 // the same for bf16 rows of C = 32 channels: a lane owns one 16-byte piece (8 channels) of a pixel and a quarter of the images
 // (4 loads in flight), the four image groups of a workgroup meet in LDS; 16 pixels per 256-thread workgroup.  (One lane per
 // (channel, pixel) with 2-byte loads 64 bytes apart and N dependent iterations: 17.6 us for 16.8 MB.)
-__global__ __launch_bounds__(256) void add_pos_bwd32_kernel(const bf16* __restrict__ dy, float* __restrict__ dpos, int N, long HW,
-                                                            int accumulate) {
+__device__ __forceinline__ void add_pos_bwd32_body(const bf16* __restrict__ dy, float* __restrict__ dpos, int N, long HW,
+                                                   int accumulate, int bid) {
     constexpr int C = 32;
     __shared__ float red[4][64][8];
     const int tid = threadIdx.x, q = tid & 3, px = (tid >> 2) & 15, ng = tid >> 6;
-    const long p = (long)blockIdx.x * 16 + px;
+    const long p = (long)bid * 16 + px;
     float s[4][8];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -435,6 +445,10 @@ __global__ __launch_bounds__(256) void add_pos_bwd32_kernel(const bf16* __restri
             if (accumulate) *o += t; else *o = t;
         }
     }
+}
+__global__ __launch_bounds__(256) void add_pos_bwd32_kernel(const bf16* __restrict__ dy, float* __restrict__ dpos, int N, long HW,
+                                                            int accumulate) {
+    add_pos_bwd32_body(dy, dpos, N, HW, accumulate, blockIdx.x);
 }
 
 // ---- activation derivative: dx = dy * f'(.) ---------------------------------------------------
@@ -1405,16 +1419,20 @@ extern "C" int dh_cast_to_f32(int dtype, const void* src, float* dst, long n, in
 // ---- |second half - first half| of [B][2][n] token sets (models/networks.py:1311) and its gradient
 namespace {
 template <typename T>
-__global__ void absdiff_halves_kernel(const T* __restrict__ tok, T* __restrict__ out, int B, long n) {
-    GSL(i, (long)B * n) {
+__device__ __forceinline__ void absdiff_halves_body(const T* __restrict__ tok, T* __restrict__ out, int B, long n, int bid, int nb) {
+    GSLB(i, (long)B * n, bid, nb) {
         const long b = i / n, j = i % n;
         stf(out + i, fabsf(ldf(tok + (b * 2 + 1) * n + j) - ldf(tok + (b * 2) * n + j)));
     }
 }
 template <typename T>
-__global__ void absdiff_halves_bwd_kernel(const T* __restrict__ tok, const T* __restrict__ dout, T* __restrict__ dtok,
-                                          int B, long n) {
-    GSL(i, (long)B * n) {      // accumulates into dtok
+__global__ void absdiff_halves_kernel(const T* __restrict__ tok, T* __restrict__ out, int B, long n) {
+    absdiff_halves_body<T>(tok, out, B, n, blockIdx.x, gridDim.x);
+}
+template <typename T>
+__device__ __forceinline__ void absdiff_halves_bwd_body(const T* __restrict__ tok, const T* __restrict__ dout, T* __restrict__ dtok,
+                                                        int B, long n, int bid, int nb) {
+    GSLB(i, (long)B * n, bid, nb) {      // accumulates into dtok
         const long b = i / n, j = i % n;
         const float df = ldf(tok + (b * 2 + 1) * n + j) - ldf(tok + (b * 2) * n + j);
         const float g = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * ldf(dout + i);
@@ -1424,7 +1442,88 @@ __global__ void absdiff_halves_bwd_kernel(const T* __restrict__ tok, const T* __
         stf(p0, ldf(p0) - g);
     }
 }
+template <typename T>
+__global__ void absdiff_halves_bwd_kernel(const T* __restrict__ tok, const T* __restrict__ dout, T* __restrict__ dtok,
+                                          int B, long n) {
+    absdiff_halves_bwd_body<T>(tok, dout, dtok, B, n, blockIdx.x, gridDim.x);
+}
+
+// ---- a JOB TABLE of the small element-wise kernels above: the three levels of _forward_trans_module (models/networks.py:1297-1318)
+// each issue a positional add, a channel concatenation, |token2 - token1| (and their gradients) between the launches they share;
+// recorded per round (ops.EwBatch) the independent ones go out as ONE launch: a job is a run of workgroups of it
+enum { DH_EW_ADD_POS = 1, DH_EW_CAT_HALVES = 2, DH_EW_SPLIT_HALVES = 3, DH_EW_ABSDIFF_HALVES = 4, DH_EW_ABSDIFF_HALVES_BWD = 5,
+       DH_EW_ADD_POS_BWD = 6 };       // (= include/dahitra_hip.h)
+struct EwJob {
+    int op, blk0, nblk, i0, i1;
+    long l0;
+    const void* a;
+    const void* b;
+    void* c;
+};
+constexpr int EW_MAXJ = 12;
+struct EwMulti {
+    EwJob j[EW_MAXJ];
+    int n;
+};
+__global__ __launch_bounds__(256) void ew_multi_kernel(EwMulti m) {
+    int k = 0;
+    while (k + 1 < m.n && (int)blockIdx.x >= m.j[k + 1].blk0) ++k;
+    const EwJob& J = m.j[k];
+    const int bid = (int)blockIdx.x - J.blk0, nb = J.nblk;
+    switch (J.op) {
+        case DH_EW_ADD_POS: add_pos16_body<bf16>((const bf16*)J.a, (const float*)J.b, (bf16*)J.c, J.i0, J.l0, J.i1, bid, nb); break;
+        case DH_EW_CAT_HALVES: cat_halves_body<bf16, false>((bf16*)const_cast<void*>(J.a), (bf16*)J.c, J.i0, J.l0, bid, nb); break;
+        case DH_EW_SPLIT_HALVES: cat_halves_body<bf16, true>((bf16*)J.c, (bf16*)const_cast<void*>(J.a), J.i0, J.l0, bid, nb); break;
+        case DH_EW_ABSDIFF_HALVES: absdiff_halves_body<float>((const float*)J.a, (float*)J.c, J.i0, J.l0, bid, nb); break;
+        case DH_EW_ABSDIFF_HALVES_BWD: absdiff_halves_bwd_body<float>((const float*)J.a, (const float*)J.b, (float*)J.c, J.i0, J.l0, bid, nb); break;
+        case DH_EW_ADD_POS_BWD: add_pos_bwd32_body((const bf16*)J.a, (float*)J.c, J.i0, J.l0, J.i1, bid); break;
+        default: break;
+    }
+}
 }  // namespace
+// n jobs, one launch.  op[k] and its operands:
+//   DH_EW_ADD_POS            c = a + pos (dh_add_pos, bf16, C % 8 == 0):        a = x, b = pos, c = y, i0 = N, i1 = C, l0 = H W
+//   DH_EW_CAT_HALVES         dh_cat_halves(inverse = 0), bf16, C % 8 == 0:       a = t [2 P][C], c = cat [P][2 C], i0 = C, l0 = P
+//   DH_EW_SPLIT_HALVES       dh_cat_halves(inverse = 1):                         a = cat, c = t, i0 = C, l0 = P
+//   DH_EW_ABSDIFF_HALVES     dh_absdiff_halves, fp32:                            a = tok, c = out, i0 = B, l0 = n
+//   DH_EW_ABSDIFF_HALVES_BWD dh_absdiff_halves_bwd, fp32:                        a = tok, b = dout, c = dtok (accumulated), i0 = B, l0 = n
+//   DH_EW_ADD_POS_BWD        dh_add_pos_bwd, bf16, C = 32:                       a = dy, c = dpos, i0 = N, i1 = accumulate, l0 = H W
+// The jobs of one call must not depend on each other (they run side by side).
+extern "C" int dh_ew_multi(int n, const int* op, const void* const* a, const void* const* b, void* const* c, const int* i0,
+                           const int* i1, const long* l0, void* stream) {
+    DH_REQUIRE(n >= 1 && n <= EW_MAXJ && op && a && b && c && i0 && i1 && l0, "ew_multi: 1 .. %d jobs, got %d", EW_MAXJ, n);
+    EwMulti m;
+    int nblk = 0;
+    for (int k = 0; k < n; ++k) {
+        EwJob& J = m.j[k];
+        J.op = op[k]; J.a = a[k]; J.b = b[k]; J.c = c[k]; J.i0 = i0[k]; J.i1 = i1[k]; J.l0 = l0[k];
+        long work;
+        switch (op[k]) {
+            case DH_EW_ADD_POS:
+                DH_REQUIRE(i1[k] % 8 == 0 && a[k] && b[k] && c[k], "ew_multi: add_pos job %d", k);
+                work = ew_grid((long)i0[k] * l0[k] * i1[k] / 8, 256); break;
+            case DH_EW_CAT_HALVES: case DH_EW_SPLIT_HALVES:
+                DH_REQUIRE(i0[k] % 8 == 0 && a[k] && c[k], "ew_multi: cat_halves job %d", k);
+                work = ew_grid(l0[k] * (2 * i0[k] / 8), 256); break;
+            case DH_EW_ABSDIFF_HALVES:
+                DH_REQUIRE(a[k] && c[k], "ew_multi: absdiff_halves job %d", k);
+                work = ew_grid((long)i0[k] * l0[k], 256); break;
+            case DH_EW_ABSDIFF_HALVES_BWD:
+                DH_REQUIRE(a[k] && b[k] && c[k], "ew_multi: absdiff_halves_bwd job %d", k);
+                work = ew_grid((long)i0[k] * l0[k], 256); break;
+            case DH_EW_ADD_POS_BWD:
+                DH_REQUIRE(a[k] && c[k], "ew_multi: add_pos_bwd job %d", k);
+                work = (l0[k] + 15) / 16; break;
+            default: DH_FAIL("ew_multi: unknown op %d (job %d)", op[k], k);
+        }
+        J.blk0 = nblk; J.nblk = (int)work;
+        nblk += (int)work;
+    }
+    m.n = n;
+    hipLaunchKernelGGL(ew_multi_kernel, dim3(nblk), dim3(256), 0, ST(stream), m);
+    DH_CHECK_LAUNCH("ew_multi");
+    return 0;
+}
 extern "C" int dh_absdiff_halves(int dtype, const void* tok, void* out, int B, long n, void* stream) {
     const long t = (long)B * n;
     if (dtype == DH_DTYPE_BF16) hipLaunchKernelGGL(absdiff_halves_kernel<bf16>, dim3(ew_grid(t, 256)), dim3(256), 0, ST(stream), (const bf16*)tok, (bf16*)out, B, n);

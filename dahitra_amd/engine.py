@@ -663,6 +663,10 @@ class Engine:
         mlp0 = self.shapes["%s.layers.0.1.fn.fn.net.0.weight" % pfx][0]
         fused = self.fused_decoder and self.dtype == torch.bfloat16 and L == 4 and heads * L <= 32 and rpi % 128 == 0 \
             and mlp0 in (32, 64)
+        # launches that are NOT recorded read their inputs at once: what the caller left in the element-wise batch goes out first
+        recorded = fused and ops._DEC_BATCH is not None and not self.attn_fp8
+        if not recorded:
+            ops.ew_flush()
         stack = self._prep_stack(tok, tok_b, tok_s, B, images, L, heads, dim_head, pfx, depth) if fused and depth > 1 \
             else None
         # deferred parameter gradients: the fused backward launches of a stack leave their per-workgroup partials in a per-layer
@@ -689,6 +693,8 @@ class Engine:
                 return ys[depth - 1], None
 
             def bwd_stack(d):
+                if not recorded:
+                    ops.ew_flush()
                 dx = ops.decoder_stack_bwd(x0, ys, d.contiguous(), stack, rpi, params0, w1s, w1Ts, w2s, w2Ts, pstride, mlp0,
                                            defer.partials, LN_EPS)
                 yield               # dx is valid from here on
@@ -720,6 +726,8 @@ class Engine:
             return x, None
 
         def bwd(d):
+            if not recorded:
+                ops.ew_flush()
             for b in reversed(bw):
                 d = b(d)
                 if fused:
@@ -1101,7 +1109,7 @@ class Engine:
             return out
         return torch.zeros_like(t)
 
-    def _run_staged(self, gens):
+    def _run_staged(self, gens, ew=False):
         """GENERATORS that pause right after every token-encoder call and every fused decoder stack (forward: `_level`;
         backward: the `bwd` it returns).  They run in rounds inside one ops.EncoderBatch: the launches they reach are only
         RECORDED, and after each round the recorded ones go out together -- the levels are independent, an encoder stack
@@ -1111,6 +1119,8 @@ class Engine:
         them a few dozen workgroups): with `level_streams` each level's segment goes to a stream of its own, forked from and
         joined into the main stream around the round -- in the recorded step they are parallel branches of the graph and run
         side by side instead of one after the other.
+        ew=True (the `_level` generators, which pause after them): the levels' positional adds, channel concatenations and token
+        differences (and their gradients) are recorded as well and go out as one job-table launch per round (ops.EwBatch).
         Returns the generators' return values."""
         vals = {}
         streams = None
@@ -1119,7 +1129,7 @@ class Engine:
             while len(self._lstreams) < len(gens):
                 self._lstreams.append(ops.SideStream(torch.device("cuda", dev)))
             streams = self._lstreams
-        with ops.EncoderBatch(decoder=True) as eb:
+        with ops.EncoderBatch(decoder=True, ew=ew and streams is None) as eb:
             live = list(enumerate(gens))
             while live:
                 paused = []
@@ -1152,11 +1162,11 @@ class Engine:
         tok_cat, tsaved = ops.tokenizer_fwd(sq, wa, self.p["pos_embedding_%d" % l], B, L)
         tok2d, b_enc = self.encoder(tok_cat.view(B * 2 * L, DIM), "transformer_%d" % l, self.cfg["enc_depth"],
                                     lv["heads"], lv["dim_head"], B, 2 * L)
-        yield                       # tok2d is valid from here on (_run_staged)
-        dtok = self._zeros_like(tok2d) if self.need_grad else None
         pos = self.p["pos_embedding_decoder_%d" % l]
+        xin = ops.add_pos(sq, pos)  # (may only be recorded: issued with the round's other launches)
+        yield                       # tok2d and xin are valid from here on (_run_staged)
+        dtok = self._zeros_like(tok2d) if self.need_grad else None
         dp = "transformer_decoder_%d" % l
-        xin = ops.add_pos(sq, pos)
         dec, b_dec = yield from self._decoder_gen(xin.view(S2 * hw, DIM), S2, tok2d, 2 * L * DIM, L * DIM, B, dtok, dp,
                                                   lv["dec_depth"], lv["heads"], lv["dim_head"], L)
         dec4 = dec.view(S2, fh, fw, DIM)
@@ -1166,8 +1176,9 @@ class Engine:
         dtk = torch.empty(B, L, DIM, dtype=torch.float32, device=sq.device)
         ops.absdiff_halves(tk3, dtk)
         ddtk = self._zeros_like(dtk) if self.need_grad else None
+        yield                       # cat and dtk are valid from here on
         dxc, b_cd = self.conv_act(cat, "conv_decode_%d.weight" % l, None, 3, 1, NONE)
-        xin3 = ops.add_pos(dxc, pos)
+        xin3 = ops.add_pos(dxc, pos)        # (recorded: a round issues the element-wise jobs before its decoder stacks)
         out, b_dec3 = yield from self._decoder_gen(xin3.view(B * hw, DIM), B, dtk.view(B * L, DIM), L * DIM, 0, B, ddtk, dp,
                                                    lv["dec_depth"], lv["heads"], lv["dim_head"], L)
         out4 = out.view(B, fh, fw, DIM)
@@ -1180,7 +1191,7 @@ class Engine:
             ops.add_pos_bwd(dxin3, gpos, accumulate=True)
             dcat = b_cd(dxin3)
             ops.absdiff_halves_bwd(tk3, ddtk, dtok)                    # accumulates into both token halves
-            ddec = ops.split_halves(dcat)
+            ddec = ops.split_halves(dcat)      # (these three may only be recorded: issued before the round's decoder stacks)
             dxin = (yield from b_dec(ddec.view(S2 * hw, DIM))).view(S2, fh, fw, DIM)
             ops.add_pos_bwd(dxin, gpos, accumulate=True)
             dtok_cat = b_enc(dtok)
@@ -1275,7 +1286,8 @@ class Engine:
         if self.need_grad:
             # the levels' token-gradient accumulators (dtok, ddtk: 3 B L 32 floats per level) from ONE zeroed buffer
             self._zpool = [torch.zeros(3 * 3 * B * self.cfg["token_len"] * DIM, dtype=torch.float32, device=s4.device), 0]
-        (o5, b5), (t4, b4), (t3, b3) = self._run_staged([level(5, s16, B), level(4, s8, B), level(3, s4, B)])
+        ew = self.cfg["kind"] != "xbd"          # (_level pauses after its recorded element-wise calls; _xbd_level does not)
+        (o5, b5), (t4, b4), (t3, b3) = self._run_staged([level(5, s16, B), level(4, s8, B), level(3, s4, B)], ew=ew)
         self._zpool = None
         o5u = ops.upsample2(o5)
         o4, bu4 = self._up_conv(4, ops.add(t4, o5u))
@@ -1310,7 +1322,7 @@ class Engine:
                 ds2 = ops.split_halves(dcat2)
             dsum3 = bu3(dy2)                                   # d(t3 + o4)
             dsum4 = bu4(dsum3)                                 # d(t4 + o5u)
-            ds4, ds8, ds16 = self._run_staged([b3(dsum3), b4(dsum4), b5(ops.upsample2_bwd(dsum4))])
+            ds4, ds8, ds16 = self._run_staged([b3(dsum3), b4(dsum4), b5(ops.upsample2_bwd(dsum4))], ew=ew)
             return ds16, ds8, ds4, ds2
 
         def bwd_second(state):

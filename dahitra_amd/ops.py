@@ -1120,10 +1120,46 @@ def copy_channels(src, sc0, dst, dc0, cn):
     _call("dh_copy_channels", _ci(dt(src)), P(src), _ci(Cs), _ci(sc0), P(dst), _ci(Cd), _ci(dc0), _ci(cn), _cl(Pn), S())
 
 
+# ---- small element-wise launches of independent levels, recorded and issued as one job-table launch (dh_ew_multi) ----
+EW_ADD_POS, EW_CAT_HALVES, EW_SPLIT_HALVES, EW_ABSDIFF_HALVES, EW_ABSDIFF_HALVES_BWD, EW_ADD_POS_BWD = 1, 2, 3, 4, 5, 6
+EW_MAXJ = 12
+_EW_BATCH = None         # while an EncoderBatch(ew=True) is open: [(op, a, b, c, i0, i1, l0)] of the recorded calls (tensors kept alive)
+
+
+def _ew_record(op, a, b, c, i0, i1, l0):
+    """True: the call was recorded (its result is valid after the batch's next launch)"""
+    if _EW_BATCH is None:
+        return False
+    if len(_EW_BATCH) == EW_MAXJ:
+        ew_flush()
+    _EW_BATCH.append((op, a, b, c, int(i0), int(i1), int(l0)))
+    return True
+
+
+def ew_flush():
+    """issue what has been recorded (one launch); a no-op without pending jobs"""
+    if not _EW_BATCH:
+        return
+    n = len(_EW_BATCH)
+    ptr = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+    ops_ = (ctypes.c_int * n)(*[j[0] for j in _EW_BATCH])
+    a = (ctypes.c_void_p * n)(*[ptr(j[1]) for j in _EW_BATCH])
+    b = (ctypes.c_void_p * n)(*[ptr(j[2]) for j in _EW_BATCH])
+    c = (ctypes.c_void_p * n)(*[ptr(j[3]) for j in _EW_BATCH])
+    i0 = (ctypes.c_int * n)(*[j[4] for j in _EW_BATCH])
+    i1 = (ctypes.c_int * n)(*[j[5] for j in _EW_BATCH])
+    l0 = (ctypes.c_long * n)(*[j[6] for j in _EW_BATCH])
+    _call("dh_ew_multi", _ci(n), ops_, a, b, c, i0, i1, l0, S())
+    del _EW_BATCH[:]
+
+
 def cat_halves(t):
     """torch.cat([t[:B], t[B:]], channel) of a contiguous [2B, H, W, C] tensor, one launch"""
     n, h, w, c = t.shape
     cat = torch.empty(n // 2, h, w, 2 * c, dtype=t.dtype, device=t.device)
+    assert t.is_contiguous()
+    if t.dtype == torch.bfloat16 and c % 8 == 0 and _ew_record(EW_CAT_HALVES, t, None, cat, c, 0, (n // 2) * h * w):
+        return cat
     _call("dh_cat_halves", _ci(dt(t)), P(t), P(cat), _ci(c), _cl((n // 2) * h * w), _ci(0), S())
     return cat
 
@@ -1132,6 +1168,9 @@ def split_halves(cat):
     """the inverse: [B, H, W, 2C] -> [2B, H, W, C] (the gradient of cat_halves)"""
     n, h, w, c2 = cat.shape
     t = torch.empty(2 * n, h, w, c2 // 2, dtype=cat.dtype, device=cat.device)
+    assert cat.is_contiguous()
+    if cat.dtype == torch.bfloat16 and (c2 // 2) % 8 == 0 and _ew_record(EW_SPLIT_HALVES, cat, None, t, c2 // 2, 0, n * h * w):
+        return t
     _call("dh_cat_halves", _ci(dt(cat)), P(t), P(cat), _ci(c2 // 2), _cl(n * h * w), _ci(1), S())
     return t
 
@@ -1145,12 +1184,18 @@ def add(a, b):
 def add_pos(x, pos):
     N, H, W, C = x.shape
     y = torch.empty_like(x)
+    assert x.is_contiguous() and pos.is_contiguous()
+    if x.dtype == torch.bfloat16 and C % 8 == 0 and _ew_record(EW_ADD_POS, x, pos, y, N, C, H * W):
+        return y
     _call("dh_add_pos", _ci(dt(x)), P(x), P(pos), P(y), _ci(N), _cl(H * W), _ci(C), S())
     return y
 
 
 def add_pos_bwd(dy, dpos, accumulate=False):
     N, H, W, C = dy.shape
+    assert dy.is_contiguous() and dpos.is_contiguous()
+    if dy.dtype == torch.bfloat16 and C == 32 and _ew_record(EW_ADD_POS_BWD, dy, None, dpos, N, int(accumulate), H * W):
+        return
     _call("dh_add_pos_bwd", _ci(dt(dy)), P(dy), P(dpos), _ci(N), _cl(H * W), _ci(C), _ci(int(accumulate)), S())
 
 
@@ -1598,17 +1643,24 @@ class EncoderBatch:
     eb.launch() issues them together (one workgroup per image each: stacks of independent levels share the chip).  Their
     outputs are valid after launch().  Inert under ops.PROFILE (per-launch events) and with DAHITRA_ENC_BATCH=0."""
 
-    def __init__(self, decoder=False):
-        """decoder=True: the fused decoder layers (decoder_layer_fwd, and decoder_layer_bwd with `partial`) are recorded too
+    def __init__(self, decoder=False, ew=False):
+        """ew=True: add_pos / add_pos_bwd / cat_halves / split_halves / absdiff_halves(_bwd) calls are recorded too (one
+        dh_ew_multi launch per round, issued FIRST): the caller pauses between such a call and the first use of its result.
+        DAHITRA_EW_BATCH=0 switches that part off.
+        decoder=True: the fused decoder layers (decoder_layer_fwd, and decoder_layer_bwd with `partial`) are recorded too
         (dh_decoder_batch_*): layers of independent stacks share a launch.  DAHITRA_DEC_BATCH=0 switches that part off."""
         self.on = PROFILE is None and os.environ.get("DAHITRA_ENC_BATCH", "1") != "0"
         self.dec = decoder and PROFILE is None and os.environ.get("DAHITRA_DEC_BATCH", "1") != "0"
         # with the decoder stacks, their token-side preparation (XattnPrepStack and its backward, dh_xprep_batch_*) and the
         # stack's parameter-gradient finalize are recorded as well.  DAHITRA_XPREP_BATCH=0 switches that part off.
         self.xprep = self.dec and os.environ.get("DAHITRA_XPREP_BATCH", "1") != "0"
+        self.ew = ew and PROFILE is None and os.environ.get("DAHITRA_EW_BATCH", "1") != "0"
 
     def __enter__(self):
-        global _ENC_BATCH, _DEC_BATCH, _XPREP_BATCH
+        global _ENC_BATCH, _DEC_BATCH, _XPREP_BATCH, _EW_BATCH
+        if self.ew:
+            assert _EW_BATCH is None, "EncoderBatch(ew=True) is not re-entrant"
+            _EW_BATCH = []
         if self.on or self.dec:
             assert _ENC_BATCH is None and _DEC_BATCH is None and _XPREP_BATCH is None, "EncoderBatch is not re-entrant"
         if self.on:
@@ -1625,6 +1677,8 @@ class EncoderBatch:
     def launch(self):
         """program order of what one round may have recorded: a stack's preparation before its forward; a stack's finalize
         (which the decoder batch issues after its backward launches) before the preparation's backward"""
+        if self.ew:
+            ew_flush()
         if self.xprep:
             _call("dh_xprep_batch_launch_fwd", S())
         if self.on:
@@ -1638,8 +1692,12 @@ class EncoderBatch:
             del _XPREP_BATCH[:]
 
     def __exit__(self, *exc):
-        global _ENC_BATCH, _DEC_BATCH, _XPREP_BATCH
+        global _ENC_BATCH, _DEC_BATCH, _XPREP_BATCH, _EW_BATCH
         failed = bool(exc) and exc[0] is not None
+        if self.ew:
+            if not failed:
+                ew_flush()
+            _EW_BATCH = None
         if self.xprep:
             if failed:
                 _lib.lib().dh_xprep_batch_abort()
@@ -1808,10 +1866,16 @@ def absdiff_halves(tok3, out):
     """out[b] = |tok3[b, 1] - tok3[b, 0]| for tok3 [B, 2, n] (token difference, networks.py:1311)"""
     B = tok3.shape[0]
     n = out.numel() // B
+    assert tok3.is_contiguous() and out.is_contiguous()
+    if tok3.dtype == torch.float32 and _ew_record(EW_ABSDIFF_HALVES, tok3, None, out, B, 0, n):
+        return
     _call("dh_absdiff_halves", _ci(dt(tok3)), P(tok3), P(out), _ci(B), _cl(n), S())
 
 
 def absdiff_halves_bwd(tok3, dout, dtok3):
     B = tok3.shape[0]
     n = dout.numel() // B
+    assert tok3.is_contiguous() and dout.is_contiguous() and dtok3.is_contiguous()
+    if tok3.dtype == torch.float32 and _ew_record(EW_ABSDIFF_HALVES_BWD, tok3, dout, dtok3, B, 0, n):
+        return
     _call("dh_absdiff_halves_bwd", _ci(dt(tok3)), P(tok3), P(dout), P(dtok3), _ci(B), _cl(n), S())

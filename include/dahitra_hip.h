@@ -369,6 +369,16 @@ int dh_head_fwd_supported(int NC, int W);
  * callers in that mode only. */
 int dh_head_fwd(int dtype, const void* x, const float* w_oihw, const float* bias, int NC, const float* in_scale, const float* in_shift,
                 int in_groups, float* logits_nchw, int N, int H, int W, void* stream);
+/* A job table of small element-wise kernels in ONE launch (no reference counterpart: autograd runs one op at a time): the three
+ * levels of _forward_trans_module (models/networks.py:1297-1318) each issue a positional add, the channel concatenation of the two
+ * streams, |token2 - token1| and their gradients between the launches they share; the independent ones of a round go out together.
+ * n <= 12 jobs that must not depend on each other; per job an op and its operands (see csrc/pointwise.hip dh_ew_multi):
+ * ADD_POS = dh_add_pos (bf16, C % 8 == 0), CAT_HALVES / SPLIT_HALVES = dh_cat_halves (bf16), ABSDIFF_HALVES(_BWD) =
+ * dh_absdiff_halves(_bwd) (fp32), ADD_POS_BWD = dh_add_pos_bwd (bf16, C = 32). */
+enum { DH_EW_ADD_POS = 1, DH_EW_CAT_HALVES = 2, DH_EW_SPLIT_HALVES = 3, DH_EW_ABSDIFF_HALVES = 4, DH_EW_ABSDIFF_HALVES_BWD = 5,
+       DH_EW_ADD_POS_BWD = 6 };
+int dh_ew_multi(int n, const int* op, const void* const* a, const void* const* b, void* const* c, const int* i0, const int* i1,
+                const long* l0, void* stream);
 int dh_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, long HW, void* stream);
 int dh_copy_channels(int dtype, const void* src, int Cs, int sc0, void* dst, int Cd, int dc0, int Cn, long P, void* stream);
 /* torch.cat([x1, x2], 1) of the two temporal streams (models/networks.py:1309, 1344), which are the two batch halves of

@@ -1729,6 +1729,58 @@ def test_head_behind_a_relu_data_weight_and_bias_gradient_in_one_pass(ops, cfg, 
     close(dw1, dw0.cpu(), dtype, "dw vs conv2d_wgrad", factor=1.0)
 
 
+def test_job_table_of_elementwise_kernels_equals_their_single_launches(ops):
+    """ops.EncoderBatch(ew=True): add_pos / add_pos_bwd / cat_halves / split_halves / absdiff_halves(_bwd) calls of independent
+    levels recorded and issued as ONE dh_ew_multi launch -- bit-equal to the single launches (three levels' worth of jobs, more
+    jobs than one table holds, and a dtype the table does not take)"""
+    dtype = torch.bfloat16
+    lv = [(4, 16, 16), (4, 8, 8), (4, 4, 4)]          # (2B, h, w) of three levels
+    x = [dev(rnd((n, h, w, 32), dtype, 2400 + i), dtype) for i, (n, h, w) in enumerate(lv)]
+    pos = [rnd((1, 32, h, w), torch.float32, 2410 + i).cuda() for i, (n, h, w) in enumerate(lv)]
+    tok = [rnd((2, 2, 4 * 32), torch.float32, 2420 + i).cuda() for i in range(3)]
+    dout = [rnd((2, 4 * 32), torch.float32, 2430 + i).cuda() for i in range(3)]
+    xf = dev(rnd((4, 6, 6, 32), torch.float32, 2440), torch.float32)        # fp32 activations: not a table job, issued at once
+
+    def run():
+        r = []
+        for i in range(3):
+            r.append(ops.add_pos(x[i], pos[i]))
+            r.append(ops.cat_halves(x[i]))
+            d = torch.zeros(2, 4 * 32, device="cuda")
+            ops.absdiff_halves(tok[i], d)
+            r.append(d)
+        r.append(ops.add_pos(xf, pos[0][:, :, :6, :6].contiguous()))
+        return r
+
+    def run_bwd(cats):
+        r = []
+        for i in range(3):
+            g = torch.full((1, 32, lv[i][1], lv[i][2]), 0.5, device="cuda")
+            ops.add_pos_bwd(x[i], g, accumulate=True)
+            r.append(g)
+            r.append(ops.split_halves(cats[i]))
+            dt_ = torch.ones(2, 2, 4 * 32, device="cuda")
+            ops.absdiff_halves_bwd(tok[i], dout[i], dt_)
+            r.append(dt_)
+        return r
+    want = run()
+    cats = [want[3 * i + 1] for i in range(3)]
+    want_b = run_bwd(cats)
+    with ops.EncoderBatch(decoder=False, ew=True) as eb:
+        got = run()
+        assert ops._EW_BATCH is not None and len(ops._EW_BATCH) == 9          # the fp32 add_pos went out at once
+        eb.launch()
+        assert len(ops._EW_BATCH) == 0
+        got_b = run_bwd(cats)
+        for _ in range(2):          # 9 + 6 more jobs: the table (12) flushes itself
+            ops.add_pos_bwd(x[0], torch.zeros(1, 32, 16, 16, device="cuda"), accumulate=False)
+            ops.add_pos_bwd(x[1], torch.zeros(1, 32, 8, 8, device="cuda"), accumulate=False)
+            ops.add_pos_bwd(x[2], torch.zeros(1, 32, 4, 4, device="cuda"), accumulate=False)
+    assert ops._EW_BATCH is None
+    for a_, b_ in zip(want + want_b, got + got_b):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("cfg", [
     dict(n=2, h=16, w=16),          # 64 x 64 fine map
     dict(n=3, h=6, w=10),           # 24 x 40: ragged tiles in both directions, odd batch

@@ -806,6 +806,25 @@ def test_opt_in_paths_equal_default_paths_bf16(monkeypatch):
         assert cos >= 0.9995 and float((g - h).abs().max()) <= 3e-2 * float(g.abs().max()) + 1e-9, (k, cos)
 
 
+@pytest.mark.parametrize("cdtype", ["bf16", "fp32"])
+def test_elementwise_launches_of_the_levels_in_one_job_table_equal_single_launches(cdtype, monkeypatch):
+    """newUNetTrans train step with the levels' positional adds / channel concatenations / token differences and their gradients
+    recorded into one dh_ew_multi launch per round (default) against DAHITRA_EW_BATCH=0: the same kernels' bodies in the same
+    order per tensor -- bit-equal logits and gradients (fp32: only the token differences are table jobs)"""
+    from dahitra_amd.models import losses
+    a, b, lab = O.synthetic_batch(2, 256, seed=75)
+    res = {}
+    for off in ("1", "0"):
+        monkeypatch.setenv("DAHITRA_EW_BATCH", off)
+        net = make_net("newUNetTrans", cdtype).train()
+        y = net(a.cuda(), b.cuda())
+        losses.focal_loss(y, lab.cuda()).backward()
+        res[off] = (y.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert torch.equal(res["0"][0], res["1"][0])
+    for k, g in res["0"][1].items():
+        assert torch.equal(res["1"][1][k], g), k
+
+
 @pytest.mark.parametrize("cdtype", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
 def test_head_gradient_inside_the_batchnorm_backward_equals_three_kernel_path_bf16(name, cdtype, monkeypatch):
