@@ -96,6 +96,9 @@ class Engine:
         # the reduction, but the gated MFMA launches slow down by as much (4054.6 vs 4054.1 pairs/s) -- so the
         # two-pass backward stays the default and the fused path is kept, tested, as an option.
         self.fused_bn_bwd = os.environ.get("DAHITRA_BN_FUSION", "0") == "1"
+        # the 1x1 stride-2 shortcut of a Bottleneck: its data gradient as a GEMM on the COARSE grid + an in-place add at the
+        # even-even positions, instead of zero insertion + a 1x1 convolution on the fine grid (DAHITRA_NO_COARSE_SHORTCUT=1)
+        self.coarse_shortcut = os.environ.get("DAHITRA_NO_COARSE_SHORTCUT", "0") != "1"
         # BatchNorm-apply + ReLU fused into the load of the consumer convolution (forward and weight gradient): the
         # normalised activation of conv1 of every BasicBlock / of the head's first conv is never materialised
         self.lazy_bn = os.environ.get("DAHITRA_NO_LAZY_BN", "0") != "1"
@@ -507,7 +510,12 @@ class Engine:
         def bwd(dout, next_gate=None):
             dh2, dres = b3(dout, next_gate=b2.gate)
             dh1, _ = b2(dh2, next_gate=b1.gate)
-            if has_ds:
+            if has_ds and stride == 2 and next_gate is None and self.coarse_shortcut:
+                # the shortcut's gradient on its own coarse grid, added at the even-even positions of conv1's data gradient
+                dxds, _ = bds(dres, coarse_dx=True)
+                dx, _ = b1(dh1, next_gate=next_gate)
+                ops.add_coarse_(dx, dxds)
+            elif has_ds:
                 dxds, _ = bds(dres)
                 dx, _ = b1(dh1, dx_res=dxds, next_gate=next_gate)
             else:

@@ -789,6 +789,15 @@ def linear_wgrad(x2d, dy2d, dw, accumulate=False, images=1, per_image=False, use
           _ci(0), _ci(0), _ci(1), P(ws), S())
 
 
+def add_coarse_(x, coarse):
+    """x[n, 2y, 2x, :] += coarse[n, y, x, :] in place (the coarse-grid data gradient of a 1x1 stride-2 convolution)"""
+    N, H, W, C = x.shape
+    n2, OH, OW, c2 = coarse.shape
+    assert n2 == N and c2 == C and x.dtype == coarse.dtype and x.is_contiguous() and coarse.is_contiguous()
+    _call("dh_add_coarse", _ci(dt(x)), P(x), P(coarse), _ci(N), _ci(OH), _ci(OW), _ci(H), _ci(W), _ci(C), S())
+    return x
+
+
 def zero_insert2(dy, H, W):
     N, OH, OW, C = dy.shape
     z = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)

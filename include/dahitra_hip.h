@@ -216,6 +216,10 @@ int dh_pack_weights_multi(const void* jobs_dev, int njobs, int total_blocks, voi
 int dh_pack_job_size(void);
 /* z[n,2y,2x,c] = dy[n,y,x,c] (zero elsewhere): stride-2 data gradients as stride-1 convolutions */
 int dh_zero_insert2(int dtype, const void* dy, void* z, int N, int OH, int OW, int H, int W, int C, void* stream);
+/* x [N][H][W][C] (+)= coarse [N][(H+1)/2][(W+1)/2][C] at the even-even positions: the data gradient of a 1x1 stride-2 convolution
+ * (the shortcut of a stride-2 Bottleneck, models/resnet.py:106-118) computed on its own coarse grid and added where it lives,
+ * instead of zero insertion + a 1x1 convolution on the fine grid. */
+int dh_add_coarse(int dtype, void* x, const void* coarse, int N, int OH, int OW, int H, int W, int C, void* stream);
 
 /* stem nn.Conv2d(3,64,7,2,3) (models/resnet.py:150) as a 4x4/stride-1 conv on a space-to-depth image */
 int dh_stem_space_to_depth(int dtype, const float* x_nchw, void* y, int N, int H, int W, int CP, void* stream);

@@ -1729,6 +1729,32 @@ def test_head_behind_a_relu_data_weight_and_bias_gradient_in_one_pass(ops, cfg, 
     close(dw1, dw0.cpu(), dtype, "dw vs conv2d_wgrad", factor=1.0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_coarse_grid_gradient_added_at_the_even_positions(ops, dtype):
+    """dh_add_coarse: x[n, 2y, 2x, :] += coarse[n, y, x, :] -- with the coarse-grid 1x1 product it is the data gradient of a 1x1
+    stride-2 convolution (the shortcut of a stride-2 Bottleneck, models/resnet.py:106-118) == zero insertion + 1x1 convolution"""
+    for (N, H, W, C) in ((2, 12, 20, 64), (3, 7, 9, 32)):
+        OH, OW = (H + 1) // 2, (W + 1) // 2
+        x = rnd((N, H, W, C), dtype, 2501)
+        c = rnd((N, OH, OW, C), dtype, 2502)
+        want = x.clone()
+        want[:, ::2, ::2] += c
+        got = ops.add_coarse_(dev(x, dtype), dev(c, dtype))
+        close(got, want.to(dtype).float(), dtype, "add_coarse", factor=0.5)
+    # against the fine-grid path: autograd of a 1x1 stride-2 convolution
+    N, H, W, Cin, Cout = 2, 16, 32, 64, 128
+    xx = rnd((N, Cin, H, W), dtype, 2503).requires_grad_(True)
+    w = rnd((Cout, Cin, 1, 1), dtype, 2504, scale=Cin ** -0.5)
+    y = F.conv2d(xx, w, None, 2)
+    dy = rnd(tuple(y.shape), dtype, 2505)
+    y.backward(dy)
+    _, wd = ops.pack_weight(w.cuda(), dtype, want_dgrad=True)
+    coarse = ops.conv2d(dev(nhwc(dy), dtype), wd, Cin, 1, 1, 0)
+    fine = torch.zeros(N, H, W, Cin, device="cuda", dtype=dtype)
+    ops.add_coarse_(fine, coarse)
+    close(nchw(fine), xx.grad, dtype, "1x1 stride-2 data gradient on the coarse grid", factor=2.0)
+
+
 def test_job_table_of_elementwise_kernels_equals_their_single_launches(ops):
     """ops.EncoderBatch(ew=True): add_pos / add_pos_bwd / cat_halves / split_halves / absdiff_halves(_bwd) calls of independent
     levels recorded and issued as ONE dh_ew_multi launch -- bit-equal to the single launches (three levels' worth of jobs, more
