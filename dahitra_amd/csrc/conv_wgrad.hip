@@ -1115,6 +1115,7 @@ struct W1Args {
     float* part;
     long P;                   // pixels
     int Cin, CinPitch, Cout, CoutUse, splitk, ci_tiles, no_xcd_remap;
+    int stride, OW, OHW, W, HW;   // stride 2: output pixel p = (n, oy, ox) reads x at (n, 2 oy, 2 ox) of an H x W image
 };
 constexpr int W1_PS = 64;     // pixels per stage
 
@@ -1162,7 +1163,13 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_kernel(W1Args p) {
         for (int i = 0; i < NX; ++i) {
             const long px = p0 + xpx + i * (256 / XQ);
             const bool ok = xch && px < p.P;
-            const uint4 v = *reinterpret_cast<const uint4*>(p.x + (ok ? px * p.CinPitch + ci0 + xq * 8 : 0));
+            long xpix = px;
+            if (p.stride == 2) {            // (uniform; 32-bit divisions: P < 2^31)
+                const unsigned up = (unsigned)px, n = up / (unsigned)p.OHW, rem = up - n * (unsigned)p.OHW;
+                const unsigned oy = rem / (unsigned)p.OW, ox = rem - oy * (unsigned)p.OW;
+                xpix = (long)n * p.HW + (long)(2 * oy) * p.W + 2 * ox;
+            }
+            const uint4 v = *reinterpret_cast<const uint4*>(p.x + (ok ? xpix * p.CinPitch + ci0 + xq * 8 : 0));
             rx[i] = ok ? v : make_uint4(0, 0, 0, 0);
         }
     };
@@ -1231,9 +1238,10 @@ static inline bool w1_shape(int Cin, int Cout, int ks) {
     return on && ks == 1 && Cin % 8 == 0 && Cout % 8 == 0 && (long)Cin * Cout >= 128 * 128 && (Cin >= 256 || Cout >= 256);
 }
 static inline bool w1_eligible(const WgArgs& a, int ks, int stride, bool bf16_, bool tr) {
-    return bf16_ && tr && stride == 1 && w1_shape(a.Cin, a.Cout, ks) && a.groups == 1 && !a.in_scale && !a.x_split && !a.direct &&
-           !a.dyt_y && !a.phase_mode && a.CoutUse == a.Cout && a.CinPitch % 8 == 0 && a.H == a.OH && a.W == a.OW && a.pad == 0 &&
-           a.npix == a.OH * a.OW && a.in_npix == a.H * a.W;
+    const bool geo = stride == 1 ? (a.H == a.OH && a.W == a.OW) : (stride == 2 && a.OH == (a.H + 1) / 2 && a.OW == (a.W + 1) / 2);
+    return bf16_ && tr && geo && w1_shape(a.Cin, a.Cout, ks) && a.groups == 1 && !a.in_scale && !a.x_split && !a.direct &&
+           !a.dyt_y && !a.phase_mode && a.CoutUse == a.Cout && a.CinPitch % 8 == 0 && a.pad == 0 &&
+           a.npix == a.OH * a.OW && a.in_npix == a.H * a.W && (long)a.N * a.OH * a.OW < (1L << 31);
 }
 // ... and only where its few fat blocks still fill the chip (blocks x pixel splits >= 256 workgroups; the split count is capped by
 // 8 pixel tiles per workgroup, so a 256 x 128 layer at 64 x 32 x 32 pixels would be 64 workgroups: that one stays with wg_body)
@@ -1247,7 +1255,8 @@ static int launch_w1(const WgArgs& a, hipStream_t st) {
     w1_pick(a.Cout, a.Cin, ct, it);
     W1Args w;
     w.x = reinterpret_cast<const bf16*>(a.x); w.dy = reinterpret_cast<const bf16*>(a.dy); w.part = a.part;
-    w.P = (long)a.N * a.H * a.W; w.Cin = a.Cin; w.CinPitch = a.CinPitch; w.Cout = a.Cout; w.CoutUse = a.CoutUse;
+    w.P = (long)a.N * a.OH * a.OW; w.stride = (a.H == a.OH && a.W == a.OW) ? 1 : 2; w.OW = a.OW; w.OHW = a.OH * a.OW; w.W = a.W; w.HW = a.H * a.W;
+    w.Cin = a.Cin; w.CinPitch = a.CinPitch; w.Cout = a.Cout; w.CoutUse = a.CoutUse;
     w.splitk = a.splitk; w.ci_tiles = dh_cdiv(a.Cin, it); w.no_xcd_remap = a.no_xcd_remap;
     dim3 grid(dh_cdiv(a.Cout, ct) * w.ci_tiles, a.splitk);
     if (ct == 256 && it == 128) hipLaunchKernelGGL((wgrad1x1_kernel<256, 128>), grid, dim3(256), 0, st, w);

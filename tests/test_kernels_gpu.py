@@ -908,30 +908,34 @@ def test_conv2d_dgrad_wgrad_bench_scale(ops, dtype, mma, cfg):
     dict(cin=1024, cout=256, n=8, h=64, w=64, blocks=8),
     dict(cin=264, cout=520, n=8, h=64, w=66, blocks=9),        # channel counts that are multiples of 8 only: ragged blocks both ways
     dict(cin=256, cout=1024, n=8, h=32, w=32, blocks=0),       # too few pixels to fill the chip with fat blocks: the slab kernel
+    dict(cin=256, cout=512, n=8, h=128, w=128, blocks=4, stride=2),      # the stride-2 shortcut of a Bottleneck: x read at (2 oy, 2 ox)
+    dict(cin=128, cout=512, n=8, h=127, w=129, blocks=2, stride=2),      # odd input sizes would not matter: output 127 x 129 of 253 x 257
 ])
 def test_weight_gradient_of_wide_1x1_layers_in_256_by_128_blocks(ops, cfg):
     """dh_conv2d_wgrad for the bf16 1x1 / stride-1 layers of a Bottleneck (models/resnet.py:76-122) -- wgrad1x1_kernel, a CT x IT
     block of dW per workgroup over flat pixels -- against autograd of F.conv2d in fp32: direct (+)= / (=) and deferred"""
     dtype = torch.bfloat16
     N, H, W, Cin, Cout = cfg["n"], cfg["h"], cfg["w"], cfg["cin"], cfg["cout"]
-    assert ops._lib.lib().dh_conv2d_wgrad_1x1_blocks(N, H, W, Cin, Cout) == cfg["blocks"]
-    x = rnd((N, Cin, H, W), dtype, 2301)
+    st = cfg.get("stride", 1)
+    assert ops._lib.lib().dh_conv2d_wgrad_1x1_blocks(N, H, W, Cin, Cout) == cfg["blocks"]       # (H, W: the OUTPUT grid)
+    x = rnd((N, Cin, st * H - (st - 1), st * W - (st - 1)), dtype, 2301)
     w = rnd((Cout, Cin, 1, 1), dtype, 2302, scale=Cin ** -0.5).requires_grad_(True)
-    y = F.conv2d(x, w)
+    y = F.conv2d(x, w, None, st)
+    assert tuple(y.shape[2:]) == (H, W)
     dy = rnd(tuple(y.shape), dtype, 2303)
     y.backward(dy)
     xd, dyd = dev(nhwc(x), dtype), dev(nhwc(dy), dtype)
     gscale = float(w.grad.abs().max())
     dw = torch.full(tuple(w.shape), 0.5, device="cuda")
-    ops.conv2d_wgrad(xd, dyd, dw, 1, 1, 0, accumulate=True)
+    ops.conv2d_wgrad(xd, dyd, dw, 1, st, 0, accumulate=True)
     close(dw - 0.5, w.grad, dtype, "wgrad 1x1 (+=)", scale=gscale)
     dw2 = torch.full(tuple(w.shape), 7.0, device="cuda")
-    ops.conv2d_wgrad(xd, dyd, dw2, 1, 1, 0, accumulate=False)
+    ops.conv2d_wgrad(xd, dyd, dw2, 1, st, 0, accumulate=False)
     assert torch.equal(dw2, dw - 0.5) or float((dw2 - (dw - 0.5)).abs().max()) <= 1e-6 * gscale
     plan = ops.WgradPlan(xd.device)
     dw3 = torch.zeros(tuple(w.shape), device="cuda")
     with plan:
-        ops.conv2d_wgrad(xd, dyd, dw3, 1, 1, 0, accumulate=False)
+        ops.conv2d_wgrad(xd, dyd, dw3, 1, st, 0, accumulate=False)
         plan.run()
     close(dw3, w.grad, dtype, "wgrad 1x1 deferred", scale=gscale)
 
