@@ -171,7 +171,15 @@ __global__ __launch_bounds__(2 * BM, 256 / BM) void conv1x1_gemm_kernel(ConvArgs
     for (int j = 0; j < NI; ++j) {
         const int r = (j * NW + wv) * 8 + (lane >> 3);                      // LDS row
         const int c = (lane & 7) ^ (r & 7);                                  // source chunk landing in LDS chunk lane & 7
-        src[j] = (r < BN ? Wt + (size_t)(co0 + r) * rowbytes : X + (size_t)(m0 + r - BN) * rowbytes) + c * 16;
+        // (a stride-2 layer -- the shortcut of a stride-2 Bottleneck -- gathers its pixel rows: output pixel (n, oy, ox) reads the
+        // input row (n, 2 oy, 2 ox); every lane supplies its own source address anyway)
+        long xrow = m0 + r - BN;
+        if (r >= BN && (p.H != p.OH || p.W != p.OW)) {
+            const long ohw = (long)p.OH * p.OW, n = xrow / ohw, rem = xrow - n * ohw;
+            const long oy = rem / p.OW, ox = rem - oy * p.OW;
+            xrow = (n * p.H + 2 * oy) * p.W + 2 * ox;
+        }
+        src[j] = (r < BN ? Wt + (size_t)(co0 + r) * rowbytes : X + (size_t)xrow * rowbytes) + c * 16;
     }
     auto issue = [&](int stage, int k0) {
 #pragma unroll
@@ -281,8 +289,11 @@ int launch_gemm(const ConvArgs& a, hipStream_t st) {
 // the shapes this kernel serves (everything else stays on the direct kernel); bf16 only
 bool dh_conv1x1_gemm_eligible(const ConvArgs& a, int ks, int stride, int dtype) {
     static const bool off = getenv("DAHITRA_NO_GEMM1X1") != nullptr;
-    return !off && dtype == DH_DTYPE_BF16 && ks == 1 && stride == 1 && a.pad == 0 && a.Cin >= 64 && a.Cin % GBK == 0 &&
-           a.Cout % 64 == 0 && a.CoutPad == a.Cout && a.OH % 8 == 0 && a.OW % 16 == 0 && a.H == a.OH && a.W == a.OW &&
+    static const bool no_s2 = getenv("DAHITRA_GEMM1X1_NO_S2") != nullptr;       // A/B switch: stride-2 layers stay on the direct kernel
+    const bool geo = stride == 1 ? (a.H == a.OH && a.W == a.OW)
+                                 : (stride == 2 && !no_s2 && a.OH == (a.H + 1) / 2 && a.OW == (a.W + 1) / 2 && a.in_npix == a.H * a.W);
+    return !off && dtype == DH_DTYPE_BF16 && ks == 1 && geo && a.pad == 0 && a.Cin >= 64 && a.Cin % GBK == 0 &&
+           a.Cout % 64 == 0 && a.CoutPad == a.Cout && a.OH % 8 == 0 && a.OW % 16 == 0 &&
            !a.gate_y && !a.y2 && !a.in_scale && a.w_nstride == 0 && a.npix == a.OH * a.OW && a.act != DH_ACT_GELU &&
            !(a.stats && (a.res || a.act != DH_ACT_NONE)) && ((long)a.N * a.OH * a.OW) % GBM == 0;
 }
