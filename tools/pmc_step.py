@@ -36,7 +36,7 @@ def load(d):
 
 
 def steps_of(acc):
-    for name in ("adamw_tick_kernel", "adamw_kernel"):          # capturable / plain optimizer step: one launch per step
+    for name in ("adamw_tick_kernel", "adamw_xbd_tick_kernel", "adamw_kernel"):          # capturable / plain optimizer step: one launch per step
         for k, v in acc.items():
             if k.startswith(name):
                 return next(iter(v.values()))[0]

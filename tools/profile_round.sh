@@ -25,7 +25,7 @@ python3 - $O/stats $O/${pre}_graph_step.txt <<'PY'
 import csv, glob, sys, re
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adamw_tick" in r["Kernel_Name"] or "adamw_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "adamw_tick" in r["Kernel_Name"] or "adamw_kernel" in r["Kernel_Name"] or "adamw_xbd_tick" in r["Kernel_Name"]]
 span = lambda k: int(rows[idx[k + 1]]["End_Timestamp"]) - int(rows[idx[k] + 1]["Start_Timestamp"])
 k = min(range(len(idx) - 1), key=span)          # the fastest step = a replay of the recorded graph
 lo, hi = idx[k] + 1, idx[k + 1] + 1

@@ -10,7 +10,7 @@ python3 - $O/tr $R/gpurun_out/${tag}_last_step.txt <<'PY'
 import csv, glob, sys, re
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adamw_tick" in r["Kernel_Name"] or "adamw_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "adamw_tick" in r["Kernel_Name"] or "adamw_kernel" in r["Kernel_Name"] or "adamw_xbd_tick" in r["Kernel_Name"]]
 # the step with the SHORTEST span between two optimizer launches: a replay of the recorded graph (the run's last steps are the
 # eager profiling steps of bench.py, whose launches come from Python one by one)
 span = lambda k: int(rows[idx[k + 1]]["End_Timestamp"]) - int(rows[idx[k] + 1]["Start_Timestamp"])
