@@ -685,27 +685,32 @@ __global__ void bn_bwd_finalize_coef_kernel(const float* __restrict__ partial, i
 // store of dx per lane, a wave instruction covers 1 KiB of consecutive addresses.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-// dlogits [N][NC <= 2][H][W] fp32 (the loss kernel's layout) -> [N][H + 2][W + 2] bf16 pairs (class 0 low, class 1 high) inside a
-// border of zeros: what head_bn_bwd_kernel gathers its nine taps from, 4 bytes per tap and no bounds test.  PL = 2 (the
-// split-product fp32 mode): two words per pixel, the pair of the values' bf16 heads and the pair of their bf16 remainders.
-template <int PL>
+// dlogits [N][NC][H][W] fp32 (the loss kernel's layout) -> [N][H + 2][W + 2] pixels of NCP bf16 classes (NCP = 2: a pair, one word;
+// NCP = 8 for 3 .. 8 classes: one 16-byte piece) inside a border of zeros: what head_bn_bwd_kernel gathers its nine taps from, one
+// load per tap and no bounds test.  PL = 2 (the split-product fp32 mode): per pixel the piece of the values' bf16 heads, then
+// the piece of their bf16 remainders.
+template <int PL, int NCP>
 __global__ void head_dlogits_pack_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int N, int NC, int H, int W) {
     const int Wp = W + 2, Hp = H + 2;
+    constexpr int WPP = NCP / 2;            // words per plane and pixel
     const long total = (long)N * Hp * Wp;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int xx = (int)(i % Wp) - 1, yy = (int)((i / Wp) % Hp) - 1;
         const long n = i / ((long)Wp * Hp);
-        float a = 0.f, b = 0.f;
-        if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
-            a = src[((n * NC) * H + yy) * (long)W + xx];
-            b = NC > 1 ? src[((n * NC + 1) * H + yy) * (long)W + xx] : 0.f;
+        const bool in = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+        unsigned hi[WPP], lo[WPP];
+#pragma unroll
+        for (int k = 0; k < WPP; ++k) {
+            const float a = (in && 2 * k < NC) ? src[((n * NC + 2 * k) * H + yy) * (long)W + xx] : 0.f;
+            const float b = (in && 2 * k + 1 < NC) ? src[((n * NC + 2 * k + 1) * H + yy) * (long)W + xx] : 0.f;
+            hi[k] = f2bf2(a, b);
+            lo[k] = f2bf2(a - __uint_as_float(hi[k] << 16), b - __uint_as_float(hi[k] & 0xffff0000u));
         }
-        const unsigned hi = f2bf2(a, b);
-        if constexpr (PL == 1) {
-            dst[i] = hi;
-        } else {
-            const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-            reinterpret_cast<uint2*>(dst)[i] = make_uint2(hi, f2bf2(ra, rb));
+        unsigned* o = dst + i * (WPP * PL);
+#pragma unroll
+        for (int k = 0; k < WPP; ++k) {
+            o[k] = hi[k];
+            if constexpr (PL == 2) o[WPP + k] = lo[k];
         }
     }
 }
@@ -713,12 +718,14 @@ __global__ void head_dlogits_pack_kernel(const float* __restrict__ src, unsigned
 // WGRAD (pass 1 only): the head convolution's own weight gradient from the same loads.  dW1[ci][tap][class] = sum over pixels
 // of relu(BN(y))[pixel][ci] * dlogits[pixel - tap offset][class] -- for the INPUT pixel a lane holds, the nine dlogits it has
 // just gathered ARE those neighbours (k = (tap, class)).  Pixels are the K dimension of that product: both operands go through
-// a wave-private LDS tile ([16 px][32] bf16, pitch 96 bytes) and come back transposed (ds_read_b64_tr_b16, four pixels of one
-// channel / one k per lane) for v_mfma_f32_16x16x16_bf16; a wave's LDS operations execute in order, no barrier in the loop.
-// Per-workgroup partials [578][blocks] (576 = ci * 18 + tap * 2 + class, 576 / 577 = the bias gradient, sum of dlogits):
-// head_bwd_finalize_kernel.  What this replaces read y a third time (conv_wgrad_kernel, 54 us at the bench size).
-constexpr int HB_WCOLS = 32 * 18 + 2;
+// a wave-private LDS tile ([16 px][32] bf16, pitch 96 bytes; [16 px][96] at pitch 224 for NCP = 8) and come back transposed
+// (ds_read_b64_tr_b16, four pixels of one channel / one k per lane) for v_mfma_f32_16x16x16_bf16; a wave's LDS operations
+// execute in order, no barrier in the loop.  Per-workgroup partials [32 * 9 * NCP + NCP][blocks] (column ci * 9 NCP + tap * NCP +
+// class, then the bias gradient = the column sums of dlogits): head_bwd_finalize_kernel.  What this replaces read y a third time
+// (conv_wgrad_kernel, 54 us at the bench size).
 constexpr int HB_TP = 96;                                // tile pitch (bytes): odd multiple of 32 -- conflict-free transpose reads
+constexpr int hb_wcols(int ncp) { return 32 * 9 * ncp + ncp; }
+constexpr int HB_WCOLS_MAX = hb_wcols(8);
 
 // MODE 2 (dh_head_relu_bwd): no BatchNorm -- `y` is the OUTPUT of the ReLU in front of the head (classifier(conv_layer2(...)),
 // models/networks.py:1351-1355), dx = (y > 0) * g in one pass, with the head's weight gradient (WGRAD) from the same loads.
@@ -726,7 +733,9 @@ constexpr int HB_TP = 96;                                // tile pitch (bytes): 
 // product is the three split products hi.hi + hi.lo + lo.hi of bf16 planes (x = hi + lo, ~2^-17: what that mode's backward
 // convolutions and weight gradients compute): the weights' planes are formed once, the dlogits' planes come from the pair map
 // (PL = 2), the planes of relu(BN(y)) are formed per group for the weight gradient's tiles.
-template <typename T, int MODE, bool WGRAD>
+// NCP = 8 (3 .. 8 classes: the five-class heads of the xBD nets, xBD_code/zoo/model_transformer_encoding.py): k = tap * 8 + class,
+// three K steps of 32 -- lane group g of step st gathers the 16-byte piece of tap 4 st + g -- instead of one.
+template <typename T, int MODE, bool WGRAD, int NCP = 2>
 __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __restrict__ dlp, const float* __restrict__ w_oihw, int N, int H,
                                                           int W, int NC, const T* __restrict__ y, const float* __restrict__ mscale,
                                                           const float* __restrict__ mshift, int groups, float* __restrict__ partial,
@@ -734,36 +743,50 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __rest
                                                           float* __restrict__ wpartial) {
     constexpr bool APPLY = MODE == 1, RELU = MODE == 2, STORE = MODE != 0, F32 = sizeof(T) == 4;
     constexpr int PL = F32 ? 2 : 1;  // operand planes
+    constexpr int KST = NCP == 2 ? 1 : 3;                    // K steps (of 32) of the data-gradient product
+    constexpr int NKB = 2 * KST;                             // 16-wide k blocks of the neighbourhood tile
+    constexpr int TNP = NCP == 2 ? HB_TP : 224;              // ... and its pitch (bytes: an odd multiple of 32)
+    constexpr int WCOLS = hb_wcols(NCP);
     constexpr int HB_DEPTH = 2;      // groups in flight per wave (depths 3 and 4 measured: no faster, more registers)
     constexpr int PXB = 32 * (int)sizeof(T);                 // bytes of a pixel of y / dx
     static_assert(!(APPLY && WGRAD), "the weight gradient rides on the reduction pass");
-    constexpr int TILE = 16 * HB_TP;
-    __shared__ __attribute__((aligned(16))) unsigned char hb_tiles[WGRAD ? 4 * 2 * PL * TILE : 16];
+    static_assert(NCP == 2 || NCP == 8, "class pieces of 2 or 8");
+    constexpr int TILE = 16 * HB_TP, TILEN = 16 * TNP;
+    // (the four waves' partial weight gradients are parked over the tiles once the loop is done)
+    constexpr int TBYTES = 4 * PL * (TILE + TILEN), RBYTES = 4 * WCOLS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char hb_tiles[WGRAD ? (TBYTES > RBYTES ? TBYTES : RBYTES) : 16];
     const int lane = threadIdx.x & 63, pl = lane & 15, g = lane >> 4;
-    unsigned char* tH = hb_tiles + (WGRAD ? (threadIdx.x >> 6) * 2 * PL * TILE : 0);      // [PL] tiles of the head's input
-    unsigned char* tN = tH + (WGRAD ? PL * TILE : 0);                                     // [PL] tiles of the dlogits neighbourhood
-    f32x4 wacc[2][2];
-    float bsum0 = 0.f, bsum1 = 0.f;
+    unsigned char* tH = hb_tiles + (WGRAD ? (threadIdx.x >> 6) * PL * (TILE + TILEN) : 0);      // [PL] tiles of the head's input
+    unsigned char* tN = tH + (WGRAD ? PL * TILE : 0);                                           // [PL] tiles of the dlogits neighbourhood
+    f32x4 wacc[2][NKB];
+    float bsum[NCP];
 #pragma unroll
-    for (int a_ = 0; a_ < 2; ++a_) wacc[a_][0] = wacc[a_][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    s16x8 wa[PL][2];      // A fragments (planes): row ci = s * 16 + pl, k = 8 g + e -> tap 4 g + e / 2, class e & 1
+    for (int c = 0; c < NCP; ++c) bsum[c] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        float v[8];
+    for (int a_ = 0; a_ < 2; ++a_)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int tap = 4 * g + (e >> 1), co = e & 1;
-            v[e] = (tap < 9 && co < NC) ? w_oihw[((size_t)co * 32 + s * 16 + pl) * 9 + tap] : 0.f;
+        for (int kb = 0; kb < NKB; ++kb) wacc[a_][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // A fragments (planes): row ci = s * 16 + pl, k = 32 st + 8 g + e -> NCP = 2: tap 4 g + e / 2, class e & 1; NCP = 8: tap 4 st + g, class e
+    s16x8 wa[PL][KST][2];
+#pragma unroll
+    for (int st = 0; st < KST; ++st)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int tap = NCP == 2 ? 4 * g + (e >> 1) : 4 * st + g, co = NCP == 2 ? (e & 1) : e;
+                v[e] = (tap < 9 && co < NC) ? w_oihw[((size_t)co * 32 + s * 16 + pl) * 9 + tap] : 0.f;
+            }
+            uint4 wp[PL];
+            split_bf16_planes<PL>(v, wp);
+#pragma unroll
+            for (int p = 0; p < PL; ++p) {
+                union { uint4 u; s16x8 h; } pk;
+                pk.u = wp[p];
+                wa[p][st][s] = pk.h;
+            }
         }
-        uint4 wp[PL];
-        split_bf16_planes<PL>(v, wp);
-#pragma unroll
-        for (int p = 0; p < PL; ++p) {
-            union { uint4 u; s16x8 h; } pk;
-            pk.u = wp[p];
-            wa[p][s] = pk.h;
-        }
-    }
     const int bpg = gridDim.x / groups, bg = blockIdx.x / bpg;
     const long gpix = (long)N * H * W / groups, total = (bg + 1) * gpix, ngrp16 = (gpix + 15) / 16;
     // a wave takes CONSECUTIVE 16-pixel groups: its pixel coordinates advance by additions (the grid-stride form spent more
@@ -787,37 +810,43 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __rest
     // does not exist is dropped the same way.  (The entry points require the tensors below 2 GiB.)
     const unsigned npx_all = (unsigned)((long)N * H * W);
     const int Wp = W + 2;
-    const auto rs_dl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(dlp), 0, N * (H + 2) * Wp * 4 * PL, 0x00020000);
+    constexpr int PB = 2 * NCP * PL;                        // bytes of a pixel of the class map
+    const auto rs_dl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(dlp), 0, N * (H + 2) * Wp * PB, 0x00020000);
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(y), 0, (int)(npx_all * (unsigned)PXB), 0x00020000);
     const auto rs_dx = __builtin_amdgcn_make_buffer_rsrc(dx, 0, STORE ? (int)(npx_all * (unsigned)PXB) : 0, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const long pxl = bg * gpix + grp0 * 16 + pl;            // this lane's first pixel; (cx, cy) its column / row inside its image
     unsigned px = (unsigned)pxl;
     int cx = (int)(pxl % W), cy = (int)((pxl / W) % H);
-    // dlogits come as dh_head_dlogits_pack left them: [N][H + 2][W + 2] bf16 pairs (x PL planes) with a border of zeros -- a tap
+    // dlogits come as dh_head_dlogits_pack left them: [N][H + 2][W + 2] class pieces (x PL planes) with a border of zeros -- a tap
     // needs no bounds test, only an offset from the lane's own (padded) position pc4 (bytes)
-    constexpr int PB = 4 * PL;                              // bytes of a pixel of the pair map
     unsigned pc4 = (unsigned)(((pxl / ((long)W * H)) * (H + 2) + cy + 1) * Wp + cx + 1) * (unsigned)PB;
-    int toff[4];                                            // this lane group's taps: byte offset from pc4
-    bool thave[4];
+    constexpr int NLD = NCP == 2 ? 4 : KST;                 // taps this lane gathers per group
+    int toff[NLD];                                          // their byte offsets from pc4
+    bool thave[NLD];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int tap = 4 * g + q, kh = tap / 3, kw = tap - kh * 3;
+    for (int q = 0; q < NLD; ++q) {
+        const int tap = NCP == 2 ? 4 * g + q : 4 * q + g, kh = tap / 3, kw = tap - kh * 3;
         thave[q] = tap < 9;
         toff[q] = ((1 - kh) * Wp + (1 - kw)) * PB;
     }
-    struct Grp { unsigned bk[PL][4]; u32x4 yraw[PL]; unsigned at; };      // (fp32: yraw = the lane's 8 values; bf16: one piece)
+    struct Grp { u32x4 bfr[PL][KST]; u32x4 yraw[PL]; unsigned at; };      // B fragments of the K steps; (fp32: yraw = the lane's 8 values)
     auto request = [&](Grp& q_, bool valid) {
         const bool inb = valid & (px < (unsigned)total);
         q_.at = inb ? px * (unsigned)PXB + cb * (unsigned)sizeof(T) : OOB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NLD; ++q) {
             const unsigned off = (inb & thave[q]) ? pc4 + toff[q] : OOB;
-            if constexpr (F32) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_dl, off, 0, 0);
-                q_.bk[0][q] = v[0]; q_.bk[PL - 1][q] = v[1];
+            if constexpr (NCP == 2) {
+                if constexpr (F32) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_dl, off, 0, 0);
+                    q_.bfr[0][0][q] = v[0]; q_.bfr[PL - 1][0][q] = v[1];
+                } else {
+                    q_.bfr[0][0][q] = __builtin_amdgcn_raw_buffer_load_b32(rs_dl, off, 0, 0);
+                }
             } else {
-                q_.bk[0][q] = __builtin_amdgcn_raw_buffer_load_b32(rs_dl, off, 0, 0);
+                q_.bfr[0][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_dl, off, 0, 0);
+                if constexpr (F32) q_.bfr[PL - 1][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_dl, off + 16u, 0, 0);
             }
         }
         q_.yraw[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, q_.at, 0, 0);
@@ -829,21 +858,24 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __rest
         }
     };
     // lane (pl, g): pixels 4 g .. 4 g + 3 of column 16 c + pl of a tile
-    auto frag = [&](const unsigned char* t, int c) {
-        const unsigned char* base = t + (g * 4 + (pl >> 2)) * HB_TP + (c * 16 + (pl & 3) * 4) * 2;
+    auto frag = [&](const unsigned char* t, int pitch, int c) {
+        const unsigned char* base = t + (g * 4 + (pl >> 2)) * pitch + (c * 16 + (pl & 3) * 4) * 2;
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
     };
     auto use = [&](const Grp& q_) {
-        union { uint4 u; s16x8 h; } b[PL];
+        f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int p = 0; p < PL; ++p) b[p].u = make_uint4(q_.bk[p][0], q_.bk[p][1], q_.bk[p][2], q_.bk[p][3]);
-        f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][0], b[0].h, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][1], b[0].h, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        if constexpr (F32) {
-            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][0], b[PL - 1].h, d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][1], b[PL - 1].h, d1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[PL - 1][0], b[0].h, d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[PL - 1][1], b[0].h, d1, 0, 0, 0);
+        for (int st = 0; st < KST; ++st) {
+            const s16x8 b0 = __builtin_bit_cast(s16x8, q_.bfr[0][st]);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][st][0], b0, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][st][1], b0, d1, 0, 0, 0);
+            if constexpr (F32) {
+                const s16x8 bl = __builtin_bit_cast(s16x8, q_.bfr[PL - 1][st]);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][st][0], bl, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][st][1], bl, d1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[PL - 1][st][0], b0, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[PL - 1][st][1], b0, d1, 0, 0, 0);
+            }
         }
         float r[8], yv[8];
 #pragma unroll
@@ -862,7 +894,7 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __rest
         float z[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            z[e] = RELU ? yv[e] : yv[e] * ms[e] + mh[e];
+            z[e] = RELU ? yv[e] : __builtin_fmaf(yv[e], ms[e], mh[e]);      // (explicit fma: every instantiation rounds alike)
             r[e] = z[e] > 0.f ? r[e] : 0.f;          // (a group of zeros has r = 0 already)
         }
         if constexpr (WGRAD) {
@@ -877,30 +909,47 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __rest
 #pragma unroll
                 for (int p = 0; p < PL; ++p) *reinterpret_cast<uint4*>(tH + p * TILE + pl * HB_TP + cb * 2) = hp[p];
             }
-#pragma unroll
-            for (int p = 0; p < PL; ++p) *reinterpret_cast<uint4*>(tN + p * TILE + pl * HB_TP + g * 16) = b[p].u;
-            asm volatile("" ::: "memory");
-            s16x4 hf[PL][2], nf[PL][2];
+            // the neighbourhood tile, k-major as the fragments are: NCP = 2: columns 8 g ..; NCP = 8: the piece of tap 4 st + g
 #pragma unroll
             for (int p = 0; p < PL; ++p)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) { hf[p][c] = frag(tH + p * TILE, c); nf[p][c] = frag(tN + p * TILE, c); }
+                for (int st = 0; st < KST; ++st)
+                    *reinterpret_cast<uint4*>(tN + p * TILEN + pl * TNP + (NCP == 2 ? g : 4 * st + g) * 16) =
+                        make_uint4(q_.bfr[p][st][0], q_.bfr[p][st][1], q_.bfr[p][st][2], q_.bfr[p][st][3]);
+            asm volatile("" ::: "memory");
+            s16x4 hf[PL][2], nf[PL][NKB];
+#pragma unroll
+            for (int p = 0; p < PL; ++p) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) hf[p][c] = frag(tH + p * TILE, HB_TP, c);
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) nf[p][kb] = frag(tN + p * TILEN, TNP, kb);
+            }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int cs = 0; cs < 2; ++cs)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    wacc[cs][ks] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hf[0][cs], nf[0][ks], wacc[cs][ks], 0, 0, 0);
+                for (int kb = 0; kb < NKB; ++kb) {
+                    wacc[cs][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hf[0][cs], nf[0][kb], wacc[cs][kb], 0, 0, 0);
                     if constexpr (F32) {
-                        wacc[cs][ks] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hf[0][cs], nf[PL - 1][ks], wacc[cs][ks], 0, 0, 0);
-                        wacc[cs][ks] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hf[PL - 1][cs], nf[0][ks], wacc[cs][ks], 0, 0, 0);
+                        wacc[cs][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hf[0][cs], nf[PL - 1][kb], wacc[cs][kb], 0, 0, 0);
+                        wacc[cs][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hf[PL - 1][cs], nf[0][kb], wacc[cs][kb], 0, 0, 0);
                     }
                 }
-            // the centre tap (4: lane group 1, its first load) is the pixel's own dlogits: the bias gradient
+            // the centre tap is the pixel's own dlogits: the bias gradient.  NCP = 2: tap 4 = lane group 1's first load;
+            // NCP = 8: tap 4 = step 1 of lane group 0
 #pragma unroll
             for (int p = 0; p < PL; ++p) {
-                bsum0 += __uint_as_float(q_.bk[p][0] << 16);
-                bsum1 += __uint_as_float(q_.bk[p][0] & 0xffff0000u);
+                if constexpr (NCP == 2) {
+                    bsum[0] += __uint_as_float(q_.bfr[p][0][0] << 16);
+                    bsum[1] += __uint_as_float(q_.bfr[p][0][0] & 0xffff0000u);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        bsum[2 * k] += __uint_as_float(q_.bfr[p][1][k] << 16);
+                        bsum[2 * k + 1] += __uint_as_float(q_.bfr[p][1][k] & 0xffff0000u);
+                    }
+                }
             }
         }
         auto store8 = [&](const float (&o)[8]) {
@@ -915,13 +964,13 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __rest
         if constexpr (APPLY) {
             float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = cA[e] * r[e] + cB[e] * yv[e] + cC[e];
+            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(cA[e], r[e], __builtin_fmaf(cB[e], yv[e], cC[e]));
             store8(o);
         } else if constexpr (RELU) {
             store8(r);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s1[e] += r[e]; s2[e] += r[e] * yv[e]; }
+            for (int e = 0; e < 8; ++e) { s1[e] += r[e]; s2[e] = __builtin_fmaf(r[e], yv[e], s2[e]); }
         }
     };
     // HB_DEPTH groups in flight per wave
@@ -951,34 +1000,38 @@ __global__ __launch_bounds__(256) void head_bn_bwd_kernel(const unsigned* __rest
             }
         }
         if constexpr (WGRAD) {
-            __shared__ float wred[4][HB_WCOLS];
-            // D: lane (pl, g) holds rows ci = 16 cs + 4 g + j of column k = 16 ks + pl
+            float (*wred)[WCOLS] = reinterpret_cast<float (*)[WCOLS]>(hb_tiles);
+            __syncthreads();         // every wave has read its last fragments
+            // D: lane (pl, g) holds rows ci = 16 cs + 4 g + j of column k = 16 kb + pl
 #pragma unroll
             for (int cs = 0; cs < 2; ++cs)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int k = ks * 16 + pl, ci = cs * 16 + 4 * g + j;
-                        if (k < 18) wred[wv][ci * 18 + k] = wacc[cs][ks][j];
+                        const int k = kb * 16 + pl, ci = cs * 16 + 4 * g + j;
+                        if (k < 9 * NCP) wred[wv][ci * (9 * NCP) + k] = wacc[cs][kb][j];
                     }
-            const float b0 = row16_sum(bsum0), b1 = row16_sum(bsum1);
-            if (lane == 16) { wred[wv][576] = b0; wred[wv][577] = b1; }
+#pragma unroll
+            for (int c = 0; c < NCP; ++c) {
+                const float b = row16_sum(bsum[c]);
+                if (lane == (NCP == 2 ? 16 : 0)) wred[wv][32 * 9 * NCP + c] = b;
+            }
             __syncthreads();
-            for (int i = threadIdx.x; i < HB_WCOLS; i += 256)
+            for (int i = threadIdx.x; i < WCOLS; i += 256)
                 wpartial[(size_t)i * gridDim.x + blockIdx.x] = wred[0][i] + wred[1][i] + wred[2][i] + wred[3][i];
         }
     }
 }
 
-// blocks [0, bn_blocks = 32 or 0): the BatchNorm's channels (bn_bwd_finalize_coef_body); then HB_WCOLS blocks: one column of the head's
+// blocks [0, bn_blocks = 32 or 0): the BatchNorm's channels (bn_bwd_finalize_coef_body); then hb_wcols(NCP) blocks: one column of the head's
 // weight-gradient partials each -> dw [n_class][32][3][3] / db [n_class] (+)=
 __global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ partial, int bpg, int G,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, float inv_m, float* __restrict__ coef,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                                                 const float* __restrict__ wpartial, int NC, float* __restrict__ dw,
-                                                                float* __restrict__ db, int bn_blocks) {
+                                                                float* __restrict__ db, int bn_blocks, int NCP) {
     if ((int)blockIdx.x < bn_blocks) {
         bn_bwd_finalize_coef_body(blockIdx.x, partial, bpg, G, 32, mean, invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate);
         return;
@@ -993,11 +1046,12 @@ __global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __r
     __syncthreads();
     if (threadIdx.x == 0) {
         const float v = red[0] + red[1] + red[2] + red[3];
-        if (col < 576) {
-            const int ci = col / 18, k = col % 18, tap = k >> 1, co = k & 1;
+        const int kk = 9 * NCP;
+        if (col < 32 * kk) {
+            const int ci = col / kk, k = col % kk, tap = k / NCP, co = k % NCP;
             if (co < NC) { float* o = dw + ((size_t)co * 32 + ci) * 9 + tap; *o = accumulate ? *o + v : v; }
-        } else if (col - 576 < NC) {
-            float* o = db + (col - 576);
+        } else if (col - 32 * kk < NC) {
+            float* o = db + (col - 32 * kk);
             *o = accumulate ? *o + v : v;
         }
     }
@@ -1235,23 +1289,27 @@ static int head_bn_bwd_apply_blocks(int N, int H, int W, int groups) {
     return (int)(bpg * groups);
 }
 extern "C" long dh_head_bn_bwd_workspace_size(int N, int H, int W, int groups) {
-    return ((long)dh_head_bn_bwd_blocks(N, H, W, groups) * (2 * 32 + HB_WCOLS) + (long)groups * 3 * 32) * 4;
+    return ((long)dh_head_bn_bwd_blocks(N, H, W, groups) * (2 * 32 + HB_WCOLS_MAX) + (long)groups * 3 * 32) * 4;
 }
-// dw [n_class][32][3][3] / db [n_class] (both or neither; (+)= when accumulate): the head convolution's own weight and bias
-// gradient, taken by pass 1 from the loads it makes anyway (input = relu(BatchNorm(y)), rounded to bf16 as the convolution saw it)
-// dtype = DH_DTYPE_BF16: one word per pixel; DH_DTYPE_F32 (the split-product mode): two (bf16 heads, bf16 remainders)
+// dtype = DH_DTYPE_BF16: one plane of class pieces per pixel; DH_DTYPE_F32 (the split-product mode): two (bf16 heads, bf16 remainders).
+// A piece holds 2 classes (NC <= 2: one word) or 8 (3 <= NC <= 8: 16 bytes): dlp is [N][H + 2][W + 2][planes][piece].
 extern "C" int dh_head_dlogits_pack(int dtype, const float* dlogits_nchw, int N, int NC, int H, int W, void* dlp, void* stream) {
-    DH_REQUIRE(NC >= 1 && NC <= 2 && dlogits_nchw && dlp, "head_dlogits_pack: n_class=%d", NC);
+    DH_REQUIRE(NC >= 1 && NC <= 8 && dlogits_nchw && dlp, "head_dlogits_pack: n_class=%d", NC);
     const long n = (long)N * (H + 2) * (W + 2);
-    DH_REQUIRE(n * 8 < (1L << 31), "head_dlogits_pack: %d x %d x %d does not fit a 2 GiB buffer descriptor", N, H, W);
-    if (dtype == DH_DTYPE_BF16)
-        hipLaunchKernelGGL(head_dlogits_pack_kernel<1>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), dlogits_nchw, (unsigned*)dlp, N, NC, H, W);
-    else
-        hipLaunchKernelGGL(head_dlogits_pack_kernel<2>, dim3(ew_grid(n, 256)), dim3(256), 0, ST(stream), dlogits_nchw, (unsigned*)dlp, N, NC, H, W);
+    DH_REQUIRE(n * (NC <= 2 ? 8 : 32) < (1L << 31), "head_dlogits_pack: %d x %d x %d does not fit a 2 GiB buffer descriptor", N, H, W);
+    const dim3 grid(ew_grid(n, 256));
+    hipStream_t st = ST(stream);
+    if (dtype == DH_DTYPE_BF16) {
+        if (NC <= 2) hipLaunchKernelGGL((head_dlogits_pack_kernel<1, 2>), grid, dim3(256), 0, st, dlogits_nchw, (unsigned*)dlp, N, NC, H, W);
+        else hipLaunchKernelGGL((head_dlogits_pack_kernel<1, 8>), grid, dim3(256), 0, st, dlogits_nchw, (unsigned*)dlp, N, NC, H, W);
+    } else {
+        if (NC <= 2) hipLaunchKernelGGL((head_dlogits_pack_kernel<2, 2>), grid, dim3(256), 0, st, dlogits_nchw, (unsigned*)dlp, N, NC, H, W);
+        else hipLaunchKernelGGL((head_dlogits_pack_kernel<2, 8>), grid, dim3(256), 0, st, dlogits_nchw, (unsigned*)dlp, N, NC, H, W);
+    }
     DH_CHECK_LAUNCH("head_dlogits_pack");
     return 0;
 }
-template <typename T>
+template <typename T, int NCP>
 static int head_bn_bwd_launch(const void* dlp, const float* w_oihw, int NC, const void* y, const float* mask_scale, const float* mask_shift,
                               const float* mean, const float* invstd, const float* gamma, int groups, void* dx, float* dgamma, float* dbeta,
                               float* dw, float* db, int accumulate, int N, int H, int W, void* workspace, hipStream_t st) {
@@ -1261,63 +1319,61 @@ static int head_bn_bwd_launch(const void* dlp, const float* w_oihw, int NC, cons
     float* wpartial = coef + (size_t)groups * 3 * 32;
     const float inv_m = (float)(1.0 / ((double)N * H * W / groups));
     if (dw) {
-        hipLaunchKernelGGL((head_bn_bwd_kernel<T, 0, true>), dim3(grid), dim3(256), 0, st, (const unsigned*)dlp, w_oihw, N, H, W, NC,
+        hipLaunchKernelGGL((head_bn_bwd_kernel<T, 0, true, NCP>), dim3(grid), dim3(256), 0, st, (const unsigned*)dlp, w_oihw, N, H, W, NC,
                            (const T*)y, mask_scale, mask_shift, groups, partial, (const float*)nullptr, (T*)nullptr, wpartial);
-        hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(32 + HB_WCOLS), dim3(256), 0, st, partial, grid / groups, groups, mean,
-                           invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate, wpartial, NC, dw, db, 32);
+        hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(32 + hb_wcols(NCP)), dim3(256), 0, st, partial, grid / groups, groups, mean,
+                           invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate, wpartial, NC, dw, db, 32, NCP);
     } else {
-        hipLaunchKernelGGL((head_bn_bwd_kernel<T, 0, false>), dim3(grid), dim3(256), 0, st, (const unsigned*)dlp, w_oihw, N, H, W, NC,
+        hipLaunchKernelGGL((head_bn_bwd_kernel<T, 0, false, NCP>), dim3(grid), dim3(256), 0, st, (const unsigned*)dlp, w_oihw, N, H, W, NC,
                            (const T*)y, mask_scale, mask_shift, groups, partial, (const float*)nullptr, (T*)nullptr, (float*)nullptr);
         hipLaunchKernelGGL(bn_bwd_finalize_coef_kernel, dim3(32), dim3(64 * groups), 0, st, partial, grid / groups, groups, 32, mean,
                            invstd, gamma, inv_m, coef, dgamma, dbeta, accumulate);
     }
-    hipLaunchKernelGGL((head_bn_bwd_kernel<T, 1, false>), dim3(grid2), dim3(256), 0, st, (const unsigned*)dlp, w_oihw, N, H, W, NC,
+    hipLaunchKernelGGL((head_bn_bwd_kernel<T, 1, false, NCP>), dim3(grid2), dim3(256), 0, st, (const unsigned*)dlp, w_oihw, N, H, W, NC,
                        (const T*)y, mask_scale, mask_shift, groups, (float*)nullptr, coef, (T*)dx, (float*)nullptr);
     return 0;
 }
-// dtype = DH_DTYPE_F32: y / dx fp32, dlp two words per pixel, every product as three split bf16 products (the bf16x3 mode's
-// arithmetic: callers use it only under dh_set_f32_mma_mode != 0)
+// dtype = DH_DTYPE_F32: y / dx fp32, dlp with two planes, every product as three split bf16 products (the bf16x3 mode's
+// arithmetic: callers use it only under dh_set_f32_mma_mode != 0).  n_class <= 8 (3 .. 8: the 8-class piece form of dlp).
 extern "C" int dh_head_bn_bwd(int dtype, const void* dlp, const float* w_oihw, int NC, const void* y, const float* mask_scale,
                               const float* mask_shift, const float* mean, const float* invstd, const float* gamma, int groups,
                               void* dx, float* dgamma, float* dbeta, float* dw, float* db, int accumulate, int N, int H, int W,
                               void* workspace, void* stream) {
-    DH_REQUIRE(NC >= 1 && NC <= 2 && dlp && y && mask_scale && mask_shift && mean && invstd && gamma && dx && dgamma && dbeta && workspace,
+    DH_REQUIRE(NC >= 1 && NC <= 8 && dlp && y && mask_scale && mask_shift && mean && invstd && gamma && dx && dgamma && dbeta && workspace,
                "head_bn_bwd: bad arguments (n_class=%d)", NC);
     DH_REQUIRE((dw == nullptr) == (db == nullptr), "head_bn_bwd: dw and db come together");
     const int grid = dh_head_bn_bwd_blocks(N, H, W, groups);
     DH_REQUIRE(grid > 0 && groups <= BN_MAXG, "head_bn_bwd: %d images do not split into %d groups", N, groups);
     DH_REQUIRE((long)N * H * W * 128 < (1L << 31), "head_bn_bwd: %d x %d x %d pixels x 128 bytes do not fit a 2 GiB buffer descriptor", N, H, W);
-    if (dtype == DH_DTYPE_BF16)
-        head_bn_bwd_launch<bf16>(dlp, w_oihw, NC, y, mask_scale, mask_shift, mean, invstd, gamma, groups, dx, dgamma, dbeta, dw, db,
-                                 accumulate, N, H, W, workspace, ST(stream));
-    else
-        head_bn_bwd_launch<float>(dlp, w_oihw, NC, y, mask_scale, mask_shift, mean, invstd, gamma, groups, dx, dgamma, dbeta, dw, db,
-                                  accumulate, N, H, W, workspace, ST(stream));
+#define HB_GO(T, NCP) head_bn_bwd_launch<T, NCP>(dlp, w_oihw, NC, y, mask_scale, mask_shift, mean, invstd, gamma, groups, dx, dgamma, dbeta, \
+                                                 dw, db, accumulate, N, H, W, workspace, ST(stream))
+    if (dtype == DH_DTYPE_BF16) { if (NC <= 2) HB_GO(bf16, 2); else HB_GO(bf16, 8); }
+    else { if (NC <= 2) HB_GO(float, 2); else HB_GO(float, 8); }
+#undef HB_GO
     DH_CHECK_LAUNCH("head_bn_bwd");
     return 0;
 }
 
-// The class head behind a ReLU (classifier(conv_layer2(...)), models/networks.py:1351-1355; n_class <= 2): dx = (relu_out
-// > 0) * (W^T (*) dlogits) [N][H][W][32] -- dh_head_dgrad3x3_relu from the zero-bordered pair map dlp (dh_head_dlogits_pack) --
+// The class head behind a ReLU (classifier(conv_layer2(...)), models/networks.py:1351-1355; n_class <= 8): dx = (relu_out
+// > 0) * (W^T (*) dlogits) [N][H][W][32] -- dh_head_dgrad3x3_relu from the zero-bordered class map dlp (dh_head_dlogits_pack) --
 // AND the head's own weight / bias gradient dw [n_class][32][3][3] / db [n_class] ((+)= when accumulate) from the same loads
-// of relu_out, which is the head's input (head_bn_bwd_kernel<T, 2, true>).  workspace: dh_head_bn_bwd_workspace_size(N, H, W, 1).
+// of relu_out, which is the head's input (head_bn_bwd_kernel<T, 2, true, .>).  workspace: dh_head_bn_bwd_workspace_size(N, H, W, 1).
 extern "C" int dh_head_relu_bwd(int dtype, const void* dlp, const float* w_oihw, int NC, const void* relu_out, void* dx, float* dw,
                                 float* db, int accumulate, int N, int H, int W, void* workspace, void* stream) {
-    DH_REQUIRE(NC >= 1 && NC <= 2 && dlp && relu_out && dx && dw && db && workspace, "head_relu_bwd: bad arguments (n_class=%d)", NC);
+    DH_REQUIRE(NC >= 1 && NC <= 8 && dlp && relu_out && dx && dw && db && workspace, "head_relu_bwd: bad arguments (n_class=%d)", NC);
     DH_REQUIRE((long)N * H * W * 128 < (1L << 31), "head_relu_bwd: %d x %d x %d pixels x 128 bytes do not fit a 2 GiB buffer descriptor", N, H, W);
     const int grid = dh_head_bn_bwd_blocks(N, H, W, 1);
     float* wpartial = reinterpret_cast<float*>(workspace);
-    if (dtype == DH_DTYPE_BF16)
-        hipLaunchKernelGGL((head_bn_bwd_kernel<bf16, 2, true>), dim3(grid), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
-                           (const bf16*)relu_out, (const float*)nullptr, (const float*)nullptr, 1, (float*)nullptr, (const float*)nullptr,
-                           (bf16*)dx, wpartial);
-    else
-        hipLaunchKernelGGL((head_bn_bwd_kernel<float, 2, true>), dim3(grid), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, N, H, W, NC,
-                           (const float*)relu_out, (const float*)nullptr, (const float*)nullptr, 1, (float*)nullptr, (const float*)nullptr,
-                           (float*)dx, wpartial);
-    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(HB_WCOLS), dim3(256), 0, ST(stream), (const float*)nullptr, grid, 1,
+#define HR_GO(T, NCP) hipLaunchKernelGGL((head_bn_bwd_kernel<T, 2, true, NCP>), dim3(grid), dim3(256), 0, ST(stream), (const unsigned*)dlp, w_oihw, \
+                                         N, H, W, NC, (const T*)relu_out, (const float*)nullptr, (const float*)nullptr, 1, (float*)nullptr,          \
+                                         (const float*)nullptr, (T*)dx, wpartial)
+    if (dtype == DH_DTYPE_BF16) { if (NC <= 2) HR_GO(bf16, 2); else HR_GO(bf16, 8); }
+    else { if (NC <= 2) HR_GO(float, 2); else HR_GO(float, 8); }
+#undef HR_GO
+    const int ncp = NC <= 2 ? 2 : 8;
+    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(hb_wcols(ncp)), dim3(256), 0, ST(stream), (const float*)nullptr, grid, 1,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr,
-                       (float*)nullptr, accumulate, wpartial, NC, dw, db, 0);
+                       (float*)nullptr, accumulate, wpartial, NC, dw, db, 0, ncp);
     DH_CHECK_LAUNCH("head_relu_bwd");
     return 0;
 }

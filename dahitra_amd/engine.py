@@ -1003,7 +1003,7 @@ class Engine:
                 # a 32-channel K-chunk (4x the bytes, written and read twice), and take the data gradient with the
                 # dedicated head kernel instead of an MFMA convolution over 94 % zeros
                 # bf16, or the fp32 pipeline in its split-product mode (three bf16 products: NOT the exact fp32 mode)
-                fuse = self.fused_head_bn and ncls <= 2 and self.g[wkey].is_contiguous() and \
+                fuse = self.fused_head_bn and ncls <= 8 and self.g[wkey].is_contiguous() and \
                     (self.dtype == torch.bfloat16 or (self.dtype == torch.float32 and ops.get_f32_mma_mode() != 0))
                 if head_bn is not None and fuse:
                     # data gradient, weight and bias gradient of this convolution: all inside the BatchNorm backward behind it

@@ -1070,20 +1070,26 @@ def head_dgrad3x3_bn(dy, w_oihw, ncls, y, scale, shift, mean, invstd, groups):
 
 
 def head_dlogits_pack(dl_nchw, dtype=torch.bfloat16):
-    """dlogits [N, ncls <= 2, H, W] fp32 -> [N, H + 2, W + 2] bf16 pairs (int32) inside a border of zeros, for head_bn_bwd /
-    head_relu_bwd; dtype float32 (the bf16x3 mode): [N, H + 2, W + 2, 2], the pairs of bf16 heads and of bf16 remainders"""
+    """dlogits [N, ncls <= 8, H, W] fp32 -> the zero-bordered class map of head_bn_bwd / head_relu_bwd (int32 words of bf16
+    pairs, _head_dlp_shape); dtype float32 (the bf16x3 mode): the plane of bf16 heads, then the plane of bf16 remainders"""
     N, C, H, W = dl_nchw.shape
-    assert C <= 2 and dl_nchw.dtype == torch.float32
-    shape = (N, H + 2, W + 2) if dtype == torch.bfloat16 else (N, H + 2, W + 2, 2)
-    dlp = torch.empty(shape, dtype=torch.int32, device=dl_nchw.device)
+    assert C <= 8 and dl_nchw.dtype == torch.float32 and dl_nchw.is_contiguous()
+    dlp = torch.empty(_head_dlp_shape(N, H, W, C, dtype), dtype=torch.int32, device=dl_nchw.device)
     _call("dh_head_dlogits_pack", _ci(_DT[dtype]), P(dl_nchw), _ci(N), _ci(C), _ci(H), _ci(W), P(dlp), S())
     return dlp
 
 
-def _head_dlp_ok(dlp, y):
+def _head_dlp_shape(N, H, W, ncls, dtype):
+    """[N, H + 2, W + 2] + (planes * words per piece,): a piece = 2 classes (one word) for ncls <= 2, 8 classes (4 words) above;
+    one plane for bf16, two (heads, remainders) for the split fp32 form"""
+    words = (1 if ncls <= 2 else 4) * (1 if dtype == torch.bfloat16 else 2)
+    return (N, H + 2, W + 2) if words == 1 else (N, H + 2, W + 2, words)
+
+
+def _head_dlp_ok(dlp, y, ncls):
     N, H, W, C = y.shape
-    want = (N, H + 2, W + 2) if y.dtype == torch.bfloat16 else (N, H + 2, W + 2, 2)
-    return dlp.dtype == torch.int32 and tuple(dlp.shape) == want and C == 32 and y.dtype in (torch.bfloat16, torch.float32)
+    return dlp.dtype == torch.int32 and tuple(dlp.shape) == _head_dlp_shape(N, H, W, ncls, y.dtype) and C == 32 and \
+        y.dtype in (torch.bfloat16, torch.float32)
 
 
 def head_bn_bwd(dlp, w_oihw, ncls, y, scale, shift, mean, invstd, gamma, dgamma, dbeta, groups, accumulate=True, dw=None, db=None):
@@ -1093,7 +1099,7 @@ def head_bn_bwd(dlp, w_oihw, ncls, y, scale, shift, mean, invstd, gamma, dgamma,
     mode's arithmetic (three split bf16 products) -- not for the exact fp32 mode"""
     assert (dw is None) == (db is None) and (dw is None or (dw.shape == (ncls, 32, 3, 3) and dw.is_contiguous()))
     N, H, W, _ = y.shape
-    assert w_oihw.shape == (ncls, 32, 3, 3) and ncls <= 2 and _head_dlp_ok(dlp, y)
+    assert w_oihw.shape == (ncls, 32, 3, 3) and ncls <= 8 and _head_dlp_ok(dlp, y, ncls)
     dx = torch.empty_like(y)
     ws = workspace(_lib.lib().dh_head_bn_bwd_workspace_size(N, H, W, groups), y.device)
     with _Prof("bn_bwd", 0, _nb(y, y, dx)):
@@ -1106,7 +1112,7 @@ def head_relu_bwd(dlp, w_oihw, ncls, relu_out, dw, db, accumulate=True):
     """class head behind a ReLU: data gradient (masked by relu_out > 0) + the head's weight / bias gradient in one pass over
     relu_out [N,H,W,32] (dh_head_relu_bwd); dlp = head_dlogits_pack(dlogits, relu_out.dtype)"""
     N, H, W, C = relu_out.shape
-    assert w_oihw.shape == (ncls, 32, 3, 3) and ncls <= 2 and _head_dlp_ok(dlp, relu_out) and dw.shape == (ncls, 32, 3, 3) and \
+    assert w_oihw.shape == (ncls, 32, 3, 3) and ncls <= 8 and _head_dlp_ok(dlp, relu_out, ncls) and dw.shape == (ncls, 32, 3, 3) and \
         dw.is_contiguous()
     dx = torch.empty_like(relu_out)
     ws = workspace(_lib.lib().dh_head_bn_bwd_workspace_size(N, H, W, 1), dlp.device)

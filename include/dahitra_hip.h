@@ -340,10 +340,11 @@ int dh_head_dgrad3x3_bn(const void* dy, const float* w_oihw, int NC, const void*
                         const float* mean, const float* invstd, int groups, void* g, float* partial, int N, int H, int W,
                         void* stream);
 /* The head's data gradient AND the backward of the BatchNorm + ReLU behind its 32 channels in two passes that never write the
- * gradient in between (bf16, n_class <= 2; the autograd of Conv2d(32, n_class, 3) <- ReLU <- BatchNorm2d(32),
+ * gradient in between (n_class <= 8; the autograd of Conv2d(32, n_class, 3) <- ReLU <- BatchNorm2d(32),
  * models/help_funcs.py:7-15): each pass forms g = (y * mask_scale + mask_shift > 0) * (W^T (*) dlogits) on the matrix cores from
- * dlp, the dlogits as [N][H + 2][W + 2] bf16 pairs inside a border of zeros (dh_head_dlogits_pack from the loss kernel's
- * [N][n_class][H][W] fp32: a tap is one 4-byte load, no bounds test); pass 1 reduces (sum g, sum g y), pass 2 writes dx = gamma invstd (g - (s1 + xhat s2) / M).  y
+ * dlp, the dlogits as [N][H + 2][W + 2] class pieces inside a border of zeros (dh_head_dlogits_pack from the loss kernel's
+ * [N][n_class][H][W] fp32: a piece = 2 classes in one word for n_class <= 2, 8 classes in 16 bytes for 3 .. 8 -- the five-class
+ * heads of the xBD nets; a tap is one load, no bounds test); pass 1 reduces (sum g, sum g y), pass 2 writes dx = gamma invstd (g - (s1 + xhat s2) / M).  y
  * [N][H][W][32] pre-BatchNorm, statistics [groups][32] as dh_bn_finalize left them; dgamma / dbeta [32] (+)= when accumulate. */
 int dh_head_bn_bwd_blocks(int N, int H, int W, int groups);
 long dh_head_bn_bwd_workspace_size(int N, int H, int W, int groups);
@@ -356,7 +357,7 @@ int dh_head_dlogits_pack(int dtype, const float* dlogits_nchw, int N, int NC, in
 int dh_head_bn_bwd(int dtype, const void* dlp, const float* w_oihw, int NC, const void* y, const float* mask_scale, const float* mask_shift,
                    const float* mean, const float* invstd, const float* gamma, int groups, void* dx, float* dgamma, float* dbeta,
                    float* dw, float* db, int accumulate, int N, int H, int W, void* workspace, void* stream);
-/* The class head behind a ReLU (classifier(conv_layer2(...)), models/networks.py:1351-1355; bf16, n_class <= 2): the data gradient
+/* The class head behind a ReLU (classifier(conv_layer2(...)), models/networks.py:1351-1355; n_class <= 8): the data gradient
  * dx = (relu_out > 0) * (W^T (*) dlogits) of dh_head_dgrad3x3_relu, from the pair map dlp (dh_head_dlogits_pack), AND the head's
  * own weight / bias gradient dw [n_class][32][3][3] / db [n_class] ((+)= when accumulate) from the same loads of relu_out --
  * the head's input.  workspace: dh_head_bn_bwd_workspace_size(N, H, W, 1) bytes. */

@@ -698,6 +698,9 @@ def test_head_data_gradient_kernel(ops, dtype, ncls):
     dict(n=4, h=17, w=23, groups=2, ncls=2),         # ragged 16-pixel groups, two statistics groups
     dict(n=1, h=3, w=5, groups=1, ncls=1),           # fewer pixels than one wave round
     dict(n=8, h=128, w=128, groups=1, ncls=2),       # more 16-pixel groups than waves: the two-group rounds wrap
+    dict(n=2, h=20, w=36, groups=1, ncls=5),         # 3 .. 8 classes: the 8-class piece form (k = tap * 8 + class, three K steps)
+    dict(n=4, h=17, w=23, groups=2, ncls=8),
+    dict(n=2, h=64, w=64, groups=1, ncls=3),
 ])
 @pytest.mark.parametrize("dtype,mma", [pytest.param(torch.bfloat16, 0, id="bfloat16"), pytest.param(torch.float32, 1, id="bf16x3")])
 def test_head_gradient_recomputed_inside_the_batchnorm_backward(ops, cfg, dtype, mma):
@@ -734,10 +737,11 @@ def test_head_gradient_recomputed_inside_the_batchnorm_backward(ops, cfg, dtype,
     dl = ops.nchw_to_nhwc(dlog.float().cuda().contiguous(), dtype, cpad=8)
     dlp = ops.head_dlogits_pack(dlog.float().cuda().contiguous(), dtype)
     assert int(dlp[:, 0].abs().max()) == 0 and int(dlp[:, :, -1].abs().max()) == 0          # the border of zeros
+    pc = 2 if ncls <= 2 else 8          # classes per piece
     if dtype == torch.bfloat16:
-        assert torch.equal(dlp[:, 1:-1, 1:-1].contiguous().view(torch.bfloat16).view(N, H, W, 2)[..., :ncls], dl[..., :ncls])
+        assert torch.equal(dlp[:, 1:-1, 1:-1].contiguous().view(torch.bfloat16).view(N, H, W, pc)[..., :ncls], dl[..., :ncls])
     else:       # heads + remainders = the fp32 values to 2^-17
-        pl = dlp[:, 1:-1, 1:-1].contiguous().view(torch.bfloat16).view(N, H, W, 2, 2).float().sum(3)
+        pl = dlp[:, 1:-1, 1:-1].contiguous().view(torch.bfloat16).view(N, H, W, 2, pc).float().sum(3)
         assert float((pl[..., :ncls] - dl[..., :ncls]).abs().max()) <= 2.0 ** -16 * float(dl.abs().max())
     dg1, db1 = torch.zeros(32, device="cuda"), torch.zeros(32, device="cuda")
     dx1 = ops.head_bn_bwd(dlp, w.cuda(), ncls, yd, scale, shift, mean, invstd, gamma.cuda(), dg1, db1, G, accumulate=False)
@@ -1703,7 +1707,8 @@ def test_head_data_gradient_with_the_relu_in_front_of_it_folded_in(ops):
     assert float((got != 0).float().mean()) < float((ops.head_dgrad3x3(dl, w, 2) != 0).float().mean())
 
 
-@pytest.mark.parametrize("cfg", [dict(n=3, h=64, w=48, ncls=2), dict(n=2, h=9, w=21, ncls=1), dict(n=8, h=128, w=128, ncls=2)])
+@pytest.mark.parametrize("cfg", [dict(n=3, h=64, w=48, ncls=2), dict(n=2, h=9, w=21, ncls=1), dict(n=8, h=128, w=128, ncls=2),
+                                 dict(n=2, h=40, w=24, ncls=5), dict(n=1, h=64, w=64, ncls=8)])
 @pytest.mark.parametrize("dtype,mma", [pytest.param(torch.bfloat16, 0, id="bfloat16"), pytest.param(torch.float32, 1, id="bf16x3")])
 def test_head_behind_a_relu_data_weight_and_bias_gradient_in_one_pass(ops, cfg, dtype, mma):
     """dh_head_relu_bwd against torch autograd of conv2d(relu_out, W, b) with the gradient masked by relu_out > 0
@@ -1721,8 +1726,8 @@ def test_head_behind_a_relu_data_weight_and_bias_gradient_in_one_pass(ops, cfg, 
     close(nchw(dx), pre.grad, dtype, "dx vs autograd", factor=2.0)
     close(dw - 0.25, w.grad, dtype, "dw vs autograd", factor=2.0)
     close(db - 1.0, hb.grad, dtype, "db vs autograd", factor=2.0)
-    dl = ops.nchw_to_nhwc(dlog.float().cuda().contiguous(), dtype, cpad=8 if dtype == torch.bfloat16 else 4)
-    if dtype == torch.bfloat16:
+    dl = ops.nchw_to_nhwc(dlog.float().cuda().contiguous(), dtype, cpad=8 if (dtype == torch.bfloat16 or ncls > 4) else 4)
+    if dtype == torch.bfloat16 and ncls <= 2:
         assert torch.equal(dx, ops.head_dgrad3x3(dl, w.detach().cuda(), ncls, relu_out=out))      # same products, same order
     else:
         close(dx, ops.head_dgrad3x3(dl, w.detach().cuda(), ncls, relu_out=out).cpu(), dtype, "dx vs head_dgrad3x3", factor=1.0)
