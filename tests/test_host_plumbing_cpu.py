@@ -166,8 +166,9 @@ def test_staged_levels_advance_in_rounds_and_launch_between_them(monkeypatch):
     log = []
 
     class FakeBatch:
-        def __init__(self, decoder=False):
+        def __init__(self, decoder=False, ew=False):
             log.append(("open", decoder))
+            assert ew is False           # (only the _level generators, which pause after their element-wise calls, ask for it)
 
         def __enter__(self):
             return self
