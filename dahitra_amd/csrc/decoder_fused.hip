@@ -19,11 +19,14 @@
 // MFMA through wave-private LDS tiles read back with ds_read_b64_tr_b16; biases / LayerNorm gradients are
 // lane-local sums.  Per-workgroup partials are combined deterministically by dec_bwd_finalize_kernel.
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
+#include <unordered_map>
 
 namespace {
 
 constexpr int D = 32;
+constexpr int DEC_MAXDEPTH = 8;      // layers of a stack launch (the backward keeps every layer's parameter vectors in LDS)
 // Weight rows sit in LDS in FRAGMENT ORDER: the eight elements kappa(g, 0..7) a lane multiplies are contiguous, so an A
 // fragment is ONE ds_read_b128.  (The first form read them as two 8-byte halves 32 bytes apart; hipcc merged each pair into a
 // ds_read2_b64, which is banked modulo 32 dwords over 16 CONTIGUOUS lanes and runs at half the ds_read_b128 rate: at the
@@ -41,7 +44,10 @@ struct DecArgs {
     const bf16 *w1, *w2, *w1T, *w2T;          // [MLP][32], [32][MLP], [32][MLP], [MLP][32]
     const float *g1, *be1, *bo, *g2, *be2, *fb1, *fb2;
     float* partial;              // bwd: [nblk][PSZ]
-    int rows_per_image, rows_per_block;
+    // A workgroup takes `upb` consecutive 64-row UNITS of one image (one 16-pixel sub-tile per wave and unit); an image is cut
+    // into bpi = ceil(units per image / upb) blocks, the last of them shorter: any upb serves, not only the powers of two that
+    // divide an image, so the host can size the blocks of every job of a launch for the launch as a whole (dec_balance)
+    int rows_per_image, upb, bpi;
     long rows;
     float eps;
     // A whole decoder STACK in one launch (depth > 1; dh_decoder_stack_fwd / _bwd).  A pixel row attends to the tokens of its
@@ -92,6 +98,23 @@ __device__ __forceinline__ float group4_sum(float v) {
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// a wave-uniform pointer, forced into scalar registers
+template <typename T> __device__ __forceinline__ const T* uniform_ptr(const T* q) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
+}
+
+// 8 bytes at (uniform base, 32-bit lane offset), as GLOBAL accesses: a pointer rebuilt from scalar halves is generic to the
+// compiler, and a flat load counts on lgkmcnt as well -- every LDS wait of the chain would wait for x / dy of the next sub-tile
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) u32x2 gu32x2;
+__device__ __forceinline__ uint2 gld8(const char* base, unsigned off) {
+    const u32x2 v = *(const gu32x2*)(base + off);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void gst8(char* base, unsigned off, uint2 v) { *(gu32x2*)(base + off) = u32x2{v.x, v.y}; }
+
 // cooperative copy of a [ROWS][COLS] bf16 matrix (global, dense) into LDS with pitch, every 32-column block in fragment order:
 // logical columns 4q .. 4q+3 (q = 0..7) land at position 8 (q & 3) + 4 (q >> 2), i.e. kappa(g, e) at g * 8 + e.
 // 32-column rows: a ds_write_b64 lane group (16 lanes, banks modulo 32 dwords) covers two rows of 16 dwords, and rows r, r + 1
@@ -102,16 +125,19 @@ __device__ __forceinline__ float group4_sum(float v) {
 // matrix: seven L2 round trips in a row at the head of every layer of the backward (3.1 k of the ~9 k cycles a workgroup spends
 // per layer outside its sub-tile loop, tools/dec_timeline.py), four in the forward.
 template <int ROWS, int COLS> struct StageRegs { uint2 v[(ROWS * COLS / 4 + 255) / 256]; };
+// (the matrix base is wave-uniform: as scalar base + 32-bit lane offset a load needs ONE address register, and the matrices of one
+// shape share it -- as 64-bit lane addresses the seven matrices of the backward held 14 registers across the layer loop)
 template <int ROWS, int COLS>
 __device__ __forceinline__ void stage_ld(StageRegs<ROWS, COLS>& s, const bf16* src, int tid) {
     constexpr int VEC = COLS / 4, N = (ROWS * VEC + 255) / 256;
+    const char* base = reinterpret_cast<const char*>(uniform_ptr(src));
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const int i = tid + k * 256;
         if (ROWS * VEC % 256 == 0 || i < ROWS * VEC) {
             const int r0 = i / VEC, q = i % VEC;
             const int r = VEC == 8 ? ((r0 & ~3) | ((r0 & 1) << 1) | ((r0 >> 1) & 1)) : r0;
-            s.v[k] = *reinterpret_cast<const uint2*>(src + (size_t)r * COLS + q * 4);
+            s.v[k] = gld8(base, (unsigned)((r * COLS + q * 4) * 2));
         }
     }
 }
@@ -147,13 +173,6 @@ __device__ __forceinline__ float gelu_fast(float z, float* dgelu) {
         *dgelu = s + (z * ap) * (s - s * s);
     }
     return z * s;
-}
-
-// a wave-uniform pointer, forced into scalar registers
-template <typename T> __device__ __forceinline__ const T* uniform_ptr(const T* q) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
 }
 
 struct LNres {
@@ -192,9 +211,9 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& p, const int bid) {
     constexpr int W2P = wide_pitch(MLP);
     __shared__ __attribute__((aligned(16))) unsigned short sKq[32 * WP], sVoT[32 * WP], sW1[MLP * WP], sW2[32 * W2P];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
-    const long row0 = (long)bid * p.rows_per_block;
-    const int img = (int)(row0 / p.rows_per_image);
-    const int nsub = p.rows_per_block / 64;          // 16-pixel sub-tiles per wave
+    const int img = bid / p.bpi, u0 = (bid - img * p.bpi) * p.upb;
+    const long row0 = (long)img * p.rows_per_image + (long)u0 * 64;
+    const int nsub = min(p.upb, (p.rows_per_image >> 6) - u0);          // 16-pixel sub-tiles per wave
     const int depth = STACK ? p.depth : 1;
 #pragma unroll 1
     for (int l = 0; l < depth; ++l) {
@@ -326,6 +345,15 @@ __global__ __launch_bounds__(256) void dec_fwd_multi_kernel(DecMulti m) {
 template <int MLP> struct PL {
     static constexpr int W1 = 0, W2 = MLP * D, B1 = 2 * MLP * D, B2 = B1 + MLP, BO = B2 + D, G1 = BO + D, BE1 = G1 + D,
                          G2 = BE1 + D, BE2 = G2 + D, KQ = BE2 + D, VOT = KQ + 32 * D, SIZE = VOT + D * 32;
+    // The four matrix regions hold their 16 x 16 accumulator blocks as the backward's lanes own them (dec_bwd_body): float n of
+    // a region = accumulator n >> 8, lane (n >> 2) & 63 (pixel-column pl = lane & 15, row group g = lane >> 4), register j = n & 3,
+    // i.e. element (row block * 16 + g * 4 + j, column block * 16 + pl).  Accumulator order: W1 [MLP][D] and KQ / VOT [32][32]
+    // (row block, column block) row-major over 2 column blocks; W2 [D][MLP] over MLP / 16 column blocks.
+    // Returns the row-major index of float n of a region whose matrix has `cols` columns.
+    __host__ __device__ static int matrix_index(int n, int cols) {
+        const int acc = n >> 8, ln = (n >> 2) & 63, j = n & 3, nb = cols / 16;
+        return ((acc / nb) * 16 + (ln >> 4) * 4 + j) * cols + (acc % nb) * 16 + (ln & 15);
+    }
 };
 constexpr int lds_pitch(int row_bytes) { return ((row_bytes / 32) & 1) ? row_bytes : row_bytes + 32; }
 
@@ -354,6 +382,26 @@ __device__ __forceinline__ s16x4 tile_frag16(const unsigned char* tile, int pitc
 __device__ __forceinline__ f32x4 mma16(s16x4 a, s16x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
+// row16_sum (common.h) of four values at once, as v_add_f32_dpp: through __builtin_amdgcn_update_dpp every step came out as
+// v_mov_b32 (the `old` operand) + v_mov_b32_dpp + v_add -- 2.5 instructions where one does -- and its zero register, reloaded from
+// scratch, drew an s_waitcnt vmcnt(0) in front of the sums that drained the next layer's operands in flight.  The four chains are
+// interleaved step by step: a DPP read wants two wait states after the write of its source, the three other chains provide them
+// (the s_nop covers the producers of the inputs, which the assembler cannot see).
+__device__ __forceinline__ void row16_sum4(float (&v)[4]) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+// workgroup barrier that orders LDS traffic only: __syncthreads() is also a fence for global memory, i.e. s_waitcnt vmcnt(0) --
+// it would drain the next layer's operands requested just before it (dec_bwd_body: prefetch)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void lds4(const float* p, float (&o)[4]) {
     const float4 v = *reinterpret_cast<const float4*>(p);
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -393,57 +441,83 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
     unsigned short* sW2T = sW1 + MLP * WP;                  // [MLP][32]
     unsigned short* sW1T = sW2T + MLP * WP;                 // [32][MLP]
     constexpr int W1TP = wide_pitch(MLP);
-    float* sPar = reinterpret_cast<float*>(sW1T + 32 * W1TP);           // g1, be1, bo, g2, be2, fb1[MLP]: 5 * 32 + MLP floats
-    unsigned char* tiles = reinterpret_cast<unsigned char*>(sPar + 5 * 32 + MLP);
+    unsigned char* tiles = reinterpret_cast<unsigned char*>(sW1T + 32 * W1TP);
+    // g1, be1, bo, g2, be2, fb1[MLP] of EVERY layer (PARW floats each), staged once, behind the area the final combine reuses
+    constexpr int PARW = 5 * 32 + MLP;
+    float* sParAll = reinterpret_cast<float*>(smem + (size_t)P::SIZE * 4 * 4);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
     unsigned char* tA0 = tiles + (wv * 4 + 0) * TILE;
     unsigned char* tB0 = tiles + (wv * 4 + 1) * TILE;
     unsigned char* tA1 = tiles + (wv * 4 + 2) * TILE;
     unsigned char* tB1 = tiles + (wv * 4 + 3) * TILE;
-    const long row0 = (long)bid * p.rows_per_block;
-    const int img = (int)(row0 / p.rows_per_image);
+    const int img = bid / p.bpi, u0 = (bid - img * p.bpi) * p.upb;
+    const long row0 = (long)img * p.rows_per_image + (long)u0 * 64;
+    const int nsub = min(p.upb, (p.rows_per_image >> 6) - u0);         // 16-pixel sub-tiles per wave
     const int depth = STACK ? p.depth : 1;
+    // Everything a layer needs from memory before its first sub-tile -- the seven matrices, the parameter vectors, x / dy of
+    // sub-tile 0 -- is REQUESTED while the layer before it (in backward order) parks and reduces its parameter-gradient partials,
+    // and committed to LDS after that layer's last barrier.  (Requested at the head of the layer the wait was exposed in every
+    // layer of every workgroup: ~6 us per layer and workgroup outside the sub-tile loop against 3.5 us per sub-tile,
+    // tools/dec_stack_bench.py at 128 / 256 / 512 rows per workgroup; profiles/r06a.)
+    struct {
+        StageRegs<32, D> rKq, rVoT, rVo, rKqT;
+        StageRegs<MLP, D> rW1, rW2T;
+        StageRegs<D, MLP> rW1T;
+    } pre;
+    uint2 nx[2], ndy[2];
+    // this lane's 8 bytes of a row, relative to the first row of the workgroup's sub-tile round (byte offset; the rounds of a
+    // wave lie 4 x 16 rows = 4096 bytes apart: a scalar step)
+    const unsigned loff = (unsigned)(((wv * 16 + pl) * D + g * 4) * 2);
+    auto prefetch = [&](int l, int ll) {
+        // (the staging addresses are derived from a value the optimiser cannot see through: hoisted out of the layer loop they
+        // would sit in -- or be spilled from -- registers the sub-tile loop needs)
+        int ts = tid;
+        if constexpr (STACK) asm volatile("" : "+v"(ts));
+        const long ko = STACK ? l * p.kq_ls : 0, wo = STACK ? l * p.w_ls : 0;
+        // x / dy of this wave's first sub-tile.  (dy of a lower layer is what this very lane stored to dwork in the layer
+        // above: program order, same address.)
+        {
+            const char* xb = reinterpret_cast<const char*>(uniform_ptr((STACK ? (l == 0 ? p.x : p.ys + (l - 1) * p.act_ls) : p.x) + row0 * D));
+            const char* gb = reinterpret_cast<const char*>(uniform_ptr((STACK ? (ll == 0 ? p.dy : p.dwork) : p.dy) + row0 * D));
+            nx[0] = gld8(xb, loff);
+            nx[1] = gld8(xb, loff + 32);
+            ndy[0] = gld8(gb, loff);
+            ndy[1] = gld8(gb, loff + 32);
+        }
+        stage_ld(pre.rKq, p.kq + ko + (size_t)img * 32 * D, ts);
+        stage_ld(pre.rVoT, p.voT + ko + (size_t)img * D * 32, ts);
+        stage_ld(pre.rVo, p.vo + ko + (size_t)img * 32 * D, ts);
+        stage_ld(pre.rKqT, p.kqT + ko + (size_t)img * D * 32, ts);
+        stage_ld(pre.rW1, p.w1 + wo, ts);
+        stage_ld(pre.rW2T, p.w2T + wo, ts);
+        stage_ld(pre.rW1T, p.w1T + wo, ts);
+    };
+    prefetch(depth - 1, 0);
+    for (int i = tid; i < depth * PARW; i += 256) {
+        const int l = i / PARW, k = i - l * PARW, c = k & 31;
+        const float* src = k < 32 ? p.g1 : k < 64 ? p.be1 : k < 96 ? p.bo : k < 128 ? p.g2 : k < 160 ? p.be2 : p.fb1;
+        sParAll[i] = src[(STACK ? l * p.par_ls : 0) + (k < 160 ? c : k - 160)];
+    }
     // the layers of a stack, last to first (DecArgs::depth): this workgroup's rows only, no synchronisation with any other
 #pragma unroll 1
     for (int ll = 0; ll < depth; ++ll) {
     const int l = depth - 1 - ll;
     // (uniform values, pinned to scalar registers: the kernel sits at its 256-register budget)
-    const bf16* x_in = STACK ? uniform_ptr(l == 0 ? p.x : p.ys + (l - 1) * p.act_ls) : p.x;
-    const bf16* dy_in = STACK ? uniform_ptr(ll == 0 ? p.dy : p.dwork) : p.dy;
-    bf16* dx_out = STACK ? const_cast<bf16*>(uniform_ptr(l == 0 ? p.y : p.dwork)) : p.y;
-    if (ll) __syncthreads();                                 // the partial sums of the layer before have left the LDS
+    const char* x_in = reinterpret_cast<const char*>(uniform_ptr((STACK ? (l == 0 ? p.x : p.ys + (l - 1) * p.act_ls) : p.x) + row0 * D));
+    const char* dy_in = reinterpret_cast<const char*>(uniform_ptr((STACK ? (ll == 0 ? p.dy : p.dwork) : p.dy) + row0 * D));
+    char* dx_out = const_cast<char*>(reinterpret_cast<const char*>(uniform_ptr((STACK ? (l == 0 ? p.y : p.dwork) : p.y) + row0 * D)));
+    if (ll) lds_barrier();                                   // the partial sums of the layer before have left the LDS
     {
-        // (the staging addresses are derived from a value the optimiser cannot see through: hoisted out of the layer loop they
-        // would sit in -- or be spilled from -- registers the sub-tile loop needs)
-        int ts = tid;
-        if constexpr (STACK) asm volatile("" : "+v"(ts));
-        const long ko = STACK ? l * p.kq_ls : 0, wo = STACK ? l * p.w_ls : 0, po = STACK ? l * p.par_ls : 0;
-        {
-            StageRegs<32, D> rKq, rVoT, rVo, rKqT;
-            StageRegs<MLP, D> rW1, rW2T;
-            StageRegs<D, MLP> rW1T;
-            stage_ld(rKq, p.kq + ko + (size_t)img * 32 * D, ts);
-            stage_ld(rVoT, p.voT + ko + (size_t)img * D * 32, ts);
-            stage_ld(rVo, p.vo + ko + (size_t)img * 32 * D, ts);
-            stage_ld(rKqT, p.kqT + ko + (size_t)img * D * 32, ts);
-            stage_ld(rW1, p.w1 + wo, ts);
-            stage_ld(rW2T, p.w2T + wo, ts);
-            stage_ld(rW1T, p.w1T + wo, ts);
-            stage_st(sKq, WP, rKq, ts);
-            stage_st(sVoT, WP, rVoT, ts);
-            stage_st(sVo, WP, rVo, ts);
-            stage_st(sKqT, WP, rKqT, ts);
-            stage_st(sW1, WP, rW1, ts);
-            stage_st(sW2T, WP, rW2T, ts);
-            stage_st(sW1T, W1TP, rW1T, ts);
-        }
-        if (ts < 32) {
-            sPar[ts] = p.g1[po + ts]; sPar[32 + ts] = p.be1[po + ts]; sPar[64 + ts] = p.bo[po + ts];
-            sPar[96 + ts] = p.g2[po + ts]; sPar[128 + ts] = p.be2[po + ts];
-        }
-        if (ts < MLP) sPar[160 + ts] = p.fb1[po + ts];
+        stage_st(sKq, WP, pre.rKq, tid);
+        stage_st(sVoT, WP, pre.rVoT, tid);
+        stage_st(sVo, WP, pre.rVo, tid);
+        stage_st(sKqT, WP, pre.rKqT, tid);
+        stage_st(sW1, WP, pre.rW1, tid);
+        stage_st(sW2T, WP, pre.rW2T, tid);
+        stage_st(sW1T, W1TP, pre.rW1T, tid);
     }
     __syncthreads();
+    const float* sPar = sParAll + l * PARW;
     const float *cG1 = sPar, *cBe1 = sPar + 32, *cBo = sPar + 64, *cG2 = sPar + 96, *cBe2 = sPar + 128, *cFb1 = sPar + 160;
 
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -452,38 +526,39 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
     for (int a = 0; a < NM; ++a) { aW1[a][0] = aW1[a][1] = zero4; aW2[0][a] = aW2[1][a] = zero4; }
 #pragma unroll
     for (int a = 0; a < 2; ++a) { aKq[a][0] = aKq[a][1] = zero4; aVoT[a][0] = aVoT[a][1] = zero4; }
-    float sb1[NM][4], sb2[2][4], sbo[2][4], sg1[2][4], sbe1[2][4], sg2[2][4], sbe2[2][4];
+    // The bias gradients db1 = sum_p dz, db2 = sum_p dy, dbo = sum_p dx1 are sums over pixels of operands that sit in the
+    // transposed tiles anyway: one more K = 16 MFMA per fragment against a ones matrix leaves them in an accumulator (every
+    // column the same; the lanes of column 0 write them) -- no vector add per sub-tile, no cross-lane reduction at the end of
+    // the layer (24 of the loop's ~460 vector instructions, 96 of the 224 row-sum steps).  The LayerNorm gradients are sums of
+    // fp32 products that no tile holds: lane-local as before.
+    f32x4 sb1[NM], sb2[2], sbo[2];
 #pragma unroll
-    for (int a = 0; a < NM; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sb1[a][j] = 0.f;
+    for (int a = 0; a < NM; ++a) sb1[a] = zero4;
+    sb2[0] = sb2[1] = sbo[0] = sbo[1] = zero4;
+    const s16x4 ones4 = s16x4{(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};
+    float sg1[2][4], sbe1[2][4], sg2[2][4], sbe2[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { sb2[a][j] = sbo[a][j] = sg1[a][j] = sbe1[a][j] = sg2[a][j] = sbe2[a][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) { sg1[a][j] = sbe1[a][j] = sg2[a][j] = sbe2[a][j] = 0.f; }
 
-    const int nsub = p.rows_per_block / 64;                 // 16-pixel sub-tiles per wave
     // x / dy of the NEXT sub-tile are requested while this one is computed (raw bf16: 8 registers): the loop is one
     // dependent chain, a load at its head would be waited for at HBM latency in every round
-    uint2 nx[2], ndy[2];
     auto request = [&](int it) {
-        const long row = row0 + (it * 4 + wv) * 16 + pl;
-        const bf16* xr = x_in + row * D;
-        const bf16* gr = dy_in + row * D;
-        nx[0] = *reinterpret_cast<const uint2*>(xr + g * 4);
-        nx[1] = *reinterpret_cast<const uint2*>(xr + 16 + g * 4);
-        ndy[0] = *reinterpret_cast<const uint2*>(gr + g * 4);
-        ndy[1] = *reinterpret_cast<const uint2*>(gr + 16 + g * 4);
+        const char* xr = x_in + (size_t)it * 4096;
+        const char* gr = dy_in + (size_t)it * 4096;
+        nx[0] = gld8(xr, loff);
+        nx[1] = gld8(xr, loff + 32);
+        ndy[0] = gld8(gr, loff);
+        ndy[1] = gld8(gr, loff + 32);
     };
     auto widen = [](const uint2& u, float (&o)[4]) {
         o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
         o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
     };
-    request(0);
     DEC_T(10);
 #pragma unroll 1
     for (int it = 0; it < nsub; ++it) {
-        const long row = row0 + (it * 4 + wv) * 16 + pl;
         float x[2][4], dy[2][4];
         widen(nx[0], x[0]);
         widen(nx[1], x[1]);
@@ -586,7 +661,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
         for (int s = 0; s < NM; ++s) {
             f32x4 dh = mma(lds_a(sW2T, WP, s * 16 + pl, 0, g), kdy, zero4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { dz[s][j] = dh[j] * dg[s][j]; sb1[s][j] += dz[s][j]; }
+            for (int j = 0; j < 4; ++j) dz[s][j] = dh[j] * dg[s][j];
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) kdz[q] = pack8(dz[2 * q], dz[2 * q + 1]);
@@ -600,6 +675,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
             const s16x4 fa = tile_frag16(tA0, TP32, sc, pl, g);
 #pragma unroll
             for (int sm = 0; sm < NM; ++sm) aW2[sc][sm] = mma16(fa, tile_frag16(tB0, TPM, sm, pl, g), aW2[sc][sm]);
+            sb2[sc] = mma16(fa, ones4, sb2[sc]);
         }
         f32x4 dl2[2] = {zero4, zero4};
 #pragma unroll
@@ -615,7 +691,6 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
             for (int j = 0; j < 4; ++j) {
                 sg2[s][j] += dl2[s][j] * xh2[s][j];
                 sbe2[s][j] += dl2[s][j];
-                sb2[s][j] += dy[s][j];
                 gh[s][j] = dl2[s][j] * gam2[s][j];
                 sa += gh[s][j];
                 sbb += gh[s][j] * xh2[s][j];
@@ -627,7 +702,6 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 dx1[s][j] = n2.rstd * (gh[s][j] - (sa + xh2[s][j] * sbb) * (1.f / D)) + dy[s][j];
-                sbo[s][j] += dx1[s][j];
             }
         const s16x8 kdx1 = pack8(dx1[0], dx1[1]);
         DEC_T(6);
@@ -636,6 +710,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
             const s16x4 fa = tile_frag16(tA1, TPM, sm, pl, g);
 #pragma unroll
             for (int sc = 0; sc < 2; ++sc) aW1[sm][sc] = mma16(fa, tile_frag16(tB1, TP32, sc, pl, g), aW1[sm][sc]);
+            sb1[sm] = mma16(fa, ones4, sb1[sm]);
         }
         // dVoT[c][hl] += dx1^T attn  (tiles A0 / B0 again: the reads of dW2 were issued above, LDS runs a wave's operations in order)
         tile_put(tA0, TP32, pl, 0, g, kdx1);
@@ -661,6 +736,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
             const s16x4 fa = tile_frag16(tA0, TP32, sr, pl, g);
 #pragma unroll
             for (int sc = 0; sc < 2; ++sc) aVoT[sr][sc] = mma16(fa, tile_frag16(tB0, TP32, sc, pl, g), aVoT[sr][sc]);
+            sbo[sr] = mma16(fa, ones4, sbo[sr]);
         }
         float dxn[2][4];
 #pragma unroll
@@ -682,13 +758,13 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
             }
         sa = group4_sum(sa);
         sbb = group4_sum(sbb);
-        bf16* dxr = dx_out + row * D;
+        char* dxr = dx_out + (size_t)it * 4096;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float r[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = n1.rstd * (gh[s][j] - (sa + xh1[s][j] * sbb) * (1.f / D)) + dx1[s][j];
-            st4(dxr + s * 16 + g * 4, r);
+            gst8(dxr, loff + s * 32, make_uint2(f2bf2(r[0], r[1]), f2bf2(r[2], r[3])));
         }
         DEC_T(8);
 #pragma unroll
@@ -705,65 +781,62 @@ __device__ __forceinline__ void dec_bwd_body(const DecArgs& p, const int bid, un
     // are added in wave order.  (Measured alternatives: turn-taking through ONE slot with ds_bpermute butterflies inside each
     // wave's turn took 40 of the first kernel's 70 us; two slots with waves 2 / 3 ADDING onto waves 0 / 1 -- 130 dependent
     // LDS read-modify-writes the compiler may not reorder -- 17k of this kernel's 74k cycles, tools/dec_timeline.py.)
+    // The matrices are parked AS THE ACCUMULATORS HOLD THEM: accumulator a of a matrix at floats [a * 256 + lane * 4 + j] of its
+    // region -- one conflict-free ds_write_b128 per accumulator and lane (in row-major order they were four 4-byte writes D
+    // floats apart each) -- and the partial keeps that order in memory; dec_bwd_finalize_kernel decodes it (PL::matrix_index).
     __syncthreads();                                         // every wave is done with the weights / tiles
     DEC_T(12);
     float* red = reinterpret_cast<float*>(smem);             // [4][P::SIZE] floats (host sized the LDS)
     float* mine = red + (size_t)wv * P::SIZE;
+    {
+        f32x4* m4 = reinterpret_cast<f32x4*>(mine);
 #pragma unroll
-    for (int sm = 0; sm < NM; ++sm)
+        for (int sm = 0; sm < NM; ++sm)
 #pragma unroll
-        for (int sc = 0; sc < 2; ++sc)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                mine[P::W1 + (sm * 16 + g * 4 + j) * D + sc * 16 + pl] = aW1[sm][sc][j];
-                mine[P::W2 + (sc * 16 + g * 4 + j) * MLP + sm * 16 + pl] = aW2[sc][sm][j];
+            for (int sc = 0; sc < 2; ++sc) {
+                m4[P::W1 / 4 + (sm * 2 + sc) * 64 + lane] = aW1[sm][sc];
+                m4[P::W2 / 4 + (sc * NM + sm) * 64 + lane] = aW2[sc][sm];
             }
 #pragma unroll
-    for (int sr = 0; sr < 2; ++sr)
+        for (int sr = 0; sr < 2; ++sr)
 #pragma unroll
-        for (int sc = 0; sc < 2; ++sc)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                mine[P::KQ + (sr * 16 + g * 4 + j) * D + sc * 16 + pl] = aKq[sr][sc][j];
-                mine[P::VOT + (sr * 16 + g * 4 + j) * 32 + sc * 16 + pl] = aVoT[sr][sc][j];
+            for (int sc = 0; sc < 2; ++sc) {
+                m4[P::KQ / 4 + (sr * 2 + sc) * 64 + lane] = aKq[sr][sc];
+                m4[P::VOT / 4 + (sr * 2 + sc) * 64 + lane] = aVoT[sr][sc];
             }
+    }
     DEC_T(13);
+    // (here: the 64 accumulator registers are free, and from here to the head of the next layer only LDS-ordering barriers)
+    if (ll + 1 < depth) prefetch(l - 1, ll + 1);             // in flight while the column sums are reduced, the partial written
     // lane-local column sums: over the 16 pixel lanes of the row.  All the DPP row sums first (independent chains, full
     // exec), then ONE masked block of 16-byte stores: a masked 4-byte store after every sum toggled exec 56 times and took
     // 3.9k of the workgroup's 65k cycles (tools/dec_timeline.py)
 #pragma unroll
-    for (int s = 0; s < NM; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sb1[s][j] = row16_sum(sb1[s][j]);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sb2[s][j] = row16_sum(sb2[s][j]); sbo[s][j] = row16_sum(sbo[s][j]); sg1[s][j] = row16_sum(sg1[s][j]);
-            sbe1[s][j] = row16_sum(sbe1[s][j]); sg2[s][j] = row16_sum(sg2[s][j]); sbe2[s][j] = row16_sum(sbe2[s][j]);
-        }
+    for (int s = 0; s < 2; ++s) { row16_sum4(sg1[s]); row16_sum4(sbe1[s]); row16_sum4(sg2[s]); row16_sum4(sbe2[s]); }
     if (pl == 0) {
         auto put4 = [&](int off, const float (&v)[4]) { *reinterpret_cast<float4*>(mine + off + g * 4) = make_float4(v[0], v[1], v[2], v[3]); };
+        auto putv = [&](int off, const f32x4& v) { *reinterpret_cast<f32x4*>(mine + off + g * 4) = v; };
 #pragma unroll
-        for (int s = 0; s < NM; ++s) put4(P::B1 + s * 16, sb1[s]);
+        for (int s = 0; s < NM; ++s) putv(P::B1 + s * 16, sb1[s]);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            put4(P::B2 + s * 16, sb2[s]); put4(P::BO + s * 16, sbo[s]); put4(P::G1 + s * 16, sg1[s]);
+            putv(P::B2 + s * 16, sb2[s]); putv(P::BO + s * 16, sbo[s]); put4(P::G1 + s * 16, sg1[s]);
             put4(P::BE1 + s * 16, sbe1[s]); put4(P::G2 + s * 16, sg2[s]); put4(P::BE2 + s * 16, sbe2[s]);
         }
     }
     DEC_T(14);
-    __syncthreads();
+    lds_barrier();
     DEC_T(15);
-    float* out = p.partial + (STACK ? l * p.part_ls : 0) + (size_t)bid * P::SIZE;
-    for (int i = tid; i < P::SIZE; i += 256)
-        out[i] = ((red[i] + red[P::SIZE + i]) + red[2 * P::SIZE + i]) + red[3 * P::SIZE + i];
+    f32x4* out = reinterpret_cast<f32x4*>(p.partial + (STACK ? l * p.part_ls : 0) + (size_t)bid * P::SIZE);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(red);
+    for (int i = tid; i < P::SIZE / 4; i += 256)
+        out[i] = ((r4[i] + r4[P::SIZE / 4 + i]) + r4[2 * (P::SIZE / 4) + i]) + r4[3 * (P::SIZE / 4) + i];
     }   // layers
 #ifdef DEC_TIMING
     DEC_T(11);
     if (tid == 0 && blockIdx.x < 4096) {
         for (int k = 0; k < 16; ++k) g_dect[blockIdx.x * 20 + k] = t_acc[k];
-        g_dect[blockIdx.x * 20 + 16] = p.rows_per_block / 64;
+        g_dect[blockIdx.x * 20 + 16] = p.upb;
         g_dect[blockIdx.x * 20 + 17] = t_last - t_begin;
     }
 #endif
@@ -837,8 +910,8 @@ __device__ __forceinline__ void dec_bwd_finalize_body(const FinArgs& fa, const u
             for (int r = 0; r < 8; ++r) t += red[r][lane];
             float* dst;
             int o;
-            if (i < P::W2) { dst = dw1; o = i - P::W1; }
-            else if (i < P::B1) { dst = dw2; o = i - P::W2; }
+            if (i < P::W2) { dst = dw1; o = P::matrix_index(i - P::W1, D); }
+            else if (i < P::B1) { dst = dw2; o = P::matrix_index(i - P::W2, MLP); }
             else if (i < P::B2) { dst = db1; o = i - P::B1; }
             else if (i < P::BO) { dst = db2; o = i - P::B2; }
             else if (i < P::G1) { dst = dbo; o = i - P::BO; }
@@ -856,8 +929,8 @@ __device__ __forceinline__ void dec_bwd_finalize_body(const FinArgs& fa, const u
             const float* src = partial + (size_t)img * bpi * P::SIZE + P::KQ + e;
 #pragma unroll 4
             for (int b = 0; b < bpi; ++b) s += src[(size_t)b * P::SIZE];       // (order kept: loads issue ahead, adds in order)
-            if (e < 1024) dkq[(size_t)img * 1024 + e] = s;
-            else dvoT[(size_t)img * 1024 + e - 1024] = s;
+            if (e < 1024) dkq[(size_t)img * 1024 + P::matrix_index(e, D)] = s;
+            else dvoT[(size_t)img * 1024 + P::matrix_index(e - 1024, 32)] = s;
         }
     }
 }
@@ -896,16 +969,132 @@ __global__ __launch_bounds__(256) void dec_bwd_finalize_multi_kernel(FinMulti m)
 }
 
 template <int MLP> size_t bwd_lds_bytes() {
-    const size_t w = (size_t)(4 * 32 * WP + 2 * MLP * WP + 32 * wide_pitch(MLP)) * 2 + (size_t)(5 * 32 + MLP) * 4;
+    const size_t w = (size_t)(4 * 32 * WP + 2 * MLP * WP + 32 * wide_pitch(MLP)) * 2;
     const size_t tile = 16 * (size_t)(lds_pitch(MLP * 2) > lds_pitch(64) ? lds_pitch(MLP * 2) : lds_pitch(64));
     size_t t = w + 16 * tile;                                 // four tiles per wave
-    if (t < (size_t)PL<MLP>::SIZE * 4 * 4) t = (size_t)PL<MLP>::SIZE * 4 * 4;      // the four wave slots of the final combine
-    return t;
+    static_assert((size_t)(4 * 32 * WP + 2 * MLP * WP + 32 * wide_pitch(MLP)) * 2 + 16 * 16 * (size_t)(lds_pitch(MLP * 2) > lds_pitch(64) ? lds_pitch(MLP * 2) : lds_pitch(64))
+                  <= (size_t)PL<MLP>::SIZE * 4 * 4, "the parameter table sits behind the four wave slots of the final combine");
+    t = (size_t)PL<MLP>::SIZE * 4 * 4;                        // the four wave slots of the final combine (>= weights + tiles)
+    return t + (size_t)DEC_MAXDEPTH * (5 * 32 + MLP) * 4;     // + the parameter vectors of every layer
 }
 
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
+
+
+// ---- block sizes (DecArgs::upb / bpi) ---------------------------------------------------------------------------------
+// A plan cuts every image of a job into blocks of `upb` 64-row units.  The DEFAULT plans are the fixed rules of the first builds
+// (powers of two that divide an image); launches that hold several jobs (dh_decoder_batch_*: DAHiTra's three levels) are
+// re-planned as a whole by dec_balance when they are issued.
+struct DecPlan { int upb, bpi; };
+static inline DecPlan dec_plan(int rows_per_image, int upb) {
+    const int upi = rows_per_image / 64;
+    upb = std::max(1, std::min(upb, upi));
+    return DecPlan{upb, (upi + upb - 1) / upb};
+}
+// rows per forward workgroup: every workgroup stages the image's kq / voT and the two weight matrices first (a quarter of the
+// instructions of a 128-row workgroup), so large launches take more rows per workgroup while >= 1024 workgroups remain
+static inline DecPlan dec_fwd_default(long rows, int rows_per_image) {
+    static const long minblk = getenv("DAHITRA_DEC_FWD_MINBLK") ? atol(getenv("DAHITRA_DEC_FWD_MINBLK")) : 1024;
+    int rpb = 512;
+    while (rpb > 64 && (rows_per_image % rpb || rows / rpb < minblk)) rpb >>= 1;
+    return dec_plan(rows_per_image, rpb / 64);
+}
+// rows per backward workgroup: 512 at most (every workgroup writes a PL::SIZE partial), fewer while that leaves less than 256
+// workgroups; per layer a workgroup spends several microseconds outside its sub-tile loop (parking and reducing the
+// parameter-gradient partials, writing them: tools/dec_timeline.py), so the small levels of a staged launch want rows, not
+// workgroups.  MLP = 64 (one workgroup per CU at 344 registers: 256 resident) takes up to 1024 rows: 256 workgroups in ONE
+// round instead of 512 in two (+0.3 % on the s4 step; DAHITRA_DEC_BWD_MAXRPB64=512 restores the old rule)
+static inline DecPlan dec_bwd_default(long rows, int rows_per_image, int mlp) {
+    static const long minblk = getenv("DAHITRA_DEC_BWD_MINBLK") ? atol(getenv("DAHITRA_DEC_BWD_MINBLK")) : 256;
+    static const int max64 = getenv("DAHITRA_DEC_BWD_MAXRPB64") ? atoi(getenv("DAHITRA_DEC_BWD_MAXRPB64")) : 1024;
+    int rpb = mlp == 64 ? max64 : 512;
+    while (rpb > 64 && (rows_per_image % rpb || rows / rpb < minblk)) rpb >>= 1;
+    return dec_plan(rows_per_image, rpb / 64);
+}
+// the smallest backward block a re-plan may choose: the partial workspace (dh_decoder_layer_bwd_workspace_size) is sized for it
+static inline int dec_bwd_min_upb(long rows, int rows_per_image, int mlp) {
+    return std::max(1, dec_bwd_default(rows, rows_per_image, mlp).upb / 2);
+}
+// The plan a backward launch used, by the address of its partial workspace: the finalize (a separate call, possibly issued in a
+// later round of the batch) sums exactly the blocks that launch wrote.
+static thread_local std::unordered_map<const void*, DecPlan> g_bwd_plan;
+static void dec_remember_plan(const void* partial, DecPlan pl) {
+    if (g_bwd_plan.size() > 512) g_bwd_plan.clear();
+    g_bwd_plan[partial] = pl;
+}
+static DecPlan dec_recall_plan(const void* partial, long rows, int rows_per_image, int mlp) {
+    auto it = g_bwd_plan.find(partial);
+    return it != g_bwd_plan.end() ? it->second : dec_bwd_default(rows, rows_per_image, mlp);
+}
+
+// dec_balance: block sizes for ALL jobs of one launch (dh_decoder_batch_*: DAHiTra's three levels).  These kernels are bound by
+// the vector ALU of a CU, not by resident workgroups: one backward workgroup alone on a CU takes ~1.75 us per 64-row unit, two
+// share it at ~3.5 us each -- the same throughput -- while every (workgroup, layer) pays for staging the layer's matrices and for
+// parking, reducing and writing 17 KB of parameter-gradient partials.  So: as FEW, LARGE blocks as keep every CU busy.  The job
+// with the most work gets the largest upb <= 16 that still leaves `per_cu` blocks per CU (backward 1, forward 2: its
+// workgroups are short and three are resident); the smaller jobs ride along with blocks no smaller than that.  Measured on the
+// three levels of a DAHiTra pass (tools/dec_stack_bench.py, profiles/r06a_dec_stack.txt): backward 293 -> 289 us (64 images) and
+// 166 -> 160 us (32 images) against the per-job rules, forward 146 -> 139 and 76 -> 69 us; a list-scheduling model over
+// resident-workgroup slots (the first form of this function) predicted gains it did not deliver, because a slot is not a
+// processor.  DAHITRA_DEC_BALANCE=0: the per-job default plans.  DAHITRA_DEC_UPB_FWD / _BWD=<n>: that block size for every job.
+static void dec_balance(DecMulti& m, int n, bool bwd, int mlp, int cus) {
+    static const bool on = !(getenv("DAHITRA_DEC_BALANCE") && atoi(getenv("DAHITRA_DEC_BALANCE")) == 0);
+    static const int force_f = getenv("DAHITRA_DEC_UPB_FWD") ? atoi(getenv("DAHITRA_DEC_UPB_FWD")) : 0;
+    static const int force_b = getenv("DAHITRA_DEC_UPB_BWD") ? atoi(getenv("DAHITRA_DEC_UPB_BWD")) : 0;
+    int upb[DEC_MAXJ], lo[DEC_MAXJ];
+    int big = 0;
+    for (int j = 0; j < n; ++j) {
+        const DecArgs& a = m.a[j];
+        upb[j] = a.upb;
+        lo[j] = bwd ? dec_bwd_min_upb(a.rows, a.rows_per_image, mlp) : 1;
+        if ((a.depth > 1 ? a.depth : 1) * a.rows > (m.a[big].depth > 1 ? m.a[big].depth : 1) * m.a[big].rows) big = j;
+    }
+    const int force = bwd ? force_b : force_f;
+    if (force > 0) {
+        for (int j = 0; j < n; ++j) upb[j] = std::max(lo[j], std::min(force, m.a[j].rows_per_image / 64));
+    } else if (on && cus > 0 && n > 1) {
+        const DecArgs& a = m.a[big];
+        const int upi = a.rows_per_image / 64, images = (int)(a.rows / a.rows_per_image), want = (bwd ? 1 : 2) * cus;
+        // (block sizes that divide an image: a ragged last block is a short workgroup next to long ones)
+        int u = std::min(16, upi);
+        while (u > lo[big] && (upi % u || images * (upi / u) < want)) --u;
+        if (upi % u) u = upb[big];
+        upb[big] = u;
+        for (int j = 0; j < n; ++j)
+            if (j != big) {
+                int v = std::min(std::min(16, m.a[j].rows_per_image / 64), std::max(u, 4));
+                while (v > lo[j] && (m.a[j].rows_per_image / 64) % v) --v;
+                upb[j] = std::max(lo[j], v);
+            }
+    }
+    if (getenv("DAHITRA_DEC_BALANCE_LOG")) {
+        fprintf(stderr, "[dec_balance] %s mlp %d cus %d:", bwd ? "bwd" : "fwd", mlp, cus);
+        for (int j = 0; j < n; ++j)
+            fprintf(stderr, "  (%ld x %d rows, depth %d) upb %d -> %d", m.a[j].rows / m.a[j].rows_per_image, m.a[j].rows_per_image, m.a[j].depth,
+                    m.a[j].upb, upb[j]);
+        fprintf(stderr, "\n");
+    }
+    m.first[0] = 0;
+    for (int j = 0; j < n; ++j) {
+        const DecPlan pl = dec_plan(m.a[j].rows_per_image, upb[j]);
+        m.a[j].upb = pl.upb;
+        m.a[j].bpi = pl.bpi;
+        m.first[j + 1] = m.first[j] + (int)(m.a[j].rows / m.a[j].rows_per_image) * pl.bpi;
+        if (bwd) dec_remember_plan(m.a[j].partial, pl);
+    }
+}
+static int dec_cus() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 0;
+        if (!cus) (void)hipGetLastError();
+    }
+    return cus;
+}
 
 // ---- batched launches (dh_decoder_batch_*): index 0 = MLP 32, 1 = MLP 64; forward and backward each
 struct DecBatch {      // index = (MLP == 64) + 2 * (layer-fused stack)
@@ -936,8 +1125,8 @@ static void dec_sort_jobs(DecMulti& m, int n) {
     for (int j = 0; j < n; ++j) nblk[j] = m.first[j + 1] - m.first[j];
     for (int i = 1; i < n; ++i)                      // insertion sort, stable: n <= 4
         for (int j = i; j > 0; --j) {
-            const long wa = (long)(m.a[j].depth > 1 ? m.a[j].depth : 1) * m.a[j].rows_per_block;
-            const long wb = (long)(m.a[j - 1].depth > 1 ? m.a[j - 1].depth : 1) * m.a[j - 1].rows_per_block;
+            const long wa = (long)(m.a[j].depth > 1 ? m.a[j].depth : 1) * m.a[j].upb;
+            const long wb = (long)(m.a[j - 1].depth > 1 ? m.a[j - 1].depth : 1) * m.a[j - 1].upb;
             if (wa <= wb) break;
             const DecArgs t = m.a[j]; m.a[j] = m.a[j - 1]; m.a[j - 1] = t;
             const int tb = nblk[j]; nblk[j] = nblk[j - 1]; nblk[j - 1] = tb;
@@ -949,6 +1138,8 @@ static int dec_batch_flush(hipStream_t st) {
     DecBatch& d = g_db;
     static bool m32 = false, m64 = false, s32 = false, s64 = false;
     for (int k = 0; k < 4; ++k) {
+        if (d.nf[k]) dec_balance(d.f[k], d.nf[k], false, k & 1 ? 64 : 32, dec_cus());
+        if (d.nb[k]) dec_balance(d.b[k], d.nb[k], true, k & 1 ? 64 : 32, dec_cus());
         if (d.nf[k] > 1) dec_sort_jobs(d.f[k], d.nf[k]);
         if (d.nb[k] > 1) dec_sort_jobs(d.b[k], d.nb[k]);
         if (d.nf[k]) {
@@ -982,6 +1173,12 @@ static int dec_batch_flush(hipStream_t st) {
     for (int k = 0; k < 2; ++k)
         if (d.nfin[k]) {
             d.fin[k].n = d.nfin[k];
+            for (int j = 0; j < d.nfin[k]; ++j) {        // the blocks the backward launch of this workspace wrote (dec_balance)
+                FinArgs& fa = d.fin[k].a[j];
+                const int images = d.fin[k].gy[j] - 1;
+                const auto it = g_bwd_plan.find(fa.partial);
+                if (it != g_bwd_plan.end()) { fa.bpi = it->second.bpi; fa.nblk = images * fa.bpi; }
+            }
             const int total = d.fin[k].first[d.nfin[k]];
             if (k == 0) hipLaunchKernelGGL(dec_bwd_finalize_multi_kernel<32>, dim3(total), dim3(256), 0, st, d.fin[k]);
             else hipLaunchKernelGGL(dec_bwd_finalize_multi_kernel<64>, dim3(total), dim3(256), 0, st, d.fin[k]);
@@ -1007,15 +1204,6 @@ static int check_common(long rows, int rows_per_image, int mlp) {
     return 0;
 }
 
-// rows per forward workgroup: every workgroup stages the image's kq / voT and the two weight matrices first (a quarter of the
-// instructions of a 128-row workgroup), so large launches take more rows per workgroup while >= 1024 workgroups remain
-static inline int dec_fwd_rows_per_block(long rows, int rows_per_image) {
-    static const long minblk = getenv("DAHITRA_DEC_FWD_MINBLK") ? atol(getenv("DAHITRA_DEC_FWD_MINBLK")) : 1024;
-    int rpb = 512;
-    while (rpb > 64 && (rows_per_image % rpb || rows / rpb < minblk)) rpb >>= 1;
-    return rpb;
-}
-
 // x, y: [rows][32] bf16; kq, voT: [images][32][32] bf16 (dh_xattn_prep_fwd); w1: [mlp][32], w2: [32][mlp] bf16
 extern "C" int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, const void* voT, const float* ln1_g,
                                     const float* ln1_b, const float* bo, const float* ln2_g, const float* ln2_b,
@@ -1027,28 +1215,14 @@ extern "C" int dh_decoder_layer_fwd(const void* x, void* y, const void* kq, cons
     a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2;
     a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
     a.rows_per_image = rows_per_image; a.rows = rows; a.eps = eps;
-    a.rows_per_block = dec_fwd_rows_per_block(rows, rows_per_image);
-    const int grid = (int)(rows / a.rows_per_block);
+    const DecPlan pl = dec_fwd_default(rows, rows_per_image);
+    a.upb = pl.upb; a.bpi = pl.bpi;
+    const int grid = (int)(rows / rows_per_image) * pl.bpi;
     if (g_db.on) return dec_batch_record(&g_db.f[mlp == 64], &g_db.nf[mlp == 64], a, grid, ST(stream));
     if (mlp == 64) hipLaunchKernelGGL(dec_fwd_kernel<64>, dim3(grid), dim3(256), 0, ST(stream), a);
     else hipLaunchKernelGGL(dec_fwd_kernel<32>, dim3(grid), dim3(256), 0, ST(stream), a);
     DH_CHECK_LAUNCH("decoder_layer_fwd");
     return 0;
-}
-
-// rows per backward workgroup: 512 at most (every workgroup writes a PL::SIZE partial), fewer while that leaves less than 256
-// workgroups; a multiple of 64 (one 16-pixel sub-tile per wave) that divides an image.  Per layer a workgroup spends ~9.2 k cycles
-// outside its sub-tile loop (staging, parking and reducing the parameter-gradient partials, writing them: tools/dec_timeline.py)
-// against 5.5 k per sub-tile, so the small levels of a staged launch want rows, not workgroups: with 512 as the floor (two per
-// CU, the residency) the 32 x 32 / 16 x 16 levels ran 2 / 1 sub-tiles per wave and layer; 256: +0.7 % on the DAHiTra step (128: +0.4 %)
-// MLP = 64 (one workgroup per CU at 344 registers: 256 resident) takes up to 1024 rows: 256 workgroups in ONE round instead of 512 in
-// two, half the per-layer overhead per row (+0.3 % on the s4 step; DAHITRA_DEC_BWD_MAXRPB64=512 restores the old rule)
-static inline int dec_rows_per_block(long rows, int rows_per_image, int mlp) {
-    static const long minblk = getenv("DAHITRA_DEC_BWD_MINBLK") ? atol(getenv("DAHITRA_DEC_BWD_MINBLK")) : 256;
-    static const int max64 = getenv("DAHITRA_DEC_BWD_MAXRPB64") ? atoi(getenv("DAHITRA_DEC_BWD_MAXRPB64")) : 1024;
-    int rpb = mlp == 64 ? max64 : 512;
-    while (rpb > 64 && (rows_per_image % rpb || rows / rpb < minblk)) rpb >>= 1;
-    return rpb;
 }
 
 // Batched decoder layers: between dh_decoder_batch_begin() and _end(), dh_decoder_layer_fwd and the data-gradient-only form of
@@ -1064,7 +1238,8 @@ extern "C" int dh_decoder_batch_end(void* stream) { const int rc = dec_batch_flu
 extern "C" int dh_decoder_batch_abort() { g_db.on = false; dec_batch_clear(); return 0; }
 
 extern "C" long dh_decoder_layer_bwd_workspace_size(long rows, int rows_per_image, int mlp) {
-    const long nblk = rows / dec_rows_per_block(rows, rows_per_image, mlp);
+    // (sized for the smallest block a re-planned launch may use, dec_balance: up to twice the default plan's blocks)
+    const long nblk = (rows / rows_per_image) * dec_plan(rows_per_image, dec_bwd_min_upb(rows, rows_per_image, mlp)).bpi;
     return nblk * (mlp == 64 ? PL<64>::SIZE : PL<32>::SIZE) * 4;
 }
 
@@ -1087,10 +1262,13 @@ extern "C" int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, con
     a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2; a.w1T = (const bf16*)w1T; a.w2T = (const bf16*)w2T;
     a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
     a.partial = reinterpret_cast<float*>(workspace);
-    a.rows_per_image = rows_per_image; a.rows_per_block = dec_rows_per_block(rows, rows_per_image, mlp); a.rows = rows; a.eps = eps;
-    const int nblk = (int)(rows / a.rows_per_block), bpi = rows_per_image / a.rows_per_block;
+    a.rows_per_image = rows_per_image; a.rows = rows; a.eps = eps;
+    const DecPlan pl = dec_bwd_default(rows, rows_per_image, mlp);
+    a.upb = pl.upb; a.bpi = pl.bpi;
     const int images = (int)(rows / rows_per_image);
+    const int bpi = pl.bpi, nblk = images * bpi;
     if (g_db.on && !dw1) return dec_batch_record(&g_db.b[mlp == 64], &g_db.nb[mlp == 64], a, nblk, ST(stream));
+    dec_remember_plan(a.partial, pl);
     static bool attr64 = false, attr32 = false;
     if (mlp == 64) {
         const size_t lds = bwd_lds_bytes<64>();
@@ -1145,8 +1323,9 @@ extern "C" int dh_decoder_stack_fwd(const void* x, void* ys, const void* kq, con
     a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
     a.rows_per_image = rows_per_image; a.rows = rows; a.eps = eps;
     a.depth = depth; a.act_ls = rows * D; a.kq_ls = kq_lstride; a.w_ls = w_lstride; a.par_ls = par_lstride;
-    a.rows_per_block = dec_fwd_rows_per_block(rows, rows_per_image);
-    const int grid = (int)(rows / a.rows_per_block);
+    const DecPlan pl = dec_fwd_default(rows, rows_per_image);
+    a.upb = pl.upb; a.bpi = pl.bpi;
+    const int grid = (int)(rows / rows_per_image) * pl.bpi;
     if (g_db.on) return dec_batch_record(&g_db.f[2 + (mlp == 64)], &g_db.nf[2 + (mlp == 64)], a, grid, ST(stream));
     if (mlp == 64) hipLaunchKernelGGL((dec_fwd_kernel<64, true>), dim3(grid), dim3(256), 0, ST(stream), a);
     else hipLaunchKernelGGL((dec_fwd_kernel<32, true>), dim3(grid), dim3(256), 0, ST(stream), a);
@@ -1163,18 +1342,22 @@ extern "C" int dh_decoder_stack_bwd(const void* x, const void* ys, const void* d
                                     long w_lstride, long par_lstride, long rows, int rows_per_image, int mlp, float eps,
                                     void* workspace, void* stream) {
     if (check_common(rows, rows_per_image, mlp)) return 1;
-    DH_REQUIRE(depth >= 1 && x && (ys || depth == 1) && dy && dx && (dwork || depth == 1) && workspace, "decoder_stack_bwd: bad arguments (depth %d)", depth);
+    DH_REQUIRE(depth >= 1 && depth <= DEC_MAXDEPTH && x && (ys || depth == 1) && dy && dx && (dwork || depth == 1) && workspace,
+               "decoder_stack_bwd: bad arguments (depth %d, 1 .. %d supported)", depth, DEC_MAXDEPTH);
     DecArgs a = {};
     a.x = (const bf16*)x; a.ys = (bf16*)const_cast<void*>(ys); a.dy = (const bf16*)dy; a.y = (bf16*)dx; a.dwork = (bf16*)dwork;
     a.kq = (const bf16*)kq; a.voT = (const bf16*)voT; a.vo = (const bf16*)vo; a.kqT = (const bf16*)kqT;
     a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2; a.w1T = (const bf16*)w1T; a.w2T = (const bf16*)w2T;
     a.g1 = ln1_g; a.be1 = ln1_b; a.bo = bo; a.g2 = ln2_g; a.be2 = ln2_b; a.fb1 = b1; a.fb2 = b2;
     a.partial = reinterpret_cast<float*>(workspace);
-    a.rows_per_image = rows_per_image; a.rows_per_block = dec_rows_per_block(rows, rows_per_image, mlp); a.rows = rows; a.eps = eps;
+    a.rows_per_image = rows_per_image; a.rows = rows; a.eps = eps;
+    const DecPlan pl = dec_bwd_default(rows, rows_per_image, mlp);
+    a.upb = pl.upb; a.bpi = pl.bpi;
     a.depth = depth; a.act_ls = rows * D; a.kq_ls = kq_lstride; a.w_ls = w_lstride; a.par_ls = par_lstride;
     a.part_ls = dh_decoder_layer_bwd_workspace_size(rows, rows_per_image, mlp) / 4;
-    const int nblk = (int)(rows / a.rows_per_block);
+    const int nblk = (int)(rows / rows_per_image) * pl.bpi;
     if (g_db.on) return dec_batch_record(&g_db.b[2 + (mlp == 64)], &g_db.nb[2 + (mlp == 64)], a, nblk, ST(stream));
+    dec_remember_plan(a.partial, pl);
     static bool m32 = false, m64 = false;
     if (mlp == 64) {
         if (dec_set_bwd_lds<64>(reinterpret_cast<const void*>(dec_bwd_kernel<64, true>), m64)) return 1;
@@ -1194,9 +1377,9 @@ extern "C" int dh_decoder_stack_bwd_finalize(const void* workspace, int depth, l
                                              float* dln2_g, float* dln2_b, long grad_stride, float* dkq, float* dvoT, void* stream) {
     if (check_common(rows, rows_per_image, mlp)) return 1;
     DH_REQUIRE(depth >= 1 && workspace && dw1 && dkq && dvoT, "decoder_stack_bwd_finalize: bad arguments (depth %d)", depth);
-    const int rpb = dec_rows_per_block(rows, rows_per_image, mlp);
-    const int nblk = (int)(rows / rpb), bpi = rows_per_image / rpb, images = (int)(rows / rows_per_image);
     const float* partial = reinterpret_cast<const float*>(workspace);
+    const int images = (int)(rows / rows_per_image);
+    const int bpi = dec_recall_plan(partial, rows, rows_per_image, mlp).bpi, nblk = images * bpi;
     const long pstride = dh_decoder_layer_bwd_workspace_size(rows, rows_per_image, mlp) / 4, kstride = (long)images * 1024;
     const FinArgs fa = {partial, nblk, bpi, dw1, dw2, db1, db2, dbo, dln1_g, dln1_b, dln2_g, dln2_b, dkq, dvoT, pstride, grad_stride, kstride};
     if (g_db.on) {          // recorded: issued with the other stacks' finalizes, after the recorded backward launches
