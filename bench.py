@@ -43,6 +43,11 @@ ALG_MB_PER_PAIR = 110.0         # fused-layer boundary ten
 
 
 ALG_MB_PER_PAIR_BY_NET = {NET: ALG_MB_PER_PAIR, "newUNetTrans": 200.0}      # SURVEY.md section 8d / BASELINE.md section 2
+# ALGORITHMIC GFLOP per pair at 256 x 256 of the attention blocks -- the cross-attention decoder stacks (help_funcs.py:170-186:
+# to_q / to_k / to_v, dots, attn . v, to_out, the MLP) as the reference executes them, q materialised at 512 (inner) columns --
+# FlopCounterMode per module over the imported reference, tools/attn_flops.py (same counter and totals as BASELINE.md section 2):
+# (forward, forward + backward).  The token encoder is 0.001 - 0.004 GFLOP per pair and not part of the record.
+ATTN_GFLOP_PER_PAIR = {NET: (0.6716, 2.0148), "newUNetTrans": (8.2890, 25.2633)}
 
 
 def _profile(suffix, net=NET):
@@ -209,11 +214,11 @@ def build(args, dtype, dev, local, rank, use_graph):
         # fwd + loss + bwd (+ clip / AdamW when single process) recorded once, replayed per step
         graphed = GraphedXbdStep(net, opt, x6, msk) if xbd_mode else GraphedTrainStep(net, opt, a, b, lab)
 
-    def step():
+    def step(eager=False):
         if args.fwd_only:
             with torch.no_grad():
                 return net(x6) if xbd_mode else net(a, b)
-        if graphed is not None and ops.PROFILE is None:
+        if graphed is not None and ops.PROFILE is None and not eager:
             # the synthetic batch already sits in the graph's static input buffers (where a loader's host-to-device
             # copy would land it): replay without the device-to-device staging copy
             return graphed()
@@ -236,6 +241,230 @@ def build(args, dtype, dev, local, rank, use_graph):
         return loss
     step.graphed = graphed
     return step, xbd_mode
+
+
+def roofline_records(step, args):
+    """per-class kernel times of `step`'s net: HIP events around every profiled launch (1 + 3 extra EAGER steps); returns the
+    `roofline` and `hbm` records (see the module docstring)"""
+    import torch
+    from dahitra_amd import ops
+    roof = hbm = None
+    if True:
+        ops.PROFILE = {}
+        step()                                   # first eager step after the graph replays: allocator / lazy-load noise
+        torch.cuda.synchronize()
+        ops.PROFILE = {}
+        NREP = 3
+        for _ in range(NREP):
+            step()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        # An event pair costs time of its own: two records with NOTHING between them are 4.6 - 12.7 us apart depending on the
+        # box (a 2 us kernel between them: 6.8 us), which is why the per-launch figures sit 2 - 12 us above rocprofv3's kernel
+        # durations (profiles/*_kernel_stats.csv: 40.7 - 42.0 us for the class on every box, where this raw figure moved
+        # between 42.6 and 53.5 us).  `achieved` stays on the raw (conservative) event time; the empty-pair time is measured
+        # here and the figure with it taken off is reported next to it -- as information only: on one box it over-corrected
+        # (12.7 us measured for the empty pair, 33.1 us "net" per launch against rocprofv3's 40.7 us of the same build).
+        # ... and a measurement without any per-launch event: the launches of the dominant class of ONE more eager step are
+        # recorded as closures (their tensors kept alive) and re-issued back to back, in program order, inside a recorded HIP
+        # graph; one event pair around `reps` replays.  22 launches x ~66 MB of distinct operands per round: cache-cold like
+        # the step itself.  Reported as `graph_replay` next to the per-launch figures (same FLOPs, duration = elapsed / launches).
+        def class_replay(key, reps=10):
+            ops.REPLAY, ops.PROFILE = {"key": key, "calls": []}, {}       # (PROFILE set: `step` takes its eager path)
+            try:
+                step()
+            finally:
+                rp, ops.REPLAY, ops.PROFILE = ops.REPLAY, None, None
+            torch.cuda.synchronize()
+            calls = rp["calls"]
+            if not calls:
+                return None
+            side, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                for c, _, _ in calls:
+                    c(ops.S())
+                with torch.cuda.graph(graph, stream=side):
+                    for c, _, _ in calls:
+                        c(ops.S())
+            torch.cuda.synchronize()
+            graph.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            fl = sum(f for _, _, f in calls)
+            return {"launches": len(calls), "ms_per_round": round(ms, 4), "avg_launch_us": round(ms * 1e3 / len(calls), 2),
+                    "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                    "how": "the class's launches of one step re-issued back to back inside a recorded HIP graph, one event pair "
+                           "around %d replays (no per-launch event; includes the graph's launch-to-launch gaps)" % reps}
+        cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        for e0, e1 in cal:
+            e0.record()
+            e1.record()
+        torch.cuda.synchronize()
+        ev_ov = sorted(e0.elapsed_time(e1) for e0, e1 in cal)[len(cal) // 2]
+        agg, raw_ms = {}, {}
+        for key, recs in prof.items():
+            per = len(recs) // NREP              # launches of this class per step, in program order
+            ms = raw = 0.0
+            for j in range(per):                 # per launch: the median of the NREP steps (a host stall between the
+                t = sorted(recs[r * per + j][0][0].elapsed_time(recs[r * per + j][0][1])        # two event records of
+                           for r in range(NREP))[NREP // 2]                                     # one step does not count)
+                ms += t
+                raw += max(t - ev_ov, 0.25 * t)
+            agg[key] = (ms, sum(f for _, f, _ in recs[:per]), sum(b for _, _, b in recs[:per]), per)
+            raw_ms[key] = raw            # the same sum with the empty-pair time taken off every launch
+        mfma = {k: v for k, v in agg.items() if k.startswith("conv_mfma")}
+        if mfma:
+            key = max(mfma, key=lambda k: mfma[k][0])
+            ms, fl, _, n = mfma[key]
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+            ach = fl / (ms * 1e-3) / 1e12
+            replay = class_replay(key) if not args.no_class_replay else None
+            if replay:
+                replay["frac"] = round(replay["achieved"] / peak, 4)
+            traffic = source = None      # HBM bytes per launch from committed rocprofv3 --pmc passes of this command
+            headline = args.dtype == "bf16" and args.net in ALG_MB_PER_PAIR_BY_NET and args.img == SIZE and args.batch == PER_GPU_BATCH
+            tprof = _profile("_pmc_traffic_conv3x3.json", args.net)
+            if headline and tprof:
+                tj = json.load(open(os.path.join(ROOT, tprof)))
+                ln = sum(v["launches"] for v in tj.values())
+                traffic = round(sum(v["launches"] * (v["fetch_MB_per_launch_corrected_x2"] + v["write_MB_per_launch"])
+                                    for v in tj.values()) / ln * 1e6)
+                source = tprof
+            # the second-largest MFMA class: the weight gradients (all conv_wgrad launches of the step)
+            wg = {k: v for k, v in agg.items() if k.startswith("conv_wgrad")}
+            wgrad = None
+            if wg:
+                wms, wfl, wn = sum(v[0] for v in wg.values()), sum(v[1] for v in wg.values()), sum(v[3] for v in wg.values())
+                wraw = sum(raw_ms[k] for k in wg)
+                wgrad = {"bound": "mfma", "kernel": "conv_wgrad<*> (every weight-gradient launch of the step)",
+                         "achieved": round(wfl / (wms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(wfl / (wms * 1e-3) / 1e12 / peak, 4), "launches_per_step": wn,
+                         "ms_per_step": round(wms, 3), "achieved_minus_event_overhead": round(wfl / (wraw * 1e-3) / 1e12, 2),
+                         "note": "per-launch events need one launch per layer: these eager profiling steps run with the batched "
+                                 "weight gradient off (ops.WgradPlan: PROFILE set); the timed steps issue the wave-specialised "
+                                 "3x3 layers of a pass as ONE launch (conv_wgrad_ws_multi_kernel, profiles/*_kernel_stats.csv)"}
+            # whole-step HBM traffic against the algorithmic bytes (constant of the newest committed --pmc step profile)
+            step_traffic = None
+            sprof = _profile("_pmc_step_traffic.json", args.net)
+            if headline and sprof:
+                sj = json.load(open(os.path.join(ROOT, sprof)))
+                tot = sj.get("total_MB_per_step")
+                if tot:
+                    alg = ALG_MB_PER_PAIR_BY_NET[args.net] * args.batch
+                    step_traffic = {"total_MB_per_step": round(tot, 1), "algorithmic_MB_per_step": round(alg, 1),
+                                    "ratio": round(tot / alg, 2), "source": sprof,
+                                    "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE summed over every kernel of a step; "
+                                            "a constant of the named committed profile, not measured by this run"}
+            roof = {"bound": "mfma", "kernel": key, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": source,
+                    "traffic_note": "constant of the named committed rocprofv3 --pmc profile (FETCH_SIZE x2 per the gfx950 "
+                                    "correction + WRITE_SIZE), not measured by this run" if source else None,
+                    "algorithmic_bytes_per_launch": round(mfma[key][2] / n), "launches_per_step": n,
+                    "avg_launch_us": round(ms * 1e3 / n, 2), "event_pair_overhead_us": round(ev_ov * 1e3, 2),
+                    "avg_launch_us_minus_event_overhead": round(raw_ms[key] * 1e3 / n, 2),
+                    "achieved_minus_event_overhead": round(fl / (raw_ms[key] * 1e-3) / 1e12, 2),
+                    "all_mfma_conv_ms_per_step": round(sum(v[0] for v in mfma.values()), 3),
+                    "all_wgrad_ms_per_step": round(sum(v[0] for k, v in agg.items() if k.startswith("conv_wgrad")), 3),
+                    "all_mfma_conv_tflops": round(sum(v[1] for v in mfma.values()) / (sum(v[0] for v in mfma.values()) * 1e-3) / 1e12, 1),
+                    "kernels_of_class": "conv_mfma_kernel<bf16,3,1,64,...> (tap-oriented) and conv3x3_wreg_kernel (register-resident "
+                                        "weights: the 64-channel layers and, without BatchNorm on load, the 128- and 256-channel ones): every 3x3 stride-1 convolution and data gradient of the "
+                                        "step; the 2x2 phase convolutions are their own class (conv_phase<...>)",
+                    "graph_replay": replay, "weight_gradient": wgrad, "step_traffic": step_traffic}
+        classes = {}
+        for k in ("bn_apply", "bn_bwd", "stem7_fwd", "decoder_layer_fwd", "decoder_layer_bwd"):
+            if k in agg:
+                ms, _, by, n = agg[k]
+                gbs = by / (ms * 1e-3) / 1e9
+                classes[k] = {"achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": n,
+                              "ms_per_step": round(ms, 3), "algorithmic_MB_per_step": round(by / 1e6, 1)}
+        if classes:
+            hbm = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "classes": classes}
+    return roof, hbm
+
+
+def attention_record(step, net, batch, img, mfma_profile):
+    """north_star: ">= 40 % MFMA util on the attention blocks" -- answered with STATED definitions.  One eager step of `net` is run
+    with ops.DEC_RECORD set: every fused-decoder call of the step (csrc/decoder_fused.hip: cross attention + MLP of a decoder
+    layer / stack, forward, backward, parameter-gradient finalize), with its real operands, in program order and with the
+    launch grouping of the step (DAHiTra's three levels share a launch per direction).  The forward calls and the backward +
+    finalize calls are then re-issued, grouped the same way, inside a recorded HIP graph; one event pair around `reps` replays.
+      algorithmic  -- the decoder blocks' FLOPs as the reference executes them (ATTN_GFLOP_PER_PAIR) / that time / 2.5 PFLOP/s
+      executed     -- the MFMA FLOPs the kernels issue after the K = 4 re-association (dots = LN(x) . (Wq^T k),
+                      out = attn . (v Wo): 4 x 32 x 32 MACs per pixel and layer forward instead of ~37 k) / the same time / peak
+      mfma_busy    -- SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES of the same kernels from the committed --pmc pass (a constant of
+                      that profile, not measured by this run)
+    The token-side operand preparation (4 tokens per image: < 40 us per step, csrc/tokens.hip) is outside the record."""
+    import torch
+    from dahitra_amd import ops
+    ops.DEC_RECORD = []
+    try:
+        step(eager=True)
+    finally:
+        recs, ops.DEC_RECORD = ops.DEC_RECORD, None
+    torch.cuda.synchronize()
+    if not any(r["kind"] in ("fwd", "bwd") for r in recs):
+        return None
+
+    def timed(kinds, reps=10):
+        def run():
+            with ops.EncoderBatch(decoder=True) as eb:
+                pending = 0
+                for r in recs:
+                    if r["kind"] == "launch":
+                        if pending:
+                            eb.launch()
+                        pending = 0
+                    elif r["kind"] in kinds:
+                        r["call"]()
+                        pending += 1
+        side, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            run()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(reps):              # (inside ONE graph: a graph launch of its own per step's worth would add ~10 us to
+                    run()                          # the 20 - 60 us of the one-layer nets)
+        torch.cuda.synchronize()
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (3 * reps)    # ms per step's worth of launches
+
+    # executed MACs per pixel row and layer (mlp = MLP width): forward dots + o + W1 + W2; backward the recomputed dots, o, W1 +
+    # dh, dl2, da, dxn + the four pixel-reduction products (dW2, dW1, dVoT, dKq) + six 16 x 16 x 16 column-sum products per 16 rows
+    def macs(kind, mlp):
+        return (2 * 1024 + 2 * 32 * mlp) if kind == "fwd" else (2 * 1024 + 32 * mlp) + (2 * 32 * mlp + 2 * 1024) + (2 * 32 * mlp + 2 * 1024) + 96
+    ex = {k: sum(2.0 * macs(k, r["mlp"]) * r["rows"] * r["depth"] for r in recs if r["kind"] == k) for k in ("fwd", "bwd")}
+    t_f, t_b = timed(("fwd",)), timed(("bwd", "fin"))
+    scale = (img / 256.0) ** 2
+    alg_f = ATTN_GFLOP_PER_PAIR[net][0] * batch * scale * 1e9
+    alg_b = (ATTN_GFLOP_PER_PAIR[net][1] - ATTN_GFLOP_PER_PAIR[net][0]) * batch * scale * 1e9
+    frac = lambda fl, ms: round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+    busy = None
+    if mfma_profile:
+        pj = json.load(open(os.path.join(ROOT, mfma_profile))).get("kernels", {})
+        busy = {k: v.get("mfma_util") for k, v in pj.items() if k.startswith("dec_") and "finalize" not in k}
+    launches = lambda kinds: sum(1 for r in recs if r["kind"] in kinds)
+    return {"net": net, "bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "forward": {"ms_per_step": round(t_f, 4), "calls": launches(("fwd",)),
+                        "algorithmic_GFLOP": round(alg_f / 1e9, 1), "algorithmic_frac": frac(alg_f, t_f),
+                        "executed_GFLOP": round(ex["fwd"] / 1e9, 1), "executed_frac": frac(ex["fwd"], t_f)},
+            "backward": {"ms_per_step": round(t_b, 4), "calls": launches(("bwd", "fin")),
+                         "algorithmic_GFLOP": round(alg_b / 1e9, 1), "algorithmic_frac": frac(alg_b, t_b),
+                         "executed_GFLOP": round(ex["bwd"] / 1e9, 1), "executed_frac": frac(ex["bwd"], t_b)},
+            "algorithmic_frac": frac(alg_f + alg_b, t_f + t_b), "executed_frac": frac(ex["fwd"] + ex["bwd"], t_f + t_b),
+            "mfma_busy": busy, "mfma_busy_source": mfma_profile,
+            "definition": "decoder blocks (cross attention + MLP, help_funcs.py:170-186) of one train step: fused-decoder launches with the "
+                          "step's operands and launch grouping, re-issued in a recorded graph; algorithmic = FlopCounterMode FLOPs of "
+                          "the reference's decoder modules (tools/attn_flops.py), executed = MFMA FLOPs after the K = 4 re-association"}
 
 
 def main():
@@ -375,140 +604,7 @@ def main():
     # ---- per-class kernel times: HIP events around every profiled launch (1 + 3 extra EAGER steps, rank 0) ----
     roof = hbm = None
     if rank == 0 and not args.fwd_only and world == 1 and not args.no_roofline:
-        ops.PROFILE = {}
-        step()                                   # first eager step after the graph replays: allocator / lazy-load noise
-        torch.cuda.synchronize()
-        ops.PROFILE = {}
-        NREP = 3
-        for _ in range(NREP):
-            step()
-        torch.cuda.synchronize()
-        prof, ops.PROFILE = ops.PROFILE, None
-        # An event pair costs time of its own: two records with NOTHING between them are 4.6 - 12.7 us apart depending on the
-        # box (a 2 us kernel between them: 6.8 us), which is why the per-launch figures sit 2 - 12 us above rocprofv3's kernel
-        # durations (profiles/*_kernel_stats.csv: 40.7 - 42.0 us for the class on every box, where this raw figure moved
-        # between 42.6 and 53.5 us).  `achieved` stays on the raw (conservative) event time; the empty-pair time is measured
-        # here and the figure with it taken off is reported next to it -- as information only: on one box it over-corrected
-        # (12.7 us measured for the empty pair, 33.1 us "net" per launch against rocprofv3's 40.7 us of the same build).
-        # ... and a measurement without any per-launch event: the launches of the dominant class of ONE more eager step are
-        # recorded as closures (their tensors kept alive) and re-issued back to back, in program order, inside a recorded HIP
-        # graph; one event pair around `reps` replays.  22 launches x ~66 MB of distinct operands per round: cache-cold like
-        # the step itself.  Reported as `graph_replay` next to the per-launch figures (same FLOPs, duration = elapsed / launches).
-        def class_replay(key, reps=10):
-            ops.REPLAY, ops.PROFILE = {"key": key, "calls": []}, {}       # (PROFILE set: `step` takes its eager path)
-            try:
-                step()
-            finally:
-                rp, ops.REPLAY, ops.PROFILE = ops.REPLAY, None, None
-            torch.cuda.synchronize()
-            calls = rp["calls"]
-            if not calls:
-                return None
-            side, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
-            with torch.cuda.stream(side):
-                for c, _, _ in calls:
-                    c(ops.S())
-                with torch.cuda.graph(graph, stream=side):
-                    for c, _, _ in calls:
-                        c(ops.S())
-            torch.cuda.synchronize()
-            graph.replay()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                graph.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / reps
-            fl = sum(f for _, _, f in calls)
-            return {"launches": len(calls), "ms_per_round": round(ms, 4), "avg_launch_us": round(ms * 1e3 / len(calls), 2),
-                    "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
-                    "how": "the class's launches of one step re-issued back to back inside a recorded HIP graph, one event pair "
-                           "around %d replays (no per-launch event; includes the graph's launch-to-launch gaps)" % reps}
-        cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
-        for e0, e1 in cal:
-            e0.record()
-            e1.record()
-        torch.cuda.synchronize()
-        ev_ov = sorted(e0.elapsed_time(e1) for e0, e1 in cal)[len(cal) // 2]
-        agg, raw_ms = {}, {}
-        for key, recs in prof.items():
-            per = len(recs) // NREP              # launches of this class per step, in program order
-            ms = raw = 0.0
-            for j in range(per):                 # per launch: the median of the NREP steps (a host stall between the
-                t = sorted(recs[r * per + j][0][0].elapsed_time(recs[r * per + j][0][1])        # two event records of
-                           for r in range(NREP))[NREP // 2]                                     # one step does not count)
-                ms += t
-                raw += max(t - ev_ov, 0.25 * t)
-            agg[key] = (ms, sum(f for _, f, _ in recs[:per]), sum(b for _, _, b in recs[:per]), per)
-            raw_ms[key] = raw            # the same sum with the empty-pair time taken off every launch
-        mfma = {k: v for k, v in agg.items() if k.startswith("conv_mfma")}
-        if mfma:
-            key = max(mfma, key=lambda k: mfma[k][0])
-            ms, fl, _, n = mfma[key]
-            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-            ach = fl / (ms * 1e-3) / 1e12
-            replay = class_replay(key) if not args.no_class_replay else None
-            if replay:
-                replay["frac"] = round(replay["achieved"] / peak, 4)
-            traffic = source = None      # HBM bytes per launch from committed rocprofv3 --pmc passes of this command
-            headline = args.dtype == "bf16" and args.net in ALG_MB_PER_PAIR_BY_NET and args.img == SIZE and args.batch == PER_GPU_BATCH
-            tprof = _profile("_pmc_traffic_conv3x3.json", args.net)
-            if headline and tprof:
-                tj = json.load(open(os.path.join(ROOT, tprof)))
-                ln = sum(v["launches"] for v in tj.values())
-                traffic = round(sum(v["launches"] * (v["fetch_MB_per_launch_corrected_x2"] + v["write_MB_per_launch"])
-                                    for v in tj.values()) / ln * 1e6)
-                source = tprof
-            # the second-largest MFMA class: the weight gradients (all conv_wgrad launches of the step)
-            wg = {k: v for k, v in agg.items() if k.startswith("conv_wgrad")}
-            wgrad = None
-            if wg:
-                wms, wfl, wn = sum(v[0] for v in wg.values()), sum(v[1] for v in wg.values()), sum(v[3] for v in wg.values())
-                wraw = sum(raw_ms[k] for k in wg)
-                wgrad = {"bound": "mfma", "kernel": "conv_wgrad<*> (every weight-gradient launch of the step)",
-                         "achieved": round(wfl / (wms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(wfl / (wms * 1e-3) / 1e12 / peak, 4), "launches_per_step": wn,
-                         "ms_per_step": round(wms, 3), "achieved_minus_event_overhead": round(wfl / (wraw * 1e-3) / 1e12, 2),
-                         "note": "per-launch events need one launch per layer: these eager profiling steps run with the batched "
-                                 "weight gradient off (ops.WgradPlan: PROFILE set); the timed steps issue the wave-specialised "
-                                 "3x3 layers of a pass as ONE launch (conv_wgrad_ws_multi_kernel, profiles/*_kernel_stats.csv)"}
-            # whole-step HBM traffic against the algorithmic bytes (constant of the newest committed --pmc step profile)
-            step_traffic = None
-            sprof = _profile("_pmc_step_traffic.json", args.net)
-            if headline and sprof:
-                sj = json.load(open(os.path.join(ROOT, sprof)))
-                tot = sj.get("total_MB_per_step")
-                if tot:
-                    alg = ALG_MB_PER_PAIR_BY_NET[args.net] * args.batch
-                    step_traffic = {"total_MB_per_step": round(tot, 1), "algorithmic_MB_per_step": round(alg, 1),
-                                    "ratio": round(tot / alg, 2), "source": sprof,
-                                    "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE summed over every kernel of a step; "
-                                            "a constant of the named committed profile, not measured by this run"}
-            roof = {"bound": "mfma", "kernel": key, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": source,
-                    "traffic_note": "constant of the named committed rocprofv3 --pmc profile (FETCH_SIZE x2 per the gfx950 "
-                                    "correction + WRITE_SIZE), not measured by this run" if source else None,
-                    "algorithmic_bytes_per_launch": round(mfma[key][2] / n), "launches_per_step": n,
-                    "avg_launch_us": round(ms * 1e3 / n, 2), "event_pair_overhead_us": round(ev_ov * 1e3, 2),
-                    "avg_launch_us_minus_event_overhead": round(raw_ms[key] * 1e3 / n, 2),
-                    "achieved_minus_event_overhead": round(fl / (raw_ms[key] * 1e-3) / 1e12, 2),
-                    "all_mfma_conv_ms_per_step": round(sum(v[0] for v in mfma.values()), 3),
-                    "all_wgrad_ms_per_step": round(sum(v[0] for k, v in agg.items() if k.startswith("conv_wgrad")), 3),
-                    "all_mfma_conv_tflops": round(sum(v[1] for v in mfma.values()) / (sum(v[0] for v in mfma.values()) * 1e-3) / 1e12, 1),
-                    "kernels_of_class": "conv_mfma_kernel<bf16,3,1,64,...> (tap-oriented) and conv3x3_wreg_kernel (register-resident "
-                                        "weights: the 64-channel layers and, without BatchNorm on load, the 128- and 256-channel ones): every 3x3 stride-1 convolution and data gradient of the "
-                                        "step; the 2x2 phase convolutions are their own class (conv_phase<...>)",
-                    "graph_replay": replay, "weight_gradient": wgrad, "step_traffic": step_traffic}
-        classes = {}
-        for k in ("bn_apply", "bn_bwd", "stem7_fwd", "decoder_layer_fwd", "decoder_layer_bwd"):
-            if k in agg:
-                ms, _, by, n = agg[k]
-                gbs = by / (ms * 1e-3) / 1e9
-                classes[k] = {"achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": n,
-                              "ms_per_step": round(ms, 3), "algorithmic_MB_per_step": round(by / 1e6, 1)}
-        if classes:
-            hbm = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "classes": classes}
+        roof, hbm = roofline_records(step, args)
 
     # ---- parity mode: the modes that meet the 1e-3 logit bar, timed by the same driver run.  "bf16x3" = the fp32 pipeline with
     # its matrix products on the 16-bit matrix cores as three split products (fp16 planes forward, bf16 planes backward: the same
@@ -558,8 +654,52 @@ def main():
         d2 = time.perf_counter() - t1
         secondary = {"net": "newUNetTrans", "dtype": "bf16", "value": round(args.batch * k2 / d2, 2), "unit": "image-pairs/s",
                      "steps": k2, "ms_per_step": round(d2 / k2 * 1e3, 3), "batch": args.batch, "img_size": args.img,
-                     "workload": "BASE_Transformer_UNet (models/networks.py:1040-1357), fwd+focal+bwd+AdamW, one HIP graph per step"}
+                     "workload": "BASE_Transformer_UNet (models/networks.py:1040-1357), fwd+focal+bwd+AdamW, one HIP graph per step",
+                     "step_tflops": round(args.batch * k2 / d2 * GFLOP_256["newUNetTrans"] / 1e3, 2)}
+        if not args.no_roofline:
+            try:                        # the dominant MFMA class and the HBM-bound classes of DAHiTra proper, as for the headline net
+                secondary["roofline"], secondary["hbm"] = roofline_records(stp, a2)
+            except Exception as e:
+                secondary["roofline"] = {"error": repr(e)[:300]}
+        try:
+            secondary["attention"] = attention_record(stp, "newUNetTrans", args.batch, args.img, _profile("_pmc_mfma_util.json", "newUNetTrans"))
+        except Exception as e:                                          # the line never depends on a sub-record
+            secondary["attention"] = {"error": repr(e)[:300]}
         del stp
+
+    # ---- forward_only: the evaluation forward (eval-mode BatchNorm, no gradient state; models/evaluator.py:156-164) of both nets,
+    # SURVEY.md section 8d "also report fwd-only", timed by the same driver run ----
+    forward_only = None
+    if rank == 0 and world == 1 and headline_run and not args.no_secondary:
+        import copy
+        forward_only = {}
+        for nname in (NET, "newUNetTrans"):
+            af = copy.copy(args)
+            af.net, af.fwd_only = nname, True
+            try:
+                stp, _ = build(af, "bf16", dev, local, rank, False)
+                for _ in range(3):
+                    stp()
+                torch.cuda.synchronize()
+                kf = 20
+                t1 = time.perf_counter()
+                for _ in range(kf):
+                    stp()
+                torch.cuda.synchronize()
+                df = time.perf_counter() - t1
+                forward_only[nname] = {"value": round(args.batch * kf / df, 1), "unit": "image-pairs/s", "ms_per_batch": round(df / kf * 1e3, 3),
+                                       "batch": args.batch, "dtype": "bf16", "steps": kf,
+                                       "how": "net.eval(); torch.no_grad(); net(A, B) -> logits, launched from Python (no recorded graph)"}
+                del stp
+            except Exception as e:
+                forward_only[nname] = {"error": repr(e)[:300]}
+
+    attention = None
+    if rank == 0 and world == 1 and not args.fwd_only and args.dtype == "bf16" and args.net in ATTN_GFLOP_PER_PAIR and not args.no_roofline:
+        try:
+            attention = attention_record(step, args.net, args.batch, args.img, _profile("_pmc_mfma_util.json", args.net))
+        except Exception as e:
+            attention = {"error": repr(e)[:300]}
 
     if rank == 0:
         pairs = args.batch * world * args.steps
@@ -586,6 +726,8 @@ def main():
             "roofline": roof,
             "hbm": hbm,
             "parity_mode": parity,
+            "attention": attention,
+            "forward_only": forward_only,
             "secondary": secondary,
             "ddp_rehearsal": None if rehearsal is None else dict(rehearsal, one_graph_ms_per_step=round(dt / args.steps * 1e3, 3)),
         }

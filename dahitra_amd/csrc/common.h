@@ -22,9 +22,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // v_mfma_f32_16x16x32_bf16 products a_i * b_j with i + j < NPL:
 //   f32x3  NPL = 2: a0 b0 + a1 b0 + a0 b1               unit roundoff ~2^-17   3/16 of the exact fp32 MFMA's cycles
 //   f32x6  NPL = 3: + a2 b0 + a1 b1 + a0 b2             unit roundoff ~2^-23   6/16
-// (fp32: 2^-24).  f32x6 serves the FORWARD products of the "bf16x3" compute mode -- the activation error is what the gradients
-// are sensitive to (measured: forward at 2^-17 puts the gradients 150x above their fp32 distance from the oracle, backward at
-// 2^-17 leaves them at it) -- f32x3 the data and weight gradients.
+// (fp32: 2^-24).  In the "bf16x3" compute mode f32x3 (mode 1) serves the data and weight gradients; the FORWARD products run by
+// default on the fp16-plane form f32h3 below (mode 3, ~2^-21, operands inside fp16's range) -- the activation error is what the
+// gradients are sensitive to (measured: forward at 2^-17 puts the gradients 150x above their fp32 distance from the oracle,
+// backward at 2^-17 leaves them at it) -- and f32x6 (mode 2, 2^-23, fp32's range) is the forward's fallback: DAHITRA_X3_FWD=2.
 struct f32x3 { float v; };
 struct f32x6 { float v; };
 // f32h3: the two-plane / three-product form on FP16 planes (v_mfma_f32_16x16x32_f16): hi = fp16(x), lo = fp16(x - hi) carry 11

@@ -27,6 +27,9 @@ static int x_rw4_cin_min() {
     const char* e = getenv("DAHITRA_X_RW4");
     return e ? atoi(e) : 32;
 }
+// modes: 0 exact fp32 MFMA; 1 split-bf16, two planes / three products (2^-17: the backward of compute_dtype "bf16x3"); 2 split-bf16,
+// three planes / six products (2^-23: the forward's fallback); 3 split-fp16, two planes / three products (~2^-21, fp16's range:
+// the forward's default).  DAHITRA_F32_MMA sets the thread default (bf16x3 -> 1, bf16x6 -> 2); engines set the mode per pass.
 static int f32_mma_env_default() {
     const char* e = getenv("DAHITRA_F32_MMA");
     return e && !strcmp(e, "bf16x3") ? 1 : (e && !strcmp(e, "bf16x6") ? 2 : 0);
@@ -228,9 +231,10 @@ extern "C" int dh_conv3x3_up4_fwd(const void* a, const void* b, const void* w_pa
 }
 
 // number of workgroup tiles along the pixel dimension (= rows of the stats_partial buffer)
-extern "C" int dh_conv2d_fwd_num_tiles(int N, int OH, int OW, int Cin, int ks, int stride) {
-    // (the fp32 split forms may pick other tiles: the count is for an fp32 launch under the current mode when that matters)
+extern "C" int dh_conv2d_fwd_num_tiles(int dtype, int N, int OH, int OW, int Cin, int ks, int stride) {
+    // (the fp32 split forms may pick other tiles than a bf16 launch of the same shape: the rule of the launch that will WRITE the
+    // buffer -- dtype, and for fp32 the thread's current MMA mode -- sizes it)
     static const int cmin = x_rw4_cin_min();
-    if (cmin && g_f32_mma_mode != 0) return N * dh_cdiv(OW, TW) * dh_cdiv(OH, 4 * pick_rw_mode(DH_DTYPE_F32, N, OH, OW, Cin, ks, stride));
+    if (dtype == DH_DTYPE_F32 && cmin && g_f32_mma_mode != 0) return N * dh_cdiv(OW, TW) * dh_cdiv(OH, 4 * pick_rw_mode(DH_DTYPE_F32, N, OH, OW, Cin, ks, stride));
     return N * dh_cdiv(OW, TW) * dh_cdiv(OH, 4 * pick_rw(N, OH, OW, Cin, ks, stride));
 }

@@ -84,6 +84,7 @@ class Engine:
         self.mma_x3 = bool(mma_x3) and dtype == torch.float32
         self.mma_fwd = int(os.environ.get("DAHITRA_X3_FWD", "3")) if self.mma_x3 else 0
         self.mma_bwd = int(os.environ.get("DAHITRA_X3_BWD", "1")) if self.mma_x3 else 0
+        self._x3_checked = False
         # fp8 (OCP e4m3) MFMA operands in the fused decoder layers' forward products (BASELINE configs[4]); bf16 mode only
         self.attn_fp8 = bool(attn_fp8) or os.environ.get("DAHITRA_ATTN_FP8", "0") == "1"
         self.cfg = get_config(net_G)
@@ -907,6 +908,15 @@ class Engine:
             logits, bwd = self._unet(x1, x2)        # "unet" and "xbd" share the trunk / up path; levels differ
         if need_grad:
             self._bwd = bwd        # a no-grad forward (validation, metrics) leaves a pending backward alone
+        # fp16-plane forward (form 3): operands beyond fp16's range (|x| >= 65504; |w| >= 255, which BatchNorm-folded eval weights
+        # of near-dead channels can reach) become inf / NaN without any other sign.  The FIRST forward of an engine in that form is
+        # checked once (one synchronisation, outside any stream capture) and fails loudly, naming the six-product bf16 form.
+        if self.mma_fwd == 3 and not self._x3_checked and not torch.cuda.is_current_stream_capturing():
+            self._x3_checked = True
+            if not bool(torch.isfinite(logits).all()):
+                raise FloatingPointError(
+                    "dahitra_amd: compute_dtype='bf16x3' produced non-finite logits in its fp16-plane forward (operands beyond "
+                    "fp16's range: |x| < 65504, |w| < 255); set DAHITRA_X3_FWD=2 (three bf16 planes, six products, fp32's range)")
         return logits
 
     def split_prefixes(self):

@@ -17,7 +17,9 @@ torch.distributed the step is TWO graphs around the exchange:
              newUNetTrans / xBD: the whole ResNet trunk)             }
     all-reduce of the arena head, wait for both, then the update: AdamW with 1/world folded into its grad_scale, or for the
     xBD step the mean over ranks, clip_grad_norm_ over the complete arena and the hand-rolled AdamW (train.py:373-374).
-DAHITRA_NO_OVERLAP=1: one graph, then one all-reduce and the update.  The warm-up steps torch needs before capture are
+DAHITRA_OVERLAP=auto (default) takes this form only where the all-reduce it hides is modelled longer than the form costs
+(parallel.split_offset: world size and tail bytes; 1 forces it, 0 / DAHITRA_NO_OVERLAP=1 gives one graph, then one all-reduce and
+the update).  The warm-up steps torch needs before capture are
 undone (parameters, BN buffers and optimizer state are restored), so the first graphed step is step 1."""
 import os
 
@@ -76,7 +78,9 @@ class GraphedTrainStep:
         # freeing the one the graph still reads and writes).
         # The capture runs on a stream of our own that inherits the warm-up stream's scratch workspace (ops.workspace is keyed
         # by stream): sized by the warm-up, allocated outside the graph's private pool, and no entry of a dead stream remains.
-        cs = torch.cuda.Stream()
+        # (kept for the life of the step: released, PyTorch's stream pool could hand its handle to a later torch.cuda.Stream(),
+        # whose eager launches would then look up -- and scribble over -- the workspace the recorded graph reads and writes)
+        cs = self._capture_stream = torch.cuda.Stream()
         ops.rekey_workspace(a.device, s, cs)
         self.graph = torch.cuda.CUDAGraph()
         if split:
@@ -159,7 +163,7 @@ class GraphedTrainStep:
         xbd: the whole trunk) lies below the first offset of what the first graph completes: the arena tail [split, end) is
         final after the first graph.  Keys below the split that the first graph writes (positional embeddings are registered
         first) just ride with the second all-reduce."""
-        self.split_off = parallel.split_offset(self.net)
+        self.split_off = parallel.split_offset(self.net, self.world)
         return self.split_off is not None
 
     def _split_first(self):

@@ -439,7 +439,7 @@ def conv2d(x, wp, cout, ks=3, stride=1, pad=1, bias=None, residual=None, act=ACT
     pre = torch.empty_like(y) if want_preact else None
     stats = None
     if want_stats:
-        nt = _lib.lib().dh_conv2d_fwd_num_tiles(N, OH, OW, Cin, ks, stride)
+        nt = _lib.lib().dh_conv2d_fwd_num_tiles(_DT[x.dtype], N, OH, OW, Cin, ks, stride)
         stats = torch.empty(2, cpad, nt, dtype=torch.float32, device=x.device)      # [sum | sumsq][channel][tile]
     nt_ = 64 if cpad % 64 == 0 else (32 if cpad % 32 == 0 else 16)
     key = "conv_mfma<%s,ks%d,s%d,nt%d>" % ("bf16" if x.dtype == torch.bfloat16 else "f32", ks, stride, nt_)
@@ -486,7 +486,7 @@ def _conv3x3_up4(u, wp, cout, bias, act, want_stats):
     y = torch.empty(N, H, W, 32, dtype=torch.bfloat16, device=u.a.device)
     stats = None
     if want_stats:
-        stats = torch.empty(2, 32, _lib.lib().dh_conv2d_fwd_num_tiles(N, H, W, 32, 3, 1), dtype=torch.float32, device=y.device)
+        stats = torch.empty(2, 32, _lib.lib().dh_conv2d_fwd_num_tiles(_DT[torch.bfloat16], N, H, W, 32, 3, 1), dtype=torch.float32, device=y.device)
     key, flops = "conv_mfma<bf16,ks3,s1,nt32>", 2.0 * N * H * W * 32 * 32 * 9
     fixed = (P(u.a), P(u.b), P(wp), P(bias), _ci(act), P(y), P(stats), _ci(N), _ci(H), _ci(W))
     with _Prof(key, flops, _nb(u.a, u.b, y, wp)):
@@ -541,7 +541,7 @@ def conv3x3_split(x, wp, w_frag, cout, want_stats=False, split_out=False, alg_fl
         ysplit = 0
     stats = None
     if want_stats:
-        nt = _lib.lib().dh_conv2d_fwd_num_tiles(N, H, W, Cin, 3, 1)
+        nt = _lib.lib().dh_conv2d_fwd_num_tiles(_DT[xt.dtype], N, H, W, Cin, 3, 1)
         stats = torch.empty(2, cout, nt, dtype=torch.float32, device=xt.device)
     flops = alg_flops if alg_flops else 2.0 * N * H * W * cout * Cin * 9
     fixed = (P(xt), _cl(xs.split_bytes if xs is not None else 0), P(wp), P(w_frag), P(y), _cl(ysplit), P(stats), _ci(N), _ci(H),
@@ -1367,6 +1367,27 @@ def prep_mfma_supported(dtype, Sn, L, heads, dim_head, HLP):
     return bool(_lib.lib().dh_xattn_prep_mfma_supported(_ci(_DT[dtype]), _ci(Sn), _ci(L), _ci(heads), _ci(dim_head), _ci(HLP)))
 
 
+DEC_RECORD = None    # set to [] by bench.py for ONE eager step: every fused-decoder call (layer / stack, forward / backward /
+                     # finalize) as {"kind", "rows", "depth", "mlp", "call"} in program order, with {"kind": "launch"} where an
+                     # EncoderBatch issued what it had recorded -- bench.py re-issues them, grouped the same way, inside a recorded
+                     # graph to time the attention blocks by themselves (the `attention` record of its line)
+
+
+def _dec_recorded(kind, rows_of, depth_of, mlp_of):
+    """decorator of the fused-decoder entry points: see DEC_RECORD"""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            if DEC_RECORD is not None:
+                DEC_RECORD.append(dict(kind=kind, rows=rows_of(a), depth=depth_of(a), mlp=mlp_of(a, k),
+                                       call=functools.partial(fn, *a, **k)))
+            return fn(*a, **k)
+        return wrapped
+    return deco
+
+
 class XattnPrep:
     """Per-image operands of the re-associated cross attention (see csrc/tokens.hip)."""
 
@@ -1516,6 +1537,7 @@ def xattn_prep_bwd(prep, tok, dtok_accum, ln_g, wqT, wk, wv, wo, dkq, dvoT, dln_
           P(dwk), P(dwv), P(dwo), _ci(int(accumulate)), P(ws), S())
 
 
+@_dec_recorded("fwd", lambda a: a[0].shape[0], lambda a: 1, lambda a, k: a[12])
 def decoder_layer_fwd(x2d, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b, w1, b1, w2, b2, mlp, eps=1e-5, fp8=False):
     """fused cross-attention + MLP decoder layer (csrc/decoder_fused.hip); x2d [rows, 32] bf16.
     fp8=True: the four MFMA products on OCP e4m3 operands (csrc/decoder_fp8.hip)"""
@@ -1528,6 +1550,7 @@ def decoder_layer_fwd(x2d, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b,
     return y
 
 
+@_dec_recorded("bwd", lambda a: a[0].shape[0], lambda a: 1, lambda a, k: a[16])
 def decoder_layer_bwd(x2d, dy, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln2_b, w1, w1T, b1, w2, w2T, b2, grads, mlp,
                       eps=1e-5, dkq=None, dvoT=None, partial=None):
     """returns (dx, dkq [S,32,32] fp32, dvoT [S,32,32] fp32); grads = (dw1, dw2, db1, db2, dbo, dg1, dbe1, dg2, dbe2)
@@ -1553,6 +1576,7 @@ def decoder_layer_bwd(x2d, dy, prep, rows_per_image, ln1_g, ln1_b, bo, ln2_g, ln
     return dx, dkq, dvoT
 
 
+@_dec_recorded("fwd", lambda a: a[0].shape[0], lambda a: a[1].layers, lambda a, k: a[7])
 def decoder_stack_fwd(x2d, stack, rows_per_image, params0, w1s, w2s, par_stride, mlp, eps=1e-5):
     """ALL layers of a fused decoder stack in one launch (csrc/decoder_fused.hip, DecArgs::depth): a workgroup takes its
     pixel rows through every layer.  stack: the XattnPrepStack of the layers; params0 = (ln1_g, ln1_b, bo, ln2_g, ln2_b, b1,
@@ -1570,6 +1594,7 @@ def decoder_stack_fwd(x2d, stack, rows_per_image, params0, w1s, w2s, par_stride,
     return ys
 
 
+@_dec_recorded("bwd", lambda a: a[0].shape[0], lambda a: a[3].layers, lambda a, k: a[11])
 def decoder_stack_bwd(x2d, ys, dy, stack, rows_per_image, params0, w1s, w1Ts, w2s, w2Ts, par_stride, mlp, partials, eps=1e-5):
     """data gradient of decoder_stack_fwd in one launch; the per-workgroup parameter-gradient partials of layer l land in
     partials[l] (decoder_stack_bwd_finalize sums them).  Returns dx."""
@@ -1591,6 +1616,7 @@ def decoder_layer_bwd_partial_floats(rows, rows_per_image, mlp):
     return _lib.lib().dh_decoder_layer_bwd_workspace_size(_cl(rows), rows_per_image, mlp) // 4
 
 
+@_dec_recorded("fin", lambda a: a[1], lambda a: a[0].shape[0], lambda a, k: a[3])
 def decoder_stack_bwd_finalize(partials, rows, rows_per_image, mlp, grads0, grad_stride, dkq, dvoT):
     """one launch for the parameter gradients of all layers of a decoder stack: partials [depth, floats], grads0 = the nine
     gradient tensors of layer 0 (layer l's sit grad_stride floats further), dkq / dvoT [depth, images, 32, 32]"""
@@ -1702,6 +1728,8 @@ class EncoderBatch:
         if self.dec:
             _call("dh_decoder_batch_launch", S())
             del _DEC_BATCH[:]
+            if DEC_RECORD is not None:
+                DEC_RECORD.append(dict(kind="launch"))
         if self.xprep:
             _call("dh_xprep_batch_launch_bwd", S())
             del _XPREP_BATCH[:]

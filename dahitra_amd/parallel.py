@@ -97,13 +97,42 @@ class ShardSampler(torch.utils.data.Sampler):
         return len(self.idx)
 
 
-def split_offset(net):
+# ---- which form of the data-parallel step: ONE graph + one all-reduce + AdamW ("serial"), or TWO graphs around an all-reduce of
+# the arena tail that overlaps the rest of the backward ("overlapped", dahitra_amd/graph.py).  The overlapped form is not free: two
+# graph launches, an event hand-over to RCCL's stream and back, and a second graph that may not hold the persistent one-launch
+# BatchNorm backward (its device-wide barrier needs every CU; RCCL's kernels hold some) -- measured on ONE rank, where the
+# collectives move nothing: 3.52 against 3.34 ms per step of base_transformer_pos_s4, i.e. ~0.18 ms (bench.py `ddp_rehearsal`).
+# It pays when the all-reduce it hides takes longer than that.  No multi-GPU node was available to any round of this build, so
+# the crossover is a MODEL, stated here and overridable: a ring all-reduce over xGMI (point-to-point links, per-link bound)
+#     t(bytes, world) = 10 us + 2 (world - 1) x 5 us  +  2 (world - 1) / world x bytes / (0.6 x 153 GB/s)
+# DAHITRA_OVERLAP = auto (default: overlapped iff t(tail bytes, world) > DAHITRA_OVERLAP_OVERHEAD_US [180]) | 1 (always, when the
+# net has a split point) | 0 (never; DAHITRA_NO_OVERLAP=1 is the older spelling).  DAHITRA_XGMI_GBS overrides the 92 GB/s.
+def overlap_mode():
+    if os.environ.get("DAHITRA_NO_OVERLAP", "0") == "1":
+        return "0"
+    m = os.environ.get("DAHITRA_OVERLAP", "auto")
+    if m not in ("0", "1", "auto"):
+        raise ValueError("DAHITRA_OVERLAP=%s (0, 1 or auto)" % m)
+    return m
+
+
+def allreduce_model_us(nbytes, world):
+    """modelled duration of a ring all-reduce of `nbytes` over `world` ranks on xGMI (see above); 0 for one rank"""
+    if world <= 1:
+        return 0.0
+    gbs = float(os.environ.get("DAHITRA_XGMI_GBS", "92"))
+    return 10.0 + 2 * (world - 1) * 5.0 + 2.0 * (world - 1) / world * nbytes / (gbs * 1e3)
+
+
+def split_offset(net, world=None):
     """Arena offset (in floats) at which the overlapped data-parallel step cuts the gradient exchange, or None.
     The backward runs in two parts (Engine.backward_first / backward_second); every gradient the SECOND part writes (BiT nets:
     stem, layer1, layer2; newUNetTrans / xBD: the whole ResNet trunk -- Engine.split_prefixes) must lie below the offset, so
     that the tail [offset, end) is final after the first part and can be all-reduced while the second part computes.  None when
-    DAHITRA_NO_OVERLAP=1, when the net has no such parameters, or when less than 1 MB would be overlapped."""
-    if os.environ.get("DAHITRA_NO_OVERLAP", "0") == "1":
+    the form is switched off (overlap_mode), when the net has no such parameters, when less than 1 MB would be overlapped, or --
+    DAHITRA_OVERLAP=auto with `world` given -- when the modelled all-reduce of the tail is shorter than what the two-graph form costs."""
+    mode = overlap_mode()
+    if mode == "0":
         return None
     off = net._arena.offsets
     early = net._engine.split_prefixes()
@@ -113,6 +142,10 @@ def split_offset(net):
     split = max(off[k][0] + off[k][1] for k in second)           # end of the last gradient the second part writes
     if (net._arena.n_active - split) * 4 < (1 << 20):
         return None
+    if mode == "auto" and world is not None:
+        overhead = float(os.environ.get("DAHITRA_OVERLAP_OVERHEAD_US", "180"))
+        if allreduce_model_us((net._arena.n_active - split) * 4, world) <= overhead:
+            return None
     return split
 
 

@@ -44,7 +44,7 @@ void dh_set_error(const char* msg);
  *                      + bias[co] + residual[n,oy,ox,co] )
  * w_packed: [ks*ks][CoutPad][Cin] T (dh_pack_weight).  Cin*sizeof(T) must be a multiple of 64.
  * y_preact (optional): receives the value before `act`.  stats_partial (optional):
- * [2][CoutPad][dh_conv2d_fwd_num_tiles(N,OH,OW,Cin,ks,stride)] fp32 per-tile (sum, sum of squares) of y for BatchNorm
+ * [2][CoutPad][dh_conv2d_fwd_num_tiles(dtype,N,OH,OW,Cin,ks,stride)] fp32 per-tile (sum, sum of squares) of y for BatchNorm
  * (channel-major: the per-channel combine reads contiguous runs).
  * npix_valid > 0: treat each image as a row list with that many valid rows (H*W >= npix_valid). */
 int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const float* bias,
@@ -72,7 +72,7 @@ int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const
  * epilogue then stores g = dout * (gate_out > 0) and writes stats_partial[tile] = (sum g, sum g * xhat), which
  * dh_bn_bwd_from_partials consumes (replaces the reduction pass of dh_bn_bwd; torch autograd's native_batch_norm
  * backward + threshold_backward, called from models/resnet.py:58-73 via loss.backward()). */
-int dh_conv2d_fwd_num_tiles(int N, int OH, int OW, int Cin, int ks, int stride);
+int dh_conv2d_fwd_num_tiles(int dtype, int N, int OH, int OW, int Cin, int ks, int stride);   /* dtype: of the launch that fills the buffer */
 /* bf16 3x3 / stride-1 / pad-1 convolutions with 64 / 128 / 256 input channels and Cout % 64 == 0 on whole 8x16 tiles run,
  * inside dh_conv2d_fwd, on the register-resident-weights kernel (csrc/conv_wreg.hip: persistent workgroups, the weights of
  * a wavefront's output channels stay in its registers, only the input halo is staged) -- same products in the same order as

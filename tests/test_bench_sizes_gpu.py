@@ -15,11 +15,16 @@ import types
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import cdnet_ref as O
+import _bounds as B
 
 pytestmark = pytest.mark.gpu
-GRAD_TOL, NORM_TOL = 6e-2, 3e-2          # the fp32 gradient noise floor of these nets (tests/test_model_gpu.py docstring)
+# tests/_bounds.py; measured on MI355X (profiles/r06a_grad_fixture_values.txt): gradient norms worst 8.9e-4 / 9.0e-4 (exact / bf16x3),
+# stored tensors 8.2e-3 (tie-sized) and 8.9e-4 (others): 3 x those, the tie-sized ones keep B.GRAD_TOL_TIE
+GRAD_TOL_REST, NORM_TOL = 3e-3, 3e-3
+NORM_TOL_XBD = 3e-2          # CALIBRATE
 R50 = "base_transformer_pos_s4_resnet50"
 
 
@@ -59,23 +64,17 @@ def check_logits(g, y, stride, tol, what):
     assert abs(float(y.double().sum()) - float(g["sum_train"])) <= 2 * tol * float(g["abssum_train"])
 
 
-def check_grads(g, net, floor=0.0):
+def check_grads(g, net, floor=0.0, what=""):
+    """gradient norms of every tensor + the small tensors the fixture stores in full (tests/_bounds.py: tie-sized bound for the
+    per-channel tensors a flipped ReLU / max-pool tie can move, 3 x the measured worst for the rest and for the norms)"""
     params = dict(net.named_parameters())
     nograd = sorted(k for k, p in params.items() if p.grad is None)
     assert nograd == sorted(g["nograd_keys"].tolist())
-    worst = 0.0
-    for k, v in zip(g["gradnorm_keys"].tolist(), g["gradnorm_vals"].tolist()):
-        gn = float(params[k].grad.double().norm())
-        worst = max(worst, abs(gn - v) / max(v, 1e-12))
-        assert abs(gn - v) <= NORM_TOL * v + 1e-7 + floor, "grad norm %s: %.6e vs %.6e" % (k, gn, v)
-    full = 0
-    for k in g.files:
-        if k.startswith("grad0/"):
-            w = torch.from_numpy(g[k])
-            e = float((params[k[6:]].grad.cpu() - w).abs().max())
-            assert e <= GRAD_TOL * float(w.abs().max()) + 1e-8 + floor, "grad %s err %.3e (max %.3e)" % (k[6:], e, float(w.abs().max()))
-            full += 1
-    print("   %d gradient norms (worst rel err %.2e), %d small gradients element-wise" % (len(g["gradnorm_keys"]), worst, full))
+    verbose = what if os.environ.get("DAHITRA_TEST_VERBOSE") else None
+    worst = B.assert_grad_norms(params, g["gradnorm_keys"].tolist(), g["gradnorm_vals"].tolist(), NORM_TOL, floor_abs=floor, verbose=verbose)
+    full, wg = B.assert_stored_grads(params, g, GRAD_TOL_REST, floor_abs=floor, verbose=verbose)
+    print("   %d gradient norms (worst rel err %.2e), %d small gradients element-wise (worst %.2e tie-sized / %.2e others)"
+          % (len(g["gradnorm_keys"]), worst, full, wg["tie"], wg["rest"]))
 
 
 @pytest.mark.parametrize("cdtype", ["fp32", "bf16x3"])       # both parity modes at the same bounds (tests/test_model_gpu.py)
@@ -86,7 +85,7 @@ def test_benchmarked_size_fp32_graphed_step_matches_the_reference(case, cdtype, 
     check_logits(g, step.logits.float().cpu(), stride, 3e-4, "%s %s" % (case, cdtype))
     print("   focal loss %.7f (reference %.7f)" % (loss, float(g["loss"])))
     assert abs(loss - float(g["loss"])) <= 3e-5 * max(1.0, abs(float(g["loss"])))
-    check_grads(g, net)
+    check_grads(g, net, what="%s %s" % (case, cdtype))
 
 
 @pytest.mark.parametrize("case", ["newUNetTrans_b32", "o5_512_b8"])
@@ -136,7 +135,9 @@ def test_xbd_step_at_1024_batch_4_matches_the_reference(cdtype, golden_dir):
     params = dict(net.named_parameters())
     for k, v in zip(g["gradnorm_keys"].tolist(), g["gradnorm_vals"].tolist()):
         gn = float(params[k].grad.double().norm()) / coef
-        assert abs(gn - v) <= NORM_TOL * v + 1e-7 * total, "grad norm %s: %.6e vs %.6e" % (k, gn, v)
+        if os.environ.get("DAHITRA_TEST_VERBOSE"):
+            print("VERBOSE norm xbd %s %s %.3e" % (cdtype, k, abs(gn - v) / max(v, 1e-12)))
+        assert abs(gn - v) <= NORM_TOL_XBD * v + 1e-7 * total, "grad norm %s: %.6e vs %.6e" % (k, gn, v)
     got_total = float(torch.cat([p.grad.flatten() for p in net.parameters() if p.grad is not None]).double().norm()) / coef
     print("   total gradient norm %.6f (reference %.6f)" % (got_total, total))
     assert abs(got_total - total) <= 1e-2 * total
@@ -156,12 +157,42 @@ def test_resnet50_trunk_at_1024_batch_8_forward_and_fp8_train_step(golden_dir):
     assert abs(float(losses.focal_loss(y, lab.cuda())) - float(g["loss"])) <= 1e-4 * max(1.0, float(g["loss"]))
     del net, y
     torch.cuda.empty_cache()
-    net = init_net(BASE_Transformer(backbone='resnet50', compute_dtype="bf16", attn_dtype="fp8"), gpu_ids=[0])
-    net.load_state_dict(O.deterministic_state(name))
-    net.train()
-    y = net(a.cuda(), b.cuda())
-    losses.focal_loss(y, lab.cuda()).backward()
-    assert torch.isfinite(y).all() and all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+
+    # The bf16 + fp8-attention step at this size (the reference's backward does not fit the build container here; its backward is
+    # pinned at 512 x 512 below).  Reference = the fp32 HIP step whose forward was just checked against the reference's logits;
+    # yardstick = what rounding ONLY the weights and images to bf16 does to that fp32 pipeline (tests/test_config1_gpu.py): logits
+    # within 3 x that distance, gradient cosines no further from 1 than 3 x what the yardstick loses.
+    def run(cdtype, state, aa, bb, **kw):
+        n = init_net(BASE_Transformer(backbone='resnet50', compute_dtype=cdtype, **kw), gpu_ids=[0])
+        n.load_state_dict(state)
+        n.train()
+        yy = n(aa.cuda(), bb.cuda())
+        losses.focal_loss(yy, lab.cuda()).backward()
+        out = yy.detach().float().cpu(), {k: p.grad.detach().float().cpu() for k, p in n.named_parameters() if p.grad is not None}
+        del n, yy
+        torch.cuda.empty_cache()
+        return out
+    state = O.deterministic_state(name)
+    y32, g32 = run("fp32", state, a, b)
+    rounded = {k: (v.bfloat16().float() if v.dtype.is_floating_point and v.dim() > 1 else v) for k, v in state.items()}
+    y_r, g_r = run("fp32", rounded, a.bfloat16().float(), b.bfloat16().float())
+    y_b, g_b = run("bf16", state, a, b, attn_dtype="fp8")
+    assert torch.isfinite(y_b).all() and all(torch.isfinite(v).all() for v in g_b.values())
+    l2 = lambda u, v: float((u - v).norm() / v.norm())
+    sens, got = l2(y_r, y32), l2(y_b, y32)
+
+    def cosines(gg):
+        c = sorted((float(F.cosine_similarity(gg[k].double().flatten(), v.double().flatten(), dim=0)), k)
+                   for k, v in g32.items() if v.numel() >= 64 and float(v.norm()) > 0)
+        return c
+    cb, cr = cosines(g_b), cosines(g_r)
+    med = lambda c: c[len(c) // 2][0]
+    print("resnet50 1024x1024 batch 8 bf16 + fp8 attention: logits l2 vs the fp32 HIP step %.3e (fp32 pipeline on bf16-rounded weights + "
+          "images: %.3e); gradient cosine min %.4f (%s) median %.5f | yardstick min %.4f (%s) median %.5f"
+          % (got, sens, cb[0][0], cb[0][1], med(cb), cr[0][0], cr[0][1], med(cr)))
+    assert got <= 3.0 * sens, (got, sens)
+    assert 1.0 - med(cb) <= 3.0 * (1.0 - med(cr)) + 1e-3
+    assert 1.0 - cb[0][0] <= 3.0 * (1.0 - cr[0][0]) + 1e-2
 
 
 def test_resnet50_trunk_backward_on_sixteen_row_tiles_matches_the_reference(golden_dir):
@@ -177,7 +208,7 @@ def test_resnet50_trunk_backward_on_sixteen_row_tiles_matches_the_reference(gold
     g, name, stride, a, b, lab = load(golden_dir, "r50_512_b8_train")
     fl = json.load(open(os.path.join(golden_dir, "grad_noise_floor.json")))[name]
     L = _lib.lib()
-    assert L.dh_conv2d_fwd_num_tiles(16, 64, 64, 256, 3, 1) == 16 * 4 * 4          # layer3's 3x3 convolutions: 16-row tiles
+    assert L.dh_conv2d_fwd_num_tiles(0, 16, 64, 64, 256, 3, 1) == 16 * 4 * 4          # layer3's 3x3 convolutions: 16-row tiles
     net = make_net(name, "fp32")
     y = net(a.cuda(), b.cuda())
     loss = losses.focal_loss(y, lab.cuda())

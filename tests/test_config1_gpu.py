@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 import cdnet_ref as O
+import _bounds as B
 
 pytestmark = pytest.mark.gpu
 NAME, BATCH, SIZE, LR = "base_transformer_pos_s4", 32, 256, 1e-3
@@ -45,7 +46,7 @@ def graphed(dtype, a, b, lab, state=None):
 
 
 @pytest.mark.parametrize("cdtype", ["fp32", "bf16x3"])
-def test_config1_full_size_fp32_graphed_step_matches_oracle(oracle_step, cdtype):
+def test_config1_full_size_fp32_graphed_step_matches_oracle(oracle_step, cdtype, golden_dir):
     """both parity modes: exact fp32 MFMA and the split-bf16 three-product form (compute_dtype="bf16x3", what bench.py's
     parity_mode times) -- same bounds"""
     r = oracle_step
@@ -56,23 +57,17 @@ def test_config1_full_size_fp32_graphed_step_matches_oracle(oracle_step, cdtype)
     print("configs[1] " + cdtype + ": logits rel err %.3e, loss %.7f (oracle %.7f)" % (err, loss, r["loss"]))
     assert err <= 2e-4
     assert abs(loss - r["loss"]) <= 2e-5 * max(1.0, abs(r["loss"]))
-    # gradients (the arena still holds them after the replay): every tensor by cosine, the set by median distance
-    rels, coss = [], []
+    # gradients (the arena still holds them after the replay): every tensor against the oracle's, bounded by stated multiples of the
+    # oracle's OWN float32-vs-float64 distance on THIS batch (tests/golden/grad_noise_floor.json, key "...@config1": relative L2
+    # 2.5e-3 median / 3.9e-3 worst tensor at 32 x 256 x 256 -- three orders above the 3 x 64 x 64 case, more ties flip) -- worst
+    # tensor, median, cosine (tests/_bounds.py)
     params = dict(net.named_parameters())
-    for k, ref in r["grads"].items():
-        p = params[k]
-        assert (p.grad is None) == (ref is None), k
-        if ref is None:
-            continue
-        g = p.grad.cpu()
-        e, s = float((g - ref).abs().max()), float(ref.abs().max())
-        rels.append(e / max(s, 1e-30))
-        if ref.numel() >= 64 and float(ref.norm()) > 0:
-            coss.append((float(F.cosine_similarity(g.double().flatten(), ref.double().flatten(), dim=0)), k))
-    print("configs[1] " + cdtype + ": grad rel err median %.2e, p90 %.2e, max %.2e; min cosine %.5f (%s)"
-          % (float(np.median(rels)), float(np.quantile(rels, 0.9)), max(rels), min(coss)[0], min(coss)[1]))
-    assert float(np.median(rels)) <= 2e-2
-    assert min(coss)[0] >= 0.995, min(coss)
+    got, ref = {}, {}
+    for k, gr in r["grads"].items():
+        assert (params[k].grad is None) == (gr is None), k
+        if gr is not None:
+            got[k], ref[k] = params[k].grad, gr
+    B.assert_grads_at_floor(got, ref, B.floor(NAME + "@config1", golden_dir), "configs[1] " + cdtype)
     # the AdamW update the graph applied: first step = -lr * (sign(g) + wd * w); only elements whose gradient is far
     # from zero have a well-defined sign
     bad = tot = 0

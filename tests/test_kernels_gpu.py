@@ -93,6 +93,27 @@ def test_conv2d_fwd(ops, dtype, mma, cfg):
     close(tot[1, :cfg["cout"]], (want * want).sum((0, 2, 3)), dtype, "stats sumsq")
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_bf16_conv_statistics_buffer_under_a_split_fp32_mode(ops, mode):
+    """dh_conv2d_fwd_num_tiles takes the dtype of the launch that fills the buffer: a bf16 convolution with BatchNorm partial sums
+    issued while the thread's fp32 MMA mode is a split form (the library default under DAHITRA_F32_MMA, or after a bf16x3 engine
+    ran in the thread) tiles by the bf16 rule -- 8-row tiles for 32 <= Cin < 128 where the split fp32 forms take 16 rows.  Sized
+    by the fp32 rule the buffer had half the tile columns the kernel writes."""
+    dtype, N, C, H = torch.bfloat16, 8, 64, 64                      # 8 x 4 x 8 = 256 tiles of 8 rows
+    x = rnd((N, C, H, H), dtype, 21)
+    w = rnd((C, C, 3, 3), dtype, 22, scale=(C * 9) ** -0.5)
+    want = F.conv2d(x, w, None, 1, 1)
+    wp, _ = ops.pack_weight(w.cuda(), dtype, want_dgrad=False)
+    with ops.f32_mma_mode(0):
+        y0, st0 = ops.conv2d(dev(nhwc(x), dtype), wp, C, 3, 1, 1, want_stats=True)
+    with ops.f32_mma_mode(mode):
+        y1, st1 = ops.conv2d(dev(nhwc(x), dtype), wp, C, 3, 1, 1, want_stats=True)
+    torch.cuda.synchronize()
+    assert st1.shape == st0.shape
+    assert torch.equal(y1, y0) and torch.equal(st1, st0)
+    close(st1.sum(2).cpu()[0, :C], want.sum((0, 2, 3)), dtype, "stats sum", scale=float(want.abs().sum((0, 2, 3)).max()))
+
+
 @pytest.mark.parametrize("dtype,mma", DTYPES_MMA)
 @pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("want_stats", [False, True])

@@ -213,3 +213,91 @@ def test_evaluation_uses_rank0_batchnorm_statistics_on_every_rank(tmp_path):
     assert torch.equal(b0["rm"], b1["rm"]) and float(b1["rm"][0]) == 1.0         # rank 0 filled its buffers with 1
     assert b0["nbt"] == b1["nbt"] == 10
     assert b0["params_untouched"] and b1["params_untouched"]
+
+
+def _forms_worker(rank, world, port, out):
+    """both forms of the data-parallel exchange (dahitra_amd/graph.py) on the net's REAL flat gradient arena, filled with this
+    rank's oracle gradients: "serial" = one all-reduce of the arena; "overlapped" = the tail [split, end) asynchronously, then the
+    head, both waited for -- then the same AdamW update (1 / world folded into the gradient, as dahitra_amd.optim does)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), DAHITRA_OVERLAP="1")
+    torch.set_num_threads(2)
+    import cdnet_ref as O
+    from dahitra_amd import parallel
+    from dahitra_amd.models.networks import CDNet
+    parallel.init_from_env("gloo")
+    a, b, lab = O.synthetic_batch(4, 64, seed=3)
+    lo, hi = parallel.shard_batch(4, rank, world)
+    st = O.TrainState(NAME, O.deterministic_state(NAME), lr=0.01)
+    O.focal_loss(O.forward(st.sd, NAME, a[lo:hi], b[lo:hi], training=True), lab[lo:hi]).backward()
+    net = CDNet(NAME, "fp32")
+    net._ensure_arena(torch.device("cpu"))
+    n = net._arena.n_active
+    grad = torch.zeros(n)
+    for k in net._active_keys:                        # the arena's own order and offsets
+        o, ln = net._arena.offsets[k]
+        grad[o:o + ln] = st.sd[k].grad.reshape(-1)
+    split = parallel.split_offset(net, world)
+    assert split is not None and 0 < split < n
+    serial = grad.clone()
+    scale = parallel.allreduce_sum_(serial)
+    over = grad.clone()
+    w1 = dist.all_reduce(over[split:], op=dist.ReduceOp.SUM, async_op=True)
+    w2 = dist.all_reduce(over[:split], op=dist.ReduceOp.SUM, async_op=True)
+    w1.wait()
+    w2.wait()
+    upd = []
+    for g in (serial, over):
+        p = torch.nn.Parameter(torch.linspace(-1, 1, n))
+        p.grad = g * scale
+        opt = torch.optim.AdamW([p], lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+        opt.step()
+        upd.append(p.detach().clone())
+    torch.save({"serial": serial, "over": over, "p_serial": upd[0], "p_over": upd[1], "split": split, "n": n},
+               os.path.join(out, "f%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_serial_and_overlapped_exchange_leave_bit_equal_parameters(tmp_path):
+    """whichever form DAHITRA_OVERLAP=auto picks, the step's result is the same -- the all-reduce is
+    element-wise, so reducing the arena in one piece or as tail + head gives the same bits, on every rank, and so does the update"""
+    port = _free_port()
+    mp.spawn(_forms_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    f0, f1 = (torch.load(os.path.join(tmp_path, "f%d.pt" % r)) for r in (0, 1))
+    for f in (f0, f1):
+        assert torch.equal(f["serial"], f["over"])
+        assert torch.equal(f["p_serial"], f["p_over"])
+    assert torch.equal(f0["serial"], f1["serial"]) and torch.equal(f0["p_over"], f1["p_over"])
+    assert 3006562 <= f0["n"] <= 3006562 + 64 and f0["split"] == f1["split"]      # (grad-carrying parameters + the arena's alignment padding)
+
+
+def test_overlap_auto_picks_the_form_from_world_size_and_tail_bytes(monkeypatch):
+    """parallel.split_offset(net, world) under DAHITRA_OVERLAP=auto (the default): overlapped only where the modelled ring
+    all-reduce of the arena tail outlasts what the two-graph form costs on one rank (0.18 ms measured, bench.py ddp_rehearsal)"""
+    sys.path.insert(0, ROOT)
+    from dahitra_amd import parallel
+    from dahitra_amd.models.networks import CDNet
+    for k in ("DAHITRA_OVERLAP", "DAHITRA_NO_OVERLAP", "DAHITRA_OVERLAP_OVERHEAD_US", "DAHITRA_XGMI_GBS"):
+        monkeypatch.delenv(k, raising=False)
+    net = CDNet(NAME, "fp32")
+    net._ensure_arena(torch.device("cpu"))
+    always = parallel.split_offset(net)                               # (no world given: the split point itself)
+    assert always is not None
+    tail = (net._arena.n_active - always) * 4
+    assert parallel.allreduce_model_us(tail, 1) == 0.0
+    t2, t8 = parallel.allreduce_model_us(tail, 2), parallel.allreduce_model_us(tail, 8)
+    assert 100 < t2 < 180 < t8 < 400                                  # 9.3 MB: ~0.12 ms between two ranks, ~0.26 ms in a ring of eight
+    assert parallel.split_offset(net, 2) is None and parallel.split_offset(net, 8) == always
+    monkeypatch.setenv("DAHITRA_OVERLAP", "1")
+    assert parallel.split_offset(net, 2) == always
+    monkeypatch.setenv("DAHITRA_OVERLAP", "0")
+    assert parallel.split_offset(net, 8) is None
+    monkeypatch.setenv("DAHITRA_OVERLAP", "auto")
+    monkeypatch.setenv("DAHITRA_OVERLAP_OVERHEAD_US", "60")           # a cheaper two-graph form moves the crossover
+    assert parallel.split_offset(net, 2) == always
+    monkeypatch.setenv("DAHITRA_OVERLAP", "sometimes")
+    with pytest.raises(ValueError):
+        parallel.split_offset(net, 2)

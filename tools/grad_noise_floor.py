@@ -30,6 +30,9 @@ import cdnet_ref as O  # noqa: E402
 R50 = "base_transformer_pos_s4_resnet50"
 NETS = ["base_transformer_pos_s4", "base_transformer_pos_s4_dd8_t8_e2d4", "newUNetTrans", R50]
 CASE = dict(batch=3, size=64, seed=77)          # (newUNetTrans runs at 256 x 256 only: batch 2 there)
+# BASELINE.json configs[1] at its own size (tests/test_config1_gpu.py: batch 32, 256 x 256, seed 1234): stored under this key
+CONFIG1 = "base_transformer_pos_s4@config1"
+CONFIG1_CASE = dict(batch=32, size=256, seed=1234)
 
 
 def grads(name, dtype, batch, size, seed):
@@ -46,7 +49,9 @@ def grads(name, dtype, batch, size, seed):
 def measure(name, threads=8):
     torch.set_num_threads(threads)
     case = dict(CASE)
-    if O.get_config(name)["kind"] != "bit":
+    if name == CONFIG1:
+        name, case = name.split("@")[0], dict(CONFIG1_CASE)
+    elif O.get_config(name)["kind"] != "bit":
         case.update(batch=2, size=256)
     g64 = grads(name, torch.float64, **case)
     g32 = grads(name, torch.float32, **case)
