@@ -521,25 +521,31 @@ def main():
     if headline_run and not args.no_ddp_rehearsal and not profiled and os.environ.get("DAHITRA_FORCE_DIST", "0") != "1":
         import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        env = dict(os.environ, DAHITRA_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "20", "--warmup", "5", "--batch", str(args.batch),
                "--no-cpu-baseline", "--no-parity-mode", "--no-secondary", "--no-ddp-rehearsal", "--no-roofline"]
-        try:
+
+        def child(overlap):
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            env = dict(os.environ, DAHITRA_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                       DAHITRA_OVERLAP=overlap)
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode == 0 and len(line) == 1:
-                cj = json.loads(line[0])
-                rehearsal = {"ms_per_step": cj["ms_per_step"], "value": cj["value"], "unit": "image-pairs/s", "steps": cj["steps"],
-                             "rccl_ranks": cj["rccl_ranks"], "step_form": cj["config"].get("step_form"),
-                             "how": "child process, DAHITRA_FORCE_DIST=1: RCCL process group of one rank, parameter broadcast, two "
-                                    "recorded graphs around the asynchronous all-reduce of the arena tail, second all-reduce, AdamW "
-                                    "with 1/world -- the launches an N-GPU rank makes (the collectives move no bytes here)"}
-            else:
-                rehearsal = {"error": (r.stderr or r.stdout)[-400:]}
+            if r.returncode != 0 or len(line) != 1:
+                raise RuntimeError((r.stderr or r.stdout)[-400:])
+            return json.loads(line[0])
+        try:
+            cj, sj = child("1"), child("0")
+            rehearsal = {"ms_per_step": cj["ms_per_step"], "value": cj["value"], "unit": "image-pairs/s", "steps": cj["steps"],
+                         "rccl_ranks": cj["rccl_ranks"], "step_form": cj["config"].get("step_form"),
+                         "serial_form": {"ms_per_step": sj["ms_per_step"], "value": sj["value"], "step_form": sj["config"].get("step_form")},
+                         "how": "child processes, DAHITRA_FORCE_DIST=1: RCCL process group of one rank, parameter broadcast, then (a) "
+                                "DAHITRA_OVERLAP=1: two recorded graphs around the asynchronous all-reduce of the arena tail, second "
+                                "all-reduce, AdamW with 1/world; (b) serial_form, DAHITRA_OVERLAP=0: one graph, one all-reduce, AdamW -- "
+                                "the launches an N-GPU rank makes (the collectives move no bytes here).  DAHITRA_OVERLAP=auto picks "
+                                "between them per world size and tail bytes (dahitra_amd/parallel.py)"}
         except Exception as e:                                         # the headline line never depends on the rehearsal
             rehearsal = {"error": repr(e)[:400]}
 

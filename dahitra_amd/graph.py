@@ -182,6 +182,9 @@ class GraphedTrainStep:
     def _second(self):
         """graph 2 (layer2 / layer1 / stem backward) replays WHILE the all-reduce of the arena tail runs on RCCL's stream: its
         BatchNorm backward must not be the persistent one-launch form, whose device-wide barrier needs every CU"""
+        if os.environ.get("DAHITRA_OVERLAP_PERSIST_BN") == "1":      # EXPERIMENT (one rank only): what the two-pass BatchNorm of graph 2 costs
+            self.net._engine.backward_second()
+            return
         with ops.no_persist_bn():
             self.net._engine.backward_second()
 

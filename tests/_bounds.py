@@ -21,7 +21,29 @@ import torch.nn.functional as F
 FLOOR_X_WORST, FLOOR_X_MEDIAN = 5.0, 5.0
 FLOOR_MIN_L2, FLOOR_MIN_MEDIAN = 2e-3, 1e-4        # absolute lower ends: the well-conditioned small cases' floors are ~1e-5
 FLOOR_X_COS = 8.0                                   # 1 - cos may be this many times the floor's worst (1 - cos)
-FLOOR_X_TENSOR, FLOOR_MIN_TENSOR = 8.0, 3e-4        # per tensor against its OWN floor, with an absolute lower end (CALIBRATE)
+# ... and per tensor against its OWN floor.  Measured on MI355X (profiles/r06a_grad_fixture_values.txt): every tensor of
+# base_transformer_pos_s4, _dd8_t8_e2d4 and the ResNet-50 variant within 8 x its own floor (worst 7.9 x, on floors of 5e-6), but
+# WHICH ties flip is a property of the run, not of the code: on newUNetTrans the exact-fp32 HIP run flips a ReLU of layer3.0 that
+# the oracle's float32-vs-float64 pair does not, and the three tensors around it (layer3.0.bn1.bias / .weight, conv1.weight) sit
+# at 2 - 3e-3 where their own floor is 5e-5 -- the size the floor file shows for tensors next to ITS flips.  So a few tensors
+# (3, or 2 % of them) may exceed their own bound while staying inside the worst-tensor bound above.  What a single wrong
+# weight-gradient kernel at 1e-3 turns red is therefore the KERNEL-level check (`close`, below: 8e-5 of the tensor's maximum
+# in fp32 on tie-free data), not this one; tests/test_bounds_cpu.py pins both statements.
+FLOOR_X_TENSOR, FLOOR_MIN_TENSOR = 10.0, 3e-4
+TIE_OUTLIERS_MIN, TIE_OUTLIERS_FRAC = 3, 0.02
+
+
+# ---- kernel-level closeness (tests/test_kernels_gpu.py: one kernel against torch on random, tie-free data) ----
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 2.5e-2
+
+
+def close(got, want, dtype, what, scale=None, factor=1.0):
+    """max |got - want| <= factor x tol(dtype) x max |want| (or `scale`)"""
+    got = got.float().cpu()
+    s = float(want.abs().max()) if scale is None else scale
+    err = float((got - want).abs().max())
+    assert err <= factor * tol(dtype) * max(s, 1e-6), "%s: max err %.3e vs scale %.3e (%s)" % (what, err, s, dtype)
 
 
 def floor(name, golden_dir):
@@ -70,8 +92,10 @@ def assert_grads_at_floor(got, ref, fl, what=""):
             if os.environ.get("DAHITRA_TEST_VERBOSE"):
                 print("VERBOSE floor %s %s %.3e floor %.3e" % (what, k, v, per[k]["rel_l2"]))
     bad = {k: r for k, r in ratios.items() if r > 1.0}
-    assert not bad, "gradient tensors beyond %g x their own fp32-vs-fp64 floor (>= %g): %s" % (FLOOR_X_TENSOR, FLOOR_MIN_TENSOR, sorted(bad.items(), key=lambda kv: -kv[1])[:5])
-    return dict(median=med, worst=rl2[worst], worst_key=worst, min_cos=min(coss))
+    allowed = max(TIE_OUTLIERS_MIN, int(TIE_OUTLIERS_FRAC * len(ratios)))
+    assert len(bad) <= allowed, "%d gradient tensors (allowed: %d) beyond %g x their own fp32-vs-fp64 floor (>= %g): %s" % (
+        len(bad), allowed, FLOOR_X_TENSOR, FLOOR_MIN_TENSOR, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
+    return dict(median=med, worst=rl2[worst], worst_key=worst, min_cos=min(coss), outliers=sorted(bad))
 
 
 # ---- fixture-based train tests (the reference wrote gradient NORMS of every tensor and a few small tensors in full) ----

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 # tests/_bounds.py; measured on MI355X (profiles/r06a_grad_fixture_values.txt): gradient norms worst 8.9e-4 / 9.0e-4 (exact / bf16x3),
 # stored tensors 8.2e-3 (tie-sized) and 8.9e-4 (others): 3 x those, the tie-sized ones keep B.GRAD_TOL_TIE
 GRAD_TOL_REST, NORM_TOL = 3e-3, 3e-3
-NORM_TOL_XBD = 3e-2          # CALIBRATE
+NORM_TOL_XBD = 2e-3          # xBD 1024 x 1024 batch 4: 3 x the worst measured (6.2e-4; the biases that cancel in |t2 - t1| have zero norm: absolute term)
 R50 = "base_transformer_pos_s4_resnet50"
 
 

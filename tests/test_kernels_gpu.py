@@ -17,8 +17,7 @@ DTYPES_MMA = [pytest.param(torch.float32, 0, id="float32"), pytest.param(torch.b
               pytest.param(torch.float32, 3, id="f16x3")]
 
 
-def tol(dtype):
-    return 2e-5 if dtype == torch.float32 else 2.5e-2
+from _bounds import close, tol      # (shared with tests/test_bounds_cpu.py, which checks the checker)
 
 
 def rnd(shape, dtype, seed, scale=1.0):
@@ -37,13 +36,6 @@ def nhwc(x):      # NCHW cpu -> NHWC
 
 def nchw(x):
     return x.permute(0, 3, 1, 2).contiguous()
-
-
-def close(got, want, dtype, what, scale=None, factor=1.0):
-    got = got.float().cpu()
-    s = float(want.abs().max()) if scale is None else scale
-    err = float((got - want).abs().max())
-    assert err <= factor * tol(dtype) * max(s, 1e-6), "%s: max err %.3e vs scale %.3e (%s)" % (what, err, s, dtype)
 
 
 @pytest.fixture(scope="module")
@@ -834,9 +826,9 @@ def test_maxpool_with_batchnorm_relu_on_load(ops, dtype):
 BENCH_N = 64
 
 
-def _is_rw4(ops, N, OH, OW, cin, ks=3, stride=1):
+def _is_rw4(ops, N, OH, OW, cin, ks=3, stride=1, dtype=torch.bfloat16):
     from dahitra_amd import _lib
-    nt = _lib.lib().dh_conv2d_fwd_num_tiles(N, OH, OW, cin, ks, stride)
+    nt = _lib.lib().dh_conv2d_fwd_num_tiles(0 if dtype == torch.float32 else 1, N, OH, OW, cin, ks, stride)
     return nt == N * ops.cdiv(OH, 16) * ops.cdiv(OW, 16) and nt != N * ops.cdiv(OH, 8) * ops.cdiv(OW, 16)
 
 
@@ -854,7 +846,7 @@ def _is_rw4(ops, N, OH, OW, cin, ks=3, stride=1):
 def test_conv2d_fwd_bench_scale_16row_tiles(ops, dtype, mma, cfg):
     N = cfg.get("n", BENCH_N)
     dil = cfg.get("dil", 1)
-    assert _is_rw4(ops, N, cfg["h"], cfg["w"], cfg["cin"]), "case does not select the 16-row tile"
+    assert _is_rw4(ops, N, cfg["h"], cfg["w"], cfg["cin"], dtype=dtype), "case does not select the 16-row tile"
     x = rnd((N, cfg["cin"], cfg["h"], cfg["w"]), dtype, 601)
     w = rnd((cfg["cout"], cfg["cin"], 3, 3), dtype, 602, scale=(cfg["cin"] * 9) ** -0.5)
     b = rnd((cfg["cout"],), torch.float32, 603, 0.1)
@@ -899,7 +891,7 @@ def test_conv2d_dgrad_wgrad_bench_scale(ops, dtype, mma, cfg):
     dyp = torch.zeros(N, cfg["h"], cfg["w"], cout_k)
     dyp[..., :cfg["cout"]] = nhwc(dy)
     if cout_k >= 128:
-        assert _is_rw4(ops, N, cfg["h"], cfg["w"], cout_k)
+        assert _is_rw4(ops, N, cfg["h"], cfg["w"], cout_k, dtype=dtype)
     dx = ops.conv2d(dev(dyp, dtype), wd, cfg["cin"], 3, 1, 1)
     close(nchw(dx), x.grad, dtype, "dgrad (bench scale)", factor=2.0)
     xd, dyd = dev(nhwc(x.detach()), dtype), dev(nhwc(dy), dtype)
