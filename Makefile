@@ -25,7 +25,9 @@ $(OBJ)/norm.o: EXTRA := -mllvm -amdgpu-mfma-vgpr-form
 
 # conv_wreg: its stream loop is ONE fully unrolled tile (up to 1152 steps); the default pragma-unroll budget (16 K instructions)
 # silently falls back to a partial unroll, which turns the register-resident weight array into scratch memory
-$(OBJ)/conv_wreg.o: EXTRA := -mllvm -pragma-unroll-threshold=262144
+# ... and no SLP packing of fp32 chains into v_pk_*_f32: conv3x3_up4_wreg32_kernel returned wrong bits from run to run with it (see the
+# note at that kernel); the other kernels of the file are bit-identical and time-neutral under the flag
+$(OBJ)/conv_wreg.o: EXTRA := -mllvm -pragma-unroll-threshold=262144 -fno-slp-vectorize
 
 $(OBJ)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/conv_mfma_impl.h
 	@mkdir -p $(OBJ)

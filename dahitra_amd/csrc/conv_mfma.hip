@@ -63,6 +63,8 @@ int dh_conv1x1_gemm_launch(const ConvArgs& a, hipStream_t st);
 // 3x3 stride-1 convolutions with the weights resident in registers, persistent workgroups (conv_wreg.hip)
 bool dh_conv_wreg_eligible(const ConvArgs& a, int ks, int stride, int dtype);
 int dh_conv_wreg_launch(const ConvArgs& a, hipStream_t st);
+bool dh_conv_wreg_up4_eligible(const ConvArgs& a);
+int dh_conv_wreg_up4_launch(const ConvArgs& a, hipStream_t st);
 
 // C ABI: see include/dahitra_hip.h
 extern "C" int dh_conv2d_fwd(int dtype, const void* x, const void* w_packed, void* y, const float* bias,
@@ -227,6 +229,9 @@ extern "C" int dh_conv3x3_up4_fwd(const void* a, const void* b, const void* w_pa
     c.up4_a = a; c.up4_b = b;
     c.rw = 2;
     c.tilesX = dh_cdiv(W, TW); c.tilesY = dh_cdiv(H, 8);
+    // the persistent register-resident-weights stream with the interpolation in LDS (csrc/conv_wreg.hip) where it serves the shape;
+    // else (ragged tiles, ReLU, few tiles; DAHITRA_UP4_TAP=1) the tap kernel with the interpolation on its load path
+    if (dh_conv_wreg_up4_eligible(c)) return dh_conv_wreg_up4_launch(c, reinterpret_cast<hipStream_t>(stream));
     return dh_conv_launch_bf16(c, 3, 1, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -787,6 +787,326 @@ int wr32_launch(const ConvArgs& c, hipStream_t st, int cus) {
     return 0;
 }
 
+
+// ---- classifier.0 on the bilinear-x4 upsampled |A - B| map WITHOUT that map (models/networks.py:200,383-389) -------------------
+// The 32 -> 32 stream above, fed from the two COARSE maps a, b [N][H / 4][W / 4][32]: the upsampled tensor (134 MB at 32 pairs of
+// 256 x 256) is neither written by dh_absdiff_upsample4_fwd nor read here.  Per 8 x 16 tile the 10 x 18 halo depends on 4 x 6
+// coarse pixels (rows oy0 / 4 - 1 .. + 2, columns ox0 / 4 - 1 .. + 4, clamped to the map: a clamped entry is only ever read with
+// weight 0).  Three small stages run AHEAD of the matrix stream, each published by the stream's one barrier per tile:
+//   tile T - 4 (after its barrier)   the 2 x 24 x 64 B of a and b are requested into registers of lanes 0 .. 95 (plain loads)
+//   tile T - 3 (after its barrier)   d = |a - b| in fp32, once per coarse value (those 96 lanes: one 8-channel piece each), to LDS
+//   tile T - 1 (steps before the barrier)  every lane interpolates ITS three pieces of the halo image -- the pieces its loads bring
+//                                     in the kernel above -- from d: the four bilinear terms in the order of absdiff_up4_fwd_kernel
+//                                     (bit-identical to convolving that kernel's bf16 output), one piece per step between the MFMAs
+// so the interpolation happens ONCE per halo element, in LDS, beside the matrix work of the tile before.  (The first attempt
+// put it on the load path of the tap kernel, which stages 18 KB of weights per tile and cannot overlap anything inside its one
+// tile per workgroup: 121 us against 32 + 76 for the two-kernel path.)
+// THIS FILE IS COMPILED WITH -fno-slp-vectorize (Makefile): with the default SLP packing of the interpolation's fp32 chains
+// into v_pk_fma_f32 / v_pk_mul_f32 the kernel returned, from run to run, wrong EVEN channels for groups of 16 consecutive lanes
+// (4 adjacent halo pixels; 0.1 - 0.4 % of the pixels), with every cross-wave stage fenced by full barriers and with or without
+// the direct-to-LDS loads -- scalar fp32 instructions give the materialised path's bits on every run (tools/up4_bench.py,
+// test_classifier0_upsample_fused_into_the_weights_resident_stream).  The other kernels of the file are bit-identical and time-
+// neutral under the flag (s4 step 9667 / 9632 against 9656 / 9628 pairs/s, same box, interleaved).
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void conv3x3_up4_wreg32_kernel(WrArgs a) {
+    constexpr int D = 3, PFD = 2, NB = PFD + 1;
+    constexpr int RH = 4, HR = RH + 2;
+    constexpr int NSTEP = 3 * HR;
+    constexpr int SYNC = 8;
+    constexpr int NCO = 32, TPITCH = NCO * 2 + 16, PPR = NCO * 2 / 16;
+    constexpr int NST = WR_TH * TW * PPR / 256;
+    constexpr int CPX = 4 * 6;                             // coarse pixels per tile footprint
+    constexpr int DSLOT = CPX * 32 * 4;                    // bytes of one |a - b| slot: [24 px][32 fp32]
+    static_assert(NSTEP % NB == 0 && SYNC + NST + 1 < NSTEP && RH < SYNC, "pipeline shape");
+    const ConvArgs& p = a.c;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* dif0 = smem;                                                       // [2 slots][DSLOT]
+    unsigned char* ring = dif0 + 2 * DSLOT;
+    constexpr int OT = WR_TH * TW * TPITCH;
+    unsigned char* otile0 = ring + D * WR_IMG;
+    float* spart0 = reinterpret_cast<float*>(otile0 + 2 * OT);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, g = lane >> 4;
+    const int ch = wv & 1, rh = wv >> 1;
+    const int j0 = blockIdx.x;
+    const int co_w = ch * 16;
+    const int CHh = p.H >> 2, CWw = p.W >> 2;
+
+    s16x8 A[9];
+    {
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(p.w);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            A[t] = *reinterpret_cast<const s16x8*>(
+                a.wfrag ? wb + ((size_t)ch * 9 + t) * 1024 + lane * 16
+                        : wb + ((size_t)(t * p.CoutPad + co_w + pl) * 32 + g * 8) * 2);
+    }
+    float bs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bs[j] = p.bias ? p.bias[co_w + g * 4 + j] : 0.f;
+
+    // this lane's three pieces of a halo image (as the loads of the kernel above bring them): (source piece, hy, hx) or -1
+    int hyx[WR_NI];
+#pragma unroll
+    for (int k = 0; k < WR_NI; ++k) {
+        const int i = (k * 4 + wv) * 64 + lane, px = i >> 2, qs = i & 3;
+        const int hy = px / WR_HW, hx = px - hy * WR_HW;
+        hyx[k] = px < WR_NPX ? (((qs ^ (((hx >> 2) & 1) << 1)) << 16) | (hy << 8) | hx) : -1;
+    }
+    int lo[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) lo[kw] = wr_off(rh * RH, pl + kw, g);
+
+    const int K = a.nunits > j0 ? (a.nunits - j0 + a.J - 1) / a.J : 0;
+    // tile T of this workgroup's stream -> (image, oy0, ox0); T >= K: a dummy inside the first image (its stages are computed
+    // and never read)
+    auto coords = [&](int T, int& n, int& oy0, int& ox0) {
+        const int u = T < K ? j0 + T * a.J : 0;
+        const int tx = u % a.tilesX, r = u / a.tilesX, uy = r % a.unitsY;
+        n = r / a.unitsY; oy0 = uy * WR_TH; ox0 = tx * TW;
+    };
+    // stage 1: the coarse footprint of tile T into REGISTERS of lanes 0 .. 95 (piece tid of [24 px][4 pieces], a and b): plain
+    // global loads, consumed one tile later -- the only loads of the stream, so the wait the compiler puts in front of their
+    // use finds nothing else outstanding (the stores of a tile's epilogue are issued after it)
+    uint4 fa = make_uint4(0, 0, 0, 0), fb = fa;
+    auto load_coarse = [&](int T) {
+        if (tid >= CPX * 4) return;
+        int n, oy0, ox0;
+        coords(T, n, oy0, ox0);
+        const int cp = tid >> 2, q = tid & 3, r = cp / 6, c = cp - r * 6;
+        int cy = (oy0 >> 2) - 1 + r, cx = (ox0 >> 2) - 1 + c;
+        cy = cy < 0 ? 0 : (cy > CHh - 1 ? CHh - 1 : cy);
+        cx = cx < 0 ? 0 : (cx > CWw - 1 ? CWw - 1 : cx);
+        const size_t off = (((size_t)n * CHh + cy) * CWw + cx) * 32 + q * 8;
+        fa = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.up4_a) + off);
+        fb = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.up4_b) + off);
+    };
+    // stage 2: d = |a - b| (fp32) of the footprint in the registers -> difference slot T & 1
+    auto absdiff = [&](int T) {
+        if (tid >= CPX * 4) return;
+        float u[8], v[8];
+        unpack16(fa, u);
+        unpack16(fb, v);
+        float* d = reinterpret_cast<float*>(dif0 + (T & 1) * DSLOT) + tid * 8;
+        *reinterpret_cast<float4*>(d) = make_float4(fabsf(u[0] - v[0]), fabsf(u[1] - v[1]), fabsf(u[2] - v[2]), fabsf(u[3] - v[3]));
+        *reinterpret_cast<float4*>(d + 4) = make_float4(fabsf(u[4] - v[4]), fabsf(u[5] - v[5]), fabsf(u[6] - v[6]), fabsf(u[7] - v[7]));
+    };
+    // stage 3: piece k of this lane in the halo image of tile T (ring slot `slot`), from difference slot T & 1
+    auto interp = [&](int T, int slot, int k) {
+        const int code = wr_opaque(hyx[k]);
+        if (code < 0) return;
+        int n, oy0, ox0;
+        coords(T, n, oy0, ox0);
+        const int hy = (code >> 8) & 0xff, hx = code & 0xff, q = (code >> 16) & 3;
+        const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+        uint4 out = make_uint4(0, 0, 0, 0);                // padding of the upsampled tensor
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+            int y0, y1, x0, x1;
+            float ly, lx;
+            up4_src(iy, CHh, y0, y1, ly);
+            up4_src(ix, CWw, x0, x1, lx);
+            const float wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+            const int cyb = (oy0 >> 2) - 1, cxb = (ox0 >> 2) - 1;
+            const int rr[2] = {y0 - cyb, y1 - cyb}, cc[2] = {x0 - cxb, x1 - cxb};
+            const float* dbase = reinterpret_cast<const float*>(dif0 + (T & 1) * DSLOT);
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const float* d = dbase + (rr[pp] * 6 + cc[qq]) * 32 + q * 8;
+                    float dv[8];
+                    *reinterpret_cast<float4*>(dv) = *reinterpret_cast<const float4*>(d);
+                    *reinterpret_cast<float4*>(dv + 4) = *reinterpret_cast<const float4*>(d + 4);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += wy[pp] * wx[qq] * dv[j];
+                }
+            out = pack16<bf16>(acc);
+        }
+        *reinterpret_cast<uint4*>(ring + slot * WR_IMG + ((k * 4 + wv) * 64 + lane) * 16) = out;
+    };
+
+    f32x4 acc[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ssum[4], ssq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+
+    // ---- prologue: differences 0 .. 2 formed, halo image 0 published, footprint 3 in the registers ----
+#pragma unroll
+    for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(A[t]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bs[j]));
+    load_coarse(0);
+    absdiff(0);
+    load_coarse(1);
+    absdiff(1);
+    load_coarse(2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // differences 0, 1 published
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < WR_NI; ++k) interp(0, 0, k);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // halo image 0 published; difference slot 0 free
+    asm volatile("" ::: "memory");
+    absdiff(2);                                            // (published by the barrier of tile 0, read in tile 1)
+    load_coarse(3);
+    int s0 = 0;                                            // ring slot of the current tile
+
+    V16u B[NB];
+    auto rd = [&](int gg) {
+        const int st = gg / NSTEP, i = gg - st * NSTEP, kw = i / HR, hh = i - kw * HR;
+        int slot = s0 + st;
+        slot = slot >= D ? slot - D : slot;
+        B[gg % NB].u = *reinterpret_cast<const uint4*>(ring + slot * WR_IMG + lo[kw] + hh * (WR_HW * 64));
+    };
+#pragma unroll
+    for (int gg = 0; gg < PFD; ++gg) rd(gg);
+
+    int en = 0, eoy0 = 0, eox0 = 0;                        // the tile whose epilogue is pending
+    unsigned char* otile = otile0;
+    float* spart = spart0;
+    auto epi_row = [&](int r) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = acc[r][j] + bs[j];
+            ssum[j] += v[j];
+            ssq[j] += v[j] * v[j];
+        }
+        st4(reinterpret_cast<bf16*>(otile + ((rh * RH + r) * TW + pl) * TPITCH) + co_w + g * 4, v);
+    };
+    float tsum[4], tsq[4];
+    auto epi_stats_park = [&]() {
+        if (!p.stats) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tsum[j] = row16_sum(ssum[j]); tsq[j] = row16_sum(ssq[j]);
+            ssum[j] = 0.f; ssq[j] = 0.f;
+        }
+        if (rh == 1 && pl == 0) {
+            *reinterpret_cast<float4*>(spart + ((ch * 4 + g) * 2 + 0) * 4) = make_float4(tsum[0], tsum[1], tsum[2], tsum[3]);
+            *reinterpret_cast<float4*>(spart + ((ch * 4 + g) * 2 + 1) * 4) = make_float4(tsq[0], tsq[1], tsq[2], tsq[3]);
+        }
+    };
+    auto epi_stats_write = [&](int kk) {
+        if (!p.stats || rh != 0 || pl != 0) return;
+        const int unit = j0 + kk * a.J;
+        const float4 us = *reinterpret_cast<const float4*>(spart + ((ch * 4 + g) * 2 + 0) * 4);
+        const float4 uq = *reinterpret_cast<const float4*>(spart + ((ch * 4 + g) * 2 + 1) * 4);
+        const float hs[4] = {us.x, us.y, us.z, us.w}, hq[4] = {uq.x, uq.y, uq.z, uq.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = co_w + wr_opaque(g) * 4 + j;
+            p.stats[((size_t)0 * p.CoutPad + c) * a.nunits + unit] = tsum[j] + hs[j];
+            p.stats[((size_t)1 * p.CoutPad + c) * a.nunits + unit] = tsq[j] + hq[j];
+        }
+    };
+    uint4 ehold;
+    auto epi_fetch = [&](int it) {
+        const int i = wr_opaque(tid) + it * 256, px = i / PPR, q = i - px * PPR;
+        ehold = *reinterpret_cast<const uint4*>(otile + px * TPITCH + q * 16);
+    };
+    auto epi_store = [&](int it) {
+        bf16* yout = reinterpret_cast<bf16*>(p.y) + (size_t)en * p.OH * p.OW * p.Cout;
+        const int i = wr_opaque(tid) + it * 256, px = i / PPR, q = i - px * PPR;
+        *reinterpret_cast<uint4*>(yout + (size_t)((eoy0 + (px >> 4)) * p.OW + eox0 + (px & 15)) * p.Cout + q * 8) = ehold;
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int k = 0; k < K; ++k) {
+        const bool pend = k > 0;
+        otile = otile0 + ((k - 1) & 1) * OT;
+        spart = spart0 + ((k - 1) & 1) * 64;
+        int nslot = s0 + 1;
+        nslot = nslot >= D ? nslot - D : nslot;
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) {
+            const int kw = i / HR, hh = i - kw * HR;
+            if (i <= RH && pend) {
+                if (i < RH) epi_row(i);
+                else epi_stats_park();
+            }
+            // the halo image of tile k + 1 from the differences of tile k + 1: one piece in each of three steps before the barrier
+            if (i == 1 || i == 3 || i == 5) interp(k + 1, nslot, (i - 1) >> 1);
+            if (i == SYNC) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            // footprint k + 3 (requested a tile ago) -> the slot of difference k + 1, read before this barrier; then the request
+            // for footprint k + 4.  Before the epilogue's stores: what the wait in front of the registers' use finds outstanding
+            if (i == SYNC + 1) { absdiff(k + 3); load_coarse(k + 4); }
+            if (i == SYNC + 1 && pend) epi_stats_write(k - 1);
+            if (i > SYNC && i <= SYNC + NST + 1 && pend) {
+                if (i > SYNC + 1) epi_store(i - SYNC - 2);
+                if (i <= SYNC + NST) epi_fetch(i - SYNC - 1);
+            }
+            rd(i + PFD);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int r = hh - kh;
+                if (r < 0 || r >= RH) continue;
+                const bool first = kw == 0 && kh == 0;
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[kh * 3 + kw], B[i % NB].h, first ? zero4 : acc[r], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        coords(k, en, eoy0, eox0);
+        s0 = nslot;
+    }
+    if (K > 0) {                                           // the last tile's epilogue
+        otile = otile0 + ((K - 1) & 1) * OT;
+        spart = spart0 + ((K - 1) & 1) * 64;
+#pragma unroll
+        for (int r = 0; r < RH; ++r) epi_row(r);
+        epi_stats_park();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        epi_stats_write(K - 1);
+#pragma unroll
+        for (int it = 0; it < NST; ++it) { epi_fetch(it); epi_store(it); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int wr32_up4_launch(const ConvArgs& c, hipStream_t st, int cus) {
+    constexpr int WPS = 2;
+    WrArgs a;
+    a.c = c;
+    a.ncb = 1;
+    a.subt = 1;
+    a.tilesX = c.OW / TW;
+    a.unitsY = c.OH / WR_TH;
+    a.nunits = c.N * a.unitsY * a.tilesX;
+    int J = (cus * WPS) & ~7;
+    if (J > a.nunits) J = (a.nunits + 7) & ~7;
+    if (J < 8) J = 8;
+    a.J = J;
+    a.wfrag = c.w_frag != nullptr;
+    if (a.wfrag) a.c.w = c.w_frag;
+    const size_t lds = (size_t)3 * WR_IMG + (size_t)2 * WR_TH * TW * (32 * 2 + 16) + 2 * 64 * 4 + 2 * (24 * 32 * 4);
+    auto kern = conv3x3_up4_wreg32_kernel<WPS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        attr_done = true;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            DH_FAIL("conv_wreg32 (up4): cannot raise dynamic LDS");
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(J), dim3(256), lds, st, a);
+    DH_CHECK_LAUNCH("conv_wreg32_up4");
+    return 0;
+}
+
 int g_wreg_mode = -1;      // dh_conv_wreg_mode: -1 = where it is the faster kernel, 0 = never, 1 = wherever it can run
 
 
@@ -838,6 +1158,27 @@ extern "C" int dh_conv_wreg_mode(int mode) {
 extern "C" int dh_debug_wreg_ts(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(wr_ts), (size_t)n * 8); }
 extern "C" int dh_debug_wreg_clear() { static long long z[4096 * 32]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(wr_ts), z, sizeof(z)); }
 #endif
+
+// classifier.0 on upsample4(|a - b|) from the coarse maps (ConvArgs::up4_a / up4_b): the persistent 32 -> 32 stream with the
+// interpolation in LDS.  Eligible: what that stream serves (whole 8x16 tiles, enough of them), no residual, no activation.
+// NOT the default route (DAHITRA_UP4_WREG=1, or dh_conv_wreg_mode(1)): measured at 32 x 256 x 256 (tools/up4_bench.py,
+// profiles/r06a_up4_fused.txt) it takes 116 us against 29.5 + 83.5 for dh_absdiff_upsample4_fwd + the plain stream -- the
+// interpolation more than doubles the stream's vector instructions (rocprofv3 SQ_INSTS_VALU 4.15e7 against 1.82e7, SQ_INSTS_LDS
+// 3.6e6 against 1.7e6) and two waves per SIMD are then bound by VALU issue (~630 instructions per wave and tile next to 36
+// MFMAs), where the plain stream is bound by the 268 MB it moves.
+bool dh_conv_wreg_up4_eligible(const ConvArgs& a) {
+    static const bool off = getenv("DAHITRA_NO_WREG") != nullptr;
+    static const bool on = getenv("DAHITRA_UP4_WREG") != nullptr && atoi(getenv("DAHITRA_UP4_WREG")) == 1;
+    if (off || g_wreg_mode == 0 || !(on || g_wreg_mode == 1) || !a.up4_a || !a.up4_b) return false;
+    if (a.Cin != 32 || a.Cout != 32 || a.CoutPad != 32 || a.res || a.act != DH_ACT_NONE || a.in_scale) return false;
+    if (a.OH != a.H || a.OW != a.W || a.OH % 8 || a.OW % 16) return false;
+    return (long)a.N * (a.OH / 8) * (a.OW / 16) >= (g_wreg_mode == 1 ? 16 : 4 * 512);
+}
+int dh_conv_wreg_up4_launch(const ConvArgs& a, hipStream_t st) {
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    return wr32_up4_launch(a, st, cus);
+}
 
 int dh_conv_wreg_launch(const ConvArgs& a, hipStream_t st) {
     static int cus = 0;

@@ -1881,6 +1881,43 @@ def test_classifier0_on_the_upsampled_absdiff_map_formed_on_load(ops, cfg):
     close(dw_ref, wt.grad, dtype, "weight gradient over the upsampled |a - b|", factor=4.0)
 
 
+@pytest.mark.parametrize("cfg", [dict(n=2, h=16, w=16), dict(n=5, h=8, w=12), dict(n=1, h=2, w=4), dict(n=3, h=32, w=64)])
+def test_classifier0_upsample_fused_into_the_weights_resident_stream(ops, cfg):
+    """north_star "bilinear upsample fused with the seg head", forward: conv3x3_up4_wreg32_kernel (csrc/conv_wreg.hip) -- the
+    persistent 32 -> 32 stream whose halo images are interpolated in LDS from the two coarse maps, one piece per lane and step,
+    three small stages ahead of the matrix work -- against the materialised path (dh_absdiff_upsample4_fwd, then the same
+    convolution): bit for bit, at sizes that give a workgroup one tile, a few, and a ragged count (dh_conv_wreg_mode(1) makes the
+    stream eligible from 16 tiles on); the per-tile BatchNorm sums to fp32 rounding (this stream adds a tile's two row halves)"""
+    from dahitra_amd import _lib
+    N, h, w = cfg["n"], cfg["h"], cfg["w"]
+    dtype = torch.bfloat16
+    a, b = rnd((N, 32, h, w), dtype, 1501), rnd((N, 32, h, w), dtype, 1502)
+    wt = rnd((32, 32, 3, 3), dtype, 1503, (32 * 9) ** -0.5)
+    bias = rnd((32,), torch.float32, 1504, 0.1)
+    ad, bd = dev(nhwc(a), dtype), dev(nhwc(b), dtype)
+    wp, _ = ops.pack_weight(wt.cuda(), dtype, want_dgrad=False)
+    u = ops.Up4Input(ad, bd)
+    mat = u.materialize()
+    L = _lib.lib()
+    prev = L.dh_conv_wreg_mode(0)                      # reference: the tap kernel on the materialised map
+    try:
+        y_ref, st_ref = ops.conv2d(mat, wp, 32, 3, 1, 1, want_stats=True)
+        yb_ref = ops.conv2d(mat, wp, 32, 3, 1, 1, bias=bias.cuda())
+        L.dh_conv_wreg_mode(1)                         # the fused stream wherever it can run
+        y, st = ops.conv2d(u, wp, 32, 3, 1, 1, want_stats=True)
+        yb = ops.conv2d(u, wp, 32, 3, 1, 1, bias=bias.cuda())
+        y2, st2 = ops.conv2d(u, wp, 32, 3, 1, 1, want_stats=True)
+    finally:
+        L.dh_conv_wreg_mode(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref), float((y.float() - y_ref.float()).abs().max())
+    assert torch.equal(yb, yb_ref)
+    assert torch.equal(y2, y) and torch.equal(st2, st)             # reproducible
+    assert float((st - st_ref).abs().max()) <= 1e-5 * float(st_ref.abs().max())
+    up = F.interpolate((a - b).abs(), scale_factor=4, mode="bilinear", align_corners=False)
+    close(nchw(y), F.conv2d(up, wt, None, 1, 1), dtype, "conv over the upsampled |a - b| (interpolated in LDS)", factor=2.0)
+
+
 @pytest.mark.parametrize("cfg", [dict(images=6, rpi=256, depth=8, mlp=32), dict(images=4, rpi=1024, depth=4, mlp=32),
                                  dict(images=2, rpi=4096, depth=3, mlp=64)])
 def test_decoder_stack_in_one_launch_equals_layer_by_layer(ops, cfg):
