@@ -115,6 +115,15 @@ __device__ __forceinline__ uint2 gld8(const char* base, unsigned off) {
 }
 __device__ __forceinline__ void gst8(char* base, unsigned off, uint2 v) { *(gu32x2*)(base + off) = u32x2{v.x, v.y}; }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() is also a fence for global memory, i.e. s_waitcnt vmcnt(0) --
+// it would drain the next layer's operands requested just before it (prefetch of dec_fwd_body / dec_bwd_body)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void lds4(const float* p, float (&o)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+
 // cooperative copy of a [ROWS][COLS] bf16 matrix (global, dense) into LDS with pitch, every 32-column block in fragment order:
 // logical columns 4q .. 4q+3 (q = 0..7) land at position 8 (q & 3) + 4 (q >> 2), i.e. kappa(g, e) at g * 8 + e.
 // 32-column rows: a ds_write_b64 lane group (16 lanes, banks modulo 32 dwords) covers two rows of 16 dwords, and rows r, r + 1
@@ -209,66 +218,85 @@ __device__ __forceinline__ LNres layer_norm(const float (&v)[2][4], const float 
 template <int MLP, bool STACK>
 __device__ __forceinline__ void dec_fwd_body(const DecArgs& p, const int bid) {
     constexpr int W2P = wide_pitch(MLP);
+    constexpr int PARW = 6 * 32 + MLP;                   // g1 be1 bo g2 be2 fb2 (32 each), fb1 (MLP): one layer's parameter vectors
     __shared__ __attribute__((aligned(16))) unsigned short sKq[32 * WP], sVoT[32 * WP], sW1[MLP * WP], sW2[32 * W2P];
+    __shared__ __attribute__((aligned(16))) float sParAll[(STACK ? DEC_MAXDEPTH : 1) * PARW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 15, g = lane >> 4;
     const int img = bid / p.bpi, u0 = (bid - img * p.bpi) * p.upb;
     const long row0 = (long)img * p.rows_per_image + (long)u0 * 64;
     const int nsub = min(p.upb, (p.rows_per_image >> 6) - u0);          // 16-pixel sub-tiles per wave
     const int depth = STACK ? p.depth : 1;
+    // this lane's 8 bytes of a row, relative to the first row of the workgroup's sub-tile round (the rounds lie 4096 bytes apart)
+    const unsigned loff = (unsigned)(((wv * 16 + pl) * D + g * 4) * 2);
+    // What a layer needs from memory before its first sub-tile -- the four matrices and x of sub-tile 0 -- is REQUESTED before the
+    // LAST sub-tile of the layer before it and committed to LDS after that layer's last barrier (as in the backward).  Requested at
+    // the head of the layer, a workgroup waited per layer for an L2 round trip (matrices), then a barrier, then an HBM round trip
+    // (x): ~3 us next to 16 us of work in the 512-row blocks of DAHiTra's 64 x 64 level.
+    struct {
+        StageRegs<32, D> rKq, rVoT;
+        StageRegs<MLP, D> rW1;
+        StageRegs<D, MLP> rW2;
+    } pre;
+    uint2 nx[2];
+    auto layer_in = [&](int l) { return reinterpret_cast<const char*>(uniform_ptr(((!STACK || l == 0) ? p.x : p.ys + (l - 1) * p.act_ls) + row0 * D)); };
+    auto prefetch_w = [&](int l) {
+        int ts = tid;
+        if constexpr (STACK) asm volatile("" : "+v"(ts));
+        const long ko = STACK ? l * p.kq_ls : 0, wo = STACK ? l * p.w_ls : 0;
+        stage_ld(pre.rKq, p.kq + ko + (size_t)img * 32 * D, ts);
+        stage_ld(pre.rVoT, p.voT + ko + (size_t)img * D * 32, ts);
+        stage_ld(pre.rW1, p.w1 + wo, ts);
+        stage_ld(pre.rW2, p.w2 + wo, ts);
+    };
+    auto prefetch_x = [&](int l) {
+        const char* xb = layer_in(l);
+        nx[0] = gld8(xb, loff);
+        nx[1] = gld8(xb, loff + 32);
+    };
+    prefetch_x(0);
+    prefetch_w(0);
+    for (int i = tid; i < depth * PARW; i += 256) {
+        const int l = i / PARW, k = i - l * PARW, c = k & 31;
+        const float* src = k < 32 ? p.g1 : k < 64 ? p.be1 : k < 96 ? p.bo : k < 128 ? p.g2 : k < 160 ? p.be2 : k < 192 ? p.fb2 : p.fb1;
+        sParAll[i] = src[(STACK ? l * p.par_ls : 0) + (k < 192 ? c : k - 192)];
+    }
 #pragma unroll 1
     for (int l = 0; l < depth; ++l) {
-        if (l) __syncthreads();                      // every wave is done with the previous layer's weights
-        const bf16* xin = (!STACK || l == 0) ? p.x : p.ys + (l - 1) * p.act_ls;
-        bf16* yout = STACK ? p.ys + l * p.act_ls : p.y;
-        const long ko = STACK ? l * p.kq_ls : 0, wo = STACK ? l * p.w_ls : 0;
-        {
-            StageRegs<32, D> rKq, rVoT;
-            StageRegs<MLP, D> rW1;
-            StageRegs<D, MLP> rW2;
-            stage_ld(rKq, p.kq + ko + (size_t)img * 32 * D, tid);
-            stage_ld(rVoT, p.voT + ko + (size_t)img * D * 32, tid);
-            stage_ld(rW1, p.w1 + wo, tid);
-            stage_ld(rW2, p.w2 + wo, tid);
-            stage_st(sKq, WP, rKq, tid);
-            stage_st(sVoT, WP, rVoT, tid);
-            stage_st(sW1, WP, rW1, tid);
-            stage_st(sW2, W2P, rW2, tid);
-        }
-        // the seven parameter vectors: this lane's 8 (fb1: MLP / 4) channels, in registers for the whole layer.  (Read through
-        // the pointers inside the loop they were 14 global loads per sub-tile: the store to y may alias them for all the compiler knows.)
+        if (l) lds_barrier();                        // every wave is done with the previous layer's weights
+        const char* xin = layer_in(l);
+        char* yout = const_cast<char*>(reinterpret_cast<const char*>(uniform_ptr((STACK ? p.ys + l * p.act_ls : p.y) + row0 * D)));
+        stage_st(sKq, WP, pre.rKq, tid);
+        stage_st(sVoT, WP, pre.rVoT, tid);
+        stage_st(sW1, WP, pre.rW1, tid);
+        stage_st(sW2, W2P, pre.rW2, tid);
+        __syncthreads();                             // (the first layer's parameter table included)
+        // the seven parameter vectors: this lane's 8 (fb1: MLP / 4) channels, in registers for the whole layer
         float cg1[2][4], cbe1[2][4], cbo[2][4], cg2[2][4], cbe2[2][4], cfb2[2][4], cfb1[MLP / 16][4];
-        const long po = STACK ? l * p.par_ls : 0;
+        const float* par = sParAll + l * PARW;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int c = h * 16 + g * 4;
-            ld4(p.g1 + po + c, cg1[h]); ld4(p.be1 + po + c, cbe1[h]); ld4(p.bo + po + c, cbo[h]);
-            ld4(p.g2 + po + c, cg2[h]); ld4(p.be2 + po + c, cbe2[h]); ld4(p.fb2 + po + c, cfb2[h]);
+            lds4(par + c, cg1[h]); lds4(par + 32 + c, cbe1[h]); lds4(par + 64 + c, cbo[h]);
+            lds4(par + 96 + c, cg2[h]); lds4(par + 128 + c, cbe2[h]); lds4(par + 160 + c, cfb2[h]);
         }
 #pragma unroll
-        for (int h = 0; h < MLP / 16; ++h) ld4(p.fb1 + po + h * 16 + g * 4, cfb1[h]);
-        __syncthreads();
+        for (int h = 0; h < MLP / 16; ++h) lds4(par + 192 + h * 16 + g * 4, cfb1[h]);
         // x of the NEXT sub-tile is requested while this one is computed (raw bf16: 4 registers), as in the backward: a load at the
         // head of the chain was waited for at memory latency in every round
-        uint2 nx[2];
-        auto request = [&](int ps) {
-            const long row = row0 + (ps * 4 + wv) * 16 + pl;
-            if (row < p.rows) {
-                const bf16* xr = xin + row * D;
-                nx[0] = *reinterpret_cast<const uint2*>(xr + g * 4);
-                nx[1] = *reinterpret_cast<const uint2*>(xr + 16 + g * 4);
-            }
-        };
-        request(0);
         for (int ps = 0; ps < nsub; ++ps) {
-            const long row = row0 + (ps * 4 + wv) * 16 + pl;
-            if (row >= p.rows) break;                  // (never splits a wave's MFMA: rows % 16 == 0 is required)
             float x[2][4], xh[2][4], xn[2][4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 x[h][0] = __uint_as_float(nx[h].x << 16); x[h][1] = __uint_as_float(nx[h].x & 0xffff0000u);
                 x[h][2] = __uint_as_float(nx[h].y << 16); x[h][3] = __uint_as_float(nx[h].y & 0xffff0000u);
             }
-            if (ps + 1 < nsub) request(ps + 1);
+            if (ps + 1 < nsub) {
+                nx[0] = gld8(xin + (size_t)(ps + 1) * 4096, loff);
+                nx[1] = gld8(xin + (size_t)(ps + 1) * 4096, loff + 32);
+            } else if (STACK && l + 1 < depth) {
+                prefetch_w(l + 1);                   // in flight during the layer's last sub-tile
+                if (nsub > 1) prefetch_x(l + 1);     // (sub-tile 0 of this layer's output: stored by this lane rounds ago)
+            }
             layer_norm(x, cg1, cbe1, p.eps, xh, xn);
             // dots -> softmax over the 4 keys of each head (lane-local)
             const s16x8 bxn = pack8(xn[0], xn[1]);
@@ -309,15 +337,16 @@ __device__ __forceinline__ void dec_fwd_body(const DecArgs& p, const int bid) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) out[s] = mma(lds_a(sW2, W2P, s * 16 + pl, 32 * q, g), bh, out[s]);
             }
-            bf16* yr = yout + row * D;
+            char* yr = yout + (size_t)ps * 4096;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float r[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) r[j] = out[s][j] + cfb2[s][j] + x1[s][j];
-                st4(yr + s * 16 + g * 4, r);
+                gst8(yr, loff + s * 32, make_uint2(f2bf2(r[0], r[1]), f2bf2(r[2], r[3])));
             }
         }
+        if (STACK && l + 1 < depth && nsub == 1) prefetch_x(l + 1);      // (one sub-tile per wave: its output was stored just now)
     }
 }
 template <int MLP, bool STACK = false>
@@ -398,13 +427,6 @@ __device__ __forceinline__ void row16_sum4(float (&v)[4]) {
         "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf"
         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
-}
-// workgroup barrier that orders LDS traffic only: __syncthreads() is also a fence for global memory, i.e. s_waitcnt vmcnt(0) --
-// it would drain the next layer's operands requested just before it (dec_bwd_body: prefetch)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void lds4(const float* p, float (&o)[4]) {
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
 
 // Backward, TWO workgroups per CU (<= 256 registers).  The first form of this kernel carried two 16-pixel sub-tiles per wave
@@ -1316,7 +1338,7 @@ extern "C" int dh_decoder_stack_fwd(const void* x, void* ys, const void* kq, con
                                     const void* w2, const float* b2, int depth, long kq_lstride, long w_lstride, long par_lstride,
                                     long rows, int rows_per_image, int mlp, float eps, void* stream) {
     if (check_common(rows, rows_per_image, mlp)) return 1;
-    DH_REQUIRE(depth >= 1 && x && ys, "decoder_stack_fwd: bad arguments (depth %d)", depth);
+    DH_REQUIRE(depth >= 1 && depth <= DEC_MAXDEPTH && x && ys, "decoder_stack_fwd: bad arguments (depth %d, 1 .. %d supported)", depth, DEC_MAXDEPTH);
     DecArgs a = {};
     a.x = (const bf16*)x; a.ys = (bf16*)ys; a.y = (bf16*)ys; a.kq = (const bf16*)kq; a.voT = (const bf16*)voT;
     a.w1 = (const bf16*)w1; a.w2 = (const bf16*)w2;

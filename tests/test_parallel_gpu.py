@@ -79,7 +79,10 @@ def _eager(kind, net, opt, a, b, lab, scale_fn):
 
 
 def _worker(rank, world, port, steps, use_graph, out, kind="bit"):
-    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    """use_graph: False = eager steps; True = the OVERLAPPED two-graph form (DAHITRA_OVERLAP=1: with two ranks `auto` would take
+    the serial form, see parallel.split_offset); "serial" = one graph + one all-reduce + AdamW (DAHITRA_OVERLAP=0)"""
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      DAHITRA_OVERLAP="0" if use_graph == "serial" else "1")
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch.distributed as dist
@@ -106,10 +109,13 @@ def _worker(rank, world, port, steps, use_graph, out, kind="bit"):
         else:
             step = GraphedTrainStep(net, opt, a, b, lab)
             args = (a, b, lab)
-        # the overlapped form: two graphs around the all-reduce of the arena tail
-        assert step.exchange and step.split_off is not None and 0 < step.split_off < net._arena.n_active
-        second = net._engine.split_prefixes()
-        assert all(net._arena.offsets[k][0] < step.split_off for k in net._active_keys if k.startswith(second))
+        if use_graph == "serial":
+            assert step.exchange and step.split_off is None
+        else:
+            # the overlapped form: two graphs around the all-reduce of the arena tail
+            assert step.exchange and step.split_off is not None and 0 < step.split_off < net._arena.n_active
+            second = net._engine.split_prefixes()
+            assert all(net._arena.offsets[k][0] < step.split_off for k in net._active_keys if k.startswith(second))
     grads = None
     for it in range(steps):
         if step is not None:
@@ -126,7 +132,7 @@ def _worker(rank, world, port, steps, use_graph, out, kind="bit"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,use_graph", [("bit", False), ("bit", True), ("unet", True), ("xbd", True)])
+@pytest.mark.parametrize("kind,use_graph", [("bit", False), ("bit", True), ("bit", "serial"), ("unet", True), ("xbd", True)])
 def test_two_ranks_match_the_single_process_emulation(tmp_path, kind, use_graph):
     import torch.multiprocessing as mp
     world, steps = 2, 2
@@ -277,7 +283,7 @@ def test_bench_refuses_more_gpus_than_the_box_has():
 def _bench_size_rank(_index, out):
     """one RCCL rank at the BENCH size (32 pairs, 256 x 256, bf16) through the overlapped two-graph step"""
     os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
-                      DAHITRA_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      DAHITRA_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", DAHITRA_OVERLAP="1")
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch.distributed as dist
