@@ -667,10 +667,11 @@ def main():
                 secondary["roofline"], secondary["hbm"] = roofline_records(stp, a2)
             except Exception as e:
                 secondary["roofline"] = {"error": repr(e)[:300]}
-        try:
-            secondary["attention"] = attention_record(stp, "newUNetTrans", args.batch, args.img, _profile("_pmc_mfma_util.json", "newUNetTrans"))
-        except Exception as e:                                          # the line never depends on a sub-record
-            secondary["attention"] = {"error": repr(e)[:300]}
+        if not args.no_class_replay:
+            try:
+                secondary["attention"] = attention_record(stp, "newUNetTrans", args.batch, args.img, _profile("_pmc_mfma_util.json", "newUNetTrans"))
+            except Exception as e:                                      # the line never depends on a sub-record
+                secondary["attention"] = {"error": repr(e)[:300]}
         del stp
 
     # ---- forward_only: the evaluation forward (eval-mode BatchNorm, no gradient state; models/evaluator.py:156-164) of both nets,
@@ -701,7 +702,9 @@ def main():
                 forward_only[nname] = {"error": repr(e)[:300]}
 
     attention = None
-    if rank == 0 and world == 1 and not args.fwd_only and args.dtype == "bf16" and args.net in ATTN_GFLOP_PER_PAIR and not args.no_roofline:
+    # (not in profiler runs, --no-class-replay: its replays would be counted into the per-step kernel statistics and PMC sums)
+    if rank == 0 and world == 1 and not args.fwd_only and args.dtype == "bf16" and args.net in ATTN_GFLOP_PER_PAIR and not args.no_roofline \
+            and not args.no_class_replay:
         try:
             attention = attention_record(step, args.net, args.batch, args.img, _profile("_pmc_mfma_util.json", args.net))
         except Exception as e:
