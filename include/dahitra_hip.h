@@ -553,7 +553,12 @@ int dh_decoder_layer_bwd(const void* x, const void* dy, void* dx, const void* kq
  * + l * kq_lstride elements (the dh_xattn_prep_fwd_stack outputs), packed MLP weights + l * w_lstride elements, fp32
  * parameter vectors + l * par_lstride floats.  dh_decoder_stack_bwd: dy = gradient of ys[depth - 1], dx = gradient of x, dwork
  * [rows][32] bf16 scratch; partials of layer l at workspace + l * dh_decoder_layer_bwd_workspace_size bytes, for
- * dh_decoder_stack_bwd_finalize.  Bit-identical to `depth` dh_decoder_layer_fwd / _bwd calls; both join an open decoder batch. */
+ * dh_decoder_stack_bwd_finalize.  Bit-identical to `depth` dh_decoder_layer_fwd / _bwd calls; both join an open decoder batch.
+ * depth <= 8 (a workgroup keeps every layer's parameter vectors in LDS).  A launch of SEVERAL recorded jobs sizes the pixel
+ * blocks of each for the launch as a whole (csrc/decoder_fused.hip dec_balance; DAHITRA_DEC_BALANCE=0: the per-job rule): y / dx
+ * do not depend on it, the partial sums -- hence the parameter gradients -- to fp32 summation order.  The workspace of
+ * dh_decoder_layer_bwd_workspace_size holds the smallest blocks such a launch may choose (only the blocks written are read);
+ * the finalize looks the layout up by the workspace's address, so it must follow the backward that filled that workspace. */
 int dh_decoder_stack_fwd(const void* x, void* ys, const void* kq, const void* voT, const float* ln1_g, const float* ln1_b,
                          const float* bo, const float* ln2_g, const float* ln2_b, const void* w1, const float* b1, const void* w2,
                          const float* b2, int depth, long kq_lstride, long w_lstride, long par_lstride, long rows,
