@@ -14,6 +14,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+    config.addinivalue_line("markers", "slow: minutes on the GPU box (deselect with -m 'gpu and not slow' for a quick pass)")
 
 
 @pytest.fixture(scope="session")

@@ -42,6 +42,7 @@ def make_args(tmp_path, **kw):
     return args
 
 
+@pytest.mark.slow          # ~4 of the GPU suite's ~7.5 minutes (two epochs of CDTrainer through the PIL loaders, evaluation, resume)
 def test_main_cd_sequence_train_eval_resume_and_16_patches(data_root):
     from dahitra_amd import utils
     from dahitra_amd.models.evaluator import CDEvaluator
