@@ -240,6 +240,7 @@ def build(args, dtype, dev, local, rank, use_graph):
         opt.step(grad_scale=scale)
         return loss
     step.graphed = graphed
+    step.net = net
     return step, xbd_mode
 
 
@@ -697,7 +698,23 @@ def main():
                 forward_only[nname] = {"value": round(args.batch * kf / df, 1), "unit": "image-pairs/s", "ms_per_batch": round(df / kf * 1e3, 3),
                                        "batch": args.batch, "dtype": "bf16", "steps": kf,
                                        "how": "net.eval(); torch.no_grad(); net(A, B) -> logits, launched from Python (no recorded graph)"}
-                del stp
+                # ... and as CDEvaluator runs it since round 6: the eval forward + arg-max / confusion count as one recorded graph
+                from dahitra_amd.graph import GraphedEvalStep
+                ea, eb, el = synthetic(args.batch, args.img, 777, dev)
+                conf = torch.zeros(2, 2, dtype=torch.int64, device=dev)
+                gstep = GraphedEvalStep(stp.net, ea, eb, el, confusion=conf)
+                for _ in range(3):
+                    gstep()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(kf):
+                    gstep()
+                torch.cuda.synchronize()
+                dg = time.perf_counter() - t1
+                forward_only[nname]["graph"] = {"value": round(args.batch * kf / dg, 1), "ms_per_batch": round(dg / kf * 1e3, 3),
+                                                "how": "dahitra_amd.graph.GraphedEvalStep: eval-mode weight re-pack + forward + arg-max / confusion "
+                                                       "count, one hipGraphLaunch per batch (what CDEvaluator.eval_models replays)"}
+                del stp, gstep
             except Exception as e:
                 forward_only[nname] = {"error": repr(e)[:300]}
 

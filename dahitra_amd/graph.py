@@ -228,6 +228,68 @@ class GraphedTrainStep:
         return self.loss
 
 
+class GraphedEvalStep:
+    """The evaluation forward (models/evaluator.py:156-164: net.eval(), no gradient state) as ONE HIP graph: the eval-mode weight
+    re-pack (every BatchNorm folded into its convolution), the forward and -- with `confusion` -- the arg-max + confusion-matrix
+    count against the labels (one kernel, no host read).  ~130 (BiT) / ~200 (DAHiTra) launches per batch become one
+    hipGraphLaunch: the eager evaluation forward of DAHiTra proper is bound by its launches from Python.
+
+        step = GraphedEvalStep(net, a, b, lab, confusion)      # net.eval() is called here
+        logits = step(a, b, lab)                                # static shapes; the caller runs other shapes eagerly
+
+    The parameters are read when the graph replays, so a checkpoint loaded into `net` afterwards is what the next replay scores."""
+
+    def __init__(self, net, a, b, lab=None, confusion=None, warmup=2):
+        self.net, self.confusion = net, confusion
+        net.eval()
+        self.a, self.b = a.clone(), b.clone()
+        self.lab = lab.clone() if lab is not None else None
+        if confusion is not None and lab is None:
+            raise ValueError("GraphedEvalStep: a confusion matrix needs the labels")
+        net._ensure_arena(a.device)
+        conf0 = confusion.clone() if confusion is not None else None
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        if confusion is not None:
+            confusion.copy_(conf0)
+        cs = self._capture_stream = torch.cuda.Stream()       # (kept: see GraphedTrainStep)
+        ops.rekey_workspace(a.device, s, cs)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=cs):
+            self.logits = self._body()
+        self._pinned = ops.pin_captured_buffers(net)
+        self._generation = net._arena.generation
+        torch.cuda.synchronize()
+
+    def _body(self):
+        with torch.no_grad():
+            logits = self.net(self.a, self.b)
+        if self.confusion is not None:
+            tgt = self.lab[:, 0] if self.lab.dim() == logits.dim() else self.lab
+            ops.confusion_matrix(logits.detach().float().contiguous(), tgt.to(torch.int64).contiguous(), self.confusion)
+        return logits
+
+    def __call__(self, a=None, b=None, lab=None):
+        if self.net._arena.generation != self._generation:
+            raise RuntimeError("dahitra_amd: the net's parameter arena was rebuilt after this evaluation step was captured; "
+                               "build a new GraphedEvalStep")
+        if self.net.training:
+            raise RuntimeError("dahitra_amd: GraphedEvalStep replays the eval-mode forward; call net.eval() (a train-mode forward "
+                               "in between re-packs the weights for training)")
+        if a is not None:
+            self.a.copy_(a, non_blocking=True)
+            self.b.copy_(b, non_blocking=True)
+            if lab is not None and self.lab is not None:
+                self.lab.copy_(lab, non_blocking=True)
+        self.graph.replay()
+        return self.logits
+
+
 class GraphedXbdStep(GraphedTrainStep):
     """The xBD step (xBD_code/train.py:331-374) as one HIP graph: forward of the 6-channel model, the five weighted
     ComboLoss terms, backward, clip_grad_norm_(0.999) and the hand-rolled AdamW.

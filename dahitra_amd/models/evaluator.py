@@ -49,6 +49,10 @@ class CDEvaluator:
         self.is_training = False
         self.batch_id = 0
         self.epoch_id = 0
+        # the evaluation forward + the confusion count as one recorded HIP graph per batch shape (dahitra_amd.graph.GraphedEvalStep);
+        # args.hip_graph = False / DAHITRA_NO_GRAPH=1, or a batch of another shape (the ragged last one): the eager forward
+        self.use_graph = bool(getattr(args, "hip_graph", True)) and os.environ.get("DAHITRA_NO_GRAPH", "0") != "1"
+        self._graph, self._graph_key = None, None
 
     def _log(self, message):
         if self.logger is not None:
@@ -95,7 +99,24 @@ class CDEvaluator:
         self.is_training = False
         self.net_G.eval()
         for self.batch_id, batch in enumerate(self.dataloader, 0):
-            with torch.no_grad():
-                self._forward_pass(batch)
-            self._collect_running_batch_states()
+            if not self._graphed_batch(batch):
+                with torch.no_grad():
+                    self._forward_pass(batch)
+                self._collect_running_batch_states()
         return self._collect_epoch_states()
+
+    def _graphed_batch(self, batch):
+        """forward + confusion count of `batch` through the recorded graph; False when this batch takes the eager path"""
+        if not self.use_graph:
+            return False
+        a, b, lab = batch['A'].to(self.device), batch['B'].to(self.device), batch['L'].to(self.device).long().contiguous()
+        key = (tuple(a.shape), a.dtype, tuple(lab.shape))
+        if self._graph is None:
+            from ..graph import GraphedEvalStep
+            self._graph = GraphedEvalStep(self.net_G, a.float(), b.float(), lab, confusion=self.confusion)
+            self._graph_key = key
+        if key != self._graph_key:
+            return False
+        self.batch = batch
+        self.G_pred = self._graph(a.float(), b.float(), lab)
+        return True

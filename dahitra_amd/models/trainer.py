@@ -68,6 +68,7 @@ class CDTrainer:
         # (also without the graph: the eager step then runs the very same update kernel, bit for bit)
         self.optimizer_G = AdamW(self.net_G.parameters(), lr=self.lr, betas=(0.9, 0.999), weight_decay=0.01, capturable=True)
         self._graph, self._graph_key = None, None
+        self._val_graph, self._val_graph_key = None, None      # the validation forward + confusion count (GraphedEvalStep)
         self.exp_lr_scheduler_G = get_scheduler(self.optimizer_G, args)
         self.running_metric = ConfuseMatrixMeter(n_class=self.n_class)
         self.checkpoint_dir = getattr(args, "checkpoint_dir", None)
@@ -325,6 +326,25 @@ class CDTrainer:
         self._counted = True                      # counted inside the graph
         self._focal, self._dice_args = loss, (self.G_pred, self._graph.lab)
 
+    def _val_graphed(self, batch):
+        """the validation forward + confusion count of a batch of the recorded shape as one hipGraphLaunch
+        (dahitra_amd.graph.GraphedEvalStep); False: this batch takes the eager forward (another shape, graphs off)"""
+        if not self.use_graph:
+            return False
+        a, b = batch['A'].to(self.device).float(), batch['B'].to(self.device).float()
+        lab = batch['L'].to(self.device).long().contiguous()
+        key = (tuple(a.shape), tuple(lab.shape))
+        if self._val_graph is None:
+            from ..graph import GraphedEvalStep
+            self._val_graph = GraphedEvalStep(self.net_G, a, b, lab, confusion=self.confusion)
+            self._val_graph_key = key
+        if key != self._val_graph_key:
+            return False
+        self.batch = batch
+        self.G_pred = self.G_final_pred = self._val_graph(a, b, lab)
+        self._counted = True                      # counted inside the graph
+        return True
+
     def train_models(self):
         self._load_checkpoint()
         for self.epoch_id in range(self.epoch_to_start, self.max_num_epochs):
@@ -352,8 +372,9 @@ class CDTrainer:
             # 0's model, so that the logged epoch score IS the score of the checkpointed model
             parallel.broadcast_buffers_(self.net_G)
             for self.batch_id, batch in enumerate(self.dataloaders['val'], 0):
-                with torch.no_grad():
-                    self._forward_pass(batch)
+                if not self._val_graphed(batch):
+                    with torch.no_grad():
+                        self._forward_pass(batch)
                 self._collect_running_batch_states()
             self._collect_epoch_states()
             # ---- checkpoints ----

@@ -484,6 +484,46 @@ def test_hip_graph_step_equals_eager_step(name):
     assert res["eager"][3] == res["graph"][3] == 6
 
 
+@pytest.mark.parametrize("cdtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("name", ["base_transformer_pos_s4", "newUNetTrans"])
+def test_hip_graph_eval_step_equals_the_eager_evaluation_forward(name, cdtype):
+    """GraphedEvalStep (models/evaluator.py:156-164 as one hipGraphLaunch per batch: eval-mode weight re-pack, forward, arg-max +
+    confusion count): logits and counts equal to the eager no-grad forward bit for bit, for a second batch through the same
+    graph as well; and the replay reads the CURRENT parameters (a checkpoint loaded after the capture is what gets scored)"""
+    from dahitra_amd import ops
+    from dahitra_amd.graph import GraphedEvalStep
+    size = 256 if name == "newUNetTrans" else 64
+    a, b, lab = (t.cuda() for t in O.synthetic_batch(2, size, seed=21))
+    a2, b2, lab2 = (t.cuda() for t in O.synthetic_batch(2, size, seed=22))
+    net = make_net(name, cdtype).eval()
+
+    def eager(x, y, l):
+        cm = torch.zeros(2, 2, dtype=torch.int64, device="cuda")
+        with torch.no_grad():
+            lo = net(x, y)
+        ops.confusion_matrix(lo.float().contiguous(), l[:, 0].contiguous(), cm)
+        return lo.clone(), cm
+    lo1, cm1 = eager(a, b, lab)
+    lo2, cm2 = eager(a2, b2, lab2)
+    conf = torch.zeros(2, 2, dtype=torch.int64, device="cuda")
+    step = GraphedEvalStep(net, a, b, lab, confusion=conf)
+    assert int(conf.sum()) == 0                                    # the warm-up and the capture left no counts behind
+    g1 = step(a, b, lab).clone()
+    assert torch.equal(g1, lo1) and torch.equal(conf, cm1)
+    g2 = step(a2, b2, lab2).clone()
+    assert torch.equal(g2, lo2) and torch.equal(conf, cm1 + cm2)
+    # other weights, same graph
+    sd = {k: (v * 1.5 if v.dtype.is_floating_point and v.dim() > 1 else v) for k, v in O.deterministic_state(name).items()}
+    net.load_state_dict(sd)
+    net.eval()
+    lo3, _ = eager(a, b, lab)
+    assert not torch.equal(lo3, lo1)
+    assert torch.equal(step(a, b, lab), lo3)
+    net.train()
+    with pytest.raises(RuntimeError, match="eval"):
+        step(a, b, lab)
+
+
 @pytest.mark.parametrize("name", ["base_transformer_pos_s4_dd8", "newUNetTrans"])
 def test_fused_decoder_layer_matches_unfused_kernels(name):
     """csrc/decoder_fused.hip (one kernel per layer and direction) against the validated chain of separate
