@@ -745,7 +745,8 @@ def main():
                                      ("two graphs around an overlapped all-reduce of the arena tail + all-reduce of the head + AdamW"
                                       if step.graphed.exchange and step.graphed.split_off is not None else
                                       ("one graph + one all-reduce + AdamW" if step.graphed.exchange else "one graph (AdamW inside)"))),
-                       "attn_dtype": "fp8" if os.environ.get("DAHITRA_ATTN_FP8", "0") == "1" and args.dtype == "bf16" else args.dtype,
+                       "attn_dtype": "fp8 e4m3 in the decoder layers' FORWARD products (csrc/decoder_fp8.hip); their backward and everything else bf16"
+                       if os.environ.get("DAHITRA_ATTN_FP8", "0") == "1" and args.dtype == "bf16" else args.dtype,
                        "step_tflops": round(pairs / dt * GFLOP_256[args.net] * (args.img / 256.0) ** 2 / 1e3, 2)
                        if args.net in GFLOP_256 and not args.fwd_only else None},
             "step_ms": step_ms,
